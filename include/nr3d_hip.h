@@ -1,0 +1,237 @@
+/* include/nr3d_hip.h -- C ABI of libnr3d_hip.so (MI355X / gfx950 kernels for the nr3d hot path).
+ *
+ * This is the drop-in boundary: every entry point takes plain device/host pointers, sizes, element
+ * strides and a hipStream_t (as void*); no torch / ATen types.  Each group cites the reference
+ * interface it replaces (paths relative to the reference checkout).  All functions return 0 on
+ * success, nonzero on failure with a message available from nr3d_last_error() (thread-local).
+ *
+ * Ownership: the CALLER allocates every buffer (inputs and outputs) on the device the stream
+ * belongs to; the library holds no state besides the thread-local error string.  Buffers documented
+ * "zero-init" must be zeroed by the caller; all other outputs are fully written by the kernels
+ * (skipped points are written as zeros), so they may be allocated uninitialised.
+ *
+ * dtype codes (NR3D_*) name the element type behind a void*.
+ */
+#ifndef NR3D_HIP_H
+#define NR3D_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { NR3D_F32 = 0, NR3D_F16 = 1, NR3D_F64 = 2, NR3D_I32 = 3, NR3D_I64 = 4, NR3D_U8 = 5, NR3D_I16 = 6, NR3D_I8 = 7 };
+
+const char *nr3d_last_error(void);
+int nr3d_abi_version(void);
+
+/* =================================================================================================
+ * LoTD encoder -- replaces nr3d_lib.bindings._lotd
+ *   pybind surface   csrc/lotd/src/lotd.cpp:23-110
+ *   host API         csrc/lotd/include/lotd/lotd_torch_api.h:79-249, csrc/lotd/src/lotd_torch_api.cu
+ *   device meta      csrc/lotd/include/lotd/lotd_cuda.h:29-76 (LoDMetaRef)
+ * ============================================================================================== */
+#define NR3D_LOTD_MAX_LEVELS 32
+#define NR3D_LOTD_MAX_DIMS 4
+#define NR3D_LOTD_MAX_PSEUDO 256
+
+/* csrc/lotd/include/lotd/lotd_types.h:16-25 */
+enum {
+	NR3D_LOD_Dense = 0, NR3D_LOD_VectorMatrix = 1, NR3D_LOD_VecZMatXoY = 2, NR3D_LOD_CP = 3,
+	NR3D_LOD_CPfast = 4, NR3D_LOD_NPlaneMul = 5, NR3D_LOD_NPlaneSum = 6, NR3D_LOD_Hash = 7
+};
+
+typedef struct nr3d_lotd_level {
+	uint32_t res[NR3D_LOTD_MAX_DIMS]; /* level_res_multidim */
+	uint32_t n_feats;                 /* level_n_feats  */
+	uint32_t type;                    /* level_types    */
+	uint32_t size;                    /* level_sizes    (entries, feature width not counted) */
+	uint32_t offset;                  /* level_offsets  (elements, inside one batch entry)   */
+} nr3d_lotd_level_t;                  /* 32 B: one level per half cache line */
+
+typedef struct nr3d_lotd_meta {
+	nr3d_lotd_level_t levels[NR3D_LOTD_MAX_LEVELS];
+	uint16_t map_levels[NR3D_LOTD_MAX_PSEUDO];
+	uint16_t map_cnt[NR3D_LOTD_MAX_PSEUDO];
+	uint32_t n_levels;
+	uint32_t n_pseudo_levels;
+	uint32_t n_feat_per_pseudo_lvl;
+	uint32_t n_dims_to_encode;
+	uint32_t n_encoded_dims;
+	uint32_t n_params;               /* == level_offsets[n_levels] */
+	uint32_t interpolation_type;     /* 0 Linear, 1 Smoothstep (lotd_types.h:78-82) */
+	uint32_t c_hash_only;            /* every level is Dense or Hash */
+} nr3d_lotd_meta_t;
+
+/* LoDMeta::create_meta (lotd_torch_api.cu:29-230).  Host only, no GPU needed.
+ * res_multidim is [n_levels, n_input_dim] row-major; types are NR3D_LOD_* codes. */
+int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, const int32_t *res_multidim,
+                          const int32_t *n_feats, const int32_t *types, uint32_t hashmap_size,
+                          int use_smooth_step, nr3d_lotd_meta_t *out);
+
+/* Batch addressing shared by all LoTD entry points (lotd_encoding.h:166-178):
+ *   batch_inds   int64 [N] or NULL (value < 0 => point skipped)
+ *   batch_offsets int64 [B] or NULL (element offset of each batch entry; default b * n_params)
+ *   batch_data_size  >0 => b = i / batch_data_size when batch_inds is NULL
+ *   max_level    levels > max_level contribute zeros; <= -1 => everything zero (lotd_torch_api.cu:294)
+ * `meta_dev` is a device-resident byte copy of *meta (the caller uploads it once per meta/device).
+ * Strides are in ELEMENTS.  x is [N, D] contiguous; params is 1-D contiguous.
+ */
+
+/* lod_fwd (lotd_torch_api.cu:232-395): y[i*y_sn + e*y_se] (params dtype);
+ * dy_dx[i*dydx_sn + e*dydx_se + d] (x dtype) or NULL. */
+int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
+                  int x_dtype, int param_dtype, const void *x, const void *params,
+                  const int64_t *batch_inds, const int64_t *batch_offsets, uint32_t batch_data_size,
+                  int32_t max_level, void *y, int64_t y_sn, int64_t y_se,
+                  void *dy_dx, int64_t dydx_sn, int64_t dydx_se, void *stream);
+
+/* lod_bwd, input-gradient half (lotd_encoding.h:1562-1586 / lotd_hash_only.h:839-863):
+ * dL_dx[i, d] = sum_e dL_dy[i, e] * dy_dx[i, e, d];  dL_dx is [N, D] contiguous (x dtype). */
+int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t n_points, int x_dtype, int param_dtype,
+                     const void *dL_dy, int64_t dldy_sn, int64_t dldy_se,
+                     const void *dy_dx, int64_t dydx_sn, int64_t dydx_se, void *dL_dx, void *stream);
+
+/* lod_bwd, parameter-gradient half (kernel_lod[_hashonly]_backward_grid, lotd_encoding.h:467-711,
+ * lotd_hash_only.h:380-470).  dL_dparam: params dtype, same numel as params, ZERO-INIT by caller. */
+int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
+                         int x_dtype, int param_dtype, const void *dL_dy, int64_t dldy_sn, int64_t dldy_se,
+                         const void *x, const void *params, const int64_t *batch_inds,
+                         const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
+                         void *dL_dparam, void *stream);
+
+/* lod_bwd_bwd_input (lotd_torch_api.cu:575-729), three independent outputs:
+ * (i)  dL_ddLdy[i, e] = sum_d dL_ddLdx[i, d] * dy_dx[i, e, d]      (lotd_encoding.h:1703-1727) */
+int nr3d_lotd_bwd_bwd_ddLdy(const nr3d_lotd_meta_t *meta, uint32_t n_points, int x_dtype, int param_dtype,
+                            const void *dL_ddLdx, const void *dy_dx, int64_t dydx_sn, int64_t dydx_se,
+                            void *dL_ddLdy, int64_t out_sn, int64_t out_se, void *stream);
+/* (ii) d(dL/dx)/dparam (lotd_encoding.h:764-1041, lotd_hash_only.h:472-574); ZERO-INIT output. */
+int nr3d_lotd_bwd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
+                             int x_dtype, int param_dtype, const void *dL_ddLdx,
+                             const void *dL_dy, int64_t dldy_sn, int64_t dldy_se, const void *x,
+                             const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
+                             uint32_t batch_data_size, int32_t max_level, void *dL_dparam, void *stream);
+/* (iii) d(dL/dx)/dx (lotd_encoding.h:1157-1298, lotd_hash_only.h:576-695); dL_dx [N, D] fully written. */
+int nr3d_lotd_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
+                         int x_dtype, int param_dtype, const void *dL_ddLdx,
+                         const void *dL_dy, int64_t dldy_sn, int64_t dldy_se, const void *x,
+                         const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
+                         uint32_t batch_data_size, int32_t max_level, void *dL_dx, void *stream);
+
+/* lod_get_grid_index (lotd_torch_api.cu:771-855; kernel lotd_encoding.h:1300-1433):
+ * grid_inds int64 [N, n_encoded_dims, 2^D] contiguous, ZERO-INIT.  Dense/Hash levels only. */
+int nr3d_lotd_grid_index(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points, int x_dtype,
+                         const void *x, const int64_t *batch_inds, const int64_t *batch_offsets,
+                         uint32_t batch_data_size, int32_t max_level, int64_t *grid_inds, void *stream);
+
+/* =================================================================================================
+ * occ_grid ray marching -- replaces nr3d_lib.bindings._occ_grid
+ *   csrc/occ_grid/include/occ_grid/cpp_api.h:14-66, csrc/occ_grid/src/ray_marching.cu:136-244,
+ *   csrc/occ_grid/src/batched_marching.cu:153-287
+ * Two-phase: *_count writes num_steps[n_rays] AND the exclusive scan packed_info[n_rays,2]
+ * (= [cumsum - num, num], int32) plus the grand total into total_steps[0] (device int32/int64);
+ * the caller reads total_steps back (the single host sync), allocates outputs, calls *_emit.
+ *   grid_binary: uint8/bool [ (B,) Rx, Ry, Rz ], z contiguous.  roi: f32 [6] or [B,6].
+ *   batched != 0: batch_inds int32 [n_rays] or NULL (<0 skips), batch_data_size as for LoTD.
+ * ============================================================================================== */
+enum { NR3D_CONTRACT_AABB = 0, NR3D_CONTRACT_UN_BOUNDED_TANH = 1, NR3D_CONTRACT_UN_BOUNDED_SPHERE = 2 };
+
+int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                            const float *t_max, const float *roi, const int32_t grid_res[3],
+                            const uint8_t *grid_binary, int contraction_type, float step_size,
+                            float max_step_size, float dt_gamma, uint32_t max_steps, int batched,
+                            const int32_t *batch_inds, uint32_t batch_data_size,
+                            int32_t *packed_info /*[n_rays,2]*/, int64_t *total_steps /*[1]*/,
+                            void *scan_tmp /* >= nr3d_scan_tmp_bytes(n_rays) bytes */, void *stream);
+
+int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                           const float *t_max, const float *roi, const int32_t grid_res[3],
+                           const uint8_t *grid_binary, int contraction_type, float step_size,
+                           float max_step_size, float dt_gamma, int batched, const int32_t *batch_inds,
+                           uint32_t batch_data_size, const int32_t *packed_info, float *t_starts,
+                           float *t_ends, int32_t *ridx, int32_t *bidx /*NULL unless batched*/,
+                           int32_t *gidx /*or NULL*/, void *stream);
+
+/* Scratch bytes needed by the device-wide scans used in two-phase ops (any n). */
+uint64_t nr3d_scan_tmp_bytes(uint64_t n);
+
+/* =================================================================================================
+ * pack_ops -- replaces nr3d_lib.bindings._pack_ops  (csrc/pack_ops/pack_ops.h:11-65,
+ * csrc/pack_ops/pack_ops.cpp:21-58, kernels csrc/pack_ops/pack_ops_cuda.cu)
+ * pack_infos: int64 [P,2] = (begin, length), contiguous.  feats: [S] or [S, feat_dim] contiguous.
+ * ============================================================================================== */
+
+/* n_per_pack (int64 [P]) -> pack_infos [P,2] = (exclusive cumsum, n) and total[0]; the host-side
+ * `cumsum` + `stack` of every two-phase pack op (e.g. pack_ops_cuda.cu:584-586). */
+int nr3d_pack_infos_from_n(uint32_t P, const int64_t *n_per_pack, int64_t *pack_infos, int64_t *total,
+                           void *scan_tmp, void *stream);
+
+/* interleave_arange / interleave_linstep (:47-218).  starts/step_sizes may be NULL (then scalars
+ * start_s/step_s are used; passed as double and converted to dtype).  nidx may be NULL. */
+int nr3d_interleave_linstep(uint32_t P, int dtype, const int64_t *pack_infos, const void *starts,
+                            const void *step_sizes, double start_s, double step_s, void *out,
+                            int64_t *nidx, void *stream);
+
+/* interleave_sample_step_wrt_depth_clamped (:480-604), round 1 then round 2. */
+int nr3d_sample_step_count(uint32_t P, const float *nears, const float *fars, uint32_t max_steps,
+                           float dt_gamma, float min_step, float max_step, int64_t *n_per_pack, void *stream);
+int nr3d_sample_step_emit(uint32_t P, const float *nears, const int64_t *pack_infos, float dt_gamma,
+                          float min_step, float max_step, float *t_samples, float *deltas, int64_t *nidx,
+                          void *stream);
+/* interleave_sample_step_wrt_depth_in_packed_segments (:606-795): emit == 0 -> n_per_pack. */
+int nr3d_sample_step_segments(uint32_t P, const float *nears, const float *fars, const float *entries,
+                              const float *exits, const int64_t *seg_pack_infos, uint32_t max_steps,
+                              float dt_gamma, float min_step, float max_step, int emit, int64_t *n_per_pack,
+                              const int64_t *pack_infos, float *t_samples, float *deltas, int64_t *nidx,
+                              int64_t *sidx, void *stream);
+
+/* packed_sum (:798-861).  out [P, feat_dim], fully written (empty packs -> 0). */
+int nr3d_packed_sum(uint32_t P, uint64_t S, uint32_t feat_dim, int dtype, const void *feats,
+                    const int64_t *pack_infos, void *out, void *stream);
+/* packed_cumsum / packed_cumprod (:864-1095).  out fully written, reference first-element semantics. */
+int nr3d_packed_scan(uint32_t P, uint64_t S, uint32_t feat_dim, int dtype, const void *feats,
+                     const int64_t *pack_infos, int is_prod, int exclusive, int reverse, void *out,
+                     void *stream);
+/* packed_diff / packed_backward_diff (:1098-1333).  edge_a = appends|prepends, edge_fill = last|first fill
+ * (at most one non-NULL).  backward != 0 selects packed_backward_diff.  out fully written. */
+int nr3d_packed_diff(uint32_t P, uint64_t S, uint32_t feat_dim, int dtype, const void *feats,
+                     const int64_t *pack_infos, const void *edge_a, const void *edge_fill, int backward,
+                     void *out, void *stream);
+/* packed_{add,sub,mul,div,gt,geq,lt,leq,eq,neq} (:1960-2480).  op = PackBinaryOpType value
+ * (pack_ops.h:25-37: Add 0, Subtract 1, Multiply 2, Division 3, Matmul 4, Gt 5 ... Neq 10).
+ * Comparisons write uint8 (bool).  Matmul: other [P, out_dim, feat_dim], out [S, out_dim]. */
+int nr3d_packed_binary(uint32_t P, uint64_t S, uint32_t feat_dim, uint32_t out_dim, int dtype,
+                       const void *feats, const void *other, const int64_t *pack_infos, int op, void *out,
+                       void *stream);
+/* packed_searchsorted[_packed_vals] (:1336-1503).  val_pack_infos NULL -> vals is [P, num_to_search]. */
+int nr3d_packed_searchsorted(uint32_t P, int dtype, const void *bins, const void *vals,
+                             const int64_t *pack_infos, uint32_t num_to_search,
+                             const int64_t *val_pack_infos, int64_t *pidx, void *stream);
+/* try_merge_two_packs_sorted_aligned (:1505-1631).  pidx_a / pidx_b ZERO-INIT. */
+int nr3d_try_merge_two_packs_sorted_aligned(uint32_t P, int dtype, const void *vals_a,
+                                            const int64_t *pack_infos_a, const void *vals_b,
+                                            const int64_t *pack_infos_b, const int64_t *pack_infos_merged,
+                                            int b_sorted, int64_t *pidx_a, int64_t *pidx_b, void *stream);
+/* packed_invert_cdf (:1633-1733). */
+int nr3d_packed_invert_cdf(uint32_t P, const float *bins, const float *cdfs, const int64_t *pack_infos,
+                           const float *u_vals, uint32_t num_to_sample, float *samples, int64_t *bin_idx,
+                           void *stream);
+/* packed_sort_qsort (:2634-2763): sorts vals IN PLACE per pack; ids (int64 arange, or NULL) permuted. */
+int nr3d_packed_sort(uint32_t P, uint64_t S, int dtype, void *vals, int64_t *ids, const int64_t *pack_infos,
+                     void *stream);
+/* packed_alpha_to_vw_forward (:1735-1793, :1850-1907).  Any of weights / num_steps / selector may be
+ * NULL; weights and selector are fully written (skipped samples -> 0). */
+int nr3d_alpha_to_vw_forward(uint32_t P, uint64_t S, const float *alphas, const int64_t *pack_infos,
+                             float early_stop_eps, float alpha_thre, float *weights, int64_t *num_steps,
+                             uint8_t *selector, void *stream);
+/* packed_alpha_to_vw_backward (:1795-1848, :1910-1958).  grad_alphas fully written. */
+int nr3d_alpha_to_vw_backward(uint32_t P, uint64_t S, const float *alphas, const float *weights,
+                              const float *grad_weights, const int64_t *pack_infos, float early_stop_eps,
+                              float alpha_thre, float *grad_alphas, void *stream);
+/* mark_pack_boundaries_cuda (:2765-2805): boundaries int32 [num]. */
+int nr3d_mark_pack_boundaries(uint64_t num, int dtype, const void *pack_ids, int32_t *boundaries, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NR3D_HIP_H */

@@ -1,0 +1,97 @@
+"""ctypes loader for libnr3d_hip.so (the C-ABI kernel library, include/nr3d_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a kernel entry point is
+called without a GPU tensor, this module raises.  ``build()`` compiles the library in-tree with hipcc
+for gfx950 (works without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnr3d_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+# dtype codes of include/nr3d_hip.h
+F32, F16, F64, I32, I64, U8, I16, I8 = range(8)
+DTYPE_CODE = {
+    torch.float32: F32, torch.float16: F16, torch.float64: F64, torch.int32: I32, torch.int64: I64,
+    torch.uint8: U8, torch.bool: U8, torch.int16: I16, torch.int8: I8,
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(verbose=False, jobs=None):
+    """hipcc --offload-arch=gfx950 build of nr3d_lib_amd/libnr3d_hip.so (incremental, via make)."""
+    jobs = jobs or os.cpu_count() or 4
+    cmd = ["make", "-C", CSRC, f"-j{jobs}"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("nr3d_lib_amd: building libnr3d_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded C-ABI library; raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"nr3d_lib_amd: {LIB_PATH} not found. Build it with "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C nr3d_lib_amd/csrc`. "
+                        "There is no CPU fallback for the kernel path.")
+                l = C.CDLL(LIB_PATH)
+                l.nr3d_last_error.restype = C.c_char_p
+                l.nr3d_scan_tmp_bytes.restype = C.c_uint64
+                l.nr3d_scan_tmp_bytes.argtypes = [C.c_uint64]
+                _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().nr3d_last_error().decode())
+
+
+def ptr(t):
+    """Device (or host) address of a tensor as c_void_p; None -> NULL."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    """hipStream_t of torch's current stream on the tensor's device."""
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("nr3d_lib_amd: kernels run on the GPU only (got a CPU tensor); "
+                               "there is no CPU fallback in the product path")
+
+
+def i64(v):
+    return C.c_int64(int(v))
+
+
+def u32(v):
+    return C.c_uint32(int(v))
+
+
+def i32(v):
+    return C.c_int32(int(v))
+
+
+def f32(v):
+    return C.c_float(float(v))

@@ -1,0 +1,426 @@
+"""nr3d_lib_amd.bindings._lotd -- drop-in for the reference pybind module ``nr3d_lib.bindings._lotd``
+(csrc/lotd/src/lotd.cpp:23-110), backed by the HIP kernels in libnr3d_hip.so through the C ABI of
+include/nr3d_hip.h.
+
+Same Python-visible names, argument order/defaults and return structure:
+  LoDType, InterpolationType, LoDMeta, lod_fwd, lod_bwd, lod_bwd_bwd_input, lod_get_grid_index.
+
+Differences that are deliberate and documented in DESIGN.md:
+  * y / dy_dx are stored feature-major ([E, N] / [E, N, D]) and returned as transposed views for EVERY
+    meta (the reference does this only on its hash-only path; its generic path returns row-major
+    [N, E] / [N, E*D]).  Set ``meta.c_permute_dydx = False`` to get the reference's row-major
+    [N, E*D] Jacobian.
+  * kernels compute in fp32; fp16 params / inputs are converted on the way in and results cast back
+    (the reference accumulates in half on its (half, half) path).
+  * forest overloads (``metas`` tuple) are not provided (out of the hot-path scope).
+"""
+import ctypes as C
+import enum
+
+import torch
+
+from .. import _hip as H
+
+MAX_LEVELS, MAX_DIMS, MAX_PSEUDO = 32, 4, 256
+
+
+class LoDType(enum.IntEnum):
+    """csrc/lotd/include/lotd/lotd_types.h:16-25 (VecZMatXoY is not exported by the reference's
+    pybind enum, lotd.cpp:60-68; kept here because the string type is accepted)."""
+    Dense = 0
+    VectorMatrix = 1
+    VecZMatXoY = 2
+    CP = 3
+    CPfast = 4
+    NPlaneMul = 5
+    NPlaneSum = 6
+    Hash = 7
+
+
+class InterpolationType(enum.IntEnum):
+    Linear = 0
+    Smoothstep = 1
+
+
+# export_values() of the pybind enums
+for _e in (LoDType, InterpolationType):
+    for _k, _v in _e.__members__.items():
+        globals()[_k] = _v
+
+_TYPE_NAMES = {  # lotd_types.h:42-62 (case-insensitive)
+    "dense": LoDType.Dense, "hash": LoDType.Hash, "nplane": LoDType.NPlaneSum, "nplanesum": LoDType.NPlaneSum,
+    "nplanemul": LoDType.NPlaneMul, "vectormatrix": LoDType.VectorMatrix, "vm": LoDType.VectorMatrix,
+    "veczmatxoy": LoDType.VecZMatXoY, "cpfast": LoDType.CPfast, "cp": LoDType.CP,
+}
+
+
+def string_to_lod_type(s):
+    try:
+        return _TYPE_NAMES[str(s).lower()]
+    except KeyError:
+        raise RuntimeError(f"LoTDEncoding: Invalid lod type: {s}")
+
+
+class _CLevel(C.Structure):
+    _fields_ = [("res", C.c_uint32 * MAX_DIMS), ("n_feats", C.c_uint32), ("type", C.c_uint32),
+                ("size", C.c_uint32), ("offset", C.c_uint32)]
+
+
+class _CMeta(C.Structure):
+    """nr3d_lotd_meta_t of include/nr3d_hip.h"""
+    _fields_ = [
+        ("levels", _CLevel * MAX_LEVELS),
+        ("map_levels", C.c_uint16 * MAX_PSEUDO),
+        ("map_cnt", C.c_uint16 * MAX_PSEUDO),
+        ("n_levels", C.c_uint32), ("n_pseudo_levels", C.c_uint32), ("n_feat_per_pseudo_lvl", C.c_uint32),
+        ("n_dims_to_encode", C.c_uint32), ("n_encoded_dims", C.c_uint32), ("n_params", C.c_uint32),
+        ("interpolation_type", C.c_uint32), ("c_hash_only", C.c_uint32),
+    ]
+
+
+class LoDMeta:
+    """LoDMeta(n_input_dims, lod_res | lod_res_multidim, lod_n_feats, lod_types, hashmap_size=None,
+    use_smooth_step=None) -- lotd.cpp:75-110, lotd_torch_api.h:79-142, create_meta lotd_torch_api.cu:29-230."""
+
+    def __init__(self, n_input_dims, lod_res, lod_n_feats, lod_types, hashmap_size=None, use_smooth_step=None):
+        lod_res, lod_n_feats, lod_types = list(lod_res), list(lod_n_feats), list(lod_types)
+        if not (len(lod_res) == len(lod_n_feats) == len(lod_types)):
+            raise RuntimeError("LoTDEncoding: Expect los_res, lod_n_feats, lod_types to have the same length")
+        L, D = len(lod_res), int(n_input_dims)
+        if D not in (2, 3, 4):
+            raise RuntimeError("LoTDEncoding: `n_input_dim` must be 2/3/4.")
+        res = (C.c_int32 * (L * D))()
+        for l, r in enumerate(lod_res):
+            rr = [int(r)] * D if not isinstance(r, (list, tuple)) else [int(v) for v in r]
+            if len(rr) != D:
+                raise RuntimeError("LoTDEncoding: each multi-dim resolution must have n_input_dims entries")
+            for d in range(D):
+                res[l * D + d] = rr[d]
+        nf = (C.c_int32 * L)(*[int(v) for v in lod_n_feats])
+        self.level_types_str = [str(t) for t in lod_types]
+        tp = (C.c_int32 * L)(*[int(string_to_lod_type(t)) for t in lod_types])
+        self._c = _CMeta()
+        H.check(H.lib().nr3d_lotd_meta_create(C.c_int32(D), C.c_uint32(L), res, nf, tp,
+                                              C.c_uint32(int(hashmap_size or 0)),
+                                              C.c_int(int(bool(use_smooth_step))), C.byref(self._c)))
+        c = self._c
+        self.level_res_multidim = [[int(c.levels[l].res[d]) for d in range(D)] for l in range(L)]
+        self.level_res = [r[0] if all(v == r[0] for v in r) else 0 for r in self.level_res_multidim]
+        self.level_n_feats = [int(c.levels[l].n_feats) for l in range(L)]
+        self.level_types = [int(c.levels[l].type) for l in range(L)]
+        self.level_sizes = [int(c.levels[l].size) for l in range(L)]
+        self.level_n_params = [s * f for s, f in zip(self.level_sizes, self.level_n_feats)]
+        self.level_offsets = [int(c.levels[l].offset) for l in range(L)] + [int(c.n_params)]
+        self.map_levels = [int(c.map_levels[q]) for q in range(c.n_pseudo_levels)]
+        self.map_cnt = [int(c.map_cnt[q]) for q in range(c.n_pseudo_levels)]
+        self.n_levels = int(c.n_levels)
+        self.n_pseudo_levels = int(c.n_pseudo_levels)
+        self.n_feat_per_pseudo_lvl = int(c.n_feat_per_pseudo_lvl)
+        self.n_dims_to_encode = int(c.n_dims_to_encode)
+        self.n_encoded_dims = int(c.n_encoded_dims)
+        self.n_params = int(c.n_params)
+        self.interpolation_type = InterpolationType(int(c.interpolation_type))
+        # read-write configuration flags (lotd_torch_api.h:98-103)
+        self.c_hash_only = bool(c.c_hash_only)
+        self.c_profile = False
+        self.c_bmm_backend = True
+        self.c_prefetch = True
+        self.c_permute_dydx = True
+        self._all_dense_hash = bool(c.c_hash_only)
+        self._dev_cache = {}
+
+    # ---- C-ABI views -------------------------------------------------------------------------
+    def _cmeta(self):
+        """host struct with the current value of the writable c_hash_only flag"""
+        want = 1 if (self.c_hash_only and self._all_dense_hash) else 0
+        if self._c.c_hash_only != want:
+            self._c.c_hash_only = want
+            self._dev_cache.clear()
+        return self._c
+
+    def _dev(self, device):
+        """device-resident byte copy of the struct (uploaded once per device)"""
+        c = self._cmeta()
+        key = (device.type, device.index)
+        t = self._dev_cache.get(key)
+        if t is None:
+            host = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8)
+            t = host.to(device)
+            self._dev_cache[key] = t
+        return t
+
+    def __repr__(self):
+        return (f"LoDMeta(D={self.n_dims_to_encode}, levels={self.n_levels}, n_params={self.n_params}, "
+                f"n_encoded_dims={self.n_encoded_dims}, hash_only={self.c_hash_only})")
+
+
+# ------------------------------------------------------------------------------------------------
+# argument checks shared by the entry points (lotd_torch_api.cu:244-290 and twins)
+# ------------------------------------------------------------------------------------------------
+def _is_divisible(a, b):
+    return (a - (a // b) * b) == 0
+
+
+def _check_common(fn, meta, input, params, batch_inds, batch_offsets, batch_data_size):
+    if isinstance(meta, tuple):
+        raise NotImplementedError("nr3d_lib_amd: forest LoTD (metas tuple) is outside the hot-path scope")
+    if input.dim() != 2:
+        raise RuntimeError(f"{fn}: Expected 2-dimensional tensor for argument x, got {input.dim()}")
+    H.require_gpu(input, params, batch_inds, batch_offsets)
+    if not input.is_contiguous():
+        raise RuntimeError(f"{fn}: Expected contiguous tensor for argument x")
+    if input.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError(f"{fn}: Expected x to have one of scalar types Half, Float; got {input.dtype}")
+    if input.shape[1] != meta.n_dims_to_encode:
+        raise RuntimeError(f"{fn}: Expected x to have size {meta.n_dims_to_encode} at dimension 1, "
+                           f"but got size {input.shape[1]}")
+    N = input.shape[0]
+    if params is not None:
+        if params.dim() != 1:
+            raise RuntimeError(f"{fn}: Expected 1-dimensional tensor for argument grid, got {params.dim()}")
+        if not params.is_contiguous():
+            raise RuntimeError(f"{fn}: Expected contiguous tensor for argument grid")
+        if params.dtype not in (torch.float16, torch.float32):
+            raise RuntimeError(f"{fn}: Expected grid to have one of scalar types Half, Float; got {params.dtype}")
+        if params.device != input.device:
+            raise RuntimeError(f"{fn}: Expected x and grid on the same GPU")
+        if not _is_divisible(params.shape[0], meta.n_params):
+            raise RuntimeError(f"LoTDEncoding::{fn}: Expect size of `params`={params.shape[0]} to be an integral "
+                               f"multiple of `n_param`={meta.n_params}")
+        if input.dtype == torch.float16 and params.dtype == torch.float32:
+            raise RuntimeError("LoTDEncoding: Input type combination not supported. Supported types are: "
+                               "<input,param> -> (half, half), (float, half), (float, float)")
+    if batch_inds is not None:
+        if batch_inds.dim() != 1 or batch_inds.shape[0] != N or batch_inds.dtype != torch.int64 \
+                or not batch_inds.is_contiguous() or batch_inds.device != input.device:
+            raise RuntimeError(f"{fn}: batch_inds must be a contiguous int64 [n_points] tensor on the input's GPU")
+    if batch_offsets is not None:
+        if batch_offsets.dim() != 1 or batch_offsets.dtype != torch.int64 or not batch_offsets.is_contiguous() \
+                or batch_offsets.device != input.device:
+            raise RuntimeError(f"{fn}: batch_offsets must be a contiguous int64 1-D tensor on the input's GPU")
+    bds = int(batch_data_size) if batch_data_size is not None else 0
+    if not (bds == 0 or _is_divisible(N, bds)):
+        raise RuntimeError(f"LoTDEncoding::{fn}: Expect nonzero `batch_data_size`={bds} to be a divisor of "
+                           f"`batch_size`={N}")
+    return N, bds
+
+
+def _f32c(t):
+    """fp32 working copy (no-op for fp32 tensors)"""
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def _strides2(t):
+    return t.stride(0), t.stride(1)
+
+
+def _jac_view(dy_dx, N, E, D):
+    """Interpret a Jacobian handed back by the caller: [N,E,D] (any layout with unit inner stride) or
+    contiguous [N,E*D].  Returns (fp32 tensor, stride_n, stride_e)."""
+    j = _f32c(dy_dx)
+    if j.dim() == 2:
+        j = j.view(N, E, D) if j.is_contiguous() else j.reshape(N, E, D)
+    if tuple(j.shape) != (N, E, D):
+        raise RuntimeError(f"LoTDEncoding: dy_dx must have {N * E * D} elements viewable as [{N}, {E}, {D}]")
+    if D > 1 and j.stride(2) != 1:
+        j = j.contiguous()
+    return j, j.stride(0), j.stride(1)
+
+
+class _Prof:
+    """c_profile: event-timed launches, printed like the reference (lotd_hash_only.h:748-760)."""
+
+    def __init__(self, meta, name, n):
+        self.on, self.name, self.n = bool(meta.c_profile), name, n
+
+    def __enter__(self):
+        if self.on:
+            self.t0, self.t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.t1.record()
+            self.t1.synchronize()
+            ms = self.t0.elapsed_time(self.t1)
+            print(f"{self.name}, {self.n}, {ms}, {ms / max(self.n, 1) * 1e6}")
+
+
+# ------------------------------------------------------------------------------------------------
+# lod_fwd  (lotd.cpp:29-31, lotd_torch_api.cu:232-395)
+# ------------------------------------------------------------------------------------------------
+def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_data_size=None, max_level=None,
+            need_input_grad=None):
+    m = lod_meta
+    N, bds = _check_common("fwd", m, input, params, batch_inds, batch_offsets, batch_data_size)
+    max_level = m.n_levels if max_level is None else int(max_level)
+    need_input_grad = bool(input.requires_grad) if need_input_grad is None else bool(need_input_grad)
+    E, D = m.n_encoded_dims, m.n_dims_to_encode
+    if max_level <= -1:  # lotd_torch_api.cu:294-297
+        return (torch.zeros((N, E), dtype=params.dtype, device=params.device),
+                torch.zeros((N, E * D), dtype=input.dtype, device=input.device))
+    x32, p32 = _f32c(input.detach()), _f32c(params.detach())
+    dev = input.device
+    with torch.cuda.device(dev):
+        y_store = torch.empty((E, N), dtype=torch.float32, device=dev)
+        y = y_store.t()
+        dy_dx = None
+        if need_input_grad:
+            if m.c_permute_dydx:
+                dy_dx = torch.empty((E, N, D), dtype=torch.float32, device=dev).permute(1, 0, 2)
+                dsn, dse = dy_dx.stride(0), dy_dx.stride(1)
+            else:
+                dy_dx = torch.empty((N, E * D), dtype=torch.float32, device=dev)
+                dsn, dse = E * D, D
+        else:
+            dsn = dse = 0
+        with _Prof(m, f"LoTD{D}-fwd" + ("-grad" if need_input_grad else ""), N):
+            H.check(H.lib().nr3d_lotd_fwd(
+                C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
+                H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds), H.i32(max_level),
+                H.ptr(y_store), H.i64(y.stride(0)), H.i64(y.stride(1)),
+                H.ptr(dy_dx), H.i64(dsn), H.i64(dse), H.stream_of(input)))
+    if params.dtype != torch.float32:
+        y = y.to(params.dtype)
+    if dy_dx is not None and input.dtype != torch.float32:
+        dy_dx = dy_dx.to(input.dtype)
+    return y, dy_dx
+
+
+# ------------------------------------------------------------------------------------------------
+# lod_bwd  (lotd.cpp:32-35, lotd_torch_api.cu:397-573)
+# ------------------------------------------------------------------------------------------------
+def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offsets=None, batch_data_size=None,
+            max_level=None, need_input_grad=None, need_param_grad=None):
+    m = lod_meta
+    N, bds = _check_common("bwd", m, input, params, batch_inds, batch_offsets, batch_data_size)
+    E, D = m.n_encoded_dims, m.n_dims_to_encode
+    H.require_gpu(dL_dy, dy_dx)
+    if dL_dy.dim() != 2 or tuple(dL_dy.shape) != (N, E):
+        raise RuntimeError(f"bwd: Expected dL_dy of size [{N}, {E}], got {list(dL_dy.shape)}")
+    if dL_dy.dtype != params.dtype:
+        raise RuntimeError("bwd: Expected dL_dy and grid to have the same dtype")
+    if dy_dx is not None and dy_dx.dtype != input.dtype:
+        raise RuntimeError("bwd: Expected x and dy_dx to have the same dtype")
+    max_level = m.n_levels if max_level is None else int(max_level)
+    need_input_grad = bool(input.requires_grad) if need_input_grad is None else bool(need_input_grad)
+    need_param_grad = bool(params.requires_grad) if need_param_grad is None else bool(need_param_grad)
+    dev = input.device
+    dL_dx = dL_dparam = None
+    with torch.cuda.device(dev):
+        if need_input_grad:
+            if dy_dx is None:
+                raise RuntimeError("LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.")
+            dL_dx = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        if need_param_grad:
+            dL_dparam = torch.zeros((params.shape[0],), dtype=torch.float32, device=dev)
+        if max_level <= -1 or not (need_input_grad or need_param_grad):
+            return (_cast(dL_dx, input.dtype), _cast(dL_dparam, params.dtype))
+        g32 = _f32c(dL_dy.detach())
+        gsn, gse = _strides2(g32)
+        st = H.stream_of(input)
+        tag = ("dx" if need_input_grad else "") + ("dp" if need_param_grad else "")
+        with _Prof(m, f"LoTD{D}-bwd-{tag}", N):
+            if need_input_grad and N > 0:
+                j, jsn, jse = _jac_view(dy_dx.detach(), N, E, D)
+                H.check(H.lib().nr3d_lotd_bwd_dx(
+                    C.byref(m._cmeta()), H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(g32), H.i64(gsn),
+                    H.i64(gse), H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), st))
+            if need_param_grad and N > 0:
+                x32, p32 = _f32c(input.detach()), _f32c(params.detach())
+                H.check(H.lib().nr3d_lotd_bwd_dparam(
+                    C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
+                    H.ptr(g32), H.i64(gsn), H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
+                    H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparam), st))
+    return _cast(dL_dx, input.dtype), _cast(dL_dparam, params.dtype)
+
+
+def _cast(t, dtype):
+    if t is None or t.dtype == dtype:
+        return t
+    return t.to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# lod_bwd_bwd_input  (lotd.cpp:36-40, lotd_torch_api.cu:575-748)
+# ------------------------------------------------------------------------------------------------
+def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offsets=None,
+                      batch_data_size=None, max_level=None, need_dLdinput_ddLdoutput=None,
+                      need_dLdinput_dparams=None, need_dLdinput_dinput=None):
+    m = lod_meta
+    N, bds = _check_common("bwd_bwd_input", m, input, params, batch_inds, batch_offsets, batch_data_size)
+    E, D = m.n_encoded_dims, m.n_dims_to_encode
+    H.require_gpu(dL_ddLdx, dL_dy, dy_dx)
+    if input.dtype != torch.float32:  # lotd_encoding.h:1805-1810: (half, half) has no second-order path
+        raise RuntimeError("LoTDEncoding: Input type combination not supported. Supported types are: "
+                           "<input,param> -> (half, half), (float, half), (float, float)")
+    if tuple(dL_ddLdx.shape) != (N, D) or not dL_ddLdx.is_contiguous() or dL_ddLdx.dtype != input.dtype:
+        raise RuntimeError(f"bwd_bwd_input: Expected contiguous dL_ddLdx of size [{N}, {D}] and the input's dtype")
+    if tuple(dL_dy.shape) != (N, E) or dL_dy.dtype != params.dtype:
+        raise RuntimeError(f"bwd_bwd_input: Expected dL_dy of size [{N}, {E}] and the params' dtype")
+    if dy_dx is not None and dy_dx.dtype != input.dtype:
+        raise RuntimeError("bwd_bwd_input: Expected x and dy_dx to have the same dtype")
+    max_level = m.n_levels if max_level is None else int(max_level)
+    need_dLdy = bool(dL_dy.requires_grad) if need_dLdinput_ddLdoutput is None else bool(need_dLdinput_ddLdoutput)
+    need_dx = bool(input.requires_grad) if need_dLdinput_dinput is None else bool(need_dLdinput_dinput)
+    need_dp = bool(params.requires_grad) if need_dLdinput_dparams is None else bool(need_dLdinput_dparams)
+    dev = input.device
+    dL_ddLdy = dL_dparams = dL_dx = None
+    with torch.cuda.device(dev):
+        if need_dLdy:
+            if dy_dx is None:
+                raise RuntimeError("LoTDEncoding::bwd_bwd_input: need `dy_dx` to compute `dL_d(dLdy)`.")
+            dL_ddLdy = torch.zeros((E, N), dtype=torch.float32, device=dev).t()
+        if need_dx:
+            dL_dx = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        if need_dp:
+            dL_dparams = torch.zeros((params.shape[0],), dtype=torch.float32, device=dev)
+        if max_level <= -1 or not (need_dLdy or need_dx or need_dp) or N == 0:
+            return _cast(dL_ddLdy, dL_dy.dtype), _cast(dL_dparams, params.dtype), _cast(dL_dx, input.dtype)
+        st = H.stream_of(input)
+        v32 = _f32c(dL_ddLdx.detach())
+        g32 = _f32c(dL_dy.detach())
+        gsn, gse = _strides2(g32)
+        x32, p32 = _f32c(input.detach()), _f32c(params.detach())
+        cm, md = C.byref(m._cmeta()), H.ptr(m._dev(dev))
+        tag = ("dx" if need_dx else "") + ("dp" if need_dp else "") + ("dLdy" if need_dLdy else "")
+        with _Prof(m, f"LoTD{D}-bwd2-{tag}", N):
+            if need_dLdy:
+                j, jsn, jse = _jac_view(dy_dx.detach(), N, E, D)
+                H.check(H.lib().nr3d_lotd_bwd_bwd_ddLdy(
+                    cm, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(j), H.i64(jsn), H.i64(jse),
+                    H.ptr(dL_ddLdy), H.i64(dL_ddLdy.stride(0)), H.i64(dL_ddLdy.stride(1)), st))
+            if need_dx:
+                H.check(H.lib().nr3d_lotd_bwd_bwd_dx(
+                    cm, md, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(g32), H.i64(gsn),
+                    H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
+                    H.i32(max_level), H.ptr(dL_dx), st))
+            if need_dp:
+                H.check(H.lib().nr3d_lotd_bwd_bwd_dparam(
+                    cm, md, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(g32), H.i64(gsn),
+                    H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
+                    H.i32(max_level), H.ptr(dL_dparams), st))
+    return _cast(dL_ddLdy, dL_dy.dtype), _cast(dL_dparams, params.dtype), _cast(dL_dx, input.dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# lod_get_grid_index  (lotd.cpp:41-42, lotd_torch_api.cu:771-855)
+# ------------------------------------------------------------------------------------------------
+def lod_get_grid_index(lod_meta, input, batch_inds=None, batch_offsets=None, batch_data_size=None, max_level=None):
+    m = lod_meta
+    N, bds = _check_common("get_grid_index", m, input, None, batch_inds, batch_offsets, batch_data_size)
+    for tp in m.level_types:
+        if tp not in (int(LoDType.Dense), int(LoDType.Hash)):
+            raise RuntimeError("LoTDEncoding::get_grid_index: Only support Dense/Hash type.")
+    max_level = m.n_levels if max_level is None else int(max_level)
+    E, D = m.n_encoded_dims, m.n_dims_to_encode
+    dev = input.device
+    with torch.cuda.device(dev):
+        out = torch.zeros((N, E, 1 << D), dtype=torch.int64, device=dev)
+        if max_level <= -1 or N == 0:
+            return out
+        H.check(H.lib().nr3d_lotd_grid_index(
+            C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), H.ptr(_f32c(input.detach())),
+            H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(out), H.stream_of(input)))
+    return out

@@ -1,0 +1,34 @@
+// nr3d_lib_amd/csrc/common.h -- shared host/device helpers for libnr3d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/nr3d_hip.h"
+
+namespace nr3d {
+
+// thread-local error string behind nr3d_last_error()
+char *err_buf();
+int fail(const char *fmt, ...);
+
+#define NR3D_CHECK(cond, ...) do { if (!(cond)) return ::nr3d::fail(__VA_ARGS__); } while (0)
+#define NR3D_HIP_CHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
+	return ::nr3d::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+#define NR3D_LAUNCH_CHECK() NR3D_HIP_CHECK(hipGetLastError())
+
+static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---- dtype <-> float conversions used by kernels templated on storage type ----
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half(v); }
+
+// Hardware fp32 add atomic at agent scope (global_atomic_add_f32); memory is coarse-grained device
+// memory allocated by the caller, for which the hardware instruction is valid.
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+}  // namespace nr3d

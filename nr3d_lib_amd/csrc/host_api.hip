@@ -1,0 +1,113 @@
+// nr3d_lib_amd/csrc/host_api.hip -- host-only parts of the C ABI: error string, ABI version and the
+// LoTD meta builder (reference: LoDMeta::create_meta, csrc/lotd/src/lotd_torch_api.cu:29-230).
+#include "common.h"
+#include <string.h>
+#include <limits>
+
+namespace nr3d {
+
+static thread_local char g_err[512] = {0};
+
+char *err_buf() { return g_err; }
+
+int fail(const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return 1;
+}
+
+}  // namespace nr3d
+
+using namespace nr3d;
+
+extern "C" const char *nr3d_last_error(void) { return err_buf(); }
+extern "C" int nr3d_abi_version(void) { return 1; }
+
+extern "C" int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, const int32_t *res_multidim,
+                                     const int32_t *n_feats, const int32_t *types, uint32_t hashmap_size,
+                                     int use_smooth_step, nr3d_lotd_meta_t *m) {
+	NR3D_CHECK(m && res_multidim && n_feats && types, "LoTDEncoding: NULL argument");
+	memset(m, 0, sizeof(*m));
+	NR3D_CHECK(n_input_dim == 2 || n_input_dim == 3 || n_input_dim == 4, "LoTDEncoding: `n_input_dim` must be 2/3/4.");
+	NR3D_CHECK(n_levels <= NR3D_LOTD_MAX_LEVELS, "LoTDEncoding:` num_level`=%u exceeds maximum level=%d", n_levels,
+	           NR3D_LOTD_MAX_LEVELS);
+	const uint32_t D = (uint32_t)n_input_dim;
+	m->n_dims_to_encode = D;
+	m->n_levels = n_levels;
+	m->interpolation_type = use_smooth_step ? 1u : 0u;
+
+	// feature width of a pseudo level = largest of {8,4,2} dividing every level's width
+	auto divides_all = [&](int32_t k) {
+		for (uint32_t l = 0; l < n_levels; ++l) if (n_feats[l] % k != 0) return false;
+		return true;
+	};
+	uint32_t G = 0;
+	for (int32_t k : {8, 4, 2}) if (divides_all(k)) { G = (uint32_t)k; break; }
+	NR3D_CHECK(G != 0, "LoTDEncoding: the greatest common divisor of `lod_n_feats` must be at least 2");
+	m->n_feat_per_pseudo_lvl = G;
+
+	const float max_params = (float)(std::numeric_limits<uint32_t>::max() / 2);
+	uint32_t total = 0, n_pseudo = 0, n_enc = 0;
+	float total_f = 0.0f;
+	bool dense_hash_only = true;
+	for (uint32_t l = 0; l < n_levels; ++l) {
+		nr3d_lotd_level_t &L = m->levels[l];
+		const uint32_t tp = (uint32_t)types[l];
+		NR3D_CHECK(tp <= NR3D_LOD_Hash, "LoTDEncoding: Invalid lod type: %u", tp);
+		NR3D_CHECK(n_feats[l] > 0, "LoTDEncoding: n_feats must be positive");
+		if (tp != NR3D_LOD_Dense && tp != NR3D_LOD_Hash) dense_hash_only = false;
+		uint64_t vol = 1, sum_r = 0;
+		for (uint32_t d = 0; d < D; ++d) {
+			const int32_t r = res_multidim[l * D + d];
+			NR3D_CHECK(r > 2, "LoTDEncoding: only support grid resolutions >= 3");
+			L.res[d] = (uint32_t)r;
+			vol *= (uint64_t)r;
+			sum_r += (uint64_t)r;
+		}
+		// entries per level; plane_d = volume / R_d
+		uint64_t sum_planes = 0;
+		for (uint32_t d = 0; d < D; ++d) sum_planes += vol / L.res[d];
+		uint64_t size = 0;
+		switch (tp) {
+		case NR3D_LOD_Dense: size = vol; break;
+		case NR3D_LOD_NPlaneMul:
+		case NR3D_LOD_NPlaneSum: size = sum_planes; break;
+		case NR3D_LOD_VectorMatrix:
+			NR3D_CHECK(D == 3, "LoTDEncoding: VectorMatrix mode only support 3D encoding.");
+			size = sum_planes + sum_r;
+			break;
+		case NR3D_LOD_VecZMatXoY:
+			NR3D_CHECK(D == 3, "LoTDEncoding: VecZMatXoY mode only support 3D encoding.");
+			size = (uint64_t)L.res[0] * L.res[1] + L.res[2];
+			break;
+		case NR3D_LOD_CP:
+		case NR3D_LOD_CPfast: size = sum_r; break;
+		case NR3D_LOD_Hash:
+			NR3D_CHECK(hashmap_size != 0, "LoTDEncoding: Hash mode need `hashmap_size`");
+			size = hashmap_size;
+			break;
+		}
+		total_f += (float)size * (float)n_feats[l];
+		NR3D_CHECK(total_f <= max_params, "LoTDEncoding: param size too large.");
+		L.n_feats = (uint32_t)n_feats[l];
+		L.type = tp;
+		L.size = (uint32_t)size;
+		L.offset = total;
+		total += (uint32_t)size * (uint32_t)n_feats[l];
+		for (uint32_t j = 0; j < (uint32_t)n_feats[l] / G; ++j) {
+			NR3D_CHECK(n_pseudo < NR3D_LOTD_MAX_PSEUDO, "LoTDEncoding: too many pseudo levels");
+			m->map_levels[n_pseudo] = (uint16_t)l;
+			m->map_cnt[n_pseudo] = (uint16_t)j;
+			++n_pseudo;
+		}
+		n_enc += (uint32_t)n_feats[l];
+	}
+	NR3D_CHECK(n_enc <= 1024, "LoTDEncoding: total number of features too large. Shoule be <= 1024.");
+	m->n_params = total;
+	m->n_pseudo_levels = n_pseudo;
+	m->n_encoded_dims = n_enc;
+	m->c_hash_only = dense_hash_only ? 1u : 0u;
+	return 0;
+}

@@ -1,0 +1,779 @@
+// nr3d_lib_amd/csrc/lotd.hip -- LoTD encoder kernels + C-ABI entry points (gfx950 / MI355X).
+//
+// Replaces the reference extension nr3d_lib.bindings._lotd:
+//   forward            kernel_lod / kernel_lod_hash_only[_with_dydx]   lotd_encoding.h:113-428, lotd_hash_only.h:15-378
+//   dL/dparam          kernel_lod[_hashonly]_backward_grid               lotd_encoding.h:467-711, lotd_hash_only.h:380-470
+//   dL/dx              ATen mul+sum                                      lotd_encoding.h:1562-1586
+//   d(dL/dx)/dparam    kernel_lod[_hashonly]_backward_input_backward_grid  lotd_encoding.h:764-1041
+//   d(dL/dx)/dx        kernel_lod[_hashonly]_backward_input_backward_input lotd_encoding.h:1157-1298
+//   d(dL/dx)/d(dL/dy)  ATen mul+sum                                      lotd_encoding.h:1703-1727
+//   get_grid_index     kernel_lod_get_grid_index                         lotd_encoding.h:1300-1433
+//   meta               LoDMeta::create_meta                              lotd_torch_api.cu:29-230
+//
+// Design (MI355X-first, not a translation):
+//  * one lane = one (point, pseudo-level); the 2^D corner values of a feature group live in VGPRs and
+//    feed BOTH y and dy/dx (no second gather sweep for the Jacobian);
+//  * outputs are written feature-major ([E, N] / [E, N, D] storage, returned as strided views), so a
+//    wave's 64 lanes store 256 / 768 contiguous bytes per feature;
+//  * per-level descriptors come from a device copy of the meta through scalar loads (the block's
+//    level is wave-uniform) instead of a 3.3 KB by-value kernel argument;
+//  * blocks are scheduled XCD-affinely: each of the 8 XCDs walks its own levels one after another,
+//    so one <=4 MiB table at a time is hot in that XCD's private L2;
+//  * the second-order parameter scatter combines the reference's 2*D*2^(D-1) left/right updates into
+//    one update per corner in registers (2^D atomics instead of D*2^D);
+//  * every output element is written (zeros for skipped points), so callers allocate with empty().
+#include "lotd_device.h"
+#include <stdlib.h>
+
+namespace nr3d {
+namespace lotd {
+
+// =============================================================================================
+// Forward
+// =============================================================================================
+template <int D, int G, bool DYDX, bool DH>
+__global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                const float *__restrict__ params, Batch ba, uint32_t vec_ok,
+                                                float *__restrict__ y, int64_t y_sn, int64_t y_se,
+                                                float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
+	uint32_t q, chunk;
+	if (!decode_block(s, blockIdx.x, q, chunk)) return;
+	const uint32_t i = chunk * kBlock + threadIdx.x;
+	if (i >= N) return;
+	const uint32_t level = md->map_levels[q];
+	const uint32_t foff0 = (uint32_t)md->map_cnt[q] * G;
+	const uint32_t out0 = q * G;
+
+	float out_y[G];
+	float out_g[G][D];
+#pragma unroll
+	for (int f = 0; f < G; ++f) {
+		out_y[f] = 0.0f;
+#pragma unroll
+		for (int d = 0; d < D; ++d) out_g[f][d] = 0.0f;
+	}
+
+	uint32_t base = 0;
+	const bool active = ((int32_t)level <= max_level) && batch_base(ba, i, base);
+	if (active) {
+		const Lvl L = load_level(md, level);
+		const float *__restrict__ grid = params + (base + L.off);
+		float xp[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
+		Cell<D> c;
+		locate<D>(xp, L, smooth != 0, c);
+
+		if (DH || L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash) {
+			// ---- all corners of all G features at once; vector loads when alignment allows ----
+			float v[1 << D][G];
+#pragma unroll
+			for (uint32_t k = 0; k < (1u << D); ++k) {
+				uint32_t p[D];
+				corner_pos<D>(c, k, p);
+				const uint32_t e = (L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p);
+				const float *src = grid + (e * L.F + foff0);
+				if (vec_ok) {
+					if constexpr (G == 2) {
+						const float2 t = *reinterpret_cast<const float2 *>(src);
+						v[k][0] = t.x; v[k][1] = t.y;
+					} else {
+#pragma unroll
+						for (int f4 = 0; f4 < G; f4 += 4) {
+							const float4 t = *reinterpret_cast<const float4 *>(src + f4);
+							v[k][f4] = t.x; v[k][f4 + 1] = t.y; v[k][f4 + 2] = t.z; v[k][f4 + 3] = t.w;
+						}
+					}
+				} else {
+#pragma unroll
+					for (int f = 0; f < G; ++f) v[k][f] = src[f];
+				}
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < (1u << D); ++k) {
+				const float w = corner_weight<D>(c, k);
+#pragma unroll
+				for (int f = 0; f < G; ++f) out_y[f] = __fmaf_rn(w, v[k][f], out_y[f]);
+			}
+			if (DYDX) {
+#pragma unroll
+				for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+					for (uint32_t k = 0; k < (1u << D); ++k) {
+						if ((k >> gd) & 1u) continue;   // k = lower corner along gd
+						const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
+#pragma unroll
+						for (int f = 0; f < G; ++f)
+							out_g[f][gd] = __fmaf_rn(w, v[k | (1u << gd)][f] - v[k][f], out_g[f][gd]);
+					}
+			}
+		} else if (L.type == NR3D_LOD_NPlaneSum) {
+			// sum over the D axis planes of an (D-1)-linear interpolation (reference: lotd_encoding.h:268-351)
+			if constexpr (D > 2) {
+#pragma unroll 1
+				for (uint32_t jd = 0; jd < (uint32_t)D; ++jd) {
+					float pv[1 << (D - 1)][G];
+#pragma unroll
+					for (uint32_t k = 0; k < (1u << (D - 1)); ++k) {
+						uint32_t pp[D];
+#pragma unroll
+						for (int d2 = 0; d2 < D - 1; ++d2) {
+							const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+							pp[d2] = c.g[d3] + ((k >> d2) & 1u);
+						}
+						const uint32_t e = entry_nplane_sum<D>(L, jd, pp) * L.F + foff0;
+#pragma unroll
+						for (int f = 0; f < G; ++f) pv[k][f] = grid[e + f];
+					}
+#pragma unroll
+					for (uint32_t k = 0; k < (1u << (D - 1)); ++k) {
+						float w = 1.0f;
+#pragma unroll
+						for (int d2 = 0; d2 < D - 1; ++d2) {
+							const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+							w *= ((k >> d2) & 1u) ? c.w[d3] : (1.0f - c.w[d3]);
+						}
+#pragma unroll
+						for (int f = 0; f < G; ++f) out_y[f] = __fmaf_rn(w, pv[k][f], out_y[f]);
+					}
+					if (DYDX) {
+#pragma unroll
+						for (int g2 = 0; g2 < D - 1; ++g2) {
+							const int g3 = (uint32_t)g2 >= jd ? g2 + 1 : g2;
+#pragma unroll
+							for (uint32_t k = 0; k < (1u << (D - 1)); ++k) {
+								if ((k >> g2) & 1u) continue;
+								float w = c.sc[g3] * c.dw[g3];
+#pragma unroll
+								for (int d2 = 0; d2 < D - 1; ++d2) {
+									if (d2 == g2) continue;
+									const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+									w *= ((k >> d2) & 1u) ? c.w[d3] : (1.0f - c.w[d3]);
+								}
+#pragma unroll
+								for (int f = 0; f < G; ++f) {
+									// out_g is indexed with a runtime dim here; unrolled select keeps it in VGPRs
+#pragma unroll
+									for (int d = 0; d < D; ++d)
+										if (d == g3) out_g[f][d] = __fmaf_rn(w, pv[k | (1u << g2)][f] - pv[k][f], out_g[f][d]);
+								}
+							}
+						}
+					}
+				}
+			}
+		} else if (L.type == NR3D_LOD_CPfast) {
+			// product over dims of 1-D linear interpolations (reference: lotd_encoding.h:353-410)
+			float lv[D][2][G], li[D][G];
+#pragma unroll
+			for (int d = 0; d < D; ++d) {
+				const uint32_t e0 = entry_line<D>(L, d, c.g[d]) * L.F + foff0;
+				const uint32_t e1 = entry_line<D>(L, d, c.g[d] + 1u) * L.F + foff0;
+#pragma unroll
+				for (int f = 0; f < G; ++f) {
+					lv[d][0][f] = grid[e0 + f];
+					lv[d][1][f] = grid[e1 + f];
+					li[d][f] = __fmaf_rn(c.w[d], lv[d][1][f], (1.0f - c.w[d]) * lv[d][0][f]);
+				}
+			}
+#pragma unroll
+			for (int f = 0; f < G; ++f) {
+				float r = 1.0f;
+#pragma unroll
+				for (int d = 0; d < D; ++d) r *= li[d][f];
+				out_y[f] = r;
+			}
+			if (DYDX) {
+#pragma unroll
+				for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+					for (int f = 0; f < G; ++f) {
+						float r = (c.sc[gd] * c.dw[gd]) * (lv[gd][1][f] - lv[gd][0][f]);
+#pragma unroll
+						for (int d = 0; d < D; ++d) if (d != gd) r *= li[d][f];
+						out_g[f][gd] = r;
+					}
+			}
+		} else {
+			// ---- remaining N-linear types (VM, VecZMatXoY, CP, NPlaneMul): feature pairs to bound VGPRs ----
+#pragma unroll 1
+			for (int f0 = 0; f0 < G; f0 += 2) {
+				float v[1 << D][2];
+#pragma unroll
+				for (uint32_t k = 0; k < (1u << D); ++k) {
+					uint32_t p[D];
+					corner_pos<D>(c, k, p);
+					corner_value<D, 2>(L, grid, foff0 + f0, p, v[k]);
+				}
+				float yy[2] = {0.0f, 0.0f}, gg[2][D];
+#pragma unroll
+				for (int f = 0; f < 2; ++f)
+#pragma unroll
+					for (int d = 0; d < D; ++d) gg[f][d] = 0.0f;
+#pragma unroll
+				for (uint32_t k = 0; k < (1u << D); ++k) {
+					const float w = corner_weight<D>(c, k);
+					yy[0] = __fmaf_rn(w, v[k][0], yy[0]);
+					yy[1] = __fmaf_rn(w, v[k][1], yy[1]);
+				}
+				if (DYDX) {
+#pragma unroll
+					for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+						for (uint32_t k = 0; k < (1u << D); ++k) {
+							if ((k >> gd) & 1u) continue;
+							const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
+							gg[0][gd] = __fmaf_rn(w, v[k | (1u << gd)][0] - v[k][0], gg[0][gd]);
+							gg[1][gd] = __fmaf_rn(w, v[k | (1u << gd)][1] - v[k][1], gg[1][gd]);
+						}
+				}
+#pragma unroll
+				for (int f = 0; f < G; ++f)
+					if (f == f0 || f == f0 + 1) {
+						out_y[f] = yy[f - f0];
+#pragma unroll
+						for (int d = 0; d < D; ++d) out_g[f][d] = gg[f - f0][d];
+					}
+			}
+		}
+	}
+
+#pragma unroll
+	for (int f = 0; f < G; ++f) y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se] = out_y[f];
+	if (DYDX) {
+#pragma unroll
+		for (int f = 0; f < G; ++f) {
+			float *dst = dydx + (int64_t)i * d_sn + (int64_t)(out0 + f) * d_se;
+#pragma unroll
+			for (int d = 0; d < D; ++d) dst[d] = out_g[f][d];
+		}
+	}
+}
+
+// =============================================================================================
+// dL/dparam (SECOND == false) and d(dL/dx)/dparam (SECOND == true)
+// =============================================================================================
+template <int D, int G, bool SECOND, bool DH>
+__global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                       int32_t max_level, uint32_t smooth,
+                                                       const float *__restrict__ dL_ddLdx,
+                                                       const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
+                                                       const float *__restrict__ x, const float *__restrict__ params,
+                                                       Batch ba, float *__restrict__ dparam) {
+	uint32_t q, chunk;
+	if (!decode_block(s, blockIdx.x, q, chunk)) return;
+	const uint32_t i = chunk * kBlock + threadIdx.x;
+	if (i >= N) return;
+	const uint32_t level = md->map_levels[q];
+	if ((int32_t)level > max_level) return;
+	uint32_t base = 0;
+	if (!batch_base(ba, i, base)) return;
+	const uint32_t foff0 = (uint32_t)md->map_cnt[q] * G;
+	const uint32_t out0 = q * G;
+	const Lvl L = load_level(md, level);
+	const float *__restrict__ grid = params + (base + L.off);
+	float *__restrict__ gg = dparam + (base + L.off);
+
+	float xp[D], vin[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) {
+		xp[d] = x[(size_t)i * D + d];
+		vin[d] = SECOND ? dL_ddLdx[(size_t)i * D + d] : 0.0f;
+	}
+	Cell<D> c;
+	locate<D>(xp, L, smooth != 0, c);
+
+	float grad[G];
+#pragma unroll
+	for (int f = 0; f < G; ++f) grad[f] = dL_dy[(int64_t)i * g_sn + (int64_t)(out0 + f) * g_se];
+
+	// per-dim seed of the second-order weights: scale_d * v_d * w'_d
+	float a[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) a[d] = SECOND ? c.sc[d] * vin[d] * c.dw[d] : 0.0f;
+
+	if (DH || L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash || L.type == NR3D_LOD_VectorMatrix ||
+	    L.type == NR3D_LOD_VecZMatXoY || L.type == NR3D_LOD_CP || L.type == NR3D_LOD_NPlaneMul) {
+		// One update per corner.  First order: W_c.  Second order: the reference issues, for every grad dim
+		// d and every face corner, -w at the lower and +w at the upper corner (lotd_encoding.h:733-761);
+		// all D contributions that land on corner c are summed here first.  The scatter rule is linear in
+		// the weight for every type, so the result is the same sum.
+#pragma unroll
+		for (uint32_t k = 0; k < (1u << D); ++k) {
+			float w;
+			if (!SECOND) {
+				w = corner_weight<D>(c, k);
+			} else {
+				w = 0.0f;
+#pragma unroll
+				for (int d = 0; d < D; ++d) {
+					const float t = face_weight<D>(c, k, d, a[d]);
+					w += ((k >> d) & 1u) ? t : -t;
+				}
+			}
+			uint32_t p[D];
+			corner_pos<D>(c, k, p);
+			if (DH) {
+				const uint32_t e = (L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p);
+				float *dst = gg + (e * L.F + foff0);
+#pragma unroll
+				for (int f = 0; f < G; ++f) atomic_add_f32(dst + f, grad[f] * w);
+			} else {
+				corner_scatter<D, G>(L, grid, gg, foff0, p, grad, w);
+			}
+		}
+	} else if (L.type == NR3D_LOD_NPlaneSum) {
+		if constexpr (D > 2) {
+#pragma unroll 1
+			for (uint32_t jd = 0; jd < (uint32_t)D; ++jd)
+#pragma unroll
+				for (uint32_t k = 0; k < (1u << (D - 1)); ++k) {
+					uint32_t pp[D];
+#pragma unroll
+					for (int d2 = 0; d2 < D - 1; ++d2) {
+						const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+						pp[d2] = c.g[d3] + ((k >> d2) & 1u);
+					}
+					float w;
+					if (!SECOND) {
+						w = 1.0f;
+#pragma unroll
+						for (int d2 = 0; d2 < D - 1; ++d2) {
+							const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+							w *= ((k >> d2) & 1u) ? c.w[d3] : (1.0f - c.w[d3]);
+						}
+					} else {
+						w = 0.0f;
+#pragma unroll
+						for (int g2 = 0; g2 < D - 1; ++g2) {
+							const int g3 = (uint32_t)g2 >= jd ? g2 + 1 : g2;
+							float t = 0.0f;
+#pragma unroll
+							for (int d = 0; d < D; ++d) if (d == g3) t = a[d];
+#pragma unroll
+							for (int d2 = 0; d2 < D - 1; ++d2) {
+								if (d2 == g2) continue;
+								const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+								t *= ((k >> d2) & 1u) ? c.w[d3] : (1.0f - c.w[d3]);
+							}
+							w += ((k >> g2) & 1u) ? t : -t;
+						}
+					}
+					float *dst = gg + (entry_nplane_sum<D>(L, jd, pp) * L.F + foff0);
+#pragma unroll
+					for (int f = 0; f < G; ++f) atomic_add_f32(dst + f, grad[f] * w);
+				}
+		}
+	} else if (L.type == NR3D_LOD_CPfast) {
+		float lv[D][2][G];
+		uint32_t le[D][2];
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			le[d][0] = entry_line<D>(L, d, c.g[d]) * L.F + foff0;
+			le[d][1] = entry_line<D>(L, d, c.g[d] + 1u) * L.F + foff0;
+#pragma unroll
+			for (int f = 0; f < G; ++f) { lv[d][0][f] = grid[le[d][0] + f]; lv[d][1][f] = grid[le[d][1] + f]; }
+		}
+		if (!SECOND) {
+			// reference lotd_encoding.h:653-705
+#pragma unroll
+			for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+				for (int f = 0; f < G; ++f) {
+					float gl = grad[f];
+#pragma unroll
+					for (int d = 0; d < D; ++d)
+						if (d != gd) gl *= __fmaf_rn(c.w[d], lv[d][1][f], (1.0f - c.w[d]) * lv[d][0][f]);
+					atomic_add_f32(gg + le[gd][0] + f, gl * (1.0f - c.w[gd]));
+					atomic_add_f32(gg + le[gd][1] + f, gl * c.w[gd]);
+				}
+		} else {
+			// reference lotd_encoding.h:970-1038: for every (line dim ld, grad dim gd) pair
+#pragma unroll
+			for (int ld = 0; ld < D; ++ld)
+#pragma unroll
+				for (int f = 0; f < G; ++f) {
+					float acc_l = 0.0f, acc_r = 0.0f;
+#pragma unroll
+					for (int gd = 0; gd < D; ++gd) {
+						float gl = grad[f] * c.sc[gd] * vin[gd] * c.dw[gd];
+						const float wl = (ld != gd) ? (1.0f - c.w[ld]) : -1.0f;
+						const float wr = (ld != gd) ? c.w[ld] : 1.0f;
+#pragma unroll
+						for (int d = 0; d < D; ++d) {
+							if (d == ld) continue;
+							const float nl = (d != gd) ? (1.0f - c.w[d]) : -1.0f;
+							const float nr = (d != gd) ? c.w[d] : 1.0f;
+							gl *= __fmaf_rn(nr, lv[d][1][f], nl * lv[d][0][f]);
+						}
+						acc_l = __fmaf_rn(gl, wl, acc_l);
+						acc_r = __fmaf_rn(gl, wr, acc_r);
+					}
+					atomic_add_f32(gg + le[ld][0] + f, acc_l);
+					atomic_add_f32(gg + le[ld][1] + f, acc_r);
+				}
+		}
+	}
+}
+
+// =============================================================================================
+// d(dL/dx)/dx  -- Hessian-vector product; Dense / Hash / VM / VecZMatXoY only (other types: 0)
+// Each lane owns ALL pseudo levels of one point (no cross-lane atomics on dL_dx).
+// =============================================================================================
+template <int D, int G>
+__global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                       uint32_t n_pseudo, int32_t max_level, uint32_t smooth,
+                                                       const float *__restrict__ dL_ddLdx,
+                                                       const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
+                                                       const float *__restrict__ x, const float *__restrict__ params,
+                                                       Batch ba, float *__restrict__ dL_dx) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= N) return;
+	float acc[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) acc[d] = 0.0f;
+	uint32_t base = 0;
+	const bool ok = batch_base(ba, i, base);
+	if (ok) {
+		float xp[D], vin[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) { xp[d] = x[(size_t)i * D + d]; vin[d] = dL_ddLdx[(size_t)i * D + d]; }
+#pragma unroll 1
+		for (uint32_t q = 0; q < n_pseudo; ++q) {
+			const uint32_t level = md->map_levels[q];
+			if ((int32_t)level > max_level) continue;
+			const Lvl L = load_level(md, level);
+			if (!(L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash || L.type == NR3D_LOD_VectorMatrix ||
+			      L.type == NR3D_LOD_VecZMatXoY)) continue;
+			const float *__restrict__ grid = params + (base + L.off);
+			Cell<D> c;
+			locate<D>(xp, L, smooth != 0, c);
+#pragma unroll 1
+			for (int f0 = 0; f0 < G; f0 += 2) {
+				const uint32_t foff = (uint32_t)md->map_cnt[q] * G + f0;
+				float grad[2];
+				grad[0] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0) * g_se];
+				grad[1] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0 + 1) * g_se];
+				// s[k] = sum_f value(corner k)[f] * grad[f]
+				float sdot[1 << D];
+#pragma unroll
+				for (uint32_t k = 0; k < (1u << D); ++k) {
+					uint32_t p[D];
+					corner_pos<D>(c, k, p);
+					sdot[k] = corner_dot<D, 2>(L, grid, foff, p, grad, 1.0f);
+				}
+				// out_d = sum_e v_e * H[e][d],  H = d^2 (sum_c W_c s_c) / dx_e dx_d
+#pragma unroll
+				for (int d = 0; d < D; ++d) {
+					float o = 0.0f;
+#pragma unroll
+					for (int e = 0; e < D; ++e) {
+						if (e == d && !smooth) continue;    // linear: zero diagonal
+						const float seed = (e == d) ? (c.sc[d] * vin[d]) * (c.sc[d] * c.ddw[d])
+						                            : (c.sc[e] * vin[e] * c.dw[e]) * (c.dw[d] * c.sc[d]);
+#pragma unroll
+						for (uint32_t k = 0; k < (1u << D); ++k) {
+							// differentiated dims contribute the sign of the corner (+upper, -lower),
+							// the others their interpolation weight (for e == d the sign appears once)
+							float w = seed;
+#pragma unroll
+							for (int m = 0; m < D; ++m) {
+								const bool up = (k >> m) & 1u;
+								if (m == d || m == e) w *= up ? 1.0f : -1.0f;
+								else w *= up ? c.w[m] : (1.0f - c.w[m]);
+							}
+							o = __fmaf_rn(w, sdot[k], o);
+						}
+					}
+					acc[d] += o;
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = acc[d];
+}
+
+// =============================================================================================
+// Dense contractions with the stored Jacobian
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_contract_dx(uint32_t N, uint32_t E, const float *__restrict__ dL_dy,
+                                                        int64_t g_sn, int64_t g_se, const float *__restrict__ dydx,
+                                                        int64_t d_sn, int64_t d_se, float *__restrict__ dL_dx) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= N) return;
+	float acc[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) acc[d] = 0.0f;
+	const float *gy = dL_dy + (int64_t)i * g_sn;
+	const float *jj = dydx + (int64_t)i * d_sn;
+#pragma unroll 4
+	for (uint32_t e = 0; e < E; ++e) {
+		const float g = gy[(int64_t)e * g_se];
+		const float *j = jj + (int64_t)e * d_se;
+#pragma unroll
+		for (int d = 0; d < D; ++d) acc[d] = __fmaf_rn(g, j[d], acc[d]);
+	}
+#pragma unroll
+	for (int d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = acc[d];
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_contract_ddLdy(uint32_t N, uint32_t E, const float *__restrict__ v,
+                                                           const float *__restrict__ dydx, int64_t d_sn, int64_t d_se,
+                                                           float *__restrict__ out, int64_t o_sn, int64_t o_se) {
+	// 2-D launch: blockIdx.y = encoded dim (keeps feature-major Jacobian reads and feature-major writes coalesced)
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	const uint32_t e = blockIdx.y;
+	if (i >= N) return;
+	const float *j = dydx + (int64_t)i * d_sn + (int64_t)e * d_se;
+	float r = 0.0f;
+#pragma unroll
+	for (int d = 0; d < D; ++d) r = __fmaf_rn(v[(size_t)i * D + d], j[d], r);
+	out[(int64_t)i * o_sn + (int64_t)e * o_se] = r;
+}
+
+// =============================================================================================
+// Corner parameter indices (Dense / Hash only) -> int64 [N, E, 2^D]
+// =============================================================================================
+template <int D, int G>
+__global__ __launch_bounds__(kBlock) void k_grid_index(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                       uint32_t E, int32_t max_level, const float *__restrict__ x,
+                                                       Batch ba, int64_t *__restrict__ out) {
+	uint32_t q, chunk;
+	if (!decode_block(s, blockIdx.x, q, chunk)) return;
+	const uint32_t i = chunk * kBlock + threadIdx.x;
+	if (i >= N) return;
+	const uint32_t level = md->map_levels[q];
+	if ((int32_t)level > max_level) return;
+	uint32_t base = 0;
+	if (!batch_base(ba, i, base)) return;
+	const Lvl L = load_level(md, level);
+	const uint32_t foff0 = (uint32_t)md->map_cnt[q] * G;
+	float xp[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
+	Cell<D> c;
+	locate<D>(xp, L, false, c);
+	int64_t *dst = out + ((size_t)i * E + (size_t)q * G) * (1u << D);
+#pragma unroll
+	for (uint32_t k = 0; k < (1u << D); ++k) {
+		uint32_t p[D];
+		corner_pos<D>(c, k, p);
+		const uint32_t e = (L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p);
+		const uint32_t ind = base + L.off + e * L.F + foff0;
+#pragma unroll
+		for (int f = 0; f < G; ++f) dst[k + f * (1u << D)] = (int64_t)(uint32_t)(ind + f);
+	}
+}
+
+// =============================================================================================
+// Host side
+// =============================================================================================
+static uint32_t sched_mode_default() {
+	static int mode = -1;
+	if (mode < 0) {
+		const char *e = getenv("NR3D_LOTD_SCHED");
+		mode = e ? atoi(e) : 1;
+		if (mode < 0 || mode > 2) mode = 1;
+	}
+	return (uint32_t)mode;
+}
+
+static Sched make_sched(uint32_t N, uint32_t n_pseudo, uint32_t &n_blocks) {
+	Sched s;
+	s.n_chunks = div_up(N, kBlock);
+	s.n_pseudo = n_pseudo;
+	s.mode = sched_mode_default();
+	s.n_slots = div_up(n_pseudo, 8);
+	n_blocks = (s.mode == 1) ? 8u * s.n_slots * s.n_chunks : n_pseudo * s.n_chunks;
+	return s;
+}
+
+static int check_common(const nr3d_lotd_meta_t *m, const void *meta_dev, int x_dtype, int p_dtype) {
+	NR3D_CHECK(m != nullptr, "LoTD: meta is NULL");
+	NR3D_CHECK(meta_dev != nullptr, "LoTD: meta_dev (device copy of the meta) is NULL");
+	NR3D_CHECK(x_dtype == NR3D_F32 && p_dtype == NR3D_F32,
+	           "LoTD: kernels compute in f32; convert half inputs/params on the caller side (got x=%d, params=%d)",
+	           x_dtype, p_dtype);
+	NR3D_CHECK(m->n_dims_to_encode >= 2 && m->n_dims_to_encode <= 4, "LoTD: `n_dims_to_encode` must be 2/3/4");
+	const uint32_t G = m->n_feat_per_pseudo_lvl;
+	NR3D_CHECK(G == 2 || G == 4 || G == 8, "LoTDEncoding: `n_feat_per_pseudo_lvl` must be one of [2,4,8]");
+	return 0;
+}
+
+#define DISPATCH_DG(D_, G_, ...)                                                     \
+	do {                                                                             \
+		const uint32_t _d = (D_), _g = (G_);                                         \
+		if (_d == 2 && _g == 2) { constexpr int D = 2, G = 2; __VA_ARGS__; }         \
+		else if (_d == 2 && _g == 4) { constexpr int D = 2, G = 4; __VA_ARGS__; }    \
+		else if (_d == 2 && _g == 8) { constexpr int D = 2, G = 8; __VA_ARGS__; }    \
+		else if (_d == 3 && _g == 2) { constexpr int D = 3, G = 2; __VA_ARGS__; }    \
+		else if (_d == 3 && _g == 4) { constexpr int D = 3, G = 4; __VA_ARGS__; }    \
+		else if (_d == 3 && _g == 8) { constexpr int D = 3, G = 8; __VA_ARGS__; }    \
+		else if (_d == 4 && _g == 2) { constexpr int D = 4, G = 2; __VA_ARGS__; }    \
+		else if (_d == 4 && _g == 4) { constexpr int D = 4, G = 4; __VA_ARGS__; }    \
+		else { constexpr int D = 4, G = 8; __VA_ARGS__; }                            \
+	} while (0)
+
+#define DISPATCH_D(D_, ...)                                          \
+	do {                                                             \
+		const uint32_t _d = (D_);                                    \
+		if (_d == 2) { constexpr int D = 2; __VA_ARGS__; }           \
+		else if (_d == 3) { constexpr int D = 3; __VA_ARGS__; }      \
+		else { constexpr int D = 4; __VA_ARGS__; }                   \
+	} while (0)
+
+}  // namespace lotd
+}  // namespace nr3d
+
+using namespace nr3d;
+using namespace nr3d::lotd;
+
+extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                             int param_dtype, const void *x, const void *params, const int64_t *batch_inds,
+                             const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level, void *y,
+                             int64_t y_sn, int64_t y_se, void *dy_dx, int64_t d_sn, int64_t d_se, void *stream) {
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	if (N == 0) return 0;
+	NR3D_CHECK(x && params && y, "LoTD::fwd: NULL tensor pointer");
+	uint32_t n_blocks;
+	const Sched s = make_sched(N, meta->n_pseudo_levels, n_blocks);
+	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
+	const uint32_t G = meta->n_feat_per_pseudo_lvl;
+	// vector gathers need every corner address G*4-byte aligned: base pointer aligned and no caller-chosen offsets
+	const uint32_t vec_ok = (((uintptr_t)params % (G >= 4 ? 16 : 8)) == 0 && batch_offsets == nullptr) ? 1u : 0u;
+	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
+	hipStream_t st = (hipStream_t)stream;
+	const bool dh = meta->c_hash_only != 0;
+	DISPATCH_DG(meta->n_dims_to_encode, G, {
+		auto launch = [&](auto kern) {
+			hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+			                   meta->interpolation_type, (const float *)x, (const float *)params, ba, vec_ok,
+			                   (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+		};
+		if (dy_dx) { if (dh) launch(k_fwd<D, G, true, true>); else launch(k_fwd<D, G, true, false>); }
+		else       { if (dh) launch(k_fwd<D, G, false, true>); else launch(k_fwd<D, G, false, false>); }
+	});
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t N, int x_dtype, int param_dtype,
+                                const void *dL_dy, int64_t g_sn, int64_t g_se, const void *dy_dx, int64_t d_sn,
+                                int64_t d_se, void *dL_dx, void *stream) {
+	NR3D_CHECK(meta != nullptr, "LoTD: meta is NULL");
+	NR3D_CHECK(x_dtype == NR3D_F32 && param_dtype == NR3D_F32, "LoTD::bwd_dx: f32 only");
+	if (N == 0) return 0;
+	NR3D_CHECK(dL_dy && dy_dx && dL_dx, "LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.");
+	DISPATCH_D(meta->n_dims_to_encode, {
+		hipLaunchKernelGGL(k_contract_dx<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N,
+		                   meta->n_encoded_dims, (const float *)dL_dy, g_sn, g_se, (const float *)dy_dx, d_sn, d_se,
+		                   (float *)dL_dx);
+	});
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N,
+                             const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
+                             const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
+                             uint32_t batch_data_size, int32_t max_level, void *dL_dparam, void *stream) {
+	if (N == 0 || max_level <= -1) return 0;
+	NR3D_CHECK(dL_dy && x && params && dL_dparam, "LoTD::bwd: NULL tensor pointer");
+	uint32_t n_blocks;
+	const Sched s = make_sched(N, meta->n_pseudo_levels, n_blocks);
+	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
+	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
+	const bool dh = meta->c_hash_only != 0;
+	DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
+		auto launch = [&](auto kern) {
+			hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
+			                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
+			                   (const float *)x, (const float *)params, ba, (float *)dL_dparam);
+		};
+		if (second) { if (dh) launch(k_bwd_dparam<D, G, true, true>); else launch(k_bwd_dparam<D, G, true, false>); }
+		else        { if (dh) launch(k_bwd_dparam<D, G, false, true>); else launch(k_bwd_dparam<D, G, false, false>); }
+	});
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                                    int param_dtype, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
+                                    const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
+                                    uint32_t batch_data_size, int32_t max_level, void *dL_dparam, void *stream) {
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	return launch_bwd_dparam(false, meta, meta_dev, N, nullptr, dL_dy, g_sn, g_se, x, params, batch_inds,
+	                         batch_offsets, batch_data_size, max_level, dL_dparam, stream);
+}
+
+extern "C" int nr3d_lotd_bwd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                                        int param_dtype, const void *dL_ddLdx, const void *dL_dy, int64_t g_sn,
+                                        int64_t g_se, const void *x, const void *params, const int64_t *batch_inds,
+                                        const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
+                                        void *dL_dparam, void *stream) {
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	NR3D_CHECK(N == 0 || dL_ddLdx != nullptr, "LoTD::bwd_bwd_input: dL_ddLdx is NULL");
+	return launch_bwd_dparam(true, meta, meta_dev, N, dL_ddLdx, dL_dy, g_sn, g_se, x, params, batch_inds,
+	                         batch_offsets, batch_data_size, max_level, dL_dparam, stream);
+}
+
+extern "C" int nr3d_lotd_bwd_bwd_ddLdy(const nr3d_lotd_meta_t *meta, uint32_t N, int x_dtype, int param_dtype,
+                                       const void *dL_ddLdx, const void *dy_dx, int64_t d_sn, int64_t d_se,
+                                       void *dL_ddLdy, int64_t o_sn, int64_t o_se, void *stream) {
+	NR3D_CHECK(meta != nullptr, "LoTD: meta is NULL");
+	NR3D_CHECK(x_dtype == NR3D_F32 && param_dtype == NR3D_F32, "LoTD::bwd_bwd_ddLdy: f32 only");
+	if (N == 0) return 0;
+	NR3D_CHECK(dL_ddLdx && dy_dx && dL_ddLdy, "LoTDEncoding::bwd_bwd_input: need `dy_dx` to compute `dL_d(dLdy)`.");
+	DISPATCH_D(meta->n_dims_to_encode, {
+		hipLaunchKernelGGL(k_contract_ddLdy<D>, dim3(div_up(N, kBlock), meta->n_encoded_dims), dim3(kBlock), 0,
+		                   (hipStream_t)stream, N, meta->n_encoded_dims, (const float *)dL_ddLdx,
+		                   (const float *)dy_dx, d_sn, d_se, (float *)dL_ddLdy, o_sn, o_se);
+	});
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_lotd_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                                    int param_dtype, const void *dL_ddLdx, const void *dL_dy, int64_t g_sn,
+                                    int64_t g_se, const void *x, const void *params, const int64_t *batch_inds,
+                                    const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
+                                    void *dL_dx, void *stream) {
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	if (N == 0) return 0;
+	NR3D_CHECK(dL_ddLdx && dL_dy && x && params && dL_dx, "LoTD::bwd_bwd_dx: NULL tensor pointer");
+	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
+	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
+	DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
+		hipLaunchKernelGGL((k_bwd_bwd_dx<D, G>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, md, N,
+		                   meta->n_pseudo_levels, max_level, meta->interpolation_type, (const float *)dL_ddLdx,
+		                   (const float *)dL_dy, g_sn, g_se, (const float *)x, (const float *)params, ba,
+		                   (float *)dL_dx);
+	});
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_lotd_grid_index(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                                    const void *x, const int64_t *batch_inds, const int64_t *batch_offsets,
+                                    uint32_t batch_data_size, int32_t max_level, int64_t *grid_inds, void *stream) {
+	if (int rc = check_common(meta, meta_dev, x_dtype, NR3D_F32)) return rc;
+	for (uint32_t l = 0; l < meta->n_levels; ++l)
+		NR3D_CHECK(meta->levels[l].type == NR3D_LOD_Dense || meta->levels[l].type == NR3D_LOD_Hash,
+		           "LoTDEncoding::get_grid_index: Only support Dense/Hash type.");
+	if (N == 0 || max_level <= -1) return 0;
+	NR3D_CHECK(x && grid_inds, "LoTD::get_grid_index: NULL tensor pointer");
+	uint32_t n_blocks;
+	const Sched s = make_sched(N, meta->n_pseudo_levels, n_blocks);
+	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
+	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
+	DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
+		hipLaunchKernelGGL((k_grid_index<D, G>), dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N,
+		                   meta->n_encoded_dims, max_level, (const float *)x, ba, grid_inds);
+	});
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}

@@ -1,0 +1,360 @@
+// nr3d_lib_amd/csrc/lotd_device.h -- device-side building blocks of the LoTD kernels (gfx950).
+//
+// Semantics follow the reference's device math (csrc/lotd/include/lotd/lotd_cuda.h index/value
+// functions :92-492, pos_fract :959-1077; corner loops csrc/lotd/include/lotd/lotd_encoding.h),
+// re-organised for CDNA4: one lane owns one (point, pseudo-level) pair, keeps all 2^D corner values
+// of a feature group in VGPRs (so y and dy/dx come from ONE set of gathers), and the per-level
+// descriptor is fetched with scalar loads from a device copy of the meta.
+//
+// The library is compiled with -ffp-contract=off; every fused multiply-add below is an explicit
+// fmaf().  The one that decides integer results is the cell locator (x*scale+0.5 -> floor), fused
+// exactly like the reference's nvcc build.
+#pragma once
+#include "common.h"
+
+namespace nr3d {
+namespace lotd {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+
+// ---------------------------------------------------------------------------------------------
+// Block -> (pseudo level, point chunk) schedule.
+//   mode 0  level-major       : q = b / n_chunks
+//   mode 1  XCD-affine        : workgroup b runs on XCD (b % 8) (observed dispatch order; only used
+//                               for cache affinity, never for correctness).  Each XCD walks the
+//                               levels {xcd, xcd+8, ...} one after another, so one 4 MiB hash table
+//                               at a time is live in that XCD's private 4 MiB L2.
+//   mode 2  chunk-major       : q = b % n_pseudo (all levels of a chunk back to back)
+// ---------------------------------------------------------------------------------------------
+struct Sched {
+	uint32_t n_chunks, n_pseudo, mode, n_slots;
+};
+
+__device__ __forceinline__ bool decode_block(const Sched &s, uint32_t b, uint32_t &q, uint32_t &chunk) {
+	if (s.mode == 1) {
+		const uint32_t xcd = b & 7u, j = b >> 3;
+		const uint32_t slot = j / s.n_chunks;
+		chunk = j - slot * s.n_chunks;
+		q = slot * 8u + xcd;
+		return q < s.n_pseudo;
+	} else if (s.mode == 2) {
+		chunk = b / s.n_pseudo;
+		q = b - chunk * s.n_pseudo;
+		return true;
+	}
+	q = b / s.n_chunks;
+	chunk = b - q * s.n_chunks;
+	return true;
+}
+
+struct Batch {
+	const int64_t *inds;
+	const int64_t *offsets;
+	uint32_t data_size;
+	uint32_t n_params;
+};
+
+// returns false when the point is skipped (batch index < 0); base = element offset of the batch entry
+__device__ __forceinline__ bool batch_base(const Batch &b, uint32_t i, uint32_t &base) {
+	uint32_t bi = 0;
+	if (b.inds) {
+		const int64_t v = b.inds[i];
+		if (v < 0) return false;
+		bi = (uint32_t)v;
+	} else if (b.data_size) {
+		bi = i / b.data_size;
+	}
+	base = b.offsets ? (uint32_t)b.offsets[bi] : bi * b.n_params;
+	return true;
+}
+
+struct Lvl {
+	uint32_t res[4];
+	uint32_t F, type, size, off;
+};
+
+__device__ __forceinline__ Lvl load_level(const nr3d_lotd_meta_t *__restrict__ md, uint32_t level) {
+	Lvl L;
+	const nr3d_lotd_level_t *l = &md->levels[level];
+#pragma unroll
+	for (int d = 0; d < 4; ++d) L.res[d] = l->res[d];
+	L.F = l->n_feats; L.type = l->type; L.size = l->size; L.off = l->offset;
+	return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cell locator: g = floor(x*(R-2)+0.5), t = frac, plus interpolation weight and its derivatives.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+struct Cell {
+	uint32_t g[D];
+	float w[D], dw[D], ddw[D], sc[D];
+};
+
+template <int D>
+__device__ __forceinline__ void locate(const float *__restrict__ xp, const Lvl &L, bool smooth, Cell<D> &c) {
+#pragma unroll
+	for (int d = 0; d < D; ++d) {
+		const float sc = (float)(L.res[d] - 2u);
+		const float v = __fmaf_rn(xp[d], sc, 0.5f);
+		const float fl = floorf(v);
+		const float t = v - fl;
+		c.sc[d] = sc;
+		c.g[d] = (uint32_t)fl;
+		if (!smooth) {
+			c.w[d] = t; c.dw[d] = 1.0f; c.ddw[d] = 0.0f;
+		} else {
+			c.w[d] = t * t * __fmaf_rn(-2.0f, t, 3.0f);
+			c.dw[d] = 6.0f * t * (1.0f - t);
+			c.ddw[d] = __fmaf_rn(-12.0f, t, 6.0f);
+		}
+	}
+}
+
+// weight of corner `c` (bit d set => upper cell along d), product taken in dim order from 1
+template <int D>
+__device__ __forceinline__ float corner_weight(const Cell<D> &c, uint32_t corner) {
+	float w = 1.0f;
+#pragma unroll
+	for (int d = 0; d < D; ++d) w *= ((corner >> d) & 1u) ? c.w[d] : (1.0f - c.w[d]);
+	return w;
+}
+
+// weight over all dims except `skip`, seeded with `seed`
+template <int D>
+__device__ __forceinline__ float face_weight(const Cell<D> &c, uint32_t corner, int skip, float seed) {
+	float w = seed;
+#pragma unroll
+	for (int d = 0; d < D; ++d)
+		if (d != skip) w *= ((corner >> d) & 1u) ? c.w[d] : (1.0f - c.w[d]);
+	return w;
+}
+
+template <int D>
+__device__ __forceinline__ void corner_pos(const Cell<D> &c, uint32_t corner, uint32_t (&p)[D]) {
+#pragma unroll
+	for (int d = 0; d < D; ++d) p[d] = c.g[d] + ((corner >> d) & 1u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Entry indices (in ENTRIES, i.e. before "* F + feature"); all uint32 wrap-around arithmetic.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ uint32_t entry_dense(const Lvl &L, const uint32_t (&p)[D]) {
+	uint32_t e = p[0];
+#pragma unroll
+	for (int d = 1; d < D; ++d) e = e * L.res[d] + p[d];   // last dim contiguous
+	return e;
+}
+
+template <int D>
+__device__ __forceinline__ uint32_t entry_hash(const Lvl &L, const uint32_t (&p)[D]) {
+	uint32_t h = 0;
+#pragma unroll
+	for (int d = 0; d < D; ++d) h ^= p[d] * kPrimes[d];
+	return ((L.size & (L.size - 1u)) == 0u) ? (h & (L.size - 1u)) : (h % L.size);
+}
+
+// CP / VM "line" tables: [ line_0 | line_1 | ... ]
+template <int D>
+__device__ __forceinline__ uint32_t entry_line(const Lvl &L, int dim, uint32_t pos) {
+	uint32_t acc = 0;
+#pragma unroll
+	for (int d = 0; d < D; ++d) if (d < dim) acc += L.res[d];
+	return acc + pos;
+}
+
+// plane spanned by all dims but `skip`, later dim contiguous; `stride_out` = number of entries
+template <int D>
+__device__ __forceinline__ uint32_t plane_local(const Lvl &L, int skip, const uint32_t (&p)[D], uint32_t &plane_size) {
+	uint32_t e = 0, sz = 1;
+	bool first = true;
+#pragma unroll
+	for (int d = 0; d < D; ++d) {
+		if (d == skip) continue;
+		e = first ? p[d] : e * L.res[d] + p[d];
+		sz *= L.res[d];
+		first = false;
+	}
+	plane_size = sz;
+	return e;
+}
+
+// VM (D == 3): entries of plane_d and line_d for corner p.  Layout: [x,y,z lines | yz, xz, xy planes]
+__device__ __forceinline__ void entry_vm(const Lvl &L, const uint32_t (&p)[3], uint32_t (&pl)[3], uint32_t (&ln)[3]) {
+	const uint32_t lines = L.res[0] + L.res[1] + L.res[2];
+	ln[0] = p[0]; ln[1] = L.res[0] + p[1]; ln[2] = L.res[0] + L.res[1] + p[2];
+	uint32_t acc = lines, sz;
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		pl[d] = acc + plane_local<3>(L, d, p, sz);
+		acc += sz;
+	}
+}
+
+// NPlaneMul plane for reference "jump_dim" j: spans all dims except (D-1-j), NO per-plane base offset
+// (reference quirk: the planes alias, lotd_cuda.h:176-206)
+template <int D>
+__device__ __forceinline__ uint32_t entry_nplane_mul(const Lvl &L, int j, const uint32_t (&p)[D]) {
+	uint32_t sz;
+	return plane_local<D>(L, D - 1 - j, p, sz);
+}
+
+// NPlaneSum sub-plane lookup, reference grid_index_nplane_sub (lotd_cuda.h:145-174), kept as-is
+// including its cubic-resolution assumption for the strides.
+template <int D>
+__device__ __forceinline__ uint32_t entry_nplane_sum(const Lvl &L, uint32_t jump, const uint32_t (&pp)[D]) {
+	constexpr int N1 = D - 1;
+	uint32_t stride = 1, e = 0;
+#pragma unroll
+	for (int d2 = 0; d2 < N1; ++d2) {
+		const int d3 = (uint32_t)d2 >= jump ? d2 + 1 : d2;
+		e += pp[N1 - 1 - d2] * stride;
+		stride *= L.res[N1 - d3];
+	}
+	return jump * stride + e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Value of NF consecutive features at one corner, for the N-linear level types.
+// ---------------------------------------------------------------------------------------------
+template <int D, int NF>
+__device__ __forceinline__ void corner_value(const Lvl &L, const float *__restrict__ grid, uint32_t foff,
+                                             const uint32_t (&p)[D], float (&v)[NF]) {
+	switch (L.type) {
+	case NR3D_LOD_Dense: {
+		const uint32_t i = entry_dense<D>(L, p) * L.F + foff;
+#pragma unroll
+		for (int f = 0; f < NF; ++f) v[f] = grid[i + f];
+	} break;
+	case NR3D_LOD_Hash: {
+		const uint32_t i = entry_hash<D>(L, p) * L.F + foff;
+#pragma unroll
+		for (int f = 0; f < NF; ++f) v[f] = grid[i + f];
+	} break;
+	case NR3D_LOD_VectorMatrix:
+		if constexpr (D == 3) {
+			uint32_t pl[3], ln[3];
+			entry_vm(L, p, pl, ln);
+#pragma unroll
+			for (int f = 0; f < NF; ++f) v[f] = 0.0f;
+#pragma unroll
+			for (int d = 0; d < 3; ++d)
+#pragma unroll
+				for (int f = 0; f < NF; ++f)
+					v[f] = __fmaf_rn(grid[pl[d] * L.F + foff + f], grid[ln[d] * L.F + foff + f], v[f]);
+		}
+		break;
+	case NR3D_LOD_VecZMatXoY:
+		if constexpr (D == 3) {
+			const uint32_t ln = p[2] * L.F + foff;
+			const uint32_t pl = (L.res[2] + p[1] + p[0] * L.res[0]) * L.F + foff;   // stride R_x, as the reference
+#pragma unroll
+			for (int f = 0; f < NF; ++f) v[f] = grid[pl + f] * grid[ln + f];
+		}
+		break;
+	case NR3D_LOD_CP: {
+#pragma unroll
+		for (int f = 0; f < NF; ++f) v[f] = grid[entry_line<D>(L, 0, p[0]) * L.F + foff + f];
+#pragma unroll
+		for (int d = 1; d < D; ++d)
+#pragma unroll
+			for (int f = 0; f < NF; ++f) v[f] *= grid[entry_line<D>(L, d, p[d]) * L.F + foff + f];
+	} break;
+	case NR3D_LOD_NPlaneMul: {
+#pragma unroll
+		for (int f = 0; f < NF; ++f) v[f] = grid[entry_nplane_mul<D>(L, 0, p) * L.F + foff + f];
+#pragma unroll
+		for (int j = 1; j < D; ++j)
+#pragma unroll
+			for (int f = 0; f < NF; ++f) v[f] *= grid[entry_nplane_mul<D>(L, j, p) * L.F + foff + f];
+	} break;
+	default:
+#pragma unroll
+		for (int f = 0; f < NF; ++f) v[f] = 0.0f;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scatter of (grad[f] * weight) at one corner into the parameter-gradient buffer, per level type.
+// Product types multiply by the other factors read from `grid` (lotd_cuda.h:494-829).
+// ---------------------------------------------------------------------------------------------
+template <int D, int NF>
+__device__ __forceinline__ void corner_scatter(const Lvl &L, const float *__restrict__ grid, float *__restrict__ gg,
+                                               uint32_t foff, const uint32_t (&p)[D], const float (&grad)[NF],
+                                               float weight) {
+	switch (L.type) {
+	case NR3D_LOD_Dense: {
+		const uint32_t i = entry_dense<D>(L, p) * L.F + foff;
+#pragma unroll
+		for (int f = 0; f < NF; ++f) atomic_add_f32(gg + i + f, grad[f] * weight);
+	} break;
+	case NR3D_LOD_Hash: {
+		const uint32_t i = entry_hash<D>(L, p) * L.F + foff;
+#pragma unroll
+		for (int f = 0; f < NF; ++f) atomic_add_f32(gg + i + f, grad[f] * weight);
+	} break;
+	case NR3D_LOD_VectorMatrix:
+		if constexpr (D == 3) {
+			uint32_t pl[3], ln[3];
+			entry_vm(L, p, pl, ln);
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const uint32_t ip = pl[d] * L.F + foff, il = ln[d] * L.F + foff;
+#pragma unroll
+				for (int f = 0; f < NF; ++f) {
+					const float wg = grad[f] * weight;
+					atomic_add_f32(gg + ip + f, wg * grid[il + f]);
+					atomic_add_f32(gg + il + f, wg * grid[ip + f]);
+				}
+			}
+		}
+		break;
+	case NR3D_LOD_VecZMatXoY:
+		if constexpr (D == 3) {
+			const uint32_t il = p[2] * L.F + foff;
+			const uint32_t ip = (L.res[2] + p[1] + p[0] * L.res[0]) * L.F + foff;
+#pragma unroll
+			for (int f = 0; f < NF; ++f) {
+				const float wg = grad[f] * weight;
+				atomic_add_f32(gg + ip + f, wg * grid[il + f]);
+				atomic_add_f32(gg + il + f, wg * grid[ip + f]);
+			}
+		}
+		break;
+	case NR3D_LOD_CP:
+	case NR3D_LOD_NPlaneMul: {
+		uint32_t idx[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d)
+			idx[d] = (L.type == NR3D_LOD_CP ? entry_line<D>(L, d, p[d]) : entry_nplane_mul<D>(L, d, p)) * L.F + foff;
+#pragma unroll
+		for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+			for (int f = 0; f < NF; ++f) {
+				float cur = grad[f] * weight;
+#pragma unroll
+				for (int k = 0; k < D; ++k) if (k != gd) cur *= grid[idx[k] + f];
+				atomic_add_f32(gg + idx[gd] + f, cur);
+			}
+	} break;
+	default: break;
+	}
+}
+
+// sum_f value(corner)[f] * grad[f] * weight, for the types that have a d(dL/dx)/dx path
+// (lotd_cuda.h:831-957)
+template <int D, int NF>
+__device__ __forceinline__ float corner_dot(const Lvl &L, const float *__restrict__ grid, uint32_t foff,
+                                            const uint32_t (&p)[D], const float (&grad)[NF], float weight) {
+	float v[NF];
+	corner_value<D, NF>(L, grid, foff, p, v);
+	float r = 0.0f;
+#pragma unroll
+	for (int f = 0; f < NF; ++f) r = __fmaf_rn(v[f] * grad[f], weight, r);
+	return r;
+}
+
+}  // namespace lotd
+}  // namespace nr3d

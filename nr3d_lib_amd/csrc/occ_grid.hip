@@ -1,0 +1,210 @@
+// nr3d_lib_amd/csrc/occ_grid.hip -- occupancy-grid ray marching (gfx950), C-ABI entry points
+// nr3d_ray_marching_count / nr3d_ray_marching_emit.
+//
+// Replaces nr3d_lib.bindings._occ_grid.{ray_marching, batched_ray_marching}:
+//   csrc/occ_grid/src/ray_marching.cu:17-244, csrc/occ_grid/src/batched_marching.cu:18-287,
+//   helpers csrc/occ_grid/include/occ_grid/helpers_march.h:11-77, helpers_contraction.h:10-125.
+//
+// The per-ray t-sequence is a serial fp32 recurrence whose rounding decides which voxel a sample lands
+// in, so each lane walks one ray with exactly the reference's operation order (origin + t*dir is an
+// explicit fmaf, matching nvcc's contraction; division and sqrt are IEEE-correct).  What changes vs. the
+// reference is everything around the loop: the per-ray counts are scanned ON THE DEVICE into
+// packed_info (no host cumsum/stack), the grand total is left in a device word for the caller's
+// single readback, and single/batched marching share one kernel.
+#include "common.h"
+#include "scan.h"
+
+namespace nr3d {
+namespace occ {
+
+constexpr int kBlock = 128;   // rays per workgroup: more workgroups in flight for small ray counts
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+__device__ __forceinline__ float calc_dt(float t, float g, float lo, float hi) { return clampf(t * g, lo, hi); }
+
+struct Grid {
+	f3 mn, mx;
+	int rx, ry, rz;
+	const uint8_t *cells;
+	int type;
+};
+
+__device__ __forceinline__ f3 to_unit(const Grid &g, f3 p) {
+	return {(p.x - g.mn.x) / (g.mx.x - g.mn.x), (p.y - g.mn.y) / (g.mx.y - g.mn.y), (p.z - g.mn.z) / (g.mx.z - g.mn.z)};
+}
+
+__device__ __forceinline__ f3 contract(const Grid &g, f3 p) {
+	f3 u = to_unit(g, p);
+	if (g.type == NR3D_CONTRACT_UN_BOUNDED_TANH) {
+		u = {tanhf(u.x - 0.5f) * 0.5f + 0.5f, tanhf(u.y - 0.5f) * 0.5f + 0.5f, tanhf(u.z - 0.5f) * 0.5f + 0.5f};
+	} else if (g.type == NR3D_CONTRACT_UN_BOUNDED_SPHERE) {
+		u = {u.x * 2.0f - 1.0f, u.y * 2.0f - 1.0f, u.z * 2.0f - 1.0f};
+		const float n2 = __fmaf_rn(u.z, u.z, __fmaf_rn(u.y, u.y, u.x * u.x));
+		const float n = sqrtf(n2);
+		if (n > 1.0f) {
+			const float s = 2.0f - 1.0f / n;
+			u = {s * (u.x / n), s * (u.y / n), s * (u.z / n)};
+		}
+		u = {u.x * 0.25f + 0.5f, u.y * 0.25f + 0.5f, u.z * 0.25f + 0.5f};
+	}
+	return u;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return max(lo, min(v, hi)); }
+
+// returns occupancy; *cell receives the flat voxel index (z contiguous)
+__device__ __forceinline__ bool probe(const Grid &g, f3 p, int *cell) {
+	if (g.type == NR3D_CONTRACT_AABB &&
+	    (p.x < g.mn.x || p.x > g.mx.x || p.y < g.mn.y || p.y > g.mx.y || p.z < g.mn.z || p.z > g.mx.z))
+		return false;
+	const f3 u = contract(g, p);
+	const int ix = clampi((int)(u.x * (float)g.rx), 0, g.rx - 1);
+	const int iy = clampi((int)(u.y * (float)g.ry), 0, g.ry - 1);
+	const int iz = clampi((int)(u.z * (float)g.rz), 0, g.rz - 1);
+	const int idx = ix * (g.ry * g.rz) + iy * g.rz + iz;
+	*cell = idx;
+	return g.cells[idx] != 0;
+}
+
+__device__ __forceinline__ float axis_exit(float q, float dirsign, float inv, float r, float extent) {
+	return ((floorf(q + 0.5f + 0.5f * dirsign) - q) * inv) / r * extent;
+}
+
+// DDA distance to the next voxel boundary, then advance in dt_min multiples (helpers_march.h:47-77)
+__device__ __forceinline__ float skip_voxel(const Grid &g, float t, float dt_min, f3 p, f3 dir, f3 inv) {
+	const f3 u = to_unit(g, p);
+	const float tx = axis_exit(u.x * (float)g.rx, copysignf(1.0f, dir.x), inv.x, (float)g.rx, g.mx.x - g.mn.x);
+	const float ty = axis_exit(u.y * (float)g.ry, copysignf(1.0f, dir.y), inv.y, (float)g.ry, g.mx.y - g.mn.y);
+	const float tz = axis_exit(u.z * (float)g.rz, copysignf(1.0f, dir.z), inv.z, (float)g.rz, g.mx.z - g.mn.z);
+	const float target = t + fmaxf(fminf(fminf(tx, ty), tz), 0.0f);
+	float tt = t;
+	do { tt += dt_min; } while (tt < target);
+	return tt;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(kBlock) void k_march(uint32_t n_rays, const float *__restrict__ rays_o,
+                                                  const float *__restrict__ rays_d, const float *__restrict__ t_min,
+                                                  const float *__restrict__ t_max, const float *__restrict__ roi,
+                                                  int rx, int ry, int rz, const uint8_t *__restrict__ cells, int type,
+                                                  float step_size, float max_step_size, float dt_gamma,
+                                                  uint32_t max_steps, int batched, const int32_t *__restrict__ batch_inds,
+                                                  uint32_t batch_data_size, const int32_t *__restrict__ packed_info,
+                                                  int32_t *__restrict__ counts, float *__restrict__ t_starts,
+                                                  float *__restrict__ t_ends, int32_t *__restrict__ ridx,
+                                                  int32_t *__restrict__ bidx, int32_t *__restrict__ gidx) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n_rays) return;
+	uint32_t b = 0;
+	if (batched) {
+		if (batch_inds) {
+			const int32_t v = batch_inds[i];
+			if (v < 0) { if (!EMIT) counts[i] = 0; return; }   // reference leaves the count uninitialised here
+			b = (uint32_t)v;
+		} else if (batch_data_size) {
+			b = i / batch_data_size;
+		}
+	}
+	const uint32_t vol = (uint32_t)(rx * ry * rz);
+	Grid g;
+	const float *r6 = roi + 6 * (size_t)b;
+	g.mn = {r6[0], r6[1], r6[2]};
+	g.mx = {r6[3], r6[4], r6[5]};
+	g.rx = rx; g.ry = ry; g.rz = rz;
+	g.cells = cells + (size_t)b * vol;
+	g.type = type;
+	const int32_t grid_offset = batched ? (int32_t)(b * vol) : 0;
+
+	uint32_t base = 0;
+	if (EMIT) {
+		base = (uint32_t)packed_info[2 * (size_t)i];
+		max_steps = (uint32_t)packed_info[2 * (size_t)i + 1];
+	}
+	const f3 o = {rays_o[3 * (size_t)i], rays_o[3 * (size_t)i + 1], rays_o[3 * (size_t)i + 2]};
+	const f3 dir = {rays_d[3 * (size_t)i], rays_d[3 * (size_t)i + 1], rays_d[3 * (size_t)i + 2]};
+	const f3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+	const float far = t_max[i];
+	const float dt_min = step_size, dt_max = max_step_size;
+
+	uint32_t j = 0;
+	float t0 = t_min[i];
+	float dt = calc_dt(t0, dt_gamma, dt_min, dt_max);
+	float t1 = t0 + dt;
+	float tm = (t0 + t1) * 0.5f;
+	while (tm < far && j < max_steps) {
+		const f3 p = {__fmaf_rn(tm, dir.x, o.x), __fmaf_rn(tm, dir.y, o.y), __fmaf_rn(tm, dir.z, o.z)};
+		int cell = -1;
+		if (probe(g, p, &cell)) {
+			if (EMIT) {
+				t_starts[base + j] = t0;
+				t_ends[base + j] = t1;
+				ridx[base + j] = (int32_t)i;
+				if (bidx) bidx[base + j] = (int32_t)b;
+				if (gidx) gidx[base + j] = cell + grid_offset;
+			}
+			++j;
+			t0 = t1;
+			t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
+			tm = (t0 + t1) * 0.5f;
+		} else if (type == NR3D_CONTRACT_AABB) {
+			tm = skip_voxel(g, tm, dt_min, p, dir, inv);
+			dt = calc_dt(tm, dt_gamma, dt_min, dt_max);
+			t0 = tm - dt * 0.5f;
+			t1 = tm + dt * 0.5f;
+		} else {
+			t0 = t1;
+			t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
+			tm = (t0 + t1) * 0.5f;
+		}
+	}
+	if (!EMIT) counts[i] = (int32_t)j;
+}
+
+}  // namespace occ
+}  // namespace nr3d
+
+using namespace nr3d;
+
+// scratch layout: [ int32 counts[n] (padded to 8 B) | tile sums ]
+extern "C" uint64_t nr3d_scan_tmp_bytes(uint64_t n) { return ((n * sizeof(int64_t) + 7) / 8) * 8 + scan::tmp_bytes(n); }
+
+extern "C" int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                                       const float *t_max, const float *roi, const int32_t grid_res[3],
+                                       const uint8_t *grid_binary, int type, float step_size, float max_step_size,
+                                       float dt_gamma, uint32_t max_steps, int batched, const int32_t *batch_inds,
+                                       uint32_t batch_data_size, int32_t *packed_info, int64_t *total_steps,
+                                       void *scan_tmp, void *stream) {
+	NR3D_CHECK(total_steps && scan_tmp, "ray_marching: NULL scratch pointer");
+	hipStream_t st = (hipStream_t)stream;
+	if (n_rays == 0) { NR3D_HIP_CHECK(hipMemsetAsync(total_steps, 0, sizeof(int64_t), st)); return 0; }
+	NR3D_CHECK(rays_o && rays_d && t_min && t_max && roi && grid_binary && packed_info, "ray_marching: NULL tensor pointer");
+	NR3D_CHECK(type >= 0 && type <= 2, "ray_marching: invalid contraction type %d", type);
+	int32_t *counts = (int32_t *)scan_tmp;
+	void *tiles = (char *)scan_tmp + (((uint64_t)n_rays * sizeof(int64_t) + 7) / 8) * 8;
+	hipLaunchKernelGGL(occ::k_march<false>, dim3(div_up(n_rays, occ::kBlock)), dim3(occ::kBlock), 0, st, n_rays, rays_o,
+	                   rays_d, t_min, t_max, roi, grid_res[0], grid_res[1], grid_res[2], grid_binary, type, step_size,
+	                   max_step_size, dt_gamma, max_steps, batched, batch_inds, batch_data_size,
+	                   (const int32_t *)nullptr, counts, (float *)nullptr, (float *)nullptr, (int32_t *)nullptr,
+	                   (int32_t *)nullptr, (int32_t *)nullptr);
+	NR3D_LAUNCH_CHECK();
+	return scan::pack_infos_from_counts<int32_t, int32_t>(n_rays, counts, packed_info, total_steps, tiles, st);
+}
+
+extern "C" int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                                      const float *t_max, const float *roi, const int32_t grid_res[3],
+                                      const uint8_t *grid_binary, int type, float step_size, float max_step_size,
+                                      float dt_gamma, int batched, const int32_t *batch_inds, uint32_t batch_data_size,
+                                      const int32_t *packed_info, float *t_starts, float *t_ends, int32_t *ridx,
+                                      int32_t *bidx, int32_t *gidx, void *stream) {
+	if (n_rays == 0) return 0;
+	NR3D_CHECK(rays_o && rays_d && t_min && t_max && roi && grid_binary && packed_info, "ray_marching: NULL tensor pointer");
+	NR3D_CHECK(t_starts && t_ends && ridx, "ray_marching: NULL output pointer");
+	hipLaunchKernelGGL(occ::k_march<true>, dim3(div_up(n_rays, occ::kBlock)), dim3(occ::kBlock), 0, (hipStream_t)stream,
+	                   n_rays, rays_o, rays_d, t_min, t_max, roi, grid_res[0], grid_res[1], grid_res[2], grid_binary,
+	                   type, step_size, max_step_size, dt_gamma, 0u, batched, batch_inds, batch_data_size, packed_info,
+	                   (int32_t *)nullptr, t_starts, t_ends, ridx, bidx, gidx);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}

@@ -1,0 +1,696 @@
+// nr3d_lib_amd/csrc/pack_ops.hip -- segmented ("packed") tensor ops for volume rendering (gfx950).
+//
+// Replaces nr3d_lib.bindings._pack_ops (csrc/pack_ops/pack_ops_cuda.cu, bindings pack_ops.cpp:21-58).
+// pack_infos: int64 [P,2] = (begin, length).
+//
+// The reference runs ONE THREAD PER PACK with a sequential loop through global memory, and a host
+// cumsum + .item() per op.  Here the unit of work is ONE WAVE (64 lanes) PER PACK:
+//   * elementwise / reduction / scan ops: lanes stride over the pack (coalesced), wave64 shuffles for
+//     the reduction / Kogge-Stone scan with a carried prefix between 64-element chunks;
+//   * serial recurrences whose ROUNDING decides integer outputs (transmittance T -> compaction
+//     selector; step samplers t += dt) keep the reference's exact operation order: a chunk of 64
+//     values is loaded coalesced, then a wave-uniform loop walks them through lane broadcasts
+//     (v_readlane), every lane tracking the same scalar state and lane j keeping the result of step j.
+//     Loads/stores stay coalesced and the sequence is bit-identical to the one-thread version.
+#include "common.h"
+#include "scan.h"
+
+namespace nr3d {
+namespace pk {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+struct Pack { uint32_t p, begin, len; int lane; bool valid; };
+
+__device__ __forceinline__ Pack my_pack(uint32_t P, const int64_t *__restrict__ pi) {
+	Pack k;
+	k.lane = threadIdx.x & 63;
+	k.p = blockIdx.x * kWaves + (threadIdx.x >> 6);
+	k.valid = k.p < P;
+	k.begin = k.valid ? (uint32_t)pi[2 * (size_t)k.p] : 0u;
+	k.len = k.valid ? (uint32_t)pi[2 * (size_t)k.p + 1] : 0u;
+	return k;
+}
+static inline dim3 grid_for(uint32_t P) { return dim3(div_up(P, kWaves)); }
+
+template <typename T> __device__ __forceinline__ T shfl_up_t(T v, int off) { return __shfl_up(v, off, 64); }
+template <typename T> __device__ __forceinline__ T shfl_t(T v, int src) { return __shfl(v, src, 64); }
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int m) { return __shfl_xor(v, m, 64); }
+
+// L2-served load (agent scope: bypasses this CU's vector L1, which may hold a line another lane's atomic
+// or store has since changed)
+__device__ __forceinline__ int64_t ld_l2(const int64_t *p) {
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T> __device__ __forceinline__ T muladd(T a, T b, T c) { return a * b + c; }
+template <> __device__ __forceinline__ float muladd<float>(float a, float b, float c) { return __fmaf_rn(a, b, c); }
+template <> __device__ __forceinline__ double muladd<double>(double a, double b, double c) { return fma(a, b, c); }
+
+// ------------------------------------------------------------------------------------------------
+// interleave_arange / interleave_linstep
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_linstep(uint32_t P, const int64_t *__restrict__ pi,
+                                                    const T *__restrict__ starts, const T *__restrict__ steps, T start,
+                                                    T step, T *__restrict__ out, int64_t *__restrict__ nidx) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	const T s0 = starts ? starts[k.p] : start;
+	const T st = steps ? steps[k.p] : step;
+	for (uint32_t j = k.lane; j < k.len; j += 64) {
+		out[k.begin + j] = muladd<T>((T)j, st, s0);
+		if (nidx) nidx[k.begin + j] = (int64_t)k.p;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// depth-proportional step samplers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clamp_lu(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }
+
+__global__ __launch_bounds__(kBlock) void k_sample_count(uint32_t P, const float *__restrict__ nears,
+                                                         const float *__restrict__ fars, uint32_t max_steps, float g,
+                                                         float lo, float hi, int64_t *__restrict__ n_per_pack) {
+	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	if (p >= P) return;
+	float t = nears[p];
+	const float far = fars[p];
+	uint32_t n = 0;
+	while (t <= far && n < max_steps) { t += clamp_lu(t * g, lo, hi); ++n; }
+	n_per_pack[p] = (int64_t)n;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sample_emit(uint32_t P, const float *__restrict__ nears,
+                                                        const int64_t *__restrict__ pi, float g, float lo, float hi,
+                                                        float *__restrict__ ts, float *__restrict__ dts,
+                                                        int64_t *__restrict__ nidx) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	float t = nears[k.p];                       // wave-uniform state
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		float my_t = 0.f, my_dt = 0.f;
+		for (uint32_t j = 0; j < n; ++j) {      // serial recurrence, identical on every lane
+			const float dt = clamp_lu(t * g, lo, hi);
+			if ((uint32_t)k.lane == j) { my_t = t; my_dt = dt; }
+			t += dt;
+		}
+		if ((uint32_t)k.lane < n) {
+			ts[k.begin + base + k.lane] = my_t;
+			dts[k.begin + base + k.lane] = my_dt;
+			nidx[k.begin + base + k.lane] = (int64_t)k.p;
+		}
+	}
+}
+
+// segments variant: data-dependent segment walk, one lane per pack
+template <bool EMIT>
+__global__ __launch_bounds__(kBlock) void k_sample_segments(uint32_t P, const float *__restrict__ nears,
+                                                            const float *__restrict__ fars,
+                                                            const float *__restrict__ entries,
+                                                            const float *__restrict__ exits,
+                                                            const int64_t *__restrict__ spi, uint32_t max_steps, float g,
+                                                            float lo, float hi, int64_t *__restrict__ n_per_pack,
+                                                            const int64_t *__restrict__ pi, float *__restrict__ ts,
+                                                            float *__restrict__ dts, int64_t *__restrict__ nidx,
+                                                            int64_t *__restrict__ sidx) {
+	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	if (p >= P) return;
+	const float near = nears[p], far = fars[p];
+	const uint32_t sb = (uint32_t)spi[2 * (size_t)p], se = sb + (uint32_t)spi[2 * (size_t)p + 1];
+	const uint32_t b = EMIT ? (uint32_t)pi[2 * (size_t)p] : 0u;
+	const uint32_t lim = EMIT ? (uint32_t)pi[2 * (size_t)p + 1] : max_steps;
+	float t = near;
+	uint32_t step = 0;
+	for (uint32_t i = sb; i < se; ++i) {
+		const float ce = entries[i], cx = exits[i];
+		if (ce >= far || cx <= near) break;
+		do { t += lo; } while (t < ce);
+		while (t <= cx && t <= far && step < lim) {
+			const float dt = clamp_lu(t * g, lo, hi);
+			if (EMIT) { ts[b + step] = t; nidx[b + step] = (int64_t)p; sidx[b + step] = (int64_t)i; dts[b + step] = dt; }
+			t += dt;
+			++step;
+		}
+	}
+	if (!EMIT) n_per_pack[p] = (int64_t)step;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed_sum
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sum(uint32_t P, uint32_t fd, const T *__restrict__ in,
+                                                const int64_t *__restrict__ pi, T *__restrict__ out) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	for (uint32_t j = 0; j < fd; ++j) {
+		T acc = (T)0;
+		for (uint32_t i = k.lane; i < k.len; i += 64) acc += in[(size_t)(k.begin + i) * fd + j];
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1) acc += shfl_xor_t<T>(acc, m);
+		if (k.lane == 0) out[(size_t)k.p * fd + j] = acc;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed_cumsum / packed_cumprod.  mode: 0 sum, 1 prod (reference semantics: exclusive prod == 0),
+// 2 prod with the documented exclusive semantics (identity 1 first)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scan(uint32_t P, uint32_t fd, const T *__restrict__ in,
+                                                 const int64_t *__restrict__ pi, int mode, int exclusive, int reverse,
+                                                 T *__restrict__ out) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid || k.len == 0) return;
+	const bool prod = mode != 0;
+	const T ident = prod ? (T)1 : (T)0;
+	for (uint32_t j = 0; j < fd; ++j) {
+		if (mode == 1 && exclusive) {            // reference quirk: first element stays 0 and poisons the pack
+			for (uint32_t i = k.lane; i < k.len; i += 64) out[(size_t)(k.begin + i) * fd + j] = (T)0;
+			continue;
+		}
+		T carry = ident;
+		for (uint32_t base = 0; base < k.len; base += 64) {
+			const uint32_t pos = base + k.lane;                      // position in scan order
+			const bool ok = pos < k.len;
+			const uint32_t idx = reverse ? (k.len - 1 - pos) : pos;   // position in memory
+			const T v = ok ? in[(size_t)(k.begin + idx) * fd + j] : ident;
+			T inc = v;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const T t = shfl_up_t<T>(inc, off);
+				if (k.lane >= off) inc = prod ? inc * t : inc + t;
+			}
+			const T incl = prod ? carry * inc : carry + inc;
+			T r;
+			if (!exclusive) r = incl;
+			else {
+				const T prev = shfl_up_t<T>(incl, 1);
+				r = (k.lane == 0) ? carry : prev;
+			}
+			if (ok) out[(size_t)(k.begin + idx) * fd + j] = r;
+			carry = shfl_t<T>(incl, 63);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed_diff / packed_backward_diff
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_diff(uint32_t P, uint32_t fd, const T *__restrict__ in,
+                                                 const int64_t *__restrict__ pi, const T *__restrict__ edge_a,
+                                                 const T *__restrict__ edge_fill, int backward, T *__restrict__ out) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid || k.len == 0) return;
+	const uint32_t total = k.len * fd;
+	for (uint32_t e = k.lane; e < total; e += 64) {
+		const uint32_t i = e / fd, j = e - i * fd;
+		const size_t at = (size_t)(k.begin + i) * fd + j;
+		T r;
+		if (!backward) {
+			if (i + 1 < k.len) r = in[at + fd] - in[at];
+			else r = edge_a ? (T)(edge_a[(size_t)k.p * fd + j] - in[at]) : (edge_fill ? edge_fill[(size_t)k.p * fd + j] : (T)0);
+		} else {
+			if (i > 0) r = in[at] - in[at - fd];
+			else r = edge_a ? (T)(in[at] - edge_a[(size_t)k.p * fd + j]) : (edge_fill ? edge_fill[(size_t)k.p * fd + j] : (T)0);
+		}
+		out[at] = r;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-pack broadcast binary ops / comparisons / matmul
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_binary(uint32_t P, uint32_t fd, const T *__restrict__ in,
+                                                   const T *__restrict__ other, const int64_t *__restrict__ pi, int op,
+                                                   T *__restrict__ out, uint8_t *__restrict__ out_b) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	const uint32_t total = k.len * fd;
+	for (uint32_t e = k.lane; e < total; e += 64) {
+		const uint32_t j = e % fd;
+		const size_t at = (size_t)k.begin * fd + e;
+		const T a = in[at], o = other[(size_t)k.p * fd + j];
+		switch (op) {
+		case 0: out[at] = a + o; break;
+		case 1: out[at] = a - o; break;
+		case 2: out[at] = a * o; break;
+		case 3: out[at] = a / o; break;
+		case 5: out_b[at] = a > o; break;
+		case 6: out_b[at] = a >= o; break;
+		case 7: out_b[at] = a < o; break;
+		case 8: out_b[at] = a <= o; break;
+		case 9: out_b[at] = a == o; break;
+		default: out_b[at] = a != o; break;
+		}
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_matmul(uint32_t P, uint32_t fd, uint32_t od, const T *__restrict__ in,
+                                                   const T *__restrict__ other, const int64_t *__restrict__ pi,
+                                                   T *__restrict__ out) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	const T *o = other + (size_t)k.p * od * fd;
+	const uint32_t total = k.len * od;
+	for (uint32_t e = k.lane; e < total; e += 64) {
+		const uint32_t i = e / od, j = e - i * od;
+		T r = (T)0;
+		for (uint32_t c = 0; c < fd; ++c) r = muladd<T>(in[(size_t)(k.begin + i) * fd + c], o[(size_t)j * fd + c], r);
+		out[(size_t)(k.begin + i) * od + j] = r;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// lower-bound searches
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ uint32_t lower_bound(T val, const T *__restrict__ data, uint32_t length) {
+	uint32_t first = 0, count = length;
+	while (count > 0) {
+		const uint32_t step = count >> 1, it = first + step;
+		if (data[it] < val) { first = it + 1; count -= step + 1; } else count = step;
+	}
+	return first;
+}
+template <typename T>
+__device__ __forceinline__ uint32_t lower_bound_clamped(T val, const T *__restrict__ data, uint32_t length) {
+	if (length == 0) return 0;
+	return min(lower_bound<T>(val, data, length), length - 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_searchsorted(uint32_t P, const T *__restrict__ bins,
+                                                         const T *__restrict__ vals, const int64_t *__restrict__ pi,
+                                                         uint32_t n_search, const int64_t *__restrict__ vpi,
+                                                         int64_t *__restrict__ pidx) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	uint32_t ob = k.p * n_search, n = n_search;
+	if (vpi) { ob = (uint32_t)vpi[2 * (size_t)k.p]; n = (uint32_t)vpi[2 * (size_t)k.p + 1]; }
+	for (uint32_t i = k.lane; i < n; i += 64)
+		pidx[ob + i] = (int64_t)(k.begin + lower_bound_clamped<T>(vals[ob + i], bins + k.begin, k.len));
+}
+
+__global__ __launch_bounds__(kBlock) void k_invert_cdf(uint32_t P, const float *__restrict__ bins,
+                                                       const float *__restrict__ cdfs, const int64_t *__restrict__ pi,
+                                                       const float *__restrict__ u_vals, uint32_t n_sample,
+                                                       float *__restrict__ samples, int64_t *__restrict__ bin_idx) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	const float *bn = bins + k.begin, *cd = cdfs + k.begin;
+	const uint32_t ob = k.p * n_sample;
+	for (uint32_t i = k.lane; i < n_sample; i += 64) {
+		const float u = u_vals[ob + i];
+		const uint32_t pos = lower_bound_clamped<float>(u, cd, k.len);
+		bin_idx[ob + i] = (int64_t)(pos + k.begin);
+		float s;
+		if (pos == 0) s = bn[0];
+		else {
+			const float c0 = cd[pos - 1], pmf = cd[pos] - c0;
+			s = pmf < 1.0e-5f ? bn[pos - 1] : __fmaf_rn((u - c0) / pmf, bn[pos] - bn[pos - 1], bn[pos - 1]);
+		}
+		samples[ob + i] = s;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// try_merge_two_packs_sorted_aligned: positions of a's and b's elements in the merged pack.
+//   lb_j      = lower_bound of b_j in a
+//   pidx_a[i] = out_begin + i + #{j : lb_j <= i}
+//   pidx_b[j] = (lb_j == 0 ? out_begin : pidx_a[lb_j - 1] + 1) + (rank of j inside its run of equal
+//               consecutive lb values)          -- reference semantics, pack_ops_cuda.cu:1538-1570
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_merge(uint32_t P, const T *__restrict__ va_, const int64_t *__restrict__ pia,
+                                                  const T *__restrict__ vb_, const int64_t *__restrict__ pib,
+                                                  const int64_t *__restrict__ pim, int64_t *__restrict__ pa_,
+                                                  int64_t *__restrict__ pb_) {
+	const Pack k = my_pack(P, pia);
+	if (!k.valid) return;
+	const uint32_t bb = (uint32_t)pib[2 * (size_t)k.p], bl = (uint32_t)pib[2 * (size_t)k.p + 1];
+	const int64_t ob = pim[2 * (size_t)k.p];
+	const T *va = va_ + k.begin, *vb = vb_ + bb;
+	int64_t *pa = pa_ + k.begin, *pb = pb_ + bb;
+	// 1. lower bounds + histogram (pa is zero-initialised by the caller)
+	for (uint32_t j = k.lane; j < bl; j += 64) {
+		const uint32_t i = lower_bound<T>(vb[j], va, k.len);
+		pb[j] = (int64_t)i;
+		if (i < k.len) atomicAdd((unsigned long long *)&pa[i], 1ull);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // atomics of this wave have reached L2
+	// 2. inclusive scan of (count + 1) over a, offset so that pa[0] = ob + count_0
+	int64_t carry = ob - 1;
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const uint32_t i = base + k.lane;
+		int64_t inc = (i < k.len) ? ld_l2(&pa[i]) + 1 : 0;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const int64_t t = shfl_up_t<int64_t>(inc, off);
+			if (k.lane >= off) inc += t;
+		}
+		if (i < k.len) pa[i] = carry + inc;
+		carry += shfl_t<int64_t>(inc, 63);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // pa stores of this wave have reached L2
+	// 3. b positions: run-rank via a max-scan of run starts
+	int64_t run_carry = 0;      // start index of the run that is open at the chunk boundary
+	int64_t prev_last = -1;     // lb of the last element of the previous chunk
+	for (uint32_t base = 0; base < bl; base += 64) {
+		const uint32_t j = base + k.lane;
+		const bool ok = j < bl;
+		const int64_t i = ok ? pb[j] : -2;
+		int64_t left = shfl_up_t<int64_t>(i, 1);
+		if (k.lane == 0) left = prev_last;
+		const bool starts = ok && (i != left);
+		int64_t st = starts ? (int64_t)j : -1;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const int64_t t = shfl_up_t<int64_t>(st, off);
+			if (k.lane >= off) st = max(st, t);
+		}
+		if (st < 0) st = run_carry;
+		if (ok) {
+			const int64_t rank = (int64_t)j - st;
+			pb[j] = rank + ((i == 0) ? ob : ld_l2(&pa[i - 1]) + 1);
+		}
+		const uint32_t last = min(63u, bl - base - 1);
+		run_carry = shfl_t<int64_t>(st, (int)last);
+		prev_last = shfl_t<int64_t>(i, (int)last);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed sort: ascending, in place, optional id permutation.  One lane per pack, heapsort (no
+// auxiliary stack buffer).  Order of equal keys is unspecified (the reference's quicksort is
+// unstable as well).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void sift_down(T *v, int64_t *ids, int64_t start, int64_t end) {
+	int64_t root = start;
+	while (2 * root + 1 <= end) {
+		int64_t child = 2 * root + 1, sw = root;
+		if (v[sw] < v[child]) sw = child;
+		if (child + 1 <= end && v[sw] < v[child + 1]) sw = child + 1;
+		if (sw == root) return;
+		{ const T t = v[root]; v[root] = v[sw]; v[sw] = t; }
+		if (ids) { const int64_t t = ids[root]; ids[root] = ids[sw]; ids[sw] = t; }
+		root = sw;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sort(uint32_t P, T *__restrict__ vals, int64_t *__restrict__ ids,
+                                                 const int64_t *__restrict__ pi) {
+	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	if (p >= P) return;
+	const int64_t b = pi[2 * (size_t)p], n = pi[2 * (size_t)p + 1];
+	if (n < 2) return;
+	T *v = vals + b;
+	int64_t *id = ids ? ids + b : nullptr;
+	for (int64_t s = (n - 2) / 2; s >= 0; --s) sift_down<T>(v, id, s, n - 1);
+	for (int64_t e = n - 1; e > 0; --e) {
+		{ const T t = v[e]; v[e] = v[0]; v[0] = t; }
+		if (id) { const int64_t t = id[e]; id[e] = id[0]; id[0] = t; }
+		sift_down<T>(v, id, 0, e - 1);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// alpha -> volume-rendering weights (and the compaction selector / counts)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_alpha_fwd(uint32_t P, const float *__restrict__ alphas,
+                                                      const int64_t *__restrict__ pi, float eps, float thre,
+                                                      float *__restrict__ weights, int64_t *__restrict__ num_steps,
+                                                      uint8_t *__restrict__ selector) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	float T = 1.0f;            // wave-uniform
+	int cnt = 0;
+	bool stopped = false;
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		const float a_mine = ((uint32_t)k.lane < n) ? alphas[k.begin + base + k.lane] : 0.0f;
+		float w_mine = 0.0f;
+		bool sel_mine = false;
+		if (!stopped) {
+			for (uint32_t j = 0; j < n; ++j) {
+				if (T < eps) { stopped = true; break; }
+				const float a = shfl_t<float>(a_mine, (int)j);
+				if (a <= thre) continue;
+				if ((uint32_t)k.lane == j) { w_mine = a * T; sel_mine = true; }
+				T *= (1.0f - a);
+				++cnt;
+			}
+		}
+		if ((uint32_t)k.lane < n) {
+			if (weights) weights[k.begin + base + k.lane] = w_mine;
+			if (selector) selector[k.begin + base + k.lane] = sel_mine ? 1 : 0;
+		}
+	}
+	if (num_steps && k.lane == 0) num_steps[k.p] = (int64_t)cnt;
+}
+
+__global__ __launch_bounds__(kBlock) void k_alpha_bwd(uint32_t P, const float *__restrict__ alphas,
+                                                      const float *__restrict__ weights,
+                                                      const float *__restrict__ grad_weights,
+                                                      const int64_t *__restrict__ pi, float eps, float thre,
+                                                      float *__restrict__ grad_alphas) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	// accum = sum_j gw_j * w_j  (wave reduction; order differs from the reference's serial sum)
+	float accum = 0.0f;
+	for (uint32_t i = k.lane; i < k.len; i += 64) accum = __fmaf_rn(grad_weights[k.begin + i], weights[k.begin + i], accum);
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) accum += shfl_xor_t<float>(accum, m);
+	float T = 1.0f;
+	bool stopped = false;
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		const bool mine = (uint32_t)k.lane < n;
+		const float a_mine = mine ? alphas[k.begin + base + k.lane] : 0.0f;
+		const float gw_mine = mine ? grad_weights[k.begin + base + k.lane] : 0.0f;
+		const float w_mine = mine ? weights[k.begin + base + k.lane] : 0.0f;
+		float ga_mine = 0.0f;
+		if (!stopped) {
+			for (uint32_t j = 0; j < n; ++j) {
+				if (T < eps) { stopped = true; break; }
+				const float a = shfl_t<float>(a_mine, (int)j);
+				if (a < thre) continue;
+				if ((uint32_t)k.lane == j) ga_mine = __fmaf_rn(gw_mine, T, -accum) / fmaxf(1.0f - a, 1e-10f);
+				accum = __fmaf_rn(-shfl_t<float>(gw_mine, (int)j), shfl_t<float>(w_mine, (int)j), accum);
+				T *= (1.0f - a);
+			}
+		}
+		if (mine) grad_alphas[k.begin + base + k.lane] = ga_mine;
+	}
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_boundaries(uint64_t n, const T *__restrict__ ids, int32_t *__restrict__ b) {
+	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	b[i] = (i == 0) ? 1 : (ids[i - 1] == ids[i] ? 0 : 1);
+}
+
+}  // namespace pk
+}  // namespace nr3d
+
+using namespace nr3d;
+
+#define PK_DISPATCH(dtype, ...)                                                          \
+	do {                                                                                 \
+		switch (dtype) {                                                                 \
+		case NR3D_F32: { using T = float; __VA_ARGS__; } break;                          \
+		case NR3D_F64: { using T = double; __VA_ARGS__; } break;                         \
+		case NR3D_I32: { using T = int32_t; __VA_ARGS__; } break;                        \
+		case NR3D_I64: { using T = int64_t; __VA_ARGS__; } break;                        \
+		default: return ::nr3d::fail("pack_ops: unsupported dtype code %d (f32/f64/i32/i64)", (int)(dtype)); \
+		}                                                                                \
+	} while (0)
+
+extern "C" int nr3d_pack_infos_from_n(uint32_t P, const int64_t *n_per_pack, int64_t *pack_infos, int64_t *total,
+                                      void *scan_tmp, void *stream) {
+	NR3D_CHECK(total && scan_tmp, "pack_infos_from_n: NULL scratch pointer");
+	return scan::pack_infos_from_counts<int64_t, int64_t>(P, n_per_pack, pack_infos, total, scan_tmp, (hipStream_t)stream);
+}
+
+extern "C" int nr3d_interleave_linstep(uint32_t P, int dtype, const int64_t *pack_infos, const void *starts,
+                                       const void *step_sizes, double start_s, double step_s, void *out, int64_t *nidx,
+                                       void *stream) {
+	if (P == 0) return 0;
+	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_linstep<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
+	                                      pack_infos, (const T *)starts, (const T *)step_sizes, (T)start_s, (T)step_s,
+	                                      (T *)out, nidx));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_sample_step_count(uint32_t P, const float *nears, const float *fars, uint32_t max_steps,
+                                      float dt_gamma, float min_step, float max_step, int64_t *n_per_pack, void *stream) {
+	if (P == 0) return 0;
+	hipLaunchKernelGGL(pk::k_sample_count, dim3(div_up(P, pk::kBlock)), dim3(pk::kBlock), 0, (hipStream_t)stream, P, nears,
+	                   fars, max_steps, dt_gamma, min_step, max_step, n_per_pack);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_sample_step_emit(uint32_t P, const float *nears, const int64_t *pack_infos, float dt_gamma,
+                                     float min_step, float max_step, float *t_samples, float *deltas, int64_t *nidx,
+                                     void *stream) {
+	if (P == 0) return 0;
+	hipLaunchKernelGGL(pk::k_sample_emit, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, nears, pack_infos,
+	                   dt_gamma, min_step, max_step, t_samples, deltas, nidx);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_sample_step_segments(uint32_t P, const float *nears, const float *fars, const float *entries,
+                                         const float *exits, const int64_t *seg_pack_infos, uint32_t max_steps,
+                                         float dt_gamma, float min_step, float max_step, int emit, int64_t *n_per_pack,
+                                         const int64_t *pack_infos, float *t_samples, float *deltas, int64_t *nidx,
+                                         int64_t *sidx, void *stream) {
+	if (P == 0) return 0;
+	const dim3 g(div_up(P, pk::kBlock)), b(pk::kBlock);
+	if (emit)
+		hipLaunchKernelGGL(pk::k_sample_segments<true>, g, b, 0, (hipStream_t)stream, P, nears, fars, entries, exits,
+		                   seg_pack_infos, max_steps, dt_gamma, min_step, max_step, n_per_pack, pack_infos, t_samples,
+		                   deltas, nidx, sidx);
+	else
+		hipLaunchKernelGGL(pk::k_sample_segments<false>, g, b, 0, (hipStream_t)stream, P, nears, fars, entries, exits,
+		                   seg_pack_infos, max_steps, dt_gamma, min_step, max_step, n_per_pack, pack_infos, t_samples,
+		                   deltas, nidx, sidx);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_packed_sum(uint32_t P, uint64_t S, uint32_t fd, int dtype, const void *feats,
+                               const int64_t *pack_infos, void *out, void *stream) {
+	if (P == 0) return 0;
+	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_sum<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, fd,
+	                                      (const T *)feats, pack_infos, (T *)out));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_packed_scan(uint32_t P, uint64_t S, uint32_t fd, int dtype, const void *feats,
+                                const int64_t *pack_infos, int is_prod, int exclusive, int reverse, void *out,
+                                void *stream) {
+	if (P == 0) return 0;
+	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_scan<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, fd,
+	                                      (const T *)feats, pack_infos, is_prod, exclusive, reverse, (T *)out));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_packed_diff(uint32_t P, uint64_t S, uint32_t fd, int dtype, const void *feats,
+                                const int64_t *pack_infos, const void *edge_a, const void *edge_fill, int backward,
+                                void *out, void *stream) {
+	NR3D_CHECK(!(edge_a && edge_fill), "You should only specify AT MOST one of [appends, prepends, last_fill, first_fill]");
+	if (P == 0) return 0;
+	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_diff<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, fd,
+	                                      (const T *)feats, pack_infos, (const T *)edge_a, (const T *)edge_fill, backward,
+	                                      (T *)out));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_packed_binary(uint32_t P, uint64_t S, uint32_t fd, uint32_t od, int dtype, const void *feats,
+                                  const void *other, const int64_t *pack_infos, int op, void *out, void *stream) {
+	NR3D_CHECK(op >= 0 && op <= 10, "packed_binary_ops: invalid op %d", op);
+	if (P == 0) return 0;
+	if (op == 4) {
+		PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_matmul<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
+		                                      fd, od, (const T *)feats, (const T *)other, pack_infos, (T *)out));
+	} else {
+		PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_binary<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
+		                                      fd, (const T *)feats, (const T *)other, pack_infos, op, (T *)out,
+		                                      (uint8_t *)out));
+	}
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_packed_searchsorted(uint32_t P, int dtype, const void *bins, const void *vals,
+                                        const int64_t *pack_infos, uint32_t num_to_search,
+                                        const int64_t *val_pack_infos, int64_t *pidx, void *stream) {
+	if (P == 0) return 0;
+	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_searchsorted<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream,
+	                                      P, (const T *)bins, (const T *)vals, pack_infos, num_to_search, val_pack_infos,
+	                                      pidx));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_try_merge_two_packs_sorted_aligned(uint32_t P, int dtype, const void *vals_a,
+                                                       const int64_t *pack_infos_a, const void *vals_b,
+                                                       const int64_t *pack_infos_b, const int64_t *pack_infos_merged,
+                                                       int b_sorted, int64_t *pidx_a, int64_t *pidx_b, void *stream) {
+	(void)b_sorted;   // the sorted-b shortcut of the reference only narrows the search range; same result
+	if (P == 0) return 0;
+	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_merge<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
+	                                      (const T *)vals_a, pack_infos_a, (const T *)vals_b, pack_infos_b,
+	                                      pack_infos_merged, pidx_a, pidx_b));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_packed_invert_cdf(uint32_t P, const float *bins, const float *cdfs, const int64_t *pack_infos,
+                                      const float *u_vals, uint32_t num_to_sample, float *samples, int64_t *bin_idx,
+                                      void *stream) {
+	if (P == 0) return 0;
+	hipLaunchKernelGGL(pk::k_invert_cdf, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, bins, cdfs,
+	                   pack_infos, u_vals, num_to_sample, samples, bin_idx);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_packed_sort(uint32_t P, uint64_t S, int dtype, void *vals, int64_t *ids, const int64_t *pack_infos,
+                                void *stream) {
+	if (P == 0) return 0;
+	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_sort<T>, dim3(div_up(P, pk::kBlock)), dim3(pk::kBlock), 0,
+	                                      (hipStream_t)stream, P, (T *)vals, ids, pack_infos));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_alpha_to_vw_forward(uint32_t P, uint64_t S, const float *alphas, const int64_t *pack_infos,
+                                        float early_stop_eps, float alpha_thre, float *weights, int64_t *num_steps,
+                                        uint8_t *selector, void *stream) {
+	if (P == 0) return 0;
+	hipLaunchKernelGGL(pk::k_alpha_fwd, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas, pack_infos,
+	                   early_stop_eps, alpha_thre, weights, num_steps, selector);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_alpha_to_vw_backward(uint32_t P, uint64_t S, const float *alphas, const float *weights,
+                                         const float *grad_weights, const int64_t *pack_infos, float early_stop_eps,
+                                         float alpha_thre, float *grad_alphas, void *stream) {
+	if (P == 0) return 0;
+	hipLaunchKernelGGL(pk::k_alpha_bwd, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas, weights,
+	                   grad_weights, pack_infos, early_stop_eps, alpha_thre, grad_alphas);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_mark_pack_boundaries(uint64_t num, int dtype, const void *pack_ids, int32_t *boundaries, void *stream) {
+	if (num == 0) return 0;
+	const dim3 g(div_up(num, pk::kBlock)), b(pk::kBlock);
+	switch (dtype) {
+	case NR3D_I64: hipLaunchKernelGGL(pk::k_boundaries<int64_t>, g, b, 0, (hipStream_t)stream, num, (const int64_t *)pack_ids, boundaries); break;
+	case NR3D_I32: hipLaunchKernelGGL(pk::k_boundaries<int32_t>, g, b, 0, (hipStream_t)stream, num, (const int32_t *)pack_ids, boundaries); break;
+	case NR3D_I16: hipLaunchKernelGGL(pk::k_boundaries<int16_t>, g, b, 0, (hipStream_t)stream, num, (const int16_t *)pack_ids, boundaries); break;
+	case NR3D_I8:  hipLaunchKernelGGL(pk::k_boundaries<int8_t>, g, b, 0, (hipStream_t)stream, num, (const int8_t *)pack_ids, boundaries); break;
+	case NR3D_U8:  hipLaunchKernelGGL(pk::k_boundaries<uint8_t>, g, b, 0, (hipStream_t)stream, num, (const uint8_t *)pack_ids, boundaries); break;
+	default: return ::nr3d::fail("mark_pack_boundaries: integral dtype required (got code %d)", dtype);
+	}
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
