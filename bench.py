@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the nr3d hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (N = 1): BASELINE.json configs[1] -- 16-level Hash LoTD (gen_ngp_cfg defaults: T = 2^19, F = 2,
+6 Dense + 10 Hash levels, 12 131 648 fp32 params), 2^20 uniformly random points, one "step" =
+forward (y and dy/dx) + dL/dx + dL/dparam, all inputs resident in HBM.  N > 1: the same per-GPU batch on every
+rank (weak scaling; points are independent so there is no data-path collective) plus ONE RCCL all-reduce of
+dL/dparam per step.  Metric: whole-job Mpoints/s.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the timed region) and,
+at N = 1, `cpu_baseline` (the CPU oracle -- a port, not the reference -- on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_POINTS_LOG2 = 20
+
+
+def algorithmic_bytes_per_point(L, F, D=3, C=8):
+    """element-granular bytes (no cache credit, no sector over-fetch), SURVEY.md section 8(d), per kernel:
+    fwd      : x 4D + corner gathers L*C*F*4 + y L*F*4 + stored Jacobian L*F*D*4
+    bwd_dx   : dL_dy L*F*4 + Jacobian L*F*D*4 + dL_dx 4D
+    bwd_dparam: x 4D + dL_dy L*F*4 + scatter as read-modify-write 2*L*C*F*4"""
+    E = L * F
+    return dict(fwd=4 * D + L * C * F * 4 + E * 4 + E * D * 4,
+                bwd_dx=E * 4 + E * D * 4 + 4 * D,
+                bwd_dparam=4 * D + E * 4 + 2 * L * C * F * 4)
+
+
+def cpu_baseline(cfg, n_sample_log2=17, min_seconds=10.0):
+    """the CPU oracle (oracle/, a C restatement with OpenMP -- kind 'port') on a bounded sample of the workload"""
+    import oracle
+    m = oracle.lotd_create_meta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
+    rng = np.random.default_rng(42)
+    n = 1 << n_sample_log2
+    x = rng.random((n, 3)).astype(np.float32).clip(1e-6, 1 - 1e-6)
+    p = rng.uniform(-1e-4, 1e-4, m.n_params).astype(np.float32)
+    g = (rng.standard_normal((n, m.n_encoded_dims)) / 1e4).astype(np.float32)
+    oracle.lotd_fwd(m, x[:1024], p, need_dydx=True)     # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        y, j = oracle.lotd_fwd(m, x, p, need_dydx=True)
+        oracle.lotd_bwd_dx(m, g, j)
+        oracle.lotd_bwd_dparam(m, g, x, p)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds or reps >= 64:
+            break
+    return dict(value=round(reps * n / el / 1e6, 4), unit="Mpoints/s", cores=os.cpu_count(), kind="port",
+                sample=f"{reps} x 2^{n_sample_log2} points, same 16-level meta, fwd+dydx + dL/dx + dL/dparam "
+                       f"({el:.1f} s of OpenMP CPU work)")
+
+
+def march_composite_rate(dev, iters=20):
+    """BASELINE configs[2] as an extra figure: occ 128^3 march + alpha composite fwd+bwd, 4096 rays"""
+    from nr3d_lib_amd.bindings import _occ_grid, _pack_ops
+    g = torch.Generator(device="cpu").manual_seed(7)
+    grid = (torch.rand(128, 128, 128, generator=g) > 0.5).to(dev)
+    n = 4096
+    u = torch.linspace(-0.4, 0.4, 64)
+    uu, vv = torch.meshgrid(u, u, indexing="ij")
+    d = torch.stack([uu.flatten(), vv.flatten(), torch.ones(n)], 1)
+    d = (d / d.norm(dim=1, keepdim=True)).to(dev)
+    o = torch.tensor([0.0, 0.0, -4.0]).repeat(n, 1).to(dev)
+    t1, t2 = (-1 - o) / d, (1 - o) / d
+    near = torch.minimum(t1, t2).amax(1).clamp_min(0).contiguous()
+    far = torch.maximum(t1, t2).amin(1).contiguous()
+    far = torch.where(far > near, far, near).contiguous()
+    roi = torch.tensor([-1., -1, -1, 1, 1, 1], device=dev)
+    step = 2 * 3 ** 0.5 / 512
+
+    def one():
+        pi, ts, te, ridx, gidx = _occ_grid.ray_marching(o, d, near, far, roi, grid, _occ_grid.ContractionType.AABB,
+                                                        step, 1e10, 0.0, 512, True)
+        pil = pi.long()
+        delta = (te - ts).squeeze(-1)
+        alpha = (1 - torch.exp(-10.0 * delta)).contiguous()
+        w = _pack_ops.packed_alpha_to_vw_forward(alpha, pil, 1e-4, 0.0, False)[0]
+        acc = _pack_ops.packed_sum(w, pil)
+        depth = _pack_ops.packed_sum((w * ts.squeeze(-1)).contiguous(), pil)
+        ga = _pack_ops.packed_alpha_to_vw_backward(w, torch.ones_like(w), alpha, pil, 1e-4, 0.0)
+        return ts.shape[0], acc, depth, ga
+    S = one()[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return dict(workload="occ 128^3 march + alpha composite fwd+bwd, 4096 rays", samples=int(S),
+                ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--log2-points", type=int, default=N_POINTS_LOG2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nr3d_lib_amd.bindings import _lotd
+    from nr3d_lib_amd.models.grid_encodings.lotd import gen_ngp_cfg
+    cfg = gen_ngp_cfg()
+    meta = _lotd.LoDMeta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
+    N = 1 << args.log2_points
+    gen = torch.Generator(device="cpu").manual_seed(42)
+    params = torch.empty(meta.n_params).uniform_(-1e-4, 1e-4, generator=gen).to(dev)
+    gen_r = torch.Generator(device="cpu").manual_seed(100 + rank)
+    x = torch.rand(N, 3, generator=gen_r).clamp_(1e-6, 1 - 1e-6).to(dev)
+    dL_dy = (torch.randn(N, meta.n_encoded_dims, generator=gen_r) / 1e4).to(dev)
+
+    names = ("fwd", "bwd_dx", "bwd_dparam")
+    ev = {k: [] for k in names}
+
+    def step(record):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
+        if record: e[0].record()
+        y, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
+        if record: e[1].record()
+        dx, _ = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=False)
+        if record: e[2].record()
+        _, dp = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=False, need_param_grad=True)
+        if record: e[3].record()
+        if dist is not None:
+            dist.all_reduce(dp)
+        if record:
+            for k, a, b in zip(names, e[:3], e[1:]):
+                ev[k].append((a, b))
+        return y, dx, dp
+
+    for _ in range(args.warmup):
+        step(False)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+        bpp = algorithmic_bytes_per_point(meta.n_levels, 2)
+        dom = max(kms, key=kms.get)
+        achieved = bpp[dom] * N / (kms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "Mpoints/s LoTD fwd+bwd (16-lvl hash) + Mrays/s march+composite, 1 & 8 GPU",
+            "value": round(world * N * args.steps / elapsed / 1e6, 3),
+            "unit": "Mpoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 16-level Hash LoTD (gen_ngp_cfg: T=2^19, F=2, 6 Dense + 10 Hash), "
+                                   f"2^{args.log2_points} points/GPU, fwd(+dy/dx) + dL/dx + dL/dparam, fp32",
+                       "points_per_gpu": N, "n_params": meta.n_params,
+                       "parallelism": f"dp{world} (points sharded; RCCL all-reduce of dL/dparam)" if world > 1 else "single GPU"},
+            "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_point": bpp[dom],
+                         "whole_step_frac": round(sum(bpp.values()) * N / (sum(kms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        }
+        if world == 1:
+            try:
+                out["extra"] = {"march_composite": march_composite_rate(dev)}
+            except Exception as ex:   # the extra figure must never cost the headline line
+                out["extra"] = {"march_composite_error": repr(ex)}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""nr3d_lib_amd.bindings._occ_grid -- drop-in for the reference pybind module
+``nr3d_lib.bindings._occ_grid`` (csrc/occ_grid/src/occ_grid.cpp:22-33, signatures
+csrc/occ_grid/include/occ_grid/cpp_api.h:14-66), backed by libnr3d_hip.so.
+
+ray_marching / batched_ray_marching keep the reference's positional signatures and return lists.
+The per-ray counts are scanned on the device; the only host sync is the read-back of the total
+sample count (needed to size the outputs -- the reference syncs at the same point).
+"""
+import ctypes as C
+import enum
+
+import torch
+
+from .. import _hip as H
+
+
+class ContractionType(enum.IntEnum):
+    AABB = 0
+    UN_BOUNDED_TANH = 1
+    UN_BOUNDED_SPHERE = 2
+
+
+AABB = ContractionType.AABB
+UN_BOUNDED_TANH = ContractionType.UN_BOUNDED_TANH
+UN_BOUNDED_SPHERE = ContractionType.UN_BOUNDED_SPHERE
+
+
+def _chk(name, t, dim=None, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dim is not None and t.dim() != dim:
+        raise RuntimeError(f"{name}: expected a {dim}-D tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+
+
+def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_binary, contraction_type,
+           step_size, max_step_size, dt_gamma, max_steps, return_gidx, batched):
+    _chk("rays_o", rays_o, 2, torch.float32)
+    _chk("rays_d", rays_d, 2, torch.float32)
+    _chk("t_min", t_min, 1, torch.float32)
+    _chk("t_max", t_max, 1, torch.float32)
+    _chk("roi", roi, 2 if batched else 1, torch.float32)
+    _chk("grid_binary", grid_binary, 4 if batched else 3)
+    if grid_binary.dtype not in (torch.bool, torch.uint8):
+        raise RuntimeError("grid_binary: expected a bool tensor")
+    if rays_o.shape[1] != 3 or rays_d.shape[1] != 3 or rays_d.shape[0] != rays_o.shape[0]:
+        raise RuntimeError("rays_o / rays_d: expected shape [n_rays, 3]")
+    n = rays_o.shape[0]
+    if t_min.shape[0] != n or t_max.shape[0] != n:
+        raise RuntimeError("t_min / t_max: expected shape [n_rays]")
+    if batched:
+        if roi.shape[1] != 6 or roi.shape[0] != grid_binary.shape[0]:
+            raise RuntimeError("roi: expected shape [B, 6] matching grid_binary's batch dim")
+        if batch_inds is not None:
+            _chk("batch_inds", batch_inds, 1, torch.int32)
+            if batch_inds.shape[0] != n:
+                raise RuntimeError("batch_inds: expected shape [n_rays]")
+        bds = int(batch_data_size or 0)
+        if not (bds == 0 or n % bds == 0):
+            raise RuntimeError(f"batched_ray_marching: Expect nonzero `batch_data_size`={bds} to be a divisor of "
+                               f"`n_rays`={n}")
+    else:
+        if roi.shape[0] != 6:
+            raise RuntimeError("roi: expected shape [6]")
+        bds = 0
+    dev = rays_o.device
+    res = (C.c_int32 * 3)(*[int(s) for s in grid_binary.shape[-3:]])
+    ctype = C.c_int(int(contraction_type))
+    with torch.cuda.device(dev):
+        st = H.stream_of(rays_o)
+        packed_info = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int64, device=dev)
+        nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(n, 1))))
+        tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        H.check(H.lib().nr3d_ray_marching_count(
+            H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
+            ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), H.u32(max_steps), C.c_int(int(batched)),
+            H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(total), H.ptr(tmp), st))
+        S = int(total.item())          # the single device->host sync of this op
+        t_starts = torch.empty((S, 1), dtype=torch.float32, device=dev)
+        t_ends = torch.empty((S, 1), dtype=torch.float32, device=dev)
+        ridx = torch.empty(S, dtype=torch.int32, device=dev)
+        bidx = torch.empty(S, dtype=torch.int32, device=dev) if batched else None
+        gidx = torch.empty(S, dtype=torch.int32, device=dev) if return_gidx else None
+        H.check(H.lib().nr3d_ray_marching_emit(
+            H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
+            ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), C.c_int(int(batched)), H.ptr(batch_inds),
+            H.u32(bds), H.ptr(packed_info), H.ptr(t_starts), H.ptr(t_ends), H.ptr(ridx), H.ptr(bidx), H.ptr(gidx), st))
+    if batched:
+        return [packed_info, t_starts, t_ends, ridx, bidx, gidx]
+    return [packed_info, t_starts, t_ends, ridx, gidx]
+
+
+def ray_marching(rays_o, rays_d, t_min, t_max, roi, grid_binary, contraction_type, step_size, max_step_size,
+                 dt_gamma, max_steps, return_gidx):
+    """-> [packed_info i32 [n,2], t_starts f32 [S,1], t_ends f32 [S,1], ridx i32 [S], gidx i32 [S] | None]
+    (ray_marching.cu:136-244)"""
+    return _march(rays_o, rays_d, t_min, t_max, None, None, roi, grid_binary, contraction_type, step_size,
+                  max_step_size, dt_gamma, max_steps, return_gidx, False)
+
+
+def batched_ray_marching(rays_o, rays_d, t_min, t_max, batch_inds_, batch_data_size_, roi, grid_binary,
+                         contraction_type, step_size, max_step_size, dt_gamma, max_steps, return_gidx):
+    """-> [packed_info, t_starts, t_ends, ridx, bidx, gidx | None]  (batched_marching.cu:153-287)"""
+    return _march(rays_o, rays_d, t_min, t_max, batch_inds_, batch_data_size_, roi, grid_binary, contraction_type,
+                  step_size, max_step_size, dt_gamma, max_steps, return_gidx, True)
+
+
+def forest_ray_marching(*args, **kwargs):
+    raise NotImplementedError("nr3d_lib_amd: forest_ray_marching needs the kaolin-based ForestMeta "
+                              "(out of the hot-path scope, SURVEY.md §8f-4)")

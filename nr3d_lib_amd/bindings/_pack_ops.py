@@ -1,0 +1,442 @@
+"""nr3d_lib_amd.bindings._pack_ops -- drop-in for the reference pybind module
+``nr3d_lib.bindings._pack_ops`` (csrc/pack_ops/pack_ops.cpp:21-58, signatures pack_ops.h:11-65),
+backed by libnr3d_hip.so.
+
+Same function names, positional arguments and return structure.  What differs by design:
+  * the reference validates ``feats.size(0) == pack_infos[-1].sum()`` with a device->host ``.item()``
+    in EVERY op (25 sync sites, e.g. pack_ops_cuda.cu:839); here that check is off by default and
+    enabled with ``nr3d_lib_amd.bindings._pack_ops.CHECK_PACK_SIZES = True`` (debug aid);
+  * two-phase producers keep their prefix sums on the device and read back ONE scalar (the total);
+  * ``packed_sort_thrust`` is an alias of the in-tree sort (no thrust on this platform).
+"""
+import ctypes as C
+
+import torch
+
+from .. import _hip as H
+
+CHECK_PACK_SIZES = False
+# packed_cumprod(exclusive=True): the reference kernel leaves the first element of each pack at 0, which
+# zeroes the whole pack (pack_ops_cuda.cu:884-894 vs the docstring at pack_ops.py:149).  False replicates
+# the reference; True gives the documented semantics (identity 1 first).
+CUMPROD_EXCLUSIVE_DOCUMENTED = False
+
+_SUPPORTED = (torch.float32, torch.float64, torch.int32, torch.int64)
+
+
+def _chk_pi(fn, pack_infos, ref=None):
+    if pack_infos.dim() != 2 or pack_infos.shape[-1] != 2:
+        raise RuntimeError(f"{fn}: Expected pack_infos of shape [num_packs, 2]")
+    if pack_infos.dtype != torch.int64:
+        raise RuntimeError(f"{fn}: Expected pack_infos to have scalar type Long")
+    if not pack_infos.is_contiguous():
+        raise RuntimeError(f"{fn}: Expected contiguous tensor for argument pack_infos")
+    H.require_gpu(pack_infos, ref)
+    if ref is not None and ref.device != pack_infos.device:
+        raise RuntimeError(f"{fn}: Expected all tensors on the same GPU")
+
+
+def _chk_feats(fn, feats, pack_infos, dims=(1, 2)):
+    if feats.dim() not in dims:
+        raise RuntimeError(f"{fn}: Expected {' or '.join(str(d) for d in dims)}-dimensional tensor for argument feats")
+    if not feats.is_contiguous():
+        raise RuntimeError(f"{fn}: Expected contiguous tensor for argument feats")
+    if feats.dtype not in _SUPPORTED:
+        raise RuntimeError(f"{fn}: dtype {feats.dtype} not supported (float32/float64/int32/int64)")
+    _chk_pi(fn, pack_infos, feats)
+    if CHECK_PACK_SIZES and pack_infos.shape[0] > 0:
+        want = int(pack_infos[-1, 0].item()) + int(pack_infos[-1, 1].item())
+        if feats.shape[0] != want:
+            raise RuntimeError(f"{fn}: Expected feats to have size {want} at dimension 0, but got size {feats.shape[0]}")
+
+
+def _fd(feats):
+    return 1 if feats.dim() == 1 else int(feats.shape[1])
+
+
+def _code(t):
+    return C.c_int(H.DTYPE_CODE[t.dtype])
+
+
+def _scan_tmp(n, device):
+    nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(int(n), 1))))
+    return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
+
+
+def _pack_infos_from_n(n_per_pack):
+    """device-side exclusive scan -> (pack_infos int64 [P,2], total python int): ONE readback."""
+    P = n_per_pack.shape[0]
+    dev = n_per_pack.device
+    pi = torch.empty((P, 2), dtype=torch.int64, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    tmp = _scan_tmp(P, dev)
+    H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(n_per_pack), H.ptr(pi), H.ptr(total), H.ptr(tmp),
+                                           H.stream_of(n_per_pack)))
+    return pi, int(total.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# interleave producers (pack_ops_cuda.cu:47-218)
+# ------------------------------------------------------------------------------------------------
+def interleave_arange(stop, return_idx):
+    if stop.dim() != 1 or stop.dtype != torch.int64 or not stop.is_contiguous():
+        raise RuntimeError("interleave_arange: Expected contiguous 1-D Long tensor for argument stop")
+    H.require_gpu(stop)
+    with torch.cuda.device(stop.device):
+        pi, num = _pack_infos_from_n(stop)
+        out = torch.empty(num, dtype=torch.int64, device=stop.device)
+        nidx = torch.empty(num, dtype=torch.int64, device=stop.device) if return_idx else None
+        H.check(H.lib().nr3d_interleave_linstep(H.u32(stop.shape[0]), C.c_int(H.I64), H.ptr(pi), None, None,
+                                                C.c_double(0), C.c_double(1), H.ptr(out), H.ptr(nidx),
+                                                H.stream_of(stop)))
+    return out, nidx
+
+
+def interleave_linstep(start, num_steps, step_size, return_idx):
+    if start.dim() != 1 or num_steps.dim() != 1 or start.shape != num_steps.shape:
+        raise RuntimeError("interleave_linstep: Expected 1-D start / num_steps of the same size")
+    if num_steps.dtype != torch.int64:
+        raise RuntimeError("interleave_linstep: Expected num_steps to have scalar type Long")
+    H.require_gpu(start, num_steps)
+    if start.dtype not in _SUPPORTED:
+        raise RuntimeError(f"interleave_linstep: dtype {start.dtype} not supported")
+    start, num_steps = start.contiguous(), num_steps.contiguous()
+    steps_t = None
+    step_s = 0.0
+    if isinstance(step_size, torch.Tensor):
+        if step_size.dim() != 1 or step_size.dtype != start.dtype:
+            raise RuntimeError("interleave_linstep: Expected 1-D step_size with the dtype of start")
+        steps_t = step_size.contiguous()
+    else:
+        step_s = float(step_size)
+    with torch.cuda.device(start.device):
+        pi, num = _pack_infos_from_n(num_steps)
+        out = torch.empty(num, dtype=start.dtype, device=start.device)
+        nidx = torch.empty(num, dtype=torch.int64, device=start.device) if return_idx else None
+        H.check(H.lib().nr3d_interleave_linstep(H.u32(start.shape[0]), _code(start), H.ptr(pi), H.ptr(start),
+                                                H.ptr(steps_t), C.c_double(0), C.c_double(step_s), H.ptr(out),
+                                                H.ptr(nidx), H.stream_of(start)))
+    return out, nidx
+
+
+def _chk_near_far(fn, near, far):
+    if near.dim() != 1 or far.dim() != 1 or near.shape != far.shape:
+        raise RuntimeError(f"{fn}: Expected 1-D near / far of the same size")
+    if near.dtype != torch.float32 or far.dtype != torch.float32:
+        raise RuntimeError(f"{fn}: float32 only on this platform")
+    if not (near.is_contiguous() and far.is_contiguous()):
+        raise RuntimeError(f"{fn}: Expected contiguous near / far")
+    H.require_gpu(near, far)
+
+
+def interleave_sample_step_wrt_depth_clamped(near, far, max_steps, dt_gamma, min_step_size, max_step_size):
+    """-> (t_samples, deltas, nidx int64, pack_infos int64 [P,2])  (pack_ops_cuda.cu:480-604)"""
+    _chk_near_far("interleave_sample_step_wrt_depth_clamped", near, far)
+    P, dev = near.shape[0], near.device
+    with torch.cuda.device(dev):
+        n = torch.empty(P, dtype=torch.int64, device=dev)
+        st = H.stream_of(near)
+        H.check(H.lib().nr3d_sample_step_count(H.u32(P), H.ptr(near), H.ptr(far), H.u32(max_steps), H.f32(dt_gamma),
+                                               H.f32(min_step_size), H.f32(max_step_size), H.ptr(n), st))
+        pi, num = _pack_infos_from_n(n)
+        t = torch.empty(num, dtype=near.dtype, device=dev)
+        dt = torch.empty(num, dtype=near.dtype, device=dev)
+        nidx = torch.empty(num, dtype=torch.int64, device=dev)
+        H.check(H.lib().nr3d_sample_step_emit(H.u32(P), H.ptr(near), H.ptr(pi), H.f32(dt_gamma), H.f32(min_step_size),
+                                              H.f32(max_step_size), H.ptr(t), H.ptr(dt), H.ptr(nidx), st))
+    return t, dt, nidx, pi
+
+
+# the deprecated v1 sampler produces the same samples (pack_ops_cuda.cu:226-366)
+interleave_sample_step_wrt_depth_clamp_deprecated = interleave_sample_step_wrt_depth_clamped
+
+
+def interleave_sample_step_wrt_depth_in_packed_segments(near, far, entry, exit, seg_pack_infos, max_steps, dt_gamma,
+                                                        min_step_size, max_step_size):
+    """-> (t_samples, deltas, sidx, nidx, pack_infos)  (pack_ops_cuda.cu:606-795)"""
+    fn = "interleave_sample_step_wrt_depth_in_packed_segments"
+    _chk_near_far(fn, near, far)
+    _chk_pi(fn, seg_pack_infos, near)
+    if entry.dim() != 1 or exit.dim() != 1 or entry.shape != exit.shape or entry.dtype != near.dtype \
+            or exit.dtype != near.dtype or not entry.is_contiguous() or not exit.is_contiguous():
+        raise RuntimeError(f"{fn}: Expected contiguous 1-D entry / exit of the same size and dtype as near")
+    if seg_pack_infos.shape[0] != near.shape[0]:
+        raise RuntimeError(f"{fn}: Expected seg_pack_infos of size [{near.shape[0]}, 2]")
+    P, dev = near.shape[0], near.device
+    with torch.cuda.device(dev):
+        n = torch.empty(P, dtype=torch.int64, device=dev)
+        st = H.stream_of(near)
+        common = (H.u32(P), H.ptr(near), H.ptr(far), H.ptr(entry), H.ptr(exit), H.ptr(seg_pack_infos),
+                  H.u32(max_steps), H.f32(dt_gamma), H.f32(min_step_size), H.f32(max_step_size))
+        H.check(H.lib().nr3d_sample_step_segments(*common, C.c_int(0), H.ptr(n), None, None, None, None, None, st))
+        pi, num = _pack_infos_from_n(n)
+        t = torch.empty(num, dtype=near.dtype, device=dev)
+        dt = torch.empty(num, dtype=near.dtype, device=dev)
+        nidx = torch.empty(num, dtype=torch.int64, device=dev)
+        sidx = torch.empty(num, dtype=torch.int64, device=dev)
+        H.check(H.lib().nr3d_sample_step_segments(*common, C.c_int(1), None, H.ptr(pi), H.ptr(t), H.ptr(dt),
+                                                  H.ptr(nidx), H.ptr(sidx), st))
+    return t, dt, sidx, nidx, pi
+
+
+# ------------------------------------------------------------------------------------------------
+# reductions / scans / differences
+# ------------------------------------------------------------------------------------------------
+def packed_sum(feats, pack_infos):
+    _chk_feats("packed_sum", feats, pack_infos)
+    P = pack_infos.shape[0]
+    with torch.cuda.device(feats.device):
+        out = torch.zeros((P,) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
+        H.check(H.lib().nr3d_packed_sum(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)), _code(feats),
+                                        H.ptr(feats), H.ptr(pack_infos), H.ptr(out), H.stream_of(feats)))
+    return out
+
+
+def _scan(fn, feats, pack_infos, mode, exclusive, reverse):
+    _chk_feats(fn, feats, pack_infos)
+    with torch.cuda.device(feats.device):
+        out = torch.zeros_like(feats)
+        H.check(H.lib().nr3d_packed_scan(H.u32(pack_infos.shape[0]), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)),
+                                         _code(feats), H.ptr(feats), H.ptr(pack_infos), C.c_int(mode),
+                                         C.c_int(int(bool(exclusive))), C.c_int(int(bool(reverse))), H.ptr(out),
+                                         H.stream_of(feats)))
+    return out
+
+
+def packed_cumsum(feats, pack_infos, exclusive, reverse):
+    return _scan("packed_cumsum", feats, pack_infos, 0, exclusive, reverse)
+
+
+def packed_cumprod(feats, pack_infos, exclusive, reverse):
+    return _scan("packed_cumprod", feats, pack_infos, 2 if CUMPROD_EXCLUSIVE_DOCUMENTED else 1, exclusive, reverse)
+
+
+def _edge(fn, name, e, feats, P):
+    if e is None:
+        return None
+    want = (P,) if feats.dim() == 1 else (P, feats.shape[1])
+    if tuple(e.shape) != want or e.dtype != feats.dtype or not e.is_contiguous() or e.device != feats.device:
+        raise RuntimeError(f"{fn}: Expected contiguous {name} of size {list(want)} with the dtype/device of feats")
+    return e
+
+
+def _diff(fn, feats, pack_infos, edge_a, edge_fill, backward, names):
+    _chk_feats(fn, feats, pack_infos)
+    if edge_a is not None and edge_fill is not None:
+        raise RuntimeError("You should only specify AT MOST one of [appends, prepends, last_fill, first_fill]")
+    P = pack_infos.shape[0]
+    edge_a, edge_fill = _edge(fn, names[0], edge_a, feats, P), _edge(fn, names[1], edge_fill, feats, P)
+    with torch.cuda.device(feats.device):
+        out = torch.zeros_like(feats)
+        H.check(H.lib().nr3d_packed_diff(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)), _code(feats),
+                                         H.ptr(feats), H.ptr(pack_infos), H.ptr(edge_a), H.ptr(edge_fill),
+                                         C.c_int(backward), H.ptr(out), H.stream_of(feats)))
+    return out
+
+
+def packed_diff(feats, pack_infos, pack_appends_=None, pack_last_fill_=None):
+    return _diff("packed_diff", feats, pack_infos, pack_appends_, pack_last_fill_, 0, ("pack_appends", "pack_last_fill"))
+
+
+def packed_backward_diff(feats, pack_infos, pack_prepends_=None, pack_first_fill_=None):
+    return _diff("packed_backward_diff", feats, pack_infos, pack_prepends_, pack_first_fill_, 1,
+                 ("pack_prepends", "pack_first_fill"))
+
+
+# ------------------------------------------------------------------------------------------------
+# per-pack broadcast arithmetic / logic (pack_ops.h:25-37 op codes)
+# ------------------------------------------------------------------------------------------------
+_OPS = dict(add=0, sub=1, mul=2, div=3, matmul=4, gt=5, geq=6, lt=7, leq=8, eq=9, neq=10)
+
+
+def _binary(name, feats, other, pack_infos):
+    fn = f"packed_{name}"
+    op = _OPS[name]
+    _chk_feats(fn, feats, pack_infos, dims=(2,) if op == 4 else (1, 2))
+    H.require_gpu(other)
+    if not other.is_contiguous() or other.dtype != feats.dtype or other.device != feats.device:
+        raise RuntimeError(f"{fn}: Expected contiguous `other` with the dtype/device of feats")
+    P = pack_infos.shape[0]
+    if other.shape[0] != P:
+        raise RuntimeError(f"{fn}: Expected other to have size {P} at dimension 0, but got size {other.shape[0]}")
+    fd = _fd(feats)
+    if op == 4:
+        if other.dim() != 3 or other.shape[2] != fd:
+            raise RuntimeError(f"{fn}: Expected other of size [num_packs, out_feat_dim, {fd}]")
+        od = int(other.shape[1])
+        out_shape, out_dtype = (feats.shape[0], od), feats.dtype
+    else:
+        if other.dim() != feats.dim() or (feats.dim() == 2 and other.shape[1] != fd):
+            raise RuntimeError(f"{fn}: Expected feats and other to have the same number of dimensions / feature width")
+        od = fd
+        out_shape, out_dtype = tuple(feats.shape), (torch.bool if op >= 5 else feats.dtype)
+    with torch.cuda.device(feats.device):
+        out = torch.zeros(out_shape, dtype=out_dtype, device=feats.device)
+        H.check(H.lib().nr3d_packed_binary(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(fd), H.u32(od), _code(feats),
+                                           H.ptr(feats), H.ptr(other), H.ptr(pack_infos), C.c_int(op), H.ptr(out),
+                                           H.stream_of(feats)))
+    return out
+
+
+def packed_add(feats, other, pack_infos): return _binary("add", feats, other, pack_infos)
+def packed_sub(feats, other, pack_infos): return _binary("sub", feats, other, pack_infos)
+def packed_mul(feats, other, pack_infos): return _binary("mul", feats, other, pack_infos)
+def packed_div(feats, other, pack_infos): return _binary("div", feats, other, pack_infos)
+def packed_matmul(feats, other, pack_infos): return _binary("matmul", feats, other, pack_infos)
+def packed_gt(feats, other, pack_infos): return _binary("gt", feats, other, pack_infos)
+def packed_geq(feats, other, pack_infos): return _binary("geq", feats, other, pack_infos)
+def packed_lt(feats, other, pack_infos): return _binary("lt", feats, other, pack_infos)
+def packed_leq(feats, other, pack_infos): return _binary("leq", feats, other, pack_infos)
+def packed_eq(feats, other, pack_infos): return _binary("eq", feats, other, pack_infos)
+def packed_neq(feats, other, pack_infos): return _binary("neq", feats, other, pack_infos)
+
+
+# ------------------------------------------------------------------------------------------------
+# sort / search / merge / inverse CDF
+# ------------------------------------------------------------------------------------------------
+def packed_sort_qsort(vals, pack_infos, return_idx):
+    """Sorts ``vals`` IN PLACE per pack (ascending); returns the index permutation or None
+    (pack_ops_cuda.cu:2634-2763)."""
+    _chk_feats("packed_sort_qsort", vals, pack_infos, dims=(1,))
+    with torch.cuda.device(vals.device):
+        idx = torch.arange(vals.shape[0], dtype=torch.int64, device=vals.device) if return_idx else None
+        H.check(H.lib().nr3d_packed_sort(H.u32(pack_infos.shape[0]), C.c_uint64(vals.shape[0]), _code(vals),
+                                         H.ptr(vals), H.ptr(idx), H.ptr(pack_infos), H.stream_of(vals)))
+    return idx
+
+
+packed_sort_thrust = packed_sort_qsort
+
+
+def packed_searchsorted(bins, vals, pack_infos):
+    _chk_feats("packed_searchsorted", bins, pack_infos, dims=(1,))
+    H.require_gpu(vals)
+    if vals.dim() != 2 or vals.dtype != bins.dtype or not vals.is_contiguous() or vals.shape[0] != pack_infos.shape[0]:
+        raise RuntimeError("packed_searchsorted: Expected contiguous vals of size [num_packs, num_to_search] "
+                           "with the dtype of bins")
+    with torch.cuda.device(bins.device):
+        pidx = torch.full(vals.shape, -1, dtype=torch.int64, device=bins.device)
+        H.check(H.lib().nr3d_packed_searchsorted(H.u32(pack_infos.shape[0]), _code(bins), H.ptr(bins), H.ptr(vals),
+                                                 H.ptr(pack_infos), H.u32(vals.shape[1]), None, H.ptr(pidx),
+                                                 H.stream_of(bins)))
+    return pidx
+
+
+def packed_searchsorted_packed_vals(bins, pack_infos, vals, val_pack_infos):
+    _chk_feats("packed_searchsorted_packed_vals", bins, pack_infos, dims=(1,))
+    _chk_feats("packed_searchsorted_packed_vals", vals, val_pack_infos, dims=(1,))
+    if vals.dtype != bins.dtype or val_pack_infos.shape[0] != pack_infos.shape[0]:
+        raise RuntimeError("packed_searchsorted_packed_vals: vals must have the dtype of bins and one pack per bin pack")
+    with torch.cuda.device(bins.device):
+        pidx = torch.full(vals.shape, -1, dtype=torch.int64, device=bins.device)
+        H.check(H.lib().nr3d_packed_searchsorted(H.u32(pack_infos.shape[0]), _code(bins), H.ptr(bins), H.ptr(vals),
+                                                 H.ptr(pack_infos), H.u32(0), H.ptr(val_pack_infos), H.ptr(pidx),
+                                                 H.stream_of(bins)))
+    return pidx
+
+
+def try_merge_two_packs_sorted_aligned(vals_a, pack_infos_a, vals_b, pack_infos_b, b_sorted):
+    """-> (pidx_a, pidx_b, pack_infos_merged)  (pack_ops_cuda.cu:1505-1631)"""
+    fn = "try_merge_two_packs_sorted_aligned"
+    _chk_feats(fn, vals_a, pack_infos_a, dims=(1,))
+    _chk_feats(fn, vals_b, pack_infos_b, dims=(1,))
+    if vals_a.dtype != vals_b.dtype or pack_infos_a.shape != pack_infos_b.shape:
+        raise RuntimeError(f"{fn}: the two packs must be aligned and share a dtype")
+    with torch.cuda.device(vals_a.device):
+        n = pack_infos_a[:, 1] + pack_infos_b[:, 1]
+        cs = n.cumsum(0)
+        pim = torch.stack([cs - n, n], 1).contiguous()
+        pa = torch.zeros(vals_a.shape[0], dtype=torch.int64, device=vals_a.device)
+        pb = torch.zeros(vals_b.shape[0], dtype=torch.int64, device=vals_a.device)
+        H.check(H.lib().nr3d_try_merge_two_packs_sorted_aligned(
+            H.u32(pack_infos_a.shape[0]), _code(vals_a), H.ptr(vals_a), H.ptr(pack_infos_a), H.ptr(vals_b),
+            H.ptr(pack_infos_b), H.ptr(pim), C.c_int(int(bool(b_sorted))), H.ptr(pa), H.ptr(pb), H.stream_of(vals_a)))
+    return pa, pb, pim
+
+
+def packed_invert_cdf(bins, cdfs, u, pack_infos):
+    fn = "packed_invert_cdf"
+    _chk_feats(fn, bins, pack_infos, dims=(1,))
+    H.require_gpu(cdfs, u)
+    if bins.dtype != torch.float32:
+        raise RuntimeError(f"{fn}: float32 only on this platform")
+    if cdfs.shape != bins.shape or cdfs.dtype != bins.dtype or not cdfs.is_contiguous():
+        raise RuntimeError(f"{fn}: Expected contiguous cdfs with the size and dtype of bins")
+    if u.dim() != 2 or u.dtype != bins.dtype or not u.is_contiguous() or u.shape[0] != pack_infos.shape[0]:
+        raise RuntimeError(f"{fn}: Expected contiguous u of size [num_packs, num_to_sample]")
+    with torch.cuda.device(bins.device):
+        bin_idx = torch.full(u.shape, -1, dtype=torch.int64, device=bins.device)
+        samples = torch.zeros_like(u)
+        H.check(H.lib().nr3d_packed_invert_cdf(H.u32(pack_infos.shape[0]), H.ptr(bins), H.ptr(cdfs), H.ptr(pack_infos),
+                                               H.ptr(u), H.u32(u.shape[1]), H.ptr(samples), H.ptr(bin_idx),
+                                               H.stream_of(bins)))
+    return samples, bin_idx
+
+
+# ------------------------------------------------------------------------------------------------
+# alpha -> volume-rendering weights (pack_ops_cuda.cu:1735-1958)
+# ------------------------------------------------------------------------------------------------
+def packed_alpha_to_vw_forward(alphas, pack_infos, early_stop_eps, alpha_thre, compression):
+    """-> (weights | None, compact_pack_infos int64 [P,2] | None, compact_selector bool [S] | None)"""
+    fn = "packed_alpha_to_vw_forward"
+    _chk_feats(fn, alphas, pack_infos, dims=(1,))
+    if alphas.dtype != torch.float32:
+        raise RuntimeError(f"{fn}: float32 only on this platform")
+    P, S, dev = pack_infos.shape[0], alphas.shape[0], alphas.device
+    with torch.cuda.device(dev):
+        st = H.stream_of(alphas)
+        if compression:
+            num = torch.zeros(P, dtype=torch.int64, device=dev)
+            sel = torch.empty(S, dtype=torch.bool, device=dev)
+            H.check(H.lib().nr3d_alpha_to_vw_forward(H.u32(P), C.c_uint64(S), H.ptr(alphas), H.ptr(pack_infos),
+                                                     H.f32(early_stop_eps), H.f32(alpha_thre), None, H.ptr(num),
+                                                     H.ptr(sel), st))
+            cpi = torch.empty((P, 2), dtype=torch.int64, device=dev)
+            total = torch.empty(1, dtype=torch.int64, device=dev)
+            H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(num), H.ptr(cpi), H.ptr(total),
+                                                   H.ptr(_scan_tmp(P, dev)), st))
+            return None, cpi, sel
+        w = torch.empty(S, dtype=alphas.dtype, device=dev)
+        H.check(H.lib().nr3d_alpha_to_vw_forward(H.u32(P), C.c_uint64(S), H.ptr(alphas), H.ptr(pack_infos),
+                                                 H.f32(early_stop_eps), H.f32(alpha_thre), H.ptr(w), None, None, st))
+    return w, None, None
+
+
+def packed_alpha_to_vw_backward(weights, grad_weights, alphas, pack_infos, early_stop_eps, alpha_thre):
+    fn = "packed_alpha_to_vw_backward"
+    _chk_feats(fn, weights, pack_infos, dims=(1,))
+    H.require_gpu(grad_weights, alphas)
+    for t in (grad_weights, alphas):
+        if t.shape != weights.shape or t.dtype != weights.dtype or not t.is_contiguous():
+            raise RuntimeError(f"{fn}: Expected contiguous weights / grad_weights / alphas of the same size and dtype")
+    if weights.dtype != torch.float32:
+        raise RuntimeError(f"{fn}: float32 only on this platform")
+    with torch.cuda.device(weights.device):
+        g = torch.empty_like(alphas)
+        H.check(H.lib().nr3d_alpha_to_vw_backward(H.u32(pack_infos.shape[0]), C.c_uint64(weights.shape[0]),
+                                                  H.ptr(alphas), H.ptr(weights), H.ptr(grad_weights), H.ptr(pack_infos),
+                                                  H.f32(early_stop_eps), H.f32(alpha_thre), H.ptr(g),
+                                                  H.stream_of(weights)))
+    return g
+
+
+# ------------------------------------------------------------------------------------------------
+# misc
+# ------------------------------------------------------------------------------------------------
+def mark_pack_boundaries_cuda(pack_ids):
+    if pack_ids.dim() != 1 or not pack_ids.is_contiguous():
+        raise RuntimeError("mark_pack_boundaries_cuda: Expected contiguous 1-D tensor for argument pack_ids")
+    if pack_ids.dtype not in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64):
+        raise RuntimeError("mark_pack_boundaries_cuda: Expected pack_ids to have one of scalar types Byte, Char, Int, "
+                           "Long, Short")
+    H.require_gpu(pack_ids)
+    with torch.cuda.device(pack_ids.device):
+        b = torch.empty(pack_ids.shape[0], dtype=torch.int32, device=pack_ids.device)
+        H.check(H.lib().nr3d_mark_pack_boundaries(C.c_uint64(pack_ids.shape[0]), _code(pack_ids), H.ptr(pack_ids),
+                                                  H.ptr(b), H.stream_of(pack_ids)))
+    return b
+
+
+def octree_mark_consecutive_segments(pidx, pack_infos, point_hierarchies):
+    raise NotImplementedError("nr3d_lib_amd: octree_mark_consecutive_segments needs kaolin SPC structures "
+                              "(out of the hot-path scope, SURVEY.md §8f-4)")

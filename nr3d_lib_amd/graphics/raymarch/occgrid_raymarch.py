@@ -1,0 +1,126 @@
+"""Ray marching through binary occupancy grids -- counterpart of the reference's
+nr3d_lib/graphics/raymarch/occgrid_raymarch.py (occgrid_raymarch :25-112, occgrid_raymarch_batched :114-221).
+
+Same signatures, same returned records (including the reference's quirk that the single-grid variant
+reports the UN-perturbed ``t_starts`` as ``depth_samples`` while the batched one reports ``t_samples``).
+"""
+from enum import Enum
+from typing import Literal, Union
+
+import torch
+
+from nr3d_lib_amd.graphics.pack_ops import packed_diff
+from nr3d_lib_amd.graphics.raymarch import RaymarchRetSingle, RaymarchRetBatched
+import nr3d_lib_amd.bindings._occ_grid as _backend
+
+__all__ = ['ContractionType', 'occgrid_raymarch', 'occgrid_raymarch_batched', 'occgrid_raymarch_forest']
+
+
+class ContractionType(Enum):
+    AABB = int(_backend.ContractionType.AABB)
+    UN_BOUNDED_TANH = int(_backend.ContractionType.UN_BOUNDED_TANH)
+    UN_BOUNDED_SPHERE = int(_backend.ContractionType.UN_BOUNDED_SPHERE)
+
+
+_CONTRACTIONS = {'aabb': ContractionType.AABB, 'sphere': ContractionType.UN_BOUNDED_SPHERE,
+                 'tanh': ContractionType.UN_BOUNDED_TANH}
+
+
+def _contraction(name):
+    try:
+        return _backend.ContractionType(_CONTRACTIONS[name.lower()].value)
+    except KeyError:
+        raise RuntimeError(f"Invalid constraction={name}")
+
+
+def _as_depth(v, like):
+    return v if isinstance(v, torch.Tensor) else like.new_full(like.shape[:-1], v)
+
+
+def _finish(rays_o, rays_d, pack_infos, t_starts, t_ends, ridx, perturb_after):
+    """shared post-processing of the raw marcher outputs"""
+    ridx = ridx.long()
+    ridx_hit = pack_infos[..., 1].nonzero().long()[..., 0].contiguous()
+    if ridx_hit.numel() == 0:
+        return None
+    pack_infos = pack_infos[ridx_hit].contiguous().long()
+    t_starts, t_ends = t_starts.squeeze_(-1), t_ends.squeeze_(-1)
+    deltas = t_ends - t_starts
+    if perturb_after:
+        # jitter inside each interval; the deltas are then re-derived as differences (last of a pack = 0)
+        t_samples = torch.addcmul(t_starts, torch.rand_like(deltas), deltas)
+        deltas = packed_diff(t_samples, pack_infos)
+    else:
+        t_samples = t_starts
+    samples = torch.addcmul(rays_o.index_select(0, ridx), rays_d.index_select(0, ridx), t_starts.unsqueeze(-1))
+    return ridx_hit, samples, t_starts, t_samples, deltas, ridx, pack_infos
+
+
+def occgrid_raymarch(occ_grid, rays_o, rays_d, near: Union[torch.Tensor, float], far: Union[torch.Tensor, float], *,
+                     constraction: Literal['aabb', 'tanh', 'sphere'] = 'aabb', perturb=False,
+                     perturb_before_march=False, roi: torch.Tensor = None, step_size: float = 1e-3,
+                     max_step_size: float = 1e10, dt_gamma: float = 0.0, max_steps: int = 512,
+                     step_size_factor=1.0) -> RaymarchRetSingle:
+    """March ``rays_o + t * rays_d`` for t in [near, far) through ``occ_grid`` (bool [Rx, Ry, Rz] over ``roi``,
+    default [-1,1]^3), emitting one sample per step inside occupied voxels and skipping empty voxels."""
+    step_size, dt_gamma = step_size * step_size_factor, dt_gamma * step_size_factor
+    near, far = _as_depth(near, rays_o), _as_depth(far, rays_o)
+    if roi is None:
+        roi = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=rays_o.dtype, device=rays_o.device)
+    ctype = _contraction(constraction)
+    if perturb and perturb_before_march:
+        near = near + step_size * torch.rand_like(near)
+    pack_infos, t_starts, t_ends, ridx, gidx = _backend.ray_marching(
+        rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(), roi.contiguous(),
+        occ_grid.contiguous(), ctype, step_size, max_step_size, dt_gamma, max_steps, True)
+    out = _finish(rays_o, rays_d, pack_infos, t_starts, t_ends, ridx, perturb and not perturb_before_march)
+    if out is None:
+        return RaymarchRetSingle(0, None, None, None, None, None, None, None, None)
+    ridx_hit, samples, t_starts, _t_samples, deltas, ridx, pack_infos = out
+    return RaymarchRetSingle(ridx_hit.numel(), ridx_hit, samples, t_starts, deltas, ridx, pack_infos, gidx.long(), None)
+
+
+def occgrid_raymarch_batched(occ_grid, rays_o, rays_d, rays_bidx: torch.Tensor = None,
+                             near: Union[torch.Tensor, float] = ..., far: Union[torch.Tensor, float] = ..., *,
+                             constraction: Literal['aabb', 'tanh', 'sphere'] = 'aabb', perturb=False,
+                             perturb_before_march=False, roi: torch.Tensor = None, step_size: float = 1e-3,
+                             max_step_size: float = 1e10, dt_gamma: float = 0.0, max_steps: int = 512,
+                             step_size_factor=1.0) -> RaymarchRetBatched:
+    """Batched grids [B, Rx, Ry, Rz]: rays are either [B, N, 3] (no ``rays_bidx``) or [N, 3] with a per-ray
+    batch index."""
+    step_size, dt_gamma = step_size * step_size_factor, dt_gamma * step_size_factor
+    assert occ_grid.dim() == 4, "Requires batched occ grid input of shape [B,Nx,Ny,Nz]"
+    B = occ_grid.shape[0]
+    near, far = _as_depth(near, rays_o), _as_depth(far, rays_o)
+    if rays_bidx is None:
+        assert rays_o.dim() == 3 and rays_o.shape[0] == B, "When not given rays_bidx, inputs should be batched"
+        batch_data_size = rays_o.shape[1]
+        rays_o, rays_d = rays_o.flatten(0, -2), rays_d.flatten(0, -2)
+        near, far = near.flatten(), far.flatten()
+    else:
+        assert rays_o.dim() == 2 and [*rays_o.shape[:-1]] == [*rays_bidx.shape], \
+            "When given rays_bidx, inputs should have the same size with rays_bidx"
+        rays_bidx = rays_bidx.int().contiguous()
+        batch_data_size = 0
+    if roi is None:
+        roi = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=rays_o.dtype, device=rays_o.device).tile(B, 1)
+    elif roi.dim() == 1:
+        roi = roi.tile(B, 1)
+    else:
+        assert roi.dim() == 2 and roi.shape[0] == B
+    ctype = _contraction(constraction)
+    if perturb and perturb_before_march:
+        near = near + step_size * torch.rand_like(near)
+    pack_infos, t_starts, t_ends, ridx, bidx, gidx = _backend.batched_ray_marching(
+        rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(), rays_bidx, batch_data_size,
+        roi.contiguous(), occ_grid.contiguous(), ctype, step_size, max_step_size, dt_gamma, max_steps, True)
+    out = _finish(rays_o, rays_d, pack_infos, t_starts, t_ends, ridx, perturb and not perturb_before_march)
+    if out is None:
+        return RaymarchRetBatched(0, None, None, None, None, None, None, None, None, None)
+    ridx_hit, samples, _t_starts, t_samples, deltas, ridx, pack_infos = out
+    return RaymarchRetBatched(ridx_hit.numel(), ridx_hit, samples, t_samples, deltas, ridx, pack_infos, bidx.long(),
+                              gidx.long(), None)
+
+
+def occgrid_raymarch_forest(*args, **kwargs):
+    raise NotImplementedError("nr3d_lib_amd: forest marching needs kaolin SPC structures (out of hot-path scope)")

@@ -1,0 +1,2 @@
+from .lotd import *      # noqa: F401,F403
+from .lotd_cfg import *  # noqa: F401,F403

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU checker (C restatement of the reference).  Built on demand with gcc."""
+    import oracle as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def hiplib():
+    """libnr3d_hip.so must exist (built by __graft_entry__.build()); never silently skipped."""
+    from nr3d_lib_amd import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        _hip.build()
+    return _hip.lib()
+
+
+@pytest.fixture(scope="session")
+def dev(hiplib):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run through gpurun)"
+    return torch.device("cuda:0")

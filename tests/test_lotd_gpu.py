@@ -1,0 +1,207 @@
+"""GPU parity: LoTD HIP kernels (through the C ABI / bindings._lotd) vs the CPU oracle.
+
+Integer outputs (grid indices) bit-exact; fp32 values within REL_TOL = 1e-5 of max|ref|
+(BASELINE.json north_star).  Param gradients come from fp32 atomics whose order is not deterministic;
+their reference is the oracle accumulated in float64 (order-free)."""
+import numpy as np
+import pytest
+import torch
+
+from util import LOTD_CASES, assert_close, assert_equal, lotd_inputs
+
+pytestmark = pytest.mark.gpu
+
+N = 3000
+
+
+def _setup(oracle, dev, case, n=N, seed=0, n_batch=1):
+    from nr3d_lib_amd.bindings import _lotd
+    D, res, nf, types, T, smooth = LOTD_CASES[case]
+    m_ref = oracle.lotd_create_meta(D, res, nf, types, T, smooth)
+    m = _lotd.LoDMeta(D, res, nf, types, T, smooth)
+    x, params, dL_dy, v = lotd_inputs(m_ref.as_dict(), n, seed, n_batch=n_batch)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return _lotd, m_ref, m, (x, params, dL_dy, v), (t(x), t(params), t(dL_dy), t(v))
+
+
+@pytest.mark.parametrize("case", list(LOTD_CASES))
+def test_fwd_and_jacobian(oracle, dev, case):
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case)
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    assert tuple(y.shape) == y_ref.shape
+    assert_close(y, y_ref, name="y")
+    assert_close(j.reshape(y_ref.shape[0], -1, m.n_dims_to_encode), j_ref, name="dy_dx")
+    y2, j2 = _lotd.lod_fwd(m, xt, pt, need_input_grad=False)
+    assert j2 is None
+    assert_close(y2, y_ref, name="y(no grad)")
+    # row-major Jacobian layout of the reference's generic path
+    m.c_permute_dydx = False
+    y3, j3 = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    assert tuple(j3.shape) == (x.shape[0], m.n_encoded_dims * m.n_dims_to_encode) and j3.is_contiguous()
+    assert_close(j3.view(j_ref.shape), j_ref, name="dy_dx row-major")
+
+
+@pytest.mark.parametrize("case", list(LOTD_CASES))
+def test_bwd(oracle, dev, case):
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=1)
+    _, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    dx, dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)
+    assert_close(dx, oracle.lotd_bwd_dx(m_ref, g, j_ref), name="dL_dx")
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam")
+    # strided dL_dy (e.g. a transposed view) must be honoured
+    dx2, dp2 = _lotd.lod_bwd(m, gt.t().contiguous().t(), xt, pt, j.contiguous(), need_input_grad=True,
+                             need_param_grad=True)
+    assert_close(dx2, dx.cpu().numpy(), name="dL_dx strided")
+    assert_close(dp2, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam strided")
+    none_dx, none_dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=False)
+    assert none_dx is None and none_dp is None
+
+
+@pytest.mark.parametrize("case", list(LOTD_CASES))
+def test_bwd_bwd_input(oracle, dev, case):
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=2)
+    _, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    ddy, dp, dx = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, j, need_dLdinput_ddLdoutput=True,
+                                          need_dLdinput_dparams=True, need_dLdinput_dinput=True)
+    assert_close(ddy, oracle.lotd_bwd_bwd_ddLdy(m_ref, v, j_ref), name="dL_ddLdy")
+    assert_close(dp, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="d(dLdx)/dparam")
+    assert_close(dx, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="d(dLdx)/dx")
+
+
+@pytest.mark.parametrize("case", ["ngp_small", "hash_npow2", "dense_2d", "hash_4d", "dense_f8"])
+def test_grid_index_bit_exact(oracle, dev, case):
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=3)
+    gi = _lotd.lod_get_grid_index(m, xt)
+    assert gi.dtype == torch.int64
+    assert_equal(gi, oracle.lotd_grid_index(m_ref, x), name="grid_inds")
+    # reference smoke test (lotd/tests/unit_test_grid_inds.py:31-40): zeroing the indexed params zeroes y
+    p2 = pt.clone()
+    p2[gi.reshape(-1)] = 0
+    y, _ = _lotd.lod_fwd(m, xt, p2)
+    assert float(y.abs().max()) == 0.0
+
+
+def test_grid_index_rejects_other_types(oracle, dev):
+    _lotd, m_ref, m, _, (xt, *_r) = _setup(oracle, dev, "mixed")
+    with pytest.raises(RuntimeError, match="Only support Dense/Hash"):
+        _lotd.lod_get_grid_index(m, xt)
+
+
+@pytest.mark.parametrize("case", ["ngp_small", "mixed"])
+def test_batched_and_max_level(oracle, dev, case):
+    B = 3
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=2400, seed=4, n_batch=B)
+    rng = np.random.default_rng(5)
+    bi = rng.integers(-1, B, x.shape[0]).astype(np.int64)       # -1 => skipped point
+    bo = (np.array([2, 0, 1]) * m.n_params).astype(np.int64)    # permuted batch placement
+    bit, bot = torch.from_numpy(bi).to(dev), torch.from_numpy(bo).to(dev)
+    for kw_ref, kw in [
+        (dict(batch_inds=bi), dict(batch_inds=bit)),
+        (dict(batch_inds=bi, batch_offsets=bo), dict(batch_inds=bit, batch_offsets=bot)),
+        (dict(batch_data_size=800), dict(batch_data_size=800)),
+        (dict(max_level=2), dict(max_level=2)),
+        (dict(batch_data_size=800, max_level=0), dict(batch_data_size=800, max_level=0)),
+    ]:
+        y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True, **kw_ref)
+        y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True, **kw)
+        assert_close(y, y_ref, name=f"y {kw_ref.keys()}")
+        assert_close(j, j_ref, name=f"dy_dx {kw_ref.keys()}")
+        if "batch_inds" in kw_ref:
+            assert float(y[bit < 0].abs().max()) == 0.0
+        _, dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=True, **kw)
+        assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw_ref), name="dL_dparam")
+        _, dp2, dx2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, j, need_dLdinput_ddLdoutput=False,
+                                              need_dLdinput_dparams=True, need_dLdinput_dinput=True, **kw)
+        assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True, **kw_ref), name="2nd dparam")
+        assert_close(dx2, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p, **kw_ref), name="2nd dx")
+    # max_level <= -1: all-zero outputs of the documented shapes (lotd_torch_api.cu:294-297)
+    y, j = _lotd.lod_fwd(m, xt, pt, max_level=-1, need_input_grad=True)
+    assert tuple(y.shape) == (x.shape[0], m.n_encoded_dims) and float(y.abs().max()) == 0
+    assert tuple(j.shape) == (x.shape[0], m.n_encoded_dims * m.n_dims_to_encode)
+
+
+def test_generic_kernel_agrees_with_dense_hash_kernel(oracle, dev):
+    """c_hash_only=False routes a Dense/Hash meta through the all-types kernel"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, "ngp_small", seed=6)
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    m.c_hash_only = False
+    y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    assert_close(y, y_ref, name="y generic")
+    assert_close(j, j_ref, name="dy_dx generic")
+    _, dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=True)
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dparam generic")
+
+
+def test_half_params_and_inputs(oracle, dev):
+    """fp16 storage: computed in fp32 on device, cast back; compared with the fp32 oracle on the rounded inputs"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, "ngp_small", seed=7)
+    ph = pt.half()
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, ph.float().cpu().numpy(), need_dydx=True)
+    y, j = _lotd.lod_fwd(m, xt, ph, need_input_grad=True)
+    assert y.dtype == torch.float16 and j.dtype == torch.float32
+    assert_close(y.float(), y_ref, rel=2e-3, name="y half")
+    dx, dp = _lotd.lod_bwd(m, gt.half(), xt, ph, j, need_input_grad=True, need_param_grad=True)
+    assert dp.dtype == torch.float16 and dx.dtype == torch.float32
+    with pytest.raises(RuntimeError, match="not supported"):
+        _lotd.lod_fwd(m, xt.half(), pt)          # (half input, float params) is not a supported combination
+
+
+def test_autograd_surface(oracle, dev):
+    """LoTDFunction / FwdDydx / BwdDydx: loss_scale handling, clamping, prefix dims, second-order chain"""
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTD, generate_meta
+    D, res, nf, types, T, smooth = LOTD_CASES["ngp_smooth"]
+    enc = LoTD(D, res, nf, types, hashmap_size=T, use_smooth_step=smooth, dtype=torch.float)
+    m_ref = oracle.lotd_create_meta(D, res, nf, types, T, smooth)
+    x, p, g, v = lotd_inputs(m_ref.as_dict(), 512, 8)
+    xt = torch.from_numpy(x).to(dev).view(8, 64, D).requires_grad_(True)
+    pt = torch.from_numpy(p).to(dev).requires_grad_(True)
+    gt = torch.from_numpy(g).to(dev).view(8, 64, -1)
+    # first order
+    y = enc(xt, pt)
+    assert tuple(y.shape) == (8, 64, enc.out_features)
+    y.backward(gt)
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    assert_close(y.reshape(512, -1), y_ref, name="y")
+    assert_close(xt.grad.reshape(512, D), oracle.lotd_bwd_dx(m_ref, g, j_ref), name="x.grad")
+    assert_close(pt.grad, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="params.grad")
+    # second order: nablas = dL_dy . dy_dx, loss = <nablas, v>
+    xt2 = torch.from_numpy(x).to(dev).requires_grad_(True)
+    pt2 = torch.from_numpy(p).to(dev).requires_grad_(True)
+    gt2 = torch.from_numpy(g).to(dev).requires_grad_(True)
+    y2, dy_dx = enc.forward_dydx(xt2, pt2)
+    nablas = enc.backward_dydx(gt2, dy_dx, xt2, pt2)
+    assert_close(nablas, oracle.lotd_bwd_dx(m_ref, g, j_ref), name="nablas")
+    vt = torch.from_numpy(v).to(dev)
+    (nablas * vt).sum().backward()
+    assert_close(gt2.grad, oracle.lotd_bwd_bwd_ddLdy(m_ref, v, j_ref), name="dL/d(dL_dy)")
+    assert_close(pt2.grad, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="2nd params.grad")
+    # points outside [0,1] are clamped, not rejected
+    y_out = enc(torch.tensor([[-0.5, 0.5, 1.5]], device=dev), pt.detach())
+    y_cl = enc(torch.tensor([[1e-6, 0.5, 1 - 1e-6]], device=dev), pt.detach())
+    assert torch.equal(y_out, y_cl)
+
+
+def test_errors(oracle, dev):
+    from nr3d_lib_amd.bindings import _lotd
+    m = _lotd.LoDMeta(3, [8, 16], [2, 2], ["Dense", "Hash"], 1024)
+    x = torch.rand(10, 3, device=dev)
+    p = torch.zeros(m.n_params, device=dev)
+    with pytest.raises(RuntimeError, match="integral multiple"):
+        _lotd.lod_fwd(m, x, p[:-1])
+    with pytest.raises(RuntimeError, match="divisor"):
+        _lotd.lod_fwd(m, x, p, batch_data_size=3)
+    with pytest.raises(RuntimeError, match="need `dy_dx`"):
+        _lotd.lod_bwd(m, torch.zeros(10, 4, device=dev), x, p, None, need_input_grad=True)
+    with pytest.raises(RuntimeError):
+        _lotd.lod_fwd(m, x.cpu(), p.cpu())           # no CPU fallback
+    with pytest.raises(RuntimeError, match="resolutions >= 3"):
+        _lotd.LoDMeta(3, [2], [2], ["Dense"])
+    with pytest.raises(RuntimeError, match="greatest common divisor"):
+        _lotd.LoDMeta(3, [8], [3], ["Dense"])
+    with pytest.raises(RuntimeError, match="hashmap_size"):
+        _lotd.LoDMeta(3, [8], [2], ["Hash"])
+    with pytest.raises(RuntimeError, match="3D"):
+        _lotd.LoDMeta(2, [8], [2], ["VM"])

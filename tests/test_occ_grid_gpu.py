@@ -1,0 +1,163 @@
+"""GPU parity: occupancy-grid marcher vs the CPU oracle.  packed_info / ridx / gidx bit-exact; t_starts /
+t_ends bit-exact too for AABB (same fp32 operation order, IEEE division, explicit FMA)."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close, assert_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def pinhole_rays(n_side, dist=4.0, seed=0, jitter=True):
+    """rays from a camera at distance `dist` looking at the origin (as the reference's smoke test,
+    occgrid_raymarch.py:281-295); near/far from the ray-AABB test against [-1,1]^3"""
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.linspace(-0.45, 0.45, n_side), np.linspace(-0.45, 0.45, n_side), indexing="ij")
+    d = np.stack([u.ravel(), v.ravel(), np.ones(u.size)], 1)
+    if jitter:
+        d[:, :2] += rng.normal(0, 1e-3, (u.size, 2))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    th = 0.7
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.4), -np.sin(0.4)], [0, np.sin(0.4), np.cos(0.4)]])
+    d = (d @ R.T).astype(np.float32)
+    o = np.tile((-dist * R[:, 2]).astype(np.float32), (u.size, 1))
+    with np.errstate(divide="ignore"):
+        t1, t2 = (-1 - o) / d, (1 - o) / d
+    near = np.minimum(t1, t2).max(1)
+    far = np.maximum(t1, t2).min(1)
+    hit = far > np.maximum(near, 0)
+    near = np.where(hit, np.maximum(near, 0), 0).astype(np.float32)
+    far = np.where(hit, far, 0).astype(np.float32)     # missed rays: near == far == 0 -> no samples
+    return o, d, near, far
+
+
+def grids(res, seed):
+    rng = np.random.default_rng(seed)
+    rnd = rng.random(res) > 0.5
+    ax = [np.linspace(-1, 1, r) for r in res]
+    X, Y, Z = np.meshgrid(*ax, indexing="ij")
+    r = np.sqrt(X ** 2 + Y ** 2 + Z ** 2)
+    shell = (r > 0.55) & (r < 0.7)
+    return {"random": rnd, "shell": shell, "empty": np.zeros(res, bool), "full": np.ones(res, bool)}
+
+
+def run_both(oracle, dev, o, d, near, far, roi, grid, ctype, step, max_step, gamma, max_steps, **batch):
+    from nr3d_lib_amd.bindings import _occ_grid
+    ref = oracle.ray_marching(o, d, near, far, roi, grid, ctype, step, max_step, gamma, max_steps, True,
+                              batch_inds=batch.get("batch_inds"), batch_data_size=batch.get("batch_data_size"))
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    if grid.ndim == 4:
+        got = _occ_grid.batched_ray_marching(t(o), t(d), t(near), t(far), t(batch.get("batch_inds")),
+                                             batch.get("batch_data_size"), t(roi), t(grid),
+                                             _occ_grid.ContractionType(ctype), step, max_step, gamma, max_steps, True)
+    else:
+        got = _occ_grid.ray_marching(t(o), t(d), t(near), t(far), t(roi), t(grid), _occ_grid.ContractionType(ctype),
+                                     step, max_step, gamma, max_steps, True)
+    return got, ref
+
+
+ROI = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+
+
+@pytest.mark.parametrize("kind", ["random", "shell", "empty", "full"])
+@pytest.mark.parametrize("gamma,max_step", [(0.0, 1e10), (0.01, 0.05)])
+def test_aabb_bit_exact(oracle, dev, kind, gamma, max_step):
+    res = (32, 24, 40)
+    o, d, near, far = pinhole_rays(24, seed=1)
+    grid = grids(res, 2)[kind]
+    got, ref = run_both(oracle, dev, o, d, near, far, ROI, grid, 0, 2 * 3 ** 0.5 / 128, max_step, gamma, 128)
+    names = ["packed_info", "t_starts", "t_ends", "ridx", "gidx"]
+    assert got[0].dtype == torch.int32 and got[3].dtype == torch.int32 and got[4].dtype == torch.int32
+    assert got[1].shape[-1] == 1 and got[1].dim() == 2
+    for g, r, n in zip(got, ref, names):
+        assert_equal(g, r, name=f"{kind}/{n}")       # incl. the float t-values: same op order => same bits
+    if kind == "empty":
+        assert got[1].shape[0] == 0
+    if kind == "full":
+        assert int(got[0][:, 1].max()) == 128        # max_steps cap reached on the long rays
+
+
+def test_c3_config_bit_exact(oracle, dev):
+    """BASELINE config 3 shape: 128^3 grid, 4096 rays, <= 512 samples per ray"""
+    res = (128, 128, 128)
+    o, d, near, far = pinhole_rays(64, seed=7)
+    rng = np.random.default_rng(7)
+    grid = rng.random(res) > 0.5
+    got, ref = run_both(oracle, dev, o, d, near, far, ROI, grid, 0, 2 * 3 ** 0.5 / 512, 1e10, 0.0, 512)
+    for g, r, n in zip(got, ref, ["packed_info", "t_starts", "t_ends", "ridx", "gidx"]):
+        assert_equal(g, r, name=n)
+    pi = got[0].cpu().numpy()
+    assert pi[:, 1].max() <= 512 and (pi[1:, 0] == np.cumsum(pi[:-1, 1])).all()
+
+
+@pytest.mark.parametrize("ctype", [1, 2])
+def test_contractions(oracle, dev, ctype):
+    """tanh / sphere contraction: transcendental (tanhf) / sqrt results may differ in the last bit between
+    libm and the device, which can move a sample across a voxel face; require >= 99.9% identical rays"""
+    res = (32, 32, 32)
+    o, d, near, far = pinhole_rays(20, seed=3)
+    far = near + 6.0
+    grid = grids(res, 4)["random"]
+    got, ref = run_both(oracle, dev, o, d, near, far, ROI * 0.5, grid, ctype, 0.02, 1e10, 0.0, 200)
+    same = (got[0].cpu().numpy() == ref[0]).all(1).mean()
+    assert same >= 0.999, f"only {same:.4f} of rays have identical packed_info"
+    if same == 1.0:
+        assert_equal(got[4], ref[4], name="gidx")
+        assert_close(got[1], ref[1], name="t_starts")
+
+
+def test_non_default_roi_and_degenerate_rays(oracle, dev):
+    res = (16, 20, 12)
+    o, d, near, far = pinhole_rays(16, seed=5)
+    roi = np.array([-0.8, -0.6, -0.9, 0.7, 0.9, 0.5], np.float32)
+    d[3] = np.array([0, 0, 1], np.float32)             # axis-aligned: inv_dir has +-inf components
+    d[4] = np.array([1, 0, 0], np.float32)
+    far[5] = near[5]                                    # zero-length
+    near[6], far[6] = 2.0, 1.0                          # inverted
+    grid = grids(res, 6)["random"]
+    got, ref = run_both(oracle, dev, o, d, near, far, roi, grid, 0, 0.01, 1e10, 0.0, 64)
+    for g, r, n in zip(got, ref, ["packed_info", "t_starts", "t_ends", "ridx", "gidx"]):
+        assert_equal(g, r, name=n)
+
+
+def test_batched_bit_exact(oracle, dev):
+    B, res = 3, (16, 16, 16)
+    o, d, near, far = pinhole_rays(18, seed=9)      # 324 rays
+    rng = np.random.default_rng(9)
+    grid = rng.random((B,) + res) > 0.6
+    roi = np.stack([ROI, ROI * 0.9, ROI * 1.1]).astype(np.float32)
+    bi = rng.integers(-1, B, o.shape[0]).astype(np.int32)
+    for kw in (dict(batch_inds=bi), dict(batch_data_size=108)):
+        got, ref = run_both(oracle, dev, o, d, near, far, roi, grid, 0, 0.01, 1e10, 0.0, 96, **kw)
+        for g, r, n in zip(got, ref, ["packed_info", "t_starts", "t_ends", "ridx", "bidx", "gidx"]):
+            assert_equal(g, r, name=f"{list(kw)}/{n}")
+
+
+def test_wrapper_record(oracle, dev):
+    """occgrid_raymarch: the 9-field record, derived tensors and the no-hit case"""
+    from nr3d_lib_amd.graphics.raymarch.occgrid_raymarch import occgrid_raymarch, occgrid_raymarch_batched
+    res = (32, 32, 32)
+    o, d, near, far = pinhole_rays(16, seed=11)
+    grid = grids(res, 12)["shell"]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ret = occgrid_raymarch(t(grid), t(o), t(d), t(near), t(far), step_size=0.01, max_steps=256)
+    ref = oracle.ray_marching(o, d, near, far, ROI, grid, 0, 0.01, 1e10, 0.0, 256, True)
+    hit = np.nonzero(ref[0][:, 1])[0]
+    assert ret.num_hit_rays == len(hit)
+    assert_equal(ret.ridx_hit, hit, "ridx_hit")
+    assert_equal(ret.pack_infos, ref[0][hit].astype(np.int64), "pack_infos")
+    assert ret.pack_infos.dtype == torch.int64 and ret.ridx.dtype == torch.int64 and ret.gidx.dtype == torch.int64
+    assert_equal(ret.depth_samples, ref[1][:, 0], "depth_samples")
+    assert_equal(ret.deltas, ref[2][:, 0] - ref[1][:, 0], "deltas")
+    samples_ref = o[ref[3]] + d[ref[3]] * ref[1]
+    assert_close(ret.samples, samples_ref, name="samples")
+    assert len(list(ret)) == 9 and ret["gidx"] is ret.gidx
+    ret_p = occgrid_raymarch(t(grid), t(o), t(d), t(near), t(far), step_size=0.01, max_steps=256, perturb=True)
+    assert torch.equal(ret_p.depth_samples, ret.depth_samples)      # reference quirk: unperturbed t_starts
+    none = occgrid_raymarch(t(np.zeros(res, bool)), t(o), t(d), 0.0, 5.0)
+    assert none.num_hit_rays == 0 and none.samples is None
+    retb = occgrid_raymarch_batched(t(np.stack([grid, grid])), t(np.stack([o, o])), t(np.stack([d, d])), None,
+                                    t(np.stack([near, near])), t(np.stack([far, far])), step_size=0.01, max_steps=256)
+    assert retb.num_hit_rays == 2 * len(hit) and int(retb.bidx.max()) == 1

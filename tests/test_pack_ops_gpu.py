@@ -1,0 +1,329 @@
+"""GPU parity: pack_ops HIP kernels vs the CPU oracle.  Offsets / indices / selectors bit-exact, values
+within REL_TOL (wave-parallel reductions reorder the reference's serial sums)."""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close, assert_equal, random_packs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def P(hiplib):
+    from nr3d_lib_amd.bindings import _pack_ops
+    return _pack_ops
+
+
+def T(a, dev):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+PACK_SHAPES = [(37, 0, 5, 0.3), (64, 1, 200, 0.1), (5, 300, 700, 0.0)]   # (n_packs, lo, hi, empty_frac)
+
+
+@pytest.mark.parametrize("shape", PACK_SHAPES)
+@pytest.mark.parametrize("fd", [None, 1, 3])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64, np.int32])
+def test_sum_scan_diff(oracle, dev, P, shape, fd, dtype):
+    rng = np.random.default_rng(hash((shape, fd, dtype.__name__)) % 2 ** 31)
+    pi, S = random_packs(rng, *shape)
+    shp = (S,) if fd is None else (S, fd)
+    if np.issubdtype(dtype, np.floating):
+        x = rng.uniform(0.5, 1.5, shp).astype(dtype)
+    else:
+        x = rng.integers(-3, 4, shp).astype(dtype)
+    rel = 1e-5 if dtype == np.float32 else 1e-12
+    cmp = assert_close if np.issubdtype(dtype, np.floating) else (lambda a, b, rel=None, name="": assert_equal(a, b, name))
+    cmp(P.packed_sum(T(x, dev), T(pi, dev)), oracle.packed_sum(x, pi), rel=rel, name="sum")
+    for excl in (False, True):
+        for rev in (False, True):
+            cmp(P.packed_cumsum(T(x, dev), T(pi, dev), excl, rev), oracle.packed_cumsum(x, pi, excl, rev), rel=rel,
+                name=f"cumsum e{excl} r{rev}")
+            cmp(P.packed_cumprod(T(x, dev), T(pi, dev), excl, rev), oracle.packed_cumprod(x, pi, excl, rev),
+                rel=max(rel, 1e-4 if shape[2] > 100 else rel), name=f"cumprod e{excl} r{rev}")
+    npk = pi.shape[0]
+    e = (rng.uniform(0.5, 1.5, (npk,) + shp[1:]) if np.issubdtype(dtype, np.floating)
+         else rng.integers(-3, 4, (npk,) + shp[1:])).astype(dtype)
+    for a, f in ((None, None), (e, None), (None, e)):
+        assert_equal(P.packed_diff(T(x, dev), T(pi, dev), T(a, dev), T(f, dev)), oracle.packed_diff(x, pi, a, f), "diff")
+        assert_equal(P.packed_backward_diff(T(x, dev), T(pi, dev), T(a, dev), T(f, dev)),
+                     oracle.packed_backward_diff(x, pi, a, f), "backward_diff")
+
+
+def test_reference_known_answers(dev, P):
+    """literal tensors of the reference's own test (graphics/pack_ops/unit_test.py:536-563, 4 printed digits)"""
+    boundary = np.array([1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0], bool)
+    first = np.nonzero(boundary)[0]
+    pi = np.stack([first, np.diff(np.append(first, 13))], 1).astype(np.int64)
+    feat = np.array([0.8750, 0.0581, 0.9378, 0.9638, 0.9859, 0.4652, 0.9105, 0.5071, 0.0173, 0.6071, 0.7123,
+                     0.7371, 0.8094], np.float32)
+    incl = np.array([0.8750, 0.9331, 1.8709, 2.8347, 0.9859, 1.4512, 2.3617, 2.8688, 2.8860, 3.4931, 4.2054,
+                     0.7371, 1.5465], np.float32)
+    excl = np.array([0.0, 0.8750, 0.9331, 1.8709, 0.0, 0.9859, 1.4512, 2.3617, 2.8688, 2.8860, 3.4931, 0.0,
+                     0.7371], np.float32)
+    np.testing.assert_allclose(P.packed_cumsum(T(feat, dev), T(pi, dev), False, False).cpu().numpy(), incl, atol=2e-4)
+    np.testing.assert_allclose(P.packed_cumsum(T(feat, dev), T(pi, dev), True, False).cpu().numpy(), excl, atol=2e-4)
+    featp = np.array([-0.8033, 1.2413, 0.1971, 1.2183, 1.3434, 1.7485, 0.0624, -0.3419, -0.1997, -1.4790, 1.1720,
+                      0.1686, -0.0704], np.float32)
+    inclp = np.array([-0.8033, -0.9972, -0.1965, -0.2394, 1.3434, 2.3489, 0.1465, -0.0501, 0.0100, -0.0148, -0.0173,
+                      0.1686, -0.0119], np.float32)
+    np.testing.assert_allclose(P.packed_cumprod(T(featp, dev), T(pi, dev), False, False).cpu().numpy(), inclp, atol=2e-4)
+    # exclusive cumprod: the reference KERNEL yields zeros (see DESIGN.md quirk list); the documented
+    # right-shift-with-1 semantics (the kaolin numbers of the docstring) are available behind the flag
+    assert float(P.packed_cumprod(T(featp, dev), T(pi, dev), True, False).abs().max()) == 0.0
+    P.CUMPROD_EXCLUSIVE_DOCUMENTED = True
+    try:
+        exclp = np.array([1.0, -0.8033, -0.9972, -0.1965, 1.0, 1.3434, 2.3489, 0.1465, -0.0501, 0.0100, -0.0148, 1.0,
+                          0.1686], np.float32)
+        np.testing.assert_allclose(P.packed_cumprod(T(featp, dev), T(pi, dev), True, False).cpu().numpy(), exclp, atol=2e-4)
+    finally:
+        P.CUMPROD_EXCLUSIVE_DOCUMENTED = False
+    assert_equal(P.mark_pack_boundaries_cuda(T(np.repeat(np.arange(3), [4, 7, 2]).astype(np.int64), dev)),
+                 boundary.astype(np.int32), "boundaries")
+    # docs/pack_ops.md:21
+    from nr3d_lib_amd.graphics.pack_ops import get_pack_infos_from_n
+    assert get_pack_infos_from_n(torch.tensor([4, 1, 5, 3])).tolist() == [[0, 4], [4, 1], [5, 5], [10, 3]]
+
+
+@pytest.mark.parametrize("shape", PACK_SHAPES)
+@pytest.mark.parametrize("fd", [None, 4])
+def test_binary_ops(oracle, dev, P, shape, fd):
+    rng = np.random.default_rng(11)
+    pi, S = random_packs(rng, *shape)
+    npk = pi.shape[0]
+    x = rng.uniform(0.5, 2.0, (S,) if fd is None else (S, fd)).astype(np.float32)
+    o = rng.uniform(0.5, 2.0, (npk,) if fd is None else (npk, fd)).astype(np.float32)
+    o[::3] = x[np.minimum(pi[::3, 0], max(S - 1, 0))] if S else o[::3]      # force some equalities
+    for op in ("add", "sub", "mul", "div"):
+        assert_equal(getattr(P, f"packed_{op}")(T(x, dev), T(o, dev), T(pi, dev)), oracle.packed_binary(op, x, o, pi), op)
+    for op in ("gt", "geq", "lt", "leq", "eq", "neq"):
+        got = getattr(P, f"packed_{op}")(T(x, dev), T(o, dev), T(pi, dev))
+        assert got.dtype == torch.bool
+        assert_equal(got, oracle.packed_binary(op, x, o, pi), op)
+    xi = rng.integers(0, 100, (S,)).astype(np.int64)
+    oi = rng.integers(0, 100, (npk,)).astype(np.int64)
+    assert_equal(P.packed_add(T(xi, dev), T(oi, dev), T(pi, dev)), oracle.packed_binary("add", xi, oi, pi), "add i64")
+    if fd:
+        w = rng.standard_normal((npk, 3, fd)).astype(np.float32)
+        assert_close(P.packed_matmul(T(x, dev), T(w, dev), T(pi, dev)), oracle.packed_matmul(x, w, pi), name="matmul")
+
+
+def test_interleave(oracle, dev, P):
+    rng = np.random.default_rng(12)
+    n = rng.integers(0, 300, 97).astype(np.int64)
+    out, nidx = P.interleave_arange(T(n, dev), True)
+    ro, rn = oracle.interleave_arange(n, True)
+    assert_equal(out, ro, "arange"); assert_equal(nidx, rn, "arange nidx")
+    assert P.interleave_arange(T(n, dev), False)[1] is None
+    start = rng.uniform(0, 10, 97).astype(np.float32)
+    step = rng.uniform(0.1, 1, 97).astype(np.float32)
+    for ss, rs in ((T(step, dev), step), (0.25, 0.25)):
+        out, nidx = P.interleave_linstep(T(start, dev), T(n, dev), ss, True)
+        ro, rn = oracle.interleave_linstep(start, n, rs, True)
+        assert_equal(out, ro, "linstep"); assert_equal(nidx, rn, "linstep nidx")
+    starti = rng.integers(0, 1000, 97).astype(np.int64)
+    out, _ = P.interleave_linstep(T(starti, dev), T(n, dev), 1, False)
+    assert_equal(out, oracle.interleave_linstep(starti, n, 1, False)[0], "linstep i64")
+    # literal inputs of the reference test (unit_test.py:697-701) through the arange wrapper
+    from nr3d_lib_amd.graphics.pack_ops import interleave_arange
+    y = interleave_arange(torch.tensor([1.1, 2.2, 3.3], device=dev), torch.tensor([9.9, 5.5, 7.7], device=dev),
+                          torch.tensor([0.5, 1.3, 0.9], device=dev), False)
+    want = np.concatenate([np.float32(1.1) + np.arange(18, dtype=np.float32) * np.float32(0.5),
+                           np.float32(2.2) + np.arange(3, dtype=np.float32) * np.float32(1.3),
+                           np.float32(3.3) + np.arange(5, dtype=np.float32) * np.float32(0.9)])
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-6)
+
+
+@pytest.mark.parametrize("gamma,lo,hi", [(0.01, 0.01, 1.0), (0.0, 0.02, 1e10), (0.05, 0.001, 0.04)])
+def test_sample_step(oracle, dev, P, gamma, lo, hi):
+    rng = np.random.default_rng(13)
+    near = rng.uniform(0.1, 2, 301).astype(np.float32)
+    far = (near + rng.uniform(-0.5, 6, 301)).astype(np.float32)     # some far < near -> empty packs
+    got = P.interleave_sample_step_wrt_depth_clamped(T(near, dev), T(far, dev), 200, gamma, lo, hi)
+    ref = oracle.interleave_sample_step_wrt_depth_clamped(near, far, 200, gamma, lo, hi)
+    for g, r, n in zip(got, ref, ["t", "dt", "nidx", "pack_infos"]):
+        assert_equal(g, r, n)                                       # serial recurrence replayed exactly
+    # segments
+    nseg = rng.integers(0, 4, 301).astype(np.int64)
+    spi = oracle.get_pack_infos_from_n(nseg)
+    entry, exit = [], []
+    for i in range(301):
+        cuts = np.sort(rng.uniform(near[i], max(far[i], near[i] + 0.1), 2 * nseg[i])).astype(np.float32)
+        entry += list(cuts[0::2]); exit += list(cuts[1::2])
+    entry, exit = np.array(entry, np.float32), np.array(exit, np.float32)
+    got = P.interleave_sample_step_wrt_depth_in_packed_segments(T(near, dev), T(far, dev), T(entry, dev), T(exit, dev),
+                                                                T(spi, dev), 64, gamma, lo, hi)
+    ref = oracle.interleave_sample_step_wrt_depth_in_packed_segments(near, far, entry, exit, spi, 64, gamma, lo, hi)
+    for g, r, n in zip(got, ref, ["t", "dt", "sidx", "nidx", "pack_infos"]):
+        assert_equal(g, r, "seg " + n)
+
+
+def test_search_and_invert_cdf(oracle, dev, P):
+    # literal inputs of the reference test (unit_test.py:1125-1143)
+    bins = np.array([2, 3, 7, 1, 0, 4, 8, 3, 6], np.float32)
+    u = np.array([4, 0, 2, 9, 7], np.float32)[:, None]
+    pi = oracle.get_pack_infos_from_n(np.array([3, 1, 2, 1, 2]))
+    assert_equal(P.packed_searchsorted(T(bins, dev), T(u, dev), T(pi, dev)), oracle.packed_searchsorted(bins, u, pi), "ss")
+    assert P.packed_searchsorted(T(bins, dev), T(u, dev), T(pi, dev)).flatten().tolist() == [2, 3, 5, 6, 8]
+    up = np.array([3.5, 1.2, 2.2, -1, 3.2, 6.0, 7.0, 5.0], np.float32)
+    upi = oracle.get_pack_infos_from_n(np.array([2, 0, 3, 2, 1]))
+    assert_equal(P.packed_searchsorted_packed_vals(T(bins, dev), T(pi, dev), T(up, dev), T(upi, dev)),
+                 oracle.packed_searchsorted_packed_vals(bins, pi, up, upi), "ss packed")
+    bins = np.array([2, 3, 7, 1, 2, 3, 4, 6, 8], np.float32)
+    cdfs = np.array([0.0, 0.4, 1.0, 0.0, 1.0, 0.0, 0.1, 0.8, 1.0], np.float32)
+    pi = oracle.get_pack_infos_from_n(np.array([3, 2, 4]))
+    uu = np.tile(np.array([0.5, 0.9], np.float32), (3, 1))
+    s, b = P.packed_invert_cdf(T(bins, dev), T(cdfs, dev), T(uu, dev), T(pi, dev))
+    rs, rb = oracle.packed_invert_cdf(bins, cdfs, uu, pi)
+    assert_equal(b, rb, "bin_idx"); assert_equal(s, rs, "samples")
+    # random, larger
+    rng = np.random.default_rng(14)
+    pi, S = random_packs(rng, 150, 1, 90)
+    bins = np.concatenate([np.sort(rng.uniform(0, 5, int(n))) for n in pi[:, 1]]).astype(np.float32)
+    pdf = rng.uniform(0, 1, S) * (rng.random(S) > 0.2)
+    cdfs = np.concatenate([np.cumsum(pdf[b:b + n]) / max(pdf[b:b + n].sum(), 1e-9) for b, n in pi]).astype(np.float32)
+    uu = rng.uniform(0, 1, (150, 70)).astype(np.float32)
+    s, b = P.packed_invert_cdf(T(bins, dev), T(cdfs, dev), T(uu, dev), T(pi, dev))
+    rs, rb = oracle.packed_invert_cdf(bins, cdfs, uu, pi)
+    assert_equal(b, rb, "bin_idx rnd"); assert_equal(s, rs, "samples rnd")
+    vals = rng.uniform(-1, 6, (150, 70)).astype(np.float32)
+    assert_equal(P.packed_searchsorted(T(bins, dev), T(vals, dev), T(pi, dev)), oracle.packed_searchsorted(bins, vals, pi), "ss rnd")
+
+
+@pytest.mark.parametrize("b_sorted", [True, False])
+def test_merge_sorted(oracle, dev, P, b_sorted):
+    rng = np.random.default_rng(15)
+    pia, Sa = random_packs(rng, 80, 0, 150, 0.1)
+    pib, Sb = random_packs(rng, 80, 0, 90, 0.2)
+    va = np.concatenate([np.sort(rng.integers(0, 60, int(n))) for n in pia[:, 1]] + [np.zeros(0)]).astype(np.float32)
+    # unsorted b: the reference's run-rank only separates CONSECUTIVE equal lower bounds; kernel and oracle
+    # implement the same formula, so equality holds either way
+    vb = [rng.integers(0, 60, int(n)) + 0.5 * (rng.random(int(n)) > 0.5) for n in pib[:, 1]]
+    vb = np.concatenate([np.sort(v) if b_sorted else v for v in vb] + [np.zeros(0)]).astype(np.float32)
+    pa, pb, pim = P.try_merge_two_packs_sorted_aligned(T(va, dev), T(pia, dev), T(vb, dev), T(pib, dev), b_sorted)
+    ra, rb, rm = oracle.try_merge_two_packs_sorted_aligned(va, pia, vb, pib, b_sorted)
+    assert_equal(pim, rm, "merged pack_infos"); assert_equal(pa, ra, "pidx_a"); assert_equal(pb, rb, "pidx_b")
+    if b_sorted:   # the merged array really is sorted and a permutation
+        merged = np.full(Sa + Sb, np.nan, np.float32)
+        merged[pa.cpu().numpy()] = va; merged[pb.cpu().numpy()] = vb
+        assert not np.isnan(merged).any()
+        for b, n in rm:
+            assert (np.diff(merged[b:b + n]) >= 0).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int64])
+def test_sort(oracle, dev, P, dtype):
+    # literal example of the reference test (unit_test.py:1086-1092)
+    vals = np.array([0.2, 0.1, 0.3, 2.9, 2.3, 2.5, 2.4, 2.1, 1.0, 1.1], np.float32)
+    pi = oracle.get_pack_infos_from_n(np.array([3, 5, 2]))
+    v = T(vals, dev).clone()
+    idx = P.packed_sort_qsort(v, T(pi, dev), True)
+    assert v.tolist() == pytest.approx([0.1, 0.2, 0.3, 2.1, 2.3, 2.4, 2.5, 2.9, 1.0, 1.1])
+    assert torch.equal(T(vals, dev)[idx], v)
+    rng = np.random.default_rng(16)
+    pi, S = random_packs(rng, 60, 0, 400, 0.1)
+    x = (rng.standard_normal(S) * 100).astype(dtype)
+    v = T(x, dev).clone()
+    idx = P.packed_sort_qsort(v, T(pi, dev), True)
+    want = np.concatenate([np.sort(x[b:b + n]) for b, n in pi] + [np.zeros(0, dtype)])
+    assert_equal(v, want, "sorted values")
+    assert_equal(T(x, dev)[idx], want, "vals[idx]")
+    ii = idx.cpu().numpy()
+    for b, n in pi:
+        assert sorted(ii[b:b + n].tolist()) == list(range(b, b + n))      # a permutation inside every pack
+    assert P.packed_sort_qsort(T(x, dev).clone(), T(pi, dev), False) is None
+
+
+@pytest.mark.parametrize("eps,thre", [(1e-4, 0.0), (1e-2, 0.05), (0.0, 0.0)])
+def test_alpha_to_vw(oracle, dev, P, eps, thre):
+    rng = np.random.default_rng(17)
+    pi, S = random_packs(rng, 257, 0, 300, 0.1)
+    alpha = (rng.uniform(0, 1, S) ** 3).astype(np.float32)
+    alpha[rng.random(S) < 0.1] = 0.0
+    alpha[rng.random(S) < 0.02] = 1.0
+    if thre > 0:
+        alpha[rng.random(S) < 0.05] = np.float32(thre)                  # exactly on the threshold: fwd <=, bwd <
+    w, _, _ = P.packed_alpha_to_vw_forward(T(alpha, dev), T(pi, dev), eps, thre, False)
+    rw, _, _ = oracle.packed_alpha_to_vw_forward(alpha, pi, eps, thre, False)
+    assert_equal(w, rw, "weights")                                      # serial T replayed exactly
+    _, cpi, sel = P.packed_alpha_to_vw_forward(T(alpha, dev), T(pi, dev), eps, thre, True)
+    _, rcpi, rsel = oracle.packed_alpha_to_vw_forward(alpha, pi, eps, thre, True)
+    assert sel.dtype == torch.bool and cpi.dtype == torch.int64
+    assert_equal(sel, rsel, "compact_selector"); assert_equal(cpi, rcpi, "compact_pack_infos")
+    gw = rng.standard_normal(S).astype(np.float32)
+    ga = P.packed_alpha_to_vw_backward(T(rw, dev), T(gw, dev), T(alpha, dev), T(pi, dev), eps, thre)
+    assert_close(ga, oracle.packed_alpha_to_vw_backward(rw, gw, alpha, pi, eps, thre), rel=2e-5, name="grad_alphas")
+
+
+def test_autograd_wrappers(oracle, dev):
+    """gradients of the pack_ops.py autograd layer against dense torch autograd on equal-length packs
+    (the reference's own strategy, unit_test.py:100-131, 203-210)"""
+    import nr3d_lib_amd.graphics.pack_ops as po
+    torch.manual_seed(0)
+    npk, n, F = 12, 9, 3
+    pi = po.get_pack_infos_from_batch(npk, n, device=dev)
+    x = torch.rand(npk * n, F, device=dev, dtype=torch.float64) + 0.5
+    o = torch.rand(npk, F, device=dev, dtype=torch.float64) + 0.5
+    g = torch.randn(npk * n, F, device=dev, dtype=torch.float64)
+
+    def check(fn_packed, fn_dense, inputs, gout):
+        a = [t.clone().requires_grad_(True) for t in inputs]
+        b = [t.clone().requires_grad_(True) for t in inputs]
+        ya, yb = fn_packed(*a), fn_dense(*b)
+        torch.testing.assert_close(ya, yb.reshape(ya.shape), rtol=1e-10, atol=1e-12)
+        ga = torch.autograd.grad(ya, a, gout.reshape(ya.shape))
+        gb = torch.autograd.grad(yb, b, gout.reshape(yb.shape))
+        for u, v in zip(ga, gb):
+            torch.testing.assert_close(u, v, rtol=1e-9, atol=1e-11)
+
+    d = lambda t: t.view(npk, n, F)
+    check(lambda x: po.packed_sum(x, pi), lambda x: d(x).sum(1), [x], torch.randn(npk, F, device=dev, dtype=torch.float64))
+    check(lambda x: po.packed_cumsum(x, pi), lambda x: d(x).cumsum(1), [x], g)
+    check(lambda x: po.packed_cumsum(x, pi, reverse=True), lambda x: d(x).flip(1).cumsum(1).flip(1), [x], g)
+    check(lambda x: po.packed_cumprod(x, pi), lambda x: d(x).cumprod(1), [x], g)
+    check(lambda x: po.packed_diff(x, pi), lambda x: torch.cat([d(x).diff(dim=1), torch.zeros_like(d(x)[:, :1])], 1), [x], g)
+    check(lambda x, a: po.packed_diff(x, pi, pack_appends=a), lambda x, a: torch.cat([d(x), a[:, None]], 1).diff(dim=1), [x, o], g)
+    check(lambda x, a: po.packed_backward_diff(x, pi, pack_prepends=a), lambda x, a: torch.cat([a[:, None], d(x)], 1).diff(dim=1), [x, o], g)
+    check(lambda x: po.packed_backward_diff(x, pi), lambda x: torch.cat([torch.zeros_like(d(x)[:, :1]), d(x).diff(dim=1)], 1), [x], g)
+    for name, f in (("add", torch.add), ("sub", torch.sub), ("mul", torch.mul), ("div", torch.div)):
+        check(lambda x, o, name=name: getattr(po, f"packed_{name}")(x, o, pi), lambda x, o, f=f: f(d(x), o[:, None]), [x, o], g)
+    # alpha -> weights against the cumprod formulation
+    al = (torch.rand(npk * n, device=dev) * 0.8).float()
+
+    def dense_vw(a):
+        a = a.view(npk, n)
+        Tr = torch.cumprod(torch.cat([torch.ones_like(a[:, :1]), 1 - a[:, :-1]], 1), 1)
+        return (a * Tr).reshape(-1)
+    a1, a2 = al.clone().requires_grad_(True), al.clone().requires_grad_(True)
+    w1, w2 = po.packed_alpha_to_vw(a1, pi, early_stop_eps=0.0), dense_vw(a2)
+    torch.testing.assert_close(w1, w2, rtol=1e-5, atol=1e-7)
+    gw = torch.randn_like(w1)
+    torch.testing.assert_close(torch.autograd.grad(w1, a1, gw)[0], torch.autograd.grad(w2, a2, gw)[0], rtol=2e-4, atol=1e-6)
+    # compression helper
+    nidx_useful, cpi, pidx = po.packed_volume_render_compression(al, pi, early_stop_eps=0.05, alpha_thre=0.1)
+    assert cpi.dtype == torch.int64 and int(cpi[:, 1].sum()) == pidx.numel() and (cpi[:, 1] > 0).all()
+
+
+def test_merge_wrappers(oracle, dev):
+    """merge_two_packs_sorted* (pure-torch orchestration over the kernels): merged values sorted per pack"""
+    import nr3d_lib_amd.graphics.pack_ops as po
+    rng = np.random.default_rng(18)
+    nidx_a = np.sort(rng.choice(40, 25, replace=False))
+    nidx_b_sub = np.sort(rng.choice(nidx_a, 11, replace=False))
+    nidx_b_any = np.sort(rng.choice(40, 20, replace=False))
+
+    def mk(nidx):
+        n = rng.integers(1, 30, len(nidx))
+        pi = oracle.get_pack_infos_from_n(n)
+        v = np.concatenate([np.sort(rng.uniform(0, 1, int(k))) for k in n]).astype(np.float32)
+        return T(v, dev), T(pi, dev), T(nidx.astype(np.int64), dev)
+    va, pia, na = mk(nidx_a)
+    for nb, fn in ((nidx_b_sub, po.merge_two_packs_sorted_a_includes_b), (nidx_b_any, po.merge_two_packs_sorted),
+                   (nidx_a, po.merge_two_packs_sorted)):
+        vb, pib, nbt = mk(nb)
+        val, pim = fn(va, pia, na, vb, pib, nbt, return_val=True)
+        assert val.numel() == va.numel() + vb.numel()
+        for b, n in pim.tolist():
+            assert (val[b:b + n].diff() >= 0).all()
+        assert torch.equal(torch.sort(val)[0], torch.sort(torch.cat([va, vb]))[0])

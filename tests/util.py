@@ -1,0 +1,73 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+import torch
+
+# ---- tolerance of the fp32 parity contract (BASELINE.json north_star: "within 1e-5 rel fp32") -------------
+# Compared quantity: max |got - want| relative to max |want| (sums with cancellation make an elementwise
+# relative error meaningless); elementwise rtol for well-conditioned outputs.
+REL_TOL = 1e-5
+
+
+def assert_close(got, want, rel=REL_TOL, name=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
+    scale = max(float(np.abs(want).max()) if want.size else 0.0, 1e-30)
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()) if want.size else 0.0
+    assert err <= rel * scale, f"{name}: max abs err {err:.3e} > {rel:g} * max|ref| ({scale:.3e})"
+
+
+def assert_equal(got, want, name=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
+    assert np.array_equal(got, want), f"{name}: {int((got != want).sum())} of {want.size} entries differ"
+
+
+# ---- LoTD test metas ------------------------------------------------------------------------------------
+LOTD_CASES = {
+    # name: (D, lod_res, n_feats, types, hashmap_size, smoothstep)
+    "ngp_small": (3, [8, 11, 15, 21, 29, 40, 55, 76], [2] * 8, ["Dense"] * 4 + ["Hash"] * 4, 2 ** 12, False),
+    "ngp_smooth": (3, [8, 13, 21, 34, 55], [2] * 5, ["Dense", "Dense", "Hash", "Hash", "Hash"], 2 ** 11, True),
+    "hash_npow2": (3, [9, 17, 33], [4, 4, 4], ["Dense", "Hash", "Hash"], 3001, False),
+    "dense_f8": (3, [6, 9], [8, 8], ["Dense", "Dense"], None, False),
+    "dense_2d": (2, [16, 33], [2, 4], ["Dense", "Hash"], 257, False),
+    "hash_4d": (4, [5, 9], [2, 2], ["Dense", "Hash"], 2 ** 10, False),
+    "mixed": (3, [8, 12, 10, 14, 9, 16, 11, 13], [4, 4, 8, 4, 2, 16, 8, 4],
+              ["Dense", "Dense", "VM", "VM", "VM", "CP", "CP", "CP"], None, False),
+    "mixed_cuboid": (3, [[8, 6, 5], [12, 9, 7], [10, 8, 6], [14, 11, 9], [9, 7, 6], [16, 12, 8]],
+                     [4, 4, 8, 4, 2, 16], ["Dense", "Dense", "VM", "VM", "CP", "CP"], None, False),
+    "mixed_smooth": (3, [7, 9, 8, 10], [2, 2, 2, 2], ["Dense", "VM", "CP", "Hash"], 509, True),
+    "nplane": (3, [8, 9, 7, 10], [2, 4, 2, 2], ["NPlaneMul", "NPlaneSum", "CPfast", "VecZMatXoY"], None, False),
+    "nplane_smooth": (3, [8, 9, 7], [2, 2, 4], ["NPlaneSum", "CPfast", "NPlaneMul"], None, True),
+    "cp_2d": (2, [9, 12], [2, 2], ["CP", "CPfast"], None, False),
+    "cp_4d": (4, [5, 6, 4], [2, 2, 2], ["CP", "NPlaneMul", "CPfast"], None, False),
+}
+
+
+def lotd_inputs(meta_dict, n_points, seed, param_scale=0.1, n_batch=1):
+    """seeded inputs kept away from exact cell boundaries (x*(R-2)+0.5 never within 1e-3 of an integer) so that
+    fp32 last-bit differences cannot move a point into another cell"""
+    rng = np.random.default_rng(seed)
+    D = meta_dict["n_dims_to_encode"]
+    x = rng.random((n_points, D)).astype(np.float32).clip(1e-6, 1 - 1e-6)
+    for _ in range(8):
+        bad = np.zeros(n_points, bool)
+        for res in meta_dict["level_res_multidim"]:
+            v = x.astype(np.float64) * (np.array(res) - 2) + 0.5
+            bad |= (np.abs(v - np.round(v)) < 1e-3).any(1)
+        if not bad.any():
+            break
+        x[bad] = rng.random((int(bad.sum()), D)).astype(np.float32).clip(1e-6, 1 - 1e-6)
+    params = (rng.standard_normal(meta_dict["n_params"] * n_batch) * param_scale).astype(np.float32)
+    dL_dy = (rng.standard_normal((n_points, meta_dict["n_encoded_dims"])) * 0.1).astype(np.float32)
+    dL_ddLdx = rng.standard_normal((n_points, D)).astype(np.float32)
+    return x, params, dL_dy, dL_ddLdx
+
+
+def random_packs(rng, n_packs, lo, hi, empty_frac=0.0):
+    n = rng.integers(lo, hi + 1, n_packs).astype(np.int64)
+    if empty_frac > 0:
+        n[rng.random(n_packs) < empty_frac] = 0
+    cs = np.cumsum(n)
+    return np.ascontiguousarray(np.stack([cs - n, n], 1)), int(cs[-1])
