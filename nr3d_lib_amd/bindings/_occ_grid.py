@@ -85,10 +85,12 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
         ridx = torch.empty(S, dtype=torch.int32, device=dev)
         bidx = torch.empty(S, dtype=torch.int32, device=dev) if batched else None
         gidx = torch.empty(S, dtype=torch.int32, device=dev) if return_gidx else None
-        H.check(H.lib().nr3d_ray_marching_emit(
-            H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
-            ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), C.c_int(int(batched)), H.ptr(batch_inds),
-            H.u32(bds), H.ptr(packed_info), H.ptr(t_starts), H.ptr(t_ends), H.ptr(ridx), H.ptr(bidx), H.ptr(gidx), st))
+        if S > 0:
+            H.check(H.lib().nr3d_ray_marching_emit(
+                H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res,
+                H.ptr(grid_binary), ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma),
+                C.c_int(int(batched)), H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(t_starts),
+                H.ptr(t_ends), H.ptr(ridx), H.ptr(bidx), H.ptr(gidx), st))
     if batched:
         return [packed_info, t_starts, t_ends, ridx, bidx, gidx]
     return [packed_info, t_starts, t_ends, ridx, gidx]

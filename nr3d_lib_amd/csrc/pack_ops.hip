@@ -464,11 +464,17 @@ __global__ __launch_bounds__(kBlock) void k_alpha_bwd(uint32_t P, const float *_
                                                       float *__restrict__ grad_alphas) {
 	const Pack k = my_pack(P, pi);
 	if (!k.valid) return;
-	// accum = sum_j gw_j * w_j  (wave reduction; order differs from the reference's serial sum)
+	// accum = sum_j gw_j * w_j in the reference's serial order (fma chain): the backward divides by
+	// max(1 - alpha, 1e-10), so for alpha == 1 a last-bit difference in accum is amplified by 1e10
 	float accum = 0.0f;
-	for (uint32_t i = k.lane; i < k.len; i += 64) accum = __fmaf_rn(grad_weights[k.begin + i], weights[k.begin + i], accum);
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1) accum += shfl_xor_t<float>(accum, m);
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		const bool mine = (uint32_t)k.lane < n;
+		const float gw_mine = mine ? grad_weights[k.begin + base + k.lane] : 0.0f;
+		const float w_mine = mine ? weights[k.begin + base + k.lane] : 0.0f;
+		for (uint32_t j = 0; j < n; ++j)
+			accum = __fmaf_rn(shfl_t<float>(gw_mine, (int)j), shfl_t<float>(w_mine, (int)j), accum);
+	}
 	float T = 1.0f;
 	bool stopped = false;
 	for (uint32_t base = 0; base < k.len; base += 64) {
