@@ -205,6 +205,30 @@ def _check_common(fn, meta, input, params, batch_inds, batch_offsets, batch_data
     return N, bds
 
 
+# scratch for the atomic-free parameter-gradient path, grown on demand, one buffer per (device, stream)
+_workspaces = {}
+USE_BINNED_DPARAM = True      # False forces the hardware-atomic scatter (debug / A-B measurements)
+
+
+def _dparam_workspace(meta, n_points, device):
+    """(tensor | None, nbytes): device scratch for nr3d_lotd_bwd_dparam's binned path; (None, 0) when that path
+    does not apply to this meta."""
+    if not USE_BINNED_DPARAM:
+        return None, 0
+    H.lib().nr3d_lotd_dparam_workspace_bytes.restype = C.c_uint64
+    need = int(H.lib().nr3d_lotd_dparam_workspace_bytes(C.byref(meta._cmeta()), H.u32(n_points)))
+    if need == 0:
+        return None, 0
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = None
+        _workspaces.pop(key, None)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws, need
+
+
 def _f32c(t):
     """fp32 working copy (no-op for fp32 tensors)"""
     return t if t.dtype == torch.float32 else t.float()
@@ -329,10 +353,13 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                     H.i64(gse), H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), st))
             if need_param_grad and N > 0:
                 x32, p32 = _f32c(input.detach()), _f32c(params.detach())
+                batched = batch_inds is not None or batch_offsets is not None or bds != 0
+                ws, wsb = (None, 0) if batched else _dparam_workspace(m, N, dev)
                 H.check(H.lib().nr3d_lotd_bwd_dparam(
                     C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
                     H.ptr(g32), H.i64(gsn), H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
-                    H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparam), st))
+                    H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparam), H.ptr(ws),
+                    C.c_uint64(wsb), st))
     return _cast(dL_dx, input.dtype), _cast(dL_dparam, params.dtype)
 
 
@@ -397,10 +424,12 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
                     H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
                     H.i32(max_level), H.ptr(dL_dx), st))
             if need_dp:
+                batched = batch_inds is not None or batch_offsets is not None or bds != 0
+                ws, wsb = (None, 0) if batched else _dparam_workspace(m, N, dev)
                 H.check(H.lib().nr3d_lotd_bwd_bwd_dparam(
                     cm, md, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(g32), H.i64(gsn),
                     H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
-                    H.i32(max_level), H.ptr(dL_dparams), st))
+                    H.i32(max_level), H.ptr(dL_dparams), H.ptr(ws), C.c_uint64(wsb), st))
     return _cast(dL_ddLdy, dL_dy.dtype), _cast(dL_dparams, params.dtype), _cast(dL_dx, input.dtype)
 
 

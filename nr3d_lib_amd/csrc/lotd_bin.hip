@@ -1,0 +1,357 @@
+// nr3d_lib_amd/csrc/lotd_bin.hip -- dL/dparam and d(dL/dx)/dparam for Dense/Hash LoTD levels WITHOUT global atomics.
+//
+// Why: measured on MI355X (tools/ubench_mem.hip, tools/ubench_lds.hip, profiles/) every global atomic flavour
+// (f32/u32/u64/f64/pk_f16, any scope, any table size) saturates at ~21-27 G atomics/s chip-wide, so the
+// reference's scatter (2^20 pts x 16 levels x 8 corners x 2 feats = 268 M atomicAdds,
+// kernel_lod_hashonly_backward_grid, lotd_hash_only.h:380-470) costs >= 12.8 ms.  LDS ds_add_f64 sustains
+// ~1.3-1.5 T/s at random addresses (ds_add_f32 only ~0.2 T/s).  So the scatter is reorganised as
+//
+//   stage A  k_bin    one workgroup = 512 points x 1 pseudo-level: compute the 2^D corner updates, counting-sort
+//                     them by table BUCKET (a bucket = the slice of the level's table whose fp64 accumulators fit
+//                     one CU's LDS: 16384/G entries) inside the workgroup and write them as SoA records
+//                     {local entry, value[G]} plus the per-bucket start offsets;
+//   stage B  k_accum  one workgroup = one bucket (x an optional replica that takes a share of the point blocks):
+//                     stream that bucket's records (contiguous runs), accumulate into a 128 KiB fp64 LDS table with
+//                     ds_add_f64, then write the slice of dL/dparam once (plain stores; f32 atomics only for the
+//                     few replicated small levels).
+//
+// Both stages are pure streaming (12 B per corner update written once and read once); the fp64 accumulation makes
+// the result independent of the update order up to the final f64->f32 rounding.
+#include "lotd_device.h"
+#include <stdlib.h>
+
+namespace nr3d {
+namespace lotd {
+
+constexpr int kBinPts = 512;              // points per stage-A workgroup
+constexpr int kAccThreads = 1024;         // stage-B workgroup
+constexpr int kLdsDoubles = 16384;        // 128 KiB of fp64 accumulators
+constexpr int kMaxPlanLevels = 64;        // pseudo levels handled by the binned path
+constexpr uint32_t kMaxBuckets = 8192;    // per pseudo level
+
+#define DISPATCH_DG_BIN(D_, G_, ...)                                                 \
+	do {                                                                             \
+		const uint32_t _d = (D_), _g = (G_);                                         \
+		if (_d == 2 && _g == 2) { constexpr int D = 2, G = 2; __VA_ARGS__; }         \
+		else if (_d == 2 && _g == 4) { constexpr int D = 2, G = 4; __VA_ARGS__; }    \
+		else if (_d == 2 && _g == 8) { constexpr int D = 2, G = 8; __VA_ARGS__; }    \
+		else if (_d == 3 && _g == 2) { constexpr int D = 3, G = 2; __VA_ARGS__; }    \
+		else if (_d == 3 && _g == 4) { constexpr int D = 3, G = 4; __VA_ARGS__; }    \
+		else if (_d == 3 && _g == 8) { constexpr int D = 3, G = 8; __VA_ARGS__; }    \
+		else if (_d == 4 && _g == 2) { constexpr int D = 4, G = 2; __VA_ARGS__; }    \
+		else if (_d == 4 && _g == 4) { constexpr int D = 4, G = 4; __VA_ARGS__; }    \
+		else { constexpr int D = 4, G = 8; __VA_ARGS__; }                            \
+	} while (0)
+
+struct BinPlan {
+	uint32_t nb[kMaxPlanLevels];          // buckets per pseudo level
+	uint32_t rep[kMaxPlanLevels];         // replicas per bucket (stage B)
+	uint32_t offs_base[kMaxPlanLevels];   // start of this pseudo level's offset table (in uint32 units)
+	uint32_t epb_log2;                    // log2(entries per bucket)
+	uint32_t n_blk;                       // stage-A workgroups along the points of the current chunk
+	uint32_t n_pseudo;
+};
+
+// -------------------------------------------------------------------------------------------------
+// [n, E] row-major -> [E, n] (32x32 LDS tiles), so the level-major stage A reads its G columns coalesced
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose(uint32_t n, uint32_t E, const float *__restrict__ src, int64_t s_sn,
+                                                   int64_t s_se, float *__restrict__ dst) {
+	__shared__ float tile[32][33];
+	const uint32_t i0 = blockIdx.x * 32, e0 = blockIdx.y * 32;
+	const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+	for (int k = 0; k < 32; k += 8) {
+		const uint32_t i = i0 + ty + k, e = e0 + tx;
+		tile[ty + k][tx] = (i < n && e < E) ? src[(int64_t)i * s_sn + (int64_t)e * s_se] : 0.0f;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < 32; k += 8) {
+		const uint32_t e = e0 + ty + k, i = i0 + tx;
+		if (i < n && e < E) dst[(size_t)e * n + i] = tile[tx][ty + k];
+	}
+}
+
+// -------------------------------------------------------------------------------------------------
+// Stage A: bin the corner updates of 512 points x 1 pseudo level by bucket
+// -------------------------------------------------------------------------------------------------
+template <int D, int G, bool SECOND>
+__global__ __launch_bounds__(kBinPts) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                 int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                 const float *__restrict__ vin_, const float *__restrict__ g,
+                                                 int64_t g_sn, int64_t g_se, uint32_t *__restrict__ rec,
+                                                 uint32_t *__restrict__ offs_g) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [nb + 1]
+	__shared__ uint64_t scan_lds[kBinPts / 64];
+	constexpr int C = 1 << D;
+	const uint32_t blk = blockIdx.x, q = blockIdx.y;
+	const uint32_t nb = plan.nb[q];
+	const uint32_t level = md->map_levels[q];
+	const uint32_t i = blk * kBinPts + threadIdx.x;
+	const Lvl L = load_level(md, level);
+
+	for (uint32_t b = threadIdx.x; b <= nb; b += kBinPts) hist[b] = 0;
+	__syncthreads();
+
+	const bool active = (i < n) && ((int32_t)level <= max_level);
+	uint32_t ent[C], rank[C];
+	float w[C], grad[G];
+	if (active) {
+		float xp[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
+		Cell<D> c;
+		locate<D>(xp, L, smooth != 0, c);
+#pragma unroll
+		for (int f = 0; f < G; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(q * G + f) * g_se];
+		float a[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) a[d] = SECOND ? c.sc[d] * vin_[(size_t)i * D + d] * c.dw[d] : 0.0f;
+#pragma unroll
+		for (uint32_t k = 0; k < (uint32_t)C; ++k) {
+			if (!SECOND) {
+				w[k] = corner_weight<D>(c, k);
+			} else {
+				float s = 0.0f;
+#pragma unroll
+				for (int d = 0; d < D; ++d) {
+					const float t = face_weight<D>(c, k, d, a[d]);
+					s += ((k >> d) & 1u) ? t : -t;
+				}
+				w[k] = s;
+			}
+			uint32_t p[D];
+			corner_pos<D>(c, k, p);
+			ent[k] = (L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p);
+			rank[k] = atomicAdd(&hist[ent[k] >> plan.epb_log2], 1u);
+		}
+	}
+	__syncthreads();
+
+	// exclusive scan of the bucket histogram (in place); hist[nb] = total
+	uint64_t carry = 0;
+	for (uint32_t base = 0; base <= nb; base += kBinPts) {
+		const uint32_t b = base + threadIdx.x;
+		const uint64_t v = (b < nb) ? hist[b] : 0;
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		uint64_t inc = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint64_t t = __shfl_up(inc, off, 64);
+			if (lane >= off) inc += t;
+		}
+		if (lane == 63) scan_lds[wave] = inc;
+		__syncthreads();
+		uint64_t wave_off = 0, tot = 0;
+#pragma unroll
+		for (int k = 0; k < kBinPts / 64; ++k) { const uint64_t s = scan_lds[k]; if (k < wave) wave_off += s; tot += s; }
+		if (b <= nb) hist[b] = (uint32_t)(carry + wave_off + inc - v);
+		carry += tot;
+		__syncthreads();
+	}
+
+	// records of this (pseudo level, point block): SoA [1 + G][kBinPts * C]
+	constexpr uint32_t cap = kBinPts * C;
+	uint32_t *r_idx = rec + ((size_t)q * plan.n_blk + blk) * (size_t)(1 + G) * cap;
+	float *r_val = reinterpret_cast<float *>(r_idx + cap);
+	if (active) {
+		const uint32_t mask = (1u << plan.epb_log2) - 1u;
+#pragma unroll
+		for (uint32_t k = 0; k < (uint32_t)C; ++k) {
+			const uint32_t pos = hist[ent[k] >> plan.epb_log2] + rank[k];
+			r_idx[pos] = ent[k] & mask;
+#pragma unroll
+			for (int f = 0; f < G; ++f) r_val[(size_t)f * cap + pos] = grad[f] * w[k];
+		}
+	}
+	uint32_t *ob = offs_g + plan.offs_base[q];
+	for (uint32_t b = threadIdx.x; b <= nb; b += kBinPts) ob[(size_t)b * plan.n_blk + blk] = hist[b];
+}
+
+// -------------------------------------------------------------------------------------------------
+// Stage B: one bucket (x replica) -> fp64 LDS accumulation -> slice of dL/dparam
+// -------------------------------------------------------------------------------------------------
+template <int D, int G>
+__global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
+                                                       const uint32_t *__restrict__ rec,
+                                                       const uint32_t *__restrict__ offs_g,
+                                                       float *__restrict__ dparam) {
+	extern __shared__ __attribute__((aligned(16))) double acc[];      // [kLdsDoubles]
+	constexpr uint32_t cap = kBinPts << D;
+	const uint32_t q = blockIdx.y;
+	const uint32_t nb = plan.nb[q], R = plan.rep[q];
+	if (blockIdx.x >= nb * R) return;
+	const uint32_t b = blockIdx.x / R, r = blockIdx.x - b * R;
+	const uint32_t level = md->map_levels[q];
+	const Lvl L = load_level(md, level);
+	const uint32_t foff0 = (uint32_t)md->map_cnt[q] * G;
+
+	for (uint32_t t = threadIdx.x; t < (uint32_t)kLdsDoubles; t += kAccThreads) acc[t] = 0.0;
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	constexpr uint32_t n_waves = kAccThreads / 64;
+	const uint32_t blk_lo = (uint32_t)(((uint64_t)plan.n_blk * r) / R), blk_hi = (uint32_t)(((uint64_t)plan.n_blk * (r + 1)) / R);
+	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)b * plan.n_blk;
+	const uint32_t *ob1 = ob0 + plan.n_blk;
+	// the point blocks of this replica are split evenly over the waves; per step a wave takes up to 64 of its blocks:
+	// lane t fetches the [start, end) of block blk0 + t (coalesced), then the wave walks the runs one after another
+	// with all lanes on the records of one run
+	const uint32_t per_wave = (blk_hi - blk_lo + n_waves - 1) / n_waves;
+	const uint32_t w_lo = min(blk_lo + wave * per_wave, blk_hi), w_hi = min(w_lo + per_wave, blk_hi);
+	for (uint32_t blk0 = w_lo; blk0 < w_hi; blk0 += 64) {
+		const uint32_t mb = blk0 + lane;
+		const uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
+		const uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
+		const uint32_t cnt = min(64u, w_hi - blk0);
+		for (uint32_t j = 0; j < cnt; ++j) {
+			const uint32_t s = __shfl(s_l, (int)j, 64), e = __shfl(e_l, (int)j, 64);
+			const uint32_t *r_idx = rec + ((size_t)q * plan.n_blk + (blk0 + j)) * (size_t)(1 + G) * cap;
+			const float *r_val = reinterpret_cast<const float *>(r_idx + cap);
+			for (uint32_t p = s + lane; p < e; p += 64) {
+				const uint32_t idx = r_idx[p];
+#pragma unroll
+				for (int f = 0; f < G; ++f) atomicAdd(&acc[idx * G + f], (double)r_val[(size_t)f * cap + p]);
+			}
+		}
+	}
+	__syncthreads();
+
+	const uint32_t epb = 1u << plan.epb_log2;
+	float *dst = dparam + L.off;
+	for (uint32_t t = threadIdx.x; t < epb * G; t += kAccThreads) {
+		const uint32_t el = t / G, f = t - el * G;
+		const uint32_t entry = b * epb + el;
+		if (entry >= L.size) continue;
+		const float v = (float)acc[t];
+		float *p = dst + ((size_t)entry * L.F + foff0 + f);
+		if (R == 1) *p += v;                       // this workgroup is the only writer of the slice
+		else if (v != 0.0f) atomic_add_f32(p, v);
+	}
+}
+
+// -------------------------------------------------------------------------------------------------
+// Host side
+// -------------------------------------------------------------------------------------------------
+static uint32_t chunk_points(uint32_t n) {
+	static uint32_t chunk = 0;
+	if (!chunk) {
+		const char *e = getenv("NR3D_LOTD_BIN_CHUNK_LOG2");
+		const int lg = e ? atoi(e) : 20;
+		chunk = 1u << (lg < 12 ? 12 : (lg > 24 ? 24 : lg));
+	}
+	return n < chunk ? n : chunk;
+}
+
+static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinPlan &plan, uint64_t &offs_words) {
+	const uint32_t G = m->n_feat_per_pseudo_lvl;
+	if (m->n_pseudo_levels > kMaxPlanLevels || !m->c_hash_only) return false;
+	uint32_t lg = 0;
+	while ((1u << (lg + 1)) <= (uint32_t)kLdsDoubles / G) ++lg;
+	plan.epb_log2 = lg;
+	plan.n_blk = div_up(n_chunk, kBinPts);
+	plan.n_pseudo = m->n_pseudo_levels;
+	uint64_t base = 0;
+	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
+		const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
+		const uint32_t nb = div_up(L.size, 1u << lg);
+		if (nb > kMaxBuckets) return false;
+		plan.nb[q] = nb;
+		// enough stage-B workgroups per level to spread over the chip, never more replicas than point blocks
+		uint32_t rep = nb >= 32 ? 1u : div_up(32, nb);
+		if (rep > plan.n_blk) rep = plan.n_blk ? plan.n_blk : 1u;
+		plan.rep[q] = rep;
+		if (base > 0xFFFFFFFFull) return false;
+		plan.offs_base[q] = (uint32_t)base;
+		base += (uint64_t)(nb + 1) * plan.n_blk;
+	}
+	offs_words = base;
+	return true;
+}
+
+struct BinLayout { uint64_t rec_bytes, offs_bytes, gt_bytes, total; };
+
+static BinLayout layout(const nr3d_lotd_meta_t *m, const BinPlan &plan, uint64_t offs_words, uint32_t n_chunk) {
+	BinLayout l;
+	const uint64_t cap = (uint64_t)kBinPts << m->n_dims_to_encode;
+	l.rec_bytes = (uint64_t)m->n_pseudo_levels * plan.n_blk * (1 + m->n_feat_per_pseudo_lvl) * cap * 4;
+	l.offs_bytes = ((offs_words * 4 + 255) / 256) * 256;
+	l.gt_bytes = (((uint64_t)m->n_encoded_dims * n_chunk * 4 + 255) / 256) * 256;
+	l.total = l.rec_bytes + l.offs_bytes + l.gt_bytes;
+	return l;
+}
+
+// returns 0 when the binned path does not apply (caller falls back to the atomic kernels)
+uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points) {
+	if (!m || n_points == 0) return 0;
+	BinPlan plan;
+	uint64_t offs_words;
+	const uint32_t nc = chunk_points(n_points);
+	if (!make_plan(m, nc, plan, offs_words)) return 0;
+	return layout(m, plan, offs_words, nc).total;
+}
+
+int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
+                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, int32_t max_level, float *dparam,
+                  void *workspace, uint64_t workspace_bytes, hipStream_t st, bool &handled) {
+	handled = false;
+	BinPlan plan;
+	uint64_t offs_words;
+	const uint32_t nc = chunk_points(N);
+	if (!workspace || !make_plan(meta, nc, plan, offs_words)) return 0;
+	const BinLayout lay = layout(meta, plan, offs_words, nc);
+	if (workspace_bytes < lay.total) return 0;
+	handled = true;
+	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
+	const uint32_t D = meta->n_dims_to_encode, G = meta->n_feat_per_pseudo_lvl, E = meta->n_encoded_dims;
+	uint32_t *rec = (uint32_t *)workspace;
+	uint32_t *offs = (uint32_t *)((char *)workspace + lay.rec_bytes);
+	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes);
+	uint32_t nb_max = 0, acc_max = 0;
+	for (uint32_t q = 0; q < plan.n_pseudo; ++q) {
+		nb_max = nb_max > plan.nb[q] ? nb_max : plan.nb[q];
+		const uint32_t a = plan.nb[q] * plan.rep[q];
+		acc_max = acc_max > a ? acc_max : a;
+	}
+	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && E > 1);
+
+	for (uint32_t p0 = 0; p0 < N; p0 += nc) {
+		const uint32_t n = (N - p0) < nc ? (N - p0) : nc;
+		BinPlan pl = plan;
+		if (n != nc) {   // last, shorter chunk: fewer point blocks (offset tables shrink, bases stay valid upper bounds)
+			uint64_t ow;
+			make_plan(meta, n, pl, ow);
+		}
+		const float *xc = x + (size_t)p0 * D;
+		const float *vc = dL_ddLdx ? dL_ddLdx + (size_t)p0 * D : nullptr;
+		const float *gc = dL_dy + (int64_t)p0 * g_sn;
+		int64_t sn = g_sn, se = g_se;
+		if (row_major) {
+			hipLaunchKernelGGL(k_transpose, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, gc, g_sn, g_se, gt);
+			gc = gt; sn = 1; se = (int64_t)n;
+		}
+		const size_t hist_bytes = ((size_t)nb_max + 1) * sizeof(uint32_t);
+		DISPATCH_DG_BIN(D, G, {
+			if (second)
+				hipLaunchKernelGGL((k_bin<D, G, true>), dim3(pl.n_blk, pl.n_pseudo), dim3(kBinPts), hist_bytes, st, pl, md, n,
+				                   max_level, meta->interpolation_type, xc, vc, gc, sn, se, rec, offs);
+			else
+				hipLaunchKernelGGL((k_bin<D, G, false>), dim3(pl.n_blk, pl.n_pseudo), dim3(kBinPts), hist_bytes, st, pl, md, n,
+				                   max_level, meta->interpolation_type, xc, vc, gc, sn, se, rec, offs);
+			static bool attr_set = false;
+			if (!attr_set) {
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+				                                   kLdsDoubles * 8));
+				attr_set = true;
+			}
+			hipLaunchKernelGGL((k_accum<D, G>), dim3(acc_max, pl.n_pseudo), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md,
+			                   rec, offs, dparam);
+		});
+		NR3D_LAUNCH_CHECK();
+	}
+	return 0;
+}
+
+}  // namespace lotd
+}  // namespace nr3d

@@ -84,6 +84,32 @@ def test_grid_index_bit_exact(oracle, dev, case):
     assert float(y.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "hash_npow2", "dense_f8", "dense_2d", "hash_4d"])
+def test_dparam_atomic_and_binned_paths_agree(oracle, dev, case):
+    """the default (binned, fp64 LDS accumulation) and the hardware-atomic scatter must both match the oracle,
+    including a point count that is not a multiple of the 512-point bin blocks and spans several of them"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=9)
+    ref1 = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
+    ref2 = oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True)
+    for binned in (True, False):
+        _lotd.USE_BINNED_DPARAM = binned
+        try:
+            _, dp = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
+            _, dp2, _ = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False,
+                                                need_dLdinput_dparams=True, need_dLdinput_dinput=False)
+        finally:
+            _lotd.USE_BINNED_DPARAM = True
+        assert_close(dp, ref1, name=f"dL_dparam binned={binned}")
+        assert_close(dp2, ref2, name=f"2nd dparam binned={binned}")
+        # max_level restricts the scatter to the coarse levels
+        _lotd.USE_BINNED_DPARAM = binned
+        try:
+            _, dp3 = _lotd.lod_bwd(m, gt, xt, pt, None, max_level=0, need_input_grad=False, need_param_grad=True)
+        finally:
+            _lotd.USE_BINNED_DPARAM = True
+        assert_close(dp3, oracle.lotd_bwd_dparam(m_ref, g, x, p, max_level=0, accum_double=True), name="max_level=0")
+
+
 def test_grid_index_rejects_other_types(oracle, dev):
     _lotd, m_ref, m, _, (xt, *_r) = _setup(oracle, dev, "mixed")
     with pytest.raises(RuntimeError, match="Only support Dense/Hash"):
