@@ -23,7 +23,6 @@
 namespace nr3d {
 namespace lotd {
 
-constexpr int kBinPts = 512;              // points per stage-A workgroup
 constexpr int kAccThreads = 1024;         // stage-B workgroup
 constexpr int kLdsDoubles = 16384;        // 128 KiB of fp64 accumulators
 constexpr int kMaxPlanLevels = 64;        // pseudo levels handled by the binned path
@@ -74,24 +73,37 @@ __global__ __launch_bounds__(256) void k_transpose(uint32_t n, uint32_t E, const
 }
 
 // -------------------------------------------------------------------------------------------------
-// Stage A: bin the corner updates of 512 points x 1 pseudo level by bucket
+// Stage A: bin the corner updates of BP points x 1 pseudo level by bucket.
+// BP (points = threads per workgroup) is the largest power of two whose record staging area
+// ((1 + G) words x BP x 2^D records) fits in 64 KiB of LDS, so 2 workgroups share a CU.
 // -------------------------------------------------------------------------------------------------
+template <int D, int G>
+struct BinCfg {
+	static constexpr int raw = 16384 / ((1 + G) * (1 << D));
+	static constexpr int BP = raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
+	static constexpr uint32_t cap = (uint32_t)BP << D;          // records per (pseudo level, point block)
+};
+
 template <int D, int G, bool SECOND>
-__global__ __launch_bounds__(kBinPts) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
-                                                 int32_t max_level, uint32_t smooth, const float *__restrict__ x,
-                                                 const float *__restrict__ vin_, const float *__restrict__ g,
-                                                 int64_t g_sn, int64_t g_se, uint32_t *__restrict__ rec,
-                                                 uint32_t *__restrict__ offs_g) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t hist[];   // [nb + 1]
-	__shared__ uint64_t scan_lds[kBinPts / 64];
+__global__ __launch_bounds__((BinCfg<D, G>::BP)) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                          int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                          const float *__restrict__ vin_, const float *__restrict__ g,
+                                                          int64_t g_sn, int64_t g_se, uint32_t *__restrict__ rec,
+                                                          uint32_t *__restrict__ offs_g) {
+	constexpr int BP = BinCfg<D, G>::BP;
+	constexpr uint32_t cap = BinCfg<D, G>::cap;
 	constexpr int C = 1 << D;
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // stage[(1+G)*cap] | hist[nb + 1]
+	__shared__ uint64_t scan_lds[BP / 64 > 0 ? BP / 64 : 1];
+	uint32_t *stage = smem;
+	uint32_t *hist = smem + (size_t)(1 + G) * cap;
 	const uint32_t blk = blockIdx.x, q = blockIdx.y;
 	const uint32_t nb = plan.nb[q];
 	const uint32_t level = md->map_levels[q];
-	const uint32_t i = blk * kBinPts + threadIdx.x;
+	const uint32_t i = blk * BP + threadIdx.x;
 	const Lvl L = load_level(md, level);
 
-	for (uint32_t b = threadIdx.x; b <= nb; b += kBinPts) hist[b] = 0;
+	for (uint32_t b = threadIdx.x; b <= nb; b += BP) hist[b] = 0;
 	__syncthreads();
 
 	const bool active = (i < n) && ((int32_t)level <= max_level);
@@ -113,13 +125,13 @@ __global__ __launch_bounds__(kBinPts) void k_bin(BinPlan plan, const nr3d_lotd_m
 			if (!SECOND) {
 				w[k] = corner_weight<D>(c, k);
 			} else {
-				float s = 0.0f;
+				float sum = 0.0f;
 #pragma unroll
 				for (int d = 0; d < D; ++d) {
 					const float t = face_weight<D>(c, k, d, a[d]);
-					s += ((k >> d) & 1u) ? t : -t;
+					sum += ((k >> d) & 1u) ? t : -t;
 				}
-				w[k] = s;
+				w[k] = sum;
 			}
 			uint32_t p[D];
 			corner_pos<D>(c, k, p);
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(kBinPts) void k_bin(BinPlan plan, const nr3d_lotd_m
 
 	// exclusive scan of the bucket histogram (in place); hist[nb] = total
 	uint64_t carry = 0;
-	for (uint32_t base = 0; base <= nb; base += kBinPts) {
+	for (uint32_t base = 0; base <= nb; base += BP) {
 		const uint32_t b = base + threadIdx.x;
 		const uint64_t v = (b < nb) ? hist[b] : 0;
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -141,32 +153,38 @@ __global__ __launch_bounds__(kBinPts) void k_bin(BinPlan plan, const nr3d_lotd_m
 			const uint64_t t = __shfl_up(inc, off, 64);
 			if (lane >= off) inc += t;
 		}
-		if (lane == 63) scan_lds[wave] = inc;
+		if (lane == 63 || (BP < 64 && lane == BP - 1)) scan_lds[wave] = inc;
 		__syncthreads();
 		uint64_t wave_off = 0, tot = 0;
 #pragma unroll
-		for (int k = 0; k < kBinPts / 64; ++k) { const uint64_t s = scan_lds[k]; if (k < wave) wave_off += s; tot += s; }
+		for (int k = 0; k < (BP + 63) / 64; ++k) { const uint64_t t = scan_lds[k]; if (k < wave) wave_off += t; tot += t; }
 		if (b <= nb) hist[b] = (uint32_t)(carry + wave_off + inc - v);
 		carry += tot;
 		__syncthreads();
 	}
 
-	// records of this (pseudo level, point block): SoA [1 + G][kBinPts * C]
-	constexpr uint32_t cap = kBinPts * C;
-	uint32_t *r_idx = rec + ((size_t)q * plan.n_blk + blk) * (size_t)(1 + G) * cap;
-	float *r_val = reinterpret_cast<float *>(r_idx + cap);
+	// counting-sort the records into the LDS staging area (SoA: idx | val[0] | ... | val[G-1])
 	if (active) {
 		const uint32_t mask = (1u << plan.epb_log2) - 1u;
 #pragma unroll
 		for (uint32_t k = 0; k < (uint32_t)C; ++k) {
 			const uint32_t pos = hist[ent[k] >> plan.epb_log2] + rank[k];
-			r_idx[pos] = ent[k] & mask;
+			stage[pos] = ent[k] & mask;
 #pragma unroll
-			for (int f = 0; f < G; ++f) r_val[(size_t)f * cap + pos] = grad[f] * w[k];
+			for (int f = 0; f < G; ++f) stage[(size_t)(1 + f) * cap + pos] = __float_as_uint(grad[f] * w[k]);
 		}
 	}
+	__syncthreads();
+
+	// coalesced 16-byte write-out of the filled prefix of every array
+	const uint32_t total = hist[nb];                          // multiple of 2^D >= 4
+	uint4 *dst = reinterpret_cast<uint4 *>(rec + ((size_t)q * plan.n_blk + blk) * (size_t)(1 + G) * cap);
+	const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+#pragma unroll
+	for (int arr = 0; arr <= G; ++arr)
+		for (uint32_t v4 = threadIdx.x; v4 < total / 4; v4 += BP) dst[(size_t)arr * (cap / 4) + v4] = src[(size_t)arr * (cap / 4) + v4];
 	uint32_t *ob = offs_g + plan.offs_base[q];
-	for (uint32_t b = threadIdx.x; b <= nb; b += kBinPts) ob[(size_t)b * plan.n_blk + blk] = hist[b];
+	for (uint32_t b = threadIdx.x; b <= nb; b += BP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
                                                        const uint32_t *__restrict__ offs_g,
                                                        float *__restrict__ dparam) {
 	extern __shared__ __attribute__((aligned(16))) double acc[];      // [kLdsDoubles]
-	constexpr uint32_t cap = kBinPts << D;
+	constexpr uint32_t cap = BinCfg<D, G>::cap;
 	const uint32_t q = blockIdx.y;
 	const uint32_t nb = plan.nb[q], R = plan.rep[q];
 	if (blockIdx.x >= nb * R) return;
@@ -195,24 +213,42 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 	const uint32_t blk_lo = (uint32_t)(((uint64_t)plan.n_blk * r) / R), blk_hi = (uint32_t)(((uint64_t)plan.n_blk * (r + 1)) / R);
 	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)b * plan.n_blk;
 	const uint32_t *ob1 = ob0 + plan.n_blk;
-	// the point blocks of this replica are split evenly over the waves; per step a wave takes up to 64 of its blocks:
-	// lane t fetches the [start, end) of block blk0 + t (coalesced), then the wave walks the runs one after another
-	// with all lanes on the records of one run
+	const uint32_t *rec_q = rec + (size_t)q * plan.n_blk * (size_t)(1 + G) * cap;
+	// The point blocks of this replica are split evenly over the waves.  Per step a wave takes up to 64 of its
+	// blocks: lane t fetches the run [start, end) of block blk0 + t (coalesced), a wave scan turns the run lengths
+	// into a prefix, and the lanes then walk the CONCATENATION of the 64 runs (all lanes busy, independent loads);
+	// the owning run of flat position t is found by a 6-step binary search over the prefix held in the lanes.
 	const uint32_t per_wave = (blk_hi - blk_lo + n_waves - 1) / n_waves;
 	const uint32_t w_lo = min(blk_lo + wave * per_wave, blk_hi), w_hi = min(w_lo + per_wave, blk_hi);
 	for (uint32_t blk0 = w_lo; blk0 < w_hi; blk0 += 64) {
 		const uint32_t mb = blk0 + lane;
 		const uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
 		const uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
-		const uint32_t cnt = min(64u, w_hi - blk0);
-		for (uint32_t j = 0; j < cnt; ++j) {
-			const uint32_t s = __shfl(s_l, (int)j, 64), e = __shfl(e_l, (int)j, 64);
-			const uint32_t *r_idx = rec + ((size_t)q * plan.n_blk + (blk0 + j)) * (size_t)(1 + G) * cap;
-			const float *r_val = reinterpret_cast<const float *>(r_idx + cap);
-			for (uint32_t p = s + lane; p < e; p += 64) {
+		uint32_t pre = e_l - s_l;                         // inclusive prefix of run lengths
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t t = __shfl_up(pre, off, 64);
+			if ((int)lane >= off) pre += t;
+		}
+		const uint32_t total = __shfl(pre, 63, 64);
+		const uint32_t shift_l = s_l - (pre - (e_l - s_l));   // run start minus exclusive prefix: p = t + shift
+		for (uint32_t t0 = 0; t0 < total; t0 += 64) {        // wave-uniform trip count: every lane feeds the shuffles
+			const uint32_t t = t0 + lane;
+			// smallest j with pre_j > t
+			uint32_t j = 0;
+#pragma unroll
+			for (int step = 32; step >= 1; step >>= 1) {
+				const uint32_t pv = __shfl(pre, (int)(j + step - 1), 64);
+				if (pv <= t) j += step;
+			}
+			j = min(j, 63u);
+			const uint32_t p = t + __shfl(shift_l, (int)j, 64);
+			if (t < total) {
+				const uint32_t *r_idx = rec_q + (size_t)(blk0 + j) * (size_t)(1 + G) * cap;
 				const uint32_t idx = r_idx[p];
 #pragma unroll
-				for (int f = 0; f < G; ++f) atomicAdd(&acc[idx * G + f], (double)r_val[(size_t)f * cap + p]);
+				for (int f = 0; f < G; ++f)
+					atomicAdd(&acc[idx * G + f], (double)__uint_as_float(r_idx[(size_t)(1 + f) * cap + p]));
 			}
 		}
 	}
@@ -244,8 +280,14 @@ static uint32_t chunk_points(uint32_t n) {
 	return n < chunk ? n : chunk;
 }
 
+static uint32_t bin_points(uint32_t D, uint32_t G) {
+	const uint32_t raw = 16384u / ((1u + G) * (1u << D));
+	return raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
+}
+
 static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinPlan &plan, uint64_t &offs_words) {
 	const uint32_t G = m->n_feat_per_pseudo_lvl;
+	const uint32_t kBinPts = bin_points(m->n_dims_to_encode, G);
 	if (m->n_pseudo_levels > kMaxPlanLevels || !m->c_hash_only) return false;
 	uint32_t lg = 0;
 	while ((1u << (lg + 1)) <= (uint32_t)kLdsDoubles / G) ++lg;
@@ -274,7 +316,7 @@ struct BinLayout { uint64_t rec_bytes, offs_bytes, gt_bytes, total; };
 
 static BinLayout layout(const nr3d_lotd_meta_t *m, const BinPlan &plan, uint64_t offs_words, uint32_t n_chunk) {
 	BinLayout l;
-	const uint64_t cap = (uint64_t)kBinPts << m->n_dims_to_encode;
+	const uint64_t cap = (uint64_t)bin_points(m->n_dims_to_encode, m->n_feat_per_pseudo_lvl) << m->n_dims_to_encode;
 	l.rec_bytes = (uint64_t)m->n_pseudo_levels * plan.n_blk * (1 + m->n_feat_per_pseudo_lvl) * cap * 4;
 	l.offs_bytes = ((offs_words * 4 + 255) / 256) * 256;
 	l.gt_bytes = (((uint64_t)m->n_encoded_dims * n_chunk * 4 + 255) / 256) * 256;
@@ -331,20 +373,23 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			hipLaunchKernelGGL(k_transpose, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, gc, g_sn, g_se, gt);
 			gc = gt; sn = 1; se = (int64_t)n;
 		}
-		const size_t hist_bytes = ((size_t)nb_max + 1) * sizeof(uint32_t);
 		DISPATCH_DG_BIN(D, G, {
-			if (second)
-				hipLaunchKernelGGL((k_bin<D, G, true>), dim3(pl.n_blk, pl.n_pseudo), dim3(kBinPts), hist_bytes, st, pl, md, n,
-				                   max_level, meta->interpolation_type, xc, vc, gc, sn, se, rec, offs);
-			else
-				hipLaunchKernelGGL((k_bin<D, G, false>), dim3(pl.n_blk, pl.n_pseudo), dim3(kBinPts), hist_bytes, st, pl, md, n,
-				                   max_level, meta->interpolation_type, xc, vc, gc, sn, se, rec, offs);
+			constexpr int BP = BinCfg<D, G>::BP;
+			const size_t bin_lds = ((size_t)(1 + G) * BinCfg<D, G>::cap + nb_max + 1) * sizeof(uint32_t);
 			static bool attr_set = false;
 			if (!attr_set) {
 				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
 				                                   kLdsDoubles * 8));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + (kMaxBuckets + 1) * 4));
 				attr_set = true;
 			}
+			if (second)
+				hipLaunchKernelGGL((k_bin<D, G, true>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n,
+				                   max_level, meta->interpolation_type, xc, vc, gc, sn, se, rec, offs);
+			else
+				hipLaunchKernelGGL((k_bin<D, G, false>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n,
+				                   max_level, meta->interpolation_type, xc, vc, gc, sn, se, rec, offs);
 			hipLaunchKernelGGL((k_accum<D, G>), dim3(acc_max, pl.n_pseudo), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md,
 			                   rec, offs, dparam);
 		});

@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd SQLite database (kernel-trace) into a per-kernel table:
+calls, total / average / min / max duration.  Usage: python tools/prof_summary.py <results.db> [min_calls]"""
+import re
+import sqlite3
+import sys
+
+
+def main(path, out=sys.stdout):
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = next(t for t in tabs if t.startswith("rocpd_kernel_dispatch"))
+    ks = next(t for t in tabs if t.startswith("rocpd_info_kernel_symbol"))
+    cols = [r[1] for r in c.execute(f"pragma table_info({kd})")]
+    scol = [r[1] for r in c.execute(f"pragma table_info({ks})")]
+    name_col = "display_name" if "display_name" in scol else ("kernel_name" if "kernel_name" in scol else scol[-1])
+    rows = c.execute(f"select s.{name_col}, d.end - d.start from {kd} d join {ks} s on d.kernel_id = s.id").fetchall()
+    agg = {}
+    for n, dur in rows:
+        n = re.sub(r"\(.*", "", n or "?")
+        a = agg.setdefault(n, [0, 0, 1 << 62, 0])
+        a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
+    tot = sum(a[1] for a in agg.values()) or 1
+    print(f"{'kernel':78s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'%':>6s}", file=out)
+    for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{n[:78]:78s} {a[0]:6d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:10.2f} {a[2] / 1e3:10.2f} {a[3] / 1e3:10.2f} "
+              f"{100 * a[1] / tot:6.2f}", file=out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
