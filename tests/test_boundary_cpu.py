@@ -1,0 +1,114 @@
+"""CPU: the drop-in boundary.  The C-ABI library loads and exports every symbol include/nr3d_hip.h declares; the
+product path never touches the oracle and has no CPU fallback; host-side logic (meta, wrappers, dispatch errors)."""
+import ctypes
+import os
+import pickle
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol(hiplib):
+    header = open(os.path.join(ROOT, "include", "nr3d_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(nr3d_[A-Za-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 30, declared
+    missing = [s for s in declared if not hasattr(hiplib, s)]
+    assert not missing, f"declared in include/nr3d_hip.h but not exported: {missing}"
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "nr3d_lib_amd", "libnr3d_hip.so")],
+                        capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (nr3d_[A-Za-z0-9_]+)", nm)))
+    assert exported == declared, (set(exported) ^ set(declared))
+    assert hiplib.nr3d_abi_version() == 1
+
+
+def test_library_is_gfx950_only():
+    """the fat binary embeds code objects for exactly one target"""
+    blob = open(os.path.join(ROOT, "nr3d_lib_amd", "libnr3d_hip.so"), "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/"""
+    offenders = []
+    for base, _, files in os.walk(os.path.join(ROOT, "nr3d_lib_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M) or "liboracle" in txt:
+                    offenders.append(os.path.join(base, f))
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"\bimport oracle\b", bench)]
+    assert len(uses) == 1 and bench.rfind("def cpu_baseline", 0, uses[0]) > bench.rfind("\ndef ", 0, bench.rfind("def cpu_baseline", 0, uses[0]))
+
+
+def test_no_cpu_fallback(hiplib):
+    from nr3d_lib_amd.bindings import _lotd, _pack_ops, _occ_grid
+    m = _lotd.LoDMeta(3, [8, 16], [2, 2], ["Dense", "Hash"], 1024)
+    x, p = torch.rand(4, 3), torch.zeros(m.n_params)
+    with pytest.raises(RuntimeError, match="GPU only|CPU tensor"):
+        _lotd.lod_fwd(m, x, p)
+    with pytest.raises(RuntimeError, match="GPU only|CPU tensor"):
+        _pack_ops.packed_sum(torch.rand(5), torch.tensor([[0, 5]]))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        _occ_grid.ray_marching(torch.rand(2, 3), torch.rand(2, 3), torch.zeros(2), torch.ones(2), torch.zeros(6),
+                               torch.zeros(4, 4, 4, dtype=torch.bool), _occ_grid.ContractionType.AABB, 0.1, 1e10, 0., 8, True)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from nr3d_lib_amd import _hip
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _hip.lib()
+
+
+def test_meta_surface(hiplib):
+    from nr3d_lib_amd.bindings import _lotd
+    m = _lotd.LoDMeta(3, [[8, 6, 5], [12, 9, 7]], [4, 8], ["vm", "CP"], None, True)
+    assert m.level_types == [int(_lotd.LoDType.VectorMatrix), int(_lotd.LoDType.CP)] and m.level_types_str == ["vm", "CP"]
+    assert m.level_res == [0, 0] and m.level_res_multidim == [[8, 6, 5], [12, 9, 7]]
+    assert m.level_sizes == [6 * 5 + 8 * 5 + 8 * 6 + 8 + 6 + 5, 12 + 9 + 7]
+    assert m.n_feat_per_pseudo_lvl == 4 and m.n_pseudo_levels == 3 and m.map_levels == [0, 1, 1] and m.map_cnt == [0, 0, 1]
+    assert m.n_encoded_dims == 12 and m.interpolation_type == _lotd.InterpolationType.Smoothstep and not m.c_hash_only
+    assert (m.c_profile, m.c_bmm_backend, m.c_prefetch, m.c_permute_dydx) == (False, True, True, True)
+    assert int(_lotd.LoDType.Hash) == 7 and _lotd.Dense == _lotd.LoDType.Dense      # export_values()
+    assert _lotd.string_to_lod_type("NPlane") == _lotd.LoDType.NPlaneSum
+    with pytest.raises(RuntimeError, match="Invalid lod type"):
+        _lotd.LoDMeta(3, [8], [2], ["Octree"])
+    with pytest.raises(RuntimeError, match="exceeds maximum level"):
+        _lotd.LoDMeta(3, [8] * 33, [2] * 33, ["Dense"] * 33)
+    with pytest.raises(RuntimeError, match="too large"):
+        _lotd.LoDMeta(3, [2049], [2], ["Dense"])
+    with pytest.raises(RuntimeError, match="<= 1024"):
+        _lotd.LoDMeta(3, [8] * 17, [64] * 17, ["Dense"] * 17)
+
+
+def test_module_surface(hiplib):
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTD, LoDType, generate_meta, get_lotd_cfg
+    enc = LoTD(3, [8, 16, 32], 2, ["Dense", "Dense", "Hash"], log2_hashmap_size=10, dtype=torch.float)
+    assert (enc.in_features, enc.out_features, enc.n_levels) == (3, 6, 3)
+    assert enc.level_res == [8, 16, 32] and enc.level_types[-1] == LoDType.Hash and enc.loss_scale == 1.0
+    assert enc.n_params == 8 ** 3 * 2 + 16 ** 3 * 2 + 1024 * 2 and "num_params" in enc.extra_repr()
+    enc2 = pickle.loads(pickle.dumps(enc))
+    assert enc2.meta.level_offsets == enc.meta.level_offsets
+    assert LoTD(3, [8], 2, "Dense").loss_scale == 128.0                    # default dtype is half, like the reference
+    cfg = get_lotd_cfg("gen_ngp", 3, num_levels=4)
+    assert generate_meta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"]).n_levels == 4
+    from nr3d_lib_amd.profile import profile
+    with profile("anything"):
+        pass
+    assert profile(lambda: 7)() == 7
+
+
+def test_raymarch_records():
+    from nr3d_lib_amd.graphics.raymarch import RaymarchRetSingle, RaymarchRetBatched
+    r = RaymarchRetSingle(0, None, None, None, None, None, None, None, None)
+    assert len(list(r)) == 9 and r["num_hit_rays"] == 0
+    assert len(list(RaymarchRetBatched(0, *[None] * 9))) == 10

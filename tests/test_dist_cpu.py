@@ -1,0 +1,79 @@
+"""CPU, world_size = 2 over gloo: the data-parallel plumbing of nr3d_lib_amd.distributed (shards, bucketed
+gradient all-reduce, global packed offsets).  On the GPU the same code runs over RCCL (backend "nccl")."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nr3d_lib_amd import distributed as D
+        assert D.is_dist() and D.rank_world() == (rank, world)
+        # shards tile [0, n) exactly, sizes differ by <= 1
+        for n in (0, 1, 7, 1024, 1025):
+            a, b = D.shard_range(n)
+            spans = [D.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n and all(s[1] == t[0] for s, t in zip(spans, spans[1:]))
+            assert max(s[1] - s[0] for s in spans) - min(s[1] - s[0] for s in spans) <= 1 and (a, b) == spans[rank]
+        x = torch.arange(10.0)
+        assert torch.equal(D.shard(x), x[slice(*D.shard_range(10))])
+        # gradient all-reduce: one big tensor (its own bucket) + several small ones packed together + a None
+        torch.manual_seed(rank)
+        big, s1, s2 = torch.randn(5000), torch.randn(3, 4), torch.randn(7)
+        want = []
+        for t in (big, s1, s2):
+            parts = []
+            for r in range(world):
+                torch.manual_seed(r)
+                b_, a1, a2 = torch.randn(5000), torch.randn(3, 4), torch.randn(7)
+                parts.append({5000: b_, 12: a1, 7: a2}[t.numel()])
+            want.append(sum(parts))
+        D.allreduce_grads([big, None, s1, s2], bucket_bytes=4096)
+        for got, w in zip((big, s1, s2), want):
+            torch.testing.assert_close(got, w.view_as(got))
+        avg = torch.full((4,), float(rank + 1))
+        D.allreduce_grads([avg], average=True)
+        torch.testing.assert_close(avg, torch.full((4,), sum(range(1, world + 1)) / world))
+        off, total = D.global_pack_offsets(10 * (rank + 1))
+        assert total == sum(10 * (r + 1) for r in range(world)) and off == sum(10 * (r + 1) for r in range(rank))
+        q.put((rank, "ok"))
+    except Exception as e:   # surface the failure to the parent
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(20)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_single_process_is_a_noop():
+    from nr3d_lib_amd import distributed as D
+    assert D.rank_world() == (0, 1) and D.shard_range(10) == (0, 10)
+    g = torch.ones(3)
+    D.allreduce_grads([g])
+    assert torch.equal(g, torch.ones(3)) and D.global_pack_offsets(5) == (0, 5)
