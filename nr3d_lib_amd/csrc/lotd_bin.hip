@@ -232,24 +232,37 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 		}
 		const uint32_t total = __shfl(pre, 63, 64);
 		const uint32_t shift_l = s_l - (pre - (e_l - s_l));   // run start minus exclusive prefix: p = t + shift
-		for (uint32_t t0 = 0; t0 < total; t0 += 64) {        // wave-uniform trip count: every lane feeds the shuffles
-			const uint32_t t = t0 + lane;
-			// smallest j with pre_j > t
-			uint32_t j = 0;
+		// kUnroll flat positions per lane and step: all their loads are issued before the first LDS atomic, so a wave
+		// keeps kUnroll x 768 B in flight (one workgroup per CU => memory-level parallelism must come from here)
+		constexpr int kUnroll = 8;
+		for (uint32_t t0 = 0; t0 < total; t0 += 64 * kUnroll) {   // wave-uniform trip count: every lane feeds the shuffles
+			uint32_t idx[kUnroll];
+			float val[kUnroll][G];
+			bool ok[kUnroll];
 #pragma unroll
-			for (int step = 32; step >= 1; step >>= 1) {
-				const uint32_t pv = __shfl(pre, (int)(j + step - 1), 64);
-				if (pv <= t) j += step;
-			}
-			j = min(j, 63u);
-			const uint32_t p = t + __shfl(shift_l, (int)j, 64);
-			if (t < total) {
+			for (int u = 0; u < kUnroll; ++u) {
+				const uint32_t t_raw = t0 + (uint32_t)u * 64u + lane;
+				ok[u] = t_raw < total;
+				const uint32_t t = ok[u] ? t_raw : total - 1;      // clamp: loads stay unconditional and in bounds
+				uint32_t j = 0;                                    // smallest j with pre_j > t
+#pragma unroll
+				for (int step = 32; step >= 1; step >>= 1) {
+					const uint32_t pv = __shfl(pre, (int)(j + step - 1), 64);
+					if (pv <= t) j += step;
+				}
+				j = min(j, 63u);
+				const uint32_t p = t + __shfl(shift_l, (int)j, 64);
 				const uint32_t *r_idx = rec_q + (size_t)(blk0 + j) * (size_t)(1 + G) * cap;
-				const uint32_t idx = r_idx[p];
+				idx[u] = r_idx[p];
 #pragma unroll
-				for (int f = 0; f < G; ++f)
-					atomicAdd(&acc[idx * G + f], (double)__uint_as_float(r_idx[(size_t)(1 + f) * cap + p]));
+				for (int f = 0; f < G; ++f) val[u][f] = __uint_as_float(r_idx[(size_t)(1 + f) * cap + p]);
 			}
+#pragma unroll
+			for (int u = 0; u < kUnroll; ++u)
+				if (ok[u]) {
+#pragma unroll
+					for (int f = 0; f < G; ++f) atomicAdd(&acc[idx[u] * G + f], (double)val[u][f]);
+				}
 		}
 	}
 	__syncthreads();

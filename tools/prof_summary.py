@@ -27,5 +27,30 @@ def main(path, out=sys.stdout):
               f"{100 * a[1] / tot:6.2f}", file=out)
 
 
+def pmc(path, out=sys.stdout):
+    """per-kernel average of every collected PMC counter (rocprofv3 --pmc ...)"""
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = next(t for t in tabs if t.startswith("rocpd_kernel_dispatch"))
+    ks = next(t for t in tabs if t.startswith("rocpd_info_kernel_symbol"))
+    pe = next(t for t in tabs if t.startswith("rocpd_pmc_event"))
+    pi = next(t for t in tabs if t.startswith("rocpd_info_pmc"))
+    scol = [r[1] for r in c.execute(f"pragma table_info({ks})")]
+    name_col = "display_name" if "display_name" in scol else ("kernel_name" if "kernel_name" in scol else scol[-1])
+    rows = c.execute(f"select s.{name_col}, i.name, e.value, d.id from {pe} e join {kd} d on e.event_id = d.event_id "
+                     f"join {ks} s on d.kernel_id = s.id join {pi} i on e.pmc_id = i.id").fetchall()
+    agg = {}
+    for n, cn, v, did in rows:
+        n = re.sub(r"\(.*", "", n or "?")
+        a = agg.setdefault((n, cn), {})
+        a[did] = a.get(did, 0.0) + float(v)          # sum over instances (XCDs / channels) of one dispatch
+    print(f"{'kernel':70s} {'counter':14s} {'dispatches':>10s} {'avg_per_dispatch':>18s}", file=out)
+    for (n, cn), a in sorted(agg.items(), key=lambda kv: -sum(kv[1].values())):
+        print(f"{n[:70]:70s} {cn:14s} {len(a):10d} {sum(a.values()) / len(a):18.1f}", file=out)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "pmc":
+        pmc(sys.argv[1])
+    else:
+        main(sys.argv[1])
