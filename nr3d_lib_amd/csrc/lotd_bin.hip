@@ -8,7 +8,7 @@
 //
 //   stage A  k_bin    one workgroup = 512 points x 1 pseudo-level: compute the 2^D corner updates, counting-sort
 //                     them by table BUCKET (a bucket = the slice of the level's table whose fp64 accumulators fit
-//                     one CU's LDS: 16384/G entries) inside the workgroup and write them as SoA records
+//                     one CU's LDS: 16384/G entries) inside the workgroup and write them as AoS records
 //                     {local entry, value[G]} plus the per-bucket start offsets;
 //   stage B  k_accum  one workgroup = one bucket (x an optional replica that takes a share of the point blocks):
 //                     stream that bucket's records (contiguous runs), accumulate into a 128 KiB fp64 LDS table with
@@ -163,26 +163,25 @@ __global__ __launch_bounds__((BinCfg<D, G>::BP)) void k_bin(BinPlan plan, const 
 		__syncthreads();
 	}
 
-	// counting-sort the records into the LDS staging area (SoA: idx | val[0] | ... | val[G-1])
+	// counting-sort the records into the LDS staging area (AoS: {idx, val[0..G-1]} per record)
 	if (active) {
 		const uint32_t mask = (1u << plan.epb_log2) - 1u;
 #pragma unroll
 		for (uint32_t k = 0; k < (uint32_t)C; ++k) {
 			const uint32_t pos = hist[ent[k] >> plan.epb_log2] + rank[k];
-			stage[pos] = ent[k] & mask;
+			stage[pos * (1 + G)] = ent[k] & mask;
 #pragma unroll
-			for (int f = 0; f < G; ++f) stage[(size_t)(1 + f) * cap + pos] = __float_as_uint(grad[f] * w[k]);
+			for (int f = 0; f < G; ++f) stage[pos * (1 + G) + 1 + f] = __float_as_uint(grad[f] * w[k]);
 		}
 	}
 	__syncthreads();
 
-	// coalesced 16-byte write-out of the filled prefix of every array
+	// coalesced 16-byte write-out of the filled prefix (records are (1 + G)-word AoS, so a bucket's run is one
+	// contiguous span of the slot and stage B over-fetches at most one cache line per run)
 	const uint32_t total = hist[nb];                          // multiple of 2^D >= 4
 	uint4 *dst = reinterpret_cast<uint4 *>(rec + ((size_t)q * plan.n_blk + blk) * (size_t)(1 + G) * cap);
 	const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-#pragma unroll
-	for (int arr = 0; arr <= G; ++arr)
-		for (uint32_t v4 = threadIdx.x; v4 < total / 4; v4 += BP) dst[(size_t)arr * (cap / 4) + v4] = src[(size_t)arr * (cap / 4) + v4];
+	for (uint32_t v4 = threadIdx.x; v4 < total / 4 * (1 + G); v4 += BP) dst[v4] = src[v4];
 	uint32_t *ob = offs_g + plan.offs_base[q];
 	for (uint32_t b = threadIdx.x; b <= nb; b += BP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
 }
@@ -252,10 +251,10 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 				}
 				j = min(j, 63u);
 				const uint32_t p = t + __shfl(shift_l, (int)j, 64);
-				const uint32_t *r_idx = rec_q + (size_t)(blk0 + j) * (size_t)(1 + G) * cap;
-				idx[u] = r_idx[p];
+				const uint32_t *r_p = rec_q + ((size_t)(blk0 + j) * cap + p) * (size_t)(1 + G);
+				idx[u] = r_p[0];
 #pragma unroll
-				for (int f = 0; f < G; ++f) val[u][f] = __uint_as_float(r_idx[(size_t)(1 + f) * cap + p]);
+				for (int f = 0; f < G; ++f) val[u][f] = __uint_as_float(r_p[1 + f]);
 			}
 #pragma unroll
 			for (int u = 0; u < kUnroll; ++u)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box: rocprofv3 kernel-trace (+ optional PMC passes) of bench.py, summarised to text under gpurun_out/<tag>/.
+# usage: tools/gpu_profile.sh <tag> [pmc]       (databases stay in /tmp: gpurun_out is size-limited)
+set -u
+TAG=${1:-prof}; PMC=${2:-}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+rm -rf /tmp/prof_k && rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o p -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1
+DB=$(find /tmp/prof_k -name '*.db' | head -1)
+python $ROOT/tools/prof_summary.py "$DB" > "$OUT/bench_kernel_stats.txt" 2>&1
+if [ -n "$PMC" ]; then
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/prof_c && rocprofv3 --kernel-trace --pmc $CTR -d /tmp/prof_c -o p -- $BENCH > /dev/null 2>&1
+    DB=$(find /tmp/prof_c -name '*.db' | head -1)
+    python $ROOT/tools/prof_summary.py "$DB" pmc > "$OUT/bench_pmc_$(echo $CTR | tr A-Z a-z).txt" 2>&1
+  done
+fi
+head -16 "$OUT/bench_kernel_stats.txt"
