@@ -45,6 +45,7 @@ constexpr uint32_t kMaxBuckets = 8192;    // per pseudo level
 struct BinPlan {
 	uint32_t nb[kMaxPlanLevels];          // buckets per pseudo level
 	uint32_t rep[kMaxPlanLevels];         // replicas per bucket (stage B)
+	uint32_t order[kMaxPlanLevels];       // stage-B launch order of the pseudo levels: largest workgroups first
 	uint32_t offs_base[kMaxPlanLevels];   // start of this pseudo level's offset table (in uint32 units)
 	uint32_t epb_log2;                    // log2(entries per bucket)
 	uint32_t n_blk;                       // stage-A workgroups along the points of the current chunk
@@ -194,9 +195,10 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
                                                        const uint32_t *__restrict__ rec,
                                                        const uint32_t *__restrict__ offs_g,
                                                        float *__restrict__ dparam) {
+	// accumulators are feature-major (acc[f][entry]): the G atomics of a record spread over all LDS banks
 	extern __shared__ __attribute__((aligned(16))) double acc[];      // [kLdsDoubles]
 	constexpr uint32_t cap = BinCfg<D, G>::cap;
-	const uint32_t q = blockIdx.y;
+	const uint32_t q = plan.order[blockIdx.y];
 	const uint32_t nb = plan.nb[q], R = plan.rep[q];
 	if (blockIdx.x >= nb * R) return;
 	const uint32_t b = blockIdx.x / R, r = blockIdx.x - b * R;
@@ -213,69 +215,83 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)b * plan.n_blk;
 	const uint32_t *ob1 = ob0 + plan.n_blk;
 	const uint32_t *rec_q = rec + (size_t)q * plan.n_blk * (size_t)(1 + G) * cap;
-	// The point blocks of this replica are split evenly over the waves.  Per step a wave takes up to 64 of its
-	// blocks: lane t fetches the run [start, end) of block blk0 + t (coalesced), a wave scan turns the run lengths
-	// into a prefix, and the lanes then walk the CONCATENATION of the 64 runs (all lanes busy, independent loads);
-	// the owning run of flat position t is found by a 6-step binary search over the prefix held in the lanes.
+	// The point blocks of this replica are split evenly over the waves.  Per step a wave takes up to 64 of its blocks:
+	// lane t fetches the run [start, end) of block blk0 + t (coalesced); the runs are then walked one per
+	// wave-instruction (lane < run length active, run bounds broadcast with v_readlane), kUnroll runs in flight.
+	// No per-record ownership search: a hash level's runs hold 64 +- 8 records, so a run costs one full and at most
+	// one sparse pass.  The kernel is bound by the LDS atomic pipe (SQ_ACTIVE_INST_LDS + SQ_LDS_BANK_CONFLICT ~ 100 %
+	// of the busy cycles: 64 random 8-byte addresses over 16 bank pairs cost ~58 cycles per ds_add_f64), not by HBM,
+	// so neither deeper load pipelining nor a bucket-major record stream (both tried) shortens it.
+	const uint32_t epb = 1u << plan.epb_log2;
 	const uint32_t per_wave = (blk_hi - blk_lo + n_waves - 1) / n_waves;
 	const uint32_t w_lo = min(blk_lo + wave * per_wave, blk_hi), w_hi = min(w_lo + per_wave, blk_hi);
+	constexpr int kUnroll = 8;
+	constexpr int W = 1 + G;
 	for (uint32_t blk0 = w_lo; blk0 < w_hi; blk0 += 64) {
 		const uint32_t mb = blk0 + lane;
 		const uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
 		const uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
-		uint32_t pre = e_l - s_l;                         // inclusive prefix of run lengths
-#pragma unroll
-		for (int off = 1; off < 64; off <<= 1) {
-			const uint32_t t = __shfl_up(pre, off, 64);
-			if ((int)lane >= off) pre += t;
-		}
-		const uint32_t total = __shfl(pre, 63, 64);
-		const uint32_t shift_l = s_l - (pre - (e_l - s_l));   // run start minus exclusive prefix: p = t + shift
-		// kUnroll flat positions per lane and step: all their loads are issued before the first LDS atomic, so a wave
-		// keeps kUnroll x 768 B in flight (one workgroup per CU => memory-level parallelism must come from here)
-		constexpr int kUnroll = 8;
-		for (uint32_t t0 = 0; t0 < total; t0 += 64 * kUnroll) {   // wave-uniform trip count: every lane feeds the shuffles
+		const uint32_t n_run = min(64u, w_hi - blk0);
+		const uint32_t *rec_b = rec_q + (size_t)blk0 * cap * W;
+		for (uint32_t j0 = 0; j0 < n_run; j0 += kUnroll) {
 			uint32_t idx[kUnroll];
 			float val[kUnroll][G];
-			bool ok[kUnroll];
+			uint32_t rs[kUnroll], rn[kUnroll];
+			uint32_t longest = 0;
+			// Loads are branch-free (lanes past the run re-read its first record and drop it): a load under an `if`
+			// makes the compiler drain ALL outstanding loads at the join.
+			for (uint32_t off = 0; off == 0 || off < longest; off += 64) {   // > 1 pass: runs longer than 64 records
 #pragma unroll
-			for (int u = 0; u < kUnroll; ++u) {
-				const uint32_t t_raw = t0 + (uint32_t)u * 64u + lane;
-				ok[u] = t_raw < total;
-				const uint32_t t = ok[u] ? t_raw : total - 1;      // clamp: loads stay unconditional and in bounds
-				uint32_t j = 0;                                    // smallest j with pre_j > t
+				for (int u = 0; u < kUnroll; ++u) {
+					if (off == 0) {
+						const uint32_t j = min(j0 + (uint32_t)u, 63u);
+						const uint32_t s_j = __builtin_amdgcn_readlane(s_l, j), e_j = __builtin_amdgcn_readlane(e_l, j);
+						rs[u] = s_j + j * cap;
+						rn[u] = (j0 + (uint32_t)u < n_run) ? e_j - s_j : 0u;
+						longest = max(longest, rn[u]);
+					}
+					const uint32_t t = off + lane;
+					const uint32_t *r_p = rec_b + (size_t)(rs[u] + (t < rn[u] ? t : 0u)) * W;
+					idx[u] = r_p[0];
 #pragma unroll
-				for (int step = 32; step >= 1; step >>= 1) {
-					const uint32_t pv = __shfl(pre, (int)(j + step - 1), 64);
-					if (pv <= t) j += step;
+					for (int f = 0; f < G; ++f) val[u][f] = __uint_as_float(r_p[1 + f]);
 				}
-				j = min(j, 63u);
-				const uint32_t p = t + __shfl(shift_l, (int)j, 64);
-				const uint32_t *r_p = rec_q + ((size_t)(blk0 + j) * cap + p) * (size_t)(1 + G);
-				idx[u] = r_p[0];
 #pragma unroll
-				for (int f = 0; f < G; ++f) val[u][f] = __uint_as_float(r_p[1 + f]);
+				for (int u = 0; u < kUnroll; ++u)
+					if (off + lane < rn[u]) {
+#pragma unroll
+						for (int f = 0; f < G; ++f) atomicAdd(&acc[(uint32_t)f * epb + idx[u]], (double)val[u][f]);
+					}
 			}
-#pragma unroll
-			for (int u = 0; u < kUnroll; ++u)
-				if (ok[u]) {
-#pragma unroll
-					for (int f = 0; f < G; ++f) atomicAdd(&acc[idx[u] * G + f], (double)val[u][f]);
-				}
 		}
 	}
 	__syncthreads();
 
-	const uint32_t epb = 1u << plan.epb_log2;
+	// flush: batches of kFlush read-modify-writes per thread, all loads issued before the first store (the compiler
+	// cannot hoist them itself: dparam may alias itself across iterations)
 	float *dst = dparam + L.off;
-	for (uint32_t t = threadIdx.x; t < epb * G; t += kAccThreads) {
-		const uint32_t el = t / G, f = t - el * G;
-		const uint32_t entry = b * epb + el;
-		if (entry >= L.size) continue;
-		const float v = (float)acc[t];
-		float *p = dst + ((size_t)entry * L.F + foff0 + f);
-		if (R == 1) *p += v;                       // this workgroup is the only writer of the slice
-		else if (v != 0.0f) atomic_add_f32(p, v);
+	constexpr int kFlush = 8;
+	for (uint32_t tb = threadIdx.x; tb < epb * G; tb += kAccThreads * kFlush) {
+		float *p[kFlush];
+		float v[kFlush], old[kFlush];
+#pragma unroll
+		for (int k = 0; k < kFlush; ++k) {
+			const uint32_t t = tb + (uint32_t)k * kAccThreads;
+			const uint32_t el = t / G, f = t - el * G;
+			const uint32_t entry = b * epb + el;
+			const bool in = (t < epb * G) && (entry < L.size);
+			p[k] = in ? dst + ((size_t)entry * L.F + foff0 + f) : nullptr;
+			v[k] = in ? (float)acc[f * epb + el] : 0.0f;
+		}
+		if (R == 1) {                              // this workgroup is the only writer of the slice
+#pragma unroll
+			for (int k = 0; k < kFlush; ++k) old[k] = p[k] ? *p[k] : 0.0f;
+#pragma unroll
+			for (int k = 0; k < kFlush; ++k) if (p[k]) *p[k] = old[k] + v[k];
+		} else {
+#pragma unroll
+			for (int k = 0; k < kFlush; ++k) if (p[k] && v[k] != 0.0f) atomic_add_f32(p[k], v[k]);
+		}
 	}
 }
 
@@ -313,14 +329,34 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinPlan &plan
 		if (nb > kMaxBuckets) return false;
 		plan.nb[q] = nb;
 		// enough stage-B workgroups per level to spread over the chip, never more replicas than point blocks
-		uint32_t rep = nb >= 32 ? 1u : div_up(32, nb);
-		if (rep > plan.n_blk) rep = plan.n_blk ? plan.n_blk : 1u;
+		uint32_t rep = 1;
 		plan.rep[q] = rep;
 		if (base > 0xFFFFFFFFull) return false;
 		plan.offs_base[q] = (uint32_t)base;
 		base += (uint64_t)(nb + 1) * plan.n_blk;
 	}
 	offs_words = base;
+	// A bucket of the largest level is the unsplittable unit of stage-B work (one workgroup, ~n * 2^D / nb_max records
+	// when the points are spread out).  Smaller levels are replicated until their workgroups are about that size too
+	// (rounded down: a few larger workgroups, launched first, pack better than many that spill into another round),
+	// and the levels are launched by decreasing workgroup size.
+	uint32_t nb_max = 1;
+	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) nb_max = plan.nb[q] > nb_max ? plan.nb[q] : nb_max;
+	const uint32_t unit = nb_max < 64 ? 64 : nb_max;              // at least 64 workgroups per level to cover the chip
+	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
+		uint32_t rep = unit / plan.nb[q];
+		rep = rep < 1 ? 1 : rep;
+		if (rep > plan.n_blk) rep = plan.n_blk ? plan.n_blk : 1u;
+		plan.rep[q] = rep;
+		plan.order[q] = q;
+	}
+	for (uint32_t i = 1; i < m->n_pseudo_levels; ++i) {           // insertion sort by nb * rep ascending (= work descending)
+		const uint32_t q = plan.order[i];
+		const uint32_t key = plan.nb[q] * plan.rep[q];
+		uint32_t j = i;
+		while (j > 0 && plan.nb[plan.order[j - 1]] * plan.rep[plan.order[j - 1]] > key) { plan.order[j] = plan.order[j - 1]; --j; }
+		plan.order[j] = q;
+	}
 	return true;
 }
 
