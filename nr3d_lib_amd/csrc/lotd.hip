@@ -28,6 +28,53 @@
 namespace nr3d {
 namespace lotd {
 
+struct __attribute__((aligned(8))) Pair16 { float x, y, z, w; };   // two neighbouring F=2 entries, 8-byte aligned
+
+// The gather rate is bound by L2->L1 line requests (one per lane and instruction, ~260 G/s chip-wide,
+// tools/ubench_mem), not by bytes.  Corner pairs that are neighbours in memory come from ONE 16-byte load:
+//   Dense -> the pair along the contiguous last dim (always neighbours, 8-byte aligned 16-byte load);
+//   Hash  -> the pair along dim 0 (prime 1): for even x0 (and a power-of-two table)
+//            hash(x0 + 1, ..) == hash(x0, ..) ^ 1, the other half of the same aligned 16-byte slot.
+// Lanes whose partner lives elsewhere fetch it with a second 8-byte load, all of them under ONE branch so that
+// no load has to be waited for before the last one is issued.  F == 2 (8-byte entries) only.
+template <int D, bool DENSE>
+__device__ __forceinline__ void gather_pairs(const Lvl &L, const Cell<D> &c, const float *__restrict__ grid,
+                                             float (&v)[1 << D][2]) {
+	constexpr uint32_t PBIT = DENSE ? (1u << (D - 1)) : 1u;
+	uint32_t e1s[1 << (D - 1)];
+	bool all_adj = true;
+#pragma unroll
+	for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
+		constexpr uint32_t dummy = 0; (void)dummy;
+		const uint32_t k0 = DENSE ? m : (m << 1);          // m with a zero bit inserted at the pair dimension
+		const uint32_t k1 = k0 | PBIT;
+		uint32_t p0[D], p1[D];
+		corner_pos<D>(c, k0, p0);
+		corner_pos<D>(c, k1, p1);
+		const uint32_t e0 = DENSE ? entry_dense<D>(L, p0) : entry_hash<D>(L, p0);
+		const uint32_t e1 = DENSE ? e0 + 1u : entry_hash<D>(L, p1);
+		const uint32_t base = DENSE ? e0 : min(e0 & ~1u, L.size - 2u);
+		const Pair16 t = *reinterpret_cast<const Pair16 *>(grid + (size_t)base * 2u);
+		const bool hi0 = (e0 != base);
+		v[k0][0] = hi0 ? t.z : t.x;
+		v[k0][1] = hi0 ? t.w : t.y;
+		const uint32_t o1 = e1 - base;
+		v[k1][0] = (o1 == 1u) ? t.z : t.x;
+		v[k1][1] = (o1 == 1u) ? t.w : t.y;
+		all_adj = all_adj && (o1 < 2u);
+		e1s[m] = e1;
+	}
+	if (!DENSE && !all_adj) {
+#pragma unroll
+		for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
+			const uint32_t k1 = (m << 1) | 1u;
+			const float2 t = *reinterpret_cast<const float2 *>(grid + (size_t)e1s[m] * 2u);
+			v[k1][0] = t.x;
+			v[k1][1] = t.y;
+		}
+	}
+}
+
 // =============================================================================================
 // Forward
 // =============================================================================================
@@ -68,6 +115,14 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 		if (DH || L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash) {
 			// ---- all corners of all G features at once; vector loads when alignment allows ----
 			float v[1 << D][G];
+			bool paired = false;
+			if constexpr (G == 2) paired = vec_ok && L.F == 2 && L.size >= 2;
+			if (paired) {
+				if constexpr (G == 2) {
+					if (L.type == NR3D_LOD_Dense) gather_pairs<D, true>(L, c, grid, v);
+					else gather_pairs<D, false>(L, c, grid, v);
+				}
+			} else
 #pragma unroll
 			for (uint32_t k = 0; k < (1u << D); ++k) {
 				uint32_t p[D];
@@ -520,6 +575,56 @@ __global__ __launch_bounds__(kBlock) void k_contract_dx(uint32_t N, uint32_t E, 
 	for (int d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = acc[d];
 }
 
+// Same contraction for a row-major dL/dy ([N, E], the layout autograd hands over): a lane reading its own row
+// touches one cache line per lane and instruction, so the block first transposes its 256 x 32 tile of dL/dy through
+// LDS (coalesced 16-byte reads), then streams the feature-major Jacobian.  Same summation order as above.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_contract_dx_rowmajor(uint32_t N, uint32_t E, const float *__restrict__ dL_dy,
+                                                                 const float *__restrict__ dydx, int64_t d_sn,
+                                                                 int64_t d_se, float *__restrict__ dL_dx) {
+	constexpr int TE = 32;
+	__shared__ float tile[TE][kBlock + 1];
+	const uint32_t i0 = blockIdx.x * kBlock, i = i0 + threadIdx.x;
+	const uint32_t n_here = min((uint32_t)kBlock, N - i0);
+	float acc[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) acc[d] = 0.0f;
+	for (uint32_t e0 = 0; e0 < E; e0 += TE) {
+		const uint32_t te = min((uint32_t)TE, E - e0);
+		if (te == TE && (E & 3u) == 0u) {
+#pragma unroll
+			for (uint32_t v = threadIdx.x; v < kBlock * TE / 4; v += kBlock) {   // 8 lanes x float4 per point row
+				const uint32_t p = v >> 3, e4 = (v & 7u) * 4u;
+				if (p < n_here) {
+					const float4 t = *reinterpret_cast<const float4 *>(dL_dy + (size_t)(i0 + p) * E + e0 + e4);
+					tile[e4][p] = t.x; tile[e4 + 1][p] = t.y; tile[e4 + 2][p] = t.z; tile[e4 + 3][p] = t.w;
+				}
+			}
+		} else {
+			for (uint32_t v = threadIdx.x; v < kBlock * te; v += kBlock) {
+				const uint32_t p = v / te, e = v - p * te;
+				if (p < n_here) tile[e][p] = dL_dy[(size_t)(i0 + p) * E + e0 + e];
+			}
+		}
+		__syncthreads();
+		if (i < N) {
+			const float *jj = dydx + (int64_t)i * d_sn + (int64_t)e0 * d_se;
+#pragma unroll 8
+			for (uint32_t e = 0; e < te; ++e) {
+				const float g = tile[e][threadIdx.x];
+				const float *j = jj + (int64_t)e * d_se;
+#pragma unroll
+				for (int d = 0; d < D; ++d) acc[d] = __fmaf_rn(g, j[d], acc[d]);
+			}
+		}
+		__syncthreads();
+	}
+	if (i < N) {
+#pragma unroll
+		for (int d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = acc[d];
+	}
+}
+
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_contract_ddLdy(uint32_t N, uint32_t E, const float *__restrict__ v,
                                                            const float *__restrict__ dydx, int64_t d_sn, int64_t d_se,
@@ -576,18 +681,75 @@ static uint32_t sched_mode_default() {
 	static int mode = -1;
 	if (mode < 0) {
 		const char *e = getenv("NR3D_LOTD_SCHED");
-		mode = e ? atoi(e) : 1;
-		if (mode < 0 || mode > 2) mode = 1;
+		mode = e ? atoi(e) : 3;
+		if (mode < 0 || mode > 3) mode = 3;
 	}
 	return (uint32_t)mode;
 }
 
-static Sched make_sched(uint32_t N, uint32_t n_pseudo, uint32_t &n_blocks) {
+// estimated cost of one (point, pseudo level) item, in half L2 requests (see lotd_device.h, mode 3)
+static uint32_t level_cost(const nr3d_lotd_meta_t *m, uint32_t q) {
+	const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
+	const uint32_t D = m->n_dims_to_encode, G = m->n_feat_per_pseudo_lvl;
+	uint32_t req = 1u << D;
+	const bool paired = (G == 2 && L.n_feats == 2);
+	if (L.type == NR3D_LOD_Dense) req = paired ? req / 2 : req;
+	else if (L.type == NR3D_LOD_Hash) req = (paired && (L.size & (L.size - 1u)) == 0u) ? req * 3 / 4 : req;
+	else req = 2 * D + 2;                                         // line/plane tables: small, mostly L1/L2 hits
+	const uint64_t bytes = (uint64_t)L.size * L.n_feats * 4;
+	uint32_t c = 2 * req;
+	if (bytes <= 32 * 1024) c = req;                              // L1 resident
+	return c + 1;                                                 // + the point read / output writes
+}
+
+static Sched make_sched(uint32_t N, const nr3d_lotd_meta_t *m, uint32_t &n_blocks) {
 	Sched s;
+	const uint32_t n_pseudo = m->n_pseudo_levels;
 	s.n_chunks = div_up(N, kBlock);
 	s.n_pseudo = n_pseudo;
 	s.mode = sched_mode_default();
 	s.n_slots = div_up(n_pseudo, 8);
+	if (s.mode == 3) {
+		// work line: level q occupies n_chunks items of cost c_q each; XCD x takes the items that START in
+		// [x, x + 1) * total / 8
+		uint64_t total = 0;
+		for (uint32_t q = 0; q < n_pseudo; ++q) total += (uint64_t)level_cost(m, q) * s.n_chunks;
+		uint32_t max_blocks = 0;
+		bool ok = total > 0;
+		uint64_t pos = 0;                                             // start of level q on the line
+		uint32_t nseg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int x = 0; x < 8; ++x) s.seg_cum[x][0] = 0;
+		for (uint32_t q = 0; q < n_pseudo && ok; ++q) {
+			const uint64_t c = level_cost(m, q);
+			uint32_t ch = 0;
+			while (ch < s.n_chunks) {
+				const uint64_t start = pos + (uint64_t)ch * c;
+				uint32_t x = (uint32_t)((start * 8) / total);
+				x = x > 7 ? 7 : x;
+				// last chunk of this level that still starts inside XCD x's share
+				const uint64_t bound = ((uint64_t)(x + 1) * total + 7) / 8;          // first position owned by x + 1
+				uint64_t ch_end = (bound > pos) ? (bound - pos + c - 1) / c : 0;      // chunks with start < bound
+				if (x == 7 || ch_end > s.n_chunks) ch_end = s.n_chunks;
+				if (ch_end <= ch) ch_end = ch + 1;
+				if (nseg[x] >= (uint32_t)kSchedSegs) { ok = false; break; }
+				const uint32_t i = nseg[x]++;
+				s.seg_q[x][i] = (uint16_t)q;
+				s.seg_begin[x][i] = ch;
+				s.seg_cum[x][i + 1] = s.seg_cum[x][i] + (uint32_t)(ch_end - ch);
+				ch = (uint32_t)ch_end;
+			}
+			pos += c * s.n_chunks;
+		}
+		if (ok) {
+			for (int x = 0; x < 8; ++x) {
+				for (int i = nseg[x]; i < kSchedSegs; ++i) { s.seg_cum[x][i + 1] = s.seg_cum[x][i]; s.seg_q[x][i] = 0; s.seg_begin[x][i] = 0; }
+				max_blocks = s.seg_cum[x][kSchedSegs] > max_blocks ? s.seg_cum[x][kSchedSegs] : max_blocks;
+			}
+			n_blocks = 8u * max_blocks;
+			return s;
+		}
+		s.mode = 1;                                                   // too fragmented: plain XCD-affine
+	}
 	n_blocks = (s.mode == 1) ? 8u * s.n_slots * s.n_chunks : n_pseudo * s.n_chunks;
 	return s;
 }
@@ -640,7 +802,7 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 	if (N == 0) return 0;
 	NR3D_CHECK(x && params && y, "LoTD::fwd: NULL tensor pointer");
 	uint32_t n_blocks;
-	const Sched s = make_sched(N, meta->n_pseudo_levels, n_blocks);
+	const Sched s = make_sched(N, meta, n_blocks);
 	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 	const uint32_t G = meta->n_feat_per_pseudo_lvl;
 	// vector gathers need every corner address G*4-byte aligned: base pointer aligned and no caller-chosen offsets
@@ -668,10 +830,15 @@ extern "C" int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t N, int x_
 	NR3D_CHECK(x_dtype == NR3D_F32 && param_dtype == NR3D_F32, "LoTD::bwd_dx: f32 only");
 	if (N == 0) return 0;
 	NR3D_CHECK(dL_dy && dy_dx && dL_dx, "LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.");
+	const uint32_t E = meta->n_encoded_dims;
+	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && ((uintptr_t)dL_dy % 16) == 0);
 	DISPATCH_D(meta->n_dims_to_encode, {
-		hipLaunchKernelGGL(k_contract_dx<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N,
-		                   meta->n_encoded_dims, (const float *)dL_dy, g_sn, g_se, (const float *)dy_dx, d_sn, d_se,
-		                   (float *)dL_dx);
+		if (row_major)
+			hipLaunchKernelGGL(k_contract_dx_rowmajor<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,
+			                   (const float *)dL_dy, (const float *)dy_dx, d_sn, d_se, (float *)dL_dx);
+		else
+			hipLaunchKernelGGL(k_contract_dx<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,
+			                   (const float *)dL_dy, g_sn, g_se, (const float *)dy_dx, d_sn, d_se, (float *)dL_dx);
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -694,7 +861,7 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
 		if (handled) return 0;
 	}
 	uint32_t n_blocks;
-	const Sched s = make_sched(N, meta->n_pseudo_levels, n_blocks);
+	const Sched s = make_sched(N, meta, n_blocks);
 	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	const bool dh = meta->c_hash_only != 0;
@@ -782,7 +949,7 @@ extern "C" int nr3d_lotd_grid_index(const nr3d_lotd_meta_t *meta, const void *me
 	if (N == 0 || max_level <= -1) return 0;
 	NR3D_CHECK(x && grid_inds, "LoTD::get_grid_index: NULL tensor pointer");
 	uint32_t n_blocks;
-	const Sched s = make_sched(N, meta->n_pseudo_levels, n_blocks);
+	const Sched s = make_sched(N, meta, n_blocks);
 	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {

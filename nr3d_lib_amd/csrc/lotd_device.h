@@ -26,13 +26,30 @@ constexpr uint32_t kPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 20971
 //                               levels {xcd, xcd+8, ...} one after another, so one 4 MiB hash table
 //                               at a time is live in that XCD's private 4 MiB L2.
 //   mode 2  chunk-major       : q = b % n_pseudo (all levels of a chunk back to back)
+//   mode 3  XCD-affine, cost-balanced (default): the (level, chunk) items laid out level after level are cut into
+//                               8 contiguous pieces of equal estimated COST (L2 gather requests per point differ
+//                               between levels: 4 for Dense, 6 for Hash with the paired 16-byte gathers, half of
+//                               that when the table fits the L1).  An XCD still walks few tables, one at a time.
 // ---------------------------------------------------------------------------------------------
+constexpr int kSchedSegs = 16;             // max (level, chunk range) segments per XCD in mode 3
 struct Sched {
 	uint32_t n_chunks, n_pseudo, mode, n_slots;
+	uint32_t seg_cum[8][kSchedSegs + 1];   // blocks of this XCD before segment i
+	uint32_t seg_begin[8][kSchedSegs];     // first chunk of segment i
+	uint16_t seg_q[8][kSchedSegs];         // pseudo level of segment i
 };
 
 __device__ __forceinline__ bool decode_block(const Sched &s, uint32_t b, uint32_t &q, uint32_t &chunk) {
-	if (s.mode == 1) {
+	if (s.mode == 3) {
+		const uint32_t xcd = b & 7u, j = b >> 3;
+		for (int i = 0; i < kSchedSegs; ++i)
+			if (j < s.seg_cum[xcd][i + 1]) {
+				q = s.seg_q[xcd][i];
+				chunk = s.seg_begin[xcd][i] + (j - s.seg_cum[xcd][i]);
+				return true;
+			}
+		return false;
+	} else if (s.mode == 1) {
 		const uint32_t xcd = b & 7u, j = b >> 3;
 		const uint32_t slot = j / s.n_chunks;
 		chunk = j - slot * s.n_chunks;
