@@ -136,6 +136,9 @@ int nr3d_lotd_grid_index(const nr3d_lotd_meta_t *meta, const void *meta_dev, uin
  * Two-phase: *_count writes num_steps[n_rays] AND the exclusive scan packed_info[n_rays,2]
  * (= [cumsum - num, num], int32) plus the grand total into total_steps[0] (device int32/int64);
  * the caller reads total_steps back (the single host sync), allocates outputs, calls *_emit.
+ * Optional sample cache (>= nr3d_ray_marching_cache_bytes(n_rays, max_steps) bytes, or NULL): *_count also stores
+ * every sample in it and *_emit(sample_cache, cache_max_steps = that max_steps) becomes a parallel compaction
+ * instead of a second march (the reference always marches twice, ray_marching.cu:170-240).
  *   grid_binary: uint8/bool [ (B,) Rx, Ry, Rz ], z contiguous.  roi: f32 [6] or [B,6].
  *   batched != 0: batch_inds int32 [n_rays] or NULL (<0 skips), batch_data_size as for LoTD.
  * ============================================================================================== */
@@ -147,7 +150,10 @@ int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, const float *r
                             float max_step_size, float dt_gamma, uint32_t max_steps, int batched,
                             const int32_t *batch_inds, uint32_t batch_data_size,
                             int32_t *packed_info /*[n_rays,2]*/, int64_t *total_steps /*[1]*/,
-                            void *scan_tmp /* >= nr3d_scan_tmp_bytes(n_rays) bytes */, void *stream);
+                            void *scan_tmp /* >= nr3d_scan_tmp_bytes(n_rays) bytes */,
+                            void *sample_cache /*or NULL*/, uint64_t sample_cache_bytes, void *stream);
+
+uint64_t nr3d_ray_marching_cache_bytes(uint32_t n_rays, uint32_t max_steps);
 
 int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
                            const float *t_max, const float *roi, const int32_t grid_res[3],
@@ -155,7 +161,8 @@ int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, const float *ra
                            float max_step_size, float dt_gamma, int batched, const int32_t *batch_inds,
                            uint32_t batch_data_size, const int32_t *packed_info, float *t_starts,
                            float *t_ends, int32_t *ridx, int32_t *bidx /*NULL unless batched*/,
-                           int32_t *gidx /*or NULL*/, void *stream);
+                           int32_t *gidx /*or NULL*/, const void *sample_cache /*or NULL*/,
+                           uint32_t cache_max_steps, void *stream);
 
 /* Scratch bytes needed by the device-wide scans used in two-phase ops (any n). */
 uint64_t nr3d_scan_tmp_bytes(uint64_t n);

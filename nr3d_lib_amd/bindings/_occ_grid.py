@@ -24,6 +24,9 @@ AABB = ContractionType.AABB
 UN_BOUNDED_TANH = ContractionType.UN_BOUNDED_TANH
 UN_BOUNDED_SPHERE = ContractionType.UN_BOUNDED_SPHERE
 
+# largest per-call sample cache ([n_rays, max_steps] x 12 B) the binding allocates; beyond it the op marches twice
+SAMPLE_CACHE_MAX_BYTES = 2 << 30
+
 
 def _chk(name, t, dim=None, dtype=None):
     if not t.is_cuda:
@@ -75,10 +78,15 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
         total = torch.empty(1, dtype=torch.int64, device=dev)
         nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(n, 1))))
         tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        # sample cache: the count pass keeps every sample, the emit pass only compacts (no second march)
+        cache_bytes = n * int(max_steps) * 12
+        cache = (torch.empty((cache_bytes + 3) // 4, dtype=torch.int32, device=dev)
+                 if 0 < cache_bytes <= SAMPLE_CACHE_MAX_BYTES else None)
         H.check(H.lib().nr3d_ray_marching_count(
             H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
             ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), H.u32(max_steps), C.c_int(int(batched)),
-            H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(total), H.ptr(tmp), st))
+            H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(total), H.ptr(tmp), H.ptr(cache),
+            C.c_uint64(cache_bytes if cache is not None else 0), st))
         S = int(total.item())          # the single device->host sync of this op
         t_starts = torch.empty((S, 1), dtype=torch.float32, device=dev)
         t_ends = torch.empty((S, 1), dtype=torch.float32, device=dev)
@@ -90,7 +98,7 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
                 H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res,
                 H.ptr(grid_binary), ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma),
                 C.c_int(int(batched)), H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(t_starts),
-                H.ptr(t_ends), H.ptr(ridx), H.ptr(bidx), H.ptr(gidx), st))
+                H.ptr(t_ends), H.ptr(ridx), H.ptr(bidx), H.ptr(gidx), H.ptr(cache), H.u32(max_steps), st))
     if batched:
         return [packed_info, t_starts, t_ends, ridx, bidx, gidx]
     return [packed_info, t_starts, t_ends, ridx, gidx]

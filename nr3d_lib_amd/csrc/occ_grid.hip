@@ -13,6 +13,7 @@
 // single readback, and single/batched marching share one kernel.
 #include "common.h"
 #include "scan.h"
+#include <stdlib.h>
 
 namespace nr3d {
 namespace occ {
@@ -29,14 +30,27 @@ struct Grid {
 	int rx, ry, rz;
 	const uint8_t *cells;
 	int type;
+	// POW2 fast path: when the ROI extents and the resolution are powers of two, x / d == x * (1 / d) bit for bit
+	// (1 / d is exact and scaling by a power of two does not round), so the ~12-instruction IEEE division
+	// sequences of the probe and of the voxel-exit distance become single multiplies.
+	f3 inv_ext, inv_res;
 };
 
+__device__ __forceinline__ bool is_pow2f(float v) {
+	const uint32_t b = __float_as_uint(v);
+	const uint32_t e = (b >> 23) & 0xFFu;
+	return (b & 0x807FFFFFu) == 0u && e >= 64u && e <= 190u;    // positive, mantissa 0, comfortably normal (and so is 1/v)
+}
+
+template <bool POW2>
 __device__ __forceinline__ f3 to_unit(const Grid &g, f3 p) {
+	if (POW2) return {(p.x - g.mn.x) * g.inv_ext.x, (p.y - g.mn.y) * g.inv_ext.y, (p.z - g.mn.z) * g.inv_ext.z};
 	return {(p.x - g.mn.x) / (g.mx.x - g.mn.x), (p.y - g.mn.y) / (g.mx.y - g.mn.y), (p.z - g.mn.z) / (g.mx.z - g.mn.z)};
 }
 
+template <bool POW2>
 __device__ __forceinline__ f3 contract(const Grid &g, f3 p) {
-	f3 u = to_unit(g, p);
+	f3 u = to_unit<POW2>(g, p);
 	if (g.type == NR3D_CONTRACT_UN_BOUNDED_TANH) {
 		u = {tanhf(u.x - 0.5f) * 0.5f + 0.5f, tanhf(u.y - 0.5f) * 0.5f + 0.5f, tanhf(u.z - 0.5f) * 0.5f + 0.5f};
 	} else if (g.type == NR3D_CONTRACT_UN_BOUNDED_SPHERE) {
@@ -55,11 +69,12 @@ __device__ __forceinline__ f3 contract(const Grid &g, f3 p) {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return max(lo, min(v, hi)); }
 
 // returns occupancy; *cell receives the flat voxel index (z contiguous)
+template <bool POW2>
 __device__ __forceinline__ bool probe(const Grid &g, f3 p, int *cell) {
 	if (g.type == NR3D_CONTRACT_AABB &&
 	    (p.x < g.mn.x || p.x > g.mx.x || p.y < g.mn.y || p.y > g.mx.y || p.z < g.mn.z || p.z > g.mx.z))
 		return false;
-	const f3 u = contract(g, p);
+	const f3 u = contract<POW2>(g, p);
 	const int ix = clampi((int)(u.x * (float)g.rx), 0, g.rx - 1);
 	const int iy = clampi((int)(u.y * (float)g.ry), 0, g.ry - 1);
 	const int iz = clampi((int)(u.z * (float)g.rz), 0, g.rz - 1);
@@ -68,23 +83,80 @@ __device__ __forceinline__ bool probe(const Grid &g, f3 p, int *cell) {
 	return g.cells[idx] != 0;
 }
 
-__device__ __forceinline__ float axis_exit(float q, float dirsign, float inv, float r, float extent) {
-	return ((floorf(q + 0.5f + 0.5f * dirsign) - q) * inv) / r * extent;
+template <bool POW2>
+__device__ __forceinline__ float axis_exit(float q, float dirsign, float inv, float r, float inv_r, float extent) {
+	const float d = (floorf(q + 0.5f + 0.5f * dirsign) - q) * inv;
+	return (POW2 ? d * inv_r : d / r) * extent;
 }
 
 // DDA distance to the next voxel boundary, then advance in dt_min multiples (helpers_march.h:47-77)
+template <bool POW2>
 __device__ __forceinline__ float skip_voxel(const Grid &g, float t, float dt_min, f3 p, f3 dir, f3 inv) {
-	const f3 u = to_unit(g, p);
-	const float tx = axis_exit(u.x * (float)g.rx, copysignf(1.0f, dir.x), inv.x, (float)g.rx, g.mx.x - g.mn.x);
-	const float ty = axis_exit(u.y * (float)g.ry, copysignf(1.0f, dir.y), inv.y, (float)g.ry, g.mx.y - g.mn.y);
-	const float tz = axis_exit(u.z * (float)g.rz, copysignf(1.0f, dir.z), inv.z, (float)g.rz, g.mx.z - g.mn.z);
+	const f3 u = to_unit<POW2>(g, p);
+	const float tx = axis_exit<POW2>(u.x * (float)g.rx, copysignf(1.0f, dir.x), inv.x, (float)g.rx, g.inv_res.x, g.mx.x - g.mn.x);
+	const float ty = axis_exit<POW2>(u.y * (float)g.ry, copysignf(1.0f, dir.y), inv.y, (float)g.ry, g.inv_res.y, g.mx.y - g.mn.y);
+	const float tz = axis_exit<POW2>(u.z * (float)g.rz, copysignf(1.0f, dir.z), inv.z, (float)g.rz, g.inv_res.z, g.mx.z - g.mn.z);
 	const float target = t + fmaxf(fminf(fminf(tx, ty), tz), 0.0f);
 	float tt = t;
 	do { tt += dt_min; } while (tt < target);
 	return tt;
 }
 
-template <bool EMIT>
+// the serial march of one ray (one lane); returns the number of samples
+template <bool EMIT, bool CACHE, bool POW2>
+__device__ __forceinline__ uint32_t march_ray(const Grid &g, uint32_t i, uint32_t b, int32_t grid_offset, f3 o, f3 dir, f3 inv,
+                                              float near, float far, float dt_min, float dt_max, float dt_gamma,
+                                              uint32_t max_steps, uint32_t base, float *__restrict__ t_starts,
+                                              float *__restrict__ t_ends, int32_t *__restrict__ ridx,
+                                              int32_t *__restrict__ bidx, int32_t *__restrict__ gidx,
+                                              uint32_t *__restrict__ cache) {
+	const int type = g.type;
+	uint32_t j = 0;
+	float t0 = near;
+	float dt = calc_dt(t0, dt_gamma, dt_min, dt_max);
+	float t1 = t0 + dt;
+	float tm = (t0 + t1) * 0.5f;
+	while (tm < far && j < max_steps) {
+		const f3 p = {__fmaf_rn(tm, dir.x, o.x), __fmaf_rn(tm, dir.y, o.y), __fmaf_rn(tm, dir.z, o.z)};
+		int cell = -1;
+		if (probe<POW2>(g, p, &cell)) {
+			if (EMIT) {
+				t_starts[base + j] = t0;
+				t_ends[base + j] = t1;
+				ridx[base + j] = (int32_t)i;
+				if (bidx) bidx[base + j] = (int32_t)b;
+				if (gidx) gidx[base + j] = cell + grid_offset;
+			}
+			if (CACHE) {
+				uint32_t *c = cache + ((size_t)i * max_steps + j) * 3;
+				c[0] = __float_as_uint(t0);
+				c[1] = __float_as_uint(t1);
+				c[2] = (uint32_t)(cell + grid_offset);
+			}
+			++j;
+			t0 = t1;
+			t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
+			tm = (t0 + t1) * 0.5f;
+		} else if (type == NR3D_CONTRACT_AABB) {
+			tm = skip_voxel<POW2>(g, tm, dt_min, p, dir, inv);
+			dt = calc_dt(tm, dt_gamma, dt_min, dt_max);
+			t0 = tm - dt * 0.5f;
+			t1 = tm + dt * 0.5f;
+		} else {
+			t0 = t1;
+			t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
+			tm = (t0 + t1) * 0.5f;
+		}
+	}
+	return j;
+}
+
+// CACHE (count pass only): every emitted sample is also stored in a per-ray slot of a caller-provided cache
+// ([n_rays][max_steps] x {t_start, t_end, cell}); the emit pass then is a parallel compaction (k_emit_cached) instead
+// of a second serial march.  A ray is one serial chain of dependent VALU ops and one dependent byte load per probe
+// (~1300 cycles per probe for a lone wave; measured: 4..64 rays per wave take the same time), so for small ray
+// counts the op is bound by its longest ray and skipping the second march halves it.
+template <bool EMIT, bool CACHE>
 __global__ __launch_bounds__(kBlock) void k_march(uint32_t n_rays, const float *__restrict__ rays_o,
                                                   const float *__restrict__ rays_d, const float *__restrict__ t_min,
                                                   const float *__restrict__ t_max, const float *__restrict__ roi,
@@ -94,7 +166,8 @@ __global__ __launch_bounds__(kBlock) void k_march(uint32_t n_rays, const float *
                                                   uint32_t batch_data_size, const int32_t *__restrict__ packed_info,
                                                   int32_t *__restrict__ counts, float *__restrict__ t_starts,
                                                   float *__restrict__ t_ends, int32_t *__restrict__ ridx,
-                                                  int32_t *__restrict__ bidx, int32_t *__restrict__ gidx) {
+                                                  int32_t *__restrict__ bidx, int32_t *__restrict__ gidx,
+                                                  uint32_t *__restrict__ cache) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= n_rays) return;
 	uint32_t b = 0;
@@ -128,38 +201,40 @@ __global__ __launch_bounds__(kBlock) void k_march(uint32_t n_rays, const float *
 	const float far = t_max[i];
 	const float dt_min = step_size, dt_max = max_step_size;
 
-	uint32_t j = 0;
-	float t0 = t_min[i];
-	float dt = calc_dt(t0, dt_gamma, dt_min, dt_max);
-	float t1 = t0 + dt;
-	float tm = (t0 + t1) * 0.5f;
-	while (tm < far && j < max_steps) {
-		const f3 p = {__fmaf_rn(tm, dir.x, o.x), __fmaf_rn(tm, dir.y, o.y), __fmaf_rn(tm, dir.z, o.z)};
-		int cell = -1;
-		if (probe(g, p, &cell)) {
-			if (EMIT) {
-				t_starts[base + j] = t0;
-				t_ends[base + j] = t1;
-				ridx[base + j] = (int32_t)i;
-				if (bidx) bidx[base + j] = (int32_t)b;
-				if (gidx) gidx[base + j] = cell + grid_offset;
-			}
-			++j;
-			t0 = t1;
-			t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
-			tm = (t0 + t1) * 0.5f;
-		} else if (type == NR3D_CONTRACT_AABB) {
-			tm = skip_voxel(g, tm, dt_min, p, dir, inv);
-			dt = calc_dt(tm, dt_gamma, dt_min, dt_max);
-			t0 = tm - dt * 0.5f;
-			t1 = tm + dt * 0.5f;
-		} else {
-			t0 = t1;
-			t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
-			tm = (t0 + t1) * 0.5f;
-		}
-	}
+	g.inv_ext = {1.0f / (g.mx.x - g.mn.x), 1.0f / (g.mx.y - g.mn.y), 1.0f / (g.mx.z - g.mn.z)};
+	g.inv_res = {1.0f / (float)rx, 1.0f / (float)ry, 1.0f / (float)rz};
+	const bool pow2 = is_pow2f(g.mx.x - g.mn.x) && is_pow2f(g.mx.y - g.mn.y) && is_pow2f(g.mx.z - g.mn.z) &&
+	                  is_pow2f((float)rx) && is_pow2f((float)ry) && is_pow2f((float)rz);
+	uint32_t j;
+	if (__all(pow2))      // wave-uniform: no divergence between the two instantiations
+		j = march_ray<EMIT, CACHE, true>(g, i, b, grid_offset, o, dir, inv, t_min[i], far, dt_min, dt_max, dt_gamma, max_steps,
+		                                 base, t_starts, t_ends, ridx, bidx, gidx, cache);
+	else
+		j = march_ray<EMIT, CACHE, false>(g, i, b, grid_offset, o, dir, inv, t_min[i], far, dt_min, dt_max, dt_gamma, max_steps,
+		                                  base, t_starts, t_ends, ridx, bidx, gidx, cache);
 	if (!EMIT) counts[i] = (int32_t)j;
+}
+
+// one wave per ray: copy the ray's cached samples to their packed position
+__global__ __launch_bounds__(256) void k_emit_cached(uint32_t n_rays, uint32_t stride, int batched,
+                                                     const int32_t *__restrict__ batch_inds, uint32_t batch_data_size,
+                                                     const int32_t *__restrict__ packed_info,
+                                                     const uint32_t *__restrict__ cache, float *__restrict__ t_starts,
+                                                     float *__restrict__ t_ends, int32_t *__restrict__ ridx,
+                                                     int32_t *__restrict__ bidx, int32_t *__restrict__ gidx) {
+	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (i >= n_rays) return;
+	const uint32_t base = (uint32_t)packed_info[2 * (size_t)i], cnt = (uint32_t)packed_info[2 * (size_t)i + 1];
+	int32_t b = 0;
+	if (batched) b = batch_inds ? batch_inds[i] : (batch_data_size ? (int32_t)(i / batch_data_size) : 0);
+	const uint32_t *c = cache + (size_t)i * stride * 3;
+	for (uint32_t j = lane; j < cnt; j += 64) {
+		t_starts[base + j] = __uint_as_float(c[3 * j]);
+		t_ends[base + j] = __uint_as_float(c[3 * j + 1]);
+		ridx[base + j] = (int32_t)i;
+		if (bidx) bidx[base + j] = b;
+		if (gidx) gidx[base + j] = (int32_t)c[3 * j + 2];
+	}
 }
 
 }  // namespace occ
@@ -170,12 +245,17 @@ using namespace nr3d;
 // scratch layout: [ int32 counts[n] (padded to 8 B) | tile sums ]
 extern "C" uint64_t nr3d_scan_tmp_bytes(uint64_t n) { return ((n * sizeof(int64_t) + 7) / 8) * 8 + scan::tmp_bytes(n); }
 
+extern "C" uint64_t nr3d_ray_marching_cache_bytes(uint32_t n_rays, uint32_t max_steps) {
+	return (uint64_t)n_rays * max_steps * 12u;
+}
+
 extern "C" int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
                                        const float *t_max, const float *roi, const int32_t grid_res[3],
                                        const uint8_t *grid_binary, int type, float step_size, float max_step_size,
                                        float dt_gamma, uint32_t max_steps, int batched, const int32_t *batch_inds,
                                        uint32_t batch_data_size, int32_t *packed_info, int64_t *total_steps,
-                                       void *scan_tmp, void *stream) {
+                                       void *scan_tmp, void *sample_cache, uint64_t sample_cache_bytes,
+                                       void *stream) {
 	NR3D_CHECK(total_steps && scan_tmp, "ray_marching: NULL scratch pointer");
 	hipStream_t st = (hipStream_t)stream;
 	if (n_rays == 0) { NR3D_HIP_CHECK(hipMemsetAsync(total_steps, 0, sizeof(int64_t), st)); return 0; }
@@ -183,11 +263,15 @@ extern "C" int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, con
 	NR3D_CHECK(type >= 0 && type <= 2, "ray_marching: invalid contraction type %d", type);
 	int32_t *counts = (int32_t *)scan_tmp;
 	void *tiles = (char *)scan_tmp + (((uint64_t)n_rays * sizeof(int64_t) + 7) / 8) * 8;
-	hipLaunchKernelGGL(occ::k_march<false>, dim3(div_up(n_rays, occ::kBlock)), dim3(occ::kBlock), 0, st, n_rays, rays_o,
-	                   rays_d, t_min, t_max, roi, grid_res[0], grid_res[1], grid_res[2], grid_binary, type, step_size,
-	                   max_step_size, dt_gamma, max_steps, batched, batch_inds, batch_data_size,
-	                   (const int32_t *)nullptr, counts, (float *)nullptr, (float *)nullptr, (int32_t *)nullptr,
-	                   (int32_t *)nullptr, (int32_t *)nullptr);
+	const bool cached = sample_cache && sample_cache_bytes >= nr3d_ray_marching_cache_bytes(n_rays, max_steps);
+	auto launch = [&](auto kern) {
+		hipLaunchKernelGGL(kern, dim3(div_up(n_rays, occ::kBlock)), dim3(occ::kBlock), 0, st, n_rays, rays_o, rays_d, t_min,
+		                   t_max, roi, grid_res[0], grid_res[1], grid_res[2], grid_binary, type, step_size, max_step_size,
+		                   dt_gamma, max_steps, batched, batch_inds, batch_data_size, (const int32_t *)nullptr, counts,
+		                   (float *)nullptr, (float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+		                   (uint32_t *)sample_cache);
+	};
+	if (cached) launch(occ::k_march<false, true>); else launch(occ::k_march<false, false>);
 	NR3D_LAUNCH_CHECK();
 	return scan::pack_infos_from_counts<int32_t, int32_t>(n_rays, counts, packed_info, total_steps, tiles, st);
 }
@@ -197,14 +281,22 @@ extern "C" int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, cons
                                       const uint8_t *grid_binary, int type, float step_size, float max_step_size,
                                       float dt_gamma, int batched, const int32_t *batch_inds, uint32_t batch_data_size,
                                       const int32_t *packed_info, float *t_starts, float *t_ends, int32_t *ridx,
-                                      int32_t *bidx, int32_t *gidx, void *stream) {
+                                      int32_t *bidx, int32_t *gidx, const void *sample_cache,
+                                      uint32_t cache_max_steps, void *stream) {
 	if (n_rays == 0) return 0;
 	NR3D_CHECK(rays_o && rays_d && t_min && t_max && roi && grid_binary && packed_info, "ray_marching: NULL tensor pointer");
 	NR3D_CHECK(t_starts && t_ends && ridx, "ray_marching: NULL output pointer");
-	hipLaunchKernelGGL(occ::k_march<true>, dim3(div_up(n_rays, occ::kBlock)), dim3(occ::kBlock), 0, (hipStream_t)stream,
+	if (sample_cache) {   // filled by nr3d_ray_marching_count with the same rays and max_steps == cache_max_steps
+		hipLaunchKernelGGL(occ::k_emit_cached, dim3(div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, n_rays,
+		                   cache_max_steps, batched, batch_inds, batch_data_size, packed_info, (const uint32_t *)sample_cache,
+		                   t_starts, t_ends, ridx, bidx, gidx);
+		NR3D_LAUNCH_CHECK();
+		return 0;
+	}
+	hipLaunchKernelGGL((occ::k_march<true, false>), dim3(div_up(n_rays, occ::kBlock)), dim3(occ::kBlock), 0, (hipStream_t)stream,
 	                   n_rays, rays_o, rays_d, t_min, t_max, roi, grid_res[0], grid_res[1], grid_res[2], grid_binary,
 	                   type, step_size, max_step_size, dt_gamma, 0u, batched, batch_inds, batch_data_size, packed_info,
-	                   (int32_t *)nullptr, t_starts, t_ends, ridx, bidx, gidx);
+	                   (int32_t *)nullptr, t_starts, t_ends, ridx, bidx, gidx, (uint32_t *)nullptr);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

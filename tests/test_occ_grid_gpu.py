@@ -162,3 +162,18 @@ def test_wrapper_record(oracle, dev):
     retb = occgrid_raymarch_batched(t(np.stack([grid, grid])), t(np.stack([o, o])), t(np.stack([d, d])), None,
                                     t(np.stack([near, near])), t(np.stack([far, far])), step_size=0.01, max_steps=256)
     assert retb.num_hit_rays == 2 * len(hit) and int(retb.bidx.max()) == 1
+
+
+def test_sample_cache_and_second_march_agree(oracle, dev, monkeypatch):
+    """emit = compaction of the samples cached by the count pass (default) vs. a second march (no cache):
+    identical outputs, and both equal to the oracle"""
+    res = (64, 64, 64)                                   # power-of-two ROI and res: the multiply-only probe path
+    o, d, near, far = pinhole_rays(32, seed=13)
+    grid = grids(res, 14)["random"]
+    args = (o, d, near, far, ROI, grid, 0, 0.01, 1e10, 0.0, 300)
+    got_cached, ref = run_both(oracle, dev, *args)
+    monkeypatch.setattr(_occ_grid, "SAMPLE_CACHE_MAX_BYTES", 0)
+    got_twice, _ = run_both(oracle, dev, *args)
+    for a, b, r, n in zip(got_cached, got_twice, ref, ["packed_info", "t_starts", "t_ends", "ridx", "gidx"]):
+        assert_equal(a, r, name=f"cached/{n}")
+        assert_equal(b, r, name=f"two-march/{n}")
