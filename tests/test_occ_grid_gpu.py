@@ -167,6 +167,7 @@ def test_wrapper_record(oracle, dev):
 def test_sample_cache_and_second_march_agree(oracle, dev, monkeypatch):
     """emit = compaction of the samples cached by the count pass (default) vs. a second march (no cache):
     identical outputs, and both equal to the oracle"""
+    from nr3d_lib_amd.bindings import _occ_grid
     res = (64, 64, 64)                                   # power-of-two ROI and res: the multiply-only probe path
     o, d, near, far = pinhole_rays(32, seed=13)
     grid = grids(res, 14)["random"]
