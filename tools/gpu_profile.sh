@@ -11,10 +11,12 @@ rm -rf /tmp/prof_k && rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o p -- $B
 DB=$(find /tmp/prof_k -name '*.db' | head -1)
 python $ROOT/tools/prof_summary.py "$DB" > "$OUT/bench_kernel_stats.txt" 2>&1
 if [ -n "$PMC" ]; then
+  rm -f "$OUT/pmc_traffic.json"
   for CTR in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/prof_c && rocprofv3 --kernel-trace --pmc $CTR -d /tmp/prof_c -o p -- $BENCH > /dev/null 2>&1
     DB=$(find /tmp/prof_c -name '*.db' | head -1)
     python $ROOT/tools/prof_summary.py "$DB" pmc > "$OUT/bench_pmc_$(echo $CTR | tr A-Z a-z).txt" 2>&1
+    python $ROOT/tools/prof_summary.py "$DB" pmc-json "$OUT/pmc_traffic.json"
   done
 fi
 head -16 "$OUT/bench_kernel_stats.txt"

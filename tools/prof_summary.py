@@ -49,8 +49,23 @@ def pmc(path, out=sys.stdout):
         print(f"{n[:70]:70s} {cn:14s} {len(a):10d} {sum(a.values()) / len(a):18.1f}", file=out)
 
 
+def pmc_json(path, out_path):
+    """merge the per-kernel averages of one PMC pass into a JSON file {kernel: {counter: avg_per_dispatch}}"""
+    import io, json, os
+    buf = io.StringIO()
+    pmc(path, buf)
+    data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    for line in buf.getvalue().splitlines()[1:]:
+        name, rest = line[:70].strip(), line[70:].split()
+        if len(rest) == 3:
+            data.setdefault(name, {})[rest[0]] = float(rest[2])
+    json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "pmc":
+    if len(sys.argv) > 3 and sys.argv[2] == "pmc-json":
+        pmc_json(sys.argv[1], sys.argv[3])
+    elif len(sys.argv) > 2 and sys.argv[2] == "pmc":
         pmc(sys.argv[1])
     else:
         main(sys.argv[1])
