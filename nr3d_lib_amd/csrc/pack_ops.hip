@@ -498,6 +498,89 @@ __global__ __launch_bounds__(kBlock) void k_alpha_bwd(uint32_t P, const float *_
 	}
 }
 
+// ---- lane-per-pack variants: many short packs (>= 1 wave of packs per SIMD).  The recurrences are serial per pack
+// either way; with one pack per lane a wave advances 64 packs per instruction instead of broadcasting one pack's
+// samples lane by lane.  Same operation order per pack => same bits as the wave-per-pack kernels.
+struct __attribute__((packed, aligned(4))) F4u { float v[4]; };     // 4 samples, dword aligned (one dwordx4 access)
+struct __attribute__((packed, aligned(1))) B4u { uint8_t v[4]; };
+
+__global__ __launch_bounds__(kBlock) void k_alpha_fwd_lpp(uint32_t P, const float *__restrict__ alphas,
+                                                          const int64_t *__restrict__ pi, float eps, float thre,
+                                                          float *__restrict__ weights, int64_t *__restrict__ num_steps,
+                                                          uint8_t *__restrict__ selector) {
+	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	if (p >= P) return;
+	const uint32_t begin = (uint32_t)pi[2 * (size_t)p], len = (uint32_t)pi[2 * (size_t)p + 1];
+	float T = 1.0f;
+	int cnt = 0;
+	bool stopped = false;
+	auto one = [&](float a, float &w, bool &sel) {
+		w = 0.0f; sel = false;
+		if (stopped) return;
+		if (T < eps) { stopped = true; return; }
+		if (!(a <= thre)) { w = a * T; sel = true; T *= (1.0f - a); ++cnt; }
+	};
+	uint32_t j = 0;
+	for (; j + 4 <= len; j += 4) {          // 4 samples per memory request (the lanes' packs are in different lines)
+		const F4u a4 = *reinterpret_cast<const F4u *>(alphas + begin + j);
+		F4u w4; B4u s4;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) { bool sel; one(a4.v[u], w4.v[u], sel); s4.v[u] = sel ? 1 : 0; }
+		if (weights) *reinterpret_cast<F4u *>(weights + begin + j) = w4;
+		if (selector) *reinterpret_cast<B4u *>(selector + begin + j) = s4;
+	}
+	for (; j < len; ++j) {
+		float w; bool sel;
+		one(alphas[begin + j], w, sel);
+		if (weights) weights[begin + j] = w;
+		if (selector) selector[begin + j] = sel ? 1 : 0;
+	}
+	if (num_steps) num_steps[p] = (int64_t)cnt;
+}
+
+__global__ __launch_bounds__(kBlock) void k_alpha_bwd_lpp(uint32_t P, const float *__restrict__ alphas,
+                                                          const float *__restrict__ weights,
+                                                          const float *__restrict__ grad_weights,
+                                                          const int64_t *__restrict__ pi, float eps, float thre,
+                                                          float *__restrict__ grad_alphas) {
+	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	if (p >= P) return;
+	const uint32_t begin = (uint32_t)pi[2 * (size_t)p], len = (uint32_t)pi[2 * (size_t)p + 1];
+	float accum = 0.0f;
+	uint32_t j = 0;
+	for (; j + 4 <= len; j += 4) {
+		const F4u g4 = *reinterpret_cast<const F4u *>(grad_weights + begin + j);
+		const F4u w4 = *reinterpret_cast<const F4u *>(weights + begin + j);
+#pragma unroll
+		for (int u = 0; u < 4; ++u) accum = __fmaf_rn(g4.v[u], w4.v[u], accum);
+	}
+	for (; j < len; ++j) accum = __fmaf_rn(grad_weights[begin + j], weights[begin + j], accum);
+	float T = 1.0f;
+	bool stopped = false;
+	auto one = [&](float a, float gw, float w) -> float {
+		if (stopped) return 0.0f;
+		if (T < eps) { stopped = true; return 0.0f; }
+		if (a < thre) return 0.0f;
+		const float ga = __fmaf_rn(gw, T, -accum) / fmaxf(1.0f - a, 1e-10f);
+		accum = __fmaf_rn(-gw, w, accum);
+		T *= (1.0f - a);
+		return ga;
+	};
+	for (j = 0; j + 4 <= len; j += 4) {
+		const F4u a4 = *reinterpret_cast<const F4u *>(alphas + begin + j);
+		const F4u g4 = *reinterpret_cast<const F4u *>(grad_weights + begin + j);
+		const F4u w4 = *reinterpret_cast<const F4u *>(weights + begin + j);
+		F4u o4;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) o4.v[u] = one(a4.v[u], g4.v[u], w4.v[u]);
+		*reinterpret_cast<F4u *>(grad_alphas + begin + j) = o4;
+	}
+	for (; j < len; ++j) grad_alphas[begin + j] = one(alphas[begin + j], grad_weights[begin + j], weights[begin + j]);
+}
+
+// wave-per-pack unless there are enough packs to give every SIMD (1024 on MI355X) a wave of them
+static inline bool lane_per_pack(uint32_t P) { return P >= 64u * 1024u; }
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_boundaries(uint64_t n, const T *__restrict__ ids, int32_t *__restrict__ b) {
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -670,8 +753,12 @@ extern "C" int nr3d_alpha_to_vw_forward(uint32_t P, uint64_t S, const float *alp
                                         float early_stop_eps, float alpha_thre, float *weights, int64_t *num_steps,
                                         uint8_t *selector, void *stream) {
 	if (P == 0) return 0;
-	hipLaunchKernelGGL(pk::k_alpha_fwd, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas, pack_infos,
-	                   early_stop_eps, alpha_thre, weights, num_steps, selector);
+	if (pk::lane_per_pack(P))
+		hipLaunchKernelGGL(pk::k_alpha_fwd_lpp, dim3(div_up(P, pk::kBlock)), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas,
+		                   pack_infos, early_stop_eps, alpha_thre, weights, num_steps, selector);
+	else
+		hipLaunchKernelGGL(pk::k_alpha_fwd, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas, pack_infos,
+		                   early_stop_eps, alpha_thre, weights, num_steps, selector);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
@@ -680,8 +767,12 @@ extern "C" int nr3d_alpha_to_vw_backward(uint32_t P, uint64_t S, const float *al
                                          const float *grad_weights, const int64_t *pack_infos, float early_stop_eps,
                                          float alpha_thre, float *grad_alphas, void *stream) {
 	if (P == 0) return 0;
-	hipLaunchKernelGGL(pk::k_alpha_bwd, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas, weights,
-	                   grad_weights, pack_infos, early_stop_eps, alpha_thre, grad_alphas);
+	if (pk::lane_per_pack(P))
+		hipLaunchKernelGGL(pk::k_alpha_bwd_lpp, dim3(div_up(P, pk::kBlock)), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas,
+		                   weights, grad_weights, pack_infos, early_stop_eps, alpha_thre, grad_alphas);
+	else
+		hipLaunchKernelGGL(pk::k_alpha_bwd, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas, weights,
+		                   grad_weights, pack_infos, early_stop_eps, alpha_thre, grad_alphas);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

@@ -257,6 +257,24 @@ def test_alpha_to_vw(oracle, dev, P, eps, thre):
     assert_equal(ga, oracle.packed_alpha_to_vw_backward(rw, gw, alpha, pi, eps, thre), "grad_alphas")
 
 
+def test_alpha_to_vw_many_short_packs(oracle, dev, P):
+    """>= 65536 packs switch to the lane-per-pack kernels: same bits as the oracle"""
+    rng = np.random.default_rng(23)
+    pi, S = random_packs(rng, 70000, 0, 24, 0.05)
+    alpha = (rng.uniform(0, 1, S) ** 2).astype(np.float32)
+    alpha[rng.random(S) < 0.05] = 1.0
+    eps, thre = 1e-4, 0.01
+    w, _, _ = P.packed_alpha_to_vw_forward(T(alpha, dev), T(pi, dev), eps, thre, False)
+    rw, _, _ = oracle.packed_alpha_to_vw_forward(alpha, pi, eps, thre, False)
+    assert_equal(w, rw, "weights")
+    _, cpi, sel = P.packed_alpha_to_vw_forward(T(alpha, dev), T(pi, dev), eps, thre, True)
+    _, rcpi, rsel = oracle.packed_alpha_to_vw_forward(alpha, pi, eps, thre, True)
+    assert_equal(sel, rsel, "compact_selector"); assert_equal(cpi, rcpi, "compact_pack_infos")
+    gw = rng.standard_normal(S).astype(np.float32)
+    ga = P.packed_alpha_to_vw_backward(T(rw, dev), T(gw, dev), T(alpha, dev), T(pi, dev), eps, thre)
+    assert_equal(ga, oracle.packed_alpha_to_vw_backward(rw, gw, alpha, pi, eps, thre), "grad_alphas")
+
+
 def test_autograd_wrappers(oracle, dev):
     """gradients of the pack_ops.py autograd layer against dense torch autograd on equal-length packs
     (the reference's own strategy, unit_test.py:100-131, 203-210)"""
