@@ -851,12 +851,12 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
                              uint64_t workspace_bytes, void *stream) {
 	if (N == 0 || max_level <= -1) return 0;
 	NR3D_CHECK(dL_dy && x && params && dL_dparam, "LoTD::bwd: NULL tensor pointer");
-	// atomic-free binned path: Dense/Hash metas without batching, when the caller supplied the workspace
+	// atomic-free binned path: metas without NPlaneSum/CPfast levels and without batching, when the caller supplied the workspace
 	if (workspace && !batch_inds && !batch_offsets && batch_data_size == 0) {
 		bool handled = false;
 		if (int rc = dparam_binned(second, meta, meta_dev, N, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
-		                           (const float *)x, max_level, (float *)dL_dparam, workspace, workspace_bytes,
-		                           (hipStream_t)stream, handled))
+		                           (const float *)x, (const float *)params, max_level, (float *)dL_dparam, workspace,
+		                           workspace_bytes, (hipStream_t)stream, handled))
 			return rc;
 		if (handled) return 0;
 	}

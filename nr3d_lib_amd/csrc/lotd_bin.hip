@@ -42,14 +42,32 @@ constexpr uint32_t kMaxBuckets = 8192;    // per pseudo level
 		else { constexpr int D = 4, G = 8; __VA_ARGS__; }                            \
 	} while (0)
 
+// Record classes: NR = capacity in records per (point, pseudo level).  Updates that hit the same table entry from
+// several corners of one point are summed in registers first (CP: 2 entries per line, VM: 4 per plane + 2 per line...).
+//   Dense/Hash 2^D | CP 2D | VecZMatXoY 4 + 2 | NPlaneMul D * 2^(D-1) | VM 3 * (4 + 2) = 18
+// NPlaneSum / CPfast (and NPlaneMul in 4-D) are not binned: such metas use the atomic kernels.
+__host__ __device__ inline uint32_t rec_count(uint32_t type, uint32_t D) {
+	switch (type) {
+	case NR3D_LOD_Dense: case NR3D_LOD_Hash: return 1u << D;
+	case NR3D_LOD_CP: return 2u * D;
+	case NR3D_LOD_VecZMatXoY: return D == 3 ? 6u : 0u;
+	case NR3D_LOD_NPlaneMul: return D <= 3 ? D << (D - 1) : 0u;
+	case NR3D_LOD_VectorMatrix: return D == 3 ? 18u : 0u;
+	default: return 0u;
+	}
+}
+static inline uint32_t rec_class(uint32_t n_rec) { return n_rec == 0 ? 0u : n_rec <= 8 ? 8u : n_rec <= 16 ? 16u : 24u; }
+
 struct BinPlan {
+	uint32_t qmap[kMaxPlanLevels];        // pseudo level of the meta behind local index q (levels of ONE record class)
 	uint32_t nb[kMaxPlanLevels];          // buckets per pseudo level
 	uint32_t rep[kMaxPlanLevels];         // replicas per bucket (stage B)
 	uint32_t order[kMaxPlanLevels];       // stage-B launch order of the pseudo levels: largest workgroups first
 	uint32_t offs_base[kMaxPlanLevels];   // start of this pseudo level's offset table (in uint32 units)
 	uint32_t epb_log2;                    // log2(entries per bucket)
 	uint32_t n_blk;                       // stage-A workgroups along the points of the current chunk
-	uint32_t n_pseudo;
+	uint32_t n_pseudo;                    // pseudo levels in this plan
+	uint32_t cap;                         // records per slot = stage-A points per workgroup x NR
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -74,32 +92,188 @@ __global__ __launch_bounds__(256) void k_transpose(uint32_t n, uint32_t E, const
 }
 
 // -------------------------------------------------------------------------------------------------
-// Stage A: bin the corner updates of BP points x 1 pseudo level by bucket.
+// Stage A: bin the parameter updates of BP points x 1 pseudo level by bucket.
 // BP (points = threads per workgroup) is the largest power of two whose record staging area
-// ((1 + G) words x BP x 2^D records) fits in 64 KiB of LDS, so 2 workgroups share a CU.
+// ((1 + G) words x BP x NR records) fits in 72 KiB of LDS, so 2 workgroups share a CU.
 // -------------------------------------------------------------------------------------------------
-template <int D, int G>
+template <int G, int NR>
 struct BinCfg {
-	static constexpr int raw = 16384 / ((1 + G) * (1 << D));
+	static constexpr int raw = (72 * 1024 / 4) / ((1 + G) * NR);
 	static constexpr int BP = raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
-	static constexpr uint32_t cap = (uint32_t)BP << D;          // records per (pseudo level, point block)
+	static constexpr uint32_t cap = (uint32_t)BP * NR;          // records per (pseudo level, point block)
 };
+static uint32_t bin_points(uint32_t G, uint32_t NR) {
+	const uint32_t raw = (72u * 1024u / 4u) / ((1u + G) * NR);
+	return raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
+}
 
-template <int D, int G, bool SECOND>
-__global__ __launch_bounds__((BinCfg<D, G>::BP)) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
-                                                          int32_t max_level, uint32_t smooth, const float *__restrict__ x,
-                                                          const float *__restrict__ vin_, const float *__restrict__ g,
-                                                          int64_t g_sn, int64_t g_se, uint32_t *__restrict__ rec,
-                                                          uint32_t *__restrict__ offs_g) {
-	constexpr int BP = BinCfg<D, G>::BP;
-	constexpr uint32_t cap = BinCfg<D, G>::cap;
+// bits of corner k without bit `skip`, packed
+template <int D>
+__device__ __forceinline__ constexpr uint32_t drop_bit(uint32_t k, int skip) {
+	return (k & ((1u << skip) - 1u)) | ((k >> (skip + 1)) << skip);
+}
+// inverse: m with a zero bit inserted at position `at`
+__device__ __forceinline__ constexpr uint32_t insert_zero(uint32_t m, int at) {
+	return (m & ((1u << at) - 1u)) | ((m >> at) << (at + 1));
+}
+
+// Product of D factor tables T_d; corner k uses slot s_d(k) of table d.
+//   CP:        T_d = line d, slot = bit d of k (NS = 2)
+//   NPlaneMul: T_j = plane spanning all dims but D-1-j, slot = the other dims' bits (NS = 2^(D-1))
+// d/dT_gd[slot] = sum over the corners with that slot of (grad * w) * prod_{j != gd} T_j[s_j(k)]   (corner_scatter order)
+template <int D, int G, int NR, int NS, bool CP>
+__device__ __forceinline__ uint32_t emit_product(const Lvl &L, const Cell<D> &c, const float (&w)[1 << D], const float (&grad)[G],
+                                                 const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
+                                                 float (&val)[NR][G]) {
+	constexpr uint32_t C = 1u << D;
+	float tv[D][NS][G];
+	uint32_t te[D][NS];
+	auto slot = [](uint32_t k, int d) -> uint32_t { return CP ? ((k >> d) & 1u) : drop_bit<D>(k, D - 1 - d); };
+#pragma unroll
+	for (int d = 0; d < D; ++d)
+#pragma unroll
+		for (uint32_t sl = 0; sl < (uint32_t)NS; ++sl) {
+			uint32_t e;
+			if (CP) e = entry_line<D>(L, d, c.g[d] + sl);
+			else {
+				uint32_t p[D];
+				corner_pos<D>(c, insert_zero(sl, D - 1 - d), p);
+				e = entry_nplane_mul<D>(L, d, p);
+			}
+			te[d][sl] = e;
+#pragma unroll
+			for (int f = 0; f < G; ++f) tv[d][sl][f] = grid[e * L.F + foff + f];
+		}
+#pragma unroll
+	for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+		for (uint32_t sl = 0; sl < (uint32_t)NS; ++sl) {
+			float acc[G];
+#pragma unroll
+			for (int f = 0; f < G; ++f) acc[f] = 0.0f;
+#pragma unroll
+			for (uint32_t k = 0; k < C; ++k) {
+				if (slot(k, gd) != sl) continue;
+#pragma unroll
+				for (int f = 0; f < G; ++f) {
+					float cur = grad[f] * w[k];
+#pragma unroll
+					for (int j = 0; j < D; ++j)
+						if (j != gd) cur *= tv[j][slot(k, j)][f];
+					acc[f] += cur;
+				}
+			}
+			ent[gd * NS + sl] = te[gd][sl];
+#pragma unroll
+			for (int f = 0; f < G; ++f) val[gd * NS + sl][f] = acc[f];
+		}
+	return (uint32_t)(D * NS);
+}
+
+// The parameter updates of one (point, pseudo level): table entry + G values each.  `w[k]` is the weight of corner k
+// (first order: the interpolation weight; second order: the combined d/dx weight), `grad` = dL/dy of the G features,
+// `grid` = params + level offset, `foff` = first feature of this pseudo level inside the level's entries.
+// Same per-update arithmetic as corner_scatter() (lotd_device.h); contributions to one entry are added in corner order.
+template <int D, int G, int NR>
+__device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c, const float (&w)[1 << D], const float (&grad)[G],
+                                                 const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
+                                                 float (&val)[NR][G]) {
+	constexpr uint32_t C = 1u << D;
+	if (L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash) {
+		if constexpr (NR >= (int)C) {
+#pragma unroll
+			for (uint32_t k = 0; k < C; ++k) {
+				uint32_t p[D];
+				corner_pos<D>(c, k, p);
+				ent[k] = (L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p);
+#pragma unroll
+				for (int f = 0; f < G; ++f) val[k][f] = grad[f] * w[k];
+			}
+			return C;
+		}
+	} else if (L.type == NR3D_LOD_CP) {
+		if constexpr (NR >= 2 * D) return emit_product<D, G, NR, 2, true>(L, c, w, grad, grid, foff, ent, val);
+	} else if (L.type == NR3D_LOD_NPlaneMul) {
+		if constexpr (D <= 3 && NR >= D * (1 << (D - 1)))
+			return emit_product<D, G, NR, (1 << (D - 1)), false>(L, c, w, grad, grid, foff, ent, val);
+	} else if (L.type == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VecZMatXoY) {
+		if constexpr (D == 3) {
+			const bool vm = L.type == NR3D_LOD_VectorMatrix;
+			if constexpr (NR >= 6) {
+				if (vm && NR < 18) return 0;
+				// per component d: plane (the two dims != d, 4 slots) x line (dim d, 2 slots); VecZMatXoY has d = 2 only
+				uint32_t n = 0;
+#pragma unroll
+				for (int d = 0; d < 3; ++d) {
+					if (!vm && d != 2) continue;
+					float pv[4][G], lv[2][G];
+					uint32_t pe[4], le[2];
+#pragma unroll
+					for (uint32_t m = 0; m < 4; ++m) {
+						uint32_t p[3];
+						corner_pos<3>(c, insert_zero(m, d), p);
+						if (vm) { uint32_t pl[3], ln[3]; entry_vm(L, p, pl, ln); pe[m] = pl[d]; if (m == 0) le[0] = ln[d]; }
+						else { pe[m] = L.res[2] + p[1] + p[0] * L.res[0]; if (m == 0) le[0] = p[2]; }
+#pragma unroll
+						for (int f = 0; f < G; ++f) pv[m][f] = grid[pe[m] * L.F + foff + f];
+					}
+					le[1] = le[0] + 1u;
+#pragma unroll
+					for (uint32_t sl = 0; sl < 2; ++sl)
+#pragma unroll
+						for (int f = 0; f < G; ++f) lv[sl][f] = grid[le[sl] * L.F + foff + f];
+					// plane slots
+#pragma unroll
+					for (uint32_t m = 0; m < 4; ++m) {
+						if ((int)n < NR) {
+							ent[n] = pe[m];
+#pragma unroll
+							for (int f = 0; f < G; ++f) {
+								const uint32_t k0 = insert_zero(m, d), k1 = k0 | (1u << d);
+								val[n][f] = (grad[f] * w[k0]) * lv[0][f] + (grad[f] * w[k1]) * lv[1][f];
+							}
+						}
+						++n;
+					}
+					// line slots
+#pragma unroll
+					for (uint32_t sl = 0; sl < 2; ++sl) {
+						if ((int)n < NR) {
+							ent[n] = le[sl];
+#pragma unroll
+							for (int f = 0; f < G; ++f) {
+								float acc = 0.0f;
+#pragma unroll
+								for (uint32_t m = 0; m < 4; ++m) acc += (grad[f] * w[insert_zero(m, d) | (sl << d)]) * pv[m][f];
+								val[n][f] = acc;
+							}
+						}
+						++n;
+					}
+				}
+				return n;
+			}
+		}
+	}
+	return 0;
+}
+
+template <int D, int G, bool SECOND, int NR>
+__global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                           int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                           const float *__restrict__ vin_, const float *__restrict__ g,
+                                                           int64_t g_sn, int64_t g_se, const float *__restrict__ params,
+                                                           uint32_t *__restrict__ rec, uint32_t *__restrict__ offs_g) {
+	constexpr int BP = BinCfg<G, NR>::BP;
+	constexpr uint32_t cap = BinCfg<G, NR>::cap;
 	constexpr int C = 1 << D;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // stage[(1+G)*cap] | hist[nb + 1]
 	__shared__ uint64_t scan_lds[BP / 64 > 0 ? BP / 64 : 1];
 	uint32_t *stage = smem;
 	uint32_t *hist = smem + (size_t)(1 + G) * cap;
-	const uint32_t blk = blockIdx.x, q = blockIdx.y;
-	const uint32_t nb = plan.nb[q];
+	const uint32_t blk = blockIdx.x, ql = blockIdx.y;
+	const uint32_t q = plan.qmap[ql];
+	const uint32_t nb = plan.nb[ql];
 	const uint32_t level = md->map_levels[q];
 	const uint32_t i = blk * BP + threadIdx.x;
 	const Lvl L = load_level(md, level);
@@ -108,14 +282,16 @@ __global__ __launch_bounds__((BinCfg<D, G>::BP)) void k_bin(BinPlan plan, const 
 	__syncthreads();
 
 	const bool active = (i < n) && ((int32_t)level <= max_level);
-	uint32_t ent[C], rank[C];
-	float w[C], grad[G];
+	uint32_t ent[NR], rank[NR];
+	float val[NR][G];
+	uint32_t n_rec = 0;
 	if (active) {
 		float xp[D];
 #pragma unroll
 		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
 		Cell<D> c;
 		locate<D>(xp, L, smooth != 0, c);
+		float grad[G], w[C];
 #pragma unroll
 		for (int f = 0; f < G; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(q * G + f) * g_se];
 		float a[D];
@@ -134,11 +310,11 @@ __global__ __launch_bounds__((BinCfg<D, G>::BP)) void k_bin(BinPlan plan, const 
 				}
 				w[k] = sum;
 			}
-			uint32_t p[D];
-			corner_pos<D>(c, k, p);
-			ent[k] = (L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p);
-			rank[k] = atomicAdd(&hist[ent[k] >> plan.epb_log2], 1u);
 		}
+		n_rec = emit_updates<D, G, NR>(L, c, w, grad, params + L.off, (uint32_t)md->map_cnt[q] * G, ent, val);
+#pragma unroll
+		for (uint32_t r = 0; r < (uint32_t)NR; ++r)
+			if (r < n_rec) rank[r] = atomicAdd(&hist[ent[r] >> plan.epb_log2], 1u);
 	}
 	__syncthreads();
 
@@ -168,22 +344,23 @@ __global__ __launch_bounds__((BinCfg<D, G>::BP)) void k_bin(BinPlan plan, const 
 	if (active) {
 		const uint32_t mask = (1u << plan.epb_log2) - 1u;
 #pragma unroll
-		for (uint32_t k = 0; k < (uint32_t)C; ++k) {
-			const uint32_t pos = hist[ent[k] >> plan.epb_log2] + rank[k];
-			stage[pos * (1 + G)] = ent[k] & mask;
+		for (uint32_t r = 0; r < (uint32_t)NR; ++r) {
+			if (r >= n_rec) continue;
+			const uint32_t pos = hist[ent[r] >> plan.epb_log2] + rank[r];
+			stage[pos * (1 + G)] = ent[r] & mask;
 #pragma unroll
-			for (int f = 0; f < G; ++f) stage[pos * (1 + G) + 1 + f] = __float_as_uint(grad[f] * w[k]);
+			for (int f = 0; f < G; ++f) stage[pos * (1 + G) + 1 + f] = __float_as_uint(val[r][f]);
 		}
 	}
 	__syncthreads();
 
 	// coalesced 16-byte write-out of the filled prefix (records are (1 + G)-word AoS, so a bucket's run is one
 	// contiguous span of the slot and stage B over-fetches at most one cache line per run)
-	const uint32_t total = hist[nb];                          // multiple of 2^D >= 4
-	uint4 *dst = reinterpret_cast<uint4 *>(rec + ((size_t)q * plan.n_blk + blk) * (size_t)(1 + G) * cap);
+	const uint32_t total = hist[nb];
+	uint4 *dst = reinterpret_cast<uint4 *>(rec + ((size_t)ql * plan.n_blk + blk) * (size_t)(1 + G) * cap);
 	const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-	for (uint32_t v4 = threadIdx.x; v4 < total / 4 * (1 + G); v4 += BP) dst[v4] = src[v4];
-	uint32_t *ob = offs_g + plan.offs_base[q];
+	for (uint32_t v4 = threadIdx.x; v4 < (total * (1 + G) + 3) / 4; v4 += BP) dst[v4] = src[v4];   // tail: <= 3 stale words
+	uint32_t *ob = offs_g + plan.offs_base[ql];
 	for (uint32_t b = threadIdx.x; b <= nb; b += BP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
 }
 
@@ -197,14 +374,15 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
                                                        float *__restrict__ dparam) {
 	// accumulators are feature-major (acc[f][entry]): the G atomics of a record spread over all LDS banks
 	extern __shared__ __attribute__((aligned(16))) double acc[];      // [kLdsDoubles]
-	constexpr uint32_t cap = BinCfg<D, G>::cap;
-	const uint32_t q = plan.order[blockIdx.y];
+	const uint32_t cap = plan.cap;
+	const uint32_t q = plan.order[blockIdx.y];            // local index into this plan's levels
 	const uint32_t nb = plan.nb[q], R = plan.rep[q];
 	if (blockIdx.x >= nb * R) return;
 	const uint32_t b = blockIdx.x / R, r = blockIdx.x - b * R;
-	const uint32_t level = md->map_levels[q];
+	const uint32_t qg = plan.qmap[q];                     // pseudo level of the meta
+	const uint32_t level = md->map_levels[qg];
 	const Lvl L = load_level(md, level);
-	const uint32_t foff0 = (uint32_t)md->map_cnt[q] * G;
+	const uint32_t foff0 = (uint32_t)md->map_cnt[qg] * G;
 
 	for (uint32_t t = threadIdx.x; t < (uint32_t)kLdsDoubles; t += kAccThreads) acc[t] = 0.0;
 	__syncthreads();
@@ -219,9 +397,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 	// lane t fetches the run [start, end) of block blk0 + t (coalesced); the runs are then walked one per
 	// wave-instruction (lane < run length active, run bounds broadcast with v_readlane), kUnroll runs in flight.
 	// No per-record ownership search: a hash level's runs hold 64 +- 8 records, so a run costs one full and at most
-	// one sparse pass.  The kernel is bound by the LDS atomic pipe (SQ_ACTIVE_INST_LDS + SQ_LDS_BANK_CONFLICT ~ 100 %
-	// of the busy cycles: 64 random 8-byte addresses over 16 bank pairs cost ~58 cycles per ds_add_f64), not by HBM,
-	// so neither deeper load pipelining nor a bucket-major record stream (both tried) shortens it.
+	// one sparse pass.  While workgroups are resident the kernel streams at ~5.4 TB/s with the LDS atomic pipe about
+	// 70 % busy; deeper load pipelining and a bucket-major record stream (both tried) do not shorten it, the rest is
+	// the workgroup tail (one 128-KiB-LDS workgroup per CU).
 	const uint32_t epb = 1u << plan.epb_log2;
 	const uint32_t per_wave = (blk_hi - blk_lo + n_waves - 1) / n_waves;
 	const uint32_t w_lo = min(blk_lo + wave * per_wave, blk_hi), w_hi = min(w_lo + per_wave, blk_hi);
@@ -308,49 +486,47 @@ static uint32_t chunk_points(uint32_t n) {
 	return n < chunk ? n : chunk;
 }
 
-static uint32_t bin_points(uint32_t D, uint32_t G) {
-	const uint32_t raw = 16384u / ((1u + G) * (1u << D));
-	return raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
-}
-
-static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinPlan &plan, uint64_t &offs_words) {
-	const uint32_t G = m->n_feat_per_pseudo_lvl;
-	const uint32_t kBinPts = bin_points(m->n_dims_to_encode, G);
-	if (m->n_pseudo_levels > kMaxPlanLevels || !m->c_hash_only) return false;
+// plan for the pseudo levels of record class `cls` (0 levels => n_pseudo == 0)
+static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t cls, BinPlan &plan, uint64_t &offs_words) {
+	const uint32_t D = m->n_dims_to_encode, G = m->n_feat_per_pseudo_lvl;
+	const uint32_t kBinPts = bin_points(G, cls);
+	if (m->n_pseudo_levels > kMaxPlanLevels) return false;
 	uint32_t lg = 0;
 	while ((1u << (lg + 1)) <= (uint32_t)kLdsDoubles / G) ++lg;
 	plan.epb_log2 = lg;
 	plan.n_blk = div_up(n_chunk, kBinPts);
-	plan.n_pseudo = m->n_pseudo_levels;
+	plan.cap = kBinPts * cls;
+	uint32_t nq = 0;
 	uint64_t base = 0;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
+		if (rec_class(rec_count(L.type, D)) != cls) continue;
 		const uint32_t nb = div_up(L.size, 1u << lg);
 		if (nb > kMaxBuckets) return false;
-		plan.nb[q] = nb;
-		// enough stage-B workgroups per level to spread over the chip, never more replicas than point blocks
-		uint32_t rep = 1;
-		plan.rep[q] = rep;
+		plan.qmap[nq] = q;
+		plan.nb[nq] = nb;
 		if (base > 0xFFFFFFFFull) return false;
-		plan.offs_base[q] = (uint32_t)base;
+		plan.offs_base[nq] = (uint32_t)base;
 		base += (uint64_t)(nb + 1) * plan.n_blk;
+		++nq;
 	}
+	plan.n_pseudo = nq;
 	offs_words = base;
-	// A bucket of the largest level is the unsplittable unit of stage-B work (one workgroup, ~n * 2^D / nb_max records
-	// when the points are spread out).  Smaller levels are replicated until their workgroups are about that size too
-	// (rounded down: a few larger workgroups, launched first, pack better than many that spill into another round),
-	// and the levels are launched by decreasing workgroup size.
+	// A bucket of the largest level is the unsplittable unit of stage-B work (one workgroup, ~n * records / nb_max
+	// records when the points are spread out).  Smaller levels are replicated until their workgroups are about that
+	// size too (rounded down: a few larger workgroups, launched first, pack better than many that spill into another
+	// round), and the levels are launched by decreasing workgroup size.
 	uint32_t nb_max = 1;
-	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) nb_max = plan.nb[q] > nb_max ? plan.nb[q] : nb_max;
+	for (uint32_t q = 0; q < nq; ++q) nb_max = plan.nb[q] > nb_max ? plan.nb[q] : nb_max;
 	const uint32_t unit = nb_max < 64 ? 64 : nb_max;              // at least 64 workgroups per level to cover the chip
-	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
+	for (uint32_t q = 0; q < nq; ++q) {
 		uint32_t rep = unit / plan.nb[q];
 		rep = rep < 1 ? 1 : rep;
 		if (rep > plan.n_blk) rep = plan.n_blk ? plan.n_blk : 1u;
 		plan.rep[q] = rep;
 		plan.order[q] = q;
 	}
-	for (uint32_t i = 1; i < m->n_pseudo_levels; ++i) {           // insertion sort by nb * rep ascending (= work descending)
+	for (uint32_t i = 1; i < nq; ++i) {                            // insertion sort by nb * rep ascending (= work descending)
 		const uint32_t q = plan.order[i];
 		const uint32_t key = plan.nb[q] * plan.rep[q];
 		uint32_t j = i;
@@ -360,37 +536,82 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinPlan &plan
 	return true;
 }
 
+// every level must have a binned form, and params must not be batched (checked by the caller)
+static bool binnable(const nr3d_lotd_meta_t *m) {
+	if (m->n_pseudo_levels > kMaxPlanLevels) return false;
+	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q)
+		if (rec_count(m->levels[m->map_levels[q]].type, m->n_dims_to_encode) == 0) return false;
+	return true;
+}
+
+constexpr uint32_t kClasses[3] = {8, 16, 24};
+
 struct BinLayout { uint64_t rec_bytes, offs_bytes, gt_bytes, total; };
 
-static BinLayout layout(const nr3d_lotd_meta_t *m, const BinPlan &plan, uint64_t offs_words, uint32_t n_chunk) {
-	BinLayout l;
-	const uint64_t cap = (uint64_t)bin_points(m->n_dims_to_encode, m->n_feat_per_pseudo_lvl) << m->n_dims_to_encode;
-	l.rec_bytes = (uint64_t)m->n_pseudo_levels * plan.n_blk * (1 + m->n_feat_per_pseudo_lvl) * cap * 4;
-	l.offs_bytes = ((offs_words * 4 + 255) / 256) * 256;
+// workspace = max over the record classes (they run one after another) of records + offsets, + the transposed dL/dy
+static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinLayout &l) {
+	l.rec_bytes = l.offs_bytes = 0;
+	for (uint32_t cls : kClasses) {
+		BinPlan plan;
+		uint64_t ow;
+		if (!make_plan(m, n_chunk, cls, plan, ow)) return false;
+		const uint64_t rb = (uint64_t)plan.n_pseudo * plan.n_blk * (1 + m->n_feat_per_pseudo_lvl) * plan.cap * 4;
+		const uint64_t ob = ((ow * 4 + 255) / 256) * 256;
+		l.rec_bytes = rb > l.rec_bytes ? rb : l.rec_bytes;
+		l.offs_bytes = ob > l.offs_bytes ? ob : l.offs_bytes;
+	}
+	l.rec_bytes = ((l.rec_bytes + 255) / 256) * 256;
 	l.gt_bytes = (((uint64_t)m->n_encoded_dims * n_chunk * 4 + 255) / 256) * 256;
 	l.total = l.rec_bytes + l.offs_bytes + l.gt_bytes;
-	return l;
+	return true;
 }
 
 // returns 0 when the binned path does not apply (caller falls back to the atomic kernels)
 uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points) {
-	if (!m || n_points == 0) return 0;
-	BinPlan plan;
-	uint64_t offs_words;
-	const uint32_t nc = chunk_points(n_points);
-	if (!make_plan(m, nc, plan, offs_words)) return 0;
-	return layout(m, plan, offs_words, nc).total;
+	if (!m || n_points == 0 || !binnable(m)) return 0;
+	BinLayout lay;
+	if (!layout(m, chunk_points(n_points), lay)) return 0;
+	return lay.total;
+}
+
+template <int D, int G, int NR>
+static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
+                        int32_t max_level, const float *xc, const float *vc, const float *gc, int64_t sn, int64_t se,
+                        const float *params, uint32_t *rec, uint32_t *offs, float *dparam, hipStream_t st) {
+	constexpr int BP = BinCfg<G, NR>::BP;
+	uint32_t nb_max = 0, acc_max = 0;
+	for (uint32_t q = 0; q < pl.n_pseudo; ++q) {
+		nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
+		const uint32_t a = pl.nb[q] * pl.rep[q];
+		acc_max = acc_max > a ? acc_max : a;
+	}
+	const size_t bin_lds = ((size_t)(1 + G) * BinCfg<G, NR>::cap + nb_max + 1) * sizeof(uint32_t);
+	static bool attr_set = false;
+	if (!attr_set) {
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoubles * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024 + (kMaxBuckets + 1) * 4));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024 + (kMaxBuckets + 1) * 4));
+		attr_set = true;
+	}
+	if (second)
+		hipLaunchKernelGGL((k_bin<D, G, true, NR>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+		                   meta->interpolation_type, xc, vc, gc, sn, se, params, rec, offs);
+	else
+		hipLaunchKernelGGL((k_bin<D, G, false, NR>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+		                   meta->interpolation_type, xc, vc, gc, sn, se, params, rec, offs);
+	hipLaunchKernelGGL((k_accum<D, G>), dim3(acc_max, pl.n_pseudo), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs,
+	                   dparam);
+	NR3D_LAUNCH_CHECK();
+	return 0;
 }
 
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
-                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, int32_t max_level, float *dparam,
-                  void *workspace, uint64_t workspace_bytes, hipStream_t st, bool &handled) {
+                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, int32_t max_level,
+                  float *dparam, void *workspace, uint64_t workspace_bytes, hipStream_t st, bool &handled) {
 	handled = false;
-	BinPlan plan;
-	uint64_t offs_words;
+	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
-	if (!workspace || !make_plan(meta, nc, plan, offs_words)) return 0;
-	const BinLayout lay = layout(meta, plan, offs_words, nc);
+	if (!workspace || !binnable(meta) || !layout(meta, nc, lay)) return 0;
 	if (workspace_bytes < lay.total) return 0;
 	handled = true;
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
@@ -398,21 +619,10 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	uint32_t *rec = (uint32_t *)workspace;
 	uint32_t *offs = (uint32_t *)((char *)workspace + lay.rec_bytes);
 	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes);
-	uint32_t nb_max = 0, acc_max = 0;
-	for (uint32_t q = 0; q < plan.n_pseudo; ++q) {
-		nb_max = nb_max > plan.nb[q] ? nb_max : plan.nb[q];
-		const uint32_t a = plan.nb[q] * plan.rep[q];
-		acc_max = acc_max > a ? acc_max : a;
-	}
 	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && E > 1);
 
 	for (uint32_t p0 = 0; p0 < N; p0 += nc) {
 		const uint32_t n = (N - p0) < nc ? (N - p0) : nc;
-		BinPlan pl = plan;
-		if (n != nc) {   // last, shorter chunk: fewer point blocks (offset tables shrink, bases stay valid upper bounds)
-			uint64_t ow;
-			make_plan(meta, n, pl, ow);
-		}
 		const float *xc = x + (size_t)p0 * D;
 		const float *vc = dL_ddLdx ? dL_ddLdx + (size_t)p0 * D : nullptr;
 		const float *gc = dL_dy + (int64_t)p0 * g_sn;
@@ -421,27 +631,23 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			hipLaunchKernelGGL(k_transpose, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, gc, g_sn, g_se, gt);
 			gc = gt; sn = 1; se = (int64_t)n;
 		}
-		DISPATCH_DG_BIN(D, G, {
-			constexpr int BP = BinCfg<D, G>::BP;
-			const size_t bin_lds = ((size_t)(1 + G) * BinCfg<D, G>::cap + nb_max + 1) * sizeof(uint32_t);
-			static bool attr_set = false;
-			if (!attr_set) {
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-				                                   kLdsDoubles * 8));
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + (kMaxBuckets + 1) * 4));
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + (kMaxBuckets + 1) * 4));
-				attr_set = true;
-			}
-			if (second)
-				hipLaunchKernelGGL((k_bin<D, G, true>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n,
-				                   max_level, meta->interpolation_type, xc, vc, gc, sn, se, rec, offs);
-			else
-				hipLaunchKernelGGL((k_bin<D, G, false>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n,
-				                   max_level, meta->interpolation_type, xc, vc, gc, sn, se, rec, offs);
-			hipLaunchKernelGGL((k_accum<D, G>), dim3(acc_max, pl.n_pseudo), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md,
-			                   rec, offs, dparam);
-		});
-		NR3D_LAUNCH_CHECK();
+		for (uint32_t cls : kClasses) {
+			BinPlan pl;
+			uint64_t ow;
+			make_plan(meta, n, cls, pl, ow);
+			if (pl.n_pseudo == 0) continue;
+			int rc = 0;
+			// only the (D, class) pairs some level type can produce are instantiated
+			DISPATCH_DG_BIN(D, G, {
+				if (cls == 8) rc = launch_class<D, G, 8>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+				else if (cls == 16) {
+					if constexpr (D >= 3) rc = launch_class<D, G, 16>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+				} else {
+					if constexpr (D == 3) rc = launch_class<D, G, 24>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+				}
+			});
+			if (rc) return rc;
+		}
 	}
 	return 0;
 }

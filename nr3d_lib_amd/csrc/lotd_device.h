@@ -373,11 +373,11 @@ __device__ __forceinline__ float corner_dot(const Lvl &L, const float *__restric
 	return r;
 }
 
-// lotd_bin.hip: atomic-free parameter-gradient path (Dense/Hash metas, no batching)
+// lotd_bin.hip: atomic-free parameter-gradient path (all level types but NPlaneSum/CPfast, no batching)
 uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points);
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
-                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, int32_t max_level, float *dparam,
-                  void *workspace, uint64_t workspace_bytes, hipStream_t st, bool &handled);
+                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, int32_t max_level,
+                  float *dparam, void *workspace, uint64_t workspace_bytes, hipStream_t st, bool &handled);
 
 }  // namespace lotd
 }  // namespace nr3d

@@ -84,11 +84,16 @@ def test_grid_index_bit_exact(oracle, dev, case):
     assert float(y.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "hash_npow2", "dense_f8", "dense_2d", "hash_4d"])
+BINNED_CASES = ["ngp_small", "ngp_smooth", "hash_npow2", "dense_f8", "dense_2d", "hash_4d",
+                "mixed", "mixed_cuboid", "mixed_smooth", "cp_only_2d4d", "cp_only_4d", "vecz_nplanemul"]
+
+
+@pytest.mark.parametrize("case", BINNED_CASES)
 def test_dparam_atomic_and_binned_paths_agree(oracle, dev, case):
     """the default (binned, fp64 LDS accumulation) and the hardware-atomic scatter must both match the oracle,
     including a point count that is not a multiple of the 512-point bin blocks and spans several of them"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=9)
+    assert _lotd._dparam_workspace(m, 5003, dev)[1] > 0, "this meta must take the atomic-free path"
     ref1 = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
     ref2 = oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True)
     for binned in (True, False):

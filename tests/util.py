@@ -38,9 +38,12 @@ LOTD_CASES = {
     "mixed_cuboid": (3, [[8, 6, 5], [12, 9, 7], [10, 8, 6], [14, 11, 9], [9, 7, 6], [16, 12, 8]],
                      [4, 4, 8, 4, 2, 16], ["Dense", "Dense", "VM", "VM", "CP", "CP"], None, False),
     "mixed_smooth": (3, [7, 9, 8, 10], [2, 2, 2, 2], ["Dense", "VM", "CP", "Hash"], 509, True),
+    "vecz_nplanemul": (3, [9, 8, 7], [2, 2, 4], ["VecZMatXoY", "NPlaneMul", "VecZMatXoY"], None, False),
     "nplane": (3, [8, 9, 7, 10], [2, 4, 2, 2], ["NPlaneMul", "NPlaneSum", "CPfast", "VecZMatXoY"], None, False),
     "nplane_smooth": (3, [8, 9, 7], [2, 2, 4], ["NPlaneSum", "CPfast", "NPlaneMul"], None, True),
     "cp_2d": (2, [9, 12], [2, 2], ["CP", "CPfast"], None, False),
+    "cp_only_2d4d": (2, [9, 12], [2, 4], ["CP", "NPlaneMul"], None, False),
+    "cp_only_4d": (4, [5, 6], [2, 2], ["CP", "Dense"], None, False),
     "cp_4d": (4, [5, 6, 4], [2, 2, 2], ["CP", "NPlaneMul", "CPfast"], None, False),
 }
 
