@@ -131,6 +131,16 @@ def march_composite_rate(dev, iters=20, side=64):
                 ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4))
 
 
+def c4_mixed_rate():
+    """BASELINE configs[3] as an extra figure (tools/bench_c4.py): mixed Dense/VM/CP LoTD, 2^22 points,
+    fwd + dL/dx + dL/dparam + the three second-order passes"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_c4.py"), "--log2-points", "22", "--iters", "3"],
+                       capture_output=True, text=True, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +241,8 @@ def main():
             try:
                 out["extra"] = {"march_composite": march_composite_rate(dev),
                                 "march_composite_262144_rays": march_composite_rate(dev, iters=5, side=512)}
+                torch.cuda.empty_cache()
+                out["extra"]["c4_mixed_lotd"] = c4_mixed_rate()
             except Exception as ex:   # the extra figure must never cost the headline line
                 out["extra"] = {"march_composite_error": repr(ex)}
             if not args.no_cpu_baseline:

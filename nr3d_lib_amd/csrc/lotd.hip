@@ -255,12 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 #pragma unroll 1
 			for (int f0 = 0; f0 < G; f0 += 2) {
 				float v[1 << D][2];
-#pragma unroll
-				for (uint32_t k = 0; k < (1u << D); ++k) {
-					uint32_t p[D];
-					corner_pos<D>(c, k, p);
-					corner_value<D, 2>(L, grid, foff0 + f0, p, v[k]);
-				}
+				corner_values_pair<D>(L, grid, foff0 + f0, vec_ok != 0 && (L.F & 1u) == 0u, c, v);
 				float yy[2] = {0.0f, 0.0f}, gg[2][D];
 #pragma unroll
 				for (int f = 0; f < 2; ++f)
@@ -482,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
                                                        const float *__restrict__ dL_ddLdx,
                                                        const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
                                                        const float *__restrict__ x, const float *__restrict__ params,
-                                                       Batch ba, float *__restrict__ dL_dx) {
+                                                       Batch ba, bool vec_ok, float *__restrict__ dL_dx) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= N) return;
 	float acc[D];
@@ -512,11 +507,12 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 				grad[1] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0 + 1) * g_se];
 				// s[k] = sum_f value(corner k)[f] * grad[f]
 				float sdot[1 << D];
+				{
+					float v[1 << D][2];
+					corner_values_pair<D>(L, grid, foff, vec_ok && (L.F & 1u) == 0u, c, v);
 #pragma unroll
-				for (uint32_t k = 0; k < (1u << D); ++k) {
-					uint32_t p[D];
-					corner_pos<D>(c, k, p);
-					sdot[k] = corner_dot<D, 2>(L, grid, foff, p, grad, 1.0f);
+					for (uint32_t k = 0; k < (1u << D); ++k)      // same arithmetic as corner_dot(..., weight = 1)
+						sdot[k] = __fmaf_rn(v[k][1] * grad[1], 1.0f, __fmaf_rn(v[k][0] * grad[0], 1.0f, 0.0f));
 				}
 				// out_d = sum_e v_e * H[e][d],  H = d^2 (sum_c W_c s_c) / dx_e dx_d
 #pragma unroll
@@ -933,7 +929,7 @@ extern "C" int nr3d_lotd_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *me
 		hipLaunchKernelGGL((k_bwd_bwd_dx<D, G>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, md, N,
 		                   meta->n_pseudo_levels, max_level, meta->interpolation_type, (const float *)dL_ddLdx,
 		                   (const float *)dL_dy, g_sn, g_se, (const float *)x, (const float *)params, ba,
-		                   (float *)dL_dx);
+		                   (((uintptr_t)params % 8) == 0 && batch_offsets == nullptr), (float *)dL_dx);
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;

@@ -62,6 +62,8 @@ struct BinPlan {
 	uint32_t qmap[kMaxPlanLevels];        // pseudo level of the meta behind local index q (levels of ONE record class)
 	uint32_t nb[kMaxPlanLevels];          // buckets per pseudo level
 	uint32_t rep[kMaxPlanLevels];         // replicas per bucket (stage B)
+	uint32_t n_first[kMaxPlanLevels];     // the first n_first buckets (line tables of VM-like levels: far more updates
+	uint32_t rep_first[kMaxPlanLevels];   //   per entry than the planes behind them) get rep_first replicas instead
 	uint32_t order[kMaxPlanLevels];       // stage-B launch order of the pseudo levels: largest workgroups first
 	uint32_t offs_base[kMaxPlanLevels];   // start of this pseudo level's offset table (in uint32 units)
 	uint32_t epb_log2;                    // log2(entries per bucket)
@@ -105,16 +107,6 @@ struct BinCfg {
 static uint32_t bin_points(uint32_t G, uint32_t NR) {
 	const uint32_t raw = (72u * 1024u / 4u) / ((1u + G) * NR);
 	return raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
-}
-
-// bits of corner k without bit `skip`, packed
-template <int D>
-__device__ __forceinline__ constexpr uint32_t drop_bit(uint32_t k, int skip) {
-	return (k & ((1u << skip) - 1u)) | ((k >> (skip + 1)) << skip);
-}
-// inverse: m with a zero bit inserted at position `at`
-__device__ __forceinline__ constexpr uint32_t insert_zero(uint32_t m, int at) {
-	return (m & ((1u << at) - 1u)) | ((m >> at) << (at + 1));
 }
 
 // Product of D factor tables T_d; corner k uses slot s_d(k) of table d.
@@ -376,9 +368,16 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 	extern __shared__ __attribute__((aligned(16))) double acc[];      // [kLdsDoubles]
 	const uint32_t cap = plan.cap;
 	const uint32_t q = plan.order[blockIdx.y];            // local index into this plan's levels
-	const uint32_t nb = plan.nb[q], R = plan.rep[q];
-	if (blockIdx.x >= nb * R) return;
-	const uint32_t b = blockIdx.x / R, r = blockIdx.x - b * R;
+	const uint32_t nb = plan.nb[q];
+	const uint32_t nf = plan.n_first[q], first_wgs = nf * plan.rep_first[q];
+	uint32_t R, b, r;
+	if (blockIdx.x < first_wgs) { R = plan.rep_first[q]; b = blockIdx.x / R; r = blockIdx.x - b * R; }
+	else {
+		R = plan.rep[q];
+		const uint32_t xr = blockIdx.x - first_wgs;
+		b = nf + xr / R; r = xr - (xr / R) * R;
+		if (b >= nb) return;
+	}
 	const uint32_t qg = plan.qmap[q];                     // pseudo level of the meta
 	const uint32_t level = md->map_levels[qg];
 	const Lvl L = load_level(md, level);
@@ -512,26 +511,53 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t cls,
 	}
 	plan.n_pseudo = nq;
 	offs_words = base;
-	// A bucket of the largest level is the unsplittable unit of stage-B work (one workgroup, ~n * records / nb_max
-	// records when the points are spread out).  Smaller levels are replicated until their workgroups are about that
-	// size too (rounded down: a few larger workgroups, launched first, pack better than many that spill into another
-	// round), and the levels are launched by decreasing workgroup size.
-	uint32_t nb_max = 1;
-	for (uint32_t q = 0; q < nq; ++q) nb_max = plan.nb[q] > nb_max ? plan.nb[q] : nb_max;
-	const uint32_t unit = nb_max < 64 ? 64 : nb_max;              // at least 64 workgroups per level to cover the chip
-	for (uint32_t q = 0; q < nq; ++q) {
-		uint32_t rep = unit / plan.nb[q];
-		rep = rep < 1 ? 1 : rep;
-		if (rep > plan.n_blk) rep = plan.n_blk ? plan.n_blk : 1u;
-		plan.rep[q] = rep;
-		plan.order[q] = q;
+	// Stage-B work is balanced on the EXPECTED number of records per bucket for spread-out points: a level's table is a
+	// concatenation of segments (lines, planes, the dense/hash grid), each receiving a fixed number of updates per point
+	// spread over its entries.  Target ~4 workgroups per CU; a (level, tier) whose buckets carry more than one unit
+	// of work is split into replicas (which flush with f32 atomics).  Tier 0 = the leading buckets that hold line
+	// tables (2 updates per point and dim concentrated on R_d entries), tier 1 = the rest.
+	const uint32_t epb = 1u << lg;
+	double total = 0.0, load_first[kMaxPlanLevels], load_rest[kMaxPlanLevels];
+	for (uint32_t ql = 0; ql < nq; ++ql) {
+		const nr3d_lotd_level_t &L = m->levels[m->map_levels[plan.qmap[ql]]];
+		const uint32_t nrec = rec_count(L.type, D);
+		uint64_t lines = 0;
+		if (L.type == NR3D_LOD_VectorMatrix) lines = (uint64_t)L.res[0] + L.res[1] + L.res[2];
+		else if (L.type == NR3D_LOD_VecZMatXoY) lines = L.res[2];
+		const uint32_t nf = lines ? (uint32_t)((lines + epb - 1) / epb) : 0u;
+		const uint32_t rec_lines = L.type == NR3D_LOD_VectorMatrix ? 6u : (lines ? 2u : 0u);
+		plan.n_first[ql] = nf < plan.nb[ql] ? nf : plan.nb[ql];
+		// expected records per bucket (per point): line records over tier 0, everything else evenly over all entries
+		const double per_entry_rest = (double)(nrec - rec_lines) / (double)(L.size > lines ? L.size - lines : 1);
+		const uint64_t first_entries = (uint64_t)plan.n_first[ql] * epb < L.size ? (uint64_t)plan.n_first[ql] * epb : L.size;
+		load_first[ql] = plan.n_first[ql]
+		    ? ((double)rec_lines + per_entry_rest * (double)(first_entries > lines ? first_entries - lines : 0)) / plan.n_first[ql] : 0.0;
+		const uint32_t n_rest = plan.nb[ql] - plan.n_first[ql];
+		load_rest[ql] = n_rest ? per_entry_rest * (double)(L.size - first_entries) / n_rest : 0.0;
+		total += (double)nrec;
 	}
-	for (uint32_t i = 1; i < nq; ++i) {                            // insertion sort by nb * rep ascending (= work descending)
-		const uint32_t q = plan.order[i];
-		const uint32_t key = plan.nb[q] * plan.rep[q];
+	const double unit = total / 1024.0;                            // records per point and workgroup at ~4 workgroups per CU
+	for (uint32_t ql = 0; ql < nq; ++ql) {
+		auto reps = [&](double load) {
+			uint32_t r = (uint32_t)(load / unit + 0.25);     // round down mostly: a few larger workgroups pack better than a spill
+			r = r < 1 ? 1 : r;
+			return r > plan.n_blk ? (plan.n_blk ? plan.n_blk : 1u) : r;
+		};
+		plan.rep[ql] = reps(load_rest[ql]);
+		plan.rep_first[ql] = plan.n_first[ql] ? reps(load_first[ql]) : 1u;
+		plan.order[ql] = ql;
+	}
+	auto wg_load = [&](uint32_t ql) {                               // heaviest workgroup of the level
+		const double a = plan.n_first[ql] ? load_first[ql] / plan.rep_first[ql] : 0.0;
+		const double b2 = (plan.nb[ql] > plan.n_first[ql]) ? load_rest[ql] / plan.rep[ql] : 0.0;
+		return a > b2 ? a : b2;
+	};
+	for (uint32_t i = 1; i < nq; ++i) {                            // launch the levels with the largest workgroups first
+		const uint32_t ql = plan.order[i];
+		const double key = wg_load(ql);
 		uint32_t j = i;
-		while (j > 0 && plan.nb[plan.order[j - 1]] * plan.rep[plan.order[j - 1]] > key) { plan.order[j] = plan.order[j - 1]; --j; }
-		plan.order[j] = q;
+		while (j > 0 && wg_load(plan.order[j - 1]) < key) { plan.order[j] = plan.order[j - 1]; --j; }
+		plan.order[j] = ql;
 	}
 	return true;
 }
@@ -582,7 +608,7 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	uint32_t nb_max = 0, acc_max = 0;
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) {
 		nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
-		const uint32_t a = pl.nb[q] * pl.rep[q];
+		const uint32_t a = pl.n_first[q] * pl.rep_first[q] + (pl.nb[q] - pl.n_first[q]) * pl.rep[q];
 		acc_max = acc_max > a ? acc_max : a;
 	}
 	const size_t bin_lds = ((size_t)(1 + G) * BinCfg<G, NR>::cap + nb_max + 1) * sizeof(uint32_t);

@@ -293,6 +293,112 @@ __device__ __forceinline__ void corner_value(const Lvl &L, const float *__restri
 	}
 }
 
+// bits of corner k without bit `skip`, packed
+template <int D>
+__device__ __forceinline__ constexpr uint32_t drop_bit(uint32_t k, int skip) {
+	return (k & ((1u << skip) - 1u)) | ((k >> (skip + 1)) << skip);
+}
+// inverse: m with a zero bit inserted at position `at`
+__device__ __forceinline__ constexpr uint32_t insert_zero(uint32_t m, int at) {
+	return (m & ((1u << at) - 1u)) | ((m >> at) << (at + 1));
+}
+
+// two consecutive features of one table entry (8-byte load when the table base allows it)
+__device__ __forceinline__ void ld_pair(const float *__restrict__ grid, uint32_t idx, bool vec, float (&o)[2]) {
+	if (vec) { const float2 t = *reinterpret_cast<const float2 *>(grid + idx); o[0] = t.x; o[1] = t.y; }
+	else { o[0] = grid[idx]; o[1] = grid[idx + 1]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Values of 2 consecutive features at ALL 2^D corners of a cell.  Product types read each distinct table entry once
+// (CP: 2D lines entries instead of D per corner; VM: 12 plane + 6 line entries instead of 6 per corner) and then form
+// the corner values with exactly corner_value()'s arithmetic, so the results are bit-identical to the per-corner form.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__restrict__ grid, uint32_t foff, bool vec,
+                                                   const Cell<D> &c, float (&v)[1 << D][2]) {
+	constexpr uint32_t C = 1u << D;
+	if (L.type == NR3D_LOD_CP) {
+		float t[D][2][2];
+#pragma unroll
+		for (int d = 0; d < D; ++d)
+#pragma unroll
+			for (uint32_t sl = 0; sl < 2; ++sl) ld_pair(grid, entry_line<D>(L, d, c.g[d] + sl) * L.F + foff, vec, t[d][sl]);
+#pragma unroll
+		for (uint32_t k = 0; k < C; ++k)
+#pragma unroll
+			for (int f = 0; f < 2; ++f) {
+				float r = t[0][k & 1u][f];
+#pragma unroll
+				for (int d = 1; d < D; ++d) r *= t[d][(k >> d) & 1u][f];
+				v[k][f] = r;
+			}
+		return;
+	}
+	if constexpr (D <= 3) {
+		if (L.type == NR3D_LOD_NPlaneMul) {
+			constexpr uint32_t NS = 1u << (D - 1);
+			float t[D][NS][2];
+#pragma unroll
+			for (int j = 0; j < D; ++j)
+#pragma unroll
+				for (uint32_t sl = 0; sl < NS; ++sl) {
+					uint32_t p[D];
+					corner_pos<D>(c, insert_zero(sl, D - 1 - j), p);
+					ld_pair(grid, entry_nplane_mul<D>(L, j, p) * L.F + foff, vec, t[j][sl]);
+				}
+#pragma unroll
+			for (uint32_t k = 0; k < C; ++k)
+#pragma unroll
+				for (int f = 0; f < 2; ++f) {
+					float r = t[0][drop_bit<D>(k, D - 1)][f];
+#pragma unroll
+					for (int j = 1; j < D; ++j) r *= t[j][drop_bit<D>(k, D - 1 - j)][f];
+					v[k][f] = r;
+				}
+			return;
+		}
+	}
+	if constexpr (D == 3) {
+		if (L.type == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VecZMatXoY) {
+			const bool vm = L.type == NR3D_LOD_VectorMatrix;
+#pragma unroll
+			for (uint32_t k = 0; k < C; ++k) { v[k][0] = 0.0f; v[k][1] = 0.0f; }
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				if (!vm && d != 2) continue;
+				float pv[4][2], lv[2][2];
+				uint32_t le0 = 0;
+#pragma unroll
+				for (uint32_t m = 0; m < 4; ++m) {
+					uint32_t p[3];
+					corner_pos<3>(c, insert_zero(m, d), p);
+					uint32_t pe;
+					if (vm) { uint32_t pl[3], ln[3]; entry_vm(L, p, pl, ln); pe = pl[d]; if (m == 0) le0 = ln[d]; }
+					else { pe = L.res[2] + p[1] + p[0] * L.res[0]; if (m == 0) le0 = p[2]; }
+					ld_pair(grid, pe * L.F + foff, vec, pv[m]);
+				}
+				ld_pair(grid, le0 * L.F + foff, vec, lv[0]);
+				ld_pair(grid, (le0 + 1u) * L.F + foff, vec, lv[1]);
+#pragma unroll
+				for (uint32_t k = 0; k < C; ++k)
+#pragma unroll
+					for (int f = 0; f < 2; ++f) {
+						const float pvv = pv[drop_bit<3>(k, d)][f], lvv = lv[(k >> d) & 1u][f];
+						v[k][f] = vm ? __fmaf_rn(pvv, lvv, v[k][f]) : pvv * lvv;
+					}
+			}
+			return;
+		}
+	}
+#pragma unroll
+	for (uint32_t k = 0; k < C; ++k) {
+		uint32_t p[D];
+		corner_pos<D>(c, k, p);
+		corner_value<D, 2>(L, grid, foff, p, v[k]);
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // Scatter of (grad[f] * weight) at one corner into the parameter-gradient buffer, per level type.
 // Product types multiply by the other factors read from `grid` (lotd_cuda.h:494-829).
