@@ -88,8 +88,8 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
 	const uint32_t i = chunk * kBlock + threadIdx.x;
 	if (i >= N) return;
-	const uint32_t level = md->map_levels[q];
-	const uint32_t foff0 = (uint32_t)md->map_cnt[q] * G;
+	const uint32_t level = meta_level_of(md, q);
+	const uint32_t foff0 = meta_cnt_of(md, q) * G;
 	const uint32_t out0 = q * G;
 
 	float out_y[G];
@@ -315,11 +315,11 @@ __global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
 	const uint32_t i = chunk * kBlock + threadIdx.x;
 	if (i >= N) return;
-	const uint32_t level = md->map_levels[q];
+	const uint32_t level = meta_level_of(md, q);
 	if ((int32_t)level > max_level) return;
 	uint32_t base = 0;
 	if (!batch_base(ba, i, base)) return;
-	const uint32_t foff0 = (uint32_t)md->map_cnt[q] * G;
+	const uint32_t foff0 = meta_cnt_of(md, q) * G;
 	const uint32_t out0 = q * G;
 	const Lvl L = load_level(md, level);
 	const float *__restrict__ grid = params + (base + L.off);
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 		for (int d = 0; d < D; ++d) { xp[d] = x[(size_t)i * D + d]; vin[d] = dL_ddLdx[(size_t)i * D + d]; }
 #pragma unroll 1
 		for (uint32_t q = 0; q < n_pseudo; ++q) {
-			const uint32_t level = md->map_levels[q];
+			const uint32_t level = meta_level_of(md, q);
 			if ((int32_t)level > max_level) continue;
 			const Lvl L = load_level(md, level);
 			if (!(L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash || L.type == NR3D_LOD_VectorMatrix ||
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 			locate<D>(xp, L, smooth != 0, c);
 #pragma unroll 1
 			for (int f0 = 0; f0 < G; f0 += 2) {
-				const uint32_t foff = (uint32_t)md->map_cnt[q] * G + f0;
+				const uint32_t foff = meta_cnt_of(md, q) * G + f0;
 				float grad[2];
 				grad[0] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0) * g_se];
 				grad[1] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0 + 1) * g_se];
@@ -647,12 +647,12 @@ __global__ __launch_bounds__(kBlock) void k_grid_index(Sched s, const nr3d_lotd_
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
 	const uint32_t i = chunk * kBlock + threadIdx.x;
 	if (i >= N) return;
-	const uint32_t level = md->map_levels[q];
+	const uint32_t level = meta_level_of(md, q);
 	if ((int32_t)level > max_level) return;
 	uint32_t base = 0;
 	if (!batch_base(ba, i, base)) return;
 	const Lvl L = load_level(md, level);
-	const uint32_t foff0 = (uint32_t)md->map_cnt[q] * G;
+	const uint32_t foff0 = meta_cnt_of(md, q) * G;
 	float xp[D];
 #pragma unroll
 	for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];

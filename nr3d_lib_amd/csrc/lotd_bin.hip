@@ -162,16 +162,64 @@ __device__ __forceinline__ uint32_t emit_product(const Lvl &L, const Cell<D> &c,
 	return (uint32_t)(D * NS);
 }
 
+// VM (3-D): per component d a plane over the two dims != d (4 slots) times a line along d (2 slots);
+// VecZMatXoY is the d = 2 component alone.  Record index is compile-time: VM d * 6 + {0..3 plane, 4..5 line}.
+template <int G, int NR, bool VM>
+__device__ __forceinline__ uint32_t emit_plane_line(const Lvl &L, const Cell<3> &c, const float (&w)[8], const float (&grad)[G],
+                                                    const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
+                                                    float (&val)[NR][G]) {
+#pragma unroll
+	for (int d = VM ? 0 : 2; d < 3; ++d) {
+		constexpr int kDummy = 0; (void)kDummy;
+		const int base = VM ? d * 6 : 0;
+		float pv[4][G], lv[2][G];
+		uint32_t pe[4], le[2];
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) {
+			uint32_t p[3];
+			corner_pos<3>(c, insert_zero(m, d), p);
+			if (VM) { uint32_t pl[3], ln[3]; entry_vm(L, p, pl, ln); pe[m] = pl[d]; if (m == 0) le[0] = ln[d]; }
+			else { pe[m] = L.res[2] + p[1] + p[0] * L.res[0]; if (m == 0) le[0] = p[2]; }
+#pragma unroll
+			for (int f = 0; f < G; ++f) pv[m][f] = grid[pe[m] * L.F + foff + f];
+		}
+		le[1] = le[0] + 1u;
+#pragma unroll
+		for (uint32_t sl = 0; sl < 2; ++sl)
+#pragma unroll
+			for (int f = 0; f < G; ++f) lv[sl][f] = grid[le[sl] * L.F + foff + f];
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) {            // plane slots: the two corners that differ along d
+			ent[base + m] = pe[m];
+			const uint32_t k0 = insert_zero(m, d), k1 = k0 | (1u << d);
+#pragma unroll
+			for (int f = 0; f < G; ++f) val[base + m][f] = (grad[f] * w[k0]) * lv[0][f] + (grad[f] * w[k1]) * lv[1][f];
+		}
+#pragma unroll
+		for (uint32_t sl = 0; sl < 2; ++sl) {         // line slots: the four corners with bit d == sl
+			ent[base + 4 + sl] = le[sl];
+#pragma unroll
+			for (int f = 0; f < G; ++f) {
+				float acc = 0.0f;
+#pragma unroll
+				for (uint32_t m = 0; m < 4; ++m) acc += (grad[f] * w[insert_zero(m, d) | (sl << d)]) * pv[m][f];
+				val[base + 4 + sl][f] = acc;
+			}
+		}
+	}
+	return VM ? 18u : 6u;
+}
+
 // The parameter updates of one (point, pseudo level): table entry + G values each.  `w[k]` is the weight of corner k
 // (first order: the interpolation weight; second order: the combined d/dx weight), `grad` = dL/dy of the G features,
 // `grid` = params + level offset, `foff` = first feature of this pseudo level inside the level's entries.
 // Same per-update arithmetic as corner_scatter() (lotd_device.h); contributions to one entry are added in corner order.
-template <int D, int G, int NR>
+template <int D, int G, int NR, bool DH>
 __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c, const float (&w)[1 << D], const float (&grad)[G],
                                                  const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
                                                  float (&val)[NR][G]) {
 	constexpr uint32_t C = 1u << D;
-	if (L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash) {
+	if (DH || L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash) {     // DH: the meta has no other level types
 		if constexpr (NR >= (int)C) {
 #pragma unroll
 			for (uint32_t k = 0; k < C; ++k) {
@@ -184,73 +232,19 @@ __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c,
 			return C;
 		}
 	} else if (L.type == NR3D_LOD_CP) {
-		if constexpr (NR >= 2 * D) return emit_product<D, G, NR, 2, true>(L, c, w, grad, grid, foff, ent, val);
+		if constexpr (!DH && NR >= 2 * D) return emit_product<D, G, NR, 2, true>(L, c, w, grad, grid, foff, ent, val);
 	} else if (L.type == NR3D_LOD_NPlaneMul) {
-		if constexpr (D <= 3 && NR >= D * (1 << (D - 1)))
+		if constexpr (!DH && D <= 3 && NR >= D * (1 << (D - 1)))
 			return emit_product<D, G, NR, (1 << (D - 1)), false>(L, c, w, grad, grid, foff, ent, val);
-	} else if (L.type == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VecZMatXoY) {
-		if constexpr (D == 3) {
-			const bool vm = L.type == NR3D_LOD_VectorMatrix;
-			if constexpr (NR >= 6) {
-				if (vm && NR < 18) return 0;
-				// per component d: plane (the two dims != d, 4 slots) x line (dim d, 2 slots); VecZMatXoY has d = 2 only
-				uint32_t n = 0;
-#pragma unroll
-				for (int d = 0; d < 3; ++d) {
-					if (!vm && d != 2) continue;
-					float pv[4][G], lv[2][G];
-					uint32_t pe[4], le[2];
-#pragma unroll
-					for (uint32_t m = 0; m < 4; ++m) {
-						uint32_t p[3];
-						corner_pos<3>(c, insert_zero(m, d), p);
-						if (vm) { uint32_t pl[3], ln[3]; entry_vm(L, p, pl, ln); pe[m] = pl[d]; if (m == 0) le[0] = ln[d]; }
-						else { pe[m] = L.res[2] + p[1] + p[0] * L.res[0]; if (m == 0) le[0] = p[2]; }
-#pragma unroll
-						for (int f = 0; f < G; ++f) pv[m][f] = grid[pe[m] * L.F + foff + f];
-					}
-					le[1] = le[0] + 1u;
-#pragma unroll
-					for (uint32_t sl = 0; sl < 2; ++sl)
-#pragma unroll
-						for (int f = 0; f < G; ++f) lv[sl][f] = grid[le[sl] * L.F + foff + f];
-					// plane slots
-#pragma unroll
-					for (uint32_t m = 0; m < 4; ++m) {
-						if ((int)n < NR) {
-							ent[n] = pe[m];
-#pragma unroll
-							for (int f = 0; f < G; ++f) {
-								const uint32_t k0 = insert_zero(m, d), k1 = k0 | (1u << d);
-								val[n][f] = (grad[f] * w[k0]) * lv[0][f] + (grad[f] * w[k1]) * lv[1][f];
-							}
-						}
-						++n;
-					}
-					// line slots
-#pragma unroll
-					for (uint32_t sl = 0; sl < 2; ++sl) {
-						if ((int)n < NR) {
-							ent[n] = le[sl];
-#pragma unroll
-							for (int f = 0; f < G; ++f) {
-								float acc = 0.0f;
-#pragma unroll
-								for (uint32_t m = 0; m < 4; ++m) acc += (grad[f] * w[insert_zero(m, d) | (sl << d)]) * pv[m][f];
-								val[n][f] = acc;
-							}
-						}
-						++n;
-					}
-				}
-				return n;
-			}
-		}
+	} else if (L.type == NR3D_LOD_VectorMatrix) {
+		if constexpr (!DH && D == 3 && NR >= 18) return emit_plane_line<G, NR, true>(L, c, w, grad, grid, foff, ent, val);
+	} else if (L.type == NR3D_LOD_VecZMatXoY) {
+		if constexpr (!DH && D == 3 && NR >= 6) return emit_plane_line<G, NR, false>(L, c, w, grad, grid, foff, ent, val);
 	}
 	return 0;
 }
 
-template <int D, int G, bool SECOND, int NR>
+template <int D, int G, bool SECOND, int NR, bool DH>
 __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                                            int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                            const float *__restrict__ vin_, const float *__restrict__ g,
@@ -266,7 +260,7 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 	const uint32_t blk = blockIdx.x, ql = blockIdx.y;
 	const uint32_t q = plan.qmap[ql];
 	const uint32_t nb = plan.nb[ql];
-	const uint32_t level = md->map_levels[q];
+	const uint32_t level = meta_level_of(md, q);
 	const uint32_t i = blk * BP + threadIdx.x;
 	const Lvl L = load_level(md, level);
 
@@ -303,7 +297,7 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 				w[k] = sum;
 			}
 		}
-		n_rec = emit_updates<D, G, NR>(L, c, w, grad, params + L.off, (uint32_t)md->map_cnt[q] * G, ent, val);
+		n_rec = emit_updates<D, G, NR, DH>(L, c, w, grad, params + L.off, meta_cnt_of(md, q) * G, ent, val);
 #pragma unroll
 		for (uint32_t r = 0; r < (uint32_t)NR; ++r)
 			if (r < n_rec) rank[r] = atomicAdd(&hist[ent[r] >> plan.epb_log2], 1u);
@@ -379,9 +373,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 		if (b >= nb) return;
 	}
 	const uint32_t qg = plan.qmap[q];                     // pseudo level of the meta
-	const uint32_t level = md->map_levels[qg];
+	const uint32_t level = meta_level_of(md, qg);
 	const Lvl L = load_level(md, level);
-	const uint32_t foff0 = (uint32_t)md->map_cnt[qg] * G;
+	const uint32_t foff0 = meta_cnt_of(md, qg) * G;
 
 	for (uint32_t t = threadIdx.x; t < (uint32_t)kLdsDoubles; t += kAccThreads) acc[t] = 0.0;
 	__syncthreads();
@@ -600,7 +594,7 @@ uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points) {
 	return lay.total;
 }
 
-template <int D, int G, int NR>
+template <int D, int G, int NR, bool DH>
 static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
                         int32_t max_level, const float *xc, const float *vc, const float *gc, int64_t sn, int64_t se,
                         const float *params, uint32_t *rec, uint32_t *offs, float *dparam, hipStream_t st) {
@@ -615,15 +609,15 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	static bool attr_set = false;
 	if (!attr_set) {
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoubles * 8));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024 + (kMaxBuckets + 1) * 4));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024 + (kMaxBuckets + 1) * 4));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024 + (kMaxBuckets + 1) * 4));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024 + (kMaxBuckets + 1) * 4));
 		attr_set = true;
 	}
 	if (second)
-		hipLaunchKernelGGL((k_bin<D, G, true, NR>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+		hipLaunchKernelGGL((k_bin<D, G, true, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
 		                   meta->interpolation_type, xc, vc, gc, sn, se, params, rec, offs);
 	else
-		hipLaunchKernelGGL((k_bin<D, G, false, NR>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+		hipLaunchKernelGGL((k_bin<D, G, false, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
 		                   meta->interpolation_type, xc, vc, gc, sn, se, params, rec, offs);
 	hipLaunchKernelGGL((k_accum<D, G>), dim3(acc_max, pl.n_pseudo), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs,
 	                   dparam);
@@ -665,11 +659,15 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			int rc = 0;
 			// only the (D, class) pairs some level type can produce are instantiated
 			DISPATCH_DG_BIN(D, G, {
-				if (cls == 8) rc = launch_class<D, G, 8>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+				// hash-only metas (every level Dense or Hash) get kernels without the product-type code
+				if (meta->c_hash_only) {
+					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
 				else if (cls == 16) {
-					if constexpr (D >= 3) rc = launch_class<D, G, 16>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
 				} else {
-					if constexpr (D == 3) rc = launch_class<D, G, 24>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
 				}
 			});
 			if (rc) return rc;

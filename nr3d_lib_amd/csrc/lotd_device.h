@@ -91,14 +91,27 @@ struct Lvl {
 	uint32_t F, type, size, off;
 };
 
+// The device copy of the meta is read-only for every kernel and indexed wave-uniformly (the block's level): reading it
+// through the constant address space makes these scalar loads (s_load_dwordx8 via the scalar cache, results in SGPRs)
+// instead of 64-lane vector loads.  There is no sub-dword scalar load: uint16 tables are read as dwords and shifted.
+typedef const __attribute__((address_space(4))) uint32_t *cu32_t;
+
 __device__ __forceinline__ Lvl load_level(const nr3d_lotd_meta_t *__restrict__ md, uint32_t level) {
 	Lvl L;
-	const nr3d_lotd_level_t *l = &md->levels[level];
+	const cu32_t w = (cu32_t)(&md->levels[level]);     // {res[4], n_feats, type, size, offset}
+	static_assert(sizeof(nr3d_lotd_level_t) == 32, "level descriptor layout");
 #pragma unroll
-	for (int d = 0; d < 4; ++d) L.res[d] = l->res[d];
-	L.F = l->n_feats; L.type = l->type; L.size = l->size; L.off = l->offset;
+	for (int d = 0; d < 4; ++d) L.res[d] = w[d];
+	L.F = w[4]; L.type = w[5]; L.size = w[6]; L.off = w[7];
 	return L;
 }
+
+__device__ __forceinline__ uint32_t meta_u16(const uint16_t *tab, uint32_t i) {
+	const cu32_t w = (cu32_t)tab;                      // the tables are 4-byte aligned inside the meta struct
+	return (w[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t meta_level_of(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q) { return meta_u16(md->map_levels, q); }
+__device__ __forceinline__ uint32_t meta_cnt_of(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q) { return meta_u16(md->map_cnt, q); }
 
 // ---------------------------------------------------------------------------------------------
 // Cell locator: g = floor(x*(R-2)+0.5), t = frac, plus interpolation weight and its derivatives.
