@@ -6,7 +6,7 @@
 
 Workload (N = 1): BASELINE.json configs[1] -- 16-level Hash LoTD (gen_ngp_cfg defaults: T = 2^19, F = 2,
 6 Dense + 10 Hash levels, 12 131 648 fp32 params), 2^20 uniformly random points, one "step" =
-forward (y and dy/dx) + dL/dx + dL/dparam, all inputs resident in HBM.  N > 1: the same per-GPU batch on every
+forward (y and dy/dx) + backward (dL/dx and dL/dparam, one call), all inputs resident in HBM.  N > 1: the same per-GPU batch on every
 rank (weak scaling; points are independent so there is no data-path collective) plus ONE RCCL all-reduce of
 dL/dparam per step.  Metric: whole-job Mpoints/s.
 
@@ -35,13 +35,15 @@ def algorithmic_bytes_per_point(L, F, D=3, C=8):
     bwd_dx   : dL_dy L*F*4 + Jacobian L*F*D*4 + dL_dx 4D
     bwd_dparam: x 4D + dL_dy L*F*4 + scatter as read-modify-write 2*L*C*F*4"""
     E = L * F
-    return dict(fwd=4 * D + L * C * F * 4 + E * 4 + E * D * 4,
-                bwd_dx=E * 4 + E * D * 4 + 4 * D,
-                bwd_dparam=4 * D + E * 4 + 2 * L * C * F * 4)
+    d = dict(fwd=4 * D + L * C * F * 4 + E * 4 + E * D * 4,
+             bwd_dx=E * 4 + E * D * 4 + 4 * D,
+             bwd_dparam=4 * D + E * 4 + 2 * L * C * F * 4)
+    d["bwd"] = d.pop("bwd_dx") + d.pop("bwd_dparam")     # one lod_bwd call computes both, as the reference's does
+    return d
 
 
 # kernels behind each timed op (names as rocprofv3 prints them, template arguments stripped)
-OP_KERNELS = {"fwd": ["k_fwd"], "bwd_dx": ["k_contract_dx_rowmajor"], "bwd_dparam": ["k_transpose", "k_bin", "k_accum"]}
+OP_KERNELS = {"fwd": ["k_fwd"], "bwd": ["k_contract_dx_rowmajor", "k_bin", "k_accum"]}
 
 
 def pmc_traffic_bytes(op):
@@ -173,22 +175,21 @@ def main():
     x = torch.rand(N, 3, generator=gen_r).clamp_(1e-6, 1 - 1e-6).to(dev)
     dL_dy = (torch.randn(N, meta.n_encoded_dims, generator=gen_r) / 1e4).to(dev)
 
-    names = ("fwd", "bwd_dx", "bwd_dparam")
+    names = ("fwd", "bwd")
     ev = {k: [] for k in names}
 
     def step(record):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
         if record: e[0].record()
         y, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
         if record: e[1].record()
-        dx, _ = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=False)
+        # ONE backward call for both gradients (what LoTDFunction.backward does, lotd.py / lotd_torch_api.cu:397-573)
+        dx, dp = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=True)
         if record: e[2].record()
-        _, dp = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=False, need_param_grad=True)
-        if record: e[3].record()
         if dist is not None:
             dist.all_reduce(dp)
         if record:
-            for k, a, b in zip(names, e[:3], e[1:]):
+            for k, a, b in zip(names, e[:2], e[1:]):
                 ev[k].append((a, b))
         return y, dx, dp
 

@@ -90,7 +90,11 @@ int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n
  * dL_dx[i, d] = sum_e dL_dy[i, e] * dy_dx[i, e, d];  dL_dx is [N, D] contiguous (x dtype). */
 int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t n_points, int x_dtype, int param_dtype,
                      const void *dL_dy, int64_t dldy_sn, int64_t dldy_se,
-                     const void *dy_dx, int64_t dydx_sn, int64_t dydx_se, void *dL_dx, void *stream);
+                     const void *dy_dx, int64_t dydx_sn, int64_t dydx_se, void *dL_dx,
+                     void *dL_dy_T /* optional out, f32 [n_encoded_dims, n_points]: feature-major copy of a contiguous
+                                      dL_dy; pass it to nr3d_lotd_bwd_dparam as dL_dy with strides (1, n_points) and
+                                      the scatter skips its own transposition */,
+                     void *stream);
 
 /* lod_bwd, parameter-gradient half (kernel_lod[_hashonly]_backward_grid, lotd_encoding.h:467-711,
  * lotd_hash_only.h:380-470).  dL_dparam: params dtype, same numel as params, ZERO-INIT by caller.

@@ -346,15 +346,23 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
         st = H.stream_of(input)
         tag = ("dx" if need_input_grad else "") + ("dp" if need_param_grad else "")
         with _Prof(m, f"LoTD{D}-bwd-{tag}", N):
+            batched = batch_inds is not None or batch_offsets is not None or bds != 0
+            gT = None
             if need_input_grad and N > 0:
                 j, jsn, jse = _jac_view(dy_dx.detach(), N, E, D)
+                # both gradients wanted: the dL/dx kernel stages dL_dy through LDS anyway and leaves the feature-major
+                # copy the atomic-free parameter scatter reads (saves that path's own transposition pass)
+                if (need_param_grad and not batched and USE_BINNED_DPARAM and gse == 1 and gsn == E
+                        and g32.data_ptr() % 16 == 0):
+                    gT = torch.empty((E, N), dtype=torch.float32, device=dev)
                 H.check(H.lib().nr3d_lotd_bwd_dx(
                     C.byref(m._cmeta()), H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(g32), H.i64(gsn),
-                    H.i64(gse), H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), st))
+                    H.i64(gse), H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), H.ptr(gT), st))
             if need_param_grad and N > 0:
                 x32, p32 = _f32c(input.detach()), _f32c(params.detach())
-                batched = batch_inds is not None or batch_offsets is not None or bds != 0
                 ws, wsb = (None, 0) if batched else _dparam_workspace(m, N, dev)
+                if gT is not None:
+                    g32, gsn, gse = gT, 1, N
                 H.check(H.lib().nr3d_lotd_bwd_dparam(
                     C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
                     H.ptr(g32), H.i64(gsn), H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),

@@ -577,7 +577,8 @@ __global__ __launch_bounds__(kBlock) void k_contract_dx(uint32_t N, uint32_t E, 
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_contract_dx_rowmajor(uint32_t N, uint32_t E, const float *__restrict__ dL_dy,
                                                                  const float *__restrict__ dydx, int64_t d_sn,
-                                                                 int64_t d_se, float *__restrict__ dL_dx) {
+                                                                 int64_t d_se, float *__restrict__ dL_dx,
+                                                                 float *__restrict__ dL_dy_T) {
 	constexpr int TE = 32;
 	__shared__ float tile[TE][kBlock + 1];
 	const uint32_t i0 = blockIdx.x * kBlock, i = i0 + threadIdx.x;
@@ -603,6 +604,10 @@ __global__ __launch_bounds__(kBlock) void k_contract_dx_rowmajor(uint32_t N, uin
 			}
 		}
 		__syncthreads();
+		if (dL_dy_T && i < N) {      // by-product: the feature-major copy the parameter scatter wants (coalesced rows)
+#pragma unroll 8
+			for (uint32_t e = 0; e < te; ++e) dL_dy_T[(size_t)(e0 + e) * N + i] = tile[e][threadIdx.x];
+		}
 		if (i < N) {
 			const float *jj = dydx + (int64_t)i * d_sn + (int64_t)e0 * d_se;
 #pragma unroll 8
@@ -821,17 +826,18 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 
 extern "C" int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t N, int x_dtype, int param_dtype,
                                 const void *dL_dy, int64_t g_sn, int64_t g_se, const void *dy_dx, int64_t d_sn,
-                                int64_t d_se, void *dL_dx, void *stream) {
+                                int64_t d_se, void *dL_dx, void *dL_dy_T, void *stream) {
 	NR3D_CHECK(meta != nullptr, "LoTD: meta is NULL");
 	NR3D_CHECK(x_dtype == NR3D_F32 && param_dtype == NR3D_F32, "LoTD::bwd_dx: f32 only");
 	if (N == 0) return 0;
 	NR3D_CHECK(dL_dy && dy_dx && dL_dx, "LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.");
 	const uint32_t E = meta->n_encoded_dims;
 	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && ((uintptr_t)dL_dy % 16) == 0);
+	NR3D_CHECK(dL_dy_T == nullptr || row_major, "LoTD::bwd_dx: dL_dy_T needs a contiguous, 16-byte aligned [N, E] dL_dy");
 	DISPATCH_D(meta->n_dims_to_encode, {
 		if (row_major)
 			hipLaunchKernelGGL(k_contract_dx_rowmajor<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,
-			                   (const float *)dL_dy, (const float *)dy_dx, d_sn, d_se, (float *)dL_dx);
+			                   (const float *)dL_dy, (const float *)dy_dx, d_sn, d_se, (float *)dL_dx, (float *)dL_dy_T);
 		else
 			hipLaunchKernelGGL(k_contract_dx<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,
 			                   (const float *)dL_dy, g_sn, g_se, (const float *)dy_dx, d_sn, d_se, (float *)dL_dx);
