@@ -133,6 +133,40 @@ def march_composite_rate(dev, iters=20, side=64):
                 ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4))
 
 
+def full_loop_rate(dev, side=512, iters=5):
+    """BASELINE configs[4] on one GPU: 16-level Hash encode + occ-grid march + pack composite, forward AND backward
+    through nerf_ray_query_march_occ (visibility pruning on) with a tiny random MLP head (tools/demo_field.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from demo_field import DemoField, pinhole_rays
+    from nr3d_lib_amd.graphics.nerf import composite_packed_volume_buffer, nerf_ray_query_march_occ
+    res = 128
+    ax = (torch.arange(res) + 0.5) / res * 2 - 1
+    r = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).norm(dim=-1)
+    occ = ((r > 0.45) & (r < 0.8)).to(dev)                      # a shell: ~19 % of the voxels occupied
+    model = DemoField(occ, 2 * 3 ** 0.5 / 512, max_steps=512, seed=1, device=dev)
+    o, d, near, far = pinhole_rays(side, dev)
+    n = side * side
+    rays = dict(num_rays=n, rays_o=o, rays_d=d, near=near, far=far, rays_inds=torch.arange(n, device=dev))
+
+    def one():
+        model.zero_grad(set_to_none=True)
+        vb, det = nerf_ray_query_march_occ(model, rays, with_rgb=True, compression=True)
+        out = composite_packed_volume_buffer(vb, n)
+        (out["rgb_volume"].mean() + out["depth_volume"].mean()).backward()
+        return int(det["march.num_per_ray"].sum()), int(det["render.num_per_ray"].sum())
+    marched, rendered = one()
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return dict(workload=f"march + prune + 16-level Hash LoTD encode (+ tiny MLP) + composite, fwd+bwd, {n} rays",
+                samples_marched=marched, samples_rendered=rendered, ms_per_iter=round(ms, 3),
+                mrays_per_s=round(n / ms / 1e3, 3), msamples_per_s=round((marched + rendered) / ms / 1e3, 3))
+
+
 def c4_mixed_rate():
     """BASELINE configs[3] as an extra figure (tools/bench_c4.py): mixed Dense/VM/CP LoTD, 2^22 points,
     fwd + dL/dx + dL/dparam + the three second-order passes"""
@@ -242,6 +276,7 @@ def main():
             try:
                 out["extra"] = {"march_composite": march_composite_rate(dev),
                                 "march_composite_262144_rays": march_composite_rate(dev, iters=5, side=512)}
+                out["extra"]["full_loop_1gpu"] = full_loop_rate(dev)
                 torch.cuda.empty_cache()
                 out["extra"]["c4_mixed_lotd"] = c4_mixed_rate()
             except Exception as ex:   # the extra figure must never cost the headline line

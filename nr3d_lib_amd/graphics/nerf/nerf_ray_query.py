@@ -1,0 +1,149 @@
+"""March -> (prune) -> query -> volume buffer: the driver that chains the three hot-path pieces.
+
+Counterpart of ``nerf_ray_query_march_occ`` (nr3d_lib/graphics/nerf/nerf_ray_query.py:28-188) with the same
+signature, ``ray_tested`` keys, model attribute protocol (``use_ts`` / ``use_fidx`` / ``use_bidx`` / ``use_pix`` /
+``use_h_appear`` / ``use_view_dirs`` and their ``fwd_density_*`` twins), returned ``volume_buffer`` keys and
+``details``; plus ``composite_packed_volume_buffer``, the packed branch of the renderer's composite
+(nr3d_lib/models/fields/nerf/renderer_mixin.py:298-311).
+
+Data flow on the device (no host sync except the marcher's single total readback and the two nonzero() compactions of
+the pruning stage):  occ-grid march (HIP) -> density query on all marched samples under no_grad (LoTD forward, HIP) ->
+alpha -> packed_volume_render_compression (HIP alpha_to_vw in compaction mode) keeps the samples that are still
+visible (T >= early_stop_eps) -> the differentiable query runs only on those -> alpha -> caller composites."""
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from nr3d_lib_amd.graphics.nerf.nerf_utils import packed_alpha_to_vw, packed_volume_render_compression, tau_to_alpha
+from nr3d_lib_amd.graphics.pack_ops import packed_div, packed_sum
+from nr3d_lib_amd.profile import profile
+
+__all__ = ['nerf_ray_query_march_occ', 'composite_packed_volume_buffer']
+
+_PER_RAY_KEYS = (('ts', 'rays_ts'), ('fidx', 'rays_fidx'), ('bidx', 'rays_bidx'), ('pix', 'rays_pix'),
+                 ('h_appear', 'rays_h_appear'))
+_PASSTHROUGH = ('flow_fwd', 'flow_fwd_pred_bwd', 'flow_bwd', 'flow_bwd_pred_fwd', 'sigma_static', 'rgb_static',
+                'sigma_dynamic', 'rgb_dynamic')
+
+
+def _flag(model, name):
+    return bool(getattr(model, name, False))
+
+
+def _march(model, ray_tested, rays_o, rays_d, near, far, perturb, march_cfg):
+    """dispatch on what the accel's ray_march accepts (single / dynamic / batched / batched-dynamic accels of the
+    reference differ only in the extra per-ray arguments, nerf_ray_query.py:84-104)"""
+    accel = model.accel
+    if hasattr(accel, 'cur_batch__ray_march'):
+        extra = [ray_tested['rays_bidx']] + ([ray_tested['rays_ts']] if getattr(accel, 'is_dynamic', False) else [])
+        return accel.cur_batch__ray_march(rays_o, rays_d, *extra, near=near, far=far, perturb=perturb, **march_cfg)
+    if getattr(accel, 'is_dynamic', False):
+        return accel.ray_march(rays_o, rays_d, ray_tested['rays_ts'], near=near, far=far, perturb=perturb, **march_cfg)
+    return accel.ray_march(rays_o, rays_d, near=near, far=far, perturb=perturb, **march_cfg)
+
+
+def nerf_ray_query_march_occ(model, ray_tested: Dict[str, torch.Tensor], with_rgb: bool = True, perturb: bool = False,
+                             march_cfg=dict(), compression=True, bypass_sigma_fn: Optional[Callable] = None,
+                             bypass_alpha_fn: Optional[Callable] = None, forward_params: dict = {}) -> Tuple[dict, dict]:
+    assert hasattr(model, 'forward'), "model.forward() is requried"
+    assert getattr(model, 'accel', None) is not None, "model.accel is required"
+    if not with_rgb:
+        assert hasattr(model, 'forward_density'), "model.forward_density() is requried"
+    if compression:
+        assert hasattr(model, 'query_density'), "model.query_density() is requried"
+    assert (bypass_sigma_fn is None) or (bypass_alpha_fn is None), \
+        "Please pass at most one of bypass_sigma_fn or bypass_alpha_fn"
+
+    # which per-ray attributes go into the density-only query and into the full query
+    density_uses = {k: _flag(model, 'use_' + k) if k in ('ts', 'fidx', 'bidx') else _flag(model, 'fwd_density_use_' + k)
+                    for k, _ in _PER_RAY_KEYS}
+    full_uses = {k: density_uses[k] or (_flag(model, 'use_' + k) and with_rgb) for k, _ in _PER_RAY_KEYS}
+    density_view = _flag(model, 'fwd_density_use_view_dirs')
+    full_view = density_view or (_flag(model, 'use_view_dirs') and with_rgb)
+
+    empty = dict(type='empty', rays_inds_hit=[])
+    if ray_tested['num_rays'] == 0:
+        return empty, {}
+    rays_o, rays_d = ray_tested['rays_o'], ray_tested['rays_d']
+    near, far, rays_inds = ray_tested['near'], ray_tested['far'], ray_tested['rays_inds']
+    assert rays_o.dim() == 2 and rays_d.dim() == 2
+    dtype = rays_o.dtype
+    view_dirs = None
+    if full_view:
+        view_dirs = rays_d / rays_d.detach().norm(dim=-1, keepdim=True).clamp_min(1.0e-10)
+
+    def query_kwargs(samples, ridx, uses, use_view):
+        kw = dict(x=samples)
+        for k, src in _PER_RAY_KEYS:
+            if uses[k]:
+                kw[k] = ray_tested[src][ridx]
+        if use_view:
+            kw['v'] = view_dirs[ridx]
+        return kw
+
+    with profile("Ray marching"):
+        marched = _march(model, ray_tested, rays_o, rays_d, near, far, perturb, march_cfg)
+    if marched.ridx_hit is None:
+        return empty, {}
+
+    pack_infos, ridx_hit, ridx_all = marched.pack_infos, marched.ridx_hit, marched.ridx
+    depth_samples, deltas, samples = marched.depth_samples, marched.deltas, marched.samples
+    details = {'march.num_per_ray': marched.pack_infos[:, 1]}
+    nidx_useful = None
+    if compression:
+        with torch.no_grad(), profile("Visibility pruning"):
+            kw = query_kwargs(samples, ridx_all, density_uses, density_view)
+            if bypass_alpha_fn is not None:
+                alphas = bypass_alpha_fn(**kw)
+            else:
+                sigmas = bypass_sigma_fn(**kw) if bypass_sigma_fn is not None else model.query_density(**kw)
+                alphas = tau_to_alpha(sigmas * deltas)
+            nidx_useful, pack_infos, pidx_useful = packed_volume_render_compression(alphas, marched.pack_infos)
+        if nidx_useful.numel() == 0:
+            return empty, {}
+        details['render.num_per_ray0'] = marched.pack_infos[:, 1]
+        ridx_hit, ridx_all = ridx_hit[nidx_useful], ridx_all[pidx_useful]
+        depth_samples, deltas, samples = depth_samples[pidx_useful], deltas[pidx_useful], samples[pidx_useful]
+    details['render.num_per_ray'] = pack_infos[:, 1]
+
+    volume_buffer = dict(type='packed', rays_inds_hit=rays_inds[ridx_hit], pack_infos_hit=pack_infos,
+                         t=depth_samples.to(dtype))
+    if full_uses['bidx'] and nidx_useful is not None:
+        volume_buffer['rays_bidx_hit'] = ray_tested['rays_bidx'][nidx_useful]     # indexing as in the reference (:148)
+
+    with profile("Query"):
+        kw = query_kwargs(samples, ridx_all, full_uses, full_view)
+        net_out = (model.forward if with_rgb else model.forward_density)(**kw, **forward_params)
+    if with_rgb:
+        volume_buffer['rgb'] = net_out['rgb'].to(dtype)
+    volume_buffer['deltas'] = deltas.to(dtype)
+    volume_buffer['sigma'] = net_out['sigma'].to(dtype)
+    volume_buffer['opacity_alpha'] = tau_to_alpha(volume_buffer['sigma'] * volume_buffer['deltas'])
+    for k in _PASSTHROUGH:
+        if k in net_out:
+            volume_buffer[k] = net_out[k].to(dtype)
+    return volume_buffer, details
+
+
+def composite_packed_volume_buffer(volume_buffer: dict, num_rays: int, with_rgb: bool = True,
+                                   depth_use_normalized_vw: bool = True, device=None, dtype=torch.float32) -> dict:
+    """alpha-composite a packed volume buffer into per-ray mask / depth / rgb (renderer_mixin.py:270-311):
+    rays that were not hit keep zeros."""
+    if device is None:
+        device = volume_buffer['pack_infos_hit'].device if volume_buffer['type'] != 'empty' else 'cpu'
+    out = dict(mask_volume=torch.zeros(num_rays, device=device, dtype=dtype),
+               depth_volume=torch.zeros(num_rays, device=device, dtype=dtype))
+    if with_rgb:
+        out['rgb_volume'] = torch.zeros(num_rays, 3, device=device, dtype=dtype)
+    if volume_buffer['type'] == 'empty':
+        return out
+    assert volume_buffer['type'] == 'packed', "composite_packed_volume_buffer: packed buffers only"
+    pi, hit = volume_buffer['pack_infos_hit'], volume_buffer['rays_inds_hit']
+    volume_buffer['vw'] = vw = packed_alpha_to_vw(volume_buffer['opacity_alpha'], pi)
+    vw_sum = packed_sum(vw.view(-1), pi)
+    out['mask_volume'][hit] = vw_sum
+    w_depth = packed_div(vw, vw_sum + 1e-10, pi) if depth_use_normalized_vw else vw.view(-1)
+    out['depth_volume'][hit] = packed_sum(w_depth * volume_buffer['t'].view(-1), pi)
+    if with_rgb:
+        out['rgb_volume'][hit] = packed_sum(vw.view(-1, 1) * volume_buffer['rgb'].view(-1, 3), pi)
+    return out

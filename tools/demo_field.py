@@ -1,0 +1,73 @@
+"""tools/demo_field.py -- TEST / BENCH INFRASTRUCTURE: the smallest model that satisfies the protocol of
+nerf_ray_query_march_occ (accel.ray_march, query_density, forward_density, forward).  16-level NGP LoTD encoder (the
+HIP path) + two tiny torch MLPs with random weights; not part of the product."""
+import torch
+import torch.nn as nn
+
+from nr3d_lib_amd.graphics.raymarch.occgrid_raymarch import occgrid_raymarch
+from nr3d_lib_amd.models.grid_encodings.lotd import LoTD, gen_ngp_cfg
+
+
+class StaticOccGridAccel:
+    """occupancy grid over ``roi`` with the marching parameters fixed at construction"""
+
+    def __init__(self, occ_grid: torch.Tensor, step_size: float, max_steps: int = 512, roi: torch.Tensor = None):
+        self.occ_grid, self.step_size, self.max_steps, self.roi = occ_grid, step_size, max_steps, roi
+
+    def ray_march(self, rays_o, rays_d, near=None, far=None, perturb=False, **march_cfg):
+        cfg = dict(step_size=self.step_size, max_steps=self.max_steps, roi=self.roi)
+        cfg.update(march_cfg)
+        return occgrid_raymarch(self.occ_grid, rays_o, rays_d, near, far, perturb=perturb, **cfg)
+
+
+class DemoField(nn.Module):
+    use_view_dirs = True
+
+    def __init__(self, occ_grid, step_size, max_steps=512, hidden=32, seed=0, device=None):
+        super().__init__()
+        cfg = gen_ngp_cfg()
+        self.encoding = LoTD(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], hashmap_size=cfg["hashmap_size"])
+        g = torch.Generator().manual_seed(seed)
+        n_params = self.encoding.meta.n_params if hasattr(self.encoding, "meta") else self.encoding.n_params
+        self.grid = nn.Parameter(torch.empty(n_params).uniform_(-1e-1, 1e-1, generator=g))
+        e = self.encoding.out_features
+        self.density = nn.Sequential(nn.Linear(e, hidden), nn.ReLU(), nn.Linear(hidden, 1 + 15))
+        self.color = nn.Sequential(nn.Linear(15 + 3, hidden), nn.ReLU(), nn.Linear(hidden, 3))
+        for p, s in zip(self.parameters(), range(100)):
+            if p is not self.grid:
+                with torch.no_grad():
+                    p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() > 1 else 0.1))
+        self.accel = StaticOccGridAccel(occ_grid, step_size, max_steps)
+        if device is not None:
+            self.to(device)
+
+    def _h(self, x):
+        feat = self.encoding(((x + 1) * 0.5).clamp(1e-6, 1 - 1e-6), self.grid)
+        h = self.density(feat.float())
+        return torch.nn.functional.softplus(h[..., 0] + 2.0) * 20.0, h[..., 1:]
+
+    def query_density(self, x, **kw):
+        return self._h(x)[0]
+
+    def forward_density(self, x, **kw):
+        return dict(sigma=self._h(x)[0])
+
+    def forward(self, x, v=None, **kw):
+        sigma, geo = self._h(x)
+        rgb = torch.sigmoid(self.color(torch.cat([geo, v if v is not None else torch.zeros_like(x)], -1)))
+        return dict(sigma=sigma, rgb=rgb)
+
+
+def pinhole_rays(side, device, fov=0.4, dist=4.0):
+    """side^2 rays from a pinhole at (0, 0, -dist) looking at the origin, with near/far from the [-1, 1]^3 box"""
+    u = torch.linspace(-fov, fov, side)
+    uu, vv = torch.meshgrid(u, u, indexing="ij")
+    n = side * side
+    d = torch.stack([uu.flatten(), vv.flatten(), torch.ones(n)], 1)
+    d = (d / d.norm(dim=1, keepdim=True)).to(device)
+    o = torch.tensor([0.0, 0.0, -dist]).repeat(n, 1).to(device)
+    t1, t2 = (-1 - o) / d, (1 - o) / d
+    near = torch.minimum(t1, t2).amax(1).clamp_min(0).contiguous()
+    far = torch.maximum(t1, t2).amin(1).contiguous()
+    far = torch.where(far > near, far, near).contiguous()
+    return o, d, near, far
