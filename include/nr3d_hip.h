@@ -171,6 +171,17 @@ int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, const float *ra
 /* Scratch bytes needed by the device-wide scans used in two-phase ops (any n). */
 uint64_t nr3d_scan_tmp_bytes(uint64_t n);
 
+/* Occupancy-value grid maintenance -- replaces torch_scatter.scatter_max in update_occ_val_grid[_idx]_ /
+ * update_batched_occ_val_grid[_idx]_ (nr3d_lib/models/accelerations/occgrid/utils.py:80-125):
+ *   grid[v] <- max(ema_decay * grid[v], max_{samples in v} occ_val)  for touched voxels, unchanged otherwise.
+ * scatter_max: vmax [n_batches * Rx*Ry*Rz] f32 scratch := -inf, then the per-voxel maximum of occ_val.  Voxel of
+ *   sample i: gidx[i] (int64 [n,3]) or, when gidx == NULL, ((pts[i]/2 + 0.5) * res).long().clamp(0, res-1);
+ *   batch of sample i: bidx[i] (int64) or i / per_batch (per_batch == 0: single grid).
+ * apply_max: applies the decayed maximum in place.  A sharded caller all-reduces(MAX) vmax between the two. */
+int nr3d_occ_scatter_max(uint64_t n, const int64_t *gidx, const float *pts, const int64_t *bidx, uint64_t per_batch,
+                         const float *occ_val, const int32_t grid_res[3], uint32_t n_batches, float *vmax, void *stream);
+int nr3d_occ_apply_max(uint64_t n_voxels, float ema_decay, const float *vmax, float *occ_val_grid, void *stream);
+
 /* =================================================================================================
  * pack_ops -- replaces nr3d_lib.bindings._pack_ops  (csrc/pack_ops/pack_ops.h:11-65,
  * csrc/pack_ops/pack_ops.cpp:21-58, kernels csrc/pack_ops/pack_ops_cuda.cu)

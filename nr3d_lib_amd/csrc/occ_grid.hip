@@ -237,10 +237,78 @@ __global__ __launch_bounds__(256) void k_emit_cached(uint32_t n_rays, uint32_t s
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Occupancy-value grid maintenance (the producer side of the marcher's input):
+//   new[v] = max(ema_decay * old[v], max over the samples that fall into voxel v)   for touched voxels, old[v] otherwise
+// (update_occ_val_grid[_idx]_ / update_batched_*, nr3d_lib/models/accelerations/occgrid/utils.py:80-125, there built on
+// torch_scatter.scatter_max with `out = ema_decay * grid`).  Two kernels so that a sharded caller can all-reduce(MAX)
+// the per-voxel sample maxima before the decay is applied once.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
+	// order-preserving integer views: non-negative floats compare like signed ints, negative ones inversely as uints
+	if (v >= 0.0f) atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
+	else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void k_occ_scatter_max(uint64_t n, const int64_t *__restrict__ gidx,
+                                                         const float *__restrict__ pts, const int64_t *__restrict__ bidx,
+                                                         uint64_t per_batch, const float *__restrict__ val, int rx, int ry,
+                                                         int rz, float *__restrict__ vmax) {
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	int64_t ix, iy, iz;
+	if (gidx) {
+		ix = gidx[3 * i]; iy = gidx[3 * i + 1]; iz = gidx[3 * i + 2];
+	} else {
+		// ((pts / 2 + 0.5) * resolution).long().clamp(0, resolution - 1): fp32, truncation toward zero
+		ix = (int64_t)((pts[3 * i] / 2.0f + 0.5f) * (float)rx);
+		iy = (int64_t)((pts[3 * i + 1] / 2.0f + 0.5f) * (float)ry);
+		iz = (int64_t)((pts[3 * i + 2] / 2.0f + 0.5f) * (float)rz);
+		ix = max((int64_t)0, min(ix, (int64_t)rx - 1));
+		iy = max((int64_t)0, min(iy, (int64_t)ry - 1));
+		iz = max((int64_t)0, min(iz, (int64_t)rz - 1));
+	}
+	const uint64_t vol = (uint64_t)rx * ry * rz;
+	const uint64_t b = bidx ? (uint64_t)bidx[i] : (per_batch ? i / per_batch : 0);
+	atomic_max_f32(vmax + b * vol + (uint64_t)ix * ((uint64_t)ry * rz) + (uint64_t)iy * rz + (uint64_t)iz, val[i]);
+}
+
+__global__ __launch_bounds__(256) void k_occ_apply_max(uint64_t n_voxels, float ema_decay, const float *__restrict__ vmax,
+                                                       float *__restrict__ grid) {
+	const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (v >= n_voxels) return;
+	const float m = vmax[v];
+	if (__float_as_uint(m) != 0xFF800000u) grid[v] = fmaxf(ema_decay * grid[v], m);
+}
+
 }  // namespace occ
 }  // namespace nr3d
 
 using namespace nr3d;
+
+extern "C" int nr3d_occ_scatter_max(uint64_t n, const int64_t *gidx, const float *pts, const int64_t *bidx,
+                                    uint64_t per_batch, const float *occ_val, const int32_t grid_res[3], uint32_t n_batches,
+                                    float *vmax, void *stream) {
+	NR3D_CHECK(vmax != nullptr, "occ_scatter_max: NULL scratch grid");
+	NR3D_CHECK(n == 0 || (gidx != nullptr) != (pts != nullptr), "occ_scatter_max: pass exactly one of gidx / pts");
+	const uint64_t total = (uint64_t)grid_res[0] * grid_res[1] * grid_res[2] * (n_batches ? n_batches : 1);
+	NR3D_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)vmax, (int)0xFF800000u, total, (hipStream_t)stream));   // -inf
+	if (n == 0) return 0;
+	NR3D_CHECK(occ_val != nullptr, "occ_scatter_max: NULL occ_val");
+	hipLaunchKernelGGL(occ::k_occ_scatter_max, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, gidx, pts, bidx,
+	                   per_batch, occ_val, grid_res[0], grid_res[1], grid_res[2], vmax);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_occ_apply_max(uint64_t n_voxels, float ema_decay, const float *vmax, float *occ_val_grid, void *stream) {
+	if (n_voxels == 0) return 0;
+	NR3D_CHECK(vmax && occ_val_grid, "occ_apply_max: NULL pointer");
+	hipLaunchKernelGGL(occ::k_occ_apply_max, dim3(div_up(n_voxels, 256)), dim3(256), 0, (hipStream_t)stream, n_voxels, ema_decay,
+	                   vmax, occ_val_grid);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
 
 // scratch layout: [ int32 counts[n] (padded to 8 B) | tile sums ]
 extern "C" uint64_t nr3d_scan_tmp_bytes(uint64_t n) { return ((n * sizeof(int64_t) + 7) / 8) * 8 + scan::tmp_bytes(n); }

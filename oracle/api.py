@@ -476,3 +476,45 @@ def get_pack_infos_from_n(n_per_pack):
     n = _i64(n_per_pack)
     cs = np.cumsum(n)
     return np.ascontiguousarray(np.stack([cs - n, n], 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# occupancy-value grid maintenance (nr3d_lib/models/accelerations/occgrid/utils.py:80-125): numpy restatement
+# ---------------------------------------------------------------------------------------------------------------------
+def occ_gidx_from_pts(pts, res):
+    """((pts / 2 + 0.5) * resolution).long().clamp(0, resolution - 1) in fp32 (utils.py:98)"""
+    p = np.asarray(pts, np.float32)
+    r = np.asarray(res, np.int64)
+    g = ((p / np.float32(2.0) + np.float32(0.5)) * r.astype(np.float32)).astype(np.float32)
+    return np.clip(np.trunc(g).astype(np.int64), 0, r - 1)
+
+
+def occ_scatter_max(shape, gidx, occ_val, bidx=None):
+    """per-voxel maximum of occ_val (-inf where no sample falls), flat over `shape` = [Rx,Ry,Rz] or [B,Rx,Ry,Rz]"""
+    res = tuple(shape[-3:])
+    vol = int(np.prod(res))
+    gi = np.asarray(gidx, np.int64)
+    val = np.asarray(occ_val, np.float32)
+    if len(shape) == 4 and bidx is None:
+        b = np.repeat(np.arange(shape[0]), gi.shape[1])
+    else:
+        b = np.zeros(gi.reshape(-1, 3).shape[0], np.int64) if bidx is None else np.asarray(bidx, np.int64).reshape(-1)
+    gi, val = gi.reshape(-1, 3), val.reshape(-1)
+    idx = b * vol + gi[:, 0] * (res[1] * res[2]) + gi[:, 1] * res[2] + gi[:, 2]
+    vmax = np.full(int(np.prod(shape)), -np.inf, np.float32)
+    np.maximum.at(vmax, idx, val)
+    return vmax
+
+
+def occ_apply_max(grid, vmax, ema_decay=1.0):
+    g = np.array(grid, np.float32, copy=True)
+    flat = g.reshape(-1)
+    touched = vmax > -np.inf
+    flat[touched] = np.maximum(np.float32(ema_decay) * flat[touched], vmax[touched])
+    return g
+
+
+def occ_update_grid(grid, gidx, occ_val, ema_decay=1.0, bidx=None):
+    """returns the updated copy: touched voxels get max(ema_decay * old, max of their samples), the rest keep old.
+    grid [Rx,Ry,Rz] or [B,Rx,Ry,Rz] (then bidx [n] or gidx [B,n,3] / occ_val [B,n])"""
+    return occ_apply_max(grid, occ_scatter_max(np.shape(grid), gidx, occ_val, bidx), ema_decay)

@@ -48,6 +48,25 @@ def _worker(rank, world, port, q):
         avg = torch.full((4,), float(rank + 1))
         D.allreduce_grads([avg], average=True)
         torch.testing.assert_close(avg, torch.full((4,), sum(range(1, world + 1)) / world))
+        # sharded occupancy-grid update: every rank scatters the maxima of ITS samples, all-reduce(MAX) of the per-voxel
+        # maxima, then the decay is applied once -- must equal the unsharded update (oracle restatement on the CPU; on
+        # the GPU nr3d_lib_amd.models.accelerations.occgrid.update_*(..., group=...) runs the same three steps)
+        import numpy as np
+        import oracle
+        rng = np.random.default_rng(5)
+        res, n = (6, 5, 7), 600
+        grid0 = rng.uniform(0, 1, res).astype(np.float32)
+        gidx = np.stack([rng.integers(0, r, n) for r in res], 1)
+        val = rng.uniform(-0.5, 2, n).astype(np.float32)
+        a, b = D.shard_range(n)
+        vmax = torch.from_numpy(oracle.occ_scatter_max(res, gidx[a:b], val[a:b]))
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        got = oracle.occ_apply_max(grid0, vmax.numpy(), 0.9)
+        assert np.array_equal(got, oracle.occ_update_grid(grid0, gidx, val, 0.9))
+        # ... whereas all-reducing the locally decayed grids would be wrong wherever only the other rank has samples
+        local = torch.from_numpy(oracle.occ_update_grid(grid0, gidx[a:b], val[a:b], 0.9))
+        dist.all_reduce(local, op=dist.ReduceOp.MAX)
+        assert not np.array_equal(local.numpy(), got)
         off, total = D.global_pack_offsets(10 * (rank + 1))
         assert total == sum(10 * (r + 1) for r in range(world)) and off == sum(10 * (r + 1) for r in range(rank))
         q.put((rank, "ok"))

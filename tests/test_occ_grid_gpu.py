@@ -178,3 +178,82 @@ def test_sample_cache_and_second_march_agree(oracle, dev, monkeypatch):
     for a, b, r, n in zip(got_cached, got_twice, ref, ["packed_info", "t_starts", "t_ends", "ridx", "gidx"]):
         assert_equal(a, r, name=f"cached/{n}")
         assert_equal(b, r, name=f"two-march/{n}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# occupancy-value grid maintenance
+# ---------------------------------------------------------------------------------------------------------------------
+def test_update_occ_val_grid_bit_exact(oracle, dev):
+    from nr3d_lib_amd.models.accelerations.occgrid import (binarize, update_occ_val_grid_, update_occ_val_grid_idx_)
+    rng = np.random.default_rng(21)
+    res = (24, 20, 28)
+    grid0 = rng.uniform(-0.5, 2.0, res).astype(np.float32)
+    n = 50000                                              # ~3.7 samples per voxel: duplicates, and untouched voxels
+    gidx = np.stack([rng.integers(0, r, n) for r in res], 1)
+    val = rng.uniform(-1.0, 3.0, n).astype(np.float32)     # mixed signs: both branches of the float atomic max
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for ema in (1.0, 0.95):
+        g = t(grid0.copy())
+        update_occ_val_grid_idx_(g, t(gidx), t(val), ema_decay=ema)
+        assert_equal(g, oracle.occ_update_grid(grid0, gidx, val, ema), name=f"gidx ema={ema}")
+    # positions in [-1, 1]^3 incl. the faces and points outside (clamped), voxel rule of the reference in fp32
+    pts = rng.uniform(-1.05, 1.05, (n, 3)).astype(np.float32)
+    pts[:10] = 1.0; pts[10:20] = -1.0
+    g = t(grid0.copy())
+    update_occ_val_grid_(g, t(pts), t(val), ema_decay=0.9)
+    want = oracle.occ_update_grid(grid0, oracle.occ_gidx_from_pts(pts, res), val, 0.9)
+    assert_equal(g, want, name="pts")
+    # no samples: nothing changes; binarize incl. the mean rule
+    g2 = t(grid0.copy())
+    update_occ_val_grid_idx_(g2, t(gidx[:0]), t(val[:0]), ema_decay=0.5)
+    assert_equal(g2, grid0, name="empty update")
+    assert_equal(binarize(g, 0.7), want > 0.7, name="binarize")
+    thr = min(0.7, float(want.mean()) - 1e-5)
+    assert_equal(binarize(g, 0.7, consider_mean=True), want > np.float32(thr), name="binarize(mean)")
+
+
+def test_update_batched_occ_val_grid(oracle, dev):
+    from nr3d_lib_amd.models.accelerations.occgrid import (update_batched_occ_val_grid_, update_batched_occ_val_grid_idx_)
+    rng = np.random.default_rng(22)
+    B, res = 3, (12, 10, 14)
+    grid0 = rng.uniform(0, 1, (B,) + res).astype(np.float32)
+    n = 4000
+    t = lambda a: torch.from_numpy(a).to(dev)
+    gidx = np.stack([rng.integers(0, r, n) for r in res], 1)
+    bidx = rng.integers(0, B, n)
+    val = rng.uniform(0, 2, n).astype(np.float32)
+    g = t(grid0.copy())
+    update_batched_occ_val_grid_idx_(g, t(bidx), t(gidx), t(val), ema_decay=0.8)
+    assert_equal(g, oracle.occ_update_grid(grid0, gidx, val, 0.8, bidx=bidx), name="per-sample bidx")
+    gb = np.stack([np.stack([rng.integers(0, r, n) for r in res], 1) for _ in range(B)])
+    vb = rng.uniform(0, 2, (B, n)).astype(np.float32)
+    g = t(grid0.copy())
+    update_batched_occ_val_grid_idx_(g, None, t(gb), t(vb), ema_decay=0.8)
+    assert_equal(g, oracle.occ_update_grid(grid0, gb, vb, 0.8), name="batched input")
+    pb = rng.uniform(-1, 1, (B, n, 3)).astype(np.float32)
+    g = t(grid0.copy())
+    update_batched_occ_val_grid_(g, t(pb), None, t(vb), ema_decay=1.0)
+    want = oracle.occ_update_grid(grid0, oracle.occ_gidx_from_pts(pb, res), vb, 1.0)
+    assert_equal(g, want, name="batched pts")
+
+
+def test_occ_grid_ema_loop_feeds_the_marcher(oracle, dev):
+    """sample -> query -> update -> binarize -> march: the producer/consumer pair end to end"""
+    from nr3d_lib_amd.models.accelerations.occgrid import binarize, sample_pts_in_voxels, update_occ_val_grid_
+    res = (32, 32, 32)
+    torch.manual_seed(0)
+    occ_val = torch.zeros(res, device=dev)
+    gidx_full = torch.stack(torch.meshgrid(*[torch.arange(r, device=dev) for r in res], indexing="ij"), -1).view(-1, 3)
+    density = lambda p: torch.exp(-((p.norm(dim=-1) - 0.6) / 0.08) ** 2)          # a spherical shell
+    for _ in range(4):
+        pts, vidx = sample_pts_in_voxels(gidx_full, 2 ** 16, torch.tensor(res, device=dev))
+        assert pts.shape[0] == vidx.shape[0] and float(pts.abs().max()) <= 1.0
+        update_occ_val_grid_(occ_val, pts, density(pts), ema_decay=0.95)
+    occ = binarize(occ_val, 0.3)
+    frac = float(occ.float().mean())
+    assert 0.02 < frac < 0.5
+    o, d, near, far = pinhole_rays(16, seed=4)
+    got, ref = run_both(oracle, dev, o, d, near, far, ROI, occ.cpu().numpy(), 0, 0.02, 1e10, 0.0, 128)
+    for g, r, nme in zip(got, ref, ["packed_info", "t_starts", "t_ends", "ridx", "gidx"]):
+        assert_equal(g, r, name=nme)
+    assert got[1].shape[0] > 0
