@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra figures (used when profiling the timed loop)")
     ap.add_argument("--log2-points", type=int, default=N_POINTS_LOG2)
     args = ap.parse_args()
 
@@ -272,7 +273,7 @@ def main():
                                     for k in names},
                          "whole_step_frac": round(sum(bpp.values()) * N / (sum(kms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
-        if world == 1:
+        if world == 1 and not args.no_extra:
             try:
                 out["extra"] = {"march_composite": march_composite_rate(dev),
                                 "march_composite_262144_rays": march_composite_rate(dev, iters=5, side=512)}
@@ -281,8 +282,8 @@ def main():
                 out["extra"]["c4_mixed_lotd"] = c4_mixed_rate()
             except Exception as ex:   # the extra figure must never cost the headline line
                 out["extra"] = {"march_composite_error": repr(ex)}
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(cfg)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
