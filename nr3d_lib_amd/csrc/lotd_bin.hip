@@ -61,10 +61,7 @@ static inline uint32_t rec_class(uint32_t n_rec) { return n_rec == 0 ? 0u : n_re
 struct BinPlan {
 	uint32_t qmap[kMaxPlanLevels];        // pseudo level of the meta behind local index q (levels of ONE record class)
 	uint32_t nb[kMaxPlanLevels];          // buckets per pseudo level
-	uint32_t rep[kMaxPlanLevels];         // replicas per bucket (stage B)
-	uint32_t n_first[kMaxPlanLevels];     // the first n_first buckets (line tables of VM-like levels: far more updates
-	uint32_t rep_first[kMaxPlanLevels];   //   per entry than the planes behind them) get rep_first replicas instead
-	uint32_t order[kMaxPlanLevels];       // stage-B launch order of the pseudo levels: largest workgroups first
+	uint32_t bucket_base[kMaxPlanLevels + 1];   // flat bucket index of the level's first bucket ([n_pseudo] = total)
 	uint32_t offs_base[kMaxPlanLevels];   // start of this pseudo level's offset table (in uint32 units)
 	uint32_t epb_log2;                    // log2(entries per bucket)
 	uint32_t n_blk;                       // stage-A workgroups along the points of the current chunk
@@ -351,27 +348,95 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 }
 
 // -------------------------------------------------------------------------------------------------
+// Stage-B planning on the device: the number of records per bucket is only known after stage A and depends on where the
+// points are (uniform points fill hash buckets evenly; samples along rays through a thin shell do not).  A bucket
+// with more than one unit of work (1/1024 of all records, ~4 units per CU) is split into replicas over its point
+// blocks; empty buckets get no workgroup at all.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bucket_totals(BinPlan plan, const uint32_t *__restrict__ offs_g,
+                                                       uint32_t *__restrict__ tot) {
+	const uint32_t fb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (fb >= plan.bucket_base[plan.n_pseudo]) return;
+	uint32_t q = 0;
+	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
+	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)(fb - plan.bucket_base[q]) * plan.n_blk;
+	const uint32_t *ob1 = ob0 + plan.n_blk;
+	uint32_t sum = 0;
+	for (uint32_t blk = lane; blk < plan.n_blk; blk += 64) sum += ob1[blk] - ob0[blk];
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+	if (lane == 0) tot[fb] = sum;
+}
+
+__global__ __launch_bounds__(1024) void k_plan_items(uint32_t NB, uint32_t n_blk, const uint32_t *__restrict__ tot,
+                                                     uint32_t *__restrict__ rep, uint32_t *__restrict__ item_start) {
+	__shared__ uint64_t red[16];
+	__shared__ uint64_t carry_s;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint64_t part = 0;
+	for (uint32_t fb = threadIdx.x; fb < NB; fb += 1024) part += tot[fb];
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+	if (lane == 0) red[wave] = part;
+	__syncthreads();
+	uint64_t total = 0;
+#pragma unroll
+	for (int w = 0; w < 16; ++w) total += red[w];
+	const uint64_t unit = total / 1024 > 0 ? total / 1024 : 1;
+	if (threadIdx.x == 0) carry_s = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < NB; base += 1024) {
+		const uint32_t fb = base + threadIdx.x;
+		uint32_t r = 0;
+		if (fb < NB) {
+			const uint64_t t = tot[fb];
+			r = t == 0 ? 0u : (uint32_t)((t + unit / 2) / unit);
+			if (t != 0 && r < 1) r = 1;
+			if (r > n_blk) r = n_blk;
+			rep[fb] = r;
+		}
+		uint64_t inc = r;                      // inclusive scan over the 1024 threads
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) { const uint64_t t2 = __shfl_up(inc, off, 64); if ((int)lane >= off) inc += t2; }
+		__syncthreads();
+		if (lane == 63) red[wave] = inc;
+		__syncthreads();
+		uint64_t woff = 0, tsum = 0;
+#pragma unroll
+		for (int w = 0; w < 16; ++w) { if (w < (int)wave) woff += red[w]; tsum += red[w]; }
+		const uint64_t c = carry_s;
+		if (fb < NB) item_start[fb] = (uint32_t)(c + woff + inc - r);
+		__syncthreads();
+		if (threadIdx.x == 0) carry_s = c + tsum;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) item_start[NB] = (uint32_t)carry_s;
+}
+
+// -------------------------------------------------------------------------------------------------
 // Stage B: one bucket (x replica) -> fp64 LDS accumulation -> slice of dL/dparam
 // -------------------------------------------------------------------------------------------------
 template <int D, int G>
 __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
                                                        const uint32_t *__restrict__ rec,
                                                        const uint32_t *__restrict__ offs_g,
+                                                       const uint32_t *__restrict__ rep_g,
+                                                       const uint32_t *__restrict__ item_start,
                                                        float *__restrict__ dparam) {
 	// accumulators are feature-major (acc[f][entry]): the G atomics of a record spread over all LDS banks
 	extern __shared__ __attribute__((aligned(16))) double acc[];      // [kLdsDoubles]
 	const uint32_t cap = plan.cap;
-	const uint32_t q = plan.order[blockIdx.y];            // local index into this plan's levels
-	const uint32_t nb = plan.nb[q];
-	const uint32_t nf = plan.n_first[q], first_wgs = nf * plan.rep_first[q];
-	uint32_t R, b, r;
-	if (blockIdx.x < first_wgs) { R = plan.rep_first[q]; b = blockIdx.x / R; r = blockIdx.x - b * R; }
-	else {
-		R = plan.rep[q];
-		const uint32_t xr = blockIdx.x - first_wgs;
-		b = nf + xr / R; r = xr - (xr / R) * R;
-		if (b >= nb) return;
-	}
+	// work item -> (flat bucket, replica): items of a bucket are consecutive, item_start is their exclusive prefix
+	const uint32_t NB = plan.bucket_base[plan.n_pseudo];
+	const cu32_t istart = (cu32_t)item_start, irep = (cu32_t)rep_g;       // uniform reads -> scalar loads
+	if (blockIdx.x >= istart[NB]) return;
+	uint32_t lo = 0, hi = NB;                                             // last fb with item_start[fb] <= blockIdx.x
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (istart[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+	const uint32_t fb = lo, R = irep[fb], r = blockIdx.x - istart[fb];
+	uint32_t q = 0;
+	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;   // local level of the bucket
+	const uint32_t nb = plan.nb[q], b = fb - plan.bucket_base[q];
+	(void)nb;
 	const uint32_t qg = plan.qmap[q];                     // pseudo level of the meta
 	const uint32_t level = meta_level_of(md, qg);
 	const Lvl L = load_level(md, level);
@@ -498,61 +563,15 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t cls,
 		if (nb > kMaxBuckets) return false;
 		plan.qmap[nq] = q;
 		plan.nb[nq] = nb;
+		plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
 		if (base > 0xFFFFFFFFull) return false;
 		plan.offs_base[nq] = (uint32_t)base;
 		base += (uint64_t)(nb + 1) * plan.n_blk;
 		++nq;
 	}
 	plan.n_pseudo = nq;
+	plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
 	offs_words = base;
-	// Stage-B work is balanced on the EXPECTED number of records per bucket for spread-out points: a level's table is a
-	// concatenation of segments (lines, planes, the dense/hash grid), each receiving a fixed number of updates per point
-	// spread over its entries.  Target ~4 workgroups per CU; a (level, tier) whose buckets carry more than one unit
-	// of work is split into replicas (which flush with f32 atomics).  Tier 0 = the leading buckets that hold line
-	// tables (2 updates per point and dim concentrated on R_d entries), tier 1 = the rest.
-	const uint32_t epb = 1u << lg;
-	double total = 0.0, load_first[kMaxPlanLevels], load_rest[kMaxPlanLevels];
-	for (uint32_t ql = 0; ql < nq; ++ql) {
-		const nr3d_lotd_level_t &L = m->levels[m->map_levels[plan.qmap[ql]]];
-		const uint32_t nrec = rec_count(L.type, D);
-		uint64_t lines = 0;
-		if (L.type == NR3D_LOD_VectorMatrix) lines = (uint64_t)L.res[0] + L.res[1] + L.res[2];
-		else if (L.type == NR3D_LOD_VecZMatXoY) lines = L.res[2];
-		const uint32_t nf = lines ? (uint32_t)((lines + epb - 1) / epb) : 0u;
-		const uint32_t rec_lines = L.type == NR3D_LOD_VectorMatrix ? 6u : (lines ? 2u : 0u);
-		plan.n_first[ql] = nf < plan.nb[ql] ? nf : plan.nb[ql];
-		// expected records per bucket (per point): line records over tier 0, everything else evenly over all entries
-		const double per_entry_rest = (double)(nrec - rec_lines) / (double)(L.size > lines ? L.size - lines : 1);
-		const uint64_t first_entries = (uint64_t)plan.n_first[ql] * epb < L.size ? (uint64_t)plan.n_first[ql] * epb : L.size;
-		load_first[ql] = plan.n_first[ql]
-		    ? ((double)rec_lines + per_entry_rest * (double)(first_entries > lines ? first_entries - lines : 0)) / plan.n_first[ql] : 0.0;
-		const uint32_t n_rest = plan.nb[ql] - plan.n_first[ql];
-		load_rest[ql] = n_rest ? per_entry_rest * (double)(L.size - first_entries) / n_rest : 0.0;
-		total += (double)nrec;
-	}
-	const double unit = total / 1024.0;                            // records per point and workgroup at ~4 workgroups per CU
-	for (uint32_t ql = 0; ql < nq; ++ql) {
-		auto reps = [&](double load) {
-			uint32_t r = (uint32_t)(load / unit + 0.25);     // round down mostly: a few larger workgroups pack better than a spill
-			r = r < 1 ? 1 : r;
-			return r > plan.n_blk ? (plan.n_blk ? plan.n_blk : 1u) : r;
-		};
-		plan.rep[ql] = reps(load_rest[ql]);
-		plan.rep_first[ql] = plan.n_first[ql] ? reps(load_first[ql]) : 1u;
-		plan.order[ql] = ql;
-	}
-	auto wg_load = [&](uint32_t ql) {                               // heaviest workgroup of the level
-		const double a = plan.n_first[ql] ? load_first[ql] / plan.rep_first[ql] : 0.0;
-		const double b2 = (plan.nb[ql] > plan.n_first[ql]) ? load_rest[ql] / plan.rep[ql] : 0.0;
-		return a > b2 ? a : b2;
-	};
-	for (uint32_t i = 1; i < nq; ++i) {                            // launch the levels with the largest workgroups first
-		const uint32_t ql = plan.order[i];
-		const double key = wg_load(ql);
-		uint32_t j = i;
-		while (j > 0 && wg_load(plan.order[j - 1]) < key) { plan.order[j] = plan.order[j - 1]; --j; }
-		plan.order[j] = ql;
-	}
 	return true;
 }
 
@@ -566,11 +585,11 @@ static bool binnable(const nr3d_lotd_meta_t *m) {
 
 constexpr uint32_t kClasses[3] = {8, 16, 24};
 
-struct BinLayout { uint64_t rec_bytes, offs_bytes, gt_bytes, total; };
+struct BinLayout { uint64_t rec_bytes, offs_bytes, plan_bytes, gt_bytes, total; };
 
 // workspace = max over the record classes (they run one after another) of records + offsets, + the transposed dL/dy
 static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinLayout &l) {
-	l.rec_bytes = l.offs_bytes = 0;
+	l.rec_bytes = l.offs_bytes = l.plan_bytes = 0;
 	for (uint32_t cls : kClasses) {
 		BinPlan plan;
 		uint64_t ow;
@@ -579,10 +598,12 @@ static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinLayout &l) {
 		const uint64_t ob = ((ow * 4 + 255) / 256) * 256;
 		l.rec_bytes = rb > l.rec_bytes ? rb : l.rec_bytes;
 		l.offs_bytes = ob > l.offs_bytes ? ob : l.offs_bytes;
+		const uint64_t pb = (((uint64_t)plan.bucket_base[plan.n_pseudo] * 3 + 4) * 4 + 255) / 256 * 256;   // tot | rep | item_start
+		l.plan_bytes = pb > l.plan_bytes ? pb : l.plan_bytes;
 	}
 	l.rec_bytes = ((l.rec_bytes + 255) / 256) * 256;
 	l.gt_bytes = (((uint64_t)m->n_encoded_dims * n_chunk * 4 + 255) / 256) * 256;
-	l.total = l.rec_bytes + l.offs_bytes + l.gt_bytes;
+	l.total = l.rec_bytes + l.offs_bytes + l.plan_bytes + l.gt_bytes;
 	return true;
 }
 
@@ -597,14 +618,13 @@ uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points) {
 template <int D, int G, int NR, bool DH>
 static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
                         int32_t max_level, const float *xc, const float *vc, const float *gc, int64_t sn, int64_t se,
-                        const float *params, uint32_t *rec, uint32_t *offs, float *dparam, hipStream_t st) {
+                        const float *params, uint32_t *rec, uint32_t *offs, uint32_t *plan_buf, float *dparam,
+                        hipStream_t st) {
 	constexpr int BP = BinCfg<G, NR>::BP;
-	uint32_t nb_max = 0, acc_max = 0;
-	for (uint32_t q = 0; q < pl.n_pseudo; ++q) {
-		nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
-		const uint32_t a = pl.n_first[q] * pl.rep_first[q] + (pl.nb[q] - pl.n_first[q]) * pl.rep[q];
-		acc_max = acc_max > a ? acc_max : a;
-	}
+	uint32_t nb_max = 0;
+	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
+	const uint32_t NB = pl.bucket_base[pl.n_pseudo];
+	uint32_t *tot = plan_buf, *rep = plan_buf + NB, *item_start = plan_buf + 2 * (size_t)NB;
 	const size_t bin_lds = ((size_t)(1 + G) * BinCfg<G, NR>::cap + nb_max + 1) * sizeof(uint32_t);
 	static bool attr_set = false;
 	if (!attr_set) {
@@ -619,8 +639,11 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	else
 		hipLaunchKernelGGL((k_bin<D, G, false, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
 		                   meta->interpolation_type, xc, vc, gc, sn, se, params, rec, offs);
-	hipLaunchKernelGGL((k_accum<D, G>), dim3(acc_max, pl.n_pseudo), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs,
-	                   dparam);
+	hipLaunchKernelGGL(k_bucket_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
+	hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, NB, pl.n_blk, tot, rep, item_start);
+	// sum of replicas <= 1024 (rounded shares of the total) + one per non-empty bucket
+	hipLaunchKernelGGL((k_accum<D, G>), dim3(1024 + NB), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs, rep,
+	                   item_start, dparam);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
@@ -638,7 +661,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	const uint32_t D = meta->n_dims_to_encode, G = meta->n_feat_per_pseudo_lvl, E = meta->n_encoded_dims;
 	uint32_t *rec = (uint32_t *)workspace;
 	uint32_t *offs = (uint32_t *)((char *)workspace + lay.rec_bytes);
-	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes);
+	uint32_t *plan_buf = (uint32_t *)((char *)workspace + lay.rec_bytes + lay.offs_bytes);
+	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes);
 	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && E > 1);
 
 	for (uint32_t p0 = 0; p0 < N; p0 += nc) {
@@ -661,13 +685,13 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			DISPATCH_DG_BIN(D, G, {
 				// hash-only metas (every level Dense or Hash) get kernels without the product-type code
 				if (meta->c_hash_only) {
-					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
-					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
-				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
+					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
+				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
 				else if (cls == 16) {
-					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
 				} else {
-					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, dparam, st);
+					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
 				}
 			});
 			if (rc) return rc;
