@@ -1,2 +1,3 @@
 from .lotd import *      # noqa: F401,F403
 from .lotd_cfg import *  # noqa: F401,F403
+from .lotd_encoding import *  # noqa: F401,F403

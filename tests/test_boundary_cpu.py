@@ -112,3 +112,30 @@ def test_raymarch_records():
     r = RaymarchRetSingle(0, None, None, None, None, None, None, None, None)
     assert len(list(r)) == 9 and r["num_hit_rays"] == 0
     assert len(list(RaymarchRetBatched(0, *[None] * 9))) == 10
+
+
+def test_lotd_encoding_module_cpu_surface():
+    """LoTDEncoding: per-type init bounds, whole-level views, state_dict round trip (no kernel is launched)"""
+    import torch
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTDEncoding
+    cfg = dict(lod_res=[8, 12, 10, 14, 9], lod_n_feats=[4, 4, 8, 2, 4], lod_types=["Dense", "VM", "CP", "NPlaneSum", "Hash"],
+               hashmap_size=512)
+    torch.manual_seed(0)
+    e = LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float)
+    assert e.flattened_params.dtype == torch.float32 and e.out_features == sum(cfg["lod_n_feats"])
+    bounds = [1e-4, 1e-2, 1e-4 ** (1 / 3), 1e-4, 1e-4]
+    for l, b in enumerate(bounds):
+        p = e.get_level_param(l)
+        assert p.shape[1] == cfg["lod_n_feats"][l] and 0.5 * b < float(p.detach().abs().max()) <= b * (1 + 1e-6)
+    assert tuple(e.get_level_param(0, "vol").shape) == (8, 8, 8, 4)
+    with pytest.raises(NotImplementedError):
+        e.get_level_param(1, "vec", 0)
+    e.set_level_param(4, value=torch.ones(512, 4))
+    assert float(e.get_level_param(4).detach().min()) == 1.0 and float(e.get_level_param(3).detach().abs().max()) <= 1e-4
+    e2 = LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float, param_init_cfg={"type": "normal", "std": 0.1})
+    e2.load_state_dict(e.state_dict())
+    assert torch.equal(e2.flattened_params, e.flattened_params) and e2.lotd_cfg == cfg
+    auto = LoTDEncoding(3, lotd_auto_compute_cfg=dict(type="gen_ngp", num_levels=4), dtype=torch.half)
+    assert auto.lotd.n_levels == 4 and auto.inference_param.dtype == torch.half
+    with pytest.raises(NotImplementedError):
+        LoTDEncoding(3, lotd_cfg=cfg, anneal_cfg=dict(type="hardmask"))

@@ -236,3 +236,32 @@ def test_errors(oracle, dev):
         _lotd.LoDMeta(3, [8], [2], ["Hash"])
     with pytest.raises(RuntimeError, match="3D"):
         _lotd.LoDMeta(2, [8], [2], ["VM"])
+
+
+def test_lotd_encoding_module(oracle, dev):
+    """LoTDEncoding: inputs in [-1, 1], halved nablas, max_level / window masking, gradients reach flattened_params"""
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTDEncoding
+    D, res, nf, types, T, smooth = LOTD_CASES["ngp_small"]
+    cfg = dict(lod_res=res, lod_n_feats=nf, lod_types=types, hashmap_size=T)
+    torch.manual_seed(1)
+    enc = LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float, device=dev, param_init_cfg={"type": "uniform", "bound": 0.5})
+    m_ref = oracle.lotd_create_meta(D, res, nf, types, T, smooth)
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-0.999, 0.999, (2000, 3)).astype(np.float32)
+    p = enc.flattened_params.detach().cpu().numpy()
+    x01 = (x / np.float32(2.0) + np.float32(0.5)).astype(np.float32)
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x01, p, need_dydx=True)
+    xt = torch.from_numpy(x).to(dev)
+    y = enc(xt)
+    assert_close(y, y_ref, name="forward")
+    y2, dy_dx = enc.forward_dydx(xt)
+    g = rng.standard_normal(y_ref.shape).astype(np.float32)
+    nablas = enc.backward_dydx(torch.from_numpy(g).to(dev), dy_dx, xt)
+    assert_close(nablas, oracle.lotd_bwd_dx(m_ref, g, j_ref) / 2, name="nablas (halved)")
+    y.backward(torch.from_numpy(g).to(dev))
+    assert_close(enc.flattened_params.grad, oracle.lotd_bwd_dparam(m_ref, g, x01, p, accum_double=True), name="param grad")
+    enc.max_level = 2
+    y3 = enc(xt)
+    assert_close(y3, oracle.lotd_fwd(m_ref, x01, p, max_level=2)[0], name="max_level")
+    enc.max_level, enc.window = None, torch.linspace(0, 1, enc.out_features, device=dev)
+    assert_close(enc(xt), y_ref * np.linspace(0, 1, enc.out_features, dtype=np.float32), name="window")
