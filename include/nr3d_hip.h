@@ -98,14 +98,16 @@ int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t n_points, int x_dtyp
 
 /* lod_bwd, parameter-gradient half (kernel_lod[_hashonly]_backward_grid, lotd_encoding.h:467-711,
  * lotd_hash_only.h:380-470).  dL_dparam: params dtype, same numel as params, ZERO-INIT by caller.
- * workspace: optional device scratch of >= nr3d_lotd_dparam_workspace_bytes() bytes; when given (and the meta
- * is Dense/Hash only, no batching) the scatter runs atomic-free (binned records + fp64 LDS accumulation);
- * otherwise (NULL / too small / other level types) hardware f32 atomics are used. */
-uint64_t nr3d_lotd_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points);
+ * workspace: optional device scratch of >= nr3d_lotd_dparam_workspace_bytes() bytes; when given (and the meta has
+ * no NPlaneSum / CPfast level) the scatter runs atomic-free (binned records + fp64 LDS accumulation); otherwise
+ * (NULL / too small / those level types) hardware f32 atomics are used.
+ * n_batches: number of table sets behind `params` when batch_inds / batch_offsets / batch_data_size are used (the
+ * reference derives it from params.numel(); 0 = unknown -> batched calls take the atomic path); 0 or 1 otherwise. */
+uint64_t nr3d_lotd_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint32_t n_batches);
 int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
                          int x_dtype, int param_dtype, const void *dL_dy, int64_t dldy_sn, int64_t dldy_se,
                          const void *x, const void *params, const int64_t *batch_inds,
-                         const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
+                         const int64_t *batch_offsets, uint32_t batch_data_size, uint32_t n_batches, int32_t max_level,
                          void *dL_dparam, void *workspace, uint64_t workspace_bytes, void *stream);
 
 /* lod_bwd_bwd_input (lotd_torch_api.cu:575-729), three independent outputs:
@@ -118,8 +120,8 @@ int nr3d_lotd_bwd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev,
                              int x_dtype, int param_dtype, const void *dL_ddLdx,
                              const void *dL_dy, int64_t dldy_sn, int64_t dldy_se, const void *x,
                              const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
-                             uint32_t batch_data_size, int32_t max_level, void *dL_dparam, void *workspace,
-                             uint64_t workspace_bytes, void *stream);
+                             uint32_t batch_data_size, uint32_t n_batches, int32_t max_level, void *dL_dparam,
+                             void *workspace, uint64_t workspace_bytes, void *stream);
 /* (iii) d(dL/dx)/dx (lotd_encoding.h:1157-1298, lotd_hash_only.h:576-695); dL_dx [N, D] fully written. */
 int nr3d_lotd_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
                          int x_dtype, int param_dtype, const void *dL_ddLdx,

@@ -210,13 +210,20 @@ _workspaces = {}
 USE_BINNED_DPARAM = True      # False forces the hardware-atomic scatter (debug / A-B measurements)
 
 
-def _dparam_workspace(meta, n_points, device):
+def _n_batches(meta, params, batch_offsets, batched):
+    """number of table sets behind `params` (1 when the call is not batched)"""
+    if not batched:
+        return 1
+    return int(batch_offsets.shape[0]) if batch_offsets is not None else int(params.shape[0]) // meta.n_params
+
+
+def _dparam_workspace(meta, n_points, device, n_batches=1):
     """(tensor | None, nbytes): device scratch for nr3d_lotd_bwd_dparam's binned path; (None, 0) when that path
     does not apply to this meta."""
     if not USE_BINNED_DPARAM:
         return None, 0
     H.lib().nr3d_lotd_dparam_workspace_bytes.restype = C.c_uint64
-    need = int(H.lib().nr3d_lotd_dparam_workspace_bytes(C.byref(meta._cmeta()), H.u32(n_points)))
+    need = int(H.lib().nr3d_lotd_dparam_workspace_bytes(C.byref(meta._cmeta()), H.u32(n_points), H.u32(n_batches)))
     if need == 0:
         return None, 0
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -360,13 +367,14 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                     H.i64(gse), H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), H.ptr(gT), st))
             if need_param_grad and N > 0:
                 x32, p32 = _f32c(input.detach()), _f32c(params.detach())
-                ws, wsb = (None, 0) if batched else _dparam_workspace(m, N, dev)
+                nbat = _n_batches(m, p32, batch_offsets, batched)
+                ws, wsb = _dparam_workspace(m, N, dev, nbat)
                 if gT is not None:
                     g32, gsn, gse = gT, 1, N
                 H.check(H.lib().nr3d_lotd_bwd_dparam(
                     C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
                     H.ptr(g32), H.i64(gsn), H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
-                    H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparam), H.ptr(ws),
+                    H.ptr(batch_offsets), H.u32(bds), H.u32(nbat), H.i32(max_level), H.ptr(dL_dparam), H.ptr(ws),
                     C.c_uint64(wsb), st))
     return _cast(dL_dx, input.dtype), _cast(dL_dparam, params.dtype)
 
@@ -433,11 +441,12 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
                     H.i32(max_level), H.ptr(dL_dx), st))
             if need_dp:
                 batched = batch_inds is not None or batch_offsets is not None or bds != 0
-                ws, wsb = (None, 0) if batched else _dparam_workspace(m, N, dev)
+                nbat = _n_batches(m, p32, batch_offsets, batched)
+                ws, wsb = _dparam_workspace(m, N, dev, nbat)
                 H.check(H.lib().nr3d_lotd_bwd_bwd_dparam(
                     cm, md, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(g32), H.i64(gsn),
                     H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
-                    H.i32(max_level), H.ptr(dL_dparams), H.ptr(ws), C.c_uint64(wsb), st))
+                    H.u32(nbat), H.i32(max_level), H.ptr(dL_dparams), H.ptr(ws), C.c_uint64(wsb), st))
     return _cast(dL_ddLdy, dL_dy.dtype), _cast(dL_dparams, params.dtype), _cast(dL_dx, input.dtype)
 
 

@@ -849,16 +849,19 @@ extern "C" int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t N, int x_
 static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N,
                              const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
                              const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
-                             uint32_t batch_data_size, int32_t max_level, void *dL_dparam, void *workspace,
-                             uint64_t workspace_bytes, void *stream) {
+                             uint32_t batch_data_size, uint32_t n_batches, int32_t max_level, void *dL_dparam,
+                             void *workspace, uint64_t workspace_bytes, void *stream) {
 	if (N == 0 || max_level <= -1) return 0;
 	NR3D_CHECK(dL_dy && x && params && dL_dparam, "LoTD::bwd: NULL tensor pointer");
-	// atomic-free binned path: metas without NPlaneSum/CPfast levels and without batching, when the caller supplied the workspace
-	if (workspace && !batch_inds && !batch_offsets && batch_data_size == 0) {
+	// atomic-free binned path: metas without NPlaneSum/CPfast levels, when the caller supplied the workspace (batched
+	// params need n_batches, the number of table sets behind `params`)
+	const bool batched = batch_inds || batch_offsets || batch_data_size;
+	if (workspace && (!batched || n_batches > 0)) {
 		bool handled = false;
+		const Batch bb{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 		if (int rc = dparam_binned(second, meta, meta_dev, N, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
-		                           (const float *)x, (const float *)params, max_level, (float *)dL_dparam, workspace,
-		                           workspace_bytes, (hipStream_t)stream, handled))
+		                           (const float *)x, (const float *)params, bb, batched ? n_batches : 1u, max_level,
+		                           (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled))
 			return rc;
 		if (handled) return 0;
 	}
@@ -883,26 +886,29 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
 extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
                                     int param_dtype, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
                                     const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
-                                    uint32_t batch_data_size, int32_t max_level, void *dL_dparam, void *workspace,
-                                    uint64_t workspace_bytes, void *stream) {
+                                    uint32_t batch_data_size, uint32_t n_batches, int32_t max_level, void *dL_dparam,
+                                    void *workspace, uint64_t workspace_bytes, void *stream) {
 	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
 	return launch_bwd_dparam(false, meta, meta_dev, N, nullptr, dL_dy, g_sn, g_se, x, params, batch_inds,
-	                         batch_offsets, batch_data_size, max_level, dL_dparam, workspace, workspace_bytes, stream);
+	                         batch_offsets, batch_data_size, n_batches, max_level, dL_dparam, workspace, workspace_bytes,
+	                         stream);
 }
 
-extern "C" uint64_t nr3d_lotd_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points) {
-	return dparam_workspace_bytes(meta, n_points);
+extern "C" uint64_t nr3d_lotd_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint32_t n_batches) {
+	return dparam_workspace_bytes(meta, n_points, n_batches);
 }
 
 extern "C" int nr3d_lotd_bwd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
                                         int param_dtype, const void *dL_ddLdx, const void *dL_dy, int64_t g_sn,
                                         int64_t g_se, const void *x, const void *params, const int64_t *batch_inds,
-                                        const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
-                                        void *dL_dparam, void *workspace, uint64_t workspace_bytes, void *stream) {
+                                        const int64_t *batch_offsets, uint32_t batch_data_size, uint32_t n_batches,
+                                        int32_t max_level, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
+                                        void *stream) {
 	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
 	NR3D_CHECK(N == 0 || dL_ddLdx != nullptr, "LoTD::bwd_bwd_input: dL_ddLdx is NULL");
 	return launch_bwd_dparam(true, meta, meta_dev, N, dL_ddLdx, dL_dy, g_sn, g_se, x, params, batch_inds,
-	                         batch_offsets, batch_data_size, max_level, dL_dparam, workspace, workspace_bytes, stream);
+	                         batch_offsets, batch_data_size, n_batches, max_level, dL_dparam, workspace, workspace_bytes,
+	                         stream);
 }
 
 extern "C" int nr3d_lotd_bwd_bwd_ddLdy(const nr3d_lotd_meta_t *meta, uint32_t N, int x_dtype, int param_dtype,

@@ -67,6 +67,7 @@ struct BinPlan {
 	uint32_t n_blk;                       // stage-A workgroups along the points of the current chunk
 	uint32_t n_pseudo;                    // pseudo levels in this plan
 	uint32_t cap;                         // records per slot = stage-A points per workgroup x NR
+	uint32_t n_batches;                   // batched params: a level's entry space is n_batches x level size (else 1)
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -246,7 +247,8 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
                                                            int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                            const float *__restrict__ vin_, const float *__restrict__ g,
                                                            int64_t g_sn, int64_t g_se, const float *__restrict__ params,
-                                                           uint32_t *__restrict__ rec, uint32_t *__restrict__ offs_g) {
+                                                           Batch ba, uint32_t *__restrict__ rec,
+                                                           uint32_t *__restrict__ offs_g) {
 	constexpr int BP = BinCfg<G, NR>::BP;
 	constexpr uint32_t cap = BinCfg<G, NR>::cap;
 	constexpr int C = 1 << D;
@@ -264,7 +266,10 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 	for (uint32_t b = threadIdx.x; b <= nb; b += BP) hist[b] = 0;
 	__syncthreads();
 
-	const bool active = (i < n) && ((int32_t)level <= max_level);
+	// batched params (one table set per batch entry): the level's entry space becomes [batch entry][entry]
+	uint32_t pbase = 0, bi = 0;
+	const bool in_batch = (i < n) && batch_base_index(ba, i, pbase, bi);
+	const bool active = in_batch && ((int32_t)level <= max_level);
 	uint32_t ent[NR], rank[NR];
 	float val[NR][G];
 	uint32_t n_rec = 0;
@@ -294,10 +299,13 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 				w[k] = sum;
 			}
 		}
-		n_rec = emit_updates<D, G, NR, DH>(L, c, w, grad, params + L.off, meta_cnt_of(md, q) * G, ent, val);
+		n_rec = emit_updates<D, G, NR, DH>(L, c, w, grad, params + (pbase + L.off), meta_cnt_of(md, q) * G, ent, val);
 #pragma unroll
 		for (uint32_t r = 0; r < (uint32_t)NR; ++r)
-			if (r < n_rec) rank[r] = atomicAdd(&hist[ent[r] >> plan.epb_log2], 1u);
+			if (r < n_rec) {
+				ent[r] += bi * L.size;
+				rank[r] = atomicAdd(&hist[ent[r] >> plan.epb_log2], 1u);
+			}
 	}
 	__syncthreads();
 
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
                                                        const uint32_t *__restrict__ rec,
                                                        const uint32_t *__restrict__ offs_g,
                                                        const uint32_t *__restrict__ rep_g,
-                                                       const uint32_t *__restrict__ item_start,
+                                                       const uint32_t *__restrict__ item_start, Batch ba,
                                                        float *__restrict__ dparam) {
 	// accumulators are feature-major (acc[f][entry]): the G atomics of a record spread over all LDS banks
 	extern __shared__ __attribute__((aligned(16))) double acc[];      // [kLdsDoubles]
@@ -505,8 +513,8 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 
 	// flush: batches of kFlush read-modify-writes per thread, all loads issued before the first store (the compiler
 	// cannot hoist them itself: dparam may alias itself across iterations)
-	float *dst = dparam + L.off;
 	constexpr int kFlush = 8;
+	const uint32_t n_virtual = plan.n_batches * L.size;     // entries of this level over all batch entries
 	for (uint32_t tb = threadIdx.x; tb < epb * G; tb += kAccThreads * kFlush) {
 		float *p[kFlush];
 		float v[kFlush], old[kFlush];
@@ -514,9 +522,15 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 		for (int k = 0; k < kFlush; ++k) {
 			const uint32_t t = tb + (uint32_t)k * kAccThreads;
 			const uint32_t el = t / G, f = t - el * G;
-			const uint32_t entry = b * epb + el;
-			const bool in = (t < epb * G) && (entry < L.size);
-			p[k] = in ? dst + ((size_t)entry * L.F + foff0 + f) : nullptr;
+			const uint32_t ev = b * epb + el;
+			const bool in = (t < epb * G) && (ev < n_virtual);
+			uint32_t entry = ev, pbase = 0;
+			if (in && (plan.n_batches > 1 || ba.offsets)) {
+				const uint32_t bi = ev / L.size;
+				entry = ev - bi * L.size;
+				pbase = ba.offsets ? (uint32_t)ba.offsets[bi] : bi * ba.n_params;
+			}
+			p[k] = in ? dparam + (pbase + L.off) + ((size_t)entry * L.F + foff0 + f) : nullptr;
 			v[k] = in ? (float)acc[f * epb + el] : 0.0f;
 		}
 		if (R == 1) {                              // this workgroup is the only writer of the slice
@@ -545,7 +559,8 @@ static uint32_t chunk_points(uint32_t n) {
 }
 
 // plan for the pseudo levels of record class `cls` (0 levels => n_pseudo == 0)
-static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t cls, BinPlan &plan, uint64_t &offs_words) {
+static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, uint32_t cls, BinPlan &plan,
+                      uint64_t &offs_words) {
 	const uint32_t D = m->n_dims_to_encode, G = m->n_feat_per_pseudo_lvl;
 	const uint32_t kBinPts = bin_points(G, cls);
 	if (m->n_pseudo_levels > kMaxPlanLevels) return false;
@@ -554,12 +569,15 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t cls,
 	plan.epb_log2 = lg;
 	plan.n_blk = div_up(n_chunk, kBinPts);
 	plan.cap = kBinPts * cls;
+	plan.n_batches = n_batches ? n_batches : 1u;
 	uint32_t nq = 0;
 	uint64_t base = 0;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
 		if (rec_class(rec_count(L.type, D)) != cls) continue;
-		const uint32_t nb = div_up(L.size, 1u << lg);
+		const uint64_t n_virtual = (uint64_t)plan.n_batches * L.size;
+		if (n_virtual > 0xFFFFFFFFull) return false;
+		const uint32_t nb = div_up(n_virtual, 1u << lg);
 		if (nb > kMaxBuckets) return false;
 		plan.qmap[nq] = q;
 		plan.nb[nq] = nb;
@@ -588,12 +606,12 @@ constexpr uint32_t kClasses[3] = {8, 16, 24};
 struct BinLayout { uint64_t rec_bytes, offs_bytes, plan_bytes, gt_bytes, total; };
 
 // workspace = max over the record classes (they run one after another) of records + offsets, + the transposed dL/dy
-static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinLayout &l) {
+static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, BinLayout &l) {
 	l.rec_bytes = l.offs_bytes = l.plan_bytes = 0;
 	for (uint32_t cls : kClasses) {
 		BinPlan plan;
 		uint64_t ow;
-		if (!make_plan(m, n_chunk, cls, plan, ow)) return false;
+		if (!make_plan(m, n_chunk, n_batches, cls, plan, ow)) return false;
 		const uint64_t rb = (uint64_t)plan.n_pseudo * plan.n_blk * (1 + m->n_feat_per_pseudo_lvl) * plan.cap * 4;
 		const uint64_t ob = ((ow * 4 + 255) / 256) * 256;
 		l.rec_bytes = rb > l.rec_bytes ? rb : l.rec_bytes;
@@ -608,18 +626,18 @@ static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, BinLayout &l) {
 }
 
 // returns 0 when the binned path does not apply (caller falls back to the atomic kernels)
-uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points) {
+uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches) {
 	if (!m || n_points == 0 || !binnable(m)) return 0;
 	BinLayout lay;
-	if (!layout(m, chunk_points(n_points), lay)) return 0;
+	if (!layout(m, chunk_points(n_points), n_batches, lay)) return 0;
 	return lay.total;
 }
 
 template <int D, int G, int NR, bool DH>
 static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
                         int32_t max_level, const float *xc, const float *vc, const float *gc, int64_t sn, int64_t se,
-                        const float *params, uint32_t *rec, uint32_t *offs, uint32_t *plan_buf, float *dparam,
-                        hipStream_t st) {
+                        const float *params, const Batch &ba, uint32_t *rec, uint32_t *offs, uint32_t *plan_buf,
+                        float *dparam, hipStream_t st) {
 	constexpr int BP = BinCfg<G, NR>::BP;
 	uint32_t nb_max = 0;
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
@@ -635,26 +653,27 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	}
 	if (second)
 		hipLaunchKernelGGL((k_bin<D, G, true, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
-		                   meta->interpolation_type, xc, vc, gc, sn, se, params, rec, offs);
+		                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, rec, offs);
 	else
 		hipLaunchKernelGGL((k_bin<D, G, false, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
-		                   meta->interpolation_type, xc, vc, gc, sn, se, params, rec, offs);
+		                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, rec, offs);
 	hipLaunchKernelGGL(k_bucket_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
 	hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, NB, pl.n_blk, tot, rep, item_start);
 	// sum of replicas <= 1024 (rounded shares of the total) + one per non-empty bucket
 	hipLaunchKernelGGL((k_accum<D, G>), dim3(1024 + NB), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs, rep,
-	                   item_start, dparam);
+	                   item_start, ba, dparam);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
 
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
-                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, int32_t max_level,
-                  float *dparam, void *workspace, uint64_t workspace_bytes, hipStream_t st, bool &handled) {
+                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
+                  uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
+                  hipStream_t st, bool &handled) {
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
-	if (!workspace || !binnable(meta) || !layout(meta, nc, lay)) return 0;
+	if (!workspace || !binnable(meta) || !layout(meta, nc, n_batches, lay)) return 0;
 	if (workspace_bytes < lay.total) return 0;
 	handled = true;
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
@@ -671,6 +690,9 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		const float *vc = dL_ddLdx ? dL_ddLdx + (size_t)p0 * D : nullptr;
 		const float *gc = dL_dy + (int64_t)p0 * g_sn;
 		int64_t sn = g_sn, se = g_se;
+		Batch ba = batch;                              // this chunk's view of the batch description
+		if (ba.inds) ba.inds += p0;
+		ba.first_point = p0;
 		if (row_major) {
 			hipLaunchKernelGGL(k_transpose, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, gc, g_sn, g_se, gt);
 			gc = gt; sn = 1; se = (int64_t)n;
@@ -678,20 +700,20 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		for (uint32_t cls : kClasses) {
 			BinPlan pl;
 			uint64_t ow;
-			make_plan(meta, n, cls, pl, ow);
+			make_plan(meta, n, n_batches, cls, pl, ow);
 			if (pl.n_pseudo == 0) continue;
 			int rc = 0;
 			// only the (D, class) pairs some level type can produce are instantiated
 			DISPATCH_DG_BIN(D, G, {
 				// hash-only metas (every level Dense or Hash) get kernels without the product-type code
 				if (meta->c_hash_only) {
-					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
-					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
-				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
+					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
+					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
+				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
 				else if (cls == 16) {
-					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
+					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
 				} else {
-					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, rec, offs, plan_buf, dparam, st);
+					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
 				}
 			});
 			if (rc) return rc;

@@ -70,6 +70,7 @@ struct Batch {
 	const int64_t *offsets;
 	uint32_t data_size;
 	uint32_t n_params;
+	uint32_t first_point = 0;   // index of point 0 of this launch inside the caller's batch (chunked launches)
 };
 
 // returns false when the point is skipped (batch index < 0); base = element offset of the batch entry
@@ -81,6 +82,20 @@ __device__ __forceinline__ bool batch_base(const Batch &b, uint32_t i, uint32_t 
 		bi = (uint32_t)v;
 	} else if (b.data_size) {
 		bi = i / b.data_size;
+	}
+	base = b.offsets ? (uint32_t)b.offsets[bi] : bi * b.n_params;
+	return true;
+}
+
+// same, also returning the batch entry index
+__device__ __forceinline__ bool batch_base_index(const Batch &b, uint32_t i, uint32_t &base, uint32_t &bi) {
+	bi = 0;
+	if (b.inds) {
+		const int64_t v = b.inds[i];
+		if (v < 0) return false;
+		bi = (uint32_t)v;
+	} else if (b.data_size) {
+		bi = (b.first_point + i) / b.data_size;
 	}
 	base = b.offsets ? (uint32_t)b.offsets[bi] : bi * b.n_params;
 	return true;
@@ -493,10 +508,11 @@ __device__ __forceinline__ float corner_dot(const Lvl &L, const float *__restric
 }
 
 // lotd_bin.hip: atomic-free parameter-gradient path (all level types but NPlaneSum/CPfast, no batching)
-uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points);
+uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches);
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
-                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, int32_t max_level,
-                  float *dparam, void *workspace, uint64_t workspace_bytes, hipStream_t st, bool &handled);
+                  const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
+                  uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
+                  hipStream_t st, bool &handled);
 
 }  // namespace lotd
 }  // namespace nr3d

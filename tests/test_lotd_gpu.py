@@ -129,6 +129,7 @@ def test_batched_and_max_level(oracle, dev, case):
     bi = rng.integers(-1, B, x.shape[0]).astype(np.int64)       # -1 => skipped point
     bo = (np.array([2, 0, 1]) * m.n_params).astype(np.int64)    # permuted batch placement
     bit, bot = torch.from_numpy(bi).to(dev), torch.from_numpy(bo).to(dev)
+    assert _lotd._dparam_workspace(m, x.shape[0], dev, B)[1] > 0      # batched params also scatter atomic-free
     for kw_ref, kw in [
         (dict(batch_inds=bi), dict(batch_inds=bit)),
         (dict(batch_inds=bi, batch_offsets=bo), dict(batch_inds=bit, batch_offsets=bot)),
@@ -144,6 +145,12 @@ def test_batched_and_max_level(oracle, dev, case):
             assert float(y[bit < 0].abs().max()) == 0.0
         _, dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=True, **kw)
         assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw_ref), name="dL_dparam")
+        _lotd.USE_BINNED_DPARAM = False               # the hardware-atomic scatter on the same batched call
+        try:
+            _, dp_a = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=True, **kw)
+        finally:
+            _lotd.USE_BINNED_DPARAM = True
+        assert_close(dp_a, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw_ref), name="dL_dparam (atomic)")
         _, dp2, dx2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, j, need_dLdinput_ddLdoutput=False,
                                               need_dLdinput_dparams=True, need_dLdinput_dinput=True, **kw)
         assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True, **kw_ref), name="2nd dparam")
