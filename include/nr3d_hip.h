@@ -99,8 +99,8 @@ int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t n_points, int x_dtyp
 /* lod_bwd, parameter-gradient half (kernel_lod[_hashonly]_backward_grid, lotd_encoding.h:467-711,
  * lotd_hash_only.h:380-470).  dL_dparam: params dtype, same numel as params, ZERO-INIT by caller.
  * workspace: optional device scratch of >= nr3d_lotd_dparam_workspace_bytes() bytes; when given (and the meta has
- * no NPlaneSum / CPfast level) the scatter runs atomic-free (binned records + fp64 LDS accumulation); otherwise
- * (NULL / too small / those level types) hardware f32 atomics are used.
+ * no 4-D NPlaneMul / NPlaneSum level) the scatter runs atomic-free (binned records + fp64 LDS accumulation); otherwise
+ * (NULL / too small / those levels) hardware f32 atomics are used.
  * n_batches: number of table sets behind `params` when batch_inds / batch_offsets / batch_data_size are used (the
  * reference derives it from params.numel(); 0 = unknown -> batched calls take the atomic path); 0 or 1 otherwise. */
 uint64_t nr3d_lotd_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint32_t n_batches);

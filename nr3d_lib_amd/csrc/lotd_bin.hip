@@ -44,12 +44,13 @@ constexpr uint32_t kMaxBuckets = 8192;    // per pseudo level
 
 // Record classes: NR = capacity in records per (point, pseudo level).  Updates that hit the same table entry from
 // several corners of one point are summed in registers first (CP: 2 entries per line, VM: 4 per plane + 2 per line...).
-//   Dense/Hash 2^D | CP 2D | VecZMatXoY 4 + 2 | NPlaneMul D * 2^(D-1) | VM 3 * (4 + 2) = 18
-// NPlaneSum / CPfast (and NPlaneMul in 4-D) are not binned: such metas use the atomic kernels.
+//   Dense/Hash 2^D | CP, CPfast 2D | VecZMatXoY 4 + 2 | NPlaneMul D * 2^(D-1) | NPlaneSum (3-D) 3 * 4 | VM 3 * (4 + 2) = 18
+// NPlaneMul / NPlaneSum in 4-D are not binned: such metas use the atomic kernels.
 __host__ __device__ inline uint32_t rec_count(uint32_t type, uint32_t D) {
 	switch (type) {
 	case NR3D_LOD_Dense: case NR3D_LOD_Hash: return 1u << D;
-	case NR3D_LOD_CP: return 2u * D;
+	case NR3D_LOD_CP: case NR3D_LOD_CPfast: return 2u * D;
+	case NR3D_LOD_NPlaneSum: return D == 3 ? 12u : 0u;
 	case NR3D_LOD_VecZMatXoY: return D == 3 ? 6u : 0u;
 	case NR3D_LOD_NPlaneMul: return D <= 3 ? D << (D - 1) : 0u;
 	case NR3D_LOD_VectorMatrix: return D == 3 ? 18u : 0u;
@@ -212,8 +213,108 @@ __device__ __forceinline__ uint32_t emit_plane_line(const Lvl &L, const Cell<3> 
 // (first order: the interpolation weight; second order: the combined d/dx weight), `grad` = dL/dy of the G features,
 // `grid` = params + level offset, `foff` = first feature of this pseudo level inside the level's entries.
 // Same per-update arithmetic as corner_scatter() (lotd_device.h); contributions to one entry are added in corner order.
-template <int D, int G, int NR, bool DH>
+// CPfast: y = prod_d lerp(line_d) evaluated per line, not per corner (lotd_encoding.h:653-705, second order :970-1038);
+// same arithmetic as k_bwd_dparam's CPfast branch, one record per line entry.
+template <int D, int G, int NR, bool SECOND>
+__device__ __forceinline__ uint32_t emit_cpfast(const Lvl &L, const Cell<D> &c, const float (&grad)[G], const float (&vin)[D],
+                                                const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
+                                                float (&val)[NR][G]) {
+	float lv[D][2][G];
+#pragma unroll
+	for (int d = 0; d < D; ++d)
+#pragma unroll
+		for (uint32_t sl = 0; sl < 2; ++sl) {
+			const uint32_t e = entry_line<D>(L, d, c.g[d] + sl);
+			ent[2 * d + sl] = e;
+#pragma unroll
+			for (int f = 0; f < G; ++f) lv[d][sl][f] = grid[e * L.F + foff + f];
+		}
+#pragma unroll
+	for (int ld = 0; ld < D; ++ld)
+#pragma unroll
+		for (int f = 0; f < G; ++f) {
+			if (!SECOND) {
+				float gl = grad[f];
+#pragma unroll
+				for (int d = 0; d < D; ++d)
+					if (d != ld) gl *= __fmaf_rn(c.w[d], lv[d][1][f], (1.0f - c.w[d]) * lv[d][0][f]);
+				val[2 * ld][f] = gl * (1.0f - c.w[ld]);
+				val[2 * ld + 1][f] = gl * c.w[ld];
+			} else {
+				float acc_l = 0.0f, acc_r = 0.0f;
+#pragma unroll
+				for (int gd = 0; gd < D; ++gd) {
+					float gl = grad[f] * c.sc[gd] * vin[gd] * c.dw[gd];
+					const float wl = (ld != gd) ? (1.0f - c.w[ld]) : -1.0f;
+					const float wr = (ld != gd) ? c.w[ld] : 1.0f;
+#pragma unroll
+					for (int d = 0; d < D; ++d) {
+						if (d == ld) continue;
+						const float nl = (d != gd) ? (1.0f - c.w[d]) : -1.0f;
+						const float nr = (d != gd) ? c.w[d] : 1.0f;
+						gl *= __fmaf_rn(nr, lv[d][1][f], nl * lv[d][0][f]);
+					}
+					acc_l = __fmaf_rn(gl, wl, acc_l);
+					acc_r = __fmaf_rn(gl, wr, acc_r);
+				}
+				val[2 * ld][f] = acc_l;
+				val[2 * ld + 1][f] = acc_r;
+			}
+		}
+	return 2u * D;
+}
+
+// NPlaneSum (3-D): sum over the 3 axis planes of a bilinear interpolation; one record per plane corner
+// (same weights as k_bwd_dparam's NPlaneSum branch, reference lotd_encoding.h:268-351 and its backward).
+template <int G, int NR, bool SECOND>
+__device__ __forceinline__ uint32_t emit_nplane_sum(const Lvl &L, const Cell<3> &c, const float (&grad)[G], const float (&a)[3],
+                                                    uint32_t (&ent)[NR], float (&val)[NR][G]) {
+	constexpr int D = 3;
+#pragma unroll
+	for (uint32_t jd = 0; jd < 3; ++jd)
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			uint32_t pp[D];
+#pragma unroll
+			for (int d2 = 0; d2 < D - 1; ++d2) {
+				const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+				pp[d2] = c.g[d3] + ((k >> d2) & 1u);
+			}
+			float w;
+			if (!SECOND) {
+				w = 1.0f;
+#pragma unroll
+				for (int d2 = 0; d2 < D - 1; ++d2) {
+					const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+					w *= ((k >> d2) & 1u) ? c.w[d3] : (1.0f - c.w[d3]);
+				}
+			} else {
+				w = 0.0f;
+#pragma unroll
+				for (int g2 = 0; g2 < D - 1; ++g2) {
+					const int g3 = (uint32_t)g2 >= jd ? g2 + 1 : g2;
+					float t = 0.0f;
+#pragma unroll
+					for (int d = 0; d < D; ++d) if (d == g3) t = a[d];
+#pragma unroll
+					for (int d2 = 0; d2 < D - 1; ++d2) {
+						if (d2 == g2) continue;
+						const int d3 = (uint32_t)d2 >= jd ? d2 + 1 : d2;
+						t *= ((k >> d2) & 1u) ? c.w[d3] : (1.0f - c.w[d3]);
+					}
+					w += ((k >> g2) & 1u) ? t : -t;
+				}
+			}
+			ent[jd * 4 + k] = entry_nplane_sum<D>(L, jd, pp);
+#pragma unroll
+			for (int f = 0; f < G; ++f) val[jd * 4 + k][f] = grad[f] * w;
+		}
+	return 12u;
+}
+
+template <int D, int G, int NR, bool DH, bool SECOND>
 __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c, const float (&w)[1 << D], const float (&grad)[G],
+                                                 const float (&a)[D], const float (&vin)[D],
                                                  const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
                                                  float (&val)[NR][G]) {
 	constexpr uint32_t C = 1u << D;
@@ -238,6 +339,10 @@ __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c,
 		if constexpr (!DH && D == 3 && NR >= 18) return emit_plane_line<G, NR, true>(L, c, w, grad, grid, foff, ent, val);
 	} else if (L.type == NR3D_LOD_VecZMatXoY) {
 		if constexpr (!DH && D == 3 && NR >= 6) return emit_plane_line<G, NR, false>(L, c, w, grad, grid, foff, ent, val);
+	} else if (L.type == NR3D_LOD_CPfast) {
+		if constexpr (!DH && NR >= 2 * D) return emit_cpfast<D, G, NR, SECOND>(L, c, grad, vin, grid, foff, ent, val);
+	} else if (L.type == NR3D_LOD_NPlaneSum) {
+		if constexpr (!DH && D == 3 && NR >= 12) return emit_nplane_sum<G, NR, SECOND>(L, c, grad, a, ent, val);
 	}
 	return 0;
 }
@@ -282,9 +387,12 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 		float grad[G], w[C];
 #pragma unroll
 		for (int f = 0; f < G; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(q * G + f) * g_se];
-		float a[D];
+		float a[D], vin[D];
 #pragma unroll
-		for (int d = 0; d < D; ++d) a[d] = SECOND ? c.sc[d] * vin_[(size_t)i * D + d] * c.dw[d] : 0.0f;
+		for (int d = 0; d < D; ++d) {
+			vin[d] = SECOND ? vin_[(size_t)i * D + d] : 0.0f;
+			a[d] = SECOND ? c.sc[d] * vin[d] * c.dw[d] : 0.0f;
+		}
 #pragma unroll
 		for (uint32_t k = 0; k < (uint32_t)C; ++k) {
 			if (!SECOND) {
@@ -299,7 +407,7 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 				w[k] = sum;
 			}
 		}
-		n_rec = emit_updates<D, G, NR, DH>(L, c, w, grad, params + (pbase + L.off), meta_cnt_of(md, q) * G, ent, val);
+		n_rec = emit_updates<D, G, NR, DH, SECOND>(L, c, w, grad, a, vin, params + (pbase + L.off), meta_cnt_of(md, q) * G, ent, val);
 #pragma unroll
 		for (uint32_t r = 0; r < (uint32_t)NR; ++r)
 			if (r < n_rec) {
