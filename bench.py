@@ -195,7 +195,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("NR3D_BENCH_FORCE_DIST") == "1":   # the latter: exercise the RCCL plumbing on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
