@@ -43,7 +43,8 @@ def algorithmic_bytes_per_point(L, F, D=3, C=8):
 
 
 # kernels behind each timed op (names as rocprofv3 prints them, template arguments stripped)
-OP_KERNELS = {"fwd": ["k_fwd"], "bwd": ["k_contract_dx_rowmajor", "k_bin", "k_accum"]}
+OP_KERNELS = {"fwd": ["k_fwd<3, 2, true, true>"],
+              "bwd": ["k_contract_dx_rowmajor<3>", "k_bin<3, 2, false, 8, true>", "k_accum<3, 2>"]}
 
 
 def pmc_traffic_bytes(op):
@@ -59,8 +60,7 @@ def pmc_traffic_bytes(op):
     total, found = 0.0, 0
     for want in OP_KERNELS[op]:
         for name, ctr in data.items():
-            base = name.split("<")[0].split("::")[-1].replace("void ", "").strip()
-            if base == want and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+            if name.endswith("::" + want) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
                 total += (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
                 found += 1
                 break
