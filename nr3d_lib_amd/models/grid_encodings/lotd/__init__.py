@@ -1,3 +1,4 @@
 from .lotd import *      # noqa: F401,F403
 from .lotd_cfg import *  # noqa: F401,F403
 from .lotd_encoding import *  # noqa: F401,F403
+from .lotd_batched import *  # noqa: F401,F403

@@ -273,3 +273,42 @@ def test_lotd_encoding_module(oracle, dev):
     assert_close(y3, oracle.lotd_fwd(m_ref, x01, p, max_level=2)[0], name="max_level")
     enc.max_level, enc.window = None, torch.linspace(0, 1, enc.out_features, device=dev)
     assert_close(enc(xt), y_ref * np.linspace(0, 1, enc.out_features, dtype=np.float32), name="window")
+
+
+def test_lotd_batched_module(oracle, dev):
+    """LoTDBatched: grower -> per-batch tables; batched inputs and flat inputs + bidx; gradients reach the grower"""
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTDBatched
+    D, res, nf, types, T, smooth = LOTD_CASES["mixed_smooth"]
+    cfg = dict(lod_res=res, lod_n_feats=nf, lod_types=types, hashmap_size=T, use_smooth_step=smooth)
+    m_ref = oracle.lotd_create_meta(D, res, nf, types, T, smooth)
+    n_params, B, zdim = m_ref.as_dict()["n_params"], 3, 5
+    torch.manual_seed(2)
+    grower = torch.nn.Linear(zdim, n_params).to(dev)
+    enc = LoTDBatched(3, lotd_cfg=cfg, grower=grower, device=dev)
+    z = torch.randn(B, zdim, device=dev)
+    enc.grow(z)
+    p = enc.lod_params.detach().cpu().numpy()
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-0.99, 0.99, (B, 700, 3)).astype(np.float32)
+    x01 = (x / np.float32(2) + np.float32(0.5)).reshape(-1, 3)
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x01, p, batch_data_size=700, need_dydx=True)
+    xt = torch.from_numpy(x).to(dev)
+    y = enc(xt)
+    assert tuple(y.shape) == (B, 700, enc.out_features)
+    assert_close(y.reshape(-1, enc.out_features), y_ref, name="batched input")
+    bidx = rng.integers(0, B, 1500)
+    xf = rng.uniform(-0.99, 0.99, (1500, 3)).astype(np.float32)
+    yf = enc(torch.from_numpy(xf).to(dev), torch.from_numpy(bidx).to(dev))
+    yf_ref, jf_ref = oracle.lotd_fwd(m_ref, xf / np.float32(2) + np.float32(0.5), p, batch_inds=bidx, need_dydx=True)
+    assert_close(yf, yf_ref, name="flat input + bidx")
+    g = rng.standard_normal(yf_ref.shape).astype(np.float32)
+    yf.backward(torch.from_numpy(g).to(dev))
+    dp_ref = oracle.lotd_bwd_dparam(m_ref, g, xf / np.float32(2) + np.float32(0.5), p, batch_inds=bidx, accum_double=True)
+    # d loss / d grower.weight = (dL/dparams [B, n_params])^T z
+    want_w = dp_ref.reshape(B, n_params).T.astype(np.float64) @ z.cpu().numpy().astype(np.float64)
+    assert_close(grower.weight.grad, want_w.astype(np.float32), rel=1e-4, name="grower weight grad")
+    y2, dy_dx = enc.forward_dydx(torch.from_numpy(xf).to(dev), torch.from_numpy(bidx).to(dev))
+    nablas = enc.backward_dydx(torch.from_numpy(g).to(dev), dy_dx, torch.from_numpy(xf).to(dev), torch.from_numpy(bidx).to(dev))
+    assert_close(nablas, oracle.lotd_bwd_dx(m_ref, g, jf_ref) / 2, name="nablas")
+    enc.clear()
+    assert not hasattr(enc, "lod_params")
