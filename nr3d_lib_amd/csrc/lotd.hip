@@ -289,14 +289,15 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 		}
 	}
 
+	// outputs are written once and not read by this kernel: non-temporal stores keep the level tables in the L2
 #pragma unroll
-	for (int f = 0; f < G; ++f) y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se] = out_y[f];
+	for (int f = 0; f < G; ++f) __builtin_nontemporal_store(out_y[f], &y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se]);
 	if (DYDX) {
 #pragma unroll
 		for (int f = 0; f < G; ++f) {
 			float *dst = dydx + (int64_t)i * d_sn + (int64_t)(out0 + f) * d_se;
 #pragma unroll
-			for (int d = 0; d < D; ++d) dst[d] = out_g[f][d];
+			for (int d = 0; d < D; ++d) __builtin_nontemporal_store(out_g[f][d], &dst[d]);
 		}
 	}
 }
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void k_contract_dx_rowmajor(uint32_t N, uin
 		__syncthreads();
 		if (dL_dy_T && i < N) {      // by-product: the feature-major copy the parameter scatter wants (coalesced rows)
 #pragma unroll 8
-			for (uint32_t e = 0; e < te; ++e) dL_dy_T[(size_t)(e0 + e) * N + i] = tile[e][threadIdx.x];
+			for (uint32_t e = 0; e < te; ++e) __builtin_nontemporal_store(tile[e][threadIdx.x], &dL_dy_T[(size_t)(e0 + e) * N + i]);
 		}
 		if (i < N) {
 			const float *jj = dydx + (int64_t)i * d_sn + (int64_t)e0 * d_se;
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(kBlock) void k_contract_dx_rowmajor(uint32_t N, uin
 				const float g = tile[e][threadIdx.x];
 				const float *j = jj + (int64_t)e * d_se;
 #pragma unroll
-				for (int d = 0; d < D; ++d) acc[d] = __fmaf_rn(g, j[d], acc[d]);
+				for (int d = 0; d < D; ++d) acc[d] = __fmaf_rn(g, __builtin_nontemporal_load(j + d), acc[d]);   // streamed once
 			}
 		}
 		__syncthreads();

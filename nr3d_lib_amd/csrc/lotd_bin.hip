@@ -458,7 +458,13 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 	const uint32_t total = hist[nb];
 	uint4 *dst = reinterpret_cast<uint4 *>(rec + ((size_t)ql * plan.n_blk + blk) * (size_t)(1 + G) * cap);
 	const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-	for (uint32_t v4 = threadIdx.x; v4 < (total * (1 + G) + 3) / 4; v4 += BP) dst[v4] = src[v4];   // tail: <= 3 stale words
+	// written once, read once by the next kernel: non-temporal, so x / dL_dy keep their L2 lines
+	for (uint32_t v4 = threadIdx.x; v4 < (total * (1 + G) + 3) / 4; v4 += BP) {   // tail: <= 3 stale words
+		const uint4 t = src[v4];
+		uint32_t *d = reinterpret_cast<uint32_t *>(dst + v4);
+		__builtin_nontemporal_store(t.x, d); __builtin_nontemporal_store(t.y, d + 1);
+		__builtin_nontemporal_store(t.z, d + 2); __builtin_nontemporal_store(t.w, d + 3);
+	}
 	uint32_t *ob = offs_g + plan.offs_base[ql];
 	for (uint32_t b = threadIdx.x; b <= nb; b += BP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
 }
@@ -604,9 +610,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 					}
 					const uint32_t t = off + lane;
 					const uint32_t *r_p = rec_b + (size_t)(rs[u] + (t < rn[u] ? t : 0u)) * W;
-					idx[u] = r_p[0];
+					idx[u] = __builtin_nontemporal_load(r_p);          // read exactly once: do not keep in L2
 #pragma unroll
-					for (int f = 0; f < G; ++f) val[u][f] = __uint_as_float(r_p[1 + f]);
+					for (int f = 0; f < G; ++f) val[u][f] = __uint_as_float(__builtin_nontemporal_load(r_p + 1 + f));
 				}
 #pragma unroll
 				for (int u = 0; u < kUnroll; ++u)
