@@ -1,0 +1,235 @@
+"""NeuS ray query with multi-stage up-sampling on occupancy-grid marched samples (StreetSurf sec. 4.1).
+
+Counterpart of ``neus_ray_query_march_occ_multi_upsample`` (nr3d_lib/graphics/neus/neus_ray_query.py:358-729): same
+signature, ``ray_tested`` keys, model protocol (``forward``, ``forward_sdf``, ``forward_inv_s``, ``accel``; the
+``use_*`` / ``fwd_sdf_use_*`` attribute flags) and the four result shapes -- batched buffer of the fine samples
+(``num_coarse == 0``), packed buffer of coarse + fine samples, batched coarse-only buffer when nothing is hit, empty.
+The up-sampling loop is where the secondary pack ops run end to end on the device: SDF at the marched samples ->
+opacity -> ``packed_alpha_to_vw`` -> exclusive ``packed_cumsum`` normalised with ``packed_div`` -> ``packed_sample_cdf``
+(``packed_invert_cdf``) -> ``merge_two_packs_sorted_aligned`` of the new depths into the packed buffer, once per
+``upsample_inv_s_factors`` entry; ``merge_two_batch_a_includes_b`` joins coarse and fine samples.
+(The reference reads ``marched.ridx_hitx`` at :470, an attribute its records do not have; ``ridx_hit`` is used here.)"""
+from typing import Dict, List, Tuple
+
+import torch
+
+from nr3d_lib_amd.graphics.nerf.nerf_utils import packed_alpha_to_vw
+from nr3d_lib_amd.graphics.neus.neus_utils import (neus_packed_sdf_to_alpha, neus_packed_sdf_to_upsample_alpha,
+                                                   neus_ray_sdf_to_alpha)
+from nr3d_lib_amd.graphics.pack_ops import (get_pack_infos_from_batch, merge_two_batch_a_includes_b,
+                                            merge_two_packs_sorted_aligned, packed_cumsum, packed_diff, packed_div)
+from nr3d_lib_amd.graphics.raysample import (batch_sample_step_linear, batch_sample_step_wrt_depth,
+                                             batch_sample_step_wrt_sqrt_depth, packed_sample_cdf)
+from nr3d_lib_amd.profile import profile
+
+__all__ = ['neus_ray_query_march_occ_multi_upsample']
+
+_RAY_ATTRS = (('ts', 'rays_ts'), ('fidx', 'rays_fidx'), ('bidx', 'rays_bidx'), ('pix', 'rays_pix'),
+              ('h_appear', 'rays_h_appear'))
+_COARSE_SAMPLERS = dict(linear=batch_sample_step_linear, depth=batch_sample_step_wrt_depth,
+                        sqrt_depth=batch_sample_step_wrt_sqrt_depth)
+
+
+def _flag(model, name):
+    return bool(getattr(model, name, False))
+
+
+def _chunked(fn, kwargs: dict, chunk: int) -> torch.Tensor:
+    """fn(**kwargs) evaluated on slices of at most `chunk` rows (every tensor argument is sliced along dim 0)"""
+    n = next(iter(kwargs.values())).shape[0]
+    if n <= chunk:
+        return fn(**kwargs)
+    return torch.cat([fn(**{k: v[i:i + chunk] for k, v in kwargs.items()}) for i in range(0, n, chunk)], 0)
+
+
+def _march(model, ray_tested, rays_o, rays_d, near, far, perturb, march_cfg):
+    accel = model.accel
+    if hasattr(accel, 'cur_batch__ray_march'):
+        extra = [ray_tested['rays_bidx']] + ([ray_tested['rays_ts']] if getattr(accel, 'is_dynamic', False) else [])
+        return accel.cur_batch__ray_march(rays_o, rays_d, *extra, near=near, far=far, perturb=perturb, **march_cfg)
+    if getattr(accel, 'is_dynamic', False):
+        return accel.ray_march(rays_o, rays_d, ray_tested['rays_ts'], near=near, far=far, perturb=perturb, **march_cfg)
+    return accel.ray_march(rays_o, rays_d, near=near, far=far, perturb=perturb, **march_cfg)
+
+
+def neus_ray_query_march_occ_multi_upsample(
+        model, ray_tested: Dict[str, torch.Tensor],
+        with_rgb: bool = True, with_normal: bool = True, perturb: bool = False, nablas_has_grad: bool = False,
+        forward_inv_s: float = None,
+        num_coarse: int = 0, coarse_step_cfg=dict(step_mode='linear'), chunksize_query: int = 2 ** 24, march_cfg=dict(),
+        num_fine: int = 8, upsample_inv_s: float = 64., upsample_s_divisor: float = 1.0,
+        upsample_inv_s_factors: List[int] = [1, 4, 16], upsample_use_estimate_alpha=False,
+        debug_query_data: dict = None) -> Tuple[dict, dict]:
+    for need in ('forward', 'forward_sdf', 'forward_inv_s'):
+        assert hasattr(model, need), f"model.{need}() is requried"
+    assert getattr(model, 'accel', None) is not None, "model.accel is required"
+
+    sdf_uses = {k: _flag(model, 'use_' + k) if k in ('ts', 'fidx', 'bidx') else _flag(model, 'fwd_sdf_use_' + k)
+                for k, _ in _RAY_ATTRS}
+    full_uses = {k: sdf_uses[k] or (_flag(model, 'use_' + k) and with_rgb) for k, _ in _RAY_ATTRS}
+    sdf_view = _flag(model, 'fwd_sdf_use_view_dirs')
+    full_view = sdf_view or (_flag(model, 'use_view_dirs') and with_rgb)
+
+    empty = dict(type='empty', rays_inds_hit=[])
+    if ray_tested['num_rays'] == 0:
+        return empty, {}
+    n_stages = len(upsample_inv_s_factors)
+    num_fine = [num_fine] * n_stages if isinstance(num_fine, int) else list(num_fine)
+    assert len(num_fine) == n_stages, f"num_fine should be of the same length={n_stages} with upsample"
+    num_fine = [n // 2 * 2 + 1 for n in num_fine]                       # odd counts: a sample at the median
+    upsample_inv_s = upsample_inv_s / upsample_s_divisor
+    forward_inv_s = model.forward_inv_s() if forward_inv_s is None else forward_inv_s
+
+    rays_o, rays_d = ray_tested['rays_o'], ray_tested['rays_d']
+    near, far, rays_inds = ray_tested['near'], ray_tested['far'], ray_tested['rays_inds']
+    assert rays_o.dim() == 2 and rays_d.dim() == 2
+    device, dtype = rays_o.device, rays_o.dtype
+    view_dirs = rays_d / rays_d.detach().norm(dim=-1, keepdim=True).clamp_min(1.0e-10) if full_view else None
+
+    def attrs(uses, use_view, pick):
+        """per-ray extras of the model query; `pick` maps a [num_rays, ...] tensor to the layout of the query points"""
+        kw = {k: pick(ray_tested[src]) for k, src in _RAY_ATTRS if uses[k]}
+        if use_view:
+            kw['v'] = pick(view_dirs)
+        return kw
+
+    def spread(sel, *shape):
+        """pick for points laid out as [len(sel), *shape]: the ray's value repeated over its samples"""
+        def pick(t):
+            t = t if sel is None else t[sel]
+            return t.reshape(t.shape[0], *([1] * len(shape)), *t.shape[1:]).expand(t.shape[0], *shape, *t.shape[1:]).contiguous()
+        return pick
+
+    def query_sdf(x, extra):
+        return model.forward_sdf(x=x, **extra)['sdf']
+
+    def full_query(x, extra):
+        out = model.forward(x=x, nablas_has_grad=nablas_has_grad, with_rgb=with_rgb, with_normal=with_normal, **extra)
+        buf = {'net_x': x}
+        for k in ('nablas', 'rgb'):
+            if k in out:
+                buf[k] = out[k].to(dtype)
+        return buf
+
+    # ---- coarse samples: num_coarse + 1 interval boundaries per ray ---------------------------------------------------
+    if num_coarse > 0:
+        cfg = dict(coarse_step_cfg)
+        mode = cfg.pop('step_mode')
+        if mode not in _COARSE_SAMPLERS:
+            raise RuntimeError(f"Invalid step_mode={mode}")
+        depths_coarse_1, deltas_coarse_1 = _COARSE_SAMPLERS[mode](near, far, num_coarse + 1, perturb=perturb,
+                                                                  return_dt=True, **cfg)
+
+    with profile("Ray marching"):
+        marched = _march(model, ray_tested, rays_o, rays_d, near, far, perturb, march_cfg)
+
+    if marched.ridx_hit is None:
+        if num_coarse == 0:
+            return empty, {}
+        # nothing marched: a batched buffer of the coarse samples on every ray
+        with profile("Acquire volume buffer"):
+            pts = lambda d: torch.addcmul(rays_o[..., None, :], rays_d[..., None, :], d[..., None])
+            sdf = query_sdf(pts(depths_coarse_1), attrs(sdf_uses, sdf_view, spread(None, num_coarse + 1)))
+            depths = depths_coarse_1[..., :num_coarse] + deltas_coarse_1[..., :num_coarse] / 2.
+            vb = dict(type='batched', rays_inds_hit=rays_inds, num_per_hit=num_coarse, t=depths.to(dtype),
+                      opacity_alpha=neus_ray_sdf_to_alpha(sdf, forward_inv_s).to(dtype))
+            if full_uses['bidx']:
+                vb['rays_bidx_hit'] = ray_tested['rays_bidx']
+            if with_rgb or with_normal:
+                vb.update(full_query(pts(depths), attrs(full_uses, full_view, spread(None, num_coarse))))
+        return vb, {'render.num_per_ray': num_coarse}
+
+    # ---- multi-stage up-sampling on the marched samples (no gradients) -------------------------------------------------
+    hit, n_hit = marched.ridx_hit, marched.num_hit_rays
+    rays_inds_hit = rays_inds[hit]
+    o_hit, d_hit = rays_o[hit].unsqueeze(-2), rays_d[hit].unsqueeze(-2)
+    with profile("Upsampling"), torch.no_grad():
+        pack_infos = marched.pack_infos.clone()
+        depth_samples = marched.depth_samples
+        sdf = _chunked(lambda x, **kw: query_sdf(x, kw),
+                       dict(x=marched.samples, **attrs(sdf_uses, sdf_view, lambda t: t[marched.ridx])), chunksize_query)
+        stage_depths = []
+        for i, factor in enumerate(upsample_inv_s_factors):
+            inv_s = upsample_inv_s * factor
+            alpha = (neus_packed_sdf_to_upsample_alpha(sdf, depth_samples, inv_s, pack_infos) if upsample_use_estimate_alpha
+                     else neus_packed_sdf_to_alpha(sdf, inv_s, pack_infos))
+            cdf = packed_cumsum(packed_alpha_to_vw(alpha, pack_infos), pack_infos, exclusive=True)
+            last = cdf[pack_infos[..., 0] + pack_infos[..., 1] - 1]
+            cdf = packed_div(cdf, last.clamp_min(1e-5), pack_infos)
+            fine = packed_sample_cdf(depth_samples, cdf.to(depth_samples.dtype), pack_infos, num_fine[i], perturb=perturb)[0]
+            stage_depths.append(fine)
+            if n_stages > 1:
+                # the new depths join the packed buffer (sorted merge per ray) for the next, sharper stage
+                pinfo_fine = get_pack_infos_from_batch(n_hit, num_fine[i], device=device)
+                pidx0, pidx1, pack_infos = merge_two_packs_sorted_aligned(depth_samples, pack_infos, fine.flatten(), pinfo_fine,
+                                                                          b_sorted=True, return_val=False)
+                merged = depth_samples.new_empty(depth_samples.numel() + fine.numel())
+                merged[pidx0], merged[pidx1] = depth_samples, fine.flatten()
+                if i < n_stages - 1:
+                    x_fine = torch.addcmul(o_hit, d_hit, fine.unsqueeze(-1)).flatten(0, -2)
+                    extra = {k: v.flatten(0, 1) for k, v in attrs(sdf_uses, sdf_view, spread(hit, num_fine[i])).items()}
+                    sdf_m = sdf.new_empty(merged.numel())
+                    sdf_m[pidx0], sdf_m[pidx1] = sdf, query_sdf(x_fine, extra)
+                    sdf = sdf_m
+                depth_samples = merged
+        if n_stages > 1:
+            order = torch.cat(stage_depths, dim=-1).sort(dim=-1)
+            depths_1 = order.values
+            stage_of = torch.repeat_interleave(1 + torch.arange(n_stages, device=device),
+                                               torch.tensor(num_fine, device=device))
+            upsample_stages = stage_of[order.indices]
+        else:
+            depths_1 = stage_depths[0]
+            upsample_stages = torch.ones_like(depths_1, dtype=torch.long)
+
+    details = {'march.num_per_ray': marched.pack_infos[:, 1]}
+    with profile("Acquire volume buffer"):
+        if num_coarse == 0:
+            # batched buffer: the fine depths are interval boundaries, samples sit at the interval mid-points
+            k1 = depths_1.shape[-1]
+            x1 = torch.addcmul(o_hit, d_hit, depths_1.unsqueeze(-1))
+            extra1 = attrs(sdf_uses, sdf_view, spread(hit, k1))
+            if model.training:
+                sdf = query_sdf(x1, extra1)
+            else:
+                sdf = _chunked(lambda x, **kw: query_sdf(x, kw), dict(x=x1, **extra1), chunksize_query)
+            depths = depths_1[..., :-1] + depths_1.diff(dim=-1) / 2.
+            if debug_query_data is not None:
+                debug_query_data["fine"] = dict(ridx=rays_inds_hit[..., None].expand_as(depths).flatten(),
+                                                depth=depths_1.data.to(dtype).flatten(), sdf=sdf.data.to(dtype).flatten(),
+                                                upsample_stages=upsample_stages.flatten())
+            vb = dict(type='batched', rays_inds_hit=rays_inds_hit, num_per_hit=depths.size(-1), t=depths.to(dtype),
+                      opacity_alpha=neus_ray_sdf_to_alpha(sdf, forward_inv_s).to(dtype))
+            if full_uses['bidx']:
+                vb['rays_bidx_hit'] = ray_tested['rays_bidx'][hit]
+            if with_rgb or with_normal:
+                vb.update(full_query(torch.addcmul(o_hit, d_hit, depths[..., None]),
+                                     attrs(full_uses, full_view, spread(hit, depths.shape[-1]))))
+            details['render.num_per_ray'] = depths.size(-1)
+            return vb, details
+
+        # packed buffer over ALL tested rays: coarse boundaries of every ray + fine depths of the hit rays
+        all_rays = torch.arange(rays_inds.numel(), device=device)
+        pidx0, pidx1, pack_infos = merge_two_batch_a_includes_b(depths_coarse_1, all_rays, depths_1, hit, a_sorted=True)
+        total = depths_1.numel() + depths_coarse_1.numel()
+        depths_1p, stages_p, ridx_all = depths_1.new_zeros(total), upsample_stages.new_zeros(total), hit.new_zeros(total)
+        ridx_all[pidx0], ridx_all[pidx1] = all_rays.unsqueeze(-1), hit.unsqueeze(-1)
+        depths_1p[pidx0], depths_1p[pidx1] = depths_coarse_1, depths_1
+        stages_p[pidx0], stages_p[pidx1] = 0, upsample_stages
+        o_p, d_p = rays_o[ridx_all], rays_d[ridx_all]
+        sdf_p = query_sdf(torch.addcmul(o_p, d_p, depths_1p.unsqueeze(-1)), attrs(sdf_uses, sdf_view, lambda t: t[ridx_all]))
+        depths_p = depths_1p + packed_diff(depths_1p, pack_infos) / 2.
+        if debug_query_data is not None:
+            for name, sel in (("coarse", (stages_p == 0).nonzero(as_tuple=True)[0]),
+                              ("fine", (stages_p > 0).nonzero(as_tuple=True)[0])):
+                debug_query_data[name] = dict(ridx=ridx_all[sel], depth=depths_1p.data.to(dtype)[sel],
+                                              sdf=sdf_p.data.to(dtype)[sel])
+            debug_query_data["fine"]["upsample_stages"] = stages_p[(stages_p > 0).nonzero(as_tuple=True)[0]]
+        vb = dict(type='packed', rays_inds_hit=rays_inds, pack_infos_hit=pack_infos, t=depths_p.to(dtype),
+                  opacity_alpha=neus_packed_sdf_to_alpha(sdf_p, forward_inv_s, pack_infos).to(dtype))
+        if full_uses['bidx']:
+            vb['rays_bidx_hit'] = ray_tested['rays_bidx']
+        if with_rgb or with_normal:
+            vb.update(full_query(torch.addcmul(o_p, d_p, depths_p.unsqueeze(-1)), attrs(full_uses, full_view, lambda t: t[ridx_all])))
+        details['render.num_per_ray'] = pack_infos[:, 1]
+        return vb, details
