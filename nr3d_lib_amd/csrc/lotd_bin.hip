@@ -12,8 +12,8 @@
 //                     {local entry, value[G]} plus the per-bucket start offsets;
 //   stage B  k_accum  one workgroup = one bucket (x an optional replica that takes a share of the point blocks):
 //                     stream that bucket's records (contiguous runs), accumulate into a 128 KiB fp64 LDS table with
-//                     ds_add_f64, then write the slice of dL/dparam once (plain stores; f32 atomics only for the
-//                     few replicated small levels).
+//                     ds_add_f64, then add the slice to dL/dparam once (replicas store fp32 partial tables that
+//                     k_reduce_partials sums in a fixed order: there is no global atomic on this path).
 //
 // Both stages are pure streaming (12 B per corner update written once and read once); the fp64 accumulation makes
 // the result independent of the update order up to the final f64->f32 rounding.
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void k_bucket_totals(BinPlan plan, const uint3
 	if (lane == 0) tot[fb] = sum;
 }
 
-__global__ __launch_bounds__(1024) void k_plan_items(uint32_t NB, uint32_t n_blk, const uint32_t *__restrict__ tot,
+__global__ __launch_bounds__(1024) void k_plan_items(uint32_t NB, uint32_t n_blk, uint32_t n_units, const uint32_t *__restrict__ tot,
                                                      uint32_t *__restrict__ rep, uint32_t *__restrict__ item_start) {
 	__shared__ uint64_t red[16];
 	__shared__ uint64_t carry_s;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(1024) void k_plan_items(uint32_t NB, uint32_t n_blk
 	uint64_t total = 0;
 #pragma unroll
 	for (int w = 0; w < 16; ++w) total += red[w];
-	const uint64_t unit = total / 1024 > 0 ? total / 1024 : 1;
+	const uint64_t unit = total / n_units > 0 ? total / n_units : 1;
 	if (threadIdx.x == 0) carry_s = 0;
 	__syncthreads();
 	for (uint32_t base = 0; base < NB; base += 1024) {
@@ -535,6 +535,25 @@ __global__ __launch_bounds__(1024) void k_plan_items(uint32_t NB, uint32_t n_blk
 	if (threadIdx.x == 0) item_start[NB] = (uint32_t)carry_s;
 }
 
+// where accumulator slot t (= entry el of the bucket, feature f; t = el * G + f) of bucket b lives in dL/dparam;
+// nullptr past the end of the level's (batched) entry space
+template <int G>
+__device__ __forceinline__ float *flush_target(const BinPlan &plan, const Lvl &L, const Batch &ba, uint32_t foff0, uint32_t b,
+                                               uint32_t t, float *__restrict__ dparam, uint32_t &slot) {
+	const uint32_t epb = 1u << plan.epb_log2;
+	const uint32_t el = t / G, f = t - el * G;
+	slot = f * epb + el;                                     // feature-major accumulator / partial layout
+	const uint32_t ev = b * epb + el;
+	if (t >= epb * G || ev >= plan.n_batches * L.size) return nullptr;
+	uint32_t entry = ev, pbase = 0;
+	if (plan.n_batches > 1 || ba.offsets) {
+		const uint32_t bi = ev / L.size;
+		entry = ev - bi * L.size;
+		pbase = ba.offsets ? (uint32_t)ba.offsets[bi] : bi * ba.n_params;
+	}
+	return dparam + (pbase + L.off) + ((size_t)entry * L.F + foff0 + f);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Stage B: one bucket (x replica) -> fp64 LDS accumulation -> slice of dL/dparam
 // -------------------------------------------------------------------------------------------------
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
                                                        const uint32_t *__restrict__ offs_g,
                                                        const uint32_t *__restrict__ rep_g,
                                                        const uint32_t *__restrict__ item_start, Batch ba,
-                                                       float *__restrict__ dparam) {
+                                                       float *__restrict__ partial, float *__restrict__ dparam) {
 	// accumulators are feature-major (acc[f][entry]): the G atomics of a record spread over all LDS banks
 	extern __shared__ __attribute__((aligned(16))) double acc[];      // [kLdsDoubles]
 	const uint32_t cap = plan.cap;
@@ -625,43 +644,73 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 	}
 	__syncthreads();
 
-	// flush: batches of kFlush read-modify-writes per thread, all loads issued before the first store (the compiler
-	// cannot hoist them itself: dparam may alias itself across iterations)
+	// flush.  The only workgroup of a bucket adds its slice to dL/dparam itself (batches of kFlush read-modify-writes,
+	// all loads issued before the first store: the compiler cannot hoist them, dparam may alias itself).  A replica
+	// stores its fp32 partial sums instead (plain coalesced stores); k_reduce_partials adds the replicas of a bucket
+	// in a fixed order -- no global atomic anywhere, and the result does not depend on scheduling.
+	if (R > 1) {
+		float *mine = partial + (size_t)blockIdx.x * kLdsDoubles;
+		for (uint32_t t = threadIdx.x; t < (uint32_t)kLdsDoubles; t += kAccThreads) mine[t] = (float)acc[t];
+		return;
+	}
 	constexpr int kFlush = 8;
-	const uint32_t n_virtual = plan.n_batches * L.size;     // entries of this level over all batch entries
 	for (uint32_t tb = threadIdx.x; tb < epb * G; tb += kAccThreads * kFlush) {
 		float *p[kFlush];
 		float v[kFlush], old[kFlush];
 #pragma unroll
 		for (int k = 0; k < kFlush; ++k) {
-			const uint32_t t = tb + (uint32_t)k * kAccThreads;
-			const uint32_t el = t / G, f = t - el * G;
-			const uint32_t ev = b * epb + el;
-			const bool in = (t < epb * G) && (ev < n_virtual);
-			uint32_t entry = ev, pbase = 0;
-			if (in && (plan.n_batches > 1 || ba.offsets)) {
-				const uint32_t bi = ev / L.size;
-				entry = ev - bi * L.size;
-				pbase = ba.offsets ? (uint32_t)ba.offsets[bi] : bi * ba.n_params;
-			}
-			p[k] = in ? dparam + (pbase + L.off) + ((size_t)entry * L.F + foff0 + f) : nullptr;
-			v[k] = in ? (float)acc[f * epb + el] : 0.0f;
+			uint32_t slot;
+			p[k] = flush_target<G>(plan, L, ba, foff0, b, tb + (uint32_t)k * kAccThreads, dparam, slot);
+			v[k] = p[k] ? (float)acc[slot] : 0.0f;
 		}
-		if (R == 1) {                              // this workgroup is the only writer of the slice
 #pragma unroll
-			for (int k = 0; k < kFlush; ++k) old[k] = p[k] ? *p[k] : 0.0f;
+		for (int k = 0; k < kFlush; ++k) old[k] = p[k] ? *p[k] : 0.0f;
 #pragma unroll
-			for (int k = 0; k < kFlush; ++k) if (p[k]) *p[k] = old[k] + v[k];
-		} else {
-#pragma unroll
-			for (int k = 0; k < kFlush; ++k) if (p[k] && v[k] != 0.0f) atomic_add_f32(p[k], v[k]);
-		}
+		for (int k = 0; k < kFlush; ++k) if (p[k]) *p[k] = old[k] + v[k];
 	}
+}
+
+// one workgroup per replicated bucket: dL/dparam slice += sum of the replicas' partials, replica 0 first
+template <int D, int G>
+__global__ __launch_bounds__(kAccThreads) void k_reduce_partials(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
+                                                                 const uint32_t *__restrict__ rep_g,
+                                                                 const uint32_t *__restrict__ item_start, Batch ba,
+                                                                 const float *__restrict__ partial,
+                                                                 float *__restrict__ dparam) {
+	const uint32_t fb = blockIdx.x;
+	const uint32_t R = rep_g[fb];
+	if (R <= 1) return;
+	uint32_t q = 0;
+	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
+	const uint32_t b = fb - plan.bucket_base[q], qg = plan.qmap[q];
+	const Lvl L = load_level(md, meta_level_of(md, qg));
+	const uint32_t foff0 = meta_cnt_of(md, qg) * G;
+	const float *part0 = partial + (size_t)item_start[fb] * kLdsDoubles;
+	const uint32_t t = blockIdx.y * kAccThreads + threadIdx.x;        // one accumulator slot per thread
+	uint32_t slot;
+	float *p = flush_target<G>(plan, L, ba, foff0, b, t, dparam, slot);
+	if (!p) return;
+	float sum = 0.0f;
+	for (uint32_t r0 = 0; r0 < R; r0 += 8) {                           // 8 independent loads in flight, summed in order
+		float v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = (r0 + k < R) ? part0[(size_t)(r0 + k) * kLdsDoubles + slot] : 0.0f;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) sum += v[k];
+	}
+	*p += sum;
 }
 
 // -------------------------------------------------------------------------------------------------
 // Host side
 // -------------------------------------------------------------------------------------------------
+// target number of stage-B work items (a bucket holding more than total / units records is split into replicas)
+static uint32_t work_units() {
+	static uint32_t u = 0;
+	if (!u) { const char *e = getenv("NR3D_LOTD_ACC_UNITS"); const int v = e ? atoi(e) : 1024; u = (uint32_t)(v < 256 ? 256 : (v > 8192 ? 8192 : v)); }
+	return u;
+}
+
 static uint32_t chunk_points(uint32_t n) {
 	static uint32_t chunk = 0;
 	if (!chunk) {
@@ -717,11 +766,11 @@ static bool binnable(const nr3d_lotd_meta_t *m) {
 
 constexpr uint32_t kClasses[3] = {8, 16, 24};
 
-struct BinLayout { uint64_t rec_bytes, offs_bytes, plan_bytes, gt_bytes, total; };
+struct BinLayout { uint64_t rec_bytes, offs_bytes, plan_bytes, part_bytes, gt_bytes, total; };
 
 // workspace = max over the record classes (they run one after another) of records + offsets, + the transposed dL/dy
 static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, BinLayout &l) {
-	l.rec_bytes = l.offs_bytes = l.plan_bytes = 0;
+	l.rec_bytes = l.offs_bytes = l.plan_bytes = l.part_bytes = 0;
 	for (uint32_t cls : kClasses) {
 		BinPlan plan;
 		uint64_t ow;
@@ -732,10 +781,13 @@ static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batch
 		l.offs_bytes = ob > l.offs_bytes ? ob : l.offs_bytes;
 		const uint64_t pb = (((uint64_t)plan.bucket_base[plan.n_pseudo] * 3 + 4) * 4 + 255) / 256 * 256;   // tot | rep | item_start
 		l.plan_bytes = pb > l.plan_bytes ? pb : l.plan_bytes;
+		// one fp32 partial table per possible stage-B work item (only replicas write theirs)
+		const uint64_t qb = (uint64_t)(work_units() + plan.bucket_base[plan.n_pseudo]) * kLdsDoubles * 4;
+		l.part_bytes = qb > l.part_bytes ? qb : l.part_bytes;
 	}
 	l.rec_bytes = ((l.rec_bytes + 255) / 256) * 256;
 	l.gt_bytes = (((uint64_t)m->n_encoded_dims * n_chunk * 4 + 255) / 256) * 256;
-	l.total = l.rec_bytes + l.offs_bytes + l.plan_bytes + l.gt_bytes;
+	l.total = l.rec_bytes + l.offs_bytes + l.plan_bytes + l.part_bytes + l.gt_bytes;
 	return true;
 }
 
@@ -751,7 +803,7 @@ template <int D, int G, int NR, bool DH>
 static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
                         int32_t max_level, const float *xc, const float *vc, const float *gc, int64_t sn, int64_t se,
                         const float *params, const Batch &ba, uint32_t *rec, uint32_t *offs, uint32_t *plan_buf,
-                        float *dparam, hipStream_t st) {
+                        float *partial, float *dparam, hipStream_t st) {
 	constexpr int BP = BinCfg<G, NR>::BP;
 	uint32_t nb_max = 0;
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
@@ -772,10 +824,11 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 		hipLaunchKernelGGL((k_bin<D, G, false, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
 		                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, rec, offs);
 	hipLaunchKernelGGL(k_bucket_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
-	hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, NB, pl.n_blk, tot, rep, item_start);
+	hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, NB, pl.n_blk, work_units(), tot, rep, item_start);
 	// sum of replicas <= 1024 (rounded shares of the total) + one per non-empty bucket
-	hipLaunchKernelGGL((k_accum<D, G>), dim3(1024 + NB), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs, rep,
-	                   item_start, ba, dparam);
+	hipLaunchKernelGGL((k_accum<D, G>), dim3(work_units() + NB), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs, rep,
+	                   item_start, ba, partial, dparam);
+	hipLaunchKernelGGL((k_reduce_partials<D, G>), dim3(NB, kLdsDoubles / kAccThreads), dim3(kAccThreads), 0, st, pl, md, rep, item_start, ba, partial, dparam);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
@@ -795,7 +848,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	uint32_t *rec = (uint32_t *)workspace;
 	uint32_t *offs = (uint32_t *)((char *)workspace + lay.rec_bytes);
 	uint32_t *plan_buf = (uint32_t *)((char *)workspace + lay.rec_bytes + lay.offs_bytes);
-	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes);
+	float *partial = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes);
+	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes + lay.part_bytes);
 	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && E > 1);
 
 	for (uint32_t p0 = 0; p0 < N; p0 += nc) {
@@ -821,13 +875,13 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			DISPATCH_DG_BIN(D, G, {
 				// hash-only metas (every level Dense or Hash) get kernels without the product-type code
 				if (meta->c_hash_only) {
-					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
-					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
-				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
+					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
+					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
+				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
 				else if (cls == 16) {
-					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
+					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
 				} else {
-					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, dparam, st);
+					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
 				}
 			});
 			if (rc) return rc;
