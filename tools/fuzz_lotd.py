@@ -1,0 +1,32 @@
+import sys, os, numpy as np, torch
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import oracle
+from util import LOTD_CASES, lotd_inputs
+from nr3d_lib_amd.bindings import _lotd
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(0)
+bad = 0
+cases = [c for c in LOTD_CASES if c not in ("cp_4d",)]
+for it in range(60):
+    case = cases[it % len(cases)]
+    D, res, nf, types, T, smooth = LOTD_CASES[case]
+    n = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 511, 513, 1000, 4097, 9999]))
+    m_ref = oracle.lotd_create_meta(D, res, nf, types, T, smooth)
+    m = _lotd.LoDMeta(D, res, nf, types, T, smooth)
+    x, p, g, v = lotd_inputs(m_ref.as_dict(), n, it)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ml = int(rng.integers(-1, m.n_levels + 1)) if it % 5 == 0 else None
+    kw = {} if ml is None else dict(max_level=ml)
+    y, j = _lotd.lod_fwd(m, t(x), t(p), need_input_grad=True, **kw)
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True, **kw)
+    dx, dp = _lotd.lod_bwd(m, t(g), t(x), t(p), j, need_input_grad=True, need_param_grad=True, **kw)
+    dp_ref = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw)
+    _, dp2, dx2 = _lotd.lod_bwd_bwd_input(m, t(v), t(g), t(x), t(p), j, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True, need_dLdinput_dinput=True, **kw)
+    dp2_ref = oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True, **kw)
+    def err(a, b):
+        a = a.cpu().numpy().reshape(b.shape); s = max(np.abs(b).max(), 1e-30); return np.abs(a - b).max() / s
+    es = (err(y, y_ref), err(j, j_ref), err(dp, dp_ref), err(dp2, dp2_ref))
+    ok = all(e <= 1e-5 for e in es)
+    bad += not ok
+    if not ok: print("MISMATCH", case, n, ml, es)
+print("fuzz done, mismatches:", bad)
