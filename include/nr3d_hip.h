@@ -104,6 +104,9 @@ int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t n_points, int x_dtyp
  * n_batches: number of table sets behind `params` when batch_inds / batch_offsets / batch_data_size are used (the
  * reference derives it from params.numel(); 0 = unknown -> batched calls take the atomic path); 0 or 1 otherwise. */
 uint64_t nr3d_lotd_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint32_t n_batches);
+/* Tuning knob: points per pass of the atomic-free scatter = 2^log2_points (10..24; 0 restores the default 2^22 or
+ * NR3D_LOTD_BIN_CHUNK_LOG2).  The workspace size follows; query it again after changing this. */
+void nr3d_lotd_set_dparam_chunk_log2(int log2_points);
 int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
                          int x_dtype, int param_dtype, const void *dL_dy, int64_t dldy_sn, int64_t dldy_se,
                          const void *x, const void *params, const int64_t *batch_inds,

@@ -895,6 +895,8 @@ extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *me
 	                         stream);
 }
 
+extern "C" void nr3d_lotd_set_dparam_chunk_log2(int log2_points) { set_dparam_chunk_log2(log2_points); }
+
 extern "C" uint64_t nr3d_lotd_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint32_t n_batches) {
 	return dparam_workspace_bytes(meta, n_points, n_batches);
 }

@@ -509,6 +509,7 @@ __device__ __forceinline__ float corner_dot(const Lvl &L, const float *__restric
 
 // lotd_bin.hip: atomic-free parameter-gradient path (all level types but NPlaneSum/CPfast, no batching)
 uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches);
+void set_dparam_chunk_log2(int lg);
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,

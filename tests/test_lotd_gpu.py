@@ -312,3 +312,24 @@ def test_lotd_batched_module(oracle, dev):
     assert_close(nablas, oracle.lotd_bwd_dx(m_ref, g, jf_ref) / 2, name="nablas")
     enc.clear()
     assert not hasattr(enc, "lod_params")
+
+
+@pytest.mark.parametrize("case", ["ngp_small", "mixed"])
+def test_dparam_multi_pass_chunking(oracle, dev, hiplib, case):
+    """the atomic-free scatter in several passes (2^10-point chunks over 5003 points: 4 full + 1 partial pass), with the
+    feature-major dL_dy handed over by the dL/dx kernel (strided per pass) and with a plain row-major dL_dy"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=12)
+    ref1 = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
+    ref2 = oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True)
+    hiplib.nr3d_lotd_set_dparam_chunk_log2(10)
+    try:
+        _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+        dx, dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)       # fused gT path
+        _, dp_b = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)  # row-major dL_dy
+        _, dp2, _ = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False,
+                                            need_dLdinput_dparams=True, need_dLdinput_dinput=False)
+    finally:
+        hiplib.nr3d_lotd_set_dparam_chunk_log2(0)
+    assert_close(dp, ref1, name="dL_dparam (fused, chunked)")
+    assert_close(dp_b, ref1, name="dL_dparam (chunked)")
+    assert_close(dp2, ref2, name="2nd-order dparam (chunked)")
