@@ -167,6 +167,19 @@ def full_loop_rate(dev, side=512, iters=5):
                 mrays_per_s=round(n / ms / 1e3, 3), msamples_per_s=round((marched + rendered) / ms / 1e3, 3))
 
 
+def lotd_large_batch_rate(log2n=24):
+    """the headline workload at 2^24 points (the size BASELINE.json's target is quoted on), in a fresh process"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--log2-points", str(log2n), "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    d = json.loads(line[-1])
+    return dict(workload=d["config"]["workload"], mpoints_per_s=d["value"], ms_per_step=d["ms_per_step"],
+                kernel_ms=d["kernel_ms"], whole_step_frac=d["roofline"]["whole_step_frac"])
+
+
 def c4_mixed_rate():
     """BASELINE configs[3] as an extra figure (tools/bench_c4.py): mixed Dense/VM/CP LoTD, 2^22 points,
     fwd + dL/dx + dL/dparam + the three second-order passes"""
@@ -280,6 +293,7 @@ def main():
                 out["extra"]["full_loop_1gpu"] = full_loop_rate(dev)
                 torch.cuda.empty_cache()
                 out["extra"]["c4_mixed_lotd"] = c4_mixed_rate()
+                out["extra"]["lotd_2p24_points"] = lotd_large_batch_rate(24)
             except Exception as ex:   # the extra figure must never cost the headline line
                 out["extra"] = {"march_composite_error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
