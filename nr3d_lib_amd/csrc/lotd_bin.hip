@@ -20,6 +20,10 @@
 #include "lotd_device.h"
 #include <stdlib.h>
 
+#ifndef NR3D_BIN_LDS_KB
+#define NR3D_BIN_LDS_KB 72     // stage-A record staging per workgroup (2 workgroups per CU)
+#define NR3D_BIN_MAX_BP 512
+#endif
 namespace nr3d {
 namespace lotd {
 
@@ -99,13 +103,13 @@ __global__ __launch_bounds__(256) void k_transpose(uint32_t n, uint32_t E, const
 // -------------------------------------------------------------------------------------------------
 template <int G, int NR>
 struct BinCfg {
-	static constexpr int raw = (72 * 1024 / 4) / ((1 + G) * NR);
-	static constexpr int BP = raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
+	static constexpr int raw = (NR3D_BIN_LDS_KB * 1024 / 4) / ((1 + G) * NR);
+	static constexpr int BP = (raw >= 1024 && NR3D_BIN_MAX_BP >= 1024) ? 1024 : raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
 	static constexpr uint32_t cap = (uint32_t)BP * NR;          // records per (pseudo level, point block)
 };
 static uint32_t bin_points(uint32_t G, uint32_t NR) {
-	const uint32_t raw = (72u * 1024u / 4u) / ((1u + G) * NR);
-	return raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
+	const uint32_t raw = ((uint32_t)NR3D_BIN_LDS_KB * 1024u / 4u) / ((1u + G) * NR);
+	return (raw >= 1024 && NR3D_BIN_MAX_BP >= 1024) ? 1024 : raw >= 512 ? 512 : raw >= 256 ? 256 : raw >= 128 ? 128 : raw >= 64 ? 64 : 32;
 }
 
 // Product of D factor tables T_d; corner k uses slot s_d(k) of table d.
@@ -820,8 +824,8 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	static bool attr_set = false;
 	if (!attr_set) {
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoubles * 8));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024 + (kMaxBuckets + 1) * 4));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024 + (kMaxBuckets + 1) * 4));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
 		attr_set = true;
 	}
 	if (second)
