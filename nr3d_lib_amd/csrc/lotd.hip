@@ -45,7 +45,6 @@ __device__ __forceinline__ void gather_pairs(const Lvl &L, const Cell<D> &c, con
 	bool all_adj = true;
 #pragma unroll
 	for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
-		constexpr uint32_t dummy = 0; (void)dummy;
 		const uint32_t k0 = DENSE ? m : (m << 1);          // m with a zero bit inserted at the pair dimension
 		const uint32_t k1 = k0 | PBIT;
 		uint32_t p0[D], p1[D];

@@ -173,7 +173,6 @@ __device__ __forceinline__ uint32_t emit_plane_line(const Lvl &L, const Cell<3> 
                                                     float (&val)[NR][G]) {
 #pragma unroll
 	for (int d = VM ? 0 : 2; d < 3; ++d) {
-		constexpr int kDummy = 0; (void)kDummy;
 		const int base = VM ? d * 6 : 0;
 		float pv[4][G], lv[2][G];
 		uint32_t pe[4], le[2];
@@ -580,8 +579,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 	const uint32_t fb = lo, R = irep[fb], r = blockIdx.x - istart[fb];
 	uint32_t q = 0;
 	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;   // local level of the bucket
-	const uint32_t nb = plan.nb[q], b = fb - plan.bucket_base[q];
-	(void)nb;
+	const uint32_t b = fb - plan.bucket_base[q];
 	const uint32_t qg = plan.qmap[q];                     // pseudo level of the meta
 	const uint32_t level = meta_level_of(md, qg);
 	const Lvl L = load_level(md, level);
