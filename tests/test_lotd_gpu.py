@@ -333,3 +333,27 @@ def test_dparam_multi_pass_chunking(oracle, dev, hiplib, case):
     assert_close(dp, ref1, name="dL_dparam (fused, chunked)")
     assert_close(dp_b, ref1, name="dL_dparam (chunked)")
     assert_close(dp2, ref2, name="2nd-order dparam (chunked)")
+
+
+@pytest.mark.parametrize("case", ["ngp_small", "mixed", "nplane"])
+def test_dparam_coherent_points(oracle, dev, case):
+    """samples along rays: long runs of consecutive points in the same coarse cell take stage A's wave-level merge
+    (their updates are summed into the first lane of the run before they are binned)"""
+    _lotd, m_ref, m, _, _ = _setup(oracle, dev, case, n=8)
+    rng = np.random.default_rng(31)
+    n_rays, n_per = 48, 160
+    o = rng.uniform(0.05, 0.3, (n_rays, 1, 3)).astype(np.float32)
+    d = rng.uniform(0.2, 0.65, (n_rays, 1, 3)).astype(np.float32)
+    t = np.linspace(0, 1, n_per, dtype=np.float32).reshape(1, n_per, 1)
+    x = (o + d * t).reshape(-1, 3).clip(1e-6, 1 - 1e-6).astype(np.float32)        # 7680 points, ray after ray
+    x[5::97] = x[4::97][: len(x[5::97])]                                            # some exact duplicates too
+    md = m_ref.as_dict()
+    p = (rng.standard_normal(md["n_params"]) * 0.1).astype(np.float32)
+    g = (rng.standard_normal((x.shape[0], md["n_encoded_dims"])) * 0.1).astype(np.float32)
+    v = rng.standard_normal((x.shape[0], 3)).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    _, dp = _lotd.lod_bwd(m, T(g), T(x), T(p), None, need_input_grad=False, need_param_grad=True)
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam (coherent)")
+    _, dp2, _ = _lotd.lod_bwd_bwd_input(m, T(v), T(g), T(x), T(p), None, need_dLdinput_ddLdoutput=False,
+                                        need_dLdinput_dparams=True, need_dLdinput_dinput=False)
+    assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="2nd-order dparam (coherent)")
