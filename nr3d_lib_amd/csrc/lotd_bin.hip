@@ -428,10 +428,13 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 	// stage B 2.08 -> 0.90 ms at unchanged stage-A time; a threshold of three quarters gives almost nothing (1.89 ms).
 	{
 		const uint32_t lane = threadIdx.x & 63;
+		// previous lane's values through DPP wave_shr:1 (a VALU move; ds_bpermute would add to the LDS pipe this
+		// kernel is bound by)
+		auto prev = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); };
 		bool same = active && lane > 0;
 #pragma unroll
-		for (int d = 0; d < D; ++d) same = same && (__shfl_up(cell[d], 1, 64) == cell[d]);
-		same = same && (__shfl_up(bi, 1, 64) == bi) && (__shfl_up((uint32_t)active, 1, 64) != 0u);
+		for (int d = 0; d < D; ++d) same = same && (prev(cell[d]) == cell[d]);
+		same = same && (prev(bi) == bi) && (prev((uint32_t)active) != 0u);
 		const unsigned long long cont = __ballot(same);               // bit i: lane i continues lane i-1's run
 		if (__popcll(cont) >= 16) {
 #pragma unroll
