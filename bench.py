@@ -180,6 +180,38 @@ def lotd_large_batch_rate(log2n=24):
                 kernel_ms=d["kernel_ms"], whole_step_frac=d["roofline"]["whole_step_frac"])
 
 
+def c1_dense_rate(dev):
+    """BASELINE configs[0]: single Dense level 32^3 x 4 features, 65 536 points, forward only -- the HIP kernel next to a
+    pure-PyTorch trilinear sampler on the host cores (grid_sample on the [32,32,32,4] table with the LoTD coordinate
+    convention x * (R-2)/(R-1), align_corners=True: the formulation of the reference's CPU helper param_interpolate,
+    lotd_helpers.py:274-346, restated here because the reference cannot travel to the GPU box)"""
+    import torch.nn.functional as F
+    from nr3d_lib_amd.bindings import _lotd
+    R, Fe, n = 32, 4, 65536
+    g = torch.Generator().manual_seed(0)
+    params = torch.randn(R ** 3 * Fe, generator=g)
+    x = torch.rand(n, 3, generator=g).clamp_(1e-6, 1 - 1e-6)
+    meta = _lotd.LoDMeta(3, [R], [Fe], ["Dense"], None)
+    xd, pd = x.to(dev), params.to(dev)
+    y = _lotd.lod_fwd(meta, xd, pd)[0]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50):
+        y = _lotd.lod_fwd(meta, xd, pd)[0]
+    torch.cuda.synchronize(); gpu_ms = (time.perf_counter() - t0) / 50 * 1e3
+    vol = params.view(1, R, R, R, Fe).permute(0, 4, 1, 2, 3).contiguous()            # [1, F, Rx, Ry, Rz]
+    rel = ((x * 2 - 1) * ((R - 2.) / (R - 1.)))[:, [2, 1, 0]].view(1, 1, 1, n, 3)     # grid_sample wants (z, y, x) last
+    ref = F.grid_sample(vol, rel, align_corners=True, padding_mode="zeros").view(Fe, n).t()
+    t0 = time.perf_counter(); reps = 0
+    while time.perf_counter() - t0 < 2.0:
+        F.grid_sample(vol, rel, align_corners=True, padding_mode="zeros"); reps += 1
+    cpu_ms = (time.perf_counter() - t0) / reps * 1e3
+    err = float((y.cpu() - ref).abs().max() / ref.abs().max())
+    return dict(workload="configs[0]: Dense 32^3 x 4, 65536 points, forward", gpu_ms=round(gpu_ms, 4),
+                gpu_mpoints_per_s=round(n / gpu_ms / 1e3, 2), cpu_pytorch_ms=round(cpu_ms, 3),
+                cpu_pytorch_mpoints_per_s=round(n / cpu_ms / 1e3, 3), cpu_threads=torch.get_num_threads(),
+                max_rel_diff=float(f"{err:.2e}"))
+
+
 def c4_mixed_rate():
     """BASELINE configs[3] as an extra figure (tools/bench_c4.py): mixed Dense/VM/CP LoTD, 2^22 points,
     fwd + dL/dx + dL/dparam + the three second-order passes"""
@@ -308,6 +340,7 @@ def main():
             try:
                 out["extra"] = {"march_composite": march_composite_rate(dev),
                                 "march_composite_262144_rays": march_composite_rate(dev, iters=5, side=512)}
+                out["extra"]["c1_dense_fwd"] = c1_dense_rate(dev)
                 out["extra"]["full_loop_1gpu"] = full_loop_rate(dev)
                 torch.cuda.empty_cache()
                 out["extra"]["c4_mixed_lotd"] = c4_mixed_rate()
