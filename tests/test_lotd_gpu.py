@@ -357,3 +357,22 @@ def test_dparam_coherent_points(oracle, dev, case):
     _, dp2, _ = _lotd.lod_bwd_bwd_input(m, T(v), T(g), T(x), T(p), None, need_dLdinput_ddLdoutput=False,
                                         need_dLdinput_dparams=True, need_dLdinput_dinput=False)
     assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="2nd-order dparam (coherent)")
+
+
+@pytest.mark.parametrize("case", ["ngp_small", "mixed"])
+def test_params_at_odd_alignment(oracle, dev, case):
+    """params that start 4 bytes into an allocation: the 8 / 16-byte vector gathers must not be used"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=14)
+    big = torch.empty(pt.numel() + 1, device=dev)
+    p_odd = big[1:]
+    p_odd.copy_(pt)
+    assert p_odd.data_ptr() % 8 == 4 and p_odd.is_contiguous()
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    y, j = _lotd.lod_fwd(m, xt, p_odd, need_input_grad=True)
+    assert_close(y, y_ref, name="y")
+    assert_close(j, j_ref, name="dy_dx")
+    _, dp = _lotd.lod_bwd(m, gt, xt, p_odd, j, need_input_grad=False, need_param_grad=True)
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam")
+    _, _, dx2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, p_odd, j, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=False,
+                                        need_dLdinput_dinput=True)
+    assert_close(dx2, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="2nd-order dx")
