@@ -862,7 +862,10 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	const uint32_t NB = pl.bucket_base[pl.n_pseudo];
 	uint32_t *tot = plan_buf, *rep = plan_buf + NB, *item_start = plan_buf + 2 * (size_t)NB;
 	const size_t bin_lds = ((size_t)(1 + G) * BinCfg<G, NR>::cap + nb_max + 1) * sizeof(uint32_t);
-	static bool attr_set = false;
+	static bool attr_set_dev[64] = {};                 // per device: a process may drive several GPUs
+	int dev_id = 0;
+	NR3D_HIP_CHECK(hipGetDevice(&dev_id));
+	bool &attr_set = attr_set_dev[dev_id & 63];
 	if (!attr_set) {
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoubles * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
