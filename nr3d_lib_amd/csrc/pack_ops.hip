@@ -521,16 +521,22 @@ __global__ __launch_bounds__(kBlock) void k_alpha_fwd_lpp(uint32_t P, const floa
 		if (T < eps) { stopped = true; return; }
 		if (!(a <= thre)) { w = a * T; sel = true; T *= (1.0f - a); ++cnt; }
 	};
-	uint32_t j = 0;
-	for (; j + 4 <= len; j += 4) {          // 4 samples per memory request (the lanes' packs are in different lines)
-		const F4u a4 = *reinterpret_cast<const F4u *>(alphas + begin + j);
-		F4u w4; B4u s4;
+	// 4 samples per memory request (the lanes' packs are in different lines); chunk c + 1 is loaded, branch-free,
+	// before chunk c is processed (see k_alpha_bwd_lpp)
+	const uint32_t n4 = len / 4;
+	if (n4) {
+		F4u a_n = *reinterpret_cast<const F4u *>(alphas + begin);
+		for (uint32_t c = 0; c < n4; ++c) {
+			const F4u a4 = a_n;
+			a_n = *reinterpret_cast<const F4u *>(alphas + begin + 4 * min(c + 1, n4 - 1));
+			F4u w4; B4u s4;
 #pragma unroll
-		for (int u = 0; u < 4; ++u) { bool sel; one(a4.v[u], w4.v[u], sel); s4.v[u] = sel ? 1 : 0; }
-		if (weights) *reinterpret_cast<F4u *>(weights + begin + j) = w4;
-		if (selector) *reinterpret_cast<B4u *>(selector + begin + j) = s4;
+			for (int u = 0; u < 4; ++u) { bool sel; one(a4.v[u], w4.v[u], sel); s4.v[u] = sel ? 1 : 0; }
+			if (weights) *reinterpret_cast<F4u *>(weights + begin + 4 * c) = w4;
+			if (selector) *reinterpret_cast<B4u *>(selector + begin + 4 * c) = s4;
+		}
 	}
-	for (; j < len; ++j) {
+	for (uint32_t j = 4 * n4; j < len; ++j) {
 		float w; bool sel;
 		one(alphas[begin + j], w, sel);
 		if (weights) weights[begin + j] = w;
@@ -547,15 +553,22 @@ __global__ __launch_bounds__(kBlock) void k_alpha_bwd_lpp(uint32_t P, const floa
 	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
 	if (p >= P) return;
 	const uint32_t begin = (uint32_t)pi[2 * (size_t)p], len = (uint32_t)pi[2 * (size_t)p + 1];
+	// Chunks of 4 samples; the loads of chunk c + 1 are issued (branch-free: the last chunk is simply re-read) before
+	// chunk c is processed, so the serial recurrences run under the memory latency instead of after it.
+	const uint32_t n4 = len / 4;
+	auto ld4 = [&](const float *base, uint32_t c) { return *reinterpret_cast<const F4u *>(base + begin + 4 * c); };
 	float accum = 0.0f;
-	uint32_t j = 0;
-	for (; j + 4 <= len; j += 4) {
-		const F4u g4 = *reinterpret_cast<const F4u *>(grad_weights + begin + j);
-		const F4u w4 = *reinterpret_cast<const F4u *>(weights + begin + j);
+	if (n4) {
+		F4u g_n = ld4(grad_weights, 0), w_n = ld4(weights, 0);
+		for (uint32_t c = 0; c < n4; ++c) {
+			const F4u g4 = g_n, w4 = w_n;
+			const uint32_t cn = min(c + 1, n4 - 1);
+			g_n = ld4(grad_weights, cn); w_n = ld4(weights, cn);
 #pragma unroll
-		for (int u = 0; u < 4; ++u) accum = __fmaf_rn(g4.v[u], w4.v[u], accum);
+			for (int u = 0; u < 4; ++u) accum = __fmaf_rn(g4.v[u], w4.v[u], accum);
+		}
 	}
-	for (; j < len; ++j) accum = __fmaf_rn(grad_weights[begin + j], weights[begin + j], accum);
+	for (uint32_t j = 4 * n4; j < len; ++j) accum = __fmaf_rn(grad_weights[begin + j], weights[begin + j], accum);
 	float T = 1.0f;
 	bool stopped = false;
 	auto one = [&](float a, float gw, float w) -> float {
@@ -567,16 +580,19 @@ __global__ __launch_bounds__(kBlock) void k_alpha_bwd_lpp(uint32_t P, const floa
 		T *= (1.0f - a);
 		return ga;
 	};
-	for (j = 0; j + 4 <= len; j += 4) {
-		const F4u a4 = *reinterpret_cast<const F4u *>(alphas + begin + j);
-		const F4u g4 = *reinterpret_cast<const F4u *>(grad_weights + begin + j);
-		const F4u w4 = *reinterpret_cast<const F4u *>(weights + begin + j);
-		F4u o4;
+	if (n4) {
+		F4u a_n = ld4(alphas, 0), g_n = ld4(grad_weights, 0), w_n = ld4(weights, 0);
+		for (uint32_t c = 0; c < n4; ++c) {
+			const F4u a4 = a_n, g4 = g_n, w4 = w_n;
+			const uint32_t cn = min(c + 1, n4 - 1);
+			a_n = ld4(alphas, cn); g_n = ld4(grad_weights, cn); w_n = ld4(weights, cn);
+			F4u o4;
 #pragma unroll
-		for (int u = 0; u < 4; ++u) o4.v[u] = one(a4.v[u], g4.v[u], w4.v[u]);
-		*reinterpret_cast<F4u *>(grad_alphas + begin + j) = o4;
+			for (int u = 0; u < 4; ++u) o4.v[u] = one(a4.v[u], g4.v[u], w4.v[u]);
+			*reinterpret_cast<F4u *>(grad_alphas + begin + 4 * c) = o4;
+		}
 	}
-	for (; j < len; ++j) grad_alphas[begin + j] = one(alphas[begin + j], grad_weights[begin + j], weights[begin + j]);
+	for (uint32_t j = 4 * n4; j < len; ++j) grad_alphas[begin + j] = one(alphas[begin + j], grad_weights[begin + j], weights[begin + j]);
 }
 
 // wave-per-pack for few packs; from 2048 packs on (32 waves of lanes) one lane per pack is faster at every pack
