@@ -137,3 +137,89 @@ def test_coarse_plus_fine_packed_buffer_and_coarse_only(dev):
         assert vb2["type"] == "batched" and vb2["t"].shape == (n, 16) and det2 == {"render.num_per_ray": 16}
         vb3, det3 = neus_ray_query_march_occ_multi_upsample(model, rays)
         assert vb3["type"] == "empty" and det3 == {}
+
+
+def _expect_compressed(oracle, alpha, t, pack_infos, pack_rays):
+    """the oracle's compaction of (alpha, t) laid out in packs -> kept samples, their packs, the rays of those packs"""
+    _, cpi, sel = oracle.packed_alpha_to_vw_forward(alpha, pack_infos, 1e-4, 0.0, True)
+    keep = cpi[:, 1] > 0
+    return alpha[sel], t[sel], cpi[keep], pack_rays[keep]
+
+
+def test_compressed_fine_buffer_is_the_compaction_of_the_batched_one(oracle, dev):
+    from nr3d_lib_amd.graphics.nerf import composite_packed_volume_buffer
+    from nr3d_lib_amd.graphics.neus import (neus_ray_query_march_occ_multi_upsample,
+                                            neus_ray_query_march_occ_multi_upsample_compressed)
+    model, rays, occ, step = _scene(dev)
+    n = rays["num_rays"]
+    kw = dict(num_fine=8, upsample_inv_s_factors=[1, 4, 16])
+    with torch.no_grad():
+        full, _ = neus_ray_query_march_occ_multi_upsample(model, rays, **kw)
+        vb, details = neus_ray_query_march_occ_multi_upsample_compressed(model, rays, **kw)
+    assert vb["type"] == "packed"
+    a, t = full["opacity_alpha"].cpu().numpy(), full["t"].cpu().numpy()
+    k = a.shape[1]
+    pinfo = np.stack([np.arange(a.shape[0]) * k, np.full(a.shape[0], k)], 1).astype(np.int64)
+    a_ref, t_ref, pi_ref, rays_ref = _expect_compressed(oracle, a.ravel(), t.ravel(), pinfo, full["rays_inds_hit"].cpu().numpy())
+    np.testing.assert_array_equal(vb["pack_infos_hit"].cpu().numpy(), pi_ref)
+    np.testing.assert_array_equal(vb["rays_inds_hit"].cpu().numpy(), rays_ref)
+    np.testing.assert_array_equal(vb["opacity_alpha"].cpu().numpy(), a_ref)
+    np.testing.assert_array_equal(vb["t"].cpu().numpy(), t_ref)
+    assert 0 < vb["t"].numel() < a.size                              # something was pruned, something is left
+    assert details["render.num_per_ray0"] == k
+    np.testing.assert_array_equal(details["render.num_per_ray"].cpu().numpy(), pi_ref[:, 1])
+    assert vb["rgb"].shape == (vb["t"].numel(), 3) and vb["nablas"].shape == (vb["t"].numel(), 3)
+    # net_x are the kept samples' positions on their own rays
+    o, d = rays["rays_o"].cpu().numpy(), rays["rays_d"].cpu().numpy()
+    ridx = np.repeat(rays_ref, pi_ref[:, 1])
+    np.testing.assert_allclose(vb["net_x"].cpu().numpy(), o[ridx] + d[ridx] * t_ref[:, None], rtol=0, atol=1e-6)
+    # compression does not change the image: dropped samples carry (almost) no weight
+    m = composite_packed_volume_buffer(vb, n)["mask_volume"].cpu().numpy()
+    w = a * np.cumprod(np.concatenate([np.ones_like(a[:, :1]), 1 - a[:, :-1]], 1), 1)
+    m_ref = np.zeros(n, np.float32); m_ref[full["rays_inds_hit"].cpu().numpy()] = w.sum(1)
+    np.testing.assert_allclose(m, m_ref, rtol=0, atol=2e-4)
+
+
+def test_compressed_coarse_plus_fine_and_coarse_only(oracle, dev):
+    from nr3d_lib_amd.graphics.neus import (neus_ray_query_march_occ_multi_upsample,
+                                            neus_ray_query_march_occ_multi_upsample_compressed,
+                                            neus_ray_query_march_occ_multi_upsample_compressed_strategy)
+    model, rays, occ, step = _scene(dev)
+    n = rays["num_rays"]
+    kw = dict(num_coarse=16, num_fine=4, upsample_inv_s_factors=[1, 4])
+    with torch.no_grad():
+        full, _ = neus_ray_query_march_occ_multi_upsample(model, rays, **kw)
+        vb, details = neus_ray_query_march_occ_multi_upsample_compressed(model, rays, **kw)
+    a_ref, t_ref, pi_ref, rays_ref = _expect_compressed(oracle, full["opacity_alpha"].cpu().numpy(), full["t"].cpu().numpy(),
+                                                        full["pack_infos_hit"].cpu().numpy(), np.arange(n))
+    np.testing.assert_array_equal(vb["pack_infos_hit"].cpu().numpy(), pi_ref)
+    np.testing.assert_array_equal(vb["rays_inds_hit"].cpu().numpy(), rays_ref)
+    np.testing.assert_array_equal(vb["opacity_alpha"].cpu().numpy(), a_ref)
+    np.testing.assert_array_equal(vb["t"].cpu().numpy(), t_ref)
+    np.testing.assert_array_equal(details["render.num_per_ray0"].cpu().numpy(), full["pack_infos_hit"][:, 1].cpu().numpy())
+    assert len(rays_ref) < n                                         # rays that miss the sphere keep nothing
+    # gradients reach the model through the kept samples only
+    model.train()
+    radius = torch.nn.Parameter(torch.tensor(model.radius, device=dev))
+    model.radius = radius
+    vb_t, _ = neus_ray_query_march_occ_multi_upsample_compressed(model, rays, **kw)
+    vb_t["opacity_alpha"].sum().backward()
+    assert radius.grad is not None and torch.isfinite(radius.grad) and radius.grad.abs() > 0
+    del model.radius
+    model.radius = float(radius.detach()); model.eval()
+    # nothing marched: compressed coarse samples; without coarse samples, empty
+    model.accel.occ_grid = torch.zeros_like(model.accel.occ_grid)
+    with torch.no_grad():
+        full2, _ = neus_ray_query_march_occ_multi_upsample(model, rays, num_coarse=16)
+        vb2, det2 = neus_ray_query_march_occ_multi_upsample_compressed(model, rays, num_coarse=16)
+        a2 = full2["opacity_alpha"].cpu().numpy()
+        pinfo = np.stack([np.arange(n) * 16, np.full(n, 16)], 1).astype(np.int64)
+        a_ref, t_ref, pi_ref, rays_ref = _expect_compressed(oracle, a2.ravel(), full2["t"].cpu().numpy().ravel(), pinfo, np.arange(n))
+        assert vb2["type"] == "packed" and det2["render.num_per_ray0"] == 16
+        np.testing.assert_array_equal(vb2["pack_infos_hit"].cpu().numpy(), pi_ref)
+        np.testing.assert_array_equal(vb2["rays_inds_hit"].cpu().numpy(), rays_ref)
+        np.testing.assert_array_equal(vb2["t"].cpu().numpy(), t_ref)
+        vb3, det3 = neus_ray_query_march_occ_multi_upsample_compressed(model, rays)
+        assert vb3["type"] == "empty" and det3 == {}
+    with pytest.raises(NotImplementedError):
+        neus_ray_query_march_occ_multi_upsample_compressed_strategy(model, rays)
