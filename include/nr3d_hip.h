@@ -139,6 +139,60 @@ int nr3d_lotd_grid_index(const nr3d_lotd_meta_t *meta, const void *meta_dev, uin
                          uint32_t batch_data_size, int32_t max_level, int64_t *grid_inds, void *stream);
 
 /* =================================================================================================
+ * Forest of blocks -- replaces nr3d_lib.bindings._forest.ForestMeta and the forest overloads of
+ * nr3d_lib.bindings._lotd (csrc/forest/forest_cpp_api.h:18-37, csrc/forest/forest.h:25-97,
+ * csrc/lotd/src/lotd.cpp:44-60, csrc/lotd/include/lotd/lotd_forest.h).
+ * The octree is the breadth-first byte octree of a kaolin SPC: one occupancy byte per non-leaf node (child
+ * index = x<<2 | y<<1 | z), exsum = exclusive prefix sum of the bytes' popcounts, node 0 = root; the blocks are
+ * the nodes on `level`, block index = node index - level_poffset, block_ks their integer coordinates.
+ * All three arrays are DEVICE pointers; the struct itself lives on the host and is passed by value to kernels.
+ * ============================================================================================== */
+typedef struct nr3d_forest_meta {
+	const uint8_t *octree;        /* [n_nodes] */
+	const int32_t *exsum;         /* [n_nodes + 1] */
+	const int16_t *block_ks;      /* [n_trees, 3] */
+	float world_block_size[3];
+	float world_origin[3];
+	int32_t resolution[3];
+	uint32_t n_trees;
+	uint32_t level;
+	uint32_t level_poffset;
+	int32_t continuity_enabled;   /* look corner values up in the neighbouring block across block faces */
+} nr3d_forest_meta_t;
+
+/* block index (or -1) of integer block coordinates ks (int16 [n,3]) -- `identify`, forest.h:25-58 /
+ * ForestMetaRef::map_block_ind :88-95 (the reference queries through kaolin's unbatched_query on the host side,
+ * nr3d_lib/models/spatial/forest.py:244-260). */
+int nr3d_forest_identify(const nr3d_forest_meta_t *forest, uint64_t n, const int16_t *ks, int32_t *block_inds,
+                         void *stream);
+
+/* lod_fwd(metas=(lod_meta, forest_meta), ...)  (lotd_torch_api.cu:333-361, kernel_lod_forest lotd_forest.h:158-333).
+ * x in [0,1]^3 INSIDE the point's block; block_inds int64 [N] (<0: the point is skipped, outputs zero) or NULL with
+ * batch_data_size (points per block, blocks in order) or neither (block 0); block_offsets int64 [n_trees] or NULL
+ * (block b's parameters start at b * n_params).  f32, D == 3, level types Dense / VectorMatrix / NPlaneMul / CP / Hash
+ * (the reference's forest kernels handle no others).  y [N,E], dy_dx [N,E,3] or NULL, both contiguous. */
+int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
+                         uint32_t n_points, const float *x, const float *params, const int64_t *block_inds,
+                         const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level, float *y,
+                         float *dy_dx, void *stream);
+
+/* dL/dparam (dL_ddLdx == NULL; kernel_lod_forest_backward_grid :414-542) or d(dL/dx)/dparam
+ * (kernel_lod_forest_backward_input_backward_grid :636-773).  dL_dparam [n_trees * n_params] ZERO-INIT by the caller;
+ * contributions of corners that lie in a neighbouring block go to that block's parameters. */
+int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
+                                uint32_t n_points, const float *dL_ddLdx, const float *dL_dy, const float *x,
+                                const float *params, const int64_t *block_inds, const int64_t *block_offsets,
+                                uint32_t batch_data_size, int32_t max_level, float *dL_dparam, void *stream);
+
+/* d(dL/dx)/dx (kernel_lod_forest_backward_input_backward_input :929-1065): Dense / VectorMatrix / Hash levels
+ * contribute.  dL_dx [N,3] is overwritten.  (dL/dx and dL/d(dL/dy) are contractions with dy_dx:
+ * nr3d_lotd_bwd_dx / nr3d_lotd_bwd_bwd_ddLdy.) */
+int nr3d_lotd_forest_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
+                                uint32_t n_points, const float *dL_ddLdx, const float *dL_dy, const float *x,
+                                const float *params, const int64_t *block_inds, const int64_t *block_offsets,
+                                uint32_t batch_data_size, int32_t max_level, float *dL_dx, void *stream);
+
+/* =================================================================================================
  * occ_grid ray marching -- replaces nr3d_lib.bindings._occ_grid
  *   csrc/occ_grid/include/occ_grid/cpp_api.h:14-66, csrc/occ_grid/src/ray_marching.cu:136-244,
  *   csrc/occ_grid/src/batched_marching.cu:153-287
@@ -172,6 +226,25 @@ int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, const float *ra
                            float *t_ends, int32_t *ridx, int32_t *bidx /*NULL unless batched*/,
                            int32_t *gidx /*or NULL*/, const void *sample_cache /*or NULL*/,
                            uint32_t cache_max_steps, void *stream);
+
+/* forest_ray_marching (csrc/occ_grid/src/forest_marching.cu:16-303): marching through the occupancy grids of the
+ * blocks a ray crosses.  The block segments of every ray (seg_block_inds int32 [S], seg_entries / seg_exits f32 [S],
+ * packed per ray by seg_pack_infos int32 [n_rays,2]) come from the caller's octree ray trace.
+ * grid_binary uint8/bool [n_trees, Rx, Ry, Rz].  Same two-phase contract as nr3d_ray_marching_count/_emit. */
+int nr3d_forest_ray_marching_count(const nr3d_forest_meta_t *forest, uint32_t n_rays, const float *rays_o,
+                                   const float *rays_d, const float *t_min, const float *t_max,
+                                   const int32_t *seg_block_inds, const float *seg_entries, const float *seg_exits,
+                                   const int32_t *seg_pack_infos, const int32_t grid_res[3], const uint8_t *grid_binary,
+                                   float step_size, float max_step_size, float dt_gamma, uint32_t max_steps,
+                                   int32_t *packed_info /*[n_rays,2]*/, int64_t *total_steps /*[1]*/, void *scan_tmp,
+                                   void *stream);
+int nr3d_forest_ray_marching_emit(const nr3d_forest_meta_t *forest, uint32_t n_rays, const float *rays_o,
+                                  const float *rays_d, const float *t_min, const float *t_max,
+                                  const int32_t *seg_block_inds, const float *seg_entries, const float *seg_exits,
+                                  const int32_t *seg_pack_infos, const int32_t grid_res[3], const uint8_t *grid_binary,
+                                  float step_size, float max_step_size, float dt_gamma, const int32_t *packed_info,
+                                  float *t_starts, float *t_ends, int32_t *ridx, int32_t *blidx, int32_t *gidx /*or NULL*/,
+                                  void *stream);
 
 /* Scratch bytes needed by the device-wide scans used in two-phase ops (any n). */
 uint64_t nr3d_scan_tmp_bytes(uint64_t n);

@@ -12,7 +12,8 @@ Differences that are deliberate and documented in DESIGN.md:
     [N, E*D] Jacobian.
   * kernels compute in fp32; fp16 params / inputs are converted on the way in and results cast back
     (the reference accumulates in half on its (half, half) path).
-  * forest overloads (``metas`` tuple) are not provided (out of the hot-path scope).
+  * the forest overloads (``metas`` = ``(lod_meta, forest_meta)`` tuple, lotd.cpp:44-60) live in
+    ``bindings/_forest.py``; the functions here dispatch to them.
 """
 import ctypes as C
 import enum
@@ -163,7 +164,7 @@ def _is_divisible(a, b):
 
 def _check_common(fn, meta, input, params, batch_inds, batch_offsets, batch_data_size):
     if isinstance(meta, tuple):
-        raise NotImplementedError("nr3d_lib_amd: forest LoTD (metas tuple) is outside the hot-path scope")
+        raise RuntimeError(f"{fn}: expected a LoDMeta, got a tuple (forest calls go through bindings._forest)")
     if input.dim() != 2:
         raise RuntimeError(f"{fn}: Expected 2-dimensional tensor for argument x, got {input.dim()}")
     H.require_gpu(input, params, batch_inds, batch_offsets)
@@ -283,6 +284,9 @@ class _Prof:
 # ------------------------------------------------------------------------------------------------
 def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_data_size=None, max_level=None,
             need_input_grad=None):
+    if isinstance(lod_meta, tuple):
+        from . import _forest
+        return _forest.lod_fwd(lod_meta, input, params, batch_inds, batch_offsets, batch_data_size, max_level, need_input_grad)
     m = lod_meta
     N, bds = _check_common("fwd", m, input, params, batch_inds, batch_offsets, batch_data_size)
     max_level = m.n_levels if max_level is None else int(max_level)
@@ -324,6 +328,10 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
 # ------------------------------------------------------------------------------------------------
 def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offsets=None, batch_data_size=None,
             max_level=None, need_input_grad=None, need_param_grad=None):
+    if isinstance(lod_meta, tuple):
+        from . import _forest
+        return _forest.lod_bwd(lod_meta, dL_dy, input, params, dy_dx, batch_inds, batch_offsets, batch_data_size, max_level,
+                               need_input_grad, need_param_grad)
     m = lod_meta
     N, bds = _check_common("bwd", m, input, params, batch_inds, batch_offsets, batch_data_size)
     E, D = m.n_encoded_dims, m.n_dims_to_encode
@@ -391,6 +399,11 @@ def _cast(t, dtype):
 def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offsets=None,
                       batch_data_size=None, max_level=None, need_dLdinput_ddLdoutput=None,
                       need_dLdinput_dparams=None, need_dLdinput_dinput=None):
+    if isinstance(lod_meta, tuple):
+        from . import _forest
+        return _forest.lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx, batch_inds, batch_offsets,
+                                         batch_data_size, max_level, need_dLdinput_ddLdoutput, need_dLdinput_dparams,
+                                         need_dLdinput_dinput)
     m = lod_meta
     N, bds = _check_common("bwd_bwd_input", m, input, params, batch_inds, batch_offsets, batch_data_size)
     E, D = m.n_encoded_dims, m.n_dims_to_encode
@@ -454,6 +467,9 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
 # lod_get_grid_index  (lotd.cpp:41-42, lotd_torch_api.cu:771-855)
 # ------------------------------------------------------------------------------------------------
 def lod_get_grid_index(lod_meta, input, batch_inds=None, batch_offsets=None, batch_data_size=None, max_level=None):
+    if isinstance(lod_meta, tuple):
+        from . import _forest
+        return _forest.lod_get_grid_index(lod_meta, input, batch_inds, batch_offsets, batch_data_size, max_level)
     m = lod_meta
     N, bds = _check_common("get_grid_index", m, input, None, batch_inds, batch_offsets, batch_data_size)
     for tp in m.level_types:

@@ -2,7 +2,7 @@
 ``nr3d_lib.bindings._occ_grid`` (csrc/occ_grid/src/occ_grid.cpp:22-33, signatures
 csrc/occ_grid/include/occ_grid/cpp_api.h:14-66), backed by libnr3d_hip.so.
 
-ray_marching / batched_ray_marching keep the reference's positional signatures and return lists.
+ray_marching / batched_ray_marching / forest_ray_marching keep the reference's positional signatures and return lists.
 The per-ray counts are scanned on the device; the only host sync is the read-back of the total
 sample count (needed to size the outputs -- the reference syncs at the same point).
 """
@@ -119,6 +119,53 @@ def batched_ray_marching(rays_o, rays_d, t_min, t_max, batch_inds_, batch_data_s
                   step_size, max_step_size, dt_gamma, max_steps, return_gidx, True)
 
 
-def forest_ray_marching(*args, **kwargs):
-    raise NotImplementedError("nr3d_lib_amd: forest_ray_marching needs the kaolin-based ForestMeta "
-                              "(out of the hot-path scope, SURVEY.md §8f-4)")
+def forest_ray_marching(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, seg_entries, seg_exits, seg_pack_infos,
+                        grid_binary, step_size, max_step_size, dt_gamma, max_steps, return_gidx):
+    """-> [packed_info, t_starts, t_ends, ridx, blidx, gidx | None]  (forest_marching.cu:145-303; `forest` is a
+    bindings._forest.ForestMeta, the segments are the caller's per-ray block crossings, packed by seg_pack_infos)"""
+    _chk("rays_o", rays_o, 2, torch.float32)
+    _chk("rays_d", rays_d, 2, torch.float32)
+    _chk("t_min", t_min, 1, torch.float32)
+    _chk("t_max", t_max, 1, torch.float32)
+    _chk("seg_block_inds", seg_block_inds, 1, torch.int32)
+    _chk("seg_entries", seg_entries, 1, torch.float32)
+    _chk("seg_exits", seg_exits, 1, torch.float32)
+    _chk("seg_pack_infos", seg_pack_infos, 2, torch.int32)
+    _chk("grid_binary", grid_binary, 4)
+    if grid_binary.dtype not in (torch.bool, torch.uint8):
+        raise RuntimeError("grid_binary: expected a bool tensor")
+    n = rays_o.shape[0]
+    if tuple(rays_o.shape) != (n, 3) or tuple(rays_d.shape) != (n, 3):
+        raise RuntimeError("rays_o / rays_d: expected shape [n_rays, 3]")
+    if t_min.shape[0] != n or t_max.shape[0] != n or tuple(seg_pack_infos.shape) != (n, 2):
+        raise RuntimeError("t_min / t_max / seg_pack_infos: expected n_rays rows")
+    if seg_entries.shape != seg_block_inds.shape or seg_exits.shape != seg_block_inds.shape:
+        raise RuntimeError("seg_block_inds / seg_entries / seg_exits: expected the same size")
+    forest._check("forest_ray_marching", rays_o)
+    if grid_binary.shape[0] != int(forest.n_trees):
+        raise RuntimeError(f"grid_binary: expected {int(forest.n_trees)} block grids, got {grid_binary.shape[0]}")
+    dev = rays_o.device
+    res = (C.c_int32 * 3)(*[int(v) for v in grid_binary.shape[-3:]])
+    with torch.cuda.device(dev):
+        st = H.stream_of(rays_o)
+        fc = forest._c()
+        packed_info = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int64, device=dev)
+        nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(n, 1))))
+        tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        common = (H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(seg_block_inds), H.ptr(seg_entries),
+                  H.ptr(seg_exits), H.ptr(seg_pack_infos), res, H.ptr(grid_binary), H.f32(step_size),
+                  H.f32(max_step_size), H.f32(dt_gamma))
+        H.check(H.lib().nr3d_forest_ray_marching_count(C.byref(fc), H.u32(n), *common, H.u32(max_steps),
+                                                       H.ptr(packed_info), H.ptr(total), H.ptr(tmp), st))
+        S = int(total.item())          # the single device->host sync of this op
+        t_starts = torch.empty((S, 1), dtype=torch.float32, device=dev)
+        t_ends = torch.empty((S, 1), dtype=torch.float32, device=dev)
+        ridx = torch.empty(S, dtype=torch.int32, device=dev)
+        blidx = torch.empty(S, dtype=torch.int32, device=dev)
+        gidx = torch.empty(S, dtype=torch.int32, device=dev) if return_gidx else None
+        if S > 0:
+            H.check(H.lib().nr3d_forest_ray_marching_emit(C.byref(fc), H.u32(n), *common, H.ptr(packed_info),
+                                                          H.ptr(t_starts), H.ptr(t_ends), H.ptr(ridx), H.ptr(blidx),
+                                                          H.ptr(gidx), st))
+    return [packed_info, t_starts, t_ends, ridx, blidx, gidx]

@@ -238,6 +238,96 @@ __global__ __launch_bounds__(256) void k_emit_cached(uint32_t n_rays, uint32_t s
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Forest of occupancy grids (forest_marching.cu:16-143): the ray's block segments (block, entry, exit) are walked in
+// order; inside a segment the march is the single-grid one against the block's own grid and ROI
+// (world_origin + k * world_block_size, one fused multiply-add as nvcc contracts it).  No ROI test on the probe
+// (block_grid_occupied_at :16-25) and one unconditional `t_mid += step_size` at every segment start (:99-101).
+// ---------------------------------------------------------------------------------------------------
+template <bool EMIT>
+__global__ __launch_bounds__(kBlock) void k_forest_march(const int16_t *__restrict__ block_ks, f3 world_origin,
+                                                         f3 world_block_size, uint32_t n_rays,
+                                                         const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                         const float *__restrict__ t_min, const float *__restrict__ t_max,
+                                                         const int32_t *__restrict__ seg_block_inds,
+                                                         const float *__restrict__ seg_entries,
+                                                         const float *__restrict__ seg_exits,
+                                                         const int32_t *__restrict__ seg_pack_infos, int rx, int ry, int rz,
+                                                         const uint8_t *__restrict__ cells, float step_size,
+                                                         float max_step_size, float dt_gamma, uint32_t max_steps,
+                                                         const int32_t *__restrict__ packed_info,
+                                                         int32_t *__restrict__ counts, float *__restrict__ t_starts,
+                                                         float *__restrict__ t_ends, int32_t *__restrict__ ridx,
+                                                         int32_t *__restrict__ blidx, int32_t *__restrict__ gidx) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n_rays) return;
+	const uint32_t seg_begin = (uint32_t)seg_pack_infos[2 * (size_t)i], seg_len = (uint32_t)seg_pack_infos[2 * (size_t)i + 1];
+	const uint32_t vol = (uint32_t)(rx * ry * rz);
+	uint32_t base = 0;
+	if (EMIT) {
+		base = (uint32_t)packed_info[2 * (size_t)i];
+		max_steps = (uint32_t)packed_info[2 * (size_t)i + 1];
+	}
+	const f3 o = {rays_o[3 * (size_t)i], rays_o[3 * (size_t)i + 1], rays_o[3 * (size_t)i + 2]};
+	const f3 dir = {rays_d[3 * (size_t)i], rays_d[3 * (size_t)i + 1], rays_d[3 * (size_t)i + 2]};
+	const f3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+	const float near = t_min[i], far = t_max[i];
+	const float dt_min = step_size, dt_max = max_step_size;
+	Grid g;
+	g.rx = rx; g.ry = ry; g.rz = rz;
+	g.type = NR3D_CONTRACT_AABB;
+	g.inv_ext = {0.0f, 0.0f, 0.0f};
+	g.inv_res = {0.0f, 0.0f, 0.0f};
+
+	uint32_t j = 0;
+	float t0 = near;
+	float dt = calc_dt(t0, dt_gamma, dt_min, dt_max);
+	float t1 = t0 + dt;
+	float tm = (t0 + t1) * 0.5f;
+	for (uint32_t s = 0; s < seg_len; ++s) {
+		const float entry = seg_entries[seg_begin + s], exit = seg_exits[seg_begin + s];
+		const uint32_t b = (uint32_t)seg_block_inds[seg_begin + s];
+		const int16_t *k = block_ks + 3 * (size_t)b;
+		g.mn = {__fmaf_rn((float)k[0], world_block_size.x, world_origin.x), __fmaf_rn((float)k[1], world_block_size.y, world_origin.y),
+		        __fmaf_rn((float)k[2], world_block_size.z, world_origin.z)};
+		g.mx = {g.mn.x + world_block_size.x, g.mn.y + world_block_size.y, g.mn.z + world_block_size.z};
+		const uint32_t grid_offset = b * vol;
+		g.cells = cells + grid_offset;
+		if (entry >= far || exit <= near) break;
+		do { tm += step_size; } while (tm < entry);
+		dt = calc_dt(tm, dt_gamma, dt_min, dt_max);
+		t0 = tm - dt * 0.5f;
+		t1 = tm + dt * 0.5f;
+		while (tm <= exit && tm <= far && j < max_steps) {
+			const f3 p = {__fmaf_rn(tm, dir.x, o.x), __fmaf_rn(tm, dir.y, o.y), __fmaf_rn(tm, dir.z, o.z)};
+			const f3 u = to_unit<false>(g, p);
+			const int ix = clampi((int)(u.x * (float)rx), 0, rx - 1);
+			const int iy = clampi((int)(u.y * (float)ry), 0, ry - 1);
+			const int iz = clampi((int)(u.z * (float)rz), 0, rz - 1);
+			const int cell = ix * (ry * rz) + iy * rz + iz;
+			if (g.cells[cell] != 0) {
+				if (EMIT) {
+					t_starts[base + j] = t0;
+					t_ends[base + j] = t1;
+					ridx[base + j] = (int32_t)i;
+					blidx[base + j] = (int32_t)b;
+					if (gidx) gidx[base + j] = cell + (int32_t)grid_offset;
+				}
+				++j;
+				t0 = t1;
+				t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
+				tm = (t0 + t1) * 0.5f;
+			} else {
+				tm = skip_voxel<false>(g, tm, dt_min, p, dir, inv);
+				dt = calc_dt(tm, dt_gamma, dt_min, dt_max);
+				t0 = tm - dt * 0.5f;
+				t1 = tm + dt * 0.5f;
+			}
+		}
+	}
+	if (!EMIT) counts[i] = (int32_t)j;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Occupancy-value grid maintenance (the producer side of the marcher's input):
 //   new[v] = max(ema_decay * old[v], max over the samples that fall into voxel v)   for touched voxels, old[v] otherwise
 // (update_occ_val_grid[_idx]_ / update_batched_*, nr3d_lib/models/accelerations/occgrid/utils.py:80-125, there built on
@@ -365,6 +455,62 @@ extern "C" int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, cons
 	                   n_rays, rays_o, rays_d, t_min, t_max, roi, grid_res[0], grid_res[1], grid_res[2], grid_binary,
 	                   type, step_size, max_step_size, dt_gamma, 0u, batched, batch_inds, batch_data_size, packed_info,
 	                   (int32_t *)nullptr, t_starts, t_ends, ridx, bidx, gidx, (uint32_t *)nullptr);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+static int forest_march_check(const nr3d_forest_meta_t *forest, const void *a, const void *b, const void *c, const void *d,
+                              const void *e, const void *f, const void *g, const void *h, const void *grid) {
+	NR3D_CHECK(forest && forest->block_ks, "forest_ray_marching: forest meta or block_ks is NULL");
+	NR3D_CHECK(a && b && c && d && h && grid, "forest_ray_marching: NULL tensor pointer");
+	(void)e; (void)f; (void)g;       // segment arrays may be empty (NULL) when no ray crosses a block
+	return 0;
+}
+
+extern "C" int nr3d_forest_ray_marching_count(const nr3d_forest_meta_t *forest, uint32_t n_rays, const float *rays_o,
+                                              const float *rays_d, const float *t_min, const float *t_max,
+                                              const int32_t *seg_block_inds, const float *seg_entries,
+                                              const float *seg_exits, const int32_t *seg_pack_infos,
+                                              const int32_t grid_res[3], const uint8_t *grid_binary, float step_size,
+                                              float max_step_size, float dt_gamma, uint32_t max_steps,
+                                              int32_t *packed_info, int64_t *total_steps, void *scan_tmp, void *stream) {
+	NR3D_CHECK(total_steps && scan_tmp, "forest_ray_marching: NULL scratch pointer");
+	hipStream_t st = (hipStream_t)stream;
+	if (n_rays == 0) { NR3D_HIP_CHECK(hipMemsetAsync(total_steps, 0, sizeof(int64_t), st)); return 0; }
+	if (int rc = forest_march_check(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, seg_entries, seg_exits,
+	                                seg_pack_infos, grid_binary)) return rc;
+	NR3D_CHECK(packed_info, "forest_ray_marching: NULL packed_info");
+	int32_t *counts = (int32_t *)scan_tmp;
+	void *tiles = (char *)scan_tmp + (((uint64_t)n_rays * sizeof(int64_t) + 7) / 8) * 8;
+	const occ::f3 wo = {forest->world_origin[0], forest->world_origin[1], forest->world_origin[2]};
+	const occ::f3 wb = {forest->world_block_size[0], forest->world_block_size[1], forest->world_block_size[2]};
+	hipLaunchKernelGGL((occ::k_forest_march<false>), dim3(div_up(n_rays, occ::kBlock)), dim3(occ::kBlock), 0, st, forest->block_ks,
+	                   wo, wb, n_rays, rays_o, rays_d, t_min, t_max, seg_block_inds, seg_entries, seg_exits, seg_pack_infos,
+	                   grid_res[0], grid_res[1], grid_res[2], grid_binary, step_size, max_step_size, dt_gamma, max_steps,
+	                   (const int32_t *)nullptr, counts, (float *)nullptr, (float *)nullptr, (int32_t *)nullptr,
+	                   (int32_t *)nullptr, (int32_t *)nullptr);
+	NR3D_LAUNCH_CHECK();
+	return scan::pack_infos_from_counts<int32_t, int32_t>(n_rays, counts, packed_info, total_steps, tiles, st);
+}
+
+extern "C" int nr3d_forest_ray_marching_emit(const nr3d_forest_meta_t *forest, uint32_t n_rays, const float *rays_o,
+                                             const float *rays_d, const float *t_min, const float *t_max,
+                                             const int32_t *seg_block_inds, const float *seg_entries,
+                                             const float *seg_exits, const int32_t *seg_pack_infos,
+                                             const int32_t grid_res[3], const uint8_t *grid_binary, float step_size,
+                                             float max_step_size, float dt_gamma, const int32_t *packed_info,
+                                             float *t_starts, float *t_ends, int32_t *ridx, int32_t *blidx, int32_t *gidx,
+                                             void *stream) {
+	if (n_rays == 0) return 0;
+	if (int rc = forest_march_check(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, seg_entries, seg_exits,
+	                                seg_pack_infos, grid_binary)) return rc;
+	NR3D_CHECK(packed_info && t_starts && t_ends && ridx && blidx, "forest_ray_marching: NULL output pointer");
+	const occ::f3 wo = {forest->world_origin[0], forest->world_origin[1], forest->world_origin[2]};
+	const occ::f3 wb = {forest->world_block_size[0], forest->world_block_size[1], forest->world_block_size[2]};
+	hipLaunchKernelGGL((occ::k_forest_march<true>), dim3(div_up(n_rays, occ::kBlock)), dim3(occ::kBlock), 0, (hipStream_t)stream,
+	                   forest->block_ks, wo, wb, n_rays, rays_o, rays_d, t_min, t_max, seg_block_inds, seg_entries, seg_exits,
+	                   seg_pack_infos, grid_res[0], grid_res[1], grid_res[2], grid_binary, step_size, max_step_size, dt_gamma,
+	                   0u, packed_info, (int32_t *)nullptr, t_starts, t_ends, ridx, blidx, gidx);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

@@ -518,3 +518,140 @@ def occ_update_grid(grid, gidx, occ_val, ema_decay=1.0, bidx=None):
     """returns the updated copy: touched voxels get max(ema_decay * old, max of their samples), the rest keep old.
     grid [Rx,Ry,Rz] or [B,Rx,Ry,Rz] (then bidx [n] or gidx [B,n,3] / occ_val [B,n])"""
     return occ_apply_max(grid, occ_scatter_max(np.shape(grid), gidx, occ_val, bidx), ema_decay)
+
+
+# ------------------------------------------------------------------------------------------------
+# forest of blocks (csrc/forest/forest.h, lotd_forest.h, forest_marching.cu)
+# ------------------------------------------------------------------------------------------------
+class _ForestC(C.Structure):
+    _fields_ = [("octree", C.c_void_p), ("exsum", C.c_void_p), ("block_ks", C.c_void_p), ("n_trees", C.c_uint32),
+                ("level", C.c_uint32), ("level_poffset", C.c_uint32), ("continuity_enabled", C.c_int32)]
+
+
+class Forest:
+    """host copy of the reference's ForestMeta (forest_cpp_api.h:18-37)"""
+
+    def __init__(self, octree, exsum, block_ks, level, level_poffset, world_origin=(0, 0, 0), world_block_size=(1, 1, 1),
+                 continuity_enabled=True):
+        self.octree = np.ascontiguousarray(octree, np.uint8)
+        self.exsum = np.ascontiguousarray(exsum, np.int32)
+        self.block_ks = np.ascontiguousarray(block_ks, np.int16)
+        self.level, self.level_poffset = int(level), int(level_poffset)
+        self.n_trees = self.block_ks.shape[0]
+        self.world_origin = np.asarray(world_origin, np.float64)
+        self.world_block_size = np.asarray(world_block_size, np.float64)
+        self.continuity_enabled = bool(continuity_enabled)
+
+    def c(self):
+        return _ForestC(self.octree.ctypes.data, self.exsum.ctypes.data, self.block_ks.ctypes.data, self.n_trees,
+                        self.level, self.level_poffset, int(self.continuity_enabled))
+
+
+def forest_from_blocks(block_coords, level, **kw):
+    """Octree over the given integer block coordinates on `level`, in the layout kaolin's SPC uses and `identify`
+    walks: nodes breadth first, children of a node in child-index order (x<<2 | y<<1 | z), one occupancy byte per
+    non-leaf node, exsum = exclusive prefix sum of the bytes' popcounts (one extra trailing entry), node 0 = root.
+    Built level by level with python sets -- deliberately naive."""
+    coords = sorted({tuple(int(v) for v in c) for c in np.asarray(block_coords).reshape(-1, 3)})
+    assert all(0 <= v < (1 << level) for c in coords for v in c)
+    levels = [None] * (level + 1)
+    levels[level] = set(coords)
+    for l in range(level - 1, -1, -1):
+        levels[l] = {(x >> 1, y >> 1, z >> 1) for x, y, z in levels[l + 1]}
+    order = [[(0, 0, 0)]] if level >= 0 else []
+    octree = []
+    for l in range(level):
+        nxt = []
+        for x, y, z in order[l]:
+            bits = 0
+            for child in range(8):
+                k = (2 * x + ((child >> 2) & 1), 2 * y + ((child >> 1) & 1), 2 * z + (child & 1))
+                if k in levels[l + 1]:
+                    bits |= 1 << child
+                    nxt.append(k)
+            octree.append(bits)
+        order.append(nxt)
+    octree = np.array(octree, np.uint8)
+    pop = np.array([bin(b).count("1") for b in octree], np.int64)
+    exsum = np.concatenate([[0], np.cumsum(pop)]).astype(np.int32)
+    poffset = sum(len(o) for o in order[:level])
+    return Forest(octree, exsum, np.array(order[level], np.int16).reshape(-1, 3), level, poffset, **kw)
+
+
+def forest_identify(forest, ks):
+    ks = np.ascontiguousarray(ks, np.int16).reshape(-1, 3)
+    fc = forest.c()
+    lib().orc_forest_identify.restype = C.c_int32
+    return np.array([lib().orc_forest_identify(C.byref(fc), _p(ks[i:i + 1])) for i in range(ks.shape[0])], np.int32)
+
+
+def lotd_forest_fwd(meta, forest, x, params, block_inds=None, block_offsets=None, batch_data_size=0, max_level=None,
+                    need_dydx=False):
+    x, params = _f32(x), _f32(params)
+    N, E = x.shape[0], meta.n_encoded_dims
+    y = np.zeros((N, E), np.float32)
+    dydx = np.zeros((N, E, 3), np.float32) if need_dydx else None
+    bi, bo, bds = _batch_args(block_inds, block_offsets, batch_data_size)
+    fc = forest.c()
+    rc = lib().orc_lotd_forest_fwd(C.byref(meta), C.byref(fc), C.c_uint32(N), _p(x), _p(params), _p(bi), _p(bo), bds,
+                                   _ml(meta, max_level), _p(y), _p(dydx))
+    if rc:
+        raise RuntimeError("lotd forest: 3D Dense / VM / NPlaneMul / CP / Hash levels only")
+    return y, dydx
+
+
+def lotd_forest_bwd_dparam(meta, forest, dL_dy, x, params, block_inds=None, block_offsets=None, batch_data_size=0,
+                           max_level=None, dL_ddLdx=None, accum_double=False):
+    """dL_ddLdx None: dL/dparam; else d(dL/dx)/dparam"""
+    dL_dy, x, params, g2 = _f32(dL_dy), _f32(x), _f32(params), _f32(dL_ddLdx)
+    grad = np.zeros(params.shape[0], np.float32)
+    bi, bo, bds = _batch_args(block_inds, block_offsets, batch_data_size)
+    fc = forest.c()
+    rc = lib().orc_lotd_forest_bwd_dparam(C.byref(meta), C.byref(fc), C.c_uint32(x.shape[0]), _p(g2), _p(dL_dy), _p(x),
+                                          _p(params), _p(bi), _p(bo), bds, _ml(meta, max_level),
+                                          C.c_int(int(accum_double)), _p(grad), C.c_uint64(grad.shape[0]))
+    if rc:
+        raise RuntimeError("lotd forest: 3D Dense / VM / NPlaneMul / CP / Hash levels only")
+    return grad
+
+
+def lotd_forest_bwd_bwd_dx(meta, forest, dL_ddLdx, dL_dy, x, params, block_inds=None, block_offsets=None,
+                           batch_data_size=0, max_level=None):
+    dL_ddLdx, dL_dy, x, params = _f32(dL_ddLdx), _f32(dL_dy), _f32(x), _f32(params)
+    out = np.zeros((x.shape[0], 3), np.float32)
+    bi, bo, bds = _batch_args(block_inds, block_offsets, batch_data_size)
+    fc = forest.c()
+    rc = lib().orc_lotd_forest_bwd_bwd_dx(C.byref(meta), C.byref(fc), C.c_uint32(x.shape[0]), _p(dL_ddLdx), _p(dL_dy),
+                                          _p(x), _p(params), _p(bi), _p(bo), bds, _ml(meta, max_level), _p(out))
+    if rc:
+        raise RuntimeError("lotd forest: 3D Dense / VM / NPlaneMul / CP / Hash levels only")
+    return out
+
+
+def forest_ray_marching(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, seg_entries, seg_exits, seg_pack_infos,
+                        grid_binary, step_size, max_step_size, dt_gamma, max_steps, return_gidx=False):
+    """-> (packed_info int32 [n_rays,2], t_starts [S,1], t_ends [S,1], ridx, blidx, gidx | None)"""
+    o, d, tn, tf = _f32(rays_o), _f32(rays_d), _f32(t_min), _f32(t_max)
+    sb = np.ascontiguousarray(seg_block_inds, np.int32)
+    se, sx = _f32(seg_entries), _f32(seg_exits)
+    sp = np.ascontiguousarray(seg_pack_infos, np.int32)
+    grid = np.ascontiguousarray(grid_binary).astype(np.uint8)
+    res = np.array(grid.shape[1:], np.int32)
+    wo, wb = forest.world_origin.astype(np.float32), forest.world_block_size.astype(np.float32)
+    n = o.shape[0]
+    num = np.zeros(n, np.int32)
+
+    def run(pi, ts, te, ridx, bl, gi):
+        lib().orc_forest_march(C.c_uint32(n), _p(o), _p(d), _p(tn), _p(tf), _p(sb), _p(se), _p(sx), _p(sp), _p(res),
+                               _p(grid), _p(forest.block_ks), _p(wo), _p(wb), C.c_float(step_size),
+                               C.c_float(max_step_size), C.c_float(dt_gamma), C.c_uint32(max_steps), _p(pi), _p(num),
+                               _p(ts), _p(te), _p(ridx), _p(bl), _p(gi))
+    run(None, None, None, None, None, None)
+    cs = np.cumsum(num, dtype=np.int32)
+    pi = np.ascontiguousarray(np.stack([cs - num, num], 1).astype(np.int32))
+    S = int(cs[-1]) if n else 0
+    ts, te = np.zeros((S, 1), np.float32), np.zeros((S, 1), np.float32)
+    ridx, bl = np.zeros(S, np.int32), np.zeros(S, np.int32)
+    gi = np.zeros(S, np.int32) if return_gidx else None
+    run(pi, ts, te, ridx, bl, gi)
+    return pi, ts, te, ridx, bl, gi

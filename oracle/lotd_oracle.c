@@ -228,7 +228,58 @@ typedef struct {
 	const float *grid;                         /* already offset to batch + level */
 	uint32_t base;                             /* batch_offset + level_offsets[level] */
 	int smooth;
+	/* forest mode only (lotd_forest.h): the block of the point and how to find its neighbours' parameters */
+	const orc_forest_t *forest;
+	int16_t bk[3];
+	uint32_t block_offset, block_n_params;
+	const int64_t *block_offsets;
 } ctx_t;
+
+/* Set by the orc_lotd_forest_* wrappers around the shared bodies below; NULL = plain LoTD. */
+static const orc_forest_t *g_forest = NULL;
+
+/* identify  (csrc/forest/forest.h:25-58, modified from kaolin): index of the octree node at integer
+ * coordinates k on `level` in the breadth-first point hierarchy, or -1 */
+int32_t orc_forest_identify(const orc_forest_t *fo, const int16_t *k) {
+	const int maxval = (1 << fo->level) - 1;
+	if (k[0] < 0 || k[1] < 0 || k[2] < 0 || k[0] > maxval || k[1] > maxval || k[2] > maxval) return -1;
+	int ord = 0;
+	for (uint32_t l = 0; l < fo->level; ++l) {
+		const uint32_t depth = fo->level - l - 1;
+		const uint32_t mask = 1u << depth;
+		const uint32_t child = ((mask & (uint32_t)k[0]) << 2 | (mask & (uint32_t)k[1]) << 1 | (mask & (uint32_t)k[2])) >> depth;
+		const uint8_t bits = fo->octree[ord];
+		if (!(bits & (1u << child))) return -1;
+		const uint32_t cnt = (uint32_t)__builtin_popcount(bits & ((2u << child) - 1u));   /* inclusive */
+		ord = fo->exsum[ord] + (int)cnt;
+		if (depth == 0) return ord;
+	}
+	return ord;
+}
+
+/* the "continuity fixing" of every forest_*_n_linear (lotd_forest.h:55-88 and its twins): corner index 0 is
+ * the left neighbour's res-1, res+1 the right neighbour's 0, 1..res the block's own 0..res-1.
+ * -> 0 when the corner has no parameters (continuity off / neighbour missing); else the corner's position inside
+ * its block and the offset of that block's parameters relative to the point's own block. */
+static int forest_resolve(const ctx_t *c, const uint32_t *lp, uint32_t *lpl, int64_t *delta) {
+	int16_t bl[3];
+	int changed = 0;
+	for (uint32_t d = 0; d < c->D; ++d) {
+		if (lp[d] == 0) { bl[d] = (int16_t)(c->bk[d] - 1); lpl[d] = c->res[d] - 1; changed = 1; }
+		else if (lp[d] == c->res[d] + 1) { bl[d] = (int16_t)(c->bk[d] + 1); lpl[d] = 0; changed = 1; }
+		else { bl[d] = c->bk[d]; lpl[d] = lp[d] - 1; }
+	}
+	*delta = 0;
+	if (changed) {
+		if (!c->forest->continuity_enabled) return 0;
+		const int32_t pidx = orc_forest_identify(c->forest, bl);
+		const int32_t bi = pidx == -1 ? -1 : pidx - (int32_t)c->forest->level_poffset;
+		if (bi < 0) return 0;
+		const uint32_t off = c->block_offsets ? (uint32_t)c->block_offsets[bi] : (uint32_t)bi * c->block_n_params;
+		*delta = (int64_t)off - (int64_t)c->block_offset;
+	}
+	return 1;
+}
 
 /* pos_fract, all three overloads  (lotd_cuda.h:959-1077); scale = res-2 (lotd_encoding.h:185-191) */
 static void pos_fract(ctx_t *c, const float *x) {
@@ -263,6 +314,13 @@ static int setup_ctx(ctx_t *c, const orc_lotd_meta_t *m, uint32_t level, uint32_
 	                                            : batch_ind * m->level_offsets[m->n_levels];
 	c->base = batch_offset + m->level_offsets[level];
 	c->grid = params ? params + c->base : NULL;
+	c->forest = g_forest;
+	if (g_forest) {                 /* lotd_forest.h:213-216 */
+		c->block_offset = batch_offset;
+		c->block_n_params = m->level_offsets[m->n_levels];
+		c->block_offsets = batch_offsets;
+		for (int d = 0; d < 3; ++d) c->bk[d] = g_forest->block_ks[3 * (size_t)batch_ind + d];
+	}
 	c->D = m->n_dims_to_encode;
 	c->size = m->level_sizes[level];
 	c->F = m->level_n_feats[level];
@@ -270,7 +328,8 @@ static int setup_ctx(ctx_t *c, const orc_lotd_meta_t *m, uint32_t level, uint32_
 	c->smooth = (m->interpolation_type == 1);
 	for (uint32_t d = 0; d < c->D; ++d) {
 		c->res[d] = m->level_res[level][d];
-		c->scale[d] = (float)(c->res[d] - 2);
+		c->scale[d] = g_forest ? (float)c->res[d]          /* "NOTE: for forest", lotd_forest.h:231 */
+		                       : (float)(c->res[d] - 2);
 	}
 	pos_fract(c, x + (size_t)i * c->D);
 	return 1;
@@ -282,6 +341,12 @@ static int setup_ctx(ctx_t *c, const orc_lotd_meta_t *m, uint32_t level, uint32_
 static void grid_val(const ctx_t *c, const uint32_t *lp, uint32_t feat_off, uint32_t nf, float *val) {
 	const float *g = c->grid;
 	const uint32_t D = c->D, F = c->F;
+	uint32_t lpl[ORC_MAX_DIMS];
+	if (c->forest) {
+		int64_t delta;
+		if (!forest_resolve(c, lp, lpl, &delta)) { for (uint32_t f = 0; f < nf; ++f) val[f] = 0.f; return; }
+		g += delta; lp = lpl;
+	}
 	switch (c->type) {
 	case ORC_Dense: {
 		uint32_t idx = idx_dense(D, feat_off, c->res, F, lp);
@@ -337,6 +402,14 @@ static void add_grad(const ctx_t *c, const uint32_t *lp, uint32_t feat_off, uint
                      const float *grad, float weight, acc_t a) {
 	const float *g = c->grid;
 	const uint32_t D = c->D, F = c->F;
+	uint32_t lpl[ORC_MAX_DIMS];
+	if (c->forest) {
+		int64_t delta;
+		if (!forest_resolve(c, lp, lpl, &delta)) return;
+		g += delta; lp = lpl;
+		if (a.g) a.g += delta;
+		if (a.gd) a.gd += delta;
+	}
 	switch (c->type) {
 	case ORC_Dense: {
 		uint32_t idx = idx_dense(D, feat_off, c->res, F, lp);
@@ -395,6 +468,12 @@ static float calc_dLdx(const ctx_t *c, const uint32_t *lp, uint32_t feat_off, ui
 	const float *g = c->grid;
 	const uint32_t D = c->D, F = c->F;
 	float r = 0.f;
+	uint32_t lpl[ORC_MAX_DIMS];
+	if (c->forest) {
+		int64_t delta;
+		if (!forest_resolve(c, lp, lpl, &delta)) return 0.f;
+		g += delta; lp = lpl;
+	}
 	switch (c->type) {
 	case ORC_Dense: {
 		uint32_t idx = idx_dense(D, feat_off, c->res, F, lp);
@@ -849,5 +928,56 @@ int orc_lotd_grid_index(const orc_lotd_meta_t *m, uint32_t N, const float *x,
 				for (uint32_t f = 0; f < G; ++f) out[idx + f * C] = (int64_t)(uint32_t)(c.base + ind + f);
 			}
 		}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * LoTD forest  (csrc/lotd/include/lotd/lotd_forest.h): the same N-linear bodies with scale = res, the corner
+ * remap of forest_resolve and per-point block_inds / block_offsets in place of the batch arguments.
+ * The reference's forest kernels switch over Dense / VectorMatrix / NPlaneMul / CP / Hash only (:263-311);
+ * other level types return 1 here.
+ * ---------------------------------------------------------------------------------------------- */
+static int forest_types_ok(const orc_lotd_meta_t *m) {
+	if (m->n_dims_to_encode != 3) return 0;
+	for (uint32_t l = 0; l < m->n_levels; ++l) {
+		const uint32_t t = m->level_types[l];
+		if (!(t == ORC_Dense || t == ORC_VectorMatrix || t == ORC_NPlaneMul || t == ORC_CP || t == ORC_Hash)) return 0;
+	}
+	return 1;
+}
+
+int orc_lotd_forest_fwd(const orc_lotd_meta_t *m, const orc_forest_t *fo, uint32_t N, const float *x,
+                        const float *params, const int64_t *block_inds, const int64_t *block_offsets,
+                        uint32_t batch_data_size, int32_t max_level, float *y, float *dy_dx) {
+	if (!forest_types_ok(m)) return 1;
+	g_forest = fo;
+	orc_lotd_fwd(m, N, x, params, block_inds, block_offsets, batch_data_size, max_level, y, dy_dx);
+	g_forest = NULL;
+	return 0;
+}
+
+int orc_lotd_forest_bwd_dparam(const orc_lotd_meta_t *m, const orc_forest_t *fo, uint32_t N, const float *dL_ddLdx,
+                               const float *dL_dy, const float *x, const float *params, const int64_t *block_inds,
+                               const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level,
+                               int accum_double, float *grad, uint64_t numel) {
+	if (!forest_types_ok(m)) return 1;
+	if (max_level <= -1) return 0;
+	g_forest = fo;
+	/* a corner may belong to a neighbouring block, but always to the SAME level: levels stay disjoint, so the
+	 * per-level parallel loop of bwd_dparam_all remains race free */
+	bwd_dparam_all(m, N, dL_ddLdx, dL_dy, x, params, block_inds, block_offsets, batch_data_size, max_level,
+	               accum_double, grad, numel);
+	g_forest = NULL;
+	return 0;
+}
+
+int orc_lotd_forest_bwd_bwd_dx(const orc_lotd_meta_t *m, const orc_forest_t *fo, uint32_t N, const float *dL_ddLdx,
+                               const float *dL_dy, const float *x, const float *params, const int64_t *block_inds,
+                               const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level,
+                               float *dL_dx) {
+	if (!forest_types_ok(m)) return 1;
+	g_forest = fo;          /* kernel_lod_forest_backward_input_backward_input: Dense / VM / Hash only (:1029-1057) */
+	orc_lotd_bwd_bwd_dx(m, N, dL_ddLdx, dL_dy, x, params, block_inds, block_offsets, batch_data_size, max_level, dL_dx);
+	g_forest = NULL;
 	return 0;
 }

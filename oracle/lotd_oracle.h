@@ -40,6 +40,15 @@ typedef struct {
 	uint32_t reserved;
 } orc_lotd_meta_t;
 
+/* csrc/forest/forest.h:60-97 (ForestMetaRef); block_ks is int16 [n_trees, 3] */
+typedef struct {
+	const uint8_t *octree;
+	const int32_t *exsum;
+	const int16_t *block_ks;
+	uint32_t n_trees, level, level_poffset;
+	int32_t continuity_enabled;
+} orc_forest_t;
+
 /* returns 0 on success, nonzero + message in errbuf otherwise */
 int orc_lotd_create_meta(int32_t n_input_dim, uint32_t n_levels, const int32_t *res_multidim /*[L,D]*/,
                          const int32_t *n_feats, const int32_t *types, uint32_t hashmap_size,
@@ -75,4 +84,18 @@ int orc_lotd_grid_index(const orc_lotd_meta_t *m, uint32_t N, const float *x,
                         const int64_t *batch_inds, const int64_t *batch_offsets,
                         uint32_t batch_data_size, int32_t max_level,
                         int64_t *grid_inds /*[N,E,2^D] zero-init*/);
+
+int32_t orc_forest_identify(const orc_forest_t *fo, const int16_t *k /*[3]*/);
+int orc_lotd_forest_fwd(const orc_lotd_meta_t *m, const orc_forest_t *fo, uint32_t N, const float *x,
+                        const float *params, const int64_t *block_inds, const int64_t *block_offsets,
+                        uint32_t batch_data_size, int32_t max_level, float *y, float *dy_dx);
+/* dL_ddLdx == NULL: first order; else d(dL/dx)/dparam */
+int orc_lotd_forest_bwd_dparam(const orc_lotd_meta_t *m, const orc_forest_t *fo, uint32_t N, const float *dL_ddLdx,
+                               const float *dL_dy, const float *x, const float *params, const int64_t *block_inds,
+                               const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level,
+                               int accum_double, float *grad, uint64_t numel);
+int orc_lotd_forest_bwd_bwd_dx(const orc_lotd_meta_t *m, const orc_forest_t *fo, uint32_t N, const float *dL_ddLdx,
+                               const float *dL_dy, const float *x, const float *params, const int64_t *block_inds,
+                               const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level,
+                               float *dL_dx);
 #endif

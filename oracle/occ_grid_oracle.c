@@ -183,3 +183,71 @@ void orc_march_emit(uint32_t n_rays, const float *rays_o, const float *rays_d, c
 		          bidx ? bidx + base : NULL, gidx ? gidx + base : NULL, NULL);
 	}
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Forest of occupancy grids  (csrc/occ_grid/src/forest_marching.cu:16-143).  The block segments of every ray
+ * (block index, entry / exit depth; packed per ray) come from the octree ray trace (kaolin, not restated).
+ * One call = one pass: packed_info == NULL counts (num_steps), otherwise emits.
+ * `local_roi_min = world_origin + k * world_block_size` is one expression: FMA under nvcc's contraction.
+ * Per segment the marcher first steps `t_mid += step_size` at least once (do-while, :99-101) -- kept.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_forest_march(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                      const float *t_max, const int32_t *seg_block_inds, const float *seg_entries,
+                      const float *seg_exits, const int32_t *seg_pack_infos, const int *res,
+                      const uint8_t *grid /*[B,Rx,Ry,Rz]*/, const int16_t *block_ks, const float *world_origin,
+                      const float *world_block_size, float step_size, float max_step_size, float dt_gamma,
+                      uint32_t max_steps_in, const int32_t *packed_info, int32_t *num_steps, float *t_starts,
+                      float *t_ends, int32_t *ridx, int32_t *blidx, int32_t *gidx) {
+	const uint32_t vol = (uint32_t)(res[0] * res[1] * res[2]);
+	for (uint32_t i = 0; i < n_rays; ++i) {
+		const uint32_t seg_begin = (uint32_t)seg_pack_infos[2 * i], seg_len = (uint32_t)seg_pack_infos[2 * i + 1];
+		uint32_t max_steps = max_steps_in, base = 0;
+		if (packed_info) { base = (uint32_t)packed_info[2 * i]; max_steps = (uint32_t)packed_info[2 * i + 1]; }
+		const f3 origin = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
+		const f3 dir = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
+		const f3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+		const float near = t_min[i], far = t_max[i];
+		const float dt_min = step_size, dt_max = max_step_size;
+		uint32_t j = 0;
+		float t0 = near;
+		float dt = calc_dt(t0, dt_gamma, dt_min, dt_max);
+		float t1 = t0 + dt;
+		float t_mid = (t0 + t1) * 0.5f;
+		for (uint32_t s = 0; s < seg_len; ++s) {
+			const float cur_entry = seg_entries[seg_begin + s], cur_exit = seg_exits[seg_begin + s];
+			const uint32_t b = (uint32_t)seg_block_inds[seg_begin + s];
+			const int16_t *k = block_ks + 3 * (size_t)b;
+			const f3 mn = {fmaf((float)k[0], world_block_size[0], world_origin[0]),
+			               fmaf((float)k[1], world_block_size[1], world_origin[1]),
+			               fmaf((float)k[2], world_block_size[2], world_origin[2])};
+			const f3 mx = {mn.x + world_block_size[0], mn.y + world_block_size[1], mn.z + world_block_size[2]};
+			const uint32_t grid_offset = b * vol;
+			if (cur_entry >= far || cur_exit <= near) break;
+			do { t_mid += step_size; } while (t_mid < cur_entry);
+			dt = calc_dt(t_mid, dt_gamma, dt_min, dt_max);
+			t0 = t_mid - dt * 0.5f;
+			t1 = t_mid + dt * 0.5f;
+			while (t_mid <= cur_exit && t_mid <= far && j < max_steps) {
+				const f3 p = {fmaf(t_mid, dir.x, origin.x), fmaf(t_mid, dir.y, origin.y), fmaf(t_mid, dir.z, origin.z)};
+				const int gi = grid_idx_at(roi_to_unit(p, mn, mx), res);     /* block_grid_occupied_at :16-25: no ROI test */
+				if (grid[(size_t)grid_offset + (uint32_t)gi]) {
+					if (packed_info) {
+						t_starts[base + j] = t0; t_ends[base + j] = t1; ridx[base + j] = (int32_t)i;
+						blidx[base + j] = (int32_t)b;
+						if (gidx) gidx[base + j] = gi + (int32_t)grid_offset;
+					}
+					++j;
+					t0 = t1;
+					t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
+					t_mid = (t0 + t1) * 0.5f;
+				} else {
+					t_mid = advance_next_voxel(t_mid, dt_min, p, dir, inv, mn, mx, res);
+					dt = calc_dt(t_mid, dt_gamma, dt_min, dt_max);
+					t0 = t_mid - dt * 0.5f;
+					t1 = t_mid + dt * 0.5f;
+				}
+			}
+		}
+		if (!packed_info) num_steps[i] = (int32_t)j;
+	}
+}
