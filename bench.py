@@ -212,6 +212,39 @@ def c1_dense_rate(dev):
                 max_rel_diff=float(f"{err:.2e}"))
 
 
+def forest_lotd_rate(dev, log2n=20, iters=10):
+    """SURVEY 8f rank 4 as an extra figure: LoTD over a forest of 8 blocks (dense level-1 octree, continuity on), the
+    NGP config's first 8 levels (4 Dense + 4 Hash) per block, 2^20 points spread over the blocks:
+    fwd(+dy/dx) + dL/dx + dL/dparam"""
+    from nr3d_lib_amd.bindings import _lotd
+    from nr3d_lib_amd.models.grid_encodings.lotd import gen_ngp_cfg
+    from nr3d_lib_amd.models.spatial import ForestBlockSpace
+    cfg = gen_ngp_cfg()
+    L = 8
+    meta = _lotd.LoDMeta(3, cfg["lod_res"][:L], cfg["lod_n_feats"][:L], cfg["lod_types"][:L], cfg["hashmap_size"])
+    space = ForestBlockSpace(device=dev)
+    space.populate(mode="dense", level=1)
+    metas = (meta, space.meta)
+    n = 1 << log2n
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(n, 3, generator=g).clamp_(1e-6, 1 - 1e-6).to(dev)
+    bi = torch.randint(0, space.n_trees, (n,), generator=g).to(dev)
+    params = torch.empty(space.n_trees * meta.n_params).uniform_(-1e-4, 1e-4, generator=g).to(dev)
+    gy = (torch.randn(n, meta.n_encoded_dims, generator=g) / 1e4).to(dev)
+
+    def one():
+        y, j = _lotd.lod_fwd(metas, x, params, bi, need_input_grad=True)
+        return _lotd.lod_bwd(metas, gy, x, params, j, bi, need_input_grad=True, need_param_grad=True)
+    one(); one()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / iters * 1e3
+    return dict(workload=f"forest LoTD, {space.n_trees} blocks x {L} levels (4 Dense + 4 Hash), 2^{log2n} points, "
+                         f"fwd(+dy/dx) + dL/dx + dL/dparam (binned)", ms_per_iter=round(ms, 3),
+                mpoints_per_s=round(n / ms / 1e3, 2))
+
+
 def c4_mixed_rate():
     """BASELINE configs[3] as an extra figure (tools/bench_c4.py): mixed Dense/VM/CP LoTD, 2^22 points,
     fwd + dL/dx + dL/dparam + the three second-order passes"""
@@ -337,16 +370,19 @@ def main():
                          "whole_step_frac": round(sum(bpp.values()) * N / (sum(kms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
         if world == 1 and not args.no_extra:
-            try:
-                out["extra"] = {"march_composite": march_composite_rate(dev),
-                                "march_composite_262144_rays": march_composite_rate(dev, iters=5, side=512)}
-                out["extra"]["c1_dense_fwd"] = c1_dense_rate(dev)
-                out["extra"]["full_loop_1gpu"] = full_loop_rate(dev)
-                torch.cuda.empty_cache()
-                out["extra"]["c4_mixed_lotd"] = c4_mixed_rate()
-                out["extra"]["lotd_2p24_points"] = lotd_large_batch_rate(24)
-            except Exception as ex:   # the extra figure must never cost the headline line
-                out["extra"] = {"march_composite_error": repr(ex)}
+            out["extra"] = {}
+            for name, fn in (("march_composite", lambda: march_composite_rate(dev)),
+                             ("march_composite_262144_rays", lambda: march_composite_rate(dev, iters=5, side=512)),
+                             ("c1_dense_fwd", lambda: c1_dense_rate(dev)),
+                             ("full_loop_1gpu", lambda: full_loop_rate(dev)),
+                             ("forest_lotd", lambda: forest_lotd_rate(dev)),
+                             ("c4_mixed_lotd", c4_mixed_rate),
+                             ("lotd_2p24_points", lambda: lotd_large_batch_rate(24))):
+                try:                     # an extra figure must never cost the headline line (or the other extras)
+                    torch.cuda.empty_cache()
+                    out["extra"][name] = fn()
+                except Exception as ex:
+                    out["extra"][name] = {"error": repr(ex)[:300]}
         if multi_march is not None:
             out.setdefault("extra", {})["march_composite_262144_rays_per_gpu"] = multi_march
         if world == 1 and not args.no_cpu_baseline:

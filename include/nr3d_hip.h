@@ -178,11 +178,16 @@ int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, con
 
 /* dL/dparam (dL_ddLdx == NULL; kernel_lod_forest_backward_grid :414-542) or d(dL/dx)/dparam
  * (kernel_lod_forest_backward_input_backward_grid :636-773).  dL_dparam [n_trees * n_params] ZERO-INIT by the caller;
- * contributions of corners that lie in a neighbouring block go to that block's parameters. */
+ * contributions of corners that lie in a neighbouring block go to that block's parameters.
+ * workspace: >= nr3d_lotd_dparam_workspace_bytes(meta, n_points, n_trees) bytes of device scratch, or NULL.  With it,
+ * metas whose levels are all Dense / Hash take the atomic-free sort + segmented-sum path of nr3d_lotd_bwd_dparam (the
+ * blocks play the role of batch entries; a corner owned by a neighbour is binned into that block's table); otherwise
+ * (or when the path does not apply) fp32 hardware atomics. */
 int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                                 uint32_t n_points, const float *dL_ddLdx, const float *dL_dy, const float *x,
                                 const float *params, const int64_t *block_inds, const int64_t *block_offsets,
-                                uint32_t batch_data_size, int32_t max_level, float *dL_dparam, void *stream);
+                                uint32_t batch_data_size, int32_t max_level, float *dL_dparam, void *workspace,
+                                uint64_t workspace_bytes, void *stream);
 
 /* d(dL/dx)/dx (kernel_lod_forest_backward_input_backward_input :929-1065): Dense / VectorMatrix / Hash levels
  * contribute.  dL_dx [N,3] is overwritten.  (dL/dx and dL/d(dL/dy) are contractions with dy_dx:

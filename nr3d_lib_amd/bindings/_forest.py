@@ -97,6 +97,14 @@ def _check(fn, metas, input, params, block_inds, block_offsets, batch_data_size)
     return m, fo, N, bds
 
 
+def _workspace(m, fo, N, dev):
+    """scratch of the atomic-free parameter-gradient path (Dense/Hash metas; blocks play the role of batch entries)"""
+    from . import _lotd
+    if not all(t in (int(_lotd.LoDType.Dense), int(_lotd.LoDType.Hash)) for t in m.level_types):
+        return None, 0
+    return _lotd._dparam_workspace(m, N, dev, int(fo.n_trees))
+
+
 def lod_fwd(metas, input, params, batch_inds=None, batch_offsets=None, batch_data_size=None, max_level=None,
             need_input_grad=None):
     from . import _lotd
@@ -150,9 +158,11 @@ def lod_bwd(metas, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offs
         if need_param_grad:
             x32, p32 = _lotd._f32c(input.detach()), _lotd._f32c(params.detach())
             c = fo._c()
+            ws, wsb = _workspace(m, fo, N, dev)
             H.check(H.lib().nr3d_lotd_forest_bwd_dparam(
                 C.byref(m._cmeta()), H.ptr(m._dev(dev)), C.byref(c), H.u32(N), None, H.ptr(g32), H.ptr(x32), H.ptr(p32),
-                H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparam), st))
+                H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparam), H.ptr(ws),
+                C.c_uint64(wsb), st))
     return _lotd._cast(dL_dx, input.dtype), _lotd._cast(dL_dparam, params.dtype)
 
 
@@ -200,9 +210,10 @@ def lod_bwd_bwd_input(metas, dL_ddLdx, dL_dy, input, params, dy_dx=None, batch_i
                 cm, md, C.byref(c), H.u32(N), H.ptr(v32), H.ptr(g32), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
                 H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dx), st))
         if need_dp:
+            ws, wsb = _workspace(m, fo, N, dev)
             H.check(H.lib().nr3d_lotd_forest_bwd_dparam(
                 cm, md, C.byref(c), H.u32(N), H.ptr(v32), H.ptr(g32), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
-                H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparams), st))
+                H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparams), H.ptr(ws), C.c_uint64(wsb), st))
     return _lotd._cast(dL_ddLdy, dL_dy.dtype), _lotd._cast(dL_dparams, params.dtype), _lotd._cast(dL_dx, input.dtype)
 
 

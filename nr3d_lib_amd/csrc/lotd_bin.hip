@@ -350,13 +350,35 @@ __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c,
 	return 0;
 }
 
-template <int D, int G, bool SECOND, int NR, bool DH>
-__global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
-                                                           int32_t max_level, uint32_t smooth, const float *__restrict__ x,
-                                                           const float *__restrict__ vin_, const float *__restrict__ g,
-                                                           int64_t g_sn, int64_t g_se, const float *__restrict__ params,
-                                                           Batch ba, uint32_t *__restrict__ rec,
-                                                           uint32_t *__restrict__ offs_g) {
+// forest (FO): the 8 corner updates of a Dense / Hash level, each in the table of the block that owns the corner
+// (virtual entry = owner block * level size + entry).  A corner nobody owns becomes a zero update of the point's own block.
+template <int G, int NR>
+__device__ __forceinline__ uint32_t emit_forest(const ForestDev &fo, const Lvl &L, const Cell<3> &c, const float (&w)[8],
+                                                const float (&grad)[G], const int (&bk)[3], uint32_t bi,
+                                                uint32_t (&ent)[NR], float (&val)[NR][G]) {
+	if constexpr (NR >= 8) {
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) {
+			uint32_t p[3], pl[3], owner = bi;
+			corner_pos<3>(c, k, p);
+			const bool ok = resolve_block(fo, L, bk, p, pl, owner);
+			const uint32_t e = (L.type == NR3D_LOD_Dense) ? entry_dense<3>(L, pl) : entry_hash<3>(L, pl);
+			ent[k] = ok ? owner * L.size + e : bi * L.size;
+#pragma unroll
+			for (int f = 0; f < G; ++f) val[k][f] = ok ? grad[f] * w[k] : 0.0f;
+		}
+		return 8;
+	}
+	return 0;
+}
+
+template <int D, int G, bool SECOND, int NR, bool DH, bool FO>
+__device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                         int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                         const float *__restrict__ vin_, const float *__restrict__ g,
+                                         int64_t g_sn, int64_t g_se, const float *__restrict__ params,
+                                         const Batch &ba, const ForestDev &fo, uint32_t *__restrict__ rec,
+                                         uint32_t *__restrict__ offs_g) {
 	constexpr int BP = BinCfg<G, NR>::BP;
 	constexpr uint32_t cap = BinCfg<G, NR>::cap;
 	constexpr int C = 1 << D;
@@ -392,7 +414,7 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 #pragma unroll
 		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
 		Cell<D> c;
-		locate<D>(xp, L, smooth != 0, c);
+		if constexpr (FO) locate_forest(xp, L, smooth != 0, c); else locate<D>(xp, L, smooth != 0, c);
 		float grad[G], w[C];
 #pragma unroll
 		for (int f = 0; f < G; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(q * G + f) * g_se];
@@ -416,7 +438,14 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 				w[k] = sum;
 			}
 		}
-		n_rec = emit_updates<D, G, NR, DH, SECOND>(L, c, w, grad, a, vin, params + (pbase + L.off), meta_cnt_of(md, q) * G, ent, val);
+		if constexpr (FO) {
+			int bk[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) bk[d] = fo.block_ks[3 * (size_t)bi + d];
+			n_rec = emit_forest<G, NR>(fo, L, c, w, grad, bk, bi, ent, val);
+		} else {
+			n_rec = emit_updates<D, G, NR, DH, SECOND>(L, c, w, grad, a, vin, params + (pbase + L.off), meta_cnt_of(md, q) * G, ent, val);
+		}
 #pragma unroll
 		for (int d = 0; d < D; ++d) cell[d] = c.g[d];
 	}
@@ -457,7 +486,7 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 #pragma unroll
 		for (uint32_t r = 0; r < (uint32_t)NR; ++r)
 			if (r < n_rec) {
-				ent[r] += bi * L.size;
+				if (!FO) ent[r] += bi * L.size;          // forest records already carry their owner block
 				rank[r] = atomicAdd(&hist[ent[r] >> plan.epb_log2], 1u);
 			}
 	}
@@ -513,6 +542,27 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 	}
 	uint32_t *ob = offs_g + plan.offs_base[ql];
 	for (uint32_t b = threadIdx.x; b <= nb; b += BP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
+}
+
+template <int D, int G, bool SECOND, int NR, bool DH>
+__global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                           int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                           const float *__restrict__ vin_, const float *__restrict__ g,
+                                                           int64_t g_sn, int64_t g_se, const float *__restrict__ params,
+                                                           Batch ba, uint32_t *__restrict__ rec,
+                                                           uint32_t *__restrict__ offs_g) {
+	bin_body<D, G, SECOND, NR, DH, false>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, ForestDev{}, rec, offs_g);
+}
+
+// stage A for a forest of blocks (3-D, Dense / Hash levels): same sort, corner owners resolved through the octree
+template <int G, bool SECOND>
+__global__ __launch_bounds__((BinCfg<G, 8>::BP)) void k_bin_forest(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
+                                                                  uint32_t n, int32_t max_level, uint32_t smooth,
+                                                                  const float *__restrict__ x, const float *__restrict__ vin_,
+                                                                  const float *__restrict__ g, int64_t g_sn, int64_t g_se,
+                                                                  const float *__restrict__ params, Batch ba, ForestDev fo,
+                                                                  uint32_t *__restrict__ rec, uint32_t *__restrict__ offs_g) {
+	bin_body<3, G, SECOND, 8, true, true>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, fo, rec, offs_g);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -855,7 +905,7 @@ template <int D, int G, int NR, bool DH>
 static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
                         int32_t max_level, const float *xc, const float *vc, const float *gc, int64_t sn, int64_t se,
                         const float *params, const Batch &ba, uint32_t *rec, uint32_t *offs, uint32_t *plan_buf,
-                        float *partial, float *dparam, hipStream_t st) {
+                        float *partial, float *dparam, hipStream_t st, const ForestDev *fo = nullptr) {
 	constexpr int BP = BinCfg<G, NR>::BP;
 	uint32_t nb_max = 0;
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
@@ -872,7 +922,24 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
 		attr_set = true;
 	}
-	if (second)
+	if (fo) {
+		if constexpr (D == 3 && NR == 8 && DH) {
+			static bool fattr_dev[64] = {};
+			if (!fattr_dev[dev_id & 63]) {
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				fattr_dev[dev_id & 63] = true;
+			}
+			if (second)
+				hipLaunchKernelGGL((k_bin_forest<G, true>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+				                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, *fo, rec, offs);
+			else
+				hipLaunchKernelGGL((k_bin_forest<G, false>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+				                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, *fo, rec, offs);
+		} else {
+			return ::nr3d::fail("LoTD forest: the binned path handles 3-D Dense/Hash metas only");
+		}
+	} else if (second)
 		hipLaunchKernelGGL((k_bin<D, G, true, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
 		                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, rec, offs);
 	else
@@ -891,10 +958,11 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
-                  hipStream_t st, bool &handled) {
+                  hipStream_t st, bool &handled, const ForestDev *forest) {
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
+	if (forest && !(meta->c_hash_only && meta->n_dims_to_encode == 3)) return 0;
 	if (!workspace || !binnable(meta) || !layout(meta, nc, n_batches, lay)) return 0;
 	if (workspace_bytes < lay.total) return 0;
 	handled = true;
@@ -930,7 +998,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			DISPATCH_DG_BIN(D, G, {
 				// hash-only metas (every level Dense or Hash) get kernels without the product-type code
 				if (meta->c_hash_only) {
-					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
+					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st, forest);
 					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
 				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
 				else if (cls == 16) {

@@ -507,13 +507,105 @@ __device__ __forceinline__ float corner_dot(const Lvl &L, const float *__restric
 	return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forest of blocks (csrc/forest/forest.h, lotd_forest.h): octree lookup, corner resolver, cell locator
+// ---------------------------------------------------------------------------------------------
+struct ForestDev {
+	const uint8_t *__restrict__ octree;
+	const int32_t *__restrict__ exsum;
+	const int16_t *__restrict__ block_ks;
+	uint32_t level, level_poffset, continuity;
+};
+
+// forest.h:25-58: walk the byte octree from the root to `level`; index of the node in the breadth-first hierarchy
+__device__ __forceinline__ int32_t identify(const ForestDev &fo, int kx, int ky, int kz) {
+	const int maxval = (1 << fo.level) - 1;
+	if (kx < 0 || ky < 0 || kz < 0 || kx > maxval || ky > maxval || kz > maxval) return -1;
+	int32_t ord = 0;
+	for (uint32_t l = 0; l < fo.level; ++l) {
+		const uint32_t depth = fo.level - l - 1;
+		const uint32_t child = (((uint32_t)kx >> depth) & 1u) << 2 | (((uint32_t)ky >> depth) & 1u) << 1 | (((uint32_t)kz >> depth) & 1u);
+		const uint32_t bits = fo.octree[ord];
+		if (!(bits & (1u << child))) return -1;
+		ord = fo.exsum[ord] + (int32_t)__popc(bits & ((2u << child) - 1u));    // inclusive count of set children
+	}
+	return ord;
+}
+
+// the point's block: parameter offset and integer coordinates
+struct Block {
+	uint32_t offset;
+	int k[3];
+};
+
+__device__ __forceinline__ bool load_block(const ForestDev &fo, const Batch &ba, uint32_t i, Block &b) {
+	uint32_t bi;
+	if (!batch_base_index(ba, i, b.offset, bi)) return false;
+#pragma unroll
+	for (int d = 0; d < 3; ++d) b.k[d] = fo.block_ks[3 * (size_t)bi + d];
+	return true;
+}
+
+// continuity fixing (lotd_forest.h:55-88): corner position p in 0..R+1 -> position inside the block that owns it and
+// that block's index (`owner` comes in as the point's own block); false when nothing is stored there (continuity
+// off / no such block)
+__device__ __forceinline__ bool resolve_block(const ForestDev &fo, const Lvl &L, const int (&k)[3], const uint32_t (&p)[3],
+                                              uint32_t (&pl)[3], uint32_t &owner) {
+	int kk[3];
+	bool changed = false;
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		if (p[d] == 0u) { kk[d] = k[d] - 1; pl[d] = L.res[d] - 1u; changed = true; }
+		else if (p[d] == L.res[d] + 1u) { kk[d] = k[d] + 1; pl[d] = 0u; changed = true; }
+		else { kk[d] = k[d]; pl[d] = p[d] - 1u; }
+	}
+	if (changed) {
+		if (!fo.continuity) return false;
+		const int32_t pidx = identify(fo, (int16_t)kk[0], (int16_t)kk[1], (int16_t)kk[2]);
+		const int32_t bi = pidx < 0 ? -1 : pidx - (int32_t)fo.level_poffset;
+		if (bi < 0) return false;
+		owner = (uint32_t)bi;
+	}
+	return true;
+}
+
+// same, giving the owner's parameter offset
+__device__ __forceinline__ bool resolve(const ForestDev &fo, const Batch &ba, const Lvl &L, const Block &b,
+                                        const uint32_t (&p)[3], uint32_t (&pl)[3], uint32_t &offset) {
+	uint32_t owner = 0xFFFFFFFFu;
+	if (!resolve_block(fo, L, b.k, p, pl, owner)) return false;
+	offset = (owner == 0xFFFFFFFFu) ? b.offset : (ba.offsets ? (uint32_t)ba.offsets[owner] : owner * ba.n_params);
+	return true;
+}
+
+// cell locator with the forest's scale = R ("NOTE: for forest", lotd_forest.h:228-232)
+__device__ __forceinline__ void locate_forest(const float (&xp)[3], const Lvl &L, bool smooth, Cell<3> &c) {
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		const float sc = (float)L.res[d];
+		const float v = __fmaf_rn(xp[d], sc, 0.5f);
+		const float fl = floorf(v);
+		const float t = v - fl;
+		c.sc[d] = sc;
+		c.g[d] = (uint32_t)fl;
+		if (!smooth) {
+			c.w[d] = t; c.dw[d] = 1.0f; c.ddw[d] = 0.0f;
+		} else {
+			c.w[d] = t * t * __fmaf_rn(-2.0f, t, 3.0f);
+			c.dw[d] = 6.0f * t * (1.0f - t);
+			c.ddw[d] = __fmaf_rn(-12.0f, t, 6.0f);
+		}
+	}
+}
+
 // lotd_bin.hip: atomic-free parameter-gradient path (all level types but NPlaneSum/CPfast, no batching)
 uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches);
 void set_dparam_chunk_log2(int lg);
+// `forest` != NULL: the points live in the blocks of a forest (n_batches = n_trees); Dense/Hash 3-D metas only
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
-                  hipStream_t st, bool &handled);
+                  hipStream_t st, bool &handled, const ForestDev *forest = nullptr);
 
 }  // namespace lotd
 }  // namespace nr3d

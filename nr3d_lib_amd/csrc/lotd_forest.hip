@@ -9,92 +9,13 @@
 // right neighbour's 0, 1..R the block's own 0..R-1 (the cell locator uses scale = R).  Only the boundary cells of a
 // block ever touch a neighbour, so the octree walk (`identify`, one dependent byte + one int per octree level) runs for
 // a 6/R fraction of the corners; everything else is the plain per-corner arithmetic of lotd_device.h.
-// One lane = one (point, pseudo level); parameter gradients are fp32 hardware atomics (this is the "next" row of
-// SURVEY 8f, built for parity first; the binned atomic-free path of lotd_bin.hip is single-block only).
+// One lane = one (point, pseudo level); parameter gradients are fp32 hardware atomics or, for
+// Dense/Hash metas with a workspace, the atomic-free binned path of lotd_bin.hip (k_bin_forest: blocks = batch entries).
 #include "common.h"
 #include "lotd_device.h"
 
 namespace nr3d {
 namespace lotd {
-
-struct ForestDev {
-	const uint8_t *__restrict__ octree;
-	const int32_t *__restrict__ exsum;
-	const int16_t *__restrict__ block_ks;
-	uint32_t level, level_poffset, continuity;
-};
-
-// forest.h:25-58: walk the byte octree from the root to `level`; index of the node in the breadth-first hierarchy
-__device__ __forceinline__ int32_t identify(const ForestDev &fo, int kx, int ky, int kz) {
-	const int maxval = (1 << fo.level) - 1;
-	if (kx < 0 || ky < 0 || kz < 0 || kx > maxval || ky > maxval || kz > maxval) return -1;
-	int32_t ord = 0;
-	for (uint32_t l = 0; l < fo.level; ++l) {
-		const uint32_t depth = fo.level - l - 1;
-		const uint32_t child = (((uint32_t)kx >> depth) & 1u) << 2 | (((uint32_t)ky >> depth) & 1u) << 1 | (((uint32_t)kz >> depth) & 1u);
-		const uint32_t bits = fo.octree[ord];
-		if (!(bits & (1u << child))) return -1;
-		ord = fo.exsum[ord] + (int32_t)__popc(bits & ((2u << child) - 1u));    // inclusive count of set children
-	}
-	return ord;
-}
-
-// the point's block: parameter offset and integer coordinates
-struct Block {
-	uint32_t offset;
-	int k[3];
-};
-
-__device__ __forceinline__ bool load_block(const ForestDev &fo, const Batch &ba, uint32_t i, Block &b) {
-	uint32_t bi;
-	if (!batch_base_index(ba, i, b.offset, bi)) return false;
-#pragma unroll
-	for (int d = 0; d < 3; ++d) b.k[d] = fo.block_ks[3 * (size_t)bi + d];
-	return true;
-}
-
-// continuity fixing (lotd_forest.h:55-88): corner position p in 0..R+1 -> position inside the block that owns it and
-// that block's parameter offset; false when nothing is stored there (continuity off / no such block)
-__device__ __forceinline__ bool resolve(const ForestDev &fo, const Batch &ba, const Lvl &L, const Block &b,
-                                        const uint32_t (&p)[3], uint32_t (&pl)[3], uint32_t &offset) {
-	int kk[3];
-	bool changed = false;
-#pragma unroll
-	for (int d = 0; d < 3; ++d) {
-		if (p[d] == 0u) { kk[d] = b.k[d] - 1; pl[d] = L.res[d] - 1u; changed = true; }
-		else if (p[d] == L.res[d] + 1u) { kk[d] = b.k[d] + 1; pl[d] = 0u; changed = true; }
-		else { kk[d] = b.k[d]; pl[d] = p[d] - 1u; }
-	}
-	offset = b.offset;
-	if (changed) {
-		if (!fo.continuity) return false;
-		const int32_t pidx = identify(fo, (int16_t)kk[0], (int16_t)kk[1], (int16_t)kk[2]);
-		const int32_t bi = pidx < 0 ? -1 : pidx - (int32_t)fo.level_poffset;
-		if (bi < 0) return false;
-		offset = ba.offsets ? (uint32_t)ba.offsets[bi] : (uint32_t)bi * ba.n_params;
-	}
-	return true;
-}
-
-// cell locator with the forest's scale = R ("NOTE: for forest", lotd_forest.h:228-232)
-__device__ __forceinline__ void locate_forest(const float (&xp)[3], const Lvl &L, bool smooth, Cell<3> &c) {
-#pragma unroll
-	for (int d = 0; d < 3; ++d) {
-		const float sc = (float)L.res[d];
-		const float v = __fmaf_rn(xp[d], sc, 0.5f);
-		const float fl = floorf(v);
-		const float t = v - fl;
-		c.sc[d] = sc;
-		c.g[d] = (uint32_t)fl;
-		if (!smooth) {
-			c.w[d] = t; c.dw[d] = 1.0f; c.ddw[d] = 0.0f;
-		} else {
-			c.w[d] = t * t * __fmaf_rn(-2.0f, t, 3.0f);
-			c.dw[d] = 6.0f * t * (1.0f - t);
-			c.ddw[d] = __fmaf_rn(-12.0f, t, 6.0f);
-		}
-	}
-}
 
 __device__ __forceinline__ bool forest_type(uint32_t t) {
 	return t == NR3D_LOD_Dense || t == NR3D_LOD_VectorMatrix || t == NR3D_LOD_NPlaneMul || t == NR3D_LOD_CP || t == NR3D_LOD_Hash;
@@ -366,12 +287,21 @@ extern "C" int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *me
 extern "C" int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                                            uint32_t N, const float *dL_ddLdx, const float *dL_dy, const float *x,
                                            const float *params, const int64_t *block_inds, const int64_t *block_offsets,
-                                           uint32_t batch_data_size, int32_t max_level, float *dL_dparam, void *stream) {
+                                           uint32_t batch_data_size, int32_t max_level, float *dL_dparam, void *workspace,
+                                           uint64_t workspace_bytes, void *stream) {
 	if (int rc = check_forest(meta, meta_dev, forest)) return rc;
 	if (N == 0 || max_level < 0) return 0;
 	NR3D_CHECK(dL_dy && x && params && dL_dparam, "LoTD forest::bwd: NULL tensor pointer");
 	const Batch ba{block_inds, block_offsets, batch_data_size, meta->n_params};
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
+	if (workspace) {
+		const ForestDev fo = dev_of(forest);
+		bool handled = false;
+		const int64_t E = meta->n_encoded_dims;
+		if (int rc = dparam_binned(dL_ddLdx != nullptr, meta, meta_dev, N, dL_ddLdx, dL_dy, E, 1, x, params, ba, forest->n_trees,
+		                           max_level, dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, &fo)) return rc;
+		if (handled) return 0;
+	}
 	const dim3 grid(div_up(N, kBlock), meta->n_pseudo_levels);
 	DISPATCH_G(meta->n_feat_per_pseudo_lvl, {
 		if (dL_ddLdx)

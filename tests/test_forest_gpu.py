@@ -250,3 +250,33 @@ def test_space_ray_test_feeds_the_marcher(oracle, dev):
                                      rt["seg_pack_infos"].cpu().numpy(), grid, 0.04, 1e10, 0.0, 64, True)
     for a, b, name in zip(got, ref, ("packed_info", "t_starts", "t_ends", "ridx", "blidx", "gidx")):
         assert_equal(a, b, name)
+
+
+@pytest.mark.parametrize("forest", ["plus", "scatter"])
+def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest):
+    """Dense/Hash forests take the sort + segmented-sum path (blocks = batch entries, neighbour-owned corners binned into
+    the neighbour's table); forcing the atomic scatter must give the same gradients, first and second order"""
+    _lotd, fo, m_ref, metas, (x, p, g, v, bi), (xt, pt, gt, vt, bit) = _setup(oracle, dev, forest, "dense_hash", n=20000, seed=9)
+    ref1 = oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, accum_double=True)
+    ref2 = oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, dL_ddLdx=v, accum_double=True)
+    from nr3d_lib_amd.bindings import _forest
+    assert _forest._workspace(metas[0], metas[1], 20000, dev)[1] > 0            # the binned path applies
+    _, j = _lotd.lod_fwd(metas, xt, pt, bit, need_input_grad=True)
+    try:
+        for binned in (True, False):
+            _lotd.USE_BINNED_DPARAM = binned
+            dp = _lotd.lod_bwd(metas, gt, xt, pt, None, bit, need_input_grad=False, need_param_grad=True)[1]
+            assert_close(dp, ref1, name=f"dL_dparam binned={binned}")
+            dp2 = _lotd.lod_bwd_bwd_input(metas, vt, gt, xt, pt, j, bit, need_dLdinput_ddLdoutput=False,
+                                          need_dLdinput_dparams=True, need_dLdinput_dinput=False)[1]
+            assert_close(dp2, ref2, name=f"d(dLdx)/dparam binned={binned}")
+    finally:
+        _lotd.USE_BINNED_DPARAM = True
+    # ray-like coherent points (the run-merging of stage A) inside one block, then crossing into its neighbour
+    t = np.linspace(0.02, 0.98, 4096, dtype=np.float32)
+    xs = np.stack([t, np.full_like(t, 0.37), np.full_like(t, 0.993)], 1)
+    bs = np.full(4096, 1, np.int64)
+    gs = g[:4096]
+    dpc = _lotd.lod_bwd(metas, torch.from_numpy(gs).to(dev), torch.from_numpy(xs).to(dev), pt, None, torch.from_numpy(bs).to(dev),
+                        need_input_grad=False, need_param_grad=True)[1]
+    assert_close(dpc, oracle.lotd_forest_bwd_dparam(m_ref, fo, gs, xs, p, block_inds=bs, accum_double=True), name="coherent dparam")
