@@ -170,11 +170,12 @@ int nr3d_forest_identify(const nr3d_forest_meta_t *forest, uint64_t n, const int
  * x in [0,1]^3 INSIDE the point's block; block_inds int64 [N] (<0: the point is skipped, outputs zero) or NULL with
  * batch_data_size (points per block, blocks in order) or neither (block 0); block_offsets int64 [n_trees] or NULL
  * (block b's parameters start at b * n_params).  f32, D == 3, level types Dense / VectorMatrix / NPlaneMul / CP / Hash
- * (the reference's forest kernels handle no others).  y [N,E], dy_dx [N,E,3] or NULL, both contiguous. */
+ * (the reference's forest kernels handle no others).  y[i*y_sn + e*y_se]; dy_dx[i*d_sn + e*d_se + d] or NULL
+ * (strides in elements, as for nr3d_lotd_fwd; feature-major storage y_sn = 1, y_se = N makes the stores coalesced). */
 int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                          uint32_t n_points, const float *x, const float *params, const int64_t *block_inds,
                          const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level, float *y,
-                         float *dy_dx, void *stream);
+                         int64_t y_sn, int64_t y_se, float *dy_dx, int64_t d_sn, int64_t d_se, void *stream);
 
 /* dL/dparam (dL_ddLdx == NULL; kernel_lod_forest_backward_grid :414-542) or d(dL/dx)/dparam
  * (kernel_lod_forest_backward_input_backward_grid :636-773).  dL_dparam [n_trees * n_params] ZERO-INIT by the caller;

@@ -116,12 +116,20 @@ def lod_fwd(metas, input, params, batch_inds=None, batch_offsets=None, batch_dat
         return (torch.zeros((N, E), dtype=params.dtype, device=dev), torch.zeros((N, E * 3), dtype=input.dtype, device=dev))
     x32, p32 = _lotd._f32c(input.detach()), _lotd._f32c(params.detach())
     with torch.cuda.device(dev):
-        y = torch.empty((N, E), dtype=torch.float32, device=dev)
-        dy_dx = torch.empty((N, E * 3), dtype=torch.float32, device=dev) if need_input_grad else None
+        # feature-major storage behind [N, E] / [N, E, 3] views, like the single-block path: coalesced stores
+        y = torch.empty((E, N), dtype=torch.float32, device=dev).t()
+        dy_dx, dsn, dse = None, 0, 0
+        if need_input_grad:
+            if m.c_permute_dydx:
+                dy_dx = torch.empty((E, N, 3), dtype=torch.float32, device=dev).permute(1, 0, 2)
+                dsn, dse = dy_dx.stride(0), dy_dx.stride(1)
+            else:
+                dy_dx, dsn, dse = torch.empty((N, E * 3), dtype=torch.float32, device=dev), E * 3, 3
         c = fo._c()
         H.check(H.lib().nr3d_lotd_forest_fwd(
             C.byref(m._cmeta()), H.ptr(m._dev(dev)), C.byref(c), H.u32(N), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
-            H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(y), H.ptr(dy_dx), H.stream_of(input)))
+            H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(y), H.i64(y.stride(0)), H.i64(y.stride(1)),
+            H.ptr(dy_dx), H.i64(dsn), H.i64(dse), H.stream_of(input)))
     return _lotd._cast(y, params.dtype), _lotd._cast(dy_dx, input.dtype)
 
 

@@ -34,9 +34,10 @@ __global__ __launch_bounds__(256) void k_forest_identify(ForestDev fo, uint64_t 
 // =============================================================================================
 template <int G, bool DYDX>
 __global__ __launch_bounds__(kBlock) void k_forest_fwd(const nr3d_lotd_meta_t *__restrict__ md, ForestDev fo, uint32_t N,
-                                                       uint32_t E, int32_t max_level, uint32_t smooth,
+                                                       int32_t max_level, uint32_t smooth,
                                                        const float *__restrict__ x, const float *__restrict__ params,
-                                                       Batch ba, float *__restrict__ y, float *__restrict__ dydx) {
+                                                       Batch ba, float *__restrict__ y, int64_t y_sn, int64_t y_se,
+                                                       float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= N) return;
 	const uint32_t q = blockIdx.y;
@@ -90,12 +91,14 @@ __global__ __launch_bounds__(kBlock) void k_forest_fwd(const nr3d_lotd_meta_t *_
 		}
 	}
 #pragma unroll
-	for (int f = 0; f < G; ++f) y[(size_t)i * E + out0 + f] = out_y[f];
+	for (int f = 0; f < G; ++f) __builtin_nontemporal_store(out_y[f], &y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se]);
 	if (DYDX) {
 #pragma unroll
-		for (int f = 0; f < G; ++f)
+		for (int f = 0; f < G; ++f) {
+			float *dst = dydx + (int64_t)i * d_sn + (int64_t)(out0 + f) * d_se;
 #pragma unroll
-			for (int d = 0; d < 3; ++d) dydx[((size_t)i * E + out0 + f) * 3 + d] = out_g[f][d];
+			for (int d = 0; d < 3; ++d) __builtin_nontemporal_store(out_g[f][d], &dst[d]);
+		}
 	}
 }
 
@@ -265,7 +268,7 @@ extern "C" int nr3d_forest_identify(const nr3d_forest_meta_t *forest, uint64_t n
 extern "C" int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                                     uint32_t N, const float *x, const float *params, const int64_t *block_inds,
                                     const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level, float *y,
-                                    float *dy_dx, void *stream) {
+                                    int64_t y_sn, int64_t y_se, float *dy_dx, int64_t d_sn, int64_t d_se, void *stream) {
 	if (int rc = check_forest(meta, meta_dev, forest)) return rc;
 	if (N == 0) return 0;
 	NR3D_CHECK(x && params && y, "LoTD forest::fwd: NULL tensor pointer");
@@ -275,10 +278,10 @@ extern "C" int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *me
 	DISPATCH_G(meta->n_feat_per_pseudo_lvl, {
 		if (dy_dx)
 			hipLaunchKernelGGL((k_forest_fwd<G, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
-			                   meta->n_encoded_dims, max_level, meta->interpolation_type, x, params, ba, y, dy_dx);
+			                   max_level, meta->interpolation_type, x, params, ba, y, y_sn, y_se, dy_dx, d_sn, d_se);
 		else
 			hipLaunchKernelGGL((k_forest_fwd<G, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
-			                   meta->n_encoded_dims, max_level, meta->interpolation_type, x, params, ba, y, dy_dx);
+			                   max_level, meta->interpolation_type, x, params, ba, y, y_sn, y_se, dy_dx, d_sn, d_se);
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;

@@ -83,7 +83,7 @@ def test_fwd_bwd_and_second_order(oracle, dev, forest, continuity, case):
     y_ref, j_ref = oracle.lotd_forest_fwd(m_ref, fo, x, p, block_inds=bi, need_dydx=True)
     y, j = _lotd.lod_fwd(metas, xt, pt, bit, need_input_grad=True)
     assert_close(y, y_ref, name="y")
-    assert_close(j.view(j_ref.shape), j_ref, name="dy_dx")
+    assert_close(j.reshape(j_ref.shape), j_ref, name="dy_dx")
     y2, j2 = _lotd.lod_fwd(metas, xt, pt, bit, need_input_grad=False)
     assert j2 is None
     assert_close(y2, y_ref, name="y(no grad)")
@@ -123,7 +123,7 @@ def test_block_modes_skips_max_level_and_errors(oracle, dev):
     b2t = torch.from_numpy(bi2).to(dev)
     ys, js = _lotd.lod_fwd(metas, xt, pt, b2t, None, None, 1, True)
     yr, jr = oracle.lotd_forest_fwd(m_ref, fo, x, p, block_inds=bi2, max_level=1, need_dydx=True)
-    assert_close(ys, yr, name="skips y"); assert_close(js.view(jr.shape), jr, name="skips dy_dx")
+    assert_close(ys, yr, name="skips y"); assert_close(js.reshape(jr.shape), jr, name="skips dy_dx")
     assert float(ys[::4].abs().max()) == 0 and float(ys[:, 4:].abs().max()) == 0
     dps = _lotd.lod_bwd(metas, gt, xt, pt, None, b2t, None, None, 1, False, True)[1]
     assert_close(dps, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi2, max_level=1, accum_double=True), name="skips dparam")
