@@ -267,6 +267,47 @@ int nr3d_occ_scatter_max(uint64_t n, const int64_t *gidx, const float *pts, cons
 int nr3d_occ_apply_max(uint64_t n_voxels, float ema_decay, const float *vmax, float *occ_val_grid, void *stream);
 
 /* =================================================================================================
+ * Fused fully-connected decoder -- the MLP right after the encoder: nr3d_lib/models/blocks/mlp.py:27-127 (`MLP` /
+ * `FCBlock`: D hidden DenseLayers + an output layer, nr3d_lib/models/layers.py:228-300), in the reference a chain of
+ * GEMM + elementwise launches (or tiny-cuda-nn's fused fp16 network behind nr3d_lib/models/tcnn_adapter.py:74-237).
+ * fp32 in / fp32 accumulate on the f32 MFMA; the whole network in one kernel, activations in registers.
+ *   dims[0] = in_features, dims[1..n_layers-1] = hidden widths, dims[n_layers] = out_features; every width 1..128;
+ *   weights[l]: f32 [dims[l+1], dims[l]] row-major (torch nn.Linear layout), biases[l]: f32 [dims[l+1]] or NULL.
+ * nr3d_mlp_packed_floats: size of the packed-weights buffer, or 0 when the fused kernels do not apply (a single
+ *   layer, a width > 128, packed weights beyond the LDS budget) -- the caller then keeps its unfused path.
+ * nr3d_mlp_pack: weights/biases (HOST arrays of n_layers DEVICE pointers) -> packed, in MFMA operand order; call it
+ *   whenever the parameters changed (once per optimiser step).
+ * nr3d_mlp_forward: y[i*y_stride + o] for x[i*x_stride + f]; rows need not be padded or aligned (16-byte aligned
+ *   rows take vector loads).
+ * ============================================================================================== */
+#define NR3D_MLP_MAX_LAYERS 8
+enum { NR3D_MLP_ACT_NONE = 0, NR3D_MLP_ACT_RELU = 1 };
+
+typedef struct nr3d_mlp_desc {
+	uint32_t n_layers;                          /* linear layers: hidden layers + 1 */
+	uint32_t dims[NR3D_MLP_MAX_LAYERS + 1];
+	uint32_t hidden_activation;                 /* NR3D_MLP_ACT_* after every hidden layer */
+	uint32_t output_activation;
+} nr3d_mlp_desc_t;
+
+uint64_t nr3d_mlp_packed_floats(const nr3d_mlp_desc_t *desc);
+/* extra floats of the packed buffer that nr3d_mlp_backward needs (the transposed layers), or 0 when the fused backward
+ * does not apply (hidden width > 64, more than 2 hidden layers wider than 32 / 3 narrower ones, input or output wider
+ * than the hidden layers): the caller then differentiates its unfused path. */
+uint64_t nr3d_mlp_backward_packed_floats(const nr3d_mlp_desc_t *desc);
+/* packed: nr3d_mlp_packed_floats (+ nr3d_mlp_backward_packed_floats when with_backward != 0) floats */
+int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *weights, const float *const *biases, float *packed,
+                  int with_backward, void *stream);
+/* dL/dx (or NULL), dL/dW_l [dims[l+1], dims[l]] and dL/db_l (dL_db or entries may be NULL) from x and dL/dy; the forward
+ * is recomputed in registers, nothing but x has to be kept from the forward pass.  Parameter gradients are ADDED to
+ * dL_dW / dL_db (fp32 atomics, one per element and workgroup): zero them for plain gradients. */
+int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, const float *dL_dy,
+                      int64_t gy_stride, const float *packed, float *dL_dx, int64_t gx_stride, float *const *dL_dW,
+                      float *const *dL_db, void *stream);
+int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, const float *packed,
+                     float *y, int64_t y_stride, void *stream);
+
+/* =================================================================================================
  * pack_ops -- replaces nr3d_lib.bindings._pack_ops  (csrc/pack_ops/pack_ops.h:11-65,
  * csrc/pack_ops/pack_ops.cpp:21-58, kernels csrc/pack_ops/pack_ops_cuda.cu)
  * pack_infos: int64 [P,2] = (begin, length), contiguous.  feats: [S] or [S, feat_dim] contiguous.

@@ -1,0 +1,109 @@
+"""ctypes front of the fused fully-connected decoder (include/nr3d_hip.h: nr3d_mlp_*).  No reference pybind module
+corresponds to it -- the reference's MLP (nr3d_lib/models/blocks/mlp.py) is plain torch, its fused option is
+tiny-cuda-nn (nr3d_lib/models/tcnn_adapter.py); this is the kernel side of ``nr3d_lib_amd.models.blocks.MLP``."""
+import ctypes as C
+
+import torch
+
+from .. import _hip as H
+
+MAX_LAYERS = 8
+ACT_NONE, ACT_RELU = 0, 1
+
+
+class _CDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_uint32), ("dims", C.c_uint32 * (MAX_LAYERS + 1)), ("hidden_activation", C.c_uint32),
+                ("output_activation", C.c_uint32)]
+
+
+class MLPDesc:
+    """dims = [in_features, hidden..., out_features]"""
+
+    def __init__(self, dims, hidden_activation=ACT_RELU, output_activation=ACT_NONE):
+        self.dims = [int(d) for d in dims]
+        self.hidden_activation, self.output_activation = int(hidden_activation), int(output_activation)
+        c = _CDesc()
+        n_layers = len(self.dims) - 1
+        c.n_layers = n_layers if 1 <= n_layers <= MAX_LAYERS else 0
+        for i, d in enumerate(self.dims[:MAX_LAYERS + 1]):
+            c.dims[i] = d
+        c.hidden_activation, c.output_activation = self.hidden_activation, self.output_activation
+        self._c = c
+        H.lib().nr3d_mlp_packed_floats.restype = C.c_uint64
+        H.lib().nr3d_mlp_backward_packed_floats.restype = C.c_uint64
+        self.packed_floats = int(H.lib().nr3d_mlp_packed_floats(C.byref(c))) if c.n_layers else 0
+        self.backward_floats = int(H.lib().nr3d_mlp_backward_packed_floats(C.byref(c))) if self.packed_floats else 0
+
+    @property
+    def fusable(self) -> bool:
+        return self.packed_floats > 0
+
+    @property
+    def backward_fusable(self) -> bool:
+        return self.backward_floats > 0
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def pack(desc: MLPDesc, weights, biases, with_backward=False) -> torch.Tensor:
+    """weights[l] [dims[l+1], dims[l]], biases[l] [dims[l+1]] | None (fp32, contiguous, on one GPU) -> packed buffer"""
+    if not desc.fusable:
+        raise RuntimeError("mlp.pack: network outside the fused kernels' range")
+    dev = weights[0].device
+    H.require_gpu(*weights)
+    ws = [w.detach().float().contiguous() for w in weights]
+    bs = [None if b is None else b.detach().float().contiguous() for b in biases]
+    for l, w in enumerate(ws):
+        if tuple(w.shape) != (desc.dims[l + 1], desc.dims[l]):
+            raise RuntimeError(f"mlp.pack: weights[{l}] has shape {list(w.shape)}, expected {[desc.dims[l + 1], desc.dims[l]]}")
+    if with_backward and not desc.backward_fusable:
+        raise RuntimeError("mlp.pack: the fused backward does not apply to this network")
+    packed = torch.empty(desc.packed_floats + (desc.backward_floats if with_backward else 0), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nr3d_mlp_pack(C.byref(desc._c), _ptr_array(ws), _ptr_array(bs), H.ptr(packed), C.c_int(int(with_backward)),
+                                      H.stream_of(packed)))
+    return packed
+
+
+def forward(desc: MLPDesc, x: torch.Tensor, packed: torch.Tensor) -> torch.Tensor:
+    """x [..., in] fp32 (rows may be strided: last dim contiguous) -> y [..., out]"""
+    H.require_gpu(x, packed)
+    if x.dtype != torch.float32 or x.shape[-1] != desc.dims[0]:
+        raise RuntimeError(f"mlp.forward: expected fp32 input with {desc.dims[0]} features, got {x.dtype} {list(x.shape)}")
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    n = x2.shape[0]
+    y = torch.empty((n, desc.dims[-1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        H.check(H.lib().nr3d_mlp_forward(C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(x2.stride(0) if n > 1 else x2.shape[1]),
+                                         H.ptr(packed), H.ptr(y), H.i64(y.shape[1]), H.stream_of(x)))
+    return y.view(*x.shape[:-1], desc.dims[-1])
+
+
+def backward(desc: MLPDesc, x: torch.Tensor, dL_dy: torch.Tensor, packed: torch.Tensor, need_dx=True, has_bias=None):
+    """-> (dL_dx | None, [dL_dW_l], [dL_db_l | None]); `packed` from pack(..., with_backward=True)"""
+    H.require_gpu(x, dL_dy, packed)
+    n_layers = len(desc.dims) - 1
+    x2 = x.reshape(-1, desc.dims[0])
+    g2 = dL_dy.reshape(-1, desc.dims[-1])
+    if x2.dtype != torch.float32 or g2.dtype != torch.float32 or x2.shape[0] != g2.shape[0]:
+        raise RuntimeError("mlp.backward: expected fp32 x [n, in] and dL_dy [n, out]")
+    x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+    g2 = g2 if g2.stride(-1) == 1 else g2.contiguous()
+    n, dev = x2.shape[0], x.device
+    has_bias = [True] * n_layers if has_bias is None else list(has_bias)
+    dWs = [torch.zeros(desc.dims[l + 1], desc.dims[l], dtype=torch.float32, device=dev) for l in range(n_layers)]
+    dbs = [torch.zeros(desc.dims[l + 1], dtype=torch.float32, device=dev) if has_bias[l] else None for l in range(n_layers)]
+    dx = torch.empty_like(x2, memory_format=torch.contiguous_format) if need_dx else None
+    with torch.cuda.device(dev):
+        H.check(H.lib().nr3d_mlp_backward(
+            C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(x2.stride(0) if n > 1 else desc.dims[0]), H.ptr(g2),
+            H.i64(g2.stride(0) if n > 1 else desc.dims[-1]), H.ptr(packed), H.ptr(dx), H.i64(desc.dims[0]), _ptr_array(dWs),
+            _ptr_array(dbs), H.stream_of(x)))
+    return (None if dx is None else dx.view(x.shape)), dWs, dbs

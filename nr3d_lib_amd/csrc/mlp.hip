@@ -1,0 +1,626 @@
+// nr3d_lib_amd/csrc/mlp.hip -- fused fully-connected decoder (gfx950), C-ABI entry points
+// nr3d_mlp_packed_floats / nr3d_mlp_pack / nr3d_mlp_forward / nr3d_mlp_backward.
+//
+// The step right after the encoder: nr3d_lib/models/blocks/mlp.py:27-127 (`MLP` / `FCBlock`: D hidden
+// DenseLayers of width W + an output layer, nr3d_lib/models/layers.py:228-300) -- in the reference a chain of
+// cuBLAS GEMMs + elementwise kernels, or tiny-cuda-nn's fused fp16 MLP behind tcnn_adapter.py.  Here: fp32 in, fp32
+// accumulate on the f32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, so parity with an fp32 reference is
+// round-off only), the whole network in ONE kernel: activations never leave registers.
+//
+// Layout trick: everything is computed TRANSPOSED, H^T[feature, sample] = W . X^T, per wave on a tile of 32 samples.
+// The MFMA's C/D map puts sample = lane & 31 in every lane and features 8a + 4(lane >> 5) + b (a, b < 4) in its 16
+// accumulator registers; its B operand wants sample = lane & 31 and one k per half-wave.  Feeding register j of the
+// previous layer's accumulator as B of step j means half-wave h contributes feature 8(j>>2) + 4h + (j&3) -- a fixed
+// permutation of k, absorbed into the order the weights are packed in.  So the output registers of one layer ARE the
+// input operands of the next: no LDS round trip, no shuffles.  The input X and the output Y use the same map, which
+// makes every lane read / write 16-byte pieces of its sample's row.
+// Weights (packed once per step by k_mlp_pack into MFMA operand order, zero padded to 32-wide tiles) sit in LDS.
+//
+// Backward recomputes the forward from X (keeping the activations in registers), walks the layers down with
+// dH^T = W^T . dY^T on the same register map, and accumulates dW = dH^T . H_prev over the wave's samples: that
+// product contracts over SAMPLES, which the register map has in the lane index, so both operands go through a
+// per-wave LDS transposition tile ([feature][sample] -> one sample pair per MFMA step).
+#include "common.h"
+#include <type_traits>
+
+namespace nr3d {
+namespace mlp {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;                  // 4 waves per workgroup, one 32-sample tile per wave at a time
+constexpr int kMaxLds = 144 * 1024;            // of the CU's 160 KB
+
+__host__ __device__ inline uint32_t tiles(uint32_t d) { return (d + 31u) / 32u; }
+// floats of one packed layer: weights [NO][NI][4][64][4] + bias [NO * 32]
+__host__ __device__ inline uint32_t layer_floats(uint32_t ni, uint32_t no) { return no * ni * 1024u + no * 32u; }
+
+struct Shape {
+	uint32_t n_layers;                         // linear layers (hidden + output)
+	uint32_t in_t, w_t, out_t;                 // 32-wide tiles of the input, the (widest) hidden layer, the output
+};
+
+static bool shape_of(const nr3d_mlp_desc_t *d, Shape &s) {
+	if (!d || d->n_layers < 2 || d->n_layers > NR3D_MLP_MAX_LAYERS) return false;
+	uint32_t w = 0;
+	for (uint32_t l = 1; l < d->n_layers; ++l) w = d->dims[l] > w ? d->dims[l] : w;
+	for (uint32_t l = 0; l <= d->n_layers; ++l) if (d->dims[l] == 0 || d->dims[l] > 128) return false;
+	s.n_layers = d->n_layers;
+	// 3-tile widths run on the 4-tile instantiation (one all-zero tile)
+	auto round = [](uint32_t t) { return t == 3 ? 4u : t; };
+	s.in_t = round(tiles(d->dims[0])); s.w_t = round(tiles(w)); s.out_t = round(tiles(d->dims[d->n_layers]));
+	return true;
+}
+
+static uint64_t packed_floats(const Shape &s) {
+	return (uint64_t)layer_floats(s.in_t, s.w_t) + (uint64_t)(s.n_layers - 2) * layer_floats(s.w_t, s.w_t) + layer_floats(s.w_t, s.out_t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing: for layer l, packed[(((ot*NI + it)*4 + a)*64 + lane)*4 + b] = W[32 ot + (lane & 31)][32 it + 8a + 4(lane >> 5) + b]
+// (the transposed layers of the backward pass are packed from the same W with the roles of the two indices swapped)
+// ---------------------------------------------------------------------------------------------
+struct PackArgs {
+	const float *w[NR3D_MLP_MAX_LAYERS];
+	const float *b[NR3D_MLP_MAX_LAYERS];
+	uint32_t in_dim[NR3D_MLP_MAX_LAYERS], out_dim[NR3D_MLP_MAX_LAYERS];   // of W as stored: [out_dim, in_dim] row-major
+	uint32_t ni[NR3D_MLP_MAX_LAYERS], no[NR3D_MLP_MAX_LAYERS];            // tiles of the packed layer's input / output
+	uint32_t offset[NR3D_MLP_MAX_LAYERS + 1];                             // first float of every packed layer
+	uint32_t n_layers;
+	uint32_t transposed;                                                  // pack W^T (no bias): the dH = W^T dY layers
+};
+
+__global__ __launch_bounds__(256) void k_mlp_pack(PackArgs a, float *__restrict__ packed) {
+	const uint32_t l = blockIdx.y;
+	const uint32_t nf = a.offset[l + 1] - a.offset[l];
+	const uint32_t nw = a.no[l] * a.ni[l] * 1024u;
+	for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < nf; e += gridDim.x * 256) {
+		float v = 0.0f;
+		if (e < nw) {
+			const uint32_t b = e & 3u, lane = (e >> 2) & 63u, q = (e >> 8) & 3u, tile = e >> 10;
+			const uint32_t it = tile % a.ni[l], ot = tile / a.ni[l];
+			const uint32_t o = 32u * ot + (lane & 31u), f = 32u * it + 8u * q + 4u * (lane >> 5) + b;
+			if (!a.transposed) { if (o < a.out_dim[l] && f < a.in_dim[l]) v = a.w[l][(size_t)o * a.in_dim[l] + f]; }
+			else { if (o < a.in_dim[l] && f < a.out_dim[l]) v = a.w[l][(size_t)f * a.in_dim[l] + o]; }
+		} else if (!a.transposed && a.b[l]) {
+			const uint32_t o = e - nw;
+			if (o < a.out_dim[l]) v = a.b[l][o];
+		}
+		packed[a.offset[l] + e] = v;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// one dense layer on the register map; wp -> LDS copy of the packed layer
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float activate(float v, int act) { return act == NR3D_MLP_ACT_RELU ? fmaxf(v, 0.0f) : v; }
+
+template <int NI, int NO, bool BIAS>
+__device__ __forceinline__ void dense(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
+	const float *bias = wp + NO * NI * 1024;
+	const int h = lane >> 5;
+#pragma unroll
+	for (int ot = 0; ot < NO; ++ot) {
+		f16v acc;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			f4v b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+			if (BIAS) b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
+#pragma unroll
+			for (int b = 0; b < 4; ++b) acc[4 * q + b] = b4[b];
+		}
+#pragma unroll
+		for (int it = 0; it < NI; ++it)
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const f4v w4 = *reinterpret_cast<const f4v *>(wp + ((((ot * NI + it) * 4 + q) * 64 + lane) << 2));
+#pragma unroll
+				for (int b = 0; b < 4; ++b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[b], in[it][4 * q + b], acc, 0, 0, 0);
+			}
+#pragma unroll
+		for (int j = 0; j < 16; ++j) acc[j] = activate(acc[j], act);
+		out[ot] = acc;
+	}
+}
+
+// rows of a [n, dim] matrix on the register map: lane (s = lane & 31, h = lane >> 5) owns features 32t + 8q + 4h + b
+template <int NT>
+__device__ __forceinline__ void load_rows(const float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row, bool valid,
+                                          bool vec, int lane, f16v (&r)[NT]) {
+	const int h = lane >> 5;
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint32_t f = 32u * t + 8u * q + 4u * h;
+			f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
+			if (valid && f < dim) {
+				const float *src = p + (int64_t)row * stride + f;
+				if (vec && f + 3 < dim) v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(src));
+				else {
+#pragma unroll
+					for (int b = 0; b < 4; ++b) if (f + b < dim) v[b] = src[b];
+				}
+			}
+#pragma unroll
+			for (int b = 0; b < 4; ++b) r[t][4 * q + b] = v[b];
+		}
+}
+
+template <int NT>
+__device__ __forceinline__ void store_rows(float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row, bool valid, bool vec,
+                                           int lane, const f16v (&r)[NT]) {
+	const int h = lane >> 5;
+	if (!valid) return;
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint32_t f = 32u * t + 8u * q + 4u * h;
+			if (f >= dim) continue;
+			float *dst = p + (int64_t)row * stride + f;
+			if (vec && f + 3 < dim) {
+				const f4v v = {r[t][4 * q], r[t][4 * q + 1], r[t][4 * q + 2], r[t][4 * q + 3]};
+				__builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst));
+			} else {
+#pragma unroll
+				for (int b = 0; b < 4; ++b) if (f + b < dim) dst[b] = r[t][4 * q + b];
+			}
+		}
+}
+
+struct FwdArgs {
+	uint64_t n;
+	const float *x; int64_t xs;
+	float *y; int64_t ys;
+	const float *packed; uint32_t packed_floats;
+	uint32_t n_layers, in_dim, out_dim;
+	int hidden_act, out_act;
+	uint32_t x_vec, y_vec;
+};
+
+__device__ __forceinline__ void stage_weights(const float *__restrict__ packed, uint32_t n_floats, float *lds) {
+	const f4v *src = reinterpret_cast<const f4v *>(packed);
+	f4v *dst = reinterpret_cast<f4v *>(lds);
+	for (uint32_t i = threadIdx.x; i < n_floats / 4; i += kThreads) dst[i] = src[i];
+	__syncthreads();
+}
+
+template <int IN_T, int W_T, int OUT_T>
+__global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+	stage_weights(a.packed, a.packed_floats, lds);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint64_t n_tiles = (a.n + 31) / 32;
+	const uint32_t off_hidden = layer_floats(IN_T, W_T), sz_hidden = layer_floats(W_T, W_T);
+	for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * 4) {
+		const uint64_t row = tile * 32 + (lane & 31);
+		const bool valid = row < a.n;
+		f16v xin[IN_T], hcur[W_T], yo[OUT_T];
+		load_rows<IN_T>(a.x, a.xs, a.in_dim, row, valid, a.x_vec != 0, lane, xin);
+		dense<IN_T, W_T, true>(lds, xin, hcur, a.hidden_act, lane);
+#pragma unroll 1
+		for (uint32_t l = 1; l + 1 < a.n_layers; ++l) {
+			f16v hn[W_T];
+			dense<W_T, W_T, true>(lds + off_hidden + (l - 1) * sz_hidden, hcur, hn, a.hidden_act, lane);
+#pragma unroll
+			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
+		}
+		dense<W_T, OUT_T, true>(lds + off_hidden + (a.n_layers - 2) * sz_hidden, hcur, yo, a.out_act, lane);
+		store_rows<OUT_T>(a.y, a.ys, a.out_dim, row, valid, a.y_vec != 0, lane, yo);
+	}
+}
+
+
+// =============================================================================================
+// backward: dL/dx (optional), dL/dW_l, dL/db_l from x and dL/dy, forward recomputed in registers
+// =============================================================================================
+constexpr int kTS = 36;                        // row stride (floats) of the per-wave [feature][sample] LDS tiles:
+                                               // 16-byte aligned rows, and 8 consecutive rows cover all 32 banks
+
+// dense layer whose tile counts are only bounded at compile time (ni <= MAXI, no <= MAXO; wave-uniform skips)
+template <int MAXI, int MAXO, bool BIAS>
+__device__ __forceinline__ void dense_rt(const float *__restrict__ wp, int ni, int no, const f16v (&in)[MAXI], f16v (&out)[MAXO],
+                                         int act, int lane) {
+	const float *bias = wp + no * ni * 1024;
+	const int h = lane >> 5;
+#pragma unroll
+	for (int ot = 0; ot < MAXO; ++ot) {
+		f16v acc;
+#pragma unroll
+		for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+		if (ot < no) {
+			if (BIAS) {
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const f4v b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
+#pragma unroll
+					for (int b = 0; b < 4; ++b) acc[4 * q + b] = b4[b];
+				}
+			}
+#pragma unroll
+			for (int it = 0; it < MAXI; ++it) {
+				if (it >= ni) continue;
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const f4v w4 = *reinterpret_cast<const f4v *>(wp + ((((ot * ni + it) * 4 + q) * 64 + lane) << 2));
+#pragma unroll
+					for (int b = 0; b < 4; ++b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[b], in[it][4 * q + b], acc, 0, 0, 0);
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 16; ++j) acc[j] = activate(acc[j], act);
+		}
+		out[ot] = acc;
+	}
+}
+
+// register map -> [feature][sample] tile (rows of kTS floats)
+template <int MAXT>
+__device__ __forceinline__ void write_tile(float *__restrict__ T, int nt, const f16v (&r)[MAXT], int lane) {
+	const int s = lane & 31, h = lane >> 5;
+#pragma unroll
+	for (int t = 0; t < MAXT; ++t) {
+		if (t >= nt) continue;
+#pragma unroll
+		for (int j = 0; j < 16; ++j) T[(32 * t + 8 * (j >> 2) + 4 * h + (j & 3)) * kTS + s] = r[t][j];
+	}
+}
+
+// 16 samples (half-wave h: samples 16h .. 16h+15) of row `row` -> MFMA operand values of the sample contraction
+__device__ __forceinline__ void read_row16(const float *__restrict__ T, int row, int h, float (&v)[16]) {
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const f4v t4 = *reinterpret_cast<const f4v *>(T + row * kTS + 16 * h + 4 * q);
+#pragma unroll
+		for (int b = 0; b < 4; ++b) v[4 * q + b] = t4[b];
+	}
+}
+
+struct BwdArgs {
+	uint64_t n;
+	const float *x; int64_t xs;
+	const float *gy; int64_t gys;
+	float *gx; int64_t gxs;                    // NULL: dL/dx not wanted
+	const float *packed;                       // [forward layers | transposed layers]
+	uint32_t fwd_floats, total_floats;
+	float *dW[NR3D_MLP_MAX_LAYERS];            // accumulated into (atomics): zero them for plain gradients
+	float *db[NR3D_MLP_MAX_LAYERS];            // may be NULL
+	uint32_t dims[NR3D_MLP_MAX_LAYERS + 1];
+	uint32_t n_layers, in_t, out_t;
+	int hidden_act, out_act;
+	uint32_t x_vec, gy_vec, gx_vec;
+	uint32_t tile_floats;                      // per wave
+};
+
+template <int W_T, int NH>
+__global__ __launch_bounds__(kThreads) void k_mlp_bwd(BwdArgs a) {
+	extern __shared__ __attribute__((aligned(16))) float lds[];
+	{
+		const f4v *src = reinterpret_cast<const f4v *>(a.packed);
+		f4v *dst = reinterpret_cast<f4v *>(lds);
+		for (uint32_t i = threadIdx.x; i < a.total_floats / 4; i += blockDim.x) dst[i] = src[i];
+		__syncthreads();
+	}
+	constexpr int L = NH + 1;                  // linear layers
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	const int r = lane & 31, h = lane >> 5;
+	const int in_t = (int)a.in_t, out_t = (int)a.out_t;
+	float *tiles = lds + a.total_floats + (size_t)wave * a.tile_floats;
+	// tile rows: X | H_1 .. H_NH | G_out
+	float *TX = tiles;
+	float *TH0 = tiles + 32 * in_t * kTS;                               // H_l at TH0 + (l - 1) * 32 * W_T * kTS
+	float *TGO = TH0 + NH * 32 * W_T * kTS;
+	auto TH = [&](int l) { return l == 0 ? TX : TH0 + (l - 1) * 32 * W_T * kTS; };
+	// packed layer offsets
+	uint32_t off_f[L], off_t[L];
+	{
+		uint32_t of = 0, ot = a.fwd_floats;
+#pragma unroll
+		for (int l = 0; l < L; ++l) {
+			const uint32_t ni = l == 0 ? in_t : W_T, no = l == NH ? out_t : W_T;
+			off_f[l] = of; of += layer_floats(ni, no);
+			off_t[l] = ot; ot += layer_floats(no, ni);                   // transposed layer: in = no tiles, out = ni tiles
+		}
+	}
+	f16v dW[L][W_T][W_T];
+	float db[L][W_T];
+#pragma unroll
+	for (int l = 0; l < L; ++l)
+#pragma unroll
+		for (int ot = 0; ot < W_T; ++ot) {
+			db[l][ot] = 0.0f;
+#pragma unroll
+			for (int it = 0; it < W_T; ++it)
+#pragma unroll
+				for (int j = 0; j < 16; ++j) dW[l][ot][it][j] = 0.0f;
+		}
+
+	const uint64_t n_tiles = (a.n + 31) / 32;
+	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * nw) {
+		const uint64_t row = tile * 32 + r;
+		const bool valid = row < a.n;
+		// ---- forward, activations kept as [feature][sample] tiles ----
+		f16v hcur[W_T], g[W_T];
+		load_rows<W_T>(a.x, a.xs, a.dims[0], row, valid, a.x_vec != 0, lane, hcur);      // tiles >= in_t come back zero
+		write_tile<W_T>(TX, in_t, hcur, lane);
+#pragma unroll
+		for (int l = 0; l < NH; ++l) {
+			f16v hn[W_T];
+			dense_rt<W_T, W_T, true>(lds + off_f[l], l == 0 ? in_t : W_T, W_T, hcur, hn, a.hidden_act, lane);
+#pragma unroll
+			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
+			write_tile<W_T>(TH(l + 1), W_T, hcur, lane);
+		}
+		load_rows<W_T>(a.gy, a.gys, a.dims[L], row, valid, a.gy_vec != 0, lane, g);       // zero for padded rows / columns
+		if (a.out_act == NR3D_MLP_ACT_RELU) {
+			f16v yo[W_T];
+			dense_rt<W_T, W_T, true>(lds + off_f[NH], W_T, out_t, hcur, yo, NR3D_MLP_ACT_NONE, lane);
+#pragma unroll
+			for (int t = 0; t < W_T; ++t)
+#pragma unroll
+				for (int j = 0; j < 16; ++j) g[t][j] = yo[t][j] > 0.0f ? g[t][j] : 0.0f;
+		}
+		// ---- backward sweep ----
+#pragma unroll
+		for (int l = NH; l >= 0; --l) {
+			const int no = l == NH ? out_t : W_T, ni = l == 0 ? in_t : W_T;
+			float *TG = l == NH ? TGO : TH(l + 1);                       // H_{l+1} is dead once its mask has been applied
+			write_tile<W_T>(TG, no, g, lane);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			const float *TB = TH(l);
+			float bv[W_T][16];
+#pragma unroll
+			for (int it = 0; it < W_T; ++it) if (it < ni) read_row16(TB, 32 * it + r, h, bv[it]);
+#pragma unroll
+			for (int ot = 0; ot < W_T; ++ot) {
+				if (ot >= no) continue;
+				float av[16];
+				read_row16(TG, 32 * ot + r, h, av);
+				float sum = 0.0f;
+#pragma unroll
+				for (int t = 0; t < 16; ++t) sum += av[t];
+				db[l][ot] += sum;
+#pragma unroll
+				for (int it = 0; it < W_T; ++it) {
+					if (it >= ni) continue;
+#pragma unroll
+					for (int t = 0; t < 16; ++t) dW[l][ot][it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[it][t], dW[l][ot][it], 0, 0, 0);
+				}
+			}
+			if (l > 0 || a.gx) {
+				f16v gp[W_T];
+				dense_rt<W_T, W_T, false>(lds + off_t[l], no, ni, g, gp, NR3D_MLP_ACT_NONE, lane);
+				if (l > 0 && a.hidden_act == NR3D_MLP_ACT_RELU) {
+#pragma unroll
+					for (int t = 0; t < W_T; ++t)
+#pragma unroll
+						for (int j = 0; j < 16; ++j)
+							gp[t][j] = TB[(32 * t + 8 * (j >> 2) + 4 * h + (j & 3)) * kTS + r] > 0.0f ? gp[t][j] : 0.0f;
+				}
+#pragma unroll
+				for (int t = 0; t < W_T; ++t) g[t] = gp[t];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		}
+		if (a.gx) store_rows<W_T>(a.gx, a.gxs, a.dims[0], row, valid, a.gx_vec != 0, lane, g);
+	}
+
+	// ---- reduce the waves' parameter gradients in LDS (tile area is free now), then one atomic per element ----
+	__syncthreads();
+	float *R = lds + a.total_floats;                                    // [l][ot][it][j][lane] | db: [l][ot][lane]
+	float *Rb = R + L * W_T * W_T * 1024;
+	for (int w = 0; w < nw; ++w) {
+		if (wave == w) {
+#pragma unroll
+			for (int l = 0; l < L; ++l)
+#pragma unroll
+				for (int ot = 0; ot < W_T; ++ot) {
+					const int bi = (l * W_T + ot) * 64 + lane;
+					Rb[bi] = (w == 0 ? 0.0f : Rb[bi]) + db[l][ot];
+#pragma unroll
+					for (int it = 0; it < W_T; ++it)
+#pragma unroll
+						for (int j = 0; j < 16; ++j) {
+							const int e = ((((l * W_T + ot) * W_T + it) * 16 + j) << 6) + lane;
+							R[e] = (w == 0 ? 0.0f : R[e]) + dW[l][ot][it][j];
+						}
+				}
+		}
+		__syncthreads();
+	}
+	for (uint32_t e = threadIdx.x; e < (uint32_t)(L * W_T * W_T * 1024); e += blockDim.x) {
+		const uint32_t ln = e & 63u, j = (e >> 6) & 15u, it = (e >> 10) % W_T, ot = (e >> 10) / W_T % W_T, l = (e >> 10) / (W_T * W_T);
+		const uint32_t k = 32u * it + (ln & 31u), o = 32u * ot + 8u * (j >> 2) + 4u * (ln >> 5) + (j & 3u);
+		if (o < a.dims[l + 1] && k < a.dims[l]) atomic_add_f32(a.dW[l] + (size_t)o * a.dims[l] + k, R[e]);
+	}
+	for (uint32_t e = threadIdx.x; e < (uint32_t)(L * W_T * 32); e += blockDim.x) {
+		const uint32_t rr = e & 31u, ot = (e >> 5) % W_T, l = (e >> 5) / W_T;
+		const uint32_t o = 32u * ot + rr;
+		if (a.db[l] && o < a.dims[l + 1]) atomic_add_f32(a.db[l] + o, Rb[(l * W_T + ot) * 64 + rr] + Rb[(l * W_T + ot) * 64 + 32 + rr]);
+	}
+}
+
+}  // namespace mlp
+}  // namespace nr3d
+
+using namespace nr3d;
+using namespace nr3d::mlp;
+
+extern "C" uint64_t nr3d_mlp_packed_floats(const nr3d_mlp_desc_t *desc) {
+	Shape s;
+	if (!shape_of(desc, s)) return 0;
+	const uint64_t n = packed_floats(s);
+	return n * 4 <= (uint64_t)kMaxLds ? n : 0;      // 0: the fused kernels do not apply to this network
+}
+
+static int fill_pack(const nr3d_mlp_desc_t *d, const Shape &s, const float *const *weights, const float *const *biases, PackArgs &p) {
+	p.n_layers = d->n_layers;
+	p.transposed = 0;
+	uint32_t off = 0;
+	for (uint32_t l = 0; l < d->n_layers; ++l) {
+		NR3D_CHECK(weights[l] != nullptr, "mlp_pack: weights[%u] is NULL", l);
+		p.w[l] = weights[l];
+		p.b[l] = biases ? biases[l] : nullptr;
+		p.in_dim[l] = d->dims[l]; p.out_dim[l] = d->dims[l + 1];
+		p.ni[l] = l == 0 ? s.in_t : s.w_t;
+		p.no[l] = l + 1 == d->n_layers ? s.out_t : s.w_t;
+		p.offset[l] = off;
+		off += layer_floats(p.ni[l], p.no[l]);
+	}
+	p.offset[d->n_layers] = off;
+	return 0;
+}
+
+// the fused backward keeps every layer's dW in accumulator registers: hidden width <= 64, at most 2 hidden layers of
+// width > 32 (3 of width <= 32), input / output no wider (in tiles) than the hidden layers
+static bool backward_ok(const Shape &s) {
+	if (s.w_t > 2 || s.in_t > s.w_t || s.out_t > s.w_t) return false;
+	const uint32_t nh = s.n_layers - 1;
+	return s.w_t == 1 ? nh <= 3 : nh <= 2;
+}
+
+static uint64_t transposed_floats(const Shape &s) {
+	return (uint64_t)layer_floats(s.w_t, s.in_t) + (uint64_t)(s.n_layers - 2) * layer_floats(s.w_t, s.w_t) + layer_floats(s.out_t, s.w_t);
+}
+
+// per-wave [feature][sample] tiles: X, H_1 .. H_NH, G_out
+static uint32_t bwd_tile_floats(const Shape &s) { return (32u * s.in_t + (s.n_layers - 1) * 32u * s.w_t + 32u * s.out_t) * (uint32_t)kTS; }
+
+static uint32_t bwd_waves(const Shape &s) {
+	const uint64_t wbytes = (packed_floats(s) + transposed_floats(s)) * 4;
+	const uint64_t reduce = ((uint64_t)s.n_layers * s.w_t * s.w_t * 1024 + (uint64_t)s.n_layers * s.w_t * 64) * 4;
+	for (uint32_t nw = 4; nw >= 1; --nw) {
+		const uint64_t t = (uint64_t)nw * bwd_tile_floats(s) * 4;
+		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)kMaxLds) return nw;
+	}
+	return 0;
+}
+
+extern "C" uint64_t nr3d_mlp_backward_packed_floats(const nr3d_mlp_desc_t *desc) {
+	Shape s;
+	if (!shape_of(desc, s) || nr3d_mlp_packed_floats(desc) == 0 || !backward_ok(s) || bwd_waves(s) == 0) return 0;
+	return transposed_floats(s);
+}
+
+extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *weights, const float *const *biases, float *packed,
+                             int with_backward, void *stream) {
+	Shape s;
+	NR3D_CHECK(shape_of(desc, s) && nr3d_mlp_packed_floats(desc) != 0, "mlp_pack: network outside the fused kernels' range "
+	           "(2..%d linear layers, every width 1..128, packed weights <= %d KB)", NR3D_MLP_MAX_LAYERS, kMaxLds / 1024);
+	NR3D_CHECK(weights && packed, "mlp_pack: NULL pointer");
+	NR3D_CHECK(!with_backward || nr3d_mlp_backward_packed_floats(desc) != 0, "mlp_pack: the fused backward does not apply to this network");
+	PackArgs p;
+	if (int rc = fill_pack(desc, s, weights, biases, p)) return rc;
+	hipLaunchKernelGGL(k_mlp_pack, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, p, packed);
+	if (with_backward) {
+		// the layers of dH_{l} = W_l^T dPre_{l+1}: packed input tiles = the forward layer's output tiles and vice versa
+		PackArgs t = p;
+		t.transposed = 1;
+		uint32_t off = 0;
+		for (uint32_t l = 0; l < desc->n_layers; ++l) {
+			t.ni[l] = p.no[l]; t.no[l] = p.ni[l];
+			t.offset[l] = off;
+			off += layer_floats(t.ni[l], t.no[l]);
+		}
+		t.offset[desc->n_layers] = off;
+		hipLaunchKernelGGL(k_mlp_pack, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, t, packed + packed_floats(s));
+	}
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+#define MLP_DISPATCH(S, ...)                                                                                   \
+	do {                                                                                                       \
+		const uint32_t _i = (S).in_t, _w = (S).w_t, _o = (S).out_t;                                            \
+		auto _go = [&](auto I, auto W, auto O) { constexpr int IN_T = decltype(I)::value, W_T = decltype(W)::value, OUT_T = decltype(O)::value; __VA_ARGS__; }; \
+		auto _ow = [&](auto I, auto W) {                                                                       \
+			if (_o == 1) _go(I, W, std::integral_constant<int, 1>{});                                          \
+			else if (_o == 2) _go(I, W, std::integral_constant<int, 2>{});                                     \
+			else _go(I, W, std::integral_constant<int, 4>{}); };                                               \
+		auto _iw = [&](auto I) {                                                                               \
+			if (_w == 1) _ow(I, std::integral_constant<int, 1>{});                                             \
+			else if (_w == 2) _ow(I, std::integral_constant<int, 2>{});                                        \
+			else _ow(I, std::integral_constant<int, 4>{}); };                                                  \
+		if (_i == 1) _iw(std::integral_constant<int, 1>{});                                                    \
+		else if (_i == 2) _iw(std::integral_constant<int, 2>{});                                               \
+		else _iw(std::integral_constant<int, 4>{});                                                            \
+	} while (0)
+
+extern "C" int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, const float *packed,
+                                float *y, int64_t y_stride, void *stream) {
+	Shape s;
+	NR3D_CHECK(shape_of(desc, s) && nr3d_mlp_packed_floats(desc) != 0, "mlp_forward: network outside the fused kernels' range");
+	if (n == 0) return 0;
+	NR3D_CHECK(x && packed && y, "mlp_forward: NULL pointer");
+	FwdArgs a;
+	a.n = n; a.x = x; a.xs = x_stride; a.y = y; a.ys = y_stride; a.packed = packed;
+	a.packed_floats = (uint32_t)packed_floats(s);
+	a.n_layers = desc->n_layers; a.in_dim = desc->dims[0]; a.out_dim = desc->dims[desc->n_layers];
+	a.hidden_act = (int)desc->hidden_activation; a.out_act = (int)desc->output_activation;
+	a.x_vec = ((uintptr_t)x % 16 == 0 && x_stride % 4 == 0) ? 1u : 0u;
+	a.y_vec = ((uintptr_t)y % 16 == 0 && y_stride % 4 == 0) ? 1u : 0u;
+	const size_t lds = (size_t)a.packed_floats * 4;
+	const uint64_t n_tiles = (n + 31) / 32;
+	const uint32_t grid = (uint32_t)(n_tiles / 4 + 1 < 1024 ? n_tiles / 4 + 1 : 1024);
+	int rc = 0;
+	MLP_DISPATCH(s, {
+		static bool attr[64] = {};
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess) { rc = ::nr3d::fail("mlp_forward: hipGetDevice failed"); return; }
+		if (!attr[dev & 63]) {
+			if (hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+				rc = ::nr3d::fail("mlp_forward: cannot raise the dynamic LDS limit"); return;
+			}
+			attr[dev & 63] = true;
+		}
+		hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+	});
+	if (rc) return rc;
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, const float *dL_dy,
+                                 int64_t gy_stride, const float *packed, float *dL_dx, int64_t gx_stride, float *const *dL_dW,
+                                 float *const *dL_db, void *stream) {
+	Shape s;
+	NR3D_CHECK(shape_of(desc, s) && nr3d_mlp_backward_packed_floats(desc) != 0, "mlp_backward: the fused backward does not apply to this network");
+	if (n == 0) return 0;
+	NR3D_CHECK(x && dL_dy && packed && dL_dW, "mlp_backward: NULL pointer");
+	BwdArgs a;
+	a.n = n; a.x = x; a.xs = x_stride; a.gy = dL_dy; a.gys = gy_stride; a.gx = dL_dx; a.gxs = gx_stride; a.packed = packed;
+	a.fwd_floats = (uint32_t)packed_floats(s);
+	a.total_floats = a.fwd_floats + (uint32_t)transposed_floats(s);
+	for (uint32_t l = 0; l < desc->n_layers; ++l) {
+		NR3D_CHECK(dL_dW[l] != nullptr, "mlp_backward: dL_dW[%u] is NULL", l);
+		a.dW[l] = dL_dW[l];
+		a.db[l] = dL_db ? dL_db[l] : nullptr;
+	}
+	for (uint32_t l = 0; l <= desc->n_layers; ++l) a.dims[l] = desc->dims[l];
+	a.n_layers = desc->n_layers; a.in_t = s.in_t; a.out_t = s.out_t;
+	a.hidden_act = (int)desc->hidden_activation; a.out_act = (int)desc->output_activation;
+	a.x_vec = ((uintptr_t)x % 16 == 0 && x_stride % 4 == 0) ? 1u : 0u;
+	a.gy_vec = ((uintptr_t)dL_dy % 16 == 0 && gy_stride % 4 == 0) ? 1u : 0u;
+	a.gx_vec = (dL_dx && (uintptr_t)dL_dx % 16 == 0 && gx_stride % 4 == 0) ? 1u : 0u;
+	a.tile_floats = bwd_tile_floats(s);
+	const uint32_t nw = bwd_waves(s);
+	const uint64_t reduce = ((uint64_t)s.n_layers * s.w_t * s.w_t * 1024 + (uint64_t)s.n_layers * s.w_t * 64) * 4;
+	const uint64_t tbytes = (uint64_t)nw * a.tile_floats * 4;
+	const size_t lds = (size_t)a.total_floats * 4 + (size_t)(tbytes > reduce ? tbytes : reduce);
+	const uint64_t n_tiles = (n + 31) / 32;
+	const uint32_t grid = (uint32_t)(n_tiles / nw + 1 < 256 ? n_tiles / nw + 1 : 256);     // one workgroup per CU: dW lives in registers
+	const uint32_t nh = desc->n_layers - 1;
+	auto launch = [&](auto kern) -> int {
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
+		return 0;
+	};
+	int rc;
+	if (s.w_t == 1) rc = nh == 1 ? launch(k_mlp_bwd<1, 1>) : nh == 2 ? launch(k_mlp_bwd<1, 2>) : launch(k_mlp_bwd<1, 3>);
+	else rc = nh == 1 ? launch(k_mlp_bwd<2, 1>) : launch(k_mlp_bwd<2, 2>);
+	if (rc) return rc;
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}

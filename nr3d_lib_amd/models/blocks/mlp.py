@@ -1,0 +1,144 @@
+"""MLP blocks -- counterpart of ``MLP`` / ``FCBlock`` (nr3d_lib/models/blocks/mlp.py:27-127): D hidden ``DenseLayer``s of
+width(s) W and an output layer, optional skip connections.  Same constructor, parameter names (``layers.{i}.weight`` /
+``.bias``: checkpoints carry over) and forward signature.
+
+Where the reference runs one GEMM + one activation kernel per layer (or hands the network to tiny-cuda-nn), this module
+runs the whole network in ONE kernel on the fp32 MFMA (csrc/mlp.hip) whenever it can: fp32 on a GPU, ReLU / no
+activations, no skips / weight norm / equal_lr, every width <= 128.  Forward: activations stay in registers.  Backward
+(hidden width <= 64): the forward is recomputed from x inside the backward kernel, so autograd keeps x and nothing else.
+Everything else takes the layer-by-layer torch path below, with identical semantics."""
+from typing import List, Union
+
+import torch
+import torch.nn as nn
+
+from nr3d_lib_amd.models.layers import DenseLayer, get_nonlinearity
+from nr3d_lib_amd.profile import profile
+
+__all__ = ['MLP', 'FCBlock', 'FusedMLPFunction']
+
+USE_FUSED = True                       # False: always the layer-by-layer path (A/B measurements, debugging)
+
+
+class FusedMLPFunction(torch.autograd.Function):
+    """y = MLP(x) through nr3d_mlp_forward; backward through nr3d_mlp_backward (recomputes the forward).
+    args: desc, need (bool: a gradient may be asked for -> also pack the transposed layers), x, W_0, b_0 | None, W_1, ..."""
+
+    @staticmethod
+    def forward(ctx, desc, need, x, *params):
+        from nr3d_lib_amd.bindings import _mlp
+        ws, bs = list(params[0::2]), list(params[1::2])
+        packed = _mlp.pack(desc, ws, bs, with_backward=need)
+        if need:
+            ctx.save_for_backward(x, packed)
+            ctx.desc, ctx.has_bias = desc, [b is not None for b in bs]
+        return _mlp.forward(desc, x, packed)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dL_dy):
+        from nr3d_lib_amd.bindings import _mlp
+        x, packed = ctx.saved_tensors
+        dx, dWs, dbs = _mlp.backward(ctx.desc, x, dL_dy.float(), packed, need_dx=ctx.needs_input_grad[2], has_bias=ctx.has_bias)
+        grads = []
+        for i, (dW, db) in enumerate(zip(dWs, dbs)):
+            grads += [dW if ctx.needs_input_grad[3 + 2 * i] else None, db if (db is not None and ctx.needs_input_grad[4 + 2 * i]) else None]
+        return (None, None, dx, *grads)
+
+
+class MLP(nn.Module):
+    def __init__(self, in_features: int, out_features: int, *, D: int = 4, W: Union[int, List[int]] = 128, skips: List[int] = [],
+                 activation: Union[str, dict] = 'relu', output_activation: Union[str, dict] = None, bias=True,
+                 last_bias: bool = None, equal_lr=False, weight_norm=False, dtype: Union[str, torch.dtype] = None,
+                 device: torch.device = None):
+        super().__init__()
+        self.dtype = dtype = (dtype if isinstance(dtype, torch.dtype) or dtype is None
+                              else getattr(torch, str(dtype).replace('torch.', '')))
+        nl, gain, init_fn, first_init_fn = get_nonlinearity(activation)
+        last_nl, last_gain, last_init_fn, _ = get_nonlinearity(output_activation)
+        if last_bias is None:
+            last_bias = bias
+        self.D = D
+        self.Ws = [W] * D if isinstance(W, int) else W
+        if self.D >= 1:
+            assert len(self.Ws) == D, f"The length of list W={self.Ws} should be D={D}."
+        self.in_features, self.out_features = in_features, out_features
+        self.skips, self.activation, self.output_activation = skips, activation, output_activation
+        layers = []
+        for l in range(self.D + 1):
+            out_dim = out_features if l == self.D else self.Ws[l]
+            in_dim = in_features if l == 0 else (in_features + self.Ws[l - 1] if l in self.skips else self.Ws[l - 1])
+            last = l == self.D
+            layer = DenseLayer(in_dim, out_dim, activation=last_nl if last else nl, bias=last_bias if last else bias,
+                               dtype=self.dtype or torch.float, device=device, equal_lr=equal_lr)
+            layer.apply(last_init_fn if last else (first_init_fn if l == 0 else init_fn))
+            if weight_norm:
+                layer = nn.utils.weight_norm(layer)
+            layers.append(layer)
+        self.layers = nn.ModuleList(layers)
+        self._plain = not (skips or weight_norm or equal_lr)
+        self._desc = None
+
+    @property
+    def device(self) -> torch.device:
+        return self.layers[0].weight.device
+
+    def get_weight_reg(self, norm_type: float = 2.0):
+        return torch.stack([p.norm(p=norm_type) for n, p in self.layers.named_parameters()])
+
+    # ---- the fused path ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _act_code(layer):
+        from nr3d_lib_amd.bindings import _mlp
+        a = layer.activation
+        if a is None:
+            return _mlp.ACT_NONE
+        return _mlp.ACT_RELU if isinstance(a, nn.ReLU) else None
+
+    def fused_desc(self):
+        """the kernel-side description of this network, or None when the fused kernels do not apply to it"""
+        if self._desc is None:
+            from nr3d_lib_amd.bindings import _mlp
+            ok = self._plain and self.D >= 1 and self.dtype in (None, torch.float32)
+            hid = {self._act_code(l) for l in self.layers[:-1]}
+            out = self._act_code(self.layers[-1])
+            if ok and len(hid) == 1 and None not in hid and out is not None and len(self.layers) <= _mlp.MAX_LAYERS:
+                d = _mlp.MLPDesc([self.in_features, *self.Ws, self.out_features], hid.pop(), out)
+                self._desc = d if d.fusable else False
+            else:
+                self._desc = False
+        return self._desc or None
+
+    def _fused_ok(self, x, return_last, input_max_channel):
+        if not (USE_FUSED and x.is_cuda and x.dtype == torch.float32 and not return_last and input_max_channel is None):
+            return None
+        if torch.is_autocast_enabled():
+            return None
+        desc = self.fused_desc()
+        if desc is None:
+            return None
+        self._needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.layers.parameters()))
+        return desc if (not self._needs_grad or desc.backward_fusable) else None
+
+    @profile
+    def forward(self, x: torch.Tensor, return_last: bool = False, input_max_channel: int = None):
+        desc = self._fused_ok(x, return_last, input_max_channel)
+        if desc is not None:
+            params = []
+            for layer in self.layers:
+                params += [layer.weight, layer.bias]
+            return FusedMLPFunction.apply(desc, self._needs_grad, x, *params)
+        for i, layer in enumerate(self.layers):
+            if i == 0:
+                h = layer(x, max_channel=input_max_channel)
+            elif i in self.skips:
+                h = layer(torch.cat([h, x], dim=-1))
+            elif i == self.D:
+                last_h = h
+                h = layer(h)
+            else:
+                h = layer(h)
+        return (h, last_h) if return_last else h
+
+
+FCBlock = MLP

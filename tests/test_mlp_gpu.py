@@ -1,0 +1,131 @@
+"""GPU: the fused MLP kernels (csrc/mlp.hip through bindings._mlp / models.blocks.MLP) against plain PyTorch.
+
+The f32 MFMA is an fmaf chain, so the fused network differs from torch's fp32 GEMM path by summation order only.  ReLU
+makes the function discontinuous in the pre-activations, hence the yardstick: the error against an fp64 evaluation must
+stay within a few times the error of torch's OWN fp32 path against the same fp64 evaluation (and within 1e-5 of the
+output scale when no unit sits on a kink)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # dims, n, hidden act, out act, bias
+    ([32, 32, 16], 4099, "relu", None, True),
+    ([32, 64, 64, 16], 10007, "relu", None, True),
+    ([18, 64, 3], 777, "relu", "relu", True),
+    ([16, 32, 32, 32, 7], 4097, "relu", None, False),
+    ([40, 48, 33], 33, None, None, True),
+    ([3, 8, 1], 1, "relu", None, True),
+    ([64, 64, 64], 2048, "relu", None, True),
+]
+
+
+def _net(dims, hidden, out, bias, dev, seed=0):
+    from nr3d_lib_amd.models.blocks import MLP
+    torch.manual_seed(seed)
+    m = MLP(dims[0], dims[-1], D=len(dims) - 2, W=dims[1:-1], activation=hidden or "none", output_activation=out, bias=bias,
+            dtype=torch.float, device=dev)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * (0.4 if p.dim() > 1 else 0.2))
+    return m
+
+
+def _reference(m, x, gy, dtype):
+    """layer-by-layer torch evaluation in `dtype` -> (y, dx, [dW], [db])"""
+    h = x.detach().to(dtype).requires_grad_(True)
+    h0 = h
+    ws = [l.weight.detach().to(dtype).requires_grad_(True) for l in m.layers]
+    bs = [None if l.bias is None else l.bias.detach().to(dtype).requires_grad_(True) for l in m.layers]
+    for l, W, b in zip(m.layers, ws, bs):
+        h = torch.nn.functional.linear(h, W, b)
+        if l.activation is not None:
+            h = torch.relu(h)
+    h.backward(gy.to(dtype))
+    return h.detach(), h0.grad, [w.grad for w in ws], [None if b is None else b.grad for b in bs]
+
+
+def _check(name, got, ref64, ref32):
+    scale = float(ref64.abs().max()) or 1.0
+    err = float((got.double() - ref64).abs().max()) / scale
+    err32 = float((ref32.double() - ref64).abs().max()) / scale
+    assert err <= max(1e-5, 4 * err32), f"{name}: rel err {err:.2e} (torch fp32 path: {err32:.2e})"
+
+
+@pytest.mark.parametrize("dims,n,hidden,out,bias", CASES)
+def test_fused_forward_backward_match_torch(dev, dims, n, hidden, out, bias):
+    from nr3d_lib_amd.models.blocks import mlp as mlp_mod
+    m = _net(dims, hidden, out, bias, dev)
+    desc = m.fused_desc()
+    assert desc is not None and desc.backward_fusable
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(n, dims[0], generator=g).to(dev).requires_grad_(True)
+    gy = torch.randn(n, dims[-1], generator=g).to(dev)
+    y64, dx64, dW64, db64 = _reference(m, x, gy, torch.float64)
+    y32, dx32, dW32, db32 = _reference(m, x, gy, torch.float32)
+    y = m(x)
+    assert y.grad_fn is not None and "FusedMLPFunction" in type(y.grad_fn).__name__
+    y.backward(gy)
+    _check("y", y.detach(), y64, y32)
+    _check("dL_dx", x.grad, dx64, dx32)
+    for l, layer in enumerate(m.layers):
+        _check(f"dL_dW{l}", layer.weight.grad, dW64[l], dW32[l])
+        if bias:
+            _check(f"dL_db{l}", layer.bias.grad, db64[l], db32[l])
+    # inference (no autograd): same kernel, no transposed weights packed
+    with torch.no_grad():
+        _check("y (no_grad)", m(x), y64, y32)
+    # the layer-by-layer path of the same module agrees
+    mlp_mod.USE_FUSED = False
+    try:
+        _check("unfused y", m(x).detach(), y64, y32)
+    finally:
+        mlp_mod.USE_FUSED = True
+
+
+def test_fused_handles_strided_rows_leading_dims_and_frozen_inputs(dev):
+    m = _net([32, 64, 16], "relu", None, True, dev)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    big = torch.randn(6, 50, 40, generator=g).to(dev)
+    x = big[..., 3:35]                                   # rows of 32 floats at stride 40, not 16-byte aligned
+    gy = torch.randn(6, 50, 16, generator=g).to(dev)
+    y64, _, dW64, _ = _reference(m, x.reshape(-1, 32), gy.reshape(-1, 16), torch.float64)
+    y32, _, dW32, _ = _reference(m, x.reshape(-1, 32), gy.reshape(-1, 16), torch.float32)
+    y = m(x)                                             # x does not require grad: dL/dx is not computed
+    assert tuple(y.shape) == (6, 50, 16)
+    y.backward(gy)
+    _check("y", y.detach().reshape(-1, 16), y64, y32)
+    _check("dW0", m.layers[0].weight.grad, dW64[0], dW32[0])
+    # empty batch
+    assert tuple(m(torch.zeros(0, 32, device=dev)).shape) == (0, 16)
+    # parameter gradients accumulate across calls like any autograd op
+    before = m.layers[1].weight.grad.clone()
+    m(x).backward(gy)
+    torch.testing.assert_close(m.layers[1].weight.grad, 2 * before, rtol=1e-4, atol=1e-5)
+
+
+def test_networks_outside_the_fused_range_take_the_torch_path(dev):
+    from nr3d_lib_amd.bindings import _mlp
+    from nr3d_lib_amd.models.blocks import MLP, get_blocks
+    x = torch.randn(100, 32, device=dev)
+    wide = MLP(32, 4, D=2, W=128, dtype=torch.float, device=dev)              # forward fuses, backward does not (W > 64)
+    assert wide.fused_desc() is not None and not wide.fused_desc().backward_fusable
+    with torch.no_grad():
+        y_f = wide(x)
+    y_t = wide(x)                                                             # needs grad -> torch path
+    assert "FusedMLP" not in type(y_t.grad_fn).__name__
+    torch.testing.assert_close(y_f, y_t.detach(), rtol=1e-4, atol=1e-5)
+    for kw in (dict(skips=[1]), dict(activation="softplus"), dict(weight_norm=True), dict(D=0, W=[]), dict(W=200)):
+        args = dict(D=2, W=32, dtype=torch.float, device=dev); args.update(kw)
+        net = MLP(32, 4, **args)
+        assert net.fused_desc() is None
+        assert tuple(net(x).shape) == (100, 4)
+    half = get_blocks(32, 4, D=1, W=64, dtype=torch.half, device=dev, use_tcnn_backend=True, weight_norm=False)
+    assert half.fused_desc() is None and half(x).dtype == torch.float16
+    assert _mlp.MLPDesc([32, 64, 16]).fusable and not _mlp.MLPDesc([32, 16]).fusable and not _mlp.MLPDesc([300, 64, 3]).fusable
+    with pytest.raises(RuntimeError, match="outside the fused"):
+        _mlp.pack(_mlp.MLPDesc([32, 16]), [torch.zeros(16, 32, device=dev)], [None])
+    with pytest.raises(RuntimeError, match="backward does not apply"):
+        _mlp.pack(_mlp.MLPDesc([32, 128, 4]), [torch.zeros(128, 32, device=dev), torch.zeros(4, 128, device=dev)], [None, None], True)

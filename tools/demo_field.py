@@ -1,10 +1,13 @@
 """tools/demo_field.py -- TEST / BENCH INFRASTRUCTURE: the smallest model that satisfies the protocol of
 nerf_ray_query_march_occ (accel.ray_march, query_density, forward_density, forward).  16-level NGP LoTD encoder (the
-HIP path) + two tiny torch MLPs with random weights; not part of the product."""
+HIP path) + two tiny MLP blocks with random weights; not part of the product."""
+import os
+
 import torch
 import torch.nn as nn
 
 from nr3d_lib_amd.graphics.raymarch.occgrid_raymarch import occgrid_raymarch
+from nr3d_lib_amd.models.blocks import MLP
 from nr3d_lib_amd.models.grid_encodings.lotd import LoTD, gen_ngp_cfg
 
 
@@ -31,8 +34,13 @@ class DemoField(nn.Module):
         n_params = self.encoding.meta.n_params if hasattr(self.encoding, "meta") else self.encoding.n_params
         self.grid = nn.Parameter(torch.empty(n_params).uniform_(-1e-1, 1e-1, generator=g))
         e = self.encoding.out_features
-        self.density = nn.Sequential(nn.Linear(e, hidden), nn.ReLU(), nn.Linear(hidden, 1 + 15))
-        self.color = nn.Sequential(nn.Linear(15 + 3, hidden), nn.ReLU(), nn.Linear(hidden, 3))
+        # the decoder blocks of the package (fused MFMA kernels when they apply; tools/bench: NR3D_DEMO_TORCH_MLP=1 for A/B)
+        if os.environ.get("NR3D_DEMO_TORCH_MLP") == "1":
+            self.density = nn.Sequential(nn.Linear(e, hidden), nn.ReLU(), nn.Linear(hidden, 1 + 15))
+            self.color = nn.Sequential(nn.Linear(15 + 3, hidden), nn.ReLU(), nn.Linear(hidden, 3))
+        else:
+            self.density = MLP(e, 1 + 15, D=1, W=hidden, dtype=torch.float)
+            self.color = MLP(15 + 3, 3, D=1, W=hidden, dtype=torch.float)
         for p, s in zip(self.parameters(), range(100)):
             if p is not self.grid:
                 with torch.no_grad():
