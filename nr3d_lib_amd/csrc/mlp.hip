@@ -96,31 +96,42 @@ __global__ __launch_bounds__(256) void k_mlp_pack(PackArgs a, float *__restrict_
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float activate(float v, int act) { return act == NR3D_MLP_ACT_RELU ? fmaxf(v, 0.0f) : v; }
 
+// The weight fragments (one 16-byte LDS read per lane and 4 MFMA steps) run kWPF groups ahead of the MFMAs that consume
+// them: with one or two waves per SIMD nothing else would cover the LDS latency, and left alone the compiler issues
+// each read right in front of its use.
+constexpr int kWPF = 6;
+
 template <int NI, int NO, bool BIAS>
 __device__ __forceinline__ void dense(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
 	const float *bias = wp + NO * NI * 1024;
 	const int h = lane >> 5;
+	constexpr int G = NO * NI * 4;                 // weight groups, in (ot, it, q) order = their order in LDS
+	constexpr int PF = kWPF < G ? kWPF : G;
+	const f4v *wv = reinterpret_cast<const f4v *>(wp) + lane;
+	f4v ring[PF];
+#pragma unroll
+	for (int g = 0; g < PF; ++g) ring[g] = wv[g * 64];
 #pragma unroll
 	for (int ot = 0; ot < NO; ++ot) {
-		f16v acc;
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			f4v b4 = {0.0f, 0.0f, 0.0f, 0.0f};
 			if (BIAS) b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
 #pragma unroll
-			for (int b = 0; b < 4; ++b) acc[4 * q + b] = b4[b];
+			for (int b = 0; b < 4; ++b) out[ot][4 * q + b] = b4[b];
 		}
+	}
 #pragma unroll
-		for (int it = 0; it < NI; ++it)
+	for (int g = 0; g < G; ++g) {
+		const int ot = g / (NI * 4), it = (g / 4) % NI, q = g % 4;
+		const f4v w4 = ring[g % PF];
+		if (g + PF < G) ring[g % PF] = wv[(g + PF) * 64];
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				const f4v w4 = *reinterpret_cast<const f4v *>(wp + ((((ot * NI + it) * 4 + q) * 64 + lane) << 2));
+		for (int b = 0; b < 4; ++b) out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[b], in[it][4 * q + b], out[ot], 0, 0, 0);
+		if (it == NI - 1 && q == 3) {
 #pragma unroll
-				for (int b = 0; b < 4; ++b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[b], in[it][4 * q + b], acc, 0, 0, 0);
-			}
-#pragma unroll
-		for (int j = 0; j < 16; ++j) acc[j] = activate(acc[j], act);
-		out[ot] = acc;
+			for (int j = 0; j < 16; ++j) out[ot][j] = activate(out[ot][j], act);
+		}
 	}
 }
 
@@ -143,6 +154,27 @@ __device__ __forceinline__ void load_rows(const float *__restrict__ p, int64_t s
 					for (int b = 0; b < 4; ++b) if (f + b < dim) v[b] = src[b];
 				}
 			}
+#pragma unroll
+			for (int b = 0; b < 4; ++b) r[t][4 * q + b] = v[b];
+		}
+}
+
+// Branch-free variant for 16-byte aligned rows whose width is a multiple of 4: every lane loads from a valid address
+// (row clamped to the last row, a piece beyond the width re-reads piece 0) and nothing is selected afterwards -- padded
+// features meet zero weights and rows beyond n are never stored -- so no value is consumed before the first MFMA and
+// the loads of the NEXT tile can stay in flight under this tile's arithmetic (a load under a branch makes the compiler
+// drain the memory counter at the join).
+template <int NT>
+__device__ __forceinline__ void load_rows_fast(const float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row_clamped,
+                                               int lane, f16v (&r)[NT]) {
+	const int h = lane >> 5;
+	const float *base = p + (int64_t)row_clamped * stride;
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint32_t f = 32u * t + 8u * q + 4u * h;
+			const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + (f < dim ? f : 0u)));
 #pragma unroll
 			for (int b = 0; b < 4; ++b) r[t][4 * q + b] = v[b];
 		}
@@ -187,18 +219,28 @@ __device__ __forceinline__ void stage_weights(const float *__restrict__ packed, 
 	__syncthreads();
 }
 
-template <int IN_T, int W_T, int OUT_T>
+template <int IN_T, int W_T, int OUT_T, bool XF>
 __global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	stage_weights(a.packed, a.packed_floats, lds);
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint64_t n_tiles = (a.n + 31) / 32;
+	const uint64_t n_tiles = (a.n + 31) / 32, step = (uint64_t)gridDim.x * 4;
 	const uint32_t off_hidden = layer_floats(IN_T, W_T), sz_hidden = layer_floats(W_T, W_T);
-	for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * 4) {
+	auto clamp_row = [&](uint64_t row) { return row < a.n ? row : a.n - 1; };
+	f16v xnext[IN_T];
+	if (XF) load_rows_fast<IN_T>(a.x, a.xs, a.in_dim, clamp_row(((uint64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31)), lane, xnext);
+	for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += step) {
 		const uint64_t row = tile * 32 + (lane & 31);
 		const bool valid = row < a.n;
 		f16v xin[IN_T], hcur[W_T], yo[OUT_T];
-		load_rows<IN_T>(a.x, a.xs, a.in_dim, row, valid, a.x_vec != 0, lane, xin);
+		if (XF) {
+			// software pipeline: this tile's rows were requested one iteration ago, the next tile's go out now
+#pragma unroll
+			for (int t = 0; t < IN_T; ++t) xin[t] = xnext[t];
+			load_rows_fast<IN_T>(a.x, a.xs, a.in_dim, clamp_row((tile + step) * 32 + (lane & 31)), lane, xnext);
+		} else {
+			load_rows<IN_T>(a.x, a.xs, a.in_dim, row, valid, a.x_vec != 0, lane, xin);
+		}
 		dense<IN_T, W_T, true>(lds, xin, hcur, a.hidden_act, lane);
 #pragma unroll 1
 		for (uint32_t l = 1; l + 1 < a.n_layers; ++l) {
@@ -211,7 +253,6 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
 		store_rows<OUT_T>(a.y, a.ys, a.out_dim, row, valid, a.y_vec != 0, lane, yo);
 	}
 }
-
 
 // =============================================================================================
 // backward: dL/dx (optional), dL/dW_l, dL/db_l from x and dL/dy, forward recomputed in registers
@@ -570,12 +611,16 @@ extern "C" int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const f
 		int dev = 0;
 		if (hipGetDevice(&dev) != hipSuccess) { rc = ::nr3d::fail("mlp_forward: hipGetDevice failed"); return; }
 		if (!attr[dev & 63]) {
-			if (hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+			if (hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess ||
+			    hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
 				rc = ::nr3d::fail("mlp_forward: cannot raise the dynamic LDS limit"); return;
 			}
 			attr[dev & 63] = true;
 		}
-		hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+		if (a.x_vec && a.in_dim % 4 == 0)
+			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, true>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+		else
+			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, false>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
 	});
 	if (rc) return rc;
 	NR3D_LAUNCH_CHECK();
