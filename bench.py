@@ -162,7 +162,7 @@ def full_loop_rate(dev, side=512, iters=5):
         one()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
-    return dict(workload=f"march + prune + 16-level Hash LoTD encode (+ tiny MLP) + composite, fwd+bwd, {n} rays",
+    return dict(workload=f"march + prune + 16-level Hash LoTD encode + fused MLP decoders (32-wide) + composite, fwd+bwd, {n} rays",
                 samples_marched=marched, samples_rendered=rendered, ms_per_iter=round(ms, 3),
                 mrays_per_s=round(n / ms / 1e3, 3), msamples_per_s=round((marched + rendered) / ms / 1e3, 3))
 
@@ -243,6 +243,54 @@ def forest_lotd_rate(dev, log2n=20, iters=10):
     return dict(workload=f"forest LoTD, {space.n_trees} blocks x {L} levels (4 Dense + 4 Hash), 2^{log2n} points, "
                          f"fwd(+dy/dx) + dL/dx + dL/dparam (binned)", ms_per_iter=round(ms, 3),
                 mpoints_per_s=round(n / ms / 1e3, 2))
+
+
+def mlp_decoder_rate(dev, log2n=22, iters=10):
+    """SURVEY 8f rank 4 (second half) as an extra figure: the fused decoder 32 -> 64 -> 64 -> 16 (ReLU) on 2^22 samples,
+    forward and backward (dL/dx + all dL/dW, dL/db; forward recomputed inside), against the layer-by-layer PyTorch path.
+    Roofline: the f32 MFMA (157.3 TFLOP/s dense; MI355X_MICROARCH.md), FLOPs counted on the UNPADDED layer shapes."""
+    from nr3d_lib_amd.models.blocks import MLP
+    from nr3d_lib_amd.models.blocks import mlp as mlp_mod
+    dims = [32, 64, 64, 16]
+    n = 1 << log2n
+    torch.manual_seed(0)
+    net = MLP(dims[0], dims[-1], D=2, W=64, dtype=torch.float, device=dev)
+    x = torch.randn(n, dims[0], device=dev)
+    gy = torch.randn(n, dims[-1], device=dev)
+    mac = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+
+    def timed(fn):
+        fn(); fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    def fwd():
+        with torch.no_grad():
+            return net(x)
+
+    def fwd_bwd():
+        xr = x.detach().requires_grad_(True)
+        net.zero_grad(set_to_none=True)
+        net(xr).backward(gy)
+    out = {}
+    for name, fused in (("fused", True), ("torch", False)):
+        mlp_mod.USE_FUSED = fused
+        try:
+            out[name] = dict(fwd_ms=round(timed(fwd), 4), fwd_bwd_ms=round(timed(fwd_bwd), 4))
+        finally:
+            mlp_mod.USE_FUSED = True
+    f = out["fused"]
+    bwd_ms = f["fwd_bwd_ms"] - f["fwd_ms"]
+    peak = 157.3
+    tf_fwd = 2 * mac * n / (f["fwd_ms"] * 1e-3) / 1e12
+    tf_bwd = 2 * 3 * mac * n / (bwd_ms * 1e-3) / 1e12         # recomputed forward + dH chain + dW
+    return dict(workload=f"fused MLP {dims} (ReLU), 2^{log2n} samples, fp32", fused=f, torch=out["torch"],
+                msamples_per_s_fwd=round(n / f["fwd_ms"] / 1e3, 1), msamples_per_s_fwd_bwd=round(n / f["fwd_bwd_ms"] / 1e3, 1),
+                roofline=dict(bound="mfma", unit="TFLOP/s", peak=peak, fwd_achieved=round(tf_fwd, 1), fwd_frac=round(tf_fwd / peak, 3),
+                              bwd_achieved=round(tf_bwd, 1), bwd_frac=round(tf_bwd / peak, 3)))
 
 
 def c4_mixed_rate():
@@ -376,6 +424,7 @@ def main():
                              ("c1_dense_fwd", lambda: c1_dense_rate(dev)),
                              ("full_loop_1gpu", lambda: full_loop_rate(dev)),
                              ("forest_lotd", lambda: forest_lotd_rate(dev)),
+                             ("mlp_decoder", lambda: mlp_decoder_rate(dev)),
                              ("c4_mixed_lotd", c4_mixed_rate),
                              ("lotd_2p24_points", lambda: lotd_large_batch_rate(24))):
                 try:                     # an extra figure must never cost the headline line (or the other extras)

@@ -32,9 +32,9 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 256;                  // 4 waves per workgroup, one 32-sample tile per wave at a time
 constexpr int kMaxLds = 144 * 1024;            // of the CU's 160 KB
 
-__host__ __device__ inline uint32_t tiles(uint32_t d) { return (d + 31u) / 32u; }
+__host__ __device__ constexpr uint32_t tiles(uint32_t d) { return (d + 31u) / 32u; }
 // floats of one packed layer: weights [NO][NI][4][64][4] + bias [NO * 32]
-__host__ __device__ inline uint32_t layer_floats(uint32_t ni, uint32_t no) { return no * ni * 1024u + no * 32u; }
+__host__ __device__ constexpr uint32_t layer_floats(uint32_t ni, uint32_t no) { return no * ni * 1024u + no * 32u; }
 
 struct Shape {
 	uint32_t n_layers;                         // linear layers (hidden + output)
@@ -260,43 +260,6 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
 constexpr int kTS = 36;                        // row stride (floats) of the per-wave [feature][sample] LDS tiles:
                                                // 16-byte aligned rows, and 8 consecutive rows cover all 32 banks
 
-// dense layer whose tile counts are only bounded at compile time (ni <= MAXI, no <= MAXO; wave-uniform skips)
-template <int MAXI, int MAXO, bool BIAS>
-__device__ __forceinline__ void dense_rt(const float *__restrict__ wp, int ni, int no, const f16v (&in)[MAXI], f16v (&out)[MAXO],
-                                         int act, int lane) {
-	const float *bias = wp + no * ni * 1024;
-	const int h = lane >> 5;
-#pragma unroll
-	for (int ot = 0; ot < MAXO; ++ot) {
-		f16v acc;
-#pragma unroll
-		for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-		if (ot < no) {
-			if (BIAS) {
-#pragma unroll
-				for (int q = 0; q < 4; ++q) {
-					const f4v b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
-#pragma unroll
-					for (int b = 0; b < 4; ++b) acc[4 * q + b] = b4[b];
-				}
-			}
-#pragma unroll
-			for (int it = 0; it < MAXI; ++it) {
-				if (it >= ni) continue;
-#pragma unroll
-				for (int q = 0; q < 4; ++q) {
-					const f4v w4 = *reinterpret_cast<const f4v *>(wp + ((((ot * ni + it) * 4 + q) * 64 + lane) << 2));
-#pragma unroll
-					for (int b = 0; b < 4; ++b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[b], in[it][4 * q + b], acc, 0, 0, 0);
-				}
-			}
-#pragma unroll
-			for (int j = 0; j < 16; ++j) acc[j] = activate(acc[j], act);
-		}
-		out[ot] = acc;
-	}
-}
-
 // register map -> [feature][sample] tile (rows of kTS floats)
 template <int MAXT>
 __device__ __forceinline__ void write_tile(float *__restrict__ T, int nt, const f16v (&r)[MAXT], int lane) {
@@ -329,13 +292,97 @@ struct BwdArgs {
 	float *dW[NR3D_MLP_MAX_LAYERS];            // accumulated into (atomics): zero them for plain gradients
 	float *db[NR3D_MLP_MAX_LAYERS];            // may be NULL
 	uint32_t dims[NR3D_MLP_MAX_LAYERS + 1];
-	uint32_t n_layers, in_t, out_t;
+	uint32_t n_layers;
 	int hidden_act, out_act;
 	uint32_t x_vec, gy_vec, gx_vec;
 	uint32_t tile_floats;                      // per wave
 };
 
-template <int W_T, int NH>
+// One layer of the backward sweep.  g = dL/d(pre-activation of this layer's output) on the register map (NO tiles);
+// TG: LDS tile that receives g as [feature][sample]; TB: the layer's INPUT activations as [feature][sample] (NI tiles);
+// wT: packed transposed layer.  Accumulates dW (NO x NI tiles) and the per-lane bias partial sums; when PREV, leaves
+// dL/d(input of the layer) in gp, masked with the ReLU derivative of the input activations when MASK.
+template <int NO, int NI, bool PREV, bool MASK>
+__device__ __forceinline__ void bwd_layer(const f16v (&g)[NO], float *__restrict__ TG, const float *__restrict__ TB,
+                                          const float *__restrict__ wT, f16v (&dW)[NO][NI], float (&db)[NO], f16v (&gp)[NI],
+                                          int lane) {
+	const int r = lane & 31, h = lane >> 5;
+	write_tile<NO>(TG, NO, g, lane);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	float bv[NI][16];
+#pragma unroll
+	for (int it = 0; it < NI; ++it) read_row16(TB, 32 * it + r, h, bv[it]);
+#pragma unroll
+	for (int ot = 0; ot < NO; ++ot) {
+		float av[16];
+		read_row16(TG, 32 * ot + r, h, av);
+		float sum = 0.0f;
+#pragma unroll
+		for (int t = 0; t < 16; ++t) sum += av[t];
+		db[ot] += sum;
+#pragma unroll
+		for (int it = 0; it < NI; ++it)
+#pragma unroll
+			for (int t = 0; t < 16; ++t) dW[ot][it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[it][t], dW[ot][it], 0, 0, 0);
+	}
+	if (PREV) {
+		dense<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);
+		if (MASK) {
+#pragma unroll
+			for (int t = 0; t < NI; ++t)
+#pragma unroll
+				for (int j = 0; j < 16; ++j)
+					gp[t][j] = TB[(32 * t + 8 * (j >> 2) + 4 * h + (j & 3)) * kTS + r] > 0.0f ? gp[t][j] : 0.0f;
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+// sum one layer's gradient accumulators over the waves of the workgroup (through LDS) and add them to global memory
+template <int NO, int NI>
+__device__ __forceinline__ void reduce_layer(const f16v (&dW)[NO][NI], const float (&db)[NO], float *__restrict__ R, float *gW, float *gb,
+                                             uint32_t out_dim, uint32_t in_dim, int lane, int wave, int nw) {
+	float *Rb = R + NO * NI * 1024;
+	for (int w = 0; w < nw; ++w) {
+		if (wave == w) {
+#pragma unroll
+			for (int ot = 0; ot < NO; ++ot) {
+				Rb[ot * 64 + lane] = (w == 0 ? 0.0f : Rb[ot * 64 + lane]) + db[ot];
+#pragma unroll
+				for (int it = 0; it < NI; ++it)
+#pragma unroll
+					for (int j = 0; j < 16; ++j) {
+						const int e = (((ot * NI + it) * 16 + j) << 6) + lane;
+						R[e] = (w == 0 ? 0.0f : R[e]) + dW[ot][it][j];
+					}
+			}
+		}
+		__syncthreads();
+	}
+	for (uint32_t e = threadIdx.x; e < (uint32_t)(NO * NI * 1024); e += blockDim.x) {
+		const uint32_t ln = e & 63u, j = (e >> 6) & 15u, it = (e >> 10) % NI, ot = (e >> 10) / NI;
+		const uint32_t k = 32u * it + (ln & 31u), o = 32u * ot + 8u * (j >> 2) + 4u * (ln >> 5) + (j & 3u);
+		if (o < out_dim && k < in_dim) atomic_add_f32(gW + (size_t)o * in_dim + k, R[e]);
+	}
+	if (gb)
+		for (uint32_t e = threadIdx.x; e < (uint32_t)(NO * 32); e += blockDim.x) {
+			const uint32_t o = e;                                       // 32 ot + row
+			if (o < out_dim) atomic_add_f32(gb + o, Rb[(e >> 5) * 64 + (e & 31u)] + Rb[(e >> 5) * 64 + 32 + (e & 31u)]);
+		}
+	__syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f16v (&r)[NT]) {
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+#pragma unroll
+		for (int j = 0; j < 16; ++j) r[t][j] = 0.0f;
+}
+
+// FAST: x and dL/dy rows are 16-byte aligned with widths that are multiples of 4 -> branch-free loads, the next tile's
+// rows requested while this tile is processed (one wave per SIMD: nothing else hides the memory latency)
+template <int IN_T, int W_T, int OUT_T, int NH, bool FAST>
 __global__ __launch_bounds__(kThreads) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	{
@@ -344,143 +391,105 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(BwdArgs a) {
 		for (uint32_t i = threadIdx.x; i < a.total_floats / 4; i += blockDim.x) dst[i] = src[i];
 		__syncthreads();
 	}
-	constexpr int L = NH + 1;                  // linear layers
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-	const int r = lane & 31, h = lane >> 5;
-	const int in_t = (int)a.in_t, out_t = (int)a.out_t;
+	const int r = lane & 31;
 	float *tiles = lds + a.total_floats + (size_t)wave * a.tile_floats;
 	// tile rows: X | H_1 .. H_NH | G_out
 	float *TX = tiles;
-	float *TH0 = tiles + 32 * in_t * kTS;                               // H_l at TH0 + (l - 1) * 32 * W_T * kTS
-	float *TGO = TH0 + NH * 32 * W_T * kTS;
-	auto TH = [&](int l) { return l == 0 ? TX : TH0 + (l - 1) * 32 * W_T * kTS; };
-	// packed layer offsets
-	uint32_t off_f[L], off_t[L];
-	{
-		uint32_t of = 0, ot = a.fwd_floats;
-#pragma unroll
-		for (int l = 0; l < L; ++l) {
-			const uint32_t ni = l == 0 ? in_t : W_T, no = l == NH ? out_t : W_T;
-			off_f[l] = of; of += layer_floats(ni, no);
-			off_t[l] = ot; ot += layer_floats(no, ni);                   // transposed layer: in = no tiles, out = ni tiles
-		}
-	}
-	f16v dW[L][W_T][W_T];
-	float db[L][W_T];
-#pragma unroll
-	for (int l = 0; l < L; ++l)
-#pragma unroll
-		for (int ot = 0; ot < W_T; ++ot) {
-			db[l][ot] = 0.0f;
-#pragma unroll
-			for (int it = 0; it < W_T; ++it)
-#pragma unroll
-				for (int j = 0; j < 16; ++j) dW[l][ot][it][j] = 0.0f;
-		}
+	float *TH1 = tiles + 32 * IN_T * kTS;                               // H_l at TH1 + (l - 1) * 32 * W_T * kTS
+	float *TGO = TH1 + NH * 32 * W_T * kTS;
+	// packed layers: forward [0 | hidden ... | out], then the transposed ones in the same order
+	constexpr uint32_t f0 = layer_floats(IN_T, W_T), fh = layer_floats(W_T, W_T), fo = layer_floats(W_T, OUT_T);
+	constexpr uint32_t t0 = layer_floats(W_T, IN_T), th = fh, fwd_total = f0 + (NH - 1) * fh + fo;
+	const float *wf = lds, *wt = lds + fwd_total;
 
-	const uint64_t n_tiles = (a.n + 31) / 32;
-	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * nw) {
+	f16v dW0[W_T][IN_T], dWh[NH > 1 ? NH - 1 : 1][W_T][W_T], dWo[OUT_T][W_T];
+	float db0[W_T], dbh[NH > 1 ? NH - 1 : 1][W_T], dbo[OUT_T];
+#pragma unroll
+	for (int ot = 0; ot < W_T; ++ot) { zero_tiles<IN_T>(dW0[ot]); db0[ot] = 0.0f; }
+#pragma unroll
+	for (int l = 0; l < (NH > 1 ? NH - 1 : 1); ++l)
+#pragma unroll
+		for (int ot = 0; ot < W_T; ++ot) { zero_tiles<W_T>(dWh[l][ot]); dbh[l][ot] = 0.0f; }
+#pragma unroll
+	for (int ot = 0; ot < OUT_T; ++ot) { zero_tiles<W_T>(dWo[ot]); dbo[ot] = 0.0f; }
+
+	const uint64_t n_tiles = (a.n + 31) / 32, step = (uint64_t)gridDim.x * nw;
+	auto clamp_row = [&](uint64_t row) { return row < a.n ? row : a.n - 1; };
+	f16v xnext[IN_T], gnext[OUT_T];
+	if (FAST) {
+		const uint64_t r0 = clamp_row(((uint64_t)blockIdx.x * nw + wave) * 32 + r);
+		load_rows_fast<IN_T>(a.x, a.xs, a.dims[0], r0, lane, xnext);
+		load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], r0, lane, gnext);
+	}
+	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += step) {
 		const uint64_t row = tile * 32 + r;
 		const bool valid = row < a.n;
-		// ---- forward, activations kept as [feature][sample] tiles ----
-		f16v hcur[W_T], g[W_T];
-		load_rows<W_T>(a.x, a.xs, a.dims[0], row, valid, a.x_vec != 0, lane, hcur);      // tiles >= in_t come back zero
-		write_tile<W_T>(TX, in_t, hcur, lane);
+		f16v xin[IN_T], g_out[OUT_T], hcur[W_T];
+		if (FAST) {
 #pragma unroll
-		for (int l = 0; l < NH; ++l) {
+			for (int t = 0; t < IN_T; ++t) xin[t] = xnext[t];
+#pragma unroll
+			for (int t = 0; t < OUT_T; ++t) g_out[t] = gnext[t];
+			const uint64_t rn = clamp_row((tile + step) * 32 + r);
+			load_rows_fast<IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
+			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
+		} else {
+			load_rows<IN_T>(a.x, a.xs, a.dims[0], row, valid, a.x_vec != 0, lane, xin);
+			load_rows<OUT_T>(a.gy, a.gys, a.dims[NH + 1], row, valid, a.gy_vec != 0, lane, g_out);
+		}
+		// ---- forward, activations kept as [feature][sample] tiles ----
+		write_tile<IN_T>(TX, IN_T, xin, lane);
+		dense<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
+		write_tile<W_T>(TH1, W_T, hcur, lane);
+#pragma unroll
+		for (int l = 1; l < NH; ++l) {
 			f16v hn[W_T];
-			dense_rt<W_T, W_T, true>(lds + off_f[l], l == 0 ? in_t : W_T, W_T, hcur, hn, a.hidden_act, lane);
+			dense<W_T, W_T, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
-			write_tile<W_T>(TH(l + 1), W_T, hcur, lane);
+			write_tile<W_T>(TH1 + l * 32 * W_T * kTS, W_T, hcur, lane);
 		}
-		load_rows<W_T>(a.gy, a.gys, a.dims[L], row, valid, a.gy_vec != 0, lane, g);       // zero for padded rows / columns
+		if (FAST && !valid) zero_tiles<OUT_T>(g_out);                    // rows past n were clamped, not zeroed
 		if (a.out_act == NR3D_MLP_ACT_RELU) {
-			f16v yo[W_T];
-			dense_rt<W_T, W_T, true>(lds + off_f[NH], W_T, out_t, hcur, yo, NR3D_MLP_ACT_NONE, lane);
+			f16v yo[OUT_T];
+			dense<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
 #pragma unroll
-			for (int t = 0; t < W_T; ++t)
+			for (int t = 0; t < OUT_T; ++t)
 #pragma unroll
-				for (int j = 0; j < 16; ++j) g[t][j] = yo[t][j] > 0.0f ? g[t][j] : 0.0f;
+				for (int j = 0; j < 16; ++j) g_out[t][j] = yo[t][j] > 0.0f ? g_out[t][j] : 0.0f;
 		}
 		// ---- backward sweep ----
+		const bool relu = a.hidden_act == NR3D_MLP_ACT_RELU;
+		f16v g[W_T];
+		if (relu) bwd_layer<OUT_T, W_T, true, true>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTS, wt + t0 + (NH - 1) * th, dWo, dbo, g, lane);
+		else bwd_layer<OUT_T, W_T, true, false>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTS, wt + t0 + (NH - 1) * th, dWo, dbo, g, lane);
 #pragma unroll
-		for (int l = NH; l >= 0; --l) {
-			const int no = l == NH ? out_t : W_T, ni = l == 0 ? in_t : W_T;
-			float *TG = l == NH ? TGO : TH(l + 1);                       // H_{l+1} is dead once its mask has been applied
-			write_tile<W_T>(TG, no, g, lane);
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-			const float *TB = TH(l);
-			float bv[W_T][16];
+		for (int l = NH - 1; l >= 1; --l) {                              // hidden layer l: H_l -> H_{l+1}
+			f16v gp[W_T];
+			float *TG = TH1 + l * 32 * W_T * kTS;                       // H_{l+1} is dead once its mask has been applied
+			const float *TB = TH1 + (l - 1) * 32 * W_T * kTS;
+			if (relu) bwd_layer<W_T, W_T, true, true>(g, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, lane);
+			else bwd_layer<W_T, W_T, true, false>(g, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, lane);
 #pragma unroll
-			for (int it = 0; it < W_T; ++it) if (it < ni) read_row16(TB, 32 * it + r, h, bv[it]);
-#pragma unroll
-			for (int ot = 0; ot < W_T; ++ot) {
-				if (ot >= no) continue;
-				float av[16];
-				read_row16(TG, 32 * ot + r, h, av);
-				float sum = 0.0f;
-#pragma unroll
-				for (int t = 0; t < 16; ++t) sum += av[t];
-				db[l][ot] += sum;
-#pragma unroll
-				for (int it = 0; it < W_T; ++it) {
-					if (it >= ni) continue;
-#pragma unroll
-					for (int t = 0; t < 16; ++t) dW[l][ot][it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[it][t], dW[l][ot][it], 0, 0, 0);
-				}
-			}
-			if (l > 0 || a.gx) {
-				f16v gp[W_T];
-				dense_rt<W_T, W_T, false>(lds + off_t[l], no, ni, g, gp, NR3D_MLP_ACT_NONE, lane);
-				if (l > 0 && a.hidden_act == NR3D_MLP_ACT_RELU) {
-#pragma unroll
-					for (int t = 0; t < W_T; ++t)
-#pragma unroll
-						for (int j = 0; j < 16; ++j)
-							gp[t][j] = TB[(32 * t + 8 * (j >> 2) + 4 * h + (j & 3)) * kTS + r] > 0.0f ? gp[t][j] : 0.0f;
-				}
-#pragma unroll
-				for (int t = 0; t < W_T; ++t) g[t] = gp[t];
-			}
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+			for (int t = 0; t < W_T; ++t) g[t] = gp[t];
 		}
-		if (a.gx) store_rows<W_T>(a.gx, a.gxs, a.dims[0], row, valid, a.gx_vec != 0, lane, g);
+		f16v gx[IN_T];
+		if (a.gx) {
+			bwd_layer<W_T, IN_T, true, false>(g, TH1, TX, wt, dW0, db0, gx, lane);
+			store_rows<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, a.gx_vec != 0, lane, gx);
+		} else {
+			bwd_layer<W_T, IN_T, false, false>(g, TH1, TX, wt, dW0, db0, gx, lane);
+		}
 	}
 
-	// ---- reduce the waves' parameter gradients in LDS (tile area is free now), then one atomic per element ----
+	// ---- reduce the waves' parameter gradients in LDS (the tile area is free now), one atomic per element ----
 	__syncthreads();
-	float *R = lds + a.total_floats;                                    // [l][ot][it][j][lane] | db: [l][ot][lane]
-	float *Rb = R + L * W_T * W_T * 1024;
-	for (int w = 0; w < nw; ++w) {
-		if (wave == w) {
+	float *R = lds + a.total_floats;
+	reduce_layer<W_T, IN_T>(dW0, db0, R, a.dW[0], a.db[0], a.dims[1], a.dims[0], lane, wave, nw);
 #pragma unroll
-			for (int l = 0; l < L; ++l)
-#pragma unroll
-				for (int ot = 0; ot < W_T; ++ot) {
-					const int bi = (l * W_T + ot) * 64 + lane;
-					Rb[bi] = (w == 0 ? 0.0f : Rb[bi]) + db[l][ot];
-#pragma unroll
-					for (int it = 0; it < W_T; ++it)
-#pragma unroll
-						for (int j = 0; j < 16; ++j) {
-							const int e = ((((l * W_T + ot) * W_T + it) * 16 + j) << 6) + lane;
-							R[e] = (w == 0 ? 0.0f : R[e]) + dW[l][ot][it][j];
-						}
-				}
-		}
-		__syncthreads();
-	}
-	for (uint32_t e = threadIdx.x; e < (uint32_t)(L * W_T * W_T * 1024); e += blockDim.x) {
-		const uint32_t ln = e & 63u, j = (e >> 6) & 15u, it = (e >> 10) % W_T, ot = (e >> 10) / W_T % W_T, l = (e >> 10) / (W_T * W_T);
-		const uint32_t k = 32u * it + (ln & 31u), o = 32u * ot + 8u * (j >> 2) + 4u * (ln >> 5) + (j & 3u);
-		if (o < a.dims[l + 1] && k < a.dims[l]) atomic_add_f32(a.dW[l] + (size_t)o * a.dims[l] + k, R[e]);
-	}
-	for (uint32_t e = threadIdx.x; e < (uint32_t)(L * W_T * 32); e += blockDim.x) {
-		const uint32_t rr = e & 31u, ot = (e >> 5) % W_T, l = (e >> 5) / W_T;
-		const uint32_t o = 32u * ot + rr;
-		if (a.db[l] && o < a.dims[l + 1]) atomic_add_f32(a.db[l] + o, Rb[(l * W_T + ot) * 64 + rr] + Rb[(l * W_T + ot) * 64 + 32 + rr]);
-	}
+	for (int l = 1; l < NH; ++l) reduce_layer<W_T, W_T>(dWh[l - 1], dbh[l - 1], R, a.dW[l], a.db[l], a.dims[l + 1], a.dims[l], lane, wave, nw);
+	reduce_layer<OUT_T, W_T>(dWo, dbo, R, a.dW[NH], a.db[NH], a.dims[NH + 1], a.dims[NH], lane, wave, nw);
 }
 
 }  // namespace mlp
@@ -531,7 +540,7 @@ static uint32_t bwd_tile_floats(const Shape &s) { return (32u * s.in_t + (s.n_la
 
 static uint32_t bwd_waves(const Shape &s) {
 	const uint64_t wbytes = (packed_floats(s) + transposed_floats(s)) * 4;
-	const uint64_t reduce = ((uint64_t)s.n_layers * s.w_t * s.w_t * 1024 + (uint64_t)s.n_layers * s.w_t * 64) * 4;
+	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;     // one layer at a time
 	for (uint32_t nw = 4; nw >= 1; --nw) {
 		const uint64_t t = (uint64_t)nw * bwd_tile_floats(s) * 4;
 		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)kMaxLds) return nw;
@@ -644,27 +653,33 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 		a.db[l] = dL_db ? dL_db[l] : nullptr;
 	}
 	for (uint32_t l = 0; l <= desc->n_layers; ++l) a.dims[l] = desc->dims[l];
-	a.n_layers = desc->n_layers; a.in_t = s.in_t; a.out_t = s.out_t;
+	a.n_layers = desc->n_layers;
 	a.hidden_act = (int)desc->hidden_activation; a.out_act = (int)desc->output_activation;
 	a.x_vec = ((uintptr_t)x % 16 == 0 && x_stride % 4 == 0) ? 1u : 0u;
 	a.gy_vec = ((uintptr_t)dL_dy % 16 == 0 && gy_stride % 4 == 0) ? 1u : 0u;
 	a.gx_vec = (dL_dx && (uintptr_t)dL_dx % 16 == 0 && gx_stride % 4 == 0) ? 1u : 0u;
 	a.tile_floats = bwd_tile_floats(s);
 	const uint32_t nw = bwd_waves(s);
-	const uint64_t reduce = ((uint64_t)s.n_layers * s.w_t * s.w_t * 1024 + (uint64_t)s.n_layers * s.w_t * 64) * 4;
+	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;
 	const uint64_t tbytes = (uint64_t)nw * a.tile_floats * 4;
 	const size_t lds = (size_t)a.total_floats * 4 + (size_t)(tbytes > reduce ? tbytes : reduce);
 	const uint64_t n_tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)(n_tiles / nw + 1 < 256 ? n_tiles / nw + 1 : 256);     // one workgroup per CU: dW lives in registers
 	const uint32_t nh = desc->n_layers - 1;
+	const bool fast = a.x_vec && a.gy_vec && desc->dims[0] % 4 == 0 && desc->dims[desc->n_layers] % 4 == 0;
 	auto launch = [&](auto kern) -> int {
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
 		return 0;
 	};
-	int rc;
-	if (s.w_t == 1) rc = nh == 1 ? launch(k_mlp_bwd<1, 1>) : nh == 2 ? launch(k_mlp_bwd<1, 2>) : launch(k_mlp_bwd<1, 3>);
-	else rc = nh == 1 ? launch(k_mlp_bwd<2, 1>) : launch(k_mlp_bwd<2, 2>);
+	int rc = 0;
+#define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) \
+		rc = fast ? launch(k_mlp_bwd<I, W, O, H, true>) : launch(k_mlp_bwd<I, W, O, H, false>); else
+	BWD_CASE(1, 1, 1, 1) BWD_CASE(1, 1, 1, 2) BWD_CASE(1, 1, 1, 3)
+	BWD_CASE(1, 2, 1, 1) BWD_CASE(1, 2, 1, 2) BWD_CASE(1, 2, 2, 1) BWD_CASE(1, 2, 2, 2)
+	BWD_CASE(2, 2, 1, 1) BWD_CASE(2, 2, 1, 2) BWD_CASE(2, 2, 2, 1) BWD_CASE(2, 2, 2, 2)
+	rc = ::nr3d::fail("mlp_backward: no kernel for this shape");
+#undef BWD_CASE
 	if (rc) return rc;
 	NR3D_LAUNCH_CHECK();
 	return 0;
