@@ -61,7 +61,12 @@ def _unflat(t, prefix):
 
 
 def _scaled(t, s):
-    return None if t is None else t / s
+    return t if (t is None or s == 1.0) else t / s
+
+
+def _times(t, s):
+    """t * loss_scale without the extra pass over t in the fp32 case (scale 1)"""
+    return t if s == 1.0 else t * s
 
 
 class LoTDFunction(torch.autograd.Function):
@@ -90,7 +95,7 @@ class LoTDFunction(torch.autograd.Function):
         if dL_dy is not None and (need_x or need_g):
             xc, grid, dy_dx, bidx, batch_offsets = ctx.saved_tensors
             meta, prefix, bds, ls, max_level = ctx.cfg
-            dL_dx, dL_dgrid = _backend.lod_bwd(meta, dL_dy.flatten(0, -2) * ls, xc.flatten(0, -2), grid, dy_dx,
+            dL_dx, dL_dgrid = _backend.lod_bwd(meta, _times(dL_dy.flatten(0, -2), ls), xc.flatten(0, -2), grid, dy_dx,
                                                bidx, batch_offsets, bds, max_level, need_x, need_g)
             dL_dx, dL_dgrid = _scaled(_unflat(dL_dx, prefix), ls), _scaled(dL_dgrid, ls)
         return None, dL_dx, dL_dgrid, None, None, None, None, None
@@ -124,7 +129,7 @@ class LoTDFunctionFwdDydx(torch.autograd.Function):
             meta, prefix, bds, ls, max_level, need_dL_dinput = ctx.cfg
             with torch.no_grad():
                 # x's gradient is governed by `need_dL_dinput`, not by autograd's needs_input_grad
-                dL_dx, dL_dgrid = _backend.lod_bwd(meta, dL_dy.flatten(0, -2) * ls, xc.flatten(0, -2), grid, dy_dx,
+                dL_dx, dL_dgrid = _backend.lod_bwd(meta, _times(dL_dy.flatten(0, -2), ls), xc.flatten(0, -2), grid, dy_dx,
                                                    bidx, batch_offsets, bds, max_level, need_dL_dinput,
                                                    ctx.needs_input_grad[2])
                 dL_dx, dL_dgrid = _scaled(_unflat(dL_dx, prefix), ls), _scaled(dL_dgrid, ls)
@@ -141,7 +146,7 @@ class LoTDFunctionBwdDydx(torch.autograd.Function):
                 grad_guard):
         ctx.set_materialize_grads(False)
         prefix, xc, bidx = _prep(x, bidx)
-        dL_dx, _ = _backend.lod_bwd(meta, dL_dy.flatten(0, -2) * loss_scale, xc.flatten(0, -2), grid, dy_dx, bidx,
+        dL_dx, _ = _backend.lod_bwd(meta, _times(dL_dy.flatten(0, -2), loss_scale), xc.flatten(0, -2), grid, dy_dx, bidx,
                                     batch_offsets, batch_data_size, max_level, True, False)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
             ctx.save_for_backward(dL_dy, xc, grid, dy_dx, bidx, batch_offsets)
@@ -159,7 +164,7 @@ class LoTDFunctionBwdDydx(torch.autograd.Function):
             prefix = xc.shape[:-1]
             # loss-scale bookkeeping: d/d(dL_dy) is linear in dL_ddLdx only; the other two also carry dL_dy * ls
             g_dLdy, g_grid, g_x = _backend.lod_bwd_bwd_input(
-                meta, dL_ddLdx.flatten(0, -2).contiguous(), dL_dy.flatten(0, -2) * ls, xc.flatten(0, -2), grid, dy_dx,
+                meta, dL_ddLdx.flatten(0, -2).contiguous(), _times(dL_dy.flatten(0, -2), ls), xc.flatten(0, -2), grid, dy_dx,
                 bidx, batch_offsets, bds, max_level, ctx.needs_input_grad[1], ctx.needs_input_grad[3], False)
             g_dLdy = _unflat(g_dLdy, prefix)
             g_grid = _scaled(g_grid, ls)

@@ -29,7 +29,8 @@ class DemoField(nn.Module):
     def __init__(self, occ_grid, step_size, max_steps=512, hidden=32, seed=0, device=None):
         super().__init__()
         cfg = gen_ngp_cfg()
-        self.encoding = LoTD(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], hashmap_size=cfg["hashmap_size"])
+        self.encoding = LoTD(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], hashmap_size=cfg["hashmap_size"],
+                             dtype=torch.float)           # fp32 end to end, like the headline benchmark
         g = torch.Generator().manual_seed(seed)
         n_params = self.encoding.meta.n_params if hasattr(self.encoding, "meta") else self.encoding.n_params
         self.grid = nn.Parameter(torch.empty(n_params).uniform_(-1e-1, 1e-1, generator=g))
