@@ -1,1 +1,2 @@
 from .utils import *  # noqa: F401,F403
+from .ema_single import *  # noqa: F401,F403

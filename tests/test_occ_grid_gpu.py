@@ -257,3 +257,64 @@ def test_occ_grid_ema_loop_feeds_the_marcher(oracle, dev):
     for g, r, nme in zip(got, ref, ["packed_info", "t_starts", "t_ends", "ridx", "gidx"]):
         assert_equal(g, r, name=nme)
     assert got[1].shape[0] > 0
+
+
+def test_occ_grid_ema_module(oracle, dev):
+    """OccGridEma: init from the field, warm-up and steady-state steps, renderer samples, queries, shrink / rescale,
+    checkpoint round trip; the update step itself bit-exact against the numpy restatement"""
+    from nr3d_lib_amd.models.accelerations.occgrid import OccGridEma, get_occ_val_fn
+    torch.manual_seed(1)
+    density = lambda p: torch.exp(-((p.norm(dim=-1) - 0.6) / 0.08) ** 2)          # a spherical shell of radius 0.6
+    acc = OccGridEma(32, occ_thre=0.3, ema_decay=0.9, n_steps_between_update=4, n_steps_warmup=8, device=dev,
+                     init_cfg=dict(mode="from_net", num_steps=2, num_pts=2 ** 16),
+                     update_from_net_cfg=dict(num_steps=2, num_pts=2 ** 15))
+    with pytest.raises(AssertionError):
+        acc.step(4, density)                                                       # init() first
+    assert acc.init(density) and not acc.init(density) and bool(acc.is_initialized)
+    ctr = (torch.stack(torch.meshgrid(*[torch.arange(32, device=dev)] * 3, indexing="ij"), -1) + 0.5) / 16 - 1
+    r = ctr.norm(dim=-1)
+    inside = (r > 0.5) & (r < 0.7)
+    assert float(acc.occ_grid[inside].float().mean()) > 0.9 and float(acc.occ_grid[(r < 0.3) | (r > 0.9)].float().mean()) == 0
+    # the update rule on explicit samples == the oracle's scatter-max + decay
+    pts = torch.rand(5000, 3, device=dev) * 2 - 1
+    val = density(pts)
+    before = acc.occ_val_grid.cpu().numpy().copy()
+    acc.should_collect_samples = False
+    acc._step_update_occ(pts, val)
+    gidx = oracle.occ_gidx_from_pts(pts.cpu().numpy(), (32, 32, 32))
+    assert_equal(acc.occ_val_grid, oracle.occ_update_grid(before, gidx, val.cpu().numpy(), 0.9), name="occ_val_grid")
+    assert_equal(acc.occ_grid, acc.occ_val_grid.cpu().numpy() > 0.3, name="occ_grid")
+    acc.should_collect_samples = True
+    # step(): only every n_steps_between_update iterations; warm-up (uniform) and steady-state (1/2 + 1/4 + 1/4) sampling
+    assert not acc.step(0, density) and not acc.step(3, density)
+    assert acc.step(4, density) and acc.step(12, density)
+    # samples from the renderer are merged at the next update (training mode only)
+    hot = torch.tensor([[0.05, 0.05, 0.05]], device=dev)                            # empty region of the field
+    acc.eval(); acc.collect_samples(hot, torch.tensor([5.0], device=dev))
+    assert float(acc._occ_val_grid_pcl.max()) == 0
+    acc.train(); acc.collect_samples(hot, torch.tensor([5.0], device=dev))
+    assert float(acc._occ_val_grid_pcl.max()) == 5.0
+    acc.step(16, density)
+    assert bool(acc.query(hot)[0]) and float(acc._occ_val_grid_pcl.max()) == 0 and float(acc.occ_val_grid[16, 16, 16]) == 5.0
+    assert bool(acc.query(torch.tensor([[0.6, 0.0, 0.0]], device=dev))[0]) and not bool(acc.query(torch.tensor([[0.95, 0.95, 0.95]], device=dev))[0])
+    p_occ = acc.sample_pts_in_occupied(1000)
+    assert bool(acc.query(p_occ).all())
+    # shrink: the tight box around the shell; rescale keeps the shell where it is in world coordinates
+    aabb = torch.tensor([[-1., -1, -1], [1, 1, 1]], device=dev)
+    new = acc.try_shrink(aabb)
+    assert float(new[0].max()) < -0.6 and float(new[1].min()) > 0.6 and float(new.abs().max()) <= 1.0
+    acc.occ_val_grid[16, 16, 16] = 0
+    acc.rescale_volume(aabb, torch.tensor([[-0.8, -0.8, -0.8], [0.8, 0.8, 0.8]], device=dev))
+    ctr2 = ctr * 0.8
+    r2 = ctr2.norm(dim=-1)
+    assert float(acc.occ_grid[(r2 > 0.55) & (r2 < 0.65)].float().mean()) > 0.8 and float(acc.occ_grid[r2 < 0.35].float().mean()) == 0
+    # checkpoints: the grid's resolution comes from the file
+    other = OccGridEma(8, occ_thre=0.3, device=dev, init_cfg=dict(mode="constant", constant_value=0.0))
+    other.load_state_dict(acc.state_dict())
+    assert_equal(other.occ_grid, acc.occ_grid.cpu().numpy()); assert other.resolution.tolist() == [32, 32, 32] and bool(other.is_initialized)
+    const = OccGridEma([8, 6, 4], occ_thre=0.3, device=dev, init_cfg=dict(mode="constant", constant_value=1.0))
+    const.init()
+    assert bool(const.occ_grid.all()) and tuple(const.occ_grid.shape) == (8, 6, 4)
+    f = get_occ_val_fn("sdf", inv_s=10.0)
+    assert abs(float(f(torch.zeros(1))) - 1.0) < 1e-6 and float(f(torch.tensor([1.0]))) < 0.03
+    assert float(get_occ_val_fn("raw_sdf")(torch.tensor([0.25]))) == 0.75
