@@ -96,3 +96,58 @@ def test_density_only_and_empty(dev):
         assert float(out["mask_volume"].abs().sum()) == 0.0
         none = dict(rays, num_rays=0)
         assert nerf_ray_query_march_occ(model, none)[0]["type"] == "empty"
+
+
+def test_accel_and_space_drive_the_same_query(dev):
+    """AABBSpace.ray_test -> OccGridAccel (grid learnt from the field: init + steps + renderer samples) -> ray query:
+    the volume buffer equals the one obtained with the same grid handed over as a static accelerator, in world
+    coordinates of a non-unit box"""
+    from demo_field import DemoField, StaticOccGridAccel
+    from nr3d_lib_amd.graphics.nerf import composite_packed_volume_buffer, nerf_ray_query_march_occ
+    from nr3d_lib_amd.models.accelerations.occgrid_accel import OccGridAccel
+    from nr3d_lib_amd.models.spatial import AABBSpace
+    torch.manual_seed(0)
+    space = AABBSpace(aabb=[[-2., -1, -1], [2, 1, 1]], device=dev)
+    step = 0.01
+    model = DemoField(torch.zeros(4, 4, 4, dtype=torch.bool), step, max_steps=256, seed=3, device=dev)
+    accel = OccGridAccel(space, resolution=[64, 32, 32], occ_thre=1e9, occ_thre_consider_mean=True, ema_decay=0.95, n_steps_between_update=2,
+                         n_steps_warmup=4, device=dev, init_cfg=dict(mode="from_net", num_steps=2, num_pts=2 ** 16),
+                         update_from_net_cfg=dict(num_steps=1, num_pts=2 ** 15))
+    density = lambda p: model.query_density(p)                       # normalised coordinates in, sigma out
+    accel.train()
+    assert accel.init(density)
+    for it in range(1, 7):
+        assert accel.step(it, density) == (it % 2 == 0)
+    assert 0.0 < accel.frac_occupied() < 1.0 and accel.debug_stats()["num_occupied"] == accel.num_occupied()
+    # world-space pinhole rays through the box
+    side = 20
+    u = torch.linspace(-0.3, 0.3, side, device=dev)
+    uu, vv = torch.meshgrid(u, u, indexing="ij")
+    d_w = torch.nn.functional.normalize(torch.stack([uu.flatten() * 2, vv.flatten(), torch.ones(side * side, device=dev)], 1), dim=1)
+    o_w = torch.tensor([0.0, 0.0, -4.0], device=dev).repeat(side * side, 1)
+    rt = space.ray_test(o_w, d_w, near=0.1, far=10.0)
+    assert 0 < rt["num_rays"] <= side * side and bool((rt["far"] > rt["near"]).all())
+    # ray_test returns normalised rays: depth keeps its world meaning
+    p_far = rt["rays_o"] + rt["rays_d"] * rt["far"][:, None]
+    assert float(p_far.abs().max()) <= 1 + 1e-4
+    model.accel = accel
+    with torch.no_grad():
+        vb, det = nerf_ray_query_march_occ(model, rt, with_rgb=True, compression=True, march_cfg=dict(step_size=step, max_steps=256))
+    del model.accel
+    model.accel = StaticOccGridAccel(accel.get_occ_grid().clone(), step, max_steps=256)
+    with torch.no_grad():
+        vb2, det2 = nerf_ray_query_march_occ(model, rt, with_rgb=True, compression=True)
+    assert vb["type"] == vb2["type"] == "packed"
+    for k in ("rays_inds_hit", "pack_infos_hit", "t", "opacity_alpha", "rgb"):
+        assert_equal(vb[k], vb2[k].cpu().numpy(), k)
+    img = composite_packed_volume_buffer(vb, rt["num_rays"])
+    assert float(img["mask_volume"].max()) > 0.5
+    # un-normalised entry points: the accelerator normalises rays and samples itself
+    m1 = accel.ray_march(o_w[rt["rays_inds"]], d_w[rt["rays_inds"]], rt["near"], rt["far"], normalized=False, step_size=step, max_steps=256)
+    m2 = accel.ray_march(rt["rays_o"], rt["rays_d"], rt["near"], rt["far"], step_size=step, max_steps=256)
+    assert_equal(m1.pack_infos, m2.pack_infos.cpu().numpy(), "pack_infos (world vs normalised rays)")
+    pts_w = space.unnormalize_coords(torch.tensor([[0.05, 0.05, 0.05]], device=dev))
+    accel.collect_samples(pts_w, torch.tensor([99.0], device=dev), normalized=False)
+    assert float(accel.occ._occ_val_grid_pcl.max()) == 99.0
+    new_aabb = accel.try_shrink()
+    assert tuple(new_aabb.shape) == (2, 3) and bool((new_aabb[0] >= space.aabb[0] - 1e-5).all()) and bool((new_aabb[1] <= space.aabb[1] + 1e-5).all())
