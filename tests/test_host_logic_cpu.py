@@ -1,0 +1,88 @@
+"""CPU: host-side logic of the callers around the kernels that needs no GPU -- spaces, the occupancy grid's pure-torch
+parts, the forest's octree bookkeeping."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_aabb_space_maps_and_ray_test():
+    from nr3d_lib_amd.models.spatial import AABBSpace
+    s = AABBSpace(aabb=[[-2., -1, 0], [2, 1, 4]])
+    assert s.center.tolist() == [0, 0, 2] and s.radius3d.tolist() == [2, 1, 2] and s.radius3d_original.tolist() == [2, 1, 2]
+    w = torch.tensor([[2., 1, 4], [-2, -1, 0], [0, 0, 2]])
+    n = s.normalize_coords(w)
+    assert n.tolist() == [[1, 1, 1], [-1, -1, -1], [0, 0, 0]]
+    torch.testing.assert_close(s.unnormalize_coords(n), w)
+    assert s.contains(w).tolist() == [False, True, True]                            # half-open box
+    o = torch.tensor([[0., 0, -3], [0, 0, -3], [5, 5, 5]])
+    d = torch.nn.functional.normalize(torch.tensor([[0., 0, 1], [1, 0, 0], [0, 0, 1]]), dim=1)
+    rt = s.ray_test(o, d, extra=torch.arange(3))
+    assert rt["num_rays"] == 1 and rt["rays_inds"].tolist() == [0] and rt["extra"].tolist() == [0]
+    torch.testing.assert_close(rt["near"], torch.tensor([3.])); torch.testing.assert_close(rt["far"], torch.tensor([7.]))
+    # depth keeps its world meaning on the normalised ray
+    torch.testing.assert_close(s.unnormalize_coords(rt["rays_o"] + rt["rays_d"] * rt["far"][:, None]), torch.tensor([[0., 0, 4]]))
+    assert s.ray_test(o, d, near=3.5, far=6.0)["near"].tolist() == [3.5] and s.ray_test(o, d, far=2.0)["num_rays"] == 0
+    s.rescale_volume(torch.tensor([[-1., -1, 0], [1, 1, 2]]))
+    assert s.radius3d.tolist() == [1, 1, 1] and s.radius3d_original.tolist() == [2, 1, 2]
+    assert AABBSpace(bounding_size=4.0).aabb.tolist() == [[-2, -2, -2], [2, 2, 2]] and AABBSpace().radius3d.tolist() == [1, 1, 1]
+    assert tuple(s.sample_pts_uniform(10).shape) == (10, 3) and s.get_bounding_volume().shape == (6,)
+
+
+def test_occ_grid_ema_pure_torch_parts():
+    from nr3d_lib_amd.models.accelerations.occgrid import OccGridEma, binarize, normalized_logistic_density
+    g = OccGridEma([8, 8, 8], occ_thre=0.5, init_cfg=dict(mode="constant", constant_value=0.0))
+    assert g.init() and not bool(g.occ_grid.any()) and g.gidx_full.shape == (512, 3)
+    g.occ_val_grid[2:5, 3:6, 1:3] = 1.0
+    g._rebinarize()
+    assert int(g.occ_grid.sum()) == 18
+    q = g.query(torch.tensor([[-0.4, -0.1, -0.6], [0.9, 0.9, 0.9], [-5., 0, 0]]))      # out-of-box points clamp to the border voxel
+    assert q.tolist() == [True, False, False]
+    box = g.try_shrink(torch.tensor([[-1., -1, -1], [1, 1, 1]]))
+    torch.testing.assert_close(box, torch.tensor([[1, 2, 0], [5, 6, 3]]) / 8 * 2 - 1.0)
+    # rescale onto the shrunk box: occupied world region stays occupied
+    centre_w = torch.tensor([[(3.5 / 8) * 2 - 1, (4.5 / 8) * 2 - 1, (2.0 / 8) * 2 - 1]])
+    g.rescale_volume(torch.tensor([[-1., -1, -1], [1, 1, 1]]), box)
+    o, sc = (box[1] + box[0]) / 2, (box[1] - box[0]) / 2
+    assert bool(g.query((centre_w - o) / sc)[0]) and 0 < int(g.occ_grid.sum()) < 512
+    # binarize with the mean-relative threshold; the sdf -> occupancy map
+    v = torch.tensor([0.1, 0.2, 0.9])
+    assert binarize(v, 0.5).tolist() == [False, False, True] and binarize(v, 0.5, consider_mean=True).tolist() == [False, False, True]
+    assert binarize(torch.full((4,), 0.3), 0.5, consider_mean=True).all()                 # all-equal values stay occupied
+    torch.testing.assert_close(normalized_logistic_density(torch.tensor([0.0, 1e3]), 10.0), torch.tensor([1.0, 0.0]), atol=1e-6, rtol=0)
+    with pytest.raises(AssertionError):
+        OccGridEma(4, init_cfg=dict(mode="constant", constant_value=0.0)).step(16, lambda p: p[:, 0])
+    sd = g.state_dict()
+    h = OccGridEma(4, occ_thre=0.5, init_cfg=dict(mode="constant", constant_value=0.0))
+    h.load_state_dict(sd)
+    assert h.occ_grid.shape == (8, 8, 8) and torch.equal(h.occ_grid, g.occ_grid) and h.resolution.tolist() == [8, 8, 8]
+
+
+def test_forest_block_space_bookkeeping():
+    from nr3d_lib_amd.models.spatial import ForestBlockSpace
+    sp = ForestBlockSpace()
+    sp.populate(mode="dense", level=2, world_origin=[-4., -4, -4], world_block_size=2.0)
+    assert sp.n_trees == 64 and sp.level == 2 and sp.meta.level_poffset == 9 and sp.meta.octree.numel() == 9
+    assert sp.meta.exsum.tolist() == list(range(0, 73, 8)) and sp.meta.resolution == [4, 4, 4]
+    assert sp.block_ks[0].tolist() == [0, 0, 0] and sp.block_ks[1].tolist() == [0, 0, 1] and sp.block_ks[8].tolist() == [0, 0, 2]
+    torch.testing.assert_close(sp.get_aabb(), torch.tensor([[-4., -4, -4], [4, 4, 4]]))
+    bi = torch.tensor([0, 63, 8])
+    xb = torch.tensor([[0.5, -0.5, 0.0], [1.0, 1.0, 1.0], [-1.0, 0.0, 0.25]])
+    w = sp.unnormalize_coords(xb, bi)
+    torch.testing.assert_close(w[1], torch.tensor([4., 4, 4]))
+    x2, b2 = sp.normalize_coords(w, block_inds=bi)                                       # with known blocks: pure torch
+    torch.testing.assert_close(x2, xb); assert b2 is bi
+    assert sp.pidx2blidx(torch.tensor([-1, 9, 72])).tolist() == [-1, 0, 63] and sp.blidx2pidx_unsafe(torch.tensor([0])).tolist() == [9]
+    px, pb = sp.sample_pts_uniform(num_pts_per_block=3)
+    assert tuple(px.shape) == (64, 3, 3) and pb[5].tolist() == [5, 5, 5]
+    single = ForestBlockSpace(continuity_enabled=False)
+    single.populate(mode="single_block", world_block_size=[1., 2, 3])
+    assert single.n_trees == 1 and single.level == 0 and single.meta.octree.numel() == 0 and not single.meta.continuity_enabled
+    single.set_enable_continuity(True); assert single.meta.continuity_enabled
+    sparse = ForestBlockSpace()
+    sparse.populate(mode="from_corners", corners=[[1, 1, 1], [2, 1, 1], [3, 3, 3]])       # level inferred: log2(3) + 1 = 2
+    assert sparse.level == 2 and sparse.meta.resolution == [4, 4, 4] and sparse.block_ks.tolist() == [[1, 1, 1], [2, 1, 1], [3, 3, 3]]
+    re = ForestBlockSpace()
+    re.load_state_dict(sparse.state_dict())                                              # hierarchy re-derived from the octree bytes
+    assert re.block_ks.tolist() == sparse.block_ks.tolist() and re.meta.level_poffset == sparse.meta.level_poffset
+    with pytest.raises(RuntimeError):
+        sp.populate(mode="nope")
