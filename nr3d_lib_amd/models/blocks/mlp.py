@@ -22,7 +22,12 @@ USE_FUSED = True                       # False: always the layer-by-layer path (
 
 class FusedMLPFunction(torch.autograd.Function):
     """y = MLP(x) through nr3d_mlp_forward; backward through nr3d_mlp_backward (recomputes the forward).
-    args: desc, need (bool: a gradient may be asked for -> also pack the transposed layers), x, W_0, b_0 | None, W_1, ..."""
+    args: desc, need (bool: a gradient may be asked for -> also pack the transposed layers), x, W_0, b_0 | None, W_1, ...
+
+    Higher order (``create_graph=True``, e.g. the eikonal term on nablas = d sdf / dx): backward() then runs with grad
+    mode on; in that case the gradients are produced by differentiating a layer-by-layer PyTorch evaluation of the
+    same network on the saved inputs, which autograd can differentiate again.  First-order training never takes that
+    branch."""
 
     @staticmethod
     def forward(ctx, desc, need, x, *params):
@@ -30,20 +35,54 @@ class FusedMLPFunction(torch.autograd.Function):
         ws, bs = list(params[0::2]), list(params[1::2])
         packed = _mlp.pack(desc, ws, bs, with_backward=need)
         if need:
-            ctx.save_for_backward(x, packed)
+            ctx.save_for_backward(x, packed, *[p for p in params if p is not None])
             ctx.desc, ctx.has_bias = desc, [b is not None for b in bs]
         return _mlp.forward(desc, x, packed)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, dL_dy):
         from nr3d_lib_amd.bindings import _mlp
-        x, packed = ctx.saved_tensors
+        x, packed, *flat = ctx.saved_tensors
+        n_layers = len(ctx.has_bias)
+        if torch.is_grad_enabled():
+            return (None, None, *FusedMLPFunction._differentiable_backward(ctx, x, flat, dL_dy))
         dx, dWs, dbs = _mlp.backward(ctx.desc, x, dL_dy.float(), packed, need_dx=ctx.needs_input_grad[2], has_bias=ctx.has_bias)
         grads = []
-        for i, (dW, db) in enumerate(zip(dWs, dbs)):
-            grads += [dW if ctx.needs_input_grad[3 + 2 * i] else None, db if (db is not None and ctx.needs_input_grad[4 + 2 * i]) else None]
+        for i in range(n_layers):
+            grads += [dWs[i] if ctx.needs_input_grad[3 + 2 * i] else None,
+                      dbs[i] if (dbs[i] is not None and ctx.needs_input_grad[4 + 2 * i]) else None]
         return (None, None, dx, *grads)
+
+    @staticmethod
+    def _differentiable_backward(ctx, x, flat, dL_dy):
+        """(dL/dx, dL/dW_0, dL/db_0, ...) as differentiable functions of x, the parameters and dL/dy"""
+        from nr3d_lib_amd.bindings import _mlp
+        it = iter(flat)
+        ws, bs = [], []
+        for hb in ctx.has_bias:
+            ws.append(next(it))
+            bs.append(next(it) if hb else None)
+        with torch.enable_grad():
+            h = x if x.requires_grad else x.detach().requires_grad_(ctx.needs_input_grad[2])
+            x_in = h
+            for l, (W, b) in enumerate(zip(ws, bs)):
+                h = torch.nn.functional.linear(h, W, b)
+                act = ctx.desc.hidden_activation if l + 1 < len(ws) else ctx.desc.output_activation
+                if act == _mlp.ACT_RELU:
+                    h = torch.relu(h)
+            wanted, slots = [], []
+            if ctx.needs_input_grad[2]:
+                wanted.append(x_in); slots.append(0)
+            for l, (W, b) in enumerate(zip(ws, bs)):
+                if ctx.needs_input_grad[3 + 2 * l]:
+                    wanted.append(W); slots.append(1 + 2 * l)
+                if b is not None and ctx.needs_input_grad[4 + 2 * l]:
+                    wanted.append(b); slots.append(2 + 2 * l)
+            got = torch.autograd.grad(h, wanted, dL_dy, create_graph=True, allow_unused=True) if wanted else ()
+        out = [None] * (1 + 2 * len(ws))
+        for s_, g in zip(slots, got):
+            out[s_] = g
+        return out
 
 
 class MLP(nn.Module):

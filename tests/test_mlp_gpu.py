@@ -129,3 +129,32 @@ def test_networks_outside_the_fused_range_take_the_torch_path(dev):
         _mlp.pack(_mlp.MLPDesc([32, 16]), [torch.zeros(16, 32, device=dev)], [None])
     with pytest.raises(RuntimeError, match="backward does not apply"):
         _mlp.pack(_mlp.MLPDesc([32, 128, 4]), [torch.zeros(128, 32, device=dev), torch.zeros(4, 128, device=dev)], [None, None], True)
+
+
+def test_second_order_through_the_fused_block(dev):
+    """eikonal-style use: nablas = d(sum y)/dx with create_graph, then a loss on the nablas back-propagated to the
+    parameters -- the fused block has to give what the layer-by-layer path gives"""
+    from nr3d_lib_amd.models.blocks import mlp as mlp_mod
+    m = _net([16, 32, 32, 4], "relu", None, True, dev, seed=5)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x0 = torch.randn(513, 16, generator=g).to(dev)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        nablas, = torch.autograd.grad(y[:, 0].sum(), x, create_graph=True)
+        loss = ((nablas.norm(dim=-1) - 1.0) ** 2).mean() + y.square().mean()
+        loss.backward()
+        return y.detach(), nablas.detach(), [p.grad.clone() for p in m.parameters()], x.grad.clone()
+    yf, nf, gf, xf = run()
+    mlp_mod.USE_FUSED = False
+    try:
+        yt, nt, gt, xt = run()
+    finally:
+        mlp_mod.USE_FUSED = True
+    torch.testing.assert_close(yf, yt, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(nf, nt, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xf, xt, rtol=1e-3, atol=1e-5)
+    for a, b in zip(gf, gt):
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5)
