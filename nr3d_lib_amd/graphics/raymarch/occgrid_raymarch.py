@@ -9,8 +9,8 @@ from typing import Literal, Union
 
 import torch
 
-from nr3d_lib_amd.graphics.pack_ops import packed_diff
-from nr3d_lib_amd.graphics.raymarch import RaymarchRetSingle, RaymarchRetBatched
+from nr3d_lib_amd.graphics.pack_ops import get_pack_infos_from_boundary, mark_pack_boundaries, packed_diff
+from nr3d_lib_amd.graphics.raymarch import RaymarchRetBatched, RaymarchRetForest, RaymarchRetSingle
 import nr3d_lib_amd.bindings._occ_grid as _backend
 
 __all__ = ['ContractionType', 'occgrid_raymarch', 'occgrid_raymarch_batched', 'occgrid_raymarch_forest']
@@ -122,5 +122,27 @@ def occgrid_raymarch_batched(occ_grid, rays_o, rays_d, rays_bidx: torch.Tensor =
                               gidx.long(), None)
 
 
-def occgrid_raymarch_forest(*args, **kwargs):
-    raise NotImplementedError("nr3d_lib_amd: forest marching needs kaolin SPC structures (out of hot-path scope)")
+def occgrid_raymarch_forest(forest_meta, occ_grid: torch.Tensor, rays_o, rays_d, near: Union[torch.Tensor, float],
+                            far: Union[torch.Tensor, float], seg_block_inds: torch.Tensor, seg_entries: torch.Tensor,
+                            seg_exits: torch.Tensor, seg_pack_infos: torch.Tensor, *, perturb=False,
+                            perturb_before_march=False, step_size: float = 1e-3, max_step_size: float = 1e10,
+                            dt_gamma: float = 0.0, max_steps: int = 512, step_size_factor=1.0) -> RaymarchRetForest:
+    """March world-space rays through the per-block grids ``occ_grid`` [n_trees, Rx, Ry, Rz] of a forest, along the
+    (block, entry, exit) segments of every ray (``ForestBlockSpace.ray_test``); samples carry their block index
+    (occgrid_raymarch.py:223-272)."""
+    step_size, dt_gamma = step_size * step_size_factor, dt_gamma * step_size_factor
+    near, far = _as_depth(near, rays_o), _as_depth(far, rays_o)
+    if perturb and perturb_before_march:
+        near = near + step_size * torch.rand_like(near)
+    pack_infos, t_starts, t_ends, ridx, blidx, _ = _backend.forest_ray_marching(
+        forest_meta, rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(),
+        seg_block_inds.int().contiguous(), seg_entries.contiguous(), seg_exits.contiguous(), seg_pack_infos.int().contiguous(),
+        occ_grid.contiguous(), step_size, max_step_size, dt_gamma, max_steps, False)
+    out = _finish(rays_o, rays_d, pack_infos, t_starts, t_ends, ridx, perturb and not perturb_before_march)
+    if out is None:
+        return RaymarchRetForest(0, None, None, None, None, None, None, None, None, None, None)
+    ridx_hit, samples, _t_starts, t_samples, deltas, ridx, pack_infos = out
+    blidx = blidx.long()
+    blidx_pack_infos = get_pack_infos_from_boundary(mark_pack_boundaries(blidx))
+    return RaymarchRetForest(ridx_hit.numel(), ridx_hit, samples, t_samples, deltas, ridx, pack_infos, blidx,
+                             blidx_pack_infos, None, None)

@@ -1,2 +1,3 @@
 from .utils import *  # noqa: F401,F403
 from .ema_single import *  # noqa: F401,F403
+from .ema_batched import *  # noqa: F401,F403

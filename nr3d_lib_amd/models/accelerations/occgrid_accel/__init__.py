@@ -1,1 +1,2 @@
 from .single import *  # noqa: F401,F403
+from .forest import *  # noqa: F401,F403

@@ -280,3 +280,78 @@ def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest):
     dpc = _lotd.lod_bwd(metas, torch.from_numpy(gs).to(dev), torch.from_numpy(xs).to(dev), pt, None, torch.from_numpy(bs).to(dev),
                         need_input_grad=False, need_param_grad=True)[1]
     assert_close(dpc, oracle.lotd_forest_bwd_dparam(m_ref, fo, gs, xs, p, block_inds=bs, accum_double=True), name="coherent dparam")
+
+
+def test_forest_accel_end_to_end(oracle, dev):
+    """ForestBlockSpace + OccGridAccelForest: per-block grids learnt from a world-space field (init, warm-up and steady
+    steps, renderer samples), then world rays marched through the blocks they cross -- against the oracle's march on
+    the same grids, and against the field itself"""
+    from nr3d_lib_amd.models.accelerations.occgrid import OccGridEmaBatched
+    from nr3d_lib_amd.models.accelerations.occgrid_accel import OccGridAccelForest
+    from nr3d_lib_amd.models.spatial import ForestBlockSpace
+    torch.manual_seed(0)
+    level, blocks = FORESTS["plus"]
+    space = ForestBlockSpace(device=dev)
+    space.populate(mode="from_corners", corners=blocks, level=level, world_origin=[-2., -2, -2], world_block_size=1.0)
+    accel = OccGridAccelForest(space, vox_size=1 / 16, occ_thre=0.3, ema_decay=0.9, n_steps_between_update=2, n_steps_warmup=4,
+                               init_cfg=dict(mode="from_net", num_steps=2, num_pts_per_batch=2 ** 14),
+                               update_from_net_cfg=dict(num_steps=1, num_pts_per_batch=2 ** 13))
+    accel.populate()
+    assert tuple(accel.get_occ_grid().shape) == (space.n_trees, 16, 16, 16) and isinstance(accel.occ, OccGridEmaBatched)
+    centre = torch.tensor([-0.5, -0.5, -0.5], device=dev)            # centre of block (1,1,1), the hub of the plus
+
+    def field_world(p):                                              # a spherical shell of radius 0.8 around the hub
+        return torch.exp(-(((p - centre).norm(dim=-1) - 0.8) / 0.1) ** 2)
+
+    def query(block_x, bidx):                                        # block coordinates in, field value out
+        return field_world(space.unnormalize_coords(block_x, bidx))
+    accel.train()
+    assert accel.init(query)
+    for it in range(1, 7):
+        assert accel.step(it, query) == (it % 2 == 0)
+    stats = accel.debug_stats()
+    assert 0.02 < stats["frac_occupied"] < 0.6
+    # the learnt grids agree with the field at voxel centres (well inside / well outside the shell)
+    ctr = (torch.stack(torch.meshgrid(*[torch.arange(16, device=dev)] * 3, indexing="ij"), -1) + 0.5) / 8 - 1    # block coords
+    for b in range(space.n_trees):
+        f = field_world(space.unnormalize_coords(ctr.reshape(-1, 3), torch.full((4096,), b, device=dev))).view(16, 16, 16)
+        g = accel.get_occ_grid()[b]
+        assert float(g[f > 0.8].float().mean()) > 0.95 if bool((f > 0.8).any()) else True
+        assert float(g[f < 0.01].float().mean()) < 0.02
+    # world queries, renderer samples
+    on_shell = centre + torch.tensor([[0.8, 0, 0], [0, 0.8, 0]], device=dev)       # in blocks (2,1,1) and (1,2,1)
+    assert accel.query_world(on_shell).tolist() == [True, True]
+    assert accel.query_world(torch.tensor([[-0.5, -0.5, -0.5], [5.0, 5, 5]], device=dev)).tolist() == [False, False]
+    hub = torch.tensor([[-0.5, -0.5, -0.5]], device=dev)
+    accel.collect_samples(hub, None, torch.tensor([7.0], device=dev), normalized=False)
+    accel.step(8, query)
+    assert accel.query_world(hub).tolist() == [True]
+    p_occ, b_occ = accel.sample_pts_in_occupied(500)
+    assert bool(accel.query_occupancy(p_occ, b_occ).all())
+    # rays: segments from the space, march on the GPU == the oracle's march on the same grids
+    n = 300
+    o = (torch.rand(n, 3, device=dev) * 0.4 + torch.tensor([-3.2, -0.7, -0.7], device=dev))
+    d = torch.nn.functional.normalize(centre + (torch.rand(n, 3, device=dev) - 0.5) * 1.5 - o, dim=1)
+    rt = space.ray_test(o, d, near=0.05, far=8.0)
+    assert rt["num_rays"] > 0
+    ret = accel.ray_march(rt["rays_o"], rt["rays_d"], rt["near"], rt["far"], rt["seg_block_inds"], rt["seg_entries"],
+                          rt["seg_exits"], rt["seg_pack_infos"], step_size=0.02, max_steps=128)
+    fo = oracle.forest_from_blocks(blocks, level, world_origin=(-2.0, -2.0, -2.0), world_block_size=(1.0, 1.0, 1.0))
+    c = lambda t: t.cpu().numpy()
+    ref = oracle.forest_ray_marching(fo, c(rt["rays_o"]), c(rt["rays_d"]), c(rt["near"]), c(rt["far"]), c(rt["seg_block_inds"]),
+                                     c(rt["seg_entries"]), c(rt["seg_exits"]), c(rt["seg_pack_infos"]), c(accel.get_occ_grid()),
+                                     0.02, 1e10, 0.0, 128, False)
+    hit = np.nonzero(ref[0][:, 1])[0]
+    assert ret.num_hit_rays == len(hit) > 0
+    assert_equal(ret.ridx_hit, hit, "ridx_hit")
+    assert_equal(ret.pack_infos, ref[0][hit].astype(np.int64), "pack_infos")
+    assert_equal(ret.depth_samples, ref[1][:, 0], "depth_samples")
+    assert_equal(ret.deltas, (ref[2] - ref[1])[:, 0], "deltas")
+    assert_equal(ret.blidx, ref[4].astype(np.int64), "blidx")
+    assert int(ret.blidx_pack_infos[:, 1].sum()) == ret.samples.shape[0]
+    # every sample sits where the field is alive (the shell), in world coordinates
+    assert float(field_world(ret.samples + 0.5 * ret.deltas[:, None] * rt["rays_d"][ret.ridx]).median()) > 0.05
+    coarse = accel.ray_march_simple_step_segment(rt["rays_o"], rt["rays_d"], rt["near"], rt["far"], rt["seg_block_inds"],
+                                                 rt["seg_entries"], rt["seg_exits"], rt["seg_pack_infos"], step_mode="depth",
+                                                 max_steps=64, min_step_size=0.05, dt_gamma=0.0)
+    assert coarse["samples"].shape[0] == coarse["blidx"].shape[0] > 0
