@@ -508,6 +508,55 @@ __device__ __forceinline__ float corner_dot(const Lvl &L, const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Paired 16-byte gathers of F == 2 Dense / Hash levels (forward kernels)
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(8))) Pair16 { float x, y, z, w; };   // two neighbouring F=2 entries, 8-byte aligned
+
+// The gather rate is bound by L2->L1 line requests (one per lane and instruction, ~260 G/s chip-wide,
+// tools/ubench_mem), not by bytes.  Corner pairs that are neighbours in memory come from ONE 16-byte load:
+//   Dense -> the pair along the contiguous last dim (always neighbours, 8-byte aligned 16-byte load);
+//   Hash  -> the pair along dim 0 (prime 1): for even x0 (and a power-of-two table)
+//            hash(x0 + 1, ..) == hash(x0, ..) ^ 1, the other half of the same aligned 16-byte slot.
+// Lanes whose partner lives elsewhere fetch it with a second 8-byte load, all of them under ONE branch so that
+// no load has to be waited for before the last one is issued.  F == 2 (8-byte entries) only.
+template <int D, bool DENSE>
+__device__ __forceinline__ void gather_pairs(const Lvl &L, const Cell<D> &c, const float *__restrict__ grid,
+                                             float (&v)[1 << D][2]) {
+	constexpr uint32_t PBIT = DENSE ? (1u << (D - 1)) : 1u;
+	uint32_t e1s[1 << (D - 1)];
+	bool all_adj = true;
+#pragma unroll
+	for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
+		const uint32_t k0 = DENSE ? m : (m << 1);          // m with a zero bit inserted at the pair dimension
+		const uint32_t k1 = k0 | PBIT;
+		uint32_t p0[D], p1[D];
+		corner_pos<D>(c, k0, p0);
+		corner_pos<D>(c, k1, p1);
+		const uint32_t e0 = DENSE ? entry_dense<D>(L, p0) : entry_hash<D>(L, p0);
+		const uint32_t e1 = DENSE ? e0 + 1u : entry_hash<D>(L, p1);
+		const uint32_t base = DENSE ? e0 : min(e0 & ~1u, L.size - 2u);
+		const Pair16 t = *reinterpret_cast<const Pair16 *>(grid + (size_t)base * 2u);
+		const bool hi0 = (e0 != base);
+		v[k0][0] = hi0 ? t.z : t.x;
+		v[k0][1] = hi0 ? t.w : t.y;
+		const uint32_t o1 = e1 - base;
+		v[k1][0] = (o1 == 1u) ? t.z : t.x;
+		v[k1][1] = (o1 == 1u) ? t.w : t.y;
+		all_adj = all_adj && (o1 < 2u);
+		e1s[m] = e1;
+	}
+	if (!DENSE && !all_adj) {
+#pragma unroll
+		for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
+			const uint32_t k1 = (m << 1) | 1u;
+			const float2 t = *reinterpret_cast<const float2 *>(grid + (size_t)e1s[m] * 2u);
+			v[k1][0] = t.x;
+			v[k1][1] = t.y;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // Forest of blocks (csrc/forest/forest.h, lotd_forest.h): octree lookup, corner resolver, cell locator
 // ---------------------------------------------------------------------------------------------
 struct ForestDev {

@@ -36,7 +36,7 @@ template <int G, bool DYDX>
 __global__ __launch_bounds__(kBlock) void k_forest_fwd(const nr3d_lotd_meta_t *__restrict__ md, ForestDev fo, uint32_t N,
                                                        int32_t max_level, uint32_t smooth,
                                                        const float *__restrict__ x, const float *__restrict__ params,
-                                                       Batch ba, float *__restrict__ y, int64_t y_sn, int64_t y_se,
+                                                       Batch ba, uint32_t pair_ok, float *__restrict__ y, int64_t y_sn, int64_t y_se,
                                                        float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= N) return;
@@ -60,15 +60,34 @@ __global__ __launch_bounds__(kBlock) void k_forest_fwd(const nr3d_lotd_meta_t *_
 			Cell<3> c;
 			locate_forest(xp, L, smooth != 0, c);
 			float v[8][G];
+			// a cell whose 8 corners all lie inside the point's own block (all but a 6/R fraction) is the plain level
+			// shifted by one node: same paired 16-byte gathers as the single-block kernel
+			bool fast = false;
+			if constexpr (G == 2) {
+				fast = pair_ok && L.F == 2 && L.size >= 2 && (L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash);
 #pragma unroll
-			for (uint32_t k = 0; k < 8; ++k) {
-				uint32_t p[3], pl[3], off;
-				corner_pos<3>(c, k, p);
-				if (resolve(fo, ba, L, b, p, pl, off)) {
-					corner_value<3, G>(L, params + (off + L.off), foff0, pl, v[k]);
-				} else {
+				for (int d = 0; d < 3; ++d) fast = fast && c.g[d] >= 1u && c.g[d] + 1u <= L.res[d];
+			}
+			if (fast) {
+				if constexpr (G == 2) {
+					Cell<3> cs = c;
 #pragma unroll
-					for (int f = 0; f < G; ++f) v[k][f] = 0.0f;
+					for (int d = 0; d < 3; ++d) cs.g[d] -= 1u;
+					const float *grid = params + (b.offset + L.off);
+					if (L.type == NR3D_LOD_Dense) gather_pairs<3, true>(L, cs, grid, v);
+					else gather_pairs<3, false>(L, cs, grid, v);
+				}
+			} else {
+#pragma unroll
+				for (uint32_t k = 0; k < 8; ++k) {
+					uint32_t p[3], pl[3], off;
+					corner_pos<3>(c, k, p);
+					if (resolve(fo, ba, L, b, p, pl, off)) {
+						corner_value<3, G>(L, params + (off + L.off), foff0, pl, v[k]);
+					} else {
+#pragma unroll
+						for (int f = 0; f < G; ++f) v[k][f] = 0.0f;
+					}
 				}
 			}
 #pragma unroll
@@ -275,13 +294,15 @@ extern "C" int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *me
 	const Batch ba{block_inds, block_offsets, batch_data_size, meta->n_params};
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	const dim3 grid(div_up(N, kBlock), meta->n_pseudo_levels);
+	// paired gathers: every F == 2 entry 8-byte aligned -> even block and level offsets, no caller-chosen offsets
+	const uint32_t pair_ok = ((uintptr_t)params % 8 == 0 && block_offsets == nullptr && meta->n_params % 2 == 0) ? 1u : 0u;
 	DISPATCH_G(meta->n_feat_per_pseudo_lvl, {
 		if (dy_dx)
 			hipLaunchKernelGGL((k_forest_fwd<G, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
-			                   max_level, meta->interpolation_type, x, params, ba, y, y_sn, y_se, dy_dx, d_sn, d_se);
+			                   max_level, meta->interpolation_type, x, params, ba, pair_ok, y, y_sn, y_se, dy_dx, d_sn, d_se);
 		else
 			hipLaunchKernelGGL((k_forest_fwd<G, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
-			                   max_level, meta->interpolation_type, x, params, ba, y, y_sn, y_se, dy_dx, d_sn, d_se);
+			                   max_level, meta->interpolation_type, x, params, ba, pair_ok, y, y_sn, y_se, dy_dx, d_sn, d_se);
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;
