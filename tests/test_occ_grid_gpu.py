@@ -318,3 +318,57 @@ def test_occ_grid_ema_module(oracle, dev):
     f = get_occ_val_fn("sdf", inv_s=10.0)
     assert abs(float(f(torch.zeros(1))) - 1.0) < 1e-6 and float(f(torch.tensor([1.0]))) < 0.03
     assert float(get_occ_val_fn("raw_sdf")(torch.tensor([0.25]))) == 0.75
+
+
+def test_occ_grid_ema_batched_module(oracle, dev):
+    """OccGridEmaBatched: per-entry fields, per-point and batched sample layouts, restricted updates, queries"""
+    from nr3d_lib_amd.models.accelerations.occgrid import OccGridEmaBatched
+    torch.manual_seed(2)
+    radii = torch.tensor([0.3, 0.6, 0.85], device=dev)
+    field = lambda pts, bidx: torch.exp(-((pts.norm(dim=-1) - radii[bidx]) / 0.08) ** 2)      # one shell radius per entry
+    acc = OccGridEmaBatched(3, 24, occ_thre=0.3, ema_decay=0.9, n_steps_between_update=2, n_steps_warmup=4, device=dev,
+                            init_cfg=dict(mode="net", num_steps=2, num_pts_per_batch=2 ** 15),
+                            update_from_net_cfg=dict(num_steps=1, num_pts_per_batch=2 ** 14))
+    assert acc.init(field) and tuple(acc.occ_grid.shape) == (3, 24, 24, 24)
+    ctr = (torch.stack(torch.meshgrid(*[torch.arange(24, device=dev)] * 3, indexing="ij"), -1) + 0.5) / 12 - 1
+    r = ctr.norm(dim=-1)
+    for b in range(3):
+        shell = (r - radii[b]).abs() < 0.03
+        assert float(acc.occ_grid[b][shell].float().mean()) > 0.9 and float(acc.occ_grid[b][(r - radii[b]).abs() > 0.25].float().mean()) == 0
+    # the update on explicit per-point samples == the oracle (entries as a leading grid dim)
+    pts = torch.rand(4000, 3, device=dev) * 2 - 1
+    bidx = torch.randint(0, 3, (4000,), device=dev)
+    val = field(pts, bidx)
+    before = acc.occ_val_grid.cpu().numpy().copy()
+    acc.should_collect_samples = False
+    acc._step_update_occ(pts, bidx, val)
+    gidx = oracle.occ_gidx_from_pts(pts.cpu().numpy(), (24, 24, 24))
+    assert_equal(acc.occ_val_grid, oracle.occ_update_grid(before, gidx, val.cpu().numpy(), 0.9, bidx=bidx.cpu().numpy()), name="per-point")
+    # batched layout: [entries, n, 3] without bidx
+    ptsb = torch.rand(3, 500, 3, device=dev) * 2 - 1
+    valb = field(ptsb, torch.arange(3, device=dev).view(3, 1).expand(3, 500))
+    before = acc.occ_val_grid.cpu().numpy().copy()
+    acc._step_update_occ(ptsb, None, valb)
+    gb = oracle.occ_gidx_from_pts(ptsb.reshape(-1, 3).cpu().numpy(), (24, 24, 24)).reshape(3, 500, 3)
+    assert_equal(acc.occ_val_grid, oracle.occ_update_grid(before, gb, valb.cpu().numpy(), 0.9), name="batched")
+    acc.should_collect_samples = True
+    # steps; an update restricted to entry 2 leaves the others alone
+    assert not acc.step(1, field) and acc.step(2, field) and acc.step(6, field)
+    snap = acc.occ_val_grid.clone()
+    acc._step(8, field, within_bi=torch.tensor([2], device=dev), num_steps=1, num_pts_per_batch=2 ** 12)
+    assert torch.equal(snap[:2], acc.occ_val_grid[:2]) and not torch.equal(snap[2], acc.occ_val_grid[2])
+    # renderer samples, queries (per point and batched), sampling inside occupied voxels
+    acc.train()
+    acc.collect_samples(torch.zeros(1, 3, device=dev), torch.tensor([1], device=dev), torch.tensor([3.0], device=dev))
+    acc.step(10, field)
+    assert acc.query(torch.zeros(1, 3, device=dev), torch.tensor([1], device=dev)).tolist() == [True]
+    assert acc.query(torch.zeros(1, 3, device=dev), torch.tensor([0], device=dev)).tolist() == [False]
+    qb = acc.query(torch.tensor([[[0.3, 0, 0]], [[0.6, 0, 0]], [[0.85, 0, 0]]], device=dev))
+    assert qb.tolist() == [[True], [True], [True]]
+    p, b = acc.sample_pts_in_occupied(600)
+    assert bool(acc.query(p, b).all()) and set(b.unique().tolist()) == {0, 1, 2}
+    p2, b2 = acc.sample_pts_in_occupied(100, within_bi=torch.tensor([2], device=dev))
+    assert set(b2.unique().tolist()) == {0}                                  # local to within_bi
+    other = OccGridEmaBatched(1, 4, occ_thre=0.3, device=dev, init_cfg=dict(mode="constant", constant_value=0.0))
+    other.load_state_dict(acc.state_dict())
+    assert other.num_batches == 3 and torch.equal(other.occ_grid, acc.occ_grid)
