@@ -96,23 +96,30 @@ __global__ __launch_bounds__(256) void k_mlp_pack(PackArgs a, float *__restrict_
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float activate(float v, int act) { return act == NR3D_MLP_ACT_RELU ? fmaxf(v, 0.0f) : v; }
 
-// The weight fragments (one 16-byte LDS read per lane and 4 MFMA steps) run kWPF groups ahead of the MFMAs that consume
-// them: with one or two waves per SIMD nothing else would cover the LDS latency, and left alone the compiler issues
-// each read right in front of its use.
+// Scheduling of the MFMA stream (measured rules, MI355X_MICROARCH.md): an instruction issued between two MFMAs on the
+// SAME accumulator costs ~43 cycles (a cliff), between MFMAs on DIFFERENT accumulators ~6.  So consecutive MFMAs
+// alternate accumulators -- the out tiles of the layer, or, for a single out tile, two partial sums over the even / odd
+// k-steps that are added at the end -- and the weight fragments (one 16-byte LDS read per lane and 4 MFMA steps) are
+// read kWPF groups ahead of their use: with one or two waves per SIMD nothing else would cover the LDS latency.
 constexpr int kWPF = 6;
 
 template <int NI, int NO, bool BIAS>
 __device__ __forceinline__ void dense(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
 	const float *bias = wp + NO * NI * 1024;
 	const int h = lane >> 5;
-	constexpr int G = NO * NI * 4;                 // weight groups, in (ot, it, q) order = their order in LDS
+	constexpr bool SPLIT = (NO == 1);              // one out tile: two accumulators over alternating k-steps
+	constexpr int G = NO * NI * 4;                 // weight groups, consumed in (it, q, ot) order
 	constexpr int PF = kWPF < G ? kWPF : G;
 	const f4v *wv = reinterpret_cast<const f4v *>(wp) + lane;
+	auto lds_index = [](int g) { const int ot = g % NO, s = g / NO; return ((ot * NI + s / 4) * 4 + (s % 4)) * 64; };   // [ot][it][q] in LDS
 	f4v ring[PF];
 #pragma unroll
-	for (int g = 0; g < PF; ++g) ring[g] = wv[g * 64];
+	for (int g = 0; g < PF; ++g) ring[g] = wv[lds_index(g)];
+	f16v alt;                                      // SPLIT: the odd k-steps' partial sum
 #pragma unroll
-	for (int ot = 0; ot < NO; ++ot) {
+	for (int j = 0; j < 16; ++j) alt[j] = 0.0f;
+#pragma unroll
+	for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			f4v b4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -120,19 +127,32 @@ __device__ __forceinline__ void dense(const float *__restrict__ wp, const f16v (
 #pragma unroll
 			for (int b = 0; b < 4; ++b) out[ot][4 * q + b] = b4[b];
 		}
-	}
 #pragma unroll
-	for (int g = 0; g < G; ++g) {
-		const int ot = g / (NI * 4), it = (g / 4) % NI, q = g % 4;
-		const f4v w4 = ring[g % PF];
-		if (g + PF < G) ring[g % PF] = wv[(g + PF) * 64];
+	for (int s = 0; s < NI * 4; ++s) {
+		const int it = s / 4, q = s % 4;
+		f4v w4[NO];
 #pragma unroll
-		for (int b = 0; b < 4; ++b) out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[b], in[it][4 * q + b], out[ot], 0, 0, 0);
-		if (it == NI - 1 && q == 3) {
+		for (int ot = 0; ot < NO; ++ot) {
+			const int g = s * NO + ot;
+			w4[ot] = ring[g % PF];
+			if (g + PF < G) ring[g % PF] = wv[lds_index(g + PF)];
+		}
 #pragma unroll
-			for (int j = 0; j < 16; ++j) out[ot][j] = activate(out[ot][j], act);
+		for (int b = 0; b < 4; ++b) {
+			if constexpr (SPLIT) {
+				if (b & 1) alt = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0][b], in[it][4 * q + b], alt, 0, 0, 0);
+				else out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0][b], in[it][4 * q + b], out[0], 0, 0, 0);
+			} else {
+#pragma unroll
+				for (int ot = 0; ot < NO; ++ot)
+					out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[ot][b], in[it][4 * q + b], out[ot], 0, 0, 0);
+			}
 		}
 	}
+#pragma unroll
+	for (int ot = 0; ot < NO; ++ot)
+#pragma unroll
+		for (int j = 0; j < 16; ++j) out[ot][j] = activate(SPLIT ? out[ot][j] + alt[j] : out[ot][j], act);
 }
 
 // rows of a [n, dim] matrix on the register map: lane (s = lane & 31, h = lane >> 5) owns features 32t + 8q + 4h + b
