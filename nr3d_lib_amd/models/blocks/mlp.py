@@ -18,6 +18,8 @@ from nr3d_lib_amd.profile import profile
 __all__ = ['MLP', 'FCBlock', 'FusedMLPFunction']
 
 USE_FUSED = True                       # False: always the layer-by-layer path (A/B measurements, debugging)
+CACHE_PACKED = True                    # reuse the MFMA-ordered weight copy while the parameters' version counters stand still;
+                                       # code that edits parameters through `.data` (no version bump) should switch it off
 
 
 class FusedMLPFunction(torch.autograd.Function):
@@ -33,7 +35,15 @@ class FusedMLPFunction(torch.autograd.Function):
     def forward(ctx, desc, need, x, *params):
         from nr3d_lib_amd.bindings import _mlp
         ws, bs = list(params[0::2]), list(params[1::2])
-        packed = _mlp.pack(desc, ws, bs, with_backward=need)
+        # the packed copy is reused until a parameter is written (tensor version counters) -- e.g. the no-grad density
+        # query and the differentiable query of one training iteration, or every call of an inference loop
+        key = (need, tuple((p.data_ptr(), p._version) for p in params if p is not None))
+        cached = getattr(desc, '_packed_cache', None)
+        if CACHE_PACKED and cached is not None and cached[0] == key:
+            packed = cached[1]
+        else:
+            packed = _mlp.pack(desc, ws, bs, with_backward=need)
+            desc._packed_cache = (key, packed)
         if need:
             ctx.save_for_backward(x, packed, *[p for p in params if p is not None])
             ctx.desc, ctx.has_bias = desc, [b is not None for b in bs]

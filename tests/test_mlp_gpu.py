@@ -158,3 +158,32 @@ def test_second_order_through_the_fused_block(dev):
     torch.testing.assert_close(xf, xt, rtol=1e-3, atol=1e-5)
     for a, b in zip(gf, gt):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5)
+
+
+def test_packed_weights_are_cached_until_a_parameter_changes(dev):
+    from nr3d_lib_amd.bindings import _mlp
+    m = _net([32, 32, 8], "relu", None, True, dev, seed=7)
+    x = torch.randn(257, 32, device=dev)
+    calls = []
+    orig = _mlp.pack
+    _mlp.pack = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            y1 = m(x); y2 = m(x)
+            assert len(calls) == 1 and torch.equal(y1, y2)
+            m.layers[0].weight.mul_(2.0)                                  # in-place write bumps the version counter
+            y3 = m(x)
+        assert len(calls) == 2 and not torch.equal(y1, y3)
+        m(x).sum().backward()                                             # gradients wanted: packed again with the transposed layers
+        assert len(calls) == 3
+        torch.optim.SGD(m.parameters(), lr=0.1).step()
+        with torch.no_grad():
+            y4 = m(x)
+        assert len(calls) == 4
+        ref = x
+        for i, l in enumerate(m.layers):
+            ref = torch.nn.functional.linear(ref, l.weight, l.bias)
+            ref = torch.relu(ref) if i == 0 else ref
+        torch.testing.assert_close(y4, ref, rtol=1e-4, atol=1e-5)
+    finally:
+        _mlp.pack = orig
