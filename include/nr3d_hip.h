@@ -383,6 +383,13 @@ int nr3d_alpha_to_vw_backward(uint32_t P, uint64_t S, const float *alphas, const
 /* mark_pack_boundaries_cuda (:2765-2805): boundaries int32 [num]. */
 int nr3d_mark_pack_boundaries(uint64_t num, int dtype, const void *pack_ids, int32_t *boundaries, void *stream);
 
+/* octree_mark_consecutive_segments (pack_ops.cpp:58, pack_ops_cuda.cu:2807-2887): pidx int32 [n] = octree nodes hit by
+ * every ray in order (packs = rays), point_hierarchies int16 [n_nodes,3]; mark_start / mark_end uint8 [n] ZERO-INIT:
+ * first / last node of every run of face-adjacent nodes. */
+int nr3d_octree_mark_consecutive_segments(uint32_t P, const int32_t *pidx, const int64_t *pack_infos,
+                                          const int16_t *point_hierarchies, uint8_t *mark_start, uint8_t *mark_end,
+                                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -438,5 +438,17 @@ def mark_pack_boundaries_cuda(pack_ids):
 
 
 def octree_mark_consecutive_segments(pidx, pack_infos, point_hierarchies):
-    raise NotImplementedError("nr3d_lib_amd: octree_mark_consecutive_segments needs kaolin SPC structures "
-                              "(out of the hot-path scope, SURVEY.md §8f-4)")
+    """-> (mark_start, mark_end) bool [n]  (pack_ops_cuda.cu:2843-2887)"""
+    fn = "octree_mark_consecutive_segments"
+    _chk_pi(fn, pack_infos, pidx)
+    for name, t, dim, dt in (("pidx", pidx, 1, torch.int32), ("point_hierarchies", point_hierarchies, 2, torch.int16)):
+        if t.dim() != dim or t.dtype != dt or not t.is_contiguous() or t.device != pack_infos.device:
+            raise RuntimeError(f"{fn}: Expected a contiguous {dim}-dimensional {dt} tensor on the same GPU for argument {name}")
+    n = pidx.shape[0]
+    mark_start = torch.zeros(n, dtype=torch.bool, device=pidx.device)
+    mark_end = torch.zeros(n, dtype=torch.bool, device=pidx.device)
+    with torch.cuda.device(pidx.device):
+        H.check(H.lib().nr3d_octree_mark_consecutive_segments(H.u32(pack_infos.shape[0]), H.ptr(pidx), H.ptr(pack_infos),
+                                                              H.ptr(point_hierarchies), H.ptr(mark_start), H.ptr(mark_end),
+                                                              H.stream_of(pidx)))
+    return mark_start, mark_end

@@ -610,6 +610,29 @@ __global__ __launch_bounds__(kBlock) void k_boundaries(uint64_t n, const T *__re
 	b[i] = (i == 0) ? 1 : (ids[i - 1] == ids[i] ? 0 : 1);
 }
 
+// octree_mark_consecutive_segments (pack_ops_cuda.cu:2807-2841): per ray (pack) of octree nodes hit in order, mark where
+// a run of face-adjacent nodes (L1 distance of the integer coordinates <= 1) starts and ends.  One wave per pack.
+// The reference indexes the node list without the pack's offset (`point_indices[j]` instead of `[begin + j]`), which
+// is only right for the first pack; the pack's own nodes are used here.
+__global__ __launch_bounds__(kBlock) void k_mark_consecutive(uint32_t P, const int64_t *__restrict__ pi,
+                                                             const int32_t *__restrict__ pidx, const int16_t *__restrict__ pts,
+                                                             uint8_t *__restrict__ mark_start, uint8_t *__restrict__ mark_end) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid || k.len == 0) return;
+	for (uint32_t j = k.lane; j < k.len; j += 64) {
+		bool brk = (j == 0);
+		if (j > 0) {
+			const int16_t *a = pts + 3 * (size_t)pidx[k.begin + j - 1], *b = pts + 3 * (size_t)pidx[k.begin + j];
+			brk = (abs((int)b[0] - (int)a[0]) + abs((int)b[1] - (int)a[1]) + abs((int)b[2] - (int)a[2])) > 1;
+		}
+		if (brk) {
+			mark_start[k.begin + j] = 1;
+			if (j > 0) mark_end[k.begin + j - 1] = 1;
+		}
+		if (j == k.len - 1) mark_end[k.begin + j] = 1;
+	}
+}
+
 }  // namespace pk
 }  // namespace nr3d
 
@@ -810,6 +833,17 @@ extern "C" int nr3d_mark_pack_boundaries(uint64_t num, int dtype, const void *pa
 	case NR3D_U8:  hipLaunchKernelGGL(pk::k_boundaries<uint8_t>, g, b, 0, (hipStream_t)stream, num, (const uint8_t *)pack_ids, boundaries); break;
 	default: return ::nr3d::fail("mark_pack_boundaries: integral dtype required (got code %d)", dtype);
 	}
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_octree_mark_consecutive_segments(uint32_t P, const int32_t *pidx, const int64_t *pack_infos,
+                                                     const int16_t *point_hierarchies, uint8_t *mark_start, uint8_t *mark_end,
+                                                     void *stream) {
+	if (P == 0) return 0;
+	NR3D_CHECK(pidx && pack_infos && point_hierarchies && mark_start && mark_end, "octree_mark_consecutive_segments: NULL pointer");
+	hipLaunchKernelGGL(pk::k_mark_consecutive, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, pack_infos, pidx,
+	                   point_hierarchies, mark_start, mark_end);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

@@ -520,6 +520,23 @@ def occ_update_grid(grid, gidx, occ_val, ema_decay=1.0, bidx=None):
     return occ_apply_max(grid, occ_scatter_max(np.shape(grid), gidx, occ_val, bidx), ema_decay)
 
 
+def octree_mark_consecutive_segments(pidx, pack_infos, point_hierarchies):
+    """pack_ops_cuda.cu:2807-2841 with the pack offset applied to the node list (the reference's kernel omits it)"""
+    pidx, pi = np.asarray(pidx, np.int64), np.asarray(pack_infos, np.int64)
+    pts = np.asarray(point_hierarchies, np.int64)
+    ms, me = np.zeros(pidx.shape[0], bool), np.zeros(pidx.shape[0], bool)
+    for b, n in pi:
+        if n == 0:
+            continue
+        ms[b] = True
+        for j in range(1, n):
+            if np.abs(pts[pidx[b + j]] - pts[pidx[b + j - 1]]).sum() > 1:
+                me[b + j - 1] = True
+                ms[b + j] = True
+        me[b + n - 1] = True
+    return ms, me
+
+
 # ------------------------------------------------------------------------------------------------
 # forest of blocks (csrc/forest/forest.h, lotd_forest.h, forest_marching.cu)
 # ------------------------------------------------------------------------------------------------

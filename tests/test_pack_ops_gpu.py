@@ -346,3 +346,23 @@ def test_merge_wrappers(oracle, dev):
         for b, n in pim.tolist():
             assert (val[b:b + n].diff() >= 0).all()
         assert torch.equal(torch.sort(val)[0], torch.sort(torch.cat([va, vb]))[0])
+
+
+def test_octree_mark_consecutive_segments(oracle, dev):
+    """the reference's own example (unit_test.py:760-781: nodes x = 0,1,2 | 5,6 on one ray -> two runs) plus ragged packs"""
+    from nr3d_lib_amd.graphics.pack_ops import octree_mark_consecutive_segments
+    pts = torch.tensor([[0, 3, 3], [1, 3, 3], [2, 3, 3], [5, 3, 3], [6, 3, 3]], dtype=torch.int16, device=dev)
+    ms, me = octree_mark_consecutive_segments(torch.arange(5, device=dev), torch.tensor([[0, 5]], device=dev), pts)
+    assert ms.tolist() == [True, False, False, True, False] and me.tolist() == [False, False, True, False, True]
+    rng = np.random.default_rng(0)
+    hier = rng.integers(0, 6, (400, 3)).astype(np.int16)
+    pinfo, total = random_packs(rng, 300, 0, 70, empty_frac=0.1)
+    # walks: mostly unit steps between consecutive nodes, so that both outcomes occur
+    walk = np.cumsum(rng.integers(-1, 2, (400, 3)) * (rng.random((400, 1)) < 0.8), 0).astype(np.int16)
+    pidx = rng.integers(0, 400, total).astype(np.int32)
+    pidx[1:] = np.where(rng.random(total - 1) < 0.7, np.minimum(pidx[:-1] + 1, 399), pidx[1:])
+    want_s, want_e = oracle.octree_mark_consecutive_segments(pidx, pinfo, walk)
+    got_s, got_e = octree_mark_consecutive_segments(torch.from_numpy(pidx).to(dev), torch.from_numpy(pinfo).to(dev), torch.from_numpy(walk).to(dev))
+    assert_equal(got_s, want_s, "mark_start"); assert_equal(got_e, want_e, "mark_end")
+    assert want_s.sum() == want_e.sum() > (pinfo[:, 1] > 0).sum()            # some packs split into several runs
+    assert hier.shape == (400, 3)
