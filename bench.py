@@ -133,7 +133,7 @@ def march_composite_rate(dev, iters=20, side=64):
                 ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4))
 
 
-def full_loop_rate(dev, side=512, iters=5):
+def full_loop_rate(dev, side=512, iters=9):
     """BASELINE configs[4] on one GPU: 16-level Hash encode + occ-grid march + pack composite, forward AND backward
     through nerf_ray_query_march_occ (visibility pruning on) with a tiny random MLP head (tools/demo_field.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -156,14 +156,20 @@ def full_loop_rate(dev, side=512, iters=5):
         return int(det["march.num_per_ray"].sum()), int(det["render.num_per_ray"].sum())
     marched, rendered = one()
     one()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    # every iteration timed on its own: the driver allocates data-dependent buffers, and an iteration that happens to go
+    # back to hipMalloc (caching-allocator miss) costs several ms -- the median is the steady-state figure, the mean is
+    # reported next to it
+    per_iter = []
     for _ in range(iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         one()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / iters * 1e3
+        torch.cuda.synchronize()
+        per_iter.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.median(per_iter))
     return dict(workload=f"march + prune + 16-level Hash LoTD encode + fused MLP decoders (32-wide) + composite, fwd+bwd, {n} rays",
                 samples_marched=marched, samples_rendered=rendered, ms_per_iter=round(ms, 3),
+                ms_per_iter_mean=round(float(np.mean(per_iter)), 3), iters=iters,
                 mrays_per_s=round(n / ms / 1e3, 3), msamples_per_s=round((marched + rendered) / ms / 1e3, 3))
 
 
