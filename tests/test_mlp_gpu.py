@@ -187,3 +187,17 @@ def test_packed_weights_are_cached_until_a_parameter_changes(dev):
         torch.testing.assert_close(y4, ref, rtol=1e-4, atol=1e-5)
     finally:
         _mlp.pack = orig
+
+
+@pytest.mark.parametrize("name", ["plain", "ragged_out_relu"])
+def test_fused_block_reproduces_the_reference_modules_outputs(dev, name):
+    """weights and outputs of the reference's own MLP module (tests/golden/ref_blocks.npz) through the fused kernels"""
+    from test_golden_blocks_cpu import GOLD, load_mlp
+    gold = np.load(GOLD)
+    m = load_mlp(gold, name, device=dev)
+    assert m.fused_desc() is not None
+    x = torch.from_numpy(gold[f"mlp_{name}_x"]).to(dev)
+    with torch.no_grad():
+        y = m(x)
+    want = gold[f"mlp_{name}_y"]
+    assert float(np.abs(y.cpu().numpy() - want).max()) <= 1e-5 * max(1.0, float(np.abs(want).max()))
