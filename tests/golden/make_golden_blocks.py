@@ -6,7 +6,8 @@
 Outputs of the reference's own pure-PyTorch host classes on fixed inputs: the MLP block (models/blocks/mlp.py: plain,
 ragged widths, skip connection, no bias, output activation; randomly initialised by the reference, weights stored next to
 the outputs), AABBSpace (models/spatial/aabb.py: normalisation, ray_test) and the occupancy-value helpers
-(models/accelerations/occgrid/utils.py: binarize, sdf_to_occ_val; maths/common.py: normalized_logistic_density).
+(models/accelerations/occgrid/utils.py: binarize, sdf_to_occ_val; maths/common.py: normalized_logistic_density) and the
+scatter-free parts of OccGridEma (ema_single.py: query, try_shrink, rescale_volume).
 Data only."""
 import os
 import sys
@@ -67,6 +68,25 @@ def main():
     out["occ_bin"] = occ.binarize(v, 0.3).numpy()
     out["occ_bin_mean"] = occ.binarize(v, 0.3, consider_mean=True).numpy()
     out["occ_bin_const"] = occ.binarize(torch.full((5,), 0.2), 0.3, consider_mean=True).numpy()
+    # OccGridEma: the pure-torch parts (no scatter): constant init, query, try_shrink, rescale_volume
+    ema = import_reference("nr3d_lib.models.accelerations.occgrid.ema_single")
+    g = ema.OccGridEma([8, 10, 6], occ_thre=0.5, init_cfg=dict(mode="constant", constant_value=0.0), device="cpu")
+    g.init()
+    torch.manual_seed(9)
+    val = torch.zeros(8, 10, 6)
+    val[2:5, 3:8, 1:4] = torch.rand(3, 5, 3) + 0.2
+    g.occ_val_grid.copy_(val)
+    g.occ_grid = occ.binarize(g.occ_val_grid, 0.5, False)
+    q = torch.rand(50, 3) * 2.4 - 1.2
+    old = torch.tensor([[-1., -2, -1], [1, 2, 3]])
+    out["ema_val"], out["ema_q"] = val.numpy(), q.numpy()
+    out["ema_occ"] = g.occ_grid.numpy()
+    out["ema_query"] = g.query(q).numpy()
+    out["ema_old_aabb"] = old.numpy()
+    new = g.try_shrink(old)
+    out["ema_shrink"] = new.numpy()
+    g.rescale_volume(old, new)
+    out["ema_rescaled_val"], out["ema_rescaled_occ"] = g.occ_val_grid.numpy(), g.occ_grid.numpy()
     np.savez_compressed(os.path.join(HERE, "ref_blocks.npz"), **out)
     print(sorted(k for k in out if not k.startswith("mlp_") or k.endswith("_y")))
 
