@@ -1,0 +1,166 @@
+"""Randomised checks of the rank-4 rows on the GPU: fused MLP (random shapes / sizes / strides / bias / activations) against
+PyTorch, forest LoTD (random forests, metas, block modes) against the oracle.  usage: fuzz_next_rows.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle                                                   # noqa: E402  (test infrastructure)
+from nr3d_lib_amd.bindings import _lotd, _mlp                    # noqa: E402
+from nr3d_lib_amd.bindings._forest import ForestMeta             # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def fuzz_mlp(rng):
+    n_hidden = int(rng.integers(1, 4))
+    wide = rng.random() < 0.3                                       # wide: forward-only shapes (hidden up to 128, up to 7 layers)
+    if wide:
+        n_hidden = int(rng.integers(1, 7))
+    wmax = 128 if wide else (32 if n_hidden == 3 else 64)
+    dims = [int(rng.integers(1, 129))] + [int(rng.integers(1, wmax + 1)) for _ in range(n_hidden)] + [int(rng.integers(1, 129 if wide else 65))]
+    hid, out = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    desc = _mlp.MLPDesc(dims, hid, out)
+    if not desc.fusable:
+        return "skip"
+    if not desc.backward_fusable:
+        n = int(rng.choice([1, 33, 64, 1000, 4097]))
+        Ws = [torch.randn(dims[i + 1], dims[i], device=dev) / max(dims[i], 1) ** 0.5 for i in range(len(dims) - 1)]
+        bs = [torch.randn(dims[i + 1], device=dev) * 0.3 if rng.integers(0, 2) else None for i in range(len(dims) - 1)]
+        x = torch.randn(n, dims[0], device=dev)
+        y = _mlp.forward(desc, x, _mlp.pack(desc, Ws, bs))
+        h64, h32 = x.double(), x
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            h64 = torch.nn.functional.linear(h64, W.double(), None if b is None else b.double())
+            h32 = torch.nn.functional.linear(h32, W, b)
+            if (hid if i + 1 < len(Ws) else out) == 1:
+                h64, h32 = torch.relu(h64), torch.relu(h32)
+        sc = float(h64.abs().max()) or 1.0
+        e, e32 = float((y.double() - h64).abs().max()) / sc, float((h32.double() - h64).abs().max()) / sc
+        assert e <= max(2e-5, 6 * e32), f"MLP fwd-only {dims} n={n}: err {e:.2e} (torch {e32:.2e})"
+        return "fwd"
+    n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 257, 1000, 4097, 20011]))
+    bias = [bool(rng.integers(0, 2)) for _ in range(len(dims) - 1)]
+    Ws = [torch.randn(dims[i + 1], dims[i], device=dev) / max(dims[i], 1) ** 0.5 for i in range(len(dims) - 1)]
+    bs = [torch.randn(dims[i + 1], device=dev) * 0.3 if b else None for i, b in enumerate(bias)]
+    pad = int(rng.choice([0, 0, 1, 3, 4]))
+    xb = torch.randn(n, dims[0] + pad, device=dev)
+    x = xb[:, pad:] if pad else xb                                  # strided / unaligned rows
+    gy = torch.randn(n, dims[-1], device=dev)
+    packed = _mlp.pack(desc, Ws, bs, with_backward=True)
+    y = _mlp.forward(desc, x, packed)
+    dx, dWs, dbs = _mlp.backward(desc, x, gy, packed, need_dx=True, has_bias=bias)
+
+    def ref(dt):
+        h = x.detach().to(dt).requires_grad_(True); h0 = h
+        ws = [w.to(dt).requires_grad_(True) for w in Ws]
+        bb = [None if b is None else b.to(dt).requires_grad_(True) for b in bs]
+        for i, (W, b) in enumerate(zip(ws, bb)):
+            h = torch.nn.functional.linear(h, W, b)
+            if (hid if i + 1 < len(ws) else out) == 1:
+                h = torch.relu(h)
+        h.backward(gy.to(dt))
+        return h.detach(), h0.grad, [w.grad for w in ws], [None if b is None else b.grad for b in bb]
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+
+    def chk(name, got, a64, a32):
+        scale = float(a64.abs().max()) or 1.0
+        e = float((got.double() - a64).abs().max()) / scale
+        e32 = float((a32.double() - a64).abs().max()) / scale
+        assert e <= max(2e-5, 6 * e32), f"MLP {dims} n={n} hid={hid} out={out} bias={bias} pad={pad}: {name} err {e:.2e} (torch {e32:.2e})"
+    chk("y", y, r64[0], r32[0]); chk("dx", dx, r64[1], r32[1])
+    for l in range(len(Ws)):
+        chk(f"dW{l}", dWs[l], r64[2][l], r32[2][l])
+        if bias[l]:
+            chk(f"db{l}", dbs[l], r64[3][l], r32[3][l])
+    return "ok"
+
+
+TYPES = ["Dense", "VM", "NPlaneMul", "CP", "Hash"]
+
+
+def fuzz_forest(rng):
+    level = int(rng.integers(0, 4))
+    side = 1 << level
+    nb = int(rng.integers(1, min(side ** 3, 12) + 1))
+    coords = {tuple(int(v) for v in rng.integers(0, side, 3)) for _ in range(nb)}
+    fo = oracle.forest_from_blocks(sorted(coords), level, continuity_enabled=bool(rng.integers(0, 4)))
+    L = int(rng.integers(1, 5))
+    gfeat = int(rng.choice([2, 2, 4, 8]))
+    nf = [gfeat * int(rng.integers(1, 3)) for _ in range(L)]
+    types = [TYPES[int(rng.integers(0, 5))] if rng.random() < 0.5 else ("Dense" if rng.random() < 0.5 else "Hash") for _ in range(L)]
+    res = [int(rng.integers(3, 14)) for _ in range(L)]
+    T = int(rng.choice([64, 97, 256, 1000]))
+    smooth = bool(rng.integers(0, 2))
+    m_ref = oracle.lotd_create_meta(3, res, nf, types, T, smooth)
+    m = _lotd.LoDMeta(3, res, nf, types, T, smooth)
+    n = int(rng.choice([1, 7, 64, 513, 3000]))
+    x = rng.random((n, 3)).astype(np.float32).clip(1e-6, 1 - 1e-6)
+    for _ in range(8):                                               # keep away from cell boundaries
+        bad = np.zeros(n, bool)
+        for r in res:
+            v = x.astype(np.float64) * r + 0.5
+            bad |= (np.abs(v - np.round(v)) < 1e-3).any(1)
+        if not bad.any():
+            break
+        x[bad] = rng.random((int(bad.sum()), 3)).astype(np.float32).clip(1e-6, 1 - 1e-6)
+    if bad.any():
+        return "skip"
+    p = (rng.standard_normal(fo.n_trees * m_ref.n_params) * 0.1).astype(np.float32)
+    g = (rng.standard_normal((n, m_ref.n_encoded_dims)) * 0.1).astype(np.float32)
+    v = rng.standard_normal((n, 3)).astype(np.float32)
+    mode = int(rng.integers(0, 3))
+    bi, bds = None, 0
+    if mode == 0:
+        bi = rng.integers(-1 if rng.random() < 0.3 else 0, fo.n_trees, n).astype(np.int64)
+    elif mode == 1 and n % fo.n_trees == 0:
+        bds = n // fo.n_trees
+    else:
+        bi = rng.integers(0, fo.n_trees, n).astype(np.int64)
+    max_level = None if rng.random() < 0.7 else int(rng.integers(-1, L))
+    fm = ForestMeta()
+    fm.octree, fm.exsum = torch.from_numpy(fo.octree).to(dev), torch.from_numpy(fo.exsum).to(dev)
+    fm.block_ks = torch.from_numpy(fo.block_ks).to(dev)
+    fm.n_trees, fm.level, fm.level_poffset, fm.continuity_enabled = fo.n_trees, fo.level, fo.level_poffset, fo.continuity_enabled
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    kw = dict(block_inds=bi, batch_data_size=bds, max_level=max_level)
+    y_ref, j_ref = oracle.lotd_forest_fwd(m_ref, fo, x, p, need_dydx=True, **kw)
+    y, j = _lotd.lod_fwd((m, fm), t(x), t(p), t(bi), None, bds or None, max_level, True)
+    tag = f"forest lvl={level} blocks={sorted(coords)} cont={fo.continuity_enabled} res={res} nf={nf} types={types} T={T} smooth={smooth} n={n} mode={mode} max_level={max_level}"
+
+    def chk(name, got, want):
+        want = np.asarray(want)
+        sc = max(float(np.abs(want).max()), 1e-30) if want.size else 1.0
+        e = float(np.abs(got.detach().cpu().numpy().astype(np.float64).reshape(want.shape) - want).max()) if want.size else 0.0
+        assert e <= 2e-5 * sc + 1e-12, f"{tag}: {name} err {e:.2e} vs scale {sc:.2e}"
+    chk("y", y, y_ref); chk("dydx", j, j_ref)
+    dx, dp = _lotd.lod_bwd((m, fm), t(g), t(x), t(p), j, t(bi), None, bds or None, max_level, True, True)
+    chk("dL_dx", dx, oracle.lotd_bwd_dx(m_ref, g, j_ref))
+    chk("dL_dparam", dp, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, accum_double=True, **kw))
+    ddy, dp2, dx2 = _lotd.lod_bwd_bwd_input((m, fm), t(v), t(g), t(x), t(p), j, t(bi), None, bds or None, max_level, True, True, True)
+    chk("dL_ddLdy", ddy, oracle.lotd_bwd_bwd_ddLdy(m_ref, v, j_ref))
+    chk("d(dLdx)/dparam", dp2, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, dL_ddLdx=v, accum_double=True, **kw))
+    chk("d(dLdx)/dx", dx2, oracle.lotd_forest_bwd_bwd_dx(m_ref, fo, v, g, x, p, **kw))
+    return "ok"
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    counts = {"mlp ok": 0, "mlp fwd": 0, "mlp skip": 0, "forest ok": 0, "forest skip": 0}
+    t0 = time.time()
+    while time.time() - t0 < budget:
+        counts["mlp " + fuzz_mlp(rng)] += 1
+        counts["forest " + fuzz_forest(rng)] += 1
+    print(counts)
+
+
+if __name__ == "__main__":
+    main()
