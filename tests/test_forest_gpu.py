@@ -355,3 +355,16 @@ def test_forest_accel_end_to_end(oracle, dev):
                                                  rt["seg_entries"], rt["seg_exits"], rt["seg_pack_infos"], step_mode="depth",
                                                  max_steps=64, min_step_size=0.05, dt_gamma=0.0)
     assert coarse["samples"].shape[0] == coarse["blidx"].shape[0] > 0
+
+
+def test_forest_dparam_multi_pass_chunking(oracle, dev, hiplib):
+    """the binned path in several point chunks (block_inds advance with the chunk; batched mode keeps its global point index)"""
+    _lotd, fo, m_ref, metas, (x, p, g, v, bi), (xt, pt, gt, vt, bit) = _setup(oracle, dev, "scatter", "dense_hash", n=9 * 2000, seed=11)
+    hiplib.nr3d_lotd_set_dparam_chunk_log2(12)                   # 4096-point chunks -> 5 passes
+    try:
+        dp = _lotd.lod_bwd(metas, gt, xt, pt, None, bit, need_input_grad=False, need_param_grad=True)[1]
+        assert_close(dp, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, accum_double=True), name="chunked dparam")
+        dpb = _lotd.lod_bwd(metas, gt, xt, pt, None, None, None, 2000, None, False, True)[1]
+        assert_close(dpb, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, batch_data_size=2000, accum_double=True), name="chunked batched dparam")
+    finally:
+        hiplib.nr3d_lotd_set_dparam_chunk_log2(0)
