@@ -122,7 +122,8 @@ def march_composite_rate(dev, iters=20, side=64):
         depth = _pack_ops.packed_sum((w * ts.squeeze(-1)).contiguous(), pil)
         ga = _pack_ops.packed_alpha_to_vw_backward(w, torch.ones_like(w), alpha, pil, 1e-4, 0.0)
         return ts.shape[0], acc, depth, ga
-    S = one()[0]
+    for _ in range(3):               # the caching allocator reaches its steady state (two live output sets)
+        S = one()[0]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
@@ -332,6 +333,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from nr3d_lib_amd.bindings import _lotd
+    from nr3d_lib_amd.distributed import lotd_backward_allreduce
     from nr3d_lib_amd.models.grid_encodings.lotd import gen_ngp_cfg
     cfg = gen_ngp_cfg()
     meta = _lotd.LoDMeta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
@@ -344,6 +346,7 @@ def main():
 
     names = ("fwd", "bwd")
     ev = {k: [] for k in names}
+    reduce_mode, reduce_trial = ["bucketed"], {}
 
     def step(record):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
@@ -351,14 +354,46 @@ def main():
         y, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
         if record: e[1].record()
         # ONE backward call for both gradients (what LoTDFunction.backward does, lotd.py / lotd_torch_api.cu:397-573)
-        dx, dp = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=True)
-        if record: e[2].record()
-        if dist is not None:
+        if dist is None:
+            dx, dp = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=True)
+        elif reduce_mode[0] == "bucketed":
+            # the one collective of the path: dL/dparam is computed in two level buckets and the all-reduce of the first
+            # (fine levels, 40 of 46 MiB) runs on RCCL's stream while the second is accumulated; the step ends when both
+            # reductions have completed (nr3d_lib_amd/distributed.py)
+            dx, dp = lotd_backward_allreduce(_lotd.lod_bwd, meta, dL_dy, x, params, j, need_input_grad=True,
+                                             need_param_grad=True)
+        else:
+            dx, dp = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=True)
             dist.all_reduce(dp)
+        if record: e[2].record()
         if record:
             for k, a, b in zip(names, e[:2], e[1:]):
                 ev[k].append((a, b))
         return y, dx, dp
+
+    # N > 1: bucketed (overlapped) or single all-reduce -- the split costs ~0.1 ms of extra kernel time, the overlap hides
+    # most of the 46 MiB reduction; which one wins depends on the fabric, so both are tried on a few untimed steps
+    # (before the warmup) and every rank adopts the globally faster one.  NR3D_BENCH_ALLREDUCE=bucketed|single pins it.
+    if dist is not None:
+        pin = os.environ.get("NR3D_BENCH_ALLREDUCE", "")
+        if pin in ("bucketed", "single"):
+            reduce_mode[0] = pin
+        else:
+            trial = {}
+            for mode in ("bucketed", "single"):
+                reduce_mode[0] = mode
+                for _ in range(3):
+                    step(False)
+                dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(6):
+                    step(False)
+                torch.cuda.synchronize()
+                t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                trial[mode] = float(t.item()) / 6 * 1e3
+            reduce_mode[0] = min(trial, key=trial.get)        # identical on every rank (decided on the all-reduced times)
+            reduce_trial.update({k: round(v, 4) for k, v in trial.items()})
 
     for _ in range(args.warmup):
         step(False)
@@ -411,7 +446,10 @@ def main():
             "config": {"workload": "configs[1]: 16-level Hash LoTD (gen_ngp_cfg: T=2^19, F=2, 6 Dense + 10 Hash), "
                                    f"2^{args.log2_points} points/GPU, fwd(+dy/dx) + dL/dx + dL/dparam, fp32",
                        "points_per_gpu": N, "n_params": meta.n_params,
-                       "parallelism": f"dp{world} (points sharded; RCCL all-reduce of dL/dparam)" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world} (points sharded; RCCL all-reduce of dL/dparam, {reduce_mode[0]}"
+                                       + (f"; untimed trial ms/step {reduce_trial}" if reduce_trial else "")
+                                       + "; kernel_ms.bwd includes the reduction)")
+                                      if dist is not None else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "kernels": OP_KERNELS[dom], "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

@@ -112,6 +112,17 @@ int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uin
                          const void *x, const void *params, const int64_t *batch_inds,
                          const int64_t *batch_offsets, uint32_t batch_data_size, uint32_t n_batches, int32_t max_level,
                          void *dL_dparam, void *workspace, uint64_t workspace_bytes, void *stream);
+/* Same, restricted to levels min_level..max_level (the entries of the other levels in dL_dparam are not touched).  No
+ * reference counterpart (it only has max_level): a data-parallel caller computes the gradient in level buckets and
+ * starts the all-reduce of a finished bucket -- a contiguous slice of dL_dparam, levels are stored one after another
+ * -- while the next bucket is being accumulated (bench.py, nr3d_lib_amd/distributed.py).  Per level the arithmetic is
+ * that of nr3d_lotd_bwd_dparam, so the buckets together equal the one-call result bit for bit on the binned path. */
+int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
+                                int x_dtype, int param_dtype, const void *dL_dy, int64_t dldy_sn, int64_t dldy_se,
+                                const void *x, const void *params, const int64_t *batch_inds,
+                                const int64_t *batch_offsets, uint32_t batch_data_size, uint32_t n_batches,
+                                int32_t min_level, int32_t max_level, void *dL_dparam, void *workspace,
+                                uint64_t workspace_bytes, void *stream);
 
 /* lod_bwd_bwd_input (lotd_torch_api.cu:575-729), three independent outputs:
  * (i)  dL_ddLdy[i, e] = sum_d dL_ddLdx[i, d] * dy_dx[i, e, d]      (lotd_encoding.h:1703-1727) */

@@ -327,7 +327,11 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
 # lod_bwd  (lotd.cpp:32-35, lotd_torch_api.cu:397-573)
 # ------------------------------------------------------------------------------------------------
 def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offsets=None, batch_data_size=None,
-            max_level=None, need_input_grad=None, need_param_grad=None):
+            max_level=None, need_input_grad=None, need_param_grad=None, level_buckets=None, on_bucket=None):
+    """``level_buckets`` / ``on_bucket`` (no reference counterpart, non-batched params only): compute dL/dparam in the
+    given order of inclusive level ranges ``[(lo, hi), ...]`` and call ``on_bucket(k, grad_slice)`` as soon as bucket k is
+    enqueued -- ``grad_slice`` is the contiguous part of dL_dparam that holds those levels, e.g. to start its
+    all-reduce while the next bucket is accumulated (nr3d_lotd_bwd_dparam_levels)."""
     if isinstance(lod_meta, tuple):
         from . import _forest
         return _forest.lod_bwd(lod_meta, dL_dy, input, params, dy_dx, batch_inds, batch_offsets, batch_data_size, max_level,
@@ -379,11 +383,30 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                 ws, wsb = _dparam_workspace(m, N, dev, nbat)
                 if gT is not None:
                     g32, gsn, gse = gT, 1, N
-                H.check(H.lib().nr3d_lotd_bwd_dparam(
-                    C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
-                    H.ptr(g32), H.i64(gsn), H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
-                    H.ptr(batch_offsets), H.u32(bds), H.u32(nbat), H.i32(max_level), H.ptr(dL_dparam), H.ptr(ws),
-                    C.c_uint64(wsb), st))
+                if level_buckets is None:
+                    H.check(H.lib().nr3d_lotd_bwd_dparam(
+                        C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
+                        H.ptr(g32), H.i64(gsn), H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
+                        H.ptr(batch_offsets), H.u32(bds), H.u32(nbat), H.i32(max_level), H.ptr(dL_dparam), H.ptr(ws),
+                        C.c_uint64(wsb), st))
+                else:
+                    if batched:
+                        raise RuntimeError("bwd: level_buckets need non-batched params")
+                    if params.dtype != torch.float32:
+                        raise RuntimeError("bwd: level_buckets need float params (the slices handed out are the result)")
+                    seen = set()
+                    for k, (lo, hi) in enumerate(level_buckets):
+                        lo, hi = int(lo), min(int(hi), m.n_levels - 1)
+                        if lo < 0 or lo > hi or seen & set(range(lo, hi + 1)):
+                            raise RuntimeError(f"bwd: bad or overlapping level bucket {(lo, hi)}")
+                        seen |= set(range(lo, hi + 1))
+                        H.check(H.lib().nr3d_lotd_bwd_dparam_levels(
+                            C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
+                            H.ptr(g32), H.i64(gsn), H.i64(gse), H.ptr(x32), H.ptr(p32), None, None, H.u32(0),
+                            H.u32(nbat), H.i32(lo), H.i32(min(hi, max_level)), H.ptr(dL_dparam), H.ptr(ws),
+                            C.c_uint64(wsb), st))
+                        if on_bucket is not None:
+                            on_bucket(k, dL_dparam[m.level_offsets[lo]:m.level_offsets[hi + 1]])
     return _cast(dL_dx, input.dtype), _cast(dL_dparam, params.dtype)
 
 

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 // =============================================================================================
 template <int D, int G, bool SECOND, bool DH>
 __global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
-                                                       int32_t max_level, uint32_t smooth,
+                                                       int32_t min_level, int32_t max_level, uint32_t smooth,
                                                        const float *__restrict__ dL_ddLdx,
                                                        const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
                                                        const float *__restrict__ x, const float *__restrict__ params,
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_
 	const uint32_t i = chunk * kBlock + threadIdx.x;
 	if (i >= N) return;
 	const uint32_t level = meta_level_of(md, q);
-	if ((int32_t)level > max_level) return;
+	if ((int32_t)level > max_level || (int32_t)level < min_level) return;
 	uint32_t base = 0;
 	if (!batch_base(ba, i, base)) return;
 	const uint32_t foff0 = meta_cnt_of(md, q) * G;
@@ -804,8 +804,8 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
                              const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
                              const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
                              uint32_t batch_data_size, uint32_t n_batches, int32_t max_level, void *dL_dparam,
-                             void *workspace, uint64_t workspace_bytes, void *stream) {
-	if (N == 0 || max_level <= -1) return 0;
+                             void *workspace, uint64_t workspace_bytes, void *stream, int32_t min_level = 0) {
+	if (N == 0 || max_level <= -1 || min_level > max_level) return 0;
 	NR3D_CHECK(dL_dy && x && params && dL_dparam, "LoTD::bwd: NULL tensor pointer");
 	// atomic-free binned path: metas without NPlaneSum/CPfast levels, when the caller supplied the workspace (batched
 	// params need n_batches, the number of table sets behind `params`)
@@ -815,7 +815,8 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
 		const Batch bb{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 		if (int rc = dparam_binned(second, meta, meta_dev, N, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
 		                           (const float *)x, (const float *)params, bb, batched ? n_batches : 1u, max_level,
-		                           (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled))
+		                           (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, nullptr,
+		                           min_level))
 			return rc;
 		if (handled) return 0;
 	}
@@ -826,7 +827,7 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
 	const bool dh = meta->c_hash_only != 0;
 	DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
 		auto launch = [&](auto kern) {
-			hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
+			hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, min_level, max_level,
 			                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
 			                   (const float *)x, (const float *)params, ba, (float *)dL_dparam);
 		};
@@ -846,6 +847,19 @@ extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *me
 	return launch_bwd_dparam(false, meta, meta_dev, N, nullptr, dL_dy, g_sn, g_se, x, params, batch_inds,
 	                         batch_offsets, batch_data_size, n_batches, max_level, dL_dparam, workspace, workspace_bytes,
 	                         stream);
+}
+
+extern "C" int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                                           int param_dtype, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
+                                           const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
+                                           uint32_t batch_data_size, uint32_t n_batches, int32_t min_level,
+                                           int32_t max_level, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
+                                           void *stream) {
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	NR3D_CHECK(min_level >= 0, "LoTD::bwd: min_level must be >= 0");
+	return launch_bwd_dparam(false, meta, meta_dev, N, nullptr, dL_dy, g_sn, g_se, x, params, batch_inds,
+	                         batch_offsets, batch_data_size, n_batches, max_level, dL_dparam, workspace, workspace_bytes,
+	                         stream, min_level);
 }
 
 extern "C" void nr3d_lotd_set_dparam_chunk_log2(int log2_points) { set_dparam_chunk_log2(log2_points); }

@@ -825,7 +825,7 @@ static uint32_t chunk_points(uint32_t n) {
 
 // plan for the pseudo levels of record class `cls` (0 levels => n_pseudo == 0)
 static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, uint32_t cls, BinPlan &plan,
-                      uint64_t &offs_words) {
+                      uint64_t &offs_words, int32_t min_level = 0, int32_t max_level = 0x7fffffff) {
 	const uint32_t D = m->n_dims_to_encode, G = m->n_feat_per_pseudo_lvl;
 	const uint32_t kBinPts = bin_points(G, cls);
 	if (m->n_pseudo_levels > kMaxPlanLevels) return false;
@@ -840,6 +840,9 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_ba
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
 		if (rec_class(rec_count(L.type, D)) != cls) continue;
+		// levels outside the requested range get no stage-A blocks, offsets or work items (max_level schedules, the
+		// level-bucket calls of the data-parallel path)
+		if ((int32_t)m->map_levels[q] < min_level || (int32_t)m->map_levels[q] > max_level) continue;
 		const uint64_t n_virtual = (uint64_t)plan.n_batches * L.size;
 		if (n_virtual > 0xFFFFFFFFull) return false;
 		const uint32_t nb = div_up(n_virtual, 1u << lg);
@@ -958,7 +961,7 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
-                  hipStream_t st, bool &handled, const ForestDev *forest) {
+                  hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level) {
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
@@ -991,7 +994,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		for (uint32_t cls : kClasses) {
 			BinPlan pl;
 			uint64_t ow;
-			make_plan(meta, n, n_batches, cls, pl, ow);
+			make_plan(meta, n, n_batches, cls, pl, ow, min_level, max_level);
 			if (pl.n_pseudo == 0) continue;
 			int rc = 0;
 			// only the (D, class) pairs some level type can produce are instantiated

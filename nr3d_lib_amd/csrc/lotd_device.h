@@ -651,10 +651,11 @@ __device__ __forceinline__ void locate_forest(const float (&xp)[3], const Lvl &L
 uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches);
 void set_dparam_chunk_log2(int lg);
 // `forest` != NULL: the points live in the blocks of a forest (n_batches = n_trees); Dense/Hash 3-D metas only
+// levels below `min_level` are left out (their part of dparam is not touched)
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
-                  hipStream_t st, bool &handled, const ForestDev *forest = nullptr);
+                  hipStream_t st, bool &handled, const ForestDev *forest = nullptr, int32_t min_level = 0);
 
 }  // namespace lotd
 }  // namespace nr3d

@@ -86,6 +86,35 @@ def allreduce_grads(grads: Iterable[Optional[torch.Tensor]], average: bool = Fal
     flush()
 
 
+def lotd_level_buckets(meta, first_fraction: float = 0.8):
+    """Two level buckets ``[(lo, hi), (0, lo - 1)]`` for ``lod_bwd(..., level_buckets=...)``: the finest levels first,
+    until they hold >= ``first_fraction`` of the parameter bytes, so that the large part of the gradient is on the
+    wire while the coarse levels (few bytes, a comparable share of the accumulation work -- every level receives the
+    same number of updates) are still being accumulated.  NGP config: levels 6..15 (40 of 46 MiB), then 0..5."""
+    L, total = meta.n_levels, float(meta.n_params)
+    if L < 2:
+        return [(0, L - 1)]
+    lo, acc = L, 0
+    while lo > 1 and acc < first_fraction * total:
+        lo -= 1
+        acc += meta.level_n_params[lo]
+    return [(lo, L - 1), (0, lo - 1)]
+
+
+def lotd_backward_allreduce(lod_bwd, meta, *args, first_fraction: float = 0.8, **kwargs):
+    """``lod_bwd(meta, *args, **kwargs)`` with dL/dparam all-reduced (SUM) over the default group, the reduction of the
+    first level bucket overlapped with the accumulation of the second.  Returns (dL_dx, dL_dparam) like ``lod_bwd``;
+    the gradient is complete when this returns (in stream order).  Without a process group: the plain call."""
+    if not is_dist():
+        return lod_bwd(meta, *args, **kwargs)
+    works = []
+    out = lod_bwd(meta, *args, level_buckets=lotd_level_buckets(meta, first_fraction),
+                  on_bucket=lambda k, g: works.append(dist.all_reduce(g, async_op=True)), **kwargs)
+    for w in works:
+        w.wait()
+    return out
+
+
 def global_pack_offsets(local_total: int, device=None) -> Tuple[int, int]:
     """(offset of this rank's packed samples in the concatenation over ranks, global total)"""
     if not is_dist() or dist.get_world_size() == 1:

@@ -67,6 +67,24 @@ def _worker(rank, world, port, q):
         local = torch.from_numpy(oracle.occ_update_grid(grid0, gidx[a:b], val[a:b], 0.9))
         dist.all_reduce(local, op=dist.ReduceOp.MAX)
         assert not np.array_equal(local.numpy(), got)
+        # bucketed backward + overlapped all-reduce: the wrapper drives any lod_bwd-shaped callable; here a host stand-in
+        # that honours level_buckets / on_bucket the way bindings._lotd.lod_bwd does (the HIP one needs a GPU)
+        class Meta: n_levels, n_params, level_n_params, level_offsets = 4, 100, [10, 20, 30, 40], [0, 10, 30, 60, 100]
+        calls = []
+
+        def fake_bwd(meta, scale, level_buckets=None, on_bucket=None):
+            grad = torch.zeros(meta.n_params)
+            for k, (lo, hi) in enumerate(level_buckets or [(0, meta.n_levels - 1)]):
+                a, b = meta.level_offsets[lo], meta.level_offsets[hi + 1]
+                grad[a:b] = scale * torch.arange(a, b, dtype=torch.float32)
+                calls.append((lo, hi))
+                if on_bucket is not None:
+                    on_bucket(k, grad[a:b])
+            return None, grad
+        assert D.lotd_level_buckets(Meta) == [(1, 3), (0, 0)] and D.lotd_level_buckets(Meta, 0.3) == [(3, 3), (0, 2)]
+        _, gsum = D.lotd_backward_allreduce(fake_bwd, Meta, float(rank + 1))
+        assert calls == [(1, 3), (0, 0)]
+        torch.testing.assert_close(gsum, sum(range(1, world + 1)) * torch.arange(100, dtype=torch.float32))
         off, total = D.global_pack_offsets(10 * (rank + 1))
         assert total == sum(10 * (r + 1) for r in range(world)) and off == sum(10 * (r + 1) for r in range(rank))
         q.put((rank, "ok"))
@@ -96,3 +114,19 @@ def test_single_process_is_a_noop():
     g = torch.ones(3)
     D.allreduce_grads([g])
     assert torch.equal(g, torch.ones(3)) and D.global_pack_offsets(5) == (0, 5)
+    # without a process group the bucketed backward is the plain call (no level_buckets passed)
+    assert D.lotd_backward_allreduce(lambda meta, a, **kw: (a, kw), None, 7) == (7, {})
+
+
+def test_level_buckets_of_the_ngp_config():
+    """the headline config: ten Hash levels (40 of 46 MiB) first, then the six Dense ones"""
+    from nr3d_lib_amd import distributed as D
+    from nr3d_lib_amd.bindings import _lotd
+    from nr3d_lib_amd.models.grid_encodings.lotd import gen_ngp_cfg
+    cfg = gen_ngp_cfg()
+    m = _lotd.LoDMeta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
+    b = D.lotd_level_buckets(m)
+    assert b == [(6, 15), (0, 5)], b
+    assert sum(m.level_n_params[6:]) / m.n_params > 0.8
+    one = _lotd.LoDMeta(3, [16], [2], ["Dense"], None)
+    assert D.lotd_level_buckets(one) == [(0, 0)]

@@ -116,6 +116,45 @@ def test_dparam_atomic_and_binned_paths_agree(oracle, dev, case):
         assert_close(dp3, oracle.lotd_bwd_dparam(m_ref, g, x, p, max_level=0, accum_double=True), name="max_level=0")
 
 
+@pytest.mark.parametrize("case", ["ngp_small", "mixed", "dense_2d", "nplane"])
+def test_dparam_level_buckets(oracle, dev, case):
+    """dL/dparam computed in level buckets (nr3d_lotd_bwd_dparam_levels; the data-parallel path reduces a finished
+    bucket while the next one is accumulated): the buckets together are the one-call gradient -- bit for bit on the
+    atomic-free path --, every bucket callback sees exactly its levels' slice, and levels outside the buckets stay zero"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=11)
+    L = m.n_levels
+    y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    for binned in (True, False):
+        _lotd.USE_BINNED_DPARAM = binned
+        try:
+            dx0, dp0 = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)
+            cut = max(1, L // 2)
+            buckets = [(cut, L - 1), (0, cut - 1)] if L > 1 else [(0, 0)]
+            seen = []
+            dx1, dp1 = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True, level_buckets=buckets,
+                                     on_bucket=lambda k, sl: seen.append((k, sl.data_ptr(), sl.numel(), sl.clone())))
+            _, dp2 = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True,
+                                   level_buckets=[(L - 1, L - 1)])
+        finally:
+            _lotd.USE_BINNED_DPARAM = True
+        assert_equal(dx1, dx0.cpu().numpy(), name="dL_dx")
+        if binned and _lotd._dparam_workspace(m, 5003, dev)[1] > 0:
+            assert_equal(dp1, dp0.cpu().numpy(), name="bucketed dL_dparam (atomic-free path)")
+        else:
+            assert_close(dp1, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="bucketed dL_dparam (atomics)")
+        assert [k for k, *_ in seen] == list(range(len(buckets)))
+        for (k, ptr, numel, snap), (lo, hi) in zip(seen, buckets):
+            a, b = m.level_offsets[lo], m.level_offsets[hi + 1]
+            assert ptr == dp1.data_ptr() + 4 * a and numel == b - a
+            assert torch.equal(snap, dp1[a:b]), "a bucket's slice is final when its callback runs (stream order)"
+        a = m.level_offsets[L - 1]
+        assert not dp2[:a].any(), "levels outside the buckets stay untouched"
+        if binned and _lotd._dparam_workspace(m, 5003, dev)[1] > 0:
+            assert torch.equal(dp2[a:], dp1[a:])
+    with pytest.raises(RuntimeError, match="overlapping"):
+        _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True, level_buckets=[(0, 0), (0, L - 1)])
+
+
 def test_grid_index_rejects_other_types(oracle, dev):
     _lotd, m_ref, m, _, (xt, *_r) = _setup(oracle, dev, "mixed")
     with pytest.raises(RuntimeError, match="Only support Dense/Hash"):
