@@ -29,6 +29,7 @@ namespace lotd {
 
 constexpr int kAccThreads = 1024;         // stage-B workgroup
 constexpr int kLdsDoubles = 16384;        // 128 KiB of fp64 accumulators
+constexpr int kRedSlots = 4;              // accumulator slots per thread in k_reduce_partials
 constexpr int kMaxPlanLevels = 64;        // pseudo levels handled by the binned path
 constexpr uint32_t kMaxBuckets = 8192;    // per pseudo level
 
@@ -765,7 +766,42 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(BinPlan plan, const nr3d_
 	}
 }
 
-// one workgroup per replicated bucket: dL/dparam slice += sum of the replicas' partials, replica 0 first
+// dL/dparam slice of a replicated bucket += sum of the replicas' partials, replica 0 first.  NS accumulator slots per
+// thread, NR replicas per pass (NS * NR loads in flight, summed in replica order).
+template <int G, int NS, int NR>
+__device__ __forceinline__ void reduce_rows(const BinPlan &plan, const Lvl &L, const Batch &ba, uint32_t foff0, uint32_t b,
+                                            uint32_t R, uint32_t row0, const float *__restrict__ part0,
+                                            float *__restrict__ dparam) {
+	float *p[NS];
+	uint32_t slot[NS];
+	float old[NS], sum[NS];
+#pragma unroll
+	for (int k = 0; k < NS; ++k) {
+		p[k] = flush_target<G>(plan, L, ba, foff0, b, (row0 + (uint32_t)k) * kAccThreads + threadIdx.x, dparam, slot[k]);
+		if (!p[k]) slot[k] = 0;
+		sum[k] = 0.0f;
+	}
+#pragma unroll
+	for (int k = 0; k < NS; ++k) old[k] = p[k] ? *p[k] : 0.0f;
+	for (uint32_t r0 = 0; r0 < R; r0 += NR) {
+		float v[NS][NR];
+#pragma unroll
+		for (int k = 0; k < NS; ++k)
+#pragma unroll
+			for (int j = 0; j < NR; ++j) v[k][j] = (r0 + j < R) ? part0[(size_t)(r0 + j) * kLdsDoubles + slot[k]] : 0.0f;
+#pragma unroll
+		for (int k = 0; k < NS; ++k)
+#pragma unroll
+			for (int j = 0; j < NR; ++j) sum[k] += v[k][j];
+	}
+#pragma unroll
+	for (int k = 0; k < NS; ++k) if (p[k]) *p[k] = old[k] + sum[k];
+}
+
+// grid (bucket, kLdsDoubles / kAccThreads rows).  The chain rep -> level -> item_start -> partials -> dparam is latency-
+// bound: a bucket with few replicas (the hash levels of a level-bucket call: 640 buckets x 2) gives kRedSlots rows to
+// a workgroup (61 -> 32 us), a bucket with many (the coarse Dense levels: R up to the number of point blocks) keeps one
+// row per workgroup, where the replica loop is the long part and more workgroups are what helps.
 template <int D, int G>
 __global__ __launch_bounds__(kAccThreads) void k_reduce_partials(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
                                                                  const uint32_t *__restrict__ rep_g,
@@ -775,25 +811,16 @@ __global__ __launch_bounds__(kAccThreads) void k_reduce_partials(BinPlan plan, c
 	const uint32_t fb = blockIdx.x;
 	const uint32_t R = rep_g[fb];
 	if (R <= 1) return;
+	const bool wide = R <= 4;
+	if (wide && blockIdx.y >= kLdsDoubles / kAccThreads / kRedSlots) return;
 	uint32_t q = 0;
 	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
 	const uint32_t b = fb - plan.bucket_base[q], qg = plan.qmap[q];
 	const Lvl L = load_level(md, meta_level_of(md, qg));
 	const uint32_t foff0 = meta_cnt_of(md, qg) * G;
 	const float *part0 = partial + (size_t)item_start[fb] * kLdsDoubles;
-	const uint32_t t = blockIdx.y * kAccThreads + threadIdx.x;        // one accumulator slot per thread
-	uint32_t slot;
-	float *p = flush_target<G>(plan, L, ba, foff0, b, t, dparam, slot);
-	if (!p) return;
-	float sum = 0.0f;
-	for (uint32_t r0 = 0; r0 < R; r0 += 8) {                           // 8 independent loads in flight, summed in order
-		float v[8];
-#pragma unroll
-		for (int k = 0; k < 8; ++k) v[k] = (r0 + k < R) ? part0[(size_t)(r0 + k) * kLdsDoubles + slot] : 0.0f;
-#pragma unroll
-		for (int k = 0; k < 8; ++k) sum += v[k];
-	}
-	*p += sum;
+	if (wide) reduce_rows<G, kRedSlots, 4>(plan, L, ba, foff0, b, R, blockIdx.y * kRedSlots, part0, dparam);
+	else reduce_rows<G, 1, 8>(plan, L, ba, foff0, b, R, blockIdx.y, part0, dparam);
 }
 
 // -------------------------------------------------------------------------------------------------
