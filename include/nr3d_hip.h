@@ -116,7 +116,8 @@ int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, uin
  * reference counterpart (it only has max_level): a data-parallel caller computes the gradient in level buckets and
  * starts the all-reduce of a finished bucket -- a contiguous slice of dL_dparam, levels are stored one after another
  * -- while the next bucket is being accumulated (bench.py, nr3d_lib_amd/distributed.py).  Per level the arithmetic is
- * that of nr3d_lotd_bwd_dparam, so the buckets together equal the one-call result bit for bit on the binned path. */
+ * that of nr3d_lotd_bwd_dparam; how a hot table slice is split over workgroups follows the records of the call, so the
+ * buckets together equal the one-call result to fp32 rounding of the partial sums (each is an fp64 sum), not bitwise. */
 int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
                                 int x_dtype, int param_dtype, const void *dL_dy, int64_t dldy_sn, int64_t dldy_se,
                                 const void *x, const void *params, const int64_t *batch_inds,

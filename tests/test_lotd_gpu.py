@@ -119,8 +119,9 @@ def test_dparam_atomic_and_binned_paths_agree(oracle, dev, case):
 @pytest.mark.parametrize("case", ["ngp_small", "mixed", "dense_2d", "nplane"])
 def test_dparam_level_buckets(oracle, dev, case):
     """dL/dparam computed in level buckets (nr3d_lotd_bwd_dparam_levels; the data-parallel path reduces a finished
-    bucket while the next one is accumulated): the buckets together are the one-call gradient -- bit for bit on the
-    atomic-free path --, every bucket callback sees exactly its levels' slice, and levels outside the buckets stay zero"""
+    bucket while the next one is accumulated): the buckets together are the one-call gradient (to fp32 rounding of the
+    fp64 partial sums: how a hot table slice is split over workgroups follows the call's records), every bucket callback
+    sees exactly its levels' slice, and levels outside the buckets stay zero"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=11)
     L = m.n_levels
     y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
@@ -138,10 +139,9 @@ def test_dparam_level_buckets(oracle, dev, case):
         finally:
             _lotd.USE_BINNED_DPARAM = True
         assert_equal(dx1, dx0.cpu().numpy(), name="dL_dx")
-        if binned and _lotd._dparam_workspace(m, 5003, dev)[1] > 0:
-            assert_equal(dp1, dp0.cpu().numpy(), name="bucketed dL_dparam (atomic-free path)")
-        else:
-            assert_close(dp1, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="bucketed dL_dparam (atomics)")
+        ref = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
+        assert_close(dp1, ref, name=f"bucketed dL_dparam binned={binned}")
+        assert_close(dp1, dp0.cpu().numpy(), rel=1e-6 if binned else 1e-5, name="bucketed vs one-call dL_dparam")
         assert [k for k, *_ in seen] == list(range(len(buckets)))
         for (k, ptr, numel, snap), (lo, hi) in zip(seen, buckets):
             a, b = m.level_offsets[lo], m.level_offsets[hi + 1]
@@ -149,8 +149,7 @@ def test_dparam_level_buckets(oracle, dev, case):
             assert torch.equal(snap, dp1[a:b]), "a bucket's slice is final when its callback runs (stream order)"
         a = m.level_offsets[L - 1]
         assert not dp2[:a].any(), "levels outside the buckets stay untouched"
-        if binned and _lotd._dparam_workspace(m, 5003, dev)[1] > 0:
-            assert torch.equal(dp2[a:], dp1[a:])
+        assert_close(dp2[a:], dp1[a:].cpu().numpy(), rel=1e-6 if binned else 1e-5, name="single-level bucket")
     with pytest.raises(RuntimeError, match="overlapping"):
         _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True, level_buckets=[(0, 0), (0, L - 1)])
 
