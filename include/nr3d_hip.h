@@ -289,8 +289,12 @@ int nr3d_occ_apply_max(uint64_t n_voxels, float ema_decay, const float *vmax, fl
  *   layer, a width > 128, packed weights beyond the LDS budget) -- the caller then keeps its unfused path.
  * nr3d_mlp_pack: weights/biases (HOST arrays of n_layers DEVICE pointers) -> packed, in MFMA operand order; call it
  *   whenever the parameters changed (once per optimiser step).
- * nr3d_mlp_forward: y[i*y_stride + o] for x[i*x_stride + f]; rows need not be padded or aligned (16-byte aligned
- *   rows take vector loads).
+ * nr3d_mlp_forward: y[i*y_stride + o] for x[i*x_stride + f*x_feature_stride], x either row-major (x_feature_stride == 1;
+ *   rows need not be padded or aligned, 16-byte aligned rows take vector loads) or feature-major (x_stride == 1: the
+ *   [E, N] storage the LoTD kernels write, consumed without a transposing copy -- a half-wave then reads 128 contiguous
+ *   bytes of one feature).  nr3d_mlp_backward takes x the same way and stores dL_dx in either layout
+ *   (gx_stride / gx_feature_stride; feature-major dL_dx is what nr3d_lotd_bwd_dparam reads without its transposition
+ *   pass).
  * ============================================================================================== */
 #define NR3D_MLP_MAX_LAYERS 8
 enum { NR3D_MLP_ACT_NONE = 0, NR3D_MLP_ACT_RELU = 1 };
@@ -313,11 +317,11 @@ int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *weights, cons
 /* dL/dx (or NULL), dL/dW_l [dims[l+1], dims[l]] and dL/db_l (dL_db or entries may be NULL) from x and dL/dy; the forward
  * is recomputed in registers, nothing but x has to be kept from the forward pass.  Parameter gradients are ADDED to
  * dL_dW / dL_db (fp32 atomics, one per element and workgroup): zero them for plain gradients. */
-int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, const float *dL_dy,
-                      int64_t gy_stride, const float *packed, float *dL_dx, int64_t gx_stride, float *const *dL_dW,
-                      float *const *dL_db, void *stream);
-int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, const float *packed,
-                     float *y, int64_t y_stride, void *stream);
+int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, int64_t x_feature_stride,
+                      const float *dL_dy, int64_t gy_stride, const float *packed, float *dL_dx, int64_t gx_stride,
+                      int64_t gx_feature_stride, float *const *dL_dW, float *const *dL_db, void *stream);
+int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, int64_t x_feature_stride,
+                     const float *packed, float *y, int64_t y_stride, void *stream);
 
 /* =================================================================================================
  * pack_ops -- replaces nr3d_lib.bindings._pack_ops  (csrc/pack_ops/pack_ops.h:11-65,

@@ -70,40 +70,55 @@ def pack(desc: MLPDesc, weights, biases, with_backward=False) -> torch.Tensor:
     return packed
 
 
+def _layout(t2: torch.Tensor):
+    """[n, w] tensor -> (tensor, row stride, feature stride) the kernels can read in place: row-major (rows may be strided)
+    or feature-major ([w, n] storage viewed as [n, w], what the LoTD forward returns); anything else is copied"""
+    n, w = t2.shape
+    if w == 1 or t2.stride(1) == 1:
+        return t2, (t2.stride(0) if n > 1 else w), 1
+    if n > 1 and t2.stride(0) == 1:
+        return t2, 1, t2.stride(1)
+    return t2.contiguous(), w, 1
+
+
 def forward(desc: MLPDesc, x: torch.Tensor, packed: torch.Tensor) -> torch.Tensor:
-    """x [..., in] fp32 (rows may be strided: last dim contiguous) -> y [..., out]"""
+    """x [..., in] fp32 (row-major with any row stride, or feature-major) -> y [..., out]"""
     H.require_gpu(x, packed)
     if x.dtype != torch.float32 or x.shape[-1] != desc.dims[0]:
         raise RuntimeError(f"mlp.forward: expected fp32 input with {desc.dims[0]} features, got {x.dtype} {list(x.shape)}")
-    x2 = x.reshape(-1, x.shape[-1])
-    if x2.stride(-1) != 1:
-        x2 = x2.contiguous()
+    x2, xs, xf = _layout(x.reshape(-1, x.shape[-1]))
     n = x2.shape[0]
     y = torch.empty((n, desc.dims[-1]), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        H.check(H.lib().nr3d_mlp_forward(C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(x2.stride(0) if n > 1 else x2.shape[1]),
+        H.check(H.lib().nr3d_mlp_forward(C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(xs), H.i64(xf),
                                          H.ptr(packed), H.ptr(y), H.i64(y.shape[1]), H.stream_of(x)))
     return y.view(*x.shape[:-1], desc.dims[-1])
 
 
 def backward(desc: MLPDesc, x: torch.Tensor, dL_dy: torch.Tensor, packed: torch.Tensor, need_dx=True, has_bias=None):
-    """-> (dL_dx | None, [dL_dW_l], [dL_db_l | None]); `packed` from pack(..., with_backward=True)"""
+    """-> (dL_dx | None, [dL_dW_l], [dL_db_l | None]); `packed` from pack(..., with_backward=True).  dL_dx has the layout
+    of x: for a feature-major x (the LoTD features) it is feature-major too, which is what the LoTD parameter-gradient
+    pass reads without a transposition."""
     H.require_gpu(x, dL_dy, packed)
     n_layers = len(desc.dims) - 1
     x2 = x.reshape(-1, desc.dims[0])
     g2 = dL_dy.reshape(-1, desc.dims[-1])
     if x2.dtype != torch.float32 or g2.dtype != torch.float32 or x2.shape[0] != g2.shape[0]:
         raise RuntimeError("mlp.backward: expected fp32 x [n, in] and dL_dy [n, out]")
-    x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
-    g2 = g2 if g2.stride(-1) == 1 else g2.contiguous()
+    x2, xs, xf = _layout(x2)
+    g2 = g2 if (g2.stride(-1) == 1 or g2.shape[1] == 1) else g2.contiguous()
     n, dev = x2.shape[0], x.device
     has_bias = [True] * n_layers if has_bias is None else list(has_bias)
     dWs = [torch.zeros(desc.dims[l + 1], desc.dims[l], dtype=torch.float32, device=dev) for l in range(n_layers)]
     dbs = [torch.zeros(desc.dims[l + 1], dtype=torch.float32, device=dev) if has_bias[l] else None for l in range(n_layers)]
-    dx = torch.empty_like(x2, memory_format=torch.contiguous_format) if need_dx else None
+    dx, gxs, gxf = None, desc.dims[0], 1
+    if need_dx and xf != 1:
+        dx, gxs, gxf = torch.empty((desc.dims[0], n), dtype=torch.float32, device=dev).t(), 1, n
+    elif need_dx:
+        dx = torch.empty((n, desc.dims[0]), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         H.check(H.lib().nr3d_mlp_backward(
-            C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(x2.stride(0) if n > 1 else desc.dims[0]), H.ptr(g2),
-            H.i64(g2.stride(0) if n > 1 else desc.dims[-1]), H.ptr(packed), H.ptr(dx), H.i64(desc.dims[0]), _ptr_array(dWs),
+            C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(xs), H.i64(xf), H.ptr(g2),
+            H.i64(g2.stride(0) if n > 1 else desc.dims[-1]), H.ptr(packed), H.ptr(dx), H.i64(gxs), H.i64(gxf), _ptr_array(dWs),
             _ptr_array(dbs), H.stream_of(x)))
-    return (None if dx is None else dx.view(x.shape)), dWs, dbs
+    return (None if dx is None else dx.reshape(x.shape)), dWs, dbs

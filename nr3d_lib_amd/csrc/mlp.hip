@@ -200,6 +200,38 @@ __device__ __forceinline__ void load_rows_fast(const float *__restrict__ p, int6
 		}
 }
 
+// Feature-major input (element (row, f) at p[f * fstride + row], e.g. the [E, N] storage the LoTD kernels write): a
+// half-wave reads 32 consecutive samples of one feature, 128 contiguous bytes per request -- the natural layout of the
+// B operand of H^T = W X^T.  Branch-free like load_rows_fast: the row is clamped, a feature beyond the width re-reads
+// feature 0 (it meets zero weights).  No alignment requirement.
+template <int NT>
+__device__ __forceinline__ void load_cols_fast(const float *__restrict__ p, int64_t fstride, uint32_t dim, uint64_t row_clamped,
+                                               int lane, f16v (&r)[NT]) {
+	const int h = lane >> 5;
+	const float *base = p + row_clamped;
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			const uint32_t f = 32u * t + 8u * (j >> 2) + 4u * h + (j & 3);
+			r[t][j] = __builtin_nontemporal_load(base + (int64_t)(f < dim ? f : 0u) * fstride);
+		}
+}
+
+template <int NT>
+__device__ __forceinline__ void store_cols(float *__restrict__ p, int64_t fstride, uint32_t dim, uint64_t row, bool valid, int lane,
+                                           const f16v (&r)[NT]) {
+	const int h = lane >> 5;
+	if (!valid) return;
+#pragma unroll
+	for (int t = 0; t < NT; ++t)
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {
+			const uint32_t f = 32u * t + 8u * (j >> 2) + 4u * h + (j & 3);
+			if (f < dim) __builtin_nontemporal_store(r[t][j], p + (int64_t)f * fstride + row);
+		}
+}
+
 template <int NT>
 __device__ __forceinline__ void store_rows(float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row, bool valid, bool vec,
                                            int lane, const f16v (&r)[NT]) {
@@ -239,7 +271,16 @@ __device__ __forceinline__ void stage_weights(const float *__restrict__ packed, 
 	__syncthreads();
 }
 
-template <int IN_T, int W_T, int OUT_T, bool XF>
+// XF: 0 = row-major input, any alignment / width; 1 = row-major, 16-byte aligned rows of a multiple of 4 floats
+// (prefetched); 2 = feature-major input (a.xs = feature stride, prefetched)
+template <int XF, int NT>
+__device__ __forceinline__ void prefetch_x(const float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row_clamped, int lane,
+                                           f16v (&r)[NT]) {
+	if constexpr (XF == 2) load_cols_fast<NT>(p, stride, dim, row_clamped, lane, r);
+	else load_rows_fast<NT>(p, stride, dim, row_clamped, lane, r);
+}
+
+template <int IN_T, int W_T, int OUT_T, int XF>
 __global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	stage_weights(a.packed, a.packed_floats, lds);
@@ -248,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
 	const uint32_t off_hidden = layer_floats(IN_T, W_T), sz_hidden = layer_floats(W_T, W_T);
 	auto clamp_row = [&](uint64_t row) { return row < a.n ? row : a.n - 1; };
 	f16v xnext[IN_T];
-	if (XF) load_rows_fast<IN_T>(a.x, a.xs, a.in_dim, clamp_row(((uint64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31)), lane, xnext);
+	if (XF) prefetch_x<XF, IN_T>(a.x, a.xs, a.in_dim, clamp_row(((uint64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31)), lane, xnext);
 	for (uint64_t tile = (uint64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += step) {
 		const uint64_t row = tile * 32 + (lane & 31);
 		const bool valid = row < a.n;
@@ -257,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
 			// software pipeline: this tile's rows were requested one iteration ago, the next tile's go out now
 #pragma unroll
 			for (int t = 0; t < IN_T; ++t) xin[t] = xnext[t];
-			load_rows_fast<IN_T>(a.x, a.xs, a.in_dim, clamp_row((tile + step) * 32 + (lane & 31)), lane, xnext);
+			prefetch_x<XF, IN_T>(a.x, a.xs, a.in_dim, clamp_row((tile + step) * 32 + (lane & 31)), lane, xnext);
 		} else {
 			load_rows<IN_T>(a.x, a.xs, a.in_dim, row, valid, a.x_vec != 0, lane, xin);
 		}
@@ -307,6 +348,7 @@ struct BwdArgs {
 	const float *x; int64_t xs;
 	const float *gy; int64_t gys;
 	float *gx; int64_t gxs;                    // NULL: dL/dx not wanted
+	uint32_t x_fm, gx_fm;                      // x is read / dL/dx is stored feature-major (xs / gxs = feature stride)
 	const float *packed;                       // [forward layers | transposed layers]
 	uint32_t fwd_floats, total_floats;
 	float *dW[NR3D_MLP_MAX_LAYERS];            // accumulated into (atomics): zero them for plain gradients
@@ -402,7 +444,9 @@ __device__ __forceinline__ void zero_tiles(f16v (&r)[NT]) {
 
 // FAST: x and dL/dy rows are 16-byte aligned with widths that are multiples of 4 -> branch-free loads, the next tile's
 // rows requested while this tile is processed (one wave per SIMD: nothing else hides the memory latency)
-template <int IN_T, int W_T, int OUT_T, int NH, bool FAST>
+// FAST: 0 = any layout (row-major or, with a.x_fm, feature-major x), 1 = prefetched row-major x and dL/dy, 2 = prefetched
+// feature-major x + row-major dL/dy
+template <int IN_T, int W_T, int OUT_T, int NH, int FAST>
 __global__ __launch_bounds__(kThreads) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	{
@@ -439,7 +483,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(BwdArgs a) {
 	f16v xnext[IN_T], gnext[OUT_T];
 	if (FAST) {
 		const uint64_t r0 = clamp_row(((uint64_t)blockIdx.x * nw + wave) * 32 + r);
-		load_rows_fast<IN_T>(a.x, a.xs, a.dims[0], r0, lane, xnext);
+		prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], r0, lane, xnext);
 		load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], r0, lane, gnext);
 	}
 	for (uint64_t tile = (uint64_t)blockIdx.x * nw + wave; tile < n_tiles; tile += step) {
@@ -452,10 +496,11 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(BwdArgs a) {
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t) g_out[t] = gnext[t];
 			const uint64_t rn = clamp_row((tile + step) * 32 + r);
-			load_rows_fast<IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
+			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
 			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
 		} else {
-			load_rows<IN_T>(a.x, a.xs, a.dims[0], row, valid, a.x_vec != 0, lane, xin);
+			if (a.x_fm) load_cols_fast<IN_T>(a.x, a.xs, a.dims[0], clamp_row(row), lane, xin);   // rows past n: dL/dy is zero there
+			else load_rows<IN_T>(a.x, a.xs, a.dims[0], row, valid, a.x_vec != 0, lane, xin);
 			load_rows<OUT_T>(a.gy, a.gys, a.dims[NH + 1], row, valid, a.gy_vec != 0, lane, g_out);
 		}
 		// ---- forward, activations kept as [feature][sample] tiles ----
@@ -497,7 +542,8 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(BwdArgs a) {
 		f16v gx[IN_T];
 		if (a.gx) {
 			bwd_layer<W_T, IN_T, true, false>(g, TH1, TX, wt, dW0, db0, gx, lane);
-			store_rows<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, a.gx_vec != 0, lane, gx);
+			if (a.gx_fm) store_cols<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, lane, gx);
+			else store_rows<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, a.gx_vec != 0, lane, gx);
 		} else {
 			bwd_layer<W_T, IN_T, false, false>(g, TH1, TX, wt, dW0, db0, gx, lane);
 		}
@@ -618,14 +664,16 @@ extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *we
 		else _iw(std::integral_constant<int, 4>{});                                                            \
 	} while (0)
 
-extern "C" int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, const float *packed,
-                                float *y, int64_t y_stride, void *stream) {
+extern "C" int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, int64_t x_feature_stride,
+                                const float *packed, float *y, int64_t y_stride, void *stream) {
 	Shape s;
 	NR3D_CHECK(shape_of(desc, s) && nr3d_mlp_packed_floats(desc) != 0, "mlp_forward: network outside the fused kernels' range");
 	if (n == 0) return 0;
 	NR3D_CHECK(x && packed && y, "mlp_forward: NULL pointer");
 	FwdArgs a;
-	a.n = n; a.x = x; a.xs = x_stride; a.y = y; a.ys = y_stride; a.packed = packed;
+	const bool x_fm = x_feature_stride != 1;
+	NR3D_CHECK(!x_fm || x_stride == 1, "mlp_forward: x must be row-major (feature stride 1) or feature-major (row stride 1)");
+	a.n = n; a.x = x; a.xs = x_fm ? x_feature_stride : x_stride; a.y = y; a.ys = y_stride; a.packed = packed;
 	a.packed_floats = (uint32_t)packed_floats(s);
 	a.n_layers = desc->n_layers; a.in_dim = desc->dims[0]; a.out_dim = desc->dims[desc->n_layers];
 	a.hidden_act = (int)desc->hidden_activation; a.out_act = (int)desc->output_activation;
@@ -640,31 +688,39 @@ extern "C" int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const f
 		int dev = 0;
 		if (hipGetDevice(&dev) != hipSuccess) { rc = ::nr3d::fail("mlp_forward: hipGetDevice failed"); return; }
 		if (!attr[dev & 63]) {
-			if (hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess ||
-			    hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+			if (hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess ||
+			    hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess ||
+			    hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
 				rc = ::nr3d::fail("mlp_forward: cannot raise the dynamic LDS limit"); return;
 			}
 			attr[dev & 63] = true;
 		}
-		if (a.x_vec && a.in_dim % 4 == 0)
-			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, true>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+		if (x_fm)
+			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, 2>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+		else if (a.x_vec && a.in_dim % 4 == 0)
+			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, 1>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
 		else
-			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, false>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, 0>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
 	});
 	if (rc) return rc;
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
 
-extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, const float *dL_dy,
-                                 int64_t gy_stride, const float *packed, float *dL_dx, int64_t gx_stride, float *const *dL_dW,
-                                 float *const *dL_db, void *stream) {
+extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, int64_t x_feature_stride,
+                                 const float *dL_dy, int64_t gy_stride, const float *packed, float *dL_dx, int64_t gx_stride,
+                                 int64_t gx_feature_stride, float *const *dL_dW, float *const *dL_db, void *stream) {
 	Shape s;
 	NR3D_CHECK(shape_of(desc, s) && nr3d_mlp_backward_packed_floats(desc) != 0, "mlp_backward: the fused backward does not apply to this network");
 	if (n == 0) return 0;
 	NR3D_CHECK(x && dL_dy && packed && dL_dW, "mlp_backward: NULL pointer");
 	BwdArgs a;
-	a.n = n; a.x = x; a.xs = x_stride; a.gy = dL_dy; a.gys = gy_stride; a.gx = dL_dx; a.gxs = gx_stride; a.packed = packed;
+	const bool x_fm = x_feature_stride != 1, gx_fm = dL_dx && gx_feature_stride != 1;
+	NR3D_CHECK(!x_fm || x_stride == 1, "mlp_backward: x must be row-major (feature stride 1) or feature-major (row stride 1)");
+	NR3D_CHECK(!gx_fm || gx_stride == 1, "mlp_backward: dL_dx must be row-major (feature stride 1) or feature-major (row stride 1)");
+	a.n = n; a.x = x; a.xs = x_fm ? x_feature_stride : x_stride; a.gy = dL_dy; a.gys = gy_stride; a.packed = packed;
+	a.gx = dL_dx; a.gxs = gx_fm ? gx_feature_stride : gx_stride;
+	a.x_fm = x_fm ? 1u : 0u; a.gx_fm = gx_fm ? 1u : 0u;
 	a.fwd_floats = (uint32_t)packed_floats(s);
 	a.total_floats = a.fwd_floats + (uint32_t)transposed_floats(s);
 	for (uint32_t l = 0; l < desc->n_layers; ++l) {
@@ -686,7 +742,8 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	const uint64_t n_tiles = (n + 31) / 32;
 	const uint32_t grid = (uint32_t)(n_tiles / nw + 1 < 256 ? n_tiles / nw + 1 : 256);     // one workgroup per CU: dW lives in registers
 	const uint32_t nh = desc->n_layers - 1;
-	const bool fast = a.x_vec && a.gy_vec && desc->dims[0] % 4 == 0 && desc->dims[desc->n_layers] % 4 == 0;
+	const bool gy_fast = a.gy_vec && desc->dims[desc->n_layers] % 4 == 0;
+	const int fast = !gy_fast ? 0 : x_fm ? 2 : (a.x_vec && desc->dims[0] % 4 == 0) ? 1 : 0;
 	auto launch = [&](auto kern) -> int {
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
@@ -694,7 +751,7 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	};
 	int rc = 0;
 #define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) \
-		rc = fast ? launch(k_mlp_bwd<I, W, O, H, true>) : launch(k_mlp_bwd<I, W, O, H, false>); else
+		rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1>) : launch(k_mlp_bwd<I, W, O, H, 0>); else
 	BWD_CASE(1, 1, 1, 1) BWD_CASE(1, 1, 1, 2) BWD_CASE(1, 1, 1, 3)
 	BWD_CASE(1, 2, 1, 1) BWD_CASE(1, 2, 1, 2) BWD_CASE(1, 2, 2, 1) BWD_CASE(1, 2, 2, 2)
 	BWD_CASE(2, 2, 1, 1) BWD_CASE(2, 2, 1, 2) BWD_CASE(2, 2, 2, 1) BWD_CASE(2, 2, 2, 2)

@@ -85,6 +85,37 @@ def test_fused_forward_backward_match_torch(dev, dims, n, hidden, out, bias):
         mlp_mod.USE_FUSED = True
 
 
+@pytest.mark.parametrize("dims,n,hidden,out,bias", CASES)
+def test_feature_major_input_is_consumed_in_place(dev, dims, n, hidden, out, bias):
+    """x as the LoTD forward returns it ([features, n] storage viewed as [n, features]): the kernels read it without the
+    transposing copy (16-byte aligned output rows or not: both backward kernels), and dL/dx comes back in the same layout"""
+    from nr3d_lib_amd.bindings import _mlp
+    m = _net(dims, hidden, out, bias, dev, seed=3)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    xt = torch.randn(dims[0], n, generator=g).to(dev).requires_grad_(True)
+    x = xt.t()
+    assert n == 1 or x.stride() == (1, n)
+    gy = torch.randn(n, dims[-1], generator=g).to(dev)
+    y64, dx64, dW64, db64 = _reference(m, x, gy, torch.float64)
+    y32, dx32, dW32, db32 = _reference(m, x, gy, torch.float32)
+    y = m(x)
+    y.backward(gy)
+    _check("y", y.detach(), y64, y32)
+    _check("dL_dx", xt.grad.t(), dx64, dx32)
+    for l, layer in enumerate(m.layers):
+        _check(f"dL_dW{l}", layer.weight.grad, dW64[l], dW32[l])
+        if bias:
+            _check(f"dL_db{l}", layer.bias.grad, db64[l], db32[l])
+    # the binding hands dL/dx back feature-major (what the LoTD parameter-gradient pass reads without transposing)
+    desc = m.fused_desc()
+    packed = _mlp.pack(desc, [l.weight for l in m.layers], [l.bias for l in m.layers], with_backward=True)
+    dx, _, _ = _mlp.backward(desc, x.detach(), gy, packed, need_dx=True, has_bias=[bias] * len(m.layers))
+    assert n == 1 or dx.stride() == (1, n)
+    _check("dL_dx (binding)", dx, dx64, dx32)
+    with torch.no_grad():
+        _check("y (no_grad)", m(x), y64, y32)
+
+
 def test_fused_handles_strided_rows_leading_dims_and_frozen_inputs(dev):
     m = _net([32, 64, 16], "relu", None, True, dev)
     g = torch.Generator(device="cpu").manual_seed(2)
