@@ -134,9 +134,8 @@ def march_composite_rate(dev, iters=20, side=64):
                 ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4))
 
 
-def full_loop_rate(dev, side=512, iters=9):
-    """BASELINE configs[4] on one GPU: 16-level Hash encode + occ-grid march + pack composite, forward AND backward
-    through nerf_ray_query_march_occ (visibility pruning on) with a tiny random MLP head (tools/demo_field.py)."""
+def _full_loop_setup(dev, side=512, shift=0.0):
+    """model + rays + one forward/backward of BASELINE configs[4]'s loop on `side`^2 rays (gradients accumulate)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from demo_field import DemoField, pinhole_rays
     from nr3d_lib_amd.graphics.nerf import composite_packed_volume_buffer, nerf_ray_query_march_occ
@@ -145,16 +144,26 @@ def full_loop_rate(dev, side=512, iters=9):
     r = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).norm(dim=-1)
     occ = ((r > 0.45) & (r < 0.8)).to(dev)                      # a shell: ~19 % of the voxels occupied
     model = DemoField(occ, 2 * 3 ** 0.5 / 512, max_steps=512, seed=1, device=dev)
-    o, d, near, far = pinhole_rays(side, dev)
+    o, d, near, far = pinhole_rays(side, dev, shift=shift)
     n = side * side
     rays = dict(num_rays=n, rays_o=o, rays_d=d, near=near, far=far, rays_inds=torch.arange(n, device=dev))
 
-    def one():
-        model.zero_grad(set_to_none=True)
+    def fwd_bwd():
         vb, det = nerf_ray_query_march_occ(model, rays, with_rgb=True, compression=True)
         out = composite_packed_volume_buffer(vb, n)
         (out["rgb_volume"].mean() + out["depth_volume"].mean()).backward()
         return int(det["march.num_per_ray"].sum()), int(det["render.num_per_ray"].sum())
+    return model, n, fwd_bwd
+
+
+def full_loop_rate(dev, side=512, iters=9):
+    """BASELINE configs[4] on one GPU: 16-level Hash encode + occ-grid march + pack composite, forward AND backward
+    through nerf_ray_query_march_occ (visibility pruning on) with a tiny random MLP head (tools/demo_field.py)."""
+    model, n, fwd_bwd = _full_loop_setup(dev, side)
+
+    def one():
+        model.zero_grad(set_to_none=True)
+        return fwd_bwd()
     marched, rendered = one()
     one()
     # every iteration timed on its own: the driver allocates data-dependent buffers, and an iteration that happens to go
@@ -172,6 +181,63 @@ def full_loop_rate(dev, side=512, iters=9):
                 samples_marched=marched, samples_rendered=rendered, ms_per_iter=round(ms, 3),
                 ms_per_iter_mean=round(float(np.mean(per_iter)), 3), iters=iters,
                 mrays_per_s=round(n / ms / 1e3, 3), msamples_per_s=round((marched + rendered) / ms / 1e3, 3))
+
+
+def full_loop_sharded_rate(dev, dist, rank, world, chunks=8, side=512, iters=3):
+    """BASELINE configs[4] as stated: 2^24 rays over 8 GPUs = 2^21 rays per GPU, rendered as `chunks` x `side`^2-ray
+    forward/backward passes whose gradients accumulate, then ONE all-reduce of all parameter gradients (LoTD tables +
+    decoder weights, nr3d_lib_amd.distributed.allreduce_grads) per iteration.  Every rank renders its own rays (camera
+    shifted by rank).  A rank that fails locally reports it through a MIN all-reduce before the gradient collective, so
+    the ranks leave together instead of hanging."""
+    from nr3d_lib_amd.distributed import allreduce_grads
+
+    def all_ok(ok):
+        t = torch.tensor([1.0 if ok else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+    state = {}
+    try:
+        model, n, fwd_bwd = _full_loop_setup(dev, side, shift=0.05 * rank)
+        state["ok"] = True
+    except Exception as ex:
+        state["ok"], state["err"] = False, repr(ex)[:200]
+    if not all_ok(state["ok"]):
+        return {"error": state.get("err", "setup failed on another rank")}
+    counts = [0, 0]
+
+    def iteration():
+        ok = True
+        try:
+            model.zero_grad(set_to_none=True)
+            counts[0] = counts[1] = 0
+            for _ in range(chunks):
+                m, r = fwd_bwd()
+                counts[0] += m; counts[1] += r
+        except Exception as ex:
+            ok, state["err"] = False, repr(ex)[:200]
+        if not all_ok(ok):
+            return False
+        allreduce_grads([p.grad for p in model.parameters()])
+        return True
+    if not iteration():
+        return {"error": state.get("err", "an iteration failed on another rank")}
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        if not iteration():
+            return {"error": state.get("err", "an iteration failed on another rank")}
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0, float(counts[0]), float(counts[1])], device=dev, dtype=torch.float64)
+    tmax, tsum = t.clone(), t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    ms = float(tmax[0].item()) / iters * 1e3
+    rays = world * chunks * n
+    return dict(workload=f"configs[4]: march + prune + 16-level Hash LoTD encode + fused MLP decoders + composite, fwd+bwd, "
+                         f"{chunks} x {n} rays per GPU x {world} GPUs = {rays} rays per iteration, one all-reduce of all "
+                         f"parameter gradients per iteration",
+                rays=rays, samples_marched=int(tsum[1].item()), samples_rendered=int(tsum[2].item()), ms_per_iter=round(ms, 3),
+                mrays_per_s=round(rays / ms / 1e3, 3))
 
 
 def lotd_large_batch_rate(log2n=24):
@@ -414,7 +480,7 @@ def main():
 
     # N > 1: the ray half of the metric, rays sharded like the points (every rank marches + composites its own 262 144
     # rays, no collective on the data path); whole-job rate = all rays / slowest rank
-    multi_march = None
+    multi_march = multi_loop = None
     if dist is not None and not args.no_extra and (world > 1 or os.environ.get("NR3D_BENCH_FORCE_DIST") == "1"):
         try:
             r = march_composite_rate(dev, iters=5, side=512)
@@ -429,6 +495,8 @@ def main():
         multi_march = dict(workload=f"occ 128^3 march + alpha composite fwd+bwd, 262144 rays per GPU x {world} GPUs",
                            samples=int(tsum[1].item()), ms_per_iter=round(ms_all, 4),
                            mrays_per_s=round(world * 262144 / ms_all / 1e3, 4) if ms_all == ms_all and ms_all > 0 else None)
+        torch.cuda.empty_cache()
+        multi_loop = full_loop_sharded_rate(dev, dist, rank, world)
 
     if rank == 0:
         kms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
@@ -478,6 +546,7 @@ def main():
                     out["extra"][name] = {"error": repr(ex)[:300]}
         if multi_march is not None:
             out.setdefault("extra", {})["march_composite_262144_rays_per_gpu"] = multi_march
+            out["extra"]["full_loop_2p21_rays_per_gpu"] = multi_loop
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)

@@ -67,14 +67,14 @@ class DemoField(nn.Module):
         return dict(sigma=sigma, rgb=rgb)
 
 
-def pinhole_rays(side, device, fov=0.4, dist=4.0):
-    """side^2 rays from a pinhole at (0, 0, -dist) looking at the origin, with near/far from the [-1, 1]^3 box"""
+def pinhole_rays(side, device, fov=0.4, dist=4.0, shift=0.0):
+    """side^2 rays from a pinhole at (shift, 0, -dist) looking along +z, with near/far from the [-1, 1]^3 box"""
     u = torch.linspace(-fov, fov, side)
     uu, vv = torch.meshgrid(u, u, indexing="ij")
     n = side * side
     d = torch.stack([uu.flatten(), vv.flatten(), torch.ones(n)], 1)
     d = (d / d.norm(dim=1, keepdim=True)).to(device)
-    o = torch.tensor([0.0, 0.0, -dist]).repeat(n, 1).to(device)
+    o = torch.tensor([float(shift), 0.0, -dist]).repeat(n, 1).to(device)
     t1, t2 = (-1 - o) / d, (1 - o) / d
     near = torch.minimum(t1, t2).amax(1).clamp_min(0).contiguous()
     far = torch.maximum(t1, t2).amin(1).contiguous()
