@@ -358,7 +358,10 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
             dL_dx = torch.zeros((N, D), dtype=torch.float32, device=dev)
         if need_param_grad:
             dL_dparam = torch.zeros((params.shape[0],), dtype=torch.float32, device=dev)
-        if max_level <= -1 or not (need_input_grad or need_param_grad):
+        if max_level <= -1 or not (need_input_grad or need_param_grad) or (N == 0 and need_param_grad):
+            if need_param_grad and level_buckets is not None and on_bucket is not None:
+                for k, (lo, hi) in enumerate(level_buckets):     # every bucket is announced (collectives stay matched)
+                    on_bucket(k, dL_dparam[m.level_offsets[int(lo)]:m.level_offsets[min(int(hi), m.n_levels - 1) + 1]])
             return (_cast(dL_dx, input.dtype), _cast(dL_dparam, params.dtype))
         g32 = _f32c(dL_dy.detach())
         gsn, gse = _strides2(g32)

@@ -152,6 +152,13 @@ def test_dparam_level_buckets(oracle, dev, case):
         assert_close(dp2[a:], dp1[a:].cpu().numpy(), rel=1e-6 if binned else 1e-5, name="single-level bucket")
     with pytest.raises(RuntimeError, match="overlapping"):
         _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True, level_buckets=[(0, 0), (0, L - 1)])
+    # an empty shard or max_level = -1 still announces every bucket (zeros): the ranks' collectives stay matched
+    for kw in (dict(x=xt[:0], g=gt[:0], max_level=None), dict(x=xt, g=gt, max_level=-1)):
+        seen = []
+        _, dpz = _lotd.lod_bwd(m, kw["g"], kw["x"], pt, None, max_level=kw["max_level"], need_input_grad=False,
+                               need_param_grad=True, level_buckets=buckets, on_bucket=lambda k, sl: seen.append((k, sl.numel())))
+        assert [k for k, _ in seen] == list(range(len(buckets))) and sum(n_ for _, n_ in seen) == m.n_params
+        assert not dpz.any()
 
 
 def test_grid_index_rejects_other_types(oracle, dev):

@@ -7,7 +7,7 @@ dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 bad = 0
 cases = [c for c in LOTD_CASES if c not in ("cp_4d",)]
-for it in range(60):
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     case = cases[it % len(cases)]
     D, res, nf, types, T, smooth = LOTD_CASES[case]
     n = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 511, 513, 1000, 4097, 9999]))
@@ -15,12 +15,23 @@ for it in range(60):
     m = _lotd.LoDMeta(D, res, nf, types, T, smooth)
     x, p, g, v = lotd_inputs(m_ref.as_dict(), n, it)
     t = lambda a: torch.from_numpy(a).to(dev)
-    ml = int(rng.integers(-1, m.n_levels + 1)) if it % 5 == 0 else None
+    ml = int(rng.integers(-1, m.n_levels + 1)) if it % 3 == 0 else None
     kw = {} if ml is None else dict(max_level=ml)
     y, j = _lotd.lod_fwd(m, t(x), t(p), need_input_grad=True, **kw)
     y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True, **kw)
     dx, dp = _lotd.lod_bwd(m, t(g), t(x), t(p), j, need_input_grad=True, need_param_grad=True, **kw)
     dp_ref = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw)
+    if it % 2 == 1 and m.n_levels > 1:        # the same gradient in random level buckets (a random partition, random order)
+        cuts = sorted(set(int(c) for c in rng.integers(1, m.n_levels, size=int(rng.integers(1, 4)))))
+        edges = [0] + cuts + [m.n_levels]
+        bk = [(a, b - 1) for a, b in zip(edges[:-1], edges[1:])]
+        bk = [bk[i] for i in rng.permutation(len(bk))]
+        seen = []
+        _, dpb = _lotd.lod_bwd(m, t(g), t(x), t(p), None, need_input_grad=False, need_param_grad=True, level_buckets=bk,
+                               on_bucket=lambda k, sl: seen.append(sl.numel()), **kw)
+        eb = float((dpb - dp).abs().max()) / max(float(dp.abs().max()), 1e-30)
+        if eb > 2e-6 or sum(seen) != m.n_params:
+            bad += 1; print("BUCKET MISMATCH", case, n, ml, bk, eb, sum(seen), m.n_params)
     _, dp2, dx2 = _lotd.lod_bwd_bwd_input(m, t(v), t(g), t(x), t(p), j, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True, need_dLdinput_dinput=True, **kw)
     dp2_ref = oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True, **kw)
     def err(a, b):
