@@ -422,12 +422,14 @@ def main():
         # ONE backward call for both gradients (what LoTDFunction.backward does, lotd.py / lotd_torch_api.cu:397-573)
         if dist is None:
             dx, dp = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=True)
-        elif reduce_mode[0] == "bucketed":
-            # the one collective of the path: dL/dparam is computed in two level buckets and the all-reduce of the first
-            # (fine levels, 40 of 46 MiB) runs on RCCL's stream while the second is accumulated; the step ends when both
-            # reductions have completed (nr3d_lib_amd/distributed.py)
+        elif reduce_mode[0] in ("bucketed", "bucketed3"):
+            # the one collective of the path: dL/dparam is computed in two (levels 6..15 = 40 of 46 MiB, then 0..5) or
+            # three (11..15, 6..10, 0..5) level buckets and the all-reduce of a finished bucket runs on RCCL's stream
+            # while the next one is accumulated; the step ends when all reductions have completed
+            # (nr3d_lib_amd/distributed.py)
             dx, dp = lotd_backward_allreduce(_lotd.lod_bwd, meta, dL_dy, x, params, j, need_input_grad=True,
-                                             need_param_grad=True)
+                                             need_param_grad=True,
+                                             first_fraction=0.8 if reduce_mode[0] == "bucketed" else (0.4, 0.8))
         else:
             dx, dp = _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=True)
             dist.all_reduce(dp)
@@ -439,14 +441,15 @@ def main():
 
     # N > 1: bucketed (overlapped) or single all-reduce -- the split costs ~0.1 ms of extra kernel time, the overlap hides
     # most of the 46 MiB reduction; which one wins depends on the fabric, so both are tried on a few untimed steps
-    # (before the warmup) and every rank adopts the globally faster one.  NR3D_BENCH_ALLREDUCE=bucketed|single pins it.
+    # (before the warmup) and every rank adopts the globally fastest one.  NR3D_BENCH_ALLREDUCE=bucketed|bucketed3|single
+    # pins it.
     if dist is not None:
         pin = os.environ.get("NR3D_BENCH_ALLREDUCE", "")
-        if pin in ("bucketed", "single"):
+        if pin in ("bucketed", "bucketed3", "single"):
             reduce_mode[0] = pin
         else:
             trial = {}
-            for mode in ("bucketed", "single"):
+            for mode in ("bucketed", "bucketed3", "single"):
                 reduce_mode[0] = mode
                 for _ in range(3):
                     step(False)

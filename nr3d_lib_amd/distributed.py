@@ -86,25 +86,33 @@ def allreduce_grads(grads: Iterable[Optional[torch.Tensor]], average: bool = Fal
     flush()
 
 
-def lotd_level_buckets(meta, first_fraction: float = 0.8):
-    """Two level buckets ``[(lo, hi), (0, lo - 1)]`` for ``lod_bwd(..., level_buckets=...)``: the finest levels first,
-    until they hold >= ``first_fraction`` of the parameter bytes, so that the large part of the gradient is on the
-    wire while the coarse levels (few bytes, a comparable share of the accumulation work -- every level receives the
-    same number of updates) are still being accumulated.  NGP config: levels 6..15 (40 of 46 MiB), then 0..5."""
+def lotd_level_buckets(meta, first_fraction=0.8):
+    """Level buckets for ``lod_bwd(..., level_buckets=...)``, finest levels first.  ``first_fraction``: a number -> two
+    buckets ``[(lo, L-1), (0, lo-1)]``, the first holding >= that fraction of the parameter bytes, so that the large part
+    of the gradient is on the wire while the coarse levels (few bytes, a comparable share of the accumulation work --
+    every level receives the same number of updates) are still being accumulated; a sequence of increasing fractions ->
+    one more bucket per entry (cut whenever the cumulative share reaches the next fraction).
+    NGP config: 0.8 -> levels 6..15 (40 of 46 MiB), then 0..5;  (0.4, 0.8) -> 11..15, 6..10, 0..5."""
     L, total = meta.n_levels, float(meta.n_params)
+    fractions = [float(first_fraction)] if isinstance(first_fraction, (int, float)) else [float(f) for f in first_fraction]
     if L < 2:
         return [(0, L - 1)]
-    lo, acc = L, 0
-    while lo > 1 and acc < first_fraction * total:
-        lo -= 1
-        acc += meta.level_n_params[lo]
-    return [(lo, L - 1), (0, lo - 1)]
+    buckets, hi, acc, k = [], L - 1, 0.0, 0
+    for lvl in range(L - 1, 0, -1):              # level 0 always stays in the last bucket
+        acc += meta.level_n_params[lvl]
+        if k < len(fractions) and acc >= fractions[k] * total:
+            buckets.append((lvl, hi))
+            hi, k = lvl - 1, k + 1
+            if k == len(fractions):
+                break
+    buckets.append((0, hi))
+    return buckets
 
 
-def lotd_backward_allreduce(lod_bwd, meta, *args, first_fraction: float = 0.8, **kwargs):
-    """``lod_bwd(meta, *args, **kwargs)`` with dL/dparam all-reduced (SUM) over the default group, the reduction of the
-    first level bucket overlapped with the accumulation of the second.  Returns (dL_dx, dL_dparam) like ``lod_bwd``;
-    the gradient is complete when this returns (in stream order).  Without a process group: the plain call."""
+def lotd_backward_allreduce(lod_bwd, meta, *args, first_fraction=0.8, **kwargs):
+    """``lod_bwd(meta, *args, **kwargs)`` with dL/dparam all-reduced (SUM) over the default group, the reduction of every
+    level bucket but the last overlapped with the accumulation of the next one.  Returns (dL_dx, dL_dparam) like
+    ``lod_bwd``; the gradient is complete when this returns (in stream order).  Without a process group: the plain call."""
     if not is_dist():
         return lod_bwd(meta, *args, **kwargs)
     works = []

@@ -82,6 +82,7 @@ def _worker(rank, world, port, q):
                     on_bucket(k, grad[a:b])
             return None, grad
         assert D.lotd_level_buckets(Meta) == [(1, 3), (0, 0)] and D.lotd_level_buckets(Meta, 0.3) == [(3, 3), (0, 2)]
+        assert D.lotd_level_buckets(Meta, (0.3, 0.6)) == [(3, 3), (2, 2), (0, 1)] and D.lotd_level_buckets(Meta, 1.5) == [(0, 3)]
         _, gsum = D.lotd_backward_allreduce(fake_bwd, Meta, float(rank + 1))
         assert calls == [(1, 3), (0, 0)]
         torch.testing.assert_close(gsum, sum(range(1, world + 1)) * torch.arange(100, dtype=torch.float32))
@@ -127,6 +128,7 @@ def test_level_buckets_of_the_ngp_config():
     m = _lotd.LoDMeta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
     b = D.lotd_level_buckets(m)
     assert b == [(6, 15), (0, 5)], b
+    assert D.lotd_level_buckets(m, (0.4, 0.8)) == [(11, 15), (6, 10), (0, 5)]
     assert sum(m.level_n_params[6:]) / m.n_params > 0.8
     one = _lotd.LoDMeta(3, [16], [2], ["Dense"], None)
     assert D.lotd_level_buckets(one) == [(0, 0)]
