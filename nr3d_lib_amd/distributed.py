@@ -6,7 +6,8 @@ nr3d_lib/distributed.py:40-46,99, and the --ddp flag is deprecated, nr3d_lib/con
 naturally:
 
   * points (LoTD) and rays (march + composite) are independent -> contiguous shards, NO data-path collective;
-  * the LoTD parameters are replicated, so after backward ONE all-reduce(SUM) of dL/dparam per step
+  * the LoTD parameters are replicated, so the one collective is the all-reduce(SUM) of dL/dparam per step -- after
+    the backward, or in level buckets overlapped with it (`lotd_backward_allreduce`)
     (first- and second-order parameter gradients are summed into the same buffer by autograd before it);
   * packed offsets (packed_info / pack_infos) are shard-local; a global layout, when needed, is the local one
     shifted by an exclusive scan of the per-rank totals (one small all_gather).
