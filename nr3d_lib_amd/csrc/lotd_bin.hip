@@ -30,6 +30,11 @@ namespace lotd {
 constexpr int kAccThreads = 1024;         // stage-B workgroup
 constexpr int kLdsDoubles = 16384;        // 128 KiB of fp64 accumulators
 constexpr int kRedSlots = 4;              // accumulator slots per thread in k_reduce_partials
+#ifndef NR3D_BALLOT_RANK_BUCKETS
+#define NR3D_BALLOT_RANK_BUCKETS 4
+#endif
+constexpr uint32_t kBallotRankBuckets = NR3D_BALLOT_RANK_BUCKETS;   // stage A ranks through ballots up to this many buckets
+                                                                    // (NGP config, backward ms: 0: 0.880, 4: 0.862, 12: 0.899)
 constexpr int kMaxPlanLevels = 64;        // pseudo levels handled by the binned path
 constexpr uint32_t kMaxBuckets = 8192;    // per pseudo level
 
@@ -483,7 +488,33 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			if (same) n_rec = 0;                                         // merged into the head of the run
 		}
 	}
-	if (active) {
+	if (nb <= kBallotRankBuckets) {
+		// A coarse level's table is one to four buckets: every record of the block would hit the same few histogram
+		// counters (LDS atomics on one address serialise).  Rank through ballots instead: per distinct bucket in the wave
+		// one atomic by its first lane, the other lanes take their position from the ballot mask.
+		const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+		for (uint32_t r = 0; r < (uint32_t)NR; ++r) {
+			const bool has = active && r < n_rec;
+			uint32_t bkt = 0xFFFFFFFFu;
+			if (has) {
+				if (!FO) ent[r] += bi * L.size;
+				bkt = ent[r] >> plan.epb_log2;
+			}
+			unsigned long long todo = __ballot(has);
+			while (todo) {
+				const int leader = __ffsll((long long)todo) - 1;
+				const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)bkt, leader);
+				const bool mine = has && bkt == v;
+				const unsigned long long m = __ballot(mine);
+				uint32_t first = 0;
+				if ((int)lane == leader) first = atomicAdd(&hist[v], (uint32_t)__popcll(m));
+				first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+				if (mine) rank[r] = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+				todo &= ~m;
+			}
+		}
+	} else if (active) {
 #pragma unroll
 		for (uint32_t r = 0; r < (uint32_t)NR; ++r)
 			if (r < n_rec) {
