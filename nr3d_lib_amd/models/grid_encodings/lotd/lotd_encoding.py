@@ -94,15 +94,10 @@ class LoTDEncoding(nn.Module):
 
     # ---- parameter access ---------------------------------------------------------------------------------------
     def _level_slice(self, l: int, op: str = None, dim: int = None):
-        m = self.lod_meta
-        assert 0 <= l < m.n_levels
-        sl = slice(m.level_offsets[l], m.level_offsets[l] + m.level_n_params[l])
-        if op is None:
-            return sl, (m.level_sizes[l], m.level_n_feats[l])
-        if op == 'vol' and LoDType(int(m.level_types[l])) == LoDType.Dense:
-            return sl, (*m.level_res_multidim[l], m.level_n_feats[l])
-        raise NotImplementedError(f"nr3d_lib_amd: get/set_level_param(op={op!r}, dim={dim!r}) -- only whole levels and "
-                                  f"Dense 'vol' views are provided")
+        """(slice, shape) of a level or of one of its line / plane / volume tables (lotd_helpers.level_param_index_shape)"""
+        from .lotd_helpers import level_param_index_shape
+        index, shape = level_param_index_shape(self.lod_meta, l, op, dim)
+        return index[0], shape
 
     def get_level_param(self, l: int, op: str = None, dim: int = None, grad=False) -> torch.Tensor:
         sl, shape = self._level_slice(l, op, dim)
@@ -150,5 +145,53 @@ class LoTDEncoding(nn.Module):
     def set_extra_state(self, state: Any):
         self.lotd_cfg = state
 
+    @torch.no_grad()
     def rescale_volume(self, new_aabb: torch.Tensor):
-        raise NotImplementedError("nr3d_lib_amd: rescale_volume (table re-interpolation) is model tooling, not hot path")
+        """Shrink the encoded space to ``new_aabb`` ([2, 3], inside the current one) and resample every table on its
+        full resolution over the new box (lotd_encoding.py:329-401).  Cubic levels of the tensor types only: a Hash
+        level has no spatial layout to resample.  Each table is sampled at the positions of its new vertices, expressed
+        in the old box: a Dense volume in 3-D, the line tables of VM / CP levels along their own axis, the plane tables
+        of VM / NPlane levels in the two axes they span (ascending, first one slowest).  As in the reference, the line
+        and plane vertices are taken at the cell centres of the new box (``param_vertices(..., is_forest=True)``) while
+        the old tables are sampled with the plain-level vertex convention."""
+        from .lotd_helpers import param_interpolate, param_vertices
+        m = self.lod_meta
+        assert m.level_res[0] > 0, f"Expects equal resolution on each level! \nWhile current lod_res={m.level_res_multidim}"
+        dev = self.flattened_params.device
+        new_aabb = new_aabb.view(2, 3).to(dev, torch.float)
+        old_aabb = self.space.aabb.view(2, 3).to(dev, torch.float)
+        c_old, h_old = (old_aabb[1] + old_aabb[0]) / 2., (old_aabb[1] - old_aabb[0]) / 2.
+        c_new, h_new = (new_aabb[1] + new_aabb[0]) / 2., (new_aabb[1] - new_aabb[0]) / 2.
+
+        def to_old(v, axes):
+            """normalised coordinates of the new box along ``axes`` -> normalised coordinates of the old box"""
+            ax = torch.as_tensor(axes, device=dev)
+            return (v * h_new[ax] + c_new[ax] - c_old[ax]) / h_old[ax]
+
+        def lines(R, tables):                                   # [3, R, M]: table k runs along axis k
+            v = param_vertices(R, 1, is_forest=True, device=dev).view(1, R, 1).expand(3, R, 1)
+            x = torch.stack([to_old(v[k], [k]) for k in range(3)], 0)
+            return param_interpolate(tables, x, R, False).contiguous()
+
+        def planes(R, tables):                                  # [3, R, R, M]: table k spans the two axes other than k
+            v = param_vertices(R, 2, is_forest=True, device=dev)
+            x = torch.stack([to_old(v, [a for a in range(3) if a != k]) for k in range(3)], 0)
+            return param_interpolate(tables, x, R, False).contiguous()
+
+        for l, (R, kind) in enumerate(zip(m.level_res, m.level_types)):
+            kind = LoDType(int(kind))
+            if kind == LoDType.Dense:
+                x = to_old(param_vertices(R, 3, False, device=dev, dtype=torch.float), [0, 1, 2])
+                vol = self.get_level_param(l, 'vol')
+                self.set_level_param(l, value=param_interpolate(vol.unsqueeze(0), x.unsqueeze(0), R, False).squeeze(0).contiguous())
+            elif kind == LoDType.VectorMatrix:
+                self.set_level_param(l, 'vec', value=lines(R, self.get_level_param(l, 'vec')))
+                self.set_level_param(l, 'mat', value=planes(R, self.get_level_param(l, 'mat')))
+            elif kind in (LoDType.NPlaneMul, LoDType.NPlaneSum):
+                self.set_level_param(l, value=planes(R, self.get_level_param(l, 'plane')))
+            elif kind in (LoDType.CP, LoDType.CPfast):
+                self.set_level_param(l, value=lines(R, self.get_level_param(l, 'line')))
+            elif kind == LoDType.Hash:
+                raise RuntimeError("LoDType==hash does not support spatial operations.")
+            else:
+                raise RuntimeError(f"Invalid lod_type={kind}")

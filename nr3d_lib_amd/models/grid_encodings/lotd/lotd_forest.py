@@ -155,24 +155,19 @@ class LoTDForestEncoding(nn.Module):
         return nablas / 2.
 
     # ---- parameter access: whole levels (and Dense 'vol' views), for any selection of blocks ----------------------------
-    def _level_view(self, l: int, op: str = None):
-        m = self.lod_meta
-        assert 0 <= l < m.n_levels
-        sl = slice(m.level_offsets[l], m.level_offsets[l] + m.level_n_params[l])
-        if op is None:
-            return sl, (m.level_sizes[l], m.level_n_feats[l])
-        if op == 'vol' and LoDType(int(m.level_types[l])) == LoDType.Dense:
-            return sl, (*m.level_res_multidim[l], m.level_n_feats[l])
-        raise NotImplementedError(f"nr3d_lib_amd: get/set_level_param(op={op!r}) -- only whole levels and Dense 'vol' views")
+    def _level_view(self, l: int, op: str = None, dim: int = None):
+        from .lotd_helpers import level_param_index_shape
+        index, shape = level_param_index_shape(self.lod_meta, l, op, dim)
+        return index[0], shape
 
     def get_level_param(self, bid: Union[int, List[int], slice, torch.Tensor], l: int, op: str = None, dim: int = None, grad=False):
-        sl, shape = self._level_view(l, op)
+        sl, shape = self._level_view(l, op, dim)
         src = self.forest_flattened_params.grad if grad else self.forest_flattened_params
         sel = src.data[bid, sl] if not grad else src[bid, sl]
         return sel.view(*sel.shape[:-1], *shape)
 
     def set_level_param(self, bid, l: int, op: str = None, dim: int = None, value: torch.Tensor = None):
-        sl, shape = self._level_view(l, op)
+        sl, shape = self._level_view(l, op, dim)
         with torch.no_grad():
             tgt = self.forest_flattened_params[bid, sl]
             self.forest_flattened_params[bid, sl] = value.contiguous().reshape(*tgt.shape[:-1], prod(shape))

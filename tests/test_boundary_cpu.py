@@ -128,8 +128,10 @@ def test_lotd_encoding_module_cpu_surface():
         p = e.get_level_param(l)
         assert p.shape[1] == cfg["lod_n_feats"][l] and 0.5 * b < float(p.detach().abs().max()) <= b * (1 + 1e-6)
     assert tuple(e.get_level_param(0, "vol").shape) == (8, 8, 8, 4)
-    with pytest.raises(NotImplementedError):
-        e.get_level_param(1, "vec", 0)
+    assert tuple(e.get_level_param(1, "vec", 0).shape) == (cfg["lod_res"][1], cfg["lod_n_feats"][1])   # a VM level's x lines
+    e.set_level_param(1, "vec", 0, value=torch.full((cfg["lod_res"][1], cfg["lod_n_feats"][1]), 0.5))
+    assert float(e.get_level_param(1, "vec", 0).detach().min()) == 0.5 and float(e.get_level_param(1, "vec", 1).detach().abs().max()) <= 1e-2
+    e.set_level_param(1, "vec", 0, value=e.get_level_param(1, "vec", 1).detach().clone())
     e.set_level_param(4, value=torch.ones(512, 4))
     assert float(e.get_level_param(4).detach().min()) == 1.0 and float(e.get_level_param(3).detach().abs().max()) <= 1e-4
     e2 = LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float, param_init_cfg={"type": "normal", "std": 0.1})
