@@ -3,9 +3,10 @@ feeds them to the HIP-backed ``LoTD`` functions.
 
 Counterpart of nr3d_lib/models/grid_encodings/lotd/lotd_encoding.py:37-326 for the hot path: constructor keywords,
 ``forward`` / ``forward_dydx`` / ``backward_dydx`` on inputs in [-1, 1] (mapped to [0, 1]; nablas halved), the four
-``param_init_cfg`` schemes, ``max_level`` / ``window`` masking, ``get_level_param`` / ``set_level_param`` for whole
-levels (and Dense volumes), ``inference_param``, and the ``lotd_cfg`` extra state.  Out of scope here (they raise):
-``space_cfg`` (space classes), ``anneal_cfg`` (annealer), sub-level ``op`` slices of VM/CP tables, ``rescale_volume``."""
+``param_init_cfg`` schemes, ``max_level`` / ``window`` masking driven by ``anneal_cfg`` (``MultiresAnnealer``,
+``set_anneal_iter``), ``space_cfg`` of type 'aabb' / 'unbounded', ``get_level_param`` / ``set_level_param`` on whole levels
+and on every line / plane / volume table (``lotd_helpers``), ``rescale_volume``, ``inference_param``, and the ``lotd_cfg``
+extra state.  Not provided (raise): the batched block space of ``space_cfg``, ``init_param_from_net``."""
 from math import sqrt
 from typing import Any, Optional, Tuple
 
@@ -30,12 +31,18 @@ class LoTDEncoding(nn.Module):
                  param_init_cfg={'type': 'uniform_to_type', 'bound': 1.0e-4}, clip_level_grad_ema_factor: float = 0,
                  dtype=torch.half, device=None) -> None:
         super().__init__()
-        if space_cfg is not None:
-            raise NotImplementedError("nr3d_lib_amd: `space_cfg` needs the space classes (not on the hot path); "
-                                      "pass a ready `space` module or normalise the inputs yourself")
-        if anneal_cfg is not None:
-            raise NotImplementedError("nr3d_lib_amd: the multires annealer is not on the hot path; set "
-                                      "`max_level` / `window` on the module instead")
+        if space is None and space_cfg is not None:              # lotd_encoding.py:59-75
+            space_cfg = dict(space_cfg)
+            space_type = space_cfg.pop('type').lower()
+            if space_type == 'aabb':
+                from nr3d_lib_amd.models.spatial import AABBSpace
+                space = AABBSpace(**space_cfg)
+            elif space_type in ('unbounded', 'none'):
+                space = None
+            elif space_type == 'batched':
+                raise NotImplementedError("nr3d_lib_amd: the batched block space is not provided; pass a `space` module")
+            else:
+                raise RuntimeError(f"Invalid space_type={space_type}")
         assert (lotd_cfg is not None) != (lotd_auto_compute_cfg is not None), \
             "Please specify one and only one of `lotd_cfg` and `lotd_auto_compute_cfg`"
         self.dtype = _as_dtype(dtype)
@@ -52,7 +59,11 @@ class LoTDEncoding(nn.Module):
         # parameters are always stored in fp32; `dtype` only decides what the kernels are fed
         self.flattened_params = nn.Parameter(torch.zeros(self.lotd.n_params, device=device, dtype=torch.float))
         self.init_param_random()
+        # coarse-to-fine schedule of `max_level` / `window` (lotd_encoding.py:99-103); set_anneal_iter() advances it
         self.annealer = None
+        if anneal_cfg is not None:
+            from ..multires_annealer import MultiresAnnealer
+            self.annealer = MultiresAnnealer(self.lotd.level_n_feats, **anneal_cfg, dtype=self.dtype, device=device)
         self.window: Optional[torch.Tensor] = None      # optional soft mask on the output features
         self.max_level: Optional[int] = None            # levels above it are skipped (-1: all of them)
         if clip_level_grad_ema_factor > 0:
