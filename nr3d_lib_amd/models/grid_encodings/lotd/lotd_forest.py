@@ -58,9 +58,6 @@ class LoTDForestEncoding(nn.Module):
                  param_init_cfg={'type': 'uniform_to_type', 'bound': 1.0e-4}, clip_level_grad_ema_factor: float = 0,
                  dtype=torch.half, device=None) -> None:
         super().__init__()
-        if anneal_cfg is not None:
-            raise NotImplementedError("nr3d_lib_amd: the multires annealer is not on the hot path; set "
-                                      "`max_level` / `window` on the module instead")
         self.dtype = dtype if isinstance(dtype, torch.dtype) else getattr(torch, str(dtype).replace('torch.', ''))
         self.loss_scale = 128.0 if self.dtype == torch.float16 else 1.0
         self.space = ForestBlockSpace(dtype=torch.float, device=device)           # the valid representing space
@@ -69,7 +66,10 @@ class LoTDForestEncoding(nn.Module):
         self.register_parameter("forest_flattened_params", None)
         self.clip_level_grad_ema_factor = clip_level_grad_ema_factor
         self.param_init_cfg = param_init_cfg
-        self.annealer = None
+        self.annealer = None                      # coarse-to-fine schedule (lotd_forest.py:101-105); set_anneal_iter()
+        if anneal_cfg is not None:
+            from ..multires_annealer import MultiresAnnealer
+            self.annealer = MultiresAnnealer(self.lotd.level_n_feats, **anneal_cfg, dtype=self.dtype, device=device)
         self.window: torch.Tensor = None          # optional soft mask on the output features
         self.max_level: int = None                # levels above it are skipped (-1: all of them)
         if clip_level_grad_ema_factor > 0:
