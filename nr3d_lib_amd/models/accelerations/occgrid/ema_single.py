@@ -28,9 +28,11 @@ def normalized_logistic_density(x: torch.Tensor, inv_s) -> torch.Tensor:
 
 
 def sdf_to_occ_val(sdf: torch.Tensor, *, inv_s: float = None, inv_s_anneal_cfg: dict = None):
-    if inv_s_anneal_cfg is not None:
-        raise NotImplementedError("nr3d_lib_amd: annealed inv_s needs the training-schedule helpers (outside the path); pass inv_s")
-    assert inv_s is not None, "Need config `inv_s`"
+    if inv_s_anneal_cfg is not None:                        # utils.py:63-68: the schedule's value at the configured iteration
+        from nr3d_lib_amd.models.annealers import get_anneal_val
+        inv_s = get_anneal_val(**inv_s_anneal_cfg)
+    else:
+        assert inv_s is not None, "Need config `inv_s`"
     return normalized_logistic_density(sdf, inv_s)
 
 
