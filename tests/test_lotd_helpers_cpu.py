@@ -101,3 +101,37 @@ def test_rescale_volume_matches_reference():
                           space=AABBSpace(aabb=torch.from_numpy(z["old_aabb"])), dtype=torch.float)
     with pytest.raises(RuntimeError, match="does not support spatial operations"):
         hashed.rescale_volume(torch.from_numpy(z["new_aabb"]))
+
+
+def test_vertex_convention_matches_the_encoder(oracle):
+    """The helpers and the encoder agree on where a table's vertices are: a Dense level whose vertex values are a linear
+    function of the vertex positions (param_vertices) encodes exactly that function (trilinear interpolation reproduces
+    it) -- evaluated with the CPU oracle the HIP kernels are tested against -- and still does after rescale_volume has
+    re-gridded the table onto a smaller box."""
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTDEncoding, param_vertices
+    from nr3d_lib_amd.models.spatial import AABBSpace
+    R = 12
+    old = torch.tensor([[-1.0, -2.0, -0.5], [1.0, 2.0, 1.5]])
+    enc = LoTDEncoding(3, lotd_cfg=dict(lod_res=[R], lod_n_feats=[2], lod_types=["Dense"]), space=AABBSpace(aabb=old),
+                       dtype=torch.float)
+    A = torch.tensor([[0.3, -0.2, 0.5], [-0.7, 0.1, 0.25]])
+    b = torch.tensor([0.1, -0.4])
+    field = lambda world: world @ A.t() + b
+    m_ref = oracle.lotd_create_meta(3, [R], [2], ["Dense"])
+
+    def encode(world, aabb):
+        c, h = (aabb[1] + aabb[0]) / 2, (aabb[1] - aabb[0]) / 2
+        u = ((world - c) / h) / 2 + 0.5                        # what LoTDEncoding.forward feeds the kernel
+        y, _ = oracle.lotd_fwd(m_ref, u.numpy().astype(np.float32), enc.flattened_params.detach().numpy())
+        return torch.from_numpy(y)
+
+    def world_of(v, aabb):
+        return v * (aabb[1] - aabb[0]) / 2 + (aabb[1] + aabb[0]) / 2
+    enc.set_level_param(0, 'vol', value=field(world_of(param_vertices(R, 3), old)))
+    g = torch.Generator().manual_seed(1)
+    new = torch.tensor([[-0.6, -1.1, 0.0], [0.7, 1.5, 1.2]])
+    pts = world_of(torch.rand(500, 3, generator=g) * 2 - 1, new)           # inside the new (hence the old) box
+    torch.testing.assert_close(encode(pts, old), field(pts), rtol=0, atol=2e-6)
+    enc.rescale_volume(new)
+    torch.testing.assert_close(enc.get_level_param(0, 'vol').detach(), field(world_of(param_vertices(R, 3), new)), rtol=0, atol=5e-6)
+    torch.testing.assert_close(encode(pts, new), field(pts), rtol=0, atol=5e-6)
