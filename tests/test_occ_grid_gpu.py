@@ -372,3 +372,55 @@ def test_occ_grid_ema_batched_module(oracle, dev):
     other = OccGridEmaBatched(1, 4, occ_thre=0.3, device=dev, init_cfg=dict(mode="constant", constant_value=0.0))
     other.load_state_dict(acc.state_dict())
     assert other.num_batches == 3 and torch.equal(other.occ_grid, acc.occ_grid)
+
+
+def test_batched_accel_end_to_end(oracle, dev):
+    """BatchedBlockSpace.cur_batch__ray_test -> OccGridAccelBatched_{Getter,Ema}.cur_batch__ray_march (the batched HIP
+    marcher) against the oracle marcher on the grids the accelerator holds: pack offsets / indices / depths bit-exact"""
+    from nr3d_lib_amd.models.accelerations.occgrid_accel import OccGridAccelBatched_Ema, OccGridAccelBatched_Getter
+    from nr3d_lib_amd.models.spatial import BatchedBlockSpace
+    torch.manual_seed(3)
+    B, N = 3, 200
+    space = BatchedBlockSpace(aabb=[[-1, -1.5, -1], [1, 1.5, 1]], device=dev)
+    radii = torch.tensor([0.45, 0.7, 0.9], device=dev)
+    field = lambda x, bidx: (x.norm(dim=-1) < radii[bidx]).float()
+    g = torch.Generator().manual_seed(4)
+    rays_o = torch.tensor([0.0, 0.0, -4.0]).expand(B, N, 3).clone().to(dev)
+    rays_d = (torch.randn(B, N, 3, generator=g) * 0.25 + torch.tensor([0, 0, 1.0])).to(dev)
+    rays_d = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    rt = space.cur_batch__ray_test(rays_o, rays_d)
+    assert rt["num_rays"] > 100
+
+    getter = OccGridAccelBatched_Getter(space, resolution=[16, 24, 16], occ_thre=0.5, num_steps=3, num_pts_per_batch=2 ** 15,
+                                        device=dev)
+    getter.set_condition(B, val_query_fn_normalized_x_bi=field)
+    ema = OccGridAccelBatched_Ema(space, num_batches=5, resolution=[16, 24, 16], occ_val_fn_cfg=dict(type="density"), occ_thre=0.5,
+                                  init_cfg=dict(mode='from_net', num_steps=3, num_pts_per_batch=2 ** 15), device=dev)
+    ema.set_condition(5, ins_inds_per_batch=torch.arange(5, device=dev))
+    radii5 = torch.tensor([0.3, 0.45, 0.7, 0.9, 0.2], device=dev)
+    field5 = lambda x, bidx: (x.norm(dim=-1) < radii5[bidx]).float()       # indexed by INSTANCE
+    ema.init(field5)
+    ema.set_condition(B, ins_inds_per_batch=torch.tensor([1, 2, 3], device=dev))      # the same three objects
+    for name, acc in (("getter", getter), ("ema", ema)):
+        grids_b = acc.occ_grid_per_batch
+        assert tuple(grids_b.shape) == (B, 16, 24, 16) and grids_b.dtype == torch.bool and bool(grids_b.any())
+        ret = acc.cur_batch__ray_march(rt["rays_o"], rt["rays_d"], rt["rays_bidx"], near=rt["near"], far=rt["far"],
+                                       step_size=0.02, max_steps=128)
+        roi = np.tile(np.array([-1, -1, -1, 1, 1, 1], np.float32), (B, 1))
+        ref = oracle.ray_marching(rt["rays_o"].cpu().numpy(), rt["rays_d"].cpu().numpy(), rt["near"].cpu().numpy(),
+                                  rt["far"].cpu().numpy(), roi, grids_b.cpu().numpy(), 0, 0.02, 1e10, 0.0, 128, True,
+                                  batch_inds=rt["rays_bidx"].cpu().numpy().astype(np.int32))
+        hit = np.nonzero(ref[0][:, 1])[0]
+        assert ret.num_hit_rays == len(hit) > 0, name
+        assert_equal(ret.ridx_hit, hit, f"{name}/ridx_hit")
+        assert_equal(ret.pack_infos, ref[0][hit].astype(np.int64), f"{name}/pack_infos")
+        assert_equal(ret.depth_samples, ref[1][:, 0], f"{name}/depth_samples")
+        assert_equal(ret.bidx, ref[4].astype(np.int64), f"{name}/bidx")
+        assert_equal(ret.gidx, ref[5].astype(np.int64), f"{name}/gidx")
+        pts, bi = acc.cur_batch__sample_pts_in_occupied(256)
+        assert bool(acc.cur_batch__query_occupancy(pts, bi).all())
+    # the EMA variant keeps learning from the batch's samples
+    ema.train()
+    ema.cur_batch__collect_samples(torch.zeros(4, 3, device=dev), torch.tensor([0, 1, 2, 0], device=dev), torch.ones(4, device=dev))
+    ema.cur_batch__step(16, field5)
+    assert ema.debug_stats()["num_occupied"] > 0
