@@ -4,9 +4,9 @@ feeds them to the HIP-backed ``LoTD`` functions.
 Counterpart of nr3d_lib/models/grid_encodings/lotd/lotd_encoding.py:37-326 for the hot path: constructor keywords,
 ``forward`` / ``forward_dydx`` / ``backward_dydx`` on inputs in [-1, 1] (mapped to [0, 1]; nablas halved), the four
 ``param_init_cfg`` schemes, ``max_level`` / ``window`` masking driven by ``anneal_cfg`` (``MultiresAnnealer``,
-``set_anneal_iter``), ``space_cfg`` of type 'aabb' / 'unbounded', ``get_level_param`` / ``set_level_param`` on whole levels
+``set_anneal_iter``), ``space_cfg`` of type 'aabb' / 'batched' / 'unbounded', ``get_level_param`` / ``set_level_param`` on whole levels
 and on every line / plane / volume table (``lotd_helpers``), ``rescale_volume``, ``inference_param``, and the ``lotd_cfg``
-extra state.  Not provided (raise): the batched block space of ``space_cfg``, ``init_param_from_net``."""
+extra state.  Not provided: ``init_param_from_net``."""
 from math import sqrt
 from typing import Any, Optional, Tuple
 
@@ -40,7 +40,8 @@ class LoTDEncoding(nn.Module):
             elif space_type in ('unbounded', 'none'):
                 space = None
             elif space_type == 'batched':
-                raise NotImplementedError("nr3d_lib_amd: the batched block space is not provided; pass a `space` module")
+                from nr3d_lib_amd.models.spatial import BatchedBlockSpace
+                space = BatchedBlockSpace(**space_cfg)
             else:
                 raise RuntimeError(f"Invalid space_type={space_type}")
         assert (lotd_cfg is not None) != (lotd_auto_compute_cfg is not None), \

@@ -139,8 +139,8 @@ def test_lotd_encoding_module_cpu_surface():
     assert torch.equal(e2.flattened_params, e.flattened_params) and e2.lotd_cfg == cfg
     auto = LoTDEncoding(3, lotd_auto_compute_cfg=dict(type="gen_ngp", num_levels=4), dtype=torch.half)
     assert auto.lotd.n_levels == 4 and auto.inference_param.dtype == torch.half
-    with pytest.raises(NotImplementedError):
-        LoTDEncoding(3, lotd_cfg=cfg, space_cfg=dict(type="batched"))
+    from nr3d_lib_amd.models.spatial import BatchedBlockSpace
+    assert isinstance(LoTDEncoding(3, lotd_cfg=cfg, space_cfg=dict(type="batched", bounding_size=4.0)).space, BatchedBlockSpace)
     an = LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float, anneal_cfg=dict(type="hardmask", stop_it=100, start_level=1))
     an.set_anneal_iter(0)
     assert an.max_level == 1 and an.window is None
