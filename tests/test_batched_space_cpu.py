@@ -56,3 +56,22 @@ def test_getter_accel_grids_sampling_and_query():
         raise SystemExit("expected an assertion")
     except AssertionError as e:
         assert "set_condition" in str(e)
+
+
+def test_get_space_and_dense_octree_helpers():
+    import pytest
+    from nr3d_lib_amd.models.spatial import (AABBSpace, BatchedBlockSpace, ForestBlockSpace, create_dense_grid,
+                                            create_octree_dense, create_octree_root_only, get_space)
+    assert isinstance(get_space("aabb"), AABBSpace) and isinstance(get_space(dict(type="Batched", bounding_size=3.0)), BatchedBlockSpace)
+    assert isinstance(get_space("forest"), ForestBlockSpace) and get_space("none") is None and get_space(None) is None
+    assert get_space(dict(type="batched", bounding_size=3.0)).radius3d.tolist() == [1.5, 1.5, 1.5]
+    with pytest.raises(RuntimeError, match="Invalid space_type"):
+        get_space("sphere")
+    with pytest.raises(NotImplementedError):
+        get_space("aabb_dynamic")
+    g = create_dense_grid(2)
+    assert tuple(g.shape) == (64, 3) and g.dtype == torch.int16 and g[-1].tolist() == [3, 3, 3] and g[1].tolist() == [0, 0, 1]
+    # a full octree: every node has all eight children -- 1 + 8 + 64 bytes of 255 for three levels
+    o = create_octree_dense(3)
+    assert o.dtype == torch.uint8 and o.tolist() == [255] * 73
+    assert create_octree_root_only().tolist() == [255]
