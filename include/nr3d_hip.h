@@ -396,6 +396,24 @@ int nr3d_alpha_to_vw_forward(uint32_t P, uint64_t S, const float *alphas, const 
 int nr3d_alpha_to_vw_backward(uint32_t P, uint64_t S, const float *alphas, const float *weights,
                               const float *grad_weights, const int64_t *pack_infos, float early_stop_eps,
                               float alpha_thre, float *grad_alphas, void *stream);
+/* Fused alpha composite of a packed volume buffer.  No single reference kernel: replaces the renderer's op chain
+ * nr3d_lib/models/fields/nerf/renderer_mixin.py:298-311 = packed_alpha_to_vw (pack_ops_cuda.cu:1735-1793) ->
+ * packed_sum (:798-861) -> packed_div (:1960-2062) -> packed_sum(. * t) -> packed_sum(. * rgb), and its autograd
+ * (pack_ops.py:97-116, :261-283, :293-392; kernel :1795-1848) by one launch each way.
+ *   alphas, t [S]; rgb [S,3] or NULL; ray_index int64 [P] or NULL: per-ray results go to element ray_index[p]
+ *   (rays_inds_hit) of mask / depth [num_rays] / rgb_out [num_rays,3] (caller ZERO-INITs them when ray_index is given).
+ *   vw [S] fully written, bit-identical to nr3d_alpha_to_vw_forward.  depth = sum(vw*t) / (mask + 1e-10) when
+ *   normalize_depth, else sum(vw*t). */
+int nr3d_pack_composite_fwd(uint32_t P, const float *alphas, const float *t, const float *rgb, const int64_t *pack_infos,
+                            const int64_t *ray_index, float early_stop_eps, float alpha_thre, int normalize_depth,
+                            float *vw, float *mask, float *depth, float *rgb_out, void *stream);
+/* backward of the above: g_mask / g_depth [num_rays], g_rgb [num_rays,3], g_vw [S] (each may be NULL = zero);
+ * mask, depth = the forward's outputs.  grad_alphas [S] fully written; grad_t [S], grad_rgb [S,3] optional. */
+int nr3d_pack_composite_bwd(uint32_t P, const float *alphas, const float *vw, const float *t, const float *rgb,
+                            const int64_t *pack_infos, const int64_t *ray_index, float early_stop_eps, float alpha_thre,
+                            int normalize_depth, const float *mask, const float *depth, const float *g_mask,
+                            const float *g_depth, const float *g_rgb, const float *g_vw, float *grad_alphas,
+                            float *grad_t, float *grad_rgb, void *stream);
 /* mark_pack_boundaries_cuda (:2765-2805): boundaries int32 [num]. */
 int nr3d_mark_pack_boundaries(uint64_t num, int dtype, const void *pack_ids, int32_t *boundaries, void *stream);
 

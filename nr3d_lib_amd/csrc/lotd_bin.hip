@@ -663,6 +663,11 @@ __global__ __launch_bounds__(1024) void k_plan_items(uint32_t NB, uint32_t n_blk
 	if (threadIdx.x == 0) item_start[NB] = (uint32_t)carry_s;
 }
 
+void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32_t *tot, uint32_t *rep, uint32_t *item_start,
+                       hipStream_t st) {
+	hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, NB, n_blk, units, tot, rep, item_start);
+}
+
 // where accumulator slot t (= entry el of the bucket, feature f; t = el * G + f) of bucket b lives in dL/dparam;
 // nullptr past the end of the level's (batched) entry space
 template <int G>
@@ -950,6 +955,14 @@ static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batch
 		const uint64_t qb = (uint64_t)(work_units() + plan.bucket_base[plan.n_pseudo]) * kLdsDoubles * 4;
 		l.part_bytes = qb > l.part_bytes ? qb : l.part_bytes;
 	}
+	if (n_batches <= 1 && pair_applies(m)) {       // lotd_pair.hip runs in the same regions
+		uint64_t rb, ob, pb, qb;
+		pair_layout(m, n_chunk, work_units(), rb, ob, pb, qb);
+		l.rec_bytes = rb > l.rec_bytes ? rb : l.rec_bytes;
+		l.offs_bytes = ob > l.offs_bytes ? ob : l.offs_bytes;
+		l.plan_bytes = pb > l.plan_bytes ? pb : l.plan_bytes;
+		l.part_bytes = qb > l.part_bytes ? qb : l.part_bytes;
+	}
 	l.rec_bytes = ((l.rec_bytes + 255) / 256) * 256;
 	l.gt_bytes = (((uint64_t)m->n_encoded_dims * n_chunk * 4 + 255) / 256) * 256;
 	l.total = l.rec_bytes + l.offs_bytes + l.plan_bytes + l.part_bytes + l.gt_bytes;
@@ -1037,6 +1050,9 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	float *partial = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes);
 	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes + lay.part_bytes);
 	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && E > 1);
+	// first-order gradient of an unbatched 3-D Dense/Hash meta with 2-feature pseudo levels: pair records (lotd_pair.hip)
+	const bool use_pair = !second && !forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size &&
+	                      pair_applies(meta);
 
 	for (uint32_t p0 = 0; p0 < N; p0 += nc) {
 		const uint32_t n = (N - p0) < nc ? (N - p0) : nc;
@@ -1050,6 +1066,12 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		if (row_major) {
 			hipLaunchKernelGGL(k_transpose, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, gc, g_sn, g_se, gt);
 			gc = gt; sn = 1; se = (int64_t)n;
+		}
+		if (use_pair) {
+			if (int rc = pair_chunk(meta, md, n, xc, gc, sn, se, min_level, max_level, work_units(), dparam, rec, offs, plan_buf,
+			                        partial, st))
+				return rc;
+			continue;
 		}
 		for (uint32_t cls : kClasses) {
 			BinPlan pl;

@@ -1,0 +1,500 @@
+// nr3d_lib_amd/csrc/lotd_pair.hip -- dL/dparam of 3-D Dense/Hash metas with 2-feature pseudo levels through PAIR records.
+//
+// Same two-stage, atomic-free organisation as lotd_bin.hip (stage A bins the updates of a block of points by table
+// bucket, stage B accumulates a bucket in fp64 LDS and adds the slice to dL/dparam), but the unit that travels through
+// HBM is not one corner update {entry, w_c*g0, w_c*g1} (12 B, 8 per point and level) but one PAIR of corners that land
+// in the same bucket by construction:
+//     Dense: the two corners along the contiguous last dim (entries e, e + 1; buckets are whole rows of the table);
+//     Hash : the two corners along dim 0 (prime 1): hash(x0 + 1, ..) and hash(x0, ..) differ only in the low bits that
+//            x0 -> x0 + 1 flips, so they share the 8192-entry bucket (power-of-two table, resolution <= 8192);
+// written as {idx0 | idx1 << 13 | flags, w_pair, A0, A1} (16 B, 4 per point and level), A_f = g_f * prod of the other
+// two dims' weights.  Stage B applies (1 - w_pair) * A_f to idx0 and w_pair * A_f to idx1.  Per (point, level) 64 B
+// instead of 96 B cross HBM in each direction, half as many records are ranked and staged through LDS, and a record is
+// one aligned 16-byte access everywhere.  Reference kernel replaced: kernel_lod_hashonly_backward_grid
+// (csrc/lotd/include/lotd/lotd_hash_only.h:380-470); the per-corner value g_f * w_c is formed as
+// (g_f * w_other) * w_pair instead of g_f * ((w_x * w_y) * w_z): same real number, <= 2 ulp apart.
+//
+// Coherent inputs (consecutive points in the same cell, e.g. samples along a ray) are merged like in lotd_bin.hip:
+// the lanes of a run are summed into its first lane, which then emits two SINGLE records per pair (flags say which
+// half is valid, weight 1) -- at most as many records as the unmerged lanes would have written.
+#include "lotd_device.h"
+#include <stdlib.h>
+
+#ifndef NR3D_PAIR_BP
+#define NR3D_PAIR_BP 1024            // points (= threads) per stage-A workgroup
+#endif
+
+namespace nr3d {
+namespace lotd {
+
+constexpr int kPBP = NR3D_PAIR_BP;
+constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;      // records per (pseudo level, point block) slot
+constexpr uint32_t kPEpb = 8192;                     // accumulator entries per bucket: 2 features x 8192 x 8 B = 128 KiB
+constexpr int kPAccThreads = 1024;
+constexpr int kPLds = 2 * (int)kPEpb;                // fp64 accumulators per stage-B workgroup
+constexpr int kPMaxLv = 32;                          // pseudo levels per plan
+constexpr uint32_t kPMaxNb = (kPBP < 1024 ? kPBP : 1024) - 1;   // buckets per pseudo level (one scan pass of the block)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct PairPlan {
+	uint32_t qmap[kPMaxLv];             // pseudo level of the meta
+	uint32_t nb[kPMaxLv];               // buckets
+	uint32_t epb[kPMaxLv];              // entries per bucket (Dense: rows per bucket x Rz; Hash: 8192)
+	uint32_t shift[kPMaxLv];            // Dense: log2(rows per bucket); Hash: 13
+	uint32_t bucket_base[kPMaxLv + 1];  // flat index of the level's first bucket
+	uint32_t offs_base[kPMaxLv];        // start of the level's offset table (uint32 units)
+	uint32_t n_blk, n_pseudo;
+};
+
+// -------------------------------------------------------------------------------------------------
+// Stage A
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                   int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                   const float *__restrict__ g, int64_t g_sn, int64_t g_se,
+                                                   u32x4 *__restrict__ rec, uint32_t *__restrict__ offs_g) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[kPCap] records | hist[nb + 1]
+	__shared__ uint32_t scan_lds[kPBP / 64];
+	u32x4 *stage = reinterpret_cast<u32x4 *>(smem);
+	uint32_t *hist = smem + (size_t)kPCap * 4;
+	const uint32_t blk = blockIdx.x, ql = blockIdx.y;
+	const uint32_t q = plan.qmap[ql], nb = plan.nb[ql];
+	const uint32_t level = meta_level_of(md, q);
+	const Lvl L = load_level(md, level);
+	const uint32_t i = blk * kPBP + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
+
+	for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) hist[b] = 0;
+	__syncthreads();
+
+	const bool active = (i < n) && ((int32_t)level <= max_level);
+	uint32_t hdr[4], bkt[4], cell[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+	float A[4][2], wp = 0.0f;
+#pragma unroll
+	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; }
+	if (active) {
+		float xp[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
+		Cell<3> c;
+		locate<3>(xp, L, smooth != 0, c);
+		const float g0 = g[(int64_t)i * g_sn + (int64_t)(q * 2) * g_se];
+		const float g1 = g[(int64_t)i * g_sn + (int64_t)(q * 2 + 1) * g_se];
+		const uint32_t sh = plan.shift[ql], epb = plan.epb[ql];
+		if (L.type == NR3D_LOD_Dense) {
+			wp = c.w[2];
+#pragma unroll
+			for (uint32_t m = 0; m < 4; ++m) {
+				const uint32_t bx = m & 1u, by = m >> 1;
+				const uint32_t row = (c.g[0] + bx) * L.res[1] + (c.g[1] + by);
+				const uint32_t e0 = row * L.res[2] + c.g[2];
+				const uint32_t b = row >> sh;
+				const uint32_t i0 = e0 - b * epb;
+				bkt[m] = b;
+				hdr[m] = i0 | ((i0 + 1u) << 13);
+				const float wo = (bx ? c.w[0] : 1.0f - c.w[0]) * (by ? c.w[1] : 1.0f - c.w[1]);
+				A[m][0] = g0 * wo; A[m][1] = g1 * wo;
+			}
+		} else {
+			wp = c.w[0];
+			const bool pow2 = (L.size & (L.size - 1u)) == 0u;
+#pragma unroll
+			for (uint32_t m = 0; m < 4; ++m) {
+				const uint32_t by = m & 1u, bz = m >> 1;
+				const uint32_t K = ((c.g[1] + by) * kPrimes[1]) ^ ((c.g[2] + bz) * kPrimes[2]);
+				const uint32_t h0 = c.g[0] ^ K, h1 = (c.g[0] + 1u) ^ K;
+				const uint32_t e0 = pow2 ? (h0 & (L.size - 1u)) : (h0 % L.size);
+				const uint32_t e1 = pow2 ? (h1 & (L.size - 1u)) : (h1 % L.size);
+				bkt[m] = e0 >> 13;                         // == e1 >> 13 (plan conditions)
+				hdr[m] = (e0 & 8191u) | ((e1 & 8191u) << 13);
+				const float wo = (by ? c.w[1] : 1.0f - c.w[1]) * (bz ? c.w[2] : 1.0f - c.w[2]);
+				A[m][0] = g0 * wo; A[m][1] = g1 * wo;
+			}
+		}
+#pragma unroll
+		for (int d = 0; d < 3; ++d) cell[d] = c.g[d];
+	}
+
+	// ---- coherent inputs: lanes that continue the previous lane's cell are summed into the head of their run ----
+	bool emit = active, split = false;
+	float Hh[4][2];
+#pragma unroll
+	for (int m = 0; m < 4; ++m) { Hh[m][0] = 0.0f; Hh[m][1] = 0.0f; }
+	{
+		auto prev = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); };
+		bool same = active && lane > 0;
+#pragma unroll
+		for (int d = 0; d < 3; ++d) same = same && (prev(cell[d]) == cell[d]);
+		same = same && (prev((uint32_t)active) != 0u);
+		const unsigned long long cont = __ballot(same);
+		if (__popcll(cont) >= 16) {
+			float lo[4][2], hi[4][2];
+#pragma unroll
+			for (int m = 0; m < 4; ++m)
+#pragma unroll
+				for (int f = 0; f < 2; ++f) { lo[m][f] = (1.0f - wp) * A[m][f]; hi[m][f] = wp * A[m][f]; }
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const unsigned long long need = (1ull << off) - 1ull;
+				const bool take = (lane + off < 64) && (((cont >> (lane + 1)) & need) == need);
+#pragma unroll
+				for (int m = 0; m < 4; ++m)
+#pragma unroll
+					for (int f = 0; f < 2; ++f) {
+						const float tl = __shfl_down(lo[m][f], off, 64), th = __shfl_down(hi[m][f], off, 64);
+						if (take) { lo[m][f] += tl; hi[m][f] += th; }
+					}
+			}
+			const bool head_multi = active && !same && lane < 63 && ((cont >> (lane + 1)) & 1ull);
+			if (same) emit = false;
+			if (head_multi) {
+				split = true;
+#pragma unroll
+				for (int m = 0; m < 4; ++m)
+#pragma unroll
+					for (int f = 0; f < 2; ++f) { A[m][f] = lo[m][f]; Hh[m][f] = hi[m][f]; }
+			}
+		}
+	}
+
+	// ---- rank inside the bucket (split lanes take two consecutive slots per pair) ----
+	uint32_t rank[4] = {0, 0, 0, 0};
+	const uint32_t cnt = emit ? (split ? 2u : 1u) : 0u;
+	if (nb <= 4) {
+		// one to four buckets: every record of the block would hit the same histogram counters -> rank through ballots
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+			const uint32_t bv = emit ? bkt[m] : 0xFFFFFFFFu;
+			unsigned long long todo = __ballot(emit);
+			while (todo) {
+				const int leader = __ffsll((long long)todo) - 1;
+				const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)bv, leader);
+				const bool mine = emit && bv == v;
+				const unsigned long long m1 = __ballot(mine), m2 = __ballot(mine && split);
+				uint32_t first = 0;
+				if ((int)lane == leader) first = atomicAdd(&hist[v], (uint32_t)(__popcll(m1) + __popcll(m2)));
+				first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+				const unsigned long long below = (1ull << lane) - 1ull;
+				if (mine) rank[m] = first + (uint32_t)(__popcll(m1 & below) + __popcll(m2 & below));
+				todo &= ~m1;
+			}
+		}
+	} else if (emit) {
+#pragma unroll
+		for (int m = 0; m < 4; ++m) rank[m] = atomicAdd(&hist[bkt[m]], cnt);
+	}
+	__syncthreads();
+
+	// ---- exclusive scan of the histogram, hist[nb] = total (nb + 1 <= kPBP) ----
+	{
+		const uint32_t b = threadIdx.x;
+		const uint32_t v = (b < nb) ? hist[b] : 0u;
+		uint32_t inc = v;
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) {
+			const uint32_t t = __shfl_up(inc, off, 64);
+			if ((int)lane >= off) inc += t;
+		}
+		if (lane == 63) scan_lds[threadIdx.x >> 6] = inc;
+		__syncthreads();
+		uint32_t wave_off = 0;
+#pragma unroll
+		for (int k = 0; k < kPBP / 64; ++k) { const uint32_t t = scan_lds[k]; if (k < (int)(threadIdx.x >> 6)) wave_off += t; }
+		if (b <= nb) hist[b] = wave_off + inc - v;
+		__syncthreads();
+	}
+
+	// ---- counting sort into the LDS staging area ----
+	if (emit) {
+		const uint32_t wpb = __float_as_uint(wp);
+#pragma unroll
+		for (int m = 0; m < 4; ++m) {
+			const uint32_t pos = hist[bkt[m]] + rank[m];
+			if (!split) {
+				stage[pos] = u32x4{hdr[m] | (3u << 26), wpb, __float_as_uint(A[m][0]), __float_as_uint(A[m][1])};
+			} else {
+				stage[pos] = u32x4{(hdr[m] & 0x1FFFu) | (1u << 26), 0u, __float_as_uint(A[m][0]), __float_as_uint(A[m][1])};
+				stage[pos + 1] = u32x4{(hdr[m] & 0x3FFE000u) | (2u << 26), 0u, __float_as_uint(Hh[m][0]), __float_as_uint(Hh[m][1])};
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- coalesced write-out (written once, read once by stage B: non-temporal) ----
+	const uint32_t total = hist[nb];
+	u32x4 *dst = rec + ((size_t)ql * plan.n_blk + blk) * (size_t)kPCap;
+	for (uint32_t v = threadIdx.x; v < total; v += kPBP) __builtin_nontemporal_store(stage[v], dst + v);
+	uint32_t *ob = offs_g + plan.offs_base[ql];
+	for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
+}
+
+// records per bucket over all point blocks
+__global__ __launch_bounds__(256) void k_pair_totals(PairPlan plan, const uint32_t *__restrict__ offs_g, uint32_t *__restrict__ tot) {
+	const uint32_t fb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (fb >= plan.bucket_base[plan.n_pseudo]) return;
+	uint32_t q = 0;
+	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
+	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)(fb - plan.bucket_base[q]) * plan.n_blk;
+	const uint32_t *ob1 = ob0 + plan.n_blk;
+	uint32_t sum = 0;
+	for (uint32_t blk = lane; blk < plan.n_blk; blk += 64) sum += ob1[blk] - ob0[blk];
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+	if (lane == 0) tot[fb] = sum;
+}
+
+// accumulator slot t (feature-major: t = f * 8192 + el) of bucket b -> element of dL/dparam, nullptr outside the level
+__device__ __forceinline__ float *pair_target(const Lvl &L, uint32_t epb, uint32_t foff0, uint32_t b, uint32_t t,
+                                              float *__restrict__ dparam) {
+	const uint32_t f = t >> 13, el = t & 8191u;
+	const uint64_t entry = (uint64_t)b * epb + el;
+	if (el >= epb || entry >= L.size) return nullptr;
+	return dparam + L.off + (entry * L.F + foff0 + f);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Stage B: one bucket (x replica) -> fp64 LDS accumulation -> slice of dL/dparam
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kPAccThreads) void k_pair_accum(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
+                                                             const u32x4 *__restrict__ rec,
+                                                             const uint32_t *__restrict__ offs_g,
+                                                             const uint32_t *__restrict__ rep_g,
+                                                             const uint32_t *__restrict__ item_start,
+                                                             float *__restrict__ partial, float *__restrict__ dparam) {
+	extern __shared__ __attribute__((aligned(16))) double acc[];      // [2][8192], feature-major
+	const uint32_t NB = plan.bucket_base[plan.n_pseudo];
+	const cu32_t istart = (cu32_t)item_start, irep = (cu32_t)rep_g;
+	if (blockIdx.x >= istart[NB]) return;
+	uint32_t lo = 0, hi = NB;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (istart[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+	const uint32_t fb = lo, R = irep[fb], r = blockIdx.x - istart[fb];
+	uint32_t q = 0;
+	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
+	const uint32_t b = fb - plan.bucket_base[q];
+	const uint32_t qg = plan.qmap[q];
+	const Lvl L = load_level(md, meta_level_of(md, qg));
+	const uint32_t foff0 = meta_cnt_of(md, qg) * 2u, epb = plan.epb[q];
+
+	for (uint32_t t = threadIdx.x; t < (uint32_t)kPLds; t += kPAccThreads) acc[t] = 0.0;
+	__syncthreads();
+
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	constexpr uint32_t n_waves = kPAccThreads / 64;
+	const uint32_t blk_lo = (uint32_t)(((uint64_t)plan.n_blk * r) / R), blk_hi = (uint32_t)(((uint64_t)plan.n_blk * (r + 1)) / R);
+	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)b * plan.n_blk;
+	const uint32_t *ob1 = ob0 + plan.n_blk;
+	const u32x4 *rec_q = rec + (size_t)q * plan.n_blk * (size_t)kPCap;
+	const uint32_t per_wave = (blk_hi - blk_lo + n_waves - 1) / n_waves;
+	const uint32_t w_lo = min(blk_lo + wave * per_wave, blk_hi), w_hi = min(w_lo + per_wave, blk_hi);
+#ifndef NR3D_PAIR_UNROLL
+#define NR3D_PAIR_UNROLL 4
+#endif
+	constexpr int kUnroll = NR3D_PAIR_UNROLL;          // runs in flight per wave
+	for (uint32_t blk0 = w_lo; blk0 < w_hi; blk0 += 64) {
+		const uint32_t mb = blk0 + lane;
+		const uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
+		const uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
+		const uint32_t n_run = min(64u, w_hi - blk0);
+		const u32x4 *rec_b = rec_q + (size_t)blk0 * kPCap;
+		for (uint32_t j0 = 0; j0 < n_run; j0 += kUnroll) {
+			u32x4 rv[kUnroll];
+			uint32_t rs[kUnroll], rn[kUnroll];
+			uint32_t longest = 0;
+			// branch-free loads (lanes past the run re-read its first record and drop it): a load under an `if` makes the
+			// compiler drain all outstanding loads at the join
+			for (uint32_t off = 0; off == 0 || off < longest; off += 64) {
+#pragma unroll
+				for (int u = 0; u < kUnroll; ++u) {
+					if (off == 0) {
+						const uint32_t j = min(j0 + (uint32_t)u, 63u);
+						const uint32_t s_j = __builtin_amdgcn_readlane(s_l, j), e_j = __builtin_amdgcn_readlane(e_l, j);
+						rs[u] = s_j + j * kPCap;
+						rn[u] = (j0 + (uint32_t)u < n_run) ? e_j - s_j : 0u;
+						longest = max(longest, rn[u]);
+					}
+					const uint32_t t = off + lane;
+					rv[u] = __builtin_nontemporal_load(rec_b + (size_t)(rs[u] + (t < rn[u] ? t : 0u)));
+				}
+#pragma unroll
+				for (int u = 0; u < kUnroll; ++u)
+					if (off + lane < rn[u]) {
+						const uint32_t h = rv[u].x, fl = h >> 26;
+						const uint32_t i0 = h & 8191u, i1 = (h >> 13) & 8191u;
+						const float w = __uint_as_float(rv[u].y), a0 = __uint_as_float(rv[u].z), a1 = __uint_as_float(rv[u].w);
+						const bool pair = fl == 3u;
+						const float wl = pair ? 1.0f - w : 1.0f, wh = pair ? w : 1.0f;
+						if (fl & 1u) { atomicAdd(&acc[i0], (double)(wl * a0)); atomicAdd(&acc[kPEpb + i0], (double)(wl * a1)); }
+						if (fl & 2u) { atomicAdd(&acc[i1], (double)(wh * a0)); atomicAdd(&acc[kPEpb + i1], (double)(wh * a1)); }
+					}
+			}
+		}
+	}
+	__syncthreads();
+
+	// flush: the only workgroup of a bucket adds its slice to dL/dparam itself; replicas store fp32 partial tables that
+	// k_pair_reduce adds in replica order (no global atomic anywhere)
+	if (R > 1) {
+		float *mine = partial + (size_t)blockIdx.x * kPLds;
+		for (uint32_t t = threadIdx.x; t < (uint32_t)kPLds; t += kPAccThreads) mine[t] = (float)acc[t];
+		return;
+	}
+	constexpr int kFlush = 8;
+	for (uint32_t tb = threadIdx.x; tb < (uint32_t)kPLds; tb += kPAccThreads * kFlush) {
+		float *p[kFlush];
+		float v[kFlush], old[kFlush];
+#pragma unroll
+		for (int k = 0; k < kFlush; ++k) {
+			const uint32_t t = tb + (uint32_t)k * kPAccThreads;
+			p[k] = (t < (uint32_t)kPLds) ? pair_target(L, epb, foff0, b, t, dparam) : nullptr;
+			v[k] = p[k] ? (float)acc[t] : 0.0f;
+		}
+#pragma unroll
+		for (int k = 0; k < kFlush; ++k) old[k] = p[k] ? *p[k] : 0.0f;
+#pragma unroll
+		for (int k = 0; k < kFlush; ++k) if (p[k]) *p[k] = old[k] + v[k];
+	}
+}
+
+// dL/dparam slice of a replicated bucket += sum of the replicas' partial tables, replica 0 first
+__global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
+                                                              const uint32_t *__restrict__ rep_g,
+                                                              const uint32_t *__restrict__ item_start,
+                                                              const float *__restrict__ partial, float *__restrict__ dparam) {
+	const uint32_t fb = blockIdx.x;
+	const uint32_t R = rep_g[fb];
+	if (R <= 1) return;
+	uint32_t q = 0;
+	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
+	const uint32_t b = fb - plan.bucket_base[q], qg = plan.qmap[q];
+	const Lvl L = load_level(md, meta_level_of(md, qg));
+	const uint32_t foff0 = meta_cnt_of(md, qg) * 2u;
+	const float *part0 = partial + (size_t)item_start[fb] * kPLds;
+	const uint32_t t = blockIdx.y * kPAccThreads + threadIdx.x;
+	float *p = pair_target(L, plan.epb[q], foff0, b, t, dparam);
+	if (!p) return;
+	float sum = 0.0f;
+	uint32_t r0 = 0;
+	for (; r0 + 8 <= R; r0 += 8) {
+		float v[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) v[j] = part0[(size_t)(r0 + j) * kPLds + t];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) sum += v[j];
+	}
+	for (; r0 < R; ++r0) sum += part0[(size_t)r0 * kPLds + t];
+	*p = *p + sum;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Host side
+// -------------------------------------------------------------------------------------------------
+static bool pair_enabled() {
+	static int on = -1;
+	if (on < 0) { const char *e = getenv("NR3D_LOTD_PAIR"); on = e ? (atoi(e) != 0) : 1; }
+	return on != 0;
+}
+
+bool pair_applies(const nr3d_lotd_meta_t *m) {
+	if (!pair_enabled()) return false;
+	if (!m || m->n_dims_to_encode != 3 || m->n_feat_per_pseudo_lvl != 2 || !m->c_hash_only) return false;
+	if (m->n_pseudo_levels > (uint32_t)kPMaxLv) return false;
+	for (uint32_t l = 0; l < m->n_levels; ++l) {
+		const nr3d_lotd_level_t &L = m->levels[l];
+		if (L.type == NR3D_LOD_Dense) {
+			if (L.res[2] > kPEpb) return false;
+			const uint64_t rows = (uint64_t)L.res[0] * L.res[1];
+			uint32_t lg = 0;
+			while ((2ull << lg) * L.res[2] <= kPEpb) ++lg;
+			if (((rows + (1ull << lg) - 1) >> lg) > kPMaxNb) return false;
+		} else if (L.type == NR3D_LOD_Hash) {
+			if (L.size <= kPEpb) continue;
+			if ((L.size & (L.size - 1u)) != 0u || L.res[0] > kPEpb) return false;
+			if ((L.size >> 13) > kPMaxNb) return false;
+		} else {
+			return false;
+		}
+	}
+	return true;
+}
+
+static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_level, int32_t max_level, PairPlan &plan,
+                      uint64_t &offs_words) {
+	plan.n_blk = div_up(n_chunk, kPBP);
+	uint32_t nq = 0;
+	uint64_t base = 0;
+	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
+		const int32_t lv = (int32_t)m->map_levels[q];
+		if (lv < min_level || lv > max_level) continue;
+		const nr3d_lotd_level_t &L = m->levels[lv];
+		uint32_t nb, epb, sh;
+		if (L.type == NR3D_LOD_Dense) {
+			sh = 0;
+			while ((2ull << sh) * L.res[2] <= kPEpb) ++sh;
+			epb = (1u << sh) * L.res[2];
+			nb = (uint32_t)((((uint64_t)L.res[0] * L.res[1]) + (1ull << sh) - 1) >> sh);
+		} else {
+			sh = 13; epb = kPEpb;
+			nb = L.size <= kPEpb ? 1u : (L.size >> 13);
+		}
+		plan.qmap[nq] = q; plan.nb[nq] = nb; plan.epb[nq] = epb; plan.shift[nq] = sh;
+		plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
+		plan.offs_base[nq] = (uint32_t)base;
+		base += (uint64_t)(nb + 1) * plan.n_blk;
+		++nq;
+	}
+	plan.n_pseudo = nq;
+	plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
+	offs_words = base;
+}
+
+// workspace needs of the pair path for a chunk of n_chunk points (regions as in lotd_bin.hip's layout)
+void pair_layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t units, uint64_t &rec_bytes, uint64_t &offs_bytes,
+                 uint64_t &plan_bytes, uint64_t &part_bytes) {
+	PairPlan plan;
+	uint64_t ow;
+	pair_plan(m, n_chunk, 0, 0x7fffffff, plan, ow);
+	const uint32_t NB = plan.bucket_base[plan.n_pseudo];
+	rec_bytes = (uint64_t)plan.n_pseudo * plan.n_blk * kPCap * 16;
+	offs_bytes = ((ow * 4 + 255) / 256) * 256;
+	plan_bytes = (((uint64_t)NB * 3 + 4) * 4 + 255) / 256 * 256;
+	part_bytes = (uint64_t)(units + NB) * kPLds * 4;
+}
+
+void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32_t *tot, uint32_t *rep, uint32_t *item_start,
+                       hipStream_t st);      // lotd_bin.hip
+
+// one chunk of points: dL_dy given feature-major or with any strides (g_sn, g_se)
+int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,
+               int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, void *rec,
+               uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st) {
+	PairPlan pl;
+	uint64_t ow;
+	pair_plan(meta, n, min_level, max_level, pl, ow);
+	if (pl.n_pseudo == 0) return 0;
+	uint32_t nb_max = 0;
+	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
+	const uint32_t NB = pl.bucket_base[pl.n_pseudo];
+	uint32_t *tot = plan_buf, *rep = plan_buf + NB, *item_start = plan_buf + 2 * (size_t)NB;
+	const size_t bin_lds = (size_t)kPCap * 16 + (size_t)(kPMaxNb + 2) * 4;
+	static bool attr_set_dev[64] = {};
+	int dev_id = 0;
+	NR3D_HIP_CHECK(hipGetDevice(&dev_id));
+	if (!attr_set_dev[dev_id & 63]) {
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum, hipFuncAttributeMaxDynamicSharedMemorySize, kPLds * 8));
+		attr_set_dev[dev_id & 63] = true;
+	}
+	hipLaunchKernelGGL(k_pair_bin, dim3(pl.n_blk, pl.n_pseudo), dim3(kPBP), (size_t)kPCap * 16 + (size_t)(nb_max + 1) * 4, st, pl,
+	                   md, n, max_level, meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs);
+	hipLaunchKernelGGL(k_pair_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
+	launch_plan_items(NB, pl.n_blk, units, tot, rep, item_start, st);
+	hipLaunchKernelGGL(k_pair_accum, dim3(units + NB), dim3(kPAccThreads), kPLds * 8, st, pl, md, (const u32x4 *)rec, offs, rep,
+	                   item_start, partial, dparam);
+	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, kPLds / kPAccThreads), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
+	                   dparam);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+}  // namespace lotd
+}  // namespace nr3d

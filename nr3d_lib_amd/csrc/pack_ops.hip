@@ -603,6 +603,229 @@ static inline bool lane_per_pack(uint32_t P) {
 	return P >= (uint32_t)thr;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused alpha composite of a packed volume buffer: the renderer's chain
+//     vw = packed_alpha_to_vw(alpha); mask = packed_sum(vw); depth = packed_sum(packed_div(vw, mask + 1e-10) * t)
+//     (or packed_sum(vw * t)); rgb = packed_sum(vw[:, None] * rgb)
+// (nr3d_lib/models/fields/nerf/renderer_mixin.py:298-311; kernels pack_ops_cuda.cu:1735-1848, :798-861, :1960-2062) as
+// ONE pass per ray forward and ONE backward, instead of 5 + 5 launches with [S]-sized temporaries in between.
+// The transmittance recurrence keeps the reference's serial order (its rounding decides which samples are cut by
+// early_stop_eps), so vw is bit-identical to packed_alpha_to_vw; the per-ray sums are taken as sum(vw * x) and the
+// normalised depth as sum(vw * t) / (mask + 1e-10) -- the chain's values up to summation order (<= 1e-5 rel).
+// `ray_index` (optional) scatters the per-ray results into [num_rays] outputs (rays_inds_hit) and gathers their grads.
+// ------------------------------------------------------------------------------------------------
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_fwd(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ ts,
+                                                          const float *__restrict__ rgb, const int64_t *__restrict__ pi,
+                                                          const int64_t *__restrict__ ray_index, float eps, float thre, int normalize,
+                                                          float *__restrict__ vw, float *__restrict__ mask,
+                                                          float *__restrict__ depth, float *__restrict__ rgb_out) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	float T = 1.0f;
+	bool stopped = false;
+	float s = 0.0f, dt = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		const bool mine = (uint32_t)k.lane < n;
+		const size_t i = (size_t)k.begin + base + k.lane;
+		const float a_mine = mine ? alphas[i] : 0.0f;
+		const float t_mine = mine ? ts[i] : 0.0f;
+		float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+		if (RGB && mine) { r0 = rgb[3 * i]; r1 = rgb[3 * i + 1]; r2 = rgb[3 * i + 2]; }
+		float w_mine = 0.0f;
+		if (!stopped) {
+			for (uint32_t j = 0; j < n; ++j) {
+				if (T < eps) { stopped = true; break; }
+				const float a = shfl_t<float>(a_mine, (int)j);
+				if (a <= thre) continue;
+				if ((uint32_t)k.lane == j) w_mine = a * T;
+				T *= (1.0f - a);
+			}
+		}
+		if (mine) vw[i] = w_mine;
+		s += w_mine; dt += w_mine * t_mine;
+		if (RGB) { c0 += w_mine * r0; c1 += w_mine * r1; c2 += w_mine * r2; }
+	}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		s += shfl_xor_t<float>(s, off); dt += shfl_xor_t<float>(dt, off);
+		if (RGB) { c0 += shfl_xor_t<float>(c0, off); c1 += shfl_xor_t<float>(c1, off); c2 += shfl_xor_t<float>(c2, off); }
+	}
+	if (k.lane == 0) {
+		const size_t o = ray_index ? (size_t)ray_index[k.p] : (size_t)k.p;
+		mask[o] = s;
+		depth[o] = normalize ? dt / (s + 1e-10f) : dt;
+		if (RGB) { rgb_out[3 * o] = c0; rgb_out[3 * o + 1] = c1; rgb_out[3 * o + 2] = c2; }
+	}
+}
+
+// dL/dvw of one sample from the per-ray output grads (and the optional direct grad on vw)
+struct CompGrad { float gm, cd, dref, g0, g1, g2; };
+__device__ __forceinline__ float comp_gw(const CompGrad &c, float t, float r0, float r1, float r2, float gv) {
+	float g = __fmaf_rn(c.cd, t - c.dref, c.gm);
+	g = __fmaf_rn(c.g0, r0, g); g = __fmaf_rn(c.g1, r1, g); g = __fmaf_rn(c.g2, r2, g);
+	return g + gv;
+}
+__device__ __forceinline__ CompGrad comp_grad(size_t o, int normalize, const float *mask, const float *depth, const float *g_mask,
+                                              const float *g_depth, const float *g_rgb) {
+	CompGrad c;
+	const float gd = g_depth ? g_depth[o] : 0.0f;
+	c.gm = g_mask ? g_mask[o] : 0.0f;
+	c.cd = normalize ? gd / (mask[o] + 1e-10f) : gd;
+	c.dref = normalize ? depth[o] : 0.0f;
+	c.g0 = g_rgb ? g_rgb[3 * o] : 0.0f; c.g1 = g_rgb ? g_rgb[3 * o + 1] : 0.0f; c.g2 = g_rgb ? g_rgb[3 * o + 2] : 0.0f;
+	return c;
+}
+
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_bwd(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ vw,
+                                                          const float *__restrict__ ts, const float *__restrict__ rgb,
+                                                          const int64_t *__restrict__ pi, const int64_t *__restrict__ ray_index,
+                                                          float eps, float thre, int normalize, const float *__restrict__ mask,
+                                                          const float *__restrict__ depth, const float *__restrict__ g_mask,
+                                                          const float *__restrict__ g_depth, const float *__restrict__ g_rgb,
+                                                          const float *__restrict__ g_vw, float *__restrict__ grad_alphas,
+                                                          float *__restrict__ grad_t, float *__restrict__ grad_rgb) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	const size_t o = ray_index ? (size_t)ray_index[k.p] : (size_t)k.p;
+	const CompGrad cg = comp_grad(o, normalize, mask, depth, g_mask, g_depth, g_rgb);
+	// accum = sum_j gw_j * w_j, serial fma chain like packed_alpha_to_vw_backward (the sweep below divides by
+	// max(1 - alpha, 1e-10), which amplifies any difference in accum)
+	float accum = 0.0f;
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		const bool mine = (uint32_t)k.lane < n;
+		const size_t i = (size_t)k.begin + base + k.lane;
+		const float w_mine = mine ? vw[i] : 0.0f;
+		float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+		if (RGB && mine) { r0 = rgb[3 * i]; r1 = rgb[3 * i + 1]; r2 = rgb[3 * i + 2]; }
+		const float gw_mine = mine ? comp_gw(cg, ts[i], r0, r1, r2, g_vw ? g_vw[i] : 0.0f) : 0.0f;
+		for (uint32_t j = 0; j < n; ++j)
+			accum = __fmaf_rn(shfl_t<float>(gw_mine, (int)j), shfl_t<float>(w_mine, (int)j), accum);
+	}
+	float T = 1.0f;
+	bool stopped = false;
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		const bool mine = (uint32_t)k.lane < n;
+		const size_t i = (size_t)k.begin + base + k.lane;
+		const float a_mine = mine ? alphas[i] : 0.0f;
+		const float w_mine = mine ? vw[i] : 0.0f;
+		float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+		if (RGB && mine) { r0 = rgb[3 * i]; r1 = rgb[3 * i + 1]; r2 = rgb[3 * i + 2]; }
+		const float gw_mine = mine ? comp_gw(cg, ts[i], r0, r1, r2, g_vw ? g_vw[i] : 0.0f) : 0.0f;
+		float ga_mine = 0.0f;
+		if (!stopped) {
+			for (uint32_t j = 0; j < n; ++j) {
+				if (T < eps) { stopped = true; break; }
+				const float a = shfl_t<float>(a_mine, (int)j);
+				if (a < thre) continue;
+				if ((uint32_t)k.lane == j) ga_mine = __fmaf_rn(gw_mine, T, -accum) / fmaxf(1.0f - a, 1e-10f);
+				accum = __fmaf_rn(-shfl_t<float>(gw_mine, (int)j), shfl_t<float>(w_mine, (int)j), accum);
+				T *= (1.0f - a);
+			}
+		}
+		if (mine) {
+			grad_alphas[i] = ga_mine;
+			if (grad_t) grad_t[i] = cg.cd * w_mine;
+			if (RGB && grad_rgb) { grad_rgb[3 * i] = w_mine * cg.g0; grad_rgb[3 * i + 1] = w_mine * cg.g1; grad_rgb[3 * i + 2] = w_mine * cg.g2; }
+		}
+	}
+}
+
+// lane-per-pack forms (many rays): every lane walks its own ray serially, 4 samples per memory request
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_fwd_lpp(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ ts,
+                                                              const float *__restrict__ rgb, const int64_t *__restrict__ pi,
+                                                              const int64_t *__restrict__ ray_index, float eps, float thre,
+                                                              int normalize, float *__restrict__ vw, float *__restrict__ mask,
+                                                              float *__restrict__ depth, float *__restrict__ rgb_out) {
+	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	if (p >= P) return;
+	const size_t begin = (size_t)pi[2 * (size_t)p];
+	const uint32_t len = (uint32_t)pi[2 * (size_t)p + 1];
+	float T = 1.0f, s = 0.0f, dt = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+	bool stopped = false;
+	auto one = [&](float a, float t, float r0, float r1, float r2) -> float {
+		float w = 0.0f;
+		if (!stopped) {
+			if (T < eps) stopped = true;
+			else if (!(a <= thre)) { w = a * T; T *= (1.0f - a); }
+		}
+		s += w; dt += w * t;
+		if (RGB) { c0 += w * r0; c1 += w * r1; c2 += w * r2; }
+		return w;
+	};
+	const uint32_t n4 = len / 4;
+	auto ld4 = [&](const float *base, size_t at) { return *reinterpret_cast<const F4u *>(base + at); };
+	if (n4) {
+		F4u a_n = ld4(alphas, begin), t_n = ld4(ts, begin), q0 = {}, q1 = {}, q2 = {};
+		if (RGB) { q0 = ld4(rgb, 3 * begin); q1 = ld4(rgb, 3 * begin + 4); q2 = ld4(rgb, 3 * begin + 8); }
+		for (uint32_t c = 0; c < n4; ++c) {
+			const F4u a4 = a_n, t4 = t_n, x0 = q0, x1 = q1, x2 = q2;
+			const size_t nx = begin + 4 * (size_t)min(c + 1, n4 - 1);
+			a_n = ld4(alphas, nx); t_n = ld4(ts, nx);
+			if (RGB) { q0 = ld4(rgb, 3 * nx); q1 = ld4(rgb, 3 * nx + 4); q2 = ld4(rgb, 3 * nx + 8); }
+			const float cc[12] = {x0.v[0], x0.v[1], x0.v[2], x0.v[3], x1.v[0], x1.v[1], x1.v[2], x1.v[3], x2.v[0], x2.v[1], x2.v[2], x2.v[3]};
+			F4u w4;
+#pragma unroll
+			for (int u = 0; u < 4; ++u) w4.v[u] = one(a4.v[u], t4.v[u], cc[3 * u], cc[3 * u + 1], cc[3 * u + 2]);
+			*reinterpret_cast<F4u *>(vw + begin + 4 * (size_t)c) = w4;
+		}
+	}
+	for (uint32_t j = 4 * n4; j < len; ++j) {
+		const size_t i = begin + j;
+		vw[i] = one(alphas[i], ts[i], RGB ? rgb[3 * i] : 0.0f, RGB ? rgb[3 * i + 1] : 0.0f, RGB ? rgb[3 * i + 2] : 0.0f);
+	}
+	const size_t o = ray_index ? (size_t)ray_index[p] : (size_t)p;
+	mask[o] = s;
+	depth[o] = normalize ? dt / (s + 1e-10f) : dt;
+	if (RGB) { rgb_out[3 * o] = c0; rgb_out[3 * o + 1] = c1; rgb_out[3 * o + 2] = c2; }
+}
+
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_bwd_lpp(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ vw,
+                                                              const float *__restrict__ ts, const float *__restrict__ rgb,
+                                                              const int64_t *__restrict__ pi, const int64_t *__restrict__ ray_index,
+                                                              float eps, float thre, int normalize, const float *__restrict__ mask,
+                                                              const float *__restrict__ depth, const float *__restrict__ g_mask,
+                                                              const float *__restrict__ g_depth, const float *__restrict__ g_rgb,
+                                                              const float *__restrict__ g_vw, float *__restrict__ grad_alphas,
+                                                              float *__restrict__ grad_t, float *__restrict__ grad_rgb) {
+	const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+	if (p >= P) return;
+	const size_t begin = (size_t)pi[2 * (size_t)p];
+	const uint32_t len = (uint32_t)pi[2 * (size_t)p + 1];
+	const size_t o = ray_index ? (size_t)ray_index[p] : (size_t)p;
+	const CompGrad cg = comp_grad(o, normalize, mask, depth, g_mask, g_depth, g_rgb);
+	auto gw_at = [&](size_t i) {
+		return comp_gw(cg, ts[i], RGB ? rgb[3 * i] : 0.0f, RGB ? rgb[3 * i + 1] : 0.0f, RGB ? rgb[3 * i + 2] : 0.0f, g_vw ? g_vw[i] : 0.0f);
+	};
+	float accum = 0.0f;
+	for (uint32_t j = 0; j < len; ++j) accum = __fmaf_rn(gw_at(begin + j), vw[begin + j], accum);
+	float T = 1.0f;
+	bool stopped = false;
+	for (uint32_t j = 0; j < len; ++j) {
+		const size_t i = begin + j;
+		const float a = alphas[i], w = vw[i];
+		float ga = 0.0f;
+		if (!stopped) {
+			if (T < eps) stopped = true;
+			else if (!(a < thre)) {
+				const float gw = gw_at(i);
+				ga = __fmaf_rn(gw, T, -accum) / fmaxf(1.0f - a, 1e-10f);
+				accum = __fmaf_rn(-gw, w, accum);
+				T *= (1.0f - a);
+			}
+		}
+		grad_alphas[i] = ga;
+		if (grad_t) grad_t[i] = cg.cd * w;
+		if (RGB && grad_rgb) { grad_rgb[3 * i] = w * cg.g0; grad_rgb[3 * i + 1] = w * cg.g1; grad_rgb[3 * i + 2] = w * cg.g2; }
+	}
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_boundaries(uint64_t n, const T *__restrict__ ids, int32_t *__restrict__ b) {
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -818,6 +1041,42 @@ extern "C" int nr3d_alpha_to_vw_backward(uint32_t P, uint64_t S, const float *al
 	else
 		hipLaunchKernelGGL(pk::k_alpha_bwd, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, alphas, weights,
 		                   grad_weights, pack_infos, early_stop_eps, alpha_thre, grad_alphas);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_pack_composite_fwd(uint32_t P, const float *alphas, const float *t, const float *rgb,
+                                       const int64_t *pack_infos, const int64_t *ray_index, float early_stop_eps,
+                                       float alpha_thre, int normalize_depth, float *vw, float *mask, float *depth,
+                                       float *rgb_out, void *stream) {
+	if (P == 0) return 0;
+	NR3D_CHECK(alphas && t && pack_infos && vw && mask && depth, "pack_composite_fwd: NULL pointer");
+	NR3D_CHECK(!rgb || rgb_out, "pack_composite_fwd: rgb given without rgb_out");
+	const bool lpp = pk::lane_per_pack(P);
+	const dim3 g = lpp ? dim3(div_up(P, pk::kBlock)) : pk::grid_for(P), b(pk::kBlock);
+#define NR3D_COMP_FWD(K) hipLaunchKernelGGL(K, g, b, 0, (hipStream_t)stream, P, alphas, t, rgb, pack_infos, ray_index, \
+	early_stop_eps, alpha_thre, normalize_depth, vw, mask, depth, rgb_out)
+	if (lpp) { if (rgb) NR3D_COMP_FWD(pk::k_composite_fwd_lpp<true>); else NR3D_COMP_FWD(pk::k_composite_fwd_lpp<false>); }
+	else     { if (rgb) NR3D_COMP_FWD(pk::k_composite_fwd<true>); else NR3D_COMP_FWD(pk::k_composite_fwd<false>); }
+#undef NR3D_COMP_FWD
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_pack_composite_bwd(uint32_t P, const float *alphas, const float *vw, const float *t, const float *rgb,
+                                       const int64_t *pack_infos, const int64_t *ray_index, float early_stop_eps,
+                                       float alpha_thre, int normalize_depth, const float *mask, const float *depth,
+                                       const float *g_mask, const float *g_depth, const float *g_rgb, const float *g_vw,
+                                       float *grad_alphas, float *grad_t, float *grad_rgb, void *stream) {
+	if (P == 0) return 0;
+	NR3D_CHECK(alphas && vw && t && pack_infos && mask && depth && grad_alphas, "pack_composite_bwd: NULL pointer");
+	const bool lpp = pk::lane_per_pack(P);
+	const dim3 g = lpp ? dim3(div_up(P, pk::kBlock)) : pk::grid_for(P), b(pk::kBlock);
+#define NR3D_COMP_BWD(K) hipLaunchKernelGGL(K, g, b, 0, (hipStream_t)stream, P, alphas, vw, t, rgb, pack_infos, ray_index, \
+	early_stop_eps, alpha_thre, normalize_depth, mask, depth, g_mask, g_depth, g_rgb, g_vw, grad_alphas, grad_t, grad_rgb)
+	if (lpp) { if (rgb) NR3D_COMP_BWD(pk::k_composite_bwd_lpp<true>); else NR3D_COMP_BWD(pk::k_composite_bwd_lpp<false>); }
+	else     { if (rgb) NR3D_COMP_BWD(pk::k_composite_bwd<true>); else NR3D_COMP_BWD(pk::k_composite_bwd<false>); }
+#undef NR3D_COMP_BWD
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

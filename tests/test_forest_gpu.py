@@ -89,12 +89,12 @@ def test_fwd_bwd_and_second_order(oracle, dev, forest, continuity, case):
     assert_close(y2, y_ref, name="y(no grad)")
     dx, dp = _lotd.lod_bwd(metas, gt, xt, pt, j, bit, need_input_grad=True, need_param_grad=True)
     assert_close(dx, oracle.lotd_bwd_dx(m_ref, g, j_ref), name="dL_dx")
-    assert_close(dp, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, accum_double=True), name="dL_dparam")
+    assert_close(dp, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, accum_double=True), name="dL_dparam", levels=m_ref)
     ddy, dp2, dx2 = _lotd.lod_bwd_bwd_input(metas, vt, gt, xt, pt, j, bit, need_dLdinput_ddLdoutput=True,
                                             need_dLdinput_dparams=True, need_dLdinput_dinput=True)
     assert_close(ddy, oracle.lotd_bwd_bwd_ddLdy(m_ref, v, j_ref), name="dL_ddLdy")
     assert_close(dp2, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, dL_ddLdx=v, accum_double=True),
-                 name="d(dLdx)/dparam")
+                 name="d(dLdx)/dparam", levels=m_ref)
     assert_close(dx2, oracle.lotd_forest_bwd_bwd_dx(m_ref, fo, v, g, x, p, block_inds=bi), name="d(dLdx)/dx")
 
 
@@ -106,7 +106,7 @@ def test_block_modes_skips_max_level_and_errors(oracle, dev):
     y, j = _lotd.lod_fwd(metas, xt, pt, None, None, n, None, True)
     assert_close(y, y_ref, name="batched y")
     dp = _lotd.lod_bwd(metas, gt, xt, pt, j, None, None, n, None, False, True)[1]
-    assert_close(dp, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, batch_data_size=n, accum_double=True), name="batched dparam")
+    assert_close(dp, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, batch_data_size=n, accum_double=True), name="batched dparam", levels=m_ref)
     # block_offsets: tables stored in another order
     rng = np.random.default_rng(0)
     perm = rng.permutation(T)
@@ -117,7 +117,7 @@ def test_block_modes_skips_max_level_and_errors(oracle, dev):
     assert_close(_lotd.lod_fwd(metas, xt, st, bit, ot)[0], y_ref2, name="block_offsets y")
     dp_o = _lotd.lod_bwd(metas, gt, xt, st, None, bit, ot, None, None, False, True)[1]
     assert_close(dp_o, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, shuffled, block_inds=bi, block_offsets=offs, accum_double=True),
-                 name="block_offsets dparam")
+                 name="block_offsets dparam", levels=m_ref)
     # skipped points and max_level
     bi2 = bi.copy(); bi2[::4] = -1
     b2t = torch.from_numpy(bi2).to(dev)
@@ -126,7 +126,7 @@ def test_block_modes_skips_max_level_and_errors(oracle, dev):
     assert_close(ys, yr, name="skips y"); assert_close(js.reshape(jr.shape), jr, name="skips dy_dx")
     assert float(ys[::4].abs().max()) == 0 and float(ys[:, 4:].abs().max()) == 0
     dps = _lotd.lod_bwd(metas, gt, xt, pt, None, b2t, None, None, 1, False, True)[1]
-    assert_close(dps, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi2, max_level=1, accum_double=True), name="skips dparam")
+    assert_close(dps, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi2, max_level=1, accum_double=True), name="skips dparam", levels=m_ref)
     y0, j0 = _lotd.lod_fwd(metas, xt, pt, bit, None, None, -1, True)
     assert float(y0.abs().max()) == 0 and float(j0.abs().max()) == 0
     # errors: unsupported level type, 2-D meta, wrong block_offsets size, missing octree, forest grid index
@@ -266,10 +266,10 @@ def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest):
         for binned in (True, False):
             _lotd.USE_BINNED_DPARAM = binned
             dp = _lotd.lod_bwd(metas, gt, xt, pt, None, bit, need_input_grad=False, need_param_grad=True)[1]
-            assert_close(dp, ref1, name=f"dL_dparam binned={binned}")
+            assert_close(dp, ref1, name=f"dL_dparam binned={binned}", levels=m_ref)
             dp2 = _lotd.lod_bwd_bwd_input(metas, vt, gt, xt, pt, j, bit, need_dLdinput_ddLdoutput=False,
                                           need_dLdinput_dparams=True, need_dLdinput_dinput=False)[1]
-            assert_close(dp2, ref2, name=f"d(dLdx)/dparam binned={binned}")
+            assert_close(dp2, ref2, name=f"d(dLdx)/dparam binned={binned}", levels=m_ref)
     finally:
         _lotd.USE_BINNED_DPARAM = True
     # ray-like coherent points (the run-merging of stage A) inside one block, then crossing into its neighbour
@@ -279,7 +279,7 @@ def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest):
     gs = g[:4096]
     dpc = _lotd.lod_bwd(metas, torch.from_numpy(gs).to(dev), torch.from_numpy(xs).to(dev), pt, None, torch.from_numpy(bs).to(dev),
                         need_input_grad=False, need_param_grad=True)[1]
-    assert_close(dpc, oracle.lotd_forest_bwd_dparam(m_ref, fo, gs, xs, p, block_inds=bs, accum_double=True), name="coherent dparam")
+    assert_close(dpc, oracle.lotd_forest_bwd_dparam(m_ref, fo, gs, xs, p, block_inds=bs, accum_double=True), name="coherent dparam", levels=m_ref)
 
 
 def test_forest_accel_end_to_end(oracle, dev):
@@ -363,8 +363,8 @@ def test_forest_dparam_multi_pass_chunking(oracle, dev, hiplib):
     hiplib.nr3d_lotd_set_dparam_chunk_log2(12)                   # 4096-point chunks -> 5 passes
     try:
         dp = _lotd.lod_bwd(metas, gt, xt, pt, None, bit, need_input_grad=False, need_param_grad=True)[1]
-        assert_close(dp, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, accum_double=True), name="chunked dparam")
+        assert_close(dp, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, accum_double=True), name="chunked dparam", levels=m_ref)
         dpb = _lotd.lod_bwd(metas, gt, xt, pt, None, None, None, 2000, None, False, True)[1]
-        assert_close(dpb, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, batch_data_size=2000, accum_double=True), name="chunked batched dparam")
+        assert_close(dpb, oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, batch_data_size=2000, accum_double=True), name="chunked batched dparam", levels=m_ref)
     finally:
         hiplib.nr3d_lotd_set_dparam_chunk_log2(0)

@@ -49,12 +49,12 @@ def test_bwd(oracle, dev, case):
     _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
     dx, dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)
     assert_close(dx, oracle.lotd_bwd_dx(m_ref, g, j_ref), name="dL_dx")
-    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam")
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam", levels=m_ref)
     # strided dL_dy (e.g. a transposed view) must be honoured
     dx2, dp2 = _lotd.lod_bwd(m, gt.t().contiguous().t(), xt, pt, j.contiguous(), need_input_grad=True,
                              need_param_grad=True)
     assert_close(dx2, dx.cpu().numpy(), name="dL_dx strided")
-    assert_close(dp2, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam strided")
+    assert_close(dp2, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam strided", levels=m_ref)
     none_dx, none_dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=False)
     assert none_dx is None and none_dp is None
 
@@ -67,7 +67,7 @@ def test_bwd_bwd_input(oracle, dev, case):
     ddy, dp, dx = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, j, need_dLdinput_ddLdoutput=True,
                                           need_dLdinput_dparams=True, need_dLdinput_dinput=True)
     assert_close(ddy, oracle.lotd_bwd_bwd_ddLdy(m_ref, v, j_ref), name="dL_ddLdy")
-    assert_close(dp, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="d(dLdx)/dparam")
+    assert_close(dp, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="d(dLdx)/dparam", levels=m_ref)
     assert_close(dx, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="d(dLdx)/dx")
 
 
@@ -105,15 +105,15 @@ def test_dparam_atomic_and_binned_paths_agree(oracle, dev, case):
                                                 need_dLdinput_dparams=True, need_dLdinput_dinput=False)
         finally:
             _lotd.USE_BINNED_DPARAM = True
-        assert_close(dp, ref1, name=f"dL_dparam binned={binned}")
-        assert_close(dp2, ref2, name=f"2nd dparam binned={binned}")
+        assert_close(dp, ref1, name=f"dL_dparam binned={binned}", levels=m_ref)
+        assert_close(dp2, ref2, name=f"2nd dparam binned={binned}", levels=m_ref)
         # max_level restricts the scatter to the coarse levels
         _lotd.USE_BINNED_DPARAM = binned
         try:
             _, dp3 = _lotd.lod_bwd(m, gt, xt, pt, None, max_level=0, need_input_grad=False, need_param_grad=True)
         finally:
             _lotd.USE_BINNED_DPARAM = True
-        assert_close(dp3, oracle.lotd_bwd_dparam(m_ref, g, x, p, max_level=0, accum_double=True), name="max_level=0")
+        assert_close(dp3, oracle.lotd_bwd_dparam(m_ref, g, x, p, max_level=0, accum_double=True), name="max_level=0", levels=m_ref)
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "mixed", "dense_2d", "nplane"])
@@ -140,8 +140,8 @@ def test_dparam_level_buckets(oracle, dev, case):
             _lotd.USE_BINNED_DPARAM = True
         assert_equal(dx1, dx0.cpu().numpy(), name="dL_dx")
         ref = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
-        assert_close(dp1, ref, name=f"bucketed dL_dparam binned={binned}")
-        assert_close(dp1, dp0.cpu().numpy(), rel=1e-6 if binned else 1e-5, name="bucketed vs one-call dL_dparam")
+        assert_close(dp1, ref, name=f"bucketed dL_dparam binned={binned}", levels=m_ref)
+        assert_close(dp1, dp0.cpu().numpy(), rel=1e-6 if binned else 1e-5, name="bucketed vs one-call dL_dparam", levels=m_ref)
         assert [k for k, *_ in seen] == list(range(len(buckets)))
         for (k, ptr, numel, snap), (lo, hi) in zip(seen, buckets):
             a, b = m.level_offsets[lo], m.level_offsets[hi + 1]
@@ -190,16 +190,16 @@ def test_batched_and_max_level(oracle, dev, case):
         if "batch_inds" in kw_ref:
             assert float(y[bit < 0].abs().max()) == 0.0
         _, dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=True, **kw)
-        assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw_ref), name="dL_dparam")
+        assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw_ref), name="dL_dparam", levels=m_ref)
         _lotd.USE_BINNED_DPARAM = False               # the hardware-atomic scatter on the same batched call
         try:
             _, dp_a = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=True, **kw)
         finally:
             _lotd.USE_BINNED_DPARAM = True
-        assert_close(dp_a, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw_ref), name="dL_dparam (atomic)")
+        assert_close(dp_a, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw_ref), name="dL_dparam (atomic)", levels=m_ref)
         _, dp2, dx2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, j, need_dLdinput_ddLdoutput=False,
                                               need_dLdinput_dparams=True, need_dLdinput_dinput=True, **kw)
-        assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True, **kw_ref), name="2nd dparam")
+        assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True, **kw_ref), name="2nd dparam", levels=m_ref)
         assert_close(dx2, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p, **kw_ref), name="2nd dx")
     # max_level <= -1: all-zero outputs of the documented shapes (lotd_torch_api.cu:294-297)
     y, j = _lotd.lod_fwd(m, xt, pt, max_level=-1, need_input_grad=True)
@@ -216,7 +216,7 @@ def test_generic_kernel_agrees_with_dense_hash_kernel(oracle, dev):
     assert_close(y, y_ref, name="y generic")
     assert_close(j, j_ref, name="dy_dx generic")
     _, dp = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=False, need_param_grad=True)
-    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dparam generic")
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dparam generic", levels=m_ref)
 
 
 def test_half_params_and_inputs(oracle, dev):
@@ -375,9 +375,9 @@ def test_dparam_multi_pass_chunking(oracle, dev, hiplib, case):
                                             need_dLdinput_dparams=True, need_dLdinput_dinput=False)
     finally:
         hiplib.nr3d_lotd_set_dparam_chunk_log2(0)
-    assert_close(dp, ref1, name="dL_dparam (fused, chunked)")
-    assert_close(dp_b, ref1, name="dL_dparam (chunked)")
-    assert_close(dp2, ref2, name="2nd-order dparam (chunked)")
+    assert_close(dp, ref1, name="dL_dparam (fused, chunked)", levels=m_ref)
+    assert_close(dp_b, ref1, name="dL_dparam (chunked)", levels=m_ref)
+    assert_close(dp2, ref2, name="2nd-order dparam (chunked)", levels=m_ref)
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "mixed", "nplane"])
@@ -398,10 +398,10 @@ def test_dparam_coherent_points(oracle, dev, case):
     v = rng.standard_normal((x.shape[0], 3)).astype(np.float32)
     T = lambda a: torch.from_numpy(a).to(dev)
     _, dp = _lotd.lod_bwd(m, T(g), T(x), T(p), None, need_input_grad=False, need_param_grad=True)
-    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam (coherent)")
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam (coherent)", levels=m_ref)
     _, dp2, _ = _lotd.lod_bwd_bwd_input(m, T(v), T(g), T(x), T(p), None, need_dLdinput_ddLdoutput=False,
                                         need_dLdinput_dparams=True, need_dLdinput_dinput=False)
-    assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="2nd-order dparam (coherent)")
+    assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="2nd-order dparam (coherent)", levels=m_ref)
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "mixed"])
@@ -417,7 +417,7 @@ def test_params_at_odd_alignment(oracle, dev, case):
     assert_close(y, y_ref, name="y")
     assert_close(j, j_ref, name="dy_dx")
     _, dp = _lotd.lod_bwd(m, gt, xt, p_odd, j, need_input_grad=False, need_param_grad=True)
-    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam")
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam", levels=m_ref)
     _, _, dx2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, p_odd, j, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=False,
                                         need_dLdinput_dinput=True)
     assert_close(dx2, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="2nd-order dx")
