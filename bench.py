@@ -30,41 +30,53 @@ N_POINTS_LOG2 = 20
 
 
 def algorithmic_bytes_per_point(L, F, D=3, C=8):
-    """element-granular bytes (no cache credit, no sector over-fetch), SURVEY.md section 8(d), per kernel:
-    fwd      : x 4D + corner gathers L*C*F*4 + y L*F*4 + stored Jacobian L*F*D*4
-    bwd_dx   : dL_dy L*F*4 + Jacobian L*F*D*4 + dL_dx 4D
-    bwd_dparam: x 4D + dL_dy L*F*4 + scatter as read-modify-write 2*L*C*F*4"""
+    """element-granular bytes per point (no cache credit, no sector over-fetch), exactly SURVEY.md section 8(d):
+    fwd = 4D + L*C*F*4 + L*F*4                                                   (x, corner gathers, y)         = 1164 B (C2)
+    bwd = 4D + L*F*4 + L*C*F*4 + 2*L*C*F*4 + 4D   (x, dL_dy, gather for dL/dx, scatter as RMW, dL_dx)          = 3224 B (C2)
+    ("fused, no dy_dx round trip"; this build stores the Jacobian in the forward and streams it in the backward instead
+    of re-gathering, 2*L*F*D*4 = 768 B/pt of real traffic that the model does not credit)"""
     E = L * F
-    d = dict(fwd=4 * D + L * C * F * 4 + E * 4 + E * D * 4,
-             bwd_dx=E * 4 + E * D * 4 + 4 * D,
-             bwd_dparam=4 * D + E * 4 + 2 * L * C * F * 4)
-    d["bwd"] = d.pop("bwd_dx") + d.pop("bwd_dparam")     # one lod_bwd call computes both, as the reference's does
-    return d
+    return dict(fwd=4 * D + L * C * F * 4 + E * 4,
+                bwd=4 * D + E * 4 + L * C * F * 4 + 2 * L * C * F * 4 + 4 * D)
 
 
-# kernels behind each timed op (names as rocprofv3 prints them, template arguments stripped)
-OP_KERNELS = {"fwd": ["k_fwd<3, 2, true, true>"],
-              "bwd": ["k_contract_dx_rowmajor<3>", "k_bin<3, 2, false, 8, true>", "k_accum<3, 2>"]}
+def kernel_algorithmic_bytes(kernel, n_levels_served, F=2, D=3, C=8):
+    """section 8(d)'s per-level figures restricted to what ONE launch of `kernel` processes, per point"""
+    Ls = n_levels_served
+    if kernel in ("lotd_fwd", "lotd_fwd_lds"):          # x + corner gathers + y of the levels it serves
+        return 4 * D + Ls * C * F * 4 + Ls * F * 4
+    if kernel == "lotd_contract_dx":                    # dL_dy + the stored Jacobian (8(d)'s reference-faithful variant) + dL_dx
+        return Ls * F * 4 + Ls * F * D * 4 + 4 * D
+    if kernel in ("lotd_bin", "lotd_accum"):            # x + dL_dy ... scatter as read-modify-write, half to each stage
+        return (4 * D + Ls * F * 4 + 2 * Ls * C * F * 4) // 2
+    raise KeyError(kernel)
 
 
-def pmc_traffic_bytes(op):
-    """HBM-side bytes per launch of the kernels behind `op`, from the committed rocprofv3 PMC passes
+# timers of include/nr3d_hip.h (NR3D_PROF_*) -> kernel names as rocprofv3 prints them (the default configuration)
+PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true>", "lotd_fwd_lds": "k_fwd_lds<true>",
+                "lotd_contract_dx": "k_contract_dx_rowmajor<3>", "lotd_bin": "k_pair_bin<1024>",
+                "lotd_accum": "k_pair_accum<4, true>"}
+LIVE_TIMER = "lotd_fwd"      # the dominant kernel: timed inside the timed region (2 events per step); the rest in an extra pass
+OP_TIMERS = {"fwd": ["lotd_fwd_lds", "lotd_fwd"], "bwd": ["lotd_contract_dx", "lotd_bin", "lotd_accum"]}
+
+
+def pmc_traffic_bytes(kernels, launches=None):
+    """HBM-side bytes per step of the named kernels (rocprofv3 names), from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, written by tools/gpu_profile.sh <tag> pmc on an MI355X; FETCH_SIZE and WRITE_SIZE are
-    KiB per dispatch).  Correction per MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts 64 B per 128-B request, so
-    it is doubled -- calibrated here on k_transpose, which reads exactly 128 MiB and reports 65 552 KiB; WRITE_SIZE
-    needs none (k_transpose writes 128 MiB and reports 131 072 KiB).  None when the file is absent."""
+    KiB per dispatch, `launches` = dispatches per step).  Correction per MI355X_MICROARCH.md: on gfx950 FETCH_SIZE
+    counts 64 B per 128-B request, so it is doubled -- calibrated on k_transpose, which reads exactly 128 MiB and reports
+    65 552 KiB; WRITE_SIZE needs none (k_transpose writes 128 MiB and reports 131 072 KiB).  None when a kernel is absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     data = json.load(open(path))
-    total, found = 0.0, 0
-    for want in OP_KERNELS[op]:
-        for name, ctr in data.items():
-            if name.endswith("::" + want) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-                total += (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
-                found += 1
-                break
-    return int(total) if found == len(OP_KERNELS[op]) else None
+    total = 0.0
+    for want in kernels:
+        hit = [ctr for name, ctr in data.items() if name.endswith("::" + want) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr]
+        if not hit:
+            return None
+        total += (2.0 * hit[0]["FETCH_SIZE"] + hit[0]["WRITE_SIZE"]) * 1024.0 * (launches or {}).get(want, 1)
+    return int(total)
 
 
 def cpu_baseline(cfg, n_sample_log2=17, min_seconds=10.0):
@@ -91,47 +103,132 @@ def cpu_baseline(cfg, n_sample_log2=17, min_seconds=10.0):
                        f"({el:.1f} s of OpenMP CPU work)")
 
 
-def march_composite_rate(dev, iters=20, side=64):
-    """BASELINE configs[2] as an extra figure: occ 128^3 march + alpha composite fwd+bwd, side^2 rays
-    (side = 64: the 4096 rays of configs[2] -- 64 waves, bound by the longest ray's serial march;
-     side = 512: enough rays to fill the chip, the throughput regime of configs[4])"""
-    from nr3d_lib_amd.bindings import _occ_grid, _pack_ops
+def _c3_scene(side):
+    """configs[2]'s scene: occ 128^3 = rand > 0.5 (seed 7), side^2 pinhole rays from distance 4 looking at the
+    origin, near / far from the ray-box test with [-1, 1]^3, step 2 sqrt(3) / 512, <= 512 samples per ray"""
     g = torch.Generator(device="cpu").manual_seed(7)
-    grid = (torch.rand(128, 128, 128, generator=g) > 0.5).to(dev)
+    grid = torch.rand(128, 128, 128, generator=g) > 0.5
     n = side * side
     u = torch.linspace(-0.4, 0.4, side)
     uu, vv = torch.meshgrid(u, u, indexing="ij")
     d = torch.stack([uu.flatten(), vv.flatten(), torch.ones(n)], 1)
-    d = (d / d.norm(dim=1, keepdim=True)).to(dev)
-    o = torch.tensor([0.0, 0.0, -4.0]).repeat(n, 1).to(dev)
+    d = d / d.norm(dim=1, keepdim=True)
+    o = torch.tensor([0.0, 0.0, -4.0]).repeat(n, 1)
     t1, t2 = (-1 - o) / d, (1 - o) / d
     near = torch.minimum(t1, t2).amax(1).clamp_min(0).contiguous()
     far = torch.maximum(t1, t2).amin(1).contiguous()
     far = torch.where(far > near, far, near).contiguous()
-    roi = torch.tensor([-1., -1, -1, 1, 1, 1], device=dev)
-    step = 2 * 3 ** 0.5 / 512
+    return grid, o, d, near, far, torch.tensor([-1., -1, -1, 1, 1, 1]), 2 * 3 ** 0.5 / 512
+
+
+def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
+    """BASELINE configs[2]: occ 128^3 march + alpha composite forward AND backward, side^2 rays
+    (side = 64: the 4096 rays of configs[2] -- 64 waves, bound by the longest ray's serial march;
+     side = 512: enough rays to fill the chip, the throughput regime of configs[4]).
+    One iteration = ray march (count + emit) -> alpha = 1 - exp(-sigma * delta) -> fused composite (vw, mask, normalised
+    depth, rgb) -> its backward for random upstream gradients (dL/dalpha, dL/dt, dL/drgb).
+    Roofline (SURVEY 8d byte model, element-granular): march = 32 B/ray (o, d, near, far) + 8 B/ray packed_info +
+    16 B/sample emitted (t0, t1, ridx, gidx) + 1 B per grid probe (probes counted by the oracle's marcher on the host);
+    composite fwd = per sample alpha 4 + t 4 + rgb 12 read + vw 4 written, per ray pack_infos 16 + index 8 + 20 out;
+    composite bwd = per sample alpha 4 + vw 4 + t 4 + rgb 12 read + dalpha 4 + dt 4 + drgb 12 written, per ray 16 + 8 +
+    28 in.  At 4096 rays the whole op moves ~20 MB = 2.5 us at peak: it is launch / latency bound (absolute us matter);
+    the fraction is information only, as SURVEY 8(d) says."""
+    from nr3d_lib_amd import _hip as H
+    from nr3d_lib_amd.bindings import _occ_grid, _pack_ops
+    grid_c, o_c, d_c, near_c, far_c, roi_c, step = _c3_scene(side)
+    grid, o, d, near, far, roi = (t.to(dev) for t in (grid_c, o_c, d_c, near_c, far_c, roi_c))
+    n = side * side
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    state = {}
 
     def one():
         pi, ts, te, ridx, gidx = _occ_grid.ray_marching(o, d, near, far, roi, grid, _occ_grid.ContractionType.AABB,
                                                         step, 1e10, 0.0, 512, True)
+        S = ts.shape[0]
+        if "sigma" not in state:       # per-sample inputs of the composite: fixed scene => fixed S
+            state["sigma"] = (10.0 * torch.rand(S, generator=gen)).to(dev)
+            state["rgb"] = torch.rand(S, 3, generator=gen).to(dev)
+            state["g"] = [torch.randn(n, generator=gen).to(dev), torch.randn(n, generator=gen).to(dev),
+                          torch.randn(n, 3, generator=gen).to(dev)]
+            state["hit"] = torch.arange(n, device=dev)
+        tmid = ts.squeeze(-1)
+        alpha = 1 - torch.exp(-state["sigma"] * (te - ts).squeeze(-1))
         pil = pi.long()
-        delta = (te - ts).squeeze(-1)
-        alpha = (1 - torch.exp(-10.0 * delta)).contiguous()
-        w = _pack_ops.packed_alpha_to_vw_forward(alpha, pil, 1e-4, 0.0, False)[0]
-        acc = _pack_ops.packed_sum(w, pil)
-        depth = _pack_ops.packed_sum((w * ts.squeeze(-1)).contiguous(), pil)
-        ga = _pack_ops.packed_alpha_to_vw_backward(w, torch.ones_like(w), alpha, pil, 1e-4, 0.0)
-        return ts.shape[0], acc, depth, ga
-    for _ in range(3):               # the caching allocator reaches its steady state (two live output sets)
+        # the two launches behind graphics.pack_ops.packed_composite and its autograd backward, called directly (at 4096
+        # rays the op is launch bound: no autograd graph bookkeeping inside the timed loop)
+        vw, mask, depth, rgb = _pack_ops.packed_composite_forward(alpha, tmid, state["rgb"], pil, state["hit"], n, 1e-4, 0.0, True)
+        ga, gt, gc = _pack_ops.packed_composite_backward(alpha, vw, tmid, state["rgb"], pil, state["hit"], 1e-4, 0.0, True,
+                                                         mask, depth, state["g"][0], state["g"][1], state["g"][2], None)
+        return S, mask, ga
+    for _ in range(3):               # the caching allocator reaches its steady state
         S = one()[0]
+    names = ("march", "composite_fwd", "composite_bwd")
+    for k in names:
+        H.prof_read(k)
+    H.prof_enable(*names)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
         one()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
-    return dict(workload=f"occ 128^3 march + alpha composite fwd+bwd, {n} rays x <= 512 samples", samples=int(S),
-                ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4))
+    H.prof_enable()
+    kus = {}
+    for k in names:
+        tot, cnt = H.prof_read(k)
+        kus[k] = tot / iters * 1e3                       # us per iteration (march: count + emit intervals)
+    out = dict(workload=f"configs[2]: occ 128^3 march + fused alpha composite fwd+bwd, {n} rays x <= 512 samples",
+               samples=int(S), ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4),
+               kernel_us_per_iter={k: round(v, 2) for k, v in kus.items()},
+               launches_per_iter="march 2 (count + emit) + scan 3, composite 1 + 1")
+    if cpu_seconds > 0:
+        # the oracle's marcher counts the grid probes of the byte model, and is the CPU baseline next to the chain
+        import oracle
+        args_np = [t.numpy() for t in (o_c, d_c, near_c, far_c, roi_c)] + [grid_c.numpy()]
+        pi_r, ts_r, te_r, ridx_r, gidx_r, probes = oracle.ray_marching(*args_np, 0, step, 1e10, 0.0, 512, True, return_probes=True)
+        S_r = ts_r.shape[0]
+        b_march = 32 * n + 8 * n + 16 * S_r + probes
+        b_fwd = 24 * S_r + 44 * n
+        b_bwd = 44 * S_r + 52 * n
+        total_b = b_march + b_fwd + b_bwd
+        kern_s = sum(kus.values()) * 1e-6
+        out["roofline"] = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBPS, algorithmic_bytes=int(total_b), grid_probes=int(probes),
+                               achieved=round(total_b / kern_s / 1e9, 2), frac=round(total_b / kern_s / 1e9 / HBM_PEAK_GBPS, 5),
+                               achieved_wall=round(total_b / (ms * 1e-3) / 1e9, 2),
+                               per_kernel={k: dict(us=round(kus[k], 2), algorithmic_bytes=int(bb),
+                                                   achieved=round(bb / (kus[k] * 1e-6) / 1e9, 2))
+                                           for k, bb in zip(names, (b_march, b_fwd, b_bwd))},
+                               note="launch / latency bound at this size (SURVEY 8d): fraction for information")
+        rng = np.random.default_rng(8)
+        sigma = (10.0 * rng.random(S_r)).astype(np.float32)
+        rgb = rng.random((S_r, 3), dtype=np.float32)
+        gm, gd, gc = (rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32),
+                      rng.standard_normal((n, 3)).astype(np.float32))
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            pi_r, ts_r, te_r, ridx_r, gidx_r = oracle.ray_marching(*args_np, 0, step, 1e10, 0.0, 512, True)
+            pil = pi_r.astype(np.int64)
+            tt = ts_r[:, 0]
+            alpha = (1 - np.exp(-sigma * (te_r - ts_r)[:, 0])).astype(np.float32)
+            vw = oracle.packed_alpha_to_vw_forward(alpha, pil, 1e-4, 0.0, False)[0]
+            mask = oracle.packed_sum(vw, pil)
+            wn = oracle.packed_binary("div", vw, (mask + np.float32(1e-10)).astype(np.float32), pil)
+            depth = oracle.packed_sum(wn * tt, pil)
+            col = oracle.packed_sum(vw[:, None] * rgb, pil)
+            cnt = pil[:, 1]
+            rep = lambda a: np.repeat(a, cnt, axis=0)
+            s_ = mask + np.float32(1e-10)
+            gw = rep(gm) + rep(gd / s_) * tt - rep(gd * depth / s_) + (rep(gc) * rgb).sum(1)
+            ga = oracle.packed_alpha_to_vw_backward(vw, gw.astype(np.float32), alpha, pil, 1e-4, 0.0)
+            g_t, g_c = rep(gd / s_) * vw, rep(gc) * vw[:, None]
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= cpu_seconds or reps >= 1000:
+                break
+        out["cpu_baseline"] = dict(value=round(reps * n / el / 1e6, 4), unit="Mrays/s", cores=os.cpu_count(), kind="port",
+                                   sample=f"{reps} x {n} rays: the oracle's marcher (C, OpenMP) + the pack-op chain "
+                                          f"(alpha_to_vw, packed_sum x3, packed_div; numpy glue) fwd+bwd, {el:.1f} s of CPU work")
+    return out
 
 
 def _full_loop_setup(dev, side=512, shift=0.0):
@@ -384,6 +481,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra figures (used when profiling the timed loop)")
     ap.add_argument("--log2-points", type=int, default=N_POINTS_LOG2)
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="no in-library HIP-event timers inside the timed region (A/B of their cost; roofline from an extra pass)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -464,10 +563,18 @@ def main():
             reduce_mode[0] = min(trial, key=trial.get)        # identical on every rank (decided on the all-reduced times)
             reduce_trial.update({k: round(v, 4) for k, v in trial.items()})
 
+    from nr3d_lib_amd import _hip as H
     for _ in range(args.warmup):
         step(False)
     if dist is not None:
         dist.barrier()
+    # The dominant kernel (the forward gather kernel) is bracketed by a HIP-event pair on its launch stream INSIDE the timed
+    # region (nr3d_prof_enable, include/nr3d_hip.h): `roofline.achieved` comes from these intervals.  Timing every kernel
+    # of the step that way costs ~2 % of the step (12 events), so the other kernels are timed on extra, untimed steps.
+    live_timers = not args.no_kernel_timers
+    for k in PROF_KERNELS:
+        H.prof_read(k)
+    H.prof_enable(*([LIVE_TIMER] if live_timers else []))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -476,6 +583,22 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    H.prof_enable()
+    live = H.prof_read(LIVE_TIMER) if live_timers else (0.0, 0)
+    H.prof_enable(*PROF_KERNELS)
+    n_extra = 5
+    for _ in range(n_extra):
+        step(False)
+    torch.cuda.synchronize()
+    H.prof_enable()
+    kernel_us, kernel_launches = {}, {}
+    for k in PROF_KERNELS:
+        ms, n = H.prof_read(k)
+        if n:
+            kernel_us[k] = ms / n * 1e3
+            kernel_launches[k] = n / n_extra
+    if live[1]:
+        kernel_us[LIVE_TIMER] = live[0] / live[1] * 1e3           # the live figure replaces the extra-pass one
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -503,9 +626,23 @@ def main():
 
     if rank == 0:
         kms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
-        bpp = algorithmic_bytes_per_point(meta.n_levels, 2)
-        dom = max(kms, key=kms.get)
-        achieved = bpp[dom] * N / (kms[dom] * 1e-3) / 1e9
+        L_all = meta.n_levels
+        bpp = algorithmic_bytes_per_point(L_all, 2)
+        # dominant kernel = largest time per step; levels it serves: the LDS-staged levels belong to k_fwd_lds
+        per_step_us = {k: kernel_us[k] * kernel_launches[k] for k in kernel_us}
+        dom = max(per_step_us, key=per_step_us.get)
+        n_lds = int(round(kernel_launches.get("lotd_fwd_lds", 0)))
+        served = {"lotd_fwd": L_all - n_lds, "lotd_fwd_lds": 1, "lotd_contract_dx": L_all, "lotd_bin": L_all, "lotd_accum": L_all}
+        per_kernel = {}
+        for k, us in kernel_us.items():
+            kb = kernel_algorithmic_bytes(k, served[k])
+            ach = kb * N / (us * 1e-6) / 1e9
+            per_kernel[PROF_KERNELS[k]] = {"avg_us": round(us, 2), "launches_per_step": round(kernel_launches[k], 2),
+                                           "algorithmic_bytes_per_point": kb, "achieved": round(ach, 1),
+                                           "frac": round(ach / HBM_PEAK_GBPS, 4)}
+        dom_name = PROF_KERNELS[dom]
+        launches = {PROF_KERNELS[k]: int(round(v)) for k, v in kernel_launches.items()}
+        at_default_size = args.log2_points == N_POINTS_LOG2
         out = {
             "metric": "Mpoints/s LoTD fwd+bwd (16-lvl hash) + Mrays/s march+composite, 1 & 8 GPU",
             "value": round(world * N * args.steps / elapsed / 1e6, 3),
@@ -517,24 +654,34 @@ def main():
             "config": {"workload": "configs[1]: 16-level Hash LoTD (gen_ngp_cfg: T=2^19, F=2, 6 Dense + 10 Hash), "
                                    f"2^{args.log2_points} points/GPU, fwd(+dy/dx) + dL/dx + dL/dparam, fp32",
                        "points_per_gpu": N, "n_params": meta.n_params,
-                       "parallelism": (f"dp{world} (points sharded; RCCL all-reduce of dL/dparam, {reduce_mode[0]}"
+                       "parallelism": (f"dp{world}: one process per GPU, RCCL world size {dist.get_world_size()} "
+                                       f"(points sharded; all-reduce of dL/dparam, {reduce_mode[0]}"
                                        + (f"; untimed trial ms/step {reduce_trial}" if reduce_trial else "")
                                        + "; kernel_ms.bwd includes the reduction)")
                                       if dist is not None else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "kernels": OP_KERNELS[dom], "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": pmc_traffic_bytes(dom) if args.log2_points == N_POINTS_LOG2 else None,
-                         "algorithmic_bytes": bpp[dom] * N, "algorithmic_bytes_per_point": bpp[dom],
-                         "per_op": {k: {"ms": round(kms[k], 4), "achieved": round(bpp[k] * N / (kms[k] * 1e-3) / 1e9, 1),
+            # the dominant KERNEL (largest HIP-event time per step), SURVEY 8(d) bytes of the levels one launch serves
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": per_kernel[dom_name]["achieved"],
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": per_kernel[dom_name]["frac"],
+                         "traffic": pmc_traffic_bytes([dom_name]) if at_default_size else None,
+                         "avg_launch_us": per_kernel[dom_name]["avg_us"],
+                         "algorithmic_bytes": per_kernel[dom_name]["algorithmic_bytes_per_point"] * N,
+                         "algorithmic_bytes_per_point": per_kernel[dom_name]["algorithmic_bytes_per_point"],
+                         "timers": ("in-library HIP events on the launch stream; " + PROF_KERNELS[LIVE_TIMER] + (" inside" if live_timers else " after")
+                                    + " the timed region, the other kernels on 5 extra steps"),
+                         "per_kernel": per_kernel,
+                         "per_op": {k: {"ms": round(kms[k], 4), "algorithmic_bytes_per_point": bpp[k],
+                                        "achieved": round(bpp[k] * N / (kms[k] * 1e-3) / 1e9, 1),
                                         "frac": round(bpp[k] * N / (kms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                        "traffic": pmc_traffic_bytes(k) if args.log2_points == N_POINTS_LOG2 else None}
+                                        "kernels": [PROF_KERNELS[t] for t in OP_TIMERS[k]],
+                                        "traffic": pmc_traffic_bytes([PROF_KERNELS[t] for t in OP_TIMERS[k]], launches)
+                                        if at_default_size else None}
                                     for k in names},
                          "whole_step_frac": round(sum(bpp.values()) * N / (sum(kms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
         if world == 1 and not args.no_extra:
             out["extra"] = {}
-            for name, fn in (("march_composite", lambda: march_composite_rate(dev)),
+            for name, fn in (("march_composite", lambda: march_composite_rate(dev, cpu_seconds=0.0 if args.no_cpu_baseline else 4.0)),
                              ("march_composite_262144_rays", lambda: march_composite_rate(dev, iters=5, side=512)),
                              ("c1_dense_fwd", lambda: c1_dense_rate(dev)),
                              ("full_loop_1gpu", lambda: full_loop_rate(dev)),

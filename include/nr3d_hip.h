@@ -25,6 +25,25 @@ enum { NR3D_F32 = 0, NR3D_F16 = 1, NR3D_F64 = 2, NR3D_I32 = 3, NR3D_I64 = 4, NR3
 const char *nr3d_last_error(void);
 int nr3d_abi_version(void);
 
+/* Optional per-kernel timing with HIP events on the launch stream (what the reference's c_profile flag does for whole
+ * calls: csrc/lotd/include/lotd/lotd_hash_only.h:748-760, LoDMeta::c_profile lotd_torch_api.h:102-110).
+ * nr3d_prof_enable(mask): bit id set => every launch of that kernel is bracketed by an event pair (off: no cost).
+ * nr3d_prof_read: sum of the recorded intervals of `id` in ms and their number (synchronises on them); reset != 0
+ * forgets them.  Used by bench.py for `roofline.achieved` of the dominant kernel. */
+enum {
+	NR3D_PROF_LOTD_FWD = 0,          /* k_fwd: forward of all levels served from L2 */
+	NR3D_PROF_LOTD_FWD_LDS = 1,      /* k_fwd_lds: forward of the levels staged in LDS (one interval per level) */
+	NR3D_PROF_LOTD_CONTRACT_DX = 2,  /* dL/dx = dL/dy . dy/dx */
+	NR3D_PROF_LOTD_BIN = 3,          /* dL/dparam stage A */
+	NR3D_PROF_LOTD_ACCUM = 4,        /* dL/dparam stage B */
+	NR3D_PROF_MARCH = 5,             /* ray marching, count + emit */
+	NR3D_PROF_COMPOSITE_FWD = 6,     /* fused alpha composite */
+	NR3D_PROF_COMPOSITE_BWD = 7,
+	NR3D_PROF_COUNT = 8
+};
+void nr3d_prof_enable(uint32_t mask);
+int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, int reset);
+
 /* =================================================================================================
  * LoTD encoder -- replaces nr3d_lib.bindings._lotd
  *   pybind surface   csrc/lotd/src/lotd.cpp:23-110

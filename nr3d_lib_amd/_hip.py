@@ -62,6 +62,26 @@ def check(rc):
         raise RuntimeError(lib().nr3d_last_error().decode())
 
 
+# ---- optional per-kernel HIP-event timers (include/nr3d_hip.h: NR3D_PROF_*) -------------------------------
+PROF_IDS = dict(lotd_fwd=0, lotd_fwd_lds=1, lotd_contract_dx=2, lotd_bin=3, lotd_accum=4, march=5, composite_fwd=6,
+                composite_bwd=7)
+
+
+def prof_enable(*names):
+    """time every launch of the named kernels with an event pair on its stream (no names: everything off)"""
+    mask = 0
+    for n in names:
+        mask |= 1 << PROF_IDS[n]
+    lib().nr3d_prof_enable(C.c_uint32(mask))
+
+
+def prof_read(name, reset=True):
+    """(total ms, number of intervals) recorded for `name` since the last reset; synchronises on the events"""
+    ms, n = C.c_double(0.0), C.c_uint32(0)
+    check(lib().nr3d_prof_read(C.c_int(PROF_IDS[name]), C.byref(ms), C.byref(n), C.c_int(1 if reset else 0)))
+    return float(ms.value), int(n.value)
+
+
 def ptr(t):
     """Device (or host) address of a tensor as c_void_p; None -> NULL."""
     if t is None:

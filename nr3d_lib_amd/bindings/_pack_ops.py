@@ -421,6 +421,74 @@ def packed_alpha_to_vw_backward(weights, grad_weights, alphas, pack_infos, early
 
 
 # ------------------------------------------------------------------------------------------------
+# fused alpha composite (no single reference binding: the renderer's op chain renderer_mixin.py:298-311 in one launch
+# each way, nr3d_pack_composite_fwd / _bwd)
+# ------------------------------------------------------------------------------------------------
+def _f32_1d(fn, name, t, n, inner=None):
+    shape = (n,) if inner is None else (n, inner)
+    if t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous():
+        raise RuntimeError(f"{fn}: Expected a contiguous float32 {name} of shape {list(shape)}, got {t.dtype} {list(t.shape)}")
+
+
+def packed_composite_forward(alphas, t, rgb, pack_infos, rays_inds_hit, num_rays, early_stop_eps, alpha_thre,
+                             normalize_depth):
+    """alphas, t [S]; rgb [S,3] | None; pack_infos int64 [P,2]; rays_inds_hit int64 [P] | None (then num_rays == P).
+    -> (vw [S], mask [num_rays], depth [num_rays], rgb_out [num_rays,3] | None); rays that are not hit keep zeros"""
+    fn = "packed_composite_forward"
+    _chk_feats(fn, alphas, pack_infos, dims=(1,))
+    P, S, dev = pack_infos.shape[0], alphas.shape[0], alphas.device
+    H.require_gpu(t, rgb, rays_inds_hit)
+    _f32_1d(fn, "alphas", alphas, S); _f32_1d(fn, "t", t, S)
+    if rgb is not None:
+        _f32_1d(fn, "rgb", rgb, S, 3)
+    if rays_inds_hit is not None:
+        if rays_inds_hit.dtype != torch.int64 or tuple(rays_inds_hit.shape) != (P,) or not rays_inds_hit.is_contiguous():
+            raise RuntimeError(f"{fn}: Expected a contiguous int64 rays_inds_hit of shape [{P}]")
+    elif int(num_rays) != P:
+        raise RuntimeError(f"{fn}: num_rays must equal the number of packs when rays_inds_hit is None")
+    with torch.cuda.device(dev):
+        vw = torch.empty(S, dtype=torch.float32, device=dev)
+        mask = torch.zeros(int(num_rays), dtype=torch.float32, device=dev) if rays_inds_hit is not None else \
+            torch.empty(P, dtype=torch.float32, device=dev)
+        depth = torch.zeros_like(mask) if rays_inds_hit is not None else torch.empty_like(mask)
+        rgb_out = None
+        if rgb is not None:
+            rgb_out = (torch.zeros if rays_inds_hit is not None else torch.empty)((int(num_rays), 3), dtype=torch.float32, device=dev)
+        H.check(H.lib().nr3d_pack_composite_fwd(H.u32(P), H.ptr(alphas), H.ptr(t), H.ptr(rgb), H.ptr(pack_infos),
+                                                H.ptr(rays_inds_hit), H.f32(early_stop_eps), H.f32(alpha_thre),
+                                                C.c_int(1 if normalize_depth else 0), H.ptr(vw), H.ptr(mask), H.ptr(depth),
+                                                H.ptr(rgb_out), H.stream_of(alphas)))
+    return vw, mask, depth, rgb_out
+
+
+def packed_composite_backward(alphas, vw, t, rgb, pack_infos, rays_inds_hit, early_stop_eps, alpha_thre, normalize_depth,
+                              mask, depth, g_mask, g_depth, g_rgb, g_vw, need_t=True, need_rgb=True):
+    """-> (grad_alphas [S], grad_t [S] | None, grad_rgb [S,3] | None); g_* may be None (zero)"""
+    fn = "packed_composite_backward"
+    _chk_feats(fn, alphas, pack_infos, dims=(1,))
+    P, S, dev = pack_infos.shape[0], alphas.shape[0], alphas.device
+    H.require_gpu(vw, t, rgb, rays_inds_hit, mask, depth, g_mask, g_depth, g_rgb, g_vw)
+    n_out = mask.shape[0]
+    for name, tt, inner in (("vw", vw, None), ("t", t, None), ("g_vw", g_vw, None)):
+        if tt is not None:
+            _f32_1d(fn, name, tt, S, inner)
+    for name, tt, inner in (("mask", mask, None), ("depth", depth, None), ("g_mask", g_mask, None), ("g_depth", g_depth, None),
+                            ("g_rgb", g_rgb, 3)):
+        if tt is not None:
+            _f32_1d(fn, name, tt, n_out, inner)
+    with torch.cuda.device(dev):
+        ga = torch.empty(S, dtype=torch.float32, device=dev)
+        gt = torch.empty(S, dtype=torch.float32, device=dev) if need_t else None
+        gr = torch.empty((S, 3), dtype=torch.float32, device=dev) if (need_rgb and rgb is not None) else None
+        H.check(H.lib().nr3d_pack_composite_bwd(H.u32(P), H.ptr(alphas), H.ptr(vw), H.ptr(t), H.ptr(rgb), H.ptr(pack_infos),
+                                                H.ptr(rays_inds_hit), H.f32(early_stop_eps), H.f32(alpha_thre),
+                                                C.c_int(1 if normalize_depth else 0), H.ptr(mask), H.ptr(depth), H.ptr(g_mask),
+                                                H.ptr(g_depth), H.ptr(g_rgb), H.ptr(g_vw), H.ptr(ga), H.ptr(gt), H.ptr(gr),
+                                                H.stream_of(alphas)))
+    return ga, gt, gr
+
+
+# ------------------------------------------------------------------------------------------------
 # misc
 # ------------------------------------------------------------------------------------------------
 def mark_pack_boundaries_cuda(pack_ids):

@@ -21,6 +21,20 @@ int fail(const char *fmt, ...);
 
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// Optional HIP-event timing of individual kernels (nr3d_prof_enable / nr3d_prof_read, include/nr3d_hip.h): a Scope records
+// an event pair on the launch stream around the launches in its lifetime when its id is enabled, and costs one load
+// and a branch when it is not.
+namespace prof {
+extern uint32_t g_mask;
+void begin(int id, hipStream_t st);
+void end(int id, hipStream_t st);
+struct Scope {
+	int id; hipStream_t st; bool on;
+	Scope(int id_, hipStream_t st_) : id(id_), st(st_), on((g_mask >> id_) & 1u) { if (on) begin(id, st); }
+	~Scope() { if (on) end(id, st); }
+};
+}  // namespace prof
+
 // ---- dtype <-> float conversions used by kernels templated on storage type ----
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }

@@ -3,6 +3,8 @@
 #include "common.h"
 #include <string.h>
 #include <limits>
+#include <mutex>
+#include <vector>
 
 namespace nr3d {
 
@@ -18,9 +20,56 @@ int fail(const char *fmt, ...) {
 	return 1;
 }
 
+namespace prof {
+uint32_t g_mask = 0;
+struct Pair { hipEvent_t a, b; };
+static std::mutex g_mu;
+static std::vector<Pair> g_done[NR3D_PROF_COUNT];     // recorded, not yet read
+static std::vector<Pair> g_free;                      // event pairs for reuse
+static Pair g_open[NR3D_PROF_COUNT];
+static bool g_is_open[NR3D_PROF_COUNT] = {};
+
+void begin(int id, hipStream_t st) {
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (id < 0 || id >= NR3D_PROF_COUNT || g_is_open[id]) return;
+	Pair p;
+	if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
+	else if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+	if (hipEventRecord(p.a, st) != hipSuccess) return;
+	g_open[id] = p; g_is_open[id] = true;
+}
+void end(int id, hipStream_t st) {
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (id < 0 || id >= NR3D_PROF_COUNT || !g_is_open[id]) return;
+	g_is_open[id] = false;
+	if (hipEventRecord(g_open[id].b, st) == hipSuccess) g_done[id].push_back(g_open[id]);
+}
+}  // namespace prof
+
 }  // namespace nr3d
 
 using namespace nr3d;
+
+extern "C" void nr3d_prof_enable(uint32_t mask) { prof::g_mask = mask; }
+
+extern "C" int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, int reset) {
+	NR3D_CHECK(id >= 0 && id < NR3D_PROF_COUNT && total_ms && n_intervals, "prof_read: bad argument");
+	std::lock_guard<std::mutex> lk(prof::g_mu);
+	double sum = 0.0;
+	for (const prof::Pair &p : prof::g_done[id]) {
+		NR3D_HIP_CHECK(hipEventSynchronize(p.b));
+		float ms = 0.0f;
+		NR3D_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+		sum += ms;
+	}
+	*total_ms = sum;
+	*n_intervals = (uint32_t)prof::g_done[id].size();
+	if (reset) {
+		for (const prof::Pair &p : prof::g_done[id]) prof::g_free.push_back(p);
+		prof::g_done[id].clear();
+	}
+	return 0;
+}
 
 extern "C" const char *nr3d_last_error(void) { return err_buf(); }
 extern "C" int nr3d_abi_version(void) { return 1; }

@@ -256,6 +256,185 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 }
 
 // =============================================================================================
+// Forward, two lanes per (point, pseudo level): 3-D Dense / Hash levels with 2-feature pseudo levels.
+//
+// The gather rate of k_fwd is bound by L2 requests -- one 128-byte line per lane and load instruction
+// (profiles/r02a_counters.txt: 84 M TCP->TCC requests for 2^20 points, the L2 channels 88 % busy) -- and a lane can ask
+// for at most 16 bytes.  But the texture addresser coalesces the lanes of ONE instruction by line, and the two corners
+// of a cell along x sit in the same line of a Hash table 15 times out of 16:
+//     hash(x, y, z) = x ^ K(y, z)  =>  the 16 x of an aligned block map onto the 16 entries (128 B) of an aligned block.
+// So lanes 2i and 2i + 1 share point i: lane s gathers the 4 corners with x-bit s (Dense: z-bit s, adjacent entries), the
+// pair's two 8-byte loads travel in the same instruction and leave the CU as ONE request.  4.25 requests per (point,
+// Hash level) instead of 6 (paired 16-byte loads work for even x only), 4 for Dense as before.  The lanes then swap
+// features through DPP (quad_perm 1,0,3,2): lane s ends up with all 8 corners of feature s and interpolates it with
+// exactly k_fwd's arithmetic, so the outputs are bit-identical to k_fwd's.
+// =============================================================================================
+constexpr int kPlPts = kBlock / 2;                 // points per block
+
+template <bool DYDX>
+__global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                         int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                         const float *__restrict__ params, float *__restrict__ y, int64_t y_sn,
+                                                         int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
+	constexpr int D = 3;
+	uint32_t q, chunk;
+	if (!decode_block(s, blockIdx.x, q, chunk)) return;
+	const uint32_t i = chunk * kPlPts + (threadIdx.x >> 1);
+	const uint32_t side = threadIdx.x & 1u;
+	if (i >= N) return;                                  // both lanes of a pair leave together
+	const uint32_t level = meta_level_of(md, q);
+	const uint32_t foff0 = meta_cnt_of(md, q) * 2u;
+	float out_y = 0.0f, out_g[D] = {0.0f, 0.0f, 0.0f};
+	if ((int32_t)level <= max_level) {
+		const Lvl L = load_level(md, level);
+		const float *__restrict__ grid = params + L.off;
+		float xp[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
+		Cell<D> c;
+		locate<D>(xp, L, smooth != 0, c);
+		const bool dense = L.type == NR3D_LOD_Dense;
+		float val[8];
+		float2 t[4];
+		// entry of this lane's corner m: the pair dim (Dense z, Hash x) takes `side`, the other two dims take the bits of m
+		// (Dense: bit 0 = x, bit 1 = y; Hash: bit 0 = y, bit 1 = z).  Byte offsets inside the level are 32-bit (checked on
+		// the host), the level's base address is wave-uniform.
+		uint32_t e[4];
+		if (dense) {
+			const uint32_t e00 = (c.g[0] * L.res[1] + c.g[1]) * L.res[2] + c.g[2] + side;
+			const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
+			e[0] = e00; e[1] = e00 + sx; e[2] = e00 + sy; e[3] = e00 + sx + sy;
+		} else {
+			const uint32_t hy0 = c.g[1] * kPrimes[1], hy1 = hy0 + kPrimes[1];
+			const uint32_t hz0 = c.g[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
+			const uint32_t xs = c.g[0] + side;
+			const uint32_t h[4] = {xs ^ hy0 ^ hz0, xs ^ hy1 ^ hz0, xs ^ hy0 ^ hz1, xs ^ hy1 ^ hz1};
+			if ((L.size & (L.size - 1u)) == 0u) {
+#pragma unroll
+				for (int m = 0; m < 4; ++m) e[m] = h[m] & (L.size - 1u);
+			} else {
+#pragma unroll
+				for (int m = 0; m < 4; ++m) e[m] = h[m] % L.size;
+			}
+		}
+		const char *__restrict__ base = reinterpret_cast<const char *>(grid + foff0);
+		const uint32_t stride = L.F * 4u;
+#pragma unroll
+		for (int m = 0; m < 4; ++m)                              // all four gathers first: four requests in flight per lane
+			t[m] = *reinterpret_cast<const float2 *>(base + e[m] * stride);
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) {
+			// val[k] = corner k of feature `side`.  Even lanes (side 0) own the side-0 corner: lo = own x, hi = partner's x;
+			// odd lanes: lo = partner's y, hi = own y (DPP quad_perm 1,0,3,2 swaps the lanes of a pair; the selects fold
+			// into v_cndmask_b32_dpp)
+			const float sw_x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t[m].x), 0xB1, 0xf, 0xf, true));
+			const float sw_y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t[m].y), 0xB1, 0xf, 0xf, true));
+			const float lo = side ? sw_y : t[m].x, hi = side ? t[m].y : sw_x;
+			if (dense) { val[m] = lo; val[m | 4u] = hi; }
+			else { val[m << 1] = lo; val[(m << 1) | 1u] = hi; }
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < 8; ++k) out_y = __fmaf_rn(corner_weight<D>(c, k), val[k], out_y);
+		if (DYDX) {
+#pragma unroll
+			for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+				for (uint32_t k = 0; k < 8; ++k) {
+					if ((k >> gd) & 1u) continue;
+					const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
+					out_g[gd] = __fmaf_rn(w, val[k | (1u << gd)] - val[k], out_g[gd]);
+				}
+		}
+	}
+	const uint32_t col = q * 2u + side;
+	__builtin_nontemporal_store(out_y, &y[(int64_t)i * y_sn + (int64_t)col * y_se]);
+	if (DYDX) {
+		float *dst = dydx + (int64_t)i * d_sn + (int64_t)col * d_se;
+#pragma unroll
+		for (int d = 0; d < D; ++d) __builtin_nontemporal_store(out_g[d], &dst[d]);
+	}
+}
+
+// =============================================================================================
+// Forward, LDS-staged: Dense levels of 2 features whose whole table fits one CU's LDS (NGP config: level 0 = 32 KiB,
+// level 1 = 85 KiB of the 160 KiB).  The workgroup copies the table into LDS once (coalesced) and serves the corner
+// gathers of kLdsPts points from it: 4 ds_read2_b64 per point instead of 4 L2 requests, and the forward of the fine
+// levels -- bound by L2 requests (profiles/r02a_counters.txt: 84 M TCP->TCC requests, TCC 88 % busy) -- loses
+// these levels' share.  Same arithmetic in the same order as k_fwd: bit-identical outputs.
+// =============================================================================================
+constexpr int kLdsThreads = 1024;
+constexpr uint32_t kLdsPts = 4096;                 // points per workgroup
+constexpr uint32_t kLdsMaxBytes = 96 * 1024;       // table bytes a level may have to be staged
+
+template <bool DYDX>
+__global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N, uint32_t q,
+                                                         uint32_t smooth, const float *__restrict__ x,
+                                                         const float *__restrict__ params, float *__restrict__ y, int64_t y_sn,
+                                                         int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
+	constexpr int D = 3, G = 2;
+	extern __shared__ __attribute__((aligned(16))) float2 tab[];
+	const uint32_t level = meta_level_of(md, q);
+	const Lvl L = load_level(md, level);
+	const float2 *__restrict__ src = reinterpret_cast<const float2 *>(params + L.off);
+	for (uint32_t e = threadIdx.x; e < L.size; e += kLdsThreads) tab[e] = src[e];
+	__syncthreads();
+	const uint32_t out0 = q * G;
+	const uint32_t i0 = blockIdx.x * kLdsPts;
+#pragma unroll 2
+	for (uint32_t k4 = 0; k4 < kLdsPts / kLdsThreads; ++k4) {
+		const uint32_t i = i0 + k4 * kLdsThreads + threadIdx.x;
+		if (i >= N) break;
+		float xp[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
+		Cell<D> c;
+		locate<D>(xp, L, smooth != 0, c);
+		float v[1 << D][G];
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) {                       // the corner pair along the contiguous last dim
+			uint32_t p0[D];
+			corner_pos<D>(c, m, p0);
+			const uint32_t e0 = entry_dense<D>(L, p0);
+			const float2 a = tab[e0], b = tab[e0 + 1];
+			v[m][0] = a.x; v[m][1] = a.y; v[m | 4u][0] = b.x; v[m | 4u][1] = b.y;
+		}
+		float out_y[G] = {0.0f, 0.0f}, out_g[G][D];
+#pragma unroll
+		for (int f = 0; f < G; ++f)
+#pragma unroll
+			for (int d = 0; d < D; ++d) out_g[f][d] = 0.0f;
+#pragma unroll
+		for (uint32_t k = 0; k < (1u << D); ++k) {
+			const float w = corner_weight<D>(c, k);
+#pragma unroll
+			for (int f = 0; f < G; ++f) out_y[f] = __fmaf_rn(w, v[k][f], out_y[f]);
+		}
+		if (DYDX) {
+#pragma unroll
+			for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+				for (uint32_t k = 0; k < (1u << D); ++k) {
+					if ((k >> gd) & 1u) continue;
+					const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
+#pragma unroll
+					for (int f = 0; f < G; ++f)
+						out_g[f][gd] = __fmaf_rn(w, v[k | (1u << gd)][f] - v[k][f], out_g[f][gd]);
+				}
+		}
+#pragma unroll
+		for (int f = 0; f < G; ++f) __builtin_nontemporal_store(out_y[f], &y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se]);
+		if (DYDX) {
+#pragma unroll
+			for (int f = 0; f < G; ++f) {
+				float *dst = dydx + (int64_t)i * d_sn + (int64_t)(out0 + f) * d_se;
+#pragma unroll
+				for (int d = 0; d < D; ++d) __builtin_nontemporal_store(out_g[f][d], &dst[d]);
+			}
+		}
+	}
+}
+
+// =============================================================================================
 // dL/dparam (SECOND == false) and d(dL/dx)/dparam (SECOND == true)
 // =============================================================================================
 template <int D, int G, bool SECOND, bool DH>
@@ -643,9 +822,10 @@ static uint32_t sched_mode_default() {
 }
 
 // estimated cost of one (point, pseudo level) item, in half L2 requests (see lotd_device.h, mode 3)
-static uint32_t level_cost(const nr3d_lotd_meta_t *m, uint32_t q) {
+static uint32_t level_cost(const nr3d_lotd_meta_t *m, uint32_t q, bool pairlane = false) {
 	const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
 	const uint32_t D = m->n_dims_to_encode, G = m->n_feat_per_pseudo_lvl;
+	if (pairlane) return 17;                                      // 4 / 4.25 requests for Dense / Hash alike
 	uint32_t req = 1u << D;
 	const bool paired = (G == 2 && L.n_feats == 2);
 	if (L.type == NR3D_LOD_Dense) req = paired ? req / 2 : req;
@@ -657,10 +837,12 @@ static uint32_t level_cost(const nr3d_lotd_meta_t *m, uint32_t q) {
 	return c + 1;                                                 // + the point read / output writes
 }
 
-static Sched make_sched(uint32_t N, const nr3d_lotd_meta_t *m, uint32_t &n_blocks) {
+static Sched make_sched(uint32_t N, const nr3d_lotd_meta_t *m, uint32_t &n_blocks, uint64_t skip = 0,
+                        uint32_t pts_per_block = kBlock, bool pairlane = false) {
 	Sched s;
+	s.skip = skip;
 	const uint32_t n_pseudo = m->n_pseudo_levels;
-	s.n_chunks = div_up(N, kBlock);
+	s.n_chunks = div_up(N, pts_per_block);
 	s.n_pseudo = n_pseudo;
 	s.mode = sched_mode_default();
 	s.n_slots = div_up(n_pseudo, 8);
@@ -668,14 +850,16 @@ static Sched make_sched(uint32_t N, const nr3d_lotd_meta_t *m, uint32_t &n_block
 		// work line: level q occupies n_chunks items of cost c_q each; XCD x takes the items that START in
 		// [x, x + 1) * total / 8
 		uint64_t total = 0;
-		for (uint32_t q = 0; q < n_pseudo; ++q) total += (uint64_t)level_cost(m, q) * s.n_chunks;
+		auto skipped = [&](uint32_t q) { return q < 64u && ((skip >> q) & 1ull); };
+		for (uint32_t q = 0; q < n_pseudo; ++q) if (!skipped(q)) total += (uint64_t)level_cost(m, q, pairlane) * s.n_chunks;
 		uint32_t max_blocks = 0;
 		bool ok = total > 0;
 		uint64_t pos = 0;                                             // start of level q on the line
 		uint32_t nseg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 		for (int x = 0; x < 8; ++x) s.seg_cum[x][0] = 0;
 		for (uint32_t q = 0; q < n_pseudo && ok; ++q) {
-			const uint64_t c = level_cost(m, q);
+			if (skipped(q)) continue;
+			const uint64_t c = level_cost(m, q, pairlane);
 			uint32_t ch = 0;
 			while (ch < s.n_chunks) {
 				const uint64_t start = pos + (uint64_t)ch * c;
@@ -707,6 +891,22 @@ static Sched make_sched(uint32_t N, const nr3d_lotd_meta_t *m, uint32_t &n_block
 	}
 	n_blocks = (s.mode == 1) ? 8u * s.n_slots * s.n_chunks : n_pseudo * s.n_chunks;
 	return s;
+}
+
+static bool pairlane_enabled() {
+	static int on = -1;
+	if (on < 0) { const char *e = getenv("NR3D_LOTD_FWD_PAIRLANE"); on = e ? (atoi(e) != 0) : 1; }
+	return on != 0;
+}
+static bool lds_stage_enabled() {
+	static int on = -1;
+	if (on < 0) { const char *e = getenv("NR3D_LOTD_LDS_STAGE"); on = e ? (atoi(e) != 0) : 1; }
+	return on != 0;
+}
+static uint32_t lds_stage_min_points() {
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("NR3D_LOTD_LDS_MIN_POINTS"); v = e ? atoi(e) : (1 << 18); if (v < 1) v = 1; }
+	return (uint32_t)v;
 }
 
 static int check_common(const nr3d_lotd_meta_t *m, const void *meta_dev, int x_dtype, int p_dtype) {
@@ -757,7 +957,6 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 	if (N == 0) return 0;
 	NR3D_CHECK(x && params && y, "LoTD::fwd: NULL tensor pointer");
 	uint32_t n_blocks;
-	const Sched s = make_sched(N, meta, n_blocks);
 	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 	const uint32_t G = meta->n_feat_per_pseudo_lvl;
 	// vector gathers need every corner address G*4-byte aligned: base pointer aligned and no caller-chosen offsets
@@ -765,6 +964,50 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	hipStream_t st = (hipStream_t)stream;
 	const bool dh = meta->c_hash_only != 0;
+	// small Dense levels out of LDS (k_fwd_lds): unbatched 3-D calls with enough points to amortise the table copies
+	uint64_t staged = 0;
+	if (lds_stage_enabled() && meta->n_dims_to_encode == 3 && G == 2 && vec_ok && !batch_inds && !batch_data_size &&
+	    N >= lds_stage_min_points() && meta->n_pseudo_levels <= 64) {
+		static bool attr_set_dev[64] = {};
+		int dev_id = 0;
+		NR3D_HIP_CHECK(hipGetDevice(&dev_id));
+		if (!attr_set_dev[dev_id & 63]) {
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxBytes));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxBytes));
+			attr_set_dev[dev_id & 63] = true;
+		}
+		for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
+			const uint32_t lv = meta->map_levels[q];
+			const nr3d_lotd_level_t &L = meta->levels[lv];
+			if ((int32_t)lv > max_level || L.type != NR3D_LOD_Dense || L.n_feats != 2 || (uint64_t)L.size * 8 > kLdsMaxBytes) continue;
+			staged |= 1ull << q;
+			const uint32_t lds = L.size * 8;
+			prof::Scope ps(NR3D_PROF_LOTD_FWD_LDS, st);
+			if (dy_dx)
+				hipLaunchKernelGGL(k_fwd_lds<true>, dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, q, meta->interpolation_type,
+				                   (const float *)x, (const float *)params, (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+			else
+				hipLaunchKernelGGL(k_fwd_lds<false>, dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, q, meta->interpolation_type,
+				                   (const float *)x, (const float *)params, (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+		}
+	}
+	bool pairlane = pairlane_enabled() && dh && meta->n_dims_to_encode == 3 && G == 2 && vec_ok && !batch_inds && !batch_data_size;
+	for (uint32_t l = 0; l < meta->n_levels && pairlane; ++l)                // 32-bit byte offsets inside a level
+		pairlane = (uint64_t)meta->levels[l].size * meta->levels[l].n_feats * 4 < (1ull << 32);
+	const Sched s = make_sched(N, meta, n_blocks, staged, pairlane ? (uint32_t)kPlPts : (uint32_t)kBlock, pairlane);
+	if (n_blocks == 0) { NR3D_LAUNCH_CHECK(); return 0; }
+	if (pairlane) {
+		prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
+		if (dy_dx)
+			hipLaunchKernelGGL(k_fwd_pairlane<true>, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level, meta->interpolation_type,
+			                   (const float *)x, (const float *)params, (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+		else
+			hipLaunchKernelGGL(k_fwd_pairlane<false>, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level, meta->interpolation_type,
+			                   (const float *)x, (const float *)params, (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+		NR3D_LAUNCH_CHECK();
+		return 0;
+	}
+	prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
 	DISPATCH_DG(meta->n_dims_to_encode, G, {
 		auto launch = [&](auto kern) {
 			hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
@@ -788,6 +1031,7 @@ extern "C" int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t N, int x_
 	const uint32_t E = meta->n_encoded_dims;
 	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && ((uintptr_t)dL_dy % 16) == 0);
 	NR3D_CHECK(dL_dy_T == nullptr || row_major, "LoTD::bwd_dx: dL_dy_T needs a contiguous, 16-byte aligned [N, E] dL_dy");
+	prof::Scope ps(NR3D_PROF_LOTD_CONTRACT_DX, (hipStream_t)stream);
 	DISPATCH_D(meta->n_dims_to_encode, {
 		if (row_major)
 			hipLaunchKernelGGL(k_contract_dx_rowmajor<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,

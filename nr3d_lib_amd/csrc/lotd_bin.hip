@@ -998,6 +998,7 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
 		attr_set = true;
 	}
+	prof::g_mask & (1u << NR3D_PROF_LOTD_BIN) ? prof::begin(NR3D_PROF_LOTD_BIN, st) : (void)0;
 	if (fo) {
 		if constexpr (D == 3 && NR == 8 && DH) {
 			static bool fattr_dev[64] = {};
@@ -1021,11 +1022,15 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	else
 		hipLaunchKernelGGL((k_bin<D, G, false, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
 		                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, rec, offs);
+	prof::end(NR3D_PROF_LOTD_BIN, st);
 	hipLaunchKernelGGL(k_bucket_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
 	hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, NB, pl.n_blk, work_units(), tot, rep, item_start);
 	// sum of replicas <= work_units() (rounded shares of the total) + one per non-empty bucket
-	hipLaunchKernelGGL((k_accum<D, G>), dim3(work_units() + NB), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs, rep,
-	                   item_start, ba, partial, dparam);
+	{
+		prof::Scope ps(NR3D_PROF_LOTD_ACCUM, st);
+		hipLaunchKernelGGL((k_accum<D, G>), dim3(work_units() + NB), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs, rep,
+		                   item_start, ba, partial, dparam);
+	}
 	hipLaunchKernelGGL((k_reduce_partials<D, G>), dim3(NB, kLdsDoubles / kAccThreads), dim3(kAccThreads), 0, st, pl, md, rep, item_start, ba, partial, dparam);
 	NR3D_LAUNCH_CHECK();
 	return 0;

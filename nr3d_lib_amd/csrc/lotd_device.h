@@ -34,12 +34,18 @@ constexpr uint32_t kPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 20971
 constexpr int kSchedSegs = 16;             // max (level, chunk range) segments per XCD in mode 3
 struct Sched {
 	uint32_t n_chunks, n_pseudo, mode, n_slots;
+	uint64_t skip;                         // bit q set: pseudo level q is served by another launch (LDS-staged forward)
 	uint32_t seg_cum[8][kSchedSegs + 1];   // blocks of this XCD before segment i
 	uint32_t seg_begin[8][kSchedSegs];     // first chunk of segment i
 	uint16_t seg_q[8][kSchedSegs];         // pseudo level of segment i
 };
 
+__device__ __forceinline__ bool decode_block_raw(const Sched &s, uint32_t b, uint32_t &q, uint32_t &chunk);
 __device__ __forceinline__ bool decode_block(const Sched &s, uint32_t b, uint32_t &q, uint32_t &chunk) {
+	if (!decode_block_raw(s, b, q, chunk)) return false;
+	return s.mode == 3 || q >= 64u || !((s.skip >> q) & 1ull);      // mode 3 leaves skipped levels out of the work line
+}
+__device__ __forceinline__ bool decode_block_raw(const Sched &s, uint32_t b, uint32_t &q, uint32_t &chunk) {
 	if (s.mode == 3) {
 		const uint32_t xcd = b & 7u, j = b >> 3;
 		for (int i = 0; i < kSchedSegs; ++i)

@@ -20,20 +20,16 @@
 #include "lotd_device.h"
 #include <stdlib.h>
 
-#ifndef NR3D_PAIR_BP
-#define NR3D_PAIR_BP 1024            // points (= threads) per stage-A workgroup
-#endif
 
 namespace nr3d {
 namespace lotd {
 
-constexpr int kPBP = NR3D_PAIR_BP;
-constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;      // records per (pseudo level, point block) slot
-constexpr uint32_t kPEpb = 8192;                     // accumulator entries per bucket: 2 features x 8192 x 8 B = 128 KiB
+constexpr uint32_t kPEpbMax = 8192;                  // accumulator entries per bucket: 2 features x 8192 x 8 B = 128 KiB (1 workgroup
+                                                     // per CU) or x 4096 = 64 KiB (2 per CU); plan.lg = log2 of it, NR3D_PAIR_EPB_LOG2
 constexpr int kPAccThreads = 1024;
-constexpr int kPLds = 2 * (int)kPEpb;                // fp64 accumulators per stage-B workgroup
+constexpr int kPLdsMax = 2 * (int)kPEpbMax;          // fp64 accumulators per stage-B workgroup (upper bound)
 constexpr int kPMaxLv = 32;                          // pseudo levels per plan
-constexpr uint32_t kPMaxNb = (kPBP < 1024 ? kPBP : 1024) - 1;   // buckets per pseudo level (one scan pass of the block)
+constexpr uint32_t kPMaxNb = 511;                    // buckets per pseudo level (one scan pass of the smallest block)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct PairPlan {
@@ -44,15 +40,57 @@ struct PairPlan {
 	uint32_t bucket_base[kPMaxLv + 1];  // flat index of the level's first bucket
 	uint32_t offs_base[kPMaxLv];        // start of the level's offset table (uint32 units)
 	uint32_t n_blk, n_pseudo;
+	uint32_t cap;                       // records per (pseudo level, point block) slot = 4 x points per block
+	uint32_t lg;                        // log2 of the accumulator entries per bucket (12 or 13)
+	uint32_t sum_log2;                  // updates per accumulator <= 2^sum_log2 (8 corners x points of the pass)
 };
+
+// points (= threads) per stage-A workgroup; NR3D_PAIR_BP = 512 | 768 | 1024 (measurement knob)
+static uint32_t pair_bp() {
+	static uint32_t v = 0;
+	if (!v) { const char *e = getenv("NR3D_PAIR_BP"); const int x = e ? atoi(e) : 1024; v = (x == 512 || x == 768) ? (uint32_t)x : 1024u; }
+	return v;
+}
+static uint32_t pair_lg() {
+	static uint32_t v = 0;
+	if (!v) { const char *e = getenv("NR3D_PAIR_EPB_LOG2"); const int x = e ? atoi(e) : 12; v = (x == 13) ? 13u : 12u; }
+	return v;
+}
+static uint32_t pair_unroll() {
+	static uint32_t v = 0;
+	if (!v) { const char *e = getenv("NR3D_PAIR_UNROLL"); const int x = e ? atoi(e) : 8; v = (x == 4) ? 4u : 8u; }
+	return v;
+}
+// timing experiments only (results are wrong): bit 0 = no LDS atomics, bit 1 = every lane re-reads one record
+static uint32_t pair_dbg() {
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("NR3D_PAIR_DEBUG"); v = e ? atoi(e) : 0; }
+	return (uint32_t)v;
+}
+// stage-B accumulators: 1 = 64-bit fixed point (default), 0 = fp64
+static uint32_t pair_fixed() {
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("NR3D_PAIR_FIXED"); v = e ? (atoi(e) != 0) : 1; }
+	return (uint32_t)v;
+}
+// target number of stage-B work items of the pair path (measured, NGP config, 2^20 points, 64 KiB buckets, backward ms:
+// 768: 0.679, 1024: 0.669, 1536: 0.657, 2048: 0.671)
+static uint32_t pair_units() {
+	static uint32_t v = 0;
+	if (!v) { const char *e = getenv("NR3D_PAIR_UNITS"); const int x = e ? atoi(e) : 1536; v = (uint32_t)(x < 256 ? 256 : (x > 8192 ? 8192 : x)); }
+	return v;
+}
 
 // -------------------------------------------------------------------------------------------------
 // Stage A
 // -------------------------------------------------------------------------------------------------
+template <int kPBP>
 __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                                    int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                    const float *__restrict__ g, int64_t g_sn, int64_t g_se,
-                                                   u32x4 *__restrict__ rec, uint32_t *__restrict__ offs_g) {
+                                                   u32x4 *__restrict__ rec, uint32_t *__restrict__ offs_g,
+                                                   uint32_t *__restrict__ gmax) {
+	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[kPCap] records | hist[nb + 1]
 	__shared__ uint32_t scan_lds[kPBP / 64];
 	u32x4 *stage = reinterpret_cast<u32x4 *>(smem);
@@ -70,6 +108,7 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 	const bool active = (i < n) && ((int32_t)level <= max_level);
 	uint32_t hdr[4], bkt[4], cell[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 	float A[4][2], wp = 0.0f;
+	uint32_t gbits = 0;                 // max |dL/dy| of this lane as float bits (the fixed-point scale of stage B)
 #pragma unroll
 	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; }
 	if (active) {
@@ -80,6 +119,7 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 		locate<3>(xp, L, smooth != 0, c);
 		const float g0 = g[(int64_t)i * g_sn + (int64_t)(q * 2) * g_se];
 		const float g1 = g[(int64_t)i * g_sn + (int64_t)(q * 2 + 1) * g_se];
+		gbits = max(__float_as_uint(g0) & 0x7FFFFFFFu, __float_as_uint(g1) & 0x7FFFFFFFu);
 		const uint32_t sh = plan.shift[ql], epb = plan.epb[ql];
 		if (L.type == NR3D_LOD_Dense) {
 			wp = c.w[2];
@@ -98,6 +138,7 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 		} else {
 			wp = c.w[0];
 			const bool pow2 = (L.size & (L.size - 1u)) == 0u;
+			const uint32_t emask = (1u << plan.lg) - 1u;
 #pragma unroll
 			for (uint32_t m = 0; m < 4; ++m) {
 				const uint32_t by = m & 1u, bz = m >> 1;
@@ -105,8 +146,8 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 				const uint32_t h0 = c.g[0] ^ K, h1 = (c.g[0] + 1u) ^ K;
 				const uint32_t e0 = pow2 ? (h0 & (L.size - 1u)) : (h0 % L.size);
 				const uint32_t e1 = pow2 ? (h1 & (L.size - 1u)) : (h1 % L.size);
-				bkt[m] = e0 >> 13;                         // == e1 >> 13 (plan conditions)
-				hdr[m] = (e0 & 8191u) | ((e1 & 8191u) << 13);
+				bkt[m] = e0 >> plan.lg;                    // == e1 >> plan.lg (plan conditions)
+				hdr[m] = (e0 & emask) | ((e1 & emask) << 13);
 				const float wo = (by ? c.w[1] : 1.0f - c.w[1]) * (bz ? c.w[2] : 1.0f - c.w[2]);
 				A[m][0] = g0 * wo; A[m][1] = g1 * wo;
 			}
@@ -220,6 +261,22 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 	}
 	__syncthreads();
 
+	if (gmax) {
+		// |float| bits order like unsigned integers (NaN / inf on top).  One candidate per workgroup, and the atomic only
+		// when it would raise the running maximum (an L2 load first): 2^18 same-address atomics would serialise for ms
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) gbits = max(gbits, (uint32_t)__shfl_xor((int)gbits, off, 64));
+		__syncthreads();                                       // scan_lds is free again
+		if (lane == 0) scan_lds[threadIdx.x >> 6] = gbits;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			uint32_t m = 0;
+#pragma unroll
+			for (int k = 0; k < kPBP / 64; ++k) m = max(m, scan_lds[k]);
+			if (m > __hip_atomic_load(gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gmax, m);
+		}
+	}
+
 	// ---- coalesced write-out (written once, read once by stage B: non-temporal) ----
 	const uint32_t total = hist[nb];
 	u32x4 *dst = rec + ((size_t)ql * plan.n_blk + blk) * (size_t)kPCap;
@@ -243,25 +300,50 @@ __global__ __launch_bounds__(256) void k_pair_totals(PairPlan plan, const uint32
 	if (lane == 0) tot[fb] = sum;
 }
 
-// accumulator slot t (feature-major: t = f * 8192 + el) of bucket b -> element of dL/dparam, nullptr outside the level
-__device__ __forceinline__ float *pair_target(const Lvl &L, uint32_t epb, uint32_t foff0, uint32_t b, uint32_t t,
+// accumulator slot t (feature-major: t = f * 2^lg + el) of bucket b -> element of dL/dparam, nullptr outside the level
+__device__ __forceinline__ float *pair_target(const Lvl &L, uint32_t epb, uint32_t lg, uint32_t foff0, uint32_t b, uint32_t t,
                                               float *__restrict__ dparam) {
-	const uint32_t f = t >> 13, el = t & 8191u;
+	const uint32_t f = t >> lg, el = t & ((1u << lg) - 1u);
 	const uint64_t entry = (uint64_t)b * epb + el;
 	if (el >= epb || entry >= L.size) return nullptr;
 	return dparam + L.off + (entry * L.F + foff0 + f);
 }
 
+// fp64 LDS atomics run at ~1.3-1.5 T/s chip-wide, 64-bit integer ones at ~2.5 T/s (tools/ubench_lds): with FIX the
+// accumulators are 64-bit fixed point.  Scale 2^s from the largest |dL/dy| of the call (stage A's gmax; every update is
+// a weight in [0, 1] times a gradient) and the number of points: |sum| < 8 n max|g| 2^s <= 2^62, resolution
+// max|g| * 2^-(59 - log2 n) -- far below an fp32 ulp of any non-negligible entry -- and the sum is exact, so the result
+// does not depend on the order of the updates at all.  Non-finite gradients fall back to fp64 accumulation (uniform).
+struct PairFix { double scale, inv; bool on; };
+__device__ __forceinline__ PairFix pair_fix(const uint32_t *__restrict__ gmax, uint32_t sum_log2) {
+	PairFix f;
+	const uint32_t bits = ((cu32_t)gmax)[0];
+	f.on = bits < 0x7F800000u;
+	const int e = max((int)(bits >> 23), 1) - 126;                    // max|g| < 2^e
+	const int lim = min(62 - (int)sum_log2, 50);                      // single values stay below 2^51 (rounding trick below)
+	const int sc = max(min(lim - e, 1000), -1000);
+	f.scale = __longlong_as_double((long long)(sc + 1023) << 52);
+	f.inv = __longlong_as_double((long long)(1023 - sc) << 52);
+	return f;
+}
+__device__ __forceinline__ unsigned long long to_fix(float v, double scale) {
+	const double t = __fma_rn((double)v, scale, 0x1.8p52);            // round to nearest integer in the low mantissa bits
+	return (unsigned long long)(__double_as_longlong(t) - 0x4338000000000000LL);
+}
+
 // -------------------------------------------------------------------------------------------------
-// Stage B: one bucket (x replica) -> fp64 LDS accumulation -> slice of dL/dparam
+// Stage B: one bucket (x replica) -> LDS accumulation -> slice of dL/dparam
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kPAccThreads) void k_pair_accum(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
+template <int kUnroll, bool FIX>
+__global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB workgroups per CU */ void k_pair_accum(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
                                                              const u32x4 *__restrict__ rec,
                                                              const uint32_t *__restrict__ offs_g,
                                                              const uint32_t *__restrict__ rep_g,
                                                              const uint32_t *__restrict__ item_start,
-                                                             float *__restrict__ partial, float *__restrict__ dparam) {
-	extern __shared__ __attribute__((aligned(16))) double acc[];      // [2][8192], feature-major
+                                                             const uint32_t *__restrict__ gmax,
+                                                             float *__restrict__ partial, float *__restrict__ dparam, uint32_t dbg) {
+	extern __shared__ __attribute__((aligned(16))) unsigned long long acc_raw[];   // [2][2^lg] 8-byte accumulators, feature-major
+	double *acc = reinterpret_cast<double *>(acc_raw);
 	const uint32_t NB = plan.bucket_base[plan.n_pseudo];
 	const cu32_t istart = (cu32_t)item_start, irep = (cu32_t)rep_g;
 	if (blockIdx.x >= istart[NB]) return;
@@ -274,8 +356,12 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_accum(PairPlan plan, cons
 	const uint32_t qg = plan.qmap[q];
 	const Lvl L = load_level(md, meta_level_of(md, qg));
 	const uint32_t foff0 = meta_cnt_of(md, qg) * 2u, epb = plan.epb[q];
+	PairFix fx = {1.0, 1.0, false};
+	if constexpr (FIX) fx = pair_fix(gmax, plan.sum_log2);
+	const bool fix = FIX && fx.on;
 
-	for (uint32_t t = threadIdx.x; t < (uint32_t)kPLds; t += kPAccThreads) acc[t] = 0.0;
+	const uint32_t kPEpb = 1u << plan.lg, kPLds = 2u << plan.lg;
+	for (uint32_t t = threadIdx.x; t < kPLds; t += kPAccThreads) acc_raw[t] = 0ull;       // +0.0 as a double, too
 	__syncthreads();
 
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -283,70 +369,87 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_accum(PairPlan plan, cons
 	const uint32_t blk_lo = (uint32_t)(((uint64_t)plan.n_blk * r) / R), blk_hi = (uint32_t)(((uint64_t)plan.n_blk * (r + 1)) / R);
 	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)b * plan.n_blk;
 	const uint32_t *ob1 = ob0 + plan.n_blk;
+	const uint32_t kPCap = plan.cap;
 	const u32x4 *rec_q = rec + (size_t)q * plan.n_blk * (size_t)kPCap;
 	const uint32_t per_wave = (blk_hi - blk_lo + n_waves - 1) / n_waves;
 	const uint32_t w_lo = min(blk_lo + wave * per_wave, blk_hi), w_hi = min(w_lo + per_wave, blk_hi);
-#ifndef NR3D_PAIR_UNROLL
-#define NR3D_PAIR_UNROLL 4
-#endif
-	constexpr int kUnroll = NR3D_PAIR_UNROLL;          // runs in flight per wave
+	// The point blocks of this replica are split evenly over the waves.  Per step a wave takes up to 64 of its blocks
+	// (lane t fetches the run [start, end) of block blk0 + t, coalesced) and walks them in groups of kGroup runs: the
+	// runs of a group are treated as ONE stream of `total` records and lane l of pass p takes record 64 p + l of it,
+	// whichever run that is (run boundaries are wave-uniform: kGroup - 1 compare / select pairs per load).  Every pass but
+	// the last is full, the kUnroll loads of a chunk are independent, and a run a little longer than 64 records does
+	// not cost a second, nearly empty, dependent pass.
+	constexpr int kGroup = 8;
 	for (uint32_t blk0 = w_lo; blk0 < w_hi; blk0 += 64) {
 		const uint32_t mb = blk0 + lane;
 		const uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
 		const uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
 		const uint32_t n_run = min(64u, w_hi - blk0);
 		const u32x4 *rec_b = rec_q + (size_t)blk0 * kPCap;
-		for (uint32_t j0 = 0; j0 < n_run; j0 += kUnroll) {
-			u32x4 rv[kUnroll];
-			uint32_t rs[kUnroll], rn[kUnroll];
-			uint32_t longest = 0;
-			// branch-free loads (lanes past the run re-read its first record and drop it): a load under an `if` makes the
-			// compiler drain all outstanding loads at the join
-			for (uint32_t off = 0; off == 0 || off < longest; off += 64) {
+		for (uint32_t j0 = 0; j0 < n_run; j0 += kGroup) {
+			uint32_t pre[kGroup + 1], rbase[kGroup];
+			pre[0] = 0;
 #pragma unroll
-				for (int u = 0; u < kUnroll; ++u) {
-					if (off == 0) {
-						const uint32_t j = min(j0 + (uint32_t)u, 63u);
-						const uint32_t s_j = __builtin_amdgcn_readlane(s_l, j), e_j = __builtin_amdgcn_readlane(e_l, j);
-						rs[u] = s_j + j * kPCap;
-						rn[u] = (j0 + (uint32_t)u < n_run) ? e_j - s_j : 0u;
-						longest = max(longest, rn[u]);
-					}
-					const uint32_t t = off + lane;
-					rv[u] = __builtin_nontemporal_load(rec_b + (size_t)(rs[u] + (t < rn[u] ? t : 0u)));
+			for (int u = 0; u < kGroup; ++u) {
+				const uint32_t j = min(j0 + (uint32_t)u, 63u);
+				const uint32_t s_j = __builtin_amdgcn_readlane(s_l, j), e_j = __builtin_amdgcn_readlane(e_l, j);
+				const uint32_t nrec = (j0 + (uint32_t)u < n_run) ? e_j - s_j : 0u;
+				rbase[u] = s_j + j * kPCap - pre[u];          // record index of stream position p inside run u: rbase[u] + p
+				pre[u + 1] = pre[u] + nrec;
+			}
+			const uint32_t total = pre[kGroup];
+			for (uint32_t p0 = 0; p0 < total; p0 += 64u * kUnroll) {
+				u32x4 rv[kUnroll];
+#pragma unroll
+				for (int v = 0; v < kUnroll; ++v) {
+					const uint32_t pos = p0 + 64u * (uint32_t)v + lane;
+					uint32_t at = rbase[0];
+#pragma unroll
+					for (int u = 1; u < kGroup; ++u) at = (pos >= pre[u]) ? rbase[u] : at;
+					// branch-free (a load under an `if` makes the compiler drain all outstanding loads at the join): lanes
+					// past the end re-read the group's first slot and drop it
+					rv[v] = __builtin_nontemporal_load(rec_b + (size_t)((pos < total && !(dbg & 2u)) ? at + pos : rbase[0]));
 				}
 #pragma unroll
-				for (int u = 0; u < kUnroll; ++u)
-					if (off + lane < rn[u]) {
-						const uint32_t h = rv[u].x, fl = h >> 26;
+				for (int v = 0; v < kUnroll; ++v)
+					if (p0 + 64u * (uint32_t)v + lane < total && !(dbg & 1u)) {
+						const uint32_t h = rv[v].x, fl = h >> 26;
 						const uint32_t i0 = h & 8191u, i1 = (h >> 13) & 8191u;
-						const float w = __uint_as_float(rv[u].y), a0 = __uint_as_float(rv[u].z), a1 = __uint_as_float(rv[u].w);
+						const float w = __uint_as_float(rv[v].y), a0 = __uint_as_float(rv[v].z), a1 = __uint_as_float(rv[v].w);
 						const bool pair = fl == 3u;
 						const float wl = pair ? 1.0f - w : 1.0f, wh = pair ? w : 1.0f;
-						if (fl & 1u) { atomicAdd(&acc[i0], (double)(wl * a0)); atomicAdd(&acc[kPEpb + i0], (double)(wl * a1)); }
-						if (fl & 2u) { atomicAdd(&acc[i1], (double)(wh * a0)); atomicAdd(&acc[kPEpb + i1], (double)(wh * a1)); }
+						if (fix) {
+							if (fl & 1u) { atomicAdd(&acc_raw[i0], to_fix(wl * a0, fx.scale)); atomicAdd(&acc_raw[kPEpb + i0], to_fix(wl * a1, fx.scale)); }
+							if (fl & 2u) { atomicAdd(&acc_raw[i1], to_fix(wh * a0, fx.scale)); atomicAdd(&acc_raw[kPEpb + i1], to_fix(wh * a1, fx.scale)); }
+						} else {
+							if (fl & 1u) { atomicAdd(&acc[i0], (double)(wl * a0)); atomicAdd(&acc[kPEpb + i0], (double)(wl * a1)); }
+							if (fl & 2u) { atomicAdd(&acc[i1], (double)(wh * a0)); atomicAdd(&acc[kPEpb + i1], (double)(wh * a1)); }
+						}
 					}
 			}
 		}
 	}
 	__syncthreads();
 
+	auto value = [&](uint32_t t) -> float {
+		return fix ? (float)((double)(long long)acc_raw[t] * fx.inv) : (float)acc[t];
+	};
 	// flush: the only workgroup of a bucket adds its slice to dL/dparam itself; replicas store fp32 partial tables that
 	// k_pair_reduce adds in replica order (no global atomic anywhere)
 	if (R > 1) {
 		float *mine = partial + (size_t)blockIdx.x * kPLds;
-		for (uint32_t t = threadIdx.x; t < (uint32_t)kPLds; t += kPAccThreads) mine[t] = (float)acc[t];
+		for (uint32_t t = threadIdx.x; t < kPLds; t += kPAccThreads) mine[t] = value(t);
 		return;
 	}
 	constexpr int kFlush = 8;
-	for (uint32_t tb = threadIdx.x; tb < (uint32_t)kPLds; tb += kPAccThreads * kFlush) {
+	for (uint32_t tb = threadIdx.x; tb < kPLds; tb += kPAccThreads * kFlush) {
 		float *p[kFlush];
 		float v[kFlush], old[kFlush];
 #pragma unroll
 		for (int k = 0; k < kFlush; ++k) {
 			const uint32_t t = tb + (uint32_t)k * kPAccThreads;
-			p[k] = (t < (uint32_t)kPLds) ? pair_target(L, epb, foff0, b, t, dparam) : nullptr;
-			v[k] = p[k] ? (float)acc[t] : 0.0f;
+			p[k] = (t < kPLds) ? pair_target(L, epb, plan.lg, foff0, b, t, dparam) : nullptr;
+			v[k] = p[k] ? value(t) : 0.0f;
 		}
 #pragma unroll
 		for (int k = 0; k < kFlush; ++k) old[k] = p[k] ? *p[k] : 0.0f;
@@ -368,9 +471,11 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
 	const uint32_t b = fb - plan.bucket_base[q], qg = plan.qmap[q];
 	const Lvl L = load_level(md, meta_level_of(md, qg));
 	const uint32_t foff0 = meta_cnt_of(md, qg) * 2u;
+	const uint32_t kPLds = 2u << plan.lg;
 	const float *part0 = partial + (size_t)item_start[fb] * kPLds;
 	const uint32_t t = blockIdx.y * kPAccThreads + threadIdx.x;
-	float *p = pair_target(L, plan.epb[q], foff0, b, t, dparam);
+	if (t >= kPLds) return;
+	float *p = pair_target(L, plan.epb[q], plan.lg, foff0, b, t, dparam);
 	if (!p) return;
 	float sum = 0.0f;
 	uint32_t r0 = 0;
@@ -400,6 +505,7 @@ bool pair_applies(const nr3d_lotd_meta_t *m) {
 	if (m->n_pseudo_levels > (uint32_t)kPMaxLv) return false;
 	for (uint32_t l = 0; l < m->n_levels; ++l) {
 		const nr3d_lotd_level_t &L = m->levels[l];
+		const uint32_t kPEpb = 1u << pair_lg();
 		if (L.type == NR3D_LOD_Dense) {
 			if (L.res[2] > kPEpb) return false;
 			const uint64_t rows = (uint64_t)L.res[0] * L.res[1];
@@ -409,7 +515,7 @@ bool pair_applies(const nr3d_lotd_meta_t *m) {
 		} else if (L.type == NR3D_LOD_Hash) {
 			if (L.size <= kPEpb) continue;
 			if ((L.size & (L.size - 1u)) != 0u || L.res[0] > kPEpb) return false;
-			if ((L.size >> 13) > kPMaxNb) return false;
+			if ((L.size >> pair_lg()) > kPMaxNb) return false;
 		} else {
 			return false;
 		}
@@ -419,7 +525,12 @@ bool pair_applies(const nr3d_lotd_meta_t *m) {
 
 static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_level, int32_t max_level, PairPlan &plan,
                       uint64_t &offs_words) {
-	plan.n_blk = div_up(n_chunk, kPBP);
+	plan.n_blk = div_up(n_chunk, pair_bp());
+	plan.cap = pair_bp() * 4u;
+	plan.lg = pair_lg();
+	plan.sum_log2 = 3;
+	while ((1ull << (plan.sum_log2 - 3)) < n_chunk) ++plan.sum_log2;
+	const uint32_t kPEpb = 1u << plan.lg;
 	uint32_t nq = 0;
 	uint64_t base = 0;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
@@ -433,8 +544,8 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
 			epb = (1u << sh) * L.res[2];
 			nb = (uint32_t)((((uint64_t)L.res[0] * L.res[1]) + (1ull << sh) - 1) >> sh);
 		} else {
-			sh = 13; epb = kPEpb;
-			nb = L.size <= kPEpb ? 1u : (L.size >> 13);
+			sh = plan.lg; epb = kPEpb;
+			nb = L.size <= kPEpb ? 1u : (L.size >> plan.lg);
 		}
 		plan.qmap[nq] = q; plan.nb[nq] = nb; plan.epb[nq] = epb; plan.shift[nq] = sh;
 		plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
@@ -454,10 +565,10 @@ void pair_layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t units, ui
 	uint64_t ow;
 	pair_plan(m, n_chunk, 0, 0x7fffffff, plan, ow);
 	const uint32_t NB = plan.bucket_base[plan.n_pseudo];
-	rec_bytes = (uint64_t)plan.n_pseudo * plan.n_blk * kPCap * 16;
+	rec_bytes = (uint64_t)plan.n_pseudo * plan.n_blk * plan.cap * 16;
 	offs_bytes = ((ow * 4 + 255) / 256) * 256;
 	plan_bytes = (((uint64_t)NB * 3 + 4) * 4 + 255) / 256 * 256;
-	part_bytes = (uint64_t)(units + NB) * kPLds * 4;
+	part_bytes = (uint64_t)(pair_units() + NB) * (2u << plan.lg) * 4;       // the pair path's own item count, not `units`
 }
 
 void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32_t *tot, uint32_t *rep, uint32_t *item_start,
@@ -475,22 +586,43 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
 	const uint32_t NB = pl.bucket_base[pl.n_pseudo];
 	uint32_t *tot = plan_buf, *rep = plan_buf + NB, *item_start = plan_buf + 2 * (size_t)NB;
-	const size_t bin_lds = (size_t)kPCap * 16 + (size_t)(kPMaxNb + 2) * 4;
+	uint32_t *gmax = plan_buf + 3 * (size_t)NB + 2;                  // spare word of the plan region
+	units = pair_units();
+	const size_t bin_lds_max = (size_t)1024 * 4 * 16 + (size_t)(kPMaxNb + 2) * 4;
 	static bool attr_set_dev[64] = {};
 	int dev_id = 0;
 	NR3D_HIP_CHECK(hipGetDevice(&dev_id));
 	if (!attr_set_dev[dev_id & 63]) {
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum, hipFuncAttributeMaxDynamicSharedMemorySize, kPLds * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		attr_set_dev[dev_id & 63] = true;
 	}
-	hipLaunchKernelGGL(k_pair_bin, dim3(pl.n_blk, pl.n_pseudo), dim3(kPBP), (size_t)kPCap * 16 + (size_t)(nb_max + 1) * 4, st, pl,
-	                   md, n, max_level, meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs);
+	NR3D_HIP_CHECK(hipMemsetAsync(gmax, 0, sizeof(uint32_t), st));
+	const uint32_t bp = pair_bp();
+	const size_t bin_lds = (size_t)pl.cap * 16 + (size_t)(nb_max + 1) * 4;
+#define NR3D_PAIR_BIN(BP) hipLaunchKernelGGL(k_pair_bin<BP>, dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level, \
+	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax)
+	{
+		prof::Scope ps(NR3D_PROF_LOTD_BIN, st);
+		if (bp == 512) NR3D_PAIR_BIN(512); else if (bp == 768) NR3D_PAIR_BIN(768); else NR3D_PAIR_BIN(1024);
+	}
+#undef NR3D_PAIR_BIN
 	hipLaunchKernelGGL(k_pair_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
 	launch_plan_items(NB, pl.n_blk, units, tot, rep, item_start, st);
-	hipLaunchKernelGGL(k_pair_accum, dim3(units + NB), dim3(kPAccThreads), kPLds * 8, st, pl, md, (const u32x4 *)rec, offs, rep,
-	                   item_start, partial, dparam);
-	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, kPLds / kPAccThreads), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
+#define NR3D_PAIR_ACC(U, F) hipLaunchKernelGGL((k_pair_accum<U, F>), dim3(units + NB), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, pl, md, \
+	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg())
+	{
+		prof::Scope ps(NR3D_PROF_LOTD_ACCUM, st);
+		if (pair_fixed()) { if (pair_unroll() == 4) NR3D_PAIR_ACC(4, true); else NR3D_PAIR_ACC(8, true); }
+		else              { if (pair_unroll() == 4) NR3D_PAIR_ACC(4, false); else NR3D_PAIR_ACC(8, false); }
+	}
+#undef NR3D_PAIR_ACC
+	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, (2u << pl.lg) / kPAccThreads), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
 	                   dparam);
 	NR3D_LAUNCH_CHECK();
 	return 0;

@@ -335,7 +335,9 @@ __global__ __launch_bounds__(kBlock) void k_forest_march(const int16_t *__restri
 // the per-voxel sample maxima before the decay is applied once.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
-	// order-preserving integer views: non-negative floats compare like signed ints, negative ones inversely as uints
+	// order-preserving integer views: non-negative floats compare like signed ints, negative ones inversely as uints.
+	// -0.0f (sign bit only = INT_MIN as an int) would lose against the -inf sentinel: canonicalise it to +0.0f
+	v += 0.0f;
 	if (v >= 0.0f) atomicMax(reinterpret_cast<int *>(addr), __float_as_int(v));
 	else atomicMin(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
 }
@@ -343,7 +345,7 @@ __device__ __forceinline__ void atomic_max_f32(float *addr, float v) {
 __global__ __launch_bounds__(256) void k_occ_scatter_max(uint64_t n, const int64_t *__restrict__ gidx,
                                                          const float *__restrict__ pts, const int64_t *__restrict__ bidx,
                                                          uint64_t per_batch, const float *__restrict__ val, int rx, int ry,
-                                                         int rz, float *__restrict__ vmax) {
+                                                         int rz, uint64_t n_batches, float *__restrict__ vmax) {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
 	int64_t ix, iy, iz;
@@ -359,7 +361,11 @@ __global__ __launch_bounds__(256) void k_occ_scatter_max(uint64_t n, const int64
 		iz = max((int64_t)0, min(iz, (int64_t)rz - 1));
 	}
 	const uint64_t vol = (uint64_t)rx * ry * rz;
-	const uint64_t b = bidx ? (uint64_t)bidx[i] : (per_batch ? i / per_batch : 0);
+	const int64_t bs = bidx ? bidx[i] : (int64_t)(per_batch ? i / per_batch : 0);
+	// caller-supplied voxel / batch indices outside the grid are dropped (the reference's index_put_ / scatter_max would
+	// raise; a raw kernel must not write out of bounds)
+	if (ix < 0 || iy < 0 || iz < 0 || ix >= rx || iy >= ry || iz >= rz || bs < 0 || (uint64_t)bs >= n_batches) return;
+	const uint64_t b = (uint64_t)bs;
 	atomic_max_f32(vmax + b * vol + (uint64_t)ix * ((uint64_t)ry * rz) + (uint64_t)iy * rz + (uint64_t)iz, val[i]);
 }
 
@@ -386,7 +392,7 @@ extern "C" int nr3d_occ_scatter_max(uint64_t n, const int64_t *gidx, const float
 	if (n == 0) return 0;
 	NR3D_CHECK(occ_val != nullptr, "occ_scatter_max: NULL occ_val");
 	hipLaunchKernelGGL(occ::k_occ_scatter_max, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, gidx, pts, bidx,
-	                   per_batch, occ_val, grid_res[0], grid_res[1], grid_res[2], vmax);
+	                   per_batch, occ_val, grid_res[0], grid_res[1], grid_res[2], (uint64_t)(n_batches ? n_batches : 1), vmax);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
@@ -429,7 +435,10 @@ extern "C" int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, con
 		                   (float *)nullptr, (float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
 		                   (uint32_t *)sample_cache);
 	};
-	if (cached) launch(occ::k_march<false, true>); else launch(occ::k_march<false, false>);
+	{
+		prof::Scope ps(NR3D_PROF_MARCH, st);
+		if (cached) launch(occ::k_march<false, true>); else launch(occ::k_march<false, false>);
+	}
 	NR3D_LAUNCH_CHECK();
 	return scan::pack_infos_from_counts<int32_t, int32_t>(n_rays, counts, packed_info, total_steps, tiles, st);
 }
@@ -444,6 +453,7 @@ extern "C" int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, cons
 	if (n_rays == 0) return 0;
 	NR3D_CHECK(rays_o && rays_d && t_min && t_max && roi && grid_binary && packed_info, "ray_marching: NULL tensor pointer");
 	NR3D_CHECK(t_starts && t_ends && ridx, "ray_marching: NULL output pointer");
+	prof::Scope ps(NR3D_PROF_MARCH, (hipStream_t)stream);
 	if (sample_cache) {   // filled by nr3d_ray_marching_count with the same rays and max_steps == cache_max_steps
 		hipLaunchKernelGGL(occ::k_emit_cached, dim3(div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, n_rays,
 		                   cache_max_steps, batched, batch_inds, batch_data_size, packed_info, (const uint32_t *)sample_cache,

@@ -800,27 +800,82 @@ __global__ __launch_bounds__(kBlock) void k_composite_bwd_lpp(uint32_t P, const 
 	const uint32_t len = (uint32_t)pi[2 * (size_t)p + 1];
 	const size_t o = ray_index ? (size_t)ray_index[p] : (size_t)p;
 	const CompGrad cg = comp_grad(o, normalize, mask, depth, g_mask, g_depth, g_rgb);
+	// Chunks of 4 samples (one 16-byte request per stream and chunk: the lanes' rays sit in different lines); the loads of
+	// chunk c + 1 are issued, branch-free (the last chunk is simply re-read), before chunk c is processed, so the serial
+	// recurrences run under the memory latency instead of after it (as k_alpha_bwd_lpp).
+	struct Chunk { F4u a, w, t, gv, c0, c1, c2; };
+	const uint32_t n4 = len / 4;
+	auto ld4 = [&](const float *base, size_t at) { return *reinterpret_cast<const F4u *>(base + at); };
+	auto load = [&](uint32_t c, bool with_alpha) {
+		Chunk k = {};
+		const size_t at = begin + 4 * (size_t)c;
+		if (with_alpha) k.a = ld4(alphas, at);
+		k.w = ld4(vw, at); k.t = ld4(ts, at);
+		if (g_vw) k.gv = ld4(g_vw, at);
+		if (RGB) { k.c0 = ld4(rgb, 3 * at); k.c1 = ld4(rgb, 3 * at + 4); k.c2 = ld4(rgb, 3 * at + 8); }
+		return k;
+	};
+	auto gw_of = [&](const Chunk &k, int u) {
+		const float cc[12] = {k.c0.v[0], k.c0.v[1], k.c0.v[2], k.c0.v[3], k.c1.v[0], k.c1.v[1], k.c1.v[2], k.c1.v[3],
+		                      k.c2.v[0], k.c2.v[1], k.c2.v[2], k.c2.v[3]};
+		return comp_gw(cg, k.t.v[u], cc[3 * u], cc[3 * u + 1], cc[3 * u + 2], g_vw ? k.gv.v[u] : 0.0f);
+	};
 	auto gw_at = [&](size_t i) {
 		return comp_gw(cg, ts[i], RGB ? rgb[3 * i] : 0.0f, RGB ? rgb[3 * i + 1] : 0.0f, RGB ? rgb[3 * i + 2] : 0.0f, g_vw ? g_vw[i] : 0.0f);
 	};
+	// pass 1: accum = sum_j gw_j * w_j (serial fma chain, the order of packed_alpha_to_vw_backward)
 	float accum = 0.0f;
-	for (uint32_t j = 0; j < len; ++j) accum = __fmaf_rn(gw_at(begin + j), vw[begin + j], accum);
+	if (n4) {
+		Chunk nx = load(0, false);
+		for (uint32_t c = 0; c < n4; ++c) {
+			const Chunk k = nx;
+			nx = load(min(c + 1, n4 - 1), false);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) accum = __fmaf_rn(gw_of(k, u), k.w.v[u], accum);
+		}
+	}
+	for (uint32_t j = 4 * n4; j < len; ++j) accum = __fmaf_rn(gw_at(begin + j), vw[begin + j], accum);
+	// pass 2: the transmittance sweep
 	float T = 1.0f;
 	bool stopped = false;
-	for (uint32_t j = 0; j < len; ++j) {
-		const size_t i = begin + j;
-		const float a = alphas[i], w = vw[i];
-		float ga = 0.0f;
-		if (!stopped) {
-			if (T < eps) stopped = true;
-			else if (!(a < thre)) {
-				const float gw = gw_at(i);
-				ga = __fmaf_rn(gw, T, -accum) / fmaxf(1.0f - a, 1e-10f);
-				accum = __fmaf_rn(-gw, w, accum);
-				T *= (1.0f - a);
+	auto one = [&](float a, float w, float gw) -> float {
+		if (stopped) return 0.0f;
+		if (T < eps) { stopped = true; return 0.0f; }
+		if (a < thre) return 0.0f;
+		const float ga = __fmaf_rn(gw, T, -accum) / fmaxf(1.0f - a, 1e-10f);
+		accum = __fmaf_rn(-gw, w, accum);
+		T *= (1.0f - a);
+		return ga;
+	};
+	if (n4) {
+		Chunk nx = load(0, true);
+		for (uint32_t c = 0; c < n4; ++c) {
+			const Chunk k = nx;
+			nx = load(min(c + 1, n4 - 1), true);
+			F4u ga4, gt4, r0 = {}, r1 = {}, r2 = {};
+			float gc[12];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				ga4.v[u] = one(k.a.v[u], k.w.v[u], gw_of(k, u));
+				gt4.v[u] = cg.cd * k.w.v[u];
+				gc[3 * u] = k.w.v[u] * cg.g0; gc[3 * u + 1] = k.w.v[u] * cg.g1; gc[3 * u + 2] = k.w.v[u] * cg.g2;
+			}
+			const size_t at = begin + 4 * (size_t)c;
+			*reinterpret_cast<F4u *>(grad_alphas + at) = ga4;
+			if (grad_t) *reinterpret_cast<F4u *>(grad_t + at) = gt4;
+			if (RGB && grad_rgb) {
+#pragma unroll
+				for (int u = 0; u < 4; ++u) { r0.v[u] = gc[u]; r1.v[u] = gc[4 + u]; r2.v[u] = gc[8 + u]; }
+				*reinterpret_cast<F4u *>(grad_rgb + 3 * at) = r0;
+				*reinterpret_cast<F4u *>(grad_rgb + 3 * at + 4) = r1;
+				*reinterpret_cast<F4u *>(grad_rgb + 3 * at + 8) = r2;
 			}
 		}
-		grad_alphas[i] = ga;
+	}
+	for (uint32_t j = 4 * n4; j < len; ++j) {
+		const size_t i = begin + j;
+		const float w = vw[i];
+		grad_alphas[i] = one(alphas[i], w, gw_at(i));
 		if (grad_t) grad_t[i] = cg.cd * w;
 		if (RGB && grad_rgb) { grad_rgb[3 * i] = w * cg.g0; grad_rgb[3 * i + 1] = w * cg.g1; grad_rgb[3 * i + 2] = w * cg.g2; }
 	}
@@ -1056,6 +1111,7 @@ extern "C" int nr3d_pack_composite_fwd(uint32_t P, const float *alphas, const fl
 	const dim3 g = lpp ? dim3(div_up(P, pk::kBlock)) : pk::grid_for(P), b(pk::kBlock);
 #define NR3D_COMP_FWD(K) hipLaunchKernelGGL(K, g, b, 0, (hipStream_t)stream, P, alphas, t, rgb, pack_infos, ray_index, \
 	early_stop_eps, alpha_thre, normalize_depth, vw, mask, depth, rgb_out)
+	prof::Scope ps(NR3D_PROF_COMPOSITE_FWD, (hipStream_t)stream);
 	if (lpp) { if (rgb) NR3D_COMP_FWD(pk::k_composite_fwd_lpp<true>); else NR3D_COMP_FWD(pk::k_composite_fwd_lpp<false>); }
 	else     { if (rgb) NR3D_COMP_FWD(pk::k_composite_fwd<true>); else NR3D_COMP_FWD(pk::k_composite_fwd<false>); }
 #undef NR3D_COMP_FWD
@@ -1074,6 +1130,7 @@ extern "C" int nr3d_pack_composite_bwd(uint32_t P, const float *alphas, const fl
 	const dim3 g = lpp ? dim3(div_up(P, pk::kBlock)) : pk::grid_for(P), b(pk::kBlock);
 #define NR3D_COMP_BWD(K) hipLaunchKernelGGL(K, g, b, 0, (hipStream_t)stream, P, alphas, vw, t, rgb, pack_infos, ray_index, \
 	early_stop_eps, alpha_thre, normalize_depth, mask, depth, g_mask, g_depth, g_rgb, g_vw, grad_alphas, grad_t, grad_rgb)
+	prof::Scope ps(NR3D_PROF_COMPOSITE_BWD, (hipStream_t)stream);
 	if (lpp) { if (rgb) NR3D_COMP_BWD(pk::k_composite_bwd_lpp<true>); else NR3D_COMP_BWD(pk::k_composite_bwd_lpp<false>); }
 	else     { if (rgb) NR3D_COMP_BWD(pk::k_composite_bwd<true>); else NR3D_COMP_BWD(pk::k_composite_bwd<false>); }
 #undef NR3D_COMP_BWD

@@ -15,7 +15,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 from nr3d_lib_amd.graphics.nerf.nerf_utils import packed_alpha_to_vw, packed_volume_render_compression, tau_to_alpha
-from nr3d_lib_amd.graphics.pack_ops import packed_div, packed_sum
+from nr3d_lib_amd.graphics.pack_ops import packed_composite, packed_div, packed_sum
 from nr3d_lib_amd.profile import profile
 
 __all__ = ['nerf_ray_query_march_occ', 'composite_packed_volume_buffer']
@@ -125,21 +125,40 @@ def nerf_ray_query_march_occ(model, ray_tested: Dict[str, torch.Tensor], with_rg
     return volume_buffer, details
 
 
+# True: one fused kernel each way (graphics.pack_ops.packed_composite); False: the reference's op chain
+# (packed_alpha_to_vw -> packed_sum -> packed_div -> packed_sum x2), kept for A/B measurements and as a cross-check
+FUSED_COMPOSITE = True
+
+
 def composite_packed_volume_buffer(volume_buffer: dict, num_rays: int, with_rgb: bool = True,
                                    depth_use_normalized_vw: bool = True, device=None, dtype=torch.float32) -> dict:
     """alpha-composite a packed volume buffer into per-ray mask / depth / rgb (renderer_mixin.py:270-311):
     rays that were not hit keep zeros."""
     if device is None:
         device = volume_buffer['pack_infos_hit'].device if volume_buffer['type'] != 'empty' else 'cpu'
+    if volume_buffer['type'] == 'empty':
+        out = dict(mask_volume=torch.zeros(num_rays, device=device, dtype=dtype),
+                   depth_volume=torch.zeros(num_rays, device=device, dtype=dtype))
+        if with_rgb:
+            out['rgb_volume'] = torch.zeros(num_rays, 3, device=device, dtype=dtype)
+        return out
+    assert volume_buffer['type'] == 'packed', "composite_packed_volume_buffer: packed buffers only"
+    pi, hit = volume_buffer['pack_infos_hit'], volume_buffer['rays_inds_hit']
+    alpha = volume_buffer['opacity_alpha']
+    if FUSED_COMPOSITE and alpha.dtype == torch.float32 and dtype == torch.float32 and alpha.is_cuda:
+        rgb = volume_buffer['rgb'].view(-1, 3) if with_rgb else None
+        vw, mask, depth, rgb_out = packed_composite(alpha.view(-1), volume_buffer['t'].view(-1), rgb, pi, hit.long(), num_rays,
+                                                    normalize_depth=depth_use_normalized_vw)
+        volume_buffer['vw'] = vw
+        out = dict(mask_volume=mask, depth_volume=depth)
+        if with_rgb:
+            out['rgb_volume'] = rgb_out
+        return out
     out = dict(mask_volume=torch.zeros(num_rays, device=device, dtype=dtype),
                depth_volume=torch.zeros(num_rays, device=device, dtype=dtype))
     if with_rgb:
         out['rgb_volume'] = torch.zeros(num_rays, 3, device=device, dtype=dtype)
-    if volume_buffer['type'] == 'empty':
-        return out
-    assert volume_buffer['type'] == 'packed', "composite_packed_volume_buffer: packed buffers only"
-    pi, hit = volume_buffer['pack_infos_hit'], volume_buffer['rays_inds_hit']
-    volume_buffer['vw'] = vw = packed_alpha_to_vw(volume_buffer['opacity_alpha'], pi)
+    volume_buffer['vw'] = vw = packed_alpha_to_vw(alpha, pi)
     vw_sum = packed_sum(vw.view(-1), pi)
     out['mask_volume'][hit] = vw_sum
     w_depth = packed_div(vw, vw_sum + 1e-10, pi) if depth_use_normalized_vw else vw.view(-1)

@@ -15,7 +15,7 @@ import nr3d_lib_amd.bindings._pack_ops as _backend
 __all__ = [
     'packed_sort_inplace', 'packed_sort', 'packed_searchsorted', 'packed_searchsorted_packed_vals',
     'packed_sum', 'packed_mean', 'packed_cumprod', 'packed_cumsum', 'packed_diff', 'packed_backward_diff',
-    'packed_invert_cdf', 'packed_alpha_to_vw', 'packed_volume_render_compression',
+    'packed_invert_cdf', 'packed_alpha_to_vw', 'packed_volume_render_compression', 'packed_composite',
     'packed_add', 'packed_sub', 'packed_mul', 'packed_div', 'packed_matmul',
     'packed_gt', 'packed_geq', 'packed_lt', 'packed_leq', 'packed_eq', 'packed_neq',
     'interleave_arange_simple', 'interleave_arange', 'interleave_linstep', 'interleave_linspace',
@@ -282,6 +282,54 @@ def packed_alpha_to_vw(alpha, pack_infos, early_stop_eps: float = 1e-4, alpha_th
     if alpha.requires_grad:
         return PackedAlphaToVW.apply(alpha, pack_infos, early_stop_eps, alpha_thre)
     return _backend.packed_alpha_to_vw_forward(alpha, pack_infos, early_stop_eps, alpha_thre, False)[0]
+
+
+class PackedComposite(torch.autograd.Function):
+    """The renderer's alpha-composite chain (reference: nr3d_lib/models/fields/nerf/renderer_mixin.py:298-311 =
+    packed_alpha_to_vw -> packed_sum -> packed_div -> packed_sum(. * t) -> packed_sum(. * rgb)) as one kernel each way.
+    Outputs: (vw [S], mask [num_rays], depth [num_rays], rgb [num_rays, 3] | None); all four are differentiable with
+    respect to alpha, t and rgb."""
+
+    @staticmethod
+    def forward(ctx, alphas, t, rgb, pack_infos, rays_inds_hit, num_rays, early_stop_eps, alpha_thre, normalize_depth):
+        vw, mask, depth, rgb_out = _backend.packed_composite_forward(alphas, t, rgb, pack_infos, rays_inds_hit, num_rays,
+                                                                      early_stop_eps, alpha_thre, normalize_depth)
+        ctx.save_for_backward(alphas, t, rgb, pack_infos, rays_inds_hit, vw, mask, depth)
+        ctx.cfg = (early_stop_eps, alpha_thre, normalize_depth)
+        ctx.set_materialize_grads(False)
+        if rgb is None:
+            return vw, mask, depth
+        return vw, mask, depth, rgb_out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_vw, g_mask, g_depth, g_rgb=None):
+        alphas, t, rgb, pack_infos, rays_inds_hit, vw, mask, depth = ctx.saved_tensors
+        eps, thre, normalize = ctx.cfg
+        c = lambda g: None if g is None else g.contiguous()
+        ga, gt, gr = _backend.packed_composite_backward(alphas, vw, t, rgb, pack_infos, rays_inds_hit, eps, thre, normalize,
+                                                        mask, depth, c(g_mask), c(g_depth), c(g_rgb), c(g_vw),
+                                                        need_t=ctx.needs_input_grad[1],
+                                                        need_rgb=rgb is not None and ctx.needs_input_grad[2])
+        return ga if ctx.needs_input_grad[0] else None, gt, gr, None, None, None, None, None, None
+
+
+def packed_composite(alpha, t, rgb, pack_infos, rays_inds_hit=None, num_rays=None, early_stop_eps: float = 1e-4,
+                     alpha_thre: float = 0.0, normalize_depth: bool = True):
+    """fused alpha composite of a packed volume buffer -> (vw, mask, depth, rgb | None); see PackedComposite.
+    ``rays_inds_hit`` scatters the per-pack results into [num_rays] outputs (other rays stay zero)."""
+    if num_rays is None:
+        num_rays = pack_infos.shape[0]
+    alpha, t = alpha.contiguous().view(-1), t.contiguous().view(-1)
+    rgb = None if rgb is None else rgb.contiguous().view(-1, 3)
+    if rays_inds_hit is not None:
+        rays_inds_hit = rays_inds_hit.contiguous()
+    if alpha.requires_grad or t.requires_grad or (rgb is not None and rgb.requires_grad):
+        out = PackedComposite.apply(alpha, t, rgb, pack_infos, rays_inds_hit, int(num_rays), early_stop_eps, alpha_thre,
+                                    bool(normalize_depth))
+        return out if rgb is not None else (*out, None)
+    return _backend.packed_composite_forward(alpha, t, rgb, pack_infos, rays_inds_hit, int(num_rays), early_stop_eps,
+                                             alpha_thre, bool(normalize_depth))
 
 
 @torch.no_grad()

@@ -18,8 +18,12 @@ from nr3d_lib_amd.profile import profile
 __all__ = ['MLP', 'FCBlock', 'FusedMLPFunction']
 
 USE_FUSED = True                       # False: always the layer-by-layer path (A/B measurements, debugging)
-CACHE_PACKED = True                    # reuse the MFMA-ordered weight copy while the parameters' version counters stand still;
-                                       # code that edits parameters through `.data` (no version bump) should switch it off
+# Reuse of the MFMA-ordered weight copy between calls.  OFF by default: packing is one ~3 us kernel, and the only cheap
+# change detector -- the parameters' (data_ptr, _version) -- does not see in-place edits made through `.data`
+# (EMA swaps `p.data.copy_(shadow)`, weight clipping, `.data.normal_()` re-initialisation), after which a cached copy
+# would silently be stale.  Opt in for inference loops over frozen weights; `MLP.invalidate_packed()` (also called by
+# `train()` / `eval()` / `load_state_dict()`) drops the copy explicitly.
+CACHE_PACKED = False
 
 
 class FusedMLPFunction(torch.autograd.Function):
@@ -35,15 +39,18 @@ class FusedMLPFunction(torch.autograd.Function):
     def forward(ctx, desc, need, x, *params):
         from nr3d_lib_amd.bindings import _mlp
         ws, bs = list(params[0::2]), list(params[1::2])
-        # the packed copy is reused until a parameter is written (tensor version counters) -- e.g. the no-grad density
-        # query and the differentiable query of one training iteration, or every call of an inference loop
-        key = (need, tuple((p.data_ptr(), p._version) for p in params if p is not None))
-        cached = getattr(desc, '_packed_cache', None)
-        if CACHE_PACKED and cached is not None and cached[0] == key:
-            packed = cached[1]
-        else:
+        # opt-in (CACHE_PACKED): the packed copy is keyed on the parameters alone; a copy packed with the transposed
+        # layers (with_backward) also serves forward-only calls, a forward-only copy is upgraded when `need` first is True
+        packed = None
+        if CACHE_PACKED:
+            key = tuple((p.data_ptr(), p._version) for p in params if p is not None)
+            cached = getattr(desc, '_packed_cache', None)
+            if cached is not None and cached[0] == key and (cached[2] or not need):
+                packed = cached[1]
+        if packed is None:
             packed = _mlp.pack(desc, ws, bs, with_backward=need)
-            desc._packed_cache = (key, packed)
+            if CACHE_PACKED:
+                desc._packed_cache = (key, packed, bool(need))
         if need:
             ctx.save_for_backward(x, packed, *[p for p in params if p is not None])
             ctx.desc, ctx.has_bias = desc, [b is not None for b in bs]
@@ -131,6 +138,20 @@ class MLP(nn.Module):
     @property
     def device(self) -> torch.device:
         return self.layers[0].weight.device
+
+    def invalidate_packed(self):
+        """drop the cached MFMA-ordered weight copy (see CACHE_PACKED): call after editing parameters through `.data`"""
+        if self._desc:
+            self._desc._packed_cache = None
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
 
     def get_weight_reg(self, norm_type: float = 2.0):
         return torch.stack([p.norm(p=norm_type) for n, p in self.layers.named_parameters()])

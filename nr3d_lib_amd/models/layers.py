@@ -46,52 +46,79 @@ def get_nonlinearity(config: Optional[Union[str, dict]]):
     return _NL(nl, gain, _nop, _nop)
 
 
+def _as_dtype(dtype):
+    if dtype is None or isinstance(dtype, torch.dtype):
+        return dtype
+    return getattr(torch, str(dtype).split('.')[-1])
+
+
 class DenseLayer(nn.Module):
+    """``y = act((x W^T) g_w + b g_b)`` with fp32 parameters; ``dtype`` only selects the autocast type of the forward.
+
+    Behaviour of the reference's ``DenseLayer`` (nr3d_lib/models/layers.py:228-310), written from its contract:
+
+    * default initialisation is ``nn.Linear``'s -- ``W ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in))`` drawn first, then
+      ``b ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in))`` -- with ``W`` scaled by ``weight_init / lr_mul``, the bias bound by
+      ``bias_init / lr_mul``, and both multiplied by ``lr_mul`` again at run time (so ``lr_mul`` only changes the
+      effective learning rate);
+    * ``equal_lr`` (StyleGAN-style): ``W ~ U(-weight_init/lr_mul, +weight_init/lr_mul)``, run-time gain
+      ``lr_mul / sqrt(in_features)``;
+    * ``forward(x, max_channel=c)`` uses the first ``c`` input columns of ``W`` (progressive input widths) and -- like
+      the reference -- cuts the bias with the same bound."""
+
     def __init__(self, in_features: int, out_features: int, *, bias: bool = True,
                  activation: Union[str, dict, nn.Module] = None, should_init=True, equal_lr=False, lr_mul: float = 1,
                  weight_init: float = 1, bias_init: float = 1, dtype: Union[str, torch.dtype] = torch.float, device=None):
         super().__init__()
-        self.dtype = dtype if isinstance(dtype, torch.dtype) or dtype is None else getattr(torch, str(dtype).replace('torch.', ''))
         self.in_features, self.out_features, self.equal_lr = in_features, out_features, equal_lr
-        # parameters are always stored in fp32; `dtype` is only respected when forward
-        self.weight = nn.Parameter(torch.empty((out_features, in_features), device=device, dtype=torch.float))
-        self.bias = nn.Parameter(torch.empty(out_features, device=device, dtype=torch.float)) if bias else None
-        if isinstance(activation, (str, dict)):
-            activation = get_nonlinearity(activation).nl
-        self.activation = activation
-        self.weight_gain = self.bias_gain = 1
+        self.dtype = _as_dtype(dtype)
+        self.activation = get_nonlinearity(activation).nl if isinstance(activation, (str, dict)) else activation
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, dtype=torch.float32, device=device))
+        self.bias = nn.Parameter(torch.empty(out_features, dtype=torch.float32, device=device)) if bias else None
+        self.weight_gain, self.bias_gain = 1, 1
         if should_init:
-            if equal_lr:
-                bound = weight_init / lr_mul
-                init.uniform_(self.weight, -bound, bound)
-                self.weight_gain = lr_mul / np.sqrt(self.in_features)
-            else:                                   # nn.Linear.reset_parameters()
-                init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-                with torch.no_grad():
-                    self.weight *= (weight_init / lr_mul)
-                self.weight_gain = lr_mul
-            if self.bias is not None:
-                fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
-                bound = (1 / math.sqrt(fan_in) if fan_in > 0 else 0) * (bias_init / lr_mul)
-                init.uniform_(self.bias, -bound, bound)
-                self.bias_gain = lr_mul
+            self.reset_parameters(lr_mul=lr_mul, weight_init=weight_init, bias_init=bias_init)
+
+    @torch.no_grad()
+    def reset_parameters(self, lr_mul: float = 1, weight_init: float = 1, bias_init: float = 1):
+        fan_in = self.in_features
+        if self.equal_lr:
+            self.weight.uniform_(-weight_init / lr_mul, weight_init / lr_mul)
+            self.weight_gain = lr_mul / np.sqrt(fan_in)
+        else:
+            # nn.Linear: kaiming-uniform with a = sqrt(5), i.e. bound = sqrt(3) * sqrt(2 / (1 + 5)) / sqrt(fan_in)
+            bound = math.sqrt(3.0) * (math.sqrt(2.0 / 6.0) / math.sqrt(fan_in)) if fan_in > 0 else 0.0
+            self.weight.uniform_(-bound, bound).mul_(weight_init / lr_mul)
+            self.weight_gain = lr_mul
+        if self.bias is not None:
+            b = (1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0) * (bias_init / lr_mul)
+            self.bias.uniform_(-b, b)
+            self.bias_gain = lr_mul
 
     @property
     def device(self) -> torch.device:
         return self.weight.device
 
     def get_weight_reg(self, norm_type: float = 2.0):
-        return torch.stack([p.norm(p=norm_type) for n, p in self.named_parameters()])
+        return torch.stack([p.norm(p=norm_type) for p in self.parameters()])
+
+    def _effective(self, max_channel):
+        w, b = self.weight, self.bias
+        if max_channel is not None:
+            w = w[:, :max_channel]
+            b = None if b is None else b[:max_channel]
+        if self.weight_gain != 1:
+            w = w * self.weight_gain
+        if b is not None and self.bias_gain != 1:
+            b = b * self.bias_gain
+        return w, b
 
     def forward(self, x: torch.Tensor, max_channel: int = None):
-        with torch.autocast(device_type='cuda', dtype=self.dtype, enabled=self.dtype in (torch.float16, torch.bfloat16)):
-            weight = self.weight[:, :max_channel] if max_channel is not None else self.weight
-            bias = self.bias[:max_channel] if (max_channel is not None and self.bias is not None) else self.bias
-            if self.weight_gain == 1 and (self.bias is None or self.bias_gain == 1):
-                out = F.linear(x, weight, bias)
-            else:
-                out = F.linear(x, weight * self.weight_gain, None if bias is None else bias * self.bias_gain)
-            return out if self.activation is None else self.activation(out)
+        low_precision = self.dtype in (torch.float16, torch.bfloat16)
+        with torch.autocast(device_type='cuda', dtype=self.dtype, enabled=low_precision):
+            y = F.linear(x, *self._effective(max_channel))
+            return y if self.activation is None else self.activation(y)
 
     def extra_repr(self) -> str:
-        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, equal_lr={self.equal_lr}"
+        return (f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}, "
+                f"equal_lr={self.equal_lr}")

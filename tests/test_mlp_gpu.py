@@ -191,33 +191,82 @@ def test_second_order_through_the_fused_block(dev):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-5)
 
 
-def test_packed_weights_are_cached_until_a_parameter_changes(dev):
+def _layerwise(m, x):
+    ref = x
+    for i, l in enumerate(m.layers):
+        ref = torch.nn.functional.linear(ref, l.weight, l.bias)
+        ref = torch.relu(ref) if i + 1 < len(m.layers) else ref
+    return ref
+
+
+def test_edits_through_dot_data_are_seen_by_default(dev):
+    """`.data` writes do not bump tensor version counters (EMA swaps, weight clipping, re-initialisation): with the
+    default settings the fused block packs the weights on every call and cannot go stale"""
     from nr3d_lib_amd.bindings import _mlp
+    from nr3d_lib_amd.models.blocks import mlp as mlp_mod
+    assert mlp_mod.CACHE_PACKED is False
+    m = _net([32, 32, 8], "relu", None, True, dev, seed=7)
+    x = torch.randn(257, 32, device=dev)
+    with torch.no_grad():
+        y1 = m(x)
+        v0 = m.layers[0].weight._version
+        m.layers[0].weight.data.mul_(2.0)
+        m.layers[1].bias.data.copy_(torch.ones_like(m.layers[1].bias))
+        assert m.layers[0].weight._version == v0                           # the edit is invisible to the version counter
+        y2 = m(x)
+    assert not torch.equal(y1, y2)
+    torch.testing.assert_close(y2, _layerwise(m, x), rtol=1e-4, atol=1e-5)
+    xr = x.clone().requires_grad_(True)
+    m(xr).sum().backward()                                                 # the backward's packed copy is fresh too
+    xt = x.clone().requires_grad_(True)
+    _layerwise(m, xt).sum().backward()
+    torch.testing.assert_close(xr.grad, xt.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_opt_in_packed_weight_cache(dev):
+    """CACHE_PACKED = True: the packed copy is keyed on the parameters only -- a copy packed for a differentiable call also
+    serves no-grad calls, a forward-only copy is upgraded when gradients are first wanted; version bumps, train() / eval(),
+    load_state_dict() and invalidate_packed() drop it"""
+    from nr3d_lib_amd.bindings import _mlp
+    from nr3d_lib_amd.models.blocks import mlp as mlp_mod
     m = _net([32, 32, 8], "relu", None, True, dev, seed=7)
     x = torch.randn(257, 32, device=dev)
     calls = []
     orig = _mlp.pack
-    _mlp.pack = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    _mlp.pack = lambda *a, **k: (calls.append(k.get("with_backward")), orig(*a, **k))[1]
+    mlp_mod.CACHE_PACKED = True
     try:
         with torch.no_grad():
             y1 = m(x); y2 = m(x)
-            assert len(calls) == 1 and torch.equal(y1, y2)
-            m.layers[0].weight.mul_(2.0)                                  # in-place write bumps the version counter
-            y3 = m(x)
-        assert len(calls) == 2 and not torch.equal(y1, y3)
-        m(x).sum().backward()                                             # gradients wanted: packed again with the transposed layers
-        assert len(calls) == 3
-        torch.optim.SGD(m.parameters(), lr=0.1).step()
+        assert calls == [False] and torch.equal(y1, y2)
+        m(x).sum().backward()                                             # gradients wanted: upgraded to a with_backward copy
+        assert calls == [False, True]
         with torch.no_grad():
+            y3 = m(x)                                                     # ... which serves the forward-only call as well
+        assert calls == [False, True] and torch.equal(y1, y3)
+        with torch.no_grad():
+            m.layers[0].weight.mul_(2.0)                                  # in-place write bumps the version counter
             y4 = m(x)
+        assert len(calls) == 3 and not torch.equal(y1, y4)
+        m.layers[0].weight.data.mul_(0.5)                                 # invisible edit: the documented caveat ...
+        with torch.no_grad():
+            stale = m(x)
+            assert len(calls) == 3 and torch.equal(stale, y4)
+            m.invalidate_packed()                                         # ... and its remedy
+            y5 = m(x)
         assert len(calls) == 4
-        ref = x
-        for i, l in enumerate(m.layers):
-            ref = torch.nn.functional.linear(ref, l.weight, l.bias)
-            ref = torch.relu(ref) if i == 0 else ref
-        torch.testing.assert_close(y4, ref, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(y5, _layerwise(m, x), rtol=1e-4, atol=1e-5)
+        m.eval()
+        with torch.no_grad():
+            m(x)
+        assert len(calls) == 5
+        m.load_state_dict(m.state_dict())
+        with torch.no_grad():
+            m(x)
+        assert len(calls) == 6
     finally:
         _mlp.pack = orig
+        mlp_mod.CACHE_PACKED = False
 
 
 @pytest.mark.parametrize("name", ["plain", "ragged_out_relu"])

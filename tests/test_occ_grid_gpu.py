@@ -203,6 +203,16 @@ def test_update_occ_val_grid_bit_exact(oracle, dev):
     update_occ_val_grid_(g, t(pts), t(val), ema_decay=0.9)
     want = oracle.occ_update_grid(grid0, oracle.occ_gidx_from_pts(pts, res), val, 0.9)
     assert_equal(g, want, name="pts")
+    # voxel indices outside the grid are dropped (no out-of-bounds write), and a sample value of -0.0 counts as a sample
+    gi2 = gidx[:1000].copy()
+    gi2[::7, 0] = res[0]; gi2[3::7, 2] = -1
+    keep = (gi2 >= 0).all(1) & (gi2 < np.array(res)).all(1)
+    v2 = val[:1000].copy()
+    v2[keep.nonzero()[0][:50]] = -0.0
+    gneg = -np.abs(grid0) - 1.0                                  # every old value < -0.0: a -0.0 sample must win
+    g3 = t(gneg.copy())
+    update_occ_val_grid_idx_(g3, t(gi2), t(v2), ema_decay=0.5)
+    assert_equal(g3, oracle.occ_update_grid(gneg, gi2[keep], v2[keep], 0.5), name="out-of-range gidx dropped, -0.0 kept")
     # no samples: nothing changes; binarize incl. the mean rule
     g2 = t(grid0.copy())
     update_occ_val_grid_idx_(g2, t(gidx[:0]), t(val[:0]), ema_decay=0.5)

@@ -366,3 +366,119 @@ def test_octree_mark_consecutive_segments(oracle, dev):
     assert_equal(got_s, want_s, "mark_start"); assert_equal(got_e, want_e, "mark_end")
     assert want_s.sum() == want_e.sum() > (pinfo[:, 1] > 0).sum()            # some packs split into several runs
     assert hier.shape == (400, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fused composite (graphics.pack_ops.packed_composite) against the oracle's op CHAIN
+# (renderer_mixin.py:298-311: packed_alpha_to_vw -> packed_sum -> packed_div -> packed_sum(. * t) -> packed_sum(. * rgb))
+# ---------------------------------------------------------------------------------------------------------
+def _chain_forward(oracle, alpha, t, rgb, pi, eps, thre, normalize):
+    """the reference's chain on the oracle's pack ops, fp32 like the reference"""
+    vw = oracle.packed_alpha_to_vw_forward(alpha, pi, eps, thre, False)[0]
+    mask = oracle.packed_sum(vw, pi)
+    if normalize:
+        wn = oracle.packed_binary("div", vw, (mask + np.float32(1e-10)).astype(np.float32), pi)
+        depth = oracle.packed_sum((wn * t).astype(np.float32), pi)
+    else:
+        depth = oracle.packed_sum((vw * t).astype(np.float32), pi)
+    col = oracle.packed_sum((vw[:, None] * rgb).astype(np.float32), pi) if rgb is not None else None
+    return vw, mask, depth, col
+
+
+def _chain_backward(oracle, alpha, t, rgb, pi, eps, thre, normalize, vw, mask, g_mask, g_depth, g_rgb, g_vw):
+    """autograd of the chain written out (pack_ops.py:97-116 PackedSum, :293-392 PackedDiv, :261-283 PackedAlphaToVW),
+    in float64 for everything but the alpha_to_vw backward kernel itself"""
+    n = pi[:, 1]
+    rep = lambda a: np.repeat(a, n, axis=0)
+    s = mask.astype(np.float64) + 1e-10
+    gw = rep(g_mask.astype(np.float64))
+    if normalize:
+        wt = np.bincount(np.repeat(np.arange(len(n)), n), weights=vw.astype(np.float64) * t, minlength=len(n))
+        gw = gw + rep(g_depth / s) * t - rep(g_depth * wt / s ** 2)
+        g_t = rep(g_depth / s) * vw
+    else:
+        gw = gw + rep(g_depth.astype(np.float64)) * t
+        g_t = rep(g_depth.astype(np.float64)) * vw
+    g_c = None
+    if rgb is not None:
+        gw = gw + (rep(g_rgb.astype(np.float64)) * rgb).sum(1)
+        g_c = rep(g_rgb.astype(np.float64)) * vw[:, None]
+    if g_vw is not None:
+        gw = gw + g_vw
+    g_a = oracle.packed_alpha_to_vw_backward(vw, gw.astype(np.float32), alpha, pi, eps, thre)
+    return g_a, g_t, g_c
+
+
+def _composite_case(oracle, dev, P, pi, S, seed, eps, thre, normalize, with_rgb, scatter):
+    import nr3d_lib_amd.graphics.pack_ops as po
+    rng = np.random.default_rng(seed)
+    n_packs = pi.shape[0]
+    alpha = (0.99 * rng.uniform(0, 1, S) ** 2).astype(np.float32)        # alpha == 1 makes the reference's own backward
+    alpha[rng.random(S) < 0.1] = 0.0                                     # ill-conditioned (division by max(1-a, 1e-10))
+    t = np.sort(rng.uniform(0.5, 6.0, S)).astype(np.float32)
+    rgb = rng.uniform(0, 1, (S, 3)).astype(np.float32) if with_rgb else None
+    num_rays = n_packs + 37 if scatter else n_packs
+    hit = np.sort(rng.choice(num_rays, n_packs, replace=False)).astype(np.int64) if scatter else None
+    vw_r, mask_r, depth_r, col_r = _chain_forward(oracle, alpha, t, rgb, pi, eps, thre, normalize)
+    a_t = T(alpha, dev).requires_grad_(True)
+    t_t = T(t, dev).requires_grad_(True)
+    c_t = T(rgb, dev).requires_grad_(True) if with_rgb else None
+    vw, mask, depth, col = po.packed_composite(a_t, t_t, c_t, T(pi, dev), T(hit, dev) if scatter else None, num_rays,
+                                               early_stop_eps=eps, alpha_thre=thre, normalize_depth=normalize)
+    sel = (lambda a: a[torch.from_numpy(hit).to(dev)]) if scatter else (lambda a: a)
+    assert_equal(vw, vw_r, "vw")                                          # same serial transmittance chain
+    assert_close(sel(mask), mask_r, name="mask")
+    assert_close(sel(depth), depth_r, name="depth")
+    if with_rgb:
+        assert_close(sel(col), col_r, name="rgb")
+    if scatter:                                                           # rays that are not hit stay zero
+        miss = torch.ones(num_rays, dtype=torch.bool, device=dev)
+        miss[torch.from_numpy(hit).to(dev)] = False
+        assert not mask[miss].any() and not depth[miss].any()
+    g_mask = rng.standard_normal(n_packs).astype(np.float32)
+    g_depth = rng.standard_normal(n_packs).astype(np.float32)
+    g_rgb = rng.standard_normal((n_packs, 3)).astype(np.float32) if with_rgb else None
+    g_vw = (0.1 * rng.standard_normal(S)).astype(np.float32)
+    full = lambda g: (torch.zeros((num_rays,) + g.shape[1:], device=dev).index_copy_(0, torch.from_numpy(hit).to(dev), T(g, dev))
+                      if scatter else T(g, dev))
+    loss = (vw * T(g_vw, dev)).sum() + (mask * full(g_mask)).sum() + (depth * full(g_depth)).sum()
+    if with_rgb:
+        loss = loss + (col * full(g_rgb)).sum()
+    grads = torch.autograd.grad(loss, [a_t, t_t] + ([c_t] if with_rgb else []))
+    ga_r, gt_r, gc_r = _chain_backward(oracle, alpha, t, rgb, pi, eps, thre, normalize, vw_r, mask_r, g_mask, g_depth, g_rgb, g_vw)
+    # grad_alpha_j = (gw_j T_j - sum_{k>=j} gw_k w_k) / max(1 - alpha_j, 1e-10): the division amplifies the fp32 rounding of
+    # the numerator by up to 1 / (1 - alpha) = 100 here -- in the reference's chain just as much as in the fused kernel,
+    # which forms the same gw_j in a different (fma) order.  So the 1e-5 contract is checked on the numerator
+    # (1e-5 for the fused sums + 1e-5 for the chain's own rounding), and grad_alpha itself at 100 x that.
+    one_minus = np.maximum(1.0 - alpha.astype(np.float64), 1e-10)
+    assert_close(grads[0].double().cpu().numpy() * one_minus, ga_r.astype(np.float64) * one_minus, rel=2e-5, name="grad_alpha numerator")
+    assert_close(grads[0], ga_r, rel=2e-3, name="grad_alpha")
+    assert_close(grads[1], gt_r, name="grad_t")
+    if with_rgb:
+        assert_close(grads[2], gc_r, name="grad_rgb")
+
+
+@pytest.mark.parametrize("n_packs,hi", [(257, 300), (2500, 90)])           # wave-per-pack / lane-per-pack kernels
+@pytest.mark.parametrize("normalize,with_rgb,scatter", [(True, True, True), (False, True, False), (True, False, False)])
+def test_fused_composite_against_chain(oracle, dev, P, n_packs, hi, normalize, with_rgb, scatter):
+    rng = np.random.default_rng(41)
+    pi, S = random_packs(rng, n_packs, 0, hi, 0.1)
+    _composite_case(oracle, dev, P, pi, S, 5, 1e-4, 0.0, normalize, with_rgb, scatter)
+    _composite_case(oracle, dev, P, pi, S, 6, 1e-2, 0.02, normalize, with_rgb, scatter)
+
+
+def test_c3_composite_shape(oracle, dev, P):
+    """BASELINE configs[2]'s composite half at its stated shape: 4096 packs x <= 512 samples (~1.1 M samples), unfused ops
+    bit-exact against the oracle and the fused composite against the chain"""
+    rng = np.random.default_rng(7)
+    pi, S = random_packs(rng, 4096, 0, 512, 0.02)
+    alpha = (1 - np.exp(-10.0 * rng.random(S) * (2 * 3 ** 0.5 / 512))).astype(np.float32)      # sigma * delta of configs[2]
+    alpha[rng.random(S) < 0.05] = np.float32(0.9)
+    w, _, _ = P.packed_alpha_to_vw_forward(T(alpha, dev), T(pi, dev), 1e-4, 0.0, False)
+    rw, _, _ = oracle.packed_alpha_to_vw_forward(alpha, pi, 1e-4, 0.0, False)
+    assert_equal(w, rw, "weights")
+    gw = rng.standard_normal(S).astype(np.float32)
+    ga = P.packed_alpha_to_vw_backward(T(rw, dev), T(gw, dev), T(alpha, dev), T(pi, dev), 1e-4, 0.0)
+    assert_equal(ga, oracle.packed_alpha_to_vw_backward(rw, gw, alpha, pi, 1e-4, 0.0), "grad_alphas")
+    assert_close(P.packed_sum(T(rw, dev), T(pi, dev)), oracle.packed_sum(rw, pi), name="packed_sum")
+    _composite_case(oracle, dev, P, pi, S, 8, 1e-4, 0.0, True, True, True)

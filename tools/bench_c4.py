@@ -47,9 +47,32 @@ def main():
     timed("bwd_bwd_dx", lambda: _lotd.lod_bwd_bwd_input(meta, v, dL_dy, x, params, j, need_dLdinput_ddLdoutput=False,
                                                       need_dLdinput_dparams=False, need_dLdinput_dinput=True))
     tot = sum(ops.values())
+    # FACTORED algorithmic bytes per point (element-granular, no cache credit): a point touches every DISTINCT table entry
+    # once -- Dense 8 entries, VM 3 planes x 4 + 3 lines x 2 = 18, CP 3 lines x 2 = 6 entries of F floats per level
+    # (SURVEY 8(d) quotes the un-factored count, one gather per corner and factor: 5 632 B instead of 1 936 B here).
+    ent = {"Dense": 8, "VM": 18, "CP": 6}
+    G = sum(ent[t] * f * 4 for t, f in zip(TYPES, FEATS))                       # all gathers            1 936 B
+    Gp = sum(ent[t] * f * 4 for t, f in zip(TYPES, FEATS) if t != "Dense")      # product-type factors   1 680 B
+    E4 = 4 * meta.n_encoded_dims
+    model = {"fwd": 12 + G + E4,                               # x, gathers, y (the stored Jacobian, 3 E4, is not credited)
+             "bwd_dx": E4 + G + 12,                            # dL_dy, the gather a fused dL/dx needs, dL_dx
+             "bwd_dparam": 12 + E4 + Gp + 2 * G,               # x, dL_dy, other factors of product levels, scatter as RMW
+             "bwd_bwd_ddLdy": 12 + G + E4,
+             "bwd_bwd_dparam": 24 + E4 + Gp + 2 * G,
+             "bwd_bwd_dx": 24 + E4 + G + 12}
+    peak = 8000.0
+    per = {k: {"ms": ops[k], "algorithmic_bytes_per_point": model[k],
+               "achieved": round(model[k] * N / (ops[k] * 1e-3) / 1e9, 1),
+               "frac": round(model[k] * N / (ops[k] * 1e-3) / 1e9 / peak, 4)} for k in ops}
+    tb = sum(model.values())
     print(json.dumps({"workload": f"configs[3] mixed LoTD, 2^{a.log2_points} points", "n_params": meta.n_params,
                       "n_encoded_dims": meta.n_encoded_dims, "ms": ops, "ms_total": round(tot, 3),
-                      "mpoints_per_s": round(N / tot / 1e3, 3)}))
+                      "mpoints_per_s": round(N / tot / 1e3, 3),
+                      "roofline": {"bound": "hbm", "unit": "GB/s", "peak": peak, "model": "factored (distinct table entries per point)",
+                                   "algorithmic_bytes_per_point": tb, "achieved": round(tb * N / (tot * 1e-3) / 1e9, 1),
+                                   "frac": round(tb * N / (tot * 1e-3) / 1e9 / peak, 4), "per_pass": per,
+                                   "note": "the 8 MiB of tables are cache resident; HBM carries x, dL_dy, y, the Jacobian and "
+                                           "the scatter records"}}))
 
 
 if __name__ == "__main__":
