@@ -79,9 +79,12 @@ def pmc_traffic_bytes(kernels, launches=None):
     return int(total)
 
 
-def cpu_baseline(cfg, n_sample_log2=17, min_seconds=10.0):
-    """the CPU oracle (oracle/, a C restatement with OpenMP -- kind 'port') on a bounded sample of the workload"""
+def cpu_baseline(cfg, n_sample_log2=17, min_seconds=10.0, c3=None):
+    """the CPU oracle (oracle/, a C restatement with OpenMP -- kind 'port') on a bounded sample of the workload.
+    `c3` = (scene tensors, n_rays, step, seconds): the march + composite leg of the metric instead (configs[2])"""
     import oracle
+    if c3 is not None:
+        return _cpu_baseline_c3(oracle, *c3)
     m = oracle.lotd_create_meta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
     rng = np.random.default_rng(42)
     n = 1 << n_sample_log2
@@ -101,6 +104,45 @@ def cpu_baseline(cfg, n_sample_log2=17, min_seconds=10.0):
     return dict(value=round(reps * n / el / 1e6, 4), unit="Mpoints/s", cores=os.cpu_count(), kind="port",
                 sample=f"{reps} x 2^{n_sample_log2} points, same 16-level meta, fwd+dydx + dL/dx + dL/dparam "
                        f"({el:.1f} s of OpenMP CPU work)")
+
+
+def _cpu_baseline_c3(oracle, scene, n, step, seconds):
+    """configs[2] on the host: the oracle's marcher (C, OpenMP) + the reference's pack-op chain (alpha_to_vw, packed_sum x3,
+    packed_div; numpy glue) forward and backward.  Returns (grid probes of one march, samples, cpu_baseline dict)."""
+    o_c, d_c, near_c, far_c, roi_c, grid_c = scene
+    args_np = [t.numpy() for t in (o_c, d_c, near_c, far_c, roi_c)] + [grid_c.numpy()]
+    pi_r, ts_r, te_r, ridx_r, gidx_r, probes = oracle.ray_marching(*args_np, 0, step, 1e10, 0.0, 512, True, return_probes=True)
+    S_r = ts_r.shape[0]
+    rng = np.random.default_rng(8)
+    sigma = (10.0 * rng.random(S_r)).astype(np.float32)
+    rgb = rng.random((S_r, 3), dtype=np.float32)
+    gm, gd, gc = (rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32),
+                  rng.standard_normal((n, 3)).astype(np.float32))
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        pi_r, ts_r, te_r, ridx_r, gidx_r = oracle.ray_marching(*args_np, 0, step, 1e10, 0.0, 512, True)
+        pil = pi_r.astype(np.int64)
+        tt = ts_r[:, 0]
+        alpha = (1 - np.exp(-sigma * (te_r - ts_r)[:, 0])).astype(np.float32)
+        vw = oracle.packed_alpha_to_vw_forward(alpha, pil, 1e-4, 0.0, False)[0]
+        mask = oracle.packed_sum(vw, pil)
+        wn = oracle.packed_binary("div", vw, (mask + np.float32(1e-10)).astype(np.float32), pil)
+        depth = oracle.packed_sum(wn * tt, pil)
+        col = oracle.packed_sum(vw[:, None] * rgb, pil)
+        cnt = pil[:, 1]
+        rep = lambda a: np.repeat(a, cnt, axis=0)
+        s_ = mask + np.float32(1e-10)
+        gw = rep(gm) + rep(gd / s_) * tt - rep(gd * depth / s_) + (rep(gc) * rgb).sum(1)
+        ga = oracle.packed_alpha_to_vw_backward(vw, gw.astype(np.float32), alpha, pil, 1e-4, 0.0)
+        g_t, g_c = rep(gd / s_) * vw, rep(gc) * vw[:, None]
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 1000:
+            break
+    base = dict(value=round(reps * n / el / 1e6, 4), unit="Mrays/s", cores=os.cpu_count(), kind="port",
+                sample=f"{reps} x {n} rays: the oracle's marcher (C, OpenMP) + the pack-op chain "
+                       f"(alpha_to_vw, packed_sum x3, packed_div; numpy glue) fwd+bwd, {el:.1f} s of CPU work")
+    return int(probes), int(S_r), base
 
 
 def _c3_scene(side):
@@ -183,10 +225,7 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
                launches_per_iter="march 2 (count + emit) + scan 3, composite 1 + 1")
     if cpu_seconds > 0:
         # the oracle's marcher counts the grid probes of the byte model, and is the CPU baseline next to the chain
-        import oracle
-        args_np = [t.numpy() for t in (o_c, d_c, near_c, far_c, roi_c)] + [grid_c.numpy()]
-        pi_r, ts_r, te_r, ridx_r, gidx_r, probes = oracle.ray_marching(*args_np, 0, step, 1e10, 0.0, 512, True, return_probes=True)
-        S_r = ts_r.shape[0]
+        probes, S_r, base = cpu_baseline(None, c3=((o_c, d_c, near_c, far_c, roi_c, grid_c), n, step, cpu_seconds))
         b_march = 32 * n + 8 * n + 16 * S_r + probes
         b_fwd = 24 * S_r + 44 * n
         b_bwd = 44 * S_r + 52 * n
@@ -199,35 +238,7 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
                                                    achieved=round(bb / (kus[k] * 1e-6) / 1e9, 2))
                                            for k, bb in zip(names, (b_march, b_fwd, b_bwd))},
                                note="launch / latency bound at this size (SURVEY 8d): fraction for information")
-        rng = np.random.default_rng(8)
-        sigma = (10.0 * rng.random(S_r)).astype(np.float32)
-        rgb = rng.random((S_r, 3), dtype=np.float32)
-        gm, gd, gc = (rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32),
-                      rng.standard_normal((n, 3)).astype(np.float32))
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            pi_r, ts_r, te_r, ridx_r, gidx_r = oracle.ray_marching(*args_np, 0, step, 1e10, 0.0, 512, True)
-            pil = pi_r.astype(np.int64)
-            tt = ts_r[:, 0]
-            alpha = (1 - np.exp(-sigma * (te_r - ts_r)[:, 0])).astype(np.float32)
-            vw = oracle.packed_alpha_to_vw_forward(alpha, pil, 1e-4, 0.0, False)[0]
-            mask = oracle.packed_sum(vw, pil)
-            wn = oracle.packed_binary("div", vw, (mask + np.float32(1e-10)).astype(np.float32), pil)
-            depth = oracle.packed_sum(wn * tt, pil)
-            col = oracle.packed_sum(vw[:, None] * rgb, pil)
-            cnt = pil[:, 1]
-            rep = lambda a: np.repeat(a, cnt, axis=0)
-            s_ = mask + np.float32(1e-10)
-            gw = rep(gm) + rep(gd / s_) * tt - rep(gd * depth / s_) + (rep(gc) * rgb).sum(1)
-            ga = oracle.packed_alpha_to_vw_backward(vw, gw.astype(np.float32), alpha, pil, 1e-4, 0.0)
-            g_t, g_c = rep(gd / s_) * vw, rep(gc) * vw[:, None]
-            reps += 1
-            el = time.perf_counter() - t0
-            if el >= cpu_seconds or reps >= 1000:
-                break
-        out["cpu_baseline"] = dict(value=round(reps * n / el / 1e6, 4), unit="Mrays/s", cores=os.cpu_count(), kind="port",
-                                   sample=f"{reps} x {n} rays: the oracle's marcher (C, OpenMP) + the pack-op chain "
-                                          f"(alpha_to_vw, packed_sum x3, packed_div; numpy glue) fwd+bwd, {el:.1f} s of CPU work")
+        out["cpu_baseline"] = base
     return out
 
 
