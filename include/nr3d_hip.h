@@ -144,6 +144,20 @@ int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_d
                                 int32_t min_level, int32_t max_level, void *dL_dparam, void *workspace,
                                 uint64_t workspace_bytes, void *stream);
 
+/* Native half-parameter storage, the reference's (float, half, float) type combination (<input, param, compute>,
+ * csrc/lotd/include/lotd/lotd_encoding.h:1501-1504; PARAM_T accumulators lotd_encoding.h:72): x and dy_dx float, params /
+ * y / dL_dy / dL_dparam __half, arithmetic in fp32.  nr3d_lotd_half_params_ok: 1 when nr3d_lotd_fwd (param_dtype
+ * NR3D_F16: y is __half too), nr3d_lotd_bwd_dx (param_dtype NR3D_F16: dL_dy is __half, contiguous [N, E]) and
+ * nr3d_lotd_bwd_dparam_typed serve this meta without any whole-table conversion -- unbatched 3-D Dense/Hash metas with
+ * 2-feature pseudo levels; otherwise the caller converts to fp32.  Unlike the reference's __half2 atomics the parameter
+ * gradient is accumulated exactly and rounded to half once. */
+int nr3d_lotd_half_params_ok(const nr3d_lotd_meta_t *meta, int batched);
+/* first-order dL/dparam with explicit dtypes: grad_dtype of dL_dy (any strides; F32 for the feature-major copy that
+ * nr3d_lotd_bwd_dx leaves), out_dtype of dL_dparam (ZERO-INIT by the caller); workspace as nr3d_lotd_bwd_dparam. */
+int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points, int grad_dtype,
+                               const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,
+                               int out_dtype, void *dL_dparam, void *workspace, uint64_t workspace_bytes, void *stream);
+
 /* lod_bwd_bwd_input (lotd_torch_api.cu:575-729), three independent outputs:
  * (i)  dL_ddLdy[i, e] = sum_d dL_ddLdx[i, d] * dy_dx[i, e, d]      (lotd_encoding.h:1703-1727) */
 int nr3d_lotd_bwd_bwd_ddLdy(const nr3d_lotd_meta_t *meta, uint32_t n_points, int x_dtype, int param_dtype,

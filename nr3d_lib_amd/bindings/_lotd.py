@@ -242,6 +242,16 @@ def _f32c(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
+NATIVE_HALF = True       # False: half params always go through fp32 copies (A/B measurements)
+
+
+def _native_half(meta, params, batched):
+    """the kernels read __half params / dL_dy and write __half y / dL_dparam themselves ((float, half, float) type
+    combination, lotd_encoding.h:1501-1504): no whole-table conversion per call"""
+    return (NATIVE_HALF and params.dtype == torch.float16 and not batched and params.data_ptr() % 4 == 0
+            and bool(H.lib().nr3d_lotd_half_params_ok(C.byref(meta._cmeta()), C.c_int(0))))
+
+
 def _strides2(t):
     return t.stride(0), t.stride(1)
 
@@ -295,10 +305,14 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
     if max_level <= -1:  # lotd_torch_api.cu:294-297
         return (torch.zeros((N, E), dtype=params.dtype, device=params.device),
                 torch.zeros((N, E * D), dtype=input.dtype, device=input.device))
-    x32, p32 = _f32c(input.detach()), _f32c(params.detach())
+    batched = batch_inds is not None or batch_offsets is not None or bds != 0
+    native = _native_half(m, params, batched)
+    x32 = _f32c(input.detach())
+    p32 = params.detach() if native else _f32c(params.detach())
+    pcode = H.F16 if native else H.F32
     dev = input.device
     with torch.cuda.device(dev):
-        y_store = torch.empty((E, N), dtype=torch.float32, device=dev)
+        y_store = torch.empty((E, N), dtype=torch.float16 if native else torch.float32, device=dev)
         y = y_store.t()
         dy_dx = None
         if need_input_grad:
@@ -312,11 +326,11 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
             dsn = dse = 0
         with _Prof(m, f"LoTD{D}-fwd" + ("-grad" if need_input_grad else ""), N):
             H.check(H.lib().nr3d_lotd_fwd(
-                C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
+                C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(pcode),
                 H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds), H.i32(max_level),
                 H.ptr(y_store), H.i64(y.stride(0)), H.i64(y.stride(1)),
                 H.ptr(dy_dx), H.i64(dsn), H.i64(dse), H.stream_of(input)))
-    if params.dtype != torch.float32:
+    if y.dtype != params.dtype:
         y = y.to(params.dtype)
     if dy_dx is not None and input.dtype != torch.float32:
         dy_dx = dy_dx.to(input.dtype)
@@ -356,19 +370,24 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
             if dy_dx is None:
                 raise RuntimeError("LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.")
             dL_dx = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        batched = batch_inds is not None or batch_offsets is not None or bds != 0
+        # (float, half, float): half dL_dy is read and half dL_dparam written by the kernels themselves when the meta
+        # qualifies and dL_dy is a contiguous [N, E] tensor; dL_dparam then needs no cast and is allocated as half
+        native = (_native_half(m, params, batched) and level_buckets is None and USE_BINNED_DPARAM and input.dtype == torch.float32
+                  and dL_dy.is_contiguous() and E % 4 == 0 and dL_dy.data_ptr() % 8 == 0 and N > 0 and max_level > -1)
         if need_param_grad:
-            dL_dparam = torch.zeros((params.shape[0],), dtype=torch.float32, device=dev)
+            dL_dparam = torch.zeros((params.shape[0],), dtype=torch.float16 if native else torch.float32, device=dev)
         if max_level <= -1 or not (need_input_grad or need_param_grad) or (N == 0 and need_param_grad):
             if need_param_grad and level_buckets is not None and on_bucket is not None:
                 for k, (lo, hi) in enumerate(level_buckets):     # every bucket is announced (collectives stay matched)
                     on_bucket(k, dL_dparam[m.level_offsets[int(lo)]:m.level_offsets[min(int(hi), m.n_levels - 1) + 1]])
             return (_cast(dL_dx, input.dtype), _cast(dL_dparam, params.dtype))
-        g32 = _f32c(dL_dy.detach())
+        g32 = dL_dy.detach() if native else _f32c(dL_dy.detach())
+        gcode = H.F16 if native else H.F32
         gsn, gse = _strides2(g32)
         st = H.stream_of(input)
         tag = ("dx" if need_input_grad else "") + ("dp" if need_param_grad else "")
         with _Prof(m, f"LoTD{D}-bwd-{tag}", N):
-            batched = batch_inds is not None or batch_offsets is not None or bds != 0
             gT = None
             if need_input_grad and N > 0:
                 j, jsn, jse = _jac_view(dy_dx.detach(), N, E, D)
@@ -378,9 +397,16 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                         and g32.data_ptr() % 16 == 0):
                     gT = torch.empty((E, N), dtype=torch.float32, device=dev)
                 H.check(H.lib().nr3d_lotd_bwd_dx(
-                    C.byref(m._cmeta()), H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(g32), H.i64(gsn),
+                    C.byref(m._cmeta()), H.u32(N), C.c_int(H.F32), C.c_int(gcode), H.ptr(g32), H.i64(gsn),
                     H.i64(gse), H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), H.ptr(gT), st))
-            if need_param_grad and N > 0:
+            if need_param_grad and N > 0 and native:
+                ws, wsb = _dparam_workspace(m, N, dev, 1)
+                if gT is not None:
+                    g32, gsn, gse, gcode = gT, 1, N, H.F32
+                H.check(H.lib().nr3d_lotd_bwd_dparam_typed(
+                    C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(gcode), H.ptr(g32), H.i64(gsn), H.i64(gse),
+                    H.ptr(_f32c(input.detach())), H.i32(max_level), C.c_int(H.F16), H.ptr(dL_dparam), H.ptr(ws), C.c_uint64(wsb), st))
+            elif need_param_grad and N > 0:
                 x32, p32 = _f32c(input.detach()), _f32c(params.detach())
                 nbat = _n_batches(m, p32, batch_offsets, batched)
                 ws, wsb = _dparam_workspace(m, N, dev, nbat)

@@ -271,10 +271,24 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 // =============================================================================================
 constexpr int kPlPts = kBlock / 2;                 // points per block
 
-template <bool DYDX>
+// one table entry's feature pair as floats; PT = float (8 bytes) or __half (4 bytes: the (float, half, float) type
+// combination of the reference, lotd_encoding.h:1501-1504 -- no whole-table conversion pass, half the table bytes)
+template <typename PT> __device__ __forceinline__ float2 load_pair(const char *p);
+template <> __device__ __forceinline__ float2 load_pair<float>(const char *p) { return *reinterpret_cast<const float2 *>(p); }
+template <> __device__ __forceinline__ float2 load_pair<__half>(const char *p) { return __half22float2(*reinterpret_cast<const __half2 *>(p)); }
+template <typename YT> __device__ __forceinline__ void store_nt(YT *p, float v);
+template <> __device__ __forceinline__ void store_nt<float>(float *p, float v) { __builtin_nontemporal_store(v, p); }
+template <> __device__ __forceinline__ void store_nt<__half>(__half *p, float v) {
+	// the value is the fp32 result rounded to half (what the fp32 kernel + a cast gives): keep the compiler from fusing the
+	// last fma with the conversion (v_fma_mixlo_f16 rounds the exact fma once, i.e. differently on fp32 -> half ties)
+	asm volatile("" : "+v"(v));
+	__builtin_nontemporal_store(__half_as_ushort(__float2half(v)), reinterpret_cast<unsigned short *>(p));
+}
+
+template <bool DYDX, typename PT>
 __global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                          int32_t max_level, uint32_t smooth, const float *__restrict__ x,
-                                                         const float *__restrict__ params, float *__restrict__ y, int64_t y_sn,
+                                                         const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
                                                          int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
 	constexpr int D = 3;
 	uint32_t q, chunk;
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lot
 	float out_y = 0.0f, out_g[D] = {0.0f, 0.0f, 0.0f};
 	if ((int32_t)level <= max_level) {
 		const Lvl L = load_level(md, level);
-		const float *__restrict__ grid = params + L.off;
+		const PT *__restrict__ grid = params + L.off;
 		float xp[D];
 #pragma unroll
 		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
@@ -318,10 +332,10 @@ __global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lot
 			}
 		}
 		const char *__restrict__ base = reinterpret_cast<const char *>(grid + foff0);
-		const uint32_t stride = L.F * 4u;
+		const uint32_t stride = L.F * (uint32_t)sizeof(PT);
 #pragma unroll
 		for (int m = 0; m < 4; ++m)                              // all four gathers first: four requests in flight per lane
-			t[m] = *reinterpret_cast<const float2 *>(base + e[m] * stride);
+			t[m] = load_pair<PT>(base + e[m] * stride);
 #pragma unroll
 		for (uint32_t m = 0; m < 4; ++m) {
 			// val[k] = corner k of feature `side`.  Even lanes (side 0) own the side-0 corner: lo = own x, hi = partner's x;
@@ -347,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lot
 		}
 	}
 	const uint32_t col = q * 2u + side;
-	__builtin_nontemporal_store(out_y, &y[(int64_t)i * y_sn + (int64_t)col * y_se]);
+	store_nt<PT>(&y[(int64_t)i * y_sn + (int64_t)col * y_se], out_y);
 	if (DYDX) {
 		float *dst = dydx + (int64_t)i * d_sn + (int64_t)col * d_se;
 #pragma unroll
@@ -366,17 +380,17 @@ constexpr int kLdsThreads = 1024;
 constexpr uint32_t kLdsPts = 4096;                 // points per workgroup
 constexpr uint32_t kLdsMaxBytes = 96 * 1024;       // table bytes a level may have to be staged
 
-template <bool DYDX>
+template <bool DYDX, typename PT>
 __global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N, uint32_t q,
                                                          uint32_t smooth, const float *__restrict__ x,
-                                                         const float *__restrict__ params, float *__restrict__ y, int64_t y_sn,
+                                                         const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
                                                          int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
 	constexpr int D = 3, G = 2;
 	extern __shared__ __attribute__((aligned(16))) float2 tab[];
 	const uint32_t level = meta_level_of(md, q);
 	const Lvl L = load_level(md, level);
-	const float2 *__restrict__ src = reinterpret_cast<const float2 *>(params + L.off);
-	for (uint32_t e = threadIdx.x; e < L.size; e += kLdsThreads) tab[e] = src[e];
+	const char *__restrict__ src = reinterpret_cast<const char *>(params + L.off);
+	for (uint32_t e = threadIdx.x; e < L.size; e += kLdsThreads) tab[e] = load_pair<PT>(src + (size_t)e * (2 * sizeof(PT)));
 	__syncthreads();
 	const uint32_t out0 = q * G;
 	const uint32_t i0 = blockIdx.x * kLdsPts;
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t 
 				}
 		}
 #pragma unroll
-		for (int f = 0; f < G; ++f) __builtin_nontemporal_store(out_y[f], &y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se]);
+		for (int f = 0; f < G; ++f) store_nt<PT>(&y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se], out_y[f]);
 		if (DYDX) {
 #pragma unroll
 			for (int f = 0; f < G; ++f) {
@@ -707,8 +721,8 @@ __global__ __launch_bounds__(kBlock) void k_contract_dx(uint32_t N, uint32_t E, 
 // Same contraction for a row-major dL/dy ([N, E], the layout autograd hands over): a lane reading its own row
 // touches one cache line per lane and instruction, so the block first transposes its 256 x 32 tile of dL/dy through
 // LDS (coalesced 16-byte reads), then streams the feature-major Jacobian.  Same summation order as above.
-template <int D>
-__global__ __launch_bounds__(kBlock) void k_contract_dx_rowmajor(uint32_t N, uint32_t E, const float *__restrict__ dL_dy,
+template <int D, typename GT>
+__global__ __launch_bounds__(kBlock) void k_contract_dx_rowmajor(uint32_t N, uint32_t E, const GT *__restrict__ dL_dy,
                                                                  const float *__restrict__ dydx, int64_t d_sn,
                                                                  int64_t d_se, float *__restrict__ dL_dx,
                                                                  float *__restrict__ dL_dy_T) {
@@ -726,14 +740,21 @@ __global__ __launch_bounds__(kBlock) void k_contract_dx_rowmajor(uint32_t N, uin
 			for (uint32_t v = threadIdx.x; v < kBlock * TE / 4; v += kBlock) {   // 8 lanes x float4 per point row
 				const uint32_t p = v >> 3, e4 = (v & 7u) * 4u;
 				if (p < n_here) {
-					const float4 t = *reinterpret_cast<const float4 *>(dL_dy + (size_t)(i0 + p) * E + e0 + e4);
+					float4 t;
+					if constexpr (sizeof(GT) == 4) {
+						t = *reinterpret_cast<const float4 *>(dL_dy + (size_t)(i0 + p) * E + e0 + e4);
+					} else {                            // half gradients ((float, half, float) type combination): 8-byte reads
+						const __half2 *h = reinterpret_cast<const __half2 *>(dL_dy + (size_t)(i0 + p) * E + e0 + e4);
+						const float2 a = __half22float2(h[0]), b = __half22float2(h[1]);
+						t = make_float4(a.x, a.y, b.x, b.y);
+					}
 					tile[e4][p] = t.x; tile[e4 + 1][p] = t.y; tile[e4 + 2][p] = t.z; tile[e4 + 3][p] = t.w;
 				}
 			}
 		} else {
 			for (uint32_t v = threadIdx.x; v < kBlock * te; v += kBlock) {
 				const uint32_t p = v / te, e = v - p * te;
-				if (p < n_here) tile[e][p] = dL_dy[(size_t)(i0 + p) * E + e0 + e];
+				if (p < n_here) tile[e][p] = to_f32<GT>(dL_dy[(size_t)(i0 + p) * E + e0 + e]);
 			}
 		}
 		__syncthreads();
@@ -909,10 +930,10 @@ static uint32_t lds_stage_min_points() {
 	return (uint32_t)v;
 }
 
-static int check_common(const nr3d_lotd_meta_t *m, const void *meta_dev, int x_dtype, int p_dtype) {
+static int check_common(const nr3d_lotd_meta_t *m, const void *meta_dev, int x_dtype, int p_dtype, bool half_params_ok = false) {
 	NR3D_CHECK(m != nullptr, "LoTD: meta is NULL");
 	NR3D_CHECK(meta_dev != nullptr, "LoTD: meta_dev (device copy of the meta) is NULL");
-	NR3D_CHECK(x_dtype == NR3D_F32 && p_dtype == NR3D_F32,
+	NR3D_CHECK(x_dtype == NR3D_F32 && (p_dtype == NR3D_F32 || (half_params_ok && p_dtype == NR3D_F16)),
 	           "LoTD: kernels compute in f32; convert half inputs/params on the caller side (got x=%d, params=%d)",
 	           x_dtype, p_dtype);
 	NR3D_CHECK(m->n_dims_to_encode >= 2 && m->n_dims_to_encode <= 4, "LoTD: `n_dims_to_encode` must be 2/3/4");
@@ -949,31 +970,32 @@ static int check_common(const nr3d_lotd_meta_t *m, const void *meta_dev, int x_d
 using namespace nr3d;
 using namespace nr3d::lotd;
 
-extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
-                             int param_dtype, const void *x, const void *params, const int64_t *batch_inds,
-                             const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level, void *y,
-                             int64_t y_sn, int64_t y_se, void *dy_dx, int64_t d_sn, int64_t d_se, void *stream) {
-	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
-	if (N == 0) return 0;
-	NR3D_CHECK(x && params && y, "LoTD::fwd: NULL tensor pointer");
-	uint32_t n_blocks;
-	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
-	const uint32_t G = meta->n_feat_per_pseudo_lvl;
-	// vector gathers need every corner address G*4-byte aligned: base pointer aligned and no caller-chosen offsets
-	const uint32_t vec_ok = (((uintptr_t)params % (G >= 4 ? 16 : 8)) == 0 && batch_offsets == nullptr) ? 1u : 0u;
-	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
-	hipStream_t st = (hipStream_t)stream;
-	const bool dh = meta->c_hash_only != 0;
-	// small Dense levels out of LDS (k_fwd_lds): unbatched 3-D calls with enough points to amortise the table copies
+// the two-lanes-per-point forward (+ LDS-staged coarse levels) applies: 3-D Dense/Hash meta, 2-feature pseudo levels,
+// unbatched, 32-bit byte offsets inside every level
+static bool pairlane_meta_ok(const nr3d_lotd_meta_t *meta) {
+	if (!meta->c_hash_only || meta->n_dims_to_encode != 3 || meta->n_feat_per_pseudo_lvl != 2) return false;
+	for (uint32_t l = 0; l < meta->n_levels; ++l)
+		if ((uint64_t)meta->levels[l].size * meta->levels[l].n_feats * 4 >= (1ull << 32)) return false;
+	return true;
+}
+
+// PT = float | __half (parameter and y storage type).  Returns 1 when it served the call, 0 when the generic kernels
+// have to, < 0 ... never; errors through NR3D_CHECK (positive).  `served` out-param keeps the int status free.
+template <typename PT>
+static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t N, const float *x, const PT *params,
+                         int32_t max_level, PT *y, int64_t y_sn, int64_t y_se, float *dy_dx, int64_t d_sn, int64_t d_se,
+                         hipStream_t st, bool &served) {
+	served = false;
+	if (!pairlane_enabled() || !pairlane_meta_ok(meta) || ((uintptr_t)params % (2 * sizeof(PT))) != 0) return 0;
+	served = true;
 	uint64_t staged = 0;
-	if (lds_stage_enabled() && meta->n_dims_to_encode == 3 && G == 2 && vec_ok && !batch_inds && !batch_data_size &&
-	    N >= lds_stage_min_points() && meta->n_pseudo_levels <= 64) {
+	if (lds_stage_enabled() && N >= lds_stage_min_points() && meta->n_pseudo_levels <= 64) {
 		static bool attr_set_dev[64] = {};
 		int dev_id = 0;
 		NR3D_HIP_CHECK(hipGetDevice(&dev_id));
 		if (!attr_set_dev[dev_id & 63]) {
-			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxBytes));
-			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxBytes));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<true, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxBytes));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<false, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxBytes));
 			attr_set_dev[dev_id & 63] = true;
 		}
 		for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
@@ -981,32 +1003,67 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 			const nr3d_lotd_level_t &L = meta->levels[lv];
 			if ((int32_t)lv > max_level || L.type != NR3D_LOD_Dense || L.n_feats != 2 || (uint64_t)L.size * 8 > kLdsMaxBytes) continue;
 			staged |= 1ull << q;
-			const uint32_t lds = L.size * 8;
+			const uint32_t lds = L.size * 8;                   // staged as float pairs whatever the storage type
 			prof::Scope ps(NR3D_PROF_LOTD_FWD_LDS, st);
 			if (dy_dx)
-				hipLaunchKernelGGL(k_fwd_lds<true>, dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, q, meta->interpolation_type,
-				                   (const float *)x, (const float *)params, (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+				hipLaunchKernelGGL((k_fwd_lds<true, PT>), dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, q,
+				                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
 			else
-				hipLaunchKernelGGL(k_fwd_lds<false>, dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, q, meta->interpolation_type,
-				                   (const float *)x, (const float *)params, (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+				hipLaunchKernelGGL((k_fwd_lds<false, PT>), dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, q,
+				                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
 		}
 	}
-	bool pairlane = pairlane_enabled() && dh && meta->n_dims_to_encode == 3 && G == 2 && vec_ok && !batch_inds && !batch_data_size;
-	for (uint32_t l = 0; l < meta->n_levels && pairlane; ++l)                // 32-bit byte offsets inside a level
-		pairlane = (uint64_t)meta->levels[l].size * meta->levels[l].n_feats * 4 < (1ull << 32);
-	const Sched s = make_sched(N, meta, n_blocks, staged, pairlane ? (uint32_t)kPlPts : (uint32_t)kBlock, pairlane);
-	if (n_blocks == 0) { NR3D_LAUNCH_CHECK(); return 0; }
-	if (pairlane) {
+	uint32_t n_blocks;
+	const Sched s = make_sched(N, meta, n_blocks, staged, (uint32_t)kPlPts, true);
+	if (n_blocks != 0) {
 		prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
 		if (dy_dx)
-			hipLaunchKernelGGL(k_fwd_pairlane<true>, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level, meta->interpolation_type,
-			                   (const float *)x, (const float *)params, (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+			hipLaunchKernelGGL((k_fwd_pairlane<true, PT>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
 		else
-			hipLaunchKernelGGL(k_fwd_pairlane<false>, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level, meta->interpolation_type,
-			                   (const float *)x, (const float *)params, (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
-		NR3D_LAUNCH_CHECK();
-		return 0;
+			hipLaunchKernelGGL((k_fwd_pairlane<false, PT>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
 	}
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_lotd_half_params_ok(const nr3d_lotd_meta_t *meta, int batched) {
+	return (meta && !batched && pairlane_enabled() && pairlane_meta_ok(meta) && pair_applies(meta)) ? 1 : 0;
+}
+
+extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                             int param_dtype, const void *x, const void *params, const int64_t *batch_inds,
+                             const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level, void *y,
+                             int64_t y_sn, int64_t y_se, void *dy_dx, int64_t d_sn, int64_t d_se, void *stream) {
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype, true)) return rc;
+	if (N == 0) return 0;
+	NR3D_CHECK(x && params && y, "LoTD::fwd: NULL tensor pointer");
+	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
+	hipStream_t st = (hipStream_t)stream;
+	const bool batched = batch_inds || batch_offsets || batch_data_size;
+	if (param_dtype == NR3D_F16) {
+		bool served = false;
+		NR3D_CHECK(!batched && pairlane_enabled() && pairlane_meta_ok(meta) && ((uintptr_t)params % 4) == 0,
+		           "LoTD::fwd: half params are served natively for unbatched 3-D Dense/Hash metas with 2-feature pseudo levels "
+		           "only (nr3d_lotd_half_params_ok); convert on the caller side");
+		return fwd_fast_path<__half>(meta, md, N, (const float *)x, (const __half *)params, max_level, (__half *)y, y_sn, y_se,
+		                             (float *)dy_dx, d_sn, d_se, st, served);
+	}
+	if (!batched) {
+		bool served = false;
+		if (int rc = fwd_fast_path<float>(meta, md, N, (const float *)x, (const float *)params, max_level, (float *)y, y_sn, y_se,
+		                                  (float *)dy_dx, d_sn, d_se, st, served))
+			return rc;
+		if (served) return 0;
+	}
+	uint32_t n_blocks;
+	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
+	const uint32_t G = meta->n_feat_per_pseudo_lvl;
+	// vector gathers need every corner address G*4-byte aligned: base pointer aligned and no caller-chosen offsets
+	const uint32_t vec_ok = (((uintptr_t)params % (G >= 4 ? 16 : 8)) == 0 && batch_offsets == nullptr) ? 1u : 0u;
+	const bool dh = meta->c_hash_only != 0;
+	const Sched s = make_sched(N, meta, n_blocks);
 	prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
 	DISPATCH_DG(meta->n_dims_to_encode, G, {
 		auto launch = [&](auto kern) {
@@ -1025,16 +1082,21 @@ extern "C" int nr3d_lotd_bwd_dx(const nr3d_lotd_meta_t *meta, uint32_t N, int x_
                                 const void *dL_dy, int64_t g_sn, int64_t g_se, const void *dy_dx, int64_t d_sn,
                                 int64_t d_se, void *dL_dx, void *dL_dy_T, void *stream) {
 	NR3D_CHECK(meta != nullptr, "LoTD: meta is NULL");
-	NR3D_CHECK(x_dtype == NR3D_F32 && param_dtype == NR3D_F32, "LoTD::bwd_dx: f32 only");
+	NR3D_CHECK(x_dtype == NR3D_F32 && (param_dtype == NR3D_F32 || param_dtype == NR3D_F16), "LoTD::bwd_dx: f32 x, f32 / f16 dL_dy");
 	if (N == 0) return 0;
 	NR3D_CHECK(dL_dy && dy_dx && dL_dx, "LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.");
 	const uint32_t E = meta->n_encoded_dims;
-	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && ((uintptr_t)dL_dy % 16) == 0);
+	const bool g_half = param_dtype == NR3D_F16;          // dL_dy has the params' dtype (lotd_torch_api.cu:430-433)
+	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && ((uintptr_t)dL_dy % (g_half ? 8 : 16)) == 0);
 	NR3D_CHECK(dL_dy_T == nullptr || row_major, "LoTD::bwd_dx: dL_dy_T needs a contiguous, 16-byte aligned [N, E] dL_dy");
+	NR3D_CHECK(!g_half || (row_major && (E & 3u) == 0u), "LoTD::bwd_dx: half dL_dy must be a contiguous [N, E] tensor, E % 4 == 0");
 	prof::Scope ps(NR3D_PROF_LOTD_CONTRACT_DX, (hipStream_t)stream);
 	DISPATCH_D(meta->n_dims_to_encode, {
-		if (row_major)
-			hipLaunchKernelGGL(k_contract_dx_rowmajor<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,
+		if (row_major && g_half)
+			hipLaunchKernelGGL((k_contract_dx_rowmajor<D, __half>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,
+			                   (const __half *)dL_dy, (const float *)dy_dx, d_sn, d_se, (float *)dL_dx, (float *)dL_dy_T);
+		else if (row_major)
+			hipLaunchKernelGGL((k_contract_dx_rowmajor<D, float>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,
 			                   (const float *)dL_dy, (const float *)dy_dx, d_sn, d_se, (float *)dL_dx, (float *)dL_dy_T);
 		else
 			hipLaunchKernelGGL(k_contract_dx<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N, E,
@@ -1091,6 +1153,25 @@ extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *me
 	return launch_bwd_dparam(false, meta, meta_dev, N, nullptr, dL_dy, g_sn, g_se, x, params, batch_inds,
 	                         batch_offsets, batch_data_size, n_batches, max_level, dL_dparam, workspace, workspace_bytes,
 	                         stream);
+}
+
+extern "C" int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int grad_dtype,
+                                          const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,
+                                          int out_dtype, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
+                                          void *stream) {
+	if (int rc = check_common(meta, meta_dev, NR3D_F32, NR3D_F32)) return rc;
+	NR3D_CHECK((grad_dtype == NR3D_F32 || grad_dtype == NR3D_F16) && (out_dtype == NR3D_F32 || out_dtype == NR3D_F16),
+	           "LoTD::bwd_dparam_typed: f32 / f16 only");
+	if (N == 0 || max_level <= -1) return 0;
+	NR3D_CHECK(dL_dy && x && dL_dparam && workspace, "LoTD::bwd: NULL tensor pointer");
+	bool handled = false;
+	const Batch bb{nullptr, nullptr, 0u, meta->n_params};
+	if (int rc = dparam_binned(false, meta, meta_dev, N, nullptr, (const float *)dL_dy, g_sn, g_se, (const float *)x, nullptr, bb,
+	                           1u, max_level, (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, nullptr,
+	                           0, grad_dtype == NR3D_F16, out_dtype == NR3D_F16))
+		return rc;
+	NR3D_CHECK(handled, "LoTD::bwd_dparam_typed: the pair-record path does not apply to this meta / workspace");
+	return 0;
 }
 
 extern "C" int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,

@@ -84,7 +84,8 @@ struct BinPlan {
 // -------------------------------------------------------------------------------------------------
 // [n, E] row-major -> [E, n] (32x32 LDS tiles), so the level-major stage A reads its G columns coalesced
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_transpose(uint32_t n, uint32_t E, const float *__restrict__ src, int64_t s_sn,
+template <typename ST>
+__global__ __launch_bounds__(256) void k_transpose(uint32_t n, uint32_t E, const ST *__restrict__ src, int64_t s_sn,
                                                    int64_t s_se, float *__restrict__ dst) {
 	__shared__ float tile[32][33];
 	const uint32_t i0 = blockIdx.x * 32, e0 = blockIdx.y * 32;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k_transpose(uint32_t n, uint32_t E, const
 #pragma unroll
 	for (int k = 0; k < 32; k += 8) {
 		const uint32_t i = i0 + ty + k, e = e0 + tx;
-		tile[ty + k][tx] = (i < n && e < E) ? src[(int64_t)i * s_sn + (int64_t)e * s_se] : 0.0f;
+		tile[ty + k][tx] = (i < n && e < E) ? to_f32<ST>(src[(int64_t)i * s_sn + (int64_t)e * s_se]) : 0.0f;
 	}
 	__syncthreads();
 #pragma unroll
@@ -1039,7 +1040,7 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
-                  hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level) {
+                  hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level, bool g_half, bool out_half) {
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
@@ -1054,27 +1055,34 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	uint32_t *plan_buf = (uint32_t *)((char *)workspace + lay.rec_bytes + lay.offs_bytes);
 	float *partial = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes);
 	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes + lay.part_bytes);
-	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && E > 1);
+	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && E > 1) || g_half;      // half gradients always go through gt
 	// first-order gradient of an unbatched 3-D Dense/Hash meta with 2-feature pseudo levels: pair records (lotd_pair.hip)
 	const bool use_pair = !second && !forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size &&
 	                      pair_applies(meta);
+	if ((g_half || out_half) && !use_pair)
+		return ::nr3d::fail("LoTD::bwd: half gradients are served natively on the pair-record path only (nr3d_lotd_half_params_ok)");
 
 	for (uint32_t p0 = 0; p0 < N; p0 += nc) {
 		const uint32_t n = (N - p0) < nc ? (N - p0) : nc;
 		const float *xc = x + (size_t)p0 * D;
 		const float *vc = dL_ddLdx ? dL_ddLdx + (size_t)p0 * D : nullptr;
-		const float *gc = dL_dy + (int64_t)p0 * g_sn;
+		const float *gc = g_half ? reinterpret_cast<const float *>(reinterpret_cast<const __half *>(dL_dy) + (int64_t)p0 * g_sn)
+		                         : dL_dy + (int64_t)p0 * g_sn;
 		int64_t sn = g_sn, se = g_se;
 		Batch ba = batch;                              // this chunk's view of the batch description
 		if (ba.inds) ba.inds += p0;
 		ba.first_point = p0;
 		if (row_major) {
-			hipLaunchKernelGGL(k_transpose, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, gc, g_sn, g_se, gt);
+			if (g_half)
+				hipLaunchKernelGGL(k_transpose<__half>, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E,
+				                   reinterpret_cast<const __half *>(gc), g_sn, g_se, gt);
+			else
+				hipLaunchKernelGGL(k_transpose<float>, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, gc, g_sn, g_se, gt);
 			gc = gt; sn = 1; se = (int64_t)n;
 		}
 		if (use_pair) {
-			if (int rc = pair_chunk(meta, md, n, xc, gc, sn, se, min_level, max_level, work_units(), dparam, rec, offs, plan_buf,
-			                        partial, st))
+			if (int rc = pair_chunk(meta, md, n, xc, gc, sn, se, min_level, max_level, work_units(), dparam, out_half, rec, offs,
+			                        plan_buf, partial, st))
 				return rc;
 			continue;
 		}

@@ -58,7 +58,7 @@ static uint32_t pair_lg() {
 }
 static uint32_t pair_unroll() {
 	static uint32_t v = 0;
-	if (!v) { const char *e = getenv("NR3D_PAIR_UNROLL"); const int x = e ? atoi(e) : 8; v = (x == 4) ? 4u : 8u; }
+	if (!v) { const char *e = getenv("NR3D_PAIR_UNROLL"); const int x = e ? atoi(e) : 4; v = (x == 8) ? 8u : 4u; }
 	return v;
 }
 // timing experiments only (results are wrong): bit 0 = no LDS atomics, bit 1 = every lane re-reads one record
@@ -302,11 +302,20 @@ __global__ __launch_bounds__(256) void k_pair_totals(PairPlan plan, const uint32
 
 // accumulator slot t (feature-major: t = f * 2^lg + el) of bucket b -> element of dL/dparam, nullptr outside the level
 __device__ __forceinline__ float *pair_target(const Lvl &L, uint32_t epb, uint32_t lg, uint32_t foff0, uint32_t b, uint32_t t,
-                                              float *__restrict__ dparam) {
+                                              float *__restrict__ dparam, bool out_half = false) {
 	const uint32_t f = t >> lg, el = t & ((1u << lg) - 1u);
 	const uint64_t entry = (uint64_t)b * epb + el;
 	if (el >= epb || entry >= L.size) return nullptr;
-	return dparam + L.off + (entry * L.F + foff0 + f);
+	const uint64_t at = L.off + (entry * L.F + foff0 + f);
+	// half output ((float, half, float) type combination): the same element index in a __half buffer
+	return out_half ? reinterpret_cast<float *>(reinterpret_cast<__half *>(dparam) + at) : dparam + at;
+}
+// dparam[p] += v for either storage type (p from pair_target)
+__device__ __forceinline__ float pair_ld(const float *p, bool out_half) {
+	return out_half ? __half2float(*reinterpret_cast<const __half *>(p)) : *p;
+}
+__device__ __forceinline__ void pair_st(float *p, float v, bool out_half) {
+	if (out_half) *reinterpret_cast<__half *>(p) = __float2half(v); else *p = v;
 }
 
 // fp64 LDS atomics run at ~1.3-1.5 T/s chip-wide, 64-bit integer ones at ~2.5 T/s (tools/ubench_lds): with FIX the
@@ -341,7 +350,8 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
                                                              const uint32_t *__restrict__ rep_g,
                                                              const uint32_t *__restrict__ item_start,
                                                              const uint32_t *__restrict__ gmax,
-                                                             float *__restrict__ partial, float *__restrict__ dparam, uint32_t dbg) {
+                                                             float *__restrict__ partial, float *__restrict__ dparam, uint32_t dbg,
+                                                             uint32_t out_half) {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long acc_raw[];   // [2][2^lg] 8-byte accumulators, feature-major
 	double *acc = reinterpret_cast<double *>(acc_raw);
 	const uint32_t NB = plan.bucket_base[plan.n_pseudo];
@@ -448,13 +458,13 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 #pragma unroll
 		for (int k = 0; k < kFlush; ++k) {
 			const uint32_t t = tb + (uint32_t)k * kPAccThreads;
-			p[k] = (t < kPLds) ? pair_target(L, epb, plan.lg, foff0, b, t, dparam) : nullptr;
+			p[k] = (t < kPLds) ? pair_target(L, epb, plan.lg, foff0, b, t, dparam, out_half != 0) : nullptr;
 			v[k] = p[k] ? value(t) : 0.0f;
 		}
 #pragma unroll
-		for (int k = 0; k < kFlush; ++k) old[k] = p[k] ? *p[k] : 0.0f;
+		for (int k = 0; k < kFlush; ++k) old[k] = p[k] ? pair_ld(p[k], out_half != 0) : 0.0f;
 #pragma unroll
-		for (int k = 0; k < kFlush; ++k) if (p[k]) *p[k] = old[k] + v[k];
+		for (int k = 0; k < kFlush; ++k) if (p[k]) pair_st(p[k], old[k] + v[k], out_half != 0);
 	}
 }
 
@@ -462,7 +472,8 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
                                                               const uint32_t *__restrict__ rep_g,
                                                               const uint32_t *__restrict__ item_start,
-                                                              const float *__restrict__ partial, float *__restrict__ dparam) {
+                                                              const float *__restrict__ partial, float *__restrict__ dparam,
+                                                              uint32_t out_half) {
 	const uint32_t fb = blockIdx.x;
 	const uint32_t R = rep_g[fb];
 	if (R <= 1) return;
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
 	const float *part0 = partial + (size_t)item_start[fb] * kPLds;
 	const uint32_t t = blockIdx.y * kPAccThreads + threadIdx.x;
 	if (t >= kPLds) return;
-	float *p = pair_target(L, plan.epb[q], plan.lg, foff0, b, t, dparam);
+	float *p = pair_target(L, plan.epb[q], plan.lg, foff0, b, t, dparam, out_half != 0);
 	if (!p) return;
 	float sum = 0.0f;
 	uint32_t r0 = 0;
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
 		for (int j = 0; j < 8; ++j) sum += v[j];
 	}
 	for (; r0 < R; ++r0) sum += part0[(size_t)r0 * kPLds + t];
-	*p = *p + sum;
+	pair_st(p, pair_ld(p, out_half != 0) + sum, out_half != 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -576,8 +587,8 @@ void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32
 
 // one chunk of points: dL_dy given feature-major or with any strides (g_sn, g_se)
 int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,
-               int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, void *rec,
-               uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st) {
+               int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, bool out_half,
+               void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st) {
 	PairPlan pl;
 	uint64_t ow;
 	pair_plan(meta, n, min_level, max_level, pl, ow);
@@ -615,7 +626,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	hipLaunchKernelGGL(k_pair_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
 	launch_plan_items(NB, pl.n_blk, units, tot, rep, item_start, st);
 #define NR3D_PAIR_ACC(U, F) hipLaunchKernelGGL((k_pair_accum<U, F>), dim3(units + NB), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, pl, md, \
-	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg())
+	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg(), out_half ? 1u : 0u)
 	{
 		prof::Scope ps(NR3D_PROF_LOTD_ACCUM, st);
 		if (pair_fixed()) { if (pair_unroll() == 4) NR3D_PAIR_ACC(4, true); else NR3D_PAIR_ACC(8, true); }
@@ -623,7 +634,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	}
 #undef NR3D_PAIR_ACC
 	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, (2u << pl.lg) / kPAccThreads), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
-	                   dparam);
+	                   dparam, out_half ? 1u : 0u);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

@@ -219,16 +219,43 @@ def test_generic_kernel_agrees_with_dense_hash_kernel(oracle, dev):
     assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dparam generic", levels=m_ref)
 
 
-def test_half_params_and_inputs(oracle, dev):
-    """fp16 storage: computed in fp32 on device, cast back; compared with the fp32 oracle on the rounded inputs"""
-    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, "ngp_small", seed=7)
-    ph = pt.half()
-    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, ph.float().cpu().numpy(), need_dydx=True)
-    y, j = _lotd.lod_fwd(m, xt, ph, need_input_grad=True)
-    assert y.dtype == torch.float16 and j.dtype == torch.float32
-    assert_close(y.float(), y_ref, rel=2e-3, name="y half")
-    dx, dp = _lotd.lod_bwd(m, gt.half(), xt, ph, j, need_input_grad=True, need_param_grad=True)
-    assert dp.dtype == torch.float16 and dx.dtype == torch.float32
+@pytest.mark.parametrize("case", ["ngp_small", "ngp_pair", "pair_f4", "mixed"])
+def test_half_params_and_inputs(oracle, dev, case):
+    """fp16 storage, the reference's (float, half, float) type combination: params / y / dL_dy / dL_dparam half, x and
+    dy_dx float, arithmetic in fp32.  Dense/Hash metas with 2-feature pseudo levels are served NATIVELY (the kernels read
+    half table entries and gradients and write half results: no whole-table conversion), other metas through fp32
+    copies; both are compared with the fp32 oracle on the rounded inputs -- y and dL_dparam to half precision, dy_dx /
+    dL_dx (fp32 outputs of fp32 arithmetic on the rounded tables) to the fp32 tolerance -- and with each other."""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=7)
+    ph, gh = pt.half(), gt.half()
+    p_r, g_r = ph.float().cpu().numpy(), gh.float().cpu().numpy()
+    native_expected = case != "mixed"
+    assert bool(_lotd._native_half(m, ph, False)) == native_expected
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p_r, need_dydx=True)
+    dp_ref = oracle.lotd_bwd_dparam(m_ref, g_r, x, p_r, accum_double=True)
+    dx_ref = oracle.lotd_bwd_dx(m_ref, g_r, j_ref)
+    outs = {}
+    for native in ([True, False] if native_expected else [False]):
+        _lotd.NATIVE_HALF = native
+        try:
+            y, j = _lotd.lod_fwd(m, xt, ph, need_input_grad=True)
+            y0, _ = _lotd.lod_fwd(m, xt, ph, need_input_grad=False)
+            dx, dp = _lotd.lod_bwd(m, gh, xt, ph, j, need_input_grad=True, need_param_grad=True)
+            _, dp_only = _lotd.lod_bwd(m, gh, xt, ph, None, need_input_grad=False, need_param_grad=True)     # no feature-major copy
+        finally:
+            _lotd.NATIVE_HALF = True
+        assert y.dtype == torch.float16 and j.dtype == torch.float32 and dp.dtype == torch.float16 and dx.dtype == torch.float32
+        assert torch.equal(y, y0)
+        assert_close(y.float(), y_ref, rel=1e-3, name=f"y half native={native}")                   # one rounding to half: 2^-11
+        assert_close(j.reshape(j_ref.shape), j_ref, name=f"dy_dx native={native}")
+        assert_close(dx, dx_ref, name=f"dL_dx native={native}")
+        assert_close(dp.float(), dp_ref, rel=1e-3, name=f"dL_dparam half native={native}", levels=m_ref)
+        assert_close(dp_only.float(), dp_ref, rel=1e-3, name=f"dL_dparam half (row-major dL_dy) native={native}", levels=m_ref)
+        outs[native] = (y, j, dx, dp)
+    if native_expected:      # same fp32 arithmetic on the same rounded values, one rounding of the result: identical halves
+        assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+        assert torch.equal(outs[True][2], outs[False][2])
+        assert_close(outs[True][3].float(), outs[False][3].float().cpu().numpy(), rel=1e-3, name="native vs converted dL_dparam", levels=m_ref)
     with pytest.raises(RuntimeError, match="not supported"):
         _lotd.lod_fwd(m, xt.half(), pt)          # (half input, float params) is not a supported combination
 
