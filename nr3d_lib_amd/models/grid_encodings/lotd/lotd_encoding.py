@@ -5,10 +5,12 @@ Counterpart of nr3d_lib/models/grid_encodings/lotd/lotd_encoding.py:37-326 for t
 ``forward`` / ``forward_dydx`` / ``backward_dydx`` on inputs in [-1, 1] (mapped to [0, 1]; nablas halved), the four
 ``param_init_cfg`` schemes, ``max_level`` / ``window`` masking driven by ``anneal_cfg`` (``MultiresAnnealer``,
 ``set_anneal_iter``), ``space_cfg`` of type 'aabb' / 'batched' / 'unbounded', ``get_level_param`` / ``set_level_param`` on whole levels
-and on every line / plane / volume table (``lotd_helpers``), ``rescale_volume``, ``inference_param``, and the ``lotd_cfg``
-extra state.  Not provided: ``init_param_from_net``."""
+and on every line / plane / volume table (``lotd_helpers``), ``rescale_volume``, ``inference_param``, the ``lodN`` / ``lodN_vec`` / ``lodN_matK``
+attribute views, ``clip_grad_and_update_ema``, ``stat_param``, and the ``lotd_cfg`` extra state.  Not provided:
+``init_param_from_net``."""
+import re
 from math import sqrt
-from typing import Any, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -119,6 +121,72 @@ class LoTDEncoding(nn.Module):
         sl, _ = self._level_slice(l, op, dim)
         with torch.no_grad():
             self.flattened_params[sl] = value.contiguous().reshape(-1)
+
+    # ``enc.lod3`` / ``enc.lod3_vec`` / ``enc.lod3_mat1`` read (and ``enc.lod3 = t`` writes) the parameters of a level or of
+    # one of its line / plane tables: views into ``flattened_params`` (reference lotd_encoding.py:121, :291-320)
+    _LOD_ATTR = re.compile(r"^lod(?P<level>[0-9]+)(_(?P<op>[a-z]+)(?P<dim>[0-9]+)?)?$")
+
+    def _lod_attr(self, name: str):
+        m = self._LOD_ATTR.match(name) if name.startswith('lod') else None
+        if m is None or 'flattened_params' not in self._parameters:
+            return None
+        dim = m.group('dim')
+        return int(m.group('level')), m.group('op') or None, None if dim in (None, '') else int(dim)
+
+    def __getattr__(self, name: str):
+        key = self._lod_attr(name)
+        if key is not None:
+            return self.get_level_param(*key)
+        return super().__getattr__(name)
+
+    def __setattr__(self, name: str, value) -> None:
+        key = self._lod_attr(name) if isinstance(value, torch.Tensor) else None
+        if key is not None:
+            self.set_level_param(*key, value=value)
+        else:
+            super().__setattr__(name, value)
+
+    @torch.no_grad()
+    def clip_grad_and_update_ema(self, val: float = None):
+        """per-level gradient-norm clipping against a running norm (reference lotd_encoding.py:471-486): the EMA of every
+        level's gradient 2-norm moves 1 % towards the current norm, then the level's gradient is rescaled so that its
+        norm does not exceed ``clip_level_grad_ema_factor`` x that EMA (``clip_grad_norm_``'s rule).  No-op unless the
+        encoder was built with ``clip_level_grad_ema_factor > 0``; ``val`` is accepted and ignored like in the reference."""
+        if not self.clip_level_grad_ema_factor > 0 or self.flattened_params.grad is None:
+            return
+        L = self.lotd.n_levels
+        gnorm = torch.stack([self.get_level_param(l, grad=True).norm() for l in range(L)])
+        ema = self.level_grad_norm_ema.copy_(gnorm.lerp(self.level_grad_norm_ema, 0.99))
+        for l in range(L):
+            g = self.get_level_param(l, grad=True)
+            max_norm = self.clip_level_grad_ema_factor * ema[l]
+            g.mul_((max_norm / (gnorm[l] + 1e-6)).clamp(max=1.0))
+
+    @torch.no_grad()
+    def stat_param(self, with_grad: bool = False, prefix: str = '') -> Dict[str, float]:
+        """mean / std / min / max / absmax / norm of all parameters and of every level (VM levels: lines and planes apart),
+        optionally of their gradients, plus the gradient-norm EMAs -- the keys of the reference's logger
+        (lotd_encoding.py:488-508, tensor_statistics utils.py:767-795)"""
+        def stats(t: torch.Tensor, key: str):
+            t = t.detach().float()
+            if t.numel() == 1:
+                return {f"{key}.val": t.item(), f"{key}.mean": t.item()}
+            return {f"{key}.mean": t.mean().item(), f"{key}.std": t.std().item(), f"{key}.min": t.min().item(),
+                    f"{key}.max": t.max().item(), f"{key}.absmax": t.abs().max().item(), f"{key}.norm": t.norm().item()}
+        pre = prefix + ('.' if prefix and not prefix.endswith('.') else '')
+        with_grad = with_grad and self.flattened_params.grad is not None
+        out = stats(self.flattened_params, pre + 'total')
+        if with_grad:
+            out.update(stats(self.flattened_params.grad, pre + 'grad_total'))
+        for l, tp in enumerate(self.lotd.level_types):
+            parts = [('vec', '.vec'), ('mat', '.mat')] if LoDType(tp) == LoDType.VectorMatrix else [(None, '')]
+            for op, tag in parts:
+                out.update(stats(self.get_level_param(l, op), f"{pre}lv.{l}{tag}"))
+                if with_grad:
+                    out.update(stats(self.get_level_param(l, op, grad=True), f"{pre}grad.lv.{l}{tag}"))
+        if self.clip_level_grad_ema_factor > 0:
+            out.update({f"{pre}grad.lv.{l}.ema": self.level_grad_norm_ema[l].item() for l in range(self.lotd.n_levels)})
+        return out
 
     @torch.no_grad()
     def init_param_random(self):

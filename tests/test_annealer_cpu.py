@@ -46,3 +46,39 @@ def test_lotd_encoding_anneal_and_space_cfg():
     assert LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float, space_cfg=dict(type="unbounded")).space is None
     with pytest.raises(RuntimeError, match="Invalid space_type"):
         LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float, space_cfg=dict(type="sphere"))
+
+
+def test_lotd_encoding_level_views_grad_clip_and_stats():
+    """``lodN`` attribute views, ``clip_grad_and_update_ema`` (per-level norm clipping against a running norm, reference
+    lotd_encoding.py:471-486) and ``stat_param`` (the reference logger's keys, :488-508) -- host logic, no kernel involved"""
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTDEncoding
+    cfg = dict(lod_res=[8, 12, 10], lod_n_feats=[2, 4, 2], lod_types=["Dense", "VM", "CP"])
+    e = LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float, clip_level_grad_ema_factor=2.0)
+    # attribute views are views into flattened_params
+    assert e.lod0.shape == (512, 2) and e.lod0.data_ptr() == e.flattened_params.data_ptr()
+    assert torch.equal(e.lod1_vec, e.get_level_param(1, 'vec')) and torch.equal(e.lod1_mat2, e.get_level_param(1, 'mat', 2))
+    e.lod2 = torch.full_like(e.lod2, 0.25)
+    assert float(e.get_level_param(2).min()) == 0.25 and 'lod2' not in e.__dict__
+    with pytest.raises(AttributeError):
+        e.lodestar
+    # clipping: EMA moves 1 % towards the current norm, gradient norm capped at factor * EMA
+    g = torch.randn_like(e.flattened_params)
+    e.flattened_params.grad = g.clone()
+    offs = e.lod_meta.level_offsets
+    norms = [float(g[offs[l]:offs[l + 1]].norm()) for l in range(3)]
+    e.clip_grad_and_update_ema()
+    for l in range(3):
+        ema = 0.99 * 0.1 + 0.01 * norms[l]
+        assert abs(float(e.level_grad_norm_ema[l]) - ema) < 1e-5
+        got = float(e.flattened_params.grad[offs[l]:offs[l + 1]].norm())
+        assert abs(got - min(norms[l], 2.0 * ema)) < 1e-3 * norms[l]
+    st = e.stat_param(with_grad=True, prefix='enc')
+    for key in ('enc.total.mean', 'enc.grad_total.norm', 'enc.lv.0.absmax', 'enc.lv.1.vec.std', 'enc.lv.1.mat.max',
+                'enc.grad.lv.2.norm', 'enc.grad.lv.1.ema'):
+        assert key in st, key
+    assert abs(st['enc.lv.2.mean'] - 0.25) < 1e-7
+    # an encoder built without the factor: clipping is a no-op, no EMA keys
+    e2 = LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float)
+    e2.flattened_params.grad = g.clone()
+    e2.clip_grad_and_update_ema()
+    assert torch.equal(e2.flattened_params.grad, g) and not any(k.endswith('.ema') for k in e2.stat_param())
