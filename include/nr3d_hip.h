@@ -222,6 +222,9 @@ int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, con
                          const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level, float *y,
                          int64_t y_sn, int64_t y_se, float *dy_dx, int64_t d_sn, int64_t d_se, void *stream);
 
+/* scratch for the atomic-free forest parameter gradient (per-corner records: a corner may belong to a neighbouring
+ * block; Dense / Hash / VecZMatXoY / CP / NPlaneMul / VM levels, lotd_forest.h:415-636); 0 = not applicable (atomics). */
+uint64_t nr3d_lotd_forest_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint32_t n_trees);
 /* dL/dparam (dL_ddLdx == NULL; kernel_lod_forest_backward_grid :414-542) or d(dL/dx)/dparam
  * (kernel_lod_forest_backward_input_backward_grid :636-773).  dL_dparam [n_trees * n_params] ZERO-INIT by the caller;
  * contributions of corners that lie in a neighbouring block go to that block's parameters.

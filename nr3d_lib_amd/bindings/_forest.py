@@ -97,12 +97,26 @@ def _check(fn, metas, input, params, block_inds, block_offsets, batch_data_size)
     return m, fo, N, bds
 
 
+_workspaces = {}
+
+
 def _workspace(m, fo, N, dev):
-    """scratch of the atomic-free parameter-gradient path (Dense/Hash metas; blocks play the role of batch entries)"""
+    """scratch of the atomic-free parameter-gradient path (blocks play the role of batch entries; every 3-D level type
+    of the forest kernels: per-corner records, nr3d_lotd_forest_dparam_workspace_bytes); (None, 0): global atomics"""
     from . import _lotd
-    if not all(t in (int(_lotd.LoDType.Dense), int(_lotd.LoDType.Hash)) for t in m.level_types):
+    if not _lotd.USE_BINNED_DPARAM:
         return None, 0
-    return _lotd._dparam_workspace(m, N, dev, int(fo.n_trees))
+    H.lib().nr3d_lotd_forest_dparam_workspace_bytes.restype = C.c_uint64
+    need = int(H.lib().nr3d_lotd_forest_dparam_workspace_bytes(C.byref(m._cmeta()), H.u32(N), H.u32(int(fo.n_trees))))
+    if need == 0:
+        return None, 0
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        _workspaces.pop(key, None)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws, need
 
 
 def lod_fwd(metas, input, params, batch_inds=None, batch_offsets=None, batch_data_size=None, max_level=None,

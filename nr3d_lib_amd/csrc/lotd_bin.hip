@@ -54,20 +54,31 @@ constexpr uint32_t kMaxBuckets = 8192;    // per pseudo level
 
 // Record classes: NR = capacity in records per (point, pseudo level).  Updates that hit the same table entry from
 // several corners of one point are summed in registers first (CP: 2 entries per line, VM: 4 per plane + 2 per line...).
-//   Dense/Hash 2^D | CP, CPfast 2D | VecZMatXoY 4 + 2 | NPlaneMul D * 2^(D-1) | NPlaneSum (3-D) 3 * 4 | VM 3 * (4 + 2) = 18
-// NPlaneMul / NPlaneSum in 4-D are not binned: such metas use the atomic kernels.
-__host__ __device__ inline uint32_t rec_count(uint32_t type, uint32_t D) {
+//   Dense/Hash 2^D | CP, CPfast 2D | VecZMatXoY 4 + 2 | NPlaneMul, NPlaneSum D * 2^(D-1) (4-D: 32) | VM 3 * (4 + 2) = 18
+__host__ __device__ inline uint32_t rec_count(uint32_t type, uint32_t D, bool forest = false) {
+	if (forest) {
+		// forest of blocks (3-D): every corner may belong to another block, so updates are kept per corner
+		// (8 corners x table entries one corner touches) instead of being summed per distinct entry
+		switch (type) {
+		case NR3D_LOD_Dense: case NR3D_LOD_Hash: return 8u;
+		case NR3D_LOD_CP: case NR3D_LOD_NPlaneMul: return 24u;
+		case NR3D_LOD_VectorMatrix: return 48u;
+		default: return 0u;                          // CPfast / NPlaneSum have no forest form (lotd_forest.h); VecZMatXoY: atomics
+		}
+	}
 	switch (type) {
 	case NR3D_LOD_Dense: case NR3D_LOD_Hash: return 1u << D;
 	case NR3D_LOD_CP: case NR3D_LOD_CPfast: return 2u * D;
-	case NR3D_LOD_NPlaneSum: return D == 3 ? 12u : 0u;
+	case NR3D_LOD_NPlaneSum: return D >= 3 ? D << (D - 1) : 0u;
 	case NR3D_LOD_VecZMatXoY: return D == 3 ? 6u : 0u;
-	case NR3D_LOD_NPlaneMul: return D <= 3 ? D << (D - 1) : 0u;
+	case NR3D_LOD_NPlaneMul: return D << (D - 1);
 	case NR3D_LOD_VectorMatrix: return D == 3 ? 18u : 0u;
 	default: return 0u;
 	}
 }
-static inline uint32_t rec_class(uint32_t n_rec) { return n_rec == 0 ? 0u : n_rec <= 8 ? 8u : n_rec <= 16 ? 16u : 24u; }
+static inline uint32_t rec_class(uint32_t n_rec) {
+	return n_rec == 0 ? 0u : n_rec <= 8 ? 8u : n_rec <= 16 ? 16u : n_rec <= 24 ? 24u : n_rec <= 32 ? 32u : 48u;
+}
 
 struct BinPlan {
 	uint32_t qmap[kMaxPlanLevels];        // pseudo level of the meta behind local index q (levels of ONE record class)
@@ -274,16 +285,16 @@ __device__ __forceinline__ uint32_t emit_cpfast(const Lvl &L, const Cell<D> &c, 
 	return 2u * D;
 }
 
-// NPlaneSum (3-D): sum over the 3 axis planes of a bilinear interpolation; one record per plane corner
+// NPlaneSum: sum over the D axis "planes" of a (D-1)-linear interpolation; one record per plane corner, D * 2^(D-1) in all
 // (same weights as k_bwd_dparam's NPlaneSum branch, reference lotd_encoding.h:268-351 and its backward).
-template <int G, int NR, bool SECOND>
-__device__ __forceinline__ uint32_t emit_nplane_sum(const Lvl &L, const Cell<3> &c, const float (&grad)[G], const float (&a)[3],
+template <int D, int G, int NR, bool SECOND>
+__device__ __forceinline__ uint32_t emit_nplane_sum(const Lvl &L, const Cell<D> &c, const float (&grad)[G], const float (&a)[D],
                                                     uint32_t (&ent)[NR], float (&val)[NR][G]) {
-	constexpr int D = 3;
+	constexpr uint32_t NC = 1u << (D - 1);
 #pragma unroll
-	for (uint32_t jd = 0; jd < 3; ++jd)
+	for (uint32_t jd = 0; jd < (uint32_t)D; ++jd)
 #pragma unroll
-		for (uint32_t k = 0; k < 4; ++k) {
+		for (uint32_t k = 0; k < NC; ++k) {
 			uint32_t pp[D];
 #pragma unroll
 			for (int d2 = 0; d2 < D - 1; ++d2) {
@@ -315,11 +326,11 @@ __device__ __forceinline__ uint32_t emit_nplane_sum(const Lvl &L, const Cell<3> 
 					w += ((k >> g2) & 1u) ? t : -t;
 				}
 			}
-			ent[jd * 4 + k] = entry_nplane_sum<D>(L, jd, pp);
+			ent[jd * NC + k] = entry_nplane_sum<D>(L, jd, pp);
 #pragma unroll
-			for (int f = 0; f < G; ++f) val[jd * 4 + k][f] = grad[f] * w;
+			for (int f = 0; f < G; ++f) val[jd * NC + k][f] = grad[f] * w;
 		}
-	return 12u;
+	return (uint32_t)D * NC;
 }
 
 template <int D, int G, int NR, bool DH, bool SECOND>
@@ -343,7 +354,7 @@ __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c,
 	} else if (L.type == NR3D_LOD_CP) {
 		if constexpr (!DH && NR >= 2 * D) return emit_product<D, G, NR, 2, true>(L, c, w, grad, grid, foff, ent, val);
 	} else if (L.type == NR3D_LOD_NPlaneMul) {
-		if constexpr (!DH && D <= 3 && NR >= D * (1 << (D - 1)))
+		if constexpr (!DH && NR >= D * (1 << (D - 1)))
 			return emit_product<D, G, NR, (1 << (D - 1)), false>(L, c, w, grad, grid, foff, ent, val);
 	} else if (L.type == NR3D_LOD_VectorMatrix) {
 		if constexpr (!DH && D == 3 && NR >= 18) return emit_plane_line<G, NR, true>(L, c, w, grad, grid, foff, ent, val);
@@ -352,31 +363,83 @@ __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c,
 	} else if (L.type == NR3D_LOD_CPfast) {
 		if constexpr (!DH && NR >= 2 * D) return emit_cpfast<D, G, NR, SECOND>(L, c, grad, vin, grid, foff, ent, val);
 	} else if (L.type == NR3D_LOD_NPlaneSum) {
-		if constexpr (!DH && D == 3 && NR >= 12) return emit_nplane_sum<G, NR, SECOND>(L, c, grad, a, ent, val);
+		if constexpr (!DH && NR >= D * (1 << (D - 1))) return emit_nplane_sum<D, G, NR, SECOND>(L, c, grad, a, ent, val);
 	}
 	return 0;
 }
 
-// forest (FO): the 8 corner updates of a Dense / Hash level, each in the table of the block that owns the corner
-// (virtual entry = owner block * level size + entry).  A corner nobody owns becomes a zero update of the point's own block.
+// forest (FO): the updates of the 8 corners, each in the tables of the block that OWNS the corner (virtual entry = owner
+// block * level size + entry).  A corner nobody owns becomes zero updates of the point's own block.  Product types
+// multiply by the other factors read from the owner's tables -- the per-corner arithmetic of corner_scatter()
+// (lotd_device.h; reference lotd_forest.h:415-636), one record per (corner, table entry): Dense / Hash 8, CP / NPlaneMul 24,
+// VM 48.
 template <int G, int NR>
-__device__ __forceinline__ uint32_t emit_forest(const ForestDev &fo, const Lvl &L, const Cell<3> &c, const float (&w)[8],
-                                                const float (&grad)[G], const int (&bk)[3], uint32_t bi,
-                                                uint32_t (&ent)[NR], float (&val)[NR][G]) {
-	if constexpr (NR >= 8) {
+__device__ __forceinline__ uint32_t emit_forest(const ForestDev &fo, const Batch &ba, const Lvl &L, const Cell<3> &c,
+                                                const float (&w)[8], const float (&grad)[G], const int (&bk)[3], uint32_t bi,
+                                                const float *__restrict__ params, uint32_t foff, uint32_t (&ent)[NR],
+                                                float (&val)[NR][G]) {
+	constexpr uint32_t E = NR / 8;                     // records per corner of this class
+	const uint32_t need = rec_count(L.type, 3, true) / 8u;
+	if (need != E) return 0;                           // levels are grouped by record class: a class-NR launch only sees its own types
 #pragma unroll
-		for (uint32_t k = 0; k < 8; ++k) {
-			uint32_t p[3], pl[3], owner = bi;
-			corner_pos<3>(c, k, p);
-			const bool ok = resolve_block(fo, L, bk, p, pl, owner);
+	for (uint32_t k = 0; k < 8; ++k) {
+		uint32_t p[3], pl[3], owner = bi;
+		corner_pos<3>(c, k, p);
+		const bool ok = resolve_block(fo, L, bk, p, pl, owner);
+		const uint32_t vbase = (ok ? owner : bi) * L.size;
+		float wg[G];
+#pragma unroll
+		for (int f = 0; f < G; ++f) wg[f] = ok ? grad[f] * w[k] : 0.0f;
+		if (L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash) {
 			const uint32_t e = (L.type == NR3D_LOD_Dense) ? entry_dense<3>(L, pl) : entry_hash<3>(L, pl);
-			ent[k] = ok ? owner * L.size + e : bi * L.size;
+			ent[k * E] = ok ? vbase + e : vbase;
 #pragma unroll
-			for (int f = 0; f < G; ++f) val[k][f] = ok ? grad[f] * w[k] : 0.0f;
+			for (int f = 0; f < G; ++f) val[k * E][f] = wg[f];
+			continue;
 		}
-		return 8;
+		if constexpr (E >= 2) {
+			const float *__restrict__ grid = params + ((ba.offsets ? (uint32_t)ba.offsets[ok ? owner : bi] : (ok ? owner : bi) * ba.n_params) + L.off);
+			if constexpr (E >= 3) {
+				if (L.type == NR3D_LOD_CP || L.type == NR3D_LOD_NPlaneMul) {
+					uint32_t idx[3];
+#pragma unroll
+					for (int d = 0; d < 3; ++d) idx[d] = (L.type == NR3D_LOD_CP) ? entry_line<3>(L, d, pl[d]) : entry_nplane_mul<3>(L, d, pl);
+#pragma unroll
+					for (int gd = 0; gd < 3; ++gd) {
+						ent[k * E + gd] = ok ? vbase + idx[gd] : vbase;
+#pragma unroll
+						for (int f = 0; f < G; ++f) {
+							float cur = wg[f];
+							if (ok) {
+#pragma unroll
+								for (int j = 0; j < 3; ++j) if (j != gd) cur *= grid[idx[j] * L.F + foff + f];
+							}
+							val[k * E + gd][f] = cur;
+						}
+					}
+					continue;
+				}
+				if constexpr (E >= 6) {
+					if (L.type == NR3D_LOD_VectorMatrix) {
+						uint32_t ple[3], lne[3];
+						entry_vm(L, pl, ple, lne);
+#pragma unroll
+						for (int d = 0; d < 3; ++d) {
+							ent[k * E + 2 * d] = ok ? vbase + ple[d] : vbase;
+							ent[k * E + 2 * d + 1] = ok ? vbase + lne[d] : vbase;
+#pragma unroll
+							for (int f = 0; f < G; ++f) {
+								val[k * E + 2 * d][f] = ok ? wg[f] * grid[lne[d] * L.F + foff + f] : 0.0f;
+								val[k * E + 2 * d + 1][f] = ok ? wg[f] * grid[ple[d] * L.F + foff + f] : 0.0f;
+							}
+						}
+						continue;
+					}
+				}
+			}
+		}
 	}
-	return 0;
+	return (uint32_t)NR;
 }
 
 template <int D, int G, bool SECOND, int NR, bool DH, bool FO>
@@ -449,7 +512,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			int bk[3];
 #pragma unroll
 			for (int d = 0; d < 3; ++d) bk[d] = fo.block_ks[3 * (size_t)bi + d];
-			n_rec = emit_forest<G, NR>(fo, L, c, w, grad, bk, bi, ent, val);
+			n_rec = emit_forest<G, NR>(fo, ba, L, c, w, grad, bk, bi, params, meta_cnt_of(md, q) * G, ent, val);
 		} else {
 			n_rec = emit_updates<D, G, NR, DH, SECOND>(L, c, w, grad, a, vin, params + (pbase + L.off), meta_cnt_of(md, q) * G, ent, val);
 		}
@@ -587,15 +650,16 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
 	bin_body<D, G, SECOND, NR, DH, false>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, ForestDev{}, rec, offs_g);
 }
 
-// stage A for a forest of blocks (3-D, Dense / Hash levels): same sort, corner owners resolved through the octree
-template <int G, bool SECOND>
-__global__ __launch_bounds__((BinCfg<G, 8>::BP)) void k_bin_forest(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
-                                                                  uint32_t n, int32_t max_level, uint32_t smooth,
-                                                                  const float *__restrict__ x, const float *__restrict__ vin_,
-                                                                  const float *__restrict__ g, int64_t g_sn, int64_t g_se,
-                                                                  const float *__restrict__ params, Batch ba, ForestDev fo,
-                                                                  uint32_t *__restrict__ rec, uint32_t *__restrict__ offs_g) {
-	bin_body<3, G, SECOND, 8, true, true>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, fo, rec, offs_g);
+// stage A for a forest of blocks (3-D): same sort, corner owners resolved through the octree; NR = 8 Dense / Hash,
+// 24 CP / NPlaneMul, 48 VM
+template <int G, bool SECOND, int NR>
+__global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin_forest(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
+                                                                   uint32_t n, int32_t max_level, uint32_t smooth,
+                                                                   const float *__restrict__ x, const float *__restrict__ vin_,
+                                                                   const float *__restrict__ g, int64_t g_sn, int64_t g_se,
+                                                                   const float *__restrict__ params, Batch ba, ForestDev fo,
+                                                                   uint32_t *__restrict__ rec, uint32_t *__restrict__ offs_g) {
+	bin_body<3, G, SECOND, NR, true, true>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, fo, rec, offs_g);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -891,7 +955,7 @@ static uint32_t chunk_points(uint32_t n) {
 
 // plan for the pseudo levels of record class `cls` (0 levels => n_pseudo == 0)
 static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, uint32_t cls, BinPlan &plan,
-                      uint64_t &offs_words, int32_t min_level = 0, int32_t max_level = 0x7fffffff) {
+                      uint64_t &offs_words, int32_t min_level = 0, int32_t max_level = 0x7fffffff, bool forest = false) {
 	const uint32_t D = m->n_dims_to_encode, G = m->n_feat_per_pseudo_lvl;
 	const uint32_t kBinPts = bin_points(G, cls);
 	if (m->n_pseudo_levels > kMaxPlanLevels) return false;
@@ -905,7 +969,7 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_ba
 	uint64_t base = 0;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
-		if (rec_class(rec_count(L.type, D)) != cls) continue;
+		if (rec_class(rec_count(L.type, D, forest)) != cls) continue;
 		// levels outside the requested range get no stage-A blocks, offsets or work items (max_level schedules, the
 		// level-bucket calls of the data-parallel path)
 		if ((int32_t)m->map_levels[q] < min_level || (int32_t)m->map_levels[q] > max_level) continue;
@@ -928,24 +992,24 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_ba
 }
 
 // every level must have a binned form, and params must not be batched (checked by the caller)
-static bool binnable(const nr3d_lotd_meta_t *m) {
-	if (m->n_pseudo_levels > kMaxPlanLevels) return false;
+static bool binnable(const nr3d_lotd_meta_t *m, bool forest = false) {
+	if (m->n_pseudo_levels > kMaxPlanLevels || (forest && m->n_dims_to_encode != 3)) return false;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q)
-		if (rec_count(m->levels[m->map_levels[q]].type, m->n_dims_to_encode) == 0) return false;
+		if (rec_count(m->levels[m->map_levels[q]].type, m->n_dims_to_encode, forest) == 0) return false;
 	return true;
 }
 
-constexpr uint32_t kClasses[3] = {8, 16, 24};
+constexpr uint32_t kClasses[5] = {8, 16, 24, 32, 48};
 
 struct BinLayout { uint64_t rec_bytes, offs_bytes, plan_bytes, part_bytes, gt_bytes, total; };
 
 // workspace = max over the record classes (they run one after another) of records + offsets, + the transposed dL/dy
-static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, BinLayout &l) {
+static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, BinLayout &l, bool forest = false) {
 	l.rec_bytes = l.offs_bytes = l.plan_bytes = l.part_bytes = 0;
 	for (uint32_t cls : kClasses) {
 		BinPlan plan;
 		uint64_t ow;
-		if (!make_plan(m, n_chunk, n_batches, cls, plan, ow)) return false;
+		if (!make_plan(m, n_chunk, n_batches, cls, plan, ow, 0, 0x7fffffff, forest)) return false;
 		const uint64_t rb = (uint64_t)plan.n_pseudo * plan.n_blk * (1 + m->n_feat_per_pseudo_lvl) * plan.cap * 4;
 		const uint64_t ob = ((ow * 4 + 255) / 256) * 256;
 		l.rec_bytes = rb > l.rec_bytes ? rb : l.rec_bytes;
@@ -956,7 +1020,7 @@ static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batch
 		const uint64_t qb = (uint64_t)(work_units() + plan.bucket_base[plan.n_pseudo]) * kLdsDoubles * 4;
 		l.part_bytes = qb > l.part_bytes ? qb : l.part_bytes;
 	}
-	if (n_batches <= 1 && pair_applies(m)) {       // lotd_pair.hip runs in the same regions
+	if (!forest && n_batches <= 1 && pair_applies(m)) {       // lotd_pair.hip runs in the same regions
 		uint64_t rb, ob, pb, qb;
 		pair_layout(m, n_chunk, work_units(), rb, ob, pb, qb);
 		l.rec_bytes = rb > l.rec_bytes ? rb : l.rec_bytes;
@@ -971,10 +1035,10 @@ static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batch
 }
 
 // returns 0 when the binned path does not apply (caller falls back to the atomic kernels)
-uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches) {
-	if (!m || n_points == 0 || !binnable(m)) return 0;
+uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches, bool forest) {
+	if (!m || n_points == 0 || !binnable(m, forest)) return 0;
 	BinLayout lay;
-	if (!layout(m, chunk_points(n_points), n_batches, lay)) return 0;
+	if (!layout(m, chunk_points(n_points), n_batches, lay, forest)) return 0;
 	return lay.total;
 }
 
@@ -1001,21 +1065,21 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	}
 	prof::g_mask & (1u << NR3D_PROF_LOTD_BIN) ? prof::begin(NR3D_PROF_LOTD_BIN, st) : (void)0;
 	if (fo) {
-		if constexpr (D == 3 && NR == 8 && DH) {
+		if constexpr (D == 3 && (NR == 8 || NR == 24 || NR == 48)) {
 			static bool fattr_dev[64] = {};
 			if (!fattr_dev[dev_id & 63]) {
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, true, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
 				fattr_dev[dev_id & 63] = true;
 			}
 			if (second)
-				hipLaunchKernelGGL((k_bin_forest<G, true>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+				hipLaunchKernelGGL((k_bin_forest<G, true, NR>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
 				                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, *fo, rec, offs);
 			else
-				hipLaunchKernelGGL((k_bin_forest<G, false>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+				hipLaunchKernelGGL((k_bin_forest<G, false, NR>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
 				                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, *fo, rec, offs);
 		} else {
-			return ::nr3d::fail("LoTD forest: the binned path handles 3-D Dense/Hash metas only");
+			return ::nr3d::fail("LoTD forest: the binned path handles 3-D metas only");
 		}
 	} else if (second)
 		hipLaunchKernelGGL((k_bin<D, G, true, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
@@ -1044,8 +1108,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
-	if (forest && !(meta->c_hash_only && meta->n_dims_to_encode == 3)) return 0;
-	if (!workspace || !binnable(meta) || !layout(meta, nc, n_batches, lay)) return 0;
+	if (!workspace || !binnable(meta, forest != nullptr) || !layout(meta, nc, n_batches, lay, forest != nullptr)) return 0;
 	if (workspace_bytes < lay.total) return 0;
 	handled = true;
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
@@ -1089,9 +1152,20 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		for (uint32_t cls : kClasses) {
 			BinPlan pl;
 			uint64_t ow;
-			make_plan(meta, n, n_batches, cls, pl, ow, min_level, max_level);
+			make_plan(meta, n, n_batches, cls, pl, ow, min_level, max_level, forest != nullptr);
 			if (pl.n_pseudo == 0) continue;
 			int rc = 0;
+			if (forest) {                                  // 3-D (binnable); one stage-A kernel per record class
+				const uint32_t G = meta->n_feat_per_pseudo_lvl;
+#define NR3D_FOREST_CLASS(G_, NR_) rc = launch_class<3, G_, NR_, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st, forest)
+#define NR3D_FOREST_G(G_) do { if (cls == 8) NR3D_FOREST_CLASS(G_, 8); else if (cls == 24) NR3D_FOREST_CLASS(G_, 24); \
+	else if (cls == 48) NR3D_FOREST_CLASS(G_, 48); } while (0)
+				if (G == 2) NR3D_FOREST_G(2); else if (G == 4) NR3D_FOREST_G(4); else NR3D_FOREST_G(8);
+#undef NR3D_FOREST_G
+#undef NR3D_FOREST_CLASS
+				if (rc) return rc;
+				continue;
+			}
 			// only the (D, class) pairs some level type can produce are instantiated
 			DISPATCH_DG_BIN(D, G, {
 				// hash-only metas (every level Dense or Hash) get kernels without the product-type code
@@ -1101,8 +1175,10 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
 				else if (cls == 16) {
 					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
-				} else {
+				} else if (cls == 24) {
 					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
+				} else {
+					if constexpr (D == 4) rc = launch_class<D, G, 32, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
 				}
 			});
 			if (rc) return rc;

@@ -654,7 +654,7 @@ __device__ __forceinline__ void locate_forest(const float (&xp)[3], const Lvl &L
 }
 
 // lotd_bin.hip: atomic-free parameter-gradient path (all level types but NPlaneSum/CPfast, no batching)
-uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches);
+uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches, bool forest = false);
 void set_dparam_chunk_log2(int lg);
 // `forest` != NULL: the points live in the blocks of a forest (n_batches = n_trees); Dense/Hash 3-D metas only
 // levels below `min_level` are left out (their part of dparam is not touched)

@@ -308,6 +308,10 @@ extern "C" int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *me
 	return 0;
 }
 
+extern "C" uint64_t nr3d_lotd_forest_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint32_t n_trees) {
+	return dparam_workspace_bytes(meta, n_points, n_trees, true);
+}
+
 extern "C" int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                                            uint32_t N, const float *dL_ddLdx, const float *dL_dy, const float *x,
                                            const float *params, const int64_t *block_inds, const int64_t *block_offsets,

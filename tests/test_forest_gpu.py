@@ -252,11 +252,13 @@ def test_space_ray_test_feeds_the_marcher(oracle, dev):
         assert_equal(a, b, name)
 
 
+@pytest.mark.parametrize("case", ["dense_hash", "mixed", "mixed_smooth", "cuboid_f8"])
 @pytest.mark.parametrize("forest", ["plus", "scatter"])
-def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest):
-    """Dense/Hash forests take the sort + segmented-sum path (blocks = batch entries, neighbour-owned corners binned into
-    the neighbour's table); forcing the atomic scatter must give the same gradients, first and second order"""
-    _lotd, fo, m_ref, metas, (x, p, g, v, bi), (xt, pt, gt, vt, bit) = _setup(oracle, dev, forest, "dense_hash", n=20000, seed=9)
+def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest, case):
+    """forests take the sort + segmented-sum path (blocks = batch entries, every corner's updates binned into the tables of
+    the block that owns it; Dense / Hash: 8 records per point and level, CP / NPlaneMul 24, VM 48); forcing the atomic
+    scatter must give the same gradients, first and second order"""
+    _lotd, fo, m_ref, metas, (x, p, g, v, bi), (xt, pt, gt, vt, bit) = _setup(oracle, dev, forest, case, n=20000, seed=9)
     ref1 = oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, accum_double=True)
     ref2 = oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, dL_ddLdx=v, accum_double=True)
     from nr3d_lib_amd.bindings import _forest

@@ -86,7 +86,7 @@ def test_grid_index_bit_exact(oracle, dev, case):
 
 BINNED_CASES = ["ngp_small", "ngp_smooth", "hash_npow2", "dense_f8", "dense_2d", "hash_4d",
                 "mixed", "mixed_cuboid", "mixed_smooth", "cp_only_2d4d", "cp_only_4d", "vecz_nplanemul",
-                "nplane", "nplane_smooth", "cp_2d"]
+                "nplane", "nplane_smooth", "cp_2d", "cp_4d", "nplane_4d"]
 
 
 @pytest.mark.parametrize("case", BINNED_CASES)

@@ -80,6 +80,7 @@ LOTD_CASES = {
     "cp_only_2d4d": (2, [9, 12], [2, 4], ["CP", "NPlaneMul"], None, False),
     "cp_only_4d": (4, [5, 6], [2, 2], ["CP", "Dense"], None, False),
     "cp_4d": (4, [5, 6, 4], [2, 2, 2], ["CP", "NPlaneMul", "CPfast"], None, False),
+    "nplane_4d": (4, [5, 6, 4], [2, 4, 2], ["NPlaneSum", "NPlaneMul", "Dense"], None, True),
 }
 
 
