@@ -152,11 +152,16 @@ int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_d
  * 2-feature pseudo levels; otherwise the caller converts to fp32.  Unlike the reference's __half2 atomics the parameter
  * gradient is accumulated exactly and rounded to half once. */
 int nr3d_lotd_half_params_ok(const nr3d_lotd_meta_t *meta, int batched);
-/* first-order dL/dparam with explicit dtypes: grad_dtype of dL_dy (any strides; F32 for the feature-major copy that
- * nr3d_lotd_bwd_dx leaves), out_dtype of dL_dparam (ZERO-INIT by the caller); workspace as nr3d_lotd_bwd_dparam. */
+/* first-order dL/dparam of the pair-record path (nr3d_lotd_pair_path_ok) with explicit dtypes: grad_dtype of dL_dy (any
+ * strides; F32 for the feature-major copy that nr3d_lotd_bwd_dx leaves), out_dtype of dL_dparam.  assign == 0:
+ * dL_dparam is ZERO-INIT by the caller and accumulated into, like nr3d_lotd_bwd_dparam; assign != 0: dL_dparam arrives
+ * UNINITIALISED and is fully defined on return (the flush writes instead of read-modify-writing when one pass covers
+ * all levels; the library zero-fills it itself otherwise).  workspace as nr3d_lotd_bwd_dparam. */
+int nr3d_lotd_pair_path_ok(const nr3d_lotd_meta_t *meta);
 int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points, int grad_dtype,
                                const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,
-                               int out_dtype, void *dL_dparam, void *workspace, uint64_t workspace_bytes, void *stream);
+                               int out_dtype, int assign, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
+                               void *stream);
 
 /* lod_bwd_bwd_input (lotd_torch_api.cu:575-729), three independent outputs:
  * (i)  dL_ddLdy[i, e] = sum_d dL_ddLdx[i, d] * dy_dx[i, e, d]      (lotd_encoding.h:1703-1727) */

@@ -366,18 +366,26 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
     dev = input.device
     dL_dx = dL_dparam = None
     with torch.cuda.device(dev):
-        if need_input_grad:
-            if dy_dx is None:
-                raise RuntimeError("LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.")
-            dL_dx = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        if need_input_grad and dy_dx is None:
+            raise RuntimeError("LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.")
         batched = batch_inds is not None or batch_offsets is not None or bds != 0
+        nothing = max_level <= -1 or not (need_input_grad or need_param_grad) or N == 0
         # (float, half, float): half dL_dy is read and half dL_dparam written by the kernels themselves when the meta
         # qualifies and dL_dy is a contiguous [N, E] tensor; dL_dparam then needs no cast and is allocated as half
         native = (_native_half(m, params, batched) and level_buckets is None and USE_BINNED_DPARAM and input.dtype == torch.float32
-                  and dL_dy.is_contiguous() and E % 4 == 0 and dL_dy.data_ptr() % 8 == 0 and N > 0 and max_level > -1)
+                  and dL_dy.is_contiguous() and E % 4 == 0 and dL_dy.data_ptr() % 8 == 0 and not nothing
+                  and params.shape[0] == m.n_params)
+        # the pair-record path defines every element of dL_dparam itself (nr3d_lotd_bwd_dparam_typed, assign): no
+        # zero-fill and no read-modify-write of the 46 MiB gradient
+        typed = (not nothing and not batched and level_buckets is None and USE_BINNED_DPARAM
+                 and (native or params.dtype == torch.float32) and params.shape[0] == m.n_params
+                 and bool(H.lib().nr3d_lotd_pair_path_ok(C.byref(m._cmeta()))))
+        if need_input_grad:       # fully written by the dL/dx kernel
+            dL_dx = (torch.zeros if nothing else torch.empty)((N, D), dtype=torch.float32, device=dev)
         if need_param_grad:
-            dL_dparam = torch.zeros((params.shape[0],), dtype=torch.float16 if native else torch.float32, device=dev)
-        if max_level <= -1 or not (need_input_grad or need_param_grad) or (N == 0 and need_param_grad):
+            dL_dparam = (torch.empty if typed else torch.zeros)((params.shape[0],), dtype=torch.float16 if native else torch.float32,
+                                                                device=dev)
+        if nothing:
             if need_param_grad and level_buckets is not None and on_bucket is not None:
                 for k, (lo, hi) in enumerate(level_buckets):     # every bucket is announced (collectives stay matched)
                     on_bucket(k, dL_dparam[m.level_offsets[int(lo)]:m.level_offsets[min(int(hi), m.n_levels - 1) + 1]])
@@ -399,13 +407,14 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                 H.check(H.lib().nr3d_lotd_bwd_dx(
                     C.byref(m._cmeta()), H.u32(N), C.c_int(H.F32), C.c_int(gcode), H.ptr(g32), H.i64(gsn),
                     H.i64(gse), H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), H.ptr(gT), st))
-            if need_param_grad and N > 0 and native:
+            if need_param_grad and N > 0 and typed:
                 ws, wsb = _dparam_workspace(m, N, dev, 1)
                 if gT is not None:
                     g32, gsn, gse, gcode = gT, 1, N, H.F32
                 H.check(H.lib().nr3d_lotd_bwd_dparam_typed(
                     C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(gcode), H.ptr(g32), H.i64(gsn), H.i64(gse),
-                    H.ptr(_f32c(input.detach())), H.i32(max_level), C.c_int(H.F16), H.ptr(dL_dparam), H.ptr(ws), C.c_uint64(wsb), st))
+                    H.ptr(_f32c(input.detach())), H.i32(max_level), C.c_int(H.F16 if native else H.F32), C.c_int(1),
+                    H.ptr(dL_dparam), H.ptr(ws), C.c_uint64(wsb), st))
             elif need_param_grad and N > 0:
                 x32, p32 = _f32c(input.detach()), _f32c(params.detach())
                 nbat = _n_batches(m, p32, batch_offsets, batched)

@@ -1155,20 +1155,26 @@ extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *me
 	                         stream);
 }
 
+extern "C" int nr3d_lotd_pair_path_ok(const nr3d_lotd_meta_t *meta) { return (meta && pair_applies(meta)) ? 1 : 0; }
+
 extern "C" int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int grad_dtype,
                                           const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,
-                                          int out_dtype, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
+                                          int out_dtype, int assign, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
                                           void *stream) {
 	if (int rc = check_common(meta, meta_dev, NR3D_F32, NR3D_F32)) return rc;
 	NR3D_CHECK((grad_dtype == NR3D_F32 || grad_dtype == NR3D_F16) && (out_dtype == NR3D_F32 || out_dtype == NR3D_F16),
 	           "LoTD::bwd_dparam_typed: f32 / f16 only");
-	if (N == 0 || max_level <= -1) return 0;
+	if (N == 0 || max_level <= -1) {
+		if (assign && dL_dparam)
+			NR3D_HIP_CHECK(hipMemsetAsync(dL_dparam, 0, (size_t)meta->n_params * (out_dtype == NR3D_F16 ? 2 : 4), (hipStream_t)stream));
+		return 0;
+	}
 	NR3D_CHECK(dL_dy && x && dL_dparam && workspace, "LoTD::bwd: NULL tensor pointer");
 	bool handled = false;
 	const Batch bb{nullptr, nullptr, 0u, meta->n_params};
 	if (int rc = dparam_binned(false, meta, meta_dev, N, nullptr, (const float *)dL_dy, g_sn, g_se, (const float *)x, nullptr, bb,
 	                           1u, max_level, (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, nullptr,
-	                           0, grad_dtype == NR3D_F16, out_dtype == NR3D_F16))
+	                           0, grad_dtype == NR3D_F16, out_dtype == NR3D_F16, assign != 0))
 		return rc;
 	NR3D_CHECK(handled, "LoTD::bwd_dparam_typed: the pair-record path does not apply to this meta / workspace");
 	return 0;

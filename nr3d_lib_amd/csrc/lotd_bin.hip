@@ -1104,7 +1104,7 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
-                  hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level, bool g_half, bool out_half) {
+                  hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level, bool g_half, bool out_half, bool assign) {
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
@@ -1124,6 +1124,10 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	                      pair_applies(meta);
 	if ((g_half || out_half) && !use_pair)
 		return ::nr3d::fail("LoTD::bwd: half gradients are served natively on the pair-record path only (nr3d_lotd_half_params_ok)");
+	// uninitialised dparam: the pair path assigns when ONE pass covers every level; otherwise zero-fill and accumulate
+	const bool assign_now = assign && use_pair && N <= nc && min_level <= 0 && max_level >= (int32_t)meta->n_levels - 1;
+	if (assign && !assign_now)
+		NR3D_HIP_CHECK(hipMemsetAsync(dparam, 0, (size_t)(n_batches ? n_batches : 1u) * meta->n_params * (out_half ? 2 : 4), st));
 
 	for (uint32_t p0 = 0; p0 < N; p0 += nc) {
 		const uint32_t n = (N - p0) < nc ? (N - p0) : nc;
@@ -1144,8 +1148,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			gc = gt; sn = 1; se = (int64_t)n;
 		}
 		if (use_pair) {
-			if (int rc = pair_chunk(meta, md, n, xc, gc, sn, se, min_level, max_level, work_units(), dparam, out_half, rec, offs,
-			                        plan_buf, partial, st))
+			if (int rc = pair_chunk(meta, md, n, xc, gc, sn, se, min_level, max_level, work_units(), dparam,
+			                        (out_half ? 1u : 0u) | (assign_now ? 2u : 0u), rec, offs, plan_buf, partial, st))
 				return rc;
 			continue;
 		}

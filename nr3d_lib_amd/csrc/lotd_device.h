@@ -662,15 +662,18 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
                   hipStream_t st, bool &handled, const ForestDev *forest = nullptr, int32_t min_level = 0, bool g_half = false,
-                  bool out_half = false);      // g_half: dL_dy is __half; out_half: dparam is __half (pair path only)
+                  bool out_half = false, bool assign = false);
+// g_half: dL_dy is __half; out_half: dparam is __half (pair path only); assign: dparam arrives UNINITIALISED -- the pair
+// path writes every element when one pass covers all levels, every other case zero-fills it first
 
 // lotd_pair.hip: pair-record form of the same path for unbatched 3-D Dense/Hash metas with 2-feature pseudo levels
 bool pair_applies(const nr3d_lotd_meta_t *m);
 void pair_layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t units, uint64_t &rec_bytes, uint64_t &offs_bytes,
                  uint64_t &plan_bytes, uint64_t &part_bytes);
 int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,
-               int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, bool out_half,
-               void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st);
+               int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam,
+               uint32_t out_flags /* bit 0: dparam is __half; bit 1: assign (dparam uninitialised, every element of the
+               plan's levels is written) */, void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st);
 
 }  // namespace lotd
 }  // namespace nr3d

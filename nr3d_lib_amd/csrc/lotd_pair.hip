@@ -458,13 +458,14 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 #pragma unroll
 		for (int k = 0; k < kFlush; ++k) {
 			const uint32_t t = tb + (uint32_t)k * kPAccThreads;
-			p[k] = (t < kPLds) ? pair_target(L, epb, plan.lg, foff0, b, t, dparam, out_half != 0) : nullptr;
+			p[k] = (t < kPLds) ? pair_target(L, epb, plan.lg, foff0, b, t, dparam, (out_half & 1u) != 0) : nullptr;
 			v[k] = p[k] ? value(t) : 0.0f;
 		}
+		const bool half_out = (out_half & 1u) != 0, assign = (out_half & 2u) != 0;     // assign: dparam holds no previous value
 #pragma unroll
-		for (int k = 0; k < kFlush; ++k) old[k] = p[k] ? pair_ld(p[k], out_half != 0) : 0.0f;
+		for (int k = 0; k < kFlush; ++k) old[k] = (p[k] && !assign) ? pair_ld(p[k], half_out) : 0.0f;
 #pragma unroll
-		for (int k = 0; k < kFlush; ++k) if (p[k]) pair_st(p[k], old[k] + v[k], out_half != 0);
+		for (int k = 0; k < kFlush; ++k) if (p[k]) pair_st(p[k], old[k] + v[k], half_out);
 	}
 }
 
@@ -476,7 +477,8 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
                                                               uint32_t out_half) {
 	const uint32_t fb = blockIdx.x;
 	const uint32_t R = rep_g[fb];
-	if (R <= 1) return;
+	const bool half_out = (out_half & 1u) != 0, assign = (out_half & 2u) != 0;
+	if (R == 1 || (R == 0 && !assign)) return;           // assign mode: a bucket without records still has to be written (zeros)
 	uint32_t q = 0;
 	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
 	const uint32_t b = fb - plan.bucket_base[q], qg = plan.qmap[q];
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
 	const float *part0 = partial + (size_t)item_start[fb] * kPLds;
 	const uint32_t t = blockIdx.y * kPAccThreads + threadIdx.x;
 	if (t >= kPLds) return;
-	float *p = pair_target(L, plan.epb[q], plan.lg, foff0, b, t, dparam, out_half != 0);
+	float *p = pair_target(L, plan.epb[q], plan.lg, foff0, b, t, dparam, half_out);
 	if (!p) return;
 	float sum = 0.0f;
 	uint32_t r0 = 0;
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
 		for (int j = 0; j < 8; ++j) sum += v[j];
 	}
 	for (; r0 < R; ++r0) sum += part0[(size_t)r0 * kPLds + t];
-	pair_st(p, pair_ld(p, out_half != 0) + sum, out_half != 0);
+	pair_st(p, (assign ? 0.0f : pair_ld(p, half_out)) + sum, half_out);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -587,7 +589,7 @@ void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32
 
 // one chunk of points: dL_dy given feature-major or with any strides (g_sn, g_se)
 int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,
-               int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, bool out_half,
+               int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, uint32_t out_flags,
                void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st) {
 	PairPlan pl;
 	uint64_t ow;
@@ -626,7 +628,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	hipLaunchKernelGGL(k_pair_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
 	launch_plan_items(NB, pl.n_blk, units, tot, rep, item_start, st);
 #define NR3D_PAIR_ACC(U, F) hipLaunchKernelGGL((k_pair_accum<U, F>), dim3(units + NB), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, pl, md, \
-	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg(), out_half ? 1u : 0u)
+	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg(), out_flags)
 	{
 		prof::Scope ps(NR3D_PROF_LOTD_ACCUM, st);
 		if (pair_fixed()) { if (pair_unroll() == 4) NR3D_PAIR_ACC(4, true); else NR3D_PAIR_ACC(8, true); }
@@ -634,7 +636,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	}
 #undef NR3D_PAIR_ACC
 	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, (2u << pl.lg) / kPAccThreads), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
-	                   dparam, out_half ? 1u : 0u);
+	                   dparam, out_flags);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
