@@ -43,7 +43,9 @@ struct PairPlan {
 	uint32_t cap;                       // records per (pseudo level, point block) slot = 4 x points per block
 	uint32_t lg;                        // log2 of the accumulator entries per bucket (12 or 13)
 	uint32_t sum_log2;                  // updates per accumulator <= 2^sum_log2 (8 corners x points of the pass)
+	uint32_t align_mask;                // bit ql: the level's runs start on 128-byte boundaries inside a slot (offset word = start | pad)
 };
+constexpr uint32_t kPAlignMinNb = 16;   // levels with fewer buckets have runs of >= 256 records: not worth the padding
 
 // points (= threads) per stage-A workgroup; NR3D_PAIR_BP = 512 | 768 | 1024 (measurement knob)
 static uint32_t pair_bp() {
@@ -65,6 +67,14 @@ static uint32_t pair_unroll() {
 static uint32_t pair_dbg() {
 	static int v = -1;
 	if (v < 0) { const char *e = getenv("NR3D_PAIR_DEBUG"); v = e ? atoi(e) : 0; }
+	return (uint32_t)v;
+}
+// runs padded to 128-byte boundaries inside a slot (stage B then never fetches a line another bucket's run shares: its
+// fabric reads drop from 1.32 to 1.07 GB).  OFF by default: measured slower (backward 0.651 -> 0.681 ms) -- stage A has to
+// write its slot one run per wave and step (half-empty 32-record stores) instead of one flat coalesced copy
+static uint32_t pair_align() {
+	static int v = -1;
+	if (v < 0) { const char *e = getenv("NR3D_PAIR_ALIGN"); v = e ? (atoi(e) != 0) : 0; }
 	return (uint32_t)v;
 }
 // stage-B accumulators: 1 = 64-bit fixed point (default), 0 = fp64
@@ -92,7 +102,7 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
                                                    uint32_t *__restrict__ gmax) {
 	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[kPCap] records | hist[nb + 1]
-	__shared__ uint32_t scan_lds[kPBP / 64];
+	__shared__ uint32_t scan_lds[kPBP / 64], scan_lds8[kPBP / 64];
 	u32x4 *stage = reinterpret_cast<u32x4 *>(smem);
 	uint32_t *hist = smem + (size_t)kPCap * 4;
 	const uint32_t blk = blockIdx.x, ql = blockIdx.y;
@@ -226,22 +236,30 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 	}
 	__syncthreads();
 
-	// ---- exclusive scan of the histogram, hist[nb] = total (nb + 1 <= kPBP) ----
+	// ---- exclusive scan of the histogram, hist[nb] = total (nb + 1 <= kPBP); with aligned runs also the scan of the
+	// counts rounded up to 8 records (= 128 bytes): ahist[b] = start of bucket b's run inside the slot ----
+	const bool aligned = (plan.align_mask >> ql) & 1u;
+	uint32_t *ahist = hist + (nb + 1);
 	{
 		const uint32_t b = threadIdx.x;
 		const uint32_t v = (b < nb) ? hist[b] : 0u;
-		uint32_t inc = v;
+		const uint32_t v8 = (v + 7u) & ~7u;
+		uint32_t inc = v, inc8 = v8;
 #pragma unroll
 		for (int off = 1; off < 64; off <<= 1) {
-			const uint32_t t = __shfl_up(inc, off, 64);
-			if ((int)lane >= off) inc += t;
+			const uint32_t t = __shfl_up(inc, off, 64), t8 = __shfl_up(inc8, off, 64);
+			if ((int)lane >= off) { inc += t; inc8 += t8; }
 		}
-		if (lane == 63) scan_lds[threadIdx.x >> 6] = inc;
+		if (lane == 63) { scan_lds[threadIdx.x >> 6] = inc; scan_lds8[threadIdx.x >> 6] = inc8; }
 		__syncthreads();
-		uint32_t wave_off = 0;
+		uint32_t wave_off = 0, wave_off8 = 0;
 #pragma unroll
-		for (int k = 0; k < kPBP / 64; ++k) { const uint32_t t = scan_lds[k]; if (k < (int)(threadIdx.x >> 6)) wave_off += t; }
-		if (b <= nb) hist[b] = wave_off + inc - v;
+		for (int k = 0; k < kPBP / 64; ++k)
+			if (k < (int)(threadIdx.x >> 6)) { wave_off += scan_lds[k]; wave_off8 += scan_lds8[k]; }
+		if (b <= nb) {
+			hist[b] = wave_off + inc - v;
+			if (aligned) ahist[b] = (wave_off8 + inc8 - v8) | (v8 - v);      // start (multiple of 8) | padding after the run (0..7)
+		}
 		__syncthreads();
 	}
 
@@ -278,26 +296,100 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 	}
 
 	// ---- coalesced write-out (written once, read once by stage B: non-temporal) ----
-	const uint32_t total = hist[nb];
-	u32x4 *dst = rec + ((size_t)ql * plan.n_blk + blk) * (size_t)kPCap;
-	for (uint32_t v = threadIdx.x; v < total; v += kPBP) __builtin_nontemporal_store(stage[v], dst + v);
+	u32x4 *dst = rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap;
 	uint32_t *ob = offs_g + plan.offs_base[ql];
-	for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
+	if (!aligned) {
+		const uint32_t total = hist[nb];
+		for (uint32_t v = threadIdx.x; v < total; v += kPBP) __builtin_nontemporal_store(stage[v], dst + v);
+		for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
+	} else {
+		// one run per wave and step: every run starts on a 128-byte boundary of the slot
+		for (uint32_t b = threadIdx.x >> 6; b < nb; b += kPBP / 64) {
+			const uint32_t s0 = hist[b], cnt = hist[b + 1] - s0, a0 = ahist[b] & ~7u;
+			for (uint32_t v = lane; v < cnt; v += 64) __builtin_nontemporal_store(stage[s0 + v], dst + a0 + v);
+		}
+		for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) ob[(size_t)b * plan.n_blk + blk] = ahist[b];
+	}
 }
 
-// records per bucket over all point blocks
-__global__ __launch_bounds__(256) void k_pair_totals(PairPlan plan, const uint32_t *__restrict__ offs_g, uint32_t *__restrict__ tot) {
-	const uint32_t fb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-	if (fb >= plan.bucket_base[plan.n_pseudo]) return;
-	uint32_t q = 0;
-	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
-	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)(fb - plan.bucket_base[q]) * plan.n_blk;
-	const uint32_t *ob1 = ob0 + plan.n_blk;
-	uint32_t sum = 0;
-	for (uint32_t blk = lane; blk < plan.n_blk; blk += 64) sum += ob1[blk] - ob0[blk];
+// Records per bucket over all point blocks (one wave per bucket), and -- in the LAST workgroup to finish -- the stage-B work
+// plan: a bucket with more than total / n_units records is split into replicas over its point blocks, empty buckets
+// get no workgroup (item_start = exclusive prefix of the replica counts).  One launch instead of a totals kernel and a
+// single-workgroup planning kernel; `ticket` (zeroed with gmax) counts finished workgroups.
+__global__ __launch_bounds__(1024) void k_pair_plan(PairPlan plan, const uint32_t *__restrict__ offs_g, uint32_t n_units,
+                                                    uint32_t *__restrict__ tot, uint32_t *__restrict__ rep,
+                                                    uint32_t *__restrict__ item_start, uint32_t *__restrict__ ticket) {
+	__shared__ uint64_t red[16];
+	__shared__ uint64_t carry_s;
+	__shared__ uint32_t last_s;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t NB = plan.bucket_base[plan.n_pseudo];
+	{
+		const uint32_t fb = blockIdx.x * 16 + wave;
+		if (fb < NB) {
+			uint32_t q = 0;
+			while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
+			const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)(fb - plan.bucket_base[q]) * plan.n_blk;
+			const uint32_t *ob1 = ob0 + plan.n_blk;
+			const bool aligned = (plan.align_mask >> q) & 1u;
+			uint32_t sum = 0;
+			for (uint32_t blk = lane; blk < plan.n_blk; blk += 64) {
+				const uint32_t a = ob0[blk], e = ob1[blk];
+				sum += aligned ? (e & ~7u) - (a & ~7u) - (a & 7u) : e - a;
+			}
 #pragma unroll
-	for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-	if (lane == 0) tot[fb] = sum;
+			for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+			if (lane == 0) __hip_atomic_store(tot + fb, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2-visible
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		last_s = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
+	__syncthreads();
+	if (!last_s) return;
+	auto ld_tot = [&](uint32_t fb) { return (uint64_t)__hip_atomic_load(tot + fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+	uint64_t part = 0;
+	for (uint32_t fb = threadIdx.x; fb < NB; fb += 1024) part += ld_tot(fb);
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+	if (lane == 0) red[wave] = part;
+	__syncthreads();
+	uint64_t total = 0;
+#pragma unroll
+	for (int w = 0; w < 16; ++w) total += red[w];
+	const uint64_t unit = total / n_units > 0 ? total / n_units : 1;
+	if (threadIdx.x == 0) carry_s = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < NB; base += 1024) {
+		const uint32_t fb = base + threadIdx.x;
+		uint32_t r = 0;
+		if (fb < NB) {
+			const uint64_t t = ld_tot(fb);
+			r = t == 0 ? 0u : (uint32_t)((t + unit / 2) / unit);
+			if (t != 0 && r < 1) r = 1;
+			if (r > plan.n_blk) r = plan.n_blk;
+			rep[fb] = r;
+		}
+		uint64_t inc = r;                      // inclusive scan over the 1024 threads
+#pragma unroll
+		for (int off = 1; off < 64; off <<= 1) { const uint64_t t2 = __shfl_up(inc, off, 64); if ((int)lane >= off) inc += t2; }
+		__syncthreads();
+		if (lane == 63) red[wave] = inc;
+		__syncthreads();
+		uint64_t woff = 0, tsum = 0;
+#pragma unroll
+		for (int w = 0; w < 16; ++w) { if (w < (int)wave) woff += red[w]; tsum += red[w]; }
+		const uint64_t c = carry_s;
+		if (fb < NB) item_start[fb] = (uint32_t)(c + woff + inc - r);
+		__syncthreads();
+		if (threadIdx.x == 0) carry_s = c + tsum;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) item_start[NB] = (uint32_t)carry_s;
 }
 
 // accumulator slot t (feature-major: t = f * 2^lg + el) of bucket b -> element of dL/dparam, nullptr outside the level
@@ -392,8 +484,12 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 	constexpr int kGroup = 8;
 	for (uint32_t blk0 = w_lo; blk0 < w_hi; blk0 += 64) {
 		const uint32_t mb = blk0 + lane;
-		const uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
-		const uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
+		uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
+		uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
+		if ((plan.align_mask >> q) & 1u) {               // start | padding: the run ends `padding` records before the next start
+			e_l = (e_l & ~7u) - (s_l & 7u);
+			s_l &= ~7u;
+		}
 		const uint32_t n_run = min(64u, w_hi - blk0);
 		const u32x4 *rec_b = rec_q + (size_t)blk0 * kPCap;
 		for (uint32_t j0 = 0; j0 < n_run; j0 += kGroup) {
@@ -469,6 +565,7 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 	}
 }
 
+constexpr uint32_t kRedRows = 4;
 // dL/dparam slice of a replicated bucket += sum of the replicas' partial tables, replica 0 first
 __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
                                                               const uint32_t *__restrict__ rep_g,
@@ -486,21 +583,25 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
 	const uint32_t foff0 = meta_cnt_of(md, qg) * 2u;
 	const uint32_t kPLds = 2u << plan.lg;
 	const float *part0 = partial + (size_t)item_start[fb] * kPLds;
-	const uint32_t t = blockIdx.y * kPAccThreads + threadIdx.x;
-	if (t >= kPLds) return;
-	float *p = pair_target(L, plan.epb[q], plan.lg, foff0, b, t, dparam, half_out);
-	if (!p) return;
-	float sum = 0.0f;
-	uint32_t r0 = 0;
-	for (; r0 + 8 <= R; r0 += 8) {
-		float v[8];
+	// kRedRows rows of 1024 accumulators per workgroup: most buckets have one work item and leave at the top, so fewer,
+	// fatter workgroups cut the dispatch time of this nearly empty launch
+	for (uint32_t row = 0; row < kRedRows; ++row) {
+		const uint32_t t = (blockIdx.y * kRedRows + row) * kPAccThreads + threadIdx.x;
+		if (t >= kPLds) return;
+		float *p = pair_target(L, plan.epb[q], plan.lg, foff0, b, t, dparam, half_out);
+		if (!p) continue;
+		float sum = 0.0f;
+		uint32_t r0 = 0;
+		for (; r0 + 8 <= R; r0 += 8) {
+			float v[8];
 #pragma unroll
-		for (int j = 0; j < 8; ++j) v[j] = part0[(size_t)(r0 + j) * kPLds + t];
+			for (int j = 0; j < 8; ++j) v[j] = part0[(size_t)(r0 + j) * kPLds + t];
 #pragma unroll
-		for (int j = 0; j < 8; ++j) sum += v[j];
+			for (int j = 0; j < 8; ++j) sum += v[j];
+		}
+		for (; r0 < R; ++r0) sum += part0[(size_t)r0 * kPLds + t];
+		pair_st(p, (assign ? 0.0f : pair_ld(p, half_out)) + sum, half_out);
 	}
-	for (; r0 < R; ++r0) sum += part0[(size_t)r0 * kPLds + t];
-	pair_st(p, (assign ? 0.0f : pair_ld(p, half_out)) + sum, half_out);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -540,6 +641,8 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
                       uint64_t &offs_words) {
 	plan.n_blk = div_up(n_chunk, pair_bp());
 	plan.cap = pair_bp() * 4u;
+	plan.align_mask = 0;
+	uint32_t nb_align = 0;
 	plan.lg = pair_lg();
 	plan.sum_log2 = 3;
 	while ((1ull << (plan.sum_log2 - 3)) < n_chunk) ++plan.sum_log2;
@@ -561,6 +664,7 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
 			nb = L.size <= kPEpb ? 1u : (L.size >> plan.lg);
 		}
 		plan.qmap[nq] = q; plan.nb[nq] = nb; plan.epb[nq] = epb; plan.shift[nq] = sh;
+		if (nb >= kPAlignMinNb && pair_align()) { plan.align_mask |= 1u << nq; nb_align = nb_align > nb ? nb_align : nb; }
 		plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
 		plan.offs_base[nq] = (uint32_t)base;
 		base += (uint64_t)(nb + 1) * plan.n_blk;
@@ -568,6 +672,7 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
 	}
 	plan.n_pseudo = nq;
 	plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
+	plan.cap += 8u * nb_align;          // room for the run padding (address space, not traffic)
 	offs_words = base;
 }
 
@@ -599,9 +704,9 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
 	const uint32_t NB = pl.bucket_base[pl.n_pseudo];
 	uint32_t *tot = plan_buf, *rep = plan_buf + NB, *item_start = plan_buf + 2 * (size_t)NB;
-	uint32_t *gmax = plan_buf + 3 * (size_t)NB + 2;                  // spare word of the plan region
+	uint32_t *gmax = plan_buf + 3 * (size_t)NB + 2;                  // two spare words of the plan region: gmax | ticket
 	units = pair_units();
-	const size_t bin_lds_max = (size_t)1024 * 4 * 16 + (size_t)(kPMaxNb + 2) * 4;
+	const size_t bin_lds_max = (size_t)1024 * 4 * 16 + (size_t)(kPMaxNb + 2) * 8;
 	static bool attr_set_dev[64] = {};
 	int dev_id = 0;
 	NR3D_HIP_CHECK(hipGetDevice(&dev_id));
@@ -615,9 +720,9 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		attr_set_dev[dev_id & 63] = true;
 	}
-	NR3D_HIP_CHECK(hipMemsetAsync(gmax, 0, sizeof(uint32_t), st));
+	NR3D_HIP_CHECK(hipMemsetAsync(gmax, 0, 2 * sizeof(uint32_t), st));      // gmax | ticket of k_pair_plan
 	const uint32_t bp = pair_bp();
-	const size_t bin_lds = (size_t)pl.cap * 16 + (size_t)(nb_max + 1) * 4;
+	const size_t bin_lds = (size_t)bp * 4 * 16 + (size_t)(nb_max + 1) * 8;     // stage | hist | ahist
 #define NR3D_PAIR_BIN(BP) hipLaunchKernelGGL(k_pair_bin<BP>, dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level, \
 	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax)
 	{
@@ -625,8 +730,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 		if (bp == 512) NR3D_PAIR_BIN(512); else if (bp == 768) NR3D_PAIR_BIN(768); else NR3D_PAIR_BIN(1024);
 	}
 #undef NR3D_PAIR_BIN
-	hipLaunchKernelGGL(k_pair_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
-	launch_plan_items(NB, pl.n_blk, units, tot, rep, item_start, st);
+	hipLaunchKernelGGL(k_pair_plan, dim3(div_up(NB, 16)), dim3(1024), 0, st, pl, offs, units, tot, rep, item_start, gmax + 1);
 #define NR3D_PAIR_ACC(U, F) hipLaunchKernelGGL((k_pair_accum<U, F>), dim3(units + NB), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, pl, md, \
 	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg(), out_flags)
 	{
@@ -635,7 +739,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 		else              { if (pair_unroll() == 4) NR3D_PAIR_ACC(4, false); else NR3D_PAIR_ACC(8, false); }
 	}
 #undef NR3D_PAIR_ACC
-	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, (2u << pl.lg) / kPAccThreads), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
+	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, div_up((2u << pl.lg) / kPAccThreads, kRedRows)), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
 	                   dparam, out_flags);
 	NR3D_LAUNCH_CHECK();
 	return 0;
