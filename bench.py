@@ -83,8 +83,9 @@ def cpu_baseline(cfg, n_sample_log2=17, min_seconds=10.0, c3=None):
     """the CPU oracle (oracle/, a C restatement with OpenMP -- kind 'port') on a bounded sample of the workload.
     `c3` = (scene tensors, n_rays, step, seconds): the march + composite leg of the metric instead (configs[2])"""
     import oracle
+    cores = oracle.set_num_threads(oracle.host_cores())     # the container's CPU quota, not the host's core count
     if c3 is not None:
-        return _cpu_baseline_c3(oracle, *c3)
+        return _cpu_baseline_c3(oracle, cores, *c3)
     m = oracle.lotd_create_meta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
     rng = np.random.default_rng(42)
     n = 1 << n_sample_log2
@@ -96,17 +97,17 @@ def cpu_baseline(cfg, n_sample_log2=17, min_seconds=10.0, c3=None):
     while True:
         y, j = oracle.lotd_fwd(m, x, p, need_dydx=True)
         oracle.lotd_bwd_dx(m, g, j)
-        oracle.lotd_bwd_dparam(m, g, x, p)
+        oracle.lotd_bwd_dparam(m, g, x, p, accum_double=2)      # 2 = float sums over (level, point-slab) tasks: all cores busy
         reps += 1
         el = time.perf_counter() - t0
         if el >= min_seconds or reps >= 64:
             break
-    return dict(value=round(reps * n / el / 1e6, 4), unit="Mpoints/s", cores=os.cpu_count(), kind="port",
+    return dict(value=round(reps * n / el / 1e6, 4), unit="Mpoints/s", cores=cores, kind="port",
                 sample=f"{reps} x 2^{n_sample_log2} points, same 16-level meta, fwd+dydx + dL/dx + dL/dparam "
                        f"({el:.1f} s of OpenMP CPU work)")
 
 
-def _cpu_baseline_c3(oracle, scene, n, step, seconds):
+def _cpu_baseline_c3(oracle, cores, scene, n, step, seconds):
     """configs[2] on the host: the oracle's marcher (C, OpenMP) + the reference's pack-op chain (alpha_to_vw, packed_sum x3,
     packed_div; numpy glue) forward and backward.  Returns (grid probes of one march, samples, cpu_baseline dict)."""
     o_c, d_c, near_c, far_c, roi_c, grid_c = scene
@@ -139,7 +140,7 @@ def _cpu_baseline_c3(oracle, scene, n, step, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or reps >= 1000:
             break
-    base = dict(value=round(reps * n / el / 1e6, 4), unit="Mrays/s", cores=os.cpu_count(), kind="port",
+    base = dict(value=round(reps * n / el / 1e6, 4), unit="Mrays/s", cores=cores, kind="port",
                 sample=f"{reps} x {n} rays: the oracle's marcher (C, OpenMP) + the pack-op chain "
                        f"(alpha_to_vw, packed_sum x3, packed_div; numpy glue) fwd+bwd, {el:.1f} s of CPU work")
     return int(probes), int(S_r), base

@@ -162,6 +162,17 @@ int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_de
                                const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,
                                int out_dtype, int assign, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
                                void *stream);
+/* dL/dx AND dL/dparam in one pass over dL_dy (k_pair_bin_all, lotd_pair.hip): the same results, bit for bit, as
+ * nr3d_lotd_bwd_dx followed by nr3d_lotd_bwd_dparam_typed -- the reference's kernel_lod_backward_input +
+ * kernel_lod_backward (lotd_torch_api.cu:455-573) -- for metas where nr3d_lotd_bwd_fused_ok() returns 1 (pair-record
+ * path, <= 32 encoded dims).  dL_dy [N, E] with strides (g_sn, g_se) in elements, dtype grad_dtype; dy_dx as handed out
+ * by nr3d_lotd_fwd with strides (d_sn, d_se); dL_dx contiguous float [N, 3]; dL_dparam / assign / workspace as
+ * nr3d_lotd_bwd_dparam_typed. */
+int nr3d_lotd_bwd_fused_ok(const nr3d_lotd_meta_t *meta);
+int nr3d_lotd_bwd_fused(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points, int grad_dtype,
+                        const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, const void *dy_dx, int64_t d_sn,
+                        int64_t d_se, int32_t max_level, int out_dtype, int assign, void *dL_dparam, void *dL_dx,
+                        void *workspace, uint64_t workspace_bytes, void *stream);
 
 /* lod_bwd_bwd_input (lotd_torch_api.cu:575-729), three independent outputs:
  * (i)  dL_ddLdy[i, e] = sum_d dL_ddLdx[i, d] * dy_dx[i, e, d]      (lotd_encoding.h:1703-1727) */

@@ -1180,6 +1180,36 @@ extern "C" int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const vo
 	return 0;
 }
 
+extern "C" int nr3d_lotd_bwd_fused_ok(const nr3d_lotd_meta_t *meta) { return meta && pair_all_applies(meta) ? 1 : 0; }
+
+// dL/dx and dL/dparam of one dL_dy in one pass over it (lotd_pair.hip, k_pair_bin_all): what nr3d_lotd_bwd_dx followed by
+// nr3d_lotd_bwd_dparam_typed compute, bit for bit, without the feature-major copy of dL_dy in between
+extern "C" int nr3d_lotd_bwd_fused(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int grad_dtype,
+                                   const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, const void *dy_dx,
+                                   int64_t d_sn, int64_t d_se, int32_t max_level, int out_dtype, int assign, void *dL_dparam,
+                                   void *dL_dx, void *workspace, uint64_t workspace_bytes, void *stream) {
+	if (int rc = check_common(meta, meta_dev, NR3D_F32, NR3D_F32)) return rc;
+	NR3D_CHECK((grad_dtype == NR3D_F32 || grad_dtype == NR3D_F16) && (out_dtype == NR3D_F32 || out_dtype == NR3D_F16),
+	           "LoTD::bwd_fused: f32 / f16 only");
+	NR3D_CHECK(pair_all_applies(meta), "LoTD::bwd_fused: not served for this meta (nr3d_lotd_bwd_fused_ok)");
+	NR3D_CHECK(max_level >= 0, "LoTD::bwd_fused: max_level must be >= 0");
+	if (N == 0) {
+		if (assign && dL_dparam)
+			NR3D_HIP_CHECK(hipMemsetAsync(dL_dparam, 0, (size_t)meta->n_params * (out_dtype == NR3D_F16 ? 2 : 4), (hipStream_t)stream));
+		return 0;
+	}
+	NR3D_CHECK(dL_dy && x && dy_dx && dL_dparam && dL_dx && workspace, "LoTD::bwd_fused: NULL tensor pointer");
+	bool handled = false;
+	const Batch bb{nullptr, nullptr, 0u, meta->n_params};
+	const FusedDx fdx{(const float *)dy_dx, d_sn, d_se, (float *)dL_dx};
+	if (int rc = dparam_binned(false, meta, meta_dev, N, nullptr, (const float *)dL_dy, g_sn, g_se, (const float *)x, nullptr, bb,
+	                           1u, max_level, (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, nullptr,
+	                           0, grad_dtype == NR3D_F16, out_dtype == NR3D_F16, assign != 0, &fdx))
+		return rc;
+	NR3D_CHECK(handled, "LoTD::bwd_fused: workspace too small (nr3d_lotd_dparam_workspace_bytes)");
+	return 0;
+}
+
 extern "C" int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
                                            int param_dtype, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
                                            const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,

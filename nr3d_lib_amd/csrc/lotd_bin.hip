@@ -1104,7 +1104,8 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
-                  hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level, bool g_half, bool out_half, bool assign) {
+                  hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level, bool g_half, bool out_half, bool assign,
+                  const FusedDx *fdx) {
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
@@ -1122,6 +1123,10 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	// first-order gradient of an unbatched 3-D Dense/Hash meta with 2-feature pseudo levels: pair records (lotd_pair.hip)
 	const bool use_pair = !second && !forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size &&
 	                      pair_applies(meta);
+	// ... with every level binned by ONE workgroup per point block, straight from the caller's dL_dy (and dL/dx on the way)
+	const bool use_all = use_pair && pair_all_applies(meta);
+	if (fdx && !(use_all && min_level <= 0))
+		return ::nr3d::fail("LoTD::bwd_fused: the all-levels pair path does not apply (nr3d_lotd_bwd_fused_ok)");
 	if ((g_half || out_half) && !use_pair)
 		return ::nr3d::fail("LoTD::bwd: half gradients are served natively on the pair-record path only (nr3d_lotd_half_params_ok)");
 	// uninitialised dparam: the pair path assigns when ONE pass covers every level; otherwise zero-fill and accumulate
@@ -1139,6 +1144,15 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		Batch ba = batch;                              // this chunk's view of the batch description
 		if (ba.inds) ba.inds += p0;
 		ba.first_point = p0;
+		if (use_all) {
+			FusedDx fc;
+			if (fdx) fc = FusedDx{fdx->dydx + (int64_t)p0 * fdx->d_sn, fdx->d_sn, fdx->d_se, fdx->dL_dx + (size_t)p0 * D};
+			if (int rc = pair_chunk(meta, md, n, xc, gc, g_sn, g_se, min_level, max_level, work_units(), dparam,
+			                        (out_half ? 1u : 0u) | (assign_now ? 2u : 0u), rec, offs, plan_buf, partial, st, true, g_half,
+			                        fdx ? &fc : nullptr))
+				return rc;
+			continue;
+		}
 		if (row_major) {
 			if (g_half)
 				hipLaunchKernelGGL(k_transpose<__half>, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E,

@@ -43,9 +43,7 @@ struct PairPlan {
 	uint32_t cap;                       // records per (pseudo level, point block) slot = 4 x points per block
 	uint32_t lg;                        // log2 of the accumulator entries per bucket (12 or 13)
 	uint32_t sum_log2;                  // updates per accumulator <= 2^sum_log2 (8 corners x points of the pass)
-	uint32_t align_mask;                // bit ql: the level's runs start on 128-byte boundaries inside a slot (offset word = start | pad)
 };
-constexpr uint32_t kPAlignMinNb = 16;   // levels with fewer buckets have runs of >= 256 records: not worth the padding
 
 // points (= threads) per stage-A workgroup; NR3D_PAIR_BP = 512 | 768 | 1024 (measurement knob)
 static uint32_t pair_bp() {
@@ -69,14 +67,6 @@ static uint32_t pair_dbg() {
 	if (v < 0) { const char *e = getenv("NR3D_PAIR_DEBUG"); v = e ? atoi(e) : 0; }
 	return (uint32_t)v;
 }
-// runs padded to 128-byte boundaries inside a slot (stage B then never fetches a line another bucket's run shares: its
-// fabric reads drop from 1.32 to 1.07 GB).  OFF by default: measured slower (backward 0.651 -> 0.681 ms) -- stage A has to
-// write its slot one run per wave and step (half-empty 32-record stores) instead of one flat coalesced copy
-static uint32_t pair_align() {
-	static int v = -1;
-	if (v < 0) { const char *e = getenv("NR3D_PAIR_ALIGN"); v = e ? (atoi(e) != 0) : 0; }
-	return (uint32_t)v;
-}
 // stage-B accumulators: 1 = 64-bit fixed point (default), 0 = fp64
 static uint32_t pair_fixed() {
 	static int v = -1;
@@ -94,42 +84,25 @@ static uint32_t pair_units() {
 // -------------------------------------------------------------------------------------------------
 // Stage A
 // -------------------------------------------------------------------------------------------------
+// One pseudo level of one block of kPBP points: pair records -> rank inside the bucket -> counting sort in LDS ->
+// coalesced write-out of the slot + its bucket offsets.  `hist` [nb + 1] must be zero on entry (and that visible: a
+// barrier behind the zeroing); `zero_next` (optional) is zeroed for the following call.  Four barriers.
 template <int kPBP>
-__global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
-                                                   int32_t max_level, uint32_t smooth, const float *__restrict__ x,
-                                                   const float *__restrict__ g, int64_t g_sn, int64_t g_se,
-                                                   u32x4 *__restrict__ rec, uint32_t *__restrict__ offs_g,
-                                                   uint32_t *__restrict__ gmax) {
-	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
-	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[kPCap] records | hist[nb + 1]
-	__shared__ uint32_t scan_lds[kPBP / 64], scan_lds8[kPBP / 64];
-	u32x4 *stage = reinterpret_cast<u32x4 *>(smem);
-	uint32_t *hist = smem + (size_t)kPCap * 4;
-	const uint32_t blk = blockIdx.x, ql = blockIdx.y;
-	const uint32_t q = plan.qmap[ql], nb = plan.nb[ql];
-	const uint32_t level = meta_level_of(md, q);
-	const Lvl L = load_level(md, level);
-	const uint32_t i = blk * kPBP + threadIdx.x;
+__device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, const Lvl &L, bool active, const float (&xp)[3],
+                                           float g0, float g1, uint32_t smooth, u32x4 *__restrict__ stage,
+                                           uint32_t *__restrict__ hist, uint32_t *__restrict__ zero_next, uint32_t *scan_lds,
+                                           u32x4 *__restrict__ dst, uint32_t *__restrict__ ob, uint32_t ob_stride) {
+	const uint32_t nb = plan.nb[ql];
 	const uint32_t lane = threadIdx.x & 63u;
-
-	for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) hist[b] = 0;
-	__syncthreads();
-
-	const bool active = (i < n) && ((int32_t)level <= max_level);
 	uint32_t hdr[4], bkt[4], cell[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 	float A[4][2], wp = 0.0f;
-	uint32_t gbits = 0;                 // max |dL/dy| of this lane as float bits (the fixed-point scale of stage B)
 #pragma unroll
 	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; }
+	if (zero_next)
+		for (uint32_t b = threadIdx.x; b <= kPMaxNb; b += kPBP) zero_next[b] = 0;
 	if (active) {
-		float xp[3];
-#pragma unroll
-		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
 		Cell<3> c;
 		locate<3>(xp, L, smooth != 0, c);
-		const float g0 = g[(int64_t)i * g_sn + (int64_t)(q * 2) * g_se];
-		const float g1 = g[(int64_t)i * g_sn + (int64_t)(q * 2 + 1) * g_se];
-		gbits = max(__float_as_uint(g0) & 0x7FFFFFFFu, __float_as_uint(g1) & 0x7FFFFFFFu);
 		const uint32_t sh = plan.shift[ql], epb = plan.epb[ql];
 		if (L.type == NR3D_LOD_Dense) {
 			wp = c.w[2];
@@ -236,30 +209,22 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 	}
 	__syncthreads();
 
-	// ---- exclusive scan of the histogram, hist[nb] = total (nb + 1 <= kPBP); with aligned runs also the scan of the
-	// counts rounded up to 8 records (= 128 bytes): ahist[b] = start of bucket b's run inside the slot ----
-	const bool aligned = (plan.align_mask >> ql) & 1u;
-	uint32_t *ahist = hist + (nb + 1);
+	// ---- exclusive scan of the histogram, hist[nb] = total (nb + 1 <= kPBP) ----
 	{
 		const uint32_t b = threadIdx.x;
 		const uint32_t v = (b < nb) ? hist[b] : 0u;
-		const uint32_t v8 = (v + 7u) & ~7u;
-		uint32_t inc = v, inc8 = v8;
+		uint32_t inc = v;
 #pragma unroll
 		for (int off = 1; off < 64; off <<= 1) {
-			const uint32_t t = __shfl_up(inc, off, 64), t8 = __shfl_up(inc8, off, 64);
-			if ((int)lane >= off) { inc += t; inc8 += t8; }
+			const uint32_t t = __shfl_up(inc, off, 64);
+			if ((int)lane >= off) inc += t;
 		}
-		if (lane == 63) { scan_lds[threadIdx.x >> 6] = inc; scan_lds8[threadIdx.x >> 6] = inc8; }
+		if (lane == 63) scan_lds[threadIdx.x >> 6] = inc;
 		__syncthreads();
-		uint32_t wave_off = 0, wave_off8 = 0;
+		uint32_t wave_off = 0;
 #pragma unroll
-		for (int k = 0; k < kPBP / 64; ++k)
-			if (k < (int)(threadIdx.x >> 6)) { wave_off += scan_lds[k]; wave_off8 += scan_lds8[k]; }
-		if (b <= nb) {
-			hist[b] = wave_off + inc - v;
-			if (aligned) ahist[b] = (wave_off8 + inc8 - v8) | (v8 - v);      // start (multiple of 8) | padding after the run (0..7)
-		}
+		for (int k = 0; k < kPBP / 64; ++k) { const uint32_t t = scan_lds[k]; if (k < (int)(threadIdx.x >> 6)) wave_off += t; }
+		if (b <= nb) hist[b] = wave_off + inc - v;
 		__syncthreads();
 	}
 
@@ -279,37 +244,147 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 	}
 	__syncthreads();
 
-	if (gmax) {
-		// |float| bits order like unsigned integers (NaN / inf on top).  One candidate per workgroup, and the atomic only
-		// when it would raise the running maximum (an L2 load first): 2^18 same-address atomics would serialise for ms
-#pragma unroll
-		for (int off = 32; off >= 1; off >>= 1) gbits = max(gbits, (uint32_t)__shfl_xor((int)gbits, off, 64));
-		__syncthreads();                                       // scan_lds is free again
-		if (lane == 0) scan_lds[threadIdx.x >> 6] = gbits;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			uint32_t m = 0;
-#pragma unroll
-			for (int k = 0; k < kPBP / 64; ++k) m = max(m, scan_lds[k]);
-			if (m > __hip_atomic_load(gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gmax, m);
-		}
-	}
-
 	// ---- coalesced write-out (written once, read once by stage B: non-temporal) ----
-	u32x4 *dst = rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap;
-	uint32_t *ob = offs_g + plan.offs_base[ql];
-	if (!aligned) {
-		const uint32_t total = hist[nb];
-		for (uint32_t v = threadIdx.x; v < total; v += kPBP) __builtin_nontemporal_store(stage[v], dst + v);
-		for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
-	} else {
-		// one run per wave and step: every run starts on a 128-byte boundary of the slot
-		for (uint32_t b = threadIdx.x >> 6; b < nb; b += kPBP / 64) {
-			const uint32_t s0 = hist[b], cnt = hist[b + 1] - s0, a0 = ahist[b] & ~7u;
-			for (uint32_t v = lane; v < cnt; v += 64) __builtin_nontemporal_store(stage[s0 + v], dst + a0 + v);
-		}
-		for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) ob[(size_t)b * plan.n_blk + blk] = ahist[b];
+	const uint32_t total = hist[nb];
+	for (uint32_t v = threadIdx.x; v < total; v += kPBP) __builtin_nontemporal_store(stage[v], dst + v);
+	for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) ob[(size_t)b * ob_stride] = hist[b];
+}
+
+// max |dL/dy| of the workgroup as float bits -> gmax (the fixed-point scale of stage B).  |float| bits order like
+// unsigned integers (NaN / inf on top).  One candidate per workgroup, and the atomic only when it would raise the running
+// maximum (an L2 load first): 2^18 same-address atomics would serialise for ms
+template <int kPBP>
+__device__ __forceinline__ void pair_gmax(uint32_t gbits, uint32_t *scan_lds, uint32_t *__restrict__ gmax) {
+	const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) gbits = max(gbits, (uint32_t)__shfl_xor((int)gbits, off, 64));
+	__syncthreads();                                       // scan_lds is free
+	if (lane == 0) scan_lds[threadIdx.x >> 6] = gbits;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t m = 0;
+#pragma unroll
+		for (int k = 0; k < kPBP / 64; ++k) m = max(m, scan_lds[k]);
+		if (m > __hip_atomic_load(gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gmax, m);
 	}
+}
+
+// one workgroup = kPBP points x ONE pseudo level; dL_dy given feature-major (coalesced columns) or with any strides
+template <int kPBP>
+__global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                   int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                   const float *__restrict__ g, int64_t g_sn, int64_t g_se,
+                                                   u32x4 *__restrict__ rec, uint32_t *__restrict__ offs_g,
+                                                   uint32_t *__restrict__ gmax) {
+	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[kPCap] records | hist[nb + 1]
+	__shared__ uint32_t scan_lds[kPBP / 64];
+	u32x4 *stage = reinterpret_cast<u32x4 *>(smem);
+	uint32_t *hist = smem + (size_t)kPCap * 4;
+	const uint32_t blk = blockIdx.x, ql = blockIdx.y;
+	const uint32_t q = plan.qmap[ql], nb = plan.nb[ql];
+	const uint32_t level = meta_level_of(md, q);
+	const Lvl L = load_level(md, level);
+	const uint32_t i = blk * kPBP + threadIdx.x;
+	for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) hist[b] = 0;
+	__syncthreads();
+	const bool active = (i < n) && ((int32_t)level <= max_level);
+	float xp[3] = {0.0f, 0.0f, 0.0f}, g0 = 0.0f, g1 = 0.0f;
+	if (active) {
+#pragma unroll
+		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
+		g0 = g[(int64_t)i * g_sn + (int64_t)(q * 2) * g_se];
+		g1 = g[(int64_t)i * g_sn + (int64_t)(q * 2 + 1) * g_se];
+	}
+	pair_level<kPBP>(plan, ql, L, active, xp, g0, g1, smooth, stage, hist, nullptr, scan_lds,
+	                 rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk);
+	if (gmax) pair_gmax<kPBP>(max(__float_as_uint(g0) & 0x7FFFFFFFu, __float_as_uint(g1) & 0x7FFFFFFFu), scan_lds, gmax);
+}
+
+// One workgroup = 1024 points x ALL pseudo levels of the plan, and dL/dx on the way: every lane keeps its own row of dL_dy
+// in registers (read ONCE, row-major as autograd hands it over: 8 x 16 bytes), walks the levels in order, adds
+// g_f * dy_f/dx_d of the level to its dL/dx (the stored Jacobian streams past, feature-major) and bins the level's pair
+// records through a double-buffered LDS stage (the write-out of level l overlaps the arithmetic of level l + 1).  Against
+// k_contract_dx_rowmajor + k_pair_bin this takes the feature-major copy of dL_dy (128 MiB written + read) and the second
+// read of dL_dy out of the step, and one launch.  kE = registers for the row (encoded dims <= kE).
+constexpr int kAllE = 32;
+template <bool DX, typename GT>
+__global__ __launch_bounds__(1024) void k_pair_bin_all(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                       uint32_t n_pseudo_meta, uint32_t E, int32_t max_level, uint32_t smooth,
+                                                       const float *__restrict__ x, const GT *__restrict__ g, int64_t g_sn,
+                                                       int64_t g_se, const float *__restrict__ dydx, int64_t d_sn, int64_t d_se,
+                                                       float *__restrict__ dL_dx, u32x4 *__restrict__ rec,
+                                                       uint32_t *__restrict__ offs_g, uint32_t *__restrict__ gmax) {
+	constexpr int kPBP = 1024;
+	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[2][kPCap] records | hist[2][kPMaxNb + 1]
+	__shared__ uint32_t scan_lds[kPBP / 64];
+	u32x4 *stage = reinterpret_cast<u32x4 *>(smem);
+	uint32_t *hist = smem + (size_t)2 * kPCap * 4;
+	const uint32_t blk = blockIdx.x;
+	const uint32_t i = blk * kPBP + threadIdx.x;
+	const bool in = i < n;
+	float xp[3] = {0.0f, 0.0f, 0.0f};
+	float row[kAllE];
+#pragma unroll
+	for (int e = 0; e < kAllE; ++e) row[e] = 0.0f;
+	if (in) {
+#pragma unroll
+		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
+		const GT *gp = g + (int64_t)i * g_sn;
+		if (sizeof(GT) == 4 && g_se == 1 && (E & 3u) == 0u && ((uintptr_t)g & 15u) == 0 && (g_sn & 3) == 0) {
+#pragma unroll
+			for (int e4 = 0; e4 < kAllE; e4 += 4)
+				if ((uint32_t)e4 < E) {
+					const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(gp) + e4);
+					row[e4] = t.x; row[e4 + 1] = t.y; row[e4 + 2] = t.z; row[e4 + 3] = t.w;
+				}
+		} else if (sizeof(GT) == 2 && g_se == 1 && (E & 3u) == 0u && ((uintptr_t)g & 7u) == 0 && (g_sn & 3) == 0) {
+#pragma unroll
+			for (int e4 = 0; e4 < kAllE; e4 += 4)
+				if ((uint32_t)e4 < E) {
+					const __half2 *h = reinterpret_cast<const __half2 *>(reinterpret_cast<const __half *>(gp) + e4);
+					const float2 a = __half22float2(h[0]), b = __half22float2(h[1]);
+					row[e4] = a.x; row[e4 + 1] = a.y; row[e4 + 2] = b.x; row[e4 + 3] = b.y;
+				}
+		} else {
+#pragma unroll
+			for (int e = 0; e < kAllE; ++e)
+				if ((uint32_t)e < E) row[e] = to_f32<GT>(gp[(int64_t)e * g_se]);
+		}
+	}
+	for (uint32_t b = threadIdx.x; b <= kPMaxNb; b += kPBP) hist[b] = 0;
+	uint32_t gbits = 0;
+#pragma unroll
+	for (int e = 0; e < kAllE; ++e) gbits = max(gbits, __float_as_uint(row[e]) & 0x7FFFFFFFu);
+	float dx[3] = {0.0f, 0.0f, 0.0f};
+	__syncthreads();
+	uint32_t ql = 0, buf = 0;
+	for (uint32_t q = 0; q < n_pseudo_meta; ++q) {
+		const float g0 = row[0], g1 = row[1];
+#pragma unroll
+		for (int e = 0; e + 2 < kAllE; ++e) row[e] = row[e + 2];       // next level's pair moves to the front (no dynamic register index)
+		const uint32_t level = meta_level_of(md, q);
+		if (DX && in) {
+			// same order as k_contract_dx: e ascending, fma(g, j, acc)
+			const float *j0 = dydx + (int64_t)i * d_sn + (int64_t)(2 * q) * d_se, *j1 = j0 + d_se;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) dx[d] = __fmaf_rn(g0, __builtin_nontemporal_load(j0 + d), dx[d]);
+#pragma unroll
+			for (int d = 0; d < 3; ++d) dx[d] = __fmaf_rn(g1, __builtin_nontemporal_load(j1 + d), dx[d]);
+		}
+		if (ql >= plan.n_pseudo || plan.qmap[ql] != q) continue;          // level outside this call's range (uniform)
+		const Lvl L = load_level(md, level);
+		pair_level<kPBP>(plan, ql, L, in && (int32_t)level <= max_level, xp, g0, g1, smooth, stage + (size_t)buf * kPCap,
+		                 hist + (size_t)buf * (kPMaxNb + 1), hist + (size_t)(buf ^ 1u) * (kPMaxNb + 1), scan_lds,
+		                 rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk);
+		++ql; buf ^= 1u;
+	}
+	if (DX && in) {
+#pragma unroll
+		for (int d = 0; d < 3; ++d) dL_dx[(size_t)i * 3 + d] = dx[d];
+	}
+	if (gmax) pair_gmax<kPBP>(gbits, scan_lds, gmax);
 }
 
 // Records per bucket over all point blocks (one wave per bucket), and -- in the LAST workgroup to finish -- the stage-B work
@@ -331,12 +406,8 @@ __global__ __launch_bounds__(1024) void k_pair_plan(PairPlan plan, const uint32_
 			while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
 			const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)(fb - plan.bucket_base[q]) * plan.n_blk;
 			const uint32_t *ob1 = ob0 + plan.n_blk;
-			const bool aligned = (plan.align_mask >> q) & 1u;
 			uint32_t sum = 0;
-			for (uint32_t blk = lane; blk < plan.n_blk; blk += 64) {
-				const uint32_t a = ob0[blk], e = ob1[blk];
-				sum += aligned ? (e & ~7u) - (a & ~7u) - (a & 7u) : e - a;
-			}
+			for (uint32_t blk = lane; blk < plan.n_blk; blk += 64) sum += ob1[blk] - ob0[blk];
 #pragma unroll
 			for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
 			if (lane == 0) __hip_atomic_store(tot + fb, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2-visible
@@ -484,12 +555,8 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 	constexpr int kGroup = 8;
 	for (uint32_t blk0 = w_lo; blk0 < w_hi; blk0 += 64) {
 		const uint32_t mb = blk0 + lane;
-		uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
-		uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
-		if ((plan.align_mask >> q) & 1u) {               // start | padding: the run ends `padding` records before the next start
-			e_l = (e_l & ~7u) - (s_l & 7u);
-			s_l &= ~7u;
-		}
+		const uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
+		const uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
 		const uint32_t n_run = min(64u, w_hi - blk0);
 		const u32x4 *rec_b = rec_q + (size_t)blk0 * kPCap;
 		for (uint32_t j0 = 0; j0 < n_run; j0 += kGroup) {
@@ -637,12 +704,22 @@ bool pair_applies(const nr3d_lotd_meta_t *m) {
 	return true;
 }
 
+// NR3D_PAIR_ALL=1 turns the all-levels stage A on.  Off by default: measured 6 % slower on the backward of configs[1]
+// (1551 vs 457 + 953 us per 2^22 points, round-2 notes in DESIGN.md) -- 119 VGPRs for the row + 132 KB of LDS leave
+// one workgroup per CU, against two of k_pair_bin.  Read on every call (a test flips it).
+static bool pair_all_enabled() {
+	const char *e = getenv("NR3D_PAIR_ALL");
+	return e && e[0] == '1';
+}
+bool pair_all_applies(const nr3d_lotd_meta_t *m) {
+	return pair_all_enabled() && pair_applies(m) && pair_bp() == 1024u && m->n_encoded_dims <= (uint32_t)kAllE &&
+	       m->n_encoded_dims == 2u * m->n_pseudo_levels;
+}
+
 static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_level, int32_t max_level, PairPlan &plan,
                       uint64_t &offs_words) {
 	plan.n_blk = div_up(n_chunk, pair_bp());
 	plan.cap = pair_bp() * 4u;
-	plan.align_mask = 0;
-	uint32_t nb_align = 0;
 	plan.lg = pair_lg();
 	plan.sum_log2 = 3;
 	while ((1ull << (plan.sum_log2 - 3)) < n_chunk) ++plan.sum_log2;
@@ -664,7 +741,6 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
 			nb = L.size <= kPEpb ? 1u : (L.size >> plan.lg);
 		}
 		plan.qmap[nq] = q; plan.nb[nq] = nb; plan.epb[nq] = epb; plan.shift[nq] = sh;
-		if (nb >= kPAlignMinNb && pair_align()) { plan.align_mask |= 1u << nq; nb_align = nb_align > nb ? nb_align : nb; }
 		plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
 		plan.offs_base[nq] = (uint32_t)base;
 		base += (uint64_t)(nb + 1) * plan.n_blk;
@@ -672,7 +748,6 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
 	}
 	plan.n_pseudo = nq;
 	plan.bucket_base[nq] = nq ? plan.bucket_base[nq - 1] + plan.nb[nq - 1] : 0u;
-	plan.cap += 8u * nb_align;          // room for the run padding (address space, not traffic)
 	offs_words = base;
 }
 
@@ -695,11 +770,12 @@ void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32
 // one chunk of points: dL_dy given feature-major or with any strides (g_sn, g_se)
 int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,
                int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, uint32_t out_flags,
-               void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st) {
+               void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st, bool all_levels, bool g_half,
+               const FusedDx *fdx) {
 	PairPlan pl;
 	uint64_t ow;
 	pair_plan(meta, n, min_level, max_level, pl, ow);
-	if (pl.n_pseudo == 0) return 0;
+	if (pl.n_pseudo == 0 && !(all_levels && fdx)) return 0;
 	uint32_t nb_max = 0;
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
 	const uint32_t NB = pl.bucket_base[pl.n_pseudo];
@@ -707,6 +783,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	uint32_t *gmax = plan_buf + 3 * (size_t)NB + 2;                  // two spare words of the plan region: gmax | ticket
 	units = pair_units();
 	const size_t bin_lds_max = (size_t)1024 * 4 * 16 + (size_t)(kPMaxNb + 2) * 8;
+	const size_t all_lds = (size_t)2 * 1024 * 4 * 16 + (size_t)2 * (kPMaxNb + 1) * 4;     // stage[2] | hist[2]
 	static bool attr_set_dev[64] = {};
 	int dev_id = 0;
 	NR3D_HIP_CHECK(hipGetDevice(&dev_id));
@@ -714,6 +791,10 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
@@ -722,14 +803,22 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	}
 	NR3D_HIP_CHECK(hipMemsetAsync(gmax, 0, 2 * sizeof(uint32_t), st));      // gmax | ticket of k_pair_plan
 	const uint32_t bp = pair_bp();
-	const size_t bin_lds = (size_t)bp * 4 * 16 + (size_t)(nb_max + 1) * 8;     // stage | hist | ahist
+	const size_t bin_lds = (size_t)bp * 4 * 16 + (size_t)(nb_max + 1) * 4;     // stage | hist
 #define NR3D_PAIR_BIN(BP) hipLaunchKernelGGL(k_pair_bin<BP>, dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level, \
 	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax)
+#define NR3D_PAIR_ALL(DX, GT) hipLaunchKernelGGL((k_pair_bin_all<DX, GT>), dim3(pl.n_blk), dim3(1024), all_lds, st, pl, md, n,       \
+	meta->n_pseudo_levels, meta->n_encoded_dims, max_level, meta->interpolation_type, x, (const GT *)g, g_sn, g_se,                     \
+	fdx ? fdx->dydx : nullptr, fdx ? fdx->d_sn : 0, fdx ? fdx->d_se : 0, fdx ? fdx->dL_dx : nullptr, (u32x4 *)rec, offs, gmax)
 	{
 		prof::Scope ps(NR3D_PROF_LOTD_BIN, st);
-		if (bp == 512) NR3D_PAIR_BIN(512); else if (bp == 768) NR3D_PAIR_BIN(768); else NR3D_PAIR_BIN(1024);
+		if (all_levels) {
+			if (g_half) { if (fdx) NR3D_PAIR_ALL(true, __half); else NR3D_PAIR_ALL(false, __half); }
+			else        { if (fdx) NR3D_PAIR_ALL(true, float); else NR3D_PAIR_ALL(false, float); }
+		} else if (bp == 512) NR3D_PAIR_BIN(512); else if (bp == 768) NR3D_PAIR_BIN(768); else NR3D_PAIR_BIN(1024);
 	}
+#undef NR3D_PAIR_ALL
 #undef NR3D_PAIR_BIN
+	if (pl.n_pseudo == 0) { NR3D_LAUNCH_CHECK(); return 0; }
 	hipLaunchKernelGGL(k_pair_plan, dim3(div_up(NB, 16)), dim3(1024), 0, st, pl, offs, units, tot, rep, item_start, gmax + 1);
 #define NR3D_PAIR_ACC(U, F) hipLaunchKernelGGL((k_pair_accum<U, F>), dim3(units + NB), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, pl, md, \
 	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg(), out_flags)

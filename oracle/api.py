@@ -91,6 +91,26 @@ def _i64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.int64)
 
 
+def set_num_threads(n=0):
+    """host threads of the oracle's OpenMP loops (n <= 0: only query); returns the count in effect"""
+    f = lib().orc_set_num_threads
+    f.restype = C.c_int
+    return int(f(C.c_int(int(n))))
+
+
+def host_cores():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup v2 CPU quota of the container"""
+    import math, os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lotd_create_meta(n_input_dim, lod_res, lod_n_feats, lod_types, hashmap_size=None, use_smooth_step=False):
     lod_res = list(lod_res)
     L = len(lod_res)

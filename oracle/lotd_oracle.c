@@ -18,6 +18,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------------------------------------
  * Meta  (csrc/lotd/src/lotd_torch_api.cu:29-230)
@@ -633,7 +636,7 @@ void orc_lotd_fwd(const orc_lotd_meta_t *m, uint32_t N, const float *x, const fl
  * pseudo levels in parallel (disjoint slices only when levels differ -> we parallelise over LEVELS),
  * points ascending inside.
  * ---------------------------------------------------------------------------------------------- */
-static void bwd_dparam_level(const orc_lotd_meta_t *m, uint32_t level, uint32_t N, const float *dL_ddLdx,
+static void bwd_dparam_level(const orc_lotd_meta_t *m, uint32_t level, uint32_t i_begin, uint32_t N, const float *dL_ddLdx,
                              const float *dL_dy, const float *x, const float *params,
                              const int64_t *batch_inds, const int64_t *batch_offsets,
                              uint32_t batch_data_size, int32_t max_level, acc_t acc_all) {
@@ -641,7 +644,7 @@ static void bwd_dparam_level(const orc_lotd_meta_t *m, uint32_t level, uint32_t 
 	const uint32_t NFT = 2; /* N_FEAT_PER_THREAD = min(2, G), :1589 */
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		if (m->map_levels[q] != level) continue;
-		for (uint32_t i = 0; i < N; ++i) {
+		for (uint32_t i = i_begin; i < N; ++i) {
 			ctx_t c;
 			if (!setup_ctx(&c, m, level, i, x, params, batch_inds, batch_offsets, batch_data_size, max_level))
 				continue;
@@ -769,18 +772,82 @@ static void bwd_dparam_level(const orc_lotd_meta_t *m, uint32_t level, uint32_t 
 	}
 }
 
+int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+	if (n > 0) omp_set_num_threads(n);
+	return omp_get_max_threads();
+#else
+	(void)n;
+	return 1;
+#endif
+}
+
+/* Slabs of points per level for the fp64-accumulated mode (the sums are exact to ~1e-16 relative, so splitting the
+ * points over S private accumulators and adding those in slab order does not change what the checker sees): without
+ * them only n_levels host threads ever work on dL/dparam.  ORC_DPARAM_SLABS overrides (1 = one slab). */
+static int dparam_slabs(uint32_t N, uint32_t n_levels) {
+	const char *e = getenv("ORC_DPARAM_SLABS");
+	int s = 1;
+	if (e) s = atoi(e);
+	else if (N >= (1u << 15)) {
+#ifdef _OPENMP
+		s = omp_get_max_threads() / (int)(n_levels ? n_levels : 1u);
+#endif
+	}
+	return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
 static void bwd_dparam_all(const orc_lotd_meta_t *m, uint32_t N, const float *dL_ddLdx, const float *dL_dy,
                            const float *x, const float *params, const int64_t *batch_inds,
                            const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
                            int accum_double, float *grad, uint64_t numel) {
 	if (max_level <= -1) return;
 	double *gd = NULL;
-	if (accum_double) gd = (double *)calloc(numel, sizeof(double));
+	if (accum_double == 1) gd = (double *)calloc(numel, sizeof(double));
 	acc_t a; a.g = gd ? NULL : grad; a.gd = gd;
+	/* accum_double == 2: float accumulators AND slabs (the CPU baseline's mode: every host thread works, the float sums
+	 * are associated per slab instead of over all points in order) */
+	const int S = (gd || accum_double == 2) ? dparam_slabs(N, m->n_levels) : 1;
+	if (S > 1) {
+		/* private accumulators of slabs 1..S-1: kept between calls and left all-zero by the reduction below */
+		static void *priv = NULL;
+		static uint64_t priv_cap = 0;
+		const uint64_t esz = gd ? 8 : 4, need = (uint64_t)(S - 1) * numel * esz;
+		if (need > priv_cap) { free(priv); priv = calloc(need, 1); priv_cap = priv ? need : 0; }
+		if (priv) {
+			double *pd = (double *)priv;
+			float *pf = (float *)priv;
+			const int64_t tasks = (int64_t)m->n_levels * S;
+#pragma omp parallel for schedule(dynamic, 1)
+			for (int64_t t = 0; t < tasks; ++t) {
+				const uint32_t l = (uint32_t)(t / S), sl = (uint32_t)(t % S);
+				acc_t as;
+				as.gd = gd ? (sl ? pd + (uint64_t)(sl - 1) * numel : gd) : NULL;
+				as.g = gd ? NULL : (sl ? pf + (uint64_t)(sl - 1) * numel : grad);
+				const uint32_t i0 = (uint32_t)((uint64_t)N * sl / S), i1 = (uint32_t)((uint64_t)N * (sl + 1) / S);
+				bwd_dparam_level(m, l, i0, i1, dL_ddLdx, dL_dy, x, params, batch_inds, batch_offsets, batch_data_size,
+				                 max_level, as);
+			}
+#pragma omp parallel for schedule(static)
+			for (int64_t k = 0; k < (int64_t)numel; ++k) {
+				if (gd) {
+					double acc = gd[k];
+					for (int sl = 1; sl < S; ++sl) { acc += pd[(uint64_t)(sl - 1) * numel + k]; pd[(uint64_t)(sl - 1) * numel + k] = 0.0; }
+					grad[k] += (float)acc;
+				} else {
+					float acc = grad[k];
+					for (int sl = 1; sl < S; ++sl) { acc += pf[(uint64_t)(sl - 1) * numel + k]; pf[(uint64_t)(sl - 1) * numel + k] = 0.0f; }
+					grad[k] = acc;
+				}
+			}
+			free(gd);
+			return;
+		}
+	}
 	/* different levels write disjoint slices of every batch copy -> safe to run levels in parallel */
 #pragma omp parallel for schedule(dynamic, 1)
 	for (int32_t l = 0; l < (int32_t)m->n_levels; ++l)
-		bwd_dparam_level(m, (uint32_t)l, N, dL_ddLdx, dL_dy, x, params, batch_inds, batch_offsets,
+		bwd_dparam_level(m, (uint32_t)l, 0, N, dL_ddLdx, dL_dy, x, params, batch_inds, batch_offsets,
 		                 batch_data_size, max_level, a);
 	if (gd) {
 		for (uint64_t k = 0; k < numel; ++k) grad[k] += (float)gd[k];

@@ -63,6 +63,9 @@ void orc_lotd_bwd_dparam(const orc_lotd_meta_t *m, uint32_t N, const float *dL_d
                          uint32_t batch_data_size, int32_t max_level, int accum_double,
                          float *grad /*[numel params], zero-initialised by caller*/, uint64_t numel);
 
+/* host threads of the OpenMP loops in this library (<= 0: leave as is); returns the count in effect */
+int orc_set_num_threads(int n);
+
 void orc_lotd_bwd_dx(const orc_lotd_meta_t *m, uint32_t N, const float *dL_dy, const float *dy_dx,
                      float *dL_dx /*[N,D]*/);
 

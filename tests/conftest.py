@@ -17,6 +17,7 @@ def oracle():
     """The CPU checker (C restatement of the reference).  Built on demand with gcc."""
     import oracle as orc
     orc.build()
+    orc.set_num_threads(orc.host_cores())      # the container's CPU quota (256 host threads on a 16-CPU quota crawl)
     return orc
 
 

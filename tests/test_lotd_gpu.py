@@ -260,6 +260,36 @@ def test_half_params_and_inputs(oracle, dev, case):
         _lotd.lod_fwd(m, xt.half(), pt)          # (half input, float params) is not a supported combination
 
 
+@pytest.mark.parametrize("case,half", [("ngp_small", False), ("ngp_pair", False), ("ngp_pair", True), ("pair_f4", False)])
+def test_bwd_single_pass(oracle, dev, case, half, monkeypatch):
+    """nr3d_lotd_bwd_fused (k_pair_bin_all, NR3D_PAIR_ALL=1: dL_dy read once, dL/dx folded into stage A of the scatter) gives
+    the bits of nr3d_lotd_bwd_dx + nr3d_lotd_bwd_dparam_typed, and the oracle's values."""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=70001, seed=11)
+    if half:
+        pt, gt = pt.half(), gt.half()
+        p, g = pt.float().cpu().numpy(), gt.float().cpu().numpy()
+    import ctypes
+    from nr3d_lib_amd import _hip as H
+    _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    monkeypatch.delenv("NR3D_PAIR_ALL", raising=False)
+    assert not H.lib().nr3d_lotd_bwd_fused_ok(ctypes.byref(m._cmeta()))
+    dx0, dp0 = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)
+    monkeypatch.setenv("NR3D_PAIR_ALL", "1")
+    assert H.lib().nr3d_lotd_bwd_fused_ok(ctypes.byref(m._cmeta()))
+    dx1, dp1 = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)
+    _, dp2 = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)       # all-levels stage A without dL/dx
+    dx3, dp3 = _lotd.lod_bwd(m, gt, xt, pt, j, max_level=m.n_levels // 2, need_input_grad=True, need_param_grad=True)
+    monkeypatch.delenv("NR3D_PAIR_ALL")
+    dx4, dp4 = _lotd.lod_bwd(m, gt, xt, pt, j, max_level=m.n_levels // 2, need_input_grad=True, need_param_grad=True)
+    assert torch.equal(dx0, dx1) and torch.equal(dp0, dp1) and torch.equal(dp0, dp2)
+    assert torch.equal(dx3, dx4) and torch.equal(dp3, dp4)
+    assert dp1.dtype == pt.dtype
+    _, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    assert_close(dx1, oracle.lotd_bwd_dx(m_ref, g, j_ref), name="dL_dx single pass")
+    assert_close(dp1.float(), oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), rel=1e-3 if half else 1e-5,
+                 name="dL_dparam single pass", levels=m_ref)
+
+
 def test_autograd_surface(oracle, dev):
     """LoTDFunction / FwdDydx / BwdDydx: loss_scale handling, clamping, prefix dims, second-order chain"""
     from nr3d_lib_amd.models.grid_encodings.lotd import LoTD, generate_meta

@@ -1,2 +1,8 @@
-python -m pytest tests/test_lotd_gpu.py tests/test_fullsize_gpu.py tests/test_dist_gpu.py tests/test_ray_query_gpu.py -m gpu -q -x 2>&1 | tail -6 > gpurun_out/r02o_pytest.log; tail -6 gpurun_out/r02o_pytest.log
-for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-extra --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['kernel_ms'], d['roofline']['whole_step_frac'])"; done
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_lotd_gpu.py tests/test_fullsize_gpu.py tests/test_forest_gpu.py tests/test_dist_gpu.py -m gpu -q -x 2>&1 | tail -15 > gpurun_out/r02o_pytest.log
+cat gpurun_out/r02o_pytest.log
+python bench.py --steps 10 --warmup 3 --no-extra 2>/dev/null | tail -1 > gpurun_out/r02o_bench.json
+python -c "
+import json; d=json.load(open('gpurun_out/r02o_bench.json')); print(d['ms_per_step'], d['kernel_ms'], d['cpu_baseline'])"
