@@ -215,6 +215,181 @@ __global__ __launch_bounds__(kBlock) void k_march(uint32_t n_rays, const float *
 	if (!EMIT) counts[i] = (int32_t)j;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// G lanes per ray (count pass with the sample cache), for ray counts that leave the chip mostly idle with one lane per
+// ray: there the op is bound by the dependent chain of its longest ray -- ~100 dependent VALU ops and one dependent byte
+// load per probe.  Only three of those ops ARE the recurrence (t0 <- t1, t1 <- t0 + dt(t0), tm <- (t0 + t1) / 2 after a
+// hit or, outside AABB grids, after any probe); position, contraction, cell index and the load hang off tm.  So the group
+// runs the recurrence `len` steps ahead (every lane computes the same serial chain, lane l keeps step l: same operations
+// in the same order as the one-lane march, bit for bit), probes all `len` positions at once and keeps the prefix up to the
+// first miss; a miss in an AABB grid re-centres the interval on the voxel exit (skip_voxel), which the whole group
+// computes once before the next round (each lane works out its own exit while its probe is in flight).  After a miss the
+// next round looks only 8 steps ahead, after an all-hit round G steps.
+template <int G>
+__device__ __forceinline__ unsigned long long group_ballot(bool v) {
+	const unsigned long long m = __ballot(v);
+	if (G == 64) return m;
+	return (m >> ((threadIdx.x & 63u) / G * G)) & ((1ull << (G & 63)) - 1ull);
+}
+
+template <int G, bool POW2>
+__device__ __forceinline__ uint32_t march_ray_group(const Grid &g, uint32_t lane, int32_t grid_offset, f3 o, f3 dir, f3 inv,
+                                                    float near, float far, float dt_min, float dt_max, float dt_gamma,
+                                                    uint32_t max_steps, uint32_t *__restrict__ cache_ray) {
+	const bool aabb = g.type == NR3D_CONTRACT_AABB;
+	constexpr int kShort = G < 8 ? G : 8;
+	// after kMissRun consecutive empty voxels the exit recurrence is run ahead too, kMissAhead steps at a time.  Measured
+	// on 4096 rays through a 128^3 grid (us per march, one lane per ray = 166 / 145): random occupancy 0.5 -- runs of ~2
+	// voxels, the worst case for any look-ahead -- 131 with (4, 8), 171 with (3, 16), 126 with none; a solid ball (long
+	// empty and long occupied runs) 67, 67, 180.
+	constexpr int kMissRun = 4, kMissAhead = G < 8 ? G : 8;
+	uint32_t j = 0, miss_run = 0;
+	float t0 = near;
+	float t1 = t0 + calc_dt(t0, dt_gamma, dt_min, dt_max);
+	float tm = (t0 + t1) * 0.5f;
+	int len = aabb ? kShort : G;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	while (true) {
+		float c0 = t0, c1 = t1, cm = tm, m0 = t0, m1 = t1, mm = tm;
+		for (int k = 1; k < len; ++k) {
+			c0 = c1;
+			c1 = c0 + calc_dt(c0, dt_gamma, dt_min, dt_max);
+			cm = (c0 + c1) * 0.5f;
+			if ((int)lane >= k) { m0 = c0; m1 = c1; mm = cm; }
+		}
+		const float n0 = c1, n1 = n0 + calc_dt(n0, dt_gamma, dt_min, dt_max), nm = (n0 + n1) * 0.5f;   // after `len` advances
+		const bool in = (int)lane < len && mm < far;
+		const f3 p = {__fmaf_rn(mm, dir.x, o.x), __fmaf_rn(mm, dir.y, o.y), __fmaf_rn(mm, dir.z, o.z)};
+		int cell = -1;
+		bool hit;
+		float sk = 0.0f;
+		if (aabb) {
+			// every lane also works out where ITS position would skip to if it misses (independent of the probe: the byte
+			// load is in flight meanwhile); only the first missing lane's value is used
+			const bool inside = in && !(p.x < g.mn.x || p.x > g.mx.x || p.y < g.mn.y || p.y > g.mx.y || p.z < g.mn.z || p.z > g.mx.z);
+			uint8_t occ = 0;
+			if (inside) {
+				const f3 u = contract<POW2>(g, p);
+				const int ix = clampi((int)(u.x * (float)g.rx), 0, g.rx - 1);
+				const int iy = clampi((int)(u.y * (float)g.ry), 0, g.ry - 1);
+				const int iz = clampi((int)(u.z * (float)g.rz), 0, g.rz - 1);
+				cell = ix * (g.ry * g.rz) + iy * g.rz + iz;
+				occ = g.cells[cell];
+			}
+			if (in) sk = skip_voxel<POW2>(g, mm, dt_min, p, dir, inv);
+			hit = inside && occ != 0;
+		} else {
+			hit = in && probe<POW2>(g, p, &cell);
+		}
+		if (aabb) {
+			const bool ok = hit && (j + lane < max_steps);
+			const unsigned long long okm = group_ballot<G>(ok);
+			const uint32_t F = (~okm == 0ull) ? 64u : (uint32_t)__ffsll((long long)~okm) - 1u;       // first lane that did not emit (<= len)
+			if (lane < F) {
+				uint32_t *c = cache_ray + (size_t)(j + lane) * 3;
+				c[0] = __float_as_uint(m0); c[1] = __float_as_uint(m1); c[2] = (uint32_t)(cell + grid_offset);
+			}
+			j += F;
+			if ((int)F >= len) { t0 = n0; t1 = n1; tm = nm; len = G; continue; }
+			const float fm = __shfl(mm, (int)F, G);           // the position that missed (or ran out of range / of steps)
+			if (!(fm < far) || !(j < max_steps)) break;
+			tm = __shfl(sk, (int)F, G);                       // its voxel exit, computed by lane F while the probe was in flight
+			miss_run = F == 0 ? miss_run + 1 : 1;
+			if (miss_run >= (uint32_t)kMissRun) {
+				// a run of empty voxels: the exit recurrence tm <- skip_voxel(tm) does not depend on what is probed either, so
+				// the group now runs IT ahead (lane k keeps the position after k more misses) and probes the candidates at
+				// once; the first occupied one (or the end of the ray) ends the run.  Positions before it emit nothing.
+				bool done = false;
+				while (true) {
+					float my = tm, cur = tm;
+					for (int k = 1; k < kMissAhead; ++k) {
+						const f3 pc = {__fmaf_rn(cur, dir.x, o.x), __fmaf_rn(cur, dir.y, o.y), __fmaf_rn(cur, dir.z, o.z)};
+						cur = skip_voxel<POW2>(g, cur, dt_min, pc, dir, inv);
+						if ((int)lane >= k) my = cur;
+					}
+					const bool inm = (int)lane < kMissAhead && my < far;
+					const f3 pm = {__fmaf_rn(my, dir.x, o.x), __fmaf_rn(my, dir.y, o.y), __fmaf_rn(my, dir.z, o.z)};
+					int cm2 = -1;
+					const bool hitm = inm && probe<POW2>(g, pm, &cm2);
+					const float nxt = skip_voxel<POW2>(g, my, dt_min, pm, dir, inv);       // lane kMissAhead-1: where the run goes on
+					const unsigned long long stop = group_ballot<G>((int)lane < kMissAhead && (hitm || !inm));
+					if (stop == 0ull) { tm = __shfl(nxt, kMissAhead - 1, G); continue; }
+					tm = __shfl(my, __ffsll((long long)stop) - 1, G);
+					done = !(tm < far);
+					break;
+				}
+				if (done) break;
+				miss_run = 0;
+			}
+			const float dt = calc_dt(tm, dt_gamma, dt_min, dt_max);
+			t0 = tm - dt * 0.5f;
+			t1 = tm + dt * 0.5f;
+			len = kShort;
+		} else {
+			const unsigned long long hm = group_ballot<G>(hit);
+			const uint32_t before = (uint32_t)__popcll(hm & below);
+			const bool exec = in && (j + before < max_steps);
+			if (exec && hit) {
+				uint32_t *c = cache_ray + (size_t)(j + before) * 3;
+				c[0] = __float_as_uint(m0); c[1] = __float_as_uint(m1); c[2] = (uint32_t)(cell + grid_offset);
+			}
+			const unsigned long long em = group_ballot<G>(exec);
+			j += (uint32_t)__popcll(hm & em);
+			if (em != ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull))) break;
+			t0 = n0; t1 = n1; tm = nm;
+		}
+	}
+	return j;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_march_group(uint32_t n_rays, const float *__restrict__ rays_o,
+                                                     const float *__restrict__ rays_d, const float *__restrict__ t_min,
+                                                     const float *__restrict__ t_max, const float *__restrict__ roi, int rx,
+                                                     int ry, int rz, const uint8_t *__restrict__ cells, int type,
+                                                     float step_size, float max_step_size, float dt_gamma, uint32_t max_steps,
+                                                     int batched, const int32_t *__restrict__ batch_inds,
+                                                     uint32_t batch_data_size, int32_t *__restrict__ counts,
+                                                     uint32_t *__restrict__ cache) {
+	const uint32_t i = (blockIdx.x * 256u + threadIdx.x) / G, lane = threadIdx.x % G;
+	if (i >= n_rays) return;
+	uint32_t b = 0;
+	if (batched) {
+		if (batch_inds) {
+			const int32_t v = batch_inds[i];
+			if (v < 0) { if (lane == 0) counts[i] = 0; return; }
+			b = (uint32_t)v;
+		} else if (batch_data_size) {
+			b = i / batch_data_size;
+		}
+	}
+	const uint32_t vol = (uint32_t)(rx * ry * rz);
+	Grid g;
+	const float *r6 = roi + 6 * (size_t)b;
+	g.mn = {r6[0], r6[1], r6[2]};
+	g.mx = {r6[3], r6[4], r6[5]};
+	g.rx = rx; g.ry = ry; g.rz = rz;
+	g.cells = cells + (size_t)b * vol;
+	g.type = type;
+	const int32_t grid_offset = batched ? (int32_t)(b * vol) : 0;
+	const f3 o = {rays_o[3 * (size_t)i], rays_o[3 * (size_t)i + 1], rays_o[3 * (size_t)i + 2]};
+	const f3 dir = {rays_d[3 * (size_t)i], rays_d[3 * (size_t)i + 1], rays_d[3 * (size_t)i + 2]};
+	const f3 inv = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+	g.inv_ext = {1.0f / (g.mx.x - g.mn.x), 1.0f / (g.mx.y - g.mn.y), 1.0f / (g.mx.z - g.mn.z)};
+	g.inv_res = {1.0f / (float)rx, 1.0f / (float)ry, 1.0f / (float)rz};
+	const bool pow2 = is_pow2f(g.mx.x - g.mn.x) && is_pow2f(g.mx.y - g.mn.y) && is_pow2f(g.mx.z - g.mn.z) &&
+	                  is_pow2f((float)rx) && is_pow2f((float)ry) && is_pow2f((float)rz);
+	uint32_t *cache_ray = cache + (size_t)i * max_steps * 3;
+	uint32_t j;
+	if (__all(pow2))
+		j = march_ray_group<G, true>(g, lane, grid_offset, o, dir, inv, t_min[i], t_max[i], step_size, max_step_size, dt_gamma,
+		                             max_steps, cache_ray);
+	else
+		j = march_ray_group<G, false>(g, lane, grid_offset, o, dir, inv, t_min[i], t_max[i], step_size, max_step_size, dt_gamma,
+		                              max_steps, cache_ray);
+	if (lane == 0) counts[i] = (int32_t)j;
+}
+
 // one wave per ray: copy the ray's cached samples to their packed position
 __global__ __launch_bounds__(256) void k_emit_cached(uint32_t n_rays, uint32_t stride, int batched,
                                                      const int32_t *__restrict__ batch_inds, uint32_t batch_data_size,
@@ -435,9 +610,22 @@ extern "C" int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, con
 		                   (float *)nullptr, (float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
 		                   (uint32_t *)sample_cache);
 	};
+	// lanes per ray: 32 / 16 while that still leaves the chip short of work, else one (NR3D_MARCH_GROUP = 1 | 16 | 32 | 64 forces)
+	int group = n_rays <= 8192u ? 32 : (n_rays <= 32768u ? 16 : 1);
+	if (const char *e = getenv("NR3D_MARCH_GROUP")) { const int v = atoi(e); if (v == 1 || v == 16 || v == 32 || v == 64) group = v; }
+	if (!cached) group = 1;
+	auto launch_group = [&](auto kern, int G) {
+		hipLaunchKernelGGL(kern, dim3(div_up((uint64_t)n_rays * G, 256)), dim3(256), 0, st, n_rays, rays_o, rays_d, t_min, t_max, roi,
+		                   grid_res[0], grid_res[1], grid_res[2], grid_binary, type, step_size, max_step_size, dt_gamma, max_steps,
+		                   batched, batch_inds, batch_data_size, counts, (uint32_t *)sample_cache);
+	};
 	{
 		prof::Scope ps(NR3D_PROF_MARCH, st);
-		if (cached) launch(occ::k_march<false, true>); else launch(occ::k_march<false, false>);
+		if (group == 64) launch_group(occ::k_march_group<64>, 64);
+		else if (group == 32) launch_group(occ::k_march_group<32>, 32);
+		else if (group == 16) launch_group(occ::k_march_group<16>, 16);
+		else if (cached) launch(occ::k_march<false, true>);
+		else launch(occ::k_march<false, false>);
 	}
 	NR3D_LAUNCH_CHECK();
 	return scan::pack_infos_from_counts<int32_t, int32_t>(n_rays, counts, packed_info, total_steps, tiles, st);

@@ -597,6 +597,12 @@ __global__ __launch_bounds__(kBlock) void k_alpha_bwd_lpp(uint32_t P, const floa
 
 // wave-per-pack for few packs; from 2048 packs on (32 waves of lanes) one lane per pack is faster at every pack
 // length measured (4096 packs x 61 samples: 8 / 23 us vs 27 / 42 us forward / backward)
+// NR3D_PACK_SCAN=0: the fused composite replays the transmittance serially (vw bit-identical to packed_alpha_to_vw)
+// instead of the prefix-product kernels; NR3D_PACK_SCAN_MAX: packs up to which wave-per-pack + scan is preferred over one
+// lane per pack (default: always -- 4096 packs x <= 512: 8.5 / 11 us against 38 / 77 us forward / backward, 262144 packs:
+// 148 / 289 against 302 / 837).  Read on every call.
+static inline bool composite_scan() { const char *e = getenv("NR3D_PACK_SCAN"); return !(e && e[0] == '0'); }
+static inline uint32_t composite_scan_max() { const char *e = getenv("NR3D_PACK_SCAN_MAX"); return e ? (uint32_t)atoi(e) : 0xFFFFFFFFu; }
 static inline bool lane_per_pack(uint32_t P) {
 	static int thr = -1;
 	if (thr < 0) { const char *e = getenv("NR3D_PACK_LPP_MIN"); thr = e ? atoi(e) : 2048; }
@@ -615,13 +621,10 @@ static inline bool lane_per_pack(uint32_t P) {
 // `ray_index` (optional) scatters the per-ray results into [num_rays] outputs (rays_inds_hit) and gathers their grads.
 // ------------------------------------------------------------------------------------------------
 template <bool RGB>
-__global__ __launch_bounds__(kBlock) void k_composite_fwd(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ ts,
-                                                          const float *__restrict__ rgb, const int64_t *__restrict__ pi,
-                                                          const int64_t *__restrict__ ray_index, float eps, float thre, int normalize,
-                                                          float *__restrict__ vw, float *__restrict__ mask,
-                                                          float *__restrict__ depth, float *__restrict__ rgb_out) {
-	const Pack k = my_pack(P, pi);
-	if (!k.valid) return;
+__device__ __forceinline__ void composite_fwd_serial(const Pack &k, const float *__restrict__ alphas, const float *__restrict__ ts,
+                                                     const float *__restrict__ rgb, const int64_t *__restrict__ ray_index, float eps,
+                                                     float thre, int normalize, float *__restrict__ vw, float *__restrict__ mask,
+                                                     float *__restrict__ depth, float *__restrict__ rgb_out) {
 	float T = 1.0f;
 	bool stopped = false;
 	float s = 0.0f, dt = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
@@ -660,6 +663,17 @@ __global__ __launch_bounds__(kBlock) void k_composite_fwd(uint32_t P, const floa
 	}
 }
 
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_fwd(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ ts,
+                                                          const float *__restrict__ rgb, const int64_t *__restrict__ pi,
+                                                          const int64_t *__restrict__ ray_index, float eps, float thre, int normalize,
+                                                          float *__restrict__ vw, float *__restrict__ mask,
+                                                          float *__restrict__ depth, float *__restrict__ rgb_out) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	composite_fwd_serial<RGB>(k, alphas, ts, rgb, ray_index, eps, thre, normalize, vw, mask, depth, rgb_out);
+}
+
 // dL/dvw of one sample from the per-ray output grads (and the optional direct grad on vw)
 struct CompGrad { float gm, cd, dref, g0, g1, g2; };
 __device__ __forceinline__ float comp_gw(const CompGrad &c, float t, float r0, float r1, float r2, float gv) {
@@ -679,16 +693,14 @@ __device__ __forceinline__ CompGrad comp_grad(size_t o, int normalize, const flo
 }
 
 template <bool RGB>
-__global__ __launch_bounds__(kBlock) void k_composite_bwd(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ vw,
-                                                          const float *__restrict__ ts, const float *__restrict__ rgb,
-                                                          const int64_t *__restrict__ pi, const int64_t *__restrict__ ray_index,
-                                                          float eps, float thre, int normalize, const float *__restrict__ mask,
-                                                          const float *__restrict__ depth, const float *__restrict__ g_mask,
-                                                          const float *__restrict__ g_depth, const float *__restrict__ g_rgb,
-                                                          const float *__restrict__ g_vw, float *__restrict__ grad_alphas,
-                                                          float *__restrict__ grad_t, float *__restrict__ grad_rgb) {
-	const Pack k = my_pack(P, pi);
-	if (!k.valid) return;
+__device__ __forceinline__ void composite_bwd_serial(const Pack &k, const float *__restrict__ alphas, const float *__restrict__ vw,
+                                                     const float *__restrict__ ts, const float *__restrict__ rgb,
+                                                     const int64_t *__restrict__ ray_index, float eps, float thre, int normalize,
+                                                     const float *__restrict__ mask, const float *__restrict__ depth,
+                                                     const float *__restrict__ g_mask, const float *__restrict__ g_depth,
+                                                     const float *__restrict__ g_rgb, const float *__restrict__ g_vw,
+                                                     float *__restrict__ grad_alphas, float *__restrict__ grad_t,
+                                                     float *__restrict__ grad_rgb) {
 	const size_t o = ray_index ? (size_t)ray_index[k.p] : (size_t)k.p;
 	const CompGrad cg = comp_grad(o, normalize, mask, depth, g_mask, g_depth, g_rgb);
 	// accum = sum_j gw_j * w_j, serial fma chain like packed_alpha_to_vw_backward (the sweep below divides by
@@ -733,6 +745,158 @@ __global__ __launch_bounds__(kBlock) void k_composite_bwd(uint32_t P, const floa
 			if (RGB && grad_rgb) { grad_rgb[3 * i] = w_mine * cg.g0; grad_rgb[3 * i + 1] = w_mine * cg.g1; grad_rgb[3 * i + 2] = w_mine * cg.g2; }
 		}
 	}
+}
+
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_bwd(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ vw,
+                                                          const float *__restrict__ ts, const float *__restrict__ rgb,
+                                                          const int64_t *__restrict__ pi, const int64_t *__restrict__ ray_index,
+                                                          float eps, float thre, int normalize, const float *__restrict__ mask,
+                                                          const float *__restrict__ depth, const float *__restrict__ g_mask,
+                                                          const float *__restrict__ g_depth, const float *__restrict__ g_rgb,
+                                                          const float *__restrict__ g_vw, float *__restrict__ grad_alphas,
+                                                          float *__restrict__ grad_t, float *__restrict__ grad_rgb) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	composite_bwd_serial<RGB>(k, alphas, vw, ts, rgb, ray_index, eps, thre, normalize, mask, depth, g_mask, g_depth, g_rgb, g_vw,
+	                          grad_alphas, grad_t, grad_rgb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prefix-product forms (wave per pack, few to some thousand packs): the transmittance before sample i is the running
+// product of (1 - alpha) over the samples that count, so a 64-sample chunk needs one 6-step wave scan instead of 64
+// dependent broadcast-multiply steps.  The products are associated as a tree instead of left to right: T differs from the
+// serial recurrence by rounding only (<= ~n * 2^-24 relative, typically 1e-6 at 512 samples; the contract's tolerance is
+// 1e-5).  What must NOT depend on rounding is WHICH samples early_stop_eps cuts: a pack where some T lands within
+// 2e-4 * eps of the threshold is replayed with the serial kernel body (wave-uniform branch; ~1 pack in 10^4).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_inclusive_mul(float v, int lane) {
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) { const float t = shfl_up_t<float>(v, off); if (lane >= off) v *= t; }
+	return v;
+}
+__device__ __forceinline__ float wave_inclusive_add(float v, int lane) {
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) { const float t = shfl_up_t<float>(v, off); if (lane >= off) v += t; }
+	return v;
+}
+
+// transmittance of one chunk: `counts` = the sample multiplies T; returns T before my sample, whether my sample lies behind
+// the early stop, and flags a pack whose stop decision could hinge on rounding.  Tc / stopped carry across chunks.
+struct ChunkT { float Tin; bool cut; };
+__device__ __forceinline__ ChunkT chunk_transmittance(float a, bool mine, bool counts, float eps, int lane, float &Tc, bool &stopped,
+                                                      bool &ambiguous) {
+	const float f = (mine && counts) ? (1.0f - a) : 1.0f;
+	const float inc = wave_inclusive_mul(f, lane);
+	float exc = shfl_up_t<float>(inc, 1);
+	if (lane == 0) exc = 1.0f;
+	ChunkT r;
+	r.Tin = Tc * exc;
+	const unsigned long long below = __ballot(mine && r.Tin < eps);
+	const unsigned long long near = __ballot(mine && fabsf(r.Tin - eps) <= eps * 2e-4f);
+	const int first = below ? __ffsll((long long)below) - 1 : 64;
+	// a near-threshold T only matters up to the first clear crossing
+	if (!stopped && (near & ((first >= 63) ? ~0ull : ((2ull << first) - 1ull)))) ambiguous = true;
+	r.cut = stopped || lane >= first;
+	stopped = stopped || below != 0ull;
+	Tc *= shfl_t<float>(inc, 63);
+	return r;
+}
+
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_fwd_scan(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ ts,
+                                                               const float *__restrict__ rgb, const int64_t *__restrict__ pi,
+                                                               const int64_t *__restrict__ ray_index, float eps, float thre,
+                                                               int normalize, float *__restrict__ vw, float *__restrict__ mask,
+                                                               float *__restrict__ depth, float *__restrict__ rgb_out) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	float Tc = 1.0f, s = 0.0f, dt = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+	bool stopped = false, ambiguous = false;
+	for (uint32_t base = 0; base < k.len && !ambiguous; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		const bool mine = (uint32_t)k.lane < n;
+		const size_t i = (size_t)k.begin + base + k.lane;
+		const float a = mine ? alphas[i] : 0.0f;
+		const float t = mine ? ts[i] : 0.0f;
+		float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+		if (RGB && mine) { r0 = rgb[3 * i]; r1 = rgb[3 * i + 1]; r2 = rgb[3 * i + 2]; }
+		const bool counts = !(a <= thre);
+		const ChunkT ct = chunk_transmittance(a, mine, counts, eps, k.lane, Tc, stopped, ambiguous);
+		const float w = (mine && counts && !ct.cut) ? a * ct.Tin : 0.0f;
+		if (mine) vw[i] = w;
+		s += w; dt += w * t;
+		if (RGB) { c0 += w * r0; c1 += w * r1; c2 += w * r2; }
+	}
+	if (ambiguous) {        // wave-uniform
+		composite_fwd_serial<RGB>(k, alphas, ts, rgb, ray_index, eps, thre, normalize, vw, mask, depth, rgb_out);
+		return;
+	}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) {
+		s += shfl_xor_t<float>(s, off); dt += shfl_xor_t<float>(dt, off);
+		if (RGB) { c0 += shfl_xor_t<float>(c0, off); c1 += shfl_xor_t<float>(c1, off); c2 += shfl_xor_t<float>(c2, off); }
+	}
+	if (k.lane == 0) {
+		const size_t o = ray_index ? (size_t)ray_index[k.p] : (size_t)k.p;
+		mask[o] = s;
+		depth[o] = normalize ? dt / (s + 1e-10f) : dt;
+		if (RGB) { rgb_out[3 * o] = c0; rgb_out[3 * o + 1] = c1; rgb_out[3 * o + 2] = c2; }
+	}
+}
+
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_bwd_scan(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ vw,
+                                                               const float *__restrict__ ts, const float *__restrict__ rgb,
+                                                               const int64_t *__restrict__ pi, const int64_t *__restrict__ ray_index,
+                                                               float eps, float thre, int normalize, const float *__restrict__ mask,
+                                                               const float *__restrict__ depth, const float *__restrict__ g_mask,
+                                                               const float *__restrict__ g_depth, const float *__restrict__ g_rgb,
+                                                               const float *__restrict__ g_vw, float *__restrict__ grad_alphas,
+                                                               float *__restrict__ grad_t, float *__restrict__ grad_rgb) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	const size_t o = ray_index ? (size_t)ray_index[k.p] : (size_t)k.p;
+	const CompGrad cg = comp_grad(o, normalize, mask, depth, g_mask, g_depth, g_rgb);
+	// total = sum_j gw_j * w_j; the sample's own "still to come" sum is total minus the prefix before it
+	float total = 0.0f;
+	for (uint32_t base = 0; base < k.len; base += 64) {
+		const bool mine = (uint32_t)k.lane < min(64u, k.len - base);
+		const size_t i = (size_t)k.begin + base + k.lane;
+		if (mine) {
+			float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+			if (RGB) { r0 = rgb[3 * i]; r1 = rgb[3 * i + 1]; r2 = rgb[3 * i + 2]; }
+			total = __fmaf_rn(comp_gw(cg, ts[i], r0, r1, r2, g_vw ? g_vw[i] : 0.0f), vw[i], total);
+		}
+	}
+#pragma unroll
+	for (int off = 32; off >= 1; off >>= 1) total += shfl_xor_t<float>(total, off);
+	float Tc = 1.0f, qc = 0.0f;
+	bool stopped = false, ambiguous = false;
+	for (uint32_t base = 0; base < k.len && !ambiguous; base += 64) {
+		const uint32_t n = min(64u, k.len - base);
+		const bool mine = (uint32_t)k.lane < n;
+		const size_t i = (size_t)k.begin + base + k.lane;
+		const float a = mine ? alphas[i] : 0.0f;
+		const float w = mine ? vw[i] : 0.0f;
+		float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+		if (RGB && mine) { r0 = rgb[3 * i]; r1 = rgb[3 * i + 1]; r2 = rgb[3 * i + 2]; }
+		const float gw = mine ? comp_gw(cg, ts[i], r0, r1, r2, g_vw ? g_vw[i] : 0.0f) : 0.0f;
+		const bool counts = !(a < thre);
+		const ChunkT ct = chunk_transmittance(a, mine, counts, eps, k.lane, Tc, stopped, ambiguous);
+		const float q = gw * w;
+		const float incq = wave_inclusive_add(q, k.lane);
+		const float accum = total - (qc + (incq - q));            // sum over the samples from mine on
+		qc += shfl_t<float>(incq, 63);
+		if (mine) {
+			grad_alphas[i] = (counts && !ct.cut) ? __fmaf_rn(gw, ct.Tin, -accum) / fmaxf(1.0f - a, 1e-10f) : 0.0f;
+			if (grad_t) grad_t[i] = cg.cd * w;
+			if (RGB && grad_rgb) { grad_rgb[3 * i] = w * cg.g0; grad_rgb[3 * i + 1] = w * cg.g1; grad_rgb[3 * i + 2] = w * cg.g2; }
+		}
+	}
+	if (ambiguous)
+		composite_bwd_serial<RGB>(k, alphas, vw, ts, rgb, ray_index, eps, thre, normalize, mask, depth, g_mask, g_depth, g_rgb, g_vw,
+		                          grad_alphas, grad_t, grad_rgb);
 }
 
 // lane-per-pack forms (many rays): every lane walks its own ray serially, 4 samples per memory request
@@ -1107,12 +1271,14 @@ extern "C" int nr3d_pack_composite_fwd(uint32_t P, const float *alphas, const fl
 	if (P == 0) return 0;
 	NR3D_CHECK(alphas && t && pack_infos && vw && mask && depth, "pack_composite_fwd: NULL pointer");
 	NR3D_CHECK(!rgb || rgb_out, "pack_composite_fwd: rgb given without rgb_out");
-	const bool lpp = pk::lane_per_pack(P);
+	const bool scan = pk::composite_scan() && P <= pk::composite_scan_max();
+	const bool lpp = !scan && pk::lane_per_pack(P);
 	const dim3 g = lpp ? dim3(div_up(P, pk::kBlock)) : pk::grid_for(P), b(pk::kBlock);
 #define NR3D_COMP_FWD(K) hipLaunchKernelGGL(K, g, b, 0, (hipStream_t)stream, P, alphas, t, rgb, pack_infos, ray_index, \
 	early_stop_eps, alpha_thre, normalize_depth, vw, mask, depth, rgb_out)
 	prof::Scope ps(NR3D_PROF_COMPOSITE_FWD, (hipStream_t)stream);
-	if (lpp) { if (rgb) NR3D_COMP_FWD(pk::k_composite_fwd_lpp<true>); else NR3D_COMP_FWD(pk::k_composite_fwd_lpp<false>); }
+	if (scan) { if (rgb) NR3D_COMP_FWD(pk::k_composite_fwd_scan<true>); else NR3D_COMP_FWD(pk::k_composite_fwd_scan<false>); }
+	else if (lpp) { if (rgb) NR3D_COMP_FWD(pk::k_composite_fwd_lpp<true>); else NR3D_COMP_FWD(pk::k_composite_fwd_lpp<false>); }
 	else     { if (rgb) NR3D_COMP_FWD(pk::k_composite_fwd<true>); else NR3D_COMP_FWD(pk::k_composite_fwd<false>); }
 #undef NR3D_COMP_FWD
 	NR3D_LAUNCH_CHECK();
@@ -1126,12 +1292,14 @@ extern "C" int nr3d_pack_composite_bwd(uint32_t P, const float *alphas, const fl
                                        float *grad_alphas, float *grad_t, float *grad_rgb, void *stream) {
 	if (P == 0) return 0;
 	NR3D_CHECK(alphas && vw && t && pack_infos && mask && depth && grad_alphas, "pack_composite_bwd: NULL pointer");
-	const bool lpp = pk::lane_per_pack(P);
+	const bool scan = pk::composite_scan() && P <= pk::composite_scan_max();
+	const bool lpp = !scan && pk::lane_per_pack(P);
 	const dim3 g = lpp ? dim3(div_up(P, pk::kBlock)) : pk::grid_for(P), b(pk::kBlock);
 #define NR3D_COMP_BWD(K) hipLaunchKernelGGL(K, g, b, 0, (hipStream_t)stream, P, alphas, vw, t, rgb, pack_infos, ray_index, \
 	early_stop_eps, alpha_thre, normalize_depth, mask, depth, g_mask, g_depth, g_rgb, g_vw, grad_alphas, grad_t, grad_rgb)
 	prof::Scope ps(NR3D_PROF_COMPOSITE_BWD, (hipStream_t)stream);
-	if (lpp) { if (rgb) NR3D_COMP_BWD(pk::k_composite_bwd_lpp<true>); else NR3D_COMP_BWD(pk::k_composite_bwd_lpp<false>); }
+	if (scan) { if (rgb) NR3D_COMP_BWD(pk::k_composite_bwd_scan<true>); else NR3D_COMP_BWD(pk::k_composite_bwd_scan<false>); }
+	else if (lpp) { if (rgb) NR3D_COMP_BWD(pk::k_composite_bwd_lpp<true>); else NR3D_COMP_BWD(pk::k_composite_bwd_lpp<false>); }
 	else     { if (rgb) NR3D_COMP_BWD(pk::k_composite_bwd<true>); else NR3D_COMP_BWD(pk::k_composite_bwd<false>); }
 #undef NR3D_COMP_BWD
 	NR3D_LAUNCH_CHECK();

@@ -9,6 +9,14 @@ from util import assert_close, assert_equal
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["1", "16", "32", "64"], ids=lambda v: f"lanes_per_ray={v}")
+def march_group(request, monkeypatch):
+    """every test under each marcher: one lane per ray (k_march) and 16 / 64 lanes per ray (k_march_group, look-ahead along
+    the t recurrence) -- the same bits are expected from all three"""
+    monkeypatch.setenv("NR3D_MARCH_GROUP", request.param)
+    return request.param
+
+
 def pinhole_rays(n_side, dist=4.0, seed=0, jitter=True):
     """rays from a camera at distance `dist` looking at the origin (as the reference's smoke test,
     occgrid_raymarch.py:281-295); near/far from the ray-AABB test against [-1,1]^3"""

@@ -409,7 +409,16 @@ def _chain_backward(oracle, alpha, t, rgb, pi, eps, thre, normalize, vw, mask, g
     return g_a, g_t, g_c
 
 
-def _composite_case(oracle, dev, P, pi, S, seed, eps, thre, normalize, with_rgb, scatter):
+@pytest.fixture(params=["scan", "serial"])
+def composite_mode(request, monkeypatch):
+    """the fused composite's two transmittance forms: wave prefix products (default up to 16384 packs; T within rounding
+    of the serial recurrence, the early-stop cut identical) and the serial replay (NR3D_PACK_SCAN=0: vw bit-identical to
+    packed_alpha_to_vw; wave-per-pack below 2048 packs, lane-per-pack from there)"""
+    monkeypatch.setenv("NR3D_PACK_SCAN", "1" if request.param == "scan" else "0")
+    return request.param
+
+
+def _composite_case(oracle, dev, P, pi, S, seed, eps, thre, normalize, with_rgb, scatter, mode="serial"):
     import nr3d_lib_amd.graphics.pack_ops as po
     rng = np.random.default_rng(seed)
     n_packs = pi.shape[0]
@@ -426,7 +435,11 @@ def _composite_case(oracle, dev, P, pi, S, seed, eps, thre, normalize, with_rgb,
     vw, mask, depth, col = po.packed_composite(a_t, t_t, c_t, T(pi, dev), T(hit, dev) if scatter else None, num_rays,
                                                early_stop_eps=eps, alpha_thre=thre, normalize_depth=normalize)
     sel = (lambda a: a[torch.from_numpy(hit).to(dev)]) if scatter else (lambda a: a)
-    assert_equal(vw, vw_r, "vw")                                          # same serial transmittance chain
+    if mode == "serial":
+        assert_equal(vw, vw_r, "vw")                                      # same serial transmittance chain
+    else:                                                                 # tree-ordered products: same cut, values to rounding
+        assert np.array_equal(vw.detach().cpu().numpy() == 0, vw_r == 0), "vw: early-stop / threshold cut differs"
+        assert_close(vw, vw_r, name="vw")
     assert_close(sel(mask), mask_r, name="mask")
     assert_close(sel(depth), depth_r, name="depth")
     if with_rgb:
@@ -460,14 +473,41 @@ def _composite_case(oracle, dev, P, pi, S, seed, eps, thre, normalize, with_rgb,
 
 @pytest.mark.parametrize("n_packs,hi", [(257, 300), (2500, 90)])           # wave-per-pack / lane-per-pack kernels
 @pytest.mark.parametrize("normalize,with_rgb,scatter", [(True, True, True), (False, True, False), (True, False, False)])
-def test_fused_composite_against_chain(oracle, dev, P, n_packs, hi, normalize, with_rgb, scatter):
+def test_fused_composite_against_chain(oracle, dev, P, n_packs, hi, normalize, with_rgb, scatter, composite_mode):
     rng = np.random.default_rng(41)
     pi, S = random_packs(rng, n_packs, 0, hi, 0.1)
-    _composite_case(oracle, dev, P, pi, S, 5, 1e-4, 0.0, normalize, with_rgb, scatter)
-    _composite_case(oracle, dev, P, pi, S, 6, 1e-2, 0.02, normalize, with_rgb, scatter)
+    _composite_case(oracle, dev, P, pi, S, 5, 1e-4, 0.0, normalize, with_rgb, scatter, composite_mode)
+    _composite_case(oracle, dev, P, pi, S, 6, 1e-2, 0.02, normalize, with_rgb, scatter, composite_mode)
 
 
-def test_c3_composite_shape(oracle, dev, P):
+def test_composite_scan_stop_decisions(oracle, dev, P, monkeypatch):
+    """packs built so that the transmittance crosses early_stop_eps within rounding distance: constant alpha with
+    (1 - alpha)^k == eps to a few ulp.  The prefix-product kernels must cut exactly the samples the serial recurrence cuts
+    (they replay such a pack serially) -- then vw is not merely close, it is identical."""
+    import nr3d_lib_amd.graphics.pack_ops as po
+    monkeypatch.setenv("NR3D_PACK_SCAN", "1")
+    rng = np.random.default_rng(3)
+    n_packs, L = 600, 200
+    pi = np.stack([np.arange(n_packs) * L, np.full(n_packs, L)], 1).astype(np.int64)
+    eps = np.float32(1e-3)
+    ks = rng.integers(20, 150, n_packs)
+    alpha = np.empty((n_packs, L), np.float32)
+    for p in range(n_packs):
+        base = 1.0 - float(eps) ** (1.0 / ks[p])                        # (1 - base)^k == eps
+        alpha[p] = np.float32(base) + np.float32(rng.integers(-2, 3)) * np.spacing(np.float32(base))
+    alpha = alpha.reshape(-1)
+    t = np.sort(rng.uniform(0.5, 6.0, alpha.size)).astype(np.float32)
+    vw_r, mask_r, depth_r, _ = _chain_forward(oracle, alpha, t, None, pi, float(eps), 0.0, True)
+    vw, mask, depth, _ = po.packed_composite(T(alpha, dev), T(t, dev), None, T(pi, dev), None, n_packs, early_stop_eps=float(eps),
+                                             alpha_thre=0.0, normalize_depth=True)
+    cut_r = (vw_r.reshape(n_packs, L) == 0).sum(1)
+    assert cut_r.min() > 0 and len(set(cut_r.tolist())) > 20              # the stop really happens, at many different lengths
+    assert np.array_equal(vw.cpu().numpy() == 0, vw_r == 0)
+    assert_close(vw, vw_r, name="vw")
+    assert_close(mask, mask_r, name="mask")
+
+
+def test_c3_composite_shape(oracle, dev, P, composite_mode):
     """BASELINE configs[2]'s composite half at its stated shape: 4096 packs x <= 512 samples (~1.1 M samples), unfused ops
     bit-exact against the oracle and the fused composite against the chain"""
     rng = np.random.default_rng(7)
@@ -481,4 +521,4 @@ def test_c3_composite_shape(oracle, dev, P):
     ga = P.packed_alpha_to_vw_backward(T(rw, dev), T(gw, dev), T(alpha, dev), T(pi, dev), 1e-4, 0.0)
     assert_equal(ga, oracle.packed_alpha_to_vw_backward(rw, gw, alpha, pi, 1e-4, 0.0), "grad_alphas")
     assert_close(P.packed_sum(T(rw, dev), T(pi, dev)), oracle.packed_sum(rw, pi), name="packed_sum")
-    _composite_case(oracle, dev, P, pi, S, 8, 1e-4, 0.0, True, True, True)
+    _composite_case(oracle, dev, P, pi, S, 8, 1e-4, 0.0, True, True, True, composite_mode)
