@@ -166,8 +166,9 @@ def _c3_scene(side):
 
 def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
     """BASELINE configs[2]: occ 128^3 march + alpha composite forward AND backward, side^2 rays
-    (side = 64: the 4096 rays of configs[2] -- 64 waves, bound by the longest ray's serial march;
-     side = 512: enough rays to fill the chip, the throughput regime of configs[4]).
+    (side = 64: the 4096 rays of configs[2] -- bound by the longest ray's dependent chain, marched with 32 lanes per ray
+     looking ahead along the t recurrence; side = 512: enough rays to fill the chip, one lane per ray, the throughput
+     regime of configs[4]).
     One iteration = ray march (count + emit) -> alpha = 1 - exp(-sigma * delta) -> fused composite (vw, mask, normalised
     depth, rgb) -> its backward for random upstream gradients (dL/dalpha, dL/dt, dL/drgb).
     Roofline (SURVEY 8d byte model, element-granular): march = 32 B/ray (o, d, near, far) + 8 B/ray packed_info +
@@ -223,7 +224,7 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
     out = dict(workload=f"configs[2]: occ 128^3 march + fused alpha composite fwd+bwd, {n} rays x <= 512 samples",
                samples=int(S), ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4),
                kernel_us_per_iter={k: round(v, 2) for k, v in kus.items()},
-               launches_per_iter="march 2 (count + emit) + scan 3, composite 1 + 1")
+               launches_per_iter="march 2 (count + emit) + scan 1 (3 above 32768 rays), composite 1 + 1")
     if cpu_seconds > 0:
         # the oracle's marcher counts the grid probes of the byte model, and is the CPU baseline next to the chain
         probes, S_r, base = cpu_baseline(None, c3=((o_c, d_c, near_c, far_c, roi_c, grid_c), n, step, cpu_seconds))

@@ -3,7 +3,8 @@
 // `cumsum` + `stack` + `.item()` sequence of every two-phase op (e.g. ray_marching.cu:205-209,
 // pack_ops_cuda.cu:584-586): here the scan stays on the device and the caller does ONE readback.
 //
-// Three launches (reduce tiles -> scan tile sums -> rescan + write); wave64 shuffles inside a tile.
+// Three launches (reduce tiles -> scan tile sums -> rescan + write); wave64 shuffles inside a tile.  Up to 32768 counts:
+// one launch of one workgroup.
 #pragma once
 #include "common.h"
 
@@ -98,6 +99,30 @@ __global__ __launch_bounds__(kThreads) void k_write_pack_infos(uint64_t n, const
 	}
 }
 
+// n <= kSmallMax: ONE workgroup does the whole job (the three launches above cost ~14 us of launch and drain for 4096
+// counts, this one ~4): thread t owns `per` consecutive counts, sums them, one block scan, then re-reads and writes.
+constexpr uint64_t kSmallMax = 32768;
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(kThreads) void k_pack_infos_small(uint32_t n, uint32_t per, const TIn *__restrict__ counts,
+                                                               TOut *__restrict__ pack_infos, int64_t *__restrict__ total_out) {
+	__shared__ uint64_t lds[4];
+	const uint32_t first = threadIdx.x * per;
+	uint64_t s = 0;
+	for (uint32_t k = 0; k < per; ++k)
+		if (first + k < n) s += (uint64_t)counts[first + k];
+	uint64_t tot;
+	uint64_t run = block_exclusive(s, tot, lds);
+	for (uint32_t k = 0; k < per; ++k) {
+		if (first + k < n) {
+			const uint64_t c = (uint64_t)counts[first + k];
+			pack_infos[2 * (size_t)(first + k)] = (TOut)run;
+			pack_infos[2 * (size_t)(first + k) + 1] = (TOut)c;
+			run += c;
+		}
+	}
+	if (threadIdx.x == 0) *total_out = (int64_t)tot;
+}
+
 static inline uint64_t tmp_bytes(uint64_t n) { return ((n + kTile - 1) / kTile + 1) * sizeof(uint64_t); }
 
 // counts[n] -> pack_infos[n,2] (TOut) and total[0] (int64); tmp >= tmp_bytes(n)
@@ -106,6 +131,12 @@ static int pack_infos_from_counts(uint64_t n, const TIn *counts, TOut *pack_info
                                   hipStream_t st) {
 	if (n == 0) {
 		NR3D_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(int64_t), st));
+		return 0;
+	}
+	if (n <= kSmallMax) {
+		hipLaunchKernelGGL((k_pack_infos_small<TIn, TOut>), dim3(1), dim3(kThreads), 0, st, (uint32_t)n,
+		                   (uint32_t)((n + kThreads - 1) / kThreads), counts, pack_infos, total);
+		NR3D_LAUNCH_CHECK();
 		return 0;
 	}
 	const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);

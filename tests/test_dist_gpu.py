@@ -63,3 +63,29 @@ def test_bucketed_allreduce_with_the_real_kernels(oracle, dev, nccl_group, case)
     big = dp0.clone()
     allreduce_grads([big] + small, bucket_bytes=1 << 20)
     assert torch.equal(big, dp0) and all(a is None or torch.equal(a, b) for a, b in zip(small, keep))
+
+
+@pytest.mark.parametrize("case", ["ngp_pair", "mixed"])
+def test_two_ranks_on_one_gpu(case):
+    """world size 2 with the real kernels: two processes share cuda:0 over a gloo group (tests/dist_worker_gpu.py)"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    port = 29600 + (os.getpid() % 300)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "dist_worker_gpu.py"), case], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (pr, out) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and f"rank {r} OK" in out, f"rank {r} failed:\n{out[-3000:]}"
