@@ -53,8 +53,8 @@ def kernel_algorithmic_bytes(kernel, n_levels_served, F=2, D=3, C=8):
 
 
 # timers of include/nr3d_hip.h (NR3D_PROF_*) -> kernel names as rocprofv3 prints them (the default configuration)
-PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true>", "lotd_fwd_lds": "k_fwd_lds<true>",
-                "lotd_contract_dx": "k_contract_dx_rowmajor<3>", "lotd_bin": "k_pair_bin<1024>",
+PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true, float>", "lotd_fwd_lds": "k_fwd_lds<true, float>",
+                "lotd_contract_dx": "k_contract_dx_rowmajor<3, float>", "lotd_bin": "k_pair_bin<1024>",
                 "lotd_accum": "k_pair_accum<4, true>"}
 LIVE_TIMER = "lotd_fwd"      # the dominant kernel: timed inside the timed region (2 events per step); the rest in an extra pass
 OP_TIMERS = {"fwd": ["lotd_fwd_lds", "lotd_fwd"], "bwd": ["lotd_contract_dx", "lotd_bin", "lotd_accum"]}
