@@ -363,6 +363,36 @@ def lotd_large_batch_rate(log2n=24):
                 kernel_ms=d["kernel_ms"], whole_step_frac=d["roofline"]["whole_step_frac"])
 
 
+def lotd_half_rate(dev, log2n=20, iters=10):
+    """configs[1] with the reference's DEFAULT storage type, (float, half, float): half params / y / dL_dy / dL_dparam, float x
+    and dy_dx, fp32 arithmetic (lotd_encoding.h:1501-1504).  Served natively: no whole-table conversion."""
+    from nr3d_lib_amd.bindings import _lotd
+    from nr3d_lib_amd.models.grid_encodings.lotd import gen_ngp_cfg
+    cfg = gen_ngp_cfg()
+    meta = _lotd.LoDMeta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
+    N = 1 << log2n
+    gen = torch.Generator(device="cpu").manual_seed(43)
+    params = torch.empty(meta.n_params).uniform_(-1e-2, 1e-2, generator=gen).to(dev).half()
+    x = torch.rand(N, 3, generator=gen).clamp_(1e-6, 1 - 1e-6).to(dev)
+    g = (torch.randn(N, meta.n_encoded_dims, generator=gen) * 1e-2).to(dev).half()
+
+    def one():
+        y, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
+        return _lotd.lod_bwd(meta, g, x, params, j, need_input_grad=True, need_param_grad=True)
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dx, dp = one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    assert dp.dtype == torch.float16
+    return dict(workload=f"configs[1] with half tables / outputs / gradients (float, half, float), 2^{log2n} points, fwd(+dy/dx) + dL/dx "
+                         "+ dL/dparam", native=bool(_lotd._native_half(meta, params, False)), ms_per_step=round(ms, 4),
+                mpoints_per_s=round(N / ms / 1e3, 3))
+
+
 def c1_dense_rate(dev):
     """BASELINE configs[0]: single Dense level 32^3 x 4 features, 65 536 points, forward only -- the HIP kernel next to a
     pure-PyTorch trilinear sampler on the host cores (grid_sample on the [32,32,32,4] table with the LoTD coordinate
@@ -699,6 +729,7 @@ def main():
                              ("c1_dense_fwd", lambda: c1_dense_rate(dev)),
                              ("full_loop_1gpu", lambda: full_loop_rate(dev)),
                              ("forest_lotd", lambda: forest_lotd_rate(dev)),
+                             ("lotd_half_params", lambda: lotd_half_rate(dev)),
                              ("mlp_decoder", lambda: mlp_decoder_rate(dev)),
                              ("c4_mixed_lotd", c4_mixed_rate),
                              ("lotd_2p24_points", lambda: lotd_large_batch_rate(24))):
