@@ -67,6 +67,35 @@ def one(rng):
     gw = rng.standard_normal(S).astype(np.float32)
     close(P.packed_alpha_to_vw_backward(t(w_ref), t(gw), t(a), pit, eps, thre),
           oracle.packed_alpha_to_vw_backward(w_ref, gw, a, pi, eps, thre), "alpha bwd " + tag, exact=True)
+    # fused composite: prefix-product kernels (default) against the serial replay (NR3D_PACK_SCAN=0: vw bit-identical to
+    # alpha_to_vw) -- same early-stop cut, values to rounding -- and against the oracle's weights
+    if rng.random() < 0.5:                                  # opaque and near-opaque samples drive T through eps quickly
+        a = a.copy(); a[rng.random(S) < 0.05] = np.float32(rng.choice([1.0, 0.999, 0.9]))
+        w_ref = oracle.packed_alpha_to_vw_forward(a, pi, eps, thre, False)[0]
+    tm = np.sort(rng.random(S)).astype(np.float32) + 0.5
+    rgb = rng.random((S, 3)).astype(np.float32)
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["NR3D_PACK_SCAN"] = mode
+        vw, mask, depth, col = P.packed_composite_forward(t(a), t(tm), t(rgb), pit, None, pi.shape[0], eps, thre, True)
+        gm, gd, gc = (rng.standard_normal(pi.shape[0]).astype(np.float32), rng.standard_normal(pi.shape[0]).astype(np.float32),
+                      rng.standard_normal((pi.shape[0], 3)).astype(np.float32))
+        if mode == "1":
+            g_out = [t(g_) for g_ in (gm, gd, gc)]
+        ga, gt_, gc_ = P.packed_composite_backward(t(a), vw, t(tm), t(rgb), pit, None, eps, thre, True, mask, depth, g_out[0], g_out[1],
+                                                   g_out[2], None)
+        outs[mode] = (vw, mask, depth, col, ga, gt_, gc_)
+    os.environ.pop("NR3D_PACK_SCAN", None)
+    # backward: the division by max(1 - alpha, 1e-10) amplifies rounding, so the numerators are compared
+    om = np.maximum(1.0 - a.astype(np.float64), 1e-10)
+    close(outs["1"][4].double().cpu().numpy() * om, outs["0"][4].double().cpu().numpy() * om, "composite scan vs serial dalpha numerator " + tag, 1e-4)
+    close(outs["1"][5], outs["0"][5].cpu().numpy(), "composite scan vs serial dt " + tag, 2e-5)
+    close(outs["1"][6], outs["0"][6].cpu().numpy(), "composite scan vs serial drgb " + tag, 2e-5)
+    close(outs["0"][0], w_ref, "composite serial vw " + tag, exact=True)
+    assert np.array_equal(outs["1"][0].cpu().numpy() == 0, w_ref == 0), "composite scan: cut differs " + tag
+    close(outs["1"][0], w_ref, "composite scan vw " + tag, 1e-5)
+    for k, nm in ((1, "mask"), (2, "depth"), (3, "rgb")):
+        close(outs["1"][k], outs["0"][k].cpu().numpy(), f"composite scan vs serial {nm} " + tag, 2e-5)
     # sorted bins: searchsorted + inverse CDF on the non-empty packs
     if pi.shape[0] <= 5000:
         nz = pi[pi[:, 1] > 1]
