@@ -45,6 +45,18 @@ struct PairPlan {
 	uint32_t sum_log2;                  // updates per accumulator <= 2^sum_log2 (8 corners x points of the pass)
 };
 
+// Levels with at most kDirectNb buckets skip the records altogether (k_pair_direct): every workgroup of such a level
+// reads (x, dL_dy columns) of a share of the points and accumulates the updates of ITS bucket straight into LDS --
+// nb x 20 bytes per point instead of 64 written + ~79 read as records.  C2: levels 0 (1 bucket) and 1 (4 buckets).
+constexpr uint32_t kDirectNb = 4, kDirectMaxLv = 8, kDirectMaxWg = 640;
+struct DirectPlan {
+	uint32_t n;                               // pseudo levels served (0: none)
+	uint32_t qmap[kDirectMaxLv], nb[kDirectMaxLv], epb[kDirectMaxLv], shift[kDirectMaxLv];
+	uint32_t bucket_base[kDirectMaxLv + 1];
+	uint32_t lg, sum_log2, R, pts_per_rep;    // replicas per bucket, points per replica
+};
+
+
 // points (= threads) per stage-A workgroup; NR3D_PAIR_BP = 512 | 768 | 1024 (measurement knob)
 static uint32_t pair_bp() {
 	static uint32_t v = 0;
@@ -84,6 +96,48 @@ static uint32_t pair_units() {
 // -------------------------------------------------------------------------------------------------
 // Stage A
 // -------------------------------------------------------------------------------------------------
+// The four pair records of one (point, pseudo level): bucket, bucket-local indices of the two entries (hdr = i0 | i1 << 13),
+// A_f = g_f x the weights of the two dims the pair does not run along, and the pair's own weight wp
+__device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t epb, uint32_t lg, const float (&xp)[3], float g0,
+                                             float g1, bool smooth, uint32_t (&hdr)[4], uint32_t (&bkt)[4], float (&A)[4][2],
+                                             float &wp, uint32_t (&cell)[3]) {
+	Cell<3> c;
+	locate<3>(xp, L, smooth, c);
+	if (L.type == NR3D_LOD_Dense) {
+		wp = c.w[2];
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) {
+			const uint32_t bx = m & 1u, by = m >> 1;
+			const uint32_t row = (c.g[0] + bx) * L.res[1] + (c.g[1] + by);
+			const uint32_t e0 = row * L.res[2] + c.g[2];
+			const uint32_t b = row >> sh;
+			const uint32_t i0 = e0 - b * epb;
+			bkt[m] = b;
+			hdr[m] = i0 | ((i0 + 1u) << 13);
+			const float wo = (bx ? c.w[0] : 1.0f - c.w[0]) * (by ? c.w[1] : 1.0f - c.w[1]);
+			A[m][0] = g0 * wo; A[m][1] = g1 * wo;
+		}
+	} else {
+		wp = c.w[0];
+		const bool pow2 = (L.size & (L.size - 1u)) == 0u;
+		const uint32_t emask = (1u << lg) - 1u;
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) {
+			const uint32_t by = m & 1u, bz = m >> 1;
+			const uint32_t K = ((c.g[1] + by) * kPrimes[1]) ^ ((c.g[2] + bz) * kPrimes[2]);
+			const uint32_t h0 = c.g[0] ^ K, h1 = (c.g[0] + 1u) ^ K;
+			const uint32_t e0 = pow2 ? (h0 & (L.size - 1u)) : (h0 % L.size);
+			const uint32_t e1 = pow2 ? (h1 & (L.size - 1u)) : (h1 % L.size);
+			bkt[m] = e0 >> lg;                         // == e1 >> lg (plan conditions)
+			hdr[m] = (e0 & emask) | ((e1 & emask) << 13);
+			const float wo = (by ? c.w[1] : 1.0f - c.w[1]) * (bz ? c.w[2] : 1.0f - c.w[2]);
+			A[m][0] = g0 * wo; A[m][1] = g1 * wo;
+		}
+	}
+#pragma unroll
+	for (int d = 0; d < 3; ++d) cell[d] = c.g[d];
+}
+
 // One pseudo level of one block of kPBP points: pair records -> rank inside the bucket -> counting sort in LDS ->
 // coalesced write-out of the slot + its bucket offsets.  `hist` [nb + 1] must be zero on entry (and that visible: a
 // barrier behind the zeroing); `zero_next` (optional) is zeroed for the following call.  Four barriers.
@@ -100,44 +154,7 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; }
 	if (zero_next)
 		for (uint32_t b = threadIdx.x; b <= kPMaxNb; b += kPBP) zero_next[b] = 0;
-	if (active) {
-		Cell<3> c;
-		locate<3>(xp, L, smooth != 0, c);
-		const uint32_t sh = plan.shift[ql], epb = plan.epb[ql];
-		if (L.type == NR3D_LOD_Dense) {
-			wp = c.w[2];
-#pragma unroll
-			for (uint32_t m = 0; m < 4; ++m) {
-				const uint32_t bx = m & 1u, by = m >> 1;
-				const uint32_t row = (c.g[0] + bx) * L.res[1] + (c.g[1] + by);
-				const uint32_t e0 = row * L.res[2] + c.g[2];
-				const uint32_t b = row >> sh;
-				const uint32_t i0 = e0 - b * epb;
-				bkt[m] = b;
-				hdr[m] = i0 | ((i0 + 1u) << 13);
-				const float wo = (bx ? c.w[0] : 1.0f - c.w[0]) * (by ? c.w[1] : 1.0f - c.w[1]);
-				A[m][0] = g0 * wo; A[m][1] = g1 * wo;
-			}
-		} else {
-			wp = c.w[0];
-			const bool pow2 = (L.size & (L.size - 1u)) == 0u;
-			const uint32_t emask = (1u << plan.lg) - 1u;
-#pragma unroll
-			for (uint32_t m = 0; m < 4; ++m) {
-				const uint32_t by = m & 1u, bz = m >> 1;
-				const uint32_t K = ((c.g[1] + by) * kPrimes[1]) ^ ((c.g[2] + bz) * kPrimes[2]);
-				const uint32_t h0 = c.g[0] ^ K, h1 = (c.g[0] + 1u) ^ K;
-				const uint32_t e0 = pow2 ? (h0 & (L.size - 1u)) : (h0 % L.size);
-				const uint32_t e1 = pow2 ? (h1 & (L.size - 1u)) : (h1 % L.size);
-				bkt[m] = e0 >> plan.lg;                    // == e1 >> plan.lg (plan conditions)
-				hdr[m] = (e0 & emask) | ((e1 & emask) << 13);
-				const float wo = (by ? c.w[1] : 1.0f - c.w[1]) * (bz ? c.w[2] : 1.0f - c.w[2]);
-				A[m][0] = g0 * wo; A[m][1] = g1 * wo;
-			}
-		}
-#pragma unroll
-		for (int d = 0; d < 3; ++d) cell[d] = c.g[d];
-	}
+	if (active) pair_records(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell);
 
 	// ---- coherent inputs: lanes that continue the previous lane's cell are summed into the head of their run ----
 	bool emit = active, split = false;
@@ -271,11 +288,11 @@ __device__ __forceinline__ void pair_gmax(uint32_t gbits, uint32_t *scan_lds, ui
 
 // one workgroup = kPBP points x ONE pseudo level; dL_dy given feature-major (coalesced columns) or with any strides
 template <int kPBP>
-__global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+__global__ __launch_bounds__(kPBP, kPBP == 768 ? 6 : 8) /* <= 64 VGPRs: two 64 KiB workgroups per CU */ void k_pair_bin(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                                    int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                    const float *__restrict__ g, int64_t g_sn, int64_t g_se,
                                                    u32x4 *__restrict__ rec, uint32_t *__restrict__ offs_g,
-                                                   uint32_t *__restrict__ gmax) {
+                                                   uint32_t *__restrict__ gmax, DirectPlan dp) {
 	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[kPCap] records | hist[nb + 1]
 	__shared__ uint32_t scan_lds[kPBP / 64];
@@ -298,7 +315,18 @@ __global__ __launch_bounds__(kPBP) void k_pair_bin(PairPlan plan, const nr3d_lot
 	}
 	pair_level<kPBP>(plan, ql, L, active, xp, g0, g1, smooth, stage, hist, nullptr, scan_lds,
 	                 rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk);
-	if (gmax) pair_gmax<kPBP>(max(__float_as_uint(g0) & 0x7FFFFFFFu, __float_as_uint(g1) & 0x7FFFFFFFu), scan_lds, gmax);
+	if (gmax) {
+		uint32_t gbits = max(__float_as_uint(g0) & 0x7FFFFFFFu, __float_as_uint(g1) & 0x7FFFFFFFu);
+		// the levels that bypass the records (k_pair_direct) share the fixed-point scale: their columns of dL_dy count too
+		if (ql == 0 && i < n)
+			for (uint32_t e = 0; e < dp.n; ++e) {
+				const uint32_t qd = dp.qmap[e];
+				if ((int32_t)meta_level_of(md, qd) > max_level) continue;
+				gbits = max(gbits, __float_as_uint(g[(int64_t)i * g_sn + (int64_t)(qd * 2) * g_se]) & 0x7FFFFFFFu);
+				gbits = max(gbits, __float_as_uint(g[(int64_t)i * g_sn + (int64_t)(qd * 2 + 1) * g_se]) & 0x7FFFFFFFu);
+			}
+		pair_gmax<kPBP>(gbits, scan_lds, gmax);
+	}
 }
 
 // One workgroup = 1024 points x ALL pseudo levels of the plan, and dL/dx on the way: every lane keeps its own row of dL_dy
@@ -632,6 +660,88 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 	}
 }
 
+// ---- levels without records: (x, dL_dy) -> LDS accumulators of one bucket, one replica per share of the points ----
+// Same per-update arithmetic as stage A + stage B ((g * w_other) * {1 - w_pair, w_pair}, fixed point at the call's
+// scale), so with FIX the result is the record path's, bit for bit, for inputs whose lanes stage A does not merge.
+template <bool FIX>
+__global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                                 int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                                 const float *__restrict__ g, int64_t g_sn, int64_t g_se,
+                                                                 const uint32_t *__restrict__ gmax, float *__restrict__ partial) {
+	extern __shared__ __attribute__((aligned(16))) unsigned long long acc_raw[];   // [2][2^lg]
+	double *acc = reinterpret_cast<double *>(acc_raw);
+	const uint32_t r = blockIdx.x, fb = blockIdx.y;
+	uint32_t e = 0;
+	while (e + 1 < dp.n && dp.bucket_base[e + 1] <= fb) ++e;
+	const uint32_t b = fb - dp.bucket_base[e], q = dp.qmap[e];
+	const uint32_t level = meta_level_of(md, q);
+	const Lvl L = load_level(md, level);
+	const uint32_t kPEpb = 1u << dp.lg, kPLds = 2u << dp.lg;
+	PairFix fx = {1.0, 1.0, false};
+	if constexpr (FIX) fx = pair_fix(gmax, dp.sum_log2);
+	const bool fix = FIX && fx.on;
+	for (uint32_t t = threadIdx.x; t < kPLds; t += kPAccThreads) acc_raw[t] = 0ull;
+	__syncthreads();
+	if ((int32_t)level <= max_level) {
+		const uint32_t p_lo = r * dp.pts_per_rep, p_hi = min(n, p_lo + dp.pts_per_rep);
+		for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kPAccThreads) {
+			float xp[3];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
+			const float g0 = g[(int64_t)i * g_sn + (int64_t)(q * 2) * g_se], g1 = g[(int64_t)i * g_sn + (int64_t)(q * 2 + 1) * g_se];
+			uint32_t hdr[4], bkt[4], cell[3];
+			float A[4][2], wp;
+			pair_records(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell);
+			const float wl = 1.0f - wp, wh = wp;
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				if (bkt[m] != b) continue;
+				const uint32_t i0 = hdr[m] & 8191u, i1 = (hdr[m] >> 13) & 8191u;
+				if (fix) {
+					atomicAdd(&acc_raw[i0], to_fix(wl * A[m][0], fx.scale)); atomicAdd(&acc_raw[kPEpb + i0], to_fix(wl * A[m][1], fx.scale));
+					atomicAdd(&acc_raw[i1], to_fix(wh * A[m][0], fx.scale)); atomicAdd(&acc_raw[kPEpb + i1], to_fix(wh * A[m][1], fx.scale));
+				} else {
+					atomicAdd(&acc[i0], (double)(wl * A[m][0])); atomicAdd(&acc[kPEpb + i0], (double)(wl * A[m][1]));
+					atomicAdd(&acc[i1], (double)(wh * A[m][0])); atomicAdd(&acc[kPEpb + i1], (double)(wh * A[m][1]));
+				}
+			}
+		}
+	}
+	__syncthreads();
+	float *mine = partial + ((size_t)fb * dp.R + r) * kPLds;
+	for (uint32_t t = threadIdx.x; t < kPLds; t += kPAccThreads)
+		mine[t] = fix ? (float)((double)(long long)acc_raw[t] * fx.inv) : (float)acc[t];
+}
+
+// dL/dparam slice of a direct bucket = (assign) or += the sum of its replicas' tables, replica 0 first
+__global__ __launch_bounds__(kPAccThreads) void k_pair_direct_reduce(DirectPlan dp, const nr3d_lotd_meta_t *__restrict__ md,
+                                                                     const float *__restrict__ partial, float *__restrict__ dparam,
+                                                                     uint32_t out_half) {
+	const uint32_t fb = blockIdx.x;
+	const bool half_out = (out_half & 1u) != 0, assign = (out_half & 2u) != 0;
+	uint32_t e = 0;
+	while (e + 1 < dp.n && dp.bucket_base[e + 1] <= fb) ++e;
+	const uint32_t b = fb - dp.bucket_base[e], q = dp.qmap[e];
+	const Lvl L = load_level(md, meta_level_of(md, q));
+	const uint32_t foff0 = meta_cnt_of(md, q) * 2u, kPLds = 2u << dp.lg;
+	const uint32_t t = blockIdx.y * kPAccThreads + threadIdx.x;
+	if (t >= kPLds) return;
+	float *p = pair_target(L, dp.epb[e], dp.lg, foff0, b, t, dparam, half_out);
+	if (!p) return;
+	const float *part0 = partial + (size_t)fb * dp.R * kPLds + t;
+	float sum = 0.0f;
+	uint32_t r0 = 0;
+	for (; r0 + 8 <= dp.R; r0 += 8) {
+		float v[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) v[j] = part0[(size_t)(r0 + j) * kPLds];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) sum += v[j];
+	}
+	for (; r0 < dp.R; ++r0) sum += part0[(size_t)r0 * kPLds];
+	pair_st(p, (assign ? 0.0f : pair_ld(p, half_out)) + sum, half_out);
+}
+
 constexpr uint32_t kRedRows = 4;
 // dL/dparam slice of a replicated bucket += sum of the replicas' partial tables, replica 0 first
 __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
@@ -717,7 +827,7 @@ bool pair_all_applies(const nr3d_lotd_meta_t *m) {
 }
 
 static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_level, int32_t max_level, PairPlan &plan,
-                      uint64_t &offs_words) {
+                      uint64_t &offs_words, uint64_t skip_pseudo = 0) {
 	plan.n_blk = div_up(n_chunk, pair_bp());
 	plan.cap = pair_bp() * 4u;
 	plan.lg = pair_lg();
@@ -728,7 +838,7 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
 	uint64_t base = 0;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const int32_t lv = (int32_t)m->map_levels[q];
-		if (lv < min_level || lv > max_level) continue;
+		if (lv < min_level || lv > max_level || ((skip_pseudo >> q) & 1ull)) continue;
 		const nr3d_lotd_level_t &L = m->levels[lv];
 		uint32_t nb, epb, sh;
 		if (L.type == NR3D_LOD_Dense) {
@@ -751,6 +861,36 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
 	offs_words = base;
 }
 
+// NR3D_PAIR_DIRECT=0: every level goes through records
+static bool pair_direct_enabled() {
+	const char *e = getenv("NR3D_PAIR_DIRECT");
+	return !(e && e[0] == '0');
+}
+// the pseudo levels of `full` with few buckets become the direct plan; returns the mask of those levels (0: none -- also
+// when nothing would be left for the record path, whose stage A carries the fixed-point scale)
+static uint64_t pair_direct_plan(const PairPlan &full, uint32_t n, DirectPlan &dp) {
+	dp.n = 0; dp.lg = full.lg; dp.sum_log2 = full.sum_log2; dp.R = 1; dp.pts_per_rep = n;
+	dp.bucket_base[0] = 0;
+	if (!pair_direct_enabled()) return 0;
+	uint64_t mask = 0;
+	for (uint32_t ql = 0; ql < full.n_pseudo && dp.n < kDirectMaxLv; ++ql) {
+		if (full.nb[ql] > kDirectNb || full.qmap[ql] >= 64u) continue;
+		const uint32_t e = dp.n++;
+		dp.qmap[e] = full.qmap[ql]; dp.nb[e] = full.nb[ql]; dp.epb[e] = full.epb[ql]; dp.shift[e] = full.shift[ql];
+		dp.bucket_base[e + 1] = dp.bucket_base[e] + full.nb[ql];
+		mask |= 1ull << full.qmap[ql];
+	}
+	if (dp.n == 0 || dp.n == full.n_pseudo) { dp.n = 0; return 0; }
+	const uint32_t nbk = dp.bucket_base[dp.n];
+	uint32_t R = kDirectMaxWg / nbk;                         // ~ two workgroups per CU over all direct buckets
+	R = R > 128u ? 128u : R;
+	const uint32_t by_points = div_up(n, 2048u);              // >= 2048 points per replica
+	R = R > by_points ? by_points : R;
+	dp.R = R < 1u ? 1u : R;
+	dp.pts_per_rep = div_up(n, dp.R);
+	return mask;
+}
+
 // workspace needs of the pair path for a chunk of n_chunk points (regions as in lotd_bin.hip's layout)
 void pair_layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t units, uint64_t &rec_bytes, uint64_t &offs_bytes,
                  uint64_t &plan_bytes, uint64_t &part_bytes) {
@@ -761,7 +901,7 @@ void pair_layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t units, ui
 	rec_bytes = (uint64_t)plan.n_pseudo * plan.n_blk * plan.cap * 16;
 	offs_bytes = ((ow * 4 + 255) / 256) * 256;
 	plan_bytes = (((uint64_t)NB * 3 + 4) * 4 + 255) / 256 * 256;
-	part_bytes = (uint64_t)(pair_units() + NB) * (2u << plan.lg) * 4;       // the pair path's own item count, not `units`
+	part_bytes = (uint64_t)(pair_units() + NB + kDirectMaxWg) * (2u << plan.lg) * 4;   // the pair path's own item count, not `units`; + k_pair_direct
 }
 
 void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32_t *tot, uint32_t *rep, uint32_t *item_start,
@@ -776,6 +916,14 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	uint64_t ow;
 	pair_plan(meta, n, min_level, max_level, pl, ow);
 	if (pl.n_pseudo == 0 && !(all_levels && fdx)) return 0;
+	// levels with a handful of buckets leave the record path (k_pair_direct); `pl` keeps the others
+	DirectPlan dp;
+	dp.n = 0;
+	const uint32_t NB_full = pl.bucket_base[pl.n_pseudo];
+	if (!all_levels) {
+		const uint64_t skip = pair_direct_plan(pl, n, dp);
+		if (skip) pair_plan(meta, n, min_level, max_level, pl, ow, skip);
+	}
 	uint32_t nb_max = 0;
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
 	const uint32_t NB = pl.bucket_base[pl.n_pseudo];
@@ -795,6 +943,8 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
@@ -805,7 +955,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	const uint32_t bp = pair_bp();
 	const size_t bin_lds = (size_t)bp * 4 * 16 + (size_t)(nb_max + 1) * 4;     // stage | hist
 #define NR3D_PAIR_BIN(BP) hipLaunchKernelGGL(k_pair_bin<BP>, dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level, \
-	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax)
+	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax, dp)
 #define NR3D_PAIR_ALL(DX, GT) hipLaunchKernelGGL((k_pair_bin_all<DX, GT>), dim3(pl.n_blk), dim3(1024), all_lds, st, pl, md, n,       \
 	meta->n_pseudo_levels, meta->n_encoded_dims, max_level, meta->interpolation_type, x, (const GT *)g, g_sn, g_se,                     \
 	fdx ? fdx->dydx : nullptr, fdx ? fdx->d_sn : 0, fdx ? fdx->d_se : 0, fdx ? fdx->dL_dx : nullptr, (u32x4 *)rec, offs, gmax)
@@ -830,6 +980,19 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 #undef NR3D_PAIR_ACC
 	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, div_up((2u << pl.lg) / kPAccThreads, kRedRows)), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
 	                   dparam, out_flags);
+	if (dp.n) {
+		float *dpart = partial + (size_t)(units + NB_full) * (2u << pl.lg);       // behind stage B's partial tables
+		const uint32_t nbk = dp.bucket_base[dp.n];
+		prof::Scope ps(NR3D_PROF_LOTD_ACCUM, st);
+		if (pair_fixed())
+			hipLaunchKernelGGL(k_pair_direct<true>, dim3(dp.R, nbk), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
+			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
+		else
+			hipLaunchKernelGGL(k_pair_direct<false>, dim3(dp.R, nbk), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
+			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
+		hipLaunchKernelGGL(k_pair_direct_reduce, dim3(nbk, (2u << pl.lg) / kPAccThreads), dim3(kPAccThreads), 0, st, dp, md, dpart, dparam,
+		                   out_flags);
+	}
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

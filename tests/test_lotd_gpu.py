@@ -272,6 +272,7 @@ def test_bwd_single_pass(oracle, dev, case, half, monkeypatch):
     from nr3d_lib_amd import _hip as H
     _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
     monkeypatch.delenv("NR3D_PAIR_ALL", raising=False)
+    monkeypatch.setenv("NR3D_PAIR_DIRECT", "0")        # every level through records: the route the single pass must reproduce bit for bit
     assert not H.lib().nr3d_lotd_bwd_fused_ok(ctypes.byref(m._cmeta()))
     dx0, dp0 = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)
     monkeypatch.setenv("NR3D_PAIR_ALL", "1")
@@ -288,6 +289,33 @@ def test_bwd_single_pass(oracle, dev, case, half, monkeypatch):
     assert_close(dx1, oracle.lotd_bwd_dx(m_ref, g, j_ref), name="dL_dx single pass")
     assert_close(dp1.float(), oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), rel=1e-3 if half else 1e-5,
                  name="dL_dparam single pass", levels=m_ref)
+
+
+@pytest.mark.parametrize("case,half", [("ngp_small", False), ("ngp_smooth", False), ("ngp_pair", False), ("ngp_pair", True), ("pair_f4", False)])
+def test_bwd_direct_levels(oracle, dev, case, half, monkeypatch):
+    """levels with <= 4 buckets bypass the records (k_pair_direct: LDS accumulation straight from x and dL_dy, default) --
+    against the all-records route (NR3D_PAIR_DIRECT=0; same per-update arithmetic and fixed-point sums, the two differ only
+    in how a replicated bucket's fp32 partial tables are split) and the oracle; plain and level-bucketed calls."""
+    n = 70001
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=n, seed=13)
+    if half:
+        pt, gt = pt.half(), gt.half()
+        p, g = pt.float().cpu().numpy(), gt.float().cpu().numpy()
+    monkeypatch.setenv("NR3D_PAIR_DIRECT", "1")
+    _, d1 = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
+    _, d1b = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
+    _, d1m = _lotd.lod_bwd(m, gt, xt, pt, None, max_level=1, need_input_grad=False, need_param_grad=True)
+    monkeypatch.setenv("NR3D_PAIR_DIRECT", "0")
+    _, d0 = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
+    _, d0m = _lotd.lod_bwd(m, gt, xt, pt, None, max_level=1, need_input_grad=False, need_param_grad=True)
+    assert torch.equal(d1, d1b)                                        # reproducible
+    ref = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
+    tol = 1e-3 if half else 1e-5
+    assert_close(d1.float(), ref, rel=tol, name="dL_dparam direct levels", levels=m_ref)
+    assert_close(d1.float(), d0.float().cpu().numpy(), rel=1e-3 if half else 1e-6, name="direct vs records", levels=m_ref)
+    assert_close(d1m.float(), d0m.float().cpu().numpy(), rel=1e-3 if half else 1e-6, name="direct vs records, max_level=1", levels=m_ref)
+    assert_close(d1m.float(), oracle.lotd_bwd_dparam(m_ref, g, x, p, max_level=1, accum_double=True), rel=tol,
+                 name="dL_dparam direct levels, max_level=1", levels=m_ref)
 
 
 def test_autograd_surface(oracle, dev):
