@@ -14,6 +14,7 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed 
 at N = 1, `cpu_baseline` (the CPU oracle -- a port, not the reference -- on a bounded sample).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -49,15 +50,17 @@ def kernel_algorithmic_bytes(kernel, n_levels_served, F=2, D=3, C=8):
         return Ls * F * 4 + Ls * F * D * 4 + 4 * D
     if kernel in ("lotd_bin", "lotd_accum"):            # x + dL_dy ... scatter as read-modify-write, half to each stage
         return (4 * D + Ls * F * 4 + 2 * Ls * C * F * 4) // 2
+    if kernel == "lotd_direct":                         # the same for the levels that skip the records, in one kernel
+        return 4 * D + Ls * F * 4 + 2 * Ls * C * F * 4
     raise KeyError(kernel)
 
 
 # timers of include/nr3d_hip.h (NR3D_PROF_*) -> kernel names as rocprofv3 prints them (the default configuration)
 PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true, float>", "lotd_fwd_lds": "k_fwd_lds<true, float>",
                 "lotd_contract_dx": "k_contract_dx_rowmajor<3, float>", "lotd_bin": "k_pair_bin<1024>",
-                "lotd_accum": "k_pair_accum<4, true>"}
+                "lotd_accum": "k_pair_accum<4, true>", "lotd_direct": "k_pair_direct<true>"}
 LIVE_TIMER = "lotd_fwd"      # the dominant kernel: timed inside the timed region (2 events per step); the rest in an extra pass
-OP_TIMERS = {"fwd": ["lotd_fwd_lds", "lotd_fwd"], "bwd": ["lotd_contract_dx", "lotd_bin", "lotd_accum"]}
+OP_TIMERS = {"fwd": ["lotd_fwd_lds", "lotd_fwd"], "bwd": ["lotd_contract_dx", "lotd_bin", "lotd_accum", "lotd_direct"]}
 
 
 def pmc_traffic_bytes(kernels, launches=None):
@@ -675,7 +678,9 @@ def main():
         per_step_us = {k: kernel_us[k] * kernel_launches[k] for k in kernel_us}
         dom = max(per_step_us, key=per_step_us.get)
         n_lds = int(round(kernel_launches.get("lotd_fwd_lds", 0)))
-        served = {"lotd_fwd": L_all - n_lds, "lotd_fwd_lds": 1, "lotd_contract_dx": L_all, "lotd_bin": L_all, "lotd_accum": L_all}
+        n_dir = int(H.lib().nr3d_lotd_pair_direct_levels(ctypes.byref(meta._cmeta()), ctypes.c_uint32(min(N, 1 << 22))))
+        served = {"lotd_fwd": L_all - n_lds, "lotd_fwd_lds": 1, "lotd_contract_dx": L_all, "lotd_bin": L_all - n_dir,
+                  "lotd_accum": L_all - n_dir, "lotd_direct": max(n_dir, 1)}
         per_kernel = {}
         for k, us in kernel_us.items():
             kb = kernel_algorithmic_bytes(k, served[k])

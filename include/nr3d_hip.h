@@ -39,7 +39,8 @@ enum {
 	NR3D_PROF_MARCH = 5,             /* ray marching, count + emit */
 	NR3D_PROF_COMPOSITE_FWD = 6,     /* fused alpha composite */
 	NR3D_PROF_COMPOSITE_BWD = 7,
-	NR3D_PROF_COUNT = 8
+	NR3D_PROF_LOTD_DIRECT = 8,       /* dL/dparam of the levels that skip the records (k_pair_direct) */
+	NR3D_PROF_COUNT = 9
 };
 void nr3d_prof_enable(uint32_t mask);
 int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, int reset);
@@ -158,6 +159,10 @@ int nr3d_lotd_half_params_ok(const nr3d_lotd_meta_t *meta, int batched);
  * UNINITIALISED and is fully defined on return (the flush writes instead of read-modify-writing when one pass covers
  * all levels; the library zero-fills it itself otherwise).  workspace as nr3d_lotd_bwd_dparam. */
 int nr3d_lotd_pair_path_ok(const nr3d_lotd_meta_t *meta);
+/* pseudo levels of a pair-path meta whose dL/dparam is accumulated straight from (x, dL_dy) in LDS instead of through
+ * records (levels with <= 4 buckets; 0 when the pair path does not apply or NR3D_PAIR_DIRECT=0).  Informational: which
+ * kernel serves which level (bench.py's per-kernel byte model). */
+int nr3d_lotd_pair_direct_levels(const nr3d_lotd_meta_t *meta, uint32_t n_points);
 int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points, int grad_dtype,
                                const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,
                                int out_dtype, int assign, void *dL_dparam, void *workspace, uint64_t workspace_bytes,

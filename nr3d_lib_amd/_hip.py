@@ -64,7 +64,7 @@ def check(rc):
 
 # ---- optional per-kernel HIP-event timers (include/nr3d_hip.h: NR3D_PROF_*) -------------------------------
 PROF_IDS = dict(lotd_fwd=0, lotd_fwd_lds=1, lotd_contract_dx=2, lotd_bin=3, lotd_accum=4, march=5, composite_fwd=6,
-                composite_bwd=7)
+                composite_bwd=7, lotd_direct=8)
 
 
 def prof_enable(*names):

@@ -1156,6 +1156,9 @@ extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *me
 }
 
 extern "C" int nr3d_lotd_pair_path_ok(const nr3d_lotd_meta_t *meta) { return (meta && pair_applies(meta)) ? 1 : 0; }
+extern "C" int nr3d_lotd_pair_direct_levels(const nr3d_lotd_meta_t *meta, uint32_t n_points) {
+	return (meta && pair_applies(meta)) ? (int)pair_direct_levels(meta, n_points) : 0;
+}
 
 extern "C" int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int grad_dtype,
                                           const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,

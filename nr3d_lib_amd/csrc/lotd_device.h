@@ -674,7 +674,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 
 // lotd_pair.hip: pair-record form of the same path for unbatched 3-D Dense/Hash metas with 2-feature pseudo levels
 bool pair_applies(const nr3d_lotd_meta_t *m);
-bool pair_all_applies(const nr3d_lotd_meta_t *m);      // ... and the all-levels stage A (dL_dy row in registers) on top
+bool pair_all_applies(const nr3d_lotd_meta_t *m);
+uint32_t pair_direct_levels(const nr3d_lotd_meta_t *m, uint32_t n_points);   // pseudo levels k_pair_direct serves (no records)      // ... and the all-levels stage A (dL_dy row in registers) on top
 void pair_layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t units, uint64_t &rec_bytes, uint64_t &offs_bytes,
                  uint64_t &plan_bytes, uint64_t &part_bytes);
 int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,

@@ -891,6 +891,15 @@ static uint64_t pair_direct_plan(const PairPlan &full, uint32_t n, DirectPlan &d
 	return mask;
 }
 
+uint32_t pair_direct_levels(const nr3d_lotd_meta_t *m, uint32_t n_points) {
+	PairPlan plan;
+	uint64_t ow;
+	pair_plan(m, n_points, 0, 0x7fffffff, plan, ow);
+	DirectPlan dp;
+	pair_direct_plan(plan, n_points, dp);
+	return dp.n;
+}
+
 // workspace needs of the pair path for a chunk of n_chunk points (regions as in lotd_bin.hip's layout)
 void pair_layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t units, uint64_t &rec_bytes, uint64_t &offs_bytes,
                  uint64_t &plan_bytes, uint64_t &part_bytes) {
@@ -983,7 +992,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	if (dp.n) {
 		float *dpart = partial + (size_t)(units + NB_full) * (2u << pl.lg);       // behind stage B's partial tables
 		const uint32_t nbk = dp.bucket_base[dp.n];
-		prof::Scope ps(NR3D_PROF_LOTD_ACCUM, st);
+		prof::Scope ps(NR3D_PROF_LOTD_DIRECT, st);
 		if (pair_fixed())
 			hipLaunchKernelGGL(k_pair_direct<true>, dim3(dp.R, nbk), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
 			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
