@@ -42,8 +42,16 @@ def test_fwd_and_jacobian(oracle, dev, case):
     assert_close(j3.view(j_ref.shape), j_ref, name="dy_dx row-major")
 
 
+@pytest.fixture(params=["direct", "records"])
+def bin_mode(request, monkeypatch):
+    """dL/dparam of the pair path's levels with <= 4 buckets: accumulated straight from (x, dL_dy) in LDS (k_pair_direct,
+    default) or through records like the large levels (NR3D_PAIR_DIRECT=0)"""
+    monkeypatch.setenv("NR3D_PAIR_DIRECT", "1" if request.param == "direct" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("case", list(LOTD_CASES))
-def test_bwd(oracle, dev, case):
+def test_bwd(oracle, dev, case, bin_mode):
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=1)
     _, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
     _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
@@ -60,7 +68,7 @@ def test_bwd(oracle, dev, case):
 
 
 @pytest.mark.parametrize("case", list(LOTD_CASES))
-def test_bwd_bwd_input(oracle, dev, case):
+def test_bwd_bwd_input(oracle, dev, case, bin_mode):
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=2)
     _, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
     _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
@@ -117,7 +125,7 @@ def test_dparam_atomic_and_binned_paths_agree(oracle, dev, case):
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "mixed", "dense_2d", "nplane"])
-def test_dparam_level_buckets(oracle, dev, case):
+def test_dparam_level_buckets(oracle, dev, case, bin_mode):
     """dL/dparam computed in level buckets (nr3d_lotd_bwd_dparam_levels; the data-parallel path reduces a finished
     bucket while the next one is accumulated): the buckets together are the one-call gradient (to fp32 rounding of the
     fp64 partial sums: how a hot table slice is split over workgroups follows the call's records), every bucket callback
@@ -168,7 +176,7 @@ def test_grid_index_rejects_other_types(oracle, dev):
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "mixed"])
-def test_batched_and_max_level(oracle, dev, case):
+def test_batched_and_max_level(oracle, dev, case, bin_mode):
     B = 3
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=2400, seed=4, n_batch=B)
     rng = np.random.default_rng(5)
@@ -445,7 +453,7 @@ def test_lotd_batched_module(oracle, dev):
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "mixed"])
-def test_dparam_multi_pass_chunking(oracle, dev, hiplib, case):
+def test_dparam_multi_pass_chunking(oracle, dev, hiplib, case, bin_mode):
     """the atomic-free scatter in several passes (2^10-point chunks over 5003 points: 4 full + 1 partial pass), with the
     feature-major dL_dy handed over by the dL/dx kernel (strided per pass) and with a plain row-major dL_dy"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=12)
@@ -466,7 +474,7 @@ def test_dparam_multi_pass_chunking(oracle, dev, hiplib, case):
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "mixed", "nplane"])
-def test_dparam_coherent_points(oracle, dev, case):
+def test_dparam_coherent_points(oracle, dev, case, bin_mode):
     """samples along rays: long runs of consecutive points in the same coarse cell take stage A's wave-level merge
     (their updates are summed into the first lane of the run before they are binned)"""
     _lotd, m_ref, m, _, _ = _setup(oracle, dev, case, n=8)
