@@ -138,6 +138,23 @@ __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t
 	for (int d = 0; d < 3; ++d) cell[d] = c.g[d];
 }
 
+// the buckets of the four pair records alone (pair_records' bkt): cell location + row / hash, nothing else
+__device__ __forceinline__ void pair_buckets(const Lvl &L, uint32_t sh, uint32_t lg, const float (&xp)[3], bool smooth, uint32_t (&bkt)[4]) {
+	Cell<3> c;
+	locate<3>(xp, L, smooth, c);
+	if (L.type == NR3D_LOD_Dense) {
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) bkt[m] = ((c.g[0] + (m & 1u)) * L.res[1] + (c.g[1] + (m >> 1))) >> sh;
+	} else {
+		const bool pow2 = (L.size & (L.size - 1u)) == 0u;
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) {
+			const uint32_t h0 = c.g[0] ^ ((c.g[1] + (m & 1u)) * kPrimes[1]) ^ ((c.g[2] + (m >> 1)) * kPrimes[2]);
+			bkt[m] = (pow2 ? (h0 & (L.size - 1u)) : (h0 % L.size)) >> lg;
+		}
+	}
+}
+
 // One pseudo level of one block of kPBP points: pair records -> rank inside the bucket -> counting sort in LDS ->
 // coalesced write-out of the slot + its bucket offsets.  `hist` [nb + 1] must be zero on entry (and that visible: a
 // barrier behind the zeroing); `zero_next` (optional) is zeroed for the following call.  Four barriers.
@@ -669,6 +686,7 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
                                                                  const float *__restrict__ g, int64_t g_sn, int64_t g_se,
                                                                  const uint32_t *__restrict__ gmax, float *__restrict__ partial) {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long acc_raw[];   // [2][2^lg]
+	__shared__ uint32_t queue[kPAccThreads / 64][128];                              // per wave: points waiting for the full arithmetic
 	double *acc = reinterpret_cast<double *>(acc_raw);
 	const uint32_t r = blockIdx.x, fb = blockIdx.y;
 	uint32_t e = 0;
@@ -684,7 +702,7 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 	__syncthreads();
 	if ((int32_t)level <= max_level) {
 		const uint32_t p_lo = r * dp.pts_per_rep, p_hi = min(n, p_lo + dp.pts_per_rep);
-		for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kPAccThreads) {
+		auto process = [&](uint32_t i) {
 			float xp[3];
 #pragma unroll
 			for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
@@ -705,6 +723,42 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 					atomicAdd(&acc[i1], (double)(wh * A[m][0])); atomicAdd(&acc[kPEpb + i1], (double)(wh * A[m][1]));
 				}
 			}
+		};
+		if (dp.nb[e] == 1) {
+			for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kPAccThreads) process(i);
+		} else {
+			// several buckets: most points touch one of them, so a wave first finds the points that concern ITS bucket
+			// (cell location and bucket indices only), queues them, and runs the full update arithmetic on dense waves of
+			// queued points -- the per-point cost of a pass drops from ~250 to ~60 instructions for the others
+			const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+			uint32_t *qw = queue[wave];
+			uint32_t qn = 0;
+			for (uint32_t i0 = p_lo + wave * 64u; i0 < p_hi; i0 += (uint32_t)kPAccThreads) {
+				const uint32_t i = i0 + lane;
+				bool match = false;
+				if (i < p_hi) {
+					float xp[3];
+#pragma unroll
+					for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
+					uint32_t bk[4];
+					pair_buckets(L, dp.shift[e], dp.lg, xp, smooth != 0, bk);
+					match = bk[0] == b || bk[1] == b || bk[2] == b || bk[3] == b;
+				}
+				const unsigned long long mm = __ballot(match);
+				if (match) qw[qn + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = i;
+				qn += (uint32_t)__popcll(mm);
+				__builtin_amdgcn_wave_barrier();
+				if (qn >= 64u) {
+					process(qw[lane]);
+					const uint32_t rest = qn - 64u;
+					const uint32_t t = lane < rest ? qw[64u + lane] : 0u;
+					__builtin_amdgcn_wave_barrier();
+					if (lane < rest) qw[lane] = t;
+					qn = rest;
+					__builtin_amdgcn_wave_barrier();
+				}
+			}
+			if (lane < qn) process(qw[lane]);
 		}
 	}
 	__syncthreads();
