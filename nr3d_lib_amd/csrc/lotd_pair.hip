@@ -927,8 +927,10 @@ static uint64_t pair_direct_plan(const PairPlan &full, uint32_t n, DirectPlan &d
 	dp.bucket_base[0] = 0;
 	if (!pair_direct_enabled()) return 0;
 	uint64_t mask = 0;
+	uint32_t nb_lim = kDirectNb;                              // NR3D_PAIR_DIRECT_NB: buckets up to which a level goes direct
+	if (const char *e = getenv("NR3D_PAIR_DIRECT_NB")) nb_lim = (uint32_t)atoi(e);
 	for (uint32_t ql = 0; ql < full.n_pseudo && dp.n < kDirectMaxLv; ++ql) {
-		if (full.nb[ql] > kDirectNb || full.qmap[ql] >= 64u) continue;
+		if (full.nb[ql] > nb_lim || full.qmap[ql] >= 64u) continue;
 		const uint32_t e = dp.n++;
 		dp.qmap[e] = full.qmap[ql]; dp.nb[e] = full.nb[ql]; dp.epb[e] = full.epb[ql]; dp.shift[e] = full.shift[ql];
 		dp.bucket_base[e + 1] = dp.bucket_base[e] + full.nb[ql];
