@@ -1063,17 +1063,37 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 	// vector gathers need every corner address G*4-byte aligned: base pointer aligned and no caller-chosen offsets
 	const uint32_t vec_ok = (((uintptr_t)params % (G >= 4 ? 16 : 8)) == 0 && batch_offsets == nullptr) ? 1u : 0u;
 	const bool dh = meta->c_hash_only != 0;
-	const Sched s = make_sched(N, meta, n_blocks);
 	prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
-	DISPATCH_DG(meta->n_dims_to_encode, G, {
-		auto launch = [&](auto kern) {
-			hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
-			                   meta->interpolation_type, (const float *)x, (const float *)params, ba, vec_ok,
-			                   (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
-		};
-		if (dy_dx) { if (dh) launch(k_fwd<D, G, true, true>); else launch(k_fwd<D, G, true, false>); }
-		else       { if (dh) launch(k_fwd<D, G, false, true>); else launch(k_fwd<D, G, false, false>); }
-	});
+	// A meta that mixes Dense / Hash levels with product types: the instantiation that carries every level type needs
+	// 114 VGPRs (4 waves per SIMD), the Dense / Hash one 54 (8 waves) -- so the Dense / Hash levels of a mixed meta go
+	// through the lean kernel in a launch of their own (same code for those levels, same bits), the rest through the
+	// general one.  NR3D_LOTD_FWD_SPLIT=0: one launch.
+	uint64_t lean = 0;
+	const char *split_env = getenv("NR3D_LOTD_FWD_SPLIT");
+	if (!dh && meta->n_pseudo_levels <= 64u && !(split_env && split_env[0] == '0'))
+		for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
+			const uint32_t t = meta->levels[meta->map_levels[q]].type;
+			if (t == NR3D_LOD_Dense || t == NR3D_LOD_Hash) lean |= 1ull << q;
+		}
+	const uint64_t all = meta->n_pseudo_levels >= 64u ? ~0ull : ((1ull << meta->n_pseudo_levels) - 1ull);
+	for (int pass = 0; pass < 2; ++pass) {
+		// pass 0: the general (or, for hash-only metas, the only) launch; pass 1: the lean launch of a mixed meta
+		if (pass == 1 && !lean) break;
+		if (pass == 0 && lean == all) continue;
+		const uint64_t skip = pass == 0 ? lean : (all & ~lean);
+		const bool lean_kernel = dh || pass == 1;
+		const Sched s = make_sched(N, meta, n_blocks, skip);
+		if (n_blocks == 0) continue;
+		DISPATCH_DG(meta->n_dims_to_encode, G, {
+			auto launch = [&](auto kern) {
+				hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+				                   meta->interpolation_type, (const float *)x, (const float *)params, ba, vec_ok,
+				                   (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+			};
+			if (dy_dx) { if (lean_kernel) launch(k_fwd<D, G, true, true>); else launch(k_fwd<D, G, true, false>); }
+			else       { if (lean_kernel) launch(k_fwd<D, G, false, true>); else launch(k_fwd<D, G, false, false>); }
+		});
+	}
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

@@ -50,6 +50,24 @@ def bin_mode(request, monkeypatch):
     return request.param
 
 
+@pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth", "cp_only_4d", "cp_4d", "nplane_4d"])
+def test_fwd_split_launch_same_bits(oracle, dev, case, monkeypatch):
+    """the Dense / Hash levels of a meta that also has product-type levels run through the lean Dense / Hash kernel in a
+    launch of their own (twice the occupancy): the same code for those levels, so not a bit may change"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=3)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NR3D_LOTD_FWD_SPLIT", mode)
+        y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+        y2, _ = _lotd.lod_fwd(m, xt, pt, need_input_grad=False)
+        ym, jm = _lotd.lod_fwd(m, xt, pt, max_level=m.n_levels // 2, need_input_grad=True)
+        outs[mode] = (y, j, y2, ym, jm)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+    y_ref, _ = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    assert_close(outs["1"][0], y_ref, name="y split launch")
+
+
 @pytest.mark.parametrize("case", list(LOTD_CASES))
 def test_bwd(oracle, dev, case, bin_mode):
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=1)
