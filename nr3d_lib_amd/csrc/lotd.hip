@@ -31,7 +31,7 @@ namespace lotd {
 // =============================================================================================
 // Forward
 // =============================================================================================
-template <int D, int G, bool DYDX, bool DH>
+template <int D, int G, bool DYDX, bool DH, int ONLY = -1>
 __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                 int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                 const float *__restrict__ params, Batch ba, uint32_t vec_ok,
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 		Cell<D> c;
 		locate<D>(xp, L, smooth != 0, c);
 
-		if (DH || L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash) {
+		if (DH || (ONLY < 0 && (L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash))) {
 			// ---- all corners of all G features at once; vector loads when alignment allows ----
 			float v[1 << D][G];
 			bool paired = false;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 							out_g[f][gd] = __fmaf_rn(w, v[k | (1u << gd)][f] - v[k][f], out_g[f][gd]);
 					}
 			}
-		} else if (L.type == NR3D_LOD_NPlaneSum) {
+		} else if (ONLY < 0 && L.type == NR3D_LOD_NPlaneSum) {
 			// sum over the D axis planes of an (D-1)-linear interpolation (reference: lotd_encoding.h:268-351)
 			if constexpr (D > 2) {
 #pragma unroll 1
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 					}
 				}
 			}
-		} else if (L.type == NR3D_LOD_CPfast) {
+		} else if (ONLY < 0 && L.type == NR3D_LOD_CPfast) {
 			// product over dims of 1-D linear interpolations (reference: lotd_encoding.h:353-410)
 			float lv[D][2][G], li[D][G];
 #pragma unroll
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 #pragma unroll 1
 			for (int f0 = 0; f0 < G; f0 += 2) {
 				float v[1 << D][2];
-				corner_values_pair<D>(L, grid, foff0 + f0, vec_ok != 0 && (L.F & 1u) == 0u, c, v);
+				corner_values_pair<D, ONLY>(L, grid, foff0 + f0, vec_ok != 0 && (L.F & 1u) == 0u, c, v);
 				float yy[2] = {0.0f, 0.0f}, gg[2][D];
 #pragma unroll
 				for (int f = 0; f < 2; ++f)
@@ -1068,20 +1068,26 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 	// 114 VGPRs (4 waves per SIMD), the Dense / Hash one 54 (8 waves) -- so the Dense / Hash levels of a mixed meta go
 	// through the lean kernel in a launch of their own (same code for those levels, same bits), the rest through the
 	// general one.  NR3D_LOTD_FWD_SPLIT=0: one launch.
-	uint64_t lean = 0;
+	// Likewise CP and VM levels (3-D) have instantiations of their own: the product types share one code path otherwise.
+	uint64_t grp[4] = {0, 0, 0, 0};                      // pseudo levels served by: 0 general, 1 Dense / Hash, 2 CP, 3 VM
 	const char *split_env = getenv("NR3D_LOTD_FWD_SPLIT");
-	if (!dh && meta->n_pseudo_levels <= 64u && !(split_env && split_env[0] == '0'))
+	const bool split = !dh && meta->n_pseudo_levels <= 64u && !(split_env && split_env[0] == '0');
+	const uint64_t all = meta->n_pseudo_levels >= 64u ? ~0ull : ((1ull << meta->n_pseudo_levels) - 1ull);
+	if (split) {
 		for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
 			const uint32_t t = meta->levels[meta->map_levels[q]].type;
-			if (t == NR3D_LOD_Dense || t == NR3D_LOD_Hash) lean |= 1ull << q;
+			int k = 0;
+			if (t == NR3D_LOD_Dense || t == NR3D_LOD_Hash) k = 1;
+			else if (meta->n_dims_to_encode == 3 && t == NR3D_LOD_CP) k = 2;
+			else if (meta->n_dims_to_encode == 3 && t == NR3D_LOD_VectorMatrix) k = 3;
+			grp[k] |= 1ull << q;
 		}
-	const uint64_t all = meta->n_pseudo_levels >= 64u ? ~0ull : ((1ull << meta->n_pseudo_levels) - 1ull);
-	for (int pass = 0; pass < 2; ++pass) {
-		// pass 0: the general (or, for hash-only metas, the only) launch; pass 1: the lean launch of a mixed meta
-		if (pass == 1 && !lean) break;
-		if (pass == 0 && lean == all) continue;
-		const uint64_t skip = pass == 0 ? lean : (all & ~lean);
-		const bool lean_kernel = dh || pass == 1;
+	} else {
+		grp[dh ? 1 : 0] = all;
+	}
+	for (int k = 0; k < 4; ++k) {
+		if (!grp[k]) continue;
+		const uint64_t skip = (split || meta->n_pseudo_levels <= 64u) ? (all & ~grp[k]) : 0ull;
 		const Sched s = make_sched(N, meta, n_blocks, skip);
 		if (n_blocks == 0) continue;
 		DISPATCH_DG(meta->n_dims_to_encode, G, {
@@ -1090,8 +1096,12 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 				                   meta->interpolation_type, (const float *)x, (const float *)params, ba, vec_ok,
 				                   (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
 			};
-			if (dy_dx) { if (lean_kernel) launch(k_fwd<D, G, true, true>); else launch(k_fwd<D, G, true, false>); }
-			else       { if (lean_kernel) launch(k_fwd<D, G, false, true>); else launch(k_fwd<D, G, false, false>); }
+			if (k == 1) { if (dy_dx) launch(k_fwd<D, G, true, true>); else launch(k_fwd<D, G, false, true>); }
+			else if (k == 0) { if (dy_dx) launch(k_fwd<D, G, true, false>); else launch(k_fwd<D, G, false, false>); }
+			else if constexpr (D == 3) {
+				if (k == 2) { if (dy_dx) launch(k_fwd<3, G, true, false, NR3D_LOD_CP>); else launch(k_fwd<3, G, false, false, NR3D_LOD_CP>); }
+				else { if (dy_dx) launch(k_fwd<3, G, true, false, NR3D_LOD_VectorMatrix>); else launch(k_fwd<3, G, false, false, NR3D_LOD_VectorMatrix>); }
+			}
 		});
 	}
 	NR3D_LAUNCH_CHECK();

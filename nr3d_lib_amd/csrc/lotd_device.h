@@ -348,11 +348,12 @@ __device__ __forceinline__ void ld_pair(const float *__restrict__ grid, uint32_t
 // (CP: 2D lines entries instead of D per corner; VM: 12 plane + 6 line entries instead of 6 per corner) and then form
 // the corner values with exactly corner_value()'s arithmetic, so the results are bit-identical to the per-corner form.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+// ONLY >= 0: the instantiation serves levels of that one type (the other types' code and registers drop out)
+template <int D, int ONLY = -1>
 __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__restrict__ grid, uint32_t foff, bool vec,
                                                    const Cell<D> &c, float (&v)[1 << D][2]) {
 	constexpr uint32_t C = 1u << D;
-	if (L.type == NR3D_LOD_CP) {
+	if (ONLY == NR3D_LOD_CP || (ONLY < 0 && L.type == NR3D_LOD_CP)) {
 		float t[D][2][2];
 #pragma unroll
 		for (int d = 0; d < D; ++d)
@@ -369,7 +370,7 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 			}
 		return;
 	}
-	if constexpr (D <= 3) {
+	if constexpr (D <= 3 && ONLY < 0) {
 		if (L.type == NR3D_LOD_NPlaneMul) {
 			constexpr uint32_t NS = 1u << (D - 1);
 			float t[D][NS][2];
@@ -393,9 +394,9 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 			return;
 		}
 	}
-	if constexpr (D == 3) {
-		if (L.type == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VecZMatXoY) {
-			const bool vm = L.type == NR3D_LOD_VectorMatrix;
+	if constexpr (D == 3 && (ONLY < 0 || ONLY == NR3D_LOD_VectorMatrix)) {
+		if (ONLY == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VecZMatXoY) {
+			const bool vm = ONLY == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VectorMatrix;
 #pragma unroll
 			for (uint32_t k = 0; k < C; ++k) { v[k][0] = 0.0f; v[k][1] = 0.0f; }
 #pragma unroll
@@ -425,11 +426,13 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 			return;
 		}
 	}
+	if constexpr (ONLY < 0) {
 #pragma unroll
-	for (uint32_t k = 0; k < C; ++k) {
-		uint32_t p[D];
-		corner_pos<D>(c, k, p);
-		corner_value<D, 2>(L, grid, foff, p, v[k]);
+		for (uint32_t k = 0; k < C; ++k) {
+			uint32_t p[D];
+			corner_pos<D>(c, k, p);
+			corner_value<D, 2>(L, grid, foff, p, v[k]);
+		}
 	}
 }
 
