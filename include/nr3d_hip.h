@@ -197,6 +197,18 @@ int nr3d_lotd_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uin
                          const void *dL_dy, int64_t dldy_sn, int64_t dldy_se, const void *x,
                          const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
                          uint32_t batch_data_size, int32_t max_level, void *dL_dx, void *stream);
+/* the same with a scratch buffer of nr3d_lotd_bwd_bwd_dx_workspace_bytes(meta, n_points) bytes (0: not served -- Dense /
+ * Hash metas only): the
+ * pseudo levels of a point are then worked on side by side (one lane per (point, pseudo level), the forward's level-major
+ * schedule) and summed in level order afterwards, instead of one after another in one lane.  Same values (the same bits
+ * for 2-feature pseudo levels).  A NULL / short workspace falls back to nr3d_lotd_bwd_bwd_dx. */
+uint64_t nr3d_lotd_bwd_bwd_dx_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points);
+int nr3d_lotd_bwd_bwd_dx_ws(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points,
+                            int x_dtype, int param_dtype, const void *dL_ddLdx,
+                            const void *dL_dy, int64_t dldy_sn, int64_t dldy_se, const void *x,
+                            const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
+                            uint32_t batch_data_size, int32_t max_level, void *dL_dx, void *workspace,
+                            uint64_t workspace_bytes, void *stream);
 
 /* lod_get_grid_index (lotd_torch_api.cu:771-855; kernel lotd_encoding.h:1300-1433):
  * grid_inds int64 [N, n_encoded_dims, 2^D] contiguous, ZERO-INIT.  Dense/Hash levels only. */

@@ -242,6 +242,7 @@ def _f32c(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
+HVP_WORKSPACE_MAX_BYTES = 8 << 30      # largest per-call scratch of the level-parallel d(dL/dx)/dx (beyond it: lane-serial kernel)
 NATIVE_HALF = True       # False: half params always go through fp32 copies (A/B measurements)
 
 
@@ -522,10 +523,16 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
                     cm, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(j), H.i64(jsn), H.i64(jse),
                     H.ptr(dL_ddLdy), H.i64(dL_ddLdy.stride(0)), H.i64(dL_ddLdy.stride(1)), st))
             if need_dx:
-                H.check(H.lib().nr3d_lotd_bwd_bwd_dx(
+                # scratch for the level-parallel form ([n_pseudo, N, D] floats), while it stays below HVP_WORKSPACE_MAX_BYTES
+                f = H.lib().nr3d_lotd_bwd_bwd_dx_workspace_bytes
+                f.restype = C.c_uint64
+                wsb = int(f(cm, H.u32(N)))
+                ws = (torch.empty((wsb + 3) // 4, dtype=torch.float32, device=dev)
+                      if 0 < wsb <= HVP_WORKSPACE_MAX_BYTES else None)
+                H.check(H.lib().nr3d_lotd_bwd_bwd_dx_ws(
                     cm, md, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(g32), H.i64(gsn),
                     H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
-                    H.i32(max_level), H.ptr(dL_dx), st))
+                    H.i32(max_level), H.ptr(dL_dx), H.ptr(ws), C.c_uint64(wsb if ws is not None else 0), st))
             if need_dp:
                 batched = batch_inds is not None or batch_offsets is not None or bds != 0
                 nbat = _n_batches(m, p32, batch_offsets, batched)

@@ -618,7 +618,61 @@ __global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_
 // d(dL/dx)/dx  -- Hessian-vector product; Dense / Hash / VM / VecZMatXoY only (other types: 0)
 // Each lane owns ALL pseudo levels of one point (no cross-lane atomics on dL_dx).
 // =============================================================================================
-template <int D, int G>
+// d(dL/dx)/dx contribution of ONE pseudo level to one point: acc[d] += sum_e vin[e] * d^2(sum_f grad_f y_f)/dx_e dx_d
+// (reference: kernel_lod_backward_input_backward_input, lotd_encoding.h:1157-1298; Dense / Hash / VM / VecZMatXoY only)
+template <int D, int G, bool DH>
+__device__ __forceinline__ void hvp_level(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q, const Lvl &L, const Cell<D> &c,
+                                          uint32_t smooth, const float (&vin)[D], uint32_t i, const float *__restrict__ dL_dy,
+                                          int64_t g_sn, int64_t g_se, const float *__restrict__ grid, bool vec_ok,
+                                          float (&acc)[D]) {
+#pragma unroll 1
+	for (int f0 = 0; f0 < G; f0 += 2) {
+		const uint32_t foff = meta_cnt_of(md, q) * G + f0;
+		float grad[2];
+		grad[0] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0) * g_se];
+		grad[1] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0 + 1) * g_se];
+		// s[k] = sum_f value(corner k)[f] * grad[f]
+		float sdot[1 << D];
+		{
+			float v[1 << D][2];
+			corner_values_pair<D, DH ? kOnlyDenseHash : -1>(L, grid, foff, vec_ok && (L.F & 1u) == 0u, c, v);
+#pragma unroll
+			for (uint32_t k = 0; k < (1u << D); ++k)      // same arithmetic as corner_dot(..., weight = 1)
+				sdot[k] = __fmaf_rn(v[k][1] * grad[1], 1.0f, __fmaf_rn(v[k][0] * grad[0], 1.0f, 0.0f));
+		}
+		// out_d = sum_e v_e * H[e][d],  H = d^2 (sum_c W_c s_c) / dx_e dx_d
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			float o = 0.0f;
+#pragma unroll
+			for (int e = 0; e < D; ++e) {
+				if (e == d && !smooth) continue;    // linear: zero diagonal
+				const float seed = (e == d) ? (c.sc[d] * vin[d]) * (c.sc[d] * c.ddw[d])
+				                            : (c.sc[e] * vin[e] * c.dw[e]) * (c.dw[d] * c.sc[d]);
+#pragma unroll
+				for (uint32_t k = 0; k < (1u << D); ++k) {
+					// differentiated dims contribute the sign of the corner (+upper, -lower),
+					// the others their interpolation weight (for e == d the sign appears once)
+					float w = seed;
+#pragma unroll
+					for (int m = 0; m < D; ++m) {
+						const bool up = (k >> m) & 1u;
+						if (m == d || m == e) w *= up ? 1.0f : -1.0f;
+						else w *= up ? c.w[m] : (1.0f - c.w[m]);
+					}
+					o = __fmaf_rn(w, sdot[k], o);
+				}
+			}
+			acc[d] += o;
+		}
+	}
+}
+__device__ __forceinline__ bool hvp_type(uint32_t t) {
+	return t == NR3D_LOD_Dense || t == NR3D_LOD_Hash || t == NR3D_LOD_VectorMatrix || t == NR3D_LOD_VecZMatXoY;
+}
+
+// one lane = one point, the pseudo levels one after another (no workspace needed)
+template <int D, int G, bool DH = false>
 __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                        uint32_t n_pseudo, int32_t max_level, uint32_t smooth,
                                                        const float *__restrict__ dL_ddLdx,
@@ -641,57 +695,68 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 			const uint32_t level = meta_level_of(md, q);
 			if ((int32_t)level > max_level) continue;
 			const Lvl L = load_level(md, level);
-			if (!(L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash || L.type == NR3D_LOD_VectorMatrix ||
-			      L.type == NR3D_LOD_VecZMatXoY)) continue;
-			const float *__restrict__ grid = params + (base + L.off);
+			if (!DH && !hvp_type(L.type)) continue;
 			Cell<D> c;
 			locate<D>(xp, L, smooth != 0, c);
-#pragma unroll 1
-			for (int f0 = 0; f0 < G; f0 += 2) {
-				const uint32_t foff = meta_cnt_of(md, q) * G + f0;
-				float grad[2];
-				grad[0] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0) * g_se];
-				grad[1] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0 + 1) * g_se];
-				// s[k] = sum_f value(corner k)[f] * grad[f]
-				float sdot[1 << D];
-				{
-					float v[1 << D][2];
-					corner_values_pair<D>(L, grid, foff, vec_ok && (L.F & 1u) == 0u, c, v);
-#pragma unroll
-					for (uint32_t k = 0; k < (1u << D); ++k)      // same arithmetic as corner_dot(..., weight = 1)
-						sdot[k] = __fmaf_rn(v[k][1] * grad[1], 1.0f, __fmaf_rn(v[k][0] * grad[0], 1.0f, 0.0f));
-				}
-				// out_d = sum_e v_e * H[e][d],  H = d^2 (sum_c W_c s_c) / dx_e dx_d
-#pragma unroll
-				for (int d = 0; d < D; ++d) {
-					float o = 0.0f;
-#pragma unroll
-					for (int e = 0; e < D; ++e) {
-						if (e == d && !smooth) continue;    // linear: zero diagonal
-						const float seed = (e == d) ? (c.sc[d] * vin[d]) * (c.sc[d] * c.ddw[d])
-						                            : (c.sc[e] * vin[e] * c.dw[e]) * (c.dw[d] * c.sc[d]);
-#pragma unroll
-						for (uint32_t k = 0; k < (1u << D); ++k) {
-							// differentiated dims contribute the sign of the corner (+upper, -lower),
-							// the others their interpolation weight (for e == d the sign appears once)
-							float w = seed;
-#pragma unroll
-							for (int m = 0; m < D; ++m) {
-								const bool up = (k >> m) & 1u;
-								if (m == d || m == e) w *= up ? 1.0f : -1.0f;
-								else w *= up ? c.w[m] : (1.0f - c.w[m]);
-							}
-							o = __fmaf_rn(w, sdot[k], o);
-						}
-					}
-					acc[d] += o;
-				}
-			}
+			hvp_level<D, G, DH>(md, q, L, c, smooth, vin, i, dL_dy, g_sn, g_se, params + (base + L.off), vec_ok, acc);
 		}
 	}
 #pragma unroll
 	for (int d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = acc[d];
 }
+
+// The same with one lane per (point, pseudo level), level-major blocks on the forward's XCD-affine schedule: the lane-serial
+// form above keeps 8 gathers of ONE level in flight per lane and walks all tables in every workgroup; here the levels
+// of a point run side by side (a wave works on one table) and leave their D floats in partial[q][i][:], which
+// k_sum_levels adds up in level order -- the serial kernel's order, so (for 2-feature pseudo levels) its bits.
+template <int D, int G, bool DH>
+__global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_lv(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                          int32_t max_level, uint32_t smooth, const float *__restrict__ dL_ddLdx,
+                                                          const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
+                                                          const float *__restrict__ x, const float *__restrict__ params, Batch ba,
+                                                          bool vec_ok, float *__restrict__ partial) {
+	uint32_t q, chunk;
+	if (!decode_block(s, blockIdx.x, q, chunk)) return;
+	const uint32_t i = chunk * kBlock + threadIdx.x;
+	if (i >= N) return;
+	float acc[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) acc[d] = 0.0f;
+	const uint32_t level = meta_level_of(md, q);
+	uint32_t base = 0;
+	if ((int32_t)level <= max_level && batch_base(ba, i, base)) {
+		const Lvl L = load_level(md, level);
+		if (DH || hvp_type(L.type)) {
+			float xp[D], vin[D];
+#pragma unroll
+			for (int d = 0; d < D; ++d) { xp[d] = x[(size_t)i * D + d]; vin[d] = dL_ddLdx[(size_t)i * D + d]; }
+			Cell<D> c;
+			locate<D>(xp, L, smooth != 0, c);
+			hvp_level<D, G, DH>(md, q, L, c, smooth, vin, i, dL_dy, g_sn, g_se, params + (base + L.off), vec_ok, acc);
+		}
+	}
+	float *dst = partial + ((size_t)q * N + i) * D;
+#pragma unroll
+	for (int d = 0; d < D; ++d) __builtin_nontemporal_store(acc[d], dst + d);
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_sum_levels(uint32_t N, uint32_t n_pseudo, const float *__restrict__ partial,
+                                                       float *__restrict__ dL_dx) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= N) return;
+	float acc[D];
+#pragma unroll
+	for (int d = 0; d < D; ++d) acc[d] = 0.0f;
+	for (uint32_t q = 0; q < n_pseudo; ++q) {
+		const float *src = partial + ((size_t)q * N + i) * D;
+#pragma unroll
+		for (int d = 0; d < D; ++d) acc[d] += __builtin_nontemporal_load(src + d);
+	}
+#pragma unroll
+	for (int d = 0; d < D; ++d) dL_dx[(size_t)i * D + d] = acc[d];
+}
+
 
 // =============================================================================================
 // Dense contractions with the stored Jacobian
@@ -1291,24 +1356,72 @@ extern "C" int nr3d_lotd_bwd_bwd_ddLdy(const nr3d_lotd_meta_t *meta, uint32_t N,
 	return 0;
 }
 
-extern "C" int nr3d_lotd_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
-                                    int param_dtype, const void *dL_ddLdx, const void *dL_dy, int64_t g_sn,
-                                    int64_t g_se, const void *x, const void *params, const int64_t *batch_inds,
-                                    const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
-                                    void *dL_dx, void *stream) {
+static int launch_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype, int param_dtype,
+                             const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
+                             const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
+                             uint32_t batch_data_size, int32_t max_level, void *dL_dx, void *workspace, uint64_t workspace_bytes,
+                             void *stream) {
 	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
 	if (N == 0) return 0;
 	NR3D_CHECK(dL_ddLdx && dL_dy && x && params && dL_dx, "LoTD::bwd_bwd_dx: NULL tensor pointer");
 	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
+	// hash-only metas (every level Dense or Hash): instantiations without the product types' code
+	const bool dh = meta->c_hash_only != 0;
+	const bool vec_ok = (((uintptr_t)params % 8) == 0 && batch_offsets == nullptr);
+	const uint64_t need = nr3d_lotd_bwd_bwd_dx_workspace_bytes(meta, N);
+	const char *lv_env = getenv("NR3D_LOTD_HVP_LEVELS");             // 0: the lane-serial kernel even with a workspace
+	if (workspace && need && workspace_bytes >= need && !(lv_env && lv_env[0] == '0')) {
+		uint32_t n_blocks;
+		const Sched s = make_sched(N, meta, n_blocks);
+		DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
+			auto launch = [&](auto kern) {
+				hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
+				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
+				                   (const float *)x, (const float *)params, ba, vec_ok, (float *)workspace);
+			};
+			if (dh) launch(k_bwd_bwd_dx_lv<D, G, true>); else launch(k_bwd_bwd_dx_lv<D, G, false>);
+			hipLaunchKernelGGL(k_sum_levels<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N,
+			                   meta->n_pseudo_levels, (const float *)workspace, (float *)dL_dx);
+		});
+		NR3D_LAUNCH_CHECK();
+		return 0;
+	}
 	DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
-		hipLaunchKernelGGL((k_bwd_bwd_dx<D, G>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, md, N,
-		                   meta->n_pseudo_levels, max_level, meta->interpolation_type, (const float *)dL_ddLdx,
-		                   (const float *)dL_dy, g_sn, g_se, (const float *)x, (const float *)params, ba,
-		                   (((uintptr_t)params % 8) == 0 && batch_offsets == nullptr), (float *)dL_dx);
+		auto launch = [&](auto kern) {
+			hipLaunchKernelGGL(kern, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, md, N,
+			                   meta->n_pseudo_levels, max_level, meta->interpolation_type, (const float *)dL_ddLdx,
+			                   (const float *)dL_dy, g_sn, g_se, (const float *)x, (const float *)params, ba, vec_ok, (float *)dL_dx);
+		};
+		if (dh) launch(k_bwd_bwd_dx<D, G, true>); else launch(k_bwd_bwd_dx<D, G, false>);
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;
+}
+
+extern "C" uint64_t nr3d_lotd_bwd_bwd_dx_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points) {
+	// Dense / Hash metas only: with product types in the instantiation (114+ VGPRs) one lane per level is a loss --
+	// configs[3]: 7.8 ms against 4.0 for the lane-serial kernel
+	if (!meta || !meta->c_hash_only || meta->n_pseudo_levels > 64u) return 0;
+	return (uint64_t)n_points * meta->n_pseudo_levels * meta->n_dims_to_encode * sizeof(float);
+}
+
+extern "C" int nr3d_lotd_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                                    int param_dtype, const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se,
+                                    const void *x, const void *params, const int64_t *batch_inds,
+                                    const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
+                                    void *dL_dx, void *stream) {
+	return launch_bwd_bwd_dx(meta, meta_dev, N, x_dtype, param_dtype, dL_ddLdx, dL_dy, g_sn, g_se, x, params, batch_inds,
+	                         batch_offsets, batch_data_size, max_level, dL_dx, nullptr, 0, stream);
+}
+
+extern "C" int nr3d_lotd_bwd_bwd_dx_ws(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
+                                       int param_dtype, const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se,
+                                       const void *x, const void *params, const int64_t *batch_inds,
+                                       const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level,
+                                       void *dL_dx, void *workspace, uint64_t workspace_bytes, void *stream) {
+	return launch_bwd_bwd_dx(meta, meta_dev, N, x_dtype, param_dtype, dL_ddLdx, dL_dy, g_sn, g_se, x, params, batch_inds,
+	                         batch_offsets, batch_data_size, max_level, dL_dx, workspace, workspace_bytes, stream);
 }
 
 extern "C" int nr3d_lotd_grid_index(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,

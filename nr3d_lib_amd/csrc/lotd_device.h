@@ -348,11 +348,23 @@ __device__ __forceinline__ void ld_pair(const float *__restrict__ grid, uint32_t
 // (CP: 2D lines entries instead of D per corner; VM: 12 plane + 6 line entries instead of 6 per corner) and then form
 // the corner values with exactly corner_value()'s arithmetic, so the results are bit-identical to the per-corner form.
 // ---------------------------------------------------------------------------------------------
-// ONLY >= 0: the instantiation serves levels of that one type (the other types' code and registers drop out)
+// ONLY >= 0: the instantiation serves levels of that one type (the other types' code and registers drop out);
+// kOnlyDenseHash: Dense and Hash levels only (hash-only metas)
+constexpr int kOnlyDenseHash = -2;
 template <int D, int ONLY = -1>
 __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__restrict__ grid, uint32_t foff, bool vec,
                                                    const Cell<D> &c, float (&v)[1 << D][2]) {
 	constexpr uint32_t C = 1u << D;
+	if constexpr (ONLY == kOnlyDenseHash) {                // hash-only metas: the values corner_value() loads
+#pragma unroll
+		for (uint32_t k = 0; k < C; ++k) {
+			uint32_t p[D];
+			corner_pos<D>(c, k, p);
+			const uint32_t i = ((L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p)) * L.F + foff;
+			ld_pair(grid, i, vec, v[k]);                      // one 8-byte request when the alignment allows
+		}
+		return;
+	}
 	if (ONLY == NR3D_LOD_CP || (ONLY < 0 && L.type == NR3D_LOD_CP)) {
 		float t[D][2][2];
 #pragma unroll
