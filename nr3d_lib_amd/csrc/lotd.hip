@@ -618,6 +618,36 @@ __global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_
 // d(dL/dx)/dx  -- Hessian-vector product; Dense / Hash / VM / VecZMatXoY only (other types: 0)
 // Each lane owns ALL pseudo levels of one point (no cross-lane atomics on dL_dx).
 // =============================================================================================
+// acc[d] += sum_e vin[e] * H[e][d],  H = d^2 (sum_c W_c s_c) / dx_e dx_d, s_c = the corner's value . grad
+template <int D>
+__device__ __forceinline__ void hvp_from_sdot(const Cell<D> &c, uint32_t smooth, const float (&vin)[D], const float (&sdot)[1 << D],
+                                              float (&acc)[D]) {
+#pragma unroll
+	for (int d = 0; d < D; ++d) {
+		float o = 0.0f;
+#pragma unroll
+		for (int e = 0; e < D; ++e) {
+			if (e == d && !smooth) continue;    // linear: zero diagonal
+			const float seed = (e == d) ? (c.sc[d] * vin[d]) * (c.sc[d] * c.ddw[d])
+			                            : (c.sc[e] * vin[e] * c.dw[e]) * (c.dw[d] * c.sc[d]);
+#pragma unroll
+			for (uint32_t k = 0; k < (1u << D); ++k) {
+				// differentiated dims contribute the sign of the corner (+upper, -lower),
+				// the others their interpolation weight (for e == d the sign appears once)
+				float w = seed;
+#pragma unroll
+				for (int m = 0; m < D; ++m) {
+					const bool up = (k >> m) & 1u;
+					if (m == d || m == e) w *= up ? 1.0f : -1.0f;
+					else w *= up ? c.w[m] : (1.0f - c.w[m]);
+				}
+				o = __fmaf_rn(w, sdot[k], o);
+			}
+		}
+		acc[d] += o;
+	}
+}
+
 // d(dL/dx)/dx contribution of ONE pseudo level to one point: acc[d] += sum_e vin[e] * d^2(sum_f grad_f y_f)/dx_e dx_d
 // (reference: kernel_lod_backward_input_backward_input, lotd_encoding.h:1157-1298; Dense / Hash / VM / VecZMatXoY only)
 template <int D, int G, bool DH>
@@ -640,31 +670,7 @@ __device__ __forceinline__ void hvp_level(const nr3d_lotd_meta_t *__restrict__ m
 			for (uint32_t k = 0; k < (1u << D); ++k)      // same arithmetic as corner_dot(..., weight = 1)
 				sdot[k] = __fmaf_rn(v[k][1] * grad[1], 1.0f, __fmaf_rn(v[k][0] * grad[0], 1.0f, 0.0f));
 		}
-		// out_d = sum_e v_e * H[e][d],  H = d^2 (sum_c W_c s_c) / dx_e dx_d
-#pragma unroll
-		for (int d = 0; d < D; ++d) {
-			float o = 0.0f;
-#pragma unroll
-			for (int e = 0; e < D; ++e) {
-				if (e == d && !smooth) continue;    // linear: zero diagonal
-				const float seed = (e == d) ? (c.sc[d] * vin[d]) * (c.sc[d] * c.ddw[d])
-				                            : (c.sc[e] * vin[e] * c.dw[e]) * (c.dw[d] * c.sc[d]);
-#pragma unroll
-				for (uint32_t k = 0; k < (1u << D); ++k) {
-					// differentiated dims contribute the sign of the corner (+upper, -lower),
-					// the others their interpolation weight (for e == d the sign appears once)
-					float w = seed;
-#pragma unroll
-					for (int m = 0; m < D; ++m) {
-						const bool up = (k >> m) & 1u;
-						if (m == d || m == e) w *= up ? 1.0f : -1.0f;
-						else w *= up ? c.w[m] : (1.0f - c.w[m]);
-					}
-					o = __fmaf_rn(w, sdot[k], o);
-				}
-			}
-			acc[d] += o;
-		}
+		hvp_from_sdot<D>(c, smooth, vin, sdot, acc);
 	}
 }
 __device__ __forceinline__ bool hvp_type(uint32_t t) {
@@ -738,6 +744,80 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_lv(Sched s, const nr3d_lo
 	float *dst = partial + ((size_t)q * N + i) * D;
 #pragma unroll
 	for (int d = 0; d < D; ++d) __builtin_nontemporal_store(acc[d], dst + d);
+}
+
+// ... and with the forward's TWO lanes per (point, pseudo level) (k_fwd_pairlane: 3-D Dense / Hash, 2-feature pseudo
+// levels, unbatched): lane s gathers the side-s corner of each of the four pairs -- 4 / 4.25 L2 requests per (point,
+// level) instead of 8 --, the partners swap through DPP so that lane s holds all 8 corners of FEATURE s, multiplies by its
+// dL_dy column and swaps once more: s_c = v_c[0] g_0 + v_c[1] g_1, the serial kernel's sum.  Both lanes then run the same
+// Hessian arithmetic (hvp_from_sdot); lane 0 stores.
+__global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_pl(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                          int32_t max_level, uint32_t smooth, const float *__restrict__ dL_ddLdx,
+                                                          const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
+                                                          const float *__restrict__ x, const float *__restrict__ params,
+                                                          float *__restrict__ partial) {
+	constexpr int D = 3;
+	uint32_t q, chunk;
+	if (!decode_block(s, blockIdx.x, q, chunk)) return;
+	const uint32_t i = chunk * kPlPts + (threadIdx.x >> 1);
+	const uint32_t side = threadIdx.x & 1u;
+	if (i >= N) return;                                  // both lanes of a pair leave together
+	const uint32_t level = meta_level_of(md, q);
+	const uint32_t foff0 = meta_cnt_of(md, q) * 2u;
+	float acc[D] = {0.0f, 0.0f, 0.0f};
+	if ((int32_t)level <= max_level) {
+		const Lvl L = load_level(md, level);
+		const float *__restrict__ grid = params + L.off;
+		float xp[D], vin[D];
+#pragma unroll
+		for (int d = 0; d < D; ++d) { xp[d] = x[(size_t)i * D + d]; vin[d] = dL_ddLdx[(size_t)i * D + d]; }
+		Cell<D> c;
+		locate<D>(xp, L, smooth != 0, c);
+		const bool dense = L.type == NR3D_LOD_Dense;
+		uint32_t e[4];
+		if (dense) {
+			const uint32_t e00 = (c.g[0] * L.res[1] + c.g[1]) * L.res[2] + c.g[2] + side;
+			const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
+			e[0] = e00; e[1] = e00 + sx; e[2] = e00 + sy; e[3] = e00 + sx + sy;
+		} else {
+			const uint32_t hy0 = c.g[1] * kPrimes[1], hy1 = hy0 + kPrimes[1];
+			const uint32_t hz0 = c.g[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
+			const uint32_t xs = c.g[0] + side;
+			const uint32_t h[4] = {xs ^ hy0 ^ hz0, xs ^ hy1 ^ hz0, xs ^ hy0 ^ hz1, xs ^ hy1 ^ hz1};
+			if ((L.size & (L.size - 1u)) == 0u) {
+#pragma unroll
+				for (int m = 0; m < 4; ++m) e[m] = h[m] & (L.size - 1u);
+			} else {
+#pragma unroll
+				for (int m = 0; m < 4; ++m) e[m] = h[m] % L.size;
+			}
+		}
+		const char *__restrict__ base = reinterpret_cast<const char *>(grid + foff0);
+		const uint32_t stride = L.F * (uint32_t)sizeof(float);
+		float2 t[4];
+#pragma unroll
+		for (int m = 0; m < 4; ++m) t[m] = load_pair<float>(base + e[m] * stride);
+		const float gs = dL_dy[(int64_t)i * g_sn + (int64_t)(q * 2u + side) * g_se];
+		auto swap = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); };
+		float sdot[8];
+#pragma unroll
+		for (uint32_t m = 0; m < 4; ++m) {
+			const float sw_x = swap(t[m].x), sw_y = swap(t[m].y);
+			const float lo = side ? sw_y : t[m].x, hi = side ? t[m].y : sw_x;       // feature `side` at the pair's two corners
+			const float p_lo = lo * gs, p_hi = hi * gs;
+			// v[0] g_0 + v[1] g_1: the feature-0 product first, as the serial kernel's fma chain rounds it
+			const float o_lo = swap(p_lo), o_hi = swap(p_hi);
+			const float s_lo = side ? (o_lo + p_lo) : (p_lo + o_lo), s_hi = side ? (o_hi + p_hi) : (p_hi + o_hi);
+			if (dense) { sdot[m] = s_lo; sdot[m | 4u] = s_hi; }
+			else { sdot[m << 1] = s_lo; sdot[(m << 1) | 1u] = s_hi; }
+		}
+		hvp_from_sdot<D>(c, smooth, vin, sdot, acc);
+	}
+	if (side == 0) {
+		float *dst = partial + ((size_t)q * N + i) * D;
+#pragma unroll
+		for (int d = 0; d < D; ++d) __builtin_nontemporal_store(acc[d], dst + d);
+	}
 }
 
 template <int D>
@@ -1373,14 +1453,22 @@ static int launch_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 	const char *lv_env = getenv("NR3D_LOTD_HVP_LEVELS");             // 0: the lane-serial kernel even with a workspace
 	if (workspace && need && workspace_bytes >= need && !(lv_env && lv_env[0] == '0')) {
 		uint32_t n_blocks;
-		const Sched s = make_sched(N, meta, n_blocks);
+		const bool batched = batch_inds || batch_offsets || batch_data_size;
+		const char *pl_env = getenv("NR3D_LOTD_HVP_PAIRLANE");
+		const bool pl = !batched && pairlane_enabled() && pairlane_meta_ok(meta) && ((uintptr_t)params % 8) == 0 &&
+		                !(pl_env && pl_env[0] == '0');
+		const Sched s = pl ? make_sched(N, meta, n_blocks, 0, (uint32_t)kPlPts, true) : make_sched(N, meta, n_blocks);
 		DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
 			auto launch = [&](auto kern) {
 				hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
 				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
 				                   (const float *)x, (const float *)params, ba, vec_ok, (float *)workspace);
 			};
-			if (dh) launch(k_bwd_bwd_dx_lv<D, G, true>); else launch(k_bwd_bwd_dx_lv<D, G, false>);
+			if (pl)
+				hipLaunchKernelGGL(k_bwd_bwd_dx_pl, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
+				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
+				                   (const float *)x, (const float *)params, (float *)workspace);
+			else if (dh) launch(k_bwd_bwd_dx_lv<D, G, true>); else launch(k_bwd_bwd_dx_lv<D, G, false>);
 			hipLaunchKernelGGL(k_sum_levels<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N,
 			                   meta->n_pseudo_levels, (const float *)workspace, (float *)dL_dx);
 		});
