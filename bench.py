@@ -396,6 +396,37 @@ def lotd_half_rate(dev, log2n=20, iters=10):
                 mpoints_per_s=round(N / ms / 1e3, 3))
 
 
+def lotd_second_order_rate(dev, log2n=20, iters=10):
+    """the second-order passes on configs[1]'s meta: d(dL/dx)/d{dL_dy, params, x} for a random dL_ddLdx --
+    what an eikonal / curvature loss adds to a step"""
+    from nr3d_lib_amd.bindings import _lotd
+    from nr3d_lib_amd.models.grid_encodings.lotd import gen_ngp_cfg
+    cfg = gen_ngp_cfg()
+    meta = _lotd.LoDMeta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
+    N = 1 << log2n
+    gen = torch.Generator(device="cpu").manual_seed(44)
+    params = torch.empty(meta.n_params).uniform_(-1e-2, 1e-2, generator=gen).to(dev)
+    x = torch.rand(N, 3, generator=gen).clamp_(1e-6, 1 - 1e-6).to(dev)
+    g = (torch.randn(N, meta.n_encoded_dims, generator=gen) * 1e-2).to(dev)
+    v = torch.randn(N, 3, generator=gen).to(dev)
+    _, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
+    ms = {}
+    for name, flags in (("ddLdy", (True, False, False)), ("dparam", (False, True, False)), ("dx", (False, False, True))):
+        fn = lambda: _lotd.lod_bwd_bwd_input(meta, v, g, x, params, j, need_dLdinput_ddLdoutput=flags[0],
+                                             need_dLdinput_dparams=flags[1], need_dLdinput_dinput=flags[2])
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        ms[name] = round((time.perf_counter() - t0) / iters * 1e3, 4)
+    tot = sum(ms.values())
+    return dict(workload=f"configs[1]'s meta, 2^{log2n} points: d(dL/dx)/d(dL_dy), d(dL/dx)/dparam, d(dL/dx)/dx", ms=ms,
+                ms_total=round(tot, 4), mpoints_per_s=round(N / tot / 1e3, 3))
+
+
 def c1_dense_rate(dev):
     """BASELINE configs[0]: single Dense level 32^3 x 4 features, 65 536 points, forward only -- the HIP kernel next to a
     pure-PyTorch trilinear sampler on the host cores (grid_sample on the [32,32,32,4] table with the LoTD coordinate
@@ -735,6 +766,7 @@ def main():
                              ("full_loop_1gpu", lambda: full_loop_rate(dev)),
                              ("forest_lotd", lambda: forest_lotd_rate(dev)),
                              ("lotd_half_params", lambda: lotd_half_rate(dev)),
+                             ("lotd_second_order", lambda: lotd_second_order_rate(dev)),
                              ("mlp_decoder", lambda: mlp_decoder_rate(dev)),
                              ("c4_mixed_lotd", c4_mixed_rate),
                              ("lotd_2p24_points", lambda: lotd_large_batch_rate(24))):
