@@ -237,9 +237,32 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 				todo &= ~m1;
 			}
 		}
-	} else if (emit) {
+	} else {
+		// Many buckets.  Spread-out points hit different counters and one LDS atomic per record is fine; samples along rays
+		// put most of a wave into ONE bucket and those atomics would serialise on one address.  So the bucket of the wave's
+		// first record is ranked through a ballot (one atomic for the whole group) when at least 8 lanes share it; whoever
+		// is left uses its own atomic.
 #pragma unroll
-		for (int m = 0; m < 4; ++m) rank[m] = atomicAdd(&hist[bkt[m]], cnt);
+		for (int m = 0; m < 4; ++m) {
+			const uint32_t bv = emit ? bkt[m] : 0xFFFFFFFFu;
+			const unsigned long long em = __ballot(emit);
+			bool done = !emit;
+			if (em) {
+				const int leader = __ffsll((long long)em) - 1;
+				const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)bv, leader);
+				const bool mine = emit && bv == v;
+				const unsigned long long m1 = __ballot(mine);
+				if (__popcll(m1) >= 8) {
+					const unsigned long long m2 = __ballot(mine && split);
+					uint32_t first = 0;
+					if ((int)lane == leader) first = atomicAdd(&hist[v], (uint32_t)(__popcll(m1) + __popcll(m2)));
+					first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+					const unsigned long long below = (1ull << lane) - 1ull;
+					if (mine) { rank[m] = first + (uint32_t)(__popcll(m1 & below) + __popcll(m2 & below)); done = true; }
+				}
+			}
+			if (!done) rank[m] = atomicAdd(&hist[bv], cnt);
+		}
 	}
 	__syncthreads();
 
