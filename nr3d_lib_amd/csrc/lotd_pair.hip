@@ -733,17 +733,50 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 			uint32_t hdr[4], bkt[4], cell[3];
 			float A[4][2], wp;
 			pair_records(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell);
-			const float wl = 1.0f - wp, wh = wp;
+			float lo[4][2], hi[4][2];
+#pragma unroll
+			for (int m = 0; m < 4; ++m)
+#pragma unroll
+				for (int f = 0; f < 2; ++f) { lo[m][f] = (1.0f - wp) * A[m][f]; hi[m][f] = wp * A[m][f]; }
+			// coherent inputs (samples along a ray sit in one cell of these coarse levels for many consecutive points): lanes
+			// that continue the previous lane's cell are summed into the head of their run, as in stage A -- otherwise all 64
+			// lanes of an LDS atomic hit the same eight addresses and serialise (full loop: 252 us for these two levels)
+			bool head = true;
+			{
+				const uint32_t ln = threadIdx.x & 63u;
+				auto prev = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); };
+				bool same = ln > 0;
+#pragma unroll
+				for (int d = 0; d < 3; ++d) same = same && (prev(cell[d]) == cell[d]);
+				same = same && (prev(1u) != 0u);
+				const unsigned long long cont = __ballot(same);
+				if (__popcll(cont) >= 16) {
+#pragma unroll
+					for (int off = 1; off < 64; off <<= 1) {
+						const unsigned long long need = (1ull << off) - 1ull;
+						const bool take = (ln + off < 64) && (((cont >> (ln + 1)) & need) == need);
+#pragma unroll
+						for (int m = 0; m < 4; ++m)
+#pragma unroll
+							for (int f = 0; f < 2; ++f) {
+								const float tl = __shfl_down(lo[m][f], off, 64), th = __shfl_down(hi[m][f], off, 64);
+								if (take) { lo[m][f] += tl; hi[m][f] += th; }
+							}
+					}
+					head = !same;
+				}
+			}
+			if (!head) return;
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
 				if (bkt[m] != b) continue;
 				const uint32_t i0 = hdr[m] & 8191u, i1 = (hdr[m] >> 13) & 8191u;
 				if (fix) {
-					atomicAdd(&acc_raw[i0], to_fix(wl * A[m][0], fx.scale)); atomicAdd(&acc_raw[kPEpb + i0], to_fix(wl * A[m][1], fx.scale));
-					atomicAdd(&acc_raw[i1], to_fix(wh * A[m][0], fx.scale)); atomicAdd(&acc_raw[kPEpb + i1], to_fix(wh * A[m][1], fx.scale));
+					atomicAdd(&acc_raw[i0], to_fix(lo[m][0], fx.scale)); atomicAdd(&acc_raw[kPEpb + i0], to_fix(lo[m][1], fx.scale));
+					atomicAdd(&acc_raw[i1], to_fix(hi[m][0], fx.scale)); atomicAdd(&acc_raw[kPEpb + i1], to_fix(hi[m][1], fx.scale));
 				} else {
-					atomicAdd(&acc[i0], (double)(wl * A[m][0])); atomicAdd(&acc[kPEpb + i0], (double)(wl * A[m][1]));
-					atomicAdd(&acc[i1], (double)(wh * A[m][0])); atomicAdd(&acc[kPEpb + i1], (double)(wh * A[m][1]));
+					atomicAdd(&acc[i0], (double)lo[m][0]); atomicAdd(&acc[kPEpb + i0], (double)lo[m][1]);
+					atomicAdd(&acc[i1], (double)hi[m][0]); atomicAdd(&acc[kPEpb + i1], (double)hi[m][1]);
 				}
 			}
 		};
