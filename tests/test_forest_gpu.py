@@ -268,10 +268,11 @@ def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest, case):
         for binned in (True, False):
             _lotd.USE_BINNED_DPARAM = binned
             dp = _lotd.lod_bwd(metas, gt, xt, pt, None, bit, need_input_grad=False, need_param_grad=True)[1]
-            assert_close(dp, ref1, name=f"dL_dparam binned={binned}", levels=m_ref)
+            tol = 1e-5 if binned else 5e-5          # fp32 atomics: arbitrary order, run-dependent rounding
+            assert_close(dp, ref1, rel=tol, name=f"dL_dparam binned={binned}", levels=m_ref)
             dp2 = _lotd.lod_bwd_bwd_input(metas, vt, gt, xt, pt, j, bit, need_dLdinput_ddLdoutput=False,
                                           need_dLdinput_dparams=True, need_dLdinput_dinput=False)[1]
-            assert_close(dp2, ref2, name=f"d(dLdx)/dparam binned={binned}", levels=m_ref)
+            assert_close(dp2, ref2, rel=tol, name=f"d(dLdx)/dparam binned={binned}", levels=m_ref)
     finally:
         _lotd.USE_BINNED_DPARAM = True
     # ray-like coherent points (the run-merging of stage A) inside one block, then crossing into its neighbour

@@ -65,7 +65,7 @@ def test_c2_gradient_mass_linearity_and_chunking(oracle, dev, monkeypatch):
     # hardware-atomic scatter (the reference's algorithm) agrees with the atomic-free path at full size
     monkeypatch.setattr(_lotd, "USE_BINNED_DPARAM", False)
     _, dp_a = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
-    assert_close(dp_a, dp.cpu().numpy(), name="atomic vs binned", levels=m_ref)
+    assert_close(dp_a, dp.cpu().numpy(), rel=5e-5, name="atomic vs binned", levels=m_ref)     # fp32 atomics: run-dependent rounding
 
 
 C4_RES = [[32, 24, 16], [64, 48, 32], [128, 96, 64], [256, 192, 128], [512, 384, 256], [1024, 768, 512],

@@ -154,15 +154,18 @@ def test_dparam_atomic_and_binned_paths_agree(oracle, dev, case):
                                                 need_dLdinput_dparams=True, need_dLdinput_dinput=False)
         finally:
             _lotd.USE_BINNED_DPARAM = True
-        assert_close(dp, ref1, name=f"dL_dparam binned={binned}", levels=m_ref)
-        assert_close(dp2, ref2, name=f"2nd dparam binned={binned}", levels=m_ref)
+        # hardware fp32 atomics add thousands of terms per entry of a small table in an arbitrary order (as the reference
+        # does): their rounding noise is a few 1e-6 of the level's largest gradient and run-dependent, so that path gets 5e-5
+        tol = 1e-5 if binned else 5e-5
+        assert_close(dp, ref1, rel=tol, name=f"dL_dparam binned={binned}", levels=m_ref)
+        assert_close(dp2, ref2, rel=tol, name=f"2nd dparam binned={binned}", levels=m_ref)
         # max_level restricts the scatter to the coarse levels
         _lotd.USE_BINNED_DPARAM = binned
         try:
             _, dp3 = _lotd.lod_bwd(m, gt, xt, pt, None, max_level=0, need_input_grad=False, need_param_grad=True)
         finally:
             _lotd.USE_BINNED_DPARAM = True
-        assert_close(dp3, oracle.lotd_bwd_dparam(m_ref, g, x, p, max_level=0, accum_double=True), name="max_level=0", levels=m_ref)
+        assert_close(dp3, oracle.lotd_bwd_dparam(m_ref, g, x, p, max_level=0, accum_double=True), rel=tol, name="max_level=0", levels=m_ref)
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "mixed", "dense_2d", "nplane"])
