@@ -285,87 +285,314 @@ template <> __device__ __forceinline__ void store_nt<__half>(__half *p, float v)
 	__builtin_nontemporal_store(__half_as_ushort(__float2half(v)), reinterpret_cast<unsigned short *>(p));
 }
 
-template <bool DYDX, typename PT>
+// V: experiments (NR3D_FWD_VARIANT); results of V = 1, 2, 3, 5 are wrong by design (timing only):
+//   1 x synthesised from the point index (no x loads)   2 outputs not stored   3 both   5 no gathers
+//   4 x through the SCALAR cache: s_load of the wave's 96 floats + v_writelane (exact results)
+//   6 a block walks kPlSub consecutive 128-point sub-chunks, x of the next one requested behind the gathers (exact)
+//   7 = 6 with the scalar-cache x of 4
+template <int V> struct PlCfg { static constexpr int SUB = (V == 6 || V == 7) ? 4 : 1; static constexpr bool SX = (V == 4 || V == 7); };
+
+// x of the wave's 32 points (96 consecutive floats from the 4-byte aligned xw) into the lanes: lane 2p and 2p + 1 get
+// point p.  Scalar loads have their own cache and return path: they neither queue in the vector L1 behind the gathers nor
+// hold the gathers of other waves up while they miss the L2.
+typedef float f32x16 __attribute__((ext_vector_type(16), aligned(4)));
+__device__ __forceinline__ void wave_x_scalar(const float *__restrict__ xw, float (&xp)[3]) {
+	const f32x16 *__restrict__ v = reinterpret_cast<const f32x16 *>(xw);
+	f32x16 r[6];
+#pragma unroll
+	for (int k = 0; k < 6; ++k) r[k] = v[k];
+	int xi[3] = {0, 0, 0};
+#pragma unroll
+	for (int k = 0; k < 96; ++k) {
+		const int sv = __builtin_amdgcn_readfirstlane(__float_as_int(r[k >> 4][k & 15]));
+		asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(xi[k % 3]) : "s"(sv), "n"(2 * (k / 3)));
+	}
+#pragma unroll
+	for (int d = 0; d < 3; ++d) xp[d] = __int_as_float(__builtin_amdgcn_mov_dpp(xi[d], 0xA0, 0xf, 0xf, true));
+}
+
+template <bool DYDX, typename PT, int V = 0>
 __global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                          int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                          const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
                                                          int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
 	constexpr int D = 3;
+	constexpr int SUB = PlCfg<V>::SUB;
 	uint32_t q, chunk;
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
-	const uint32_t i = chunk * kPlPts + (threadIdx.x >> 1);
 	const uint32_t side = threadIdx.x & 1u;
-	if (i >= N) return;                                  // both lanes of a pair leave together
 	const uint32_t level = meta_level_of(md, q);
 	const uint32_t foff0 = meta_cnt_of(md, q) * 2u;
-	float out_y = 0.0f, out_g[D] = {0.0f, 0.0f, 0.0f};
-	if ((int32_t)level <= max_level) {
-		const Lvl L = load_level(md, level);
-		const PT *__restrict__ grid = params + L.off;
-		float xp[D];
+	const bool live = (int32_t)level <= max_level;
+	const Lvl L = load_level(md, live ? level : 0u);
+	const PT *__restrict__ grid = params + L.off;
+	const bool dense = L.type == NR3D_LOD_Dense;
+	const char *__restrict__ base = reinterpret_cast<const char *>(grid + foff0);
+	const uint32_t stride = L.F * (uint32_t)sizeof(PT);
+	const uint32_t col = q * 2u + side;
+
+	auto load_x = [&](uint32_t sub, float (&xp)[D]) {
+		const uint32_t i = (chunk * SUB + sub) * kPlPts + (threadIdx.x >> 1);
+		if (V == 1 || V == 3) {
+			uint32_t h = i * 2654435761u + 12345u;
 #pragma unroll
-		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
-		Cell<D> c;
-		locate<D>(xp, L, smooth != 0, c);
-		const bool dense = L.type == NR3D_LOD_Dense;
-		float val[8];
-		float2 t[4];
-		// entry of this lane's corner m: the pair dim (Dense z, Hash x) takes `side`, the other two dims take the bits of m
-		// (Dense: bit 0 = x, bit 1 = y; Hash: bit 0 = y, bit 1 = z).  Byte offsets inside the level are 32-bit (checked on
-		// the host), the level's base address is wave-uniform.
-		uint32_t e[4];
-		if (dense) {
-			const uint32_t e00 = (c.g[0] * L.res[1] + c.g[1]) * L.res[2] + c.g[2] + side;
-			const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
-			e[0] = e00; e[1] = e00 + sx; e[2] = e00 + sy; e[3] = e00 + sx + sy;
-		} else {
-			const uint32_t hy0 = c.g[1] * kPrimes[1], hy1 = hy0 + kPrimes[1];
-			const uint32_t hz0 = c.g[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
-			const uint32_t xs = c.g[0] + side;
-			const uint32_t h[4] = {xs ^ hy0 ^ hz0, xs ^ hy1 ^ hz0, xs ^ hy0 ^ hz1, xs ^ hy1 ^ hz1};
-			if ((L.size & (L.size - 1u)) == 0u) {
+			for (int d = 0; d < D; ++d) {
+				h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+				xp[d] = (float)(h >> 8) * (1.0f / 16777216.0f);
+			}
+			return;
+		}
+		if (PlCfg<V>::SX) {
+			const uint32_t w0 = __builtin_amdgcn_readfirstlane((chunk * SUB + sub) * kPlPts + ((threadIdx.x >> 6) << 5));
+			if (w0 + 32u <= N) { wave_x_scalar(x + (size_t)w0 * D, xp); return; }
+		}
+		const uint32_t ic = i < N ? i : N - 1u;
 #pragma unroll
-				for (int m = 0; m < 4; ++m) e[m] = h[m] & (L.size - 1u);
+		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)ic * D + d];
+	};
+
+	float xp[D];
+	load_x(0, xp);
+#pragma unroll
+	for (int sub = 0; sub < SUB; ++sub) {
+		const uint32_t i = (chunk * SUB + sub) * kPlPts + (threadIdx.x >> 1);
+		float out_y = 0.0f, out_g[D] = {0.0f, 0.0f, 0.0f};
+		float xn[D] = {0.0f, 0.0f, 0.0f};
+		if (live) {
+			Cell<D> c;
+			locate<D>(xp, L, smooth != 0, c);
+			float val[8];
+			float2 t[4];
+			// entry of this lane's corner m: the pair dim (Dense z, Hash x) takes `side`, the other two dims take the bits of
+			// m (Dense: bit 0 = x, bit 1 = y; Hash: bit 0 = y, bit 1 = z).  Byte offsets inside the level are 32-bit (checked
+			// on the host), the level's base address is wave-uniform.
+			uint32_t e[4];
+			if (dense) {
+				const uint32_t e00 = (c.g[0] * L.res[1] + c.g[1]) * L.res[2] + c.g[2] + side;
+				const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
+				e[0] = e00; e[1] = e00 + sx; e[2] = e00 + sy; e[3] = e00 + sx + sy;
 			} else {
+				const uint32_t hy0 = c.g[1] * kPrimes[1], hy1 = hy0 + kPrimes[1];
+				const uint32_t hz0 = c.g[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
+				const uint32_t xs = c.g[0] + side;
+				const uint32_t h[4] = {xs ^ hy0 ^ hz0, xs ^ hy1 ^ hz0, xs ^ hy0 ^ hz1, xs ^ hy1 ^ hz1};
+				if ((L.size & (L.size - 1u)) == 0u) {
 #pragma unroll
-				for (int m = 0; m < 4; ++m) e[m] = h[m] % L.size;
+					for (int m = 0; m < 4; ++m) e[m] = h[m] & (L.size - 1u);
+				} else {
+#pragma unroll
+					for (int m = 0; m < 4; ++m) e[m] = h[m] % L.size;
+				}
+			}
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {                            // all four gathers first: four requests in flight per lane
+				if (V == 5) t[m] = make_float2(__int_as_float(e[m] | 0x3f000000u), __int_as_float(e[m] ^ 0x3f123456u));
+				else t[m] = load_pair<PT>(base + e[m] * stride);
+			}
+			if (sub + 1 < SUB) load_x(sub + 1, xn);                  // behind the gathers: loads return in order
+#pragma unroll
+			for (uint32_t m = 0; m < 4; ++m) {
+				// val[k] = corner k of feature `side`.  Even lanes (side 0) own the side-0 corner: lo = own x, hi = partner's
+				// x; odd lanes: lo = partner's y, hi = own y (DPP quad_perm 1,0,3,2 swaps the lanes of a pair; the selects
+				// fold into v_cndmask_b32_dpp)
+				const float sw_x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t[m].x), 0xB1, 0xf, 0xf, true));
+				const float sw_y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t[m].y), 0xB1, 0xf, 0xf, true));
+				const float lo = side ? sw_y : t[m].x, hi = side ? t[m].y : sw_x;
+				if (dense) { val[m] = lo; val[m | 4u] = hi; }
+				else { val[m << 1] = lo; val[(m << 1) | 1u] = hi; }
+			}
+#pragma unroll
+			for (uint32_t k = 0; k < 8; ++k) out_y = __fmaf_rn(corner_weight<D>(c, k), val[k], out_y);
+			if (DYDX) {
+#pragma unroll
+				for (int gd = 0; gd < D; ++gd)
+#pragma unroll
+					for (uint32_t k = 0; k < 8; ++k) {
+						if ((k >> gd) & 1u) continue;
+						const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
+						out_g[gd] = __fmaf_rn(w, val[k | (1u << gd)] - val[k], out_g[gd]);
+					}
 			}
 		}
-		const char *__restrict__ base = reinterpret_cast<const char *>(grid + foff0);
-		const uint32_t stride = L.F * (uint32_t)sizeof(PT);
+		const bool skip_store = (V == 2 || V == 3) && out_y + out_g[0] + out_g[1] + out_g[2] != 1234.56789f;
+		if (i < N && !skip_store) {                              // both lanes of a pair share i
+			store_nt<PT>(&y[(int64_t)i * y_sn + (int64_t)col * y_se], out_y);
+			if (DYDX) {
+				float *dst = dydx + (int64_t)i * d_sn + (int64_t)col * d_se;
 #pragma unroll
-		for (int m = 0; m < 4; ++m)                              // all four gathers first: four requests in flight per lane
-			t[m] = load_pair<PT>(base + e[m] * stride);
-#pragma unroll
-		for (uint32_t m = 0; m < 4; ++m) {
-			// val[k] = corner k of feature `side`.  Even lanes (side 0) own the side-0 corner: lo = own x, hi = partner's x;
-			// odd lanes: lo = partner's y, hi = own y (DPP quad_perm 1,0,3,2 swaps the lanes of a pair; the selects fold
-			// into v_cndmask_b32_dpp)
-			const float sw_x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t[m].x), 0xB1, 0xf, 0xf, true));
-			const float sw_y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t[m].y), 0xB1, 0xf, 0xf, true));
-			const float lo = side ? sw_y : t[m].x, hi = side ? t[m].y : sw_x;
-			if (dense) { val[m] = lo; val[m | 4u] = hi; }
-			else { val[m << 1] = lo; val[(m << 1) | 1u] = hi; }
+				for (int d = 0; d < D; ++d) __builtin_nontemporal_store(out_g[d], &dst[d]);
+			}
 		}
 #pragma unroll
-		for (uint32_t k = 0; k < 8; ++k) out_y = __fmaf_rn(corner_weight<D>(c, k), val[k], out_y);
-		if (DYDX) {
+		for (int d = 0; d < D; ++d) xp[d] = xn[d];
+	}
+}
+
+// =============================================================================================
+// Forward, two lanes per (point, pseudo level), LEAN instruction stream (round 3).
+//
+// Measured (tools/exp_fwd_variants.py, profiles/r03_fwd_variants.txt): with its gathers REMOVED, k_fwd_pairlane still takes
+// 236 of its 355 us -- ~300 VALU instructions per wave at 4 cycles each keep the SIMDs busy, the gathers only queue in
+// between.  The kernel is bound by its instruction stream, not by the L2.  This form keeps the gather pattern (4.25
+// requests per point and level) and cuts the instructions per wave to about a third:
+//  * N-linear interpolation as a tree of lerps, pair dim first: 7 (sub, fma) pairs give the value; the differences the
+//    lerps form anyway ARE the derivative's building blocks (3 + 1 more lerps) -- 25 flops for y and dy/dx instead of
+//    ~100 for the sum over 8 corner weights + 12 face weights.  Same polynomial, different association: results agree
+//    with the corner-sum form (k_fwd, the oracle) to fp32 rounding (~1e-7 relative), far inside the 1e-5 contract;
+//  * lanes exchange ONE value per corner pair (the feature the partner needs) and interpolate "own side first":
+//    b = keep + w_keep * (recv - keep) -- no lo / hi selects;
+//  * addresses as uniform 64-bit base (SGPRs) + 32-bit lane offset: no 64-bit vector multiplies for the strides, no
+//    64-bit vector adds per gather; 24-bit multiplies (full rate) where the level is small enough;
+//  * a wave walks SUB consecutive 32-point groups: the scalar preamble (schedule decode, level descriptor) and the lane
+//    constants are paid once, x of the next group is requested right behind the gathers of the current one.
+// =============================================================================================
+template <bool DYDX, typename PT, int SUB, bool NT = true>
+__global__ __launch_bounds__(kBlock) void k_fwd_pl(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                   int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                   const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
+                                                   int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se, uint32_t dbg) {
+	constexpr uint32_t kGroup = 32;                        // points per wave and sub-step
+	constexpr uint32_t kPts = kPlPts * SUB;                // points per block
+	uint32_t q, chunk;
+	if (!decode_block(s, blockIdx.x, q, chunk)) return;
+	const uint32_t lane = threadIdx.x & 63u, side = lane & 1u, pl = lane >> 1;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t w0 = chunk * kPts + wave * kGroup * SUB;      // first point of this wave
+	if (w0 >= N) return;                                   // whole wave past the end (uniform)
+	const uint32_t level = meta_level_of(md, q);
+	const uint32_t foff0 = meta_cnt_of(md, q) * 2u;
+	const bool live = (int32_t)level <= max_level;
+	const Lvl L = load_level(md, live ? level : 0u);
+	const bool dense = L.type == NR3D_LOD_Dense;
+	const char *__restrict__ base = reinterpret_cast<const char *>(params + L.off + foff0);      // wave-uniform
+	const uint32_t stride = L.F * (uint32_t)sizeof(PT);
+	const bool small = L.size < (1u << 24);               // entries and strides fit 24-bit multiplies
+	const float sc0 = (float)(L.res[0] - 2u), sc1 = (float)(L.res[1] - 2u), sc2 = (float)(L.res[2] - 2u);
+	// lane part of the output addresses (host-checked to fit 32 bits), in bytes
+	const uint32_t y_lane = (uint32_t)((int64_t)pl * y_sn + (int64_t)side * y_se) * (uint32_t)sizeof(PT);
+	const uint32_t d_lane = DYDX ? (uint32_t)((int64_t)pl * d_sn + (int64_t)side * d_se) * 4u : 0u;
+
+	// ---- phase 1: x of all SUB groups (lanes beyond N re-read the last point and store nothing)
+	float xp[SUB][3];
 #pragma unroll
-			for (int gd = 0; gd < D; ++gd)
+	for (int u = 0; u < SUB; ++u) {
+		const uint32_t g0 = w0 + (uint32_t)u * kGroup;     // uniform
+		const uint32_t gc = g0 < N ? g0 : w0;
+		const char *xb = reinterpret_cast<const char *>(x) + (size_t)gc * 12u;
+		uint32_t off = pl * 12u;
+		if (gc + kGroup > N) { const uint32_t i = gc + pl; off = ((i < N ? i : N - 1u) - gc) * 12u; }
+		const float *px = reinterpret_cast<const float *>(xb + off);
+		if (dbg & 4u) {
+			uint32_t h = (gc + pl) * 2654435761u + 12345u;
 #pragma unroll
-				for (uint32_t k = 0; k < 8; ++k) {
-					if ((k >> gd) & 1u) continue;
-					const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
-					out_g[gd] = __fmaf_rn(w, val[k | (1u << gd)] - val[k], out_g[gd]);
+			for (int d = 0; d < 3; ++d) { h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16; xp[u][d] = (float)(h >> 8) * (1.0f / 16777216.0f); }
+		} else { xp[u][0] = px[0]; xp[u][1] = px[1]; xp[u][2] = px[2]; }
+	}
+	float yv[SUB], gx[SUB], gy[SUB], gz[SUB];
+#pragma unroll
+	for (int u = 0; u < SUB; ++u) { yv[u] = 0.0f; gx[u] = 0.0f; gy[u] = 0.0f; gz[u] = 0.0f; }
+	if (live) {
+		// ---- phase 2: cells, corner offsets, ALL 4 * SUB gathers in flight
+		float2 t[SUB][4];
+		float wP[SUB], wA[SUB], wB[SUB], dwP[SUB], dwA[SUB], dwB[SUB];
+#pragma unroll
+		for (int u = 0; u < SUB; ++u) {
+			// cell locator (explicit fma: decides the integer cell, must match the oracle bit for bit)
+			const float v0 = __fmaf_rn(xp[u][0], sc0, 0.5f), v1 = __fmaf_rn(xp[u][1], sc1, 0.5f), v2 = __fmaf_rn(xp[u][2], sc2, 0.5f);
+			const float f0 = floorf(v0), f1 = floorf(v1), f2 = floorf(v2);
+			float t0 = v0 - f0, t1 = v1 - f1, t2 = v2 - f2;
+			const uint32_t c0 = (uint32_t)f0, c1 = (uint32_t)f1, c2 = (uint32_t)f2;
+			float dw0 = sc0, dw1 = sc1, dw2 = sc2;         // scale * w'
+			if (smooth) {
+				dw0 *= 6.0f * t0 * (1.0f - t0); dw1 *= 6.0f * t1 * (1.0f - t1); dw2 *= 6.0f * t2 * (1.0f - t2);
+				t0 = t0 * t0 * __fmaf_rn(-2.0f, t0, 3.0f); t1 = t1 * t1 * __fmaf_rn(-2.0f, t1, 3.0f); t2 = t2 * t2 * __fmaf_rn(-2.0f, t2, 3.0f);
+			}
+			// entries of this lane's four corners: pair dim P (Dense z, Hash x) takes `side`, bit 0 of m = dim A, bit 1 = dim B
+			uint32_t e[4], off[4];
+			if (dense) {
+				uint32_t e00;
+				if (small) e00 = __umul24(__umul24(c0, L.res[1]) + c1, L.res[2]) + c2 + side;
+				else e00 = (c0 * L.res[1] + c1) * L.res[2] + c2 + side;
+				const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];      // scalar
+				e[0] = e00; e[1] = e00 + sx; e[2] = e00 + sy; e[3] = e00 + sx + sy;
+				wP[u] = t2; wA[u] = t0; wB[u] = t1; dwP[u] = dw2; dwA[u] = dw0; dwB[u] = dw1;
+			} else {
+				const uint32_t hy0 = c1 * kPrimes[1], hy1 = hy0 + kPrimes[1];
+				const uint32_t hz0 = c2 * kPrimes[2], hz1 = hz0 + kPrimes[2];
+				const uint32_t xs = c0 + side;
+				const uint32_t a0 = xs ^ hy0, a1 = xs ^ hy1;
+				e[0] = a0 ^ hz0; e[1] = a1 ^ hz0; e[2] = a0 ^ hz1; e[3] = a1 ^ hz1;
+				if ((L.size & (L.size - 1u)) == 0u) {
+					const uint32_t mask = L.size - 1u;
+#pragma unroll
+					for (int m = 0; m < 4; ++m) e[m] &= mask;
+				} else {
+#pragma unroll
+					for (int m = 0; m < 4; ++m) e[m] %= L.size;
 				}
+				wP[u] = t0; wA[u] = t1; wB[u] = t2; dwP[u] = dw0; dwA[u] = dw1; dwB[u] = dw2;
+			}
+			if (small) {
+#pragma unroll
+				for (int m = 0; m < 4; ++m) off[m] = __umul24(e[m], stride);
+			} else {
+#pragma unroll
+				for (int m = 0; m < 4; ++m) off[m] = e[m] * stride;
+			}
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				if (dbg & 2u) t[u][m] = make_float2(__int_as_float(off[m] | 0x3f000000u), __int_as_float(off[m] ^ 0x3f123456u));
+				else t[u][m] = load_pair<PT>(base + off[m]);
+			}
+		}
+		// ---- phase 3: pair-dim lerps (the partner gets the feature it interpolates, this lane keeps its own; the true
+		// (v1 - v0) along P is sgn * d), then dims A and B
+#pragma unroll
+		for (int u = 0; u < SUB; ++u) {
+			const float wk = side ? 1.0f - wP[u] : wP[u];
+			float b[4], d[4];
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				const float keep = side ? t[u][m].y : t[u][m].x;
+				const float send = side ? t[u][m].x : t[u][m].y;
+				const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
+				d[m] = recv - keep;
+				b[m] = __fmaf_rn(wk, d[m], keep);
+			}
+			const float cA0 = b[1] - b[0], cA1 = b[3] - b[2];
+			const float dA0 = __fmaf_rn(wA[u], cA0, b[0]), dA1 = __fmaf_rn(wA[u], cA1, b[2]);
+			const float eB = dA1 - dA0;
+			yv[u] = __fmaf_rn(wB[u], eB, dA0);
+			if (DYDX) {
+				const float gB = eB;
+				const float gA = __fmaf_rn(wB[u], cA1 - cA0, cA0);
+				const float p0 = __fmaf_rn(wA[u], d[1] - d[0], d[0]), p1 = __fmaf_rn(wA[u], d[3] - d[2], d[2]);
+				const float gP = __fmaf_rn(wB[u], p1 - p0, p0);
+				const float rP = gP * (side ? -dwP[u] : dwP[u]), rA = gA * dwA[u], rB = gB * dwB[u];
+				if (dense) { gx[u] = rA; gy[u] = rB; gz[u] = rP; }
+				else { gx[u] = rP; gy[u] = rA; gz[u] = rB; }
+			}
 		}
 	}
-	const uint32_t col = q * 2u + side;
-	store_nt<PT>(&y[(int64_t)i * y_sn + (int64_t)col * y_se], out_y);
-	if (DYDX) {
-		float *dst = dydx + (int64_t)i * d_sn + (int64_t)col * d_se;
+	// ---- phase 4: stores (uniform base + 32-bit lane offset)
 #pragma unroll
-		for (int d = 0; d < D; ++d) __builtin_nontemporal_store(out_g[d], &dst[d]);
+	for (int u = 0; u < SUB; ++u) {
+		const uint32_t g0 = w0 + (uint32_t)u * kGroup;
+		if ((dbg & 1u) && yv[u] + gx[u] + gy[u] + gz[u] != 1234.56789f) continue;
+		if (g0 + pl < N) {
+			char *yb = reinterpret_cast<char *>(y) + ((int64_t)g0 * y_sn + (int64_t)(q * 2u) * y_se) * (int64_t)sizeof(PT);
+			if (NT) store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane), yv[u]);
+			else *reinterpret_cast<PT *>(yb + y_lane) = (PT)yv[u];
+			if (DYDX) {
+				char *db = reinterpret_cast<char *>(dydx) + ((int64_t)g0 * d_sn + (int64_t)(q * 2u) * d_se) * 4;
+				float *dst = reinterpret_cast<float *>(db + d_lane);
+				if (NT) {
+					__builtin_nontemporal_store(gx[u], &dst[0]);
+					__builtin_nontemporal_store(gy[u], &dst[1]);
+					__builtin_nontemporal_store(gz[u], &dst[2]);
+				} else { dst[0] = gx[u]; dst[1] = gy[u]; dst[2] = gz[u]; }
+			}
+		}
 	}
 }
 
@@ -1038,7 +1265,7 @@ static Sched make_sched(uint32_t N, const nr3d_lotd_meta_t *m, uint32_t &n_block
 				if (ch_end <= ch) ch_end = ch + 1;
 				if (nseg[x] >= (uint32_t)kSchedSegs) { ok = false; break; }
 				const uint32_t i = nseg[x]++;
-				s.seg_q[x][i] = (uint16_t)q;
+				s.seg_q[x][i] = q;
 				s.seg_begin[x][i] = ch;
 				s.seg_cum[x][i + 1] = s.seg_cum[x][i] + (uint32_t)(ch_end - ch);
 				ch = (uint32_t)ch_end;
@@ -1158,11 +1385,33 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 				                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
 		}
 	}
+	static int variant = -1;
+	if (variant < 0) { const char *e = getenv("NR3D_FWD_VARIANT"); variant = e ? atoi(e) : 0; }
+	const int v = (dy_dx && sizeof(PT) == 4) ? variant : 0;
 	uint32_t n_blocks;
-	const Sched s = make_sched(N, meta, n_blocks, staged, (uint32_t)kPlPts, true);
+	const Sched s = make_sched(N, meta, n_blocks, staged, (uint32_t)kPlPts * ((v == 6 || v == 7 || v == 10 || v == 11) ? 4u : v == 12 ? 8u : v == 9 ? 2u : 1u), true);
 	if (n_blocks != 0) {
 		prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
-		if (dy_dx)
+#define NR3D_FWD_V(V_) hipLaunchKernelGGL((k_fwd_pairlane<true, PT, V_>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level, \
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se)
+#define NR3D_FWD_PL(SUB_) hipLaunchKernelGGL((k_fwd_pl<true, PT, SUB_>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level, \
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se, dbg)
+		static int dbg = -1;
+		if (dbg < 0) { const char *e = getenv("NR3D_FWD_DBG"); dbg = e ? atoi(e) : 0; }
+		if (v == 8) NR3D_FWD_PL(1);
+		else if (v == 9) NR3D_FWD_PL(2);
+		else if (v == 10) NR3D_FWD_PL(4);
+		else if (v == 11) hipLaunchKernelGGL((k_fwd_pl<true, PT, 4, false>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se, dbg);
+		else if (v == 12) NR3D_FWD_PL(8);
+		else if (v == 1) NR3D_FWD_V(1);
+		else if (v == 2) NR3D_FWD_V(2);
+		else if (v == 3) NR3D_FWD_V(3);
+		else if (v == 4) NR3D_FWD_V(4);
+		else if (v == 5) NR3D_FWD_V(5);
+		else if (v == 6) NR3D_FWD_V(6);
+		else if (v == 7) NR3D_FWD_V(7);
+		else if (dy_dx)
 			hipLaunchKernelGGL((k_fwd_pairlane<true, PT>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
 			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
 		else

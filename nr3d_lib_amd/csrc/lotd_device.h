@@ -37,7 +37,7 @@ struct Sched {
 	uint64_t skip;                         // bit q set: pseudo level q is served by another launch (LDS-staged forward)
 	uint32_t seg_cum[8][kSchedSegs + 1];   // blocks of this XCD before segment i
 	uint32_t seg_begin[8][kSchedSegs];     // first chunk of segment i
-	uint16_t seg_q[8][kSchedSegs];         // pseudo level of segment i
+	uint32_t seg_q[8][kSchedSegs];         // pseudo level of segment i (32-bit: a scalar load; 16-bit fields go through the vector L1)
 };
 
 __device__ __forceinline__ bool decode_block_raw(const Sched &s, uint32_t b, uint32_t &q, uint32_t &chunk);
@@ -47,14 +47,17 @@ __device__ __forceinline__ bool decode_block(const Sched &s, uint32_t b, uint32_
 }
 __device__ __forceinline__ bool decode_block_raw(const Sched &s, uint32_t b, uint32_t &q, uint32_t &chunk) {
 	if (s.mode == 3) {
+		// branch-free: the XCD's row of segment starts is one wide scalar load, the segment is the number of starts <= j
+		// (a loop with an early exit compiles to one dependent scalar load + wait per segment: ~1.5k cycles before a wave's
+		// first vector instruction)
 		const uint32_t xcd = b & 7u, j = b >> 3;
-		for (int i = 0; i < kSchedSegs; ++i)
-			if (j < s.seg_cum[xcd][i + 1]) {
-				q = s.seg_q[xcd][i];
-				chunk = s.seg_begin[xcd][i] + (j - s.seg_cum[xcd][i]);
-				return true;
-			}
-		return false;
+		uint32_t idx = 0;
+#pragma unroll
+		for (int i = 1; i < kSchedSegs; ++i) idx += (j >= s.seg_cum[xcd][i]) ? 1u : 0u;
+		if (j >= s.seg_cum[xcd][kSchedSegs]) return false;
+		q = s.seg_q[xcd][idx];
+		chunk = s.seg_begin[xcd][idx] + (j - s.seg_cum[xcd][idx]);
+		return true;
 	} else if (s.mode == 1) {
 		const uint32_t xcd = b & 7u, j = b >> 3;
 		const uint32_t slot = j / s.n_chunks;

@@ -1,0 +1,56 @@
+"""forward-kernel experiments (k_fwd_pairlane<true, float, V>, NR3D_FWD_VARIANT): one subprocess per variant, the
+kernel's HIP-event time over 20 launches at 2^20 (and 2^22) points + a digest of y / dy_dx (exact variants must match V0)"""
+import os, sys, subprocess, json, hashlib
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+def child(log2n):
+    import torch
+    from nr3d_lib_amd import _hip as H
+    from nr3d_lib_amd.bindings import _lotd
+    from nr3d_lib_amd.models.grid_encodings.lotd import gen_ngp_cfg
+    dev = torch.device("cuda", 0)
+    cfg = gen_ngp_cfg()
+    meta = _lotd.LoDMeta(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], cfg["hashmap_size"])
+    N = (1 << log2n) if log2n < 64 else log2n
+    gen = torch.Generator(device="cpu").manual_seed(42)
+    params = torch.empty(meta.n_params).uniform_(-1e-2, 1e-2, generator=gen).to(dev)
+    x = torch.rand(N, 3, generator=gen).clamp_(1e-6, 1 - 1e-6).to(dev)
+    for _ in range(3):
+        y, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
+    torch.cuda.synchronize()
+    names = ("lotd_fwd", "lotd_fwd_lds")
+    for k in names: H.prof_read(k)
+    H.prof_enable(*names)
+    iters = 20
+    for _ in range(iters):
+        y, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
+    torch.cuda.synchronize()
+    H.prof_enable()
+    us = {k: H.prof_read(k)[0] / iters * 1e3 for k in names}
+    dig = hashlib.sha256(y.contiguous().cpu().numpy().tobytes() + j.contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
+    v = os.environ.get("NR3D_FWD_VARIANT", "0")
+    err = None
+    if log2n == 20:
+        ref = f"/tmp/exp_fwd_ref_{log2n}.pt"
+        if v == "0":
+            torch.save((y.cpu(), j.cpu()), ref)
+        elif os.path.exists(ref):
+            y0, j0 = torch.load(ref)
+            err = (float(((y.cpu() - y0).abs().amax(0) / y0.abs().amax(0)).max()),
+                   float(((j.cpu() - j0).abs().amax((0, 2)) / j0.abs().amax((0, 2))).max()))
+    print(json.dumps(dict(us_pairlane=round(us["lotd_fwd"], 1), us_lds=round(us["lotd_fwd_lds"], 1), digest=dig,
+                          max_rel_err_vs_v0=err)))
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "child":
+        child(int(sys.argv[2])); sys.exit(0)
+    variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1", "2", "3", "4", "5", "6", "7"]
+    sizes = [int(s) for s in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["20", "22"])]
+    extra_env = dict(kv.split("=") for kv in sys.argv[3:])
+    for n in sizes:
+        for v in variants:
+            env = dict(os.environ, NR3D_FWD_VARIANT=v, **extra_env)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(n)], env=env, capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            print(f"2^{n} V{v} {extra_env}: {line[-1] if line else r.stderr[-300:]}", flush=True)
