@@ -56,7 +56,7 @@ def kernel_algorithmic_bytes(kernel, n_levels_served, F=2, D=3, C=8):
 
 
 # timers of include/nr3d_hip.h (NR3D_PROF_*) -> kernel names as rocprofv3 prints them (the default configuration)
-PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true, float>", "lotd_fwd_lds": "k_fwd_lds<true, float>",
+PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true, float, 2>", "lotd_fwd_lds": "k_fwd_lds<true, float>",
                 "lotd_contract_dx": "k_contract_dx_rowmajor<3, float>", "lotd_bin": "k_pair_bin<1024>",
                 "lotd_accum": "k_pair_accum<4, true>", "lotd_direct": "k_pair_direct<true>"}
 LIVE_TIMER = "lotd_fwd"      # the dominant kernel: timed inside the timed region (2 events per step); the rest in an extra pass
@@ -203,9 +203,11 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
         pil = pi.long()
         # the two launches behind graphics.pack_ops.packed_composite and its autograd backward, called directly (at 4096
         # rays the op is launch bound: no autograd graph bookkeeping inside the timed loop)
-        vw, mask, depth, rgb = _pack_ops.packed_composite_forward(alpha, tmid, state["rgb"], pil, state["hit"], n, 1e-4, 0.0, True)
+        vw, mask, depth, rgb = _pack_ops.packed_composite_forward(alpha, tmid, state["rgb"], pil, state["hit"], n, 1e-4, 0.0, True,
+                                                                  packs_tile=True)     # a marcher's packs cover every sample
         ga, gt, gc = _pack_ops.packed_composite_backward(alpha, vw, tmid, state["rgb"], pil, state["hit"], 1e-4, 0.0, True,
-                                                         mask, depth, state["g"][0], state["g"][1], state["g"][2], None)
+                                                         mask, depth, state["g"][0], state["g"][1], state["g"][2], None,
+                                                         packs_tile=True)
         return S, mask, ga
     for _ in range(3):               # the caching allocator reaches its steady state
         S = one()[0]

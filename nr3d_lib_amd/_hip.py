@@ -57,6 +57,36 @@ def lib():
     return _lib
 
 
+# ---- debug hook: poison every uninitialised output -----------------------------------------------------------------
+# The bindings allocate outputs the kernels are documented to write completely (include/nr3d_hip.h: "fully written")
+# with empty().  With NR3D_POISON_EMPTY=1 (the whole `-m gpu` test run sets it, tests/conftest.py) such a buffer is
+# filled with NaN / 0xAB bytes before the launch, so an element a kernel forgets shows up in the parity tests instead of
+# passing on allocator-reuse luck (a fresh block from the caching allocator is often zero).
+POISON = os.environ.get("NR3D_POISON_EMPTY", "0") == "1"
+
+
+def _poison(t):
+    if t.numel() == 0:
+        return t
+    if t.dtype.is_floating_point:
+        t.fill_(float("nan"))
+    elif t.dtype == torch.bool:
+        t.fill_(True)
+    else:
+        t.fill_(-0x54545455 if t.dtype in (torch.int32, torch.int64) else 0x2B)     # 0xABABABAB as int32
+    return t
+
+
+def empty(*args, **kwargs):
+    t = torch.empty(*args, **kwargs)
+    return _poison(t) if POISON else t
+
+
+def empty_like(x, **kwargs):
+    t = torch.empty_like(x, **kwargs)
+    return _poison(t) if POISON else t
+
+
 def check(rc):
     if rc != 0:
         raise RuntimeError(lib().nr3d_last_error().decode())

@@ -73,7 +73,7 @@ def forest_identify(forest: ForestMeta, ks: torch.Tensor) -> torch.Tensor:
     forest._check("forest_identify", ks)
     H.require_gpu(ks)
     k16 = ks.reshape(-1, 3).to(torch.int16).contiguous()
-    out = torch.empty(k16.shape[0], dtype=torch.int32, device=ks.device)
+    out = H.empty(k16.shape[0], dtype=torch.int32, device=ks.device)
     with torch.cuda.device(ks.device):
         c = forest._c()
         H.check(H.lib().nr3d_forest_identify(C.byref(c), C.c_uint64(k16.shape[0]), H.ptr(k16), H.ptr(out), H.stream_of(ks)))
@@ -114,7 +114,7 @@ def _workspace(m, fo, N, dev):
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
         _workspaces.pop(key, None)
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = H.empty(need, dtype=torch.uint8, device=dev)
         _workspaces[key] = ws
     return ws, need
 
@@ -131,14 +131,14 @@ def lod_fwd(metas, input, params, batch_inds=None, batch_offsets=None, batch_dat
     x32, p32 = _lotd._f32c(input.detach()), _lotd._f32c(params.detach())
     with torch.cuda.device(dev):
         # feature-major storage behind [N, E] / [N, E, 3] views, like the single-block path: coalesced stores
-        y = torch.empty((E, N), dtype=torch.float32, device=dev).t()
+        y = H.empty((E, N), dtype=torch.float32, device=dev).t()
         dy_dx, dsn, dse = None, 0, 0
         if need_input_grad:
             if m.c_permute_dydx:
-                dy_dx = torch.empty((E, N, 3), dtype=torch.float32, device=dev).permute(1, 0, 2)
+                dy_dx = H.empty((E, N, 3), dtype=torch.float32, device=dev).permute(1, 0, 2)
                 dsn, dse = dy_dx.stride(0), dy_dx.stride(1)
             else:
-                dy_dx, dsn, dse = torch.empty((N, E * 3), dtype=torch.float32, device=dev), E * 3, 3
+                dy_dx, dsn, dse = H.empty((N, E * 3), dtype=torch.float32, device=dev), E * 3, 3
         c = fo._c()
         H.check(H.lib().nr3d_lotd_forest_fwd(
             C.byref(m._cmeta()), H.ptr(m._dev(dev)), C.byref(c), H.u32(N), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),

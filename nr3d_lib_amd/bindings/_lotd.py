@@ -232,7 +232,7 @@ def _dparam_workspace(meta, n_points, device, n_batches=1):
     if ws is None or ws.numel() < need:
         ws = None
         _workspaces.pop(key, None)
-        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        ws = H.empty(need, dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws, need
 
@@ -313,15 +313,15 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
     pcode = H.F16 if native else H.F32
     dev = input.device
     with torch.cuda.device(dev):
-        y_store = torch.empty((E, N), dtype=torch.float16 if native else torch.float32, device=dev)
+        y_store = H.empty((E, N), dtype=torch.float16 if native else torch.float32, device=dev)
         y = y_store.t()
         dy_dx = None
         if need_input_grad:
             if m.c_permute_dydx:
-                dy_dx = torch.empty((E, N, D), dtype=torch.float32, device=dev).permute(1, 0, 2)
+                dy_dx = H.empty((E, N, D), dtype=torch.float32, device=dev).permute(1, 0, 2)
                 dsn, dse = dy_dx.stride(0), dy_dx.stride(1)
             else:
-                dy_dx = torch.empty((N, E * D), dtype=torch.float32, device=dev)
+                dy_dx = H.empty((N, E * D), dtype=torch.float32, device=dev)
                 dsn, dse = E * D, D
         else:
             dsn = dse = 0
@@ -382,9 +382,9 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                  and (native or params.dtype == torch.float32) and params.shape[0] == m.n_params
                  and bool(H.lib().nr3d_lotd_pair_path_ok(C.byref(m._cmeta()))))
         if need_input_grad:       # fully written by the dL/dx kernel
-            dL_dx = (torch.zeros if nothing else torch.empty)((N, D), dtype=torch.float32, device=dev)
+            dL_dx = (torch.zeros if nothing else H.empty)((N, D), dtype=torch.float32, device=dev)
         if need_param_grad:
-            dL_dparam = (torch.empty if typed else torch.zeros)((params.shape[0],), dtype=torch.float16 if native else torch.float32,
+            dL_dparam = (H.empty if typed else torch.zeros)((params.shape[0],), dtype=torch.float16 if native else torch.float32,
                                                                 device=dev)
         if nothing:
             if need_param_grad and level_buckets is not None and on_bucket is not None:
@@ -417,7 +417,7 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                 # copy the atomic-free parameter scatter reads (saves that path's own transposition pass)
                 if (need_param_grad and not batched and USE_BINNED_DPARAM and gse == 1 and gsn == E
                         and g32.data_ptr() % 16 == 0):
-                    gT = torch.empty((E, N), dtype=torch.float32, device=dev)
+                    gT = H.empty((E, N), dtype=torch.float32, device=dev)
                 H.check(H.lib().nr3d_lotd_bwd_dx(
                     C.byref(m._cmeta()), H.u32(N), C.c_int(H.F32), C.c_int(gcode), H.ptr(g32), H.i64(gsn),
                     H.i64(gse), H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), H.ptr(gT), st))
@@ -527,7 +527,7 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
                 f = H.lib().nr3d_lotd_bwd_bwd_dx_workspace_bytes
                 f.restype = C.c_uint64
                 wsb = int(f(cm, H.u32(N)))
-                ws = (torch.empty((wsb + 3) // 4, dtype=torch.float32, device=dev)
+                ws = (H.empty((wsb + 3) // 4, dtype=torch.float32, device=dev)
                       if 0 < wsb <= HVP_WORKSPACE_MAX_BYTES else None)
                 H.check(H.lib().nr3d_lotd_bwd_bwd_dx_ws(
                     cm, md, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(g32), H.i64(gsn),

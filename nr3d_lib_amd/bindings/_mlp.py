@@ -63,7 +63,7 @@ def pack(desc: MLPDesc, weights, biases, with_backward=False) -> torch.Tensor:
             raise RuntimeError(f"mlp.pack: weights[{l}] has shape {list(w.shape)}, expected {[desc.dims[l + 1], desc.dims[l]]}")
     if with_backward and not desc.backward_fusable:
         raise RuntimeError("mlp.pack: the fused backward does not apply to this network")
-    packed = torch.empty(desc.packed_floats + (desc.backward_floats if with_backward else 0), dtype=torch.float32, device=dev)
+    packed = H.empty(desc.packed_floats + (desc.backward_floats if with_backward else 0), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         H.check(H.lib().nr3d_mlp_pack(C.byref(desc._c), _ptr_array(ws), _ptr_array(bs), H.ptr(packed), C.c_int(int(with_backward)),
                                       H.stream_of(packed)))
@@ -88,7 +88,7 @@ def forward(desc: MLPDesc, x: torch.Tensor, packed: torch.Tensor) -> torch.Tenso
         raise RuntimeError(f"mlp.forward: expected fp32 input with {desc.dims[0]} features, got {x.dtype} {list(x.shape)}")
     x2, xs, xf = _layout(x.reshape(-1, x.shape[-1]))
     n = x2.shape[0]
-    y = torch.empty((n, desc.dims[-1]), dtype=torch.float32, device=x.device)
+    y = H.empty((n, desc.dims[-1]), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         H.check(H.lib().nr3d_mlp_forward(C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(xs), H.i64(xf),
                                          H.ptr(packed), H.ptr(y), H.i64(y.shape[1]), H.stream_of(x)))
@@ -113,9 +113,9 @@ def backward(desc: MLPDesc, x: torch.Tensor, dL_dy: torch.Tensor, packed: torch.
     dbs = [torch.zeros(desc.dims[l + 1], dtype=torch.float32, device=dev) if has_bias[l] else None for l in range(n_layers)]
     dx, gxs, gxf = None, desc.dims[0], 1
     if need_dx and xf != 1:
-        dx, gxs, gxf = torch.empty((desc.dims[0], n), dtype=torch.float32, device=dev).t(), 1, n
+        dx, gxs, gxf = H.empty((desc.dims[0], n), dtype=torch.float32, device=dev).t(), 1, n
     elif need_dx:
-        dx = torch.empty((n, desc.dims[0]), dtype=torch.float32, device=dev)
+        dx = H.empty((n, desc.dims[0]), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         H.check(H.lib().nr3d_mlp_backward(
             C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(xs), H.i64(xf), H.ptr(g2),

@@ -74,13 +74,13 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
     ctype = C.c_int(int(contraction_type))
     with torch.cuda.device(dev):
         st = H.stream_of(rays_o)
-        packed_info = torch.empty((n, 2), dtype=torch.int32, device=dev)
-        total = torch.empty(1, dtype=torch.int64, device=dev)
+        packed_info = H.empty((n, 2), dtype=torch.int32, device=dev)
+        total = H.empty(1, dtype=torch.int64, device=dev)
         nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(n, 1))))
-        tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        tmp = H.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
         # sample cache: the count pass keeps every sample, the emit pass only compacts (no second march)
         cache_bytes = n * int(max_steps) * 12
-        cache = (torch.empty((cache_bytes + 3) // 4, dtype=torch.int32, device=dev)
+        cache = (H.empty((cache_bytes + 3) // 4, dtype=torch.int32, device=dev)
                  if 0 < cache_bytes <= SAMPLE_CACHE_MAX_BYTES else None)
         H.check(H.lib().nr3d_ray_marching_count(
             H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
@@ -88,11 +88,11 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
             H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(total), H.ptr(tmp), H.ptr(cache),
             C.c_uint64(cache_bytes if cache is not None else 0), st))
         S = int(total.item())          # the single device->host sync of this op
-        t_starts = torch.empty((S, 1), dtype=torch.float32, device=dev)
-        t_ends = torch.empty((S, 1), dtype=torch.float32, device=dev)
-        ridx = torch.empty(S, dtype=torch.int32, device=dev)
-        bidx = torch.empty(S, dtype=torch.int32, device=dev) if batched else None
-        gidx = torch.empty(S, dtype=torch.int32, device=dev) if return_gidx else None
+        t_starts = H.empty((S, 1), dtype=torch.float32, device=dev)
+        t_ends = H.empty((S, 1), dtype=torch.float32, device=dev)
+        ridx = H.empty(S, dtype=torch.int32, device=dev)
+        bidx = H.empty(S, dtype=torch.int32, device=dev) if batched else None
+        gidx = H.empty(S, dtype=torch.int32, device=dev) if return_gidx else None
         if S > 0:
             H.check(H.lib().nr3d_ray_marching_emit(
                 H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res,
@@ -149,21 +149,21 @@ def forest_ray_marching(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, se
     with torch.cuda.device(dev):
         st = H.stream_of(rays_o)
         fc = forest._c()
-        packed_info = torch.empty((n, 2), dtype=torch.int32, device=dev)
-        total = torch.empty(1, dtype=torch.int64, device=dev)
+        packed_info = H.empty((n, 2), dtype=torch.int32, device=dev)
+        total = H.empty(1, dtype=torch.int64, device=dev)
         nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(n, 1))))
-        tmp = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        tmp = H.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
         common = (H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(seg_block_inds), H.ptr(seg_entries),
                   H.ptr(seg_exits), H.ptr(seg_pack_infos), res, H.ptr(grid_binary), H.f32(step_size),
                   H.f32(max_step_size), H.f32(dt_gamma))
         H.check(H.lib().nr3d_forest_ray_marching_count(C.byref(fc), H.u32(n), *common, H.u32(max_steps),
                                                        H.ptr(packed_info), H.ptr(total), H.ptr(tmp), st))
         S = int(total.item())          # the single device->host sync of this op
-        t_starts = torch.empty((S, 1), dtype=torch.float32, device=dev)
-        t_ends = torch.empty((S, 1), dtype=torch.float32, device=dev)
-        ridx = torch.empty(S, dtype=torch.int32, device=dev)
-        blidx = torch.empty(S, dtype=torch.int32, device=dev)
-        gidx = torch.empty(S, dtype=torch.int32, device=dev) if return_gidx else None
+        t_starts = H.empty((S, 1), dtype=torch.float32, device=dev)
+        t_ends = H.empty((S, 1), dtype=torch.float32, device=dev)
+        ridx = H.empty(S, dtype=torch.int32, device=dev)
+        blidx = H.empty(S, dtype=torch.int32, device=dev)
+        gidx = H.empty(S, dtype=torch.int32, device=dev) if return_gidx else None
         if S > 0:
             H.check(H.lib().nr3d_forest_ray_marching_emit(C.byref(fc), H.u32(n), *common, H.ptr(packed_info),
                                                           H.ptr(t_starts), H.ptr(t_ends), H.ptr(ridx), H.ptr(blidx),

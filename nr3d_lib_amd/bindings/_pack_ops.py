@@ -60,15 +60,15 @@ def _code(t):
 
 def _scan_tmp(n, device):
     nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(int(n), 1))))
-    return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
+    return H.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
 
 
 def _pack_infos_from_n(n_per_pack):
     """device-side exclusive scan -> (pack_infos int64 [P,2], total python int): ONE readback."""
     P = n_per_pack.shape[0]
     dev = n_per_pack.device
-    pi = torch.empty((P, 2), dtype=torch.int64, device=dev)
-    total = torch.empty(1, dtype=torch.int64, device=dev)
+    pi = H.empty((P, 2), dtype=torch.int64, device=dev)
+    total = H.empty(1, dtype=torch.int64, device=dev)
     tmp = _scan_tmp(P, dev)
     H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(n_per_pack), H.ptr(pi), H.ptr(total), H.ptr(tmp),
                                            H.stream_of(n_per_pack)))
@@ -84,8 +84,8 @@ def interleave_arange(stop, return_idx):
     H.require_gpu(stop)
     with torch.cuda.device(stop.device):
         pi, num = _pack_infos_from_n(stop)
-        out = torch.empty(num, dtype=torch.int64, device=stop.device)
-        nidx = torch.empty(num, dtype=torch.int64, device=stop.device) if return_idx else None
+        out = H.empty(num, dtype=torch.int64, device=stop.device)
+        nidx = H.empty(num, dtype=torch.int64, device=stop.device) if return_idx else None
         H.check(H.lib().nr3d_interleave_linstep(H.u32(stop.shape[0]), C.c_int(H.I64), H.ptr(pi), None, None,
                                                 C.c_double(0), C.c_double(1), H.ptr(out), H.ptr(nidx),
                                                 H.stream_of(stop)))
@@ -111,8 +111,8 @@ def interleave_linstep(start, num_steps, step_size, return_idx):
         step_s = float(step_size)
     with torch.cuda.device(start.device):
         pi, num = _pack_infos_from_n(num_steps)
-        out = torch.empty(num, dtype=start.dtype, device=start.device)
-        nidx = torch.empty(num, dtype=torch.int64, device=start.device) if return_idx else None
+        out = H.empty(num, dtype=start.dtype, device=start.device)
+        nidx = H.empty(num, dtype=torch.int64, device=start.device) if return_idx else None
         H.check(H.lib().nr3d_interleave_linstep(H.u32(start.shape[0]), _code(start), H.ptr(pi), H.ptr(start),
                                                 H.ptr(steps_t), C.c_double(0), C.c_double(step_s), H.ptr(out),
                                                 H.ptr(nidx), H.stream_of(start)))
@@ -134,14 +134,14 @@ def interleave_sample_step_wrt_depth_clamped(near, far, max_steps, dt_gamma, min
     _chk_near_far("interleave_sample_step_wrt_depth_clamped", near, far)
     P, dev = near.shape[0], near.device
     with torch.cuda.device(dev):
-        n = torch.empty(P, dtype=torch.int64, device=dev)
+        n = H.empty(P, dtype=torch.int64, device=dev)
         st = H.stream_of(near)
         H.check(H.lib().nr3d_sample_step_count(H.u32(P), H.ptr(near), H.ptr(far), H.u32(max_steps), H.f32(dt_gamma),
                                                H.f32(min_step_size), H.f32(max_step_size), H.ptr(n), st))
         pi, num = _pack_infos_from_n(n)
-        t = torch.empty(num, dtype=near.dtype, device=dev)
-        dt = torch.empty(num, dtype=near.dtype, device=dev)
-        nidx = torch.empty(num, dtype=torch.int64, device=dev)
+        t = H.empty(num, dtype=near.dtype, device=dev)
+        dt = H.empty(num, dtype=near.dtype, device=dev)
+        nidx = H.empty(num, dtype=torch.int64, device=dev)
         H.check(H.lib().nr3d_sample_step_emit(H.u32(P), H.ptr(near), H.ptr(pi), H.f32(dt_gamma), H.f32(min_step_size),
                                               H.f32(max_step_size), H.ptr(t), H.ptr(dt), H.ptr(nidx), st))
     return t, dt, nidx, pi
@@ -164,16 +164,16 @@ def interleave_sample_step_wrt_depth_in_packed_segments(near, far, entry, exit, 
         raise RuntimeError(f"{fn}: Expected seg_pack_infos of size [{near.shape[0]}, 2]")
     P, dev = near.shape[0], near.device
     with torch.cuda.device(dev):
-        n = torch.empty(P, dtype=torch.int64, device=dev)
+        n = H.empty(P, dtype=torch.int64, device=dev)
         st = H.stream_of(near)
         common = (H.u32(P), H.ptr(near), H.ptr(far), H.ptr(entry), H.ptr(exit), H.ptr(seg_pack_infos),
                   H.u32(max_steps), H.f32(dt_gamma), H.f32(min_step_size), H.f32(max_step_size))
         H.check(H.lib().nr3d_sample_step_segments(*common, C.c_int(0), H.ptr(n), None, None, None, None, None, st))
         pi, num = _pack_infos_from_n(n)
-        t = torch.empty(num, dtype=near.dtype, device=dev)
-        dt = torch.empty(num, dtype=near.dtype, device=dev)
-        nidx = torch.empty(num, dtype=torch.int64, device=dev)
-        sidx = torch.empty(num, dtype=torch.int64, device=dev)
+        t = H.empty(num, dtype=near.dtype, device=dev)
+        dt = H.empty(num, dtype=near.dtype, device=dev)
+        nidx = H.empty(num, dtype=torch.int64, device=dev)
+        sidx = H.empty(num, dtype=torch.int64, device=dev)
         H.check(H.lib().nr3d_sample_step_segments(*common, C.c_int(1), None, H.ptr(pi), H.ptr(t), H.ptr(dt),
                                                   H.ptr(nidx), H.ptr(sidx), st))
     return t, dt, sidx, nidx, pi
@@ -387,16 +387,16 @@ def packed_alpha_to_vw_forward(alphas, pack_infos, early_stop_eps, alpha_thre, c
         st = H.stream_of(alphas)
         if compression:
             num = torch.zeros(P, dtype=torch.int64, device=dev)
-            sel = torch.empty(S, dtype=torch.bool, device=dev)
+            sel = H.empty(S, dtype=torch.bool, device=dev)
             H.check(H.lib().nr3d_alpha_to_vw_forward(H.u32(P), C.c_uint64(S), H.ptr(alphas), H.ptr(pack_infos),
                                                      H.f32(early_stop_eps), H.f32(alpha_thre), None, H.ptr(num),
                                                      H.ptr(sel), st))
-            cpi = torch.empty((P, 2), dtype=torch.int64, device=dev)
-            total = torch.empty(1, dtype=torch.int64, device=dev)
+            cpi = H.empty((P, 2), dtype=torch.int64, device=dev)
+            total = H.empty(1, dtype=torch.int64, device=dev)
             H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(num), H.ptr(cpi), H.ptr(total),
                                                    H.ptr(_scan_tmp(P, dev)), st))
             return None, cpi, sel
-        w = torch.empty(S, dtype=alphas.dtype, device=dev)
+        w = H.empty(S, dtype=alphas.dtype, device=dev)
         H.check(H.lib().nr3d_alpha_to_vw_forward(H.u32(P), C.c_uint64(S), H.ptr(alphas), H.ptr(pack_infos),
                                                  H.f32(early_stop_eps), H.f32(alpha_thre), H.ptr(w), None, None, st))
     return w, None, None
@@ -412,7 +412,7 @@ def packed_alpha_to_vw_backward(weights, grad_weights, alphas, pack_infos, early
     if weights.dtype != torch.float32:
         raise RuntimeError(f"{fn}: float32 only on this platform")
     with torch.cuda.device(weights.device):
-        g = torch.empty_like(alphas)
+        g = H.empty_like(alphas)
         H.check(H.lib().nr3d_alpha_to_vw_backward(H.u32(pack_infos.shape[0]), C.c_uint64(weights.shape[0]),
                                                   H.ptr(alphas), H.ptr(weights), H.ptr(grad_weights), H.ptr(pack_infos),
                                                   H.f32(early_stop_eps), H.f32(alpha_thre), H.ptr(g),
@@ -431,9 +431,12 @@ def _f32_1d(fn, name, t, n, inner=None):
 
 
 def packed_composite_forward(alphas, t, rgb, pack_infos, rays_inds_hit, num_rays, early_stop_eps, alpha_thre,
-                             normalize_depth):
+                             normalize_depth, packs_tile=False):
     """alphas, t [S]; rgb [S,3] | None; pack_infos int64 [P,2]; rays_inds_hit int64 [P] | None (then num_rays == P).
-    -> (vw [S], mask [num_rays], depth [num_rays], rgb_out [num_rays,3] | None); rays that are not hit keep zeros"""
+    -> (vw [S], mask [num_rays], depth [num_rays], rgb_out [num_rays,3] | None); rays that are not hit keep zeros.
+    The kernels write the samples that belong to a pack; samples outside every pack read zero like the reference ops'
+    at::zeros outputs -- unless the caller states ``packs_tile`` (the packs cover [0, S) exactly, as a marcher's or a
+    compaction's do), which saves the zero-fill."""
     fn = "packed_composite_forward"
     _chk_feats(fn, alphas, pack_infos, dims=(1,))
     P, S, dev = pack_infos.shape[0], alphas.shape[0], alphas.device
@@ -447,13 +450,13 @@ def packed_composite_forward(alphas, t, rgb, pack_infos, rays_inds_hit, num_rays
     elif int(num_rays) != P:
         raise RuntimeError(f"{fn}: num_rays must equal the number of packs when rays_inds_hit is None")
     with torch.cuda.device(dev):
-        vw = torch.empty(S, dtype=torch.float32, device=dev)
+        vw = (H.empty if (packs_tile and P > 0) else torch.zeros)(S, dtype=torch.float32, device=dev)
         mask = torch.zeros(int(num_rays), dtype=torch.float32, device=dev) if rays_inds_hit is not None else \
-            torch.empty(P, dtype=torch.float32, device=dev)
-        depth = torch.zeros_like(mask) if rays_inds_hit is not None else torch.empty_like(mask)
+            H.empty(P, dtype=torch.float32, device=dev)
+        depth = torch.zeros_like(mask) if rays_inds_hit is not None else H.empty_like(mask)
         rgb_out = None
         if rgb is not None:
-            rgb_out = (torch.zeros if rays_inds_hit is not None else torch.empty)((int(num_rays), 3), dtype=torch.float32, device=dev)
+            rgb_out = (torch.zeros if rays_inds_hit is not None else H.empty)((int(num_rays), 3), dtype=torch.float32, device=dev)
         H.check(H.lib().nr3d_pack_composite_fwd(H.u32(P), H.ptr(alphas), H.ptr(t), H.ptr(rgb), H.ptr(pack_infos),
                                                 H.ptr(rays_inds_hit), H.f32(early_stop_eps), H.f32(alpha_thre),
                                                 C.c_int(1 if normalize_depth else 0), H.ptr(vw), H.ptr(mask), H.ptr(depth),
@@ -462,8 +465,9 @@ def packed_composite_forward(alphas, t, rgb, pack_infos, rays_inds_hit, num_rays
 
 
 def packed_composite_backward(alphas, vw, t, rgb, pack_infos, rays_inds_hit, early_stop_eps, alpha_thre, normalize_depth,
-                              mask, depth, g_mask, g_depth, g_rgb, g_vw, need_t=True, need_rgb=True):
-    """-> (grad_alphas [S], grad_t [S] | None, grad_rgb [S,3] | None); g_* may be None (zero)"""
+                              mask, depth, g_mask, g_depth, g_rgb, g_vw, need_t=True, need_rgb=True, packs_tile=False):
+    """-> (grad_alphas [S], grad_t [S] | None, grad_rgb [S,3] | None); g_* may be None (zero); ``packs_tile`` as in the
+    forward (gradients of samples outside every pack are zero otherwise)"""
     fn = "packed_composite_backward"
     _chk_feats(fn, alphas, pack_infos, dims=(1,))
     P, S, dev = pack_infos.shape[0], alphas.shape[0], alphas.device
@@ -477,9 +481,10 @@ def packed_composite_backward(alphas, vw, t, rgb, pack_infos, rays_inds_hit, ear
         if tt is not None:
             _f32_1d(fn, name, tt, n_out, inner)
     with torch.cuda.device(dev):
-        ga = torch.empty(S, dtype=torch.float32, device=dev)
-        gt = torch.empty(S, dtype=torch.float32, device=dev) if need_t else None
-        gr = torch.empty((S, 3), dtype=torch.float32, device=dev) if (need_rgb and rgb is not None) else None
+        alloc = H.empty if (packs_tile and P > 0) else torch.zeros
+        ga = alloc(S, dtype=torch.float32, device=dev)
+        gt = alloc(S, dtype=torch.float32, device=dev) if need_t else None
+        gr = alloc((S, 3), dtype=torch.float32, device=dev) if (need_rgb and rgb is not None) else None
         H.check(H.lib().nr3d_pack_composite_bwd(H.u32(P), H.ptr(alphas), H.ptr(vw), H.ptr(t), H.ptr(rgb), H.ptr(pack_infos),
                                                 H.ptr(rays_inds_hit), H.f32(early_stop_eps), H.f32(alpha_thre),
                                                 C.c_int(1 if normalize_depth else 0), H.ptr(mask), H.ptr(depth), H.ptr(g_mask),
@@ -499,7 +504,7 @@ def mark_pack_boundaries_cuda(pack_ids):
                            "Long, Short")
     H.require_gpu(pack_ids)
     with torch.cuda.device(pack_ids.device):
-        b = torch.empty(pack_ids.shape[0], dtype=torch.int32, device=pack_ids.device)
+        b = H.empty(pack_ids.shape[0], dtype=torch.int32, device=pack_ids.device)
         H.check(H.lib().nr3d_mark_pack_boundaries(C.c_uint64(pack_ids.shape[0]), _code(pack_ids), H.ptr(pack_ids),
                                                   H.ptr(b), H.stream_of(pack_ids)))
     return b

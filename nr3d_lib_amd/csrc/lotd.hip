@@ -266,8 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 // So lanes 2i and 2i + 1 share point i: lane s gathers the 4 corners with x-bit s (Dense: z-bit s, adjacent entries), the
 // pair's two 8-byte loads travel in the same instruction and leave the CU as ONE request.  4.25 requests per (point,
 // Hash level) instead of 6 (paired 16-byte loads work for even x only), 4 for Dense as before.  The lanes then swap
-// features through DPP (quad_perm 1,0,3,2): lane s ends up with all 8 corners of feature s and interpolates it with
-// exactly k_fwd's arithmetic, so the outputs are bit-identical to k_fwd's.
+// features through DPP (quad_perm 1,0,3,2): lane s ends up with all 8 corners of feature s and interpolates it.
 // =============================================================================================
 constexpr int kPlPts = kBlock / 2;                 // points per block
 
@@ -285,169 +284,36 @@ template <> __device__ __forceinline__ void store_nt<__half>(__half *p, float v)
 	__builtin_nontemporal_store(__half_as_ushort(__float2half(v)), reinterpret_cast<unsigned short *>(p));
 }
 
-// V: experiments (NR3D_FWD_VARIANT); results of V = 1, 2, 3, 5 are wrong by design (timing only):
-//   1 x synthesised from the point index (no x loads)   2 outputs not stored   3 both   5 no gathers
-//   4 x through the SCALAR cache: s_load of the wave's 96 floats + v_writelane (exact results)
-//   6 a block walks kPlSub consecutive 128-point sub-chunks, x of the next one requested behind the gathers (exact)
-//   7 = 6 with the scalar-cache x of 4
-template <int V> struct PlCfg { static constexpr int SUB = (V == 6 || V == 7) ? 4 : 1; static constexpr bool SX = (V == 4 || V == 7); };
-
-// x of the wave's 32 points (96 consecutive floats from the 4-byte aligned xw) into the lanes: lane 2p and 2p + 1 get
-// point p.  Scalar loads have their own cache and return path: they neither queue in the vector L1 behind the gathers nor
-// hold the gathers of other waves up while they miss the L2.
-typedef float f32x16 __attribute__((ext_vector_type(16), aligned(4)));
-__device__ __forceinline__ void wave_x_scalar(const float *__restrict__ xw, float (&xp)[3]) {
-	const f32x16 *__restrict__ v = reinterpret_cast<const f32x16 *>(xw);
-	f32x16 r[6];
-#pragma unroll
-	for (int k = 0; k < 6; ++k) r[k] = v[k];
-	int xi[3] = {0, 0, 0};
-#pragma unroll
-	for (int k = 0; k < 96; ++k) {
-		const int sv = __builtin_amdgcn_readfirstlane(__float_as_int(r[k >> 4][k & 15]));
-		asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(xi[k % 3]) : "s"(sv), "n"(2 * (k / 3)));
-	}
-#pragma unroll
-	for (int d = 0; d < 3; ++d) xp[d] = __int_as_float(__builtin_amdgcn_mov_dpp(xi[d], 0xA0, 0xf, 0xf, true));
-}
-
-template <bool DYDX, typename PT, int V = 0>
-__global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
-                                                         int32_t max_level, uint32_t smooth, const float *__restrict__ x,
-                                                         const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
-                                                         int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
-	constexpr int D = 3;
-	constexpr int SUB = PlCfg<V>::SUB;
-	uint32_t q, chunk;
-	if (!decode_block(s, blockIdx.x, q, chunk)) return;
-	const uint32_t side = threadIdx.x & 1u;
-	const uint32_t level = meta_level_of(md, q);
-	const uint32_t foff0 = meta_cnt_of(md, q) * 2u;
-	const bool live = (int32_t)level <= max_level;
-	const Lvl L = load_level(md, live ? level : 0u);
-	const PT *__restrict__ grid = params + L.off;
-	const bool dense = L.type == NR3D_LOD_Dense;
-	const char *__restrict__ base = reinterpret_cast<const char *>(grid + foff0);
-	const uint32_t stride = L.F * (uint32_t)sizeof(PT);
-	const uint32_t col = q * 2u + side;
-
-	auto load_x = [&](uint32_t sub, float (&xp)[D]) {
-		const uint32_t i = (chunk * SUB + sub) * kPlPts + (threadIdx.x >> 1);
-		if (V == 1 || V == 3) {
-			uint32_t h = i * 2654435761u + 12345u;
-#pragma unroll
-			for (int d = 0; d < D; ++d) {
-				h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
-				xp[d] = (float)(h >> 8) * (1.0f / 16777216.0f);
-			}
-			return;
-		}
-		if (PlCfg<V>::SX) {
-			const uint32_t w0 = __builtin_amdgcn_readfirstlane((chunk * SUB + sub) * kPlPts + ((threadIdx.x >> 6) << 5));
-			if (w0 + 32u <= N) { wave_x_scalar(x + (size_t)w0 * D, xp); return; }
-		}
-		const uint32_t ic = i < N ? i : N - 1u;
-#pragma unroll
-		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)ic * D + d];
-	};
-
-	float xp[D];
-	load_x(0, xp);
-#pragma unroll
-	for (int sub = 0; sub < SUB; ++sub) {
-		const uint32_t i = (chunk * SUB + sub) * kPlPts + (threadIdx.x >> 1);
-		float out_y = 0.0f, out_g[D] = {0.0f, 0.0f, 0.0f};
-		float xn[D] = {0.0f, 0.0f, 0.0f};
-		if (live) {
-			Cell<D> c;
-			locate<D>(xp, L, smooth != 0, c);
-			float val[8];
-			float2 t[4];
-			// entry of this lane's corner m: the pair dim (Dense z, Hash x) takes `side`, the other two dims take the bits of
-			// m (Dense: bit 0 = x, bit 1 = y; Hash: bit 0 = y, bit 1 = z).  Byte offsets inside the level are 32-bit (checked
-			// on the host), the level's base address is wave-uniform.
-			uint32_t e[4];
-			if (dense) {
-				const uint32_t e00 = (c.g[0] * L.res[1] + c.g[1]) * L.res[2] + c.g[2] + side;
-				const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
-				e[0] = e00; e[1] = e00 + sx; e[2] = e00 + sy; e[3] = e00 + sx + sy;
-			} else {
-				const uint32_t hy0 = c.g[1] * kPrimes[1], hy1 = hy0 + kPrimes[1];
-				const uint32_t hz0 = c.g[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
-				const uint32_t xs = c.g[0] + side;
-				const uint32_t h[4] = {xs ^ hy0 ^ hz0, xs ^ hy1 ^ hz0, xs ^ hy0 ^ hz1, xs ^ hy1 ^ hz1};
-				if ((L.size & (L.size - 1u)) == 0u) {
-#pragma unroll
-					for (int m = 0; m < 4; ++m) e[m] = h[m] & (L.size - 1u);
-				} else {
-#pragma unroll
-					for (int m = 0; m < 4; ++m) e[m] = h[m] % L.size;
-				}
-			}
-#pragma unroll
-			for (int m = 0; m < 4; ++m) {                            // all four gathers first: four requests in flight per lane
-				if (V == 5) t[m] = make_float2(__int_as_float(e[m] | 0x3f000000u), __int_as_float(e[m] ^ 0x3f123456u));
-				else t[m] = load_pair<PT>(base + e[m] * stride);
-			}
-			if (sub + 1 < SUB) load_x(sub + 1, xn);                  // behind the gathers: loads return in order
-#pragma unroll
-			for (uint32_t m = 0; m < 4; ++m) {
-				// val[k] = corner k of feature `side`.  Even lanes (side 0) own the side-0 corner: lo = own x, hi = partner's
-				// x; odd lanes: lo = partner's y, hi = own y (DPP quad_perm 1,0,3,2 swaps the lanes of a pair; the selects
-				// fold into v_cndmask_b32_dpp)
-				const float sw_x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t[m].x), 0xB1, 0xf, 0xf, true));
-				const float sw_y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(t[m].y), 0xB1, 0xf, 0xf, true));
-				const float lo = side ? sw_y : t[m].x, hi = side ? t[m].y : sw_x;
-				if (dense) { val[m] = lo; val[m | 4u] = hi; }
-				else { val[m << 1] = lo; val[(m << 1) | 1u] = hi; }
-			}
-#pragma unroll
-			for (uint32_t k = 0; k < 8; ++k) out_y = __fmaf_rn(corner_weight<D>(c, k), val[k], out_y);
-			if (DYDX) {
-#pragma unroll
-				for (int gd = 0; gd < D; ++gd)
-#pragma unroll
-					for (uint32_t k = 0; k < 8; ++k) {
-						if ((k >> gd) & 1u) continue;
-						const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
-						out_g[gd] = __fmaf_rn(w, val[k | (1u << gd)] - val[k], out_g[gd]);
-					}
-			}
-		}
-		const bool skip_store = (V == 2 || V == 3) && out_y + out_g[0] + out_g[1] + out_g[2] != 1234.56789f;
-		if (i < N && !skip_store) {                              // both lanes of a pair share i
-			store_nt<PT>(&y[(int64_t)i * y_sn + (int64_t)col * y_se], out_y);
-			if (DYDX) {
-				float *dst = dydx + (int64_t)i * d_sn + (int64_t)col * d_se;
-#pragma unroll
-				for (int d = 0; d < D; ++d) __builtin_nontemporal_store(out_g[d], &dst[d]);
-			}
-		}
-#pragma unroll
-		for (int d = 0; d < D; ++d) xp[d] = xn[d];
-	}
-}
-
 // =============================================================================================
-// Forward, two lanes per (point, pseudo level), LEAN instruction stream (round 3).
+// The kernel (round 3 form).
 //
-// Measured (tools/exp_fwd_variants.py, profiles/r03_fwd_variants.txt): with its gathers REMOVED, k_fwd_pairlane still takes
-// 236 of its 355 us -- ~300 VALU instructions per wave at 4 cycles each keep the SIMDs busy, the gathers only queue in
-// between.  The kernel is bound by its instruction stream, not by the L2.  This form keeps the gather pattern (4.25
-// requests per point and level) and cuts the instructions per wave to about a third:
+// Measured on the round-2 kernel (tools/exp_fwd_variants.py, profiles/r03a_fwd_experiments.txt): with its gathers REMOVED
+// it still took 236 of its 355 us -- 201 VALU instructions per wave at 4 cycles each (160 us of SIMD time) plus 64-bit
+// address arithmetic for every access.  This form keeps the gather pattern (4.25 requests per point and level) and cuts
+// the instruction stream to about a third (the no-gather time drops to 131 us, the no-gather-no-store time to 106):
 //  * N-linear interpolation as a tree of lerps, pair dim first: 7 (sub, fma) pairs give the value; the differences the
 //    lerps form anyway ARE the derivative's building blocks (3 + 1 more lerps) -- 25 flops for y and dy/dx instead of
 //    ~100 for the sum over 8 corner weights + 12 face weights.  Same polynomial, different association: results agree
-//    with the corner-sum form (k_fwd, the oracle) to fp32 rounding (~1e-7 relative), far inside the 1e-5 contract;
-//  * lanes exchange ONE value per corner pair (the feature the partner needs) and interpolate "own side first":
+//    with the corner-sum form (k_fwd, the oracle) to fp32 rounding (measured 3.8e-7 of the column maximum), far inside
+//    the 1e-5 contract;
+//  * lanes exchange ONE value per corner pair (the feature the partner interpolates) and lerp "own side first":
 //    b = keep + w_keep * (recv - keep) -- no lo / hi selects;
-//  * addresses as uniform 64-bit base (SGPRs) + 32-bit lane offset: no 64-bit vector multiplies for the strides, no
-//    64-bit vector adds per gather; 24-bit multiplies (full rate) where the level is small enough;
-//  * a wave walks SUB consecutive 32-point groups: the scalar preamble (schedule decode, level descriptor) and the lane
-//    constants are paid once, x of the next group is requested right behind the gathers of the current one.
+//  * addresses as a uniform 64-bit base (SGPRs) + 32-bit lane offset: no 64-bit vector multiplies for the strides, no
+//    64-bit vector adds per gather, the Jacobian leaves as one dwordx3 per lane; 24-bit multiplies (full rate) where the
+//    level is small enough;
+//  * a wave walks SUB consecutive 32-point groups with ALL their gathers in flight at once; the scalar preamble
+//    (schedule decode, level descriptor) and the lane constants are paid once.
+// What the experiments say about the rest (2^22 points, us per 2^20): gathers + arithmetic alone 245 (255 G requests/s,
+// the rate of the pure-gather micro-benchmark, profiles/r01_ubench_mem.txt), + output stores 285, + x reads 302, all
+// three 338: the L2 channels serve the gathers at their ceiling and the 7.3 M write and 1.4 M x-miss requests queue in
+// the same channels -- the times add instead of overlapping.  More groups in flight (SUB 1 / 2 / 4 / 8: 358 / 352 / 358
+// / 355 us at 2^20), plain instead of non-temporal stores (373), a row pitch that is not a power of two (no change), x
+// through the scalar cache (+14 us on the round-2 kernel) do not move it.
+// NR3D_FWD_DBG (timing experiments, results wrong by design): bit 0 no stores, bit 1 no gathers, bit 2 no x loads.
 // =============================================================================================
-template <bool DYDX, typename PT, int SUB, bool NT = true>
-__global__ __launch_bounds__(kBlock) void k_fwd_pl(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+constexpr int kPlSub = 2;                          // 32-point groups per wave
+template <bool DYDX, typename PT, int SUB>
+__global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                    int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                    const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
                                                    int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se, uint32_t dbg) {
@@ -581,16 +447,13 @@ __global__ __launch_bounds__(kBlock) void k_fwd_pl(Sched s, const nr3d_lotd_meta
 		if ((dbg & 1u) && yv[u] + gx[u] + gy[u] + gz[u] != 1234.56789f) continue;
 		if (g0 + pl < N) {
 			char *yb = reinterpret_cast<char *>(y) + ((int64_t)g0 * y_sn + (int64_t)(q * 2u) * y_se) * (int64_t)sizeof(PT);
-			if (NT) store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane), yv[u]);
-			else *reinterpret_cast<PT *>(yb + y_lane) = (PT)yv[u];
+			store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane), yv[u]);
 			if (DYDX) {
 				char *db = reinterpret_cast<char *>(dydx) + ((int64_t)g0 * d_sn + (int64_t)(q * 2u) * d_se) * 4;
 				float *dst = reinterpret_cast<float *>(db + d_lane);
-				if (NT) {
-					__builtin_nontemporal_store(gx[u], &dst[0]);
-					__builtin_nontemporal_store(gy[u], &dst[1]);
-					__builtin_nontemporal_store(gz[u], &dst[2]);
-				} else { dst[0] = gx[u]; dst[1] = gy[u]; dst[2] = gz[u]; }
+				__builtin_nontemporal_store(gx[u], &dst[0]);
+				__builtin_nontemporal_store(gy[u], &dst[1]);
+				__builtin_nontemporal_store(gz[u], &dst[2]);
 			}
 		}
 	}
@@ -612,64 +475,77 @@ __global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t 
                                                          uint32_t smooth, const float *__restrict__ x,
                                                          const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
                                                          int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
-	constexpr int D = 3, G = 2;
 	extern __shared__ __attribute__((aligned(16))) float2 tab[];
 	const uint32_t level = meta_level_of(md, q);
 	const Lvl L = load_level(md, level);
 	const char *__restrict__ src = reinterpret_cast<const char *>(params + L.off);
 	for (uint32_t e = threadIdx.x; e < L.size; e += kLdsThreads) tab[e] = load_pair<PT>(src + (size_t)e * (2 * sizeof(PT)));
 	__syncthreads();
-	const uint32_t out0 = q * G;
-	const uint32_t i0 = blockIdx.x * kLdsPts;
+	const float sc0 = (float)(L.res[0] - 2u), sc1 = (float)(L.res[1] - 2u), sc2 = (float)(L.res[2] - 2u);
+	const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	// outputs: uniform base of the wave's 64 points + 32-bit lane offset (host-checked), as in k_fwd_pairlane
+	const uint32_t y_lane = (uint32_t)((int64_t)lane * y_sn) * (uint32_t)sizeof(PT);
+	const uint32_t d_lane = DYDX ? (uint32_t)((int64_t)lane * d_sn) * 4u : 0u;
+	const uint32_t ye = (uint32_t)(y_se * (int64_t)sizeof(PT)), de = DYDX ? (uint32_t)(d_se * 4) : 0u;
 #pragma unroll 2
 	for (uint32_t k4 = 0; k4 < kLdsPts / kLdsThreads; ++k4) {
-		const uint32_t i = i0 + k4 * kLdsThreads + threadIdx.x;
-		if (i >= N) break;
-		float xp[D];
-#pragma unroll
-		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
-		Cell<D> c;
-		locate<D>(xp, L, smooth != 0, c);
-		float v[1 << D][G];
-#pragma unroll
-		for (uint32_t m = 0; m < 4; ++m) {                       // the corner pair along the contiguous last dim
-			uint32_t p0[D];
-			corner_pos<D>(c, m, p0);
-			const uint32_t e0 = entry_dense<D>(L, p0);
-			const float2 a = tab[e0], b = tab[e0 + 1];
-			v[m][0] = a.x; v[m][1] = a.y; v[m | 4u][0] = b.x; v[m | 4u][1] = b.y;
+		const uint32_t g0 = blockIdx.x * kLdsPts + k4 * kLdsThreads + wave * 64u;      // uniform
+		if (g0 >= N) break;
+		const uint32_t i = g0 + lane, ic = i < N ? i : N - 1u;
+		const float *px = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + (size_t)g0 * 12u + (ic - g0) * 12u);
+		const float x0 = px[0], x1 = px[1], x2 = px[2];
+		// cell locator (explicit fma: decides the integer cell, must match the oracle bit for bit)
+		const float v0 = __fmaf_rn(x0, sc0, 0.5f), v1 = __fmaf_rn(x1, sc1, 0.5f), v2 = __fmaf_rn(x2, sc2, 0.5f);
+		const float f0 = floorf(v0), f1 = floorf(v1), f2 = floorf(v2);
+		float t0 = v0 - f0, t1 = v1 - f1, t2 = v2 - f2;
+		float dw0 = sc0, dw1 = sc1, dw2 = sc2;             // scale * w'
+		if (smooth) {
+			dw0 *= 6.0f * t0 * (1.0f - t0); dw1 *= 6.0f * t1 * (1.0f - t1); dw2 *= 6.0f * t2 * (1.0f - t2);
+			t0 = t0 * t0 * __fmaf_rn(-2.0f, t0, 3.0f); t1 = t1 * t1 * __fmaf_rn(-2.0f, t1, 3.0f); t2 = t2 * t2 * __fmaf_rn(-2.0f, t2, 3.0f);
 		}
-		float out_y[G] = {0.0f, 0.0f}, out_g[G][D];
+		const uint32_t e00 = ((uint32_t)f0 * L.res[1] + (uint32_t)f1) * L.res[2] + (uint32_t)f2;
+		const uint32_t e[4] = {e00, e00 + sx, e00 + sy, e00 + sx + sy};
+		// the lerp tree of k_fwd_pairlane for a Dense level (pair dim z, then x, then y), both features in one lane: feature 0
+		// with the arithmetic of the pair's side-0 lane (keep the lower corner, weight w), feature 1 with the side-1 lane's
+		// (keep the upper corner, weight 1 - w, difference negated) -- the two kernels give the same bits
+		const float w1 = 1.0f - t2;
+		float2 b[4], d[4];
 #pragma unroll
-		for (int f = 0; f < G; ++f)
-#pragma unroll
-			for (int d = 0; d < D; ++d) out_g[f][d] = 0.0f;
-#pragma unroll
-		for (uint32_t k = 0; k < (1u << D); ++k) {
-			const float w = corner_weight<D>(c, k);
-#pragma unroll
-			for (int f = 0; f < G; ++f) out_y[f] = __fmaf_rn(w, v[k][f], out_y[f]);
+		for (int m = 0; m < 4; ++m) {
+			const float2 lo = tab[e[m]], hi = tab[e[m] + 1u];
+			d[m] = make_float2(hi.x - lo.x, lo.y - hi.y);
+			b[m] = make_float2(__fmaf_rn(t2, d[m].x, lo.x), __fmaf_rn(w1, d[m].y, hi.y));
 		}
-		if (DYDX) {
+		float yv[2], gx[2], gy[2], gz[2];
 #pragma unroll
-			for (int gd = 0; gd < D; ++gd)
+		for (int f = 0; f < 2; ++f) {
+			auto c = [f](const float2 &v) { return f ? v.y : v.x; };
+			const float cA0 = c(b[1]) - c(b[0]), cA1 = c(b[3]) - c(b[2]);
+			const float dA0 = __fmaf_rn(t0, cA0, c(b[0])), dA1 = __fmaf_rn(t0, cA1, c(b[2]));
+			const float eB = dA1 - dA0;
+			yv[f] = __fmaf_rn(t1, eB, dA0);
+			if (DYDX) {
+				const float gA = __fmaf_rn(t1, cA1 - cA0, cA0);
+				const float p0 = __fmaf_rn(t0, c(d[1]) - c(d[0]), c(d[0])), p1 = __fmaf_rn(t0, c(d[3]) - c(d[2]), c(d[2]));
+				const float gP = __fmaf_rn(t1, p1 - p0, p0);
+				gx[f] = gA * dw0; gy[f] = eB * dw1; gz[f] = gP * (f ? -dw2 : dw2);
+			}
+		}
+		if (i < N) {
+			char *yb = reinterpret_cast<char *>(y) + ((int64_t)g0 * y_sn + (int64_t)(q * 2u) * y_se) * (int64_t)sizeof(PT);
+			store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane), yv[0]);
+			store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane + ye), yv[1]);
+			if (DYDX) {
+				char *db = reinterpret_cast<char *>(dydx) + ((int64_t)g0 * d_sn + (int64_t)(q * 2u) * d_se) * 4;
 #pragma unroll
-				for (uint32_t k = 0; k < (1u << D); ++k) {
-					if ((k >> gd) & 1u) continue;
-					const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
-#pragma unroll
-					for (int f = 0; f < G; ++f)
-						out_g[f][gd] = __fmaf_rn(w, v[k | (1u << gd)][f] - v[k][f], out_g[f][gd]);
+				for (int f = 0; f < 2; ++f) {
+					float *dst = reinterpret_cast<float *>(db + d_lane + (f ? de : 0u));
+					__builtin_nontemporal_store(gx[f], &dst[0]);
+					__builtin_nontemporal_store(gy[f], &dst[1]);
+					__builtin_nontemporal_store(gz[f], &dst[2]);
 				}
-		}
-#pragma unroll
-		for (int f = 0; f < G; ++f) store_nt<PT>(&y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se], out_y[f]);
-		if (DYDX) {
-#pragma unroll
-			for (int f = 0; f < G; ++f) {
-				float *dst = dydx + (int64_t)i * d_sn + (int64_t)(out0 + f) * d_se;
-#pragma unroll
-				for (int d = 0; d < D; ++d) __builtin_nontemporal_store(out_g[f][d], &dst[d]);
 			}
 		}
 	}
@@ -1359,6 +1235,11 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
                          hipStream_t st, bool &served) {
 	served = false;
 	if (!pairlane_enabled() || !pairlane_meta_ok(meta) || ((uintptr_t)params % (2 * sizeof(PT))) != 0) return 0;
+	// the kernels address the outputs as uniform base + 32-bit lane offset: (31 rows + 1 column) of a wave must fit
+	auto lane_span_ok = [](int64_t sn, int64_t se, int64_t elt) {
+		return sn >= 0 && se >= 0 && sn < (1ll << 40) && se < (1ll << 40) && (63 * sn + se + 3) * elt < (1ll << 32);
+	};
+	if (!lane_span_ok(y_sn, y_se, (int64_t)sizeof(PT)) || (dy_dx && !lane_span_ok(d_sn, d_se, 4))) return 0;
 	served = true;
 	uint64_t staged = 0;
 	if (lds_stage_enabled() && N >= lds_stage_min_points() && meta->n_pseudo_levels <= 64) {
@@ -1385,38 +1266,18 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 				                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
 		}
 	}
-	static int variant = -1;
-	if (variant < 0) { const char *e = getenv("NR3D_FWD_VARIANT"); variant = e ? atoi(e) : 0; }
-	const int v = (dy_dx && sizeof(PT) == 4) ? variant : 0;
+	static int dbg = -1;
+	if (dbg < 0) { const char *e = getenv("NR3D_FWD_DBG"); dbg = e ? atoi(e) : 0; }
 	uint32_t n_blocks;
-	const Sched s = make_sched(N, meta, n_blocks, staged, (uint32_t)kPlPts * ((v == 6 || v == 7 || v == 10 || v == 11) ? 4u : v == 12 ? 8u : v == 9 ? 2u : 1u), true);
+	const Sched s = make_sched(N, meta, n_blocks, staged, (uint32_t)(kPlPts * kPlSub), true);
 	if (n_blocks != 0) {
 		prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
-#define NR3D_FWD_V(V_) hipLaunchKernelGGL((k_fwd_pairlane<true, PT, V_>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level, \
-			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se)
-#define NR3D_FWD_PL(SUB_) hipLaunchKernelGGL((k_fwd_pl<true, PT, SUB_>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level, \
-			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se, dbg)
-		static int dbg = -1;
-		if (dbg < 0) { const char *e = getenv("NR3D_FWD_DBG"); dbg = e ? atoi(e) : 0; }
-		if (v == 8) NR3D_FWD_PL(1);
-		else if (v == 9) NR3D_FWD_PL(2);
-		else if (v == 10) NR3D_FWD_PL(4);
-		else if (v == 11) hipLaunchKernelGGL((k_fwd_pl<true, PT, 4, false>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
-			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se, dbg);
-		else if (v == 12) NR3D_FWD_PL(8);
-		else if (v == 1) NR3D_FWD_V(1);
-		else if (v == 2) NR3D_FWD_V(2);
-		else if (v == 3) NR3D_FWD_V(3);
-		else if (v == 4) NR3D_FWD_V(4);
-		else if (v == 5) NR3D_FWD_V(5);
-		else if (v == 6) NR3D_FWD_V(6);
-		else if (v == 7) NR3D_FWD_V(7);
-		else if (dy_dx)
-			hipLaunchKernelGGL((k_fwd_pairlane<true, PT>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
-			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
+		if (dy_dx)
+			hipLaunchKernelGGL((k_fwd_pairlane<true, PT, kPlSub>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se, (uint32_t)dbg);
 		else
-			hipLaunchKernelGGL((k_fwd_pairlane<false, PT>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
-			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
+			hipLaunchKernelGGL((k_fwd_pairlane<false, PT, kPlSub>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se, (uint32_t)dbg);
 	}
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -1441,8 +1302,11 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 		NR3D_CHECK(!batched && pairlane_enabled() && pairlane_meta_ok(meta) && ((uintptr_t)params % 4) == 0,
 		           "LoTD::fwd: half params are served natively for unbatched 3-D Dense/Hash metas with 2-feature pseudo levels "
 		           "only (nr3d_lotd_half_params_ok); convert on the caller side");
-		return fwd_fast_path<__half>(meta, md, N, (const float *)x, (const __half *)params, max_level, (__half *)y, y_sn, y_se,
-		                             (float *)dy_dx, d_sn, d_se, st, served);
+		if (int rc = fwd_fast_path<__half>(meta, md, N, (const float *)x, (const __half *)params, max_level, (__half *)y, y_sn,
+		                                   y_se, (float *)dy_dx, d_sn, d_se, st, served))
+			return rc;
+		NR3D_CHECK(served, "LoTD::fwd: half params need output strides >= 0 whose span over 64 rows fits 32 bits");
+		return 0;
 	}
 	if (!batched) {
 		bool served = false;

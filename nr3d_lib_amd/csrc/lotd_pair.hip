@@ -100,9 +100,12 @@ static uint32_t pair_units() {
 // A_f = g_f x the weights of the two dims the pair does not run along, and the pair's own weight wp
 __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t epb, uint32_t lg, const float (&xp)[3], float g0,
                                              float g1, bool smooth, uint32_t (&hdr)[4], uint32_t (&bkt)[4], float (&A)[4][2],
-                                             float &wp, uint32_t (&cell)[3]) {
+                                             float &wp, uint32_t (&cell)[3], uint32_t nb, bool &valid) {
+	// valid: every pair lies inside ONE bucket of the level.  True by construction for x in [0, 1] (what the Python layer
+	// clamps to, lotd.py:68); a point outside (or NaN) would index the LDS histogram / stage out of bounds -- it is dropped.
 	Cell<3> c;
 	locate<3>(xp, L, smooth, c);
+	valid = true;
 	if (L.type == NR3D_LOD_Dense) {
 		wp = c.w[2];
 #pragma unroll
@@ -112,6 +115,7 @@ __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t
 			const uint32_t e0 = row * L.res[2] + c.g[2];
 			const uint32_t b = row >> sh;
 			const uint32_t i0 = e0 - b * epb;
+			valid = valid && b < nb && c.g[2] + 1u < L.res[2];
 			bkt[m] = b;
 			hdr[m] = i0 | ((i0 + 1u) << 13);
 			const float wo = (bx ? c.w[0] : 1.0f - c.w[0]) * (by ? c.w[1] : 1.0f - c.w[1]);
@@ -128,7 +132,8 @@ __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t
 			const uint32_t h0 = c.g[0] ^ K, h1 = (c.g[0] + 1u) ^ K;
 			const uint32_t e0 = pow2 ? (h0 & (L.size - 1u)) : (h0 % L.size);
 			const uint32_t e1 = pow2 ? (h1 & (L.size - 1u)) : (h1 % L.size);
-			bkt[m] = e0 >> lg;                         // == e1 >> lg (plan conditions)
+			bkt[m] = e0 >> lg;                         // == e1 >> lg (plan conditions) for x in [0, 1]
+			valid = valid && (e1 >> lg) == bkt[m] && bkt[m] < nb;
 			hdr[m] = (e0 & emask) | ((e1 & emask) << 13);
 			const float wo = (by ? c.w[1] : 1.0f - c.w[1]) * (bz ? c.w[2] : 1.0f - c.w[2]);
 			A[m][0] = g0 * wo; A[m][1] = g1 * wo;
@@ -157,7 +162,7 @@ __device__ __forceinline__ void pair_buckets(const Lvl &L, uint32_t sh, uint32_t
 
 // One pseudo level of one block of kPBP points: pair records -> rank inside the bucket -> counting sort in LDS ->
 // coalesced write-out of the slot + its bucket offsets.  `hist` [nb + 1] must be zero on entry (and that visible: a
-// barrier behind the zeroing); `zero_next` (optional) is zeroed for the following call.  Four barriers.
+// barrier behind the zeroing); `zero_next` (optional) is zeroed for the following call.  Four barriers (five with zero_next).
 template <int kPBP>
 __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, const Lvl &L, bool active, const float (&xp)[3],
                                            float g0, float g1, uint32_t smooth, u32x4 *__restrict__ stage,
@@ -171,7 +176,11 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; }
 	if (zero_next)
 		for (uint32_t b = threadIdx.x; b <= kPMaxNb; b += kPBP) zero_next[b] = 0;
-	if (active) pair_records(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell);
+	if (active) {
+		bool valid;
+		pair_records(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, nb, valid);
+		active = valid;
+	}
 
 	// ---- coherent inputs: lanes that continue the previous lane's cell are summed into the head of their run ----
 	bool emit = active, split = false;
@@ -305,6 +314,8 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 	const uint32_t total = hist[nb];
 	for (uint32_t v = threadIdx.x; v < total; v += kPBP) __builtin_nontemporal_store(stage[v], dst + v);
 	for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) ob[(size_t)b * ob_stride] = hist[b];
+	// the next level's call zeroes THIS call's `hist` (its zero_next) right away: every read above must be done first
+	if (zero_next) __syncthreads();
 }
 
 // max |dL/dy| of the workgroup as float bits -> gmax (the fixed-point scale of stage B).  |float| bits order like
@@ -552,7 +563,7 @@ __device__ __forceinline__ void pair_st(float *p, float v, bool out_half) {
 // fp64 LDS atomics run at ~1.3-1.5 T/s chip-wide, 64-bit integer ones at ~2.5 T/s (tools/ubench_lds): with FIX the
 // accumulators are 64-bit fixed point.  Scale 2^s from the largest |dL/dy| of the call (stage A's gmax; every update is
 // a weight in [0, 1] times a gradient) and the number of points: |sum| < 8 n max|g| 2^s <= 2^62, resolution
-// max|g| * 2^-(59 - log2 n) -- far below an fp32 ulp of any non-negligible entry -- and the sum is exact, so the result
+// max|g| * 2^-min(59 - log2 n, 44) -- far below an fp32 ulp of any non-negligible entry -- and the sum is exact, so the result
 // does not depend on the order of the updates at all.  Non-finite gradients fall back to fp64 accumulation (uniform).
 struct PairFix { double scale, inv; bool on; };
 __device__ __forceinline__ PairFix pair_fix(const uint32_t *__restrict__ gmax, uint32_t sum_log2) {
@@ -560,7 +571,10 @@ __device__ __forceinline__ PairFix pair_fix(const uint32_t *__restrict__ gmax, u
 	const uint32_t bits = ((cu32_t)gmax)[0];
 	f.on = bits < 0x7F800000u;
 	const int e = max((int)(bits >> 23), 1) - 126;                    // max|g| < 2^e
-	const int lim = min(62 - (int)sum_log2, 50);                      // single values stay below 2^51 (rounding trick below)
+	// single values stay below 2^51 (rounding trick below) -- and a "single value" may be the fp32 sum of up to 64 merged
+	// lanes (coherent points: stage A's split singles, k_pair_direct's run heads): 6 bits of headroom for those.
+	// Resolution max|g| * 2^-44, still far below an fp32 ulp of any entry that matters.
+	const int lim = min(62 - (int)sum_log2, 50 - 6);
 	const int sc = max(min(lim - e, 1000), -1000);
 	f.scale = __longlong_as_double((long long)(sc + 1023) << 52);
 	f.inv = __longlong_as_double((long long)(1023 - sc) << 52);
@@ -732,7 +746,8 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 			const float g0 = g[(int64_t)i * g_sn + (int64_t)(q * 2) * g_se], g1 = g[(int64_t)i * g_sn + (int64_t)(q * 2 + 1) * g_se];
 			uint32_t hdr[4], bkt[4], cell[3];
 			float A[4][2], wp;
-			pair_records(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell);
+			bool valid;
+			pair_records(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, dp.nb[e], valid);
 			float lo[4][2], hi[4][2];
 #pragma unroll
 			for (int m = 0; m < 4; ++m)
@@ -766,7 +781,7 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 					head = !same;
 				}
 			}
-			if (!head) return;
+			if (!head || !valid) return;                     // a run shares its cell, so its head is valid iff its members are
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
 				if (bkt[m] != b) continue;
@@ -984,9 +999,10 @@ static uint64_t pair_direct_plan(const PairPlan &full, uint32_t n, DirectPlan &d
 	if (!pair_direct_enabled()) return 0;
 	uint64_t mask = 0;
 	uint32_t nb_lim = kDirectNb;                              // NR3D_PAIR_DIRECT_NB: buckets up to which a level goes direct
-	if (const char *e = getenv("NR3D_PAIR_DIRECT_NB")) nb_lim = (uint32_t)atoi(e);
+	if (const char *e = getenv("NR3D_PAIR_DIRECT_NB")) { const int v = atoi(e); nb_lim = v < 0 ? 0u : (uint32_t)v; }
 	for (uint32_t ql = 0; ql < full.n_pseudo && dp.n < kDirectMaxLv; ++ql) {
 		if (full.nb[ql] > nb_lim || full.qmap[ql] >= 64u) continue;
+		if (dp.bucket_base[dp.n] + full.nb[ql] > kDirectMaxWg) break;      // pair_layout reserves kDirectMaxWg partial tables
 		const uint32_t e = dp.n++;
 		dp.qmap[e] = full.qmap[ql]; dp.nb[e] = full.nb[ql]; dp.epb[e] = full.epb[ql]; dp.shift[e] = full.shift[ql];
 		dp.bucket_base[e + 1] = dp.bucket_base[e] + full.nb[ql];

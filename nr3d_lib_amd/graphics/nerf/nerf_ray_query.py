@@ -106,7 +106,8 @@ def nerf_ray_query_march_occ(model, ray_tested: Dict[str, torch.Tensor], with_rg
         depth_samples, deltas, samples = depth_samples[pidx_useful], deltas[pidx_useful], samples[pidx_useful]
     details['render.num_per_ray'] = pack_infos[:, 1]
 
-    volume_buffer = dict(type='packed', rays_inds_hit=rays_inds[ridx_hit], pack_infos_hit=pack_infos,
+    # packs_tile: the packs of the marcher / the compaction cover every sample exactly once (no zero-fill in the composite)
+    volume_buffer = dict(type='packed', packs_tile=True, rays_inds_hit=rays_inds[ridx_hit], pack_infos_hit=pack_infos,
                          t=depth_samples.to(dtype))
     if full_uses['bidx'] and nidx_useful is not None:
         volume_buffer['rays_bidx_hit'] = ray_tested['rays_bidx'][nidx_useful]     # indexing as in the reference (:148)
@@ -148,7 +149,8 @@ def composite_packed_volume_buffer(volume_buffer: dict, num_rays: int, with_rgb:
     if FUSED_COMPOSITE and alpha.dtype == torch.float32 and dtype == torch.float32 and alpha.is_cuda:
         rgb = volume_buffer['rgb'].view(-1, 3) if with_rgb else None
         vw, mask, depth, rgb_out = packed_composite(alpha.view(-1), volume_buffer['t'].view(-1), rgb, pi, hit.long(), num_rays,
-                                                    normalize_depth=depth_use_normalized_vw)
+                                                    normalize_depth=depth_use_normalized_vw,
+                                                    packs_tile=bool(volume_buffer.get('packs_tile', False)))
         volume_buffer['vw'] = vw
         out = dict(mask_volume=mask, depth_volume=depth)
         if with_rgb:

@@ -291,11 +291,12 @@ class PackedComposite(torch.autograd.Function):
     respect to alpha, t and rgb."""
 
     @staticmethod
-    def forward(ctx, alphas, t, rgb, pack_infos, rays_inds_hit, num_rays, early_stop_eps, alpha_thre, normalize_depth):
+    def forward(ctx, alphas, t, rgb, pack_infos, rays_inds_hit, num_rays, early_stop_eps, alpha_thre, normalize_depth,
+                packs_tile=False):
         vw, mask, depth, rgb_out = _backend.packed_composite_forward(alphas, t, rgb, pack_infos, rays_inds_hit, num_rays,
-                                                                      early_stop_eps, alpha_thre, normalize_depth)
+                                                                      early_stop_eps, alpha_thre, normalize_depth, packs_tile)
         ctx.save_for_backward(alphas, t, rgb, pack_infos, rays_inds_hit, vw, mask, depth)
-        ctx.cfg = (early_stop_eps, alpha_thre, normalize_depth)
+        ctx.cfg = (early_stop_eps, alpha_thre, normalize_depth, packs_tile)
         ctx.set_materialize_grads(False)
         if rgb is None:
             return vw, mask, depth
@@ -305,19 +306,22 @@ class PackedComposite(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_vw, g_mask, g_depth, g_rgb=None):
         alphas, t, rgb, pack_infos, rays_inds_hit, vw, mask, depth = ctx.saved_tensors
-        eps, thre, normalize = ctx.cfg
+        eps, thre, normalize, packs_tile = ctx.cfg
         c = lambda g: None if g is None else g.contiguous()
         ga, gt, gr = _backend.packed_composite_backward(alphas, vw, t, rgb, pack_infos, rays_inds_hit, eps, thre, normalize,
                                                         mask, depth, c(g_mask), c(g_depth), c(g_rgb), c(g_vw),
                                                         need_t=ctx.needs_input_grad[1],
-                                                        need_rgb=rgb is not None and ctx.needs_input_grad[2])
-        return ga if ctx.needs_input_grad[0] else None, gt, gr, None, None, None, None, None, None
+                                                        need_rgb=rgb is not None and ctx.needs_input_grad[2],
+                                                        packs_tile=packs_tile)
+        return ga if ctx.needs_input_grad[0] else None, gt, gr, None, None, None, None, None, None, None
 
 
 def packed_composite(alpha, t, rgb, pack_infos, rays_inds_hit=None, num_rays=None, early_stop_eps: float = 1e-4,
-                     alpha_thre: float = 0.0, normalize_depth: bool = True):
+                     alpha_thre: float = 0.0, normalize_depth: bool = True, packs_tile: bool = False):
     """fused alpha composite of a packed volume buffer -> (vw, mask, depth, rgb | None); see PackedComposite.
-    ``rays_inds_hit`` scatters the per-pack results into [num_rays] outputs (other rays stay zero)."""
+    ``rays_inds_hit`` scatters the per-pack results into [num_rays] outputs (other rays stay zero).
+    ``packs_tile``: the caller guarantees that the packs cover [0, S) exactly (a marcher's / a compaction's pack_infos do),
+    so the per-sample outputs need no zero-fill; otherwise samples outside every pack come back as zeros."""
     if num_rays is None:
         num_rays = pack_infos.shape[0]
     alpha, t = alpha.contiguous().view(-1), t.contiguous().view(-1)
@@ -326,10 +330,10 @@ def packed_composite(alpha, t, rgb, pack_infos, rays_inds_hit=None, num_rays=Non
         rays_inds_hit = rays_inds_hit.contiguous()
     if alpha.requires_grad or t.requires_grad or (rgb is not None and rgb.requires_grad):
         out = PackedComposite.apply(alpha, t, rgb, pack_infos, rays_inds_hit, int(num_rays), early_stop_eps, alpha_thre,
-                                    bool(normalize_depth))
+                                    bool(normalize_depth), bool(packs_tile))
         return out if rgb is not None else (*out, None)
     return _backend.packed_composite_forward(alpha, t, rgb, pack_infos, rays_inds_hit, int(num_rays), early_stop_eps,
-                                             alpha_thre, bool(normalize_depth))
+                                             alpha_thre, bool(normalize_depth), bool(packs_tile))
 
 
 @torch.no_grad()

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# every torch.empty output of the bindings is NaN / 0xAB-filled before its kernel runs (nr3d_lib_amd/_hip.py): a kernel that
+# leaves an element of a "fully written" output untouched fails its parity test instead of passing on a zeroed allocation
+os.environ.setdefault("NR3D_POISON_EMPTY", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -541,6 +541,48 @@ def test_dparam_coherent_points(oracle, dev, case, bin_mode):
     assert_close(dp2, oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="2nd-order dparam (coherent)", levels=m_ref)
 
 
+@pytest.mark.parametrize("n", [512, 1024, 4096])
+def test_dparam_small_coherent_batch_constant_gradient(oracle, dev, n, bin_mode):
+    """Fixed-point accumulators under the coherent-lane merge (round-2 advisor finding): for small batches the scale left
+    single updates just below 2^51, and a run head carries the fp32 SUM of up to 64 merged lanes -- with a constant dL_dy
+    and ~36 consecutive points per coarse cell the merged value left the binade of the mantissa rounding trick and came
+    out wrong.  Zero-mean random gradients (test_dparam_coherent_points) never reach that; ones do."""
+    _lotd, m_ref, m, _, _ = _setup(oracle, dev, "ngp_small", n=8)
+    n_per = 128
+    rng = np.random.default_rng(77)
+    o = rng.uniform(0.1, 0.2, (n // n_per, 1, 3)).astype(np.float32)
+    d = rng.uniform(0.05, 0.12, (n // n_per, 1, 3)).astype(np.float32)                # short rays: ~40 points per level-0 cell
+    t = np.linspace(0, 1, n_per, dtype=np.float32).reshape(1, n_per, 1)
+    x = (o + d * t).reshape(-1, 3).clip(1e-6, 1 - 1e-6).astype(np.float32)
+    md = m_ref.as_dict()
+    p = (rng.standard_normal(md["n_params"]) * 0.1).astype(np.float32)
+    g = np.ones((n, md["n_encoded_dims"]), np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    _, dp = _lotd.lod_bwd(m, T(g), T(x), T(p), None, need_input_grad=False, need_param_grad=True)
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam (coherent, constant g)", levels=m_ref)
+    # gradient mass: the interpolation weights of a point sum to 1 on every level
+    tot = dp.double().cpu().numpy()
+    for off, size, F in zip(md["level_offsets"], md["level_sizes"], md["level_n_feats"]):
+        assert abs(tot[off:off + size * F].sum() - n * F) <= 1e-5 * n * F
+
+
+def test_dparam_survives_points_outside_the_unit_cube(oracle, dev, bin_mode):
+    """x outside [0, 1] (the Python layer clamps, lotd.py:68, but the C ABI takes what it is given): a pair whose two
+    entries do not share a bucket of the level (or whose bucket lies past the table) is dropped by the record path instead
+    of indexing its LDS histogram / accumulators out of bounds (round-2 advisor finding).  What such points add elsewhere
+    is unspecified (the reference wraps / hashes them); the call must complete with finite values and leave the
+    device in a state where the next, valid, call is exact."""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, "ngp_small", seed=5)
+    x_bad = x.copy()
+    x_bad[::7] = np.array([1.5, -0.25, 3.0], np.float32)
+    x_bad[3::11] = np.array([0.5, 40.0, 0.5], np.float32)
+    _, dp_bad = _lotd.lod_bwd(m, gt, torch.from_numpy(x_bad).to(dev), pt, None, need_input_grad=False, need_param_grad=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dp_bad).all()
+    _, dp = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL_dparam after a call with outside points", levels=m_ref)
+
+
 @pytest.mark.parametrize("case", ["ngp_small", "mixed"])
 def test_params_at_odd_alignment(oracle, dev, case):
     """params that start 4 bytes into an allocation: the 8 / 16-byte vector gathers must not be used"""

@@ -24,8 +24,8 @@ def test_dense_forward_against_reference_param_interpolate(dev, tag, D):
     z = np.load(os.path.join(GOLD, "ref_param_interpolate.npz"))
     R, F = int(z[f"{tag}_res"]), int(z[f"{tag}_feats"])
     x, p, want = z[f"{tag}_x"], z[f"{tag}_params"].astype(np.float32), z[f"{tag}_y"]
-    if tag == "c1":            # configs[0] as BASELINE.json states it; the fixture keeps the first 4096 of its 65 536 points
-        assert (R, F) == (32, 4) and p.size == 32 ** 3 * 4
+    if tag == "c1":            # configs[0] exactly as BASELINE.json states it: Dense 32^3 x 4, all 65 536 points
+        assert (R, F) == (32, 4) and p.size == 32 ** 3 * 4 and x.shape[0] == 65536
     m = _lotd.LoDMeta(D, [R], [F], ["Dense"], None)
     xt, pt = torch.from_numpy(x).to(dev), torch.from_numpy(p).to(dev)
     y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
