@@ -44,8 +44,12 @@ def algorithmic_bytes_per_point(L, F, D=3, C=8):
 def kernel_algorithmic_bytes(kernel, n_levels_served, F=2, D=3, C=8):
     """section 8(d)'s per-level figures restricted to what ONE launch of `kernel` processes, per point"""
     Ls = n_levels_served
-    if kernel in ("lotd_fwd", "lotd_fwd_lds"):          # x + corner gathers + y of the levels it serves
+    if kernel == "lotd_fwd":                            # x + corner gathers + y of the levels it serves
         return 4 * D + Ls * C * F * 4 + Ls * F * 4
+    if kernel == "lotd_fwd_lds":
+        # the level's table is staged in LDS once per workgroup: the corner values (8(d)'s 64 B per point and level) never
+        # come from memory, so crediting them would put this kernel above the peak.  What it moves: x, y and the Jacobian.
+        return 4 * D + Ls * F * 4 + Ls * F * D * 4
     if kernel == "lotd_contract_dx":                    # dL_dy + the stored Jacobian (8(d)'s reference-faithful variant) + dL_dx
         return Ls * F * 4 + Ls * F * D * 4 + 4 * D
     if kernel in ("lotd_bin", "lotd_accum"):            # x + dL_dy ... scatter as read-modify-write, half to each stage
@@ -358,14 +362,20 @@ def full_loop_sharded_rate(dev, dist, rank, world, chunks=8, side=512, iters=3):
 def lotd_large_batch_rate(log2n=24):
     """the headline workload at 2^24 points (the size BASELINE.json's target is quoted on), in a fresh process"""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--log2-points", str(log2n), "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--log2-points", str(log2n), "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
         return {"error": (r.stderr or r.stdout)[-300:]}
     d = json.loads(line[-1])
-    return dict(workload=d["config"]["workload"], mpoints_per_s=d["value"], ms_per_step=d["ms_per_step"],
-                kernel_ms=d["kernel_ms"], whole_step_frac=d["roofline"]["whole_step_frac"])
+    rf = d["roofline"]
+    bpp = sum(v["algorithmic_bytes_per_point"] for v in rf["per_op"].values())
+    med = d["ms_per_step_median"]
+    return dict(workload=d["config"]["workload"], steps=d["steps"], warmup=d["warmup"], mpoints_per_s=d["value"],
+                ms_per_step=d["ms_per_step"], ms_per_step_median=med, ms_per_step_min_max=d["ms_per_step_min_max"],
+                kernel_ms=d["kernel_ms"], whole_step_frac=rf["whole_step_frac"],
+                frac_of_median_step=round(bpp * (1 << log2n) / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                per_kernel={k: {kk: v[kk] for kk in ("avg_us", "launches_per_step", "frac")} for k, v in rf["per_kernel"].items()})
 
 
 def lotd_half_rate(dev, log2n=20, iters=10):
@@ -717,7 +727,10 @@ def main():
         per_kernel = {}
         for k, us in kernel_us.items():
             kb = kernel_algorithmic_bytes(k, served[k])
-            ach = kb * N / (us * 1e-6) / 1e9
+            # bytes of ONE launch: a kernel that runs once per chunk of the batch (dL/dparam passes of 2^22 points; one
+            # launch per LDS-staged level is already in `served`) processes N / launches points each time
+            per_launch = max(1.0, kernel_launches[k] / (n_lds if k == "lotd_fwd_lds" and n_lds else 1))
+            ach = kb * (N / per_launch) / (us * 1e-6) / 1e9
             per_kernel[PROF_KERNELS[k]] = {"avg_us": round(us, 2), "launches_per_step": round(kernel_launches[k], 2),
                                            "algorithmic_bytes_per_point": kb, "achieved": round(ach, 1),
                                            "frac": round(ach / HBM_PEAK_GBPS, 4)}
@@ -730,6 +743,9 @@ def main():
             "unit": "Mpoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            # per-step GPU time from the event pairs around every step (fwd start -> bwd end): spread of the K timed steps
+            "ms_per_step_median": round(float(np.median([a[0].elapsed_time(b[1]) for a, b in zip(ev["fwd"], ev["bwd"])])), 4),
+            "ms_per_step_min_max": [round(float(f([a[0].elapsed_time(b[1]) for a, b in zip(ev["fwd"], ev["bwd"])])), 4) for f in (min, max)],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: 16-level Hash LoTD (gen_ngp_cfg: T=2^19, F=2, 6 Dense + 10 Hash), "

@@ -483,6 +483,38 @@ int nr3d_pack_composite_bwd(uint32_t P, const float *alphas, const float *vw, co
                             int normalize_depth, const float *mask, const float *depth, const float *g_mask,
                             const float *g_depth, const float *g_rgb, const float *g_vw, float *grad_alphas,
                             float *grad_t, float *grad_rgb, void *stream);
+/* -------------------------------------------------------------------------------------------------
+ * Ray-query glue (csrc/ray_glue.hip): the device-side steps between march, density query, pruning and composite that the
+ * reference runs as chains of ATen ops with host syncs in between.  No single reference kernel each; cited per entry.
+ * ---------------------------------------------------------------------------------------------- */
+/* alpha = 1 - exp(-sigma * delta)  (nr3d_lib/graphics/nerf/nerf_utils.py:23-24 applied to sigma * deltas,
+ * nerf_ray_query.py:126,178) and its gradient grad_sigma = grad_alpha * delta * exp(-sigma * delta).  [S] each. */
+int nr3d_tau_to_alpha_fwd(uint64_t S, const float *sigma, const float *delta, float *alpha, void *stream);
+int nr3d_tau_to_alpha_bwd(uint64_t S, const float *sigma, const float *delta, const float *grad_alpha, float *grad_sigma,
+                          void *stream);
+/* Post-processing of the marcher's outputs (nr3d_lib/graphics/raymarch/occgrid_raymarch.py:87-112: nonzero on the counts,
+ * index, .long()): packed_info int32 [n_rays, 2] -> the rays with >= 1 sample, ascending: ridx_hit int64 [n_hit],
+ * pack_infos int64 [n_hit, 2]; totals int64 [2] = {samples, n_hit} (the caller reads n_hit back; outputs sized n_rays).
+ * scan_tmp >= nr3d_scan_tmp_bytes(n_rays). */
+int nr3d_march_finish_rays(uint32_t n_rays, const int32_t *packed_info, int64_t *ridx_hit, int64_t *pack_infos,
+                           int64_t *totals, void *scan_tmp, void *stream);
+/* ... and per sample (same lines): ridx64 = (int64) ridx, deltas = t_ends - t_starts, samples [S, 3] =
+ * fma(rays_d[ridx], t_starts, rays_o[ridx]) (torch.addcmul).  Any output may be NULL. */
+int nr3d_march_finish_samples(uint64_t S, const float *rays_o, const float *rays_d, const int32_t *ridx,
+                              const float *t_starts, const float *t_ends, int64_t *ridx64, float *deltas, float *samples,
+                              void *stream);
+/* Visibility pruning (nr3d_lib/graphics/nerf/nerf_utils.py:64-98 packed_volume_render_compression + the index gathers
+ * of nerf_ray_query.py:128-137).  counts int64 [P] = kept samples per pack (nr3d_alpha_to_vw_forward's num_steps):
+ * begin_all [P] = new begin of EVERY pack; the packs that keep >= 1 sample, ascending: idx_out [P'] (tag[i] if tag is
+ * given, else i) and pack_infos_out int64 [P', 2]; totals int64 [2] = {kept samples, P'}. */
+int nr3d_prune_compact_packs(uint32_t P, const int64_t *counts, const int64_t *tag, int64_t *begin_all, int64_t *idx_out,
+                             int64_t *pack_infos_out, int64_t *totals, void *scan_tmp, void *stream);
+/* ... then the kept samples (selector uint8 [S], pack_infos = the un-pruned packs) move to their compact positions,
+ * ascending inside a pack: pidx int64 [S'] = their old indices, and up to four per-sample arrays are gathered in the same
+ * pass: f1, f2 float [S], f3 float [S, 3], l1 int64 [S] (each in/out pair optional). */
+int nr3d_prune_compact_samples(uint32_t P, const int64_t *pack_infos, const int64_t *begin_all, const uint8_t *selector,
+                               const float *f1, const float *f2, const float *f3, const int64_t *l1, int64_t *pidx,
+                               float *f1_out, float *f2_out, float *f3_out, int64_t *l1_out, void *stream);
 /* mark_pack_boundaries_cuda (:2765-2805): boundaries int32 [num]. */
 int nr3d_mark_pack_boundaries(uint64_t num, int dtype, const void *pack_ids, int32_t *boundaries, void *stream);
 

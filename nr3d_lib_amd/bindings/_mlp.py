@@ -109,8 +109,13 @@ def backward(desc: MLPDesc, x: torch.Tensor, dL_dy: torch.Tensor, packed: torch.
     g2 = g2 if (g2.stride(-1) == 1 or g2.shape[1] == 1) else g2.contiguous()
     n, dev = x2.shape[0], x.device
     has_bias = [True] * n_layers if has_bias is None else list(has_bias)
-    dWs = [torch.zeros(desc.dims[l + 1], desc.dims[l], dtype=torch.float32, device=dev) for l in range(n_layers)]
-    dbs = [torch.zeros(desc.dims[l + 1], dtype=torch.float32, device=dev) if has_bias[l] else None for l in range(n_layers)]
+    # the kernel ADDS its workgroups' partial sums into dW / db (one atomic per element and workgroup): all of them are views
+    # of ONE zero-filled buffer -- one fill launch instead of 2 per layer
+    sizes = [desc.dims[l + 1] * desc.dims[l] for l in range(n_layers)] + [desc.dims[l + 1] if has_bias[l] else 0 for l in range(n_layers)]
+    pool = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    parts = pool.split(sizes)
+    dWs = [parts[l].view(desc.dims[l + 1], desc.dims[l]) for l in range(n_layers)]
+    dbs = [parts[n_layers + l] if has_bias[l] else None for l in range(n_layers)]
     dx, gxs, gxf = None, desc.dims[0], 1
     if need_dx and xf != 1:
         dx, gxs, gxf = H.empty((desc.dims[0], n), dtype=torch.float32, device=dev).t(), 1, n

@@ -402,6 +402,78 @@ def packed_alpha_to_vw_forward(alphas, pack_infos, early_stop_eps, alpha_thre, c
     return w, None, None
 
 
+def packed_compression_compact(alphas, pack_infos, early_stop_eps, alpha_thre, tag=None, f1=None, f2=None, f3=None,
+                               l1=None, want_pidx=True):
+    """Visibility pruning in four launches and ONE readback: the compaction-mode alpha -> weights kernel (selector + kept
+    samples per pack), one scan that yields every pack's new begin AND the packs that keep >= 1 sample, one pass that moves
+    the kept samples -- replaces packed_alpha_to_vw_forward(compression) + 2 nonzero() + the index gathers of the caller
+    (nr3d_lib/graphics/nerf/nerf_utils.py:64-98, nerf_ray_query.py:128-137).
+    tag int64 [P] (e.g. the packs' ray indices) | None; per-sample arrays to carry along: f1, f2 float [S], f3 float [S, 3],
+    l1 int64 [S].  -> (idx of the useful packs (tag[idx] when tag is given) int64 [P'], pack_infos int64 [P', 2],
+    pidx int64 [S'] | None, f1', f2', f3', l1')"""
+    fn = "packed_compression_compact"
+    _chk_feats(fn, alphas, pack_infos, dims=(1,))
+    if alphas.dtype != torch.float32:
+        raise RuntimeError(f"{fn}: float32 only on this platform")
+    P, S, dev = pack_infos.shape[0], alphas.shape[0], alphas.device
+    H.require_gpu(tag, f1, f2, f3, l1)
+    for name, t, shape, dt in (("tag", tag, (P,), torch.int64), ("f1", f1, (S,), torch.float32), ("f2", f2, (S,), torch.float32),
+                               ("f3", f3, (S, 3), torch.float32), ("l1", l1, (S,), torch.int64)):
+        if t is not None and (t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous()):
+            raise RuntimeError(f"{fn}: Expected a contiguous {dt} {name} of shape {list(shape)}, got {t.dtype} {list(t.shape)}")
+    with torch.cuda.device(dev):
+        st = H.stream_of(alphas)
+        num = torch.zeros(P, dtype=torch.int64, device=dev)
+        sel = H.empty(S, dtype=torch.bool, device=dev)
+        H.check(H.lib().nr3d_alpha_to_vw_forward(H.u32(P), C.c_uint64(S), H.ptr(alphas), H.ptr(pack_infos), H.f32(early_stop_eps),
+                                                 H.f32(alpha_thre), None, H.ptr(num), H.ptr(sel), st))
+        begin_all = H.empty(P, dtype=torch.int64, device=dev)
+        idx = H.empty(P, dtype=torch.int64, device=dev)
+        cpi = H.empty((P, 2), dtype=torch.int64, device=dev)
+        totals = H.empty(2, dtype=torch.int64, device=dev)
+        H.check(H.lib().nr3d_prune_compact_packs(H.u32(P), H.ptr(num), H.ptr(tag), H.ptr(begin_all), H.ptr(idx), H.ptr(cpi),
+                                                 H.ptr(totals), H.ptr(_scan_tmp(P, dev)), st))
+        S2, P2 = (int(v) for v in totals.tolist())          # the one device->host sync
+        pidx = H.empty(S2, dtype=torch.int64, device=dev) if want_pidx else None
+        o1 = H.empty(S2, dtype=torch.float32, device=dev) if f1 is not None else None
+        o2 = H.empty(S2, dtype=torch.float32, device=dev) if f2 is not None else None
+        o3 = H.empty((S2, 3), dtype=torch.float32, device=dev) if f3 is not None else None
+        ol = H.empty(S2, dtype=torch.int64, device=dev) if l1 is not None else None
+        if S2 > 0:
+            H.check(H.lib().nr3d_prune_compact_samples(H.u32(P), H.ptr(pack_infos), H.ptr(begin_all), H.ptr(sel), H.ptr(f1),
+                                                       H.ptr(f2), H.ptr(f3), H.ptr(l1), H.ptr(pidx), H.ptr(o1), H.ptr(o2),
+                                                       H.ptr(o3), H.ptr(ol), st))
+    return idx[:P2], cpi[:P2], pidx, o1, o2, o3, ol
+
+
+def tau_to_alpha_forward(sigma, delta):
+    """alpha = 1 - exp(-sigma * delta), one launch (nerf_utils.py:23-24 on sigma * deltas)"""
+    fn = "tau_to_alpha_forward"
+    H.require_gpu(sigma, delta)
+    if sigma.dtype != torch.float32 or delta.dtype != torch.float32 or sigma.shape != delta.shape \
+            or not sigma.is_contiguous() or not delta.is_contiguous():
+        raise RuntimeError(f"{fn}: Expected contiguous float32 sigma / delta of the same shape")
+    with torch.cuda.device(sigma.device):
+        alpha = H.empty_like(sigma)
+        H.check(H.lib().nr3d_tau_to_alpha_fwd(C.c_uint64(sigma.numel()), H.ptr(sigma), H.ptr(delta), H.ptr(alpha),
+                                              H.stream_of(sigma)))
+    return alpha
+
+
+def tau_to_alpha_backward(sigma, delta, grad_alpha):
+    """grad_sigma = grad_alpha * delta * exp(-sigma * delta), one launch"""
+    fn = "tau_to_alpha_backward"
+    H.require_gpu(sigma, delta, grad_alpha)
+    for t in (delta, grad_alpha):
+        if t.dtype != torch.float32 or t.shape != sigma.shape or not t.is_contiguous():
+            raise RuntimeError(f"{fn}: Expected contiguous float32 tensors of sigma's shape")
+    with torch.cuda.device(sigma.device):
+        g = H.empty_like(sigma)
+        H.check(H.lib().nr3d_tau_to_alpha_bwd(C.c_uint64(sigma.numel()), H.ptr(sigma), H.ptr(delta), H.ptr(grad_alpha), H.ptr(g),
+                                              H.stream_of(sigma)))
+    return g
+
+
 def packed_alpha_to_vw_backward(weights, grad_weights, alphas, pack_infos, early_stop_eps, alpha_thre):
     fn = "packed_alpha_to_vw_backward"
     _chk_feats(fn, weights, pack_infos, dims=(1,))
@@ -451,12 +523,11 @@ def packed_composite_forward(alphas, t, rgb, pack_infos, rays_inds_hit, num_rays
         raise RuntimeError(f"{fn}: num_rays must equal the number of packs when rays_inds_hit is None")
     with torch.cuda.device(dev):
         vw = (H.empty if (packs_tile and P > 0) else torch.zeros)(S, dtype=torch.float32, device=dev)
-        mask = torch.zeros(int(num_rays), dtype=torch.float32, device=dev) if rays_inds_hit is not None else \
-            H.empty(P, dtype=torch.float32, device=dev)
-        depth = torch.zeros_like(mask) if rays_inds_hit is not None else H.empty_like(mask)
-        rgb_out = None
-        if rgb is not None:
-            rgb_out = (torch.zeros if rays_inds_hit is not None else H.empty)((int(num_rays), 3), dtype=torch.float32, device=dev)
+        # per-ray outputs: [mask | depth | rgb] views of one buffer (rays that are not hit keep zeros: one fill, not three)
+        nr = int(num_rays) if rays_inds_hit is not None else P
+        pool = (torch.zeros if rays_inds_hit is not None else H.empty)(nr * (5 if rgb is not None else 2), dtype=torch.float32, device=dev)
+        mask, depth = pool[:nr], pool[nr:2 * nr]
+        rgb_out = pool[2 * nr:].view(nr, 3) if rgb is not None else None
         H.check(H.lib().nr3d_pack_composite_fwd(H.u32(P), H.ptr(alphas), H.ptr(t), H.ptr(rgb), H.ptr(pack_infos),
                                                 H.ptr(rays_inds_hit), H.f32(early_stop_eps), H.f32(alpha_thre),
                                                 C.c_int(1 if normalize_depth else 0), H.ptr(vw), H.ptr(mask), H.ptr(depth),

@@ -14,8 +14,10 @@ from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
-from nr3d_lib_amd.graphics.nerf.nerf_utils import packed_alpha_to_vw, packed_volume_render_compression, tau_to_alpha
-from nr3d_lib_amd.graphics.pack_ops import packed_composite, packed_div, packed_sum
+from nr3d_lib_amd.graphics.nerf.nerf_utils import (packed_alpha_to_vw, packed_volume_render_compression, sigma_delta_to_alpha,
+                                                    tau_to_alpha)
+from nr3d_lib_amd.graphics.pack_ops import (packed_composite, packed_div, packed_sum,
+                                            packed_volume_render_compression_gather)
 from nr3d_lib_amd.profile import profile
 
 __all__ = ['nerf_ray_query_march_occ', 'composite_packed_volume_buffer']
@@ -97,13 +99,25 @@ def nerf_ray_query_march_occ(model, ray_tested: Dict[str, torch.Tensor], with_rg
                 alphas = bypass_alpha_fn(**kw)
             else:
                 sigmas = bypass_sigma_fn(**kw) if bypass_sigma_fn is not None else model.query_density(**kw)
-                alphas = tau_to_alpha(sigmas * deltas)
-            nidx_useful, pack_infos, pidx_useful = packed_volume_render_compression(alphas, marched.pack_infos)
+                alphas = sigma_delta_to_alpha(sigmas.view(-1), deltas.view(-1))
+            fused = (FUSED_PRUNE and alphas.is_cuda and alphas.dtype == torch.float32 and depth_samples.dtype == torch.float32
+                     and samples.dtype == torch.float32 and ridx_all.dtype == torch.int64)
+            if fused:
+                # selector -> compact packs + the kept samples' depth / delta / position / ray index in one pass, one readback
+                nidx_useful, pack_infos, kept = packed_volume_render_compression_gather(
+                    alphas, marched.pack_infos, pack_tag=ridx_hit, depths=depth_samples.view(-1), deltas=deltas.view(-1),
+                    samples=samples.view(-1, 3), sample_idx=ridx_all.view(-1))
+            else:
+                nidx_useful, pack_infos, pidx_useful = packed_volume_render_compression(alphas, marched.pack_infos)
         if nidx_useful.numel() == 0:
             return empty, {}
         details['render.num_per_ray0'] = marched.pack_infos[:, 1]
-        ridx_hit, ridx_all = ridx_hit[nidx_useful], ridx_all[pidx_useful]
-        depth_samples, deltas, samples = depth_samples[pidx_useful], deltas[pidx_useful], samples[pidx_useful]
+        if fused:
+            ridx_hit, ridx_all = kept['pack_tag'], kept['sample_idx']
+            depth_samples, deltas, samples = kept['depths'], kept['deltas'], kept['samples']
+        else:
+            ridx_hit, ridx_all = ridx_hit[nidx_useful], ridx_all[pidx_useful]
+            depth_samples, deltas, samples = depth_samples[pidx_useful], deltas[pidx_useful], samples[pidx_useful]
     details['render.num_per_ray'] = pack_infos[:, 1]
 
     # packs_tile: the packs of the marcher / the compaction cover every sample exactly once (no zero-fill in the composite)
@@ -119,12 +133,16 @@ def nerf_ray_query_march_occ(model, ray_tested: Dict[str, torch.Tensor], with_rg
         volume_buffer['rgb'] = net_out['rgb'].to(dtype)
     volume_buffer['deltas'] = deltas.to(dtype)
     volume_buffer['sigma'] = net_out['sigma'].to(dtype)
-    volume_buffer['opacity_alpha'] = tau_to_alpha(volume_buffer['sigma'] * volume_buffer['deltas'])
+    volume_buffer['opacity_alpha'] = sigma_delta_to_alpha(volume_buffer['sigma'], volume_buffer['deltas'])
     for k in _PASSTHROUGH:
         if k in net_out:
             volume_buffer[k] = net_out[k].to(dtype)
     return volume_buffer, details
 
+
+# True: pruning = compaction + gathers inside the library (packed_volume_render_compression_gather, one readback);
+# False: packed_volume_render_compression + index gathers as in the reference (cross-check)
+FUSED_PRUNE = True
 
 # True: one fused kernel each way (graphics.pack_ops.packed_composite); False: the reference's op chain
 # (packed_alpha_to_vw -> packed_sum -> packed_div -> packed_sum x2), kept for A/B measurements and as a cross-check

@@ -4,8 +4,9 @@ import torch
 
 from nr3d_lib_amd.graphics.pack_ops import (packed_alpha_to_vw, packed_cumprod, packed_cumsum,
                                             packed_volume_render_compression)
+from nr3d_lib_amd.bindings import _pack_ops as _backend
 
-__all__ = ['tau_to_alpha', 'packed_alpha_to_vw', 'packed_alpha_to_vw_v1', 'packed_alpha_to_vw_v2',
+__all__ = ['tau_to_alpha', 'sigma_delta_to_alpha', 'packed_alpha_to_vw', 'packed_alpha_to_vw_v1', 'packed_alpha_to_vw_v2',
            'packed_volume_render_compression', 'packed_tau_to_vw', 'packed_tau_alpha_to_vw', 'ray_alpha_to_vw',
            'ray_tau_to_vw', 'ray_tau_alpha_to_vw']
 
@@ -13,6 +14,34 @@ __all__ = ['tau_to_alpha', 'packed_alpha_to_vw', 'packed_alpha_to_vw_v1', 'packe
 def tau_to_alpha(tau: torch.Tensor) -> torch.Tensor:
     """opacity of an interval with optical depth ``tau`` (nerf_utils.py:23-24)"""
     return 1 - torch.exp(-tau)
+
+
+class _SigmaDeltaToAlpha(torch.autograd.Function):
+    """alpha = 1 - exp(-sigma * delta) as one kernel each way (the ray-query drivers' `tau_to_alpha(sigma * deltas)`,
+    nerf_ray_query.py:126,178: three element-wise launches forward and four backward in eager PyTorch)"""
+
+    @staticmethod
+    def forward(ctx, sigma, delta):
+        ctx.save_for_backward(sigma, delta)
+        return _backend.tau_to_alpha_forward(sigma, delta)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_alpha):
+        sigma, delta = ctx.saved_tensors
+        return _backend.tau_to_alpha_backward(sigma, delta, grad_alpha.contiguous()), None
+
+
+def sigma_delta_to_alpha(sigma: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
+    """``tau_to_alpha(sigma * delta)``; fused when both are float32 GPU tensors of one shape and ``delta`` needs no gradient
+    (interval lengths from the marcher), the plain expression otherwise"""
+    if sigma.is_cuda and sigma.dtype == torch.float32 and delta.dtype == torch.float32 and sigma.shape == delta.shape \
+            and not delta.requires_grad:
+        s, d = sigma.contiguous(), delta.contiguous()
+        if torch.is_grad_enabled() and s.requires_grad:
+            return _SigmaDeltaToAlpha.apply(s, d)
+        return _backend.tau_to_alpha_forward(s.detach(), d)
+    return tau_to_alpha(sigma * delta)
 
 
 def packed_alpha_to_vw_v1(alpha: torch.Tensor, pack_infos: torch.Tensor) -> torch.Tensor:

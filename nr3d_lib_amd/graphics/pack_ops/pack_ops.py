@@ -15,7 +15,8 @@ import nr3d_lib_amd.bindings._pack_ops as _backend
 __all__ = [
     'packed_sort_inplace', 'packed_sort', 'packed_searchsorted', 'packed_searchsorted_packed_vals',
     'packed_sum', 'packed_mean', 'packed_cumprod', 'packed_cumsum', 'packed_diff', 'packed_backward_diff',
-    'packed_invert_cdf', 'packed_alpha_to_vw', 'packed_volume_render_compression', 'packed_composite',
+    'packed_invert_cdf', 'packed_alpha_to_vw', 'packed_volume_render_compression',
+    'packed_volume_render_compression_gather', 'packed_composite',
     'packed_add', 'packed_sub', 'packed_mul', 'packed_div', 'packed_matmul',
     'packed_gt', 'packed_geq', 'packed_lt', 'packed_leq', 'packed_eq', 'packed_neq',
     'interleave_arange_simple', 'interleave_arange', 'interleave_linstep', 'interleave_linspace',
@@ -336,14 +337,40 @@ def packed_composite(alpha, t, rgb, pack_infos, rays_inds_hit=None, num_rays=Non
                                              alpha_thre, bool(normalize_depth), bool(packs_tile))
 
 
+# True: selector -> compact indices / pack_infos (+ gathers) inside the library, one readback
+# (bindings._pack_ops.packed_compression_compact); False: the reference's chain with two nonzero() (cross-check)
+FUSED_COMPRESSION = True
+
+
 @torch.no_grad()
 def packed_volume_render_compression(alpha, pack_infos, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0):
     """-> (indices of packs that keep >= 1 sample, their compact pack_infos, indices of kept samples)"""
+    if FUSED_COMPRESSION and alpha.is_cuda and alpha.dtype == torch.float32 and pack_infos.dtype == torch.int64:
+        nidx_useful, compact_pi, pidx, *_ = _backend.packed_compression_compact(alpha.contiguous().view(-1), pack_infos.contiguous(),
+                                                                               early_stop_eps, alpha_thre)
+        return nidx_useful, compact_pi, pidx
     _, compact_pi, selector = _backend.packed_alpha_to_vw_forward(alpha.contiguous(), pack_infos, early_stop_eps,
                                                                   alpha_thre, True)
     pidx = selector.nonzero().long()[..., 0]
     nidx_useful = (compact_pi[:, 1] > 0).nonzero()[..., 0]
     return nidx_useful, compact_pi[nidx_useful].long(), pidx
+
+
+@torch.no_grad()
+def packed_volume_render_compression_gather(alpha, pack_infos, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, *,
+                                            pack_tag=None, depths=None, deltas=None, samples=None, sample_idx=None):
+    """packed_volume_render_compression + what its callers do with the result, in the same pass over the kept samples
+    (nr3d_lib/graphics/nerf/nerf_ray_query.py:128-137): ``pack_tag`` int64 [P] (e.g. ray index of every pack) of the
+    useful packs, and ``depths`` / ``deltas`` float [S], ``samples`` float [S, 3], ``sample_idx`` int64 [S] of the kept
+    samples.  -> (nidx_useful, pack_infos, dict of the gathered arrays under the same names; 'pack_tag' -> tags)"""
+    nidx, cpi, _, d1, d2, d3, dl = _backend.packed_compression_compact(
+        alpha.contiguous().view(-1), pack_infos.contiguous(), early_stop_eps, alpha_thre, None,
+        None if depths is None else depths.contiguous(), None if deltas is None else deltas.contiguous(),
+        None if samples is None else samples.contiguous(), None if sample_idx is None else sample_idx.contiguous(), want_pidx=False)
+    out = dict(depths=d1, deltas=d2, samples=d3, sample_idx=dl)
+    if pack_tag is not None:
+        out['pack_tag'] = pack_tag[nidx]
+    return nidx, cpi, out
 
 
 # ------------------------------------------------------------------------------------------------

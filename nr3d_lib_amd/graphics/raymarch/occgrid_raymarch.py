@@ -37,6 +37,11 @@ def _as_depth(v, like):
     return v if isinstance(v, torch.Tensor) else like.new_full(like.shape[:-1], v)
 
 
+# True: the un-jittered post-processing runs as two kernels of the library (bindings._occ_grid.ray_marching_finished);
+# False: the reference's op chain below (kept for jitter-after-march and as the cross-check of the fused path)
+FUSED_FINISH = True
+
+
 def _finish(rays_o, rays_d, pack_infos, t_starts, t_ends, ridx, perturb_after):
     """shared post-processing of the raw marcher outputs"""
     ridx = ridx.long()
@@ -70,6 +75,15 @@ def occgrid_raymarch(occ_grid, rays_o, rays_d, near: Union[torch.Tensor, float],
     ctype = _contraction(constraction)
     if perturb and perturb_before_march:
         near = near + step_size * torch.rand_like(near)
+    if FUSED_FINISH and not (perturb and not perturb_before_march) and rays_o.dtype == torch.float32:
+        # no jitter after the march: the whole post-processing is two kernels behind the marcher (one readback in all)
+        m = _backend.ray_marching_finished(rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(),
+                                           roi.contiguous(), occ_grid.contiguous(), ctype, step_size, max_step_size, dt_gamma,
+                                           max_steps, True)
+        if m['n_hit'] == 0:
+            return RaymarchRetSingle(0, None, None, None, None, None, None, None, None)
+        return RaymarchRetSingle(m['n_hit'], m['ridx_hit'], m['samples'], m['t_starts'], m['deltas'], m['ridx'],
+                                 m['pack_infos'], m['gidx'].long(), None)
     pack_infos, t_starts, t_ends, ridx, gidx = _backend.ray_marching(
         rays_o.contiguous(), rays_d.contiguous(), near.contiguous(), far.contiguous(), roi.contiguous(),
         occ_grid.contiguous(), ctype, step_size, max_step_size, dt_gamma, max_steps, True)

@@ -172,6 +172,38 @@ def test_wrapper_record(oracle, dev):
     assert retb.num_hit_rays == 2 * len(hit) and int(retb.bidx.max()) == 1
 
 
+@pytest.mark.parametrize("side", [16, 200])
+def test_fused_march_finish_against_chain(oracle, dev, side):
+    """occgrid_raymarch: hit-ray compaction + per-sample epilogue inside the library (2 launches, readback shared with the
+    marcher's) against the reference's op chain (nonzero, index, .long(), sub, index_select x2, addcmul): every field
+    bit-identical (positions to one rounding) -- side 200 = 40 000 rays takes the three-launch scan, side 16 the single-workgroup one"""
+    import nr3d_lib_amd.graphics.raymarch.occgrid_raymarch as orm
+    o, d, near, far = pinhole_rays(side, seed=5)
+    grid = grids((32, 32, 32), 9)["shell"]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    recs = {}
+    for fused in (True, False):
+        orm.FUSED_FINISH = fused
+        try:
+            recs[fused] = orm.occgrid_raymarch(t(grid), t(o), t(d), t(near), t(far), step_size=0.02, max_steps=128)
+        finally:
+            orm.FUSED_FINISH = True
+    a, b = recs[True], recs[False]
+    assert a.num_hit_rays == b.num_hit_rays > 0
+    for name in ("ridx_hit", "samples", "depth_samples", "deltas", "ridx", "pack_infos", "gidx"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert x.dtype == y.dtype and x.shape == y.shape, name
+        if name == "samples":      # o + d * t: the kernel rounds once (fma, what the reference's CUDA addcmul contracts to), this
+            assert (x - y).abs().max() <= 1e-6, name        # platform's ATen addcmul twice -- one ulp of |position| <= 4
+        else:
+            assert torch.equal(x, y), name
+    ref = oracle.ray_marching(o, d, near, far, ROI, grid, 0, 0.02, 1e10, 0.0, 128, True)
+    hit = np.nonzero(ref[0][:, 1])[0]
+    assert_equal(a.ridx_hit, hit, "ridx_hit")
+    assert_equal(a.pack_infos, ref[0][hit].astype(np.int64), "pack_infos")
+    assert_equal(a.ridx, ref[3].astype(np.int64), "ridx")
+
+
 def test_sample_cache_and_second_march_agree(oracle, dev, monkeypatch):
     """emit = compaction of the samples cached by the count pass (default) vs. a second march (no cache):
     identical outputs, and both equal to the oracle"""

@@ -522,3 +522,66 @@ def test_c3_composite_shape(oracle, dev, P, composite_mode):
     assert_equal(ga, oracle.packed_alpha_to_vw_backward(rw, gw, alpha, pi, 1e-4, 0.0), "grad_alphas")
     assert_close(P.packed_sum(T(rw, dev), T(pi, dev)), oracle.packed_sum(rw, pi), name="packed_sum")
     _composite_case(oracle, dev, P, pi, S, 8, 1e-4, 0.0, True, True, True, composite_mode)
+
+
+# ------------------------------------------------------------------------------------------------
+# ray-query glue (csrc/ray_glue.hip): fused pruning and sigma -> alpha against the op chains they replace
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_packs,hi,empty", [(1, 40, 0.0), (37, 150, 0.1), (5000, 70, 0.3), (40000, 12, 0.2), (9, 0, 0.0)])
+def test_fused_compression_against_chain(oracle, dev, P, n_packs, hi, empty):
+    """packed_volume_render_compression(+ gathers): one scan + one compaction pass inside the library against the
+    reference's chain (compaction-mode alpha_to_vw -> nonzero x2 -> index gathers); integers bit-exact, and the oracle's
+    selector as the third opinion.  40 000 packs take the three-launch scan, the others the single-workgroup one."""
+    import nr3d_lib_amd.graphics.pack_ops.pack_ops as po
+    rng = np.random.default_rng(n_packs + hi)
+    pi, S = random_packs(rng, n_packs, 0, hi, empty)
+    alpha = (rng.random(S) ** 2).astype(np.float32)
+    alpha[rng.random(S) < 0.1] = 0.0
+    depths, deltas = rng.random(S).astype(np.float32), rng.random(S).astype(np.float32)
+    samples = rng.random((S, 3)).astype(np.float32)
+    sidx = rng.integers(0, 1 << 40, S).astype(np.int64)
+    tag = rng.integers(0, 1 << 40, n_packs).astype(np.int64)
+    eps, thre = 1e-2, 0.05
+    a_t, pi_t = T(alpha, dev), T(pi, dev)
+    outs = {}
+    for fused in (True, False):
+        po.FUSED_COMPRESSION = fused
+        try:
+            outs[fused] = po.packed_volume_render_compression(a_t, pi_t, eps, thre)
+        finally:
+            po.FUSED_COMPRESSION = True
+    for a, b in zip(outs[True], outs[False]):
+        assert a.dtype == b.dtype == torch.int64 and torch.equal(a, b)
+    nidx, cpi, pidx = outs[True]
+    _, _, sel_ref = oracle.packed_alpha_to_vw_forward(alpha, pi, eps, thre, True)
+    assert_equal(pidx, np.nonzero(sel_ref)[0], "kept samples")
+    nidx2, cpi2, kept = po.packed_volume_render_compression_gather(a_t, pi_t, eps, thre, pack_tag=T(tag, dev), depths=T(depths, dev),
+                                                                   deltas=T(deltas, dev), samples=T(samples, dev), sample_idx=T(sidx, dev))
+    assert torch.equal(nidx2, nidx) and torch.equal(cpi2, cpi)
+    k = pidx.cpu().numpy()
+    assert_equal(kept['pack_tag'], tag[nidx.cpu().numpy()], "pack tags")
+    assert_equal(kept['sample_idx'], sidx[k], "sample_idx")
+    for name, src in (("depths", depths), ("deltas", deltas), ("samples", samples)):
+        assert np.array_equal(kept[name].cpu().numpy(), src[k]), name
+    if S:
+        assert int(cpi[:, 1].sum()) == len(k) and (cpi[:, 1] > 0).all()
+
+
+def test_sigma_delta_to_alpha(dev):
+    from nr3d_lib_amd.graphics.nerf.nerf_utils import sigma_delta_to_alpha, tau_to_alpha
+    g = torch.Generator().manual_seed(3)
+    sigma = (torch.rand(10007, generator=g) * 40).to(dev).requires_grad_(True)
+    delta = (torch.rand(10007, generator=g) * 0.1).to(dev)
+    up = torch.randn(10007, generator=g).to(dev)
+    a = sigma_delta_to_alpha(sigma, delta)
+    a.backward(up)
+    s2 = sigma.detach().clone().requires_grad_(True)
+    a_ref = tau_to_alpha(s2 * delta)
+    a_ref.backward(up)
+    assert (a - a_ref).abs().max() <= 2e-7                       # one exp each, <= 1 ulp of values in [0, 1]
+    assert (sigma.grad - s2.grad).abs().max() <= 1e-6 * s2.grad.abs().max()
+    with torch.no_grad():
+        assert torch.equal(sigma_delta_to_alpha(sigma, delta), a.detach())
+    assert sigma_delta_to_alpha(sigma[:0], delta[:0]).numel() == 0
+    # shapes that do not match fall back to the plain expression
+    assert torch.allclose(sigma_delta_to_alpha(sigma.detach().view(-1, 1), delta.view(-1, 1)), a.detach().view(-1, 1), atol=2e-7)

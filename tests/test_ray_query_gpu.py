@@ -51,7 +51,7 @@ def test_volume_buffer_matches_oracle_chain(oracle, dev):
     import copy
     dens = copy.deepcopy(model.density).cpu()
     h = dens(torch.from_numpy(feat))
-    sigma_ref = (torch.nn.functional.softplus(h[:, 0] + 2.0) * 20.0).detach().numpy()
+    sigma_ref = (torch.nn.functional.softplus(h[:, 0]) * 20.0).detach().numpy()    # the +2 shift lives in the last bias
     np.testing.assert_allclose(vb["sigma"].cpu().numpy(), sigma_ref, rtol=2e-4, atol=1e-4)
     alpha_ref = 1 - np.exp(-sigma_ref * (te - ts)[:, 0])
     np.testing.assert_allclose(vb["opacity_alpha"].cpu().numpy(), alpha_ref, rtol=2e-4, atol=1e-5)

@@ -54,10 +54,13 @@ def main():
     G = sum(ent[t] * f * 4 for t, f in zip(TYPES, FEATS))                       # all gathers            1 936 B
     Gp = sum(ent[t] * f * 4 for t, f in zip(TYPES, FEATS) if t != "Dense")      # product-type factors   1 680 B
     E4 = 4 * meta.n_encoded_dims
-    model = {"fwd": 12 + G + E4,                               # x, gathers, y (the stored Jacobian, 3 E4, is not credited)
-             "bwd_dx": E4 + G + 12,                            # dL_dy, the gather a fused dL/dx needs, dL_dx
+    # per pass: the bytes THIS build's pass moves (element granular).  dL/dx and d(dL/dx)/d(dL_dy) stream the Jacobian the
+    # forward stored (3 E4 = 600 B/pt) instead of gathering again, and the forward writes it -- the model follows the
+    # build, so no pass can exceed the peak (round-2 review: the gather-based model gave "fractions" of 1.5 and 1.25).
+    model = {"fwd": 12 + G + E4 + 3 * E4,                      # x, gathers, y, the stored Jacobian
+             "bwd_dx": E4 + 3 * E4 + 12,                       # dL_dy, Jacobian, dL_dx                            812 B
              "bwd_dparam": 12 + E4 + Gp + 2 * G,               # x, dL_dy, other factors of product levels, scatter as RMW
-             "bwd_bwd_ddLdy": 12 + G + E4,
+             "bwd_bwd_ddLdy": 12 + 3 * E4 + E4,                # dL_ddLdx, Jacobian, dL_ddLdy                      812 B
              "bwd_bwd_dparam": 24 + E4 + Gp + 2 * G,
              "bwd_bwd_dx": 24 + E4 + G + 12}
     peak = 8000.0

@@ -46,14 +46,19 @@ class DemoField(nn.Module):
             if p is not self.grid:
                 with torch.no_grad():
                     p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() > 1 else 0.1))
+        with torch.no_grad():                               # sigma = 20 softplus(h0 + 2): the shift lives in the bias
+            last = [m for m in self.density.modules() if getattr(m, "bias", None) is not None][-1]
+            last.bias[0] += 2.0
+        self.register_buffer("_half", torch.tensor(0.5), persistent=False)
         self.accel = StaticOccGridAccel(occ_grid, step_size, max_steps)
         if device is not None:
             self.to(device)
 
     def _h(self, x):
-        feat = self.encoding(((x + 1) * 0.5).clamp(1e-6, 1 - 1e-6), self.grid)
+        # [-1, 1]^3 -> [0, 1]^3 in one launch (the encoder clamps to [1e-6, 1 - 1e-6] itself, lotd.py)
+        feat = self.encoding(torch.addcmul(self._half, x, self._half), self.grid)
         h = self.density(feat.float())
-        return torch.nn.functional.softplus(h[..., 0] + 2.0) * 20.0, h[..., 1:]
+        return torch.nn.functional.softplus(h[..., 0]) * 20.0, h[..., 1:]
 
     def query_density(self, x, **kw):
         return self._h(x)[0]
