@@ -313,15 +313,14 @@ template <> __device__ __forceinline__ void store_nt<__half>(__half *p, float v)
 // NR3D_FWD_DBG (timing experiments, results wrong by design): bit 0 no stores, bit 1 no gathers, bit 2 no x loads.
 // =============================================================================================
 constexpr int kPlSub = 2;                          // 32-point groups per wave
+// one work item = pseudo level q x the block's `chunk` of kPlPts * SUB points
 template <bool DYDX, typename PT, int SUB>
-__global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
-                                                   int32_t max_level, uint32_t smooth, const float *__restrict__ x,
-                                                   const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
-                                                   int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se, uint32_t dbg) {
+__device__ __forceinline__ void pl_item(uint32_t q, uint32_t chunk, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                        int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                        const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn, int64_t y_se,
+                                        float *__restrict__ dydx, int64_t d_sn, int64_t d_se, uint32_t dbg) {
 	constexpr uint32_t kGroup = 32;                        // points per wave and sub-step
 	constexpr uint32_t kPts = kPlPts * SUB;                // points per block
-	uint32_t q, chunk;
-	if (!decode_block(s, blockIdx.x, q, chunk)) return;
 	const uint32_t lane = threadIdx.x & 63u, side = lane & 1u, pl = lane >> 1;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint32_t w0 = chunk * kPts + wave * kGroup * SUB;      // first point of this wave
@@ -459,6 +458,22 @@ __global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lot
 		}
 	}
 }
+
+template <bool DYDX, typename PT, int SUB>
+__global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
+                                                   int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                   const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
+                                                   int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se, uint32_t dbg) {
+	uint32_t q, chunk;
+	if (!decode_block(s, blockIdx.x, q, chunk)) return;
+	pl_item<DYDX, PT, SUB>(q, chunk, md, N, max_level, smooth, x, params, y, y_sn, y_se, dydx, d_sn, d_se, dbg);
+}
+
+// Tried and dropped (round 3, profiles/r03e_dynamic_handout_experiment.txt): handing the items out dynamically -- resident
+// blocks pull batches from per-XCD queue counters and steal from the other XCDs' queues once theirs is empty, which would
+// even out the XCDs when ray-coherent samples make the coarse levels cheap.  Agent-scope atomics on one line serialise at
+// ~80 ns each on this part (they execute behind the per-XCD L2s): 28 672 grabs = 2.36 ms for a 0.35 ms kernel.  Counters
+// served by the XCD's own L2 (workgroup scope) would be fast but are invisible to the stealing XCDs.
 
 // =============================================================================================
 // Forward, LDS-staged: Dense levels of 2 features whose whole table fits one CU's LDS (NGP config: level 0 = 32 KiB,
