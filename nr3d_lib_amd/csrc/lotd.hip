@@ -25,6 +25,7 @@
 #include "lotd_device.h"
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 
 namespace nr3d {
 namespace lotd {
@@ -1106,6 +1107,13 @@ static uint32_t sched_mode_default() {
 	return (uint32_t)mode;
 }
 
+// NR3D_LOTD_SCHED_EXCL=0: the two-lane forward uses the cost-balanced work line like every other kernel (A/B)
+static bool sched_exclusive_enabled() {
+	static int on = -1;
+	if (on < 0) { const char *e = getenv("NR3D_LOTD_SCHED_EXCL"); on = e ? (atoi(e) != 0) : 1; }
+	return on != 0;
+}
+
 // estimated cost of one (point, pseudo level) item, in half L2 requests (see lotd_device.h, mode 3)
 static uint32_t level_cost(const nr3d_lotd_meta_t *m, uint32_t q, bool pairlane = false) {
 	const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
@@ -1131,11 +1139,57 @@ static Sched make_sched(uint32_t N, const nr3d_lotd_meta_t *m, uint32_t &n_block
 	s.n_pseudo = n_pseudo;
 	s.mode = sched_mode_default();
 	s.n_slots = div_up(n_pseudo, 8);
+	auto skipped = [&](uint32_t q) { return q < 64u && ((skip >> q) & 1ull); };
+	if (s.mode == 3 && pairlane && sched_exclusive_enabled()) {
+		// Two-lane forward (every level costs the same for spread-out points).  The 8 * floor(L / 8) LARGEST tables (ties: the
+		// finer level) are "owned": they are paired finest with least fine, and a pair of levels belongs to a pair of XCDs,
+		// each of which walks ITS half of the chunks of both levels -- one 4 MiB Hash table at a time in an XCD's L2, loaded by
+		// two XCDs instead of eight.  Every other level is split into 8 chunk ranges, one per XCD (small tables: loading one
+		// into each L2 costs microseconds).  Every XCD gets the same number of items, so spread-out points balance exactly
+		// (2^20 points: 351 -> 331 us against the cost-balanced work line, whose segments end mid-level), and the mix per
+		// XCD is even too: samples along rays coalesce in the coarse levels and not in the fine ones (per-level times on the
+		// full loop's 6.9 M samples, profiles/r03f_fwd_levels.txt: 58 us for levels 2-7, 77 / 105 / 129 for 8 / 9 / 10, 152
+		// for 11-15), so an XCD that owned only coarse levels would run dry early.
+		std::vector<uint32_t> live;
+		for (uint32_t q = 0; q < n_pseudo; ++q) if (!skipped(q)) live.push_back(q);
+		std::vector<uint32_t> by_size(live);
+		auto bytes_of = [&](uint32_t q) { const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]]; return (uint64_t)L.size * L.n_feats; };
+		std::sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) {
+			return bytes_of(a) != bytes_of(b) ? bytes_of(a) > bytes_of(b) : a > b; });
+		const size_t n_excl = live.size() / 8 * 8;
+		std::sort(by_size.begin(), by_size.begin() + n_excl, [](uint32_t a, uint32_t b) { return a > b; });      // owned: finest first
+		uint32_t nseg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		bool ok = !live.empty() && live.size() - n_excl + n_excl / 4 <= (size_t)kSchedSegs;
+		auto add = [&](int x, uint32_t q, uint32_t c0, uint32_t c1) {
+			if (c1 <= c0) return;
+			const uint32_t i = nseg[x]++;
+			s.seg_q[x][i] = q; s.seg_begin[x][i] = c0; s.seg_cum[x][i + 1] = s.seg_cum[x][i] + (c1 - c0);
+		};
+		if (ok) {
+			for (int x = 0; x < 8; ++x) s.seg_cum[x][0] = 0;
+			const uint32_t half = s.n_chunks / 2;
+			for (size_t i = 0; i < n_excl / 2; ++i) {               // level pair i = (i-th finest, i-th least fine) -> XCDs 2p, 2p + 1
+				const int p = (int)(i & 3u);
+				const uint32_t qa = by_size[i], qb = by_size[n_excl - 1 - i];
+				add(2 * p, qa, 0, half); add(2 * p, qb, 0, half);
+				add(2 * p + 1, qb, half, s.n_chunks); add(2 * p + 1, qa, half, s.n_chunks);
+			}
+			for (size_t k = n_excl; k < by_size.size(); ++k)
+				for (int x = 0; x < 8; ++x)
+					add(x, by_size[k], (uint32_t)((uint64_t)s.n_chunks * x / 8), (uint32_t)((uint64_t)s.n_chunks * (x + 1) / 8));
+			uint32_t max_blocks = 0;
+			for (int x = 0; x < 8; ++x) {
+				for (int i = nseg[x]; i < kSchedSegs; ++i) { s.seg_cum[x][i + 1] = s.seg_cum[x][i]; s.seg_q[x][i] = 0; s.seg_begin[x][i] = 0; }
+				max_blocks = s.seg_cum[x][kSchedSegs] > max_blocks ? s.seg_cum[x][kSchedSegs] : max_blocks;
+			}
+			n_blocks = 8u * max_blocks;
+			return s;
+		}
+	}
 	if (s.mode == 3) {
 		// work line: level q occupies n_chunks items of cost c_q each; XCD x takes the items that START in
 		// [x, x + 1) * total / 8
 		uint64_t total = 0;
-		auto skipped = [&](uint32_t q) { return q < 64u && ((skip >> q) & 1ull); };
 		for (uint32_t q = 0; q < n_pseudo; ++q) if (!skipped(q)) total += (uint64_t)level_cost(m, q, pairlane) * s.n_chunks;
 		uint32_t max_blocks = 0;
 		bool ok = total > 0;
@@ -1296,8 +1350,10 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 				                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
 		}
 	}
-	static int dbg = -1;
+	static int dbg = -1, only = -2;
 	if (dbg < 0) { const char *e = getenv("NR3D_FWD_DBG"); dbg = e ? atoi(e) : 0; }
+	if (only == -2) { const char *e = getenv("NR3D_FWD_ONLY_LEVEL"); only = e ? atoi(e) : -1; }      // timing experiments: one pseudo level
+	if (only >= 0) for (uint32_t q = 0; q < meta->n_pseudo_levels && q < 64u; ++q) if ((int)q != only) staged |= 1ull << q;
 	uint32_t n_blocks;
 	const Sched s = make_sched(N, meta, n_blocks, staged, (uint32_t)(kPlPts * kPlSub), true);
 	if (n_blocks != 0) {
