@@ -193,23 +193,22 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
     state = {}
 
     def one():
-        pi, ts, te, ridx, gidx = _occ_grid.ray_marching(o, d, near, far, roi, grid, _occ_grid.ContractionType.AABB,
-                                                        step, 1e10, 0.0, 512, True)
-        S = ts.shape[0]
+        # march (count + emit) and the post-processing every caller applies (hit rays, int64 packs, interval lengths: two
+        # launches, the readback shared with the marcher's), then sigma -> alpha in one launch
+        m = _occ_grid.ray_marching_finished(o, d, near, far, roi, grid, _occ_grid.ContractionType.AABB, step, 1e10, 0.0, 512, True)
+        tmid, pil = m["t_starts"], m["pack_infos"]
+        S = tmid.shape[0]
         if "sigma" not in state:       # per-sample inputs of the composite: fixed scene => fixed S
             state["sigma"] = (10.0 * torch.rand(S, generator=gen)).to(dev)
             state["rgb"] = torch.rand(S, 3, generator=gen).to(dev)
             state["g"] = [torch.randn(n, generator=gen).to(dev), torch.randn(n, generator=gen).to(dev),
                           torch.randn(n, 3, generator=gen).to(dev)]
-            state["hit"] = torch.arange(n, device=dev)
-        tmid = ts.squeeze(-1)
-        alpha = 1 - torch.exp(-state["sigma"] * (te - ts).squeeze(-1))
-        pil = pi.long()
+        alpha = _pack_ops.tau_to_alpha_forward(state["sigma"], m["deltas"])
         # the two launches behind graphics.pack_ops.packed_composite and its autograd backward, called directly (at 4096
         # rays the op is launch bound: no autograd graph bookkeeping inside the timed loop)
-        vw, mask, depth, rgb = _pack_ops.packed_composite_forward(alpha, tmid, state["rgb"], pil, state["hit"], n, 1e-4, 0.0, True,
+        vw, mask, depth, rgb = _pack_ops.packed_composite_forward(alpha, tmid, state["rgb"], pil, m["ridx_hit"], n, 1e-4, 0.0, True,
                                                                   packs_tile=True)     # a marcher's packs cover every sample
-        ga, gt, gc = _pack_ops.packed_composite_backward(alpha, vw, tmid, state["rgb"], pil, state["hit"], 1e-4, 0.0, True,
+        ga, gt, gc = _pack_ops.packed_composite_backward(alpha, vw, tmid, state["rgb"], pil, m["ridx_hit"], 1e-4, 0.0, True,
                                                          mask, depth, state["g"][0], state["g"][1], state["g"][2], None,
                                                          packs_tile=True)
         return S, mask, ga
@@ -233,7 +232,8 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
     out = dict(workload=f"configs[2]: occ 128^3 march + fused alpha composite fwd+bwd, {n} rays x <= 512 samples",
                samples=int(S), ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4),
                kernel_us_per_iter={k: round(v, 2) for k, v in kus.items()},
-               launches_per_iter="march 2 (count + emit) + scan 1 (3 above 32768 rays), composite 1 + 1")
+               launches_per_iter="march 2 (count + emit) + scan 1 (3 above 32768 rays) + finish 2 (hit rays, per-sample epilogue), "
+                                 "sigma -> alpha 1, composite 1 + 1 (+ one zero fill of the per-ray outputs); one device->host readback")
     if cpu_seconds > 0:
         # the oracle's marcher counts the grid probes of the byte model, and is the CPU baseline next to the chain
         probes, S_r, base = cpu_baseline(None, c3=((o_c, d_c, near_c, far_c, roi_c, grid_c), n, step, cpu_seconds))

@@ -95,9 +95,9 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
             totals = H.empty(2, dtype=torch.int64, device=dev)
             H.check(H.lib().nr3d_march_finish_rays(H.u32(n), H.ptr(packed_info), H.ptr(ridx_hit), H.ptr(pack_infos),
                                                    H.ptr(totals), H.ptr(tmp), st))
-            S, n_hit = (int(v) for v in totals.tolist())
+            S, n_hit = H.read_i64(totals)
         else:
-            S = int(total.item())          # the single device->host sync of this op
+            S = H.read_i64(total)[0]       # the single device->host sync of this op
         t_starts = H.empty((S, 1), dtype=torch.float32, device=dev)
         t_ends = H.empty((S, 1), dtype=torch.float32, device=dev)
         ridx = H.empty(S, dtype=torch.int32, device=dev)
@@ -188,7 +188,7 @@ def forest_ray_marching(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, se
                   H.f32(max_step_size), H.f32(dt_gamma))
         H.check(H.lib().nr3d_forest_ray_marching_count(C.byref(fc), H.u32(n), *common, H.u32(max_steps),
                                                        H.ptr(packed_info), H.ptr(total), H.ptr(tmp), st))
-        S = int(total.item())          # the single device->host sync of this op
+        S = H.read_i64(total)[0]       # the single device->host sync of this op
         t_starts = H.empty((S, 1), dtype=torch.float32, device=dev)
         t_ends = H.empty((S, 1), dtype=torch.float32, device=dev)
         ridx = H.empty(S, dtype=torch.int32, device=dev)

@@ -72,7 +72,7 @@ def _pack_infos_from_n(n_per_pack):
     tmp = _scan_tmp(P, dev)
     H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(n_per_pack), H.ptr(pi), H.ptr(total), H.ptr(tmp),
                                            H.stream_of(n_per_pack)))
-    return pi, int(total.item())
+    return pi, H.read_i64(total)[0]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -433,7 +433,7 @@ def packed_compression_compact(alphas, pack_infos, early_stop_eps, alpha_thre, t
         totals = H.empty(2, dtype=torch.int64, device=dev)
         H.check(H.lib().nr3d_prune_compact_packs(H.u32(P), H.ptr(num), H.ptr(tag), H.ptr(begin_all), H.ptr(idx), H.ptr(cpi),
                                                  H.ptr(totals), H.ptr(_scan_tmp(P, dev)), st))
-        S2, P2 = (int(v) for v in totals.tolist())          # the one device->host sync
+        S2, P2 = H.read_i64(totals)                         # the one device->host sync
         pidx = H.empty(S2, dtype=torch.int64, device=dev) if want_pidx else None
         o1 = H.empty(S2, dtype=torch.float32, device=dev) if f1 is not None else None
         o2 = H.empty(S2, dtype=torch.float32, device=dev) if f2 is not None else None

@@ -10,7 +10,8 @@ import torch
 import torch.nn as nn
 
 from .ema_single import _voxel_index_table, get_occ_val_fn
-from .utils import binarize, sample_pts_in_voxels, update_batched_occ_val_grid_, update_batched_occ_val_grid_idx_
+from .utils import (binarize, resolution_tensor, sample_pts_in_voxels, update_batched_occ_val_grid_,
+                    update_batched_occ_val_grid_idx_)
 
 __all__ = ['OccGridEmaBatched']
 
@@ -26,14 +27,7 @@ class OccGridEmaBatched(nn.Module):
                  update_from_net_cfg=dict(), update_from_samples_cfg=dict(), dtype=torch.float, device=None, group=None) -> None:
         super().__init__()
         self.num_batches, self.dtype = num_batches, dtype
-        if isinstance(resolution, int):
-            resolution = [resolution] * self.NUM_DIM
-        if isinstance(resolution, (list, tuple, np.ndarray)):
-            resolution = torch.tensor(resolution, dtype=torch.int32, device=device)
-        elif isinstance(resolution, torch.Tensor):
-            resolution = resolution.to(dtype=torch.int32, device=device)
-        else:
-            raise RuntimeError(f"Invalid type of resolution={type(resolution)}")
+        resolution = resolution_tensor(resolution, self.NUM_DIM, device)
         shape = [num_batches, *resolution.tolist()]
         self.register_buffer('is_initialized', torch.tensor([False], dtype=torch.bool), persistent=True)
         self.register_buffer("resolution", resolution, persistent=False)

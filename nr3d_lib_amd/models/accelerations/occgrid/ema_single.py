@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .utils import binarize, sample_pts_in_voxels, update_occ_val_grid_, update_occ_val_grid_idx_
+from .utils import binarize, resolution_tensor, sample_pts_in_voxels, update_occ_val_grid_, update_occ_val_grid_idx_
 
 __all__ = ['OccGridEma', 'get_occ_val_fn', 'sdf_to_occ_val', 'normalized_logistic_density']
 
@@ -61,14 +61,7 @@ class OccGridEma(nn.Module):
                  update_from_samples_cfg=dict(), dtype=torch.float, device=None, group=None) -> None:
         super().__init__()
         self.dtype = dtype
-        if isinstance(resolution, int):
-            resolution = [resolution] * self.NUM_DIM
-        if isinstance(resolution, (list, tuple, np.ndarray)):
-            resolution = torch.tensor(resolution, dtype=torch.int32, device=device)
-        elif isinstance(resolution, torch.Tensor):
-            resolution = resolution.to(dtype=torch.int32, device=device)
-        else:
-            raise RuntimeError(f"Invalid type of resolution={type(resolution)}")
+        resolution = resolution_tensor(resolution, self.NUM_DIM, device)
         shape = resolution.tolist()
         self.register_buffer('is_initialized', torch.tensor([False], dtype=torch.bool), persistent=True)
         self.register_buffer("resolution", resolution, persistent=False)

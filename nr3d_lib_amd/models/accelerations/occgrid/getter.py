@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from .ema_single import get_occ_val_fn
-from .utils import binarize
+from .utils import binarize, resolution_tensor
 
 __all__ = ['OccGridGetter']
 
@@ -30,14 +30,7 @@ class OccGridGetter(nn.Module):
                  num_pts_per_batch: int = 2 ** 18, num_pts: int = None, dtype=torch.float, device=None) -> None:
         super().__init__()
         self.dtype = dtype
-        if isinstance(resolution, int):
-            resolution = [resolution] * self.NUM_DIM
-        if isinstance(resolution, (list, tuple, np.ndarray)):
-            resolution = torch.tensor(resolution, dtype=torch.int32, device=device)
-        elif isinstance(resolution, torch.Tensor):
-            resolution = resolution.to(dtype=torch.int32, device=device)
-        else:
-            raise RuntimeError(f"Invalid type of resolution={type(resolution)}")
+        resolution = resolution_tensor(resolution, self.NUM_DIM, device)
         self.register_buffer("resolution", resolution, persistent=False)
         axes = [torch.arange(r, device=device) for r in resolution.tolist()]
         self.register_buffer("gidx_full", torch.stack(torch.meshgrid(axes, indexing='ij'), dim=-1).view(-1, self.NUM_DIM),

@@ -20,6 +20,24 @@ err_msg_empty_occ = ("Occupancy grid becomes empty during training. Your model/a
                      "incorrect. Please check configs and tensorboard.")
 
 
+
+def resolution_tensor(resolution, num_dim: int, device=None) -> torch.Tensor:
+    """int32 [num_dim] voxel counts from what the accelerator constructors accept: one int (a cube), a sequence / array of
+    ``num_dim`` ints, or a tensor"""
+    if torch.is_tensor(resolution):
+        res = resolution.to(dtype=torch.int32, device=device).reshape(-1)
+    else:
+        try:
+            vals = [int(v) for v in resolution]
+        except TypeError:
+            if not isinstance(resolution, (int,)) or isinstance(resolution, bool):
+                raise RuntimeError(f"Invalid type of resolution={type(resolution)}")
+            vals = [int(resolution)] * num_dim
+        res = torch.tensor(vals, dtype=torch.int32, device=device)
+    if res.numel() != num_dim:
+        raise RuntimeError(f"resolution: expected {num_dim} entries, got {res.numel()}")
+    return res
+
 def sample_pts_in_voxels(gidx: torch.Tensor, num_pts: int, resolution: torch.Tensor, device=None,
                          dtype=torch.float) -> Tuple[torch.Tensor, torch.Tensor]:
     """uniform points in [-1, 1] inside the voxels ``gidx`` [N, num_dim]; returns (pts, voxel index of each point).

@@ -198,16 +198,13 @@ class MLP(nn.Module):
             for layer in self.layers:
                 params += [layer.weight, layer.bias]
             return FusedMLPFunction.apply(desc, self._needs_grad, x, *params)
-        for i, layer in enumerate(self.layers):
-            if i == 0:
-                h = layer(x, max_channel=input_max_channel)
-            elif i in self.skips:
-                h = layer(torch.cat([h, x], dim=-1))
-            elif i == self.D:
+        # layer-by-layer path: layer 0 may see a truncated input, skip layers see [h, x], the input of the output layer
+        # (index D) is what return_last hands back
+        h, last_h = self.layers[0](x, max_channel=input_max_channel), None
+        for i in range(1, len(self.layers)):
+            if i == self.D and i not in self.skips:
                 last_h = h
-                h = layer(h)
-            else:
-                h = layer(h)
+            h = self.layers[i](torch.cat([h, x], dim=-1) if i in self.skips else h)
         return (h, last_h) if return_last else h
 
 
