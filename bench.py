@@ -60,7 +60,7 @@ def kernel_algorithmic_bytes(kernel, n_levels_served, F=2, D=3, C=8):
 
 
 # timers of include/nr3d_hip.h (NR3D_PROF_*) -> kernel names as rocprofv3 prints them (the default configuration)
-PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true, float, 2>", "lotd_fwd_lds": "k_fwd_lds<true, float>",
+PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true, float, 2>", "lotd_fwd_lds": "k_fwd_lds<true, float, 2>",
                 "lotd_contract_dx": "k_contract_dx_rowmajor<3, float>", "lotd_bin": "k_pair_bin<1024>",
                 "lotd_accum": "k_pair_accum<4, true>", "lotd_direct": "k_pair_direct<true>"}
 LIVE_TIMER = "lotd_fwd"      # the dominant kernel: timed inside the timed region (2 events per step); the rest in an extra pass
@@ -688,8 +688,12 @@ def main():
             kernel_launches[k] = n / n_extra
     if live[1]:
         kernel_us[LIVE_TIMER] = live[0] / live[1] * 1e3           # the live figure replaces the extra-pass one
+    per_rank_ms = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)                          # every rank's own time: what the slowest-rank figure hides
+        per_rank_ms = [round(float(v.item()) / args.steps * 1e3, 4) for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -720,16 +724,20 @@ def main():
         # dominant kernel = largest time per step; levels it serves: the LDS-staged levels belong to k_fwd_lds
         per_step_us = {k: kernel_us[k] * kernel_launches[k] for k in kernel_us}
         dom = max(per_step_us, key=per_step_us.get)
-        n_lds = int(round(kernel_launches.get("lotd_fwd_lds", 0)))
+        # levels the forward stages in LDS (lotd.hip: Dense, 2 features, table <= 96 KiB, N >= 2^18); one launch holds up
+        # to two of them (<= 150 KiB together)
+        lds_launches = int(round(kernel_launches.get("lotd_fwd_lds", 0)))
+        n_lds = sum(1 for t, f, sz in zip(meta.level_types, meta.level_n_feats, meta.level_sizes)
+                    if t == 0 and f == 2 and sz * 8 <= 96 * 1024) if lds_launches else 0
         n_dir = int(H.lib().nr3d_lotd_pair_direct_levels(ctypes.byref(meta._cmeta()), ctypes.c_uint32(min(N, 1 << 22))))
-        served = {"lotd_fwd": L_all - n_lds, "lotd_fwd_lds": 1, "lotd_contract_dx": L_all, "lotd_bin": L_all - n_dir,
+        served = {"lotd_fwd": L_all - n_lds, "lotd_fwd_lds": max(1, n_lds // max(1, lds_launches)), "lotd_contract_dx": L_all, "lotd_bin": L_all - n_dir,
                   "lotd_accum": L_all - n_dir, "lotd_direct": max(n_dir, 1)}
         per_kernel = {}
         for k, us in kernel_us.items():
             kb = kernel_algorithmic_bytes(k, served[k])
             # bytes of ONE launch: a kernel that runs once per chunk of the batch (dL/dparam passes of 2^22 points; one
             # launch per LDS-staged level is already in `served`) processes N / launches points each time
-            per_launch = max(1.0, kernel_launches[k] / (n_lds if k == "lotd_fwd_lds" and n_lds else 1))
+            per_launch = max(1.0, kernel_launches[k] / (lds_launches if k == "lotd_fwd_lds" and lds_launches else 1))
             ach = kb * (N / per_launch) / (us * 1e-6) / 1e9
             per_kernel[PROF_KERNELS[k]] = {"avg_us": round(us, 2), "launches_per_step": round(kernel_launches[k], 2),
                                            "algorithmic_bytes_per_point": kb, "achieved": round(ach, 1),
@@ -755,7 +763,8 @@ def main():
                                        f"(points sharded; all-reduce of dL/dparam, {reduce_mode[0]}"
                                        + (f"; untimed trial ms/step {reduce_trial}" if reduce_trial else "")
                                        + "; kernel_ms.bwd includes the reduction)")
-                                      if dist is not None else "single GPU"},
+                                      if dist is not None else "single GPU",
+                       **({"per_rank_ms_per_step": per_rank_ms, "allreduce_mode": reduce_mode[0]} if dist is not None else {})},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             # the dominant KERNEL (largest HIP-event time per step), SURVEY 8(d) bytes of the levels one launch serves
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": per_kernel[dom_name]["achieved"],

@@ -242,6 +242,29 @@ def _f32c(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
+_P32_CACHE = {}
+
+
+def _p32(params):
+    """fp32 working copy of a parameter table that is not served natively in half (product-type levels, batched tables --
+    small tables in practice: a VM / CP / NPlane level is planes and lines, configs[3] has 8 MB in all).  The copy is keyed on
+    the tensor's storage and version counter: the forward, the backward and the second-order calls of one step (same
+    parameters, same version) share ONE conversion instead of converting the table once per call; an in-place update (an
+    optimizer step) bumps the version and the next call converts again.  One entry per device."""
+    p = params.detach()
+    if p.dtype == torch.float32:
+        return p
+    key = (p.data_ptr(), p._version, p.numel(), p.dtype)
+    hit = _P32_CACHE.get(p.device)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    p32 = p.float()
+    # the entry holds the half table's STORAGE: while it is cached its address cannot be handed to another tensor (the
+    # caching allocator would otherwise give a later temporary the same data_ptr with version 0 -> a stale hit)
+    _P32_CACHE[p.device] = (key, p32, p.untyped_storage())
+    return p32
+
+
 HVP_WORKSPACE_MAX_BYTES = 8 << 30      # largest per-call scratch of the level-parallel d(dL/dx)/dx (beyond it: lane-serial kernel)
 NATIVE_HALF = True       # False: half params always go through fp32 copies (A/B measurements)
 
@@ -309,7 +332,7 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
     batched = batch_inds is not None or batch_offsets is not None or bds != 0
     native = _native_half(m, params, batched)
     x32 = _f32c(input.detach())
-    p32 = params.detach() if native else _f32c(params.detach())
+    p32 = params.detach() if native else _p32(params)
     pcode = H.F16 if native else H.F32
     dev = input.device
     with torch.cuda.device(dev):
@@ -430,7 +453,7 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                     H.ptr(_f32c(input.detach())), H.i32(max_level), C.c_int(H.F16 if native else H.F32), C.c_int(1),
                     H.ptr(dL_dparam), H.ptr(ws), C.c_uint64(wsb), st))
             elif need_param_grad and N > 0:
-                x32, p32 = _f32c(input.detach()), _f32c(params.detach())
+                x32, p32 = _f32c(input.detach()), _p32(params)
                 nbat = _n_batches(m, p32, batch_offsets, batched)
                 ws, wsb = _dparam_workspace(m, N, dev, nbat)
                 if gT is not None:
@@ -513,7 +536,7 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
         v32 = _f32c(dL_ddLdx.detach())
         g32 = _f32c(dL_dy.detach())
         gsn, gse = _strides2(g32)
-        x32, p32 = _f32c(input.detach()), _f32c(params.detach())
+        x32, p32 = _f32c(input.detach()), _p32(params)
         cm, md = C.byref(m._cmeta()), H.ptr(m._dev(dev))
         tag = ("dx" if need_dx else "") + ("dp" if need_dp else "") + ("dLdy" if need_dLdy else "")
         with _Prof(m, f"LoTD{D}-bwd2-{tag}", N):

@@ -486,82 +486,95 @@ __global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lot
 constexpr int kLdsThreads = 1024;
 constexpr uint32_t kLdsPts = 4096;                 // points per workgroup
 constexpr uint32_t kLdsMaxBytes = 96 * 1024;       // table bytes a level may have to be staged
+constexpr uint32_t kLdsGroupBytes = 150 * 1024;    // ... and the tables one launch holds together (160 KiB of LDS per CU)
 
-template <bool DYDX, typename PT>
-__global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N, uint32_t q,
+// NL levels per launch (round 3): the two coarsest NGP levels (32 + 85 KiB) share one workgroup -- x is read once, one
+// launch instead of two (2 x 13 us -> <see DESIGN>).  q[l] = pseudo level, its table at float2 offset lds_off[l].
+struct LdsLevels { uint32_t q[2]; uint32_t lds_off[2]; };
+
+template <bool DYDX, typename PT, int NL>
+__global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N, LdsLevels lv,
                                                          uint32_t smooth, const float *__restrict__ x,
                                                          const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
                                                          int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
-	extern __shared__ __attribute__((aligned(16))) float2 tab[];
-	const uint32_t level = meta_level_of(md, q);
-	const Lvl L = load_level(md, level);
-	const char *__restrict__ src = reinterpret_cast<const char *>(params + L.off);
-	for (uint32_t e = threadIdx.x; e < L.size; e += kLdsThreads) tab[e] = load_pair<PT>(src + (size_t)e * (2 * sizeof(PT)));
+	extern __shared__ __attribute__((aligned(16))) float2 tab_all[];
+	Lvl L[NL];
+#pragma unroll
+	for (int l = 0; l < NL; ++l) {
+		L[l] = load_level(md, meta_level_of(md, lv.q[l]));
+		const char *__restrict__ src = reinterpret_cast<const char *>(params + L[l].off);
+		float2 *tab = tab_all + lv.lds_off[l];
+		for (uint32_t e = threadIdx.x; e < L[l].size; e += kLdsThreads) tab[e] = load_pair<PT>(src + (size_t)e * (2 * sizeof(PT)));
+	}
 	__syncthreads();
-	const float sc0 = (float)(L.res[0] - 2u), sc1 = (float)(L.res[1] - 2u), sc2 = (float)(L.res[2] - 2u);
-	const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	// outputs: uniform base of the wave's 64 points + 32-bit lane offset (host-checked), as in k_fwd_pairlane
 	const uint32_t y_lane = (uint32_t)((int64_t)lane * y_sn) * (uint32_t)sizeof(PT);
 	const uint32_t d_lane = DYDX ? (uint32_t)((int64_t)lane * d_sn) * 4u : 0u;
 	const uint32_t ye = (uint32_t)(y_se * (int64_t)sizeof(PT)), de = DYDX ? (uint32_t)(d_se * 4) : 0u;
-#pragma unroll 2
+#pragma unroll 1
 	for (uint32_t k4 = 0; k4 < kLdsPts / kLdsThreads; ++k4) {
 		const uint32_t g0 = blockIdx.x * kLdsPts + k4 * kLdsThreads + wave * 64u;      // uniform
 		if (g0 >= N) break;
 		const uint32_t i = g0 + lane, ic = i < N ? i : N - 1u;
 		const float *px = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + (size_t)g0 * 12u + (ic - g0) * 12u);
 		const float x0 = px[0], x1 = px[1], x2 = px[2];
-		// cell locator (explicit fma: decides the integer cell, must match the oracle bit for bit)
-		const float v0 = __fmaf_rn(x0, sc0, 0.5f), v1 = __fmaf_rn(x1, sc1, 0.5f), v2 = __fmaf_rn(x2, sc2, 0.5f);
-		const float f0 = floorf(v0), f1 = floorf(v1), f2 = floorf(v2);
-		float t0 = v0 - f0, t1 = v1 - f1, t2 = v2 - f2;
-		float dw0 = sc0, dw1 = sc1, dw2 = sc2;             // scale * w'
-		if (smooth) {
-			dw0 *= 6.0f * t0 * (1.0f - t0); dw1 *= 6.0f * t1 * (1.0f - t1); dw2 *= 6.0f * t2 * (1.0f - t2);
-			t0 = t0 * t0 * __fmaf_rn(-2.0f, t0, 3.0f); t1 = t1 * t1 * __fmaf_rn(-2.0f, t1, 3.0f); t2 = t2 * t2 * __fmaf_rn(-2.0f, t2, 3.0f);
-		}
-		const uint32_t e00 = ((uint32_t)f0 * L.res[1] + (uint32_t)f1) * L.res[2] + (uint32_t)f2;
-		const uint32_t e[4] = {e00, e00 + sx, e00 + sy, e00 + sx + sy};
-		// the lerp tree of k_fwd_pairlane for a Dense level (pair dim z, then x, then y), both features in one lane: feature 0
-		// with the arithmetic of the pair's side-0 lane (keep the lower corner, weight w), feature 1 with the side-1 lane's
-		// (keep the upper corner, weight 1 - w, difference negated) -- the two kernels give the same bits
-		const float w1 = 1.0f - t2;
-		float2 b[4], d[4];
 #pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			const float2 lo = tab[e[m]], hi = tab[e[m] + 1u];
-			d[m] = make_float2(hi.x - lo.x, lo.y - hi.y);
-			b[m] = make_float2(__fmaf_rn(t2, d[m].x, lo.x), __fmaf_rn(w1, d[m].y, hi.y));
-		}
-		float yv[2], gx[2], gy[2], gz[2];
-#pragma unroll
-		for (int f = 0; f < 2; ++f) {
-			auto c = [f](const float2 &v) { return f ? v.y : v.x; };
-			const float cA0 = c(b[1]) - c(b[0]), cA1 = c(b[3]) - c(b[2]);
-			const float dA0 = __fmaf_rn(t0, cA0, c(b[0])), dA1 = __fmaf_rn(t0, cA1, c(b[2]));
-			const float eB = dA1 - dA0;
-			yv[f] = __fmaf_rn(t1, eB, dA0);
-			if (DYDX) {
-				const float gA = __fmaf_rn(t1, cA1 - cA0, cA0);
-				const float p0 = __fmaf_rn(t0, c(d[1]) - c(d[0]), c(d[0])), p1 = __fmaf_rn(t0, c(d[3]) - c(d[2]), c(d[2]));
-				const float gP = __fmaf_rn(t1, p1 - p0, p0);
-				gx[f] = gA * dw0; gy[f] = eB * dw1; gz[f] = gP * (f ? -dw2 : dw2);
+		for (int l = 0; l < NL; ++l) {
+			const float2 *__restrict__ tab = tab_all + lv.lds_off[l];
+			const float sc0 = (float)(L[l].res[0] - 2u), sc1 = (float)(L[l].res[1] - 2u), sc2 = (float)(L[l].res[2] - 2u);
+			const uint32_t sx = L[l].res[1] * L[l].res[2], sy = L[l].res[2];
+			// cell locator (explicit fma: decides the integer cell, must match the oracle bit for bit)
+			const float v0 = __fmaf_rn(x0, sc0, 0.5f), v1 = __fmaf_rn(x1, sc1, 0.5f), v2 = __fmaf_rn(x2, sc2, 0.5f);
+			const float f0 = floorf(v0), f1 = floorf(v1), f2 = floorf(v2);
+			float t0 = v0 - f0, t1 = v1 - f1, t2 = v2 - f2;
+			float dw0 = sc0, dw1 = sc1, dw2 = sc2;             // scale * w'
+			if (smooth) {
+				dw0 *= 6.0f * t0 * (1.0f - t0); dw1 *= 6.0f * t1 * (1.0f - t1); dw2 *= 6.0f * t2 * (1.0f - t2);
+				t0 = t0 * t0 * __fmaf_rn(-2.0f, t0, 3.0f); t1 = t1 * t1 * __fmaf_rn(-2.0f, t1, 3.0f); t2 = t2 * t2 * __fmaf_rn(-2.0f, t2, 3.0f);
 			}
-		}
-		if (i < N) {
-			char *yb = reinterpret_cast<char *>(y) + ((int64_t)g0 * y_sn + (int64_t)(q * 2u) * y_se) * (int64_t)sizeof(PT);
-			store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane), yv[0]);
-			store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane + ye), yv[1]);
-			if (DYDX) {
-				char *db = reinterpret_cast<char *>(dydx) + ((int64_t)g0 * d_sn + (int64_t)(q * 2u) * d_se) * 4;
+			const uint32_t e00 = ((uint32_t)f0 * L[l].res[1] + (uint32_t)f1) * L[l].res[2] + (uint32_t)f2;
+			const uint32_t e[4] = {e00, e00 + sx, e00 + sy, e00 + sx + sy};
+			// the lerp tree of k_fwd_pairlane for a Dense level (pair dim z, then x, then y), both features in one lane: feature
+			// 0 with the arithmetic of the pair's side-0 lane (keep the lower corner, weight w), feature 1 with the side-1
+			// lane's (keep the upper corner, weight 1 - w, difference negated) -- the two kernels give the same bits
+			const float w1 = 1.0f - t2;
+			float2 b[4], d[4];
 #pragma unroll
-				for (int f = 0; f < 2; ++f) {
-					float *dst = reinterpret_cast<float *>(db + d_lane + (f ? de : 0u));
-					__builtin_nontemporal_store(gx[f], &dst[0]);
-					__builtin_nontemporal_store(gy[f], &dst[1]);
-					__builtin_nontemporal_store(gz[f], &dst[2]);
+			for (int m = 0; m < 4; ++m) {
+				const float2 lo = tab[e[m]], hi = tab[e[m] + 1u];
+				d[m] = make_float2(hi.x - lo.x, lo.y - hi.y);
+				b[m] = make_float2(__fmaf_rn(t2, d[m].x, lo.x), __fmaf_rn(w1, d[m].y, hi.y));
+			}
+			float yv[2], gx[2], gy[2], gz[2];
+#pragma unroll
+			for (int f = 0; f < 2; ++f) {
+				auto c = [f](const float2 &v) { return f ? v.y : v.x; };
+				const float cA0 = c(b[1]) - c(b[0]), cA1 = c(b[3]) - c(b[2]);
+				const float dA0 = __fmaf_rn(t0, cA0, c(b[0])), dA1 = __fmaf_rn(t0, cA1, c(b[2]));
+				const float eB = dA1 - dA0;
+				yv[f] = __fmaf_rn(t1, eB, dA0);
+				if (DYDX) {
+					const float gA = __fmaf_rn(t1, cA1 - cA0, cA0);
+					const float p0 = __fmaf_rn(t0, c(d[1]) - c(d[0]), c(d[0])), p1 = __fmaf_rn(t0, c(d[3]) - c(d[2]), c(d[2]));
+					const float gP = __fmaf_rn(t1, p1 - p0, p0);
+					gx[f] = gA * dw0; gy[f] = eB * dw1; gz[f] = gP * (f ? -dw2 : dw2);
+				}
+			}
+			if (i < N) {
+				char *yb = reinterpret_cast<char *>(y) + ((int64_t)g0 * y_sn + (int64_t)(lv.q[l] * 2u) * y_se) * (int64_t)sizeof(PT);
+				store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane), yv[0]);
+				store_nt<PT>(reinterpret_cast<PT *>(yb + y_lane + ye), yv[1]);
+				if (DYDX) {
+					char *db = reinterpret_cast<char *>(dydx) + ((int64_t)g0 * d_sn + (int64_t)(lv.q[l] * 2u) * d_se) * 4;
+#pragma unroll
+					for (int f = 0; f < 2; ++f) {
+						float *dst = reinterpret_cast<float *>(db + d_lane + (f ? de : 0u));
+						__builtin_nontemporal_store(gx[f], &dst[0]);
+						__builtin_nontemporal_store(gy[f], &dst[1]);
+						__builtin_nontemporal_store(gz[f], &dst[2]);
+					}
 				}
 			}
 		}
@@ -1331,24 +1344,37 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 		int dev_id = 0;
 		NR3D_HIP_CHECK(hipGetDevice(&dev_id));
 		if (!attr_set_dev[dev_id & 63]) {
-			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<true, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxBytes));
-			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<false, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMaxBytes));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<true, PT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGroupBytes));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<false, PT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGroupBytes));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<true, PT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGroupBytes));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<false, PT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGroupBytes));
 			attr_set_dev[dev_id & 63] = true;
 		}
+		static int pair_levels = -1;                        // NR3D_LOTD_LDS_PAIR=0: one launch per staged level (A/B)
+		if (pair_levels < 0) { const char *e = getenv("NR3D_LOTD_LDS_PAIR"); pair_levels = e ? (atoi(e) != 0) : 1; }
+		LdsLevels grp;
+		uint32_t n_grp = 0, grp_bytes = 0;
+		auto flush = [&]() {
+			if (!n_grp) return;
+			prof::Scope ps(NR3D_PROF_LOTD_FWD_LDS, st);
+#define NR3D_LDS_LAUNCH(DY, NL) hipLaunchKernelGGL((k_fwd_lds<DY, PT, NL>), dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), grp_bytes, st, md, \
+				N, grp, meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se)
+			if (n_grp == 1) { if (dy_dx) NR3D_LDS_LAUNCH(true, 1); else NR3D_LDS_LAUNCH(false, 1); }
+			else            { if (dy_dx) NR3D_LDS_LAUNCH(true, 2); else NR3D_LDS_LAUNCH(false, 2); }
+#undef NR3D_LDS_LAUNCH
+			n_grp = 0; grp_bytes = 0;
+		};
 		for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
 			const uint32_t lv = meta->map_levels[q];
 			const nr3d_lotd_level_t &L = meta->levels[lv];
 			if ((int32_t)lv > max_level || L.type != NR3D_LOD_Dense || L.n_feats != 2 || (uint64_t)L.size * 8 > kLdsMaxBytes) continue;
 			staged |= 1ull << q;
-			const uint32_t lds = L.size * 8;                   // staged as float pairs whatever the storage type
-			prof::Scope ps(NR3D_PROF_LOTD_FWD_LDS, st);
-			if (dy_dx)
-				hipLaunchKernelGGL((k_fwd_lds<true, PT>), dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, q,
-				                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
-			else
-				hipLaunchKernelGGL((k_fwd_lds<false, PT>), dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, q,
-				                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
+			const uint32_t bytes = (L.size * 8u + 15u) & ~15u;     // staged as float pairs whatever the storage type
+			if (n_grp == 2 || (n_grp == 1 && (!pair_levels || grp_bytes + bytes > kLdsGroupBytes))) flush();
+			grp.q[n_grp] = q; grp.lds_off[n_grp] = grp_bytes / 8u;
+			++n_grp; grp_bytes += bytes;
 		}
+		flush();
 	}
 	static int dbg = -1, only = -2;
 	if (dbg < 0) { const char *e = getenv("NR3D_FWD_DBG"); dbg = e ? atoi(e) : 0; }

@@ -869,14 +869,44 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_direct_reduce(DirectPlan 
 
 constexpr uint32_t kRedRows = 4;
 // dL/dparam slice of a replicated bucket += sum of the replicas' partial tables, replica 0 first
+// ... and, in the same launch (blockIdx.x >= NB), the direct levels' buckets = sum of their replicas' tables (what
+// k_pair_direct_reduce does on its own when no level takes the record path)
 __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
                                                               const uint32_t *__restrict__ rep_g,
                                                               const uint32_t *__restrict__ item_start,
                                                               const float *__restrict__ partial, float *__restrict__ dparam,
-                                                              uint32_t out_half) {
+                                                              uint32_t out_half, uint32_t NB, DirectPlan dp,
+                                                              const float *__restrict__ dpart) {
+	const bool half_out = (out_half & 1u) != 0, assign = (out_half & 2u) != 0;
+	if (blockIdx.x >= NB) {
+		const uint32_t fb = blockIdx.x - NB;
+		uint32_t e = 0;
+		while (e + 1 < dp.n && dp.bucket_base[e + 1] <= fb) ++e;
+		const uint32_t b = fb - dp.bucket_base[e], q = dp.qmap[e];
+		const Lvl L = load_level(md, meta_level_of(md, q));
+		const uint32_t foff0 = meta_cnt_of(md, q) * 2u, kPLds = 2u << dp.lg;
+		for (uint32_t row = 0; row < kRedRows; ++row) {
+			const uint32_t t = (blockIdx.y * kRedRows + row) * kPAccThreads + threadIdx.x;
+			if (t >= kPLds) return;
+			float *p = pair_target(L, dp.epb[e], dp.lg, foff0, b, t, dparam, half_out);
+			if (!p) continue;
+			const float *part0 = dpart + (size_t)fb * dp.R * kPLds + t;
+			float sum = 0.0f;
+			uint32_t r0 = 0;
+			for (; r0 + 8 <= dp.R; r0 += 8) {
+				float v[8];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) v[j] = part0[(size_t)(r0 + j) * kPLds];
+#pragma unroll
+				for (int j = 0; j < 8; ++j) sum += v[j];
+			}
+			for (; r0 < dp.R; ++r0) sum += part0[(size_t)r0 * kPLds];
+			pair_st(p, (assign ? 0.0f : pair_ld(p, half_out)) + sum, half_out);
+		}
+		return;
+	}
 	const uint32_t fb = blockIdx.x;
 	const uint32_t R = rep_g[fb];
-	const bool half_out = (out_half & 1u) != 0, assign = (out_half & 2u) != 0;
 	if (R == 1 || (R == 0 && !assign)) return;           // assign mode: a bucket without records still has to be written (zeros)
 	uint32_t q = 0;
 	while (q + 1 < plan.n_pseudo && plan.bucket_base[q + 1] <= fb) ++q;
@@ -1105,7 +1135,26 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	}
 #undef NR3D_PAIR_ALL
 #undef NR3D_PAIR_BIN
-	if (pl.n_pseudo == 0) { NR3D_LAUNCH_CHECK(); return 0; }
+	// levels that skip the records: straight from (x, dL_dy) into LDS; needs stage A's gmax only, so it runs before stage B
+	// and its replicas are summed together with stage B's (one launch less)
+	float *dpart = partial + (size_t)(units + NB_full) * (2u << pl.lg);       // behind stage B's partial tables
+	const uint32_t nbk_direct = dp.n ? dp.bucket_base[dp.n] : 0u;
+	if (dp.n) {
+		prof::Scope ps(NR3D_PROF_LOTD_DIRECT, st);
+		if (pair_fixed())
+			hipLaunchKernelGGL(k_pair_direct<true>, dim3(dp.R, nbk_direct), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
+			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
+		else
+			hipLaunchKernelGGL(k_pair_direct<false>, dim3(dp.R, nbk_direct), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
+			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
+	}
+	if (pl.n_pseudo == 0) {
+		if (dp.n)
+			hipLaunchKernelGGL(k_pair_direct_reduce, dim3(nbk_direct, (2u << pl.lg) / kPAccThreads), dim3(kPAccThreads), 0, st, dp, md, dpart,
+			                   dparam, out_flags);
+		NR3D_LAUNCH_CHECK();
+		return 0;
+	}
 	hipLaunchKernelGGL(k_pair_plan, dim3(div_up(NB, 16)), dim3(1024), 0, st, pl, offs, units, tot, rep, item_start, gmax + 1);
 #define NR3D_PAIR_ACC(U, F) hipLaunchKernelGGL((k_pair_accum<U, F>), dim3(units + NB), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, pl, md, \
 	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg(), out_flags)
@@ -1115,21 +1164,9 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 		else              { if (pair_unroll() == 4) NR3D_PAIR_ACC(4, false); else NR3D_PAIR_ACC(8, false); }
 	}
 #undef NR3D_PAIR_ACC
-	hipLaunchKernelGGL(k_pair_reduce, dim3(NB, div_up((2u << pl.lg) / kPAccThreads, kRedRows)), dim3(kPAccThreads), 0, st, pl, md, rep, item_start, partial,
-	                   dparam, out_flags);
-	if (dp.n) {
-		float *dpart = partial + (size_t)(units + NB_full) * (2u << pl.lg);       // behind stage B's partial tables
-		const uint32_t nbk = dp.bucket_base[dp.n];
-		prof::Scope ps(NR3D_PROF_LOTD_DIRECT, st);
-		if (pair_fixed())
-			hipLaunchKernelGGL(k_pair_direct<true>, dim3(dp.R, nbk), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
-			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
-		else
-			hipLaunchKernelGGL(k_pair_direct<false>, dim3(dp.R, nbk), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
-			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
-		hipLaunchKernelGGL(k_pair_direct_reduce, dim3(nbk, (2u << pl.lg) / kPAccThreads), dim3(kPAccThreads), 0, st, dp, md, dpart, dparam,
-		                   out_flags);
-	}
+	// the replicated buckets of the record path and the direct levels' buckets are summed in ONE launch
+	hipLaunchKernelGGL(k_pair_reduce, dim3(NB + nbk_direct, div_up((2u << pl.lg) / kPAccThreads, kRedRows)), dim3(kPAccThreads), 0, st, pl, md, rep,
+	                   item_start, partial, dparam, out_flags, NB, dp, dpart);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

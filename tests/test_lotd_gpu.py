@@ -271,6 +271,28 @@ def test_generic_kernel_agrees_with_dense_hash_kernel(oracle, dev):
     assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dparam generic", levels=m_ref)
 
 
+def test_half_table_copy_is_shared_per_version_not_per_address(oracle, dev):
+    """half tables that are not served natively (product-type levels) run on an fp32 copy that the calls of one step share
+    (bindings._lotd._p32, keyed on storage + version counter): an in-place update must invalidate it, and so must a NEW
+    tensor that the caching allocator places at the address of a freed one"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, "mixed", n=2001, seed=9)
+    ph = pt.half()
+    assert not _lotd._native_half(m, ph, False)
+    y1 = _lotd.lod_fwd(m, xt, ph)[0].float().clone()
+    assert _lotd._p32(ph) is _lotd._p32(ph)                                  # one copy for the calls of a step
+    assert_close(y1, oracle.lotd_fwd(m_ref, x, ph.float().cpu().numpy())[0], rel=1e-3, name="y half (copy)")
+    ph.mul_(2.0)                                                             # an optimizer step: the version changes
+    y2 = _lotd.lod_fwd(m, xt, ph)[0].float()
+    # values scale with the tables level by level (Dense: x 2, VM: x 4, CP: x 8): nothing may be left as it was
+    assert ((y2 - y1).abs() > 1e-3 * y1.abs()).float().mean() > 0.9
+    assert_close(y2, oracle.lotd_fwd(m_ref, x, ph.float().cpu().numpy())[0], rel=1e-3, name="y half after an in-place update")
+    addr = ph.data_ptr()
+    del ph
+    other = (pt * 0.5).half()                                                # likely the freed block again, version 0
+    y3 = _lotd.lod_fwd(m, xt, other)[0].float()
+    assert_close(y3, oracle.lotd_fwd(m_ref, x, other.float().cpu().numpy())[0], rel=1e-3, name=f"y of a new table (same address: {other.data_ptr() == addr})")
+
+
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_pair", "pair_f4", "mixed"])
 def test_half_params_and_inputs(oracle, dev, case):
     """fp16 storage, the reference's (float, half, float) type combination: params / y / dL_dy / dL_dparam half, x and
