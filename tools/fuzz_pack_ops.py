@@ -25,7 +25,7 @@ def packs(rng):
     return np.ascontiguousarray(np.stack([cs - n, n], 1)), int(cs[-1])
 
 
-def close(got, want, name, tol=1e-5, exact=False):
+def close(got, want, name, tol=1e-5, exact=False, atol=0.0):
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     want = np.asarray(want)
     assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
@@ -34,7 +34,7 @@ def close(got, want, name, tol=1e-5, exact=False):
     else:
         sc = max(float(np.abs(want).max()) if want.size else 0.0, 1e-30)
         e = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max()) if want.size else 0.0
-        assert e <= tol * sc, f"{name}: err {e:.2e} vs scale {sc:.2e}"
+        assert e <= tol * sc + atol, f"{name}: err {e:.2e} vs scale {sc:.2e}"
 
 
 def one(rng):
@@ -88,7 +88,9 @@ def one(rng):
     os.environ.pop("NR3D_PACK_SCAN", None)
     # backward: the division by max(1 - alpha, 1e-10) amplifies rounding, so the numerators are compared
     om = np.maximum(1.0 - a.astype(np.float64), 1e-10)
-    close(outs["1"][4].double().cpu().numpy() * om, outs["0"][4].double().cpu().numpy() * om, "composite scan vs serial dalpha numerator " + tag, 1e-4)
+    close(outs["1"][4].double().cpu().numpy() * om, outs["0"][4].double().cpu().numpy() * om, "composite scan vs serial dalpha numerator " + tag, 1e-4,
+          atol=5e-7)     # "gradient still to come" = total - prefix (scan) vs a running difference (serial): both carry ~1e-7 of
+                         # the pack's TOTAL, which a short pack whose numerators are all small (late, faint samples) shows
     close(outs["1"][5], outs["0"][5].cpu().numpy(), "composite scan vs serial dt " + tag, 2e-5)
     close(outs["1"][6], outs["0"][6].cpu().numpy(), "composite scan vs serial drgb " + tag, 2e-5)
     close(outs["0"][0], w_ref, "composite serial vw " + tag, exact=True)
