@@ -119,9 +119,34 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(t):
-    """hipStream_t of torch's current stream on the tensor's device."""
+    """hipStream_t of torch's current stream on the tensor's device (the raw handle: building a torch.cuda.Stream object
+    per call costs ~5 us of host time, which the launch-bound ops notice)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def on_device(dev):
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager is ~3 us per use)"""
+    idx = dev.index if isinstance(dev, torch.device) else int(dev)
+    if idx is None or idx == torch.cuda.current_device():
+        return _NOCTX
+    return torch.cuda.device(idx)
 
 
 _pinned = {}

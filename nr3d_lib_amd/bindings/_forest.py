@@ -74,7 +74,7 @@ def forest_identify(forest: ForestMeta, ks: torch.Tensor) -> torch.Tensor:
     H.require_gpu(ks)
     k16 = ks.reshape(-1, 3).to(torch.int16).contiguous()
     out = H.empty(k16.shape[0], dtype=torch.int32, device=ks.device)
-    with torch.cuda.device(ks.device):
+    with H.on_device(ks.device):
         c = forest._c()
         H.check(H.lib().nr3d_forest_identify(C.byref(c), C.c_uint64(k16.shape[0]), H.ptr(k16), H.ptr(out), H.stream_of(ks)))
     return out.view(ks.shape[:-1])
@@ -129,7 +129,7 @@ def lod_fwd(metas, input, params, batch_inds=None, batch_offsets=None, batch_dat
     if max_level <= -1:
         return (torch.zeros((N, E), dtype=params.dtype, device=dev), torch.zeros((N, E * 3), dtype=input.dtype, device=dev))
     x32, p32 = _lotd._f32c(input.detach()), _lotd._f32c(params.detach())
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         # feature-major storage behind [N, E] / [N, E, 3] views, like the single-block path: coalesced stores
         y = H.empty((E, N), dtype=torch.float32, device=dev).t()
         dy_dx, dsn, dse = None, 0, 0
@@ -161,7 +161,7 @@ def lod_bwd(metas, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offs
     need_input_grad = bool(input.requires_grad) if need_input_grad is None else bool(need_input_grad)
     need_param_grad = bool(params.requires_grad) if need_param_grad is None else bool(need_param_grad)
     dL_dx = dL_dparam = None
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         if need_input_grad:
             if dy_dx is None:
                 raise RuntimeError("LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.")
@@ -207,7 +207,7 @@ def lod_bwd_bwd_input(metas, dL_ddLdx, dL_dy, input, params, dy_dx=None, batch_i
     need_dx = bool(input.requires_grad) if need_dLdinput_dinput is None else bool(need_dLdinput_dinput)
     need_dp = bool(params.requires_grad) if need_dLdinput_dparams is None else bool(need_dLdinput_dparams)
     dL_ddLdy = dL_dparams = dL_dx = None
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         if need_dLdy:
             if dy_dx is None:
                 raise RuntimeError("LoTDEncoding::bwd_bwd_input: need `dy_dx` to compute `dL_d(dLdy)`.")

@@ -335,7 +335,7 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
     p32 = params.detach() if native else _p32(params)
     pcode = H.F16 if native else H.F32
     dev = input.device
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         y_store = H.empty((E, N), dtype=torch.float16 if native else torch.float32, device=dev)
         y = y_store.t()
         dy_dx = None
@@ -389,7 +389,7 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
     need_param_grad = bool(params.requires_grad) if need_param_grad is None else bool(need_param_grad)
     dev = input.device
     dL_dx = dL_dparam = None
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         if need_input_grad and dy_dx is None:
             raise RuntimeError("LoTDEncoding::bwd: need `dy_dx` to comput `dL_dx`.")
         batched = batch_inds is not None or batch_offsets is not None or bds != 0
@@ -521,7 +521,7 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
     need_dp = bool(params.requires_grad) if need_dLdinput_dparams is None else bool(need_dLdinput_dparams)
     dev = input.device
     dL_ddLdy = dL_dparams = dL_dx = None
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         if need_dLdy:
             if dy_dx is None:
                 raise RuntimeError("LoTDEncoding::bwd_bwd_input: need `dy_dx` to compute `dL_d(dLdy)`.")
@@ -582,7 +582,7 @@ def lod_get_grid_index(lod_meta, input, batch_inds=None, batch_offsets=None, bat
     max_level = m.n_levels if max_level is None else int(max_level)
     E, D = m.n_encoded_dims, m.n_dims_to_encode
     dev = input.device
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         out = torch.zeros((N, E, 1 << D), dtype=torch.int64, device=dev)
         if max_level <= -1 or N == 0:
             return out

@@ -64,7 +64,7 @@ def pack(desc: MLPDesc, weights, biases, with_backward=False) -> torch.Tensor:
     if with_backward and not desc.backward_fusable:
         raise RuntimeError("mlp.pack: the fused backward does not apply to this network")
     packed = H.empty(desc.packed_floats + (desc.backward_floats if with_backward else 0), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         H.check(H.lib().nr3d_mlp_pack(C.byref(desc._c), _ptr_array(ws), _ptr_array(bs), H.ptr(packed), C.c_int(int(with_backward)),
                                       H.stream_of(packed)))
     return packed
@@ -89,7 +89,7 @@ def forward(desc: MLPDesc, x: torch.Tensor, packed: torch.Tensor) -> torch.Tenso
     x2, xs, xf = _layout(x.reshape(-1, x.shape[-1]))
     n = x2.shape[0]
     y = H.empty((n, desc.dims[-1]), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with H.on_device(x.device):
         H.check(H.lib().nr3d_mlp_forward(C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(xs), H.i64(xf),
                                          H.ptr(packed), H.ptr(y), H.i64(y.shape[1]), H.stream_of(x)))
     return y.view(*x.shape[:-1], desc.dims[-1])
@@ -121,7 +121,7 @@ def backward(desc: MLPDesc, x: torch.Tensor, dL_dy: torch.Tensor, packed: torch.
         dx, gxs, gxf = H.empty((desc.dims[0], n), dtype=torch.float32, device=dev).t(), 1, n
     elif need_dx:
         dx = H.empty((n, desc.dims[0]), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         H.check(H.lib().nr3d_mlp_backward(
             C.byref(desc._c), C.c_uint64(n), H.ptr(x2), H.i64(xs), H.i64(xf), H.ptr(g2),
             H.i64(g2.stride(0) if n > 1 else desc.dims[-1]), H.ptr(packed), H.ptr(dx), H.i64(gxs), H.i64(gxf), _ptr_array(dWs),

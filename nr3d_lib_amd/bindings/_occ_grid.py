@@ -72,7 +72,7 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
     dev = rays_o.device
     res = (C.c_int32 * 3)(*[int(s) for s in grid_binary.shape[-3:]])
     ctype = C.c_int(int(contraction_type))
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         st = H.stream_of(rays_o)
         packed_info = H.empty((n, 2), dtype=torch.int32, device=dev)
         total = H.empty(1, dtype=torch.int64, device=dev)
@@ -176,7 +176,7 @@ def forest_ray_marching(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, se
         raise RuntimeError(f"grid_binary: expected {int(forest.n_trees)} block grids, got {grid_binary.shape[0]}")
     dev = rays_o.device
     res = (C.c_int32 * 3)(*[int(v) for v in grid_binary.shape[-3:]])
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         st = H.stream_of(rays_o)
         fc = forest._c()
         packed_info = H.empty((n, 2), dtype=torch.int32, device=dev)

@@ -82,7 +82,7 @@ def interleave_arange(stop, return_idx):
     if stop.dim() != 1 or stop.dtype != torch.int64 or not stop.is_contiguous():
         raise RuntimeError("interleave_arange: Expected contiguous 1-D Long tensor for argument stop")
     H.require_gpu(stop)
-    with torch.cuda.device(stop.device):
+    with H.on_device(stop.device):
         pi, num = _pack_infos_from_n(stop)
         out = H.empty(num, dtype=torch.int64, device=stop.device)
         nidx = H.empty(num, dtype=torch.int64, device=stop.device) if return_idx else None
@@ -109,7 +109,7 @@ def interleave_linstep(start, num_steps, step_size, return_idx):
         steps_t = step_size.contiguous()
     else:
         step_s = float(step_size)
-    with torch.cuda.device(start.device):
+    with H.on_device(start.device):
         pi, num = _pack_infos_from_n(num_steps)
         out = H.empty(num, dtype=start.dtype, device=start.device)
         nidx = H.empty(num, dtype=torch.int64, device=start.device) if return_idx else None
@@ -133,7 +133,7 @@ def interleave_sample_step_wrt_depth_clamped(near, far, max_steps, dt_gamma, min
     """-> (t_samples, deltas, nidx int64, pack_infos int64 [P,2])  (pack_ops_cuda.cu:480-604)"""
     _chk_near_far("interleave_sample_step_wrt_depth_clamped", near, far)
     P, dev = near.shape[0], near.device
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         n = H.empty(P, dtype=torch.int64, device=dev)
         st = H.stream_of(near)
         H.check(H.lib().nr3d_sample_step_count(H.u32(P), H.ptr(near), H.ptr(far), H.u32(max_steps), H.f32(dt_gamma),
@@ -163,7 +163,7 @@ def interleave_sample_step_wrt_depth_in_packed_segments(near, far, entry, exit, 
     if seg_pack_infos.shape[0] != near.shape[0]:
         raise RuntimeError(f"{fn}: Expected seg_pack_infos of size [{near.shape[0]}, 2]")
     P, dev = near.shape[0], near.device
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         n = H.empty(P, dtype=torch.int64, device=dev)
         st = H.stream_of(near)
         common = (H.u32(P), H.ptr(near), H.ptr(far), H.ptr(entry), H.ptr(exit), H.ptr(seg_pack_infos),
@@ -185,7 +185,7 @@ def interleave_sample_step_wrt_depth_in_packed_segments(near, far, entry, exit, 
 def packed_sum(feats, pack_infos):
     _chk_feats("packed_sum", feats, pack_infos)
     P = pack_infos.shape[0]
-    with torch.cuda.device(feats.device):
+    with H.on_device(feats.device):
         out = torch.zeros((P,) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
         H.check(H.lib().nr3d_packed_sum(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)), _code(feats),
                                         H.ptr(feats), H.ptr(pack_infos), H.ptr(out), H.stream_of(feats)))
@@ -194,7 +194,7 @@ def packed_sum(feats, pack_infos):
 
 def _scan(fn, feats, pack_infos, mode, exclusive, reverse):
     _chk_feats(fn, feats, pack_infos)
-    with torch.cuda.device(feats.device):
+    with H.on_device(feats.device):
         out = torch.zeros_like(feats)
         H.check(H.lib().nr3d_packed_scan(H.u32(pack_infos.shape[0]), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)),
                                          _code(feats), H.ptr(feats), H.ptr(pack_infos), C.c_int(mode),
@@ -226,7 +226,7 @@ def _diff(fn, feats, pack_infos, edge_a, edge_fill, backward, names):
         raise RuntimeError("You should only specify AT MOST one of [appends, prepends, last_fill, first_fill]")
     P = pack_infos.shape[0]
     edge_a, edge_fill = _edge(fn, names[0], edge_a, feats, P), _edge(fn, names[1], edge_fill, feats, P)
-    with torch.cuda.device(feats.device):
+    with H.on_device(feats.device):
         out = torch.zeros_like(feats)
         H.check(H.lib().nr3d_packed_diff(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)), _code(feats),
                                          H.ptr(feats), H.ptr(pack_infos), H.ptr(edge_a), H.ptr(edge_fill),
@@ -270,7 +270,7 @@ def _binary(name, feats, other, pack_infos):
             raise RuntimeError(f"{fn}: Expected feats and other to have the same number of dimensions / feature width")
         od = fd
         out_shape, out_dtype = tuple(feats.shape), (torch.bool if op >= 5 else feats.dtype)
-    with torch.cuda.device(feats.device):
+    with H.on_device(feats.device):
         out = torch.zeros(out_shape, dtype=out_dtype, device=feats.device)
         H.check(H.lib().nr3d_packed_binary(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(fd), H.u32(od), _code(feats),
                                            H.ptr(feats), H.ptr(other), H.ptr(pack_infos), C.c_int(op), H.ptr(out),
@@ -298,7 +298,7 @@ def packed_sort_qsort(vals, pack_infos, return_idx):
     """Sorts ``vals`` IN PLACE per pack (ascending); returns the index permutation or None
     (pack_ops_cuda.cu:2634-2763)."""
     _chk_feats("packed_sort_qsort", vals, pack_infos, dims=(1,))
-    with torch.cuda.device(vals.device):
+    with H.on_device(vals.device):
         idx = torch.arange(vals.shape[0], dtype=torch.int64, device=vals.device) if return_idx else None
         H.check(H.lib().nr3d_packed_sort(H.u32(pack_infos.shape[0]), C.c_uint64(vals.shape[0]), _code(vals),
                                          H.ptr(vals), H.ptr(idx), H.ptr(pack_infos), H.stream_of(vals)))
@@ -314,7 +314,7 @@ def packed_searchsorted(bins, vals, pack_infos):
     if vals.dim() != 2 or vals.dtype != bins.dtype or not vals.is_contiguous() or vals.shape[0] != pack_infos.shape[0]:
         raise RuntimeError("packed_searchsorted: Expected contiguous vals of size [num_packs, num_to_search] "
                            "with the dtype of bins")
-    with torch.cuda.device(bins.device):
+    with H.on_device(bins.device):
         pidx = torch.full(vals.shape, -1, dtype=torch.int64, device=bins.device)
         H.check(H.lib().nr3d_packed_searchsorted(H.u32(pack_infos.shape[0]), _code(bins), H.ptr(bins), H.ptr(vals),
                                                  H.ptr(pack_infos), H.u32(vals.shape[1]), None, H.ptr(pidx),
@@ -327,7 +327,7 @@ def packed_searchsorted_packed_vals(bins, pack_infos, vals, val_pack_infos):
     _chk_feats("packed_searchsorted_packed_vals", vals, val_pack_infos, dims=(1,))
     if vals.dtype != bins.dtype or val_pack_infos.shape[0] != pack_infos.shape[0]:
         raise RuntimeError("packed_searchsorted_packed_vals: vals must have the dtype of bins and one pack per bin pack")
-    with torch.cuda.device(bins.device):
+    with H.on_device(bins.device):
         pidx = torch.full(vals.shape, -1, dtype=torch.int64, device=bins.device)
         H.check(H.lib().nr3d_packed_searchsorted(H.u32(pack_infos.shape[0]), _code(bins), H.ptr(bins), H.ptr(vals),
                                                  H.ptr(pack_infos), H.u32(0), H.ptr(val_pack_infos), H.ptr(pidx),
@@ -342,7 +342,7 @@ def try_merge_two_packs_sorted_aligned(vals_a, pack_infos_a, vals_b, pack_infos_
     _chk_feats(fn, vals_b, pack_infos_b, dims=(1,))
     if vals_a.dtype != vals_b.dtype or pack_infos_a.shape != pack_infos_b.shape:
         raise RuntimeError(f"{fn}: the two packs must be aligned and share a dtype")
-    with torch.cuda.device(vals_a.device):
+    with H.on_device(vals_a.device):
         n = pack_infos_a[:, 1] + pack_infos_b[:, 1]
         cs = n.cumsum(0)
         pim = torch.stack([cs - n, n], 1).contiguous()
@@ -364,7 +364,7 @@ def packed_invert_cdf(bins, cdfs, u, pack_infos):
         raise RuntimeError(f"{fn}: Expected contiguous cdfs with the size and dtype of bins")
     if u.dim() != 2 or u.dtype != bins.dtype or not u.is_contiguous() or u.shape[0] != pack_infos.shape[0]:
         raise RuntimeError(f"{fn}: Expected contiguous u of size [num_packs, num_to_sample]")
-    with torch.cuda.device(bins.device):
+    with H.on_device(bins.device):
         bin_idx = torch.full(u.shape, -1, dtype=torch.int64, device=bins.device)
         samples = torch.zeros_like(u)
         H.check(H.lib().nr3d_packed_invert_cdf(H.u32(pack_infos.shape[0]), H.ptr(bins), H.ptr(cdfs), H.ptr(pack_infos),
@@ -383,7 +383,7 @@ def packed_alpha_to_vw_forward(alphas, pack_infos, early_stop_eps, alpha_thre, c
     if alphas.dtype != torch.float32:
         raise RuntimeError(f"{fn}: float32 only on this platform")
     P, S, dev = pack_infos.shape[0], alphas.shape[0], alphas.device
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         st = H.stream_of(alphas)
         if compression:
             num = torch.zeros(P, dtype=torch.int64, device=dev)
@@ -421,7 +421,7 @@ def packed_compression_compact(alphas, pack_infos, early_stop_eps, alpha_thre, t
                                ("f3", f3, (S, 3), torch.float32), ("l1", l1, (S,), torch.int64)):
         if t is not None and (t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous()):
             raise RuntimeError(f"{fn}: Expected a contiguous {dt} {name} of shape {list(shape)}, got {t.dtype} {list(t.shape)}")
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         st = H.stream_of(alphas)
         num = torch.zeros(P, dtype=torch.int64, device=dev)
         sel = H.empty(S, dtype=torch.bool, device=dev)
@@ -453,7 +453,7 @@ def tau_to_alpha_forward(sigma, delta):
     if sigma.dtype != torch.float32 or delta.dtype != torch.float32 or sigma.shape != delta.shape \
             or not sigma.is_contiguous() or not delta.is_contiguous():
         raise RuntimeError(f"{fn}: Expected contiguous float32 sigma / delta of the same shape")
-    with torch.cuda.device(sigma.device):
+    with H.on_device(sigma.device):
         alpha = H.empty_like(sigma)
         H.check(H.lib().nr3d_tau_to_alpha_fwd(C.c_uint64(sigma.numel()), H.ptr(sigma), H.ptr(delta), H.ptr(alpha),
                                               H.stream_of(sigma)))
@@ -467,7 +467,7 @@ def tau_to_alpha_backward(sigma, delta, grad_alpha):
     for t in (delta, grad_alpha):
         if t.dtype != torch.float32 or t.shape != sigma.shape or not t.is_contiguous():
             raise RuntimeError(f"{fn}: Expected contiguous float32 tensors of sigma's shape")
-    with torch.cuda.device(sigma.device):
+    with H.on_device(sigma.device):
         g = H.empty_like(sigma)
         H.check(H.lib().nr3d_tau_to_alpha_bwd(C.c_uint64(sigma.numel()), H.ptr(sigma), H.ptr(delta), H.ptr(grad_alpha), H.ptr(g),
                                               H.stream_of(sigma)))
@@ -483,7 +483,7 @@ def packed_alpha_to_vw_backward(weights, grad_weights, alphas, pack_infos, early
             raise RuntimeError(f"{fn}: Expected contiguous weights / grad_weights / alphas of the same size and dtype")
     if weights.dtype != torch.float32:
         raise RuntimeError(f"{fn}: float32 only on this platform")
-    with torch.cuda.device(weights.device):
+    with H.on_device(weights.device):
         g = H.empty_like(alphas)
         H.check(H.lib().nr3d_alpha_to_vw_backward(H.u32(pack_infos.shape[0]), C.c_uint64(weights.shape[0]),
                                                   H.ptr(alphas), H.ptr(weights), H.ptr(grad_weights), H.ptr(pack_infos),
@@ -521,7 +521,7 @@ def packed_composite_forward(alphas, t, rgb, pack_infos, rays_inds_hit, num_rays
             raise RuntimeError(f"{fn}: Expected a contiguous int64 rays_inds_hit of shape [{P}]")
     elif int(num_rays) != P:
         raise RuntimeError(f"{fn}: num_rays must equal the number of packs when rays_inds_hit is None")
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         vw = (H.empty if (packs_tile and P > 0) else torch.zeros)(S, dtype=torch.float32, device=dev)
         # per-ray outputs: [mask | depth | rgb] views of one buffer (rays that are not hit keep zeros: one fill, not three)
         nr = int(num_rays) if rays_inds_hit is not None else P
@@ -551,7 +551,7 @@ def packed_composite_backward(alphas, vw, t, rgb, pack_infos, rays_inds_hit, ear
                             ("g_rgb", g_rgb, 3)):
         if tt is not None:
             _f32_1d(fn, name, tt, n_out, inner)
-    with torch.cuda.device(dev):
+    with H.on_device(dev):
         alloc = H.empty if (packs_tile and P > 0) else torch.zeros
         ga = alloc(S, dtype=torch.float32, device=dev)
         gt = alloc(S, dtype=torch.float32, device=dev) if need_t else None
@@ -574,7 +574,7 @@ def mark_pack_boundaries_cuda(pack_ids):
         raise RuntimeError("mark_pack_boundaries_cuda: Expected pack_ids to have one of scalar types Byte, Char, Int, "
                            "Long, Short")
     H.require_gpu(pack_ids)
-    with torch.cuda.device(pack_ids.device):
+    with H.on_device(pack_ids.device):
         b = H.empty(pack_ids.shape[0], dtype=torch.int32, device=pack_ids.device)
         H.check(H.lib().nr3d_mark_pack_boundaries(C.c_uint64(pack_ids.shape[0]), _code(pack_ids), H.ptr(pack_ids),
                                                   H.ptr(b), H.stream_of(pack_ids)))
@@ -591,7 +591,7 @@ def octree_mark_consecutive_segments(pidx, pack_infos, point_hierarchies):
     n = pidx.shape[0]
     mark_start = torch.zeros(n, dtype=torch.bool, device=pidx.device)
     mark_end = torch.zeros(n, dtype=torch.bool, device=pidx.device)
-    with torch.cuda.device(pidx.device):
+    with H.on_device(pidx.device):
         H.check(H.lib().nr3d_octree_mark_consecutive_segments(H.u32(pack_infos.shape[0]), H.ptr(pidx), H.ptr(pack_infos),
                                                               H.ptr(point_hierarchies), H.ptr(mark_start), H.ptr(mark_end),
                                                               H.stream_of(pidx)))

@@ -879,30 +879,30 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
                                                               const float *__restrict__ dpart) {
 	const bool half_out = (out_half & 1u) != 0, assign = (out_half & 2u) != 0;
 	if (blockIdx.x >= NB) {
-		const uint32_t fb = blockIdx.x - NB;
+		// a direct bucket has ~100 replicas to add per element: one 256-element row per workgroup (kRedRows workgroups in x per
+		// bucket and grid row), not kRedRows rows in sequence like the sparsely replicated buckets below
+		const uint32_t fb = (blockIdx.x - NB) / kRedRows, sub = (blockIdx.x - NB) % kRedRows;
 		uint32_t e = 0;
 		while (e + 1 < dp.n && dp.bucket_base[e + 1] <= fb) ++e;
 		const uint32_t b = fb - dp.bucket_base[e], q = dp.qmap[e];
 		const Lvl L = load_level(md, meta_level_of(md, q));
 		const uint32_t foff0 = meta_cnt_of(md, q) * 2u, kPLds = 2u << dp.lg;
-		for (uint32_t row = 0; row < kRedRows; ++row) {
-			const uint32_t t = (blockIdx.y * kRedRows + row) * kPAccThreads + threadIdx.x;
-			if (t >= kPLds) return;
-			float *p = pair_target(L, dp.epb[e], dp.lg, foff0, b, t, dparam, half_out);
-			if (!p) continue;
-			const float *part0 = dpart + (size_t)fb * dp.R * kPLds + t;
-			float sum = 0.0f;
-			uint32_t r0 = 0;
-			for (; r0 + 8 <= dp.R; r0 += 8) {
-				float v[8];
+		const uint32_t t = (blockIdx.y * kRedRows + sub) * kPAccThreads + threadIdx.x;
+		if (t >= kPLds) return;
+		float *p = pair_target(L, dp.epb[e], dp.lg, foff0, b, t, dparam, half_out);
+		if (!p) return;
+		const float *part0 = dpart + (size_t)fb * dp.R * kPLds + t;
+		float sum = 0.0f;
+		uint32_t r0 = 0;
+		for (; r0 + 8 <= dp.R; r0 += 8) {
+			float v[8];
 #pragma unroll
-				for (int j = 0; j < 8; ++j) v[j] = part0[(size_t)(r0 + j) * kPLds];
+			for (int j = 0; j < 8; ++j) v[j] = part0[(size_t)(r0 + j) * kPLds];
 #pragma unroll
-				for (int j = 0; j < 8; ++j) sum += v[j];
-			}
-			for (; r0 < dp.R; ++r0) sum += part0[(size_t)r0 * kPLds];
-			pair_st(p, (assign ? 0.0f : pair_ld(p, half_out)) + sum, half_out);
+			for (int j = 0; j < 8; ++j) sum += v[j];
 		}
+		for (; r0 < dp.R; ++r0) sum += part0[(size_t)r0 * kPLds];
+		pair_st(p, (assign ? 0.0f : pair_ld(p, half_out)) + sum, half_out);
 		return;
 	}
 	const uint32_t fb = blockIdx.x;
@@ -1165,7 +1165,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	}
 #undef NR3D_PAIR_ACC
 	// the replicated buckets of the record path and the direct levels' buckets are summed in ONE launch
-	hipLaunchKernelGGL(k_pair_reduce, dim3(NB + nbk_direct, div_up((2u << pl.lg) / kPAccThreads, kRedRows)), dim3(kPAccThreads), 0, st, pl, md, rep,
+	hipLaunchKernelGGL(k_pair_reduce, dim3(NB + nbk_direct * kRedRows, div_up((2u << pl.lg) / kPAccThreads, kRedRows)), dim3(kPAccThreads), 0, st, pl, md, rep,
 	                   item_start, partial, dparam, out_flags, NB, dp, dpart);
 	NR3D_LAUNCH_CHECK();
 	return 0;

@@ -8,4 +8,4 @@ pr = cProfile.Profile(); pr.enable()
 r = b.march_composite_rate(dev, iters=200)
 pr.disable()
 print(r)
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
