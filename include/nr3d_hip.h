@@ -81,6 +81,10 @@ typedef struct nr3d_lotd_meta {
 	uint32_t n_params;               /* == level_offsets[n_levels] */
 	uint32_t interpolation_type;     /* 0 Linear, 1 Smoothstep (lotd_types.h:78-82) */
 	uint32_t c_hash_only;            /* every level is Dense or Hash */
+	/* ABI 2 (appended; everything above is unchanged): first output column of pseudo level q.  q * n_feat_per_pseudo_lvl
+	 * for the meta nr3d_lotd_meta_create builds; a REGROUPED meta (nr3d_lotd_meta_regroup) lists a subset of the levels with
+	 * a wider pseudo level, and its columns are those of the original layout. */
+	uint16_t map_col[NR3D_LOTD_MAX_PSEUDO];
 } nr3d_lotd_meta_t;
 
 /* LoDMeta::create_meta (lotd_torch_api.cu:29-230).  Host only, no GPU needed.
@@ -88,6 +92,15 @@ typedef struct nr3d_lotd_meta {
 int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, const int32_t *res_multidim,
                           const int32_t *n_feats, const int32_t *types, uint32_t hashmap_size,
                           int use_smooth_step, nr3d_lotd_meta_t *out);
+
+/* Pseudo levels regrouped by feature width (no reference counterpart: the reference processes every level in pseudo levels
+ * of the GLOBAL gcd of the widths, lotd_torch_api.cu:58-75 -- a meta that mixes 2- and 16-feature levels walks the
+ * 16-feature one as eight 2-feature pseudo levels, repeating the index work eight times).  *out = *meta with
+ * n_feat_per_pseudo_lvl = width (2, 4 or 8) and ONLY the pseudo levels of the levels whose own widest admissible width
+ * (largest of 8, 4, 2 dividing n_feats) is `width`; levels, offsets, n_encoded_dims and the output columns (map_col) are
+ * those of *meta, so calls with the regrouped metas of all three widths write disjoint columns / table slices of the same
+ * tensors and together equal one call with *meta.  out->n_pseudo_levels == 0: no level has that width. */
+int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t width, nr3d_lotd_meta_t *out);
 
 /* Batch addressing shared by all LoTD entry points (lotd_encoding.h:166-178):
  *   batch_inds   int64 [N] or NULL (value < 0 => point skipped)

@@ -76,6 +76,7 @@ class _CMeta(C.Structure):
         ("n_levels", C.c_uint32), ("n_pseudo_levels", C.c_uint32), ("n_feat_per_pseudo_lvl", C.c_uint32),
         ("n_dims_to_encode", C.c_uint32), ("n_encoded_dims", C.c_uint32), ("n_params", C.c_uint32),
         ("interpolation_type", C.c_uint32), ("c_hash_only", C.c_uint32),
+        ("map_col", C.c_uint16 * MAX_PSEUDO),          # ABI 2: first output column of every pseudo level
     ]
 
 
@@ -129,6 +130,27 @@ class LoDMeta:
         self.c_permute_dydx = True
         self._all_dense_hash = bool(c.c_hash_only)
         self._dev_cache = {}
+        # Levels regrouped by their own feature width (nr3d_lotd_meta_regroup): the reference -- and the meta above -- walk
+        # every level in pseudo levels of the GLOBAL gcd of the widths, so a meta that mixes 2- and 16-feature levels
+        # (configs[3]: 4, 4, 8, 4, 2, 16, 8, 4) repeats the index work of the 16-feature level eight times and emits eight
+        # 12-byte records per table entry where two 36-byte ones would do.  The FORWARD of a meta with product-type levels
+        # and mixed widths runs as up to three calls (width 8, 4, 2) that write disjoint output columns (configs[3], 2^22
+        # points: 4.42 -> 3.62 ms).  The parameter-gradient and second-order passes keep the single call: measured with wide
+        # records / lanes they LOSE (dL/dparam 7.95 -> 12.8 ms, d(dL/dx)/dx 3.58 -> 7.17: three times fewer points per
+        # stage-A workgroup for 36-byte records, four times more buckets for the accumulators, registers).  Dense / Hash-only
+        # metas keep the single call everywhere (their 2-feature pair kernels are faster than wider lanes).
+        # REGROUP = False: always one call.
+        self._groups = None
+        if not self._all_dense_hash and any(f % (2 * self.n_feat_per_pseudo_lvl) == 0 for f in self.level_n_feats):
+            groups = []
+            for width in (8, 4, 2):
+                g = _CMeta()
+                H.check(H.lib().nr3d_lotd_meta_regroup(C.byref(self._c), C.c_uint32(width), C.byref(g)))
+                if g.n_pseudo_levels:
+                    groups.append(g)
+            if len(groups) > 1 or (groups and groups[0].n_feat_per_pseudo_lvl != self.n_feat_per_pseudo_lvl):
+                self._groups = groups
+        self._group_dev_cache = {}
 
     # ---- C-ABI views -------------------------------------------------------------------------
     def _cmeta(self):
@@ -149,6 +171,18 @@ class LoDMeta:
             t = host.to(device)
             self._dev_cache[key] = t
         return t
+
+    def _calls(self, device):
+        """[(byref(host meta), device-copy pointer)] of the calls that together cover every level: the regrouped metas
+        (width 8 / 4 / 2) of a mixed-width meta with product-type levels, else the meta itself"""
+        if self._groups is None or not REGROUP:
+            return [(C.byref(self._cmeta()), H.ptr(self._dev(device)))]
+        key = (device.type, device.index)
+        devs = self._group_dev_cache.get(key)
+        if devs is None:
+            devs = [torch.frombuffer(bytearray(bytes(g)), dtype=torch.uint8).to(device) for g in self._groups]
+            self._group_dev_cache[key] = devs
+        return [(C.byref(g), H.ptr(d)) for g, d in zip(self._groups, devs)]
 
     def __repr__(self):
         return (f"LoDMeta(D={self.n_dims_to_encode}, levels={self.n_levels}, n_params={self.n_params}, "
@@ -267,6 +301,7 @@ def _p32(params):
 
 HVP_WORKSPACE_MAX_BYTES = 8 << 30      # largest per-call scratch of the level-parallel d(dL/dx)/dx (beyond it: lane-serial kernel)
 NATIVE_HALF = True       # False: half params always go through fp32 copies (A/B measurements)
+REGROUP = True           # False: mixed-width metas run as ONE call in pseudo levels of the global gcd (A/B, cross-check)
 
 
 def _native_half(meta, params, batched):
@@ -349,11 +384,12 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
         else:
             dsn = dse = 0
         with _Prof(m, f"LoTD{D}-fwd" + ("-grad" if need_input_grad else ""), N):
-            H.check(H.lib().nr3d_lotd_fwd(
-                C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(pcode),
-                H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds), H.i32(max_level),
-                H.ptr(y_store), H.i64(y.stride(0)), H.i64(y.stride(1)),
-                H.ptr(dy_dx), H.i64(dsn), H.i64(dse), H.stream_of(input)))
+            for cm, md in m._calls(dev):          # one call, or one per feature width (disjoint output columns)
+                H.check(H.lib().nr3d_lotd_fwd(
+                    cm, md, H.u32(N), C.c_int(H.F32), C.c_int(pcode),
+                    H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds), H.i32(max_level),
+                    H.ptr(y_store), H.i64(y.stride(0)), H.i64(y.stride(1)),
+                    H.ptr(dy_dx), H.i64(dsn), H.i64(dse), H.stream_of(input)))
     if y.dtype != params.dtype:
         y = y.to(params.dtype)
     if dy_dx is not None and input.dtype != torch.float32:

@@ -72,7 +72,7 @@ extern "C" int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, i
 }
 
 extern "C" const char *nr3d_last_error(void) { return err_buf(); }
-extern "C" int nr3d_abi_version(void) { return 1; }
+extern "C" int nr3d_abi_version(void) { return 2; }
 
 extern "C" int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, const int32_t *res_multidim,
                                      const int32_t *n_feats, const int32_t *types, uint32_t hashmap_size,
@@ -149,6 +149,7 @@ extern "C" int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, con
 			NR3D_CHECK(n_pseudo < NR3D_LOTD_MAX_PSEUDO, "LoTDEncoding: too many pseudo levels");
 			m->map_levels[n_pseudo] = (uint16_t)l;
 			m->map_cnt[n_pseudo] = (uint16_t)j;
+			m->map_col[n_pseudo] = (uint16_t)(n_enc + j * G);
 			++n_pseudo;
 		}
 		n_enc += (uint32_t)n_feats[l];
@@ -158,5 +159,31 @@ extern "C" int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, con
 	m->n_pseudo_levels = n_pseudo;
 	m->n_encoded_dims = n_enc;
 	m->c_hash_only = dense_hash_only ? 1u : 0u;
+	return 0;
+}
+
+extern "C" int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t width, nr3d_lotd_meta_t *out) {
+	NR3D_CHECK(meta && out, "LoTD::meta_regroup: NULL argument");
+	NR3D_CHECK(width == 2 || width == 4 || width == 8, "LoTD::meta_regroup: width must be 2, 4 or 8");
+	*out = *meta;
+	out->n_feat_per_pseudo_lvl = width;
+	memset(out->map_levels, 0, sizeof(out->map_levels));
+	memset(out->map_cnt, 0, sizeof(out->map_cnt));
+	memset(out->map_col, 0, sizeof(out->map_col));
+	uint32_t n_pseudo = 0, col = 0;
+	for (uint32_t l = 0; l < meta->n_levels; ++l) {
+		const uint32_t F = meta->levels[l].n_feats;
+		const uint32_t best = (F % 8u == 0u) ? 8u : (F % 4u == 0u) ? 4u : 2u;
+		if (best == width)
+			for (uint32_t j = 0; j < F / width; ++j) {
+				NR3D_CHECK(n_pseudo < NR3D_LOTD_MAX_PSEUDO, "LoTD::meta_regroup: too many pseudo levels");
+				out->map_levels[n_pseudo] = (uint16_t)l;
+				out->map_cnt[n_pseudo] = (uint16_t)j;
+				out->map_col[n_pseudo] = (uint16_t)(col + j * width);
+				++n_pseudo;
+			}
+		col += F;
+	}
+	out->n_pseudo_levels = n_pseudo;
 	return 0;
 }

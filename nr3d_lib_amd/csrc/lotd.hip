@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 	if (i >= N) return;
 	const uint32_t level = meta_level_of(md, q);
 	const uint32_t foff0 = meta_cnt_of(md, q) * G;
-	const uint32_t out0 = q * G;
+	const uint32_t out0 = meta_col_of(md, q);
 
 	float out_y[G];
 	float out_g[G][D];
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_
 	uint32_t base = 0;
 	if (!batch_base(ba, i, base)) return;
 	const uint32_t foff0 = meta_cnt_of(md, q) * G;
-	const uint32_t out0 = q * G;
+	const uint32_t out0 = meta_col_of(md, q);
 	const Lvl L = load_level(md, level);
 	const float *__restrict__ grid = params + (base + L.off);
 	float *__restrict__ gg = dparam + (base + L.off);
@@ -792,8 +792,9 @@ __device__ __forceinline__ void hvp_level(const nr3d_lotd_meta_t *__restrict__ m
 	for (int f0 = 0; f0 < G; f0 += 2) {
 		const uint32_t foff = meta_cnt_of(md, q) * G + f0;
 		float grad[2];
-		grad[0] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0) * g_se];
-		grad[1] = dL_dy[(int64_t)i * g_sn + (int64_t)(q * G + f0 + 1) * g_se];
+		const uint32_t col0 = meta_col_of(md, q) + (uint32_t)f0;
+		grad[0] = dL_dy[(int64_t)i * g_sn + (int64_t)col0 * g_se];
+		grad[1] = dL_dy[(int64_t)i * g_sn + (int64_t)(col0 + 1u) * g_se];
 		// s[k] = sum_f value(corner k)[f] * grad[f]
 		float sdot[1 << D];
 		{
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_index(Sched s, const nr3d_lotd_
 	for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
 	Cell<D> c;
 	locate<D>(xp, L, false, c);
-	int64_t *dst = out + ((size_t)i * E + (size_t)q * G) * (1u << D);
+	int64_t *dst = out + ((size_t)i * E + (size_t)meta_col_of(md, q)) * (1u << D);
 #pragma unroll
 	for (uint32_t k = 0; k < (1u << D); ++k) {
 		uint32_t p[D];

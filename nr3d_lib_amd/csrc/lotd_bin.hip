@@ -486,8 +486,9 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 		Cell<D> c;
 		if constexpr (FO) locate_forest(xp, L, smooth != 0, c); else locate<D>(xp, L, smooth != 0, c);
 		float grad[G], w[C];
+		const uint32_t col0 = meta_col_of(md, q);
 #pragma unroll
-		for (int f = 0; f < G; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(q * G + f) * g_se];
+		for (int f = 0; f < G; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(col0 + f) * g_se];
 		float a[D], vin[D];
 #pragma unroll
 		for (int d = 0; d < D; ++d) {

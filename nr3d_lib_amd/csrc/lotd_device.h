@@ -136,6 +136,8 @@ __device__ __forceinline__ uint32_t meta_u16(const uint16_t *tab, uint32_t i) {
 }
 __device__ __forceinline__ uint32_t meta_level_of(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q) { return meta_u16(md->map_levels, q); }
 __device__ __forceinline__ uint32_t meta_cnt_of(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q) { return meta_u16(md->map_cnt, q); }
+// first output column of pseudo level q (q * G for a plain meta; the original layout's column for a regrouped one)
+__device__ __forceinline__ uint32_t meta_col_of(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q) { return meta_u16(md->map_col, q); }
 
 // ---------------------------------------------------------------------------------------------
 // Cell locator: g = floor(x*(R-2)+0.5), t = frac, plus interpolation weight and its derivatives.

@@ -68,6 +68,39 @@ def test_fwd_split_launch_same_bits(oracle, dev, case, monkeypatch):
     assert_close(outs["1"][0], y_ref, name="y split launch")
 
 
+@pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "nplane"])
+def test_regrouped_forward_equals_the_single_call(oracle, dev, case, monkeypatch):
+    """the forward of a mixed-width meta with product-type levels runs as one call per feature width (8 / 4 / 2: wider lanes
+    for the wide levels, bindings._lotd.REGROUP; the calls write disjoint columns through the meta's map_col) -- against the
+    single call in pseudo levels of the global gcd (the reference's decomposition) and against the oracle: values and
+    Jacobian, with max_level, without the Jacobian, and with a row-major Jacobian"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=6007, seed=21)
+    assert m._groups is not None and len(m._groups) >= 2
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(_lotd, "REGROUP", on)
+        res = []
+        for kw in ({}, dict(max_level=m.n_levels // 2)):
+            y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True, **kw)
+            y0, _ = _lotd.lod_fwd(m, xt, pt, need_input_grad=False, **kw)
+            assert torch.equal(y, y0)
+            res += [y, j]
+        outs[on] = res
+    for a, b, nm in zip(outs[True], outs[False], ["y", "dy_dx", "y (max_level)", "dy_dx (max_level)"]):
+        assert a.shape == b.shape
+        assert_close(a, b.cpu().numpy(), rel=2e-6, name=f"regrouped vs single call: {nm}")
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    assert_close(outs[True][0], y_ref, name="y regrouped")
+    assert_close(outs[True][1], j_ref, name="dy_dx regrouped")
+    # the gradients that read this Jacobian
+    dx, dp = _lotd.lod_bwd(m, gt, xt, pt, outs[True][1], need_input_grad=True, need_param_grad=True)
+    assert_close(dx, oracle.lotd_bwd_dx(m_ref, g, j_ref), name="dL_dx from the regrouped Jacobian")
+    monkeypatch.setattr(m, "c_permute_dydx", False)            # row-major [N, E * D] Jacobian
+    monkeypatch.setattr(_lotd, "REGROUP", True)
+    y3, j3 = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    assert_close(j3.view(j_ref.shape), j_ref, name="dy_dx row-major regrouped")
+
+
 @pytest.mark.parametrize("case", list(LOTD_CASES))
 def test_bwd(oracle, dev, case, bin_mode):
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=1)
