@@ -25,6 +25,7 @@
 #include "lotd_device.h"
 #include <stdlib.h>
 #include <vector>
+#include <type_traits>
 #include <algorithm>
 
 namespace nr3d {
@@ -206,21 +207,25 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 					}
 			}
 		} else {
-			// ---- remaining N-linear types (VM, VecZMatXoY, CP, NPlaneMul): feature pairs to bound VGPRs ----
-#pragma unroll 1
-			for (int f0 = 0; f0 < G; f0 += 2) {
-				float v[1 << D][2];
-				corner_values_pair<D, ONLY>(L, grid, foff0 + f0, vec_ok != 0 && (L.F & 1u) == 0u, c, v);
-				float yy[2] = {0.0f, 0.0f}, gg[2][D];
+			// ---- remaining N-linear types (VM, VecZMatXoY, CP, NPlaneMul): feature pairs to bound VGPRs; four features at a
+			// time (one 16-byte request per table entry instead of two 8-byte ones) when the pseudo level is that wide and
+			// the level's entries are 16-byte aligned
+			auto accumulate = [&](auto nf_tag, int f0) {
+				constexpr int NF = decltype(nf_tag)::value;
+				float v[1 << D][NF];
+				corner_values_pair<D, ONLY, NF>(L, grid, foff0 + f0, vec_ok != 0 && (L.F % NF) == 0u, c, v);
+				float yy[NF], gg[NF][D];
 #pragma unroll
-				for (int f = 0; f < 2; ++f)
+				for (int f = 0; f < NF; ++f) {
+					yy[f] = 0.0f;
 #pragma unroll
 					for (int d = 0; d < D; ++d) gg[f][d] = 0.0f;
+				}
 #pragma unroll
 				for (uint32_t k = 0; k < (1u << D); ++k) {
 					const float w = corner_weight<D>(c, k);
-					yy[0] = __fmaf_rn(w, v[k][0], yy[0]);
-					yy[1] = __fmaf_rn(w, v[k][1], yy[1]);
+#pragma unroll
+					for (int f = 0; f < NF; ++f) yy[f] = __fmaf_rn(w, v[k][f], yy[f]);
 				}
 				if (DYDX) {
 #pragma unroll
@@ -229,17 +234,28 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 						for (uint32_t k = 0; k < (1u << D); ++k) {
 							if ((k >> gd) & 1u) continue;
 							const float w = face_weight<D>(c, k, gd, c.sc[gd] * c.dw[gd]);
-							gg[0][gd] = __fmaf_rn(w, v[k | (1u << gd)][0] - v[k][0], gg[0][gd]);
-							gg[1][gd] = __fmaf_rn(w, v[k | (1u << gd)][1] - v[k][1], gg[1][gd]);
+#pragma unroll
+							for (int f = 0; f < NF; ++f) gg[f][gd] = __fmaf_rn(w, v[k | (1u << gd)][f] - v[k][f], gg[f][gd]);
 						}
 				}
 #pragma unroll
 				for (int f = 0; f < G; ++f)
-					if (f == f0 || f == f0 + 1) {
+					if (f >= f0 && f < f0 + NF) {
 						out_y[f] = yy[f - f0];
 #pragma unroll
 						for (int d = 0; d < D; ++d) out_g[f][d] = gg[f - f0][d];
 					}
+			};
+			bool quads = false;
+			if constexpr (G % 4 == 0) quads = vec_ok != 0 && (L.F & 3u) == 0u && ((base + L.off) & 3u) == 0u;
+			if (quads) {
+				if constexpr (G % 4 == 0) {
+#pragma unroll 1
+					for (int f0 = 0; f0 < G; f0 += 4) accumulate(std::integral_constant<int, 4>{}, f0);
+				}
+			} else {
+#pragma unroll 1
+				for (int f0 = 0; f0 < G; f0 += 2) accumulate(std::integral_constant<int, 2>{}, f0);
 			}
 		}
 	}

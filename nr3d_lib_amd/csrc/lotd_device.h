@@ -356,9 +356,23 @@ __device__ __forceinline__ void ld_pair(const float *__restrict__ grid, uint32_t
 // ONLY >= 0: the instantiation serves levels of that one type (the other types' code and registers drop out);
 // kOnlyDenseHash: Dense and Hash levels only (hash-only metas)
 constexpr int kOnlyDenseHash = -2;
-template <int D, int ONLY = -1>
+// NF consecutive features of one table entry: one 8-byte (NF = 2) / 16-byte (NF = 4) load when the alignment allows
+template <int NF>
+__device__ __forceinline__ void ld_feats(const float *__restrict__ grid, uint32_t idx, bool vec, float (&o)[NF]) {
+	if constexpr (NF == 2) { ld_pair(grid, idx, vec, o); }
+	else {
+		static_assert(NF == 4, "ld_feats: 2 or 4 features");
+		if (vec) { const float4 t = *reinterpret_cast<const float4 *>(grid + idx); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+		else { o[0] = grid[idx]; o[1] = grid[idx + 1]; o[2] = grid[idx + 2]; o[3] = grid[idx + 3]; }
+	}
+}
+
+// NF = 4 (round 3): the product-type levels of a wide pseudo level read 16 bytes per table entry instead of two 8-byte
+// pieces -- the forward of configs[3]'s CP levels was bound by L2 requests (356 M per launch = 244 G/s, profiles/
+// r03g_c4_counters.txt), 24 per (point, 8-feature pseudo level) for 6 distinct 32-byte entries.
+template <int D, int ONLY = -1, int NF = 2>
 __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__restrict__ grid, uint32_t foff, bool vec,
-                                                   const Cell<D> &c, float (&v)[1 << D][2]) {
+                                                   const Cell<D> &c, float (&v)[1 << D][NF]) {
 	constexpr uint32_t C = 1u << D;
 	if constexpr (ONLY == kOnlyDenseHash) {                // hash-only metas: the values corner_value() loads
 #pragma unroll
@@ -366,20 +380,20 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 			uint32_t p[D];
 			corner_pos<D>(c, k, p);
 			const uint32_t i = ((L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p)) * L.F + foff;
-			ld_pair(grid, i, vec, v[k]);                      // one 8-byte request when the alignment allows
+			ld_feats<NF>(grid, i, vec, v[k]);                 // one request when the alignment allows
 		}
 		return;
 	}
 	if (ONLY == NR3D_LOD_CP || (ONLY < 0 && L.type == NR3D_LOD_CP)) {
-		float t[D][2][2];
+		float t[D][2][NF];
 #pragma unroll
 		for (int d = 0; d < D; ++d)
 #pragma unroll
-			for (uint32_t sl = 0; sl < 2; ++sl) ld_pair(grid, entry_line<D>(L, d, c.g[d] + sl) * L.F + foff, vec, t[d][sl]);
+			for (uint32_t sl = 0; sl < 2; ++sl) ld_feats<NF>(grid, entry_line<D>(L, d, c.g[d] + sl) * L.F + foff, vec, t[d][sl]);
 #pragma unroll
 		for (uint32_t k = 0; k < C; ++k)
 #pragma unroll
-			for (int f = 0; f < 2; ++f) {
+			for (int f = 0; f < NF; ++f) {
 				float r = t[0][k & 1u][f];
 #pragma unroll
 				for (int d = 1; d < D; ++d) r *= t[d][(k >> d) & 1u][f];
@@ -390,19 +404,19 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 	if constexpr (D <= 3 && ONLY < 0) {
 		if (L.type == NR3D_LOD_NPlaneMul) {
 			constexpr uint32_t NS = 1u << (D - 1);
-			float t[D][NS][2];
+			float t[D][NS][NF];
 #pragma unroll
 			for (int j = 0; j < D; ++j)
 #pragma unroll
 				for (uint32_t sl = 0; sl < NS; ++sl) {
 					uint32_t p[D];
 					corner_pos<D>(c, insert_zero(sl, D - 1 - j), p);
-					ld_pair(grid, entry_nplane_mul<D>(L, j, p) * L.F + foff, vec, t[j][sl]);
+					ld_feats<NF>(grid, entry_nplane_mul<D>(L, j, p) * L.F + foff, vec, t[j][sl]);
 				}
 #pragma unroll
 			for (uint32_t k = 0; k < C; ++k)
 #pragma unroll
-				for (int f = 0; f < 2; ++f) {
+				for (int f = 0; f < NF; ++f) {
 					float r = t[0][drop_bit<D>(k, D - 1)][f];
 #pragma unroll
 					for (int j = 1; j < D; ++j) r *= t[j][drop_bit<D>(k, D - 1 - j)][f];
@@ -415,11 +429,13 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 		if (ONLY == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VecZMatXoY) {
 			const bool vm = ONLY == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_VectorMatrix;
 #pragma unroll
-			for (uint32_t k = 0; k < C; ++k) { v[k][0] = 0.0f; v[k][1] = 0.0f; }
+			for (uint32_t k = 0; k < C; ++k)
+#pragma unroll
+				for (int f = 0; f < NF; ++f) v[k][f] = 0.0f;
 #pragma unroll
 			for (int d = 0; d < 3; ++d) {
 				if (!vm && d != 2) continue;
-				float pv[4][2], lv[2][2];
+				float pv[4][NF], lv[2][NF];
 				uint32_t le0 = 0;
 #pragma unroll
 				for (uint32_t m = 0; m < 4; ++m) {
@@ -428,14 +444,14 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 					uint32_t pe;
 					if (vm) { uint32_t pl[3], ln[3]; entry_vm(L, p, pl, ln); pe = pl[d]; if (m == 0) le0 = ln[d]; }
 					else { pe = L.res[2] + p[1] + p[0] * L.res[0]; if (m == 0) le0 = p[2]; }
-					ld_pair(grid, pe * L.F + foff, vec, pv[m]);
+					ld_feats<NF>(grid, pe * L.F + foff, vec, pv[m]);
 				}
-				ld_pair(grid, le0 * L.F + foff, vec, lv[0]);
-				ld_pair(grid, (le0 + 1u) * L.F + foff, vec, lv[1]);
+				ld_feats<NF>(grid, le0 * L.F + foff, vec, lv[0]);
+				ld_feats<NF>(grid, (le0 + 1u) * L.F + foff, vec, lv[1]);
 #pragma unroll
 				for (uint32_t k = 0; k < C; ++k)
 #pragma unroll
-					for (int f = 0; f < 2; ++f) {
+					for (int f = 0; f < NF; ++f) {
 						const float pvv = pv[drop_bit<3>(k, d)][f], lvv = lv[(k >> d) & 1u][f];
 						v[k][f] = vm ? __fmaf_rn(pvv, lvv, v[k][f]) : pvv * lvv;
 					}
@@ -448,7 +464,7 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 		for (uint32_t k = 0; k < C; ++k) {
 			uint32_t p[D];
 			corner_pos<D>(c, k, p);
-			corner_value<D, 2>(L, grid, foff, p, v[k]);
+			corner_value<D, NF>(L, grid, foff, p, v[k]);
 		}
 	}
 }
