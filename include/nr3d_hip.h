@@ -97,10 +97,10 @@ int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, const int32_t 
  * of the GLOBAL gcd of the widths, lotd_torch_api.cu:58-75 -- a meta that mixes 2- and 16-feature levels walks the
  * 16-feature one as eight 2-feature pseudo levels, repeating the index work eight times).  *out = *meta with
  * n_feat_per_pseudo_lvl = width (2, 4 or 8) and ONLY the pseudo levels of the levels whose own widest admissible width
- * (largest of 8, 4, 2 dividing n_feats) is `width`; levels, offsets, n_encoded_dims and the output columns (map_col) are
+ * (largest of 8, 4, 2 dividing n_feats, capped at `max_width`) is `width`; levels, offsets, n_encoded_dims and the output columns (map_col) are
  * those of *meta, so calls with the regrouped metas of all three widths write disjoint columns / table slices of the same
  * tensors and together equal one call with *meta.  out->n_pseudo_levels == 0: no level has that width. */
-int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t width, nr3d_lotd_meta_t *out);
+int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t width, uint32_t max_width, nr3d_lotd_meta_t *out);
 
 /* Batch addressing shared by all LoTD entry points (lotd_encoding.h:166-178):
  *   batch_inds   int64 [N] or NULL (value < 0 => point skipped)

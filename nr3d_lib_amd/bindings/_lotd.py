@@ -145,7 +145,7 @@ class LoDMeta:
             groups = []
             for width in (8, 4, 2):
                 g = _CMeta()
-                H.check(H.lib().nr3d_lotd_meta_regroup(C.byref(self._c), C.c_uint32(width), C.byref(g)))
+                H.check(H.lib().nr3d_lotd_meta_regroup(C.byref(self._c), C.c_uint32(width), C.c_uint32(8), C.byref(g)))
                 if g.n_pseudo_levels:
                     groups.append(g)
             if len(groups) > 1 or (groups and groups[0].n_feat_per_pseudo_lvl != self.n_feat_per_pseudo_lvl):

@@ -162,7 +162,7 @@ extern "C" int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, con
 	return 0;
 }
 
-extern "C" int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t width, nr3d_lotd_meta_t *out) {
+extern "C" int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t width, uint32_t max_width, nr3d_lotd_meta_t *out) {
 	NR3D_CHECK(meta && out, "LoTD::meta_regroup: NULL argument");
 	NR3D_CHECK(width == 2 || width == 4 || width == 8, "LoTD::meta_regroup: width must be 2, 4 or 8");
 	*out = *meta;
@@ -173,7 +173,8 @@ extern "C" int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t wid
 	uint32_t n_pseudo = 0, col = 0;
 	for (uint32_t l = 0; l < meta->n_levels; ++l) {
 		const uint32_t F = meta->levels[l].n_feats;
-		const uint32_t best = (F % 8u == 0u) ? 8u : (F % 4u == 0u) ? 4u : 2u;
+		uint32_t best = (F % 8u == 0u) ? 8u : (F % 4u == 0u) ? 4u : 2u;
+		if (max_width >= 2u && best > max_width) best = max_width;
 		if (best == width)
 			for (uint32_t j = 0; j < F / width; ++j) {
 				NR3D_CHECK(n_pseudo < NR3D_LOTD_MAX_PSEUDO, "LoTD::meta_regroup: too many pseudo levels");
