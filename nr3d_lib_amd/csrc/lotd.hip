@@ -827,6 +827,49 @@ __device__ __forceinline__ bool hvp_type(uint32_t t) {
 	return t == NR3D_LOD_Dense || t == NR3D_LOD_Hash || t == NR3D_LOD_VectorMatrix || t == NR3D_LOD_VecZMatXoY;
 }
 
+// The same for ALL nq pseudo levels of one level at once (metas with product-type levels, lane-serial kernel; round 3).
+// The Hessian-vector product is linear in s_c = value(corner c) . grad, so the dot product is accumulated over every feature
+// of the level first and hvp_from_sdot runs once per LEVEL instead of once per feature pair; and the table entries are read
+// four features per 16-byte load when the level's entries are aligned (the kernel was L2-request bound on configs[3]:
+// 625 M requests = 177 G/s, profiles/r03g_c4_counters.txt).  Same sum, other association than the per-pair form.
+template <int D>
+__device__ __forceinline__ void hvp_level_merged(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q, uint32_t nq, uint32_t G,
+                                                 const Lvl &L, const Cell<D> &c, uint32_t smooth, const float (&vin)[D], uint32_t i,
+                                                 const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
+                                                 const float *__restrict__ grid, bool vec_ok, bool aligned4, float (&acc)[D]) {
+	const uint32_t f_begin = meta_cnt_of(md, q) * G, n_f = nq * G, col_begin = meta_col_of(md, q);
+	float sdot[1 << D];
+#pragma unroll
+	for (uint32_t k = 0; k < (1u << D); ++k) sdot[k] = 0.0f;
+	const bool quads = vec_ok && aligned4 && (L.F & 3u) == 0u && (f_begin & 3u) == 0u && (n_f & 3u) == 0u;
+	if (quads) {
+#pragma unroll 1
+		for (uint32_t f0 = 0; f0 < n_f; f0 += 4) {
+			float grad[4], v[1 << D][4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) grad[j] = dL_dy[(int64_t)i * g_sn + (int64_t)(col_begin + f0 + j) * g_se];
+			corner_values_pair<D, -1, 4>(L, grid, f_begin + f0, true, c, v);
+#pragma unroll
+			for (uint32_t k = 0; k < (1u << D); ++k)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) sdot[k] = __fmaf_rn(v[k][j], grad[j], sdot[k]);
+		}
+	} else {
+#pragma unroll 1
+		for (uint32_t f0 = 0; f0 < n_f; f0 += 2) {
+			float grad[2], v[1 << D][2];
+#pragma unroll
+			for (int j = 0; j < 2; ++j) grad[j] = dL_dy[(int64_t)i * g_sn + (int64_t)(col_begin + f0 + j) * g_se];
+			corner_values_pair<D, -1, 2>(L, grid, f_begin + f0, vec_ok && (L.F & 1u) == 0u, c, v);
+#pragma unroll
+			for (uint32_t k = 0; k < (1u << D); ++k)
+#pragma unroll
+				for (int j = 0; j < 2; ++j) sdot[k] = __fmaf_rn(v[k][j], grad[j], sdot[k]);
+		}
+	}
+	hvp_from_sdot<D>(c, smooth, vin, sdot, acc);
+}
+
 // one lane = one point, the pseudo levels one after another (no workspace needed)
 template <int D, int G, bool DH = false>
 __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
@@ -847,14 +890,23 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 #pragma unroll
 		for (int d = 0; d < D; ++d) { xp[d] = x[(size_t)i * D + d]; vin[d] = dL_ddLdx[(size_t)i * D + d]; }
 #pragma unroll 1
-		for (uint32_t q = 0; q < n_pseudo; ++q) {
+		for (uint32_t q = 0; q < n_pseudo;) {
 			const uint32_t level = meta_level_of(md, q);
+			uint32_t nq = 1;
+			if constexpr (!DH)                        // all pseudo levels of this level in one go (they are consecutive)
+				while (q + nq < n_pseudo && meta_level_of(md, q + nq) == level) ++nq;
+			const uint32_t q0 = q;
+			q += nq;
 			if ((int32_t)level > max_level) continue;
 			const Lvl L = load_level(md, level);
 			if (!DH && !hvp_type(L.type)) continue;
 			Cell<D> c;
 			locate<D>(xp, L, smooth != 0, c);
-			hvp_level<D, G, DH>(md, q, L, c, smooth, vin, i, dL_dy, g_sn, g_se, params + (base + L.off), vec_ok, acc);
+			if constexpr (DH)
+				hvp_level<D, G, DH>(md, q0, L, c, smooth, vin, i, dL_dy, g_sn, g_se, params + (base + L.off), vec_ok, acc);
+			else
+				hvp_level_merged<D>(md, q0, nq, G, L, c, smooth, vin, i, dL_dy, g_sn, g_se, params + (base + L.off), vec_ok,
+				                    (reinterpret_cast<uintptr_t>(params + (base + L.off)) & 15u) == 0u, acc);
 		}
 	}
 #pragma unroll
