@@ -954,9 +954,136 @@ static uint32_t chunk_points(uint32_t n) {
 	return n < chunk ? n : chunk;
 }
 
+// -------------------------------------------------------------------------------------------------
+// CP levels without records (round 3).  A 3-D CP level is three LINE tables, sum_d R_d entries in all (configs[3]: 2304 /
+// 4608 / 9216) -- its whole gradient table of one 2-feature pseudo level fits LDS as fp64 (<= 144 KiB).  Through the record
+// path such a level costs 6 records x 12 B per point and pseudo level written, sorted (every record lands in the ONE bucket the
+// table is: the ranks come from ballots) and read back: configs[3]'s fourteen CP pseudo levels were ~2.3 of the 8 ms of a
+// dL/dparam pass.  Here a workgroup takes a share of the points and ONE pseudo level, forms the same six updates per point
+// (emit_product: the record path's arithmetic) and adds them to its LDS table with ds_add_f64 (order-independent to fp64
+// rounding); the workgroups' tables are written out as fp32 and summed by k_cp_reduce in replica order.
+// NR3D_LOTD_CP_DIRECT=0: CP levels take the record path like every other type.
+// -------------------------------------------------------------------------------------------------
+constexpr int kCpThreads = 512;
+constexpr uint32_t kCpMaxItems = 32, kCpLdsBytes = 144 * 1024, kCpReplicas = 64;
+struct CpPlan {
+	uint32_t n_items, R, pts_per_rep;
+	uint32_t q[kCpMaxItems];             // pseudo level of item k
+	uint32_t part_off[kCpMaxItems];      // float offset of its R partial tables inside `partial`
+};
+
+template <bool SECOND>
+__global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n, uint32_t smooth,
+                                                          const float *__restrict__ x, const float *__restrict__ vin_,
+                                                          const float *__restrict__ g, int64_t g_sn, int64_t g_se,
+                                                          const float *__restrict__ params, float *__restrict__ partial) {
+	extern __shared__ __attribute__((aligned(16))) double cp_acc[];            // [entries][2]
+	const uint32_t r = blockIdx.x, item = blockIdx.y;
+	const uint32_t q = cp.q[item];
+	const Lvl L = load_level(md, meta_level_of(md, q));
+	const uint32_t n_acc = L.size * 2u;
+	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) cp_acc[t] = 0.0;
+	__syncthreads();
+	const uint32_t foff = meta_cnt_of(md, q) * 2u, col0 = meta_col_of(md, q);
+	const float *__restrict__ grid = params + L.off;
+	const uint32_t p_lo = r * cp.pts_per_rep, p_hi = min(n, p_lo + cp.pts_per_rep);
+	for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kCpThreads) {
+		float xp[3], vin[3], a[3];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
+		Cell<3> c;
+		locate<3>(xp, L, smooth != 0, c);
+		float grad[2], w[8];
+		grad[0] = g[(int64_t)i * g_sn + (int64_t)col0 * g_se];
+		grad[1] = g[(int64_t)i * g_sn + (int64_t)(col0 + 1u) * g_se];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			vin[d] = SECOND ? vin_[(size_t)i * 3 + d] : 0.0f;
+			a[d] = SECOND ? c.sc[d] * vin[d] * c.dw[d] : 0.0f;
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < 8u; ++k) {                  // bin_body's corner weights: first order / combined d/dx weight
+			if (!SECOND) w[k] = corner_weight<3>(c, k);
+			else {
+				float sum = 0.0f;
+#pragma unroll
+				for (int d = 0; d < 3; ++d) {
+					const float t = face_weight<3>(c, k, d, a[d]);
+					sum += ((k >> d) & 1u) ? t : -t;
+				}
+				w[k] = sum;
+			}
+		}
+		uint32_t ent[6];
+		float val[6][2];
+		emit_product<3, 2, 6, 2, true>(L, c, w, grad, grid, foff, ent, val);
+#pragma unroll
+		for (int u = 0; u < 6; ++u) {
+			atomicAdd(&cp_acc[ent[u] * 2u], (double)val[u][0]);
+			atomicAdd(&cp_acc[ent[u] * 2u + 1u], (double)val[u][1]);
+		}
+	}
+	__syncthreads();
+	float *mine = partial + cp.part_off[item] + (size_t)r * n_acc;
+	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) mine[t] = (float)cp_acc[t];
+}
+
+// dL/dparam of a CP pseudo level += sum of its replicas' tables (replica 0 first)
+__global__ __launch_bounds__(256) void k_cp_reduce(CpPlan cp, const nr3d_lotd_meta_t *__restrict__ md, const float *__restrict__ partial,
+                                                   float *__restrict__ dparam) {
+	const uint32_t item = blockIdx.y, q = cp.q[item];
+	const Lvl L = load_level(md, meta_level_of(md, q));
+	const uint32_t n_acc = L.size * 2u, t = blockIdx.x * 256u + threadIdx.x;
+	if (t >= n_acc) return;
+	const float *p0 = partial + cp.part_off[item] + t;
+	float sum = 0.0f;
+	for (uint32_t r = 0; r < cp.R; ++r) sum += p0[(size_t)r * n_acc];
+	float *dst = dparam + L.off + (size_t)(t >> 1) * L.F + meta_cnt_of(md, q) * 2u + (t & 1u);
+	*dst += sum;
+}
+
+static bool cp_direct_enabled() {
+	static int on = -1;
+	if (on < 0) { const char *e = getenv("NR3D_LOTD_CP_DIRECT"); on = e ? (atoi(e) != 0) : 1; }
+	return on != 0;
+}
+// the CP pseudo levels k_cp_direct serves (mask over the meta's pseudo levels; 0: none): unbatched 3-D metas with 2-feature
+// pseudo levels, levels in [min_level, max_level] whose fp64 table fits LDS, partial tables inside `part_floats`
+static uint64_t cp_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level, int32_t max_level, uint64_t part_floats, CpPlan &cp,
+                        uint32_t &max_acc) {
+	cp.n_items = 0; cp.R = 1; cp.pts_per_rep = n; max_acc = 0;
+	if (!cp_direct_enabled() || m->n_dims_to_encode != 3 || m->n_feat_per_pseudo_lvl != 2 || m->n_pseudo_levels > 64u || n == 0) return 0;
+	uint64_t mask = 0, floats_per_replica = 0;
+	for (uint32_t q = 0; q < m->n_pseudo_levels && cp.n_items < kCpMaxItems; ++q) {
+		const uint32_t lv = m->map_levels[q];
+		const nr3d_lotd_level_t &L = m->levels[lv];
+		if (L.type != NR3D_LOD_CP || (int32_t)lv < min_level || (int32_t)lv > max_level) continue;
+		if ((uint64_t)L.size * 16u > kCpLdsBytes) continue;
+		cp.q[cp.n_items++] = q;
+		mask |= 1ull << q;
+		floats_per_replica += (uint64_t)L.size * 2u;
+		max_acc = max_acc > L.size * 2u ? max_acc : L.size * 2u;
+	}
+	if (!cp.n_items) return 0;
+	uint32_t R = kCpReplicas;
+	const uint32_t by_points = div_up(n, 4096u);             // >= 4096 points per replica
+	R = R > by_points ? by_points : R;
+	while (R > 1 && floats_per_replica * R > part_floats) R >>= 1;
+	if (floats_per_replica * R > part_floats) { cp.n_items = 0; return 0; }
+	cp.R = R;
+	cp.pts_per_rep = div_up(n, R);
+	uint64_t off = 0;
+	for (uint32_t k = 0; k < cp.n_items; ++k) {
+		cp.part_off[k] = (uint32_t)off;
+		off += (uint64_t)m->levels[m->map_levels[cp.q[k]]].size * 2u * R;
+	}
+	return mask;
+}
+
 // plan for the pseudo levels of record class `cls` (0 levels => n_pseudo == 0)
 static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, uint32_t cls, BinPlan &plan,
-                      uint64_t &offs_words, int32_t min_level = 0, int32_t max_level = 0x7fffffff, bool forest = false) {
+                      uint64_t &offs_words, int32_t min_level = 0, int32_t max_level = 0x7fffffff, bool forest = false,
+                      uint64_t skip = 0) {
 	const uint32_t D = m->n_dims_to_encode, G = m->n_feat_per_pseudo_lvl;
 	const uint32_t kBinPts = bin_points(G, cls);
 	if (m->n_pseudo_levels > kMaxPlanLevels) return false;
@@ -971,6 +1098,7 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_ba
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
 		if (rec_class(rec_count(L.type, D, forest)) != cls) continue;
+		if (q < 64u && ((skip >> q) & 1ull)) continue;          // served without records (k_cp_direct)
 		// levels outside the requested range get no stage-A blocks, offsets or work items (max_level schedules, the
 		// level-bucket calls of the data-parallel path)
 		if ((int32_t)m->map_levels[q] < min_level || (int32_t)m->map_levels[q] > max_level) continue;
@@ -1168,10 +1296,37 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				return rc;
 			continue;
 		}
+		// CP levels whose table fits LDS skip the records (k_cp_direct): they run first, in the partial-table region the
+		// record classes use afterwards
+		uint64_t cp_mask = 0;
+		if (!forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size) {
+			CpPlan cp;
+			uint32_t max_acc = 0;
+			cp_mask = cp_plan(meta, n, min_level, max_level, lay.part_bytes / 4, cp, max_acc);
+			if (cp_mask) {
+				static bool cp_attr[64] = {};
+				int dev_id = 0;
+				NR3D_HIP_CHECK(hipGetDevice(&dev_id));
+				if (!cp_attr[dev_id & 63]) {
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
+					cp_attr[dev_id & 63] = true;
+				}
+				const size_t lds = (size_t)max_acc * 8;
+				if (second)
+					hipLaunchKernelGGL(k_cp_direct<true>, dim3(cp.R, cp.n_items), dim3(kCpThreads), lds, st, cp, md, n, meta->interpolation_type,
+					                   xc, vc, gc, sn, se, params, partial);
+				else
+					hipLaunchKernelGGL(k_cp_direct<false>, dim3(cp.R, cp.n_items), dim3(kCpThreads), lds, st, cp, md, n, meta->interpolation_type,
+					                   xc, vc, gc, sn, se, params, partial);
+				hipLaunchKernelGGL(k_cp_reduce, dim3(div_up(max_acc, 256u), cp.n_items), dim3(256), 0, st, cp, md, partial, dparam);
+				NR3D_LAUNCH_CHECK();
+			}
+		}
 		for (uint32_t cls : kClasses) {
 			BinPlan pl;
 			uint64_t ow;
-			make_plan(meta, n, n_batches, cls, pl, ow, min_level, max_level, forest != nullptr);
+			make_plan(meta, n, n_batches, cls, pl, ow, min_level, max_level, forest != nullptr, cp_mask);
 			if (pl.n_pseudo == 0) continue;
 			int rc = 0;
 			if (forest) {                                  // 3-D (binnable); one stage-A kernel per record class
