@@ -964,7 +964,7 @@ static uint32_t chunk_points(uint32_t n) {
 // rounding); the workgroups' tables are written out as fp32 and summed by k_cp_reduce in replica order.
 // NR3D_LOTD_CP_DIRECT=0: CP levels take the record path like every other type.
 // -------------------------------------------------------------------------------------------------
-constexpr int kCpThreads = 512;
+constexpr int kCpThreads = 1024;
 constexpr uint32_t kCpMaxItems = 32, kCpLdsBytes = 144 * 1024, kCpReplicas = 64;
 struct CpPlan {
 	uint32_t n_items, R, pts_per_rep;
@@ -987,6 +987,7 @@ __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_
 	const uint32_t foff = meta_cnt_of(md, q) * 2u, col0 = meta_col_of(md, q);
 	const float *__restrict__ grid = params + L.off;
 	const uint32_t p_lo = r * cp.pts_per_rep, p_hi = min(n, p_lo + cp.pts_per_rep);
+#pragma unroll 2
 	for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kCpThreads) {
 		float xp[3], vin[3], a[3];
 #pragma unroll
