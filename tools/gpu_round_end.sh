@@ -4,7 +4,7 @@
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT; mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -6 > gpurun_out/${TAG}_pytest.log; tail -3 gpurun_out/${TAG}_pytest.log
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" > gpurun_out/${TAG}_pytest.log; cat gpurun_out/${TAG}_pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 bash tools/gpu_profile.sh ${TAG} pmc > /dev/null 2>&1; head -16 gpurun_out/${TAG}/bench_kernel_stats.txt
 bash tools/gpu_counters.sh ${TAG}_ctr "k_fwd|k_pair_bin|k_pair_accum|k_contract|k_march|k_composite" > /dev/null 2>&1
