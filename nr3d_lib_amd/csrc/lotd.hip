@@ -949,76 +949,204 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_lv(Sched s, const nr3d_lo
 }
 
 // ... and with the forward's TWO lanes per (point, pseudo level) (k_fwd_pairlane: 3-D Dense / Hash, 2-feature pseudo
-// levels, unbatched): lane s gathers the side-s corner of each of the four pairs -- 4 / 4.25 L2 requests per (point,
-// level) instead of 8 --, the partners swap through DPP so that lane s holds all 8 corners of FEATURE s, multiplies by its
-// dL_dy column and swaps once more: s_c = v_c[0] g_0 + v_c[1] g_1, the serial kernel's sum.  Both lanes then run the same
-// Hessian arithmetic (hvp_from_sdot); lane 0 stores.
+// levels, unbatched), in the forward's lean form (round 3; the first pair-lane form formed s_c = v_c . grad per corner and
+// ran the 8-corner sum hvp_from_sdot: 423 VALU instructions per wave, 630 us for 2^20 points against the forward's 333).
+// The contraction with dL_dy is linear, so lane s keeps FEATURE s: it gathers the side-s corner of the four pairs, swaps one
+// value per pair (as the forward does) and builds the Hessian of its feature's interpolant from the lerp tree's own
+// differences.  With P the pair dim, A, B the other two, d[m] the (signed) difference along P at the (A, B) corner m and
+// b[m] the value lerped along P:
+//     G_B = lerp_A(b2, b3) - lerp_A(b0, b1)       M_AB = (b3 - b2) - (b1 - b0)            G_A = lerp_B(b1 - b0, b3 - b2)
+//     M_PB = lerp_A(d2, d3) - lerp_A(d0, d1)      M_PA = lerp_B(d1 - d0, d3 - d2)         G_P = lerp_B(lerp_A(d0, d1), lerp_A(d2, d3))
+//     H[d][e] = s_d w'_d s_e w'_e M_de  (d != e),     H[d][d] = s_d^2 w''_d G_d  (smoothstep only; 0 for linear)
+// out = (H v) * dL_dy[feature s]; the partners add their two features through one more DPP swap and lane 0 stores.  Same
+// polynomial as hvp_from_sdot (the oracle's corner sum), other association: agreement to fp32 rounding of the level's values.
+// dL_dy [N, 2 P] (any strides) -> g_pairs [P][N][2]: a level's pass of the kernel below reads its two columns as one
+// contiguous stream.  Reading them in place costs as much as the table gathers (measured, tools/exp_hvp_variants.py,
+// profiles/r03i_hvp_experiments.txt: 673 -> 401 us per 2^20 points without the dL_dy loads): 8 of every row's 128 bytes per
+// level, and every level's XCD pulls the whole line across the fabric.
+constexpr int kGpPts = 128, kGpLv = 16;            // tile: points x pseudo levels
+__global__ __launch_bounds__(kBlock) void k_hvp_pairs(uint32_t N, uint32_t P, const float *__restrict__ dL_dy, int64_t g_sn,
+                                                      int64_t g_se, float *__restrict__ g_pairs) {
+	__shared__ float2 tile[kGpLv][kGpPts + 1];
+	const uint32_t i0 = blockIdx.x * kGpPts, q0 = blockIdx.y * kGpLv;
+#pragma unroll
+	for (uint32_t k = 0; k < kGpPts * kGpLv / kBlock; ++k) {
+		const uint32_t idx = k * kBlock + threadIdx.x, i = idx / kGpLv, qq = idx % kGpLv;
+		float2 v = make_float2(0.0f, 0.0f);
+		if (i0 + i < N && q0 + qq < P) {
+			const float *src = dL_dy + (int64_t)(i0 + i) * g_sn + (int64_t)((q0 + qq) * 2u) * g_se;
+			v = make_float2(src[0], src[g_se]);
+		}
+		tile[qq][i] = v;
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t k = 0; k < kGpPts * kGpLv / kBlock; ++k) {
+		const uint32_t idx = k * kBlock + threadIdx.x, qq = idx / kGpPts, i = idx % kGpPts;
+		if (i0 + i < N && q0 + qq < P)
+		{
+			typedef float f2v __attribute__((ext_vector_type(2)));
+			const float2 v = tile[qq][i];
+			f2v o; o.x = v.x; o.y = v.y;
+			__builtin_nontemporal_store(o, reinterpret_cast<f2v *>(g_pairs) + (size_t)(q0 + qq) * N + i0 + i);
+		}
+	}
+}
+
+constexpr int kHvpSub = 2;                         // 32-point groups per wave
+template <int SUB>
 __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_pl(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                           int32_t max_level, uint32_t smooth, const float *__restrict__ dL_ddLdx,
-                                                          const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
+                                                          const float *__restrict__ g_pairs,
                                                           const float *__restrict__ x, const float *__restrict__ params,
-                                                          float *__restrict__ partial) {
-	constexpr int D = 3;
+                                                          float *__restrict__ partial, uint32_t dbg) {
 	uint32_t q, chunk;
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
-	const uint32_t i = chunk * kPlPts + (threadIdx.x >> 1);
-	const uint32_t side = threadIdx.x & 1u;
-	if (i >= N) return;                                  // both lanes of a pair leave together
+	constexpr uint32_t kGroup = 32;
+	constexpr uint32_t kPts = kPlPts * SUB;
+	const uint32_t lane = threadIdx.x & 63u, side = lane & 1u, pl = lane >> 1;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t w0 = chunk * kPts + wave * kGroup * SUB;
+	if (w0 >= N) return;
 	const uint32_t level = meta_level_of(md, q);
 	const uint32_t foff0 = meta_cnt_of(md, q) * 2u;
-	float acc[D] = {0.0f, 0.0f, 0.0f};
-	if ((int32_t)level <= max_level) {
-		const Lvl L = load_level(md, level);
-		const float *__restrict__ grid = params + L.off;
-		float xp[D], vin[D];
+	const bool live = (int32_t)level <= max_level;
+	const Lvl L = load_level(md, live ? level : 0u);
+	const bool dense = L.type == NR3D_LOD_Dense;
+	const char *__restrict__ base = reinterpret_cast<const char *>(params + L.off + foff0);
+	const uint32_t stride = L.F * 4u;
+	const bool small = L.size < (1u << 24);
+	const float sc0 = (float)(L.res[0] - 2u), sc1 = (float)(L.res[1] - 2u), sc2 = (float)(L.res[2] - 2u);
+
+	// ---- phase 1: x, v = dL_ddLdx and this lane's dL_dy column (lanes beyond N re-read the last point and store nothing)
+	float xp[SUB][3], vp[SUB][3], gs[SUB];
 #pragma unroll
-		for (int d = 0; d < D; ++d) { xp[d] = x[(size_t)i * D + d]; vin[d] = dL_ddLdx[(size_t)i * D + d]; }
-		Cell<D> c;
-		locate<D>(xp, L, smooth != 0, c);
-		const bool dense = L.type == NR3D_LOD_Dense;
-		uint32_t e[4];
-		if (dense) {
-			const uint32_t e00 = (c.g[0] * L.res[1] + c.g[1]) * L.res[2] + c.g[2] + side;
-			const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
-			e[0] = e00; e[1] = e00 + sx; e[2] = e00 + sy; e[3] = e00 + sx + sy;
-		} else {
-			const uint32_t hy0 = c.g[1] * kPrimes[1], hy1 = hy0 + kPrimes[1];
-			const uint32_t hz0 = c.g[2] * kPrimes[2], hz1 = hz0 + kPrimes[2];
-			const uint32_t xs = c.g[0] + side;
-			const uint32_t h[4] = {xs ^ hy0 ^ hz0, xs ^ hy1 ^ hz0, xs ^ hy0 ^ hz1, xs ^ hy1 ^ hz1};
-			if ((L.size & (L.size - 1u)) == 0u) {
+	for (int u = 0; u < SUB; ++u) {
+		const uint32_t g0 = w0 + (uint32_t)u * kGroup;
+		const uint32_t gc = g0 < N ? g0 : w0;
+		uint32_t pi = pl;
+		if (gc + kGroup > N) { const uint32_t i = gc + pl; pi = (i < N ? i : N - 1u) - gc; }
+		const float *px = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + (size_t)gc * 12u + pi * 12u);
+		const float *pv = reinterpret_cast<const float *>(reinterpret_cast<const char *>(dL_ddLdx) + (size_t)gc * 12u + pi * 12u);
+		const char *gb = reinterpret_cast<const char *>(g_pairs) + ((size_t)q * N + gc) * 8u;       // [pseudo level][point][2]
+		const uint32_t g_lane = pi * 8u + side * 4u;
+		xp[u][0] = px[0]; xp[u][1] = px[1]; xp[u][2] = px[2];
+		if (dbg & 8u) { vp[u][0] = xp[u][1]; vp[u][1] = xp[u][2]; vp[u][2] = xp[u][0]; }
+		else { vp[u][0] = pv[0]; vp[u][1] = pv[1]; vp[u][2] = pv[2]; }
+		gs[u] = (dbg & 4u) ? 1.0f + (float)side : *reinterpret_cast<const float *>(gb + g_lane);
+	}
+	float ox[SUB], oy[SUB], oz[SUB];
 #pragma unroll
-				for (int m = 0; m < 4; ++m) e[m] = h[m] & (L.size - 1u);
+	for (int u = 0; u < SUB; ++u) { ox[u] = 0.0f; oy[u] = 0.0f; oz[u] = 0.0f; }
+	if (live) {
+		// ---- phase 2: cells, corner offsets, all 4 * SUB gathers in flight (the forward's addressing)
+		float2 t[SUB][4];
+		float wP[SUB], wA[SUB], wB[SUB], s1P[SUB], s1A[SUB], s1B[SUB], s2P[SUB], s2A[SUB], s2B[SUB], vP[SUB], vA[SUB], vB[SUB];
+#pragma unroll
+		for (int u = 0; u < SUB; ++u) {
+			const float v0 = __fmaf_rn(xp[u][0], sc0, 0.5f), v1 = __fmaf_rn(xp[u][1], sc1, 0.5f), v2 = __fmaf_rn(xp[u][2], sc2, 0.5f);
+			const float f0 = floorf(v0), f1 = floorf(v1), f2 = floorf(v2);
+			float t0 = v0 - f0, t1 = v1 - f1, t2 = v2 - f2;
+			const uint32_t c0 = (uint32_t)f0, c1 = (uint32_t)f1, c2 = (uint32_t)f2;
+			float a0 = sc0, a1 = sc1, a2 = sc2;            // scale * w'
+			float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f;          // scale^2 * w''
+			if (smooth) {
+				h0 = (sc0 * sc0) * __fmaf_rn(-12.0f, t0, 6.0f); h1 = (sc1 * sc1) * __fmaf_rn(-12.0f, t1, 6.0f); h2 = (sc2 * sc2) * __fmaf_rn(-12.0f, t2, 6.0f);
+				a0 *= 6.0f * t0 * (1.0f - t0); a1 *= 6.0f * t1 * (1.0f - t1); a2 *= 6.0f * t2 * (1.0f - t2);
+				t0 = t0 * t0 * __fmaf_rn(-2.0f, t0, 3.0f); t1 = t1 * t1 * __fmaf_rn(-2.0f, t1, 3.0f); t2 = t2 * t2 * __fmaf_rn(-2.0f, t2, 3.0f);
+			}
+			uint32_t e[4], off[4];
+			if (dense) {
+				uint32_t e00;
+				if (small) e00 = __umul24(__umul24(c0, L.res[1]) + c1, L.res[2]) + c2 + side;
+				else e00 = (c0 * L.res[1] + c1) * L.res[2] + c2 + side;
+				const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
+				e[0] = e00; e[1] = e00 + sx; e[2] = e00 + sy; e[3] = e00 + sx + sy;
+				wP[u] = t2; wA[u] = t0; wB[u] = t1; s1P[u] = a2; s1A[u] = a0; s1B[u] = a1; s2P[u] = h2; s2A[u] = h0; s2B[u] = h1;
+				vP[u] = vp[u][2]; vA[u] = vp[u][0]; vB[u] = vp[u][1];
+			} else {
+				const uint32_t hy0 = c1 * kPrimes[1], hy1 = hy0 + kPrimes[1];
+				const uint32_t hz0 = c2 * kPrimes[2], hz1 = hz0 + kPrimes[2];
+				const uint32_t xs = c0 + side;
+				const uint32_t b0 = xs ^ hy0, b1 = xs ^ hy1;
+				e[0] = b0 ^ hz0; e[1] = b1 ^ hz0; e[2] = b0 ^ hz1; e[3] = b1 ^ hz1;
+				if ((L.size & (L.size - 1u)) == 0u) {
+					const uint32_t mask = L.size - 1u;
+#pragma unroll
+					for (int m = 0; m < 4; ++m) e[m] &= mask;
+				} else {
+#pragma unroll
+					for (int m = 0; m < 4; ++m) e[m] %= L.size;
+				}
+				wP[u] = t0; wA[u] = t1; wB[u] = t2; s1P[u] = a0; s1A[u] = a1; s1B[u] = a2; s2P[u] = h0; s2A[u] = h1; s2B[u] = h2;
+				vP[u] = vp[u][0]; vA[u] = vp[u][1]; vB[u] = vp[u][2];
+			}
+			if (small) {
+#pragma unroll
+				for (int m = 0; m < 4; ++m) off[m] = __umul24(e[m], stride);
 			} else {
 #pragma unroll
-				for (int m = 0; m < 4; ++m) e[m] = h[m] % L.size;
+				for (int m = 0; m < 4; ++m) off[m] = e[m] * stride;
+			}
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				if (dbg & 2u) t[u][m] = make_float2(__int_as_float(off[m] | 0x3f000000u), __int_as_float(off[m] ^ 0x3f123456u));
+				else t[u][m] = load_pair<float>(base + off[m]);
 			}
 		}
-		const char *__restrict__ base = reinterpret_cast<const char *>(grid + foff0);
-		const uint32_t stride = L.F * (uint32_t)sizeof(float);
-		float2 t[4];
+		// ---- phase 3: the lerp tree's differences -> gradient and mixed second differences -> H v
 #pragma unroll
-		for (int m = 0; m < 4; ++m) t[m] = load_pair<float>(base + e[m] * stride);
-		const float gs = dL_dy[(int64_t)i * g_sn + (int64_t)(q * 2u + side) * g_se];
-		auto swap = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); };
-		float sdot[8];
+		for (int u = 0; u < SUB; ++u) {
+			const float wk = side ? 1.0f - wP[u] : wP[u];
+			float b[4], d[4];
 #pragma unroll
-		for (uint32_t m = 0; m < 4; ++m) {
-			const float sw_x = swap(t[m].x), sw_y = swap(t[m].y);
-			const float lo = side ? sw_y : t[m].x, hi = side ? t[m].y : sw_x;       // feature `side` at the pair's two corners
-			const float p_lo = lo * gs, p_hi = hi * gs;
-			// v[0] g_0 + v[1] g_1: the feature-0 product first, as the serial kernel's fma chain rounds it
-			const float o_lo = swap(p_lo), o_hi = swap(p_hi);
-			const float s_lo = side ? (o_lo + p_lo) : (p_lo + o_lo), s_hi = side ? (o_hi + p_hi) : (p_hi + o_hi);
-			if (dense) { sdot[m] = s_lo; sdot[m | 4u] = s_hi; }
-			else { sdot[m << 1] = s_lo; sdot[(m << 1) | 1u] = s_hi; }
+			for (int m = 0; m < 4; ++m) {
+				const float keep = side ? t[u][m].y : t[u][m].x;
+				const float send = side ? t[u][m].x : t[u][m].y;
+				const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xf, 0xf, true));
+				d[m] = recv - keep;
+				b[m] = __fmaf_rn(wk, d[m], keep);
+			}
+			const float cA0 = b[1] - b[0], cA1 = b[3] - b[2];
+			const float mAB = cA1 - cA0;
+			const float q0 = d[1] - d[0], q1 = d[3] - d[2];
+			const float p0 = __fmaf_rn(wA[u], q0, d[0]), p1 = __fmaf_rn(wA[u], q1, d[2]);
+			const float mPB = p1 - p0;                      // the signed differences along P carry sgn = (side ? -1 : 1)
+			const float mPA = __fmaf_rn(wB[u], q1 - q0, q0);
+			const float sP = side ? -s1P[u] : s1P[u];
+			const float uP = vP[u] * sP, uA = vA[u] * s1A[u], uB = vB[u] * s1B[u];
+			float oP = sP * __fmaf_rn(uA, mPA, uB * mPB);
+			float oA = s1A[u] * __fmaf_rn(uP, mPA, uB * mAB);
+			float oB = s1B[u] * __fmaf_rn(uP, mPB, uA * mAB);
+			if (smooth) {
+				const float dA0 = __fmaf_rn(wA[u], cA0, b[0]), dA1 = __fmaf_rn(wA[u], cA1, b[2]);
+				const float gB = dA1 - dA0;
+				const float gA = __fmaf_rn(wB[u], mAB, cA0);
+				const float gP = __fmaf_rn(wB[u], mPB, p0);
+				oP = __fmaf_rn(vP[u] * (side ? -s2P[u] : s2P[u]), gP, oP);
+				oA = __fmaf_rn(vA[u] * s2A[u], gA, oA);
+				oB = __fmaf_rn(vB[u] * s2B[u], gB, oB);
+			}
+			oP *= gs[u]; oA *= gs[u]; oB *= gs[u];
+			// feature 0 (even lane) + feature 1 (odd lane); only the even lane's sum is stored
+			oP += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oP), 0xB1, 0xf, 0xf, true));
+			oA += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oA), 0xB1, 0xf, 0xf, true));
+			oB += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(oB), 0xB1, 0xf, 0xf, true));
+			if (dense) { ox[u] = oA; oy[u] = oB; oz[u] = oP; }
+			else { ox[u] = oP; oy[u] = oA; oz[u] = oB; }
 		}
-		hvp_from_sdot<D>(c, smooth, vin, sdot, acc);
 	}
-	if (side == 0) {
-		float *dst = partial + ((size_t)q * N + i) * D;
+	// ---- phase 4: partial[q][i][:] (uniform base + 32-bit lane offset)
 #pragma unroll
-		for (int d = 0; d < D; ++d) __builtin_nontemporal_store(acc[d], dst + d);
+	for (int u = 0; u < SUB; ++u) {
+		const uint32_t g0 = w0 + (uint32_t)u * kGroup;
+		if ((dbg & 1u) && ox[u] + oy[u] + oz[u] != 1234.56789f) continue;
+		if (side == 0u && g0 + pl < N) {
+			float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(partial) + ((size_t)q * N + g0) * 12u + pl * 12u);
+			__builtin_nontemporal_store(ox[u], &dst[0]);
+			__builtin_nontemporal_store(oy[u], &dst[1]);
+			__builtin_nontemporal_store(oz[u], &dst[2]);
+		}
 	}
 }
 
@@ -1749,19 +1877,26 @@ static int launch_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 		uint32_t n_blocks;
 		const bool batched = batch_inds || batch_offsets || batch_data_size;
 		const char *pl_env = getenv("NR3D_LOTD_HVP_PAIRLANE");
+		const char *dbg_env = getenv("NR3D_HVP_DBG");                  // timing experiments only (results wrong by design)
+		const uint32_t hvp_dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
 		const bool pl = !batched && pairlane_enabled() && pairlane_meta_ok(meta) && ((uintptr_t)params % 8) == 0 &&
 		                !(pl_env && pl_env[0] == '0');
-		const Sched s = pl ? make_sched(N, meta, n_blocks, 0, (uint32_t)kPlPts, true) : make_sched(N, meta, n_blocks);
+		const Sched s = pl ? make_sched(N, meta, n_blocks, 0, (uint32_t)(kPlPts * kHvpSub), true) : make_sched(N, meta, n_blocks);
 		DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
 			auto launch = [&](auto kern) {
 				hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
 				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
 				                   (const float *)x, (const float *)params, ba, vec_ok, (float *)workspace);
 			};
-			if (pl)
-				hipLaunchKernelGGL(k_bwd_bwd_dx_pl, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
-				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
-				                   (const float *)x, (const float *)params, (float *)workspace);
+			if (pl) {
+				// workspace: partial [P][N][3] | g_pairs [P][N][2]
+				float *g_pairs = (float *)workspace + (size_t)N * meta->n_pseudo_levels * 3u;
+				hipLaunchKernelGGL(k_hvp_pairs, dim3(div_up(N, kGpPts), div_up(meta->n_pseudo_levels, kGpLv)), dim3(kBlock), 0,
+				                   (hipStream_t)stream, N, meta->n_pseudo_levels, (const float *)dL_dy, g_sn, g_se, g_pairs);
+				hipLaunchKernelGGL(k_bwd_bwd_dx_pl<kHvpSub>, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
+				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)g_pairs,
+				                   (const float *)x, (const float *)params, (float *)workspace, hvp_dbg);
+			}
 			else if (dh) launch(k_bwd_bwd_dx_lv<D, G, true>); else launch(k_bwd_bwd_dx_lv<D, G, false>);
 			hipLaunchKernelGGL(k_sum_levels<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N,
 			                   meta->n_pseudo_levels, (const float *)workspace, (float *)dL_dx);
@@ -1785,7 +1920,9 @@ extern "C" uint64_t nr3d_lotd_bwd_bwd_dx_workspace_bytes(const nr3d_lotd_meta_t 
 	// Dense / Hash metas only: with product types in the instantiation (114+ VGPRs) one lane per level is a loss --
 	// configs[3]: 7.8 ms against 4.0 for the lane-serial kernel
 	if (!meta || !meta->c_hash_only || meta->n_pseudo_levels > 64u) return 0;
-	return (uint64_t)n_points * meta->n_pseudo_levels * meta->n_dims_to_encode * sizeof(float);
+	// per (point, pseudo level): the D partial sums; + the pair-lane kernel's copy of dL_dy by level (2 floats)
+	const uint64_t per = meta->n_dims_to_encode + (pairlane_meta_ok(meta) ? 2u : 0u);
+	return (uint64_t)n_points * meta->n_pseudo_levels * per * sizeof(float);
 }
 
 extern "C" int nr3d_lotd_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,

@@ -133,8 +133,9 @@ def test_bwd_bwd_input(oracle, dev, case, bin_mode):
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4", "dense_f8", "hash_npow2", "hash_4d", "dense_2d"])
 def test_hvp_level_parallel_vs_lane_serial(oracle, dev, case, monkeypatch):
     """d(dL/dx)/dx of Dense / Hash metas: one lane per (point, pseudo level) + a sum in level order (default, needs a
-    scratch buffer) against one lane per point walking the levels (NR3D_LOTD_HVP_LEVELS=0): the same per-level arithmetic
-    and the same order of the sum -- identical for 2-feature pseudo levels, to the rounding of one extra association
+    scratch buffer) against one lane per point walking the levels (NR3D_LOTD_HVP_LEVELS=0): the same order of the sum and
+    -- except for the pair-lane kernel of 3-D 2-feature metas, which builds the Hessian from the lerp tree's differences --
+    the same per-level arithmetic: identical for 2-feature pseudo levels, to the rounding of one extra association
     otherwise; with max_level too"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=9001, seed=17)
     outs = {}
@@ -145,11 +146,13 @@ def test_hvp_level_parallel_vs_lane_serial(oracle, dev, case, monkeypatch):
         b = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, max_level=m.n_levels // 2, need_dLdinput_ddLdoutput=False,
                                     need_dLdinput_dparams=False, need_dLdinput_dinput=True)[2]
         outs[mode] = (a, b)
-    if m.n_feat_per_pseudo_lvl == 2:
+    pair_lane = m.n_dims_to_encode == 3 and m.n_feat_per_pseudo_lvl == 2      # lerp-tree Hessian: other association
+    if m.n_feat_per_pseudo_lvl == 2 and not pair_lane:
         assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
     else:
-        assert_close(outs["1"][0], outs["0"][0].cpu().numpy(), rel=1e-6, name="hvp level-parallel vs lane-serial")
-        assert_close(outs["1"][1], outs["0"][1].cpu().numpy(), rel=1e-6, name="hvp level-parallel vs lane-serial, max_level")
+        rel = 2e-6 if pair_lane else 1e-6
+        assert_close(outs["1"][0], outs["0"][0].cpu().numpy(), rel=rel, name="hvp level-parallel vs lane-serial")
+        assert_close(outs["1"][1], outs["0"][1].cpu().numpy(), rel=rel, name="hvp level-parallel vs lane-serial, max_level")
     assert_close(outs["1"][0], oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="d(dL/dx)/dx level-parallel")
 
 
