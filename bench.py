@@ -215,15 +215,20 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
     for _ in range(3):               # the caching allocator reaches its steady state
         S = one()[0]
     names = ("march", "composite_fwd", "composite_bwd")
-    for k in names:
-        H.prof_read(k)
-    H.prof_enable(*names)
+    # wall clock first, with the library's event hooks off (they cost ~20 us of host time per iteration,
+    # tools/exp_c3_host.py); then the same loop again with the hooks on for the per-kernel times
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
         one()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
+    for k in names:
+        H.prof_read(k)
+    H.prof_enable(*names)
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
     H.prof_enable()
     kus = {}
     for k in names:

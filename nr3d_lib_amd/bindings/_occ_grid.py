@@ -39,6 +39,17 @@ def _chk(name, t, dim=None, dtype=None):
         raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
 
 
+_SCAN_TMP = {}
+
+
+def _scan_tmp_bytes(n):
+    """nr3d_scan_tmp_bytes(n), remembered per n (a binding call costs more than the lookup)"""
+    b = _SCAN_TMP.get(n)
+    if b is None:
+        b = _SCAN_TMP[n] = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(n, 1))))
+    return b
+
+
 def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_binary, contraction_type,
            step_size, max_step_size, dt_gamma, max_steps, return_gidx, batched, finish=False):
     _chk("rays_o", rays_o, 2, torch.float32)
@@ -76,8 +87,7 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
         st = H.stream_of(rays_o)
         packed_info = H.empty((n, 2), dtype=torch.int32, device=dev)
         total = H.empty(1, dtype=torch.int64, device=dev)
-        nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(n, 1))))
-        tmp = H.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        tmp = H.empty((_scan_tmp_bytes(n) + 7) // 8, dtype=torch.int64, device=dev)
         # sample cache: the count pass keeps every sample, the emit pass only compacts (no second march)
         cache_bytes = n * int(max_steps) * 12
         cache = (H.empty((cache_bytes + 3) // 4, dtype=torch.int32, device=dev)
