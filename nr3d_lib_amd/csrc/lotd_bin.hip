@@ -956,19 +956,25 @@ static uint32_t chunk_points(uint32_t n) {
 
 // -------------------------------------------------------------------------------------------------
 // CP levels without records (round 3).  A 3-D CP level is three LINE tables, sum_d R_d entries in all (configs[3]: 2304 /
-// 4608 / 9216) -- its whole gradient table of one 2-feature pseudo level fits LDS as fp64 (<= 144 KiB).  Through the record
-// path such a level costs 6 records x 12 B per point and pseudo level written, sorted (every record lands in the ONE bucket the
-// table is: the ranks come from ballots) and read back: configs[3]'s fourteen CP pseudo levels were ~2.3 of the 8 ms of a
-// dL/dparam pass.  Here a workgroup takes a share of the points and ONE pseudo level, forms the same six updates per point
-// (emit_product: the record path's arithmetic) and adds them to its LDS table with ds_add_f64 (order-independent to fp64
-// rounding); the workgroups' tables are written out as fp32 and summed by k_cp_reduce in replica order.
+// 4608 / 9216) -- the gradient table of a few of its 2-feature pseudo levels fits LDS as fp64 (<= 144 KiB).  Through the
+// record path such a level costs 6 records x 12 B per point and pseudo level written, sorted (every record lands in the ONE
+// bucket the table is: the ranks come from ballots) and read back: configs[3]'s fourteen CP pseudo levels were ~2.3 of the
+// 8 ms of a dL/dparam pass.  Here a workgroup takes a share of the points and up to four CONSECUTIVE pseudo levels of one
+// level (as many as fit LDS; they share the cell, the weights and the entry indices), forms the six updates per point and
+// feature pair and adds them to its LDS table with ds_add_f64 (order-independent to fp64 rounding); the workgroups' tables
+// are written out as fp32 and summed by k_cp_reduce in replica order.
+// The updates in factored form -- a CP value is a product of per-dim line interpolants I_d = (1 - w_d) T_d[0] + w_d T_d[1]:
+//     first order   dT_d[s] += g * w_d(s) * prod_{j != d} I_j
+//     second order  dT_d[s] += g * ( a_d sgn(s) prod_{j != d} I_j  +  w_d(s) sum_{j != d} a_j (T_j[1] - T_j[0]) I_k ),   a = s w' v
+// (the record path sums the same terms corner by corner -- emit_product; other association, agreement to fp32 rounding).
 // NR3D_LOTD_CP_DIRECT=0: CP levels take the record path like every other type.
 // -------------------------------------------------------------------------------------------------
 constexpr int kCpThreads = 1024;
-constexpr uint32_t kCpMaxItems = 32, kCpLdsBytes = 144 * 1024, kCpReplicas = 64;
+constexpr uint32_t kCpMaxItems = 32, kCpLdsBytes = 144 * 1024, kCpReplicas = 128, kCpMaxPairs = 4;
 struct CpPlan {
 	uint32_t n_items, R, pts_per_rep;
-	uint32_t q[kCpMaxItems];             // pseudo level of item k
+	uint32_t q[kCpMaxItems];             // first pseudo level of item k
+	uint32_t np[kCpMaxItems];            // ... and how many consecutive pseudo levels (feature pairs) it serves
 	uint32_t part_off[kCpMaxItems];      // float offset of its R partial tables inside `partial`
 };
 
@@ -977,51 +983,71 @@ __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_
                                                           const float *__restrict__ x, const float *__restrict__ vin_,
                                                           const float *__restrict__ g, int64_t g_sn, int64_t g_se,
                                                           const float *__restrict__ params, float *__restrict__ partial) {
-	extern __shared__ __attribute__((aligned(16))) double cp_acc[];            // [entries][2]
+	extern __shared__ __attribute__((aligned(16))) double cp_acc[];            // [entries][2 np]
 	const uint32_t r = blockIdx.x, item = blockIdx.y;
-	const uint32_t q = cp.q[item];
+	const uint32_t q = cp.q[item], np = cp.np[item], row = 2u * np;
 	const Lvl L = load_level(md, meta_level_of(md, q));
-	const uint32_t n_acc = L.size * 2u;
+	const uint32_t n_acc = L.size * row;
 	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) cp_acc[t] = 0.0;
 	__syncthreads();
 	const uint32_t foff = meta_cnt_of(md, q) * 2u, col0 = meta_col_of(md, q);
-	const float *__restrict__ grid = params + L.off;
+	const float *__restrict__ grid = params + L.off + foff;
+	const bool vec = ((reinterpret_cast<uintptr_t>(grid) & 7u) == 0u) && (L.F & 1u) == 0u;
+	const bool quad = ((reinterpret_cast<uintptr_t>(grid) & 15u) == 0u) && (L.F & 3u) == 0u;     // 16-byte reads: 2 pairs per request
 	const uint32_t p_lo = r * cp.pts_per_rep, p_hi = min(n, p_lo + cp.pts_per_rep);
 #pragma unroll 2
 	for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kCpThreads) {
-		float xp[3], vin[3], a[3];
+		float xp[3], a[3], w0[3], w1[3];
+		uint32_t e0[3];
 #pragma unroll
 		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
 		Cell<3> c;
 		locate<3>(xp, L, smooth != 0, c);
-		float grad[2], w[8];
-		grad[0] = g[(int64_t)i * g_sn + (int64_t)col0 * g_se];
-		grad[1] = g[(int64_t)i * g_sn + (int64_t)(col0 + 1u) * g_se];
 #pragma unroll
 		for (int d = 0; d < 3; ++d) {
-			vin[d] = SECOND ? vin_[(size_t)i * 3 + d] : 0.0f;
-			a[d] = SECOND ? c.sc[d] * vin[d] * c.dw[d] : 0.0f;
+			a[d] = SECOND ? c.sc[d] * vin_[(size_t)i * 3 + d] * c.dw[d] : 0.0f;
+			w1[d] = c.w[d]; w0[d] = 1.0f - c.w[d];
+			e0[d] = entry_line<3>(L, d, c.g[d]);
 		}
+		// NF features of the item at feature offset fo: six entries read (one request each), 6 NF updates
+		auto update = [&](auto nf_tag, uint32_t fo, bool vec_ok) {
+			constexpr int NF = decltype(nf_tag)::value;
+			float T0[3][NF], T1[3][NF], I[3][NF], gr[NF];
 #pragma unroll
-		for (uint32_t k = 0; k < 8u; ++k) {                  // bin_body's corner weights: first order / combined d/dx weight
-			if (!SECOND) w[k] = corner_weight<3>(c, k);
-			else {
-				float sum = 0.0f;
-#pragma unroll
-				for (int d = 0; d < 3; ++d) {
-					const float t = face_weight<3>(c, k, d, a[d]);
-					sum += ((k >> d) & 1u) ? t : -t;
-				}
-				w[k] = sum;
+			for (int d = 0; d < 3; ++d) {
+				ld_feats<NF>(grid, e0[d] * L.F + fo, vec_ok, T0[d]);
+				ld_feats<NF>(grid, (e0[d] + 1u) * L.F + fo, vec_ok, T1[d]);
 			}
-		}
-		uint32_t ent[6];
-		float val[6][2];
-		emit_product<3, 2, 6, 2, true>(L, c, w, grad, grid, foff, ent, val);
 #pragma unroll
-		for (int u = 0; u < 6; ++u) {
-			atomicAdd(&cp_acc[ent[u] * 2u], (double)val[u][0]);
-			atomicAdd(&cp_acc[ent[u] * 2u + 1u], (double)val[u][1]);
+			for (int f = 0; f < NF; ++f) gr[f] = g[(int64_t)i * g_sn + (int64_t)(col0 + fo + f) * g_se];
+#pragma unroll
+			for (int d = 0; d < 3; ++d)
+#pragma unroll
+				for (int f = 0; f < NF; ++f) I[d][f] = __fmaf_rn(w1[d], T1[d][f], w0[d] * T0[d][f]);
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				const int j = (d + 1) % 3, k = (d + 2) % 3;
+				double *dst0 = &cp_acc[(size_t)e0[d] * row + fo], *dst1 = dst0 + row;
+#pragma unroll
+				for (int f = 0; f < NF; ++f) {
+					const float other = I[j][f] * I[k][f];
+					float v0, v1;
+					if (!SECOND) { v0 = gr[f] * (w0[d] * other); v1 = gr[f] * (w1[d] * other); }
+					else {
+						const float cross = __fmaf_rn(a[j] * (T1[j][f] - T0[j][f]), I[k][f], a[k] * (T1[k][f] - T0[k][f]) * I[j][f]);
+						const float own = a[d] * other;
+						v0 = gr[f] * __fmaf_rn(w0[d], cross, -own);
+						v1 = gr[f] * __fmaf_rn(w1[d], cross, own);
+					}
+					atomicAdd(dst0 + f, (double)v0);
+					atomicAdd(dst1 + f, (double)v1);
+				}
+			}
+		};
+#pragma unroll 1
+		for (uint32_t fo = 0; fo < row;) {
+			if (quad && fo + 4u <= row) { update(std::integral_constant<int, 4>{}, fo, true); fo += 4u; }
+			else { update(std::integral_constant<int, 2>{}, fo, vec); fo += 2u; }
 		}
 	}
 	__syncthreads();
@@ -1029,17 +1055,17 @@ __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_
 	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) mine[t] = (float)cp_acc[t];
 }
 
-// dL/dparam of a CP pseudo level += sum of its replicas' tables (replica 0 first)
+// dL/dparam of an item's pseudo levels += sum of its replicas' tables (replica 0 first)
 __global__ __launch_bounds__(256) void k_cp_reduce(CpPlan cp, const nr3d_lotd_meta_t *__restrict__ md, const float *__restrict__ partial,
                                                    float *__restrict__ dparam) {
-	const uint32_t item = blockIdx.y, q = cp.q[item];
+	const uint32_t item = blockIdx.y, q = cp.q[item], row = 2u * cp.np[item];
 	const Lvl L = load_level(md, meta_level_of(md, q));
-	const uint32_t n_acc = L.size * 2u, t = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t n_acc = L.size * row, t = blockIdx.x * 256u + threadIdx.x;
 	if (t >= n_acc) return;
 	const float *p0 = partial + cp.part_off[item] + t;
 	float sum = 0.0f;
 	for (uint32_t r = 0; r < cp.R; ++r) sum += p0[(size_t)r * n_acc];
-	float *dst = dparam + L.off + (size_t)(t >> 1) * L.F + meta_cnt_of(md, q) * 2u + (t & 1u);
+	float *dst = dparam + L.off + (size_t)(t / row) * L.F + meta_cnt_of(md, q) * 2u + (t % row);
 	*dst += sum;
 }
 
@@ -1055,28 +1081,47 @@ static uint64_t cp_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level
 	cp.n_items = 0; cp.R = 1; cp.pts_per_rep = n; max_acc = 0;
 	if (!cp_direct_enabled() || m->n_dims_to_encode != 3 || m->n_feat_per_pseudo_lvl != 2 || m->n_pseudo_levels > 64u || n == 0) return 0;
 	uint64_t mask = 0, floats_per_replica = 0;
-	for (uint32_t q = 0; q < m->n_pseudo_levels && cp.n_items < kCpMaxItems; ++q) {
+	for (uint32_t q = 0; q < m->n_pseudo_levels;) {
 		const uint32_t lv = m->map_levels[q];
 		const nr3d_lotd_level_t &L = m->levels[lv];
+		uint32_t nq = 1;                                       // the level's pseudo levels are consecutive
+		while (q + nq < m->n_pseudo_levels && m->map_levels[q + nq] == lv) ++nq;
+		const uint32_t q0 = q;
+		q += nq;
 		if (L.type != NR3D_LOD_CP || (int32_t)lv < min_level || (int32_t)lv > max_level) continue;
-		if ((uint64_t)L.size * 16u > kCpLdsBytes) continue;
-		cp.q[cp.n_items++] = q;
-		mask |= 1ull << q;
-		floats_per_replica += (uint64_t)L.size * 2u;
-		max_acc = max_acc > L.size * 2u ? max_acc : L.size * 2u;
+		uint32_t fit = (uint32_t)(kCpLdsBytes / ((uint64_t)L.size * 16u));
+		fit = fit > kCpMaxPairs ? kCpMaxPairs : fit;
+		if (fit == 0 || cp.n_items + div_up(nq, fit) > kCpMaxItems) continue;
+		for (uint32_t k = 0; k < nq; k += fit) {
+			const uint32_t np = (nq - k) < fit ? (nq - k) : fit;
+			cp.q[cp.n_items] = q0 + k; cp.np[cp.n_items] = np;
+			++cp.n_items;
+			floats_per_replica += (uint64_t)L.size * 2u * np;
+			max_acc = max_acc > L.size * 2u * np ? max_acc : L.size * 2u * np;
+		}
+		for (uint32_t k = 0; k < nq; ++k) mask |= 1ull << (q0 + k);
 	}
 	if (!cp.n_items) return 0;
-	uint32_t R = kCpReplicas;
-	const uint32_t by_points = div_up(n, 4096u);             // >= 4096 points per replica
-	R = R > by_points ? by_points : R;
-	while (R > 1 && floats_per_replica * R > part_floats) R >>= 1;
-	if (floats_per_replica * R > part_floats) { cp.n_items = 0; return 0; }
+	// replicas: >= 4096 points each, the partial tables inside the workspace, and the launch a whole number of rounds of
+	// one workgroup per CU (256) as nearly as the divisors allow
+	uint32_t r_max = kCpReplicas;
+	const uint32_t by_points = div_up(n, 4096u);
+	r_max = r_max > by_points ? by_points : r_max;
+	while (r_max > 1 && floats_per_replica * r_max > part_floats) --r_max;
+	if (floats_per_replica * r_max > part_floats) { cp.n_items = 0; return 0; }
+	uint32_t R = r_max;
+	double best = 0.0;
+	for (uint32_t cand = r_max; cand >= 1 && cand * 2u > r_max; --cand) {
+		const uint32_t blocks = cand * cp.n_items, rounds = div_up(blocks, 256u);
+		const double fill = (double)blocks / (256.0 * rounds);
+		if (fill > best + 1e-9) { best = fill; R = cand; }
+	}
 	cp.R = R;
 	cp.pts_per_rep = div_up(n, R);
 	uint64_t off = 0;
 	for (uint32_t k = 0; k < cp.n_items; ++k) {
 		cp.part_off[k] = (uint32_t)off;
-		off += (uint64_t)m->levels[m->map_levels[cp.q[k]]].size * 2u * R;
+		off += (uint64_t)m->levels[m->map_levels[cp.q[k]]].size * 2u * cp.np[k] * R;
 	}
 	return mask;
 }
