@@ -109,6 +109,11 @@ int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t width, uint32_
  *   max_level    levels > max_level contribute zeros; <= -1 => everything zero (lotd_torch_api.cu:294)
  * `meta_dev` is a device-resident byte copy of *meta (the caller uploads it once per meta/device).
  * Strides are in ELEMENTS.  x is [N, D] contiguous; params is 1-D contiguous.
+ * param_dtype: NR3D_F32, or NR3D_F16 -- `params` are __half tables, read as half and used as float (the reference's
+ * (float, half, float) dispatch, lotd_encoding.h:1501-1504) by every kernel that reads table entries: every meta, batched
+ * tables included; a half table gives bit for bit what its fp32 copy gives.  With NR3D_F16 nr3d_lotd_fwd writes y as __half
+ * (the fp32 result rounded once); dy_dx, dL_dx and -- except through nr3d_lotd_bwd_dparam_typed -- dL_dparam stay float, and
+ * so does dL_dy (the caller widens a half dL_dy; the pair-record path below reads it as it is).
  */
 
 /* lod_fwd (lotd_torch_api.cu:232-395): y[i*y_sn + e*y_se] (params dtype);
@@ -162,9 +167,10 @@ int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_d
  * csrc/lotd/include/lotd/lotd_encoding.h:1501-1504; PARAM_T accumulators lotd_encoding.h:72): x and dy_dx float, params /
  * y / dL_dy / dL_dparam __half, arithmetic in fp32.  nr3d_lotd_half_params_ok: 1 when nr3d_lotd_fwd (param_dtype
  * NR3D_F16: y is __half too), nr3d_lotd_bwd_dx (param_dtype NR3D_F16: dL_dy is __half, contiguous [N, E]) and
- * nr3d_lotd_bwd_dparam_typed serve this meta without any whole-table conversion -- unbatched 3-D Dense/Hash metas with
- * 2-feature pseudo levels; otherwise the caller converts to fp32.  Unlike the reference's __half2 atomics the parameter
- * gradient is accumulated exactly and rounded to half once. */
+ * nr3d_lotd_bwd_dparam_typed serve this meta with half GRADIENTS as well (dL_dy read and dL_dparam written as __half) --
+ * unbatched 3-D Dense/Hash metas with 2-feature pseudo levels; for every other meta the half TABLES are still read as they
+ * are (param_dtype above) and only dL_dy / dL_dparam pass through float.  Unlike the reference's __half2 atomics the
+ * parameter gradient is accumulated exactly and rounded to half once. */
 int nr3d_lotd_half_params_ok(const nr3d_lotd_meta_t *meta, int batched);
 /* first-order dL/dparam of the pair-record path (nr3d_lotd_pair_path_ok) with explicit dtypes: grad_dtype of dL_dy (any
  * strides; F32 for the feature-major copy that nr3d_lotd_bwd_dx leaves), out_dtype of dL_dparam.  assign == 0:

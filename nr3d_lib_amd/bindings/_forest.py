@@ -128,7 +128,7 @@ def lod_fwd(metas, input, params, batch_inds=None, batch_offsets=None, batch_dat
     E, dev = m.n_encoded_dims, input.device
     if max_level <= -1:
         return (torch.zeros((N, E), dtype=params.dtype, device=dev), torch.zeros((N, E * 3), dtype=input.dtype, device=dev))
-    x32, p32 = _lotd._f32c(input.detach()), _lotd._f32c(params.detach())
+    x32, p32 = _lotd._f32c(input.detach()), _lotd._p32(params)
     with H.on_device(dev):
         # feature-major storage behind [N, E] / [N, E, 3] views, like the single-block path: coalesced stores
         y = H.empty((E, N), dtype=torch.float32, device=dev).t()
@@ -178,7 +178,7 @@ def lod_bwd(metas, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offs
                 C.byref(m._cmeta()), H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(g32), H.i64(E), H.i64(1),
                 H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), None, st))
         if need_param_grad:
-            x32, p32 = _lotd._f32c(input.detach()), _lotd._f32c(params.detach())
+            x32, p32 = _lotd._f32c(input.detach()), _lotd._p32(params)
             c = fo._c()
             ws, wsb = _workspace(m, fo, N, dev)
             H.check(H.lib().nr3d_lotd_forest_bwd_dparam(
@@ -220,7 +220,7 @@ def lod_bwd_bwd_input(metas, dL_ddLdx, dL_dy, input, params, dy_dx=None, batch_i
             return _lotd._cast(dL_ddLdy, dL_dy.dtype), _lotd._cast(dL_dparams, params.dtype), _lotd._cast(dL_dx, input.dtype)
         st = H.stream_of(input)
         v32, g32 = _lotd._f32c(dL_ddLdx.detach()), _lotd._f32c(dL_dy.detach()).contiguous()
-        x32, p32 = _lotd._f32c(input.detach()), _lotd._f32c(params.detach())
+        x32, p32 = _lotd._f32c(input.detach()), _lotd._p32(params)
         cm, md, c = C.byref(m._cmeta()), H.ptr(m._dev(dev)), fo._c()
         if need_dLdy:
             j, jsn, jse = _lotd._jac_view(dy_dx.detach(), N, E, 3)

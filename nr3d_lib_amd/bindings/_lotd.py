@@ -299,6 +299,15 @@ def _p32(params):
     return p32
 
 
+def _ptab(params):
+    """(table, dtype code) as the kernels get it: half tables as they are (every kernel that reads table entries has a
+    __half instantiation: values are read as half and used as float, the reference's (float, half, float) dispatch), unless
+    NATIVE_HALF is off -- then the fp32 copy of _p32"""
+    if NATIVE_HALF and params.dtype == torch.float16:
+        return params.detach(), H.F16
+    return _p32(params), H.F32
+
+
 HVP_WORKSPACE_MAX_BYTES = 8 << 30      # largest per-call scratch of the level-parallel d(dL/dx)/dx (beyond it: lane-serial kernel)
 NATIVE_HALF = True       # False: half params always go through fp32 copies (A/B measurements)
 REGROUP = True           # False: mixed-width metas run as ONE call in pseudo levels of the global gcd (A/B, cross-check)
@@ -365,7 +374,9 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
         return (torch.zeros((N, E), dtype=params.dtype, device=params.device),
                 torch.zeros((N, E * D), dtype=input.dtype, device=input.device))
     batched = batch_inds is not None or batch_offsets is not None or bds != 0
-    native = _native_half(m, params, batched)
+    # half tables are read as they are and y leaves as half -- by the two-lane kernels where they apply, by the general kernel
+    # for every other meta and for batched tables (k_fwd<..., __half>): no fp32 copy of the table
+    native = NATIVE_HALF and params.dtype == torch.float16
     x32 = _f32c(input.detach())
     p32 = params.detach() if native else _p32(params)
     pcode = H.F16 if native else H.F32
@@ -489,14 +500,14 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
                     H.ptr(_f32c(input.detach())), H.i32(max_level), C.c_int(H.F16 if native else H.F32), C.c_int(1),
                     H.ptr(dL_dparam), H.ptr(ws), C.c_uint64(wsb), st))
             elif need_param_grad and N > 0:
-                x32, p32 = _f32c(input.detach()), _p32(params)
+                x32, (p32, pcode) = _f32c(input.detach()), _ptab(params)
                 nbat = _n_batches(m, p32, batch_offsets, batched)
                 ws, wsb = _dparam_workspace(m, N, dev, nbat)
                 if gT is not None:
                     g32, gsn, gse = gT, 1, N
                 if level_buckets is None:
                     H.check(H.lib().nr3d_lotd_bwd_dparam(
-                        C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(H.F32),
+                        C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(H.F32), C.c_int(pcode),
                         H.ptr(g32), H.i64(gsn), H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
                         H.ptr(batch_offsets), H.u32(bds), H.u32(nbat), H.i32(max_level), H.ptr(dL_dparam), H.ptr(ws),
                         C.c_uint64(wsb), st))
@@ -572,7 +583,7 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
         v32 = _f32c(dL_ddLdx.detach())
         g32 = _f32c(dL_dy.detach())
         gsn, gse = _strides2(g32)
-        x32, p32 = _f32c(input.detach()), _p32(params)
+        x32, (p32, pcode) = _f32c(input.detach()), _ptab(params)
         cm, md = C.byref(m._cmeta()), H.ptr(m._dev(dev))
         tag = ("dx" if need_dx else "") + ("dp" if need_dp else "") + ("dLdy" if need_dLdy else "")
         with _Prof(m, f"LoTD{D}-bwd2-{tag}", N):
@@ -589,7 +600,7 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
                 ws = (H.empty((wsb + 3) // 4, dtype=torch.float32, device=dev)
                       if 0 < wsb <= HVP_WORKSPACE_MAX_BYTES else None)
                 H.check(H.lib().nr3d_lotd_bwd_bwd_dx_ws(
-                    cm, md, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(g32), H.i64(gsn),
+                    cm, md, H.u32(N), C.c_int(H.F32), C.c_int(pcode), H.ptr(v32), H.ptr(g32), H.i64(gsn),
                     H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
                     H.i32(max_level), H.ptr(dL_dx), H.ptr(ws), C.c_uint64(wsb if ws is not None else 0), st))
             if need_dp:
@@ -597,7 +608,7 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
                 nbat = _n_batches(m, p32, batch_offsets, batched)
                 ws, wsb = _dparam_workspace(m, N, dev, nbat)
                 H.check(H.lib().nr3d_lotd_bwd_bwd_dparam(
-                    cm, md, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(g32), H.i64(gsn),
+                    cm, md, H.u32(N), C.c_int(H.F32), C.c_int(pcode), H.ptr(v32), H.ptr(g32), H.i64(gsn),
                     H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
                     H.u32(nbat), H.i32(max_level), H.ptr(dL_dparams), H.ptr(ws), C.c_uint64(wsb), st))
     return _cast(dL_ddLdy, dL_dy.dtype), _cast(dL_dparams, params.dtype), _cast(dL_dx, input.dtype)

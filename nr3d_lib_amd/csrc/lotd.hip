@@ -34,11 +34,15 @@ namespace lotd {
 // =============================================================================================
 // Forward
 // =============================================================================================
-template <int D, int G, bool DYDX, bool DH, int ONLY = -1>
+template <typename YT> __device__ __forceinline__ void store_nt(YT *p, float v);      // below (two-lane kernel's section)
+
+// PT: storage type of the tables AND of y (float, or __half read as float -- lotd_device.h, HalfTab -- and y rounded to
+// half from the fp32 result); dy/dx leaves as float
+template <int D, int G, bool DYDX, bool DH, int ONLY = -1, typename PT = float>
 __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                 int32_t max_level, uint32_t smooth, const float *__restrict__ x,
-                                                const float *__restrict__ params, Batch ba, uint32_t vec_ok,
-                                                float *__restrict__ y, int64_t y_sn, int64_t y_se,
+                                                const PT *__restrict__ params, Batch ba, uint32_t vec_ok,
+                                                PT *__restrict__ y, int64_t y_sn, int64_t y_se,
                                                 float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
 	uint32_t q, chunk;
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 	const bool active = ((int32_t)level <= max_level) && batch_base(ba, i, base);
 	if (active) {
 		const Lvl L = load_level(md, level);
-		const float *__restrict__ grid = params + (base + L.off);
+		const auto grid = make_tab(params + (base + L.off));
 		float xp[D];
 #pragma unroll
 		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
@@ -84,15 +88,15 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 				uint32_t p[D];
 				corner_pos<D>(c, k, p);
 				const uint32_t e = (L.type == NR3D_LOD_Dense) ? entry_dense<D>(L, p) : entry_hash<D>(L, p);
-				const float *src = grid + (e * L.F + foff0);
+				const auto src = grid + (e * L.F + foff0);
 				if (vec_ok) {
 					if constexpr (G == 2) {
-						const float2 t = *reinterpret_cast<const float2 *>(src);
+						const float2 t = tab_ld2(src, 0);
 						v[k][0] = t.x; v[k][1] = t.y;
 					} else {
 #pragma unroll
 						for (int f4 = 0; f4 < G; f4 += 4) {
-							const float4 t = *reinterpret_cast<const float4 *>(src + f4);
+							const float4 t = tab_ld4(src, f4);
 							v[k][f4] = t.x; v[k][f4 + 1] = t.y; v[k][f4 + 2] = t.z; v[k][f4 + 3] = t.w;
 						}
 					}
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(Sched s, const nr3d_lotd_meta_t 
 
 	// outputs are written once and not read by this kernel: non-temporal stores keep the level tables in the L2
 #pragma unroll
-	for (int f = 0; f < G; ++f) __builtin_nontemporal_store(out_y[f], &y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se]);
+	for (int f = 0; f < G; ++f) store_nt<PT>(&y[(int64_t)i * y_sn + (int64_t)(out0 + f) * y_se], out_y[f]);
 	if (DYDX) {
 #pragma unroll
 		for (int f = 0; f < G; ++f) {
@@ -600,12 +604,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t 
 // =============================================================================================
 // dL/dparam (SECOND == false) and d(dL/dx)/dparam (SECOND == true)
 // =============================================================================================
-template <int D, int G, bool SECOND, bool DH>
+template <int D, int G, bool SECOND, bool DH, typename PT = float>
 __global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                        int32_t min_level, int32_t max_level, uint32_t smooth,
                                                        const float *__restrict__ dL_ddLdx,
                                                        const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
-                                                       const float *__restrict__ x, const float *__restrict__ params,
+                                                       const float *__restrict__ x, const PT *__restrict__ params,
                                                        Batch ba, float *__restrict__ dparam) {
 	uint32_t q, chunk;
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_dparam(Sched s, const nr3d_lotd_
 	const uint32_t foff0 = meta_cnt_of(md, q) * G;
 	const uint32_t out0 = meta_col_of(md, q);
 	const Lvl L = load_level(md, level);
-	const float *__restrict__ grid = params + (base + L.off);
+	const auto grid = make_tab(params + (base + L.off));
 	float *__restrict__ gg = dparam + (base + L.off);
 
 	float xp[D], vin[D];
@@ -799,10 +803,10 @@ __device__ __forceinline__ void hvp_from_sdot(const Cell<D> &c, uint32_t smooth,
 
 // d(dL/dx)/dx contribution of ONE pseudo level to one point: acc[d] += sum_e vin[e] * d^2(sum_f grad_f y_f)/dx_e dx_d
 // (reference: kernel_lod_backward_input_backward_input, lotd_encoding.h:1157-1298; Dense / Hash / VM / VecZMatXoY only)
-template <int D, int G, bool DH>
+template <int D, int G, bool DH, typename TB>
 __device__ __forceinline__ void hvp_level(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q, const Lvl &L, const Cell<D> &c,
                                           uint32_t smooth, const float (&vin)[D], uint32_t i, const float *__restrict__ dL_dy,
-                                          int64_t g_sn, int64_t g_se, const float *__restrict__ grid, bool vec_ok,
+                                          int64_t g_sn, int64_t g_se, TB grid, bool vec_ok,
                                           float (&acc)[D]) {
 #pragma unroll 1
 	for (int f0 = 0; f0 < G; f0 += 2) {
@@ -832,11 +836,11 @@ __device__ __forceinline__ bool hvp_type(uint32_t t) {
 // of the level first and hvp_from_sdot runs once per LEVEL instead of once per feature pair; and the table entries are read
 // four features per 16-byte load when the level's entries are aligned (the kernel was L2-request bound on configs[3]:
 // 625 M requests = 177 G/s, profiles/r03g_c4_counters.txt).  Same sum, other association than the per-pair form.
-template <int D>
+template <int D, typename TB>
 __device__ __forceinline__ void hvp_level_merged(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q, uint32_t nq, uint32_t G,
                                                  const Lvl &L, const Cell<D> &c, uint32_t smooth, const float (&vin)[D], uint32_t i,
                                                  const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
-                                                 const float *__restrict__ grid, bool vec_ok, bool aligned4, float (&acc)[D]) {
+                                                 TB grid, bool vec_ok, bool aligned4, float (&acc)[D]) {
 	const uint32_t f_begin = meta_cnt_of(md, q) * G, n_f = nq * G, col_begin = meta_col_of(md, q);
 	float sdot[1 << D];
 #pragma unroll
@@ -871,12 +875,12 @@ __device__ __forceinline__ void hvp_level_merged(const nr3d_lotd_meta_t *__restr
 }
 
 // one lane = one point, the pseudo levels one after another (no workspace needed)
-template <int D, int G, bool DH = false>
+template <int D, int G, bool DH = false, typename PT = float>
 __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                        uint32_t n_pseudo, int32_t max_level, uint32_t smooth,
                                                        const float *__restrict__ dL_ddLdx,
                                                        const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
-                                                       const float *__restrict__ x, const float *__restrict__ params,
+                                                       const float *__restrict__ x, const PT *__restrict__ params,
                                                        Batch ba, bool vec_ok, float *__restrict__ dL_dx) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= N) return;
@@ -902,11 +906,12 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 			if (!DH && !hvp_type(L.type)) continue;
 			Cell<D> c;
 			locate<D>(xp, L, smooth != 0, c);
+			const auto grid = make_tab(params + (base + L.off));
 			if constexpr (DH)
-				hvp_level<D, G, DH>(md, q0, L, c, smooth, vin, i, dL_dy, g_sn, g_se, params + (base + L.off), vec_ok, acc);
+				hvp_level<D, G, DH>(md, q0, L, c, smooth, vin, i, dL_dy, g_sn, g_se, grid, vec_ok, acc);
 			else
-				hvp_level_merged<D>(md, q0, nq, G, L, c, smooth, vin, i, dL_dy, g_sn, g_se, params + (base + L.off), vec_ok,
-				                    (reinterpret_cast<uintptr_t>(params + (base + L.off)) & 15u) == 0u, acc);
+				hvp_level_merged<D>(md, q0, nq, G, L, c, smooth, vin, i, dL_dy, g_sn, g_se, grid, vec_ok,
+				                    (tab_addr(grid) % (4u * tab_elt(grid))) == 0u, acc);
 		}
 	}
 #pragma unroll
@@ -917,11 +922,11 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 // form above keeps 8 gathers of ONE level in flight per lane and walks all tables in every workgroup; here the levels
 // of a point run side by side (a wave works on one table) and leave their D floats in partial[q][i][:], which
 // k_sum_levels adds up in level order -- the serial kernel's order, so (for 2-feature pseudo levels) its bits.
-template <int D, int G, bool DH>
+template <int D, int G, bool DH, typename PT = float>
 __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_lv(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                           int32_t max_level, uint32_t smooth, const float *__restrict__ dL_ddLdx,
                                                           const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
-                                                          const float *__restrict__ x, const float *__restrict__ params, Batch ba,
+                                                          const float *__restrict__ x, const PT *__restrict__ params, Batch ba,
                                                           bool vec_ok, float *__restrict__ partial) {
 	uint32_t q, chunk;
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
@@ -940,7 +945,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_lv(Sched s, const nr3d_lo
 			for (int d = 0; d < D; ++d) { xp[d] = x[(size_t)i * D + d]; vin[d] = dL_ddLdx[(size_t)i * D + d]; }
 			Cell<D> c;
 			locate<D>(xp, L, smooth != 0, c);
-			hvp_level<D, G, DH>(md, q, L, c, smooth, vin, i, dL_dy, g_sn, g_se, params + (base + L.off), vec_ok, acc);
+			hvp_level<D, G, DH>(md, q, L, c, smooth, vin, i, dL_dy, g_sn, g_se, make_tab(params + (base + L.off)), vec_ok, acc);
 		}
 	}
 	float *dst = partial + ((size_t)q * N + i) * D;
@@ -994,11 +999,11 @@ __global__ __launch_bounds__(kBlock) void k_hvp_pairs(uint32_t N, uint32_t P, co
 }
 
 constexpr int kHvpSub = 2;                         // 32-point groups per wave
-template <int SUB>
+template <int SUB, typename PT>
 __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_pl(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                           int32_t max_level, uint32_t smooth, const float *__restrict__ dL_ddLdx,
                                                           const float *__restrict__ g_pairs,
-                                                          const float *__restrict__ x, const float *__restrict__ params,
+                                                          const float *__restrict__ x, const PT *__restrict__ params,
                                                           float *__restrict__ partial, uint32_t dbg) {
 	uint32_t q, chunk;
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
@@ -1014,7 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_pl(Sched s, const nr3d_lo
 	const Lvl L = load_level(md, live ? level : 0u);
 	const bool dense = L.type == NR3D_LOD_Dense;
 	const char *__restrict__ base = reinterpret_cast<const char *>(params + L.off + foff0);
-	const uint32_t stride = L.F * 4u;
+	const uint32_t stride = L.F * (uint32_t)sizeof(PT);
 	const bool small = L.size < (1u << 24);
 	const float sc0 = (float)(L.res[0] - 2u), sc1 = (float)(L.res[1] - 2u), sc2 = (float)(L.res[2] - 2u);
 
@@ -1091,7 +1096,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_pl(Sched s, const nr3d_lo
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
 				if (dbg & 2u) t[u][m] = make_float2(__int_as_float(off[m] | 0x3f000000u), __int_as_float(off[m] ^ 0x3f123456u));
-				else t[u][m] = load_pair<float>(base + off[m]);
+				else t[u][m] = load_pair<PT>(base + off[m]);
 			}
 		}
 		// ---- phase 3: the lerp tree's differences -> gradient and mixed second differences -> H v
@@ -1498,6 +1503,9 @@ static int check_common(const nr3d_lotd_meta_t *m, const void *meta_dev, int x_d
 		else { constexpr int D = 4, G = 8; __VA_ARGS__; }                            \
 	} while (0)
 
+// both storage types of one k_fwd instantiation (inside DISPATCH_DG, with a two-kernel `launch` in scope)
+#define NR3D_FWD2(D_, DY_, DH_, ONLY_) launch(k_fwd<D_, G, DY_, DH_, ONLY_, float>, k_fwd<D_, G, DY_, DH_, ONLY_, __half>)
+
 #define DISPATCH_D(D_, ...)                                          \
 	do {                                                             \
 		const uint32_t _d = (D_);                                    \
@@ -1596,6 +1604,11 @@ extern "C" int nr3d_lotd_half_params_ok(const nr3d_lotd_meta_t *meta, int batche
 	return (meta && !batched && pairlane_enabled() && pairlane_meta_ok(meta) && pair_applies(meta)) ? 1 : 0;
 }
 
+static int fwd_generic(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t N, const void *x, const void *params,
+                       bool p_half, const int64_t *batch_inds, const int64_t *batch_offsets, uint32_t batch_data_size,
+                       int32_t max_level, void *y, int64_t y_sn, int64_t y_se, void *dy_dx, int64_t d_sn, int64_t d_se,
+                       hipStream_t st);
+
 extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
                              int param_dtype, const void *x, const void *params, const int64_t *batch_inds,
                              const int64_t *batch_offsets, uint32_t batch_data_size, int32_t max_level, void *y,
@@ -1606,29 +1619,37 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	hipStream_t st = (hipStream_t)stream;
 	const bool batched = batch_inds || batch_offsets || batch_data_size;
-	if (param_dtype == NR3D_F16) {
-		bool served = false;
-		NR3D_CHECK(!batched && pairlane_enabled() && pairlane_meta_ok(meta) && ((uintptr_t)params % 4) == 0,
-		           "LoTD::fwd: half params are served natively for unbatched 3-D Dense/Hash metas with 2-feature pseudo levels "
-		           "only (nr3d_lotd_half_params_ok); convert on the caller side");
-		if (int rc = fwd_fast_path<__half>(meta, md, N, (const float *)x, (const __half *)params, max_level, (__half *)y, y_sn,
-		                                   y_se, (float *)dy_dx, d_sn, d_se, st, served))
-			return rc;
-		NR3D_CHECK(served, "LoTD::fwd: half params need output strides >= 0 whose span over 64 rows fits 32 bits");
-		return 0;
-	}
+	// half tables (the reference's (float, half, float) combination): y is half as well; the two-lane kernels serve
+	// what they can, everything else (and every batched call) goes through the general kernel on the same storage
+	const bool p_half = param_dtype == NR3D_F16;
+	NR3D_CHECK(!p_half || ((uintptr_t)params % 2) == 0, "LoTD::fwd: misaligned half params");
 	if (!batched) {
 		bool served = false;
-		if (int rc = fwd_fast_path<float>(meta, md, N, (const float *)x, (const float *)params, max_level, (float *)y, y_sn, y_se,
-		                                  (float *)dy_dx, d_sn, d_se, st, served))
+		if (p_half) {
+			if (((uintptr_t)params % 4) == 0)
+				if (int rc = fwd_fast_path<__half>(meta, md, N, (const float *)x, (const __half *)params, max_level, (__half *)y, y_sn,
+				                                   y_se, (float *)dy_dx, d_sn, d_se, st, served))
+					return rc;
+		} else if (int rc = fwd_fast_path<float>(meta, md, N, (const float *)x, (const float *)params, max_level, (float *)y, y_sn,
+		                                         y_se, (float *)dy_dx, d_sn, d_se, st, served))
 			return rc;
 		if (served) return 0;
 	}
+	return fwd_generic(meta, md, N, x, params, p_half, batch_inds, batch_offsets, batch_data_size, max_level, y, y_sn, y_se, dy_dx,
+	                   d_sn, d_se, st);
+}
+
+// the general kernel (every level type, D = 2 / 3 / 4, batched tables): float y and dy/dx from float or half tables
+static int fwd_generic(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t N, const void *x, const void *params,
+                       bool p_half, const int64_t *batch_inds, const int64_t *batch_offsets, uint32_t batch_data_size,
+                       int32_t max_level, void *y, int64_t y_sn, int64_t y_se, void *dy_dx, int64_t d_sn, int64_t d_se,
+                       hipStream_t st) {
 	uint32_t n_blocks;
 	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 	const uint32_t G = meta->n_feat_per_pseudo_lvl;
-	// vector gathers need every corner address G*4-byte aligned: base pointer aligned and no caller-chosen offsets
-	const uint32_t vec_ok = (((uintptr_t)params % (G >= 4 ? 16 : 8)) == 0 && batch_offsets == nullptr) ? 1u : 0u;
+	// vector gathers need every corner address G elements aligned: base pointer aligned and no caller-chosen offsets
+	const uint32_t elt = p_half ? 2u : 4u;
+	const uint32_t vec_ok = (((uintptr_t)params % ((G >= 4 ? 4u : 2u) * elt)) == 0 && batch_offsets == nullptr) ? 1u : 0u;
 	const bool dh = meta->c_hash_only != 0;
 	prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
 	// A meta that mixes Dense / Hash levels with product types: the instantiation that carries every level type needs
@@ -1658,16 +1679,21 @@ extern "C" int nr3d_lotd_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 		const Sched s = make_sched(N, meta, n_blocks, skip);
 		if (n_blocks == 0) continue;
 		DISPATCH_DG(meta->n_dims_to_encode, G, {
-			auto launch = [&](auto kern) {
-				hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
-				                   meta->interpolation_type, (const float *)x, (const float *)params, ba, vec_ok,
-				                   (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+			auto launch = [&](auto kern_f32, auto kern_f16) {
+				if (p_half)
+					hipLaunchKernelGGL(kern_f16, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+					                   meta->interpolation_type, (const float *)x, (const __half *)params, ba, vec_ok,
+					                   (__half *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
+				else
+					hipLaunchKernelGGL(kern_f32, dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
+					                   meta->interpolation_type, (const float *)x, (const float *)params, ba, vec_ok,
+					                   (float *)y, y_sn, y_se, (float *)dy_dx, d_sn, d_se);
 			};
-			if (k == 1) { if (dy_dx) launch(k_fwd<D, G, true, true>); else launch(k_fwd<D, G, false, true>); }
-			else if (k == 0) { if (dy_dx) launch(k_fwd<D, G, true, false>); else launch(k_fwd<D, G, false, false>); }
+			if (k == 1) { if (dy_dx) NR3D_FWD2(D, true, true, -1); else NR3D_FWD2(D, false, true, -1); }
+			else if (k == 0) { if (dy_dx) NR3D_FWD2(D, true, false, -1); else NR3D_FWD2(D, false, false, -1); }
 			else if constexpr (D == 3) {
-				if (k == 2) { if (dy_dx) launch(k_fwd<3, G, true, false, NR3D_LOD_CP>); else launch(k_fwd<3, G, false, false, NR3D_LOD_CP>); }
-				else { if (dy_dx) launch(k_fwd<3, G, true, false, NR3D_LOD_VectorMatrix>); else launch(k_fwd<3, G, false, false, NR3D_LOD_VectorMatrix>); }
+				if (k == 2) { if (dy_dx) NR3D_FWD2(3, true, false, NR3D_LOD_CP); else NR3D_FWD2(3, false, false, NR3D_LOD_CP); }
+				else { if (dy_dx) NR3D_FWD2(3, true, false, NR3D_LOD_VectorMatrix); else NR3D_FWD2(3, false, false, NR3D_LOD_VectorMatrix); }
 			}
 		});
 	}
@@ -1707,7 +1733,8 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
                              const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
                              const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
                              uint32_t batch_data_size, uint32_t n_batches, int32_t max_level, void *dL_dparam,
-                             void *workspace, uint64_t workspace_bytes, void *stream, int32_t min_level = 0) {
+                             void *workspace, uint64_t workspace_bytes, void *stream, int32_t min_level = 0, bool p_half = false) {
+	// p_half: `params` are __half tables (read by the product-type levels only; dL_dparam stays float)
 	if (N == 0 || max_level <= -1 || min_level > max_level) return 0;
 	NR3D_CHECK(dL_dy && x && params && dL_dparam, "LoTD::bwd: NULL tensor pointer");
 	// atomic-free binned path: metas without NPlaneSum/CPfast levels, when the caller supplied the workspace (batched
@@ -1719,7 +1746,7 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
 		if (int rc = dparam_binned(second, meta, meta_dev, N, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
 		                           (const float *)x, (const float *)params, bb, batched ? n_batches : 1u, max_level,
 		                           (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, nullptr,
-		                           min_level))
+		                           min_level, false, false, false, nullptr, p_half))
 			return rc;
 		if (handled) return 0;
 	}
@@ -1729,13 +1756,20 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	const bool dh = meta->c_hash_only != 0;
 	DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
-		auto launch = [&](auto kern) {
+		auto launch = [&](auto kern, auto *tab) {
 			hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, min_level, max_level,
 			                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
-			                   (const float *)x, (const float *)params, ba, (float *)dL_dparam);
+			                   (const float *)x, tab, ba, (float *)dL_dparam);
 		};
-		if (second) { if (dh) launch(k_bwd_dparam<D, G, true, true>); else launch(k_bwd_dparam<D, G, true, false>); }
-		else        { if (dh) launch(k_bwd_dparam<D, G, false, true>); else launch(k_bwd_dparam<D, G, false, false>); }
+		const float *pf = (const float *)params;
+		const __half *ph = (const __half *)params;
+		// Dense / Hash levels read no table: the hash-only instantiations serve both storage types
+		if (dh || !p_half) {
+			if (second) { if (dh) launch(k_bwd_dparam<D, G, true, true>, pf); else launch(k_bwd_dparam<D, G, true, false>, pf); }
+			else        { if (dh) launch(k_bwd_dparam<D, G, false, true>, pf); else launch(k_bwd_dparam<D, G, false, false>, pf); }
+		} else {
+			if (second) launch(k_bwd_dparam<D, G, true, false, __half>, ph); else launch(k_bwd_dparam<D, G, false, false, __half>, ph);
+		}
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -1746,10 +1780,10 @@ extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *me
                                     const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
                                     uint32_t batch_data_size, uint32_t n_batches, int32_t max_level, void *dL_dparam,
                                     void *workspace, uint64_t workspace_bytes, void *stream) {
-	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype, true)) return rc;
 	return launch_bwd_dparam(false, meta, meta_dev, N, nullptr, dL_dy, g_sn, g_se, x, params, batch_inds,
 	                         batch_offsets, batch_data_size, n_batches, max_level, dL_dparam, workspace, workspace_bytes,
-	                         stream);
+	                         stream, 0, param_dtype == NR3D_F16);
 }
 
 extern "C" int nr3d_lotd_pair_path_ok(const nr3d_lotd_meta_t *meta) { return (meta && pair_applies(meta)) ? 1 : 0; }
@@ -1816,11 +1850,11 @@ extern "C" int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const v
                                            uint32_t batch_data_size, uint32_t n_batches, int32_t min_level,
                                            int32_t max_level, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
                                            void *stream) {
-	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype, true)) return rc;
 	NR3D_CHECK(min_level >= 0, "LoTD::bwd: min_level must be >= 0");
 	return launch_bwd_dparam(false, meta, meta_dev, N, nullptr, dL_dy, g_sn, g_se, x, params, batch_inds,
 	                         batch_offsets, batch_data_size, n_batches, max_level, dL_dparam, workspace, workspace_bytes,
-	                         stream, min_level);
+	                         stream, min_level, param_dtype == NR3D_F16);
 }
 
 extern "C" void nr3d_lotd_set_dparam_chunk_log2(int log2_points) { set_dparam_chunk_log2(log2_points); }
@@ -1835,11 +1869,11 @@ extern "C" int nr3d_lotd_bwd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void
                                         const int64_t *batch_offsets, uint32_t batch_data_size, uint32_t n_batches,
                                         int32_t max_level, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
                                         void *stream) {
-	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype, true)) return rc;
 	NR3D_CHECK(N == 0 || dL_ddLdx != nullptr, "LoTD::bwd_bwd_input: dL_ddLdx is NULL");
 	return launch_bwd_dparam(true, meta, meta_dev, N, dL_ddLdx, dL_dy, g_sn, g_se, x, params, batch_inds,
 	                         batch_offsets, batch_data_size, n_batches, max_level, dL_dparam, workspace, workspace_bytes,
-	                         stream);
+	                         stream, 0, param_dtype == NR3D_F16);
 }
 
 extern "C" int nr3d_lotd_bwd_bwd_ddLdy(const nr3d_lotd_meta_t *meta, uint32_t N, int x_dtype, int param_dtype,
@@ -1858,19 +1892,20 @@ extern "C" int nr3d_lotd_bwd_bwd_ddLdy(const nr3d_lotd_meta_t *meta, uint32_t N,
 	return 0;
 }
 
-static int launch_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype, int param_dtype,
+template <typename PT>
+static int launch_bwd_bwd_dx_t(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype, int param_dtype,
                              const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
                              const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
                              uint32_t batch_data_size, int32_t max_level, void *dL_dx, void *workspace, uint64_t workspace_bytes,
                              void *stream) {
-	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype)) return rc;
+	if (int rc = check_common(meta, meta_dev, x_dtype, param_dtype, true)) return rc;
 	if (N == 0) return 0;
 	NR3D_CHECK(dL_ddLdx && dL_dy && x && params && dL_dx, "LoTD::bwd_bwd_dx: NULL tensor pointer");
 	const Batch ba{batch_inds, batch_offsets, batch_data_size, meta->n_params};
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	// hash-only metas (every level Dense or Hash): instantiations without the product types' code
 	const bool dh = meta->c_hash_only != 0;
-	const bool vec_ok = (((uintptr_t)params % 8) == 0 && batch_offsets == nullptr);
+	const bool vec_ok = (((uintptr_t)params % (2 * sizeof(PT))) == 0 && batch_offsets == nullptr);
 	const uint64_t need = nr3d_lotd_bwd_bwd_dx_workspace_bytes(meta, N);
 	const char *lv_env = getenv("NR3D_LOTD_HVP_LEVELS");             // 0: the lane-serial kernel even with a workspace
 	if (workspace && need && workspace_bytes >= need && !(lv_env && lv_env[0] == '0')) {
@@ -1879,25 +1914,25 @@ static int launch_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 		const char *pl_env = getenv("NR3D_LOTD_HVP_PAIRLANE");
 		const char *dbg_env = getenv("NR3D_HVP_DBG");                  // timing experiments only (results wrong by design)
 		const uint32_t hvp_dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
-		const bool pl = !batched && pairlane_enabled() && pairlane_meta_ok(meta) && ((uintptr_t)params % 8) == 0 &&
+		const bool pl = !batched && pairlane_enabled() && pairlane_meta_ok(meta) && ((uintptr_t)params % (2 * sizeof(PT))) == 0 &&
 		                !(pl_env && pl_env[0] == '0');
 		const Sched s = pl ? make_sched(N, meta, n_blocks, 0, (uint32_t)(kPlPts * kHvpSub), true) : make_sched(N, meta, n_blocks);
 		DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
 			auto launch = [&](auto kern) {
 				hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
 				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
-				                   (const float *)x, (const float *)params, ba, vec_ok, (float *)workspace);
+				                   (const float *)x, (const PT *)params, ba, vec_ok, (float *)workspace);
 			};
 			if (pl) {
 				// workspace: partial [P][N][3] | g_pairs [P][N][2]
 				float *g_pairs = (float *)workspace + (size_t)N * meta->n_pseudo_levels * 3u;
 				hipLaunchKernelGGL(k_hvp_pairs, dim3(div_up(N, kGpPts), div_up(meta->n_pseudo_levels, kGpLv)), dim3(kBlock), 0,
 				                   (hipStream_t)stream, N, meta->n_pseudo_levels, (const float *)dL_dy, g_sn, g_se, g_pairs);
-				hipLaunchKernelGGL(k_bwd_bwd_dx_pl<kHvpSub>, dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
+				hipLaunchKernelGGL((k_bwd_bwd_dx_pl<kHvpSub, PT>), dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
 				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)g_pairs,
-				                   (const float *)x, (const float *)params, (float *)workspace, hvp_dbg);
+				                   (const float *)x, (const PT *)params, (float *)workspace, hvp_dbg);
 			}
-			else if (dh) launch(k_bwd_bwd_dx_lv<D, G, true>); else launch(k_bwd_bwd_dx_lv<D, G, false>);
+			else if (dh) launch(k_bwd_bwd_dx_lv<D, G, true, PT>); else launch(k_bwd_bwd_dx_lv<D, G, false, PT>);
 			hipLaunchKernelGGL(k_sum_levels<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N,
 			                   meta->n_pseudo_levels, (const float *)workspace, (float *)dL_dx);
 		});
@@ -1908,12 +1943,25 @@ static int launch_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev,
 		auto launch = [&](auto kern) {
 			hipLaunchKernelGGL(kern, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, md, N,
 			                   meta->n_pseudo_levels, max_level, meta->interpolation_type, (const float *)dL_ddLdx,
-			                   (const float *)dL_dy, g_sn, g_se, (const float *)x, (const float *)params, ba, vec_ok, (float *)dL_dx);
+			                   (const float *)dL_dy, g_sn, g_se, (const float *)x, (const PT *)params, ba, vec_ok, (float *)dL_dx);
 		};
-		if (dh) launch(k_bwd_bwd_dx<D, G, true>); else launch(k_bwd_bwd_dx<D, G, false>);
+		if (dh) launch(k_bwd_bwd_dx<D, G, true, PT>); else launch(k_bwd_bwd_dx<D, G, false, PT>);
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;
+}
+
+// float or half tables (read as float: HalfTab); dL_ddLdx, dL_dy, x and the result are float
+static int launch_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype, int param_dtype,
+                             const void *dL_ddLdx, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
+                             const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
+                             uint32_t batch_data_size, int32_t max_level, void *dL_dx, void *workspace, uint64_t workspace_bytes,
+                             void *stream) {
+	if (param_dtype == NR3D_F16)
+		return launch_bwd_bwd_dx_t<__half>(meta, meta_dev, N, x_dtype, param_dtype, dL_ddLdx, dL_dy, g_sn, g_se, x, params, batch_inds,
+		                                   batch_offsets, batch_data_size, max_level, dL_dx, workspace, workspace_bytes, stream);
+	return launch_bwd_bwd_dx_t<float>(meta, meta_dev, N, x_dtype, param_dtype, dL_ddLdx, dL_dy, g_sn, g_se, x, params, batch_inds,
+	                                  batch_offsets, batch_data_size, max_level, dL_dx, workspace, workspace_bytes, stream);
 }
 
 extern "C" uint64_t nr3d_lotd_bwd_bwd_dx_workspace_bytes(const nr3d_lotd_meta_t *meta, uint32_t n_points) {

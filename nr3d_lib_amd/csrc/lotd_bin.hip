@@ -19,6 +19,7 @@
 // the result independent of the update order up to the final f64->f32 rounding.
 #include "lotd_device.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifndef NR3D_BIN_LDS_KB
 #define NR3D_BIN_LDS_KB 72     // stage-A record staging per workgroup (2 workgroups per CU)
@@ -134,9 +135,9 @@ static uint32_t bin_points(uint32_t G, uint32_t NR) {
 //   CP:        T_d = line d, slot = bit d of k (NS = 2)
 //   NPlaneMul: T_j = plane spanning all dims but D-1-j, slot = the other dims' bits (NS = 2^(D-1))
 // d/dT_gd[slot] = sum over the corners with that slot of (grad * w) * prod_{j != gd} T_j[s_j(k)]   (corner_scatter order)
-template <int D, int G, int NR, int NS, bool CP>
+template <int D, int G, int NR, int NS, bool CP, typename TB>
 __device__ __forceinline__ uint32_t emit_product(const Lvl &L, const Cell<D> &c, const float (&w)[1 << D], const float (&grad)[G],
-                                                 const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
+                                                 TB grid, uint32_t foff, uint32_t (&ent)[NR],
                                                  float (&val)[NR][G]) {
 	constexpr uint32_t C = 1u << D;
 	float tv[D][NS][G];
@@ -185,9 +186,9 @@ __device__ __forceinline__ uint32_t emit_product(const Lvl &L, const Cell<D> &c,
 
 // VM (3-D): per component d a plane over the two dims != d (4 slots) times a line along d (2 slots);
 // VecZMatXoY is the d = 2 component alone.  Record index is compile-time: VM d * 6 + {0..3 plane, 4..5 line}.
-template <int G, int NR, bool VM>
+template <int G, int NR, bool VM, typename TB>
 __device__ __forceinline__ uint32_t emit_plane_line(const Lvl &L, const Cell<3> &c, const float (&w)[8], const float (&grad)[G],
-                                                    const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
+                                                    TB grid, uint32_t foff, uint32_t (&ent)[NR],
                                                     float (&val)[NR][G]) {
 #pragma unroll
 	for (int d = VM ? 0 : 2; d < 3; ++d) {
@@ -236,9 +237,9 @@ __device__ __forceinline__ uint32_t emit_plane_line(const Lvl &L, const Cell<3> 
 // Same per-update arithmetic as corner_scatter() (lotd_device.h); contributions to one entry are added in corner order.
 // CPfast: y = prod_d lerp(line_d) evaluated per line, not per corner (lotd_encoding.h:653-705, second order :970-1038);
 // same arithmetic as k_bwd_dparam's CPfast branch, one record per line entry.
-template <int D, int G, int NR, bool SECOND>
+template <int D, int G, int NR, bool SECOND, typename TB>
 __device__ __forceinline__ uint32_t emit_cpfast(const Lvl &L, const Cell<D> &c, const float (&grad)[G], const float (&vin)[D],
-                                                const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
+                                                TB grid, uint32_t foff, uint32_t (&ent)[NR],
                                                 float (&val)[NR][G]) {
 	float lv[D][2][G];
 #pragma unroll
@@ -333,10 +334,10 @@ __device__ __forceinline__ uint32_t emit_nplane_sum(const Lvl &L, const Cell<D> 
 	return (uint32_t)D * NC;
 }
 
-template <int D, int G, int NR, bool DH, bool SECOND>
+template <int D, int G, int NR, bool DH, bool SECOND, typename TB>
 __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c, const float (&w)[1 << D], const float (&grad)[G],
                                                  const float (&a)[D], const float (&vin)[D],
-                                                 const float *__restrict__ grid, uint32_t foff, uint32_t (&ent)[NR],
+                                                 TB grid, uint32_t foff, uint32_t (&ent)[NR],
                                                  float (&val)[NR][G]) {
 	constexpr uint32_t C = 1u << D;
 	if (DH || L.type == NR3D_LOD_Dense || L.type == NR3D_LOD_Hash) {     // DH: the meta has no other level types
@@ -442,11 +443,11 @@ __device__ __forceinline__ uint32_t emit_forest(const ForestDev &fo, const Batch
 	return (uint32_t)NR;
 }
 
-template <int D, int G, bool SECOND, int NR, bool DH, bool FO>
+template <int D, int G, bool SECOND, int NR, bool DH, bool FO, typename PT>
 __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                          int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                          const float *__restrict__ vin_, const float *__restrict__ g,
-                                         int64_t g_sn, int64_t g_se, const float *__restrict__ params,
+                                         int64_t g_sn, int64_t g_se, const PT *__restrict__ params,
                                          const Batch &ba, const ForestDev &fo, uint32_t *__restrict__ rec,
                                          uint32_t *__restrict__ offs_g) {
 	constexpr int BP = BinCfg<G, NR>::BP;
@@ -513,9 +514,10 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			int bk[3];
 #pragma unroll
 			for (int d = 0; d < 3; ++d) bk[d] = fo.block_ks[3 * (size_t)bi + d];
-			n_rec = emit_forest<G, NR>(fo, ba, L, c, w, grad, bk, bi, params, meta_cnt_of(md, q) * G, ent, val);
+			if constexpr (std::is_same<PT, float>::value)      // forests run on float tables
+				n_rec = emit_forest<G, NR>(fo, ba, L, c, w, grad, bk, bi, params, meta_cnt_of(md, q) * G, ent, val);
 		} else {
-			n_rec = emit_updates<D, G, NR, DH, SECOND>(L, c, w, grad, a, vin, params + (pbase + L.off), meta_cnt_of(md, q) * G, ent, val);
+			n_rec = emit_updates<D, G, NR, DH, SECOND>(L, c, w, grad, a, vin, make_tab(params + (pbase + L.off)), meta_cnt_of(md, q) * G, ent, val);
 		}
 #pragma unroll
 		for (int d = 0; d < D; ++d) cell[d] = c.g[d];
@@ -641,11 +643,12 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 	for (uint32_t b = threadIdx.x; b <= nb; b += BP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
 }
 
-template <int D, int G, bool SECOND, int NR, bool DH>
+// PT: storage type of the tables the product-type levels read their other factors from (DH instantiations read none)
+template <int D, int G, bool SECOND, int NR, bool DH, typename PT = float>
 __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                                            int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                            const float *__restrict__ vin_, const float *__restrict__ g,
-                                                           int64_t g_sn, int64_t g_se, const float *__restrict__ params,
+                                                           int64_t g_sn, int64_t g_se, const PT *__restrict__ params,
                                                            Batch ba, uint32_t *__restrict__ rec,
                                                            uint32_t *__restrict__ offs_g) {
 	bin_body<D, G, SECOND, NR, DH, false>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, ForestDev{}, rec, offs_g);
@@ -978,11 +981,11 @@ struct CpPlan {
 	uint32_t part_off[kCpMaxItems];      // float offset of its R partial tables inside `partial`
 };
 
-template <bool SECOND>
+template <bool SECOND, typename PT>
 __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n, uint32_t smooth,
                                                           const float *__restrict__ x, const float *__restrict__ vin_,
                                                           const float *__restrict__ g, int64_t g_sn, int64_t g_se,
-                                                          const float *__restrict__ params, float *__restrict__ partial) {
+                                                          const PT *__restrict__ params, float *__restrict__ partial) {
 	extern __shared__ __attribute__((aligned(16))) double cp_acc[];            // [entries][2 np]
 	const uint32_t r = blockIdx.x, item = blockIdx.y;
 	const uint32_t q = cp.q[item], np = cp.np[item], row = 2u * np;
@@ -991,9 +994,9 @@ __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_
 	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) cp_acc[t] = 0.0;
 	__syncthreads();
 	const uint32_t foff = meta_cnt_of(md, q) * 2u, col0 = meta_col_of(md, q);
-	const float *__restrict__ grid = params + L.off + foff;
-	const bool vec = ((reinterpret_cast<uintptr_t>(grid) & 7u) == 0u) && (L.F & 1u) == 0u;
-	const bool quad = ((reinterpret_cast<uintptr_t>(grid) & 15u) == 0u) && (L.F & 3u) == 0u;     // 16-byte reads: 2 pairs per request
+	const auto grid = make_tab(params + L.off + foff);
+	const bool vec = (tab_addr(grid) % (2u * tab_elt(grid))) == 0u && (L.F & 1u) == 0u;
+	const bool quad = (tab_addr(grid) % (4u * tab_elt(grid))) == 0u && (L.F & 3u) == 0u;       // 4 features (2 pairs) per request
 	const uint32_t p_lo = r * cp.pts_per_rep, p_hi = min(n, p_lo + cp.pts_per_rep);
 #pragma unroll 2
 	for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kCpThreads) {
@@ -1220,9 +1223,10 @@ uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, ui
 template <int D, int G, int NR, bool DH>
 static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
                         int32_t max_level, const float *xc, const float *vc, const float *gc, int64_t sn, int64_t se,
-                        const float *params, const Batch &ba, uint32_t *rec, uint32_t *offs, uint32_t *plan_buf,
+                        const void *params_, bool p_half, const Batch &ba, uint32_t *rec, uint32_t *offs, uint32_t *plan_buf,
                         float *partial, float *dparam, hipStream_t st, const ForestDev *fo = nullptr) {
 	constexpr int BP = BinCfg<G, NR>::BP;
+	const float *params = (const float *)params_;        // half tables: only the !DH instantiations read them (k_bin<..., __half>)
 	uint32_t nb_max = 0;
 	for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
 	const uint32_t NB = pl.bucket_base[pl.n_pseudo];
@@ -1236,6 +1240,10 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoubles * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+		if constexpr (!DH) {
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+		}
 		attr_set = true;
 	}
 	prof::g_mask & (1u << NR3D_PROF_LOTD_BIN) ? prof::begin(NR3D_PROF_LOTD_BIN, st) : (void)0;
@@ -1255,6 +1263,15 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 				                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, *fo, rec, offs);
 		} else {
 			return ::nr3d::fail("LoTD forest: the binned path handles 3-D metas only");
+		}
+	} else if (!DH && p_half) {
+		if constexpr (!DH) {
+			if (second)
+				hipLaunchKernelGGL((k_bin<D, G, true, NR, false, __half>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+				                   meta->interpolation_type, xc, vc, gc, sn, se, (const __half *)params_, ba, rec, offs);
+			else
+				hipLaunchKernelGGL((k_bin<D, G, false, NR, false, __half>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+				                   meta->interpolation_type, xc, vc, gc, sn, se, (const __half *)params_, ba, rec, offs);
 		}
 	} else if (second)
 		hipLaunchKernelGGL((k_bin<D, G, true, NR, DH>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
@@ -1280,8 +1297,9 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
                   hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level, bool g_half, bool out_half, bool assign,
-                  const FusedDx *fdx) {
+                  const FusedDx *fdx, bool p_half) {
 	handled = false;
+	if (p_half && forest) return ::nr3d::fail("LoTD forest: the binned path reads float tables");
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
 	if (!workspace || !binnable(meta, forest != nullptr) || !layout(meta, nc, n_batches, lay, forest != nullptr)) return 0;
@@ -1354,17 +1372,22 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				int dev_id = 0;
 				NR3D_HIP_CHECK(hipGetDevice(&dev_id));
 				if (!cp_attr[dev_id & 63]) {
-					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
-					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
 					cp_attr[dev_id & 63] = true;
 				}
 				const size_t lds = (size_t)max_acc * 8;
-				if (second)
-					hipLaunchKernelGGL(k_cp_direct<true>, dim3(cp.R, cp.n_items), dim3(kCpThreads), lds, st, cp, md, n, meta->interpolation_type,
-					                   xc, vc, gc, sn, se, params, partial);
-				else
-					hipLaunchKernelGGL(k_cp_direct<false>, dim3(cp.R, cp.n_items), dim3(kCpThreads), lds, st, cp, md, n, meta->interpolation_type,
-					                   xc, vc, gc, sn, se, params, partial);
+				auto cp_launch = [&](auto kern, auto *tab) {
+					hipLaunchKernelGGL(kern, dim3(cp.R, cp.n_items), dim3(kCpThreads), lds, st, cp, md, n, meta->interpolation_type, xc, vc,
+					                   gc, sn, se, tab, partial);
+				};
+				if (p_half) {
+					if (second) cp_launch(k_cp_direct<true, __half>, (const __half *)params); else cp_launch(k_cp_direct<false, __half>, (const __half *)params);
+				} else {
+					if (second) cp_launch(k_cp_direct<true, float>, params); else cp_launch(k_cp_direct<false, float>, params);
+				}
 				hipLaunchKernelGGL(k_cp_reduce, dim3(div_up(max_acc, 256u), cp.n_items), dim3(256), 0, st, cp, md, partial, dparam);
 				NR3D_LAUNCH_CHECK();
 			}
@@ -1377,7 +1400,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			int rc = 0;
 			if (forest) {                                  // 3-D (binnable); one stage-A kernel per record class
 				const uint32_t G = meta->n_feat_per_pseudo_lvl;
-#define NR3D_FOREST_CLASS(G_, NR_) rc = launch_class<3, G_, NR_, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st, forest)
+#define NR3D_FOREST_CLASS(G_, NR_) rc = launch_class<3, G_, NR_, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, p_half, ba, rec, offs, plan_buf, partial, dparam, st, forest)
 #define NR3D_FOREST_G(G_) do { if (cls == 8) NR3D_FOREST_CLASS(G_, 8); else if (cls == 24) NR3D_FOREST_CLASS(G_, 24); \
 	else if (cls == 48) NR3D_FOREST_CLASS(G_, 48); } while (0)
 				if (G == 2) NR3D_FOREST_G(2); else if (G == 4) NR3D_FOREST_G(4); else NR3D_FOREST_G(8);
@@ -1390,15 +1413,15 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			DISPATCH_DG_BIN(D, G, {
 				// hash-only metas (every level Dense or Hash) get kernels without the product-type code
 				if (meta->c_hash_only) {
-					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st, forest);
-					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
-				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
+					if constexpr (D <= 3) rc = launch_class<D, G, 8, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, p_half, ba, rec, offs, plan_buf, partial, dparam, st, forest);
+					else rc = launch_class<D, G, 16, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, p_half, ba, rec, offs, plan_buf, partial, dparam, st);
+				} else if (cls == 8) rc = launch_class<D, G, 8, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, p_half, ba, rec, offs, plan_buf, partial, dparam, st);
 				else if (cls == 16) {
-					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
+					if constexpr (D >= 3) rc = launch_class<D, G, 16, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, p_half, ba, rec, offs, plan_buf, partial, dparam, st);
 				} else if (cls == 24) {
-					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
+					if constexpr (D == 3) rc = launch_class<D, G, 24, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, p_half, ba, rec, offs, plan_buf, partial, dparam, st);
 				} else {
-					if constexpr (D == 4) rc = launch_class<D, G, 32, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, ba, rec, offs, plan_buf, partial, dparam, st);
+					if constexpr (D == 4) rc = launch_class<D, G, 32, false>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, p_half, ba, rec, offs, plan_buf, partial, dparam, st);
 				}
 			});
 			if (rc) return rc;

@@ -273,10 +273,49 @@ __device__ __forceinline__ uint32_t entry_nplane_sum(const Lvl &L, uint32_t jump
 }
 
 // ---------------------------------------------------------------------------------------------
+// A level's table read as floats, whatever it is stored as.  `TB` in the helpers below is either `const float *` itself or
+// HalfTab over __half storage -- the reference's (float, half, float) dispatch (lotd_encoding.h:1501-1504): parameters are
+// READ as half and every product / interpolation runs in fp32, so a half table gives exactly what its fp32 copy gives.
+// ---------------------------------------------------------------------------------------------
+struct HalfTab {
+	const __half *p;
+	__device__ __forceinline__ float operator[](size_t i) const { return __half2float(p[i]); }
+	__device__ __forceinline__ HalfTab operator+(size_t n) const { return HalfTab{p + n}; }
+};
+__device__ __forceinline__ const float *make_tab(const float *p) { return p; }
+__device__ __forceinline__ HalfTab make_tab(const __half *p) { return HalfTab{p}; }
+__device__ __forceinline__ uintptr_t tab_addr(const float *g) { return reinterpret_cast<uintptr_t>(g); }
+__device__ __forceinline__ uintptr_t tab_addr(HalfTab g) { return reinterpret_cast<uintptr_t>(g.p); }
+// bytes per element of the table behind a TB
+__device__ __forceinline__ constexpr uint32_t tab_elt(const float *) { return 4u; }
+__device__ __forceinline__ constexpr uint32_t tab_elt(HalfTab) { return 2u; }
+struct __attribute__((aligned(8))) Pair16 { float x, y, z, w; };   // two neighbouring F=2 entries, 8-byte aligned
+struct __attribute__((aligned(4))) HalfPair8 { __half2 a, b; };    // the same over half storage, 4-byte aligned
+// 2 / 4 consecutive elements from an address aligned to that many elements (tab_ld4_pair: to HALF that many)
+__device__ __forceinline__ float2 tab_ld2(const float *g, size_t i) { return *reinterpret_cast<const float2 *>(g + i); }
+__device__ __forceinline__ float2 tab_ld2(HalfTab g, size_t i) { return __half22float2(*reinterpret_cast<const __half2 *>(g.p + i)); }
+__device__ __forceinline__ float4 tab_ld4(const float *g, size_t i) { return *reinterpret_cast<const float4 *>(g + i); }
+__device__ __forceinline__ float4 tab_ld4(HalfTab g, size_t i) {
+	struct __attribute__((aligned(8))) H4 { __half2 a, b; };
+	const H4 t = *reinterpret_cast<const H4 *>(g.p + i);
+	const float2 lo = __half22float2(t.a), hi = __half22float2(t.b);
+	return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ float4 tab_ld4_pair(const float *g, size_t i) {
+	const Pair16 t = *reinterpret_cast<const Pair16 *>(g + i);
+	return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ float4 tab_ld4_pair(HalfTab g, size_t i) {
+	const HalfPair8 t = *reinterpret_cast<const HalfPair8 *>(g.p + i);
+	const float2 lo = __half22float2(t.a), hi = __half22float2(t.b);
+	return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Value of NF consecutive features at one corner, for the N-linear level types.
 // ---------------------------------------------------------------------------------------------
-template <int D, int NF>
-__device__ __forceinline__ void corner_value(const Lvl &L, const float *__restrict__ grid, uint32_t foff,
+template <int D, int NF, typename TB>
+__device__ __forceinline__ void corner_value(const Lvl &L, TB grid, uint32_t foff,
                                              const uint32_t (&p)[D], float (&v)[NF]) {
 	switch (L.type) {
 	case NR3D_LOD_Dense: {
@@ -343,8 +382,9 @@ __device__ __forceinline__ constexpr uint32_t insert_zero(uint32_t m, int at) {
 }
 
 // two consecutive features of one table entry (8-byte load when the table base allows it)
-__device__ __forceinline__ void ld_pair(const float *__restrict__ grid, uint32_t idx, bool vec, float (&o)[2]) {
-	if (vec) { const float2 t = *reinterpret_cast<const float2 *>(grid + idx); o[0] = t.x; o[1] = t.y; }
+template <typename TB>
+__device__ __forceinline__ void ld_pair(TB grid, uint32_t idx, bool vec, float (&o)[2]) {
+	if (vec) { const float2 t = tab_ld2(grid, idx); o[0] = t.x; o[1] = t.y; }
 	else { o[0] = grid[idx]; o[1] = grid[idx + 1]; }
 }
 
@@ -357,12 +397,12 @@ __device__ __forceinline__ void ld_pair(const float *__restrict__ grid, uint32_t
 // kOnlyDenseHash: Dense and Hash levels only (hash-only metas)
 constexpr int kOnlyDenseHash = -2;
 // NF consecutive features of one table entry: one 8-byte (NF = 2) / 16-byte (NF = 4) load when the alignment allows
-template <int NF>
-__device__ __forceinline__ void ld_feats(const float *__restrict__ grid, uint32_t idx, bool vec, float (&o)[NF]) {
+template <int NF, typename TB>
+__device__ __forceinline__ void ld_feats(TB grid, uint32_t idx, bool vec, float (&o)[NF]) {
 	if constexpr (NF == 2) { ld_pair(grid, idx, vec, o); }
 	else {
 		static_assert(NF == 4, "ld_feats: 2 or 4 features");
-		if (vec) { const float4 t = *reinterpret_cast<const float4 *>(grid + idx); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+		if (vec) { const float4 t = tab_ld4(grid, idx); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
 		else { o[0] = grid[idx]; o[1] = grid[idx + 1]; o[2] = grid[idx + 2]; o[3] = grid[idx + 3]; }
 	}
 }
@@ -370,8 +410,8 @@ __device__ __forceinline__ void ld_feats(const float *__restrict__ grid, uint32_
 // NF = 4 (round 3): the product-type levels of a wide pseudo level read 16 bytes per table entry instead of two 8-byte
 // pieces -- the forward of configs[3]'s CP levels was bound by L2 requests (356 M per launch = 244 G/s, profiles/
 // r03g_c4_counters.txt), 24 per (point, 8-feature pseudo level) for 6 distinct 32-byte entries.
-template <int D, int ONLY = -1, int NF = 2>
-__device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__restrict__ grid, uint32_t foff, bool vec,
+template <int D, int ONLY = -1, int NF = 2, typename TB = const float *>
+__device__ __forceinline__ void corner_values_pair(const Lvl &L, TB grid, uint32_t foff, bool vec,
                                                    const Cell<D> &c, float (&v)[1 << D][NF]) {
 	constexpr uint32_t C = 1u << D;
 	if constexpr (ONLY == kOnlyDenseHash) {                // hash-only metas: the values corner_value() loads
@@ -473,8 +513,8 @@ __device__ __forceinline__ void corner_values_pair(const Lvl &L, const float *__
 // Scatter of (grad[f] * weight) at one corner into the parameter-gradient buffer, per level type.
 // Product types multiply by the other factors read from `grid` (lotd_cuda.h:494-829).
 // ---------------------------------------------------------------------------------------------
-template <int D, int NF>
-__device__ __forceinline__ void corner_scatter(const Lvl &L, const float *__restrict__ grid, float *__restrict__ gg,
+template <int D, int NF, typename TB>
+__device__ __forceinline__ void corner_scatter(const Lvl &L, TB grid, float *__restrict__ gg,
                                                uint32_t foff, const uint32_t (&p)[D], const float (&grad)[NF],
                                                float weight) {
 	switch (L.type) {
@@ -538,8 +578,8 @@ __device__ __forceinline__ void corner_scatter(const Lvl &L, const float *__rest
 
 // sum_f value(corner)[f] * grad[f] * weight, for the types that have a d(dL/dx)/dx path
 // (lotd_cuda.h:831-957)
-template <int D, int NF>
-__device__ __forceinline__ float corner_dot(const Lvl &L, const float *__restrict__ grid, uint32_t foff,
+template <int D, int NF, typename TB>
+__device__ __forceinline__ float corner_dot(const Lvl &L, TB grid, uint32_t foff,
                                             const uint32_t (&p)[D], const float (&grad)[NF], float weight) {
 	float v[NF];
 	corner_value<D, NF>(L, grid, foff, p, v);
@@ -552,8 +592,6 @@ __device__ __forceinline__ float corner_dot(const Lvl &L, const float *__restric
 // ---------------------------------------------------------------------------------------------
 // Paired 16-byte gathers of F == 2 Dense / Hash levels (forward kernels)
 // ---------------------------------------------------------------------------------------------
-struct __attribute__((aligned(8))) Pair16 { float x, y, z, w; };   // two neighbouring F=2 entries, 8-byte aligned
-
 // The gather rate is bound by L2->L1 line requests (one per lane and instruction, ~260 G/s chip-wide,
 // tools/ubench_mem), not by bytes.  Corner pairs that are neighbours in memory come from ONE 16-byte load:
 //   Dense -> the pair along the contiguous last dim (always neighbours, 8-byte aligned 16-byte load);
@@ -561,8 +599,8 @@ struct __attribute__((aligned(8))) Pair16 { float x, y, z, w; };   // two neighb
 //            hash(x0 + 1, ..) == hash(x0, ..) ^ 1, the other half of the same aligned 16-byte slot.
 // Lanes whose partner lives elsewhere fetch it with a second 8-byte load, all of them under ONE branch so that
 // no load has to be waited for before the last one is issued.  F == 2 (8-byte entries) only.
-template <int D, bool DENSE>
-__device__ __forceinline__ void gather_pairs(const Lvl &L, const Cell<D> &c, const float *__restrict__ grid,
+template <int D, bool DENSE, typename TB>
+__device__ __forceinline__ void gather_pairs(const Lvl &L, const Cell<D> &c, TB grid,
                                              float (&v)[1 << D][2]) {
 	constexpr uint32_t PBIT = DENSE ? (1u << (D - 1)) : 1u;
 	uint32_t e1s[1 << (D - 1)];
@@ -577,7 +615,7 @@ __device__ __forceinline__ void gather_pairs(const Lvl &L, const Cell<D> &c, con
 		const uint32_t e0 = DENSE ? entry_dense<D>(L, p0) : entry_hash<D>(L, p0);
 		const uint32_t e1 = DENSE ? e0 + 1u : entry_hash<D>(L, p1);
 		const uint32_t base = DENSE ? e0 : min(e0 & ~1u, L.size - 2u);
-		const Pair16 t = *reinterpret_cast<const Pair16 *>(grid + (size_t)base * 2u);
+		const float4 t = tab_ld4_pair(grid, (size_t)base * 2u);
 		const bool hi0 = (e0 != base);
 		v[k0][0] = hi0 ? t.z : t.x;
 		v[k0][1] = hi0 ? t.w : t.y;
@@ -591,7 +629,7 @@ __device__ __forceinline__ void gather_pairs(const Lvl &L, const Cell<D> &c, con
 #pragma unroll
 		for (uint32_t m = 0; m < (1u << (D - 1)); ++m) {
 			const uint32_t k1 = (m << 1) | 1u;
-			const float2 t = *reinterpret_cast<const float2 *>(grid + (size_t)e1s[m] * 2u);
+			const float2 t = tab_ld2(grid, (size_t)e1s[m] * 2u);
 			v[k1][0] = t.x;
 			v[k1][1] = t.y;
 		}
@@ -704,7 +742,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
                   hipStream_t st, bool &handled, const ForestDev *forest = nullptr, int32_t min_level = 0, bool g_half = false,
-                  bool out_half = false, bool assign = false, const struct FusedDx *fdx = nullptr);
+                  bool out_half = false, bool assign = false, const struct FusedDx *fdx = nullptr, bool p_half = false);
+// p_half: `params` points to __half tables (the product-type levels read their other factors from them)
 // g_half: dL_dy is __half; out_half: dparam is __half (pair path only); assign: dparam arrives UNINITIALISED -- the pair
 // path writes every element when one pass covers all levels, every other case zero-fills it first
 

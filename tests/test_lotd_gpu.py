@@ -307,11 +307,12 @@ def test_generic_kernel_agrees_with_dense_hash_kernel(oracle, dev):
     assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dparam generic", levels=m_ref)
 
 
-def test_half_table_copy_is_shared_per_version_not_per_address(oracle, dev):
-    """half tables that are not served natively (product-type levels) run on an fp32 copy that the calls of one step share
-    (bindings._lotd._p32, keyed on storage + version counter): an in-place update must invalidate it, and so must a NEW
-    tensor that the caching allocator places at the address of a freed one"""
+def test_half_table_copy_is_shared_per_version_not_per_address(oracle, dev, monkeypatch):
+    """NATIVE_HALF off (A/B switch; the kernels read half tables themselves otherwise): half tables run on an fp32 copy that
+    the calls of one step share (bindings._lotd._p32, keyed on storage + version counter): an in-place update must
+    invalidate it, and so must a NEW tensor that the caching allocator places at the address of a freed one"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, "mixed", n=2001, seed=9)
+    monkeypatch.setattr(_lotd, "NATIVE_HALF", False)
     ph = pt.half()
     assert not _lotd._native_half(m, ph, False)
     y1 = _lotd.lod_fwd(m, xt, ph)[0].float().clone()
@@ -327,6 +328,105 @@ def test_half_table_copy_is_shared_per_version_not_per_address(oracle, dev):
     other = (pt * 0.5).half()                                                # likely the freed block again, version 0
     y3 = _lotd.lod_fwd(m, xt, other)[0].float()
     assert_close(y3, oracle.lotd_fwd(m_ref, x, other.float().cpu().numpy())[0], rel=1e-3, name=f"y of a new table (same address: {other.data_ptr() == addr})")
+
+
+HALF_GENERAL_CASES = ["hash_npow2", "dense_f8", "dense_2d", "hash_4d", "mixed", "mixed_cuboid", "mixed_smooth", "vecz_nplanemul",
+                      "nplane", "nplane_smooth", "cp_2d", "cp_4d", "nplane_4d"]
+
+
+@pytest.mark.parametrize("case", HALF_GENERAL_CASES)
+def test_half_tables_general_kernel_forward(oracle, dev, case):
+    """half tables of metas the two-lane kernels do not serve (every level type, D = 2 / 3 / 4, wide pseudo levels): the
+    general kernel reads the half entries itself (k_fwd<..., __half>) -- same fp32 arithmetic on the same values as the
+    run on an fp32 copy of the table, one rounding of y to half: identical y and dy_dx; also with batched tables"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=3001, seed=12)
+    ph = pt.half()
+    outs = {}
+    for native in (True, False):
+        _lotd.NATIVE_HALF = native
+        try:
+            outs[native] = (_lotd.lod_fwd(m, xt, ph, need_input_grad=True), _lotd.lod_fwd(m, xt, ph, max_level=m.n_levels // 2))
+        finally:
+            _lotd.NATIVE_HALF = True
+    (y, j), (ym, _) = outs[True]
+    (y0, j0), (ym0, _) = outs[False]
+    assert y.dtype == torch.float16 and j.dtype == torch.float32
+    assert torch.equal(y, y0) and torch.equal(j, j0) and torch.equal(ym, ym0)
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, ph.float().cpu().numpy(), need_dydx=True)
+    # one rounding to half: 2^-11 relative, or half a subnormal step (2^-25) for the products of a 4-factor CP level
+    assert np.allclose(y.float().cpu().numpy(), y_ref, rtol=1e-3, atol=6e-8), "y from half tables"
+    assert_close(j.reshape(j_ref.shape), j_ref, name="dy_dx from half tables")
+    # batched tables: three copies of the table, permuted placement, skipped points
+    B = 3
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=1500, seed=13, n_batch=B)
+    ph = pt.half()
+    rng = np.random.default_rng(6)
+    bit = torch.from_numpy(rng.integers(-1, B, x.shape[0]).astype(np.int64)).to(dev)
+    bot = torch.from_numpy((np.array([2, 0, 1]) * m.n_params).astype(np.int64)).to(dev)
+    for kw in (dict(batch_inds=bit), dict(batch_inds=bit, batch_offsets=bot), dict(batch_data_size=500)):
+        yb, jb = _lotd.lod_fwd(m, xt, ph, need_input_grad=True, **kw)
+        _lotd.NATIVE_HALF = False
+        try:
+            yb0, jb0 = _lotd.lod_fwd(m, xt, ph, need_input_grad=True, **kw)
+        finally:
+            _lotd.NATIVE_HALF = True
+        assert yb.dtype == torch.float16 and torch.equal(yb, yb0) and torch.equal(jb, jb0), f"batched {list(kw)}"
+
+
+@pytest.mark.parametrize("case", ["hash_npow2", "dense_2d", "mixed", "mixed_smooth", "vecz_nplanemul", "nplane", "nplane_smooth", "cp_4d",
+                                  "ngp_smooth"])
+@pytest.mark.parametrize("binned", [True, False])
+def test_half_tables_general_kernels_gradients(oracle, dev, case, binned, monkeypatch):
+    """dL/dparam (record path and hardware atomics) and the three second-order outputs from half tables: the kernels that read
+    table entries (product-type factors in stage A / k_cp_direct / the atomic scatter; every level in the Hessian kernels)
+    read the half entries themselves -- identical to the run on an fp32 copy of the table; batched tables too"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=2777, seed=21)
+    monkeypatch.setattr(_lotd, "USE_BINNED_DPARAM", binned)
+    ph, gh = pt.half(), gt.half()
+
+    def run():
+        _, j = _lotd.lod_fwd(m, xt, ph, need_input_grad=True)
+        dx, dp = _lotd.lod_bwd(m, gh, xt, ph, j, need_input_grad=True, need_param_grad=True)
+        ddy, dp2, dx2 = _lotd.lod_bwd_bwd_input(m, vt, gh, xt, ph, j, need_dLdinput_ddLdoutput=True, need_dLdinput_dparams=True,
+                                                need_dLdinput_dinput=True)
+        return dx, dp, ddy, dp2, dx2
+    native = run()
+    _lotd.NATIVE_HALF = False
+    try:
+        copied = run()
+    finally:
+        _lotd.NATIVE_HALF = True
+    atomics = not _lotd.USE_BINNED_DPARAM            # arrival-order fp32 sums: compared to tolerance, not bit for bit
+    for k, (a, b) in enumerate(zip(native, copied)):
+        assert a.dtype == b.dtype
+        if atomics and k in (1, 3):
+            assert_close(a.float(), b.float().cpu().numpy(), rel=1e-3, name=f"output {k}", levels=m_ref)
+        else:
+            assert torch.equal(a, b), f"output {k} differs between the half table and its fp32 copy"
+    p_r, g_r = ph.float().cpu().numpy(), gh.float().cpu().numpy()
+    assert_close(native[1].float(), oracle.lotd_bwd_dparam(m_ref, g_r, x, p_r, accum_double=True), rel=1e-3, name="dL_dparam", levels=m_ref)
+    assert_close(native[4], oracle.lotd_bwd_bwd_dx(m_ref, v, g_r, x, p_r), rel=2e-5, name="d(dL/dx)/dx from half tables")
+    if case in ("mixed", "hash_npow2"):
+        B = 2
+        _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=1200, seed=22, n_batch=B)
+        ph, gh = pt.half(), gt.half()
+        kw = dict(batch_data_size=600)
+        outs = []
+        for nat in (True, False):
+            _lotd.NATIVE_HALF = nat
+            try:
+                _, j = _lotd.lod_fwd(m, xt, ph, need_input_grad=True, **kw)
+                _, dp = _lotd.lod_bwd(m, gh, xt, ph, j, need_input_grad=False, need_param_grad=True, **kw)
+                _, dp2, dx2 = _lotd.lod_bwd_bwd_input(m, vt, gh, xt, ph, j, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
+                                                      need_dLdinput_dinput=True, **kw)
+            finally:
+                _lotd.NATIVE_HALF = True
+            outs.append((dp, dp2, dx2))
+        for k, (a, b) in enumerate(zip(*outs)):
+            if atomics and k < 2:
+                assert_close(a.float(), b.float().cpu().numpy(), rel=1e-3, name=f"batched output {k}")
+            else:
+                assert torch.equal(a, b), f"batched output {k}"
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_pair", "pair_f4", "mixed"])
@@ -345,7 +445,7 @@ def test_half_params_and_inputs(oracle, dev, case):
     dp_ref = oracle.lotd_bwd_dparam(m_ref, g_r, x, p_r, accum_double=True)
     dx_ref = oracle.lotd_bwd_dx(m_ref, g_r, j_ref)
     outs = {}
-    for native in ([True, False] if native_expected else [False]):
+    for native in (True, False):
         _lotd.NATIVE_HALF = native
         try:
             y, j = _lotd.lod_fwd(m, xt, ph, need_input_grad=True)
@@ -366,6 +466,9 @@ def test_half_params_and_inputs(oracle, dev, case):
         assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
         assert torch.equal(outs[True][2], outs[False][2])
         assert_close(outs[True][3].float(), outs[False][3].float().cpu().numpy(), rel=1e-3, name="native vs converted dL_dparam", levels=m_ref)
+    else:                    # general kernels on the half table itself against the run on its fp32 copy: the same bits
+        for a, b in zip(outs[True], outs[False]):
+            assert torch.equal(a, b)
     with pytest.raises(RuntimeError, match="not supported"):
         _lotd.lod_fwd(m, xt.half(), pt)          # (half input, float params) is not a supported combination
 
