@@ -476,7 +476,7 @@ def c1_dense_rate(dev):
                 max_rel_diff=float(f"{err:.2e}"))
 
 
-def forest_lotd_rate(dev, log2n=20, iters=10):
+def forest_lotd_rate(dev, log2n=20, iters=10, by_block=False):
     """SURVEY 8f rank 4 as an extra figure: LoTD over a forest of 8 blocks (dense level-1 octree, continuity on), the
     NGP config's first 8 levels (4 Dense + 4 Hash) per block, 2^20 points spread over the blocks:
     fwd(+dy/dx) + dL/dx + dL/dparam"""
@@ -492,7 +492,10 @@ def forest_lotd_rate(dev, log2n=20, iters=10):
     n = 1 << log2n
     g = torch.Generator().manual_seed(3)
     x = torch.rand(n, 3, generator=g).clamp_(1e-6, 1 - 1e-6).to(dev)
-    bi = torch.randint(0, space.n_trees, (n,), generator=g).to(dev)
+    bi = torch.randint(0, space.n_trees, (n,), generator=g)
+    if by_block:          # points grouped by block (what marching through the blocks delivers), not scattered over them
+        bi = bi.sort().values
+    bi = bi.to(dev)
     params = torch.empty(space.n_trees * meta.n_params).uniform_(-1e-4, 1e-4, generator=g).to(dev)
     gy = (torch.randn(n, meta.n_encoded_dims, generator=g) / 1e4).to(dev)
 
@@ -504,7 +507,8 @@ def forest_lotd_rate(dev, log2n=20, iters=10):
     for _ in range(iters):
         one()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / iters * 1e3
-    return dict(workload=f"forest LoTD, {space.n_trees} blocks x {L} levels (4 Dense + 4 Hash), 2^{log2n} points, "
+    return dict(workload=f"forest LoTD, {space.n_trees} blocks x {L} levels (4 Dense + 4 Hash), 2^{log2n} points "
+                         f"{'grouped by block' if by_block else 'scattered over the blocks'}, "
                          f"fwd(+dy/dx) + dL/dx + dL/dparam (binned)", ms_per_iter=round(ms, 3),
                 mpoints_per_s=round(n / ms / 1e3, 2))
 
@@ -797,6 +801,7 @@ def main():
                              ("c1_dense_fwd", lambda: c1_dense_rate(dev)),
                              ("full_loop_1gpu", lambda: full_loop_rate(dev)),
                              ("forest_lotd", lambda: forest_lotd_rate(dev)),
+                             ("forest_lotd_by_block", lambda: forest_lotd_rate(dev, by_block=True)),
                              ("lotd_half_params", lambda: lotd_half_rate(dev)),
                              ("lotd_second_order", lambda: lotd_second_order_rate(dev)),
                              ("mlp_decoder", lambda: mlp_decoder_rate(dev)),
