@@ -36,6 +36,22 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     dp2_ref = oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True, **kw)
     def err(a, b):
         a = a.cpu().numpy().reshape(b.shape); s = max(np.abs(b).max(), 1e-30); return np.abs(a - b).max() / s
+    if it % 4 == 2:           # half tables read by the kernels themselves against the run on the fp32 copy: the same bits
+        ph, gh = t(p).half(), t(g).half()
+        outs = []
+        for nat in (True, False):
+            _lotd.NATIVE_HALF = nat
+            try:
+                yh, jh = _lotd.lod_fwd(m, t(x), ph, need_input_grad=True, **kw)
+                dxh, dph = _lotd.lod_bwd(m, gh, t(x), ph, jh, need_input_grad=True, need_param_grad=True, **kw)
+                _, dp2h, dx2h = _lotd.lod_bwd_bwd_input(m, t(v), gh, t(x), ph, jh, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
+                                                        need_dLdinput_dinput=True, **kw)
+            finally:
+                _lotd.NATIVE_HALF = True
+            outs.append((yh, jh, dxh, dp2h, dx2h) + (() if _lotd._native_half(m, ph, False) else (dph,)))
+        for k, (a, b) in enumerate(zip(*outs)):
+            if not torch.equal(a, b):
+                bad += 1; print("HALF TABLE MISMATCH", case, n, ml, k, float((a.float() - b.float()).abs().max()))
     es = (err(y, y_ref), err(j, j_ref), err(dp, dp_ref), err(dp2, dp2_ref))
     ok = all(e <= 1e-5 for e in es)
     bad += not ok
