@@ -522,6 +522,14 @@ int nr3d_march_finish_rays(uint32_t n_rays, const int32_t *packed_info, int64_t 
 int nr3d_march_finish_samples(uint64_t S, const float *rays_o, const float *rays_d, const int32_t *ridx,
                               const float *t_starts, const float *t_ends, int64_t *ridx64, float *deltas, float *samples,
                               void *stream);
+/* nr3d_ray_marching_emit from the sample cache of nr3d_ray_marching_count AND nr3d_march_finish_samples in one launch
+ * (the cached emit is a per-ray copy: the epilogue rides on it): t_starts / t_ends / ridx (/ bidx / gidx) as
+ * nr3d_ray_marching_emit, ridx64 / deltas / samples (each optional) as nr3d_march_finish_samples -- the same values. */
+int nr3d_ray_marching_emit_finished(uint32_t n_rays, const float *rays_o, const float *rays_d, int batched,
+                                    const int32_t *batch_inds, uint32_t batch_data_size, const int32_t *packed_info,
+                                    const void *sample_cache, uint32_t cache_max_steps, float *t_starts, float *t_ends,
+                                    int32_t *ridx, int32_t *bidx, int32_t *gidx, int64_t *ridx64, float *deltas,
+                                    float *samples, void *stream);
 /* Visibility pruning (nr3d_lib/graphics/nerf/nerf_utils.py:64-98 packed_volume_render_compression + the index gathers
  * of nerf_ray_query.py:128-137).  counts int64 [P] = kept samples per pack (nr3d_alpha_to_vw_forward's num_steps):
  * begin_all [P] = new begin of EVERY pack; the packs that keep >= 1 sample, ascending: idx_out [P'] (tag[i] if tag is

@@ -113,6 +113,18 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
         ridx = H.empty(S, dtype=torch.int32, device=dev)
         bidx = H.empty(S, dtype=torch.int32, device=dev) if batched else None
         gidx = H.empty(S, dtype=torch.int32, device=dev) if return_gidx else None
+        if finish and cache is not None:
+            # the cached emit is a per-ray copy; the per-sample epilogue rides on it (one launch, one op)
+            ridx64 = H.empty(S, dtype=torch.int64, device=dev)
+            deltas = H.empty(S, dtype=torch.float32, device=dev)
+            samples = H.empty((S, 3), dtype=torch.float32, device=dev)
+            if S > 0:
+                H.check(H.lib().nr3d_ray_marching_emit_finished(
+                    H.u32(n), H.ptr(rays_o), H.ptr(rays_d), C.c_int(int(batched)), H.ptr(batch_inds), H.u32(bds),
+                    H.ptr(packed_info), H.ptr(cache), H.u32(max_steps), H.ptr(t_starts), H.ptr(t_ends), H.ptr(ridx), H.ptr(bidx),
+                    H.ptr(gidx), H.ptr(ridx64), H.ptr(deltas), H.ptr(samples), st))
+            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=pack_infos[:n_hit], t_starts=t_starts.view(-1),
+                        t_ends=t_ends.view(-1), ridx=ridx64, deltas=deltas, samples=samples, bidx=bidx, gidx=gidx)
         if S > 0:
             H.check(H.lib().nr3d_ray_marching_emit(
                 H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res,

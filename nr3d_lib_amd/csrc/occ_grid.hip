@@ -396,19 +396,35 @@ __global__ __launch_bounds__(256) void k_emit_cached(uint32_t n_rays, uint32_t s
                                                      const int32_t *__restrict__ packed_info,
                                                      const uint32_t *__restrict__ cache, float *__restrict__ t_starts,
                                                      float *__restrict__ t_ends, int32_t *__restrict__ ridx,
-                                                     int32_t *__restrict__ bidx, int32_t *__restrict__ gidx) {
+                                                     int32_t *__restrict__ bidx, int32_t *__restrict__ gidx,
+                                                     const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                     int64_t *__restrict__ ridx64, float *__restrict__ deltas,
+                                                     float *__restrict__ samples) {
 	const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (i >= n_rays) return;
 	const uint32_t base = (uint32_t)packed_info[2 * (size_t)i], cnt = (uint32_t)packed_info[2 * (size_t)i + 1];
 	int32_t b = 0;
 	if (batched) b = batch_inds ? batch_inds[i] : (batch_data_size ? (int32_t)(i / batch_data_size) : 0);
 	const uint32_t *c = cache + (size_t)i * stride * 3;
+	float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f};
+	if (samples) {
+#pragma unroll
+		for (int k = 0; k < 3; ++k) { o[k] = rays_o[3 * (size_t)i + k]; d[k] = rays_d[3 * (size_t)i + k]; }
+	}
 	for (uint32_t j = lane; j < cnt; j += 64) {
-		t_starts[base + j] = __uint_as_float(c[3 * j]);
-		t_ends[base + j] = __uint_as_float(c[3 * j + 1]);
+		const float a = __uint_as_float(c[3 * j]), e = __uint_as_float(c[3 * j + 1]);
+		t_starts[base + j] = a;
+		t_ends[base + j] = e;
 		ridx[base + j] = (int32_t)i;
 		if (bidx) bidx[base + j] = b;
 		if (gidx) gidx[base + j] = (int32_t)c[3 * j + 2];
+		// the per-sample epilogue of nr3d_march_finish_samples (ray_glue.hip: the same expressions), when asked for
+		if (ridx64) ridx64[base + j] = (int64_t)i;
+		if (deltas) deltas[base + j] = e - a;
+		if (samples) {
+#pragma unroll
+			for (int k = 0; k < 3; ++k) samples[(size_t)(base + j) * 3 + k] = __fmaf_rn(d[k], a, o[k]);
+		}
 	}
 }
 
@@ -645,7 +661,8 @@ extern "C" int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, cons
 	if (sample_cache) {   // filled by nr3d_ray_marching_count with the same rays and max_steps == cache_max_steps
 		hipLaunchKernelGGL(occ::k_emit_cached, dim3(div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, n_rays,
 		                   cache_max_steps, batched, batch_inds, batch_data_size, packed_info, (const uint32_t *)sample_cache,
-		                   t_starts, t_ends, ridx, bidx, gidx);
+		                   t_starts, t_ends, ridx, bidx, gidx, (const float *)nullptr, (const float *)nullptr, (int64_t *)nullptr,
+		                   (float *)nullptr, (float *)nullptr);
 		NR3D_LAUNCH_CHECK();
 		return 0;
 	}
@@ -653,6 +670,22 @@ extern "C" int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, cons
 	                   n_rays, rays_o, rays_d, t_min, t_max, roi, grid_res[0], grid_res[1], grid_res[2], grid_binary,
 	                   type, step_size, max_step_size, dt_gamma, 0u, batched, batch_inds, batch_data_size, packed_info,
 	                   (int32_t *)nullptr, t_starts, t_ends, ridx, bidx, gidx, (uint32_t *)nullptr);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_ray_marching_emit_finished(uint32_t n_rays, const float *rays_o, const float *rays_d, int batched,
+                                               const int32_t *batch_inds, uint32_t batch_data_size, const int32_t *packed_info,
+                                               const void *sample_cache, uint32_t cache_max_steps, float *t_starts,
+                                               float *t_ends, int32_t *ridx, int32_t *bidx, int32_t *gidx, int64_t *ridx64,
+                                               float *deltas, float *samples, void *stream) {
+	if (n_rays == 0) return 0;
+	NR3D_CHECK(packed_info && sample_cache && t_starts && t_ends && ridx, "ray_marching_emit_finished: NULL tensor pointer");
+	NR3D_CHECK(!samples || (rays_o && rays_d), "ray_marching_emit_finished: samples need rays_o / rays_d");
+	prof::Scope ps(NR3D_PROF_MARCH, (hipStream_t)stream);
+	hipLaunchKernelGGL(occ::k_emit_cached, dim3(div_up(n_rays, 4)), dim3(256), 0, (hipStream_t)stream, n_rays, cache_max_steps,
+	                   batched, batch_inds, batch_data_size, packed_info, (const uint32_t *)sample_cache, t_starts, t_ends, ridx,
+	                   bidx, gidx, rays_o, rays_d, ridx64, deltas, samples);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
