@@ -237,8 +237,9 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
     out = dict(workload=f"configs[2]: occ 128^3 march + fused alpha composite fwd+bwd, {n} rays x <= 512 samples",
                samples=int(S), ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4),
                kernel_us_per_iter={k: round(v, 2) for k, v in kus.items()},
-               launches_per_iter="march 2 (count + emit) + scan 1 (3 above 32768 rays) + finish 2 (hit rays, per-sample epilogue), "
-                                 "sigma -> alpha 1, composite 1 + 1 (+ one zero fill of the per-ray outputs); one device->host readback")
+               launches_per_iter="march 2 (count; cached emit + per-sample epilogue) + scan 1 (3 above 32768 rays: packed_info "
+                                 "and the hit rays' compaction in the same scan), sigma -> alpha 1, composite 1 + 1 (+ one zero "
+                                 "fill of the per-ray outputs); one device->host readback")
     if cpu_seconds > 0:
         # the oracle's marcher counts the grid probes of the byte model, and is the CPU baseline next to the chain
         probes, S_r, base = cpu_baseline(None, c3=((o_c, d_c, near_c, far_c, roi_c, grid_c), n, step, cpu_seconds))

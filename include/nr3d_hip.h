@@ -522,6 +522,17 @@ int nr3d_march_finish_rays(uint32_t n_rays, const int32_t *packed_info, int64_t 
 int nr3d_march_finish_samples(uint64_t S, const float *rays_o, const float *rays_d, const int32_t *ridx,
                               const float *t_starts, const float *t_ends, int64_t *ridx64, float *deltas, float *samples,
                               void *stream);
+/* nr3d_ray_marching_count AND nr3d_march_finish_rays with ONE scan of the counts: packed_info as nr3d_ray_marching_count,
+ * ridx_hit [n_rays] / pack_infos [n_rays, 2] (their first n_hit rows are written) as nr3d_march_finish_rays,
+ * totals = {number of samples, n_hit}. */
+int nr3d_ray_marching_count_finished(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                                     const float *t_max, const float *roi, const int32_t grid_res[3],
+                                     const uint8_t *grid_binary, int type, float step_size, float max_step_size,
+                                     float dt_gamma, uint32_t max_steps, int batched, const int32_t *batch_inds,
+                                     uint32_t batch_data_size, int32_t *packed_info, int64_t *ridx_hit, int64_t *pack_infos,
+                                     int64_t *totals, void *scan_tmp, void *sample_cache, uint64_t sample_cache_bytes,
+                                     void *stream);
+
 /* nr3d_ray_marching_emit from the sample cache of nr3d_ray_marching_count AND nr3d_march_finish_samples in one launch
  * (the cached emit is a per-ray copy: the epilogue rides on it): t_starts / t_ends / ridx (/ bidx / gidx) as
  * nr3d_ray_marching_emit, ridx64 / deltas / samples (each optional) as nr3d_march_finish_samples -- the same values. */

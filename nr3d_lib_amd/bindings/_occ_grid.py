@@ -86,27 +86,30 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
     with H.on_device(dev):
         st = H.stream_of(rays_o)
         packed_info = H.empty((n, 2), dtype=torch.int32, device=dev)
-        total = H.empty(1, dtype=torch.int64, device=dev)
+        total = None if finish else H.empty(1, dtype=torch.int64, device=dev)
         tmp = H.empty((_scan_tmp_bytes(n) + 7) // 8, dtype=torch.int64, device=dev)
         # sample cache: the count pass keeps every sample, the emit pass only compacts (no second march)
         cache_bytes = n * int(max_steps) * 12
         cache = (H.empty((cache_bytes + 3) // 4, dtype=torch.int32, device=dev)
                  if 0 < cache_bytes <= SAMPLE_CACHE_MAX_BYTES else None)
-        H.check(H.lib().nr3d_ray_marching_count(
-            H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
-            ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), H.u32(max_steps), C.c_int(int(batched)),
-            H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(total), H.ptr(tmp), H.ptr(cache),
-            C.c_uint64(cache_bytes if cache is not None else 0), st))
         if finish:
-            # the hit rays' compaction only needs the counts: it runs BEFORE the readback, which then fetches the number
-            # of samples and of hit rays together -- still ONE device->host sync
+            # the hit rays' compaction only needs the counts: the scan that turns them into packed_info compacts the hit rays
+            # as well, and the readback fetches the number of samples and of hit rays together -- ONE device->host sync
             ridx_hit = H.empty(n, dtype=torch.int64, device=dev)
             pack_infos = H.empty((n, 2), dtype=torch.int64, device=dev)
             totals = H.empty(2, dtype=torch.int64, device=dev)
-            H.check(H.lib().nr3d_march_finish_rays(H.u32(n), H.ptr(packed_info), H.ptr(ridx_hit), H.ptr(pack_infos),
-                                                   H.ptr(totals), H.ptr(tmp), st))
+            H.check(H.lib().nr3d_ray_marching_count_finished(
+                H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
+                ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), H.u32(max_steps), C.c_int(int(batched)),
+                H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(ridx_hit), H.ptr(pack_infos), H.ptr(totals), H.ptr(tmp),
+                H.ptr(cache), C.c_uint64(cache_bytes if cache is not None else 0), st))
             S, n_hit = H.read_i64(totals)
         else:
+            H.check(H.lib().nr3d_ray_marching_count(
+                H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
+                ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), H.u32(max_steps), C.c_int(int(batched)),
+                H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(total), H.ptr(tmp), H.ptr(cache),
+                C.c_uint64(cache_bytes if cache is not None else 0), st))
             S = H.read_i64(total)[0]       # the single device->host sync of this op
         t_starts = H.empty((S, 1), dtype=torch.float32, device=dev)
         t_ends = H.empty((S, 1), dtype=torch.float32, device=dev)

@@ -13,6 +13,7 @@
 // single readback, and single/batched marching share one kernel.
 #include "common.h"
 #include "scan.h"
+#include "compact.h"
 #include <stdlib.h>
 
 namespace nr3d {
@@ -604,16 +605,18 @@ extern "C" uint64_t nr3d_ray_marching_cache_bytes(uint32_t n_rays, uint32_t max_
 	return (uint64_t)n_rays * max_steps * 12u;
 }
 
-extern "C" int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
-                                       const float *t_max, const float *roi, const int32_t grid_res[3],
-                                       const uint8_t *grid_binary, int type, float step_size, float max_step_size,
-                                       float dt_gamma, uint32_t max_steps, int batched, const int32_t *batch_inds,
-                                       uint32_t batch_data_size, int32_t *packed_info, int64_t *total_steps,
-                                       void *scan_tmp, void *sample_cache, uint64_t sample_cache_bytes,
-                                       void *stream) {
+// count pass + the scan of the counts.  ridx_hit == NULL: packed_info and total_steps[0] (nr3d_ray_marching_count); else the
+// same scan also compacts the rays that got samples (nr3d_march_finish_rays' outputs; total_steps is then {S, n_hit})
+static int march_count(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                       const float *t_max, const float *roi, const int32_t grid_res[3],
+                       const uint8_t *grid_binary, int type, float step_size, float max_step_size,
+                       float dt_gamma, uint32_t max_steps, int batched, const int32_t *batch_inds,
+                       uint32_t batch_data_size, int32_t *packed_info, int64_t *total_steps,
+                       void *scan_tmp, void *sample_cache, uint64_t sample_cache_bytes, int64_t *ridx_hit,
+                       int64_t *pack_infos64, void *stream) {
 	NR3D_CHECK(total_steps && scan_tmp, "ray_marching: NULL scratch pointer");
 	hipStream_t st = (hipStream_t)stream;
-	if (n_rays == 0) { NR3D_HIP_CHECK(hipMemsetAsync(total_steps, 0, sizeof(int64_t), st)); return 0; }
+	if (n_rays == 0) { NR3D_HIP_CHECK(hipMemsetAsync(total_steps, 0, (ridx_hit ? 2 : 1) * sizeof(int64_t), st)); return 0; }
 	NR3D_CHECK(rays_o && rays_d && t_min && t_max && roi && grid_binary && packed_info, "ray_marching: NULL tensor pointer");
 	NR3D_CHECK(type >= 0 && type <= 2, "ray_marching: invalid contraction type %d", type);
 	int32_t *counts = (int32_t *)scan_tmp;
@@ -644,7 +647,38 @@ extern "C" int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, con
 		else launch(occ::k_march<false, false>);
 	}
 	NR3D_LAUNCH_CHECK();
+	if (ridx_hit) {
+		NR3D_CHECK(pack_infos64 != nullptr, "ray_marching_count_finished: NULL output pointer");
+		glue::PackWriter<int32_t, 1> w{counts, nullptr, nullptr, ridx_hit, pack_infos64, packed_info};
+		return glue::compact_packs<int32_t, 1>(n_rays, w, total_steps, tiles, st);
+	}
 	return scan::pack_infos_from_counts<int32_t, int32_t>(n_rays, counts, packed_info, total_steps, tiles, st);
+}
+
+extern "C" int nr3d_ray_marching_count(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                                       const float *t_max, const float *roi, const int32_t grid_res[3],
+                                       const uint8_t *grid_binary, int type, float step_size, float max_step_size,
+                                       float dt_gamma, uint32_t max_steps, int batched, const int32_t *batch_inds,
+                                       uint32_t batch_data_size, int32_t *packed_info, int64_t *total_steps,
+                                       void *scan_tmp, void *sample_cache, uint64_t sample_cache_bytes,
+                                       void *stream) {
+	return march_count(n_rays, rays_o, rays_d, t_min, t_max, roi, grid_res, grid_binary, type, step_size, max_step_size, dt_gamma,
+	                   max_steps, batched, batch_inds, batch_data_size, packed_info, total_steps, scan_tmp, sample_cache,
+	                   sample_cache_bytes, nullptr, nullptr, stream);
+}
+
+extern "C" int nr3d_ray_marching_count_finished(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                                                const float *t_max, const float *roi, const int32_t grid_res[3],
+                                                const uint8_t *grid_binary, int type, float step_size, float max_step_size,
+                                                float dt_gamma, uint32_t max_steps, int batched, const int32_t *batch_inds,
+                                                uint32_t batch_data_size, int32_t *packed_info, int64_t *ridx_hit,
+                                                int64_t *pack_infos, int64_t *totals, void *scan_tmp, void *sample_cache,
+                                                uint64_t sample_cache_bytes, void *stream) {
+	NR3D_CHECK(n_rays == 0 || (ridx_hit && pack_infos), "ray_marching_count_finished: NULL output pointer");
+	static int64_t dummy;       // n_rays == 0: only the totals are touched
+	return march_count(n_rays, rays_o, rays_d, t_min, t_max, roi, grid_res, grid_binary, type, step_size, max_step_size, dt_gamma,
+	                   max_steps, batched, batch_inds, batch_data_size, packed_info, totals, scan_tmp, sample_cache,
+	                   sample_cache_bytes, ridx_hit ? ridx_hit : &dummy, pack_infos, stream);
 }
 
 extern "C" int nr3d_ray_marching_emit(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,

@@ -14,6 +14,7 @@
 // All integer outputs are bit-exact with the op chains they replace (same order: ascending pack, ascending sample).
 #include "common.h"
 #include "scan.h"
+#include "compact.h"
 #include "../../include/nr3d_hip.h"
 
 namespace nr3d {
@@ -33,126 +34,6 @@ __global__ __launch_bounds__(kBlock) void k_tau_to_alpha_bwd(uint64_t S, const f
                                                              float *__restrict__ g_sigma) {
 	const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
 	if (i < S) g_sigma[i] = g_alpha[i] * expf(-(sigma[i] * delta[i])) * delta[i];
-}
-
-// ------------------------------------------------------------------------------------------------
-// compaction of flagged packs: value(i) = count_i | (count_i > 0) << 40, one exclusive scan gives the new begin of
-// every pack (low 40 bits) and its rank among the non-empty ones (high bits)
-// ------------------------------------------------------------------------------------------------
-constexpr int kShift = 40;
-constexpr uint64_t kLow = (1ull << kShift) - 1ull;
-
-template <typename TCnt, int STRIDE>    // counts[i * STRIDE] (STRIDE 2: the count column of an [n, 2] pack table, offset applied by the caller)
-__device__ __forceinline__ uint64_t cval(const TCnt *__restrict__ counts, uint64_t i) {
-	const uint64_t c = (uint64_t)counts[i * STRIDE];
-	return c | ((c ? 1ull : 0ull) << kShift);
-}
-
-template <typename TCnt, int STRIDE>
-__global__ __launch_bounds__(scan::kThreads) void k_c_tile_sums(uint64_t n, const TCnt *__restrict__ counts,
-                                                                uint64_t *__restrict__ tile_sums) {
-	__shared__ uint64_t lds[4];
-	const uint64_t first = (uint64_t)blockIdx.x * scan::kTile + (uint64_t)threadIdx.x * scan::kItems;
-	uint64_t s = 0;
-#pragma unroll
-	for (int k = 0; k < scan::kItems; ++k)
-		if (first + k < n) s += cval<TCnt, STRIDE>(counts, first + k);
-	uint64_t tot;
-	scan::block_exclusive(s, tot, lds);
-	if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-
-// single workgroup: exclusive scan of the tile sums in place, totals[0] = sum of counts, totals[1] = non-empty packs
-static __global__ __launch_bounds__(scan::kThreads) void k_c_scan_tiles(uint32_t n_tiles, uint64_t *__restrict__ tile_sums,
-                                                                 int64_t *__restrict__ totals) {
-	__shared__ uint64_t lds[4];
-	uint64_t carry = 0;
-	for (uint32_t base = 0; base < n_tiles; base += scan::kThreads) {
-		const uint32_t i = base + threadIdx.x;
-		const uint64_t v = i < n_tiles ? tile_sums[i] : 0;
-		uint64_t tot;
-		const uint64_t ex = scan::block_exclusive(v, tot, lds);
-		if (i < n_tiles) tile_sums[i] = carry + ex;
-		carry += tot;
-	}
-	if (threadIdx.x == 0) { totals[0] = (int64_t)(carry & kLow); totals[1] = (int64_t)(carry >> kShift); }
-}
-
-// what a pack writes once its exclusive prefix is known
-template <typename TCnt, int STRIDE>
-struct PackWriter {
-	const TCnt *counts;
-	const int64_t *tag_in;       // optional per-pack tag carried along (e.g. the pack's ray index); NULL: the pack index itself
-	int64_t *begin_all;          // [n] new begin of EVERY pack, or NULL
-	int64_t *idx_out;            // [n_hit] index (or tag) of the non-empty packs
-	int64_t *pack_infos_out;     // [n_hit, 2]
-	__device__ __forceinline__ void operator()(uint64_t i, uint64_t ex) const {
-		const uint64_t c = (uint64_t)counts[i * STRIDE];
-		const uint64_t begin = ex & kLow, rank = ex >> kShift;
-		if (begin_all) begin_all[i] = (int64_t)begin;
-		if (c) {
-			if (idx_out) idx_out[rank] = tag_in ? tag_in[i] : (int64_t)i;
-			pack_infos_out[2 * rank] = (int64_t)begin;
-			pack_infos_out[2 * rank + 1] = (int64_t)c;
-		}
-	}
-};
-
-template <typename TCnt, int STRIDE>
-__global__ __launch_bounds__(scan::kThreads) void k_c_write(uint64_t n, const uint64_t *__restrict__ tile_prefix,
-                                                            PackWriter<TCnt, STRIDE> w) {
-	__shared__ uint64_t lds[4];
-	const uint64_t first = (uint64_t)blockIdx.x * scan::kTile + (uint64_t)threadIdx.x * scan::kItems;
-	uint64_t v[scan::kItems], s = 0;
-#pragma unroll
-	for (int k = 0; k < scan::kItems; ++k) {
-		v[k] = (first + k < n) ? cval<TCnt, STRIDE>(w.counts, first + k) : 0;
-		s += v[k];
-	}
-	uint64_t tot;
-	uint64_t run = tile_prefix[blockIdx.x] + scan::block_exclusive(s, tot, lds);
-#pragma unroll
-	for (int k = 0; k < scan::kItems; ++k) {
-		if (first + k < n) w(first + k, run);
-		run += v[k];
-	}
-}
-
-// n <= scan::kSmallMax: one workgroup, one launch
-template <typename TCnt, int STRIDE>
-__global__ __launch_bounds__(scan::kThreads) void k_c_small(uint32_t n, uint32_t per, PackWriter<TCnt, STRIDE> w,
-                                                            int64_t *__restrict__ totals) {
-	__shared__ uint64_t lds[4];
-	const uint32_t first = threadIdx.x * per;
-	uint64_t s = 0;
-	for (uint32_t k = 0; k < per; ++k)
-		if (first + k < n) s += cval<TCnt, STRIDE>(w.counts, first + k);
-	uint64_t tot;
-	uint64_t run = scan::block_exclusive(s, tot, lds);
-	for (uint32_t k = 0; k < per; ++k)
-		if (first + k < n) { w(first + k, run); run += cval<TCnt, STRIDE>(w.counts, first + k); }
-	if (threadIdx.x == 0) { totals[0] = (int64_t)(tot & kLow); totals[1] = (int64_t)(tot >> kShift); }
-}
-
-template <typename TCnt, int STRIDE>
-static int compact_packs(uint64_t n, const PackWriter<TCnt, STRIDE> &w, int64_t *totals, void *tmp, hipStream_t st) {
-	if (n == 0) {
-		NR3D_HIP_CHECK(hipMemsetAsync(totals, 0, 2 * sizeof(int64_t), st));
-		return 0;
-	}
-	if (n <= scan::kSmallMax) {
-		hipLaunchKernelGGL((k_c_small<TCnt, STRIDE>), dim3(1), dim3(scan::kThreads), 0, st, (uint32_t)n,
-		                   (uint32_t)((n + scan::kThreads - 1) / scan::kThreads), w, totals);
-		NR3D_LAUNCH_CHECK();
-		return 0;
-	}
-	const uint32_t n_tiles = (uint32_t)((n + scan::kTile - 1) / scan::kTile);
-	uint64_t *tile_sums = (uint64_t *)tmp;
-	hipLaunchKernelGGL((k_c_tile_sums<TCnt, STRIDE>), dim3(n_tiles), dim3(scan::kThreads), 0, st, n, w.counts, tile_sums);
-	hipLaunchKernelGGL(k_c_scan_tiles, dim3(1), dim3(scan::kThreads), 0, st, n_tiles, tile_sums, totals);
-	hipLaunchKernelGGL((k_c_write<TCnt, STRIDE>), dim3(n_tiles), dim3(scan::kThreads), 0, st, n, tile_sums, w);
-	NR3D_LAUNCH_CHECK();
-	return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
