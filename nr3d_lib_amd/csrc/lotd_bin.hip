@@ -1293,6 +1293,12 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	return 0;
 }
 
+// NR3D_LOTD_PAIR_SECOND=0: d(dL/dx)/dparam of pair-path metas through the 12-byte corner records (A/B, and the cross-check)
+static bool pair_second_enabled() {              // read per call: the tests compare both routes in one process
+	const char *e = getenv("NR3D_LOTD_PAIR_SECOND");
+	return !(e && e[0] == '0');
+}
+
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
@@ -1313,11 +1319,11 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	float *partial = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes);
 	float *gt = (float *)((char *)workspace + lay.rec_bytes + lay.offs_bytes + lay.plan_bytes + lay.part_bytes);
 	const bool row_major = (g_se == 1 && g_sn == (int64_t)E && E > 1) || g_half;      // half gradients always go through gt
-	// first-order gradient of an unbatched 3-D Dense/Hash meta with 2-feature pseudo levels: pair records (lotd_pair.hip)
-	const bool use_pair = !second && !forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size &&
-	                      pair_applies(meta);
+	// an unbatched 3-D Dense/Hash meta with 2-feature pseudo levels: pair records (lotd_pair.hip), first and second order
+	const bool use_pair = !forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size && pair_applies(meta) &&
+	                      !(second && !pair_second_enabled());
 	// ... with every level binned by ONE workgroup per point block, straight from the caller's dL_dy (and dL/dx on the way)
-	const bool use_all = use_pair && pair_all_applies(meta);
+	const bool use_all = use_pair && !second && pair_all_applies(meta);
 	if (fdx && !(use_all && min_level <= 0))
 		return ::nr3d::fail("LoTD::bwd_fused: the all-levels pair path does not apply (nr3d_lotd_bwd_fused_ok)");
 	if ((g_half || out_half) && !use_pair)
@@ -1356,7 +1362,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		}
 		if (use_pair) {
 			if (int rc = pair_chunk(meta, md, n, xc, gc, sn, se, min_level, max_level, work_units(), dparam,
-			                        (out_half ? 1u : 0u) | (assign_now ? 2u : 0u), rec, offs, plan_buf, partial, st))
+			                        (out_half ? 1u : 0u) | (assign_now ? 2u : 0u), rec, offs, plan_buf, partial, st, false, false,
+			                        nullptr, second ? vc : nullptr))
 				return rc;
 			continue;
 		}

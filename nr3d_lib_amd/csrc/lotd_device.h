@@ -758,7 +758,7 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
                uint32_t out_flags /* bit 0: dparam is __half; bit 1: assign (dparam uninitialised, every element of the
                plan's levels is written) */, void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st,
                bool all_levels = false /* g is the caller's dL_dy (g_half: __half), any strides */, bool g_half = false,
-               const FusedDx *fdx = nullptr);
+               const FusedDx *fdx = nullptr, const float *vin = nullptr /* second order: dL_ddLdx [n, 3] */);
 
 }  // namespace lotd
 }  // namespace nr3d

@@ -97,17 +97,39 @@ static uint32_t pair_units() {
 // Stage A
 // -------------------------------------------------------------------------------------------------
 // The four pair records of one (point, pseudo level): bucket, bucket-local indices of the two entries (hdr = i0 | i1 << 13),
-// A_f = g_f x the weights of the two dims the pair does not run along, and the pair's own weight wp
+// A_f = g_f x the weights of the two dims the pair does not run along, and the pair's own weight wp[m] (the same for the
+// four records in the first-order form): the entries get (1 - wp) A_f and wp A_f.
+// Second order (vin != NULL: d(dL/dx)/dparam, kernel_lod_hashonly_backward_input_backward_grid, lotd_hash_only.h:472-574):
+// the combined weight of corner k is W'_k = sum_d a_d s_d(k) prod_{j != d} w_j(k_j), a_d = scale_d vin_d w'_d, s = -1 / +1 for
+// the lower / upper corner.  With P the pair dim, (A, B) the other two and m their corner:
+//     W'(lower) = (1 - wp) C_m - E_m,   W'(upper) = wp C_m + E_m,     C_m = a_A s_A w_B + a_B s_B w_A,  E_m = a_P w_A w_B
+// which is the SAME record form with A_f = g_f C_m and wp'_m = wp + E_m / C_m (one more weight per record, no fifth word).
+// C_m = 0 exactly (or 1e18 times smaller than E_m) is replaced by a C of that size: the products A_f (1 - wp') and A_f wp'
+// then still give -+ g_f E_m to fp32 rounding, and what is lost of g_f C_m is below 1e-18 of it.
+__device__ __forceinline__ float pair_wp2(float wp, float Cm, float Em, float &Cuse) {
+	const float floor_c = fmaxf(1e-18f * fabsf(Em), 1e-30f);
+	Cuse = fabsf(Cm) >= floor_c ? Cm : copysignf(floor_c, Cm);
+	return wp + __fdividef(Em, Cuse);                      // reciprocal + multiply (2 ulp): 1e-7 of wp', far inside the contract
+}
+template <bool SECOND = false>
 __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t epb, uint32_t lg, const float (&xp)[3], float g0,
                                              float g1, bool smooth, uint32_t (&hdr)[4], uint32_t (&bkt)[4], float (&A)[4][2],
-                                             float &wp, uint32_t (&cell)[3], uint32_t nb, bool &valid) {
+                                             float (&wpm)[SECOND ? 4 : 1], uint32_t (&cell)[3], uint32_t nb, bool &valid,
+                                             const float *__restrict__ vin = nullptr) {
+	// wpm: one pair weight per record in the second-order form, ONE for all four in the first-order form (the first-order
+	// stage-A kernel sits exactly at its 64-register budget: four copies of the same value spilled)
 	// valid: every pair lies inside ONE bucket of the level.  True by construction for x in [0, 1] (what the Python layer
 	// clamps to, lotd.py:68); a point outside (or NaN) would index the LDS histogram / stage out of bounds -- it is dropped.
 	Cell<3> c;
 	locate<3>(xp, L, smooth, c);
 	valid = true;
+	float a[3] = {0.0f, 0.0f, 0.0f};
+	if constexpr (SECOND) {
+#pragma unroll
+		for (int d = 0; d < 3; ++d) a[d] = c.sc[d] * vin[d] * c.dw[d];
+	}
 	if (L.type == NR3D_LOD_Dense) {
-		wp = c.w[2];
+		const float wp = c.w[2];
 #pragma unroll
 		for (uint32_t m = 0; m < 4; ++m) {
 			const uint32_t bx = m & 1u, by = m >> 1;
@@ -118,11 +140,18 @@ __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t
 			valid = valid && b < nb && c.g[2] + 1u < L.res[2];
 			bkt[m] = b;
 			hdr[m] = i0 | ((i0 + 1u) << 13);
-			const float wo = (bx ? c.w[0] : 1.0f - c.w[0]) * (by ? c.w[1] : 1.0f - c.w[1]);
-			A[m][0] = g0 * wo; A[m][1] = g1 * wo;
+			const float wx = bx ? c.w[0] : 1.0f - c.w[0], wy = by ? c.w[1] : 1.0f - c.w[1];
+			const float wo = wx * wy;
+			if constexpr (!SECOND) { A[m][0] = g0 * wo; A[m][1] = g1 * wo; wpm[0] = wp; }
+			else {
+				const float Cm = __fmaf_rn(bx ? a[0] : -a[0], wy, (by ? a[1] : -a[1]) * wx);
+				float Cuse;
+				wpm[m] = pair_wp2(wp, Cm, a[2] * wo, Cuse);
+				A[m][0] = g0 * Cuse; A[m][1] = g1 * Cuse;
+			}
 		}
 	} else {
-		wp = c.w[0];
+		const float wp = c.w[0];
 		const bool pow2 = (L.size & (L.size - 1u)) == 0u;
 		const uint32_t emask = (1u << lg) - 1u;
 #pragma unroll
@@ -135,8 +164,15 @@ __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t
 			bkt[m] = e0 >> lg;                         // == e1 >> lg (plan conditions) for x in [0, 1]
 			valid = valid && (e1 >> lg) == bkt[m] && bkt[m] < nb;
 			hdr[m] = (e0 & emask) | ((e1 & emask) << 13);
-			const float wo = (by ? c.w[1] : 1.0f - c.w[1]) * (bz ? c.w[2] : 1.0f - c.w[2]);
-			A[m][0] = g0 * wo; A[m][1] = g1 * wo;
+			const float wy = by ? c.w[1] : 1.0f - c.w[1], wz = bz ? c.w[2] : 1.0f - c.w[2];
+			const float wo = wy * wz;
+			if constexpr (!SECOND) { A[m][0] = g0 * wo; A[m][1] = g1 * wo; wpm[0] = wp; }
+			else {
+				const float Cm = __fmaf_rn(by ? a[1] : -a[1], wz, (bz ? a[2] : -a[2]) * wy);
+				float Cuse;
+				wpm[m] = pair_wp2(wp, Cm, a[0] * wo, Cuse);
+				A[m][0] = g0 * Cuse; A[m][1] = g1 * Cuse;
+			}
 		}
 	}
 #pragma unroll
@@ -163,22 +199,24 @@ __device__ __forceinline__ void pair_buckets(const Lvl &L, uint32_t sh, uint32_t
 // One pseudo level of one block of kPBP points: pair records -> rank inside the bucket -> counting sort in LDS ->
 // coalesced write-out of the slot + its bucket offsets.  `hist` [nb + 1] must be zero on entry (and that visible: a
 // barrier behind the zeroing); `zero_next` (optional) is zeroed for the following call.  Four barriers (five with zero_next).
-template <int kPBP>
+template <int kPBP, bool SECOND = false>
 __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, const Lvl &L, bool active, const float (&xp)[3],
                                            float g0, float g1, uint32_t smooth, u32x4 *__restrict__ stage,
                                            uint32_t *__restrict__ hist, uint32_t *__restrict__ zero_next, uint32_t *scan_lds,
-                                           u32x4 *__restrict__ dst, uint32_t *__restrict__ ob, uint32_t ob_stride) {
+                                           u32x4 *__restrict__ dst, uint32_t *__restrict__ ob, uint32_t ob_stride,
+                                           const float *__restrict__ vin = nullptr) {
 	const uint32_t nb = plan.nb[ql];
 	const uint32_t lane = threadIdx.x & 63u;
 	uint32_t hdr[4], bkt[4], cell[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-	float A[4][2], wp = 0.0f;
+	constexpr int kW = SECOND ? 3 : 0;                   // wp[m & kW]: per record (second order) or shared
+	float A[4][2], wp[SECOND ? 4 : 1];
 #pragma unroll
-	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; }
+	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; wp[m & kW] = 0.0f; }
 	if (zero_next)
 		for (uint32_t b = threadIdx.x; b <= kPMaxNb; b += kPBP) zero_next[b] = 0;
 	if (active) {
 		bool valid;
-		pair_records(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, nb, valid);
+		pair_records<SECOND>(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, nb, valid, vin);
 		active = valid;
 	}
 
@@ -199,7 +237,7 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 #pragma unroll
 			for (int m = 0; m < 4; ++m)
 #pragma unroll
-				for (int f = 0; f < 2; ++f) { lo[m][f] = (1.0f - wp) * A[m][f]; hi[m][f] = wp * A[m][f]; }
+				for (int f = 0; f < 2; ++f) { lo[m][f] = (1.0f - wp[m & kW]) * A[m][f]; hi[m][f] = wp[m & kW] * A[m][f]; }
 #pragma unroll
 			for (int off = 1; off < 64; off <<= 1) {
 				const unsigned long long need = (1ull << off) - 1ull;
@@ -296,12 +334,11 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 
 	// ---- counting sort into the LDS staging area ----
 	if (emit) {
-		const uint32_t wpb = __float_as_uint(wp);
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
 			const uint32_t pos = hist[bkt[m]] + rank[m];
 			if (!split) {
-				stage[pos] = u32x4{hdr[m] | (3u << 26), wpb, __float_as_uint(A[m][0]), __float_as_uint(A[m][1])};
+				stage[pos] = u32x4{hdr[m] | (3u << 26), __float_as_uint(wp[m & kW]), __float_as_uint(A[m][0]), __float_as_uint(A[m][1])};
 			} else {
 				stage[pos] = u32x4{(hdr[m] & 0x1FFFu) | (1u << 26), 0u, __float_as_uint(A[m][0]), __float_as_uint(A[m][1])};
 				stage[pos + 1] = u32x4{(hdr[m] & 0x3FFE000u) | (2u << 26), 0u, __float_as_uint(Hh[m][0]), __float_as_uint(Hh[m][1])};
@@ -338,12 +375,13 @@ __device__ __forceinline__ void pair_gmax(uint32_t gbits, uint32_t *scan_lds, ui
 }
 
 // one workgroup = kPBP points x ONE pseudo level; dL_dy given feature-major (coalesced columns) or with any strides
-template <int kPBP>
+template <int kPBP, bool SECOND = false>
 __global__ __launch_bounds__(kPBP, kPBP == 768 ? 6 : 8) /* <= 64 VGPRs: two 64 KiB workgroups per CU */ void k_pair_bin(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                                    int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                    const float *__restrict__ g, int64_t g_sn, int64_t g_se,
                                                    u32x4 *__restrict__ rec, uint32_t *__restrict__ offs_g,
-                                                   uint32_t *__restrict__ gmax, DirectPlan dp) {
+                                                   uint32_t *__restrict__ gmax, DirectPlan dp, const float *__restrict__ vin_) {
+	// SECOND: d(dL/dx)/dparam for dL_ddLdx = vin_ (pair_records); else vin_ is unused
 	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[kPCap] records | hist[nb + 1]
 	__shared__ uint32_t scan_lds[kPBP / 64];
@@ -357,25 +395,53 @@ __global__ __launch_bounds__(kPBP, kPBP == 768 ? 6 : 8) /* <= 64 VGPRs: two 64 K
 	for (uint32_t b = threadIdx.x; b <= nb; b += kPBP) hist[b] = 0;
 	__syncthreads();
 	const bool active = (i < n) && ((int32_t)level <= max_level);
-	float xp[3] = {0.0f, 0.0f, 0.0f}, g0 = 0.0f, g1 = 0.0f;
+	float xp[3] = {0.0f, 0.0f, 0.0f}, vin[3] = {0.0f, 0.0f, 0.0f}, g0 = 0.0f, g1 = 0.0f;
 	if (active) {
 #pragma unroll
 		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
 		g0 = g[(int64_t)i * g_sn + (int64_t)(q * 2) * g_se];
 		g1 = g[(int64_t)i * g_sn + (int64_t)(q * 2 + 1) * g_se];
+		if constexpr (SECOND) {
+#pragma unroll
+			for (int d = 0; d < 3; ++d) vin[d] = vin_[(size_t)i * 3 + d];
+		}
 	}
-	pair_level<kPBP>(plan, ql, L, active, xp, g0, g1, smooth, stage, hist, nullptr, scan_lds,
-	                 rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk);
+	pair_level<kPBP, SECOND>(plan, ql, L, active, xp, g0, g1, smooth, stage, hist, nullptr, scan_lds,
+	                         rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk, vin);
 	if (gmax) {
-		uint32_t gbits = max(__float_as_uint(g0) & 0x7FFFFFFFu, __float_as_uint(g1) & 0x7FFFFFFFu);
-		// the levels that bypass the records (k_pair_direct) share the fixed-point scale: their columns of dL_dy count too
-		if (ql == 0 && i < n)
-			for (uint32_t e = 0; e < dp.n; ++e) {
-				const uint32_t qd = dp.qmap[e];
-				if ((int32_t)meta_level_of(md, qd) > max_level) continue;
-				gbits = max(gbits, __float_as_uint(g[(int64_t)i * g_sn + (int64_t)(qd * 2) * g_se]) & 0x7FFFFFFFu);
-				gbits = max(gbits, __float_as_uint(g[(int64_t)i * g_sn + (int64_t)(qd * 2 + 1) * g_se]) & 0x7FFFFFFFu);
+		// bound of a single update: first order |g| (a weight in [0, 1] times a gradient); second order |g| sum_d |a_d| with
+		// |a_d| <= 1.5 scale_d |vin_d| (w' <= 1.5 for the smoothstep, 1 linear)
+		uint32_t gbits;
+		if constexpr (!SECOND) {
+			gbits = max(__float_as_uint(g0) & 0x7FFFFFFFu, __float_as_uint(g1) & 0x7FFFFFFFu);
+			// the levels that bypass the records (k_pair_direct) share the fixed-point scale: their columns of dL_dy count too
+			if (ql == 0 && i < n)
+				for (uint32_t e = 0; e < dp.n; ++e) {
+					const uint32_t qd = dp.qmap[e];
+					if ((int32_t)meta_level_of(md, qd) > max_level) continue;
+					gbits = max(gbits, __float_as_uint(g[(int64_t)i * g_sn + (int64_t)(qd * 2) * g_se]) & 0x7FFFFFFFu);
+					gbits = max(gbits, __float_as_uint(g[(int64_t)i * g_sn + (int64_t)(qd * 2 + 1) * g_se]) & 0x7FFFFFFFu);
+				}
+		} else {
+			auto bound = [&](const Lvl &Lq, float ga, float gb) {
+				const float m = fmaxf(fabsf(ga), fabsf(gb)) * 1.5f *
+				                ((float)(Lq.res[0] - 2u) * fabsf(vin[0]) + (float)(Lq.res[1] - 2u) * fabsf(vin[1]) + (float)(Lq.res[2] - 2u) * fabsf(vin[2]));
+				return __float_as_uint(m) & 0x7FFFFFFFu;
+			};
+			gbits = bound(L, g0, g1);
+			if (ql == 0 && i < n) {
+				if (!active) {
+#pragma unroll
+					for (int d = 0; d < 3; ++d) vin[d] = vin_[(size_t)i * 3 + d];
+				}
+				for (uint32_t e = 0; e < dp.n; ++e) {
+					const uint32_t qd = dp.qmap[e];
+					if ((int32_t)meta_level_of(md, qd) > max_level) continue;
+					const Lvl Ld = load_level(md, meta_level_of(md, qd));
+					gbits = max(gbits, bound(Ld, g[(int64_t)i * g_sn + (int64_t)(qd * 2) * g_se], g[(int64_t)i * g_sn + (int64_t)(qd * 2 + 1) * g_se]));
+				}
 			}
+		}
 		pair_gmax<kPBP>(gbits, scan_lds, gmax);
 	}
 }
@@ -717,11 +783,12 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 // ---- levels without records: (x, dL_dy) -> LDS accumulators of one bucket, one replica per share of the points ----
 // Same per-update arithmetic as stage A + stage B ((g * w_other) * {1 - w_pair, w_pair}, fixed point at the call's
 // scale), so with FIX the result is the record path's, bit for bit, for inputs whose lanes stage A does not merge.
-template <bool FIX>
+template <bool FIX, bool SECOND = false>
 __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                                                  int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                                  const float *__restrict__ g, int64_t g_sn, int64_t g_se,
-                                                                 const uint32_t *__restrict__ gmax, float *__restrict__ partial) {
+                                                                 const uint32_t *__restrict__ gmax, float *__restrict__ partial,
+                                                                 const float *__restrict__ vin_) {
 	extern __shared__ __attribute__((aligned(16))) unsigned long long acc_raw[];   // [2][2^lg]
 	__shared__ uint32_t queue[kPAccThreads / 64][128];                              // per wave: points waiting for the full arithmetic
 	double *acc = reinterpret_cast<double *>(acc_raw);
@@ -745,14 +812,19 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 			for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
 			const float g0 = g[(int64_t)i * g_sn + (int64_t)(q * 2) * g_se], g1 = g[(int64_t)i * g_sn + (int64_t)(q * 2 + 1) * g_se];
 			uint32_t hdr[4], bkt[4], cell[3];
-			float A[4][2], wp;
+			constexpr int kW = SECOND ? 3 : 0;
+			float A[4][2], wp[SECOND ? 4 : 1], vin[3] = {0.0f, 0.0f, 0.0f};
 			bool valid;
-			pair_records(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, dp.nb[e], valid);
+			if constexpr (SECOND) {
+#pragma unroll
+				for (int d = 0; d < 3; ++d) vin[d] = vin_[(size_t)i * 3 + d];
+			}
+			pair_records<SECOND>(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, dp.nb[e], valid, vin);
 			float lo[4][2], hi[4][2];
 #pragma unroll
 			for (int m = 0; m < 4; ++m)
 #pragma unroll
-				for (int f = 0; f < 2; ++f) { lo[m][f] = (1.0f - wp) * A[m][f]; hi[m][f] = wp * A[m][f]; }
+				for (int f = 0; f < 2; ++f) { lo[m][f] = (1.0f - wp[m & kW]) * A[m][f]; hi[m][f] = wp[m & kW] * A[m][f]; }
 			// coherent inputs (samples along a ray sit in one cell of these coarse levels for many consecutive points): lanes
 			// that continue the previous lane's cell are summed into the head of their run, as in stage A -- otherwise all 64
 			// lanes of an LDS atomic hit the same eight addresses and serialise (full loop: 252 us for these two levels)
@@ -1078,7 +1150,8 @@ void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32
 int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,
                int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, uint32_t out_flags,
                void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st, bool all_levels, bool g_half,
-               const FusedDx *fdx) {
+               const FusedDx *fdx, const float *vin) {
+	// vin != NULL: second order (d(dL/dx)/dparam for dL_ddLdx = vin, [n, 3]); not with all_levels
 	PairPlan pl;
 	uint64_t ow;
 	pair_plan(meta, n, min_level, max_level, pl, ow);
@@ -1106,12 +1179,17 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
@@ -1121,8 +1199,9 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	NR3D_HIP_CHECK(hipMemsetAsync(gmax, 0, 2 * sizeof(uint32_t), st));      // gmax | ticket of k_pair_plan
 	const uint32_t bp = pair_bp();
 	const size_t bin_lds = (size_t)bp * 4 * 16 + (size_t)(nb_max + 1) * 4;     // stage | hist
-#define NR3D_PAIR_BIN(BP) hipLaunchKernelGGL(k_pair_bin<BP>, dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level, \
-	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax, dp)
+#define NR3D_PAIR_BIN(BP) if (vin) NR3D_PAIR_BIN_(BP, true); else NR3D_PAIR_BIN_(BP, false)
+#define NR3D_PAIR_BIN_(BP, SEC) hipLaunchKernelGGL((k_pair_bin<BP, SEC>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level, \
+	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax, dp, vin)
 #define NR3D_PAIR_ALL(DX, GT) hipLaunchKernelGGL((k_pair_bin_all<DX, GT>), dim3(pl.n_blk), dim3(1024), all_lds, st, pl, md, n,       \
 	meta->n_pseudo_levels, meta->n_encoded_dims, max_level, meta->interpolation_type, x, (const GT *)g, g_sn, g_se,                     \
 	fdx ? fdx->dydx : nullptr, fdx ? fdx->d_sn : 0, fdx ? fdx->d_se : 0, fdx ? fdx->dL_dx : nullptr, (u32x4 *)rec, offs, gmax)
@@ -1131,22 +1210,23 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 		if (all_levels) {
 			if (g_half) { if (fdx) NR3D_PAIR_ALL(true, __half); else NR3D_PAIR_ALL(false, __half); }
 			else        { if (fdx) NR3D_PAIR_ALL(true, float); else NR3D_PAIR_ALL(false, float); }
-		} else if (bp == 512) NR3D_PAIR_BIN(512); else if (bp == 768) NR3D_PAIR_BIN(768); else NR3D_PAIR_BIN(1024);
+		} else if (bp == 512) { NR3D_PAIR_BIN(512); } else if (bp == 768) { NR3D_PAIR_BIN(768); } else { NR3D_PAIR_BIN(1024); }
 	}
 #undef NR3D_PAIR_ALL
 #undef NR3D_PAIR_BIN
+#undef NR3D_PAIR_BIN_
 	// levels that skip the records: straight from (x, dL_dy) into LDS; needs stage A's gmax only, so it runs before stage B
 	// and its replicas are summed together with stage B's (one launch less)
 	float *dpart = partial + (size_t)(units + NB_full) * (2u << pl.lg);       // behind stage B's partial tables
 	const uint32_t nbk_direct = dp.n ? dp.bucket_base[dp.n] : 0u;
 	if (dp.n) {
 		prof::Scope ps(NR3D_PROF_LOTD_DIRECT, st);
-		if (pair_fixed())
-			hipLaunchKernelGGL(k_pair_direct<true>, dim3(dp.R, nbk_direct), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
-			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
-		else
-			hipLaunchKernelGGL(k_pair_direct<false>, dim3(dp.R, nbk_direct), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
-			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart);
+		auto direct = [&](auto kern) {
+			hipLaunchKernelGGL(kern, dim3(dp.R, nbk_direct), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, dp, md, n, max_level,
+			                   meta->interpolation_type, x, g, g_sn, g_se, gmax, dpart, vin);
+		};
+		if (vin) { if (pair_fixed()) direct(k_pair_direct<true, true>); else direct(k_pair_direct<false, true>); }
+		else     { if (pair_fixed()) direct(k_pair_direct<true, false>); else direct(k_pair_direct<false, false>); }
 	}
 	if (pl.n_pseudo == 0) {
 		if (dp.n)

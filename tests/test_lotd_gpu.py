@@ -130,6 +130,31 @@ def test_bwd_bwd_input(oracle, dev, case, bin_mode):
     assert_close(dx, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="d(dLdx)/dx")
 
 
+@pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4"])
+@pytest.mark.parametrize("coherent", [False, True])
+def test_second_order_dparam_pair_records_vs_corner_records(oracle, dev, case, coherent, bin_mode, monkeypatch):
+    """d(dL/dx)/dparam of pair-path metas: pair records carrying the second-order weights (A_f = g_f C_m, wp' = wp + E_m / C_m;
+    default) against the 12-byte corner records (NR3D_LOTD_PAIR_SECOND=0) and the fp64-accumulated oracle -- random points and
+    ray-like runs of points inside one cell (the coherent-lane merge sums the lower / upper halves of many records); a
+    direction v along one axis makes C_m or E_m vanish for whole records (the guarded division)"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=6007, seed=31)
+    if coherent:
+        base = x[::40].repeat(40, axis=0)[: x.shape[0]]
+        x = np.clip(base + np.linspace(0, 2e-4, x.shape[0], dtype=np.float32)[:, None] % 1e-3, 1e-6, 1 - 1e-6).astype(np.float32)
+        xt = torch.from_numpy(x).to(dev)
+    for vv in (v, v * np.array([1.0, 0.0, 0.0], np.float32), v * np.array([0.0, 0.0, 1.0], np.float32)):
+        vvt = torch.from_numpy(np.ascontiguousarray(vv)).to(dev)
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("NR3D_LOTD_PAIR_SECOND", mode)
+            outs[mode] = _lotd.lod_bwd_bwd_input(m, vvt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
+                                                 need_dLdinput_dinput=False)[1]
+        ref = oracle.lotd_bwd_bwd_dparam(m_ref, vv, g, x, p, accum_double=True)
+        assert torch.isfinite(outs["1"]).all()
+        assert_close(outs["1"], ref, name="d(dL/dx)/dparam, pair records", levels=m_ref)
+        assert_close(outs["0"], ref, name="d(dL/dx)/dparam, corner records", levels=m_ref)
+
+
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4", "dense_f8", "hash_npow2", "hash_4d", "dense_2d"])
 def test_hvp_level_parallel_vs_lane_serial(oracle, dev, case, monkeypatch):
     """d(dL/dx)/dx of Dense / Hash metas: one lane per (point, pseudo level) + a sum in level order (default, needs a
