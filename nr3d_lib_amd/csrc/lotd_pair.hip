@@ -109,7 +109,7 @@ static uint32_t pair_units() {
 __device__ __forceinline__ float pair_wp2(float wp, float Cm, float Em, float &Cuse) {
 	const float floor_c = fmaxf(1e-18f * fabsf(Em), 1e-30f);
 	Cuse = fabsf(Cm) >= floor_c ? Cm : copysignf(floor_c, Cm);
-	return wp + __fdividef(Em, Cuse);                      // reciprocal + multiply (2 ulp): 1e-7 of wp', far inside the contract
+	return __fmaf_rn(Em, __builtin_amdgcn_rcpf(Cuse), wp);   // v_rcp_f32 (1 ulp) + fma, no division sequence: 1e-7 of wp', far inside the contract
 }
 template <bool SECOND = false>
 __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t epb, uint32_t lg, const float (&xp)[3], float g0,
