@@ -231,6 +231,50 @@ __device__ __forceinline__ uint32_t emit_plane_line(const Lvl &L, const Cell<3> 
 	return VM ? 18u : 6u;
 }
 
+// ONE component d of a VM level's updates (records 0..3: the plane's four entries, 4..5: the line's two) -- the body of
+// emit_plane_line's loop for a compile-time d, for the three-threads-per-point form of stage A (bin_body, SPLIT == 3)
+template <int G, int DC, int NRT, typename TB>
+__device__ __forceinline__ uint32_t emit_vm_component(const Lvl &L, const Cell<3> &c, const float (&w)[8], const float (&grad)[G],
+                                                      TB grid, uint32_t foff, uint32_t (&ent)[NRT], float (&val)[NRT][G]) {
+	static_assert(NRT >= 6, "six records per VM component");
+	float pv[4][G], lv[2][G];
+	uint32_t pe[4], le[2];
+#pragma unroll
+	for (uint32_t m = 0; m < 4; ++m) {
+		uint32_t p[3], pl[3], ln[3];
+		corner_pos<3>(c, insert_zero(m, DC), p);
+		entry_vm(L, p, pl, ln);
+		pe[m] = pl[DC];
+		if (m == 0) le[0] = ln[DC];
+#pragma unroll
+		for (int f = 0; f < G; ++f) pv[m][f] = grid[pe[m] * L.F + foff + f];
+	}
+	le[1] = le[0] + 1u;
+#pragma unroll
+	for (uint32_t sl = 0; sl < 2; ++sl)
+#pragma unroll
+		for (int f = 0; f < G; ++f) lv[sl][f] = grid[le[sl] * L.F + foff + f];
+#pragma unroll
+	for (uint32_t m = 0; m < 4; ++m) {
+		ent[m] = pe[m];
+		const uint32_t k0 = insert_zero(m, DC), k1 = k0 | (1u << DC);
+#pragma unroll
+		for (int f = 0; f < G; ++f) val[m][f] = (grad[f] * w[k0]) * lv[0][f] + (grad[f] * w[k1]) * lv[1][f];
+	}
+#pragma unroll
+	for (uint32_t sl = 0; sl < 2; ++sl) {
+		ent[4 + sl] = le[sl];
+#pragma unroll
+		for (int f = 0; f < G; ++f) {
+			float acc = 0.0f;
+#pragma unroll
+			for (uint32_t m = 0; m < 4; ++m) acc += (grad[f] * w[insert_zero(m, DC) | (sl << DC)]) * pv[m][f];
+			val[4 + sl][f] = acc;
+		}
+	}
+	return 6u;
+}
+
 // The parameter updates of one (point, pseudo level): table entry + G values each.  `w[k]` is the weight of corner k
 // (first order: the interpolation weight; second order: the combined d/dx weight), `grad` = dL/dy of the G features,
 // `grid` = params + level offset, `foff` = first feature of this pseudo level inside the level's entries.
@@ -443,41 +487,49 @@ __device__ __forceinline__ uint32_t emit_forest(const ForestDev &fo, const Batch
 	return (uint32_t)NR;
 }
 
-template <int D, int G, bool SECOND, int NR, bool DH, bool FO, typename PT>
+// SPLIT: threads per point.  1: a thread forms all (up to NR) records of its point.  3 (3-D VM levels, class 24): thread
+// (component d, point) forms the six records of component d -- the one-thread form holds 24 record slots in ~130 registers and
+// its 72 KB stage allows two 256-thread workgroups per CU: 2 waves per SIMD against ~1 us gathers (profiles/
+// r03k_c4_counters_before_cp16.txt: VALU 30 %, LDS 17 %, L2 requests 55 % of their ceilings).  Threads are component-major
+// (a wave holds 64 consecutive points of ONE component), so the coherent-lane merge sees what it saw.
+template <int D, int G, bool SECOND, int NR, bool DH, bool FO, typename PT, int SPLIT = 1>
 __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                          int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                          const float *__restrict__ vin_, const float *__restrict__ g,
                                          int64_t g_sn, int64_t g_se, const PT *__restrict__ params,
                                          const Batch &ba, const ForestDev &fo, uint32_t *__restrict__ rec,
                                          uint32_t *__restrict__ offs_g) {
-	constexpr int BP = BinCfg<G, NR>::BP;
+	constexpr int BP = BinCfg<G, NR>::BP;                 // points per workgroup
+	constexpr int kThr = BP * SPLIT;                      // threads per workgroup
+	constexpr int NRT = NR / SPLIT;                       // record slots per thread
 	constexpr uint32_t cap = BinCfg<G, NR>::cap;
 	constexpr int C = 1 << D;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // stage[(1+G)*cap] | hist[nb + 1]
-	__shared__ uint64_t scan_lds[BP / 64 > 0 ? BP / 64 : 1];
+	__shared__ uint64_t scan_lds[kThr / 64 > 0 ? kThr / 64 : 1];
 	uint32_t *stage = smem;
 	uint32_t *hist = smem + (size_t)(1 + G) * cap;
 	const uint32_t blk = blockIdx.x, ql = blockIdx.y;
 	const uint32_t q = plan.qmap[ql];
 	const uint32_t nb = plan.nb[ql];
 	const uint32_t level = meta_level_of(md, q);
-	const uint32_t i = blk * BP + threadIdx.x;
+	const uint32_t comp = SPLIT == 1 ? 0u : threadIdx.x / (uint32_t)BP;      // wave-uniform (BP is a multiple of 64)
+	const uint32_t i = blk * BP + (SPLIT == 1 ? threadIdx.x : threadIdx.x % (uint32_t)BP);
 	const Lvl L = load_level(md, level);
 
-	for (uint32_t b = threadIdx.x; b <= nb; b += BP) hist[b] = 0;
+	for (uint32_t b = threadIdx.x; b <= nb; b += kThr) hist[b] = 0;
 	__syncthreads();
 
 	// batched params (one table set per batch entry): the level's entry space becomes [batch entry][entry]
 	uint32_t pbase = 0, bi = 0;
 	const bool in_batch = (i < n) && batch_base_index(ba, i, pbase, bi);
 	const bool active = in_batch && ((int32_t)level <= max_level);
-	uint32_t ent[NR], rank[NR], cell[D];
-	float val[NR][G];
+	uint32_t ent[NRT], rank[NRT], cell[D];
+	float val[NRT][G];
 	uint32_t n_rec = 0;
 #pragma unroll
 	for (int d = 0; d < D; ++d) cell[d] = 0xFFFFFFFFu;
 #pragma unroll
-	for (uint32_t r = 0; r < (uint32_t)NR; ++r)
+	for (uint32_t r = 0; r < (uint32_t)NRT; ++r)
 #pragma unroll
 		for (int f = 0; f < G; ++f) val[r][f] = 0.0f;
 	if (active) {
@@ -516,6 +568,15 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			for (int d = 0; d < 3; ++d) bk[d] = fo.block_ks[3 * (size_t)bi + d];
 			if constexpr (std::is_same<PT, float>::value)      // forests run on float tables
 				n_rec = emit_forest<G, NR>(fo, ba, L, c, w, grad, bk, bi, params, meta_cnt_of(md, q) * G, ent, val);
+		} else if constexpr (SPLIT == 3) {
+			static_assert(D == 3 && NR == 24 && !DH, "three threads per point: 3-D VM levels (record class 24)");
+			if (L.type == NR3D_LOD_VectorMatrix) {
+				const auto grid = make_tab(params + (pbase + L.off));
+				const uint32_t foff = meta_cnt_of(md, q) * G;
+				if (comp == 0) n_rec = emit_vm_component<G, 0, NRT>(L, c, w, grad, grid, foff, ent, val);
+				else if (comp == 1) n_rec = emit_vm_component<G, 1, NRT>(L, c, w, grad, grid, foff, ent, val);
+				else n_rec = emit_vm_component<G, 2, NRT>(L, c, w, grad, grid, foff, ent, val);
+			}
 		} else {
 			n_rec = emit_updates<D, G, NR, DH, SECOND>(L, c, w, grad, a, vin, make_tab(params + (pbase + L.off)), meta_cnt_of(md, q) * G, ent, val);
 		}
@@ -545,7 +606,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 				const unsigned long long need = (off == 64 ? ~0ull : ((1ull << off) - 1ull));
 				const bool take = (lane + off < 64) && (((cont >> (lane + 1)) & need) == need);
 #pragma unroll
-				for (uint32_t r = 0; r < (uint32_t)NR; ++r)
+				for (uint32_t r = 0; r < (uint32_t)NRT; ++r)
 #pragma unroll
 					for (int f = 0; f < G; ++f) {
 						const float t = __shfl_down(val[r][f], off, 64);
@@ -561,7 +622,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 		// one atomic by its first lane, the other lanes take their position from the ballot mask.
 		const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
-		for (uint32_t r = 0; r < (uint32_t)NR; ++r) {
+		for (uint32_t r = 0; r < (uint32_t)NRT; ++r) {
 			const bool has = active && r < n_rec;
 			uint32_t bkt = 0xFFFFFFFFu;
 			if (has) {
@@ -583,7 +644,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 		}
 	} else if (active) {
 #pragma unroll
-		for (uint32_t r = 0; r < (uint32_t)NR; ++r)
+		for (uint32_t r = 0; r < (uint32_t)NRT; ++r)
 			if (r < n_rec) {
 				if (!FO) ent[r] += bi * L.size;          // forest records already carry their owner block
 				rank[r] = atomicAdd(&hist[ent[r] >> plan.epb_log2], 1u);
@@ -593,7 +654,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 
 	// exclusive scan of the bucket histogram (in place); hist[nb] = total
 	uint64_t carry = 0;
-	for (uint32_t base = 0; base <= nb; base += BP) {
+	for (uint32_t base = 0; base <= nb; base += kThr) {
 		const uint32_t b = base + threadIdx.x;
 		const uint64_t v = (b < nb) ? hist[b] : 0;
 		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -603,11 +664,11 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			const uint64_t t = __shfl_up(inc, off, 64);
 			if (lane >= off) inc += t;
 		}
-		if (lane == 63 || (BP < 64 && lane == BP - 1)) scan_lds[wave] = inc;
+		if (lane == 63 || (kThr < 64 && lane == kThr - 1)) scan_lds[wave] = inc;
 		__syncthreads();
 		uint64_t wave_off = 0, tot = 0;
 #pragma unroll
-		for (int k = 0; k < (BP + 63) / 64; ++k) { const uint64_t t = scan_lds[k]; if (k < wave) wave_off += t; tot += t; }
+		for (int k = 0; k < (kThr + 63) / 64; ++k) { const uint64_t t = scan_lds[k]; if (k < wave) wave_off += t; tot += t; }
 		if (b <= nb) hist[b] = (uint32_t)(carry + wave_off + inc - v);
 		carry += tot;
 		__syncthreads();
@@ -617,7 +678,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 	if (active) {
 		const uint32_t mask = (1u << plan.epb_log2) - 1u;
 #pragma unroll
-		for (uint32_t r = 0; r < (uint32_t)NR; ++r) {
+		for (uint32_t r = 0; r < (uint32_t)NRT; ++r) {
 			if (r >= n_rec) continue;
 			const uint32_t pos = hist[ent[r] >> plan.epb_log2] + rank[r];
 			stage[pos * (1 + G)] = ent[r] & mask;
@@ -633,14 +694,14 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 	uint4 *dst = reinterpret_cast<uint4 *>(rec + ((size_t)ql * plan.n_blk + blk) * (size_t)(1 + G) * cap);
 	const uint4 *src = reinterpret_cast<const uint4 *>(stage);
 	// written once, read once by the next kernel: non-temporal, so x / dL_dy keep their L2 lines
-	for (uint32_t v4 = threadIdx.x; v4 < (total * (1 + G) + 3) / 4; v4 += BP) {   // tail: <= 3 stale words
+	for (uint32_t v4 = threadIdx.x; v4 < (total * (1 + G) + 3) / 4; v4 += kThr) {   // tail: <= 3 stale words
 		const uint4 t = src[v4];
 		uint32_t *d = reinterpret_cast<uint32_t *>(dst + v4);
 		__builtin_nontemporal_store(t.x, d); __builtin_nontemporal_store(t.y, d + 1);
 		__builtin_nontemporal_store(t.z, d + 2); __builtin_nontemporal_store(t.w, d + 3);
 	}
 	uint32_t *ob = offs_g + plan.offs_base[ql];
-	for (uint32_t b = threadIdx.x; b <= nb; b += BP) ob[(size_t)b * plan.n_blk + blk] = hist[b];
+	for (uint32_t b = threadIdx.x; b <= nb; b += kThr) ob[(size_t)b * plan.n_blk + blk] = hist[b];
 }
 
 // PT: storage type of the tables the product-type levels read their other factors from (DH instantiations read none)
@@ -652,6 +713,17 @@ __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin(BinPlan plan, const
                                                            Batch ba, uint32_t *__restrict__ rec,
                                                            uint32_t *__restrict__ offs_g) {
 	bin_body<D, G, SECOND, NR, DH, false>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, ForestDev{}, rec, offs_g);
+}
+
+// stage A of 3-D VM levels (record class 24) with three threads per point (bin_body, SPLIT == 3)
+template <int G, bool SECOND, typename PT>
+__global__ __launch_bounds__((BinCfg<G, 24>::BP * 3)) void k_bin_vm3(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                                     int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                                     const float *__restrict__ vin_, const float *__restrict__ g,
+                                                                     int64_t g_sn, int64_t g_se, const PT *__restrict__ params,
+                                                                     Batch ba, uint32_t *__restrict__ rec,
+                                                                     uint32_t *__restrict__ offs_g) {
+	bin_body<3, G, SECOND, 24, false, false, PT, 3>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, ForestDev{}, rec, offs_g);
 }
 
 // stage A for a forest of blocks (3-D): same sort, corner owners resolved through the octree; NR = 8 Dense / Hash,
@@ -1220,6 +1292,12 @@ uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, ui
 	return lay.total;
 }
 
+// NR3D_LOTD_VM_SPLIT=0: VM levels through the one-thread-per-point stage A (A/B, cross-check)
+static bool vm_split_enabled() {
+	const char *e = getenv("NR3D_LOTD_VM_SPLIT");
+	return !(e && e[0] == '0');
+}
+
 template <int D, int G, int NR, bool DH>
 static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
                         int32_t max_level, const float *xc, const float *vc, const float *gc, int64_t sn, int64_t se,
@@ -1263,6 +1341,27 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 				                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, *fo, rec, offs);
 		} else {
 			return ::nr3d::fail("LoTD forest: the binned path handles 3-D metas only");
+		}
+	} else if (D == 3 && NR == 24 && !DH && vm_split_enabled()) {
+		// class 24 in 3-D is the VM levels: three threads per point (six records each) instead of one with 18
+		if constexpr (D == 3 && NR == 24 && !DH) {
+			static bool vattr_dev[64] = {};
+			if (!vattr_dev[dev_id & 63]) {
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				vattr_dev[dev_id & 63] = true;
+			}
+			auto vm_launch = [&](auto kern, auto *tab) {
+				hipLaunchKernelGGL(kern, dim3(pl.n_blk, pl.n_pseudo), dim3(BP * 3), bin_lds, st, pl, md, n, max_level,
+				                   meta->interpolation_type, xc, vc, gc, sn, se, tab, ba, rec, offs);
+			};
+			if (p_half) {
+				if (second) vm_launch(k_bin_vm3<G, true, __half>, (const __half *)params_); else vm_launch(k_bin_vm3<G, false, __half>, (const __half *)params_);
+			} else {
+				if (second) vm_launch(k_bin_vm3<G, true, float>, params); else vm_launch(k_bin_vm3<G, false, float>, params);
+			}
 		}
 	} else if (!DH && p_half) {
 		if constexpr (!DH) {
