@@ -130,6 +130,30 @@ def test_bwd_bwd_input(oracle, dev, case, bin_mode):
     assert_close(dx, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="d(dLdx)/dx")
 
 
+@pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth"])
+@pytest.mark.parametrize("coherent", [False, True])
+def test_vm_stage_a_three_threads_per_point(oracle, dev, case, coherent, monkeypatch):
+    """dL/dparam and d(dL/dx)/dparam of metas with VM levels: stage A with three threads per point (six records each; default)
+    against one thread per point (NR3D_LOTD_VM_SPLIT=0) -- the same records, stage B may add them in another order (fp64
+    accumulators) -- and the oracle; also for runs of points inside one cell (the coherent-lane merge, per component)"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=7013, seed=41)
+    if coherent:
+        base = x[::50].repeat(50, axis=0)[: x.shape[0]]
+        x = np.clip(base + (np.linspace(0, 3e-3, x.shape[0], dtype=np.float32)[:, None] % 2e-4), 1e-6, 1 - 1e-6).astype(np.float32)
+        xt = torch.from_numpy(x).to(dev)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NR3D_LOTD_VM_SPLIT", mode)
+        dp = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)[1]
+        dp2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
+                                      need_dLdinput_dinput=False)[1]
+        outs[mode] = (dp, dp2)
+    assert_close(outs["1"][0], outs["0"][0].cpu().numpy(), rel=1e-6, name="dL/dparam, 3 threads vs 1", levels=m_ref)
+    assert_close(outs["1"][1], outs["0"][1].cpu().numpy(), rel=1e-6, name="d(dL/dx)/dparam, 3 threads vs 1", levels=m_ref)
+    assert_close(outs["1"][0], oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL/dparam", levels=m_ref)
+    assert_close(outs["1"][1], oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="d(dL/dx)/dparam", levels=m_ref)
+
+
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4"])
 @pytest.mark.parametrize("coherent", [False, True])
 def test_second_order_dparam_pair_records_vs_corner_records(oracle, dev, case, coherent, bin_mode, monkeypatch):
