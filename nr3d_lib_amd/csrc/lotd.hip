@@ -836,7 +836,7 @@ __device__ __forceinline__ bool hvp_type(uint32_t t) {
 // of the level first and hvp_from_sdot runs once per LEVEL instead of once per feature pair; and the table entries are read
 // four features per 16-byte load when the level's entries are aligned (the kernel was L2-request bound on configs[3]:
 // 625 M requests = 177 G/s, profiles/r03g_c4_counters.txt).  Same sum, other association than the per-pair form.
-template <int D, typename TB>
+template <int D, int ONLY = -1, typename TB>
 __device__ __forceinline__ void hvp_level_merged(const nr3d_lotd_meta_t *__restrict__ md, uint32_t q, uint32_t nq, uint32_t G,
                                                  const Lvl &L, const Cell<D> &c, uint32_t smooth, const float (&vin)[D], uint32_t i,
                                                  const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
@@ -852,7 +852,7 @@ __device__ __forceinline__ void hvp_level_merged(const nr3d_lotd_meta_t *__restr
 			float grad[4], v[1 << D][4];
 #pragma unroll
 			for (int j = 0; j < 4; ++j) grad[j] = dL_dy[(int64_t)i * g_sn + (int64_t)(col_begin + f0 + j) * g_se];
-			corner_values_pair<D, -1, 4>(L, grid, f_begin + f0, true, c, v);
+			corner_values_pair<D, ONLY, 4>(L, grid, f_begin + f0, true, c, v);
 #pragma unroll
 			for (uint32_t k = 0; k < (1u << D); ++k)
 #pragma unroll
@@ -864,7 +864,7 @@ __device__ __forceinline__ void hvp_level_merged(const nr3d_lotd_meta_t *__restr
 			float grad[2], v[1 << D][2];
 #pragma unroll
 			for (int j = 0; j < 2; ++j) grad[j] = dL_dy[(int64_t)i * g_sn + (int64_t)(col_begin + f0 + j) * g_se];
-			corner_values_pair<D, -1, 2>(L, grid, f_begin + f0, vec_ok && (L.F & 1u) == 0u, c, v);
+			corner_values_pair<D, ONLY, 2>(L, grid, f_begin + f0, vec_ok && (L.F & 1u) == 0u, c, v);
 #pragma unroll
 			for (uint32_t k = 0; k < (1u << D); ++k)
 #pragma unroll
@@ -874,19 +874,25 @@ __device__ __forceinline__ void hvp_level_merged(const nr3d_lotd_meta_t *__restr
 	hvp_from_sdot<D>(c, smooth, vin, sdot, acc);
 }
 
-// one lane = one point, the pseudo levels one after another (no workspace needed)
-template <int D, int G, bool DH = false, typename PT = float>
+// one lane = one point, the pseudo levels one after another (no workspace needed).
+// ONLY / level_mask / accumulate (metas with product types, 3-D): the all-types instantiation needs 156 VGPRs (4 waves per
+// SIMD against ~1 us gathers: 322 M L2 requests at 155 G/s on configs[3]); the levels are therefore served by one launch per
+// level TYPE (kOnlyDenseHash, CP, VM, the rest) through single-type instantiations, each walking the levels of its mask in
+// order and continuing the sum the previous launch left in dL_dx -- for metas whose levels are grouped by type (configs[3])
+// the association of the sum is the one-launch kernel's.
+template <int D, int G, bool DH = false, typename PT = float, int ONLY = -1>
 __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                        uint32_t n_pseudo, int32_t max_level, uint32_t smooth,
                                                        const float *__restrict__ dL_ddLdx,
                                                        const float *__restrict__ dL_dy, int64_t g_sn, int64_t g_se,
                                                        const float *__restrict__ x, const PT *__restrict__ params,
-                                                       Batch ba, bool vec_ok, float *__restrict__ dL_dx) {
+                                                       Batch ba, bool vec_ok, float *__restrict__ dL_dx,
+                                                       uint32_t level_mask, uint32_t accumulate) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= N) return;
 	float acc[D];
 #pragma unroll
-	for (int d = 0; d < D; ++d) acc[d] = 0.0f;
+	for (int d = 0; d < D; ++d) acc[d] = accumulate ? dL_dx[(size_t)i * D + d] : 0.0f;
 	uint32_t base = 0;
 	const bool ok = batch_base(ba, i, base);
 	if (ok) {
@@ -901,7 +907,7 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 				while (q + nq < n_pseudo && meta_level_of(md, q + nq) == level) ++nq;
 			const uint32_t q0 = q;
 			q += nq;
-			if ((int32_t)level > max_level) continue;
+			if ((int32_t)level > max_level || !((level_mask >> (level & 31u)) & 1u)) continue;
 			const Lvl L = load_level(md, level);
 			if (!DH && !hvp_type(L.type)) continue;
 			Cell<D> c;
@@ -910,8 +916,8 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx(const nr3d_lotd_meta_t *_
 			if constexpr (DH)
 				hvp_level<D, G, DH>(md, q0, L, c, smooth, vin, i, dL_dy, g_sn, g_se, grid, vec_ok, acc);
 			else
-				hvp_level_merged<D>(md, q0, nq, G, L, c, smooth, vin, i, dL_dy, g_sn, g_se, grid, vec_ok,
-				                    (tab_addr(grid) % (4u * tab_elt(grid))) == 0u, acc);
+				hvp_level_merged<D, ONLY>(md, q0, nq, G, L, c, smooth, vin, i, dL_dy, g_sn, g_se, grid, vec_ok,
+				                          (tab_addr(grid) % (4u * tab_elt(grid))) == 0u, acc);
 		}
 	}
 #pragma unroll
@@ -1939,13 +1945,44 @@ static int launch_bwd_bwd_dx_t(const nr3d_lotd_meta_t *meta, const void *meta_de
 		NR3D_LAUNCH_CHECK();
 		return 0;
 	}
+	// level groups by type (3-D metas with product types; NR3D_LOTD_HVP_SPLIT=0: one launch): 0 Dense / Hash, 2 VM, 3 VecZMatXoY;
+	// the other types have no d(dL/dx)/dx term (hvp_type) and get no launch
+	uint32_t grp[4] = {0, 0, 0, 0};
+	const char *hs_env = getenv("NR3D_LOTD_HVP_SPLIT");
+	const bool by_type = !dh && meta->n_dims_to_encode == 3 && meta->n_levels <= 32u && !(hs_env && hs_env[0] == '0');
+	for (uint32_t l = 0; l < meta->n_levels && l < 32u; ++l) {
+		const uint32_t t = meta->levels[l].type;
+		const int k = (t == NR3D_LOD_Dense || t == NR3D_LOD_Hash) ? 0 : t == NR3D_LOD_VectorMatrix ? 2 : t == NR3D_LOD_VecZMatXoY ? 3 : -1;
+		if (k >= 0) grp[k] |= 1u << l;
+	}
+	if (!by_type) grp[3] = 0xFFFFFFFFu;
 	DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
-		auto launch = [&](auto kern) {
+		uint32_t launched = 0;
+		auto launch = [&](auto kern, uint32_t mask) {
 			hipLaunchKernelGGL(kern, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, md, N,
 			                   meta->n_pseudo_levels, max_level, meta->interpolation_type, (const float *)dL_ddLdx,
-			                   (const float *)dL_dy, g_sn, g_se, (const float *)x, (const PT *)params, ba, vec_ok, (float *)dL_dx);
+			                   (const float *)dL_dy, g_sn, g_se, (const float *)x, (const PT *)params, ba, vec_ok, (float *)dL_dx,
+			                   mask, launched);
+			launched = 1u;
 		};
-		if (dh) launch(k_bwd_bwd_dx<D, G, true, PT>); else launch(k_bwd_bwd_dx<D, G, false, PT>);
+		if (dh) launch(k_bwd_bwd_dx<D, G, true, PT>, 0xFFFFFFFFu);
+		else if (!by_type) launch(k_bwd_bwd_dx<D, G, false, PT>, 0xFFFFFFFFu);
+		else if constexpr (D == 3) {
+			// in the order of each group's first level (levels grouped by type keep the one-launch association)
+			uint32_t left[4] = {grp[0], grp[1], grp[2], grp[3]};
+			for (int n_done = 0; n_done < 4; ++n_done) {
+				int best = -1;
+				for (int k = 0; k < 4; ++k)
+					if (left[k] && (best < 0 || __builtin_ctz(left[k]) < __builtin_ctz(left[best]))) best = k;
+				if (best < 0) break;
+				const uint32_t mask = left[best];
+				left[best] = 0;
+				if (best == 0) launch(k_bwd_bwd_dx<3, G, false, PT, kOnlyDenseHash>, mask);
+				else if (best == 2) launch(k_bwd_bwd_dx<3, G, false, PT, NR3D_LOD_VectorMatrix>, mask);
+				else launch(k_bwd_bwd_dx<3, G, false, PT>, mask);
+			}
+			if (!launched) launch(k_bwd_bwd_dx<3, G, false, PT>, 0u);       // no level at all: dL_dx = 0
+		}
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;
