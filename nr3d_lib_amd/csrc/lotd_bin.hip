@@ -231,12 +231,20 @@ __device__ __forceinline__ uint32_t emit_plane_line(const Lvl &L, const Cell<3> 
 	return VM ? 18u : 6u;
 }
 
-// ONE component d of a VM level's updates (records 0..3: the plane's four entries, 4..5: the line's two) -- the body of
-// emit_plane_line's loop for a compile-time d, for the three-threads-per-point form of stage A (bin_body, SPLIT == 3)
-template <int G, int DC, int NRT, typename TB>
-__device__ __forceinline__ uint32_t emit_vm_component(const Lvl &L, const Cell<3> &c, const float (&w)[8], const float (&grad)[G],
+// ONE component d of a VM level's updates (records 0..3: the plane's four entries, 4..5: the line's two), for the
+// three-threads-per-point form of stage A (bin_body, SPLIT == 3), in SEPARABLE form: with (A, B) the plane's dims, m its corner,
+// wo_m = w_A w_B, LI = lerp_d(line), PI = sum_m wo_m plane_m:
+//     first order    plane_m += g wo_m LI                              line_s += g w_d(s) PI
+//     second order   plane_m += g (wo_m a_d (line_1 - line_0) + C_m LI) line_s += g (a_d sgn(s) PI + w_d(s) PC)
+//                    C_m = a_A sgn_A w_B + a_B sgn_B w_A,  PC = sum_m C_m plane_m,  a = scale w' v
+// -- what emit_plane_line sums corner by corner from the eight corner weights ((g w_k0) line_0 + (g w_k1) line_1, ...): the
+// same polynomial, other association, a third of the arithmetic and no corner-weight array (stage A of the VM levels was
+// half VALU after the split, profiles/r03m_c4_counters.txt).
+template <int G, int DC, int NRT, bool SECOND, typename TB>
+__device__ __forceinline__ uint32_t emit_vm_component(const Lvl &L, const Cell<3> &c, const float (&a)[3], const float (&grad)[G],
                                                       TB grid, uint32_t foff, uint32_t (&ent)[NRT], float (&val)[NRT][G]) {
 	static_assert(NRT >= 6, "six records per VM component");
+	constexpr int DA = DC == 0 ? 1 : 0, DB = DC == 2 ? 1 : 2;          // the plane's dims, ascending: bit 0 / bit 1 of m
 	float pv[4][G], lv[2][G];
 	uint32_t pe[4], le[2];
 #pragma unroll
@@ -254,24 +262,38 @@ __device__ __forceinline__ uint32_t emit_vm_component(const Lvl &L, const Cell<3
 	for (uint32_t sl = 0; sl < 2; ++sl)
 #pragma unroll
 		for (int f = 0; f < G; ++f) lv[sl][f] = grid[le[sl] * L.F + foff + f];
+	const float wd1 = c.w[DC], wd0 = 1.0f - wd1;
+	float wo[4], Cm[4];
 #pragma unroll
 	for (uint32_t m = 0; m < 4; ++m) {
-		ent[m] = pe[m];
-		const uint32_t k0 = insert_zero(m, DC), k1 = k0 | (1u << DC);
-#pragma unroll
-		for (int f = 0; f < G; ++f) val[m][f] = (grad[f] * w[k0]) * lv[0][f] + (grad[f] * w[k1]) * lv[1][f];
+		const float wa = (m & 1u) ? c.w[DA] : 1.0f - c.w[DA], wb = (m & 2u) ? c.w[DB] : 1.0f - c.w[DB];
+		wo[m] = wa * wb;
+		Cm[m] = SECOND ? __fmaf_rn((m & 1u) ? a[DA] : -a[DA], wb, ((m & 2u) ? a[DB] : -a[DB]) * wa) : 0.0f;
 	}
 #pragma unroll
-	for (uint32_t sl = 0; sl < 2; ++sl) {
-		ent[4 + sl] = le[sl];
+	for (int f = 0; f < G; ++f) {
+		const float LI = __fmaf_rn(wd1, lv[1][f], wd0 * lv[0][f]);
+		float PI = 0.0f, PC = 0.0f;
 #pragma unroll
-		for (int f = 0; f < G; ++f) {
-			float acc = 0.0f;
+		for (uint32_t m = 0; m < 4; ++m) { PI = __fmaf_rn(wo[m], pv[m][f], PI); if (SECOND) PC = __fmaf_rn(Cm[m], pv[m][f], PC); }
+		if (!SECOND) {
+			const float gl = grad[f] * LI, gp = grad[f] * PI;
 #pragma unroll
-			for (uint32_t m = 0; m < 4; ++m) acc += (grad[f] * w[insert_zero(m, DC) | (sl << DC)]) * pv[m][f];
-			val[4 + sl][f] = acc;
+			for (uint32_t m = 0; m < 4; ++m) val[m][f] = gl * wo[m];
+			val[4][f] = gp * wd0;
+			val[5][f] = gp * wd1;
+		} else {
+			const float dl = a[DC] * (lv[1][f] - lv[0][f]);
+#pragma unroll
+			for (uint32_t m = 0; m < 4; ++m) val[m][f] = grad[f] * __fmaf_rn(wo[m], dl, Cm[m] * LI);
+			const float ap = a[DC] * PI;
+			val[4][f] = grad[f] * __fmaf_rn(wd0, PC, -ap);
+			val[5][f] = grad[f] * __fmaf_rn(wd1, PC, ap);
 		}
 	}
+#pragma unroll
+	for (uint32_t m = 0; m < 4; ++m) ent[m] = pe[m];
+	ent[4] = le[0]; ent[5] = le[1];
 	return 6u;
 }
 
@@ -550,6 +572,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 		}
 #pragma unroll
 		for (uint32_t k = 0; k < (uint32_t)C; ++k) {
+			if constexpr (SPLIT == 3) { w[k] = 0.0f; continue; }          // the separable VM emitter takes the Cell itself
 			if (!SECOND) {
 				w[k] = corner_weight<D>(c, k);
 			} else {
@@ -573,9 +596,9 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			if (L.type == NR3D_LOD_VectorMatrix) {
 				const auto grid = make_tab(params + (pbase + L.off));
 				const uint32_t foff = meta_cnt_of(md, q) * G;
-				if (comp == 0) n_rec = emit_vm_component<G, 0, NRT>(L, c, w, grad, grid, foff, ent, val);
-				else if (comp == 1) n_rec = emit_vm_component<G, 1, NRT>(L, c, w, grad, grid, foff, ent, val);
-				else n_rec = emit_vm_component<G, 2, NRT>(L, c, w, grad, grid, foff, ent, val);
+				if (comp == 0) n_rec = emit_vm_component<G, 0, NRT, SECOND>(L, c, a, grad, grid, foff, ent, val);
+				else if (comp == 1) n_rec = emit_vm_component<G, 1, NRT, SECOND>(L, c, a, grad, grid, foff, ent, val);
+				else n_rec = emit_vm_component<G, 2, NRT, SECOND>(L, c, a, grad, grid, foff, ent, val);
 			}
 		} else {
 			n_rec = emit_updates<D, G, NR, DH, SECOND>(L, c, w, grad, a, vin, make_tab(params + (pbase + L.off)), meta_cnt_of(md, q) * G, ent, val);
