@@ -111,7 +111,7 @@ int nr3d_lotd_meta_regroup(const nr3d_lotd_meta_t *meta, uint32_t width, uint32_
  * Strides are in ELEMENTS.  x is [N, D] contiguous; params is 1-D contiguous.
  * param_dtype: NR3D_F32, or NR3D_F16 -- `params` are __half tables, read as half and used as float (the reference's
  * (float, half, float) dispatch, lotd_encoding.h:1501-1504) by every kernel that reads table entries: every meta, batched
- * tables included; a half table gives bit for bit what its fp32 copy gives.  With NR3D_F16 nr3d_lotd_fwd writes y as __half
+ * tables and (ABI 3) the forest entry points included; a half table gives bit for bit what its fp32 copy gives.  With NR3D_F16 nr3d_lotd_fwd writes y as __half
  * (the fp32 result rounded once); dy_dx, dL_dx and -- except through nr3d_lotd_bwd_dparam_typed -- dL_dparam stay float, and
  * so does dL_dy (the caller widens a half dL_dy; the pair-record path below reads it as it is).
  */
@@ -270,7 +270,8 @@ int nr3d_forest_identify(const nr3d_forest_meta_t *forest, uint64_t n, const int
  * (the reference's forest kernels handle no others).  y[i*y_sn + e*y_se]; dy_dx[i*d_sn + e*d_se + d] or NULL
  * (strides in elements, as for nr3d_lotd_fwd; feature-major storage y_sn = 1, y_se = N makes the stores coalesced). */
 int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
-                         uint32_t n_points, const float *x, const float *params, const int64_t *block_inds,
+                         uint32_t n_points, const float *x, const void *params, int param_dtype /* NR3D_F32 | NR3D_F16 */,
+                         const int64_t *block_inds,
                          const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level, float *y,
                          int64_t y_sn, int64_t y_se, float *dy_dx, int64_t d_sn, int64_t d_se, void *stream);
 
@@ -286,7 +287,7 @@ uint64_t nr3d_lotd_forest_dparam_workspace_bytes(const nr3d_lotd_meta_t *meta, u
  * (or when the path does not apply) fp32 hardware atomics. */
 int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                                 uint32_t n_points, const float *dL_ddLdx, const float *dL_dy, const float *x,
-                                const float *params, const int64_t *block_inds, const int64_t *block_offsets,
+                                const void *params, int param_dtype, const int64_t *block_inds, const int64_t *block_offsets,
                                 uint32_t batch_data_size, int32_t max_level, float *dL_dparam, void *workspace,
                                 uint64_t workspace_bytes, void *stream);
 
@@ -295,7 +296,7 @@ int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_d
  * nr3d_lotd_bwd_dx / nr3d_lotd_bwd_bwd_ddLdy.) */
 int nr3d_lotd_forest_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                                 uint32_t n_points, const float *dL_ddLdx, const float *dL_dy, const float *x,
-                                const float *params, const int64_t *block_inds, const int64_t *block_offsets,
+                                const void *params, int param_dtype, const int64_t *block_inds, const int64_t *block_offsets,
                                 uint32_t batch_data_size, int32_t max_level, float *dL_dx, void *stream);
 
 /* =================================================================================================

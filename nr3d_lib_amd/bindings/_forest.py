@@ -128,7 +128,7 @@ def lod_fwd(metas, input, params, batch_inds=None, batch_offsets=None, batch_dat
     E, dev = m.n_encoded_dims, input.device
     if max_level <= -1:
         return (torch.zeros((N, E), dtype=params.dtype, device=dev), torch.zeros((N, E * 3), dtype=input.dtype, device=dev))
-    x32, p32 = _lotd._f32c(input.detach()), _lotd._p32(params)
+    x32, (p32, pcode) = _lotd._f32c(input.detach()), _lotd._ptab(params)
     with H.on_device(dev):
         # feature-major storage behind [N, E] / [N, E, 3] views, like the single-block path: coalesced stores
         y = H.empty((E, N), dtype=torch.float32, device=dev).t()
@@ -141,7 +141,7 @@ def lod_fwd(metas, input, params, batch_inds=None, batch_offsets=None, batch_dat
                 dy_dx, dsn, dse = H.empty((N, E * 3), dtype=torch.float32, device=dev), E * 3, 3
         c = fo._c()
         H.check(H.lib().nr3d_lotd_forest_fwd(
-            C.byref(m._cmeta()), H.ptr(m._dev(dev)), C.byref(c), H.u32(N), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
+            C.byref(m._cmeta()), H.ptr(m._dev(dev)), C.byref(c), H.u32(N), H.ptr(x32), H.ptr(p32), C.c_int(pcode), H.ptr(batch_inds),
             H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(y), H.i64(y.stride(0)), H.i64(y.stride(1)),
             H.ptr(dy_dx), H.i64(dsn), H.i64(dse), H.stream_of(input)))
     return _lotd._cast(y, params.dtype), _lotd._cast(dy_dx, input.dtype)
@@ -178,11 +178,11 @@ def lod_bwd(metas, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offs
                 C.byref(m._cmeta()), H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(g32), H.i64(E), H.i64(1),
                 H.ptr(j), H.i64(jsn), H.i64(jse), H.ptr(dL_dx), None, st))
         if need_param_grad:
-            x32, p32 = _lotd._f32c(input.detach()), _lotd._p32(params)
+            x32, (p32, pcode) = _lotd._f32c(input.detach()), _lotd._ptab(params)
             c = fo._c()
             ws, wsb = _workspace(m, fo, N, dev)
             H.check(H.lib().nr3d_lotd_forest_bwd_dparam(
-                C.byref(m._cmeta()), H.ptr(m._dev(dev)), C.byref(c), H.u32(N), None, H.ptr(g32), H.ptr(x32), H.ptr(p32),
+                C.byref(m._cmeta()), H.ptr(m._dev(dev)), C.byref(c), H.u32(N), None, H.ptr(g32), H.ptr(x32), H.ptr(p32), C.c_int(pcode),
                 H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparam), H.ptr(ws),
                 C.c_uint64(wsb), st))
     return _lotd._cast(dL_dx, input.dtype), _lotd._cast(dL_dparam, params.dtype)
@@ -220,7 +220,7 @@ def lod_bwd_bwd_input(metas, dL_ddLdx, dL_dy, input, params, dy_dx=None, batch_i
             return _lotd._cast(dL_ddLdy, dL_dy.dtype), _lotd._cast(dL_dparams, params.dtype), _lotd._cast(dL_dx, input.dtype)
         st = H.stream_of(input)
         v32, g32 = _lotd._f32c(dL_ddLdx.detach()), _lotd._f32c(dL_dy.detach()).contiguous()
-        x32, p32 = _lotd._f32c(input.detach()), _lotd._p32(params)
+        x32, (p32, pcode) = _lotd._f32c(input.detach()), _lotd._ptab(params)
         cm, md, c = C.byref(m._cmeta()), H.ptr(m._dev(dev)), fo._c()
         if need_dLdy:
             j, jsn, jse = _lotd._jac_view(dy_dx.detach(), N, E, 3)
@@ -229,12 +229,12 @@ def lod_bwd_bwd_input(metas, dL_ddLdx, dL_dy, input, params, dy_dx=None, batch_i
                 H.ptr(dL_ddLdy), H.i64(E), H.i64(1), st))
         if need_dx:
             H.check(H.lib().nr3d_lotd_forest_bwd_bwd_dx(
-                cm, md, C.byref(c), H.u32(N), H.ptr(v32), H.ptr(g32), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
+                cm, md, C.byref(c), H.u32(N), H.ptr(v32), H.ptr(g32), H.ptr(x32), H.ptr(p32), C.c_int(pcode), H.ptr(batch_inds),
                 H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dx), st))
         if need_dp:
             ws, wsb = _workspace(m, fo, N, dev)
             H.check(H.lib().nr3d_lotd_forest_bwd_dparam(
-                cm, md, C.byref(c), H.u32(N), H.ptr(v32), H.ptr(g32), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds),
+                cm, md, C.byref(c), H.u32(N), H.ptr(v32), H.ptr(g32), H.ptr(x32), H.ptr(p32), C.c_int(pcode), H.ptr(batch_inds),
                 H.ptr(batch_offsets), H.u32(bds), H.i32(max_level), H.ptr(dL_dparams), H.ptr(ws), C.c_uint64(wsb), st))
     return _lotd._cast(dL_ddLdy, dL_dy.dtype), _lotd._cast(dL_dparams, params.dtype), _lotd._cast(dL_dx, input.dtype)
 

@@ -72,7 +72,7 @@ extern "C" int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, i
 }
 
 extern "C" const char *nr3d_last_error(void) { return err_buf(); }
-extern "C" int nr3d_abi_version(void) { return 2; }
+extern "C" int nr3d_abi_version(void) { return 3; }
 
 extern "C" int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, const int32_t *res_multidim,
                                      const int32_t *n_feats, const int32_t *types, uint32_t hashmap_size,

@@ -440,10 +440,10 @@ __device__ __forceinline__ uint32_t emit_updates(const Lvl &L, const Cell<D> &c,
 // multiply by the other factors read from the owner's tables -- the per-corner arithmetic of corner_scatter()
 // (lotd_device.h; reference lotd_forest.h:415-636), one record per (corner, table entry): Dense / Hash 8, CP / NPlaneMul 24,
 // VM 48.
-template <int G, int NR>
+template <int G, int NR, typename PT>
 __device__ __forceinline__ uint32_t emit_forest(const ForestDev &fo, const Batch &ba, const Lvl &L, const Cell<3> &c,
                                                 const float (&w)[8], const float (&grad)[G], const int (&bk)[3], uint32_t bi,
-                                                const float *__restrict__ params, uint32_t foff, uint32_t (&ent)[NR],
+                                                const PT *__restrict__ params, uint32_t foff, uint32_t (&ent)[NR],
                                                 float (&val)[NR][G]) {
 	constexpr uint32_t E = NR / 8;                     // records per corner of this class
 	const uint32_t need = rec_count(L.type, 3, true) / 8u;
@@ -465,7 +465,7 @@ __device__ __forceinline__ uint32_t emit_forest(const ForestDev &fo, const Batch
 			continue;
 		}
 		if constexpr (E >= 2) {
-			const float *__restrict__ grid = params + ((ba.offsets ? (uint32_t)ba.offsets[ok ? owner : bi] : (ok ? owner : bi) * ba.n_params) + L.off);
+			const auto grid = make_tab(params + ((ba.offsets ? (uint32_t)ba.offsets[ok ? owner : bi] : (ok ? owner : bi) * ba.n_params) + L.off));
 			if constexpr (E >= 3) {
 				if (L.type == NR3D_LOD_CP || L.type == NR3D_LOD_NPlaneMul) {
 					uint32_t idx[3];
@@ -589,8 +589,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			int bk[3];
 #pragma unroll
 			for (int d = 0; d < 3; ++d) bk[d] = fo.block_ks[3 * (size_t)bi + d];
-			if constexpr (std::is_same<PT, float>::value)      // forests run on float tables
-				n_rec = emit_forest<G, NR>(fo, ba, L, c, w, grad, bk, bi, params, meta_cnt_of(md, q) * G, ent, val);
+			n_rec = emit_forest<G, NR>(fo, ba, L, c, w, grad, bk, bi, params, meta_cnt_of(md, q) * G, ent, val);
 		} else if constexpr (SPLIT == 3) {
 			static_assert(D == 3 && NR == 24 && !DH, "three threads per point: 3-D VM levels (record class 24)");
 			if (L.type == NR3D_LOD_VectorMatrix) {
@@ -751,12 +750,12 @@ __global__ __launch_bounds__((BinCfg<G, 24>::BP * 3)) void k_bin_vm3(BinPlan pla
 
 // stage A for a forest of blocks (3-D): same sort, corner owners resolved through the octree; NR = 8 Dense / Hash,
 // 24 CP / NPlaneMul, 48 VM
-template <int G, bool SECOND, int NR>
+template <int G, bool SECOND, int NR, typename PT = float>
 __global__ __launch_bounds__((BinCfg<G, NR>::BP)) void k_bin_forest(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md,
                                                                    uint32_t n, int32_t max_level, uint32_t smooth,
                                                                    const float *__restrict__ x, const float *__restrict__ vin_,
                                                                    const float *__restrict__ g, int64_t g_sn, int64_t g_se,
-                                                                   const float *__restrict__ params, Batch ba, ForestDev fo,
+                                                                   const PT *__restrict__ params, Batch ba, ForestDev fo,
                                                                    uint32_t *__restrict__ rec, uint32_t *__restrict__ offs_g) {
 	bin_body<3, G, SECOND, NR, true, true>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, fo, rec, offs_g);
 }
@@ -1356,12 +1355,25 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
 				fattr_dev[dev_id & 63] = true;
 			}
-			if (second)
-				hipLaunchKernelGGL((k_bin_forest<G, true, NR>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
-				                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, *fo, rec, offs);
-			else
-				hipLaunchKernelGGL((k_bin_forest<G, false, NR>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
-				                   meta->interpolation_type, xc, vc, gc, sn, se, params, ba, *fo, rec, offs);
+			auto forest_launch = [&](auto kern, auto *tab) {
+				hipLaunchKernelGGL(kern, dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level,
+				                   meta->interpolation_type, xc, vc, gc, sn, se, tab, ba, *fo, rec, offs);
+			};
+			bool done = false;
+			if constexpr (NR != 8) {                       // product types read the owner block's tables; Dense / Hash read none
+				if (p_half) {
+					static bool hattr_dev[64] = {};
+					if (!hattr_dev[dev_id & 63]) {
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, true, NR, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false, NR, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+						hattr_dev[dev_id & 63] = true;
+					}
+					if (second) forest_launch(k_bin_forest<G, true, NR, __half>, (const __half *)params_);
+					else forest_launch(k_bin_forest<G, false, NR, __half>, (const __half *)params_);
+					done = true;
+				}
+			}
+			if (!done) { if (second) forest_launch(k_bin_forest<G, true, NR>, params); else forest_launch(k_bin_forest<G, false, NR>, params); }
 		} else {
 			return ::nr3d::fail("LoTD forest: the binned path handles 3-D metas only");
 		}
@@ -1427,7 +1439,6 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
                   hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level, bool g_half, bool out_half, bool assign,
                   const FusedDx *fdx, bool p_half) {
 	handled = false;
-	if (p_half && forest) return ::nr3d::fail("LoTD forest: the binned path reads float tables");
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
 	if (!workspace || !binnable(meta, forest != nullptr) || !layout(meta, nc, n_batches, lay, forest != nullptr)) return 0;

@@ -32,10 +32,11 @@ __global__ __launch_bounds__(256) void k_forest_identify(ForestDev fo, uint64_t 
 // =============================================================================================
 // forward (+ dy/dx): kernel_lod_forest, lotd_forest.h:158-333; forest_fwd_n_linear :33-156
 // =============================================================================================
-template <int G, bool DYDX>
+// PT: storage type of the tables (float, or __half read as float -- lotd_device.h, HalfTab); y and dy/dx are float
+template <int G, bool DYDX, typename PT>
 __global__ __launch_bounds__(kBlock) void k_forest_fwd(const nr3d_lotd_meta_t *__restrict__ md, ForestDev fo, uint32_t N,
                                                        int32_t max_level, uint32_t smooth,
-                                                       const float *__restrict__ x, const float *__restrict__ params,
+                                                       const float *__restrict__ x, const PT *__restrict__ params,
                                                        Batch ba, uint32_t pair_ok, float *__restrict__ y, int64_t y_sn, int64_t y_se,
                                                        float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_fwd(const nr3d_lotd_meta_t *_
 					Cell<3> cs = c;
 #pragma unroll
 					for (int d = 0; d < 3; ++d) cs.g[d] -= 1u;
-					const float *grid = params + (b.offset + L.off);
+					const auto grid = make_tab(params + (b.offset + L.off));
 					if (L.type == NR3D_LOD_Dense) gather_pairs<3, true>(L, cs, grid, v);
 					else gather_pairs<3, false>(L, cs, grid, v);
 				}
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_fwd(const nr3d_lotd_meta_t *_
 					uint32_t p[3], pl[3], off;
 					corner_pos<3>(c, k, p);
 					if (resolve(fo, ba, L, b, p, pl, off)) {
-						corner_value<3, G>(L, params + (off + L.off), foff0, pl, v[k]);
+						corner_value<3, G>(L, make_tab(params + (off + L.off)), foff0, pl, v[k]);
 					} else {
 #pragma unroll
 						for (int f = 0; f < G; ++f) v[k][f] = 0.0f;
@@ -126,12 +127,12 @@ __global__ __launch_bounds__(kBlock) void k_forest_fwd(const nr3d_lotd_meta_t *_
 // (SECOND == true; kernel_lod_forest_backward_input_backward_grid :636-773).  As in lotd.hip, the D signed
 // face contributions that land on one corner are summed before the scatter (the scatter is linear in the weight).
 // =============================================================================================
-template <int G, bool SECOND>
+template <int G, bool SECOND, typename PT>
 __global__ __launch_bounds__(kBlock) void k_forest_bwd_dparam(const nr3d_lotd_meta_t *__restrict__ md, ForestDev fo,
                                                               uint32_t N, uint32_t E, int32_t max_level, uint32_t smooth,
                                                               const float *__restrict__ dL_ddLdx,
                                                               const float *__restrict__ dL_dy, const float *__restrict__ x,
-                                                              const float *__restrict__ params, Batch ba,
+                                                              const PT *__restrict__ params, Batch ba,
                                                               float *__restrict__ dparam) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= N) return;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_bwd_dparam(const nr3d_lotd_me
 		uint32_t p[3], pl[3], off;
 		corner_pos<3>(c, k, p);
 		if (!resolve(fo, ba, L, b, p, pl, off)) continue;
-		corner_scatter<3, G>(L, params + (off + L.off), dparam + (off + L.off), foff0, pl, grad, w);
+		corner_scatter<3, G>(L, make_tab(params + (off + L.off)), dparam + (off + L.off), foff0, pl, grad, w);
 	}
 }
 
@@ -177,12 +178,12 @@ __global__ __launch_bounds__(kBlock) void k_forest_bwd_dparam(const nr3d_lotd_me
 // d(dL/dx)/dx (kernel_lod_forest_backward_input_backward_input :929-1065): Dense / VectorMatrix / Hash.
 // One lane owns all pseudo levels of its point (no atomics on dL_dx); arithmetic as k_bwd_bwd_dx in lotd.hip.
 // =============================================================================================
-template <int G>
+template <int G, typename PT>
 __global__ __launch_bounds__(kBlock) void k_forest_bwd_bwd_dx(const nr3d_lotd_meta_t *__restrict__ md, ForestDev fo,
                                                               uint32_t N, uint32_t E, uint32_t n_pseudo, int32_t max_level,
                                                               uint32_t smooth, const float *__restrict__ dL_ddLdx,
                                                               const float *__restrict__ dL_dy, const float *__restrict__ x,
-                                                              const float *__restrict__ params, Batch ba,
+                                                              const PT *__restrict__ params, Batch ba,
                                                               float *__restrict__ dL_dx) {
 	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
 	if (i >= N) return;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_forest_bwd_bwd_dx(const nr3d_lotd_me
 				for (uint32_t k = 0; k < 8; ++k) {
 					uint32_t p[3], pl[3], off;
 					corner_pos<3>(c, k, p);
-					sdot[k] = resolve(fo, ba, L, b, p, pl, off) ? corner_dot<3, 2>(L, params + (off + L.off), foff, pl, grad, 1.0f) : 0.0f;
+					sdot[k] = resolve(fo, ba, L, b, p, pl, off) ? corner_dot<3, 2>(L, make_tab(params + (off + L.off)), foff, pl, grad, 1.0f) : 0.0f;
 				}
 #pragma unroll
 				for (int d = 0; d < 3; ++d) {
@@ -285,24 +286,26 @@ extern "C" int nr3d_forest_identify(const nr3d_forest_meta_t *forest, uint64_t n
 }
 
 extern "C" int nr3d_lotd_forest_fwd(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
-                                    uint32_t N, const float *x, const float *params, const int64_t *block_inds,
+                                    uint32_t N, const float *x, const void *params, int param_dtype, const int64_t *block_inds,
                                     const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level, float *y,
                                     int64_t y_sn, int64_t y_se, float *dy_dx, int64_t d_sn, int64_t d_se, void *stream) {
 	if (int rc = check_forest(meta, meta_dev, forest)) return rc;
+	NR3D_CHECK(param_dtype == NR3D_F32 || param_dtype == NR3D_F16, "LoTD forest: params must be f32 or f16");
 	if (N == 0) return 0;
 	NR3D_CHECK(x && params && y, "LoTD forest::fwd: NULL tensor pointer");
+	const bool p_half = param_dtype == NR3D_F16;
 	const Batch ba{block_inds, block_offsets, batch_data_size, meta->n_params};
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	const dim3 grid(div_up(N, kBlock), meta->n_pseudo_levels);
 	// paired gathers: every F == 2 entry 8-byte aligned -> even block and level offsets, no caller-chosen offsets
-	const uint32_t pair_ok = ((uintptr_t)params % 8 == 0 && block_offsets == nullptr && meta->n_params % 2 == 0) ? 1u : 0u;
+	const uint32_t pair_ok = ((uintptr_t)params % (p_half ? 4 : 8) == 0 && block_offsets == nullptr && meta->n_params % 2 == 0) ? 1u : 0u;
 	DISPATCH_G(meta->n_feat_per_pseudo_lvl, {
-		if (dy_dx)
-			hipLaunchKernelGGL((k_forest_fwd<G, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
-			                   max_level, meta->interpolation_type, x, params, ba, pair_ok, y, y_sn, y_se, dy_dx, d_sn, d_se);
-		else
-			hipLaunchKernelGGL((k_forest_fwd<G, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
-			                   max_level, meta->interpolation_type, x, params, ba, pair_ok, y, y_sn, y_se, dy_dx, d_sn, d_se);
+		auto launch = [&](auto kern, auto *tab) {
+			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N, max_level,
+			                   meta->interpolation_type, x, tab, ba, pair_ok, y, y_sn, y_se, dy_dx, d_sn, d_se);
+		};
+		if (p_half) { if (dy_dx) launch(k_forest_fwd<G, true, __half>, (const __half *)params); else launch(k_forest_fwd<G, false, __half>, (const __half *)params); }
+		else        { if (dy_dx) launch(k_forest_fwd<G, true, float>, (const float *)params); else launch(k_forest_fwd<G, false, float>, (const float *)params); }
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -314,10 +317,12 @@ extern "C" uint64_t nr3d_lotd_forest_dparam_workspace_bytes(const nr3d_lotd_meta
 
 extern "C" int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                                            uint32_t N, const float *dL_ddLdx, const float *dL_dy, const float *x,
-                                           const float *params, const int64_t *block_inds, const int64_t *block_offsets,
-                                           uint32_t batch_data_size, int32_t max_level, float *dL_dparam, void *workspace,
-                                           uint64_t workspace_bytes, void *stream) {
+                                           const void *params, int param_dtype, const int64_t *block_inds,
+                                           const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level,
+                                           float *dL_dparam, void *workspace, uint64_t workspace_bytes, void *stream) {
 	if (int rc = check_forest(meta, meta_dev, forest)) return rc;
+	NR3D_CHECK(param_dtype == NR3D_F32 || param_dtype == NR3D_F16, "LoTD forest: params must be f32 or f16");
+	const bool p_half = param_dtype == NR3D_F16;
 	if (N == 0 || max_level < 0) return 0;
 	NR3D_CHECK(dL_dy && x && params && dL_dparam, "LoTD forest::bwd: NULL tensor pointer");
 	const Batch ba{block_inds, block_offsets, batch_data_size, meta->n_params};
@@ -326,18 +331,19 @@ extern "C" int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const v
 		const ForestDev fo = dev_of(forest);
 		bool handled = false;
 		const int64_t E = meta->n_encoded_dims;
-		if (int rc = dparam_binned(dL_ddLdx != nullptr, meta, meta_dev, N, dL_ddLdx, dL_dy, E, 1, x, params, ba, forest->n_trees,
-		                           max_level, dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, &fo)) return rc;
+		if (int rc = dparam_binned(dL_ddLdx != nullptr, meta, meta_dev, N, dL_ddLdx, dL_dy, E, 1, x, (const float *)params, ba,
+		                           forest->n_trees, max_level, dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, &fo,
+		                           0, false, false, false, nullptr, p_half)) return rc;
 		if (handled) return 0;
 	}
 	const dim3 grid(div_up(N, kBlock), meta->n_pseudo_levels);
 	DISPATCH_G(meta->n_feat_per_pseudo_lvl, {
-		if (dL_ddLdx)
-			hipLaunchKernelGGL((k_forest_bwd_dparam<G, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
-			                   meta->n_encoded_dims, max_level, meta->interpolation_type, dL_ddLdx, dL_dy, x, params, ba, dL_dparam);
-		else
-			hipLaunchKernelGGL((k_forest_bwd_dparam<G, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
-			                   meta->n_encoded_dims, max_level, meta->interpolation_type, dL_ddLdx, dL_dy, x, params, ba, dL_dparam);
+		auto launch = [&](auto kern, auto *tab) {
+			hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N, meta->n_encoded_dims, max_level,
+			                   meta->interpolation_type, dL_ddLdx, dL_dy, x, tab, ba, dL_dparam);
+		};
+		if (p_half) { if (dL_ddLdx) launch(k_forest_bwd_dparam<G, true, __half>, (const __half *)params); else launch(k_forest_bwd_dparam<G, false, __half>, (const __half *)params); }
+		else        { if (dL_ddLdx) launch(k_forest_bwd_dparam<G, true, float>, (const float *)params); else launch(k_forest_bwd_dparam<G, false, float>, (const float *)params); }
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -345,17 +351,23 @@ extern "C" int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const v
 
 extern "C" int nr3d_lotd_forest_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_dev, const nr3d_forest_meta_t *forest,
                                            uint32_t N, const float *dL_ddLdx, const float *dL_dy, const float *x,
-                                           const float *params, const int64_t *block_inds, const int64_t *block_offsets,
-                                           uint32_t batch_data_size, int32_t max_level, float *dL_dx, void *stream) {
+                                           const void *params, int param_dtype, const int64_t *block_inds,
+                                           const int64_t *block_offsets, uint32_t batch_data_size, int32_t max_level, float *dL_dx,
+                                           void *stream) {
 	if (int rc = check_forest(meta, meta_dev, forest)) return rc;
+	NR3D_CHECK(param_dtype == NR3D_F32 || param_dtype == NR3D_F16, "LoTD forest: params must be f32 or f16");
 	if (N == 0) return 0;
 	NR3D_CHECK(dL_ddLdx && dL_dy && x && params && dL_dx, "LoTD forest::bwd_bwd_input: NULL tensor pointer");
 	const Batch ba{block_inds, block_offsets, batch_data_size, meta->n_params};
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	DISPATCH_G(meta->n_feat_per_pseudo_lvl, {
-		hipLaunchKernelGGL((k_forest_bwd_bwd_dx<G>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, md,
-		                   dev_of(forest), N, meta->n_encoded_dims, meta->n_pseudo_levels, max_level, meta->interpolation_type,
-		                   dL_ddLdx, dL_dy, x, params, ba, dL_dx);
+		auto launch = [&](auto kern, auto *tab) {
+			hipLaunchKernelGGL(kern, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, md, dev_of(forest), N,
+			                   meta->n_encoded_dims, meta->n_pseudo_levels, max_level, meta->interpolation_type, dL_ddLdx, dL_dy, x, tab,
+			                   ba, dL_dx);
+		};
+		if (param_dtype == NR3D_F16) launch(k_forest_bwd_bwd_dx<G, __half>, (const __half *)params);
+		else launch(k_forest_bwd_bwd_dx<G, float>, (const float *)params);
 	});
 	NR3D_LAUNCH_CHECK();
 	return 0;

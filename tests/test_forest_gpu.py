@@ -77,6 +77,34 @@ def test_identify(oracle, dev, forest):
 
 
 @pytest.mark.parametrize("case", list(FOREST_METAS))
+@pytest.mark.parametrize("binned", [True, False])
+def test_half_tables_read_natively(oracle, dev, case, binned, monkeypatch):
+    """half tables of a forest: the forest kernels (forward, both dL/dparam forms incl. the binned path's product-type
+    factors, d(dL/dx)/dx) read the half entries themselves (ABI 3: param_dtype on the forest entry points) -- the same bits as
+    the run on an fp32 copy of the tables (hardware-atomic dL/dparam: to tolerance, arrival-order sums)"""
+    _lotd, fo, m_ref, metas, (x, p, g, v, bi), (xt, pt, gt, vt, bit) = _setup(oracle, dev, "plus", case, continuity=True)
+    monkeypatch.setattr(_lotd, "USE_BINNED_DPARAM", binned)
+    ph, gh = pt.half(), gt.half()
+    outs = []
+    for native in (True, False):
+        monkeypatch.setattr(_lotd, "NATIVE_HALF", native)
+        y, j = _lotd.lod_fwd(metas, xt, ph, bit, need_input_grad=True)
+        dx, dp = _lotd.lod_bwd(metas, gh, xt, ph, j, bit, need_input_grad=True, need_param_grad=True)
+        ddy, dp2, dx2 = _lotd.lod_bwd_bwd_input(metas, vt, gh, xt, ph, j, bit, need_dLdinput_ddLdoutput=True,
+                                                need_dLdinput_dparams=True, need_dLdinput_dinput=True)
+        outs.append((y, j, dx, ddy, dx2, dp, dp2))
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert a.dtype == b.dtype
+        if k >= 5 and not binned:
+            assert_close(a.float(), b.float().cpu().numpy(), rel=1e-3, name=f"output {k} (atomics)", levels=m_ref)
+        else:
+            assert torch.equal(a, b), f"output {k}: half tables vs their fp32 copy"
+    assert outs[0][0].dtype == torch.float16
+    y_ref, _ = oracle.lotd_forest_fwd(m_ref, fo, x, ph.float().cpu().numpy(), block_inds=bi, need_dydx=True)
+    assert np.allclose(outs[0][0].float().cpu().numpy(), y_ref, rtol=1e-3, atol=6e-8)
+
+
+@pytest.mark.parametrize("case", list(FOREST_METAS))
 @pytest.mark.parametrize("forest,continuity", [("plus", True), ("plus", False), ("scatter", True), ("single", True)])
 def test_fwd_bwd_and_second_order(oracle, dev, forest, continuity, case):
     _lotd, fo, m_ref, metas, (x, p, g, v, bi), (xt, pt, gt, vt, bit) = _setup(oracle, dev, forest, case, continuity=continuity)
