@@ -54,15 +54,18 @@ def kernel_algorithmic_bytes(kernel, n_levels_served, F=2, D=3, C=8):
         return Ls * F * 4 + Ls * F * D * 4 + 4 * D
     if kernel in ("lotd_bin", "lotd_accum"):            # x + dL_dy ... scatter as read-modify-write, half to each stage
         return (4 * D + Ls * F * 4 + 2 * Ls * C * F * 4) // 2
-    if kernel == "lotd_direct":                         # the same for the levels that skip the records, in one kernel
-        return 4 * D + Ls * F * 4 + 2 * Ls * C * F * 4
+    if kernel == "lotd_direct":
+        # the levels that skip the records accumulate in LDS: the scatter (8(d)'s 2 x 64 B read-modify-write per point and
+        # level) never leaves the CU, so crediting it would put this kernel above the peak.  What it moves at least: x and the
+        # level's two dL_dy columns per level (a level of several buckets reads them once per bucket).
+        return Ls * (4 * D + F * 4)
     raise KeyError(kernel)
 
 
 # timers of include/nr3d_hip.h (NR3D_PROF_*) -> kernel names as rocprofv3 prints them (the default configuration)
 PROF_KERNELS = {"lotd_fwd": "k_fwd_pairlane<true, float, 2>", "lotd_fwd_lds": "k_fwd_lds<true, float, 2>",
-                "lotd_contract_dx": "k_contract_dx_rowmajor<3, float>", "lotd_bin": "k_pair_bin<1024>",
-                "lotd_accum": "k_pair_accum<4, true>", "lotd_direct": "k_pair_direct<true>"}
+                "lotd_contract_dx": "k_contract_dx_rowmajor<3, float>", "lotd_bin": "k_pair_bin<1024, false>",
+                "lotd_accum": "k_pair_accum<4, true>", "lotd_direct": "k_pair_direct<true, false>"}
 LIVE_TIMER = "lotd_fwd"      # the dominant kernel: timed inside the timed region (2 events per step); the rest in an extra pass
 OP_TIMERS = {"fwd": ["lotd_fwd_lds", "lotd_fwd"], "bwd": ["lotd_contract_dx", "lotd_bin", "lotd_accum", "lotd_direct"]}
 
