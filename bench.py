@@ -432,7 +432,8 @@ def lotd_second_order_rate(dev, log2n=20, iters=10):
     v = torch.randn(N, 3, generator=gen).to(dev)
     _, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
     ms = {}
-    for name, flags in (("ddLdy", (True, False, False)), ("dparam", (False, True, False)), ("dx", (False, False, True))):
+    for name, flags in (("ddLdy", (True, False, False)), ("dparam", (False, True, False)), ("dx", (False, False, True)),
+                        ("one_call", (True, True, True))):     # all three in ONE call (what autograd issues; one shared copy of dL_dy)
         fn = lambda: _lotd.lod_bwd_bwd_input(meta, v, g, x, params, j, need_dLdinput_ddLdoutput=flags[0],
                                              need_dLdinput_dparams=flags[1], need_dLdinput_dinput=flags[2])
         for _ in range(3):
@@ -443,9 +444,10 @@ def lotd_second_order_rate(dev, log2n=20, iters=10):
             fn()
         torch.cuda.synchronize()
         ms[name] = round((time.perf_counter() - t0) / iters * 1e3, 4)
+    one_call = ms.pop("one_call")
     tot = sum(ms.values())
     return dict(workload=f"configs[1]'s meta, 2^{log2n} points: d(dL/dx)/d(dL_dy), d(dL/dx)/dparam, d(dL/dx)/dx", ms=ms,
-                ms_total=round(tot, 4), mpoints_per_s=round(N / tot / 1e3, 3))
+                ms_total=round(tot, 4), ms_all_three_in_one_call=one_call, mpoints_per_s=round(N / tot / 1e3, 3))
 
 
 def c1_dense_rate(dev):

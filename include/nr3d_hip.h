@@ -163,6 +163,13 @@ int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_d
                                 int32_t min_level, int32_t max_level, void *dL_dparam, void *workspace,
                                 uint64_t workspace_bytes, void *stream);
 
+/* dL_dy [N, E] (element (i, e) at i * g_sn + e * g_se; grad_dtype NR3D_F32 | NR3D_F16) -> out float [E][N], feature-major:
+ * the layout the level-major kernels read.  The dL/dparam entry points make this copy themselves when handed a row-major
+ * dL_dy; a caller that runs several of them on one dL_dy (d(dL/dx)/dparam and d(dL/dx)/dx of one second-order step) makes it
+ * once and passes it with strides (1, N) to nr3d_lotd_bwd_bwd_dparam and nr3d_lotd_bwd_bwd_dx_ws. */
+int nr3d_lotd_dLdy_feature_major(uint32_t n_points, uint32_t n_encoded_dims, int grad_dtype, const void *dL_dy,
+                                 int64_t g_sn, int64_t g_se, float *out, void *stream);
+
 /* Native half-parameter storage, the reference's (float, half, float) type combination (<input, param, compute>,
  * csrc/lotd/include/lotd/lotd_encoding.h:1501-1504; PARAM_T accumulators lotd_encoding.h:72): x and dy_dx float, params /
  * y / dL_dy / dL_dparam __half, arithmetic in fp32.  nr3d_lotd_half_params_ok: 1 when nr3d_lotd_fwd (param_dtype

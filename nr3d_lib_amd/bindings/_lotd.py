@@ -592,11 +592,22 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
                 H.check(H.lib().nr3d_lotd_bwd_bwd_ddLdy(
                     cm, H.u32(N), C.c_int(H.F32), C.c_int(H.F32), H.ptr(v32), H.ptr(j), H.i64(jsn), H.i64(jse),
                     H.ptr(dL_ddLdy), H.i64(dL_ddLdy.stride(0)), H.i64(dL_ddLdy.stride(1)), st))
+            batched = batch_inds is not None or batch_offsets is not None or bds != 0
+            wsb = 0
             if need_dx:
                 # scratch for the level-parallel form ([n_pseudo, N, D] floats), while it stays below HVP_WORKSPACE_MAX_BYTES
                 f = H.lib().nr3d_lotd_bwd_bwd_dx_workspace_bytes
                 f.restype = C.c_uint64
                 wsb = int(f(cm, H.u32(N)))
+            if (need_dx and need_dp and not batched and 0 < wsb <= HVP_WORKSPACE_MAX_BYTES and USE_BINNED_DPARAM
+                    and gse == 1 and gsn == E):
+                # both level-major passes of this step read dL_dy feature-major: ONE copy for the two of them (each would make
+                # its own: the parameter pass a [E, N] transposition, the Hessian pass its by-level pairs)
+                gT = H.empty((E, N), dtype=torch.float32, device=dev)
+                H.check(H.lib().nr3d_lotd_dLdy_feature_major(H.u32(N), H.u32(E), C.c_int(H.F32), H.ptr(g32), H.i64(gsn), H.i64(gse),
+                                                             H.ptr(gT), st))
+                g32, gsn, gse = gT, 1, N
+            if need_dx:
                 ws = (H.empty((wsb + 3) // 4, dtype=torch.float32, device=dev)
                       if 0 < wsb <= HVP_WORKSPACE_MAX_BYTES else None)
                 H.check(H.lib().nr3d_lotd_bwd_bwd_dx_ws(
@@ -604,7 +615,6 @@ def lod_bwd_bwd_input(lod_meta, dL_ddLdx, dL_dy, input, params, dy_dx=None, batc
                     H.i64(gse), H.ptr(x32), H.ptr(p32), H.ptr(batch_inds), H.ptr(batch_offsets), H.u32(bds),
                     H.i32(max_level), H.ptr(dL_dx), H.ptr(ws), C.c_uint64(wsb if ws is not None else 0), st))
             if need_dp:
-                batched = batch_inds is not None or batch_offsets is not None or bds != 0
                 nbat = _n_batches(m, p32, batch_offsets, batched)
                 ws, wsb = _dparam_workspace(m, N, dev, nbat)
                 H.check(H.lib().nr3d_lotd_bwd_bwd_dparam(

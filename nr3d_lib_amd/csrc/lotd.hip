@@ -1008,9 +1008,11 @@ constexpr int kHvpSub = 2;                         // 32-point groups per wave
 template <int SUB, typename PT>
 __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_pl(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                           int32_t max_level, uint32_t smooth, const float *__restrict__ dL_ddLdx,
-                                                          const float *__restrict__ g_pairs,
+                                                          const float *__restrict__ g_pairs, int64_t g_fm,
                                                           const float *__restrict__ x, const PT *__restrict__ params,
                                                           float *__restrict__ partial, uint32_t dbg) {
+	// g_fm == 0: g_pairs is the [pseudo level][point][2] copy of k_hvp_pairs; > 0: the caller's dL_dy is feature-major already
+	// (element (i, e) at e * g_fm + i, e.g. the copy the dL/dparam pass of the same step uses) and is read in place
 	uint32_t q, chunk;
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
 	constexpr uint32_t kGroup = 32;
@@ -1039,8 +1041,10 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_pl(Sched s, const nr3d_lo
 		if (gc + kGroup > N) { const uint32_t i = gc + pl; pi = (i < N ? i : N - 1u) - gc; }
 		const float *px = reinterpret_cast<const float *>(reinterpret_cast<const char *>(x) + (size_t)gc * 12u + pi * 12u);
 		const float *pv = reinterpret_cast<const float *>(reinterpret_cast<const char *>(dL_ddLdx) + (size_t)gc * 12u + pi * 12u);
-		const char *gb = reinterpret_cast<const char *>(g_pairs) + ((size_t)q * N + gc) * 8u;       // [pseudo level][point][2]
-		const uint32_t g_lane = pi * 8u + side * 4u;
+		const char *gb = reinterpret_cast<const char *>(g_pairs) +
+		                 (g_fm ? ((size_t)(q * 2u + side) * (size_t)g_fm + gc) * 4u       // row of column 2 q + side (lane-dependent: VGPR base)
+		                       : ((size_t)q * N + gc) * 8u);                             // [pseudo level][point][2]
+		const uint32_t g_lane = g_fm ? pi * 4u : pi * 8u + side * 4u;
 		xp[u][0] = px[0]; xp[u][1] = px[1]; xp[u][2] = px[2];
 		if (dbg & 8u) { vp[u][0] = xp[u][1]; vp[u][1] = xp[u][2]; vp[u][2] = xp[u][0]; }
 		else { vp[u][0] = pv[0]; vp[u][1] = pv[1]; vp[u][2] = pv[2]; }
@@ -1930,12 +1934,17 @@ static int launch_bwd_bwd_dx_t(const nr3d_lotd_meta_t *meta, const void *meta_de
 				                   (const float *)x, (const PT *)params, ba, vec_ok, (float *)workspace);
 			};
 			if (pl) {
-				// workspace: partial [P][N][3] | g_pairs [P][N][2]
-				float *g_pairs = (float *)workspace + (size_t)N * meta->n_pseudo_levels * 3u;
-				hipLaunchKernelGGL(k_hvp_pairs, dim3(div_up(N, kGpPts), div_up(meta->n_pseudo_levels, kGpLv)), dim3(kBlock), 0,
-				                   (hipStream_t)stream, N, meta->n_pseudo_levels, (const float *)dL_dy, g_sn, g_se, g_pairs);
+				// workspace: partial [P][N][3] | g_pairs [P][N][2]; a feature-major dL_dy (g_sn == 1) is read in place
+				const float *g_pairs = (const float *)dL_dy;
+				const int64_t g_fm = (g_sn == 1 && g_se >= (int64_t)N) ? g_se : 0;
+				if (!g_fm) {
+					float *gp = (float *)workspace + (size_t)N * meta->n_pseudo_levels * 3u;
+					hipLaunchKernelGGL(k_hvp_pairs, dim3(div_up(N, kGpPts), div_up(meta->n_pseudo_levels, kGpLv)), dim3(kBlock), 0,
+					                   (hipStream_t)stream, N, meta->n_pseudo_levels, (const float *)dL_dy, g_sn, g_se, gp);
+					g_pairs = gp;
+				}
 				hipLaunchKernelGGL((k_bwd_bwd_dx_pl<kHvpSub, PT>), dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
-				                   meta->interpolation_type, (const float *)dL_ddLdx, (const float *)g_pairs,
+				                   meta->interpolation_type, (const float *)dL_ddLdx, g_pairs, g_fm,
 				                   (const float *)x, (const PT *)params, (float *)workspace, hvp_dbg);
 			}
 			else if (dh) launch(k_bwd_bwd_dx_lv<D, G, true, PT>); else launch(k_bwd_bwd_dx_lv<D, G, false, PT>);

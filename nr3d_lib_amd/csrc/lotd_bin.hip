@@ -1427,6 +1427,33 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	return 0;
 }
 
+}  // namespace lotd
+}  // namespace nr3d
+
+// dL_dy [N, E] (any strides, float or half) -> feature-major float [E][N]: what the level-major kernels read (the parameter
+// gradient passes make this copy themselves when handed a row-major dL_dy; a caller that runs several of them on one dL_dy --
+// d(dL/dx)/dparam and d(dL/dx)/dx of one second-order step -- makes it once and hands it to both)
+extern "C" int nr3d_lotd_dLdy_feature_major(uint32_t n_points, uint32_t n_encoded_dims, int grad_dtype, const void *dL_dy,
+                                            int64_t g_sn, int64_t g_se, float *out, void *stream) {
+	using namespace nr3d;
+	using namespace nr3d::lotd;
+	NR3D_CHECK(grad_dtype == NR3D_F32 || grad_dtype == NR3D_F16, "dLdy_feature_major: f32 / f16 dL_dy");
+	if (n_points == 0 || n_encoded_dims == 0) return 0;
+	NR3D_CHECK(dL_dy && out, "dLdy_feature_major: NULL tensor pointer");
+	const dim3 grid(div_up(n_points, 32), div_up(n_encoded_dims, 32));
+	if (grad_dtype == NR3D_F16)
+		hipLaunchKernelGGL(k_transpose<__half>, grid, dim3(256), 0, (hipStream_t)stream, n_points, n_encoded_dims,
+		                   (const __half *)dL_dy, g_sn, g_se, out);
+	else
+		hipLaunchKernelGGL(k_transpose<float>, grid, dim3(256), 0, (hipStream_t)stream, n_points, n_encoded_dims, (const float *)dL_dy,
+		                   g_sn, g_se, out);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+namespace nr3d {
+namespace lotd {
+
 // NR3D_LOTD_PAIR_SECOND=0: d(dL/dx)/dparam of pair-path metas through the 12-byte corner records (A/B, and the cross-check)
 static bool pair_second_enabled() {              // read per call: the tests compare both routes in one process
 	const char *e = getenv("NR3D_LOTD_PAIR_SECOND");
