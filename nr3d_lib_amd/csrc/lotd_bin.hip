@@ -64,7 +64,7 @@ __host__ __device__ inline uint32_t rec_count(uint32_t type, uint32_t D, bool fo
 		case NR3D_LOD_Dense: case NR3D_LOD_Hash: return 8u;
 		case NR3D_LOD_CP: case NR3D_LOD_NPlaneMul: return 24u;
 		case NR3D_LOD_VectorMatrix: return 48u;
-		default: return 0u;                          // CPfast / NPlaneSum have no forest form (lotd_forest.h); VecZMatXoY: atomics
+		default: return 0u;                          // CPfast / NPlaneSum / VecZMatXoY have no forest form (lotd_forest.h:265-301)
 		}
 	}
 	switch (type) {
