@@ -63,6 +63,10 @@ static uint32_t pair_bp() {
 	if (!v) { const char *e = getenv("NR3D_PAIR_BP"); const int x = e ? atoi(e) : 1024; v = (x == 512 || x == 768) ? (uint32_t)x : 1024u; }
 	return v;
 }
+static bool pair_quad_enabled() {                 // read per call: the tests compare both record forms in one process
+	const char *e = getenv("NR3D_PAIR_QUAD");
+	return !(e && e[0] == '0');
+}
 static uint32_t pair_lg() {
 	static uint32_t v = 0;
 	if (!v) { const char *e = getenv("NR3D_PAIR_EPB_LOG2"); const int x = e ? atoi(e) : 12; v = (x == 13) ? 13u : 12u; }
@@ -111,11 +115,15 @@ __device__ __forceinline__ float pair_wp2(float wp, float Cm, float Em, float &C
 	Cuse = fabsf(Cm) >= floor_c ? Cm : copysignf(floor_c, Cm);
 	return __fmaf_rn(Em, __builtin_amdgcn_rcpf(Cuse), wp);   // v_rcp_f32 (1 ulp) + fma, no division sequence: 1e-7 of wp', far inside the contract
 }
+// Quad records (first order, Dense levels, quad_on): the pairs (x, y) and (x, y + 1) of a Dense level are neighbours in memory
+// as well -- rows r and r + 1 of the table -- so ONE 16-byte record can carry the four entries e, e + 1, e + Rz, e + Rz + 1 with
+// A_f = g_f w_x and both weights (w_y, w_z) as 24-bit fractions: half the record bytes of a Dense level (qmask bit bx: rows r,
+// r + 1 of x-corner bx lie in one bucket; wxy = {w_x, w_y}).
 template <bool SECOND = false>
 __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t epb, uint32_t lg, const float (&xp)[3], float g0,
                                              float g1, bool smooth, uint32_t (&hdr)[4], uint32_t (&bkt)[4], float (&A)[4][2],
                                              float (&wpm)[SECOND ? 4 : 1], uint32_t (&cell)[3], uint32_t nb, bool &valid,
-                                             const float *__restrict__ vin = nullptr) {
+                                             const float *__restrict__ vin, uint32_t &qmask, float (&wxy)[2], bool quad_on) {
 	// wpm: one pair weight per record in the second-order form, ONE for all four in the first-order form (the first-order
 	// stage-A kernel sits exactly at its 64-register budget: four copies of the same value spilled)
 	// valid: every pair lies inside ONE bucket of the level.  True by construction for x in [0, 1] (what the Python layer
@@ -128,6 +136,8 @@ __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t
 #pragma unroll
 		for (int d = 0; d < 3; ++d) a[d] = c.sc[d] * vin[d] * c.dw[d];
 	}
+	qmask = 0;
+	if constexpr (!SECOND) { wxy[0] = c.w[0]; wxy[1] = c.w[1]; }
 	if (L.type == NR3D_LOD_Dense) {
 		const float wp = c.w[2];
 #pragma unroll
@@ -149,6 +159,11 @@ __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t
 				wpm[m] = pair_wp2(wp, Cm, a[2] * wo, Cuse);
 				A[m][0] = g0 * Cuse; A[m][1] = g1 * Cuse;
 			}
+		}
+		if constexpr (!SECOND) {
+#pragma unroll
+			for (uint32_t bx = 0; bx < 2; ++bx)       // rows r (slot bx) and r + 1 (slot bx + 2) in one bucket, indices within 13 bits
+				if (quad_on && bkt[bx] == bkt[bx + 2u] && (hdr[bx] & 8191u) + L.res[2] + 1u < 8192u) qmask |= 1u << bx;
 		}
 	} else {
 		const float wp = c.w[0];
@@ -204,11 +219,14 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
                                            float g0, float g1, uint32_t smooth, u32x4 *__restrict__ stage,
                                            uint32_t *__restrict__ hist, uint32_t *__restrict__ zero_next, uint32_t *scan_lds,
                                            u32x4 *__restrict__ dst, uint32_t *__restrict__ ob, uint32_t ob_stride,
-                                           const float *__restrict__ vin = nullptr) {
+                                           const float *__restrict__ vin = nullptr, bool quad_on = false) {
 	const uint32_t nb = plan.nb[ql];
 	const uint32_t lane = threadIdx.x & 63u;
 	uint32_t hdr[4], bkt[4], cell[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 	constexpr int kW = SECOND ? 3 : 0;                   // wp[m & kW]: per record (second order) or shared
+	constexpr bool QUADS = !SECOND;                      // qmask stays 0 for Hash levels and with quad_on off
+	uint32_t qmask = 0;
+	float wxy[2] = {0.0f, 0.0f};
 	float A[4][2], wp[SECOND ? 4 : 1];
 #pragma unroll
 	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; wp[m & kW] = 0.0f; }
@@ -216,7 +234,8 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 		for (uint32_t b = threadIdx.x; b <= kPMaxNb; b += kPBP) zero_next[b] = 0;
 	if (active) {
 		bool valid;
-		pair_records<SECOND>(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, nb, valid, vin);
+		pair_records<SECOND>(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, nb, valid, vin, qmask, wxy,
+		                     quad_on);
 		active = valid;
 	}
 
@@ -264,17 +283,22 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 
 	// ---- rank inside the bucket (split lanes take two consecutive slots per pair) ----
 	uint32_t rank[4] = {0, 0, 0, 0};
-	const uint32_t cnt = emit ? (split ? 2u : 1u) : 0u;
+	// slot m holds a record unless its pair travels inside the quad of slot m - 2 (quads only from unmerged lanes)
+	auto emits = [&](int m) {
+		if constexpr (QUADS) return emit && !(!split && m >= 2 && ((qmask >> (m - 2)) & 1u));
+		else return emit;
+	};
 	if (nb <= 4) {
 		// one to four buckets: every record of the block would hit the same histogram counters -> rank through ballots
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
-			const uint32_t bv = emit ? bkt[m] : 0xFFFFFFFFu;
-			unsigned long long todo = __ballot(emit);
+			const bool e_m = emits(m);
+			const uint32_t bv = e_m ? bkt[m] : 0xFFFFFFFFu;
+			unsigned long long todo = __ballot(e_m);
 			while (todo) {
 				const int leader = __ffsll((long long)todo) - 1;
 				const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)bv, leader);
-				const bool mine = emit && bv == v;
+				const bool mine = e_m && bv == v;
 				const unsigned long long m1 = __ballot(mine), m2 = __ballot(mine && split);
 				uint32_t first = 0;
 				if ((int)lane == leader) first = atomicAdd(&hist[v], (uint32_t)(__popcll(m1) + __popcll(m2)));
@@ -291,13 +315,14 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 		// is left uses its own atomic.
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
-			const uint32_t bv = emit ? bkt[m] : 0xFFFFFFFFu;
-			const unsigned long long em = __ballot(emit);
-			bool done = !emit;
+			const bool e_m = emits(m);
+			const uint32_t bv = e_m ? bkt[m] : 0xFFFFFFFFu;
+			const unsigned long long em = __ballot(e_m);
+			bool done = !e_m;
 			if (em) {
 				const int leader = __ffsll((long long)em) - 1;
 				const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)bv, leader);
-				const bool mine = emit && bv == v;
+				const bool mine = e_m && bv == v;
 				const unsigned long long m1 = __ballot(mine);
 				if (__popcll(m1) >= 8) {
 					const unsigned long long m2 = __ballot(mine && split);
@@ -308,7 +333,7 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 					if (mine) { rank[m] = first + (uint32_t)(__popcll(m1 & below) + __popcll(m2 & below)); done = true; }
 				}
 			}
-			if (!done) rank[m] = atomicAdd(&hist[bv], cnt);
+			if (!done) rank[m] = atomicAdd(&hist[bv], split ? 2u : 1u);
 		}
 	}
 	__syncthreads();
@@ -336,8 +361,17 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 	if (emit) {
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
+			if (!emits(m)) continue;
 			const uint32_t pos = hist[bkt[m]] + rank[m];
-			if (!split) {
+			if (QUADS && !split && m < 2 && ((qmask >> m) & 1u)) {
+				// quad record: x = i0 | w_y bits 8..20 << 13 | 4 << 26 | w_y bits 21..23 << 29, y = w_z (24 bits) | w_y bits 0..7 << 24,
+				// z / w = g_f w_x; stage B adds (1 - w_y)(1 - w_z), (1 - w_y) w_z, w_y (1 - w_z), w_y w_z times that to the entries
+				// i0, i0 + 1, i0 + Rz, i0 + Rz + 1
+				const uint32_t wzq = (uint32_t)__float2uint_rn(wp[0] * 16777215.0f), wyq = (uint32_t)__float2uint_rn(wxy[1] * 16777215.0f);
+				const float ax = m ? wxy[0] : 1.0f - wxy[0];
+				stage[pos] = u32x4{(hdr[m] & 8191u) | (((wyq >> 8) & 8191u) << 13) | (4u << 26) | ((wyq >> 21) << 29),
+				                   wzq | ((wyq & 255u) << 24), __float_as_uint(g0 * ax), __float_as_uint(g1 * ax)};
+			} else if (!split) {
 				stage[pos] = u32x4{hdr[m] | (3u << 26), __float_as_uint(wp[m & kW]), __float_as_uint(A[m][0]), __float_as_uint(A[m][1])};
 			} else {
 				stage[pos] = u32x4{(hdr[m] & 0x1FFFu) | (1u << 26), 0u, __float_as_uint(A[m][0]), __float_as_uint(A[m][1])};
@@ -380,7 +414,8 @@ __global__ __launch_bounds__(kPBP, kPBP == 768 ? 6 : 8) /* <= 64 VGPRs: two 64 K
                                                    int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                    const float *__restrict__ g, int64_t g_sn, int64_t g_se,
                                                    u32x4 *__restrict__ rec, uint32_t *__restrict__ offs_g,
-                                                   uint32_t *__restrict__ gmax, DirectPlan dp, const float *__restrict__ vin_) {
+                                                   uint32_t *__restrict__ gmax, DirectPlan dp, const float *__restrict__ vin_,
+                                                   uint32_t quad_on) {
 	// SECOND: d(dL/dx)/dparam for dL_ddLdx = vin_ (pair_records); else vin_ is unused
 	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[kPCap] records | hist[nb + 1]
@@ -407,7 +442,8 @@ __global__ __launch_bounds__(kPBP, kPBP == 768 ? 6 : 8) /* <= 64 VGPRs: two 64 K
 		}
 	}
 	pair_level<kPBP, SECOND>(plan, ql, L, active, xp, g0, g1, smooth, stage, hist, nullptr, scan_lds,
-	                         rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk, vin);
+	                         rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk, vin,
+	                         quad_on != 0u);
 	if (gmax) {
 		// bound of a single update: first order |g| (a weight in [0, 1] times a gradient); second order |g| sum_d |a_d| with
 		// |a_d| <= 1.5 scale_d |vin_d| (w' <= 1.5 for the smoothstep, 1 linear)
@@ -459,7 +495,7 @@ __global__ __launch_bounds__(1024) void k_pair_bin_all(PairPlan plan, const nr3d
                                                        const float *__restrict__ x, const GT *__restrict__ g, int64_t g_sn,
                                                        int64_t g_se, const float *__restrict__ dydx, int64_t d_sn, int64_t d_se,
                                                        float *__restrict__ dL_dx, u32x4 *__restrict__ rec,
-                                                       uint32_t *__restrict__ offs_g, uint32_t *__restrict__ gmax) {
+                                                       uint32_t *__restrict__ offs_g, uint32_t *__restrict__ gmax, uint32_t quad_on) {
 	constexpr int kPBP = 1024;
 	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[2][kPCap] records | hist[2][kPMaxNb + 1]
@@ -522,7 +558,8 @@ __global__ __launch_bounds__(1024) void k_pair_bin_all(PairPlan plan, const nr3d
 		const Lvl L = load_level(md, level);
 		pair_level<kPBP>(plan, ql, L, in && (int32_t)level <= max_level, xp, g0, g1, smooth, stage + (size_t)buf * kPCap,
 		                 hist + (size_t)buf * (kPMaxNb + 1), hist + (size_t)(buf ^ 1u) * (kPMaxNb + 1), scan_lds,
-		                 rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk);
+		                 rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk, nullptr,
+		                 quad_on != 0u);
 		++ql; buf ^= 1u;
 	}
 	if (DX && in) {
@@ -734,9 +771,28 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 #pragma unroll
 				for (int v = 0; v < kUnroll; ++v)
 					if (p0 + 64u * (uint32_t)v + lane < total && !(dbg & 1u)) {
-						const uint32_t h = rv[v].x, fl = h >> 26;
+						const uint32_t h = rv[v].x, fl = (h >> 26) & 7u;
 						const uint32_t i0 = h & 8191u, i1 = (h >> 13) & 8191u;
 						const float w = __uint_as_float(rv[v].y), a0 = __uint_as_float(rv[v].z), a1 = __uint_as_float(rv[v].w);
+						if (fl == 4u) {
+							// quad record of a Dense level (pair_level): entries i0, i0 + 1 of row r and i0 + Rz, i0 + Rz + 1 of row r + 1
+							const uint32_t wyq = (((h >> 13) & 8191u) << 8) | (rv[v].y >> 24) | ((h >> 29) << 21), wzq = rv[v].y & 0xFFFFFFu;
+							const float wy = (float)wyq * (1.0f / 16777215.0f), wz = (float)wzq * (1.0f / 16777215.0f);
+							const float q00 = (1.0f - wy) * (1.0f - wz), q01 = (1.0f - wy) * wz, q10 = wy * (1.0f - wz), q11 = wy * wz;
+							const uint32_t i2 = i0 + L.res[2];
+							if (fix) {
+								atomicAdd(&acc_raw[i0], to_fix(q00 * a0, fx.scale)); atomicAdd(&acc_raw[kPEpb + i0], to_fix(q00 * a1, fx.scale));
+								atomicAdd(&acc_raw[i0 + 1u], to_fix(q01 * a0, fx.scale)); atomicAdd(&acc_raw[kPEpb + i0 + 1u], to_fix(q01 * a1, fx.scale));
+								atomicAdd(&acc_raw[i2], to_fix(q10 * a0, fx.scale)); atomicAdd(&acc_raw[kPEpb + i2], to_fix(q10 * a1, fx.scale));
+								atomicAdd(&acc_raw[i2 + 1u], to_fix(q11 * a0, fx.scale)); atomicAdd(&acc_raw[kPEpb + i2 + 1u], to_fix(q11 * a1, fx.scale));
+							} else {
+								atomicAdd(&acc[i0], (double)(q00 * a0)); atomicAdd(&acc[kPEpb + i0], (double)(q00 * a1));
+								atomicAdd(&acc[i0 + 1u], (double)(q01 * a0)); atomicAdd(&acc[kPEpb + i0 + 1u], (double)(q01 * a1));
+								atomicAdd(&acc[i2], (double)(q10 * a0)); atomicAdd(&acc[kPEpb + i2], (double)(q10 * a1));
+								atomicAdd(&acc[i2 + 1u], (double)(q11 * a0)); atomicAdd(&acc[kPEpb + i2 + 1u], (double)(q11 * a1));
+							}
+							continue;
+						}
 						const bool pair = fl == 3u;
 						const float wl = pair ? 1.0f - w : 1.0f, wh = pair ? w : 1.0f;
 						if (fix) {
@@ -819,7 +875,9 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 #pragma unroll
 				for (int d = 0; d < 3; ++d) vin[d] = vin_[(size_t)i * 3 + d];
 			}
-			pair_records<SECOND>(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, dp.nb[e], valid, vin);
+			uint32_t qmask;
+			float wxy[2];
+			pair_records<SECOND>(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, dp.nb[e], valid, vin, qmask, wxy, false);
 			float lo[4][2], hi[4][2];
 #pragma unroll
 			for (int m = 0; m < 4; ++m)
@@ -1199,12 +1257,14 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	NR3D_HIP_CHECK(hipMemsetAsync(gmax, 0, 2 * sizeof(uint32_t), st));      // gmax | ticket of k_pair_plan
 	const uint32_t bp = pair_bp();
 	const size_t bin_lds = (size_t)bp * 4 * 16 + (size_t)(nb_max + 1) * 4;     // stage | hist
+	// first order: the Dense levels' records in quad form (NR3D_PAIR_QUAD=0: pair records only)
+	const uint32_t quad_on = (!vin && pair_quad_enabled()) ? 1u : 0u;
 #define NR3D_PAIR_BIN(BP) if (vin) NR3D_PAIR_BIN_(BP, true); else NR3D_PAIR_BIN_(BP, false)
 #define NR3D_PAIR_BIN_(BP, SEC) hipLaunchKernelGGL((k_pair_bin<BP, SEC>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level, \
-	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax, dp, vin)
+	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax, dp, vin, quad_on)
 #define NR3D_PAIR_ALL(DX, GT) hipLaunchKernelGGL((k_pair_bin_all<DX, GT>), dim3(pl.n_blk), dim3(1024), all_lds, st, pl, md, n,       \
 	meta->n_pseudo_levels, meta->n_encoded_dims, max_level, meta->interpolation_type, x, (const GT *)g, g_sn, g_se,                     \
-	fdx ? fdx->dydx : nullptr, fdx ? fdx->d_sn : 0, fdx ? fdx->d_se : 0, fdx ? fdx->dL_dx : nullptr, (u32x4 *)rec, offs, gmax)
+	fdx ? fdx->dydx : nullptr, fdx ? fdx->d_sn : 0, fdx ? fdx->d_se : 0, fdx ? fdx->dL_dx : nullptr, (u32x4 *)rec, offs, gmax, quad_on)
 	{
 		prof::Scope ps(NR3D_PROF_LOTD_BIN, st);
 		if (all_levels) {

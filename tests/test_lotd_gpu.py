@@ -130,6 +130,31 @@ def test_bwd_bwd_input(oracle, dev, case, bin_mode):
     assert_close(dx, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="d(dLdx)/dx")
 
 
+@pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4"])
+@pytest.mark.parametrize("coherent", [False, True])
+def test_dense_quad_records_vs_pair_records(oracle, dev, case, coherent, bin_mode, monkeypatch):
+    """dL/dparam of the pair path: the Dense levels' records in quad form (four entries of two neighbouring rows per 16-byte
+    record, both weights as 24-bit fractions; default) against pair records only (NR3D_PAIR_QUAD=0) and the fp64-accumulated
+    oracle; random points and runs of points inside one cell (merged lanes emit singles, never quads); half gradients too"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=9001, seed=51)
+    if coherent:
+        base = x[::40].repeat(40, axis=0)[: x.shape[0]]
+        x = np.clip(base + (np.linspace(0, 2e-3, x.shape[0], dtype=np.float32)[:, None] % 1e-4), 1e-6, 1 - 1e-6).astype(np.float32)
+        xt = torch.from_numpy(x).to(dev)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NR3D_PAIR_QUAD", mode)
+        outs[mode] = (_lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)[1],
+                      _lotd.lod_bwd(m, gt, xt, pt, None, max_level=m.n_levels // 2, need_input_grad=False, need_param_grad=True)[1],
+                      _lotd.lod_bwd(m, gt.half(), xt, pt.half(), None, need_input_grad=False, need_param_grad=True)[1])
+    ref = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
+    assert_close(outs["1"][0], ref, name="dL/dparam, quad records", levels=m_ref)
+    assert_close(outs["0"][0], ref, name="dL/dparam, pair records", levels=m_ref)
+    assert_close(outs["1"][0], outs["0"][0].cpu().numpy(), rel=1e-6, name="quad vs pair records", levels=m_ref)
+    assert_close(outs["1"][1], outs["0"][1].cpu().numpy(), rel=1e-6, name="quad vs pair records, max_level", levels=m_ref)
+    assert_close(outs["1"][2].float(), outs["0"][2].float().cpu().numpy(), rel=1e-3, name="quad vs pair records, half", levels=m_ref)
+
+
 @pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth"])
 @pytest.mark.parametrize("coherent", [False, True])
 def test_vm_stage_a_three_threads_per_point(oracle, dev, case, coherent, monkeypatch):
