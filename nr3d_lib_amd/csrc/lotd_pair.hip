@@ -118,12 +118,12 @@ __device__ __forceinline__ float pair_wp2(float wp, float Cm, float Em, float &C
 // Quad records (first order, Dense levels, quad_on): the pairs (x, y) and (x, y + 1) of a Dense level are neighbours in memory
 // as well -- rows r and r + 1 of the table -- so ONE 16-byte record can carry the four entries e, e + 1, e + Rz, e + Rz + 1 with
 // A_f = g_f w_x and both weights (w_y, w_z) as 24-bit fractions: half the record bytes of a Dense level (qmask bit bx: rows r,
-// r + 1 of x-corner bx lie in one bucket; wxy = {w_x, w_y}).
+// r + 1 of x-corner bx lie in one bucket; wy = w_y; g_f w_x is the sum of the two pairs' A_f = g_f w_x (1 - w_y), g_f w_x w_y).
 template <bool SECOND = false>
 __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t epb, uint32_t lg, const float (&xp)[3], float g0,
                                              float g1, bool smooth, uint32_t (&hdr)[4], uint32_t (&bkt)[4], float (&A)[4][2],
                                              float (&wpm)[SECOND ? 4 : 1], uint32_t (&cell)[3], uint32_t nb, bool &valid,
-                                             const float *__restrict__ vin, uint32_t &qmask, float (&wxy)[2], bool quad_on) {
+                                             const float *__restrict__ vin, uint32_t &qmask, float &wy, bool quad_on) {
 	// wpm: one pair weight per record in the second-order form, ONE for all four in the first-order form (the first-order
 	// stage-A kernel sits exactly at its 64-register budget: four copies of the same value spilled)
 	// valid: every pair lies inside ONE bucket of the level.  True by construction for x in [0, 1] (what the Python layer
@@ -136,8 +136,7 @@ __device__ __forceinline__ void pair_records(const Lvl &L, uint32_t sh, uint32_t
 #pragma unroll
 		for (int d = 0; d < 3; ++d) a[d] = c.sc[d] * vin[d] * c.dw[d];
 	}
-	qmask = 0;
-	if constexpr (!SECOND) { wxy[0] = c.w[0]; wxy[1] = c.w[1]; }
+	if constexpr (!SECOND) { qmask = 0; wy = c.w[1]; }
 	if (L.type == NR3D_LOD_Dense) {
 		const float wp = c.w[2];
 #pragma unroll
@@ -226,7 +225,7 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 	constexpr int kW = SECOND ? 3 : 0;                   // wp[m & kW]: per record (second order) or shared
 	constexpr bool QUADS = !SECOND;                      // qmask stays 0 for Hash levels and with quad_on off
 	uint32_t qmask = 0;
-	float wxy[2] = {0.0f, 0.0f};
+	float wy = 0.0f;
 	float A[4][2], wp[SECOND ? 4 : 1];
 #pragma unroll
 	for (int m = 0; m < 4; ++m) { hdr[m] = 0; bkt[m] = 0; A[m][0] = 0.0f; A[m][1] = 0.0f; wp[m & kW] = 0.0f; }
@@ -234,7 +233,7 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 		for (uint32_t b = threadIdx.x; b <= kPMaxNb; b += kPBP) zero_next[b] = 0;
 	if (active) {
 		bool valid;
-		pair_records<SECOND>(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, nb, valid, vin, qmask, wxy,
+		pair_records<SECOND>(L, plan.shift[ql], plan.epb[ql], plan.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, nb, valid, vin, qmask, wy,
 		                     quad_on);
 		active = valid;
 	}
@@ -283,6 +282,7 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 
 	// ---- rank inside the bucket (split lanes take two consecutive slots per pair) ----
 	uint32_t rank[4] = {0, 0, 0, 0};
+	const uint32_t cnt = emit ? (split ? 2u : 1u) : 0u;      // per slot that holds a record
 	// slot m holds a record unless its pair travels inside the quad of slot m - 2 (quads only from unmerged lanes)
 	auto emits = [&](int m) {
 		if constexpr (QUADS) return emit && !(!split && m >= 2 && ((qmask >> (m - 2)) & 1u));
@@ -333,7 +333,7 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 					if (mine) { rank[m] = first + (uint32_t)(__popcll(m1 & below) + __popcll(m2 & below)); done = true; }
 				}
 			}
-			if (!done) rank[m] = atomicAdd(&hist[bv], split ? 2u : 1u);
+			if (!done) rank[m] = atomicAdd(&hist[bv], cnt);
 		}
 	}
 	__syncthreads();
@@ -361,16 +361,15 @@ __device__ __forceinline__ void pair_level(const PairPlan &plan, uint32_t ql, co
 	if (emit) {
 #pragma unroll
 		for (int m = 0; m < 4; ++m) {
-			if (!emits(m)) continue;
+			if constexpr (QUADS) { if (!emits(m)) continue; }
 			const uint32_t pos = hist[bkt[m]] + rank[m];
 			if (QUADS && !split && m < 2 && ((qmask >> m) & 1u)) {
 				// quad record: x = i0 | w_y bits 8..20 << 13 | 4 << 26 | w_y bits 21..23 << 29, y = w_z (24 bits) | w_y bits 0..7 << 24,
 				// z / w = g_f w_x; stage B adds (1 - w_y)(1 - w_z), (1 - w_y) w_z, w_y (1 - w_z), w_y w_z times that to the entries
 				// i0, i0 + 1, i0 + Rz, i0 + Rz + 1
-				const uint32_t wzq = (uint32_t)__float2uint_rn(wp[0] * 16777215.0f), wyq = (uint32_t)__float2uint_rn(wxy[1] * 16777215.0f);
-				const float ax = m ? wxy[0] : 1.0f - wxy[0];
+				const uint32_t wzq = (uint32_t)__float2uint_rn(wp[0] * 16777215.0f), wyq = (uint32_t)__float2uint_rn(wy * 16777215.0f);
 				stage[pos] = u32x4{(hdr[m] & 8191u) | (((wyq >> 8) & 8191u) << 13) | (4u << 26) | ((wyq >> 21) << 29),
-				                   wzq | ((wyq & 255u) << 24), __float_as_uint(g0 * ax), __float_as_uint(g1 * ax)};
+				                   wzq | ((wyq & 255u) << 24), __float_as_uint(A[m][0] + A[m + 2][0]), __float_as_uint(A[m][1] + A[m + 2][1])};
 			} else if (!split) {
 				stage[pos] = u32x4{hdr[m] | (3u << 26), __float_as_uint(wp[m & kW]), __float_as_uint(A[m][0]), __float_as_uint(A[m][1])};
 			} else {
@@ -876,8 +875,8 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 				for (int d = 0; d < 3; ++d) vin[d] = vin_[(size_t)i * 3 + d];
 			}
 			uint32_t qmask;
-			float wxy[2];
-			pair_records<SECOND>(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, dp.nb[e], valid, vin, qmask, wxy, false);
+			float wy_unused;
+			pair_records<SECOND>(L, dp.shift[e], dp.epb[e], dp.lg, xp, g0, g1, smooth != 0, hdr, bkt, A, wp, cell, dp.nb[e], valid, vin, qmask, wy_unused, false);
 			float lo[4][2], hi[4][2];
 #pragma unroll
 			for (int m = 0; m < 4; ++m)
