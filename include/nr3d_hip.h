@@ -6,7 +6,7 @@
  * success, nonzero on failure with a message available from nr3d_last_error() (thread-local).
  *
  * Ownership: the CALLER allocates every buffer (inputs and outputs) on the device the stream
- * belongs to; the library holds no state besides the thread-local error string.  Buffers documented
+ * belongs to; the library holds no state besides the thread-local error string and the option table below.  Buffers documented
  * "zero-init" must be zeroed by the caller; all other outputs are fully written by the kernels
  * (skipped points are written as zeros), so they may be allocated uninitialised.
  *
@@ -44,6 +44,36 @@ enum {
 };
 void nr3d_prof_enable(uint32_t mask);
 int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, int reset);
+
+/* Selectable code paths (round 4: ONE table instead of environment switches; no launch reads the environment).
+ * Every entry chooses between two implementations of the SAME result -- the parity tests run both and compare them with
+ * each other and with the oracle -- so a caller never needs them; they exist for A/B measurement and cross-checks.
+ * nr3d_set_option(id, value): value < 0 restores the default; returns nonzero for an unknown id.  Process-wide, read at
+ * launch time: set them before other threads launch (a plain int, no lock).  nr3d_get_option: current value, -1 if unknown.
+ * Measurement knobs and timing experiments are NOT options: they exist only in a -DNR3D_EXPERIMENTS build. */
+enum {
+	NR3D_OPT_LOTD_PAIR = 0,          /* 1: pair / quad records for dL/dparam of 3-D Dense/Hash metas (lotd_pair.hip); 0: corner records */
+	NR3D_OPT_PAIR_QUAD = 1,          /* 1: Dense levels of the pair path as quad records */
+	NR3D_OPT_PAIR_SECOND = 2,        /* 1: d(dL/dx)/dparam of pair-path metas on pair records */
+	NR3D_OPT_PAIR_DIRECT = 3,        /* 1: levels with <= 4 buckets skip the records (k_pair_direct) */
+	NR3D_OPT_PAIR_FIXED = 4,         /* 1: 64-bit fixed-point LDS accumulators; 0: fp64 */
+	NR3D_OPT_FWD_PAIRLANE = 5,       /* 1: two-lane forward / Hessian kernels for 3-D Dense/Hash metas; 0: k_fwd (corner sum) */
+	NR3D_OPT_FWD_SPLIT = 6,          /* 1: mixed metas launch per level type */
+	NR3D_OPT_FWD_LDS_STAGE = 7,      /* 1: coarse Dense levels staged in LDS (k_fwd_lds) */
+	NR3D_OPT_HVP_LEVELS = 8,         /* 1: d(dL/dx)/dx with one lane per (point, level) when a workspace is given */
+	NR3D_OPT_HVP_PAIRLANE = 9,       /* 1: ... through the two-lane gather */
+	NR3D_OPT_HVP_SPLIT = 10,         /* 1: lane-serial d(dL/dx)/dx launches per level type */
+	NR3D_OPT_VM_SPLIT = 11,          /* 1: stage A of VM levels with three threads per point */
+	NR3D_OPT_CP_DIRECT = 12,         /* 1: CP levels' dL/dparam accumulated in LDS without records */
+	NR3D_OPT_MARCH_GROUP = 13,       /* 0: lanes per ray chosen from the ray count; 1 | 16 | 32 | 64 forces */
+	NR3D_OPT_PACK_SCAN = 14,         /* 1: fused composite on wave prefix products; 0: serial replay */
+	NR3D_OPT_VM_LINES_DIRECT = 15,   /* 1: VM line-table gradients accumulated in LDS, plane updates as records only */
+	NR3D_OPT_FWD_CELL_MAJOR = 16,    /* 1: forward reads a cell-major replica of the mid Dense levels when the caller supplies one */
+	NR3D_OPT_SORT_WAVE = 17,         /* 1: packed_sort with one wave per pack (bitonic); 0: one lane per pack (heapsort) */
+	NR3D_OPT_COUNT = 18
+};
+int nr3d_set_option(int id, int64_t value);
+int64_t nr3d_get_option(int id);
 
 /* =================================================================================================
  * LoTD encoder -- replaces nr3d_lib.bindings._lotd
@@ -186,24 +216,13 @@ int nr3d_lotd_half_params_ok(const nr3d_lotd_meta_t *meta, int batched);
  * all levels; the library zero-fills it itself otherwise).  workspace as nr3d_lotd_bwd_dparam. */
 int nr3d_lotd_pair_path_ok(const nr3d_lotd_meta_t *meta);
 /* pseudo levels of a pair-path meta whose dL/dparam is accumulated straight from (x, dL_dy) in LDS instead of through
- * records (levels with <= 4 buckets; 0 when the pair path does not apply or NR3D_PAIR_DIRECT=0).  Informational: which
+ * records (levels with <= 4 buckets; 0 when the pair path does not apply or NR3D_OPT_PAIR_DIRECT is 0).  Informational: which
  * kernel serves which level (bench.py's per-kernel byte model). */
 int nr3d_lotd_pair_direct_levels(const nr3d_lotd_meta_t *meta, uint32_t n_points);
 int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points, int grad_dtype,
                                const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,
                                int out_dtype, int assign, void *dL_dparam, void *workspace, uint64_t workspace_bytes,
                                void *stream);
-/* dL/dx AND dL/dparam in one pass over dL_dy (k_pair_bin_all, lotd_pair.hip): the same results, bit for bit, as
- * nr3d_lotd_bwd_dx followed by nr3d_lotd_bwd_dparam_typed -- the reference's kernel_lod_backward_input +
- * kernel_lod_backward (lotd_torch_api.cu:455-573) -- for metas where nr3d_lotd_bwd_fused_ok() returns 1 (pair-record
- * path, <= 32 encoded dims).  dL_dy [N, E] with strides (g_sn, g_se) in elements, dtype grad_dtype; dy_dx as handed out
- * by nr3d_lotd_fwd with strides (d_sn, d_se); dL_dx contiguous float [N, 3]; dL_dparam / assign / workspace as
- * nr3d_lotd_bwd_dparam_typed. */
-int nr3d_lotd_bwd_fused_ok(const nr3d_lotd_meta_t *meta);
-int nr3d_lotd_bwd_fused(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points, int grad_dtype,
-                        const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, const void *dy_dx, int64_t d_sn,
-                        int64_t d_se, int32_t max_level, int out_dtype, int assign, void *dL_dparam, void *dL_dx,
-                        void *workspace, uint64_t workspace_bytes, void *stream);
 
 /* lod_bwd_bwd_input (lotd_torch_api.cu:575-729), three independent outputs:
  * (i)  dL_ddLdy[i, e] = sum_d dL_ddLdx[i, d] * dy_dx[i, e, d]      (lotd_encoding.h:1703-1727) */

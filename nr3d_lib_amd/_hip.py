@@ -112,6 +112,45 @@ def prof_read(name, reset=True):
     return float(ms.value), int(n.value)
 
 
+# ---- selectable code paths (include/nr3d_hip.h: NR3D_OPT_*) -------------------------------------------------------
+OPTION_IDS = dict(lotd_pair=0, pair_quad=1, pair_second=2, pair_direct=3, pair_fixed=4, fwd_pairlane=5, fwd_split=6,
+                  fwd_lds_stage=7, hvp_levels=8, hvp_pairlane=9, hvp_split=10, vm_split=11, cp_direct=12, march_group=13,
+                  pack_scan=14, vm_lines_direct=15, fwd_cell_major=16, sort_wave=17)
+
+
+def set_option(name, value):
+    """choose between two implementations of the same result (A/B measurement, cross-checks in the tests); value < 0 (or None)
+    restores the default.  Process-wide: set it before other threads launch."""
+    l = lib()
+    l.nr3d_set_option.argtypes = [C.c_int, C.c_int64]
+    check(l.nr3d_set_option(OPTION_IDS[name], -1 if value is None else int(value)))
+
+
+def get_option(name):
+    l = lib()
+    l.nr3d_get_option.restype = C.c_int64
+    l.nr3d_get_option.argtypes = [C.c_int]
+    return int(l.nr3d_get_option(OPTION_IDS[name]))
+
+
+class options:
+    """``with options(pair_quad=0): ...`` -- set, run, restore the previous values"""
+
+    def __init__(self, **kw):
+        self.kw, self.old = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
+
+
 def ptr(t):
     """Device (or host) address of a tensor as c_void_p; None -> NULL."""
     if t is None:
@@ -149,18 +188,26 @@ def on_device(dev):
     return torch.cuda.device(idx)
 
 
-_pinned = {}
+_tls = threading.local()
 
 
 def read_i64(t):
     """the (few) int64 values of device tensor ``t`` as python ints: THE device->host sync of a two-phase op.  Goes through
-    a per-device pinned staging buffer (async copy + stream sync) instead of ``.item()`` / ``.tolist()``, which stage through
-    pageable memory: ~10 us less per op, which is visible where an op is launch bound (configs[2]: 4096 rays)."""
+    a pinned staging buffer (async copy + stream sync) instead of ``.item()`` / ``.tolist()``, which stage through
+    pageable memory: ~10 us less per op, which is visible where an op is launch bound (configs[2]: 4096 rays).
+
+    The staging buffers are THREAD-LOCAL (keyed by device and size inside the thread): two host threads working on
+    different streams of one device never see each other's counts between the copy and the read
+    (tests/test_occ_grid_gpu.py::test_marcher_two_threads_two_streams).  Within a thread the copy, the stream
+    synchronisation and the read happen back to back, so one buffer per (device, n) is enough there."""
     n = t.numel()
+    pinned = getattr(_tls, "pinned", None)
+    if pinned is None:
+        pinned = _tls.pinned = {}
     key = (t.device.index, n)
-    buf = _pinned.get(key)
+    buf = pinned.get(key)
     if buf is None:
-        buf = _pinned[key] = torch.empty(n, dtype=torch.int64, pin_memory=True)
+        buf = pinned[key] = torch.empty(n, dtype=torch.int64, pin_memory=True)
     buf.copy_(t.view(-1), non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
     return buf.tolist()

@@ -466,21 +466,8 @@ def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_o
         gsn, gse = _strides2(g32)
         st = H.stream_of(input)
         tag = ("dx" if need_input_grad else "") + ("dp" if need_param_grad else "")
-        # both gradients of a pair-path meta: ONE pass over dL_dy (nr3d_lotd_bwd_fused) instead of dL/dx + feature-major
-        # copy + scatter
-        fused = (typed and need_input_grad and need_param_grad and max_level >= 0
-                 and bool(H.lib().nr3d_lotd_bwd_fused_ok(C.byref(m._cmeta()))))
         with _Prof(m, f"LoTD{D}-bwd-{tag}", N):
             gT = None
-            if fused:
-                j, jsn, jse = _jac_view(dy_dx.detach(), N, E, D)
-                ws, wsb = _dparam_workspace(m, N, dev, 1)
-                H.check(H.lib().nr3d_lotd_bwd_fused(
-                    C.byref(m._cmeta()), H.ptr(m._dev(dev)), H.u32(N), C.c_int(gcode), H.ptr(g32), H.i64(gsn), H.i64(gse),
-                    H.ptr(_f32c(input.detach())), H.ptr(j), H.i64(jsn), H.i64(jse), H.i32(max_level),
-                    C.c_int(H.F16 if native else H.F32), C.c_int(1), H.ptr(dL_dparam), H.ptr(dL_dx), H.ptr(ws),
-                    C.c_uint64(wsb), st))
-                return _cast(dL_dx, input.dtype), _cast(dL_dparam, params.dtype)
             if need_input_grad and N > 0:
                 j, jsn, jse = _jac_view(dy_dx.detach(), N, E, D)
                 # both gradients wanted: the dL/dx kernel stages dL_dy through LDS anyway and leaves the feature-major

@@ -7,6 +7,7 @@
 #include <stdarg.h>
 
 #include "../../include/nr3d_hip.h"
+#include "options.h"
 
 namespace nr3d {
 

@@ -1,6 +1,8 @@
 // nr3d_lib_amd/csrc/host_api.hip -- host-only parts of the C ABI: error string, ABI version and the
 // LoTD meta builder (reference: LoDMeta::create_meta, csrc/lotd/src/lotd_torch_api.cu:29-230).
 #include "common.h"
+#include <stdlib.h>
+#include <utility>
 #include <string.h>
 #include <limits>
 #include <mutex>
@@ -46,6 +48,29 @@ void end(int id, hipStream_t st) {
 }
 }  // namespace prof
 
+namespace opt {
+static const int64_t kDefault[NR3D_OPT_COUNT] = {
+	/* LOTD_PAIR */ 1, /* PAIR_QUAD */ 1, /* PAIR_SECOND */ 1, /* PAIR_DIRECT */ 1, /* PAIR_FIXED */ 1, /* FWD_PAIRLANE */ 1,
+	/* FWD_SPLIT */ 1, /* FWD_LDS_STAGE */ 1, /* HVP_LEVELS */ 1, /* HVP_PAIRLANE */ 1, /* HVP_SPLIT */ 1, /* VM_SPLIT */ 1,
+	/* CP_DIRECT */ 1, /* MARCH_GROUP */ 0, /* PACK_SCAN */ 1, /* VM_LINES_DIRECT */ 1, /* FWD_CELL_MAJOR */ 1, /* SORT_WAVE */ 1,
+};
+int64_t g_val[NR3D_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1};
+
+#ifdef NR3D_EXPERIMENTS
+// measurement knobs of the experiments build: NR3D_<NAME> from the environment, looked up once per name
+int64_t experiment_env(const char *name, int64_t dflt) {
+	static std::mutex mu;
+	static std::vector<std::pair<const char *, int64_t>> seen;
+	std::lock_guard<std::mutex> lk(mu);
+	for (const auto &kv : seen) if (kv.first == name) return kv.second;        // string literals: pointer identity
+	const char *e = getenv(name);
+	const int64_t v = e ? (int64_t)atoll(e) : dflt;
+	seen.emplace_back(name, v);
+	return v;
+}
+#endif
+}  // namespace opt
+
 }  // namespace nr3d
 
 using namespace nr3d;
@@ -71,8 +96,15 @@ extern "C" int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, i
 	return 0;
 }
 
+extern "C" int nr3d_set_option(int id, int64_t value) {
+	NR3D_CHECK(id >= 0 && id < NR3D_OPT_COUNT, "nr3d_set_option: unknown option %d", id);
+	opt::g_val[id] = value < 0 ? opt::kDefault[id] : value;
+	return 0;
+}
+extern "C" int64_t nr3d_get_option(int id) { return (id >= 0 && id < NR3D_OPT_COUNT) ? opt::g_val[id] : -1; }
+
 extern "C" const char *nr3d_last_error(void) { return err_buf(); }
-extern "C" int nr3d_abi_version(void) { return 3; }
+extern "C" int nr3d_abi_version(void) { return 4; }
 
 extern "C" int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, const int32_t *res_multidim,
                                      const int32_t *n_feats, const int32_t *types, uint32_t hashmap_size,

@@ -331,7 +331,8 @@ template <> __device__ __forceinline__ void store_nt<__half>(__half *p, float v)
 // the same channels -- the times add instead of overlapping.  More groups in flight (SUB 1 / 2 / 4 / 8: 358 / 352 / 358
 // / 355 us at 2^20), plain instead of non-temporal stores (373), a row pitch that is not a power of two (no change), x
 // through the scalar cache (+14 us on the round-2 kernel) do not move it.
-// NR3D_FWD_DBG (timing experiments, results wrong by design): bit 0 no stores, bit 1 no gathers, bit 2 no x loads.
+// `dbg` exists in a -DNR3D_EXPERIMENTS build only (timing experiments, results wrong by design): bit 0 no stores, bit 1 no
+// gathers, bit 2 no x loads; in the production build it is the constant 0 and these branches fold away.
 // =============================================================================================
 constexpr int kPlSub = 2;                          // 32-point groups per wave
 // one work item = pseudo level q x the block's `chunk` of kPlPts * SUB points
@@ -339,7 +340,8 @@ template <bool DYDX, typename PT, int SUB>
 __device__ __forceinline__ void pl_item(uint32_t q, uint32_t chunk, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                         int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                         const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn, int64_t y_se,
-                                        float *__restrict__ dydx, int64_t d_sn, int64_t d_se, uint32_t dbg) {
+                                        float *__restrict__ dydx, int64_t d_sn, int64_t d_se NR3D_DBG_PARAM) {
+	NR3D_DBG_DECL
 	constexpr uint32_t kGroup = 32;                        // points per wave and sub-step
 	constexpr uint32_t kPts = kPlPts * SUB;                // points per block
 	const uint32_t lane = threadIdx.x & 63u, side = lane & 1u, pl = lane >> 1;
@@ -484,10 +486,10 @@ template <bool DYDX, typename PT, int SUB>
 __global__ __launch_bounds__(kBlock) void k_fwd_pairlane(Sched s, const nr3d_lotd_meta_t *__restrict__ md, uint32_t N,
                                                    int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                                    const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
-                                                   int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se, uint32_t dbg) {
+                                                   int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se NR3D_DBG_PARAM) {
 	uint32_t q, chunk;
 	if (!decode_block(s, blockIdx.x, q, chunk)) return;
-	pl_item<DYDX, PT, SUB>(q, chunk, md, N, max_level, smooth, x, params, y, y_sn, y_se, dydx, d_sn, d_se, dbg);
+	pl_item<DYDX, PT, SUB>(q, chunk, md, N, max_level, smooth, x, params, y, y_sn, y_se, dydx, d_sn, d_se NR3D_DBG_ARG(dbg));
 }
 
 // Tried and dropped (round 3, profiles/r03e_dynamic_handout_experiment.txt): handing the items out dynamically -- resident
@@ -1010,7 +1012,8 @@ __global__ __launch_bounds__(kBlock) void k_bwd_bwd_dx_pl(Sched s, const nr3d_lo
                                                           int32_t max_level, uint32_t smooth, const float *__restrict__ dL_ddLdx,
                                                           const float *__restrict__ g_pairs, int64_t g_fm,
                                                           const float *__restrict__ x, const PT *__restrict__ params,
-                                                          float *__restrict__ partial, uint32_t dbg) {
+                                                          float *__restrict__ partial NR3D_DBG_PARAM) {
+	NR3D_DBG_DECL
 	// g_fm == 0: g_pairs is the [pseudo level][point][2] copy of k_hvp_pairs; > 0: the caller's dL_dy is feature-major already
 	// (element (i, e) at e * g_fm + i, e.g. the copy the dL/dparam pass of the same step uses) and is read in place
 	uint32_t q, chunk;
@@ -1322,22 +1325,10 @@ __global__ __launch_bounds__(kBlock) void k_grid_index(Sched s, const nr3d_lotd_
 // =============================================================================================
 // Host side
 // =============================================================================================
-static uint32_t sched_mode_default() {
-	static int mode = -1;
-	if (mode < 0) {
-		const char *e = getenv("NR3D_LOTD_SCHED");
-		mode = e ? atoi(e) : 3;
-		if (mode < 0 || mode > 3) mode = 3;
-	}
-	return (uint32_t)mode;
-}
-
-// NR3D_LOTD_SCHED_EXCL=0: the two-lane forward uses the cost-balanced work line like every other kernel (A/B)
-static bool sched_exclusive_enabled() {
-	static int on = -1;
-	if (on < 0) { const char *e = getenv("NR3D_LOTD_SCHED_EXCL"); on = e ? (atoi(e) != 0) : 1; }
-	return on != 0;
-}
+// knobs of the experiments build (options.h): the schedule mode, and LOTD_SCHED_EXCL = 0 for the cost-balanced work line in the
+// two-lane forward like every other kernel (A/B)
+static uint32_t sched_mode_default() { const int64_t m = NR3D_XOPT(LOTD_SCHED, 3); return (m < 0 || m > 3) ? 3u : (uint32_t)m; }
+static bool sched_exclusive_enabled() { return NR3D_XOPT(LOTD_SCHED_EXCL, 1) != 0; }
 
 // estimated cost of one (point, pseudo level) item, in half L2 requests (see lotd_device.h, mode 3)
 static uint32_t level_cost(const nr3d_lotd_meta_t *m, uint32_t q, bool pairlane = false) {
@@ -1471,21 +1462,9 @@ static Sched make_sched(uint32_t N, const nr3d_lotd_meta_t *m, uint32_t &n_block
 	return s;
 }
 
-static bool pairlane_enabled() {
-	static int on = -1;
-	if (on < 0) { const char *e = getenv("NR3D_LOTD_FWD_PAIRLANE"); on = e ? (atoi(e) != 0) : 1; }
-	return on != 0;
-}
-static bool lds_stage_enabled() {
-	static int on = -1;
-	if (on < 0) { const char *e = getenv("NR3D_LOTD_LDS_STAGE"); on = e ? (atoi(e) != 0) : 1; }
-	return on != 0;
-}
-static uint32_t lds_stage_min_points() {
-	static int v = -1;
-	if (v < 0) { const char *e = getenv("NR3D_LOTD_LDS_MIN_POINTS"); v = e ? atoi(e) : (1 << 18); if (v < 1) v = 1; }
-	return (uint32_t)v;
-}
+static bool pairlane_enabled() { return opt::on(NR3D_OPT_FWD_PAIRLANE); }
+static bool lds_stage_enabled() { return opt::on(NR3D_OPT_FWD_LDS_STAGE); }
+static uint32_t lds_stage_min_points() { const int64_t v = NR3D_XOPT(LOTD_LDS_MIN_POINTS, 1 << 18); return v < 1 ? 1u : (uint32_t)v; }
 
 static int check_common(const nr3d_lotd_meta_t *m, const void *meta_dev, int x_dtype, int p_dtype, bool half_params_ok = false) {
 	NR3D_CHECK(m != nullptr, "LoTD: meta is NULL");
@@ -1565,8 +1544,7 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds<false, PT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsGroupBytes));
 			attr_set_dev[dev_id & 63] = true;
 		}
-		static int pair_levels = -1;                        // NR3D_LOTD_LDS_PAIR=0: one launch per staged level (A/B)
-		if (pair_levels < 0) { const char *e = getenv("NR3D_LOTD_LDS_PAIR"); pair_levels = e ? (atoi(e) != 0) : 1; }
+		const bool pair_levels = NR3D_XOPT(LOTD_LDS_PAIR, 1) != 0;     // experiments build: 0 = one launch per staged level (A/B)
 		LdsLevels grp;
 		uint32_t n_grp = 0, grp_bytes = 0;
 		auto flush = [&]() {
@@ -1591,9 +1569,10 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 		}
 		flush();
 	}
-	static int dbg = -1, only = -2;
-	if (dbg < 0) { const char *e = getenv("NR3D_FWD_DBG"); dbg = e ? atoi(e) : 0; }
-	if (only == -2) { const char *e = getenv("NR3D_FWD_ONLY_LEVEL"); only = e ? atoi(e) : -1; }      // timing experiments: one pseudo level
+	// timing experiments (experiments build only; results wrong by design): FWD_DBG bit 0 no stores, 1 no gathers, 2 no x loads;
+	// FWD_ONLY_LEVEL = one pseudo level
+	const int64_t dbg = NR3D_XOPT(FWD_DBG, 0), only = NR3D_XOPT(FWD_ONLY_LEVEL, -1);
+	(void)dbg;
 	if (only >= 0) for (uint32_t q = 0; q < meta->n_pseudo_levels && q < 64u; ++q) if ((int)q != only) staged |= 1ull << q;
 	uint32_t n_blocks;
 	const Sched s = make_sched(N, meta, n_blocks, staged, (uint32_t)(kPlPts * kPlSub), true);
@@ -1601,10 +1580,10 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 		prof::Scope ps(NR3D_PROF_LOTD_FWD, st);
 		if (dy_dx)
 			hipLaunchKernelGGL((k_fwd_pairlane<true, PT, kPlSub>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
-			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se, (uint32_t)dbg);
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se NR3D_DBG_ARG(dbg));
 		else
 			hipLaunchKernelGGL((k_fwd_pairlane<false, PT, kPlSub>), dim3(n_blocks), dim3(kBlock), 0, st, s, md, N, max_level,
-			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se, (uint32_t)dbg);
+			                   meta->interpolation_type, x, params, y, y_sn, y_se, dy_dx, d_sn, d_se NR3D_DBG_ARG(dbg));
 	}
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -1668,8 +1647,7 @@ static int fwd_generic(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md,
 	// general one.  NR3D_LOTD_FWD_SPLIT=0: one launch.
 	// Likewise CP and VM levels (3-D) have instantiations of their own: the product types share one code path otherwise.
 	uint64_t grp[4] = {0, 0, 0, 0};                      // pseudo levels served by: 0 general, 1 Dense / Hash, 2 CP, 3 VM
-	const char *split_env = getenv("NR3D_LOTD_FWD_SPLIT");
-	const bool split = !dh && meta->n_pseudo_levels <= 64u && !(split_env && split_env[0] == '0');
+	const bool split = !dh && meta->n_pseudo_levels <= 64u && opt::on(NR3D_OPT_FWD_SPLIT);
 	const uint64_t all = meta->n_pseudo_levels >= 64u ? ~0ull : ((1ull << meta->n_pseudo_levels) - 1ull);
 	if (split) {
 		for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
@@ -1756,7 +1734,7 @@ static int launch_bwd_dparam(bool second, const nr3d_lotd_meta_t *meta, const vo
 		if (int rc = dparam_binned(second, meta, meta_dev, N, (const float *)dL_ddLdx, (const float *)dL_dy, g_sn, g_se,
 		                           (const float *)x, (const float *)params, bb, batched ? n_batches : 1u, max_level,
 		                           (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, nullptr,
-		                           min_level, false, false, false, nullptr, p_half))
+		                           min_level, false, false, false, p_half))
 			return rc;
 		if (handled) return 0;
 	}
@@ -1824,36 +1802,6 @@ extern "C" int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const vo
 	return 0;
 }
 
-extern "C" int nr3d_lotd_bwd_fused_ok(const nr3d_lotd_meta_t *meta) { return meta && pair_all_applies(meta) ? 1 : 0; }
-
-// dL/dx and dL/dparam of one dL_dy in one pass over it (lotd_pair.hip, k_pair_bin_all): what nr3d_lotd_bwd_dx followed by
-// nr3d_lotd_bwd_dparam_typed compute, bit for bit, without the feature-major copy of dL_dy in between
-extern "C" int nr3d_lotd_bwd_fused(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int grad_dtype,
-                                   const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, const void *dy_dx,
-                                   int64_t d_sn, int64_t d_se, int32_t max_level, int out_dtype, int assign, void *dL_dparam,
-                                   void *dL_dx, void *workspace, uint64_t workspace_bytes, void *stream) {
-	if (int rc = check_common(meta, meta_dev, NR3D_F32, NR3D_F32)) return rc;
-	NR3D_CHECK((grad_dtype == NR3D_F32 || grad_dtype == NR3D_F16) && (out_dtype == NR3D_F32 || out_dtype == NR3D_F16),
-	           "LoTD::bwd_fused: f32 / f16 only");
-	NR3D_CHECK(pair_all_applies(meta), "LoTD::bwd_fused: not served for this meta (nr3d_lotd_bwd_fused_ok)");
-	NR3D_CHECK(max_level >= 0, "LoTD::bwd_fused: max_level must be >= 0");
-	if (N == 0) {
-		if (assign && dL_dparam)
-			NR3D_HIP_CHECK(hipMemsetAsync(dL_dparam, 0, (size_t)meta->n_params * (out_dtype == NR3D_F16 ? 2 : 4), (hipStream_t)stream));
-		return 0;
-	}
-	NR3D_CHECK(dL_dy && x && dy_dx && dL_dparam && dL_dx && workspace, "LoTD::bwd_fused: NULL tensor pointer");
-	bool handled = false;
-	const Batch bb{nullptr, nullptr, 0u, meta->n_params};
-	const FusedDx fdx{(const float *)dy_dx, d_sn, d_se, (float *)dL_dx};
-	if (int rc = dparam_binned(false, meta, meta_dev, N, nullptr, (const float *)dL_dy, g_sn, g_se, (const float *)x, nullptr, bb,
-	                           1u, max_level, (float *)dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, nullptr,
-	                           0, grad_dtype == NR3D_F16, out_dtype == NR3D_F16, assign != 0, &fdx))
-		return rc;
-	NR3D_CHECK(handled, "LoTD::bwd_fused: workspace too small (nr3d_lotd_dparam_workspace_bytes)");
-	return 0;
-}
-
 extern "C" int nr3d_lotd_bwd_dparam_levels(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, int x_dtype,
                                            int param_dtype, const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x,
                                            const void *params, const int64_t *batch_inds, const int64_t *batch_offsets,
@@ -1917,15 +1865,14 @@ static int launch_bwd_bwd_dx_t(const nr3d_lotd_meta_t *meta, const void *meta_de
 	const bool dh = meta->c_hash_only != 0;
 	const bool vec_ok = (((uintptr_t)params % (2 * sizeof(PT))) == 0 && batch_offsets == nullptr);
 	const uint64_t need = nr3d_lotd_bwd_bwd_dx_workspace_bytes(meta, N);
-	const char *lv_env = getenv("NR3D_LOTD_HVP_LEVELS");             // 0: the lane-serial kernel even with a workspace
-	if (workspace && need && workspace_bytes >= need && !(lv_env && lv_env[0] == '0')) {
+	// NR3D_OPT_HVP_LEVELS = 0: the lane-serial kernel even with a workspace
+	if (workspace && need && workspace_bytes >= need && opt::on(NR3D_OPT_HVP_LEVELS)) {
 		uint32_t n_blocks;
 		const bool batched = batch_inds || batch_offsets || batch_data_size;
-		const char *pl_env = getenv("NR3D_LOTD_HVP_PAIRLANE");
-		const char *dbg_env = getenv("NR3D_HVP_DBG");                  // timing experiments only (results wrong by design)
-		const uint32_t hvp_dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
+		const int64_t hvp_dbg = NR3D_XOPT(HVP_DBG, 0);                 // timing experiments only (experiments build; results wrong by design)
+		(void)hvp_dbg;
 		const bool pl = !batched && pairlane_enabled() && pairlane_meta_ok(meta) && ((uintptr_t)params % (2 * sizeof(PT))) == 0 &&
-		                !(pl_env && pl_env[0] == '0');
+		                opt::on(NR3D_OPT_HVP_PAIRLANE);
 		const Sched s = pl ? make_sched(N, meta, n_blocks, 0, (uint32_t)(kPlPts * kHvpSub), true) : make_sched(N, meta, n_blocks);
 		DISPATCH_DG(meta->n_dims_to_encode, meta->n_feat_per_pseudo_lvl, {
 			auto launch = [&](auto kern) {
@@ -1945,7 +1892,7 @@ static int launch_bwd_bwd_dx_t(const nr3d_lotd_meta_t *meta, const void *meta_de
 				}
 				hipLaunchKernelGGL((k_bwd_bwd_dx_pl<kHvpSub, PT>), dim3(n_blocks), dim3(kBlock), 0, (hipStream_t)stream, s, md, N, max_level,
 				                   meta->interpolation_type, (const float *)dL_ddLdx, g_pairs, g_fm,
-				                   (const float *)x, (const PT *)params, (float *)workspace, hvp_dbg);
+				                   (const float *)x, (const PT *)params, (float *)workspace NR3D_DBG_ARG(hvp_dbg));
 			}
 			else if (dh) launch(k_bwd_bwd_dx_lv<D, G, true, PT>); else launch(k_bwd_bwd_dx_lv<D, G, false, PT>);
 			hipLaunchKernelGGL(k_sum_levels<D>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, N,
@@ -1957,8 +1904,7 @@ static int launch_bwd_bwd_dx_t(const nr3d_lotd_meta_t *meta, const void *meta_de
 	// level groups by type (3-D metas with product types; NR3D_LOTD_HVP_SPLIT=0: one launch): 0 Dense / Hash, 2 VM, 3 VecZMatXoY;
 	// the other types have no d(dL/dx)/dx term (hvp_type) and get no launch
 	uint32_t grp[4] = {0, 0, 0, 0};
-	const char *hs_env = getenv("NR3D_LOTD_HVP_SPLIT");
-	const bool by_type = !dh && meta->n_dims_to_encode == 3 && meta->n_levels <= 32u && !(hs_env && hs_env[0] == '0');
+	const bool by_type = !dh && meta->n_dims_to_encode == 3 && meta->n_levels <= 32u && opt::on(NR3D_OPT_HVP_SPLIT);
 	for (uint32_t l = 0; l < meta->n_levels && l < 32u; ++l) {
 		const uint32_t t = meta->levels[l].type;
 		const int k = (t == NR3D_LOD_Dense || t == NR3D_LOD_Hash) ? 0 : t == NR3D_LOD_VectorMatrix ? 2 : t == NR3D_LOD_VecZMatXoY ? 3 : -1;

@@ -38,6 +38,7 @@ constexpr uint32_t kBallotRankBuckets = NR3D_BALLOT_RANK_BUCKETS;   // stage A r
                                                                     // (NGP config, backward ms: 0: 0.880, 4: 0.862, 12: 0.899)
 constexpr int kMaxPlanLevels = 64;        // pseudo levels handled by the binned path
 constexpr uint32_t kMaxBuckets = 8192;    // per pseudo level
+constexpr int kBinLdsDyn = NR3D_BIN_LDS_KB * 1024 + (int)(kMaxBuckets + 1) * 4;   // dynamic LDS of a stage-A workgroup: record stage + bucket histogram
 
 #define DISPATCH_DG_BIN(D_, G_, ...)                                                 \
 	do {                                                                             \
@@ -1028,26 +1029,18 @@ __global__ __launch_bounds__(kAccThreads) void k_reduce_partials(BinPlan plan, c
 // target number of stage-B work items (a bucket holding more than total / units records is split into replicas).
 // Measured on the NGP config, 2^20 points (backward ms): 512: 0.904, 768: 0.884, 900: 0.884, 960: 0.880, 1000: 0.897,
 // 1024: 0.901, 1280: 0.913, 2048: 0.937.
-static uint32_t work_units() {
-	static uint32_t u = 0;
-	if (!u) { const char *e = getenv("NR3D_LOTD_ACC_UNITS"); const int v = e ? atoi(e) : 960; u = (uint32_t)(v < 256 ? 256 : (v > 8192 ? 8192 : v)); }
-	return u;
+static uint32_t work_units() {                  // knob of the experiments build only (options.h)
+	const int64_t v = NR3D_XOPT(LOTD_ACC_UNITS, 960);
+	return (uint32_t)(v < 256 ? 256 : (v > 8192 ? 8192 : v));
 }
 
 // Points per pass of the binned path: the record workspace grows with it (1.6 GB per 2^20 points for the 16-level
 // NGP config), larger passes amortise the per-bucket zero / flush better (2^22 points: backward 3.74 -> 3.51 ms with
-// 2^22 instead of 2^20).  Default 2^22 (288 GB of HBM per GPU); NR3D_LOTD_BIN_CHUNK_LOG2 or
-// nr3d_lotd_set_dparam_chunk_log2() override it.
+// 2^22 instead of 2^20).  Default 2^22 (288 GB of HBM per GPU); nr3d_lotd_set_dparam_chunk_log2() overrides it.
 static int g_chunk_log2 = 0;
 void set_dparam_chunk_log2(int lg) { g_chunk_log2 = lg <= 0 ? 0 : (lg < 10 ? 10 : (lg > 24 ? 24 : lg)); }
 static uint32_t chunk_points(uint32_t n) {
-	static int env_lg = -1;
-	if (env_lg < 0) {
-		const char *e = getenv("NR3D_LOTD_BIN_CHUNK_LOG2");
-		const int lg = e ? atoi(e) : 22;
-		env_lg = lg < 10 ? 10 : (lg > 24 ? 24 : lg);
-	}
-	const uint32_t chunk = 1u << (g_chunk_log2 ? g_chunk_log2 : env_lg);
+	const uint32_t chunk = 1u << (g_chunk_log2 ? g_chunk_log2 : 22);
 	return n < chunk ? n : chunk;
 }
 
@@ -1166,11 +1159,7 @@ __global__ __launch_bounds__(256) void k_cp_reduce(CpPlan cp, const nr3d_lotd_me
 	*dst += sum;
 }
 
-static bool cp_direct_enabled() {
-	static int on = -1;
-	if (on < 0) { const char *e = getenv("NR3D_LOTD_CP_DIRECT"); on = e ? (atoi(e) != 0) : 1; }
-	return on != 0;
-}
+static bool cp_direct_enabled() { return opt::on(NR3D_OPT_CP_DIRECT); }
 // the CP pseudo levels k_cp_direct serves (mask over the meta's pseudo levels; 0: none): unbatched 3-D metas with 2-feature
 // pseudo levels, levels in [min_level, max_level] whose fp64 table fits LDS, partial tables inside `part_floats`
 static uint64_t cp_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level, int32_t max_level, uint64_t part_floats, CpPlan &cp,
@@ -1314,11 +1303,8 @@ uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, ui
 	return lay.total;
 }
 
-// NR3D_LOTD_VM_SPLIT=0: VM levels through the one-thread-per-point stage A (A/B, cross-check)
-static bool vm_split_enabled() {
-	const char *e = getenv("NR3D_LOTD_VM_SPLIT");
-	return !(e && e[0] == '0');
-}
+// NR3D_OPT_VM_SPLIT = 0: VM levels through the one-thread-per-point stage A (A/B, cross-check)
+static bool vm_split_enabled() { return opt::on(NR3D_OPT_VM_SPLIT); }
 
 template <int D, int G, int NR, bool DH>
 static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n,
@@ -1338,11 +1324,11 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 	bool &attr_set = attr_set_dev[dev_id & 63];
 	if (!attr_set) {
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoubles * 8));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
 		if constexpr (!DH) {
-			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
-			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, true, NR, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin<D, G, false, NR, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
 		}
 		attr_set = true;
 	}
@@ -1351,8 +1337,8 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 		if constexpr (D == 3 && (NR == 8 || NR == 24 || NR == 48)) {
 			static bool fattr_dev[64] = {};
 			if (!fattr_dev[dev_id & 63]) {
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, true, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, true, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
 				fattr_dev[dev_id & 63] = true;
 			}
 			auto forest_launch = [&](auto kern, auto *tab) {
@@ -1364,8 +1350,8 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 				if (p_half) {
 					static bool hattr_dev[64] = {};
 					if (!hattr_dev[dev_id & 63]) {
-						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, true, NR, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
-						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false, NR, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, true, NR, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_forest<G, false, NR, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
 						hattr_dev[dev_id & 63] = true;
 					}
 					if (second) forest_launch(k_bin_forest<G, true, NR, __half>, (const __half *)params_);
@@ -1382,10 +1368,10 @@ static int launch_class(bool second, const BinPlan &pl, const nr3d_lotd_meta_t *
 		if constexpr (D == 3 && NR == 24 && !DH) {
 			static bool vattr_dev[64] = {};
 			if (!vattr_dev[dev_id & 63]) {
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
-				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, NR3D_BIN_LDS_KB * 1024 + (kMaxBuckets + 1) * 4));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3<G, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
 				vattr_dev[dev_id & 63] = true;
 			}
 			auto vm_launch = [&](auto kern, auto *tab) {
@@ -1454,17 +1440,14 @@ extern "C" int nr3d_lotd_dLdy_feature_major(uint32_t n_points, uint32_t n_encode
 namespace nr3d {
 namespace lotd {
 
-// NR3D_LOTD_PAIR_SECOND=0: d(dL/dx)/dparam of pair-path metas through the 12-byte corner records (A/B, and the cross-check)
-static bool pair_second_enabled() {              // read per call: the tests compare both routes in one process
-	const char *e = getenv("NR3D_LOTD_PAIR_SECOND");
-	return !(e && e[0] == '0');
-}
+// NR3D_OPT_PAIR_SECOND = 0: d(dL/dx)/dparam of pair-path metas through the 12-byte corner records (A/B, and the cross-check)
+static bool pair_second_enabled() { return opt::on(NR3D_OPT_PAIR_SECOND); }
 
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
                   hipStream_t st, bool &handled, const ForestDev *forest, int32_t min_level, bool g_half, bool out_half, bool assign,
-                  const FusedDx *fdx, bool p_half) {
+                  bool p_half) {
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
@@ -1482,10 +1465,6 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	// an unbatched 3-D Dense/Hash meta with 2-feature pseudo levels: pair records (lotd_pair.hip), first and second order
 	const bool use_pair = !forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size && pair_applies(meta) &&
 	                      !(second && !pair_second_enabled());
-	// ... with every level binned by ONE workgroup per point block, straight from the caller's dL_dy (and dL/dx on the way)
-	const bool use_all = use_pair && !second && pair_all_applies(meta);
-	if (fdx && !(use_all && min_level <= 0))
-		return ::nr3d::fail("LoTD::bwd_fused: the all-levels pair path does not apply (nr3d_lotd_bwd_fused_ok)");
 	if ((g_half || out_half) && !use_pair)
 		return ::nr3d::fail("LoTD::bwd: half gradients are served natively on the pair-record path only (nr3d_lotd_half_params_ok)");
 	// uninitialised dparam: the pair path assigns when ONE pass covers every level; otherwise zero-fill and accumulate
@@ -1503,15 +1482,6 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		Batch ba = batch;                              // this chunk's view of the batch description
 		if (ba.inds) ba.inds += p0;
 		ba.first_point = p0;
-		if (use_all) {
-			FusedDx fc;
-			if (fdx) fc = FusedDx{fdx->dydx + (int64_t)p0 * fdx->d_sn, fdx->d_sn, fdx->d_se, fdx->dL_dx + (size_t)p0 * D};
-			if (int rc = pair_chunk(meta, md, n, xc, gc, g_sn, g_se, min_level, max_level, work_units(), dparam,
-			                        (out_half ? 1u : 0u) | (assign_now ? 2u : 0u), rec, offs, plan_buf, partial, st, true, g_half,
-			                        fdx ? &fc : nullptr))
-				return rc;
-			continue;
-		}
 		if (row_major) {
 			if (g_half)
 				hipLaunchKernelGGL(k_transpose<__half>, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E,
@@ -1522,8 +1492,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		}
 		if (use_pair) {
 			if (int rc = pair_chunk(meta, md, n, xc, gc, sn, se, min_level, max_level, work_units(), dparam,
-			                        (out_half ? 1u : 0u) | (assign_now ? 2u : 0u), rec, offs, plan_buf, partial, st, false, false,
-			                        nullptr, second ? vc : nullptr))
+			                        (out_half ? 1u : 0u) | (assign_now ? 2u : 0u), rec, offs, plan_buf, partial, st,
+			                        second ? vc : nullptr))
 				return rc;
 			continue;
 		}

@@ -731,34 +731,26 @@ __device__ __forceinline__ void locate_forest(const float (&xp)[3], const Lvl &L
 uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches, bool forest = false);
 void set_dparam_chunk_log2(int lg);
 // `forest` != NULL: the points live in the blocks of a forest (n_batches = n_trees); Dense/Hash 3-D metas only
-// dL/dx folded into stage A of the pair path (k_pair_bin_all): the stored Jacobian and where dL/dx goes
-struct FusedDx {
-	const float *dydx;
-	int64_t d_sn, d_se;
-	float *dL_dx;
-};
 // levels below `min_level` are left out (their part of dparam is not touched)
 int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t N, const float *dL_ddLdx,
                   const float *dL_dy, int64_t g_sn, int64_t g_se, const float *x, const float *params, const Batch &batch,
                   uint32_t n_batches, int32_t max_level, float *dparam, void *workspace, uint64_t workspace_bytes,
                   hipStream_t st, bool &handled, const ForestDev *forest = nullptr, int32_t min_level = 0, bool g_half = false,
-                  bool out_half = false, bool assign = false, const struct FusedDx *fdx = nullptr, bool p_half = false);
+                  bool out_half = false, bool assign = false, bool p_half = false);
 // p_half: `params` points to __half tables (the product-type levels read their other factors from them)
 // g_half: dL_dy is __half; out_half: dparam is __half (pair path only); assign: dparam arrives UNINITIALISED -- the pair
 // path writes every element when one pass covers all levels, every other case zero-fills it first
 
 // lotd_pair.hip: pair-record form of the same path for unbatched 3-D Dense/Hash metas with 2-feature pseudo levels
 bool pair_applies(const nr3d_lotd_meta_t *m);
-bool pair_all_applies(const nr3d_lotd_meta_t *m);
-uint32_t pair_direct_levels(const nr3d_lotd_meta_t *m, uint32_t n_points);   // pseudo levels k_pair_direct serves (no records)      // ... and the all-levels stage A (dL_dy row in registers) on top
+uint32_t pair_direct_levels(const nr3d_lotd_meta_t *m, uint32_t n_points);   // pseudo levels k_pair_direct serves (no records)
 void pair_layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t units, uint64_t &rec_bytes, uint64_t &offs_bytes,
                  uint64_t &plan_bytes, uint64_t &part_bytes);
 int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,
                int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam,
                uint32_t out_flags /* bit 0: dparam is __half; bit 1: assign (dparam uninitialised, every element of the
                plan's levels is written) */, void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st,
-               bool all_levels = false /* g is the caller's dL_dy (g_half: __half), any strides */, bool g_half = false,
-               const FusedDx *fdx = nullptr, const float *vin = nullptr /* second order: dL_ddLdx [n, 3] */);
+               const float *vin = nullptr /* second order: dL_ddLdx [n, 3] */);
 
 }  // namespace lotd
 }  // namespace nr3d

@@ -333,7 +333,7 @@ extern "C" int nr3d_lotd_forest_bwd_dparam(const nr3d_lotd_meta_t *meta, const v
 		const int64_t E = meta->n_encoded_dims;
 		if (int rc = dparam_binned(dL_ddLdx != nullptr, meta, meta_dev, N, dL_ddLdx, dL_dy, E, 1, x, (const float *)params, ba,
 		                           forest->n_trees, max_level, dL_dparam, workspace, workspace_bytes, (hipStream_t)stream, handled, &fo,
-		                           0, false, false, false, nullptr, p_half)) return rc;
+		                           0, false, false, false, p_half)) return rc;
 		if (handled) return 0;
 	}
 	const dim3 grid(div_up(N, kBlock), meta->n_pseudo_levels);

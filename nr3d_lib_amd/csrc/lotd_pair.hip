@@ -57,45 +57,17 @@ struct DirectPlan {
 };
 
 
-// points (= threads) per stage-A workgroup; NR3D_PAIR_BP = 512 | 768 | 1024 (measurement knob)
-static uint32_t pair_bp() {
-	static uint32_t v = 0;
-	if (!v) { const char *e = getenv("NR3D_PAIR_BP"); const int x = e ? atoi(e) : 1024; v = (x == 512 || x == 768) ? (uint32_t)x : 1024u; }
-	return v;
-}
-static bool pair_quad_enabled() {                 // read per call: the tests compare both record forms in one process
-	const char *e = getenv("NR3D_PAIR_QUAD");
-	return !(e && e[0] == '0');
-}
-static uint32_t pair_lg() {
-	static uint32_t v = 0;
-	if (!v) { const char *e = getenv("NR3D_PAIR_EPB_LOG2"); const int x = e ? atoi(e) : 12; v = (x == 13) ? 13u : 12u; }
-	return v;
-}
-static uint32_t pair_unroll() {
-	static uint32_t v = 0;
-	if (!v) { const char *e = getenv("NR3D_PAIR_UNROLL"); const int x = e ? atoi(e) : 4; v = (x == 8) ? 8u : 4u; }
-	return v;
-}
-// timing experiments only (results are wrong): bit 0 = no LDS atomics, bit 1 = every lane re-reads one record
-static uint32_t pair_dbg() {
-	static int v = -1;
-	if (v < 0) { const char *e = getenv("NR3D_PAIR_DEBUG"); v = e ? atoi(e) : 0; }
-	return (uint32_t)v;
-}
-// stage-B accumulators: 1 = 64-bit fixed point (default), 0 = fp64
-static uint32_t pair_fixed() {
-	static int v = -1;
-	if (v < 0) { const char *e = getenv("NR3D_PAIR_FIXED"); v = e ? (atoi(e) != 0) : 1; }
-	return (uint32_t)v;
-}
-// target number of stage-B work items of the pair path (measured, NGP config, 2^20 points, 64 KiB buckets, backward ms:
-// 768: 0.679, 1024: 0.669, 1536: 0.657, 2048: 0.671)
-static uint32_t pair_units() {
-	static uint32_t v = 0;
-	if (!v) { const char *e = getenv("NR3D_PAIR_UNITS"); const int x = e ? atoi(e) : 1536; v = (uint32_t)(x < 256 ? 256 : (x > 8192 ? 8192 : x)); }
-	return v;
-}
+// Measurement knobs (only a -DNR3D_EXPERIMENTS build reads them, options.h): points per stage-A workgroup 512 | 768 | 1024,
+// log2 of the entries per bucket 12 | 13, loads in flight per wave in stage B 4 | 8, stage-B work items (measured, NGP config,
+// 2^20 points, 64 KiB buckets, backward ms: 768: 0.679, 1024: 0.669, 1536: 0.657, 2048: 0.671), and the timing experiment
+// PAIR_DEBUG (results wrong by design: bit 0 = no LDS atomics, bit 1 = every lane re-reads one record).
+static uint32_t pair_bp() { const int64_t x = NR3D_XOPT(PAIR_BP, 1024); return (x == 512 || x == 768) ? (uint32_t)x : 1024u; }
+static uint32_t pair_lg() { return NR3D_XOPT(PAIR_EPB_LOG2, 12) == 13 ? 13u : 12u; }
+static uint32_t pair_unroll() { return NR3D_XOPT(PAIR_UNROLL, 4) == 8 ? 8u : 4u; }
+static uint32_t pair_units() { const int64_t x = NR3D_XOPT(PAIR_UNITS, 1536); return (uint32_t)(x < 256 ? 256 : (x > 8192 ? 8192 : x)); }
+// selectable paths (nr3d_set_option; the tests compare both forms in one process)
+static bool pair_quad_enabled() { return opt::on(NR3D_OPT_PAIR_QUAD); }
+static uint32_t pair_fixed() { return opt::on(NR3D_OPT_PAIR_FIXED) ? 1u : 0u; }      // stage-B accumulators: 64-bit fixed point | fp64
 
 // -------------------------------------------------------------------------------------------------
 // Stage A
@@ -481,93 +453,6 @@ __global__ __launch_bounds__(kPBP, kPBP == 768 ? 6 : 8) /* <= 64 VGPRs: two 64 K
 	}
 }
 
-// One workgroup = 1024 points x ALL pseudo levels of the plan, and dL/dx on the way: every lane keeps its own row of dL_dy
-// in registers (read ONCE, row-major as autograd hands it over: 8 x 16 bytes), walks the levels in order, adds
-// g_f * dy_f/dx_d of the level to its dL/dx (the stored Jacobian streams past, feature-major) and bins the level's pair
-// records through a double-buffered LDS stage (the write-out of level l overlaps the arithmetic of level l + 1).  Against
-// k_contract_dx_rowmajor + k_pair_bin this takes the feature-major copy of dL_dy (128 MiB written + read) and the second
-// read of dL_dy out of the step, and one launch.  kE = registers for the row (encoded dims <= kE).
-constexpr int kAllE = 32;
-template <bool DX, typename GT>
-__global__ __launch_bounds__(1024) void k_pair_bin_all(PairPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
-                                                       uint32_t n_pseudo_meta, uint32_t E, int32_t max_level, uint32_t smooth,
-                                                       const float *__restrict__ x, const GT *__restrict__ g, int64_t g_sn,
-                                                       int64_t g_se, const float *__restrict__ dydx, int64_t d_sn, int64_t d_se,
-                                                       float *__restrict__ dL_dx, u32x4 *__restrict__ rec,
-                                                       uint32_t *__restrict__ offs_g, uint32_t *__restrict__ gmax, uint32_t quad_on) {
-	constexpr int kPBP = 1024;
-	constexpr uint32_t kPCap = (uint32_t)kPBP * 4u;
-	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];    // stage[2][kPCap] records | hist[2][kPMaxNb + 1]
-	__shared__ uint32_t scan_lds[kPBP / 64];
-	u32x4 *stage = reinterpret_cast<u32x4 *>(smem);
-	uint32_t *hist = smem + (size_t)2 * kPCap * 4;
-	const uint32_t blk = blockIdx.x;
-	const uint32_t i = blk * kPBP + threadIdx.x;
-	const bool in = i < n;
-	float xp[3] = {0.0f, 0.0f, 0.0f};
-	float row[kAllE];
-#pragma unroll
-	for (int e = 0; e < kAllE; ++e) row[e] = 0.0f;
-	if (in) {
-#pragma unroll
-		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
-		const GT *gp = g + (int64_t)i * g_sn;
-		if (sizeof(GT) == 4 && g_se == 1 && (E & 3u) == 0u && ((uintptr_t)g & 15u) == 0 && (g_sn & 3) == 0) {
-#pragma unroll
-			for (int e4 = 0; e4 < kAllE; e4 += 4)
-				if ((uint32_t)e4 < E) {
-					const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(gp) + e4);
-					row[e4] = t.x; row[e4 + 1] = t.y; row[e4 + 2] = t.z; row[e4 + 3] = t.w;
-				}
-		} else if (sizeof(GT) == 2 && g_se == 1 && (E & 3u) == 0u && ((uintptr_t)g & 7u) == 0 && (g_sn & 3) == 0) {
-#pragma unroll
-			for (int e4 = 0; e4 < kAllE; e4 += 4)
-				if ((uint32_t)e4 < E) {
-					const __half2 *h = reinterpret_cast<const __half2 *>(reinterpret_cast<const __half *>(gp) + e4);
-					const float2 a = __half22float2(h[0]), b = __half22float2(h[1]);
-					row[e4] = a.x; row[e4 + 1] = a.y; row[e4 + 2] = b.x; row[e4 + 3] = b.y;
-				}
-		} else {
-#pragma unroll
-			for (int e = 0; e < kAllE; ++e)
-				if ((uint32_t)e < E) row[e] = to_f32<GT>(gp[(int64_t)e * g_se]);
-		}
-	}
-	for (uint32_t b = threadIdx.x; b <= kPMaxNb; b += kPBP) hist[b] = 0;
-	uint32_t gbits = 0;
-#pragma unroll
-	for (int e = 0; e < kAllE; ++e) gbits = max(gbits, __float_as_uint(row[e]) & 0x7FFFFFFFu);
-	float dx[3] = {0.0f, 0.0f, 0.0f};
-	__syncthreads();
-	uint32_t ql = 0, buf = 0;
-	for (uint32_t q = 0; q < n_pseudo_meta; ++q) {
-		const float g0 = row[0], g1 = row[1];
-#pragma unroll
-		for (int e = 0; e + 2 < kAllE; ++e) row[e] = row[e + 2];       // next level's pair moves to the front (no dynamic register index)
-		const uint32_t level = meta_level_of(md, q);
-		if (DX && in) {
-			// same order as k_contract_dx: e ascending, fma(g, j, acc)
-			const float *j0 = dydx + (int64_t)i * d_sn + (int64_t)(2 * q) * d_se, *j1 = j0 + d_se;
-#pragma unroll
-			for (int d = 0; d < 3; ++d) dx[d] = __fmaf_rn(g0, __builtin_nontemporal_load(j0 + d), dx[d]);
-#pragma unroll
-			for (int d = 0; d < 3; ++d) dx[d] = __fmaf_rn(g1, __builtin_nontemporal_load(j1 + d), dx[d]);
-		}
-		if (ql >= plan.n_pseudo || plan.qmap[ql] != q) continue;          // level outside this call's range (uniform)
-		const Lvl L = load_level(md, level);
-		pair_level<kPBP>(plan, ql, L, in && (int32_t)level <= max_level, xp, g0, g1, smooth, stage + (size_t)buf * kPCap,
-		                 hist + (size_t)buf * (kPMaxNb + 1), hist + (size_t)(buf ^ 1u) * (kPMaxNb + 1), scan_lds,
-		                 rec + ((size_t)ql * plan.n_blk + blk) * (size_t)plan.cap, offs_g + plan.offs_base[ql] + blk, plan.n_blk, nullptr,
-		                 quad_on != 0u);
-		++ql; buf ^= 1u;
-	}
-	if (DX && in) {
-#pragma unroll
-		for (int d = 0; d < 3; ++d) dL_dx[(size_t)i * 3 + d] = dx[d];
-	}
-	if (gmax) pair_gmax<kPBP>(gbits, scan_lds, gmax);
-}
-
 // Records per bucket over all point blocks (one wave per bucket), and -- in the LAST workgroup to finish -- the stage-B work
 // plan: a bucket with more than total / n_units records is split into replicas over its point blocks, empty buckets
 // get no workgroup (item_start = exclusive prefix of the replica counts).  One launch instead of a totals kernel and a
@@ -697,8 +582,9 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
                                                              const uint32_t *__restrict__ rep_g,
                                                              const uint32_t *__restrict__ item_start,
                                                              const uint32_t *__restrict__ gmax,
-                                                             float *__restrict__ partial, float *__restrict__ dparam, uint32_t dbg,
+                                                             float *__restrict__ partial, float *__restrict__ dparam NR3D_DBG_PARAM,
                                                              uint32_t out_half) {
+	NR3D_DBG_DECL
 	extern __shared__ __attribute__((aligned(16))) unsigned long long acc_raw[];   // [2][2^lg] 8-byte accumulators, feature-major
 	double *acc = reinterpret_cast<double *>(acc_raw);
 	const uint32_t NB = plan.bucket_base[plan.n_pseudo];
@@ -1068,11 +954,7 @@ __global__ __launch_bounds__(kPAccThreads) void k_pair_reduce(PairPlan plan, con
 // -------------------------------------------------------------------------------------------------
 // Host side
 // -------------------------------------------------------------------------------------------------
-static bool pair_enabled() {
-	static int on = -1;
-	if (on < 0) { const char *e = getenv("NR3D_LOTD_PAIR"); on = e ? (atoi(e) != 0) : 1; }
-	return on != 0;
-}
+static bool pair_enabled() { return opt::on(NR3D_OPT_LOTD_PAIR); }
 
 bool pair_applies(const nr3d_lotd_meta_t *m) {
 	if (!pair_enabled()) return false;
@@ -1098,17 +980,9 @@ bool pair_applies(const nr3d_lotd_meta_t *m) {
 	return true;
 }
 
-// NR3D_PAIR_ALL=1 turns the all-levels stage A on.  Off by default: measured 6 % slower on the backward of configs[1]
-// (1551 vs 457 + 953 us per 2^22 points, round-2 notes in DESIGN.md) -- 119 VGPRs for the row + 132 KB of LDS leave
-// one workgroup per CU, against two of k_pair_bin.  Read on every call (a test flips it).
-static bool pair_all_enabled() {
-	const char *e = getenv("NR3D_PAIR_ALL");
-	return e && e[0] == '1';
-}
-bool pair_all_applies(const nr3d_lotd_meta_t *m) {
-	return pair_all_enabled() && pair_applies(m) && pair_bp() == 1024u && m->n_encoded_dims <= (uint32_t)kAllE &&
-	       m->n_encoded_dims == 2u * m->n_pseudo_levels;
-}
+// (Rounds 2-3 carried an all-levels stage A here -- k_pair_bin_all / nr3d_lotd_bwd_fused: dL_dy read once, dL/dx folded in --
+// measured 6 % slower on the backward of configs[1] (1551 vs 457 + 953 us per 2^22 points; 119 VGPRs for the row + 132 KB of
+// LDS left one workgroup per CU against two of k_pair_bin).  Removed in round 4; DESIGN.md section 5b keeps the numbers.)
 
 static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_level, int32_t max_level, PairPlan &plan,
                       uint64_t &offs_words, uint64_t skip_pseudo = 0) {
@@ -1145,11 +1019,8 @@ static void pair_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, int32_t min_l
 	offs_words = base;
 }
 
-// NR3D_PAIR_DIRECT=0: every level goes through records
-static bool pair_direct_enabled() {
-	const char *e = getenv("NR3D_PAIR_DIRECT");
-	return !(e && e[0] == '0');
-}
+// NR3D_OPT_PAIR_DIRECT = 0: every level goes through records
+static bool pair_direct_enabled() { return opt::on(NR3D_OPT_PAIR_DIRECT); }
 // the pseudo levels of `full` with few buckets become the direct plan; returns the mask of those levels (0: none -- also
 // when nothing would be left for the record path, whose stage A carries the fixed-point scale)
 static uint64_t pair_direct_plan(const PairPlan &full, uint32_t n, DirectPlan &dp) {
@@ -1157,8 +1028,8 @@ static uint64_t pair_direct_plan(const PairPlan &full, uint32_t n, DirectPlan &d
 	dp.bucket_base[0] = 0;
 	if (!pair_direct_enabled()) return 0;
 	uint64_t mask = 0;
-	uint32_t nb_lim = kDirectNb;                              // NR3D_PAIR_DIRECT_NB: buckets up to which a level goes direct
-	if (const char *e = getenv("NR3D_PAIR_DIRECT_NB")) { const int v = atoi(e); nb_lim = v < 0 ? 0u : (uint32_t)v; }
+	const int64_t nb_x = NR3D_XOPT(PAIR_DIRECT_NB, kDirectNb);  // buckets up to which a level goes direct (knob: experiments build)
+	const uint32_t nb_lim = nb_x < 0 ? 0u : (uint32_t)nb_x;
 	for (uint32_t ql = 0; ql < full.n_pseudo && dp.n < kDirectMaxLv; ++ql) {
 		if (full.nb[ql] > nb_lim || full.qmap[ql] >= 64u) continue;
 		if (dp.bucket_base[dp.n] + full.nb[ql] > kDirectMaxWg) break;      // pair_layout reserves kDirectMaxWg partial tables
@@ -1206,18 +1077,17 @@ void launch_plan_items(uint32_t NB, uint32_t n_blk, uint32_t units, const uint32
 // one chunk of points: dL_dy given feature-major or with any strides (g_sn, g_se)
 int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_t n, const float *x, const float *g,
                int64_t g_sn, int64_t g_se, int32_t min_level, int32_t max_level, uint32_t units, float *dparam, uint32_t out_flags,
-               void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st, bool all_levels, bool g_half,
-               const FusedDx *fdx, const float *vin) {
-	// vin != NULL: second order (d(dL/dx)/dparam for dL_ddLdx = vin, [n, 3]); not with all_levels
+               void *rec, uint32_t *offs, uint32_t *plan_buf, float *partial, hipStream_t st, const float *vin) {
+	// vin != NULL: second order (d(dL/dx)/dparam for dL_ddLdx = vin, [n, 3])
 	PairPlan pl;
 	uint64_t ow;
 	pair_plan(meta, n, min_level, max_level, pl, ow);
-	if (pl.n_pseudo == 0 && !(all_levels && fdx)) return 0;
+	if (pl.n_pseudo == 0) return 0;
 	// levels with a handful of buckets leave the record path (k_pair_direct); `pl` keeps the others
 	DirectPlan dp;
 	dp.n = 0;
 	const uint32_t NB_full = pl.bucket_base[pl.n_pseudo];
-	if (!all_levels) {
+	{
 		const uint64_t skip = pair_direct_plan(pl, n, dp);
 		if (skip) pair_plan(meta, n, min_level, max_level, pl, ow, skip);
 	}
@@ -1228,29 +1098,26 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	uint32_t *gmax = plan_buf + 3 * (size_t)NB + 2;                  // two spare words of the plan region: gmax | ticket
 	units = pair_units();
 	const size_t bin_lds_max = (size_t)1024 * 4 * 16 + (size_t)(kPMaxNb + 2) * 8;
-	const size_t all_lds = (size_t)2 * 1024 * 4 * 16 + (size_t)2 * (kPMaxNb + 1) * 4;     // stage[2] | hist[2]
 	static bool attr_set_dev[64] = {};
 	int dev_id = 0;
 	NR3D_HIP_CHECK(hipGetDevice(&dev_id));
 	if (!attr_set_dev[dev_id & 63]) {
+#ifdef NR3D_EXPERIMENTS
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
+#endif
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bin_lds_max));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_bin_all<false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)all_lds));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_direct<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_pair_accum<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax * 8));
 		attr_set_dev[dev_id & 63] = true;
 	}
 	NR3D_HIP_CHECK(hipMemsetAsync(gmax, 0, 2 * sizeof(uint32_t), st));      // gmax | ticket of k_pair_plan
@@ -1261,17 +1128,13 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 #define NR3D_PAIR_BIN(BP) if (vin) NR3D_PAIR_BIN_(BP, true); else NR3D_PAIR_BIN_(BP, false)
 #define NR3D_PAIR_BIN_(BP, SEC) hipLaunchKernelGGL((k_pair_bin<BP, SEC>), dim3(pl.n_blk, pl.n_pseudo), dim3(BP), bin_lds, st, pl, md, n, max_level, \
 	meta->interpolation_type, x, g, g_sn, g_se, (u32x4 *)rec, offs, gmax, dp, vin, quad_on)
-#define NR3D_PAIR_ALL(DX, GT) hipLaunchKernelGGL((k_pair_bin_all<DX, GT>), dim3(pl.n_blk), dim3(1024), all_lds, st, pl, md, n,       \
-	meta->n_pseudo_levels, meta->n_encoded_dims, max_level, meta->interpolation_type, x, (const GT *)g, g_sn, g_se,                     \
-	fdx ? fdx->dydx : nullptr, fdx ? fdx->d_sn : 0, fdx ? fdx->d_se : 0, fdx ? fdx->dL_dx : nullptr, (u32x4 *)rec, offs, gmax, quad_on)
 	{
 		prof::Scope ps(NR3D_PROF_LOTD_BIN, st);
-		if (all_levels) {
-			if (g_half) { if (fdx) NR3D_PAIR_ALL(true, __half); else NR3D_PAIR_ALL(false, __half); }
-			else        { if (fdx) NR3D_PAIR_ALL(true, float); else NR3D_PAIR_ALL(false, float); }
-		} else if (bp == 512) { NR3D_PAIR_BIN(512); } else if (bp == 768) { NR3D_PAIR_BIN(768); } else { NR3D_PAIR_BIN(1024); }
+#ifdef NR3D_EXPERIMENTS
+		if (bp == 512) { NR3D_PAIR_BIN(512); } else if (bp == 768) { NR3D_PAIR_BIN(768); } else
+#endif
+		{ NR3D_PAIR_BIN(1024); }
 	}
-#undef NR3D_PAIR_ALL
 #undef NR3D_PAIR_BIN
 #undef NR3D_PAIR_BIN_
 	// levels that skip the records: straight from (x, dL_dy) into LDS; needs stage A's gmax only, so it runs before stage B
@@ -1296,11 +1159,13 @@ int pair_chunk(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *md, uint32_
 	}
 	hipLaunchKernelGGL(k_pair_plan, dim3(div_up(NB, 16)), dim3(1024), 0, st, pl, offs, units, tot, rep, item_start, gmax + 1);
 #define NR3D_PAIR_ACC(U, F) hipLaunchKernelGGL((k_pair_accum<U, F>), dim3(units + NB), dim3(kPAccThreads), (size_t)(16u << pl.lg), st, pl, md, \
-	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam, pair_dbg(), out_flags)
+	(const u32x4 *)rec, offs, rep, item_start, gmax, partial, dparam NR3D_DBG_ARG(NR3D_XOPT(PAIR_DEBUG, 0)), out_flags)
 	{
 		prof::Scope ps(NR3D_PROF_LOTD_ACCUM, st);
-		if (pair_fixed()) { if (pair_unroll() == 4) NR3D_PAIR_ACC(4, true); else NR3D_PAIR_ACC(8, true); }
-		else              { if (pair_unroll() == 4) NR3D_PAIR_ACC(4, false); else NR3D_PAIR_ACC(8, false); }
+#ifdef NR3D_EXPERIMENTS
+		if (pair_unroll() == 8) { if (pair_fixed()) NR3D_PAIR_ACC(8, true); else NR3D_PAIR_ACC(8, false); } else
+#endif
+		{ if (pair_fixed()) NR3D_PAIR_ACC(4, true); else NR3D_PAIR_ACC(4, false); }
 	}
 #undef NR3D_PAIR_ACC
 	// the replicated buckets of the record path and the direct levels' buckets are summed in ONE launch

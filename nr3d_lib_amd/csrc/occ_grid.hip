@@ -629,9 +629,9 @@ static int march_count(uint32_t n_rays, const float *rays_o, const float *rays_d
 		                   (float *)nullptr, (float *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
 		                   (uint32_t *)sample_cache);
 	};
-	// lanes per ray: 32 / 16 while that still leaves the chip short of work, else one (NR3D_MARCH_GROUP = 1 | 16 | 32 | 64 forces)
+	// lanes per ray: 32 / 16 while that still leaves the chip short of work, else one (NR3D_OPT_MARCH_GROUP = 1 | 16 | 32 | 64 forces)
 	int group = n_rays <= 8192u ? 32 : (n_rays <= 32768u ? 16 : 1);
-	if (const char *e = getenv("NR3D_MARCH_GROUP")) { const int v = atoi(e); if (v == 1 || v == 16 || v == 32 || v == 64) group = v; }
+	{ const int64_t v = opt::get(NR3D_OPT_MARCH_GROUP); if (v == 1 || v == 16 || v == 32 || v == 64) group = (int)v; }
 	if (!cached) group = 1;
 	auto launch_group = [&](auto kern, int G) {
 		hipLaunchKernelGGL(kern, dim3(div_up((uint64_t)n_rays * G, 256)), dim3(256), 0, st, n_rays, rays_o, rays_d, t_min, t_max, roi,

@@ -1,0 +1,38 @@
+// nr3d_lib_amd/csrc/options.h -- the library's run-time options, ONE table (round 4).
+//
+// Rounds 1-3 grew ~35 `getenv("NR3D_*")` switches, a dozen of them on per-launch paths and two of them producing wrong
+// results by design (timing experiments).  Now:
+//   * the selectable code paths that the parity tests A/B against each other are entries of `g_val[]`, set through the C ABI
+//     (`nr3d_set_option`, include/nr3d_hip.h) -- a launch reads a plain int, never the environment;
+//   * measurement knobs and the timing experiments exist only in a build with -DNR3D_EXPERIMENTS (`make EXTRA=-DNR3D_EXPERIMENTS`):
+//     there `NR3D_XOPT(name, default)` reads the environment variable NR3D_<name> once, at first use; in the production build it IS
+//     the default, a compile-time constant, so the experiment branches and their kernel arguments fold away.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/nr3d_hip.h"
+
+namespace nr3d {
+namespace opt {
+
+extern int64_t g_val[NR3D_OPT_COUNT];            // host_api.hip (defaults there)
+
+static inline int64_t get(int id) { return g_val[id]; }
+static inline bool on(int id) { return g_val[id] != 0; }
+
+#ifdef NR3D_EXPERIMENTS
+int64_t experiment_env(const char *name, int64_t dflt);      // host_api.hip: getenv once per name (cached)
+#define NR3D_XOPT(name, dflt) (::nr3d::opt::experiment_env("NR3D_" #name, (int64_t)(dflt)))
+// the `dbg` kernel argument of the timing experiments: present only in the experiments build
+#define NR3D_DBG_PARAM , uint32_t dbg
+#define NR3D_DBG_ARG(v) , (uint32_t)(v)
+#define NR3D_DBG_DECL
+#else
+#define NR3D_XOPT(name, dflt) ((int64_t)(dflt))
+#define NR3D_DBG_PARAM
+#define NR3D_DBG_ARG(v)
+#define NR3D_DBG_DECL constexpr uint32_t dbg = 0u;
+#endif
+
+}  // namespace opt
+}  // namespace nr3d

@@ -597,17 +597,13 @@ __global__ __launch_bounds__(kBlock) void k_alpha_bwd_lpp(uint32_t P, const floa
 
 // wave-per-pack for few packs; from 2048 packs on (32 waves of lanes) one lane per pack is faster at every pack
 // length measured (4096 packs x 61 samples: 8 / 23 us vs 27 / 42 us forward / backward)
-// NR3D_PACK_SCAN=0: the fused composite replays the transmittance serially (vw bit-identical to packed_alpha_to_vw)
-// instead of the prefix-product kernels; NR3D_PACK_SCAN_MAX: packs up to which wave-per-pack + scan is preferred over one
-// lane per pack (default: always -- 4096 packs x <= 512: 8.5 / 11 us against 38 / 77 us forward / backward, 262144 packs:
-// 148 / 289 against 302 / 837).  Read on every call.
-static inline bool composite_scan() { const char *e = getenv("NR3D_PACK_SCAN"); return !(e && e[0] == '0'); }
-static inline uint32_t composite_scan_max() { const char *e = getenv("NR3D_PACK_SCAN_MAX"); return e ? (uint32_t)atoi(e) : 0xFFFFFFFFu; }
-static inline bool lane_per_pack(uint32_t P) {
-	static int thr = -1;
-	if (thr < 0) { const char *e = getenv("NR3D_PACK_LPP_MIN"); thr = e ? atoi(e) : 2048; }
-	return P >= (uint32_t)thr;
-}
+// NR3D_OPT_PACK_SCAN = 0: the fused composite replays the transmittance serially (vw bit-identical to packed_alpha_to_vw)
+// instead of the prefix-product kernels.  Knobs of the experiments build: PACK_SCAN_MAX = packs up to which wave-per-pack +
+// scan is preferred over one lane per pack (default: always -- 4096 packs x <= 512: 8.5 / 11 us against 38 / 77 us forward /
+// backward, 262144 packs: 148 / 289 against 302 / 837), PACK_LPP_MIN.
+static inline bool composite_scan() { return opt::on(NR3D_OPT_PACK_SCAN); }
+static inline uint32_t composite_scan_max() { return (uint32_t)NR3D_XOPT(PACK_SCAN_MAX, 0xFFFFFFFFll); }
+static inline bool lane_per_pack(uint32_t P) { return P >= (uint32_t)NR3D_XOPT(PACK_LPP_MIN, 2048); }
 
 // ------------------------------------------------------------------------------------------------
 // Fused alpha composite of a packed volume buffer: the renderer's chain

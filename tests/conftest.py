@@ -39,3 +39,20 @@ def dev(hiplib):
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU (run through gpurun)"
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def hip_option(hiplib):
+    """hip_option(name, value): choose one of two implementations of the same result (include/nr3d_hip.h: NR3D_OPT_*, the
+    library's option table -- no environment switches since round 4); every option set through it is back at its default when
+    the test ends"""
+    from nr3d_lib_amd import _hip
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        _hip.set_option(name, int(value))
+
+    yield set_
+    for name in touched:
+        _hip.set_option(name, -1)

@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol(hiplib):
                         capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r" T (nr3d_[A-Za-z0-9_]+)", nm)))
     assert exported == declared, (set(exported) ^ set(declared))
-    assert hiplib.nr3d_abi_version() == 3          # 2: nr3d_lotd_meta_t gained map_col; 3: forest entry points take param_dtype
+    assert hiplib.nr3d_abi_version() == 4          # 2: map_col; 3: forest entry points take param_dtype; 4: option table, bwd_fused removed
 
 
 def test_library_is_gfx950_only():

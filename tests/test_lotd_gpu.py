@@ -43,21 +43,21 @@ def test_fwd_and_jacobian(oracle, dev, case):
 
 
 @pytest.fixture(params=["direct", "records"])
-def bin_mode(request, monkeypatch):
+def bin_mode(request, hip_option):
     """dL/dparam of the pair path's levels with <= 4 buckets: accumulated straight from (x, dL_dy) in LDS (k_pair_direct,
-    default) or through records like the large levels (NR3D_PAIR_DIRECT=0)"""
-    monkeypatch.setenv("NR3D_PAIR_DIRECT", "1" if request.param == "direct" else "0")
+    default) or through records like the large levels (option pair_direct = 0)"""
+    hip_option("pair_direct", "1" if request.param == "direct" else "0")
     return request.param
 
 
 @pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth", "cp_only_4d", "cp_4d", "nplane_4d"])
-def test_fwd_split_launch_same_bits(oracle, dev, case, monkeypatch):
+def test_fwd_split_launch_same_bits(oracle, dev, case, hip_option):
     """the Dense / Hash levels of a meta that also has product-type levels run through the lean Dense / Hash kernel in a
     launch of their own (twice the occupancy): the same code for those levels, so not a bit may change"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=5003, seed=3)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("NR3D_LOTD_FWD_SPLIT", mode)
+        hip_option("fwd_split", mode)
         y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
         y2, _ = _lotd.lod_fwd(m, xt, pt, need_input_grad=False)
         ym, jm = _lotd.lod_fwd(m, xt, pt, max_level=m.n_levels // 2, need_input_grad=True)
@@ -132,9 +132,9 @@ def test_bwd_bwd_input(oracle, dev, case, bin_mode):
 
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4"])
 @pytest.mark.parametrize("coherent", [False, True])
-def test_dense_quad_records_vs_pair_records(oracle, dev, case, coherent, bin_mode, monkeypatch):
+def test_dense_quad_records_vs_pair_records(oracle, dev, case, coherent, bin_mode, hip_option):
     """dL/dparam of the pair path: the Dense levels' records in quad form (four entries of two neighbouring rows per 16-byte
-    record, both weights as 24-bit fractions; default) against pair records only (NR3D_PAIR_QUAD=0) and the fp64-accumulated
+    record, both weights as 24-bit fractions; default) against pair records only (option pair_quad = 0) and the fp64-accumulated
     oracle; random points and runs of points inside one cell (merged lanes emit singles, never quads); half gradients too"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=9001, seed=51)
     if coherent:
@@ -143,7 +143,7 @@ def test_dense_quad_records_vs_pair_records(oracle, dev, case, coherent, bin_mod
         xt = torch.from_numpy(x).to(dev)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("NR3D_PAIR_QUAD", mode)
+        hip_option("pair_quad", mode)
         outs[mode] = (_lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)[1],
                       _lotd.lod_bwd(m, gt, xt, pt, None, max_level=m.n_levels // 2, need_input_grad=False, need_param_grad=True)[1],
                       _lotd.lod_bwd(m, gt.half(), xt, pt.half(), None, need_input_grad=False, need_param_grad=True)[1])
@@ -157,9 +157,9 @@ def test_dense_quad_records_vs_pair_records(oracle, dev, case, coherent, bin_mod
 
 @pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth"])
 @pytest.mark.parametrize("coherent", [False, True])
-def test_vm_stage_a_three_threads_per_point(oracle, dev, case, coherent, monkeypatch):
+def test_vm_stage_a_three_threads_per_point(oracle, dev, case, coherent, hip_option):
     """dL/dparam and d(dL/dx)/dparam of metas with VM levels: stage A with three threads per point (six records each; default)
-    against one thread per point (NR3D_LOTD_VM_SPLIT=0) -- the same records, stage B may add them in another order (fp64
+    against one thread per point (option vm_split = 0) -- the same records, stage B may add them in another order (fp64
     accumulators) -- and the oracle; also for runs of points inside one cell (the coherent-lane merge, per component)"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=7013, seed=41)
     if coherent:
@@ -168,7 +168,7 @@ def test_vm_stage_a_three_threads_per_point(oracle, dev, case, coherent, monkeyp
         xt = torch.from_numpy(x).to(dev)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("NR3D_LOTD_VM_SPLIT", mode)
+        hip_option("vm_split", mode)
         dp = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)[1]
         dp2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
                                       need_dLdinput_dinput=False)[1]
@@ -181,9 +181,9 @@ def test_vm_stage_a_three_threads_per_point(oracle, dev, case, coherent, monkeyp
 
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4"])
 @pytest.mark.parametrize("coherent", [False, True])
-def test_second_order_dparam_pair_records_vs_corner_records(oracle, dev, case, coherent, bin_mode, monkeypatch):
+def test_second_order_dparam_pair_records_vs_corner_records(oracle, dev, case, coherent, bin_mode, hip_option):
     """d(dL/dx)/dparam of pair-path metas: pair records carrying the second-order weights (A_f = g_f C_m, wp' = wp + E_m / C_m;
-    default) against the 12-byte corner records (NR3D_LOTD_PAIR_SECOND=0) and the fp64-accumulated oracle -- random points and
+    default) against the 12-byte corner records (option pair_second = 0) and the fp64-accumulated oracle -- random points and
     ray-like runs of points inside one cell (the coherent-lane merge sums the lower / upper halves of many records); a
     direction v along one axis makes C_m or E_m vanish for whole records (the guarded division)"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=6007, seed=31)
@@ -195,7 +195,7 @@ def test_second_order_dparam_pair_records_vs_corner_records(oracle, dev, case, c
         vvt = torch.from_numpy(np.ascontiguousarray(vv)).to(dev)
         outs = {}
         for mode in ("1", "0"):
-            monkeypatch.setenv("NR3D_LOTD_PAIR_SECOND", mode)
+            hip_option("pair_second", mode)
             outs[mode] = _lotd.lod_bwd_bwd_input(m, vvt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
                                                  need_dLdinput_dinput=False)[1]
         ref = oracle.lotd_bwd_bwd_dparam(m_ref, vv, g, x, p, accum_double=True)
@@ -205,16 +205,16 @@ def test_second_order_dparam_pair_records_vs_corner_records(oracle, dev, case, c
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4", "dense_f8", "hash_npow2", "hash_4d", "dense_2d"])
-def test_hvp_level_parallel_vs_lane_serial(oracle, dev, case, monkeypatch):
+def test_hvp_level_parallel_vs_lane_serial(oracle, dev, case, hip_option):
     """d(dL/dx)/dx of Dense / Hash metas: one lane per (point, pseudo level) + a sum in level order (default, needs a
-    scratch buffer) against one lane per point walking the levels (NR3D_LOTD_HVP_LEVELS=0): the same order of the sum and
+    scratch buffer) against one lane per point walking the levels (option hvp_levels = 0): the same order of the sum and
     -- except for the pair-lane kernel of 3-D 2-feature metas, which builds the Hessian from the lerp tree's differences --
     the same per-level arithmetic: identical for 2-feature pseudo levels, to the rounding of one extra association
     otherwise; with max_level too"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=9001, seed=17)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("NR3D_LOTD_HVP_LEVELS", mode)
+        hip_option("hvp_levels", mode)
         a = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=False,
                                     need_dLdinput_dinput=True)[2]
         b = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, max_level=m.n_levels // 2, need_dLdinput_ddLdoutput=False,
@@ -547,52 +547,21 @@ def test_half_params_and_inputs(oracle, dev, case):
         _lotd.lod_fwd(m, xt.half(), pt)          # (half input, float params) is not a supported combination
 
 
-@pytest.mark.parametrize("case,half", [("ngp_small", False), ("ngp_pair", False), ("ngp_pair", True), ("pair_f4", False)])
-def test_bwd_single_pass(oracle, dev, case, half, monkeypatch):
-    """nr3d_lotd_bwd_fused (k_pair_bin_all, NR3D_PAIR_ALL=1: dL_dy read once, dL/dx folded into stage A of the scatter) gives
-    the bits of nr3d_lotd_bwd_dx + nr3d_lotd_bwd_dparam_typed, and the oracle's values."""
-    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=70001, seed=11)
-    if half:
-        pt, gt = pt.half(), gt.half()
-        p, g = pt.float().cpu().numpy(), gt.float().cpu().numpy()
-    import ctypes
-    from nr3d_lib_amd import _hip as H
-    _, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
-    monkeypatch.delenv("NR3D_PAIR_ALL", raising=False)
-    monkeypatch.setenv("NR3D_PAIR_DIRECT", "0")        # every level through records: the route the single pass must reproduce bit for bit
-    assert not H.lib().nr3d_lotd_bwd_fused_ok(ctypes.byref(m._cmeta()))
-    dx0, dp0 = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)
-    monkeypatch.setenv("NR3D_PAIR_ALL", "1")
-    assert H.lib().nr3d_lotd_bwd_fused_ok(ctypes.byref(m._cmeta()))
-    dx1, dp1 = _lotd.lod_bwd(m, gt, xt, pt, j, need_input_grad=True, need_param_grad=True)
-    _, dp2 = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)       # all-levels stage A without dL/dx
-    dx3, dp3 = _lotd.lod_bwd(m, gt, xt, pt, j, max_level=m.n_levels // 2, need_input_grad=True, need_param_grad=True)
-    monkeypatch.delenv("NR3D_PAIR_ALL")
-    dx4, dp4 = _lotd.lod_bwd(m, gt, xt, pt, j, max_level=m.n_levels // 2, need_input_grad=True, need_param_grad=True)
-    assert torch.equal(dx0, dx1) and torch.equal(dp0, dp1) and torch.equal(dp0, dp2)
-    assert torch.equal(dx3, dx4) and torch.equal(dp3, dp4)
-    assert dp1.dtype == pt.dtype
-    _, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
-    assert_close(dx1, oracle.lotd_bwd_dx(m_ref, g, j_ref), name="dL_dx single pass")
-    assert_close(dp1.float(), oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), rel=1e-3 if half else 1e-5,
-                 name="dL_dparam single pass", levels=m_ref)
-
-
 @pytest.mark.parametrize("case,half", [("ngp_small", False), ("ngp_smooth", False), ("ngp_pair", False), ("ngp_pair", True), ("pair_f4", False)])
-def test_bwd_direct_levels(oracle, dev, case, half, monkeypatch):
+def test_bwd_direct_levels(oracle, dev, case, half, hip_option):
     """levels with <= 4 buckets bypass the records (k_pair_direct: LDS accumulation straight from x and dL_dy, default) --
-    against the all-records route (NR3D_PAIR_DIRECT=0; same per-update arithmetic and fixed-point sums, the two differ only
+    against the all-records route (option pair_direct = 0; same per-update arithmetic and fixed-point sums, the two differ only
     in how a replicated bucket's fp32 partial tables are split) and the oracle; plain and level-bucketed calls."""
     n = 70001
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=n, seed=13)
     if half:
         pt, gt = pt.half(), gt.half()
         p, g = pt.float().cpu().numpy(), gt.float().cpu().numpy()
-    monkeypatch.setenv("NR3D_PAIR_DIRECT", "1")
+    hip_option("pair_direct", "1")
     _, d1 = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
     _, d1b = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
     _, d1m = _lotd.lod_bwd(m, gt, xt, pt, None, max_level=1, need_input_grad=False, need_param_grad=True)
-    monkeypatch.setenv("NR3D_PAIR_DIRECT", "0")
+    hip_option("pair_direct", "0")
     _, d0 = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)
     _, d0m = _lotd.lod_bwd(m, gt, xt, pt, None, max_level=1, need_input_grad=False, need_param_grad=True)
     assert torch.equal(d1, d1b)                                        # reproducible

@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["1", "16", "32", "64"], ids=lambda v: f"lanes_per_ray={v}")
-def march_group(request, monkeypatch):
+def march_group(request, hip_option):
     """every test under each marcher: one lane per ray (k_march) and 16 / 64 lanes per ray (k_march_group, look-ahead along
     the t recurrence) -- the same bits are expected from all three"""
-    monkeypatch.setenv("NR3D_MARCH_GROUP", request.param)
+    hip_option("march_group", request.param)
     return request.param
 
 

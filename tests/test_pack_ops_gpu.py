@@ -410,11 +410,11 @@ def _chain_backward(oracle, alpha, t, rgb, pi, eps, thre, normalize, vw, mask, g
 
 
 @pytest.fixture(params=["scan", "serial"])
-def composite_mode(request, monkeypatch):
+def composite_mode(request, hip_option):
     """the fused composite's two transmittance forms: wave prefix products (default up to 16384 packs; T within rounding
-    of the serial recurrence, the early-stop cut identical) and the serial replay (NR3D_PACK_SCAN=0: vw bit-identical to
+    of the serial recurrence, the early-stop cut identical) and the serial replay (option pack_scan = 0: vw bit-identical to
     packed_alpha_to_vw; wave-per-pack below 2048 packs, lane-per-pack from there)"""
-    monkeypatch.setenv("NR3D_PACK_SCAN", "1" if request.param == "scan" else "0")
+    hip_option("pack_scan", 1 if request.param == "scan" else 0)
     return request.param
 
 
@@ -480,12 +480,12 @@ def test_fused_composite_against_chain(oracle, dev, P, n_packs, hi, normalize, w
     _composite_case(oracle, dev, P, pi, S, 6, 1e-2, 0.02, normalize, with_rgb, scatter, composite_mode)
 
 
-def test_composite_scan_stop_decisions(oracle, dev, P, monkeypatch):
+def test_composite_scan_stop_decisions(oracle, dev, P, hip_option):
     """packs built so that the transmittance crosses early_stop_eps within rounding distance: constant alpha with
     (1 - alpha)^k == eps to a few ulp.  The prefix-product kernels must cut exactly the samples the serial recurrence cuts
     (they replay such a pack serially) -- then vw is not merely close, it is identical."""
     import nr3d_lib_amd.graphics.pack_ops as po
-    monkeypatch.setenv("NR3D_PACK_SCAN", "1")
+    hip_option("pack_scan", 1)
     rng = np.random.default_rng(3)
     n_packs, L = 600, 200
     pi = np.stack([np.arange(n_packs) * L, np.full(n_packs, L)], 1).astype(np.int64)

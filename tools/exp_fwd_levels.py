@@ -1,5 +1,8 @@
 """per-level cost of the two-lane forward on RAY-COHERENT samples (the full loop's marched samples) and on uniformly random
-points: one subprocess per pseudo level (NR3D_FWD_ONLY_LEVEL), HIP-event time of k_fwd_pairlane, y only (no Jacobian)"""
+points: one subprocess per pseudo level (NR3D_FWD_ONLY_LEVEL), HIP-event time of k_fwd_pairlane, y only (no Jacobian)
+
+Needs the experiments build of the library (round 4: measurement knobs are compiled out of the production library):
+    make -C nr3d_lib_amd/csrc clean && make -C nr3d_lib_amd/csrc -j8 EXTRA=-DNR3D_EXPERIMENTS"""
 import os, sys, subprocess, json
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

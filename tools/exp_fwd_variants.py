@@ -3,7 +3,10 @@ points + a digest of y / dy_dx.
    python tools/exp_fwd_variants.py 0 20,22 NR3D_FWD_DBG=<bits>     timing decomposition of k_fwd_pairlane (bit 0 no stores,
                                                                     bit 1 no gathers, bit 2 no x loads; results wrong by design)
 NR3D_FWD_VARIANT selected among the experimental kernels of commit a3cfea3 (profiles/r03a_fwd_experiments.txt); the
-library now holds only the kernel that came out of them, so the first argument is kept for the log format only."""
+library now holds only the kernel that came out of them, so the first argument is kept for the log format only.
+
+Needs the experiments build of the library (round 4: measurement knobs are compiled out of the production library):
+    make -C nr3d_lib_amd/csrc clean && make -C nr3d_lib_amd/csrc -j8 EXTRA=-DNR3D_EXPERIMENTS"""
 import os, sys, subprocess, json, hashlib
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

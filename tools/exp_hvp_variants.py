@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """tools/exp_hvp_variants.py -- timing decomposition of the pair-lane d(dL/dx)/dx kernel on configs[1]'s meta
 (NR3D_HVP_DBG: 1 no stores, 2 no gathers, 4 no dL_dy loads, 8 no dL_ddLdx loads; results wrong by design).
-    python tools/exp_hvp_variants.py [log2_points]"""
+    python tools/exp_hvp_variants.py [log2_points]
+
+Needs the experiments build of the library (round 4: measurement knobs are compiled out of the production library):
+    make -C nr3d_lib_amd/csrc clean && make -C nr3d_lib_amd/csrc -j8 EXTRA=-DNR3D_EXPERIMENTS"""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+# Needs the experiments build (round 4): make -C nr3d_lib_amd/csrc clean && make -C nr3d_lib_amd/csrc -j8 EXTRA=-DNR3D_EXPERIMENTS
 # Run on the GPU box: the two-lane forward's schedule -- work line (NR3D_LOTD_SCHED_EXCL=0) vs exclusive fine levels + shared
 # coarse levels (1, default): headline loop at 2^20 / 2^22 and the full loop
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle                                                   # noqa: E402  (test infrastructure)
 from nr3d_lib_amd.bindings import _occ_grid                      # noqa: E402
+from nr3d_lib_amd import _hip                                  # noqa: E402
 
 dev = torch.device("cuda:0")
 NAMES = ["packed_info", "t_starts", "t_ends", "ridx", "bidx", "gidx"]
@@ -57,7 +58,8 @@ def one(rng):
     ref = oracle.ray_marching(o, d, near, far, roi, grid, ctype, np.float32(step), max_step, gamma, max_steps, True, **kw)
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     _occ_grid.SAMPLE_CACHE_MAX_BYTES = (2 << 30) if rng.random() < 0.6 else 0
-    os.environ["NR3D_MARCH_GROUP"] = str(rng.choice(["1", "16", "32", "64"]))       # lanes per ray (count pass with the cache)
+    lanes = int(rng.choice([1, 16, 32, 64]))                                           # lanes per ray (count pass with the cache)
+    _hip.set_option("march_group", lanes)
     if batched:
         got = _occ_grid.batched_ray_marching(t(o), t(d), t(near), t(far), t(kw["batch_inds"]), kw["batch_data_size"], t(roi), t(grid),
                                              _occ_grid.ContractionType(ctype), step, max_step, gamma, max_steps, True)
@@ -77,7 +79,7 @@ def one(rng):
         r = np.asarray(r)
         ok = g.shape == r.shape and np.array_equal(g, r)
         assert ok, (f"march mismatch in {name}: batched={batched} ctype={ctype} res={res} roi={roi1.tolist()} n={n} step={step} "
-                    f"gamma={gamma} max_step={max_step} max_steps={max_steps} cache={_occ_grid.SAMPLE_CACHE_MAX_BYTES} lanes={os.environ['NR3D_MARCH_GROUP']}")
+                    f"gamma={gamma} max_step={max_step} max_steps={max_steps} cache={_occ_grid.SAMPLE_CACHE_MAX_BYTES} lanes={lanes}")
     return int(ref[1].shape[0])
 
 

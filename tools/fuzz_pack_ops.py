@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle                                                   # noqa: E402  (test infrastructure)
 from nr3d_lib_amd.bindings import _pack_ops as P                 # noqa: E402
+from nr3d_lib_amd import _hip                                  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -67,7 +68,7 @@ def one(rng):
     gw = rng.standard_normal(S).astype(np.float32)
     close(P.packed_alpha_to_vw_backward(t(w_ref), t(gw), t(a), pit, eps, thre),
           oracle.packed_alpha_to_vw_backward(w_ref, gw, a, pi, eps, thre), "alpha bwd " + tag, exact=True)
-    # fused composite: prefix-product kernels (default) against the serial replay (NR3D_PACK_SCAN=0: vw bit-identical to
+    # fused composite: prefix-product kernels (default) against the serial replay (option pack_scan = 0: vw bit-identical to
     # alpha_to_vw) -- same early-stop cut, values to rounding -- and against the oracle's weights
     if rng.random() < 0.5:                                  # opaque and near-opaque samples drive T through eps quickly
         a = a.copy(); a[rng.random(S) < 0.05] = np.float32(rng.choice([1.0, 0.999, 0.9]))
@@ -76,7 +77,7 @@ def one(rng):
     rgb = rng.random((S, 3)).astype(np.float32)
     outs = {}
     for mode in ("1", "0"):
-        os.environ["NR3D_PACK_SCAN"] = mode
+        _hip.set_option("pack_scan", int(mode))
         vw, mask, depth, col = P.packed_composite_forward(t(a), t(tm), t(rgb), pit, None, pi.shape[0], eps, thre, True)
         gm, gd, gc = (rng.standard_normal(pi.shape[0]).astype(np.float32), rng.standard_normal(pi.shape[0]).astype(np.float32),
                       rng.standard_normal((pi.shape[0], 3)).astype(np.float32))
@@ -85,7 +86,7 @@ def one(rng):
         ga, gt_, gc_ = P.packed_composite_backward(t(a), vw, t(tm), t(rgb), pit, None, eps, thre, True, mask, depth, g_out[0], g_out[1],
                                                    g_out[2], None)
         outs[mode] = (vw, mask, depth, col, ga, gt_, gc_)
-    os.environ.pop("NR3D_PACK_SCAN", None)
+    _hip.set_option("pack_scan", -1)
     # backward: the division by max(1 - alpha, 1e-10) amplifies rounding, so the numerators are compared
     om = np.maximum(1.0 - a.astype(np.float64), 1e-10)
     close(outs["1"][4].double().cpu().numpy() * om, outs["0"][4].double().cpu().numpy() * om, "composite scan vs serial dalpha numerator " + tag, 1e-4,
