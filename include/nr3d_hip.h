@@ -541,7 +541,10 @@ int nr3d_tau_to_alpha_bwd(uint64_t S, const float *sigma, const float *delta, co
 /* Post-processing of the marcher's outputs (nr3d_lib/graphics/raymarch/occgrid_raymarch.py:87-112: nonzero on the counts,
  * index, .long()): packed_info int32 [n_rays, 2] -> the rays with >= 1 sample, ascending: ridx_hit int64 [n_hit],
  * pack_infos int64 [n_hit, 2]; totals int64 [2] = {samples, n_hit} (the caller reads n_hit back; outputs sized n_rays).
- * scan_tmp >= nr3d_scan_tmp_bytes(n_rays). */
+ * scan_tmp >= nr3d_scan_tmp_bytes(n_rays).
+ * Range of the three compacting entry points (this one, nr3d_ray_marching_count_finished, nr3d_prune_compact_packs): one scan
+ * carries the running sample count (36 bits) and the rank among the non-empty packs (28 bits) -- fewer than 2^28 packs /
+ * rays per call (checked: nonzero status above that), fewer than 2^36 samples in all (more than a 288 GB device can hold). */
 int nr3d_march_finish_rays(uint32_t n_rays, const int32_t *packed_info, int64_t *ridx_hit, int64_t *pack_infos,
                            int64_t *totals, void *scan_tmp, void *stream);
 /* ... and per sample (same lines): ridx64 = (int64) ridx, deltas = t_ends - t_starts, samples [S, 3] =

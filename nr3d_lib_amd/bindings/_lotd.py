@@ -276,27 +276,14 @@ def _f32c(t):
     return t if t.dtype == torch.float32 else t.float()
 
 
-_P32_CACHE = {}
-
-
 def _p32(params):
-    """fp32 working copy of a parameter table that is not served natively in half (product-type levels, batched tables --
-    small tables in practice: a VM / CP / NPlane level is planes and lines, configs[3] has 8 MB in all).  The copy is keyed on
-    the tensor's storage and version counter: the forward, the backward and the second-order calls of one step (same
-    parameters, same version) share ONE conversion instead of converting the table once per call; an in-place update (an
-    optimizer step) bumps the version and the next call converts again.  One entry per device."""
+    """fp32 working copy of a half table for the A/B route (NATIVE_HALF = False; the kernels read half tables themselves
+    otherwise).  Converted on EVERY call: rounds 2-3 cached the copy per (data_ptr, _version), but a ``.data`` view -- what
+    ``LoTDEncoding.inference_param`` passes -- carries a fresh version counter that stays 0, so an optimizer step between two
+    inference calls went unseen and the stale table was served (round-3 advisor finding).  The route exists for cross-checks
+    only; a conversion per call is its honest cost."""
     p = params.detach()
-    if p.dtype == torch.float32:
-        return p
-    key = (p.data_ptr(), p._version, p.numel(), p.dtype)
-    hit = _P32_CACHE.get(p.device)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    p32 = p.float()
-    # the entry holds the half table's STORAGE: while it is cached its address cannot be handed to another tensor (the
-    # caching allocator would otherwise give a later temporary the same data_ptr with version 0 -> a stale hit)
-    _P32_CACHE[p.device] = (key, p32, p.untyped_storage())
-    return p32
+    return p if p.dtype == torch.float32 else p.float()
 
 
 def _ptab(params):

@@ -8,10 +8,14 @@ namespace nr3d {
 namespace glue {
 
 // ------------------------------------------------------------------------------------------------
-// compaction of flagged packs: value(i) = count_i | (count_i > 0) << 40, one exclusive scan gives the new begin of
-// every pack (low 40 bits) and its rank among the non-empty ones (high bits)
+// compaction of flagged packs: value(i) = count_i | (count_i > 0) << 36, one exclusive scan gives the new begin of
+// every pack (low 36 bits) and its rank among the non-empty ones (high 28 bits).
+// Range (round-3 advisor finding; checked in compact_packs): fewer than 2^28 packs per call, and the counts must sum to less
+// than 2^36 -- which 288 GB of HBM guarantee: a sample of these tables carries >= 16 bytes (depth, delta, ray index, ...), so a
+// device holds < 2^35 of them.  (Round 3 split 40 / 24: 2^24 rays in one call -- configs[4]'s size on ONE device -- overflowed.)
 // ------------------------------------------------------------------------------------------------
-constexpr int kShift = 40;
+constexpr int kShift = 36;
+constexpr uint64_t kMaxPacks = 1ull << (64 - kShift);
 constexpr uint64_t kLow = (1ull << kShift) - 1ull;
 
 template <typename TCnt, int STRIDE>    // counts[i * STRIDE] (STRIDE 2: the count column of an [n, 2] pack table, offset applied by the caller)
@@ -110,6 +114,7 @@ __global__ __launch_bounds__(scan::kThreads) void k_c_small(uint32_t n, uint32_t
 
 template <typename TCnt, int STRIDE>
 static int compact_packs(uint64_t n, const PackWriter<TCnt, STRIDE> &w, int64_t *totals, void *tmp, hipStream_t st) {
+	NR3D_CHECK(n < kMaxPacks, "pack compaction: %llu packs in one call, the limit is 2^28 - 1 (split the batch)", (unsigned long long)n);
 	if (n == 0) {
 		NR3D_HIP_CHECK(hipMemsetAsync(totals, 0, 2 * sizeof(int64_t), st));
 		return 0;

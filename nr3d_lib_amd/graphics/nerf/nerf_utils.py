@@ -26,9 +26,13 @@ class _SigmaDeltaToAlpha(torch.autograd.Function):
         return _backend.tau_to_alpha_forward(sigma, delta)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_alpha):
         sigma, delta = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # create_graph=True: a higher-order graph is wanted (the reference expression supports double backward,
+            # nerf_utils.py:23-24) -> the gradient as differentiable torch ops on the saved inputs; first-order training
+            # never takes this branch
+            return grad_alpha * delta * torch.exp(-sigma * delta), None
         return _backend.tau_to_alpha_backward(sigma, delta, grad_alpha.contiguous()), None
 
 

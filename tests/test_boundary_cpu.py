@@ -144,3 +144,38 @@ def test_lotd_encoding_module_cpu_surface():
     an = LoTDEncoding(3, lotd_cfg=cfg, dtype=torch.float, anneal_cfg=dict(type="hardmask", stop_it=100, start_level=1))
     an.set_anneal_iter(0)
     assert an.max_level == 1 and an.window is None
+
+
+def test_reference_call_sites_bind():
+    """INTEGRATION.md section 1 (zero-code-change route): every attribute the reference's Python takes from its three compiled
+    modules exists on the twin, and every call it makes binds against the twin's signature.  The call sites are DATA
+    (tests/golden/ref_backend_uses.json: module, name, file:line, positional count, keyword names), extracted from the reference
+    with ast by tests/golden/make_ref_backend_uses.py in the build container; nothing of the reference is read here."""
+    import importlib
+    import inspect
+    import json
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_backend_uses.json")))
+    assert d["n_uses"] == len(d["uses"]) >= 100 and d["n_names"] >= 40
+    twins = {m: importlib.import_module(f"nr3d_lib_amd.bindings.{m}") for m in ("_lotd", "_pack_ops", "_occ_grid")}
+    missing, mismatched, bound = [], [], 0
+    for r in d["uses"]:
+        where = f'{r["module"]}.{r["name"]} ({r["file"]}:{r["line"]})'
+        obj = getattr(twins[r["module"]], r["name"], None)
+        if obj is None:
+            missing.append(where)
+            continue
+        c = r.get("call")
+        if c is None or c["star_args"] or c["star_kwargs"]:
+            continue
+        try:
+            sig = inspect.signature(obj)
+        except (TypeError, ValueError):
+            continue                              # enum classes etc.: attribute presence is the contract
+        try:
+            sig.bind(*([None] * c["n_positional"]), **{k: None for k in c["keywords"]})
+            bound += 1
+        except TypeError as e:
+            mismatched.append(f"{where}: {e}")
+    assert not missing, missing
+    assert not mismatched, mismatched
+    assert bound >= 80

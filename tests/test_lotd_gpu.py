@@ -381,22 +381,25 @@ def test_generic_kernel_agrees_with_dense_hash_kernel(oracle, dev):
     assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dparam generic", levels=m_ref)
 
 
-def test_half_table_copy_is_shared_per_version_not_per_address(oracle, dev, monkeypatch):
-    """NATIVE_HALF off (A/B switch; the kernels read half tables themselves otherwise): half tables run on an fp32 copy that
-    the calls of one step share (bindings._lotd._p32, keyed on storage + version counter): an in-place update must
-    invalidate it, and so must a NEW tensor that the caching allocator places at the address of a freed one"""
+def test_half_table_copy_is_never_stale(oracle, dev, monkeypatch):
+    """NATIVE_HALF off (A/B switch; the kernels read half tables themselves otherwise): half tables run on an fp32 copy made
+    per call (bindings._lotd._p32; no cache since round 4).  An in-place update must be seen -- through the tensor itself and
+    through a `.data` view, whose version counter stays 0 (what LoTDEncoding.inference_param passes) -- and so must a NEW
+    tensor that the caching allocator places at the address of a freed one"""
     _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, "mixed", n=2001, seed=9)
     monkeypatch.setattr(_lotd, "NATIVE_HALF", False)
     ph = pt.half()
     assert not _lotd._native_half(m, ph, False)
     y1 = _lotd.lod_fwd(m, xt, ph)[0].float().clone()
-    assert _lotd._p32(ph) is _lotd._p32(ph)                                  # one copy for the calls of a step
+    yd1 = _lotd.lod_fwd(m, xt, ph.data)[0].float().clone()                   # .data: version counter 0, and it stays 0
+    assert torch.equal(yd1, y1)
     assert_close(y1, oracle.lotd_fwd(m_ref, x, ph.float().cpu().numpy())[0], rel=1e-3, name="y half (copy)")
     ph.mul_(2.0)                                                             # an optimizer step: the version changes
     y2 = _lotd.lod_fwd(m, xt, ph)[0].float()
     # values scale with the tables level by level (Dense: x 2, VM: x 4, CP: x 8): nothing may be left as it was
     assert ((y2 - y1).abs() > 1e-3 * y1.abs()).float().mean() > 0.9
     assert_close(y2, oracle.lotd_fwd(m_ref, x, ph.float().cpu().numpy())[0], rel=1e-3, name="y half after an in-place update")
+    assert torch.equal(_lotd.lod_fwd(m, xt, ph.data)[0].float(), y2)         # the update is seen through .data as well
     addr = ph.data_ptr()
     del ph
     other = (pt * 0.5).half()                                                # likely the freed block again, version 0
@@ -804,3 +807,59 @@ def test_params_at_odd_alignment(oracle, dev, case):
     _, _, dx2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, p_odd, j, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=False,
                                         need_dLdinput_dinput=True)
     assert_close(dx2, oracle.lotd_bwd_bwd_dx(m_ref, v, g, x, p), name="2nd-order dx")
+
+
+def _face_hugging_points(meta_dict, n, seed):
+    """points whose locator value fma(x, R - 2, 0.5) sits ON a cell face or within a few ulp of it, in one random (level,
+    dim) per point: x = the fp32 number nearest (k - 0.5) / (R - 2), moved by -2 ... +2 ulp.  The other coordinates are
+    random.  Which cell such a point belongs to is decided by the last bit of one fma -- the kernels must make the
+    reference's decision (lotd_cuda.h:959-1077: floorf(fma(x, scale, 0.5))), not a neighbouring one."""
+    rng = np.random.default_rng(seed)
+    D = meta_dict["n_dims_to_encode"]
+    res = np.asarray(meta_dict["level_res_multidim"])[:, :D]
+    x = rng.random((n, D)).astype(np.float32)
+    lv = rng.integers(0, res.shape[0], n)
+    dim = rng.integers(0, D, n)
+    R = res[lv, dim].astype(np.int64)
+    k = (rng.random(n) * (R - 2)).astype(np.int64) + 1                    # faces 1 .. R - 2 (inside the unit interval)
+    xf = ((k.astype(np.float64) - 0.5) / np.maximum(R - 2, 1)).astype(np.float32)
+    ulps = rng.integers(-2, 3, n)
+    for _ in range(2):
+        xf = np.where(ulps > 0, np.nextafter(xf, np.float32(2)), np.where(ulps < 0, np.nextafter(xf, np.float32(-1)), xf)).astype(np.float32)
+        ulps = ulps - np.sign(ulps)
+    x[np.arange(n), dim] = xf
+    return np.clip(x, 1e-6, 1 - 1e-6).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", list(LOTD_CASES))
+def test_points_on_cell_faces(oracle, dev, case):
+    """round-3 review: every other LoTD parity input is resampled AWAY from cell faces (tests/util.py:lotd_inputs) and the
+    full-size tests tolerate a few rows in a neighbouring cell, so the bit-for-bit cell decision was exercised only by the
+    fuzzers.  Here EVERY point hugs a face of one level (0, 1 or 2 ulp either side): global parameter indices bit-exact
+    (Dense / Hash metas, lod_get_grid_index), values and Jacobians against the oracle at the usual 1e-5 -- the Jacobian of a
+    linear level jumps across a face, so one wrong cell shows as an O(1) error there -- for the two-lane, LDS-staged and
+    generic kernels alike (n = 300 000 on the pair-type metas takes the staged route for the coarse levels)."""
+    D, res, nf, types, T, smooth = LOTD_CASES[case]
+    from nr3d_lib_amd.bindings import _lotd
+    m_ref = oracle.lotd_create_meta(D, res, nf, types, T, smooth)
+    m = _lotd.LoDMeta(D, res, nf, types, T, smooth)
+    md = m_ref.as_dict()
+    pair_type = D == 3 and all(t in ("Dense", "Hash") for t in types) and m.n_feat_per_pseudo_lvl == 2
+    n = 300_000 if pair_type else 20_011
+    x = _face_hugging_points(md, n, seed=77)
+    # the generator must do what it says: most points within 3 ulp of a face in some (level, dim)
+    v = x[:, None, :].astype(np.float64) * (np.asarray(md["level_res_multidim"])[None, :, :D] - 2) + 0.5
+    assert (np.abs(v - np.round(v)).min((1, 2)) < 1e-4).mean() > 0.95
+    rng = np.random.default_rng(78)
+    p = (rng.standard_normal(md["n_params"]) * 0.1).astype(np.float32)
+    xt, pt = torch.from_numpy(x).to(dev), torch.from_numpy(p).to(dev)
+    if all(t in ("Dense", "Hash") for t in types):
+        assert_equal(_lotd.lod_get_grid_index(m, xt), oracle.lotd_grid_index(m_ref, x), name="grid_inds on faces")
+    y_ref, j_ref = oracle.lotd_fwd(m_ref, x, p, need_dydx=True)
+    y, j = _lotd.lod_fwd(m, xt, pt, need_input_grad=True)
+    assert_close(y, y_ref, name="y on faces")
+    assert_close(j.reshape(n, -1, D), j_ref, name="dy_dx on faces")
+    # gradient scatter: the entries touched are the cell's corners -- same decision, checked through dL/dparam
+    g = (rng.standard_normal((n, m.n_encoded_dims)) * 0.1).astype(np.float32)
+    dp = _lotd.lod_bwd(m, torch.from_numpy(g).to(dev), xt, pt, None, need_input_grad=False, need_param_grad=True)[1]
+    assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL/dparam on faces", levels=m_ref)

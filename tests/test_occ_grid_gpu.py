@@ -474,3 +474,55 @@ def test_batched_accel_end_to_end(oracle, dev):
     ema.cur_batch__collect_samples(torch.zeros(4, 3, device=dev), torch.tensor([0, 1, 2, 0], device=dev), torch.ones(4, device=dev))
     ema.cur_batch__step(16, field5)
     assert ema.debug_stats()["num_occupied"] > 0
+
+
+def test_marcher_two_threads_two_streams(oracle, dev):
+    """safe from several Python threads on different streams.  Two host threads march DIFFERENT ray
+    sets (different sample counts) on their own streams, many times over, each checking every result against the oracle.
+    The op's one readback (the sample count that sizes t_starts / ridx / ...) goes through a pinned staging buffer that was
+    shared per (device, n) until round 3 -- a thread could then read the other's count and allocate too few samples
+    (round-3 review and advisor finding; thread-local since round 4, nr3d_lib_amd/_hip.py:read_i64)."""
+    import threading
+    from nr3d_lib_amd.bindings import _occ_grid
+    res = (48, 48, 48)
+    grid = grids(res, 5)["random"]
+    step = 2 * 3 ** 0.5 / 96
+    sets = []
+    for seed, side in ((11, 20), (12, 33)):
+        o, d, near, far = pinhole_rays(side, seed=seed)
+        ref = oracle.ray_marching(o, d, near, far, ROI, grid, 0, step, 1e10, 0.0, 96, True)
+        sets.append((o, d, near, far, ref))
+    assert sets[0][4][1].shape[0] != sets[1][4][1].shape[0]
+    errors = []
+    barrier = threading.Barrier(2)
+
+    def work(k):
+        try:
+            o, d, near, far, ref = sets[k]
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                args = (t(o), t(d), t(near), t(far), t(ROI), t(grid))
+                stream.synchronize()
+                barrier.wait()
+                for it in range(60):
+                    got = _occ_grid.ray_marching(*args, _occ_grid.ContractionType.AABB, step, 1e10, 0.0, 96, True)
+                    assert got[1].shape[0] == ref[1].shape[0], f"thread {k} iteration {it}: {got[1].shape[0]} samples, oracle {ref[1].shape[0]}"
+                    if it % 10 == 0:
+                        stream.synchronize()
+                        for g, r, n in zip(got, ref, ["packed_info", "t_starts", "t_ends", "ridx", "gidx"]):
+                            assert np.array_equal(g.cpu().numpy(), r), f"thread {k} iteration {it}: {n} differs"
+                stream.synchronize()
+        except Exception as e:                      # noqa: BLE001 -- reported in the main thread
+            errors.append(e)
+            try:
+                barrier.abort()
+            except Exception:                       # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors

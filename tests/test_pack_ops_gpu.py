@@ -585,3 +585,22 @@ def test_sigma_delta_to_alpha(dev):
     assert sigma_delta_to_alpha(sigma[:0], delta[:0]).numel() == 0
     # shapes that do not match fall back to the plain expression
     assert torch.allclose(sigma_delta_to_alpha(sigma.detach().view(-1, 1), delta.view(-1, 1)), a.detach().view(-1, 1), atol=2e-7)
+
+
+def test_sigma_delta_to_alpha_double_backward(dev):
+    """create_graph=True through the fused sigma -> alpha (round-3 advisor finding: the reference expression
+    `tau_to_alpha(sigma * deltas)` supports double backward, the fused Function used to be once_differentiable): the
+    second-order gradient of sum(alpha * up) wrt sigma, via a first gradient built with create_graph, against eager"""
+    from nr3d_lib_amd.graphics.nerf.nerf_utils import sigma_delta_to_alpha, tau_to_alpha
+    g = torch.Generator().manual_seed(5)
+    delta = (torch.rand(4099, generator=g) * 0.1).to(dev)
+    up = torch.randn(4099, generator=g).to(dev)
+    v = torch.randn(4099, generator=g).to(dev)
+    outs = []
+    for f in (lambda s: sigma_delta_to_alpha(s, delta), lambda s: tau_to_alpha(s * delta)):
+        sigma = (torch.rand(4099, generator=torch.Generator().manual_seed(6)) * 40).to(dev).requires_grad_(True)
+        (g1,) = torch.autograd.grad((f(sigma) * up).sum(), sigma, create_graph=True)
+        (g2,) = torch.autograd.grad((g1 * v).sum(), sigma)
+        outs.append((g1.detach(), g2))
+    assert (outs[0][0] - outs[1][0]).abs().max() <= 1e-6 * outs[1][0].abs().max()
+    assert (outs[0][1] - outs[1][1]).abs().max() <= 1e-6 * outs[1][1].abs().max()
