@@ -70,6 +70,17 @@ LIVE_TIMER = "lotd_fwd"      # the dominant kernel: timed inside the timed regio
 OP_TIMERS = {"fwd": ["lotd_fwd_lds", "lotd_fwd"], "bwd": ["lotd_contract_dx", "lotd_bin", "lotd_accum", "lotd_direct"]}
 
 
+_LIB_SHA = []
+
+
+def _lib_sha256():
+    if not _LIB_SHA:
+        import hashlib
+        from nr3d_lib_amd import _hip
+        _LIB_SHA.append(hashlib.sha256(open(_hip.LIB_PATH, "rb").read()).hexdigest() if os.path.exists(_hip.LIB_PATH) else None)
+    return _LIB_SHA[0]
+
+
 def pmc_traffic_bytes(kernels, launches=None):
     """HBM-side bytes per step of the named kernels (rocprofv3 names), from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, written by tools/gpu_profile.sh <tag> pmc on an MI355X; FETCH_SIZE and WRITE_SIZE are
@@ -80,6 +91,10 @@ def pmc_traffic_bytes(kernels, launches=None):
     if not os.path.exists(path):
         return None
     data = json.load(open(path))
+    # the counters were collected on ONE build of the library (tools/prof_summary.py stamps its sha256): for any other build
+    # -- a kernel changed after the PMC passes -- the figure would describe code that no longer runs: null then
+    if data.get("__lib_sha256") != _lib_sha256():
+        return None
     total = 0.0
     for want in kernels:
         hit = [ctr for name, ctr in data.items() if name.endswith("::" + want) and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr]
@@ -156,11 +171,17 @@ def _cpu_baseline_c3(oracle, cores, scene, n, step, seconds):
     return int(probes), int(S_r), base
 
 
-def _c3_scene(side):
-    """configs[2]'s scene: occ 128^3 = rand > 0.5 (seed 7), side^2 pinhole rays from distance 4 looking at the
-    origin, near / far from the ray-box test with [-1, 1]^3, step 2 sqrt(3) / 512, <= 512 samples per ray"""
+def _c3_scene(side, occupancy="random"):
+    """configs[2]'s scene: occ 128^3 = rand > 0.5 (seed 7; the adversarial case: runs of ~2 voxels) or the structured
+    variant SURVEY 8(d) names beside it, a sphere shell with ~5 % of the voxels occupied; side^2 pinhole rays from distance 4
+    looking at the origin, near / far from the ray-box test with [-1, 1]^3, step 2 sqrt(3) / 512, <= 512 samples per ray"""
     g = torch.Generator(device="cpu").manual_seed(7)
-    grid = torch.rand(128, 128, 128, generator=g) > 0.5
+    if occupancy == "shell":
+        ax = (torch.arange(128) + 0.5) / 128 * 2 - 1
+        r = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).norm(dim=-1)
+        grid = (r > 0.62) & (r < 0.66)                            # 5.1 % of the voxels
+    else:
+        grid = torch.rand(128, 128, 128, generator=g) > 0.5
     n = side * side
     u = torch.linspace(-0.4, 0.4, side)
     uu, vv = torch.meshgrid(u, u, indexing="ij")
@@ -174,7 +195,7 @@ def _c3_scene(side):
     return grid, o, d, near, far, torch.tensor([-1., -1, -1, 1, 1, 1]), 2 * 3 ** 0.5 / 512
 
 
-def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
+def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0, occupancy="random"):
     """BASELINE configs[2]: occ 128^3 march + alpha composite forward AND backward, side^2 rays
     (side = 64: the 4096 rays of configs[2] -- bound by the longest ray's dependent chain, marched with 32 lanes per ray
      looking ahead along the t recurrence; side = 512: enough rays to fill the chip, one lane per ray, the throughput
@@ -189,7 +210,7 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
     the fraction is information only, as SURVEY 8(d) says."""
     from nr3d_lib_amd import _hip as H
     from nr3d_lib_amd.bindings import _occ_grid, _pack_ops
-    grid_c, o_c, d_c, near_c, far_c, roi_c, step = _c3_scene(side)
+    grid_c, o_c, d_c, near_c, far_c, roi_c, step = _c3_scene(side, occupancy)
     grid, o, d, near, far, roi = (t.to(dev) for t in (grid_c, o_c, d_c, near_c, far_c, roi_c))
     n = side * side
     gen = torch.Generator(device="cpu").manual_seed(8)
@@ -215,7 +236,7 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
                                                          mask, depth, state["g"][0], state["g"][1], state["g"][2], None,
                                                          packs_tile=True)
         return S, mask, ga
-    for _ in range(3):               # the caching allocator reaches its steady state
+    for _ in range(5):               # >= 5 warm-ups; the caching allocator reaches its steady state
         S = one()[0]
     names = ("march", "composite_fwd", "composite_bwd")
     # wall clock first, with the library's event hooks off (they cost ~20 us of host time per iteration,
@@ -237,7 +258,9 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0):
     for k in names:
         tot, cnt = H.prof_read(k)
         kus[k] = tot / iters * 1e3                       # us per iteration (march: count + emit intervals)
-    out = dict(workload=f"configs[2]: occ 128^3 march + fused alpha composite fwd+bwd, {n} rays x <= 512 samples",
+    occ_txt = "rand > 0.5" if occupancy == "random" else f"sphere shell, {100 * float(grid_c.float().mean()):.1f} % occupied"
+    out = dict(workload=f"configs[2]: occ 128^3 ({occ_txt}) march + fused alpha composite fwd+bwd, {n} rays x <= 512 samples",
+               iters=iters, warmup=5,
                samples=int(S), ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4),
                kernel_us_per_iter={k: round(v, 2) for k, v in kus.items()},
                launches_per_iter="march 2 (count; cached emit + per-sample epilogue) + scan 1 (3 above 32768 rays: packed_info "
@@ -284,7 +307,7 @@ def _full_loop_setup(dev, side=512, shift=0.0):
     return model, n, fwd_bwd
 
 
-def full_loop_rate(dev, side=512, iters=9):
+def full_loop_rate(dev, side=512, iters=20, warmup=5):
     """BASELINE configs[4] on one GPU: 16-level Hash encode + occ-grid march + pack composite, forward AND backward
     through nerf_ray_query_march_occ (visibility pruning on) with a tiny random MLP head (tools/demo_field.py)."""
     model, n, fwd_bwd = _full_loop_setup(dev, side)
@@ -293,7 +316,8 @@ def full_loop_rate(dev, side=512, iters=9):
         model.zero_grad(set_to_none=True)
         return fwd_bwd()
     marched, rendered = one()
-    one()
+    for _ in range(warmup - 1):
+        one()
     # every iteration timed on its own: the driver allocates data-dependent buffers, and an iteration that happens to go
     # back to hipMalloc (caching-allocator miss) costs several ms -- the median is the steady-state figure, the mean is
     # reported next to it
@@ -307,7 +331,8 @@ def full_loop_rate(dev, side=512, iters=9):
     ms = float(np.median(per_iter))
     return dict(workload=f"march + prune + 16-level Hash LoTD encode + fused MLP decoders (32-wide) + composite, fwd+bwd, {n} rays",
                 samples_marched=marched, samples_rendered=rendered, ms_per_iter=round(ms, 3),
-                ms_per_iter_mean=round(float(np.mean(per_iter)), 3), iters=iters,
+                ms_per_iter_mean=round(float(np.mean(per_iter)), 3), ms_per_iter_min_max=[round(min(per_iter), 3), round(max(per_iter), 3)],
+                iters=iters, warmup=warmup,
                 mrays_per_s=round(n / ms / 1e3, 3), msamples_per_s=round((marched + rendered) / ms / 1e3, 3))
 
 
@@ -387,7 +412,7 @@ def lotd_large_batch_rate(log2n=24):
                 per_kernel={k: {kk: v[kk] for kk in ("avg_us", "launches_per_step", "frac")} for k, v in rf["per_kernel"].items()})
 
 
-def lotd_half_rate(dev, log2n=20, iters=10):
+def lotd_half_rate(dev, log2n=20, iters=20):
     """configs[1] with the reference's DEFAULT storage type, (float, half, float): half params / y / dL_dy / dL_dparam, float x
     and dy_dx, fp32 arithmetic (lotd_encoding.h:1501-1504).  Served natively: no whole-table conversion."""
     from nr3d_lib_amd.bindings import _lotd
@@ -403,7 +428,7 @@ def lotd_half_rate(dev, log2n=20, iters=10):
     def one():
         y, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
         return _lotd.lod_bwd(meta, g, x, params, j, need_input_grad=True, need_param_grad=True)
-    for _ in range(3):
+    for _ in range(5):
         one()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -417,7 +442,7 @@ def lotd_half_rate(dev, log2n=20, iters=10):
                 mpoints_per_s=round(N / ms / 1e3, 3))
 
 
-def lotd_second_order_rate(dev, log2n=20, iters=10):
+def lotd_second_order_rate(dev, log2n=20, iters=20):
     """the second-order passes on configs[1]'s meta: d(dL/dx)/d{dL_dy, params, x} for a random dL_ddLdx --
     what an eikonal / curvature loss adds to a step"""
     from nr3d_lib_amd.bindings import _lotd
@@ -436,7 +461,7 @@ def lotd_second_order_rate(dev, log2n=20, iters=10):
                         ("one_call", (True, True, True))):     # all three in ONE call (what autograd issues; one shared copy of dL_dy)
         fn = lambda: _lotd.lod_bwd_bwd_input(meta, v, g, x, params, j, need_dLdinput_ddLdoutput=flags[0],
                                              need_dLdinput_dparams=flags[1], need_dLdinput_dinput=flags[2])
-        for _ in range(3):
+        for _ in range(5):
             fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -482,7 +507,7 @@ def c1_dense_rate(dev):
                 max_rel_diff=float(f"{err:.2e}"))
 
 
-def forest_lotd_rate(dev, log2n=20, iters=10, by_block=False):
+def forest_lotd_rate(dev, log2n=20, iters=20, by_block=False):
     """SURVEY 8f rank 4 as an extra figure: LoTD over a forest of 8 blocks (dense level-1 octree, continuity on), the
     NGP config's first 8 levels (4 Dense + 4 Hash) per block, 2^20 points spread over the blocks:
     fwd(+dy/dx) + dL/dx + dL/dparam"""
@@ -508,7 +533,8 @@ def forest_lotd_rate(dev, log2n=20, iters=10, by_block=False):
     def one():
         y, j = _lotd.lod_fwd(metas, x, params, bi, need_input_grad=True)
         return _lotd.lod_bwd(metas, gy, x, params, j, bi, need_input_grad=True, need_param_grad=True)
-    one(); one()
+    for _ in range(5):
+        one()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(iters):
         one()
@@ -519,7 +545,7 @@ def forest_lotd_rate(dev, log2n=20, iters=10, by_block=False):
                 mpoints_per_s=round(n / ms / 1e3, 2))
 
 
-def mlp_decoder_rate(dev, log2n=22, iters=10):
+def mlp_decoder_rate(dev, log2n=22, iters=20):
     """SURVEY 8f rank 4 (second half) as an extra figure: the fused decoder 32 -> 64 -> 64 -> 16 (ReLU) on 2^22 samples,
     forward and backward (dL/dx + all dL/dW, dL/db; forward recomputed inside), against the layer-by-layer PyTorch path.
     Roofline: the f32 MFMA (157.3 TFLOP/s dense; MI355X_MICROARCH.md), FLOPs counted on the UNPADDED layer shapes."""
@@ -534,7 +560,8 @@ def mlp_decoder_rate(dev, log2n=22, iters=10):
     mac = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
 
     def timed(fn):
-        fn(); fn()
+        for _ in range(5):
+            fn()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(iters):
             fn()
@@ -571,10 +598,18 @@ def c4_mixed_rate():
     """BASELINE configs[3] as an extra figure (tools/bench_c4.py): mixed Dense/VM/CP LoTD, 2^22 points,
     fwd + dL/dx + dL/dparam + the three second-order passes"""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_c4.py"), "--log2-points", "22", "--iters", "3"],
-                       capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_c4.py"), "--log2-points", "22", "--iters", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+
+
+def reference_workloads(dev):
+    """BASELINE.md's own workloads (the reference's unit-test timings, sections 1a / 1b) on this build, one row per published figure:
+    tools/bench_reference_workloads.py"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_reference_workloads as brw
+    return brw.run(dev)
 
 
 def main():
@@ -803,7 +838,9 @@ def main():
         if world == 1 and not args.no_extra:
             out["extra"] = {}
             for name, fn in (("march_composite", lambda: march_composite_rate(dev, cpu_seconds=0.0 if args.no_cpu_baseline else 4.0)),
-                             ("march_composite_262144_rays", lambda: march_composite_rate(dev, iters=5, side=512)),
+                             ("march_composite_shell", lambda: march_composite_rate(dev, cpu_seconds=0.0 if args.no_cpu_baseline else 2.0, occupancy="shell")),
+                             ("march_composite_262144_rays", lambda: march_composite_rate(dev, iters=20, side=512)),
+                             ("march_composite_262144_rays_shell", lambda: march_composite_rate(dev, iters=20, side=512, occupancy="shell")),
                              ("c1_dense_fwd", lambda: c1_dense_rate(dev)),
                              ("full_loop_1gpu", lambda: full_loop_rate(dev)),
                              ("forest_lotd", lambda: forest_lotd_rate(dev)),
@@ -812,7 +849,8 @@ def main():
                              ("lotd_second_order", lambda: lotd_second_order_rate(dev)),
                              ("mlp_decoder", lambda: mlp_decoder_rate(dev)),
                              ("c4_mixed_lotd", c4_mixed_rate),
-                             ("lotd_2p24_points", lambda: lotd_large_batch_rate(24))):
+                             ("lotd_2p24_points", lambda: lotd_large_batch_rate(24)),
+                             ("reference_workloads", lambda: reference_workloads(dev))):
                 try:                     # an extra figure must never cost the headline line (or the other extras)
                     torch.cuda.empty_cache()
                     out["extra"][name] = fn()

@@ -388,9 +388,9 @@ __global__ __launch_bounds__(kBlock) void k_merge(uint32_t P, const T *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// packed sort: ascending, in place, optional id permutation.  One lane per pack, heapsort (no
-// auxiliary stack buffer).  Order of equal keys is unspecified (the reference's quicksort is
-// unstable as well).
+// packed sort, one LANE per pack: ascending, in place, optional id permutation; heapsort (no auxiliary stack buffer), order
+// of equal keys unspecified (the reference's quicksort is unstable as well).  Kept behind NR3D_OPT_SORT_WAVE = 0 (cross-check)
+// and as the fallback for packs the wave kernel below cannot hold in registers.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void sift_down(T *v, int64_t *ids, int64_t start, int64_t end) {
@@ -421,6 +421,145 @@ __global__ __launch_bounds__(kBlock) void k_sort(uint32_t P, T *__restrict__ val
 		if (id) { const int64_t t = id[e]; id[e] = id[0]; id[0] = t; }
 		sift_down<T>(v, id, 0, e - 1);
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed sort, one WAVE per pack (round 4; reference kernel_packed_sort_qsort pack_ops_cuda.cu:2634-2763: one thread per pack,
+// quicksort with an explicit stack in global memory -- 334 us for 4096 packs x 32..64, 12 ms for 4096 x 320..640 on its GPU).
+// A pack of up to 2048 elements lives in the wave's REGISTERS, element i = r * 64 + lane (K = 1 ... 32 registers per lane,
+// loads and stores are 256-byte rows), and goes through a bitonic network: compare-exchange partners at distance >= 64 are
+// two registers of the same lane (static indices, no data movement), partners at distance < 64 come through a wave shuffle.
+// What is compared is (order-preserving unsigned image of the key, position in the pack): all composites are distinct, so the
+// network's result is THE stable ascending order -- deterministic, and equal to a stable argsort (the reference's quicksort
+// leaves the order of equal keys unspecified).  Floats order by their IEEE total order (-0 before +0, NaNs with the sign bit
+// clear last), padding is the all-ones composite.  Packs longer than 2048 (8-byte keys: 1024) fall back to the heapsort above on
+// lane 0.
+// ------------------------------------------------------------------------------------------------
+namespace srt {
+struct E32 {                                        // 4-byte keys: one 64-bit composite, key << 32 | position
+	uint64_t c;
+	static __device__ __forceinline__ bool lt(const E32 &a, const E32 &b) { return a.c < b.c; }
+	static __device__ __forceinline__ E32 shfl_xor(const E32 &a, int m) { E32 r; r.c = __shfl_xor(a.c, m, 64); return r; }
+	static __device__ __forceinline__ E32 pad() { E32 r; r.c = ~0ull; return r; }
+	__device__ __forceinline__ uint32_t pos() const { return (uint32_t)c; }
+	static __device__ __forceinline__ E32 load(const void *vals, uint64_t at, uint32_t j, int is_float) {
+		const uint32_t b = reinterpret_cast<const uint32_t *>(vals)[at];
+		const uint32_t k = is_float ? (b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u)) : (b ^ 0x80000000u);
+		E32 r; r.c = ((uint64_t)k << 32) | j; return r;
+	}
+	__device__ __forceinline__ void store(void *vals, uint64_t at, int is_float) const {
+		const uint32_t k = (uint32_t)(c >> 32);
+		reinterpret_cast<uint32_t *>(vals)[at] = is_float ? ((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k) : (k ^ 0x80000000u);
+	}
+};
+struct E64 {                                        // 8-byte keys: (key, position) compared lexicographically
+	uint64_t k; uint32_t i;
+	static __device__ __forceinline__ bool lt(const E64 &a, const E64 &b) { return a.k < b.k || (a.k == b.k && a.i < b.i); }
+	static __device__ __forceinline__ E64 shfl_xor(const E64 &a, int m) { E64 r; r.k = __shfl_xor(a.k, m, 64); r.i = __shfl_xor(a.i, m, 64); return r; }
+	static __device__ __forceinline__ E64 pad() { E64 r; r.k = ~0ull; r.i = ~0u; return r; }
+	__device__ __forceinline__ uint32_t pos() const { return i; }
+	static __device__ __forceinline__ E64 load(const void *vals, uint64_t at, uint32_t j, int is_float) {
+		const uint64_t b = reinterpret_cast<const uint64_t *>(vals)[at];
+		E64 r; r.i = j;
+		r.k = is_float ? (b ^ ((uint64_t)((int64_t)b >> 63) | 0x8000000000000000ull)) : (b ^ 0x8000000000000000ull);
+		return r;
+	}
+	__device__ __forceinline__ void store(void *vals, uint64_t at, int is_float) const {
+		reinterpret_cast<uint64_t *>(vals)[at] = is_float ? ((k & 0x8000000000000000ull) ? (k ^ 0x8000000000000000ull) : ~k)
+		                                                  : (k ^ 0x8000000000000000ull);
+	}
+};
+
+template <typename E, int K>
+__device__ __forceinline__ void bitonic(E (&v)[K], uint32_t lane) {
+	constexpr int N = 64 * K;
+#pragma unroll
+	for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+		for (int j = k >> 1; j >= 1; j >>= 1) {
+			if (j >= 64) {                              // partners are registers r and r | jr of the same lane
+				const int jr = j >> 6;
+#pragma unroll
+				for (int r = 0; r < K; ++r) {
+					if (r & jr) continue;
+					const bool asc = ((r << 6) & k) == 0;   // k >= 128: decided by r alone
+					const E a = v[r], b = v[r | jr];
+					const bool sw = E::lt(b, a) == asc;
+					v[r] = sw ? b : a;
+					v[r | jr] = sw ? a : b;
+				}
+			} else {                                    // partner = the same register of lane ^ j
+#pragma unroll
+				for (int r = 0; r < K; ++r) {
+					const E a = v[r], b = E::shfl_xor(a, j);
+					const bool asc = ((((uint32_t)r << 6) | lane) & (uint32_t)k) == 0;
+					const bool keep_min = ((lane & (uint32_t)j) == 0) == asc;
+					v[r] = (keep_min == E::lt(b, a)) ? b : a;
+				}
+			}
+		}
+	}
+}
+
+template <typename E, int K>
+__device__ __forceinline__ void sort_pack(void *vals, int64_t *ids, uint64_t begin, uint32_t len, uint32_t lane, int is_float) {
+	E v[K];
+#pragma unroll
+	for (int r = 0; r < K; ++r) {
+		const uint32_t j = (uint32_t)r * 64u + lane;
+		v[r] = j < len ? E::load(vals, begin + j, j, is_float) : E::pad();
+	}
+	bitonic<E, K>(v, lane);
+	int64_t moved[K];
+	if (ids) {                                          // ids[begin + j] <- ids[begin + source of j]: every read before any write
+#pragma unroll
+		for (int r = 0; r < K; ++r) {
+			const uint32_t j = (uint32_t)r * 64u + lane;
+			moved[r] = j < len ? ids[begin + v[r].pos()] : 0;
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+#pragma unroll
+	for (int r = 0; r < K; ++r) {
+		const uint32_t j = (uint32_t)r * 64u + lane;
+		if (j < len) {
+			v[r].store(vals, begin + j, is_float);
+			if (ids) ids[begin + j] = moved[r];
+		}
+	}
+}
+}  // namespace srt
+
+// longest pack sorted in registers: 2048 elements with 4-byte keys, 1024 with 8-byte keys (the next size would spill)
+template <typename E> struct SortMax { static constexpr uint32_t value = sizeof(E) > 8 ? 1024u : 2048u; };
+template <typename E, typename T>
+__global__ __launch_bounds__(kBlock) void k_sort_wave(uint32_t P, void *__restrict__ vals, int64_t *__restrict__ ids,
+                                                      const int64_t *__restrict__ pi, int is_float) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t p = blockIdx.x * kWaves + (threadIdx.x >> 6);
+	if (p >= P) return;
+	const int64_t b = pi[2 * (size_t)p], n64 = pi[2 * (size_t)p + 1];
+	if (n64 < 2) return;
+	if (n64 > (int64_t)SortMax<E>::value) {             // rare: longer than the register file holds -> heapsort on one lane
+		if (lane == 0) {
+			T *v = reinterpret_cast<T *>(vals) + b;
+			int64_t *id = ids ? ids + b : nullptr;
+			for (int64_t s = (n64 - 2) / 2; s >= 0; --s) sift_down<T>(v, id, s, n64 - 1);
+			for (int64_t e = n64 - 1; e > 0; --e) {
+				{ const T t = v[e]; v[e] = v[0]; v[0] = t; }
+				if (id) { const int64_t t = id[e]; id[e] = id[0]; id[0] = t; }
+				sift_down<T>(v, id, 0, e - 1);
+			}
+		}
+		return;
+	}
+	const uint32_t n = (uint32_t)n64;
+	if (n <= 64) srt::sort_pack<E, 1>(vals, ids, (uint64_t)b, n, lane, is_float);
+	else if (n <= 128) srt::sort_pack<E, 2>(vals, ids, (uint64_t)b, n, lane, is_float);
+	else if (n <= 256) srt::sort_pack<E, 4>(vals, ids, (uint64_t)b, n, lane, is_float);
+	else if (n <= 512) srt::sort_pack<E, 8>(vals, ids, (uint64_t)b, n, lane, is_float);
+	else if (n <= 1024) srt::sort_pack<E, 16>(vals, ids, (uint64_t)b, n, lane, is_float);
+	else if constexpr (SortMax<E>::value > 1024u) srt::sort_pack<E, 32>(vals, ids, (uint64_t)b, n, lane, is_float);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1226,6 +1365,18 @@ extern "C" int nr3d_packed_invert_cdf(uint32_t P, const float *bins, const float
 extern "C" int nr3d_packed_sort(uint32_t P, uint64_t S, int dtype, void *vals, int64_t *ids, const int64_t *pack_infos,
                                 void *stream) {
 	if (P == 0) return 0;
+	if (opt::on(NR3D_OPT_SORT_WAVE)) {                  // one wave per pack, bitonic network in registers (default)
+		const hipStream_t st = (hipStream_t)stream;
+		switch (dtype) {
+		case NR3D_F32: hipLaunchKernelGGL((pk::k_sort_wave<pk::srt::E32, float>), pk::grid_for(P), dim3(pk::kBlock), 0, st, P, vals, ids, pack_infos, 1); break;
+		case NR3D_I32: hipLaunchKernelGGL((pk::k_sort_wave<pk::srt::E32, int32_t>), pk::grid_for(P), dim3(pk::kBlock), 0, st, P, vals, ids, pack_infos, 0); break;
+		case NR3D_F64: hipLaunchKernelGGL((pk::k_sort_wave<pk::srt::E64, double>), pk::grid_for(P), dim3(pk::kBlock), 0, st, P, vals, ids, pack_infos, 1); break;
+		case NR3D_I64: hipLaunchKernelGGL((pk::k_sort_wave<pk::srt::E64, int64_t>), pk::grid_for(P), dim3(pk::kBlock), 0, st, P, vals, ids, pack_infos, 0); break;
+		default: return ::nr3d::fail("pack_ops: unsupported dtype code %d (f32/f64/i32/i64)", (int)dtype);
+		}
+		NR3D_LAUNCH_CHECK();
+		return 0;
+	}
 	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_sort<T>, dim3(div_up(P, pk::kBlock)), dim3(pk::kBlock), 0,
 	                                      (hipStream_t)stream, P, (T *)vals, ids, pack_infos));
 	NR3D_LAUNCH_CHECK();

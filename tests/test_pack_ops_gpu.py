@@ -212,8 +212,12 @@ def test_merge_sorted(oracle, dev, P, b_sorted):
             assert (np.diff(merged[b:b + n]) >= 0).all()
 
 
-@pytest.mark.parametrize("dtype", [np.float32, np.int64])
-def test_sort(oracle, dev, P, dtype):
+@pytest.mark.parametrize("dtype", [np.float32, np.int64, np.float64, np.int32])
+@pytest.mark.parametrize("wave", [1, 0], ids=["wave_per_pack", "lane_per_pack"])
+def test_sort(oracle, dev, P, dtype, wave, hip_option):
+    """packed_sort_qsort: one wave per pack with a bitonic network in registers (default) and one lane per pack (heapsort,
+    option sort_wave = 0) -- packs of 0 ... 2600 elements cover every register size class (64 ... 2048) and the fallback"""
+    hip_option("sort_wave", wave)
     # literal example of the reference test (unit_test.py:1086-1092)
     vals = np.array([0.2, 0.1, 0.3, 2.9, 2.3, 2.5, 2.4, 2.1, 1.0, 1.1], np.float32)
     pi = oracle.get_pack_infos_from_n(np.array([3, 5, 2]))
@@ -223,15 +227,44 @@ def test_sort(oracle, dev, P, dtype):
     assert torch.equal(T(vals, dev)[idx], v)
     rng = np.random.default_rng(16)
     pi, S = random_packs(rng, 60, 0, 400, 0.1)
+    extra = np.array([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 2600])
+    n_all = np.concatenate([pi[:, 1], extra])
+    pi = oracle.get_pack_infos_from_n(n_all)
+    S = int(n_all.sum())
     x = (rng.standard_normal(S) * 100).astype(dtype)
+    if np.issubdtype(dtype, np.integer):
+        x = (x // 10).astype(dtype)                                        # many equal keys
+    else:
+        x[rng.random(S) < 0.05] = 0.0                                      # equal keys among floats, and signed zeros
+        x[rng.random(S) < 0.02] = -0.0
+        x[rng.random(S) < 0.01] = np.inf
+        x[rng.random(S) < 0.01] = -np.inf
     v = T(x, dev).clone()
     idx = P.packed_sort_qsort(v, T(pi, dev), True)
     want = np.concatenate([np.sort(x[b:b + n]) for b, n in pi] + [np.zeros(0, dtype)])
-    assert_equal(v, want, "sorted values")
+    assert_equal(v, want, "sorted values")                                 # (-0.0 == 0.0 compare equal: any order of the two passes)
     assert_equal(T(x, dev)[idx], want, "vals[idx]")
     ii = idx.cpu().numpy()
     for b, n in pi:
         assert sorted(ii[b:b + n].tolist()) == list(range(b, b + n))      # a permutation inside every pack
+    if wave:
+        # the register network orders (key, position): the STABLE ascending order, for packs it holds in registers
+        lim = 2048 if np.dtype(dtype).itemsize == 4 else 1024
+        for b, n in pi:
+            if 0 < n <= lim:
+                seg = x[b:b + n]
+                key = seg if np.issubdtype(dtype, np.integer) else np.where(np.signbit(seg) & (seg == 0), -np.finfo(dtype).tiny, seg)   # total order: -0 < +0
+                assert np.array_equal(ii[b:b + n] - b, np.argsort(key, kind="stable")), f"pack of {n}: not the stable order"
+    # ids need not be an arange: any int64 payload is permuted like the values
+    v2 = T(x, dev).clone()
+    payload = torch.from_numpy(rng.integers(-2 ** 40, 2 ** 40, S)).to(dev)
+    from nr3d_lib_amd import _hip as H
+    import ctypes as Cc
+    pit = T(pi, dev)
+    p0 = payload.clone()
+    H.check(H.lib().nr3d_packed_sort(H.u32(pit.shape[0]), Cc.c_uint64(S), Cc.c_int(H.DTYPE_CODE[v2.dtype]), H.ptr(v2), H.ptr(payload),
+                                     H.ptr(pit), H.stream_of(v2)))
+    assert torch.equal(payload, p0[idx]) and torch.equal(v2, v)
     assert P.packed_sort_qsort(T(x, dev).clone(), T(pi, dev), False) is None
 
 

@@ -16,7 +16,8 @@ TYPES = ["Dense", "Dense", "VM", "VM", "VM", "CP", "CP", "CP"]
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2-points", type=int, default=22)
-    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     meta = _lotd.LoDMeta(3, RES, FEATS, TYPES, None)
@@ -26,16 +27,22 @@ def main():
     x = torch.rand(N, 3, generator=g).clamp_(1e-6, 1 - 1e-6).to(dev)
     dL_dy = (torch.randn(N, meta.n_encoded_dims, generator=g) / 1e4).to(dev)
     v = torch.randn(N, 3, generator=g).to(dev)
-    ops = {}
+    ops, spread = {}, {}
 
     def timed(name, fn):
-        out = fn(); out = fn(); out = fn(); torch.cuda.synchronize()   # allocator reaches its steady state (two live output sets)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
+        # median of >= 20 timed iterations after >= 5 warm-ups, HIP events on the op's stream around EACH iteration
+        for _ in range(max(a.warmup, 3)):              # (>= 3: the allocator reaches its steady state, two live output sets)
             out = fn()
-        e1.record(); torch.cuda.synchronize()
-        ops[name] = round(e0.elapsed_time(e1) / a.iters, 4)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+        for e0, e1 in ev:
+            e0.record()
+            out = fn()
+            e1.record()
+        torch.cuda.synchronize()
+        ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        ops[name] = round(ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2]), 4)
+        spread[name] = [round(ms[0], 4), round(ms[-1], 4)]
         return out
     y, j = timed("fwd", lambda: _lotd.lod_fwd(meta, x, params, need_input_grad=True))
     timed("bwd_dx", lambda: _lotd.lod_bwd(meta, dL_dy, x, params, j, need_input_grad=True, need_param_grad=False))
@@ -69,13 +76,17 @@ def main():
                "frac": round(model[k] * N / (ops[k] * 1e-3) / 1e9 / peak, 4)} for k in ops}
     tb = sum(model.values())
     print(json.dumps({"workload": f"configs[3] mixed LoTD, 2^{a.log2_points} points", "n_params": meta.n_params,
-                      "n_encoded_dims": meta.n_encoded_dims, "ms": ops, "ms_total": round(tot, 3),
+                      "n_encoded_dims": meta.n_encoded_dims, "iters": a.iters, "warmup": max(a.warmup, 3),
+                      "protocol": "per pass: median of the per-iteration HIP-event times (ms_min_max beside it)",
+                      "ms": ops, "ms_min_max": spread, "ms_total": round(tot, 3),
                       "mpoints_per_s": round(N / tot / 1e3, 3),
                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": peak, "model": "factored (distinct table entries per point)",
                                    "algorithmic_bytes_per_point": tb, "achieved": round(tb * N / (tot * 1e-3) / 1e9, 1),
                                    "frac": round(tb * N / (tot * 1e-3) / 1e9 / peak, 4), "per_pass": per,
                                    "note": "the 8 MiB of tables are cache resident; HBM carries x, dL_dy, y, the Jacobian and "
-                                           "the scatter records"}}))
+                                           "the scatter records.  The forward's fraction prices 1 936 B/point of cache-resident "
+                                           "gathers as if they were HBM bytes (SURVEY 8d's no-cache-credit model): a fraction above "
+                                           "the ~0.79 that HBM can deliver does not mean HBM moved those bytes"}}))
 
 
 if __name__ == "__main__":

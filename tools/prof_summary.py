@@ -59,6 +59,11 @@ def pmc_json(path, out_path):
         name, rest = line[:70].strip(), line[70:].split()
         if len(rest) == 3:
             data.setdefault(name, {})[rest[0]] = float(rest[2])
+    # stamp: the counters belong to ONE build of the library; bench.py prints `traffic: null` for any other
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nr3d_lib_amd", "libnr3d_hip.so")
+    if os.path.exists(lib):
+        data["__lib_sha256"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
 
 
