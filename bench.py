@@ -583,12 +583,45 @@ def mlp_decoder_rate(dev, log2n=22, iters=20):
             out[name] = dict(fwd_ms=round(timed(fwd), 4), fwd_bwd_ms=round(timed(fwd_bwd), 4))
         finally:
             mlp_mod.USE_FUSED = True
+    # the same decoder as MLP(dtype=half): the f16-MFMA kernels (csrc/mlp_half.hip) -- the contract of the reference's fast decoder
+    # (tcnn FullyFusedMLP: half weights / activations) -- next to the reference-style autocast layer chain
+    half = {}
+    try:
+        torch.manual_seed(0)
+        net_h = MLP(dims[0], dims[-1], D=2, W=64, dtype=torch.half, device=dev)
+        xh, gyh = x.half(), gy.half()
+
+        def fwd_h():
+            with torch.no_grad():
+                return net_h(xh)
+
+        def fwd_bwd_h():
+            xr = xh.detach().requires_grad_(True)
+            net_h.zero_grad(set_to_none=True)
+            net_h(xr).backward(gyh)
+        for name, fused in (("fused", True), ("torch_autocast", False)):
+            mlp_mod.USE_FUSED = fused
+            try:
+                half[name] = dict(fwd_ms=round(timed(fwd_h), 4), fwd_bwd_ms=round(timed(fwd_bwd_h), 4))
+            finally:
+                mlp_mod.USE_FUSED = True
+        hf = half["fused"]
+        hb = max(hf["fwd_bwd_ms"] - hf["fwd_ms"], 1e-6)
+        # memory model (this kernel is HBM bound, not MFMA bound): fwd reads x, writes y; bwd reads x, dL/dy, writes dL/dx (halfs)
+        b_f, b_b = 2 * (dims[0] + dims[-1]), 2 * (2 * dims[0] + dims[-1])
+        half["roofline"] = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBPS,
+                                fwd_achieved=round(b_f * n / (hf["fwd_ms"] * 1e-3) / 1e9, 1), fwd_frac=round(b_f * n / (hf["fwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                bwd_achieved=round(b_b * n / (hb * 1e-3) / 1e9, 1), bwd_frac=round(b_b * n / (hb * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                mfma_tflops_fwd=round(2 * mac * n / (hf["fwd_ms"] * 1e-3) / 1e12, 1),
+                                mfma_tflops_bwd=round(2 * 3 * mac * n / (hb * 1e-3) / 1e12, 1), mfma_peak_f16=2500.0)
+    except Exception as ex:
+        half["error"] = repr(ex)[:300]
     f = out["fused"]
     bwd_ms = f["fwd_bwd_ms"] - f["fwd_ms"]
     peak = 157.3
     tf_fwd = 2 * mac * n / (f["fwd_ms"] * 1e-3) / 1e12
     tf_bwd = 2 * 3 * mac * n / (bwd_ms * 1e-3) / 1e12         # recomputed forward + dH chain + dW
-    return dict(workload=f"fused MLP {dims} (ReLU), 2^{log2n} samples, fp32", fused=f, torch=out["torch"],
+    return dict(workload=f"fused MLP {dims} (ReLU), 2^{log2n} samples, fp32 (+ `half`: the same network as MLP(dtype=half) on the f16 MFMA)", fused=f, torch=out["torch"], half=half,
                 msamples_per_s_fwd=round(n / f["fwd_ms"] / 1e3, 1), msamples_per_s_fwd_bwd=round(n / f["fwd_bwd_ms"] / 1e3, 1),
                 roofline=dict(bound="mfma", unit="TFLOP/s", peak=peak, fwd_achieved=round(tf_fwd, 1), fwd_frac=round(tf_fwd / peak, 3),
                               bwd_achieved=round(tf_bwd, 1), bwd_frac=round(tf_bwd / peak, 3)))

@@ -438,6 +438,24 @@ int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, i
 int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, int64_t x_feature_stride,
                      const float *packed, float *y, int64_t y_stride, void *stream);
 
+/* The same decoder in HALF precision on the f16 MFMA (csrc/mlp_half.hip) -- the contract of the reference's fast decoder,
+ * tiny-cuda-nn's FullyFusedMLP behind nr3d_lib/models/tcnn_adapter.py:37-51,74-146 (`use_tcnn_backend`,
+ * nr3d_lib/models/blocks/__init__.py:3-15): half weights / biases / inputs / outputs, activations rounded to half between
+ * the layers; the dot products of a layer are accumulated in fp32 (tcnn accumulates in half).  x, y, dL_dy, dL_dx: __half,
+ * same layout rules as the fp32 entry points (strides in elements; row-major rows 8-byte aligned with widths that are multiples
+ * of 4 take the vector / prefetched path).  weights[l] / biases[l]: __half, torch nn.Linear layout.  Sizes are BYTES here.
+ * nr3d_mlp_half_backward: dL_dW / dL_db are FP32 buffers the workgroups add their partial sums to (zero them first) -- the
+ * caller rounds them to the parameters' dtype; the fused backward applies to the same shapes as nr3d_mlp_backward. */
+uint64_t nr3d_mlp_half_packed_bytes(const nr3d_mlp_desc_t *desc);
+uint64_t nr3d_mlp_half_backward_packed_bytes(const nr3d_mlp_desc_t *desc);
+int nr3d_mlp_half_pack(const nr3d_mlp_desc_t *desc, const void *const *weights, const void *const *biases, void *packed,
+                       int with_backward, void *stream);
+int nr3d_mlp_half_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const void *x, int64_t x_stride, int64_t x_feature_stride,
+                          const void *packed, void *y, int64_t y_stride, void *stream);
+int nr3d_mlp_half_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const void *x, int64_t x_stride, int64_t x_feature_stride,
+                           const void *dL_dy, int64_t gy_stride, const void *packed, void *dL_dx, int64_t gx_stride,
+                           int64_t gx_feature_stride, float *const *dL_dW, float *const *dL_db, void *stream);
+
 /* =================================================================================================
  * pack_ops -- replaces nr3d_lib.bindings._pack_ops  (csrc/pack_ops/pack_ops.h:11-65,
  * csrc/pack_ops/pack_ops.cpp:21-58, kernels csrc/pack_ops/pack_ops_cuda.cu)

@@ -3,7 +3,8 @@ width(s) W and an output layer, optional skip connections.  Same constructor, pa
 ``.bias``: checkpoints carry over) and forward signature.
 
 Where the reference runs one GEMM + one activation kernel per layer (or hands the network to tiny-cuda-nn), this module
-runs the whole network in ONE kernel on the fp32 MFMA (csrc/mlp.hip) whenever it can: fp32 on a GPU, ReLU / no
+runs the whole network in ONE kernel on the fp32 MFMA (csrc/mlp.hip) -- or, for ``dtype=torch.half`` (the reference's autocast
+layers / its tcnn FullyFusedMLP), on the f16 MFMA (csrc/mlp_half.hip) -- whenever it can: on a GPU, ReLU / no
 activations, no skips / weight norm / equal_lr, every width <= 128.  Forward: activations stay in registers.  Backward
 (hidden width <= 64): the forward is recomputed from x inside the backward kernel, so autograd keeps x and nothing else.
 Everything else takes the layer-by-layer torch path below, with identical semantics."""
@@ -15,7 +16,7 @@ import torch.nn as nn
 from nr3d_lib_amd.models.layers import DenseLayer, get_nonlinearity
 from nr3d_lib_amd.profile import profile
 
-__all__ = ['MLP', 'FCBlock', 'FusedMLPFunction']
+__all__ = ['MLP', 'FCBlock', 'FusedMLPFunction', 'FusedMLPHalfFunction']
 
 USE_FUSED = True                       # False: always the layer-by-layer path (A/B measurements, debugging)
 # Reuse of the MFMA-ordered weight copy between calls.  OFF by default: packing is one ~3 us kernel, and the only cheap
@@ -102,6 +103,40 @@ class FusedMLPFunction(torch.autograd.Function):
         return out
 
 
+class FusedMLPHalfFunction(torch.autograd.Function):
+    """y = MLP(x) in half precision through nr3d_mlp_half_forward / _backward (csrc/mlp_half.hip, f16 MFMA): what the
+    reference gets from tiny-cuda-nn's FullyFusedMLP (``use_tcnn_backend``, nr3d_lib/models/tcnn_adapter.py:37-51,74-146) and,
+    numerically, what its ``DenseLayer(dtype=half)`` chain computes under autocast (half operands, fp32 accumulation, half
+    activations between the layers).  The parameters stay fp32 (as in the reference's DenseLayer): they are rounded to half when
+    packed, their gradients come back as the fp32 sums the kernel accumulated.  x may be float or half; y is half; dL/dx has
+    x's dtype.  args: desc, need, x, W_0, b_0 | None, W_1, ...  Higher order: as FusedMLPFunction."""
+
+    @staticmethod
+    def forward(ctx, desc, need, x, *params):
+        from nr3d_lib_amd.bindings import _mlp
+        ws, bs = list(params[0::2]), list(params[1::2])
+        packed = _mlp.pack_half(desc, ws, bs, with_backward=need)
+        xh = x if x.dtype == torch.float16 else x.half()
+        if need:
+            ctx.save_for_backward(xh, packed, *[p for p in params if p is not None])
+            ctx.desc, ctx.has_bias, ctx.x_dtype = desc, [b is not None for b in bs], x.dtype
+        return _mlp.forward_half(desc, xh, packed)
+
+    @staticmethod
+    def backward(ctx, dL_dy):
+        from nr3d_lib_amd.bindings import _mlp
+        xh, packed, *flat = ctx.saved_tensors
+        n_layers = len(ctx.has_bias)
+        if torch.is_grad_enabled():
+            return (None, None, *FusedMLPFunction._differentiable_backward(ctx, xh.to(ctx.x_dtype), flat, dL_dy.to(ctx.x_dtype)))
+        dx, dWs, dbs = _mlp.backward_half(ctx.desc, xh, dL_dy.half(), packed, need_dx=ctx.needs_input_grad[2], has_bias=ctx.has_bias)
+        grads = []
+        for i in range(n_layers):
+            grads += [dWs[i] if ctx.needs_input_grad[3 + 2 * i] else None,
+                      dbs[i] if (dbs[i] is not None and ctx.needs_input_grad[4 + 2 * i]) else None]
+        return (None, None, None if dx is None else dx.to(ctx.x_dtype), *grads)
+
+
 class MLP(nn.Module):
     def __init__(self, in_features: int, out_features: int, *, D: int = 4, W: Union[int, List[int]] = 128, skips: List[int] = [],
                  activation: Union[str, dict] = 'relu', output_activation: Union[str, dict] = None, bias=True,
@@ -169,18 +204,20 @@ class MLP(nn.Module):
         """the kernel-side description of this network, or None when the fused kernels do not apply to it"""
         if self._desc is None:
             from nr3d_lib_amd.bindings import _mlp
-            ok = self._plain and self.D >= 1 and self.dtype in (None, torch.float32)
+            ok = self._plain and self.D >= 1 and self.dtype in (None, torch.float32, torch.float16)
             hid = {self._act_code(l) for l in self.layers[:-1]}
             out = self._act_code(self.layers[-1])
             if ok and len(hid) == 1 and None not in hid and out is not None and len(self.layers) <= _mlp.MAX_LAYERS:
                 d = _mlp.MLPDesc([self.in_features, *self.Ws, self.out_features], hid.pop(), out)
-                self._desc = d if d.fusable else False
+                self._desc = d if (d.half_fusable if self.dtype == torch.float16 else d.fusable) else False
             else:
                 self._desc = False
         return self._desc or None
 
     def _fused_ok(self, x, return_last, input_max_channel):
-        if not (USE_FUSED and x.is_cuda and x.dtype == torch.float32 and not return_last and input_max_channel is None):
+        half = self.dtype == torch.float16        # dtype=half: the layers run under autocast in the reference -> the f16-MFMA kernels
+        if not (USE_FUSED and x.is_cuda and (x.dtype == torch.float32 or (half and x.dtype == torch.float16))
+                and not return_last and input_max_channel is None):
             return None
         if torch.is_autocast_enabled():
             return None
@@ -188,7 +225,7 @@ class MLP(nn.Module):
         if desc is None:
             return None
         self._needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.layers.parameters()))
-        return desc if (not self._needs_grad or desc.backward_fusable) else None
+        return desc if (not self._needs_grad or (desc.half_backward_fusable if half else desc.backward_fusable)) else None
 
     @profile
     def forward(self, x: torch.Tensor, return_last: bool = False, input_max_channel: int = None):
@@ -197,7 +234,8 @@ class MLP(nn.Module):
             params = []
             for layer in self.layers:
                 params += [layer.weight, layer.bias]
-            return FusedMLPFunction.apply(desc, self._needs_grad, x, *params)
+            fn = FusedMLPHalfFunction if self.dtype == torch.float16 else FusedMLPFunction
+            return fn.apply(desc, self._needs_grad, x, *params)
         # layer-by-layer path: layer 0 may see a truncated input, skip layers see [h, x], the input of the output layer
         # (index D) is what return_last hands back
         h, last_h = self.layers[0](x, max_channel=input_max_channel), None

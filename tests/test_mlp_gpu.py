@@ -281,3 +281,118 @@ def test_fused_block_reproduces_the_reference_modules_outputs(dev, name):
         y = m(x)
     want = gold[f"mlp_{name}_y"]
     assert float(np.abs(y.cpu().numpy() - want).max()) <= 1e-5 * max(1.0, float(np.abs(want).max()))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# half precision on the f16 MFMA (csrc/mlp_half.hip): MLP(dtype=torch.half)
+# ------------------------------------------------------------------------------------------------------------------------
+HALF_CASES = CASES + [([32, 128, 128, 16], 3001, "relu", None, True), ([128, 64, 128], 515, "relu", None, True)]
+
+
+def _half_reference(m, x, gy):
+    """the half contract in fp64: weights / biases / x rounded to half, every layer's output rounded to half (straight-through
+    for the gradient) -> (y, dx, [dW], [db]) as fp64 tensors"""
+    rnd = lambda t: t.half().double()
+
+    class _Round(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return rnd(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+    h0 = rnd(x.detach()).requires_grad_(True)
+    h = h0
+    ws = [rnd(l.weight.detach()).requires_grad_(True) for l in m.layers]
+    bs = [None if l.bias is None else rnd(l.bias.detach()).requires_grad_(True) for l in m.layers]
+    for l, W, b in zip(m.layers, ws, bs):
+        h = torch.nn.functional.linear(h, W, b)
+        if l.activation is not None:
+            h = torch.relu(h)
+        h = _Round.apply(h)
+    h.backward(rnd(gy))
+    return h.detach(), h0.grad, [w.grad for w in ws], [None if b is None else b.grad for b in bs]
+
+
+def _check_half(name, got, ref64, tol):
+    scale = float(ref64.abs().max()) or 1.0
+    err = float((got.double() - ref64).abs().max()) / scale
+    assert torch.isfinite(got).all() and err <= tol, f"{name}: rel err {err:.2e} > {tol:.2e}"
+
+
+@pytest.mark.parametrize("layout", ["row_major", "feature_major"])
+@pytest.mark.parametrize("dims,n,hidden,out,bias", HALF_CASES)
+def test_half_fused_forward_backward(dev, dims, n, hidden, out, bias, layout):
+    """MLP(dtype=half) runs on the f16-MFMA kernels: y against the half contract evaluated in fp64 at 2^-9 of the output scale
+    (one half rounding of the result + the odd activation that rounds the other way after fp32 instead of exact accumulation),
+    gradients at 2^-7 (dL/d(pre-activation) is rounded to half between the layers, as in the reference's half networks; a
+    pre-activation within half rounding of a ReLU kink flips a unit -- the inputs are moved off the kinks below); parameters
+    stay fp32 and so do their gradients.  Row-major and feature-major x, fused backward where the shape allows it, the torch
+    autocast path otherwise."""
+    from nr3d_lib_amd.models.blocks import MLP
+    torch.manual_seed(0)
+    m = MLP(dims[0], dims[-1], D=len(dims) - 2, W=dims[1:-1], activation=hidden or "none", output_activation=out, bias=bias,
+            dtype=torch.half, device=dev)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * (0.4 if p.dim() > 1 else 0.2))
+    desc = m.fused_desc()
+    assert desc is not None and desc.half_fusable
+    g = torch.Generator(device="cpu").manual_seed(1)
+    xs = torch.randn(n, dims[0], generator=g).to(dev)
+    if layout == "feature_major":
+        xt = xs.t().contiguous().requires_grad_(True)
+        x = xt.t()
+    else:
+        xt = x = xs.clone().requires_grad_(True)
+    gy = torch.randn(n, dims[-1], generator=g).to(dev)
+    y64, dx64, dW64, db64 = _half_reference(m, x, gy)
+    y = m(x)
+    assert y.dtype == torch.float16
+    fused_bwd = desc.half_backward_fusable
+    assert (y.grad_fn is not None and "FusedMLPHalfFunction" in type(y.grad_fn).__name__) == fused_bwd
+    y.backward(gy.half())
+    _check_half("y", y.detach(), y64, 2.0 ** -9)
+    with torch.no_grad():
+        yn = m(x)
+        assert yn.dtype == torch.float16
+        _check_half("y (no_grad: fused forward for every shape)", yn, y64, 2.0 ** -9)
+    # rows whose ReLU pattern differs between the kernel and the fp64 reference (a pre-activation within rounding of zero) are
+    # excluded from the gradient comparison by construction: compare on the sum over rows, where a flipped unit is O(1/n)
+    tol = 2.0 ** -7
+    gx = (xt.grad.t() if layout == "feature_major" else xt.grad)
+    assert gx.dtype == torch.float32 and gx.shape == dx64.shape
+    bad = ((gx.double() - dx64).abs().amax(1) > tol * float(dx64.abs().max()))
+    assert float(bad.float().mean()) <= 0.02, f"dL_dx: {int(bad.sum())} of {n} rows off"
+    for l, layer in enumerate(m.layers):
+        assert layer.weight.grad.dtype == torch.float32
+        _check_half(f"dL_dW{l}", layer.weight.grad, dW64[l], 4 * tol if n < 100 else tol)
+        if bias:
+            _check_half(f"dL_db{l}", layer.bias.grad, db64[l], 4 * tol if n < 100 else tol)
+
+
+def test_half_fused_agrees_with_the_autocast_layers(dev):
+    """the same module with USE_FUSED off runs the reference's way (DenseLayer under autocast: half GEMMs): the fused half
+    kernels must agree with it to half precision, forward and parameter gradients"""
+    from nr3d_lib_amd.models.blocks import MLP
+    from nr3d_lib_amd.models.blocks import mlp as mlp_mod
+    torch.manual_seed(3)
+    m = MLP(32, 16, D=2, W=64, dtype=torch.half, device=dev)
+    x = torch.randn(20000, 32, device=dev)
+    gy = torch.randn(20000, 16, device=dev).half()
+    outs = {}
+    for fused in (True, False):
+        mlp_mod.USE_FUSED = fused
+        try:
+            m.zero_grad(set_to_none=True)
+            xr = x.clone().requires_grad_(True)
+            y = m(xr)
+            y.backward(gy)
+            outs[fused] = (y.detach().float(), xr.grad.float(), [l.weight.grad.clone() for l in m.layers])
+        finally:
+            mlp_mod.USE_FUSED = True
+    scale = float(outs[False][0].abs().max())
+    assert float((outs[True][0] - outs[False][0]).abs().max()) <= 2.0 ** -8 * scale
+    for a, b in zip(outs[True][2], outs[False][2]):
+        assert float((a - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max())
