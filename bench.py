@@ -285,7 +285,7 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0, occupancy="ran
     return out
 
 
-def _full_loop_setup(dev, side=512, shift=0.0):
+def _full_loop_setup(dev, side=512, shift=0.0, precision="float"):
     """model + rays + one forward/backward of BASELINE configs[4]'s loop on `side`^2 rays (gradients accumulate)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from demo_field import DemoField, pinhole_rays
@@ -294,7 +294,7 @@ def _full_loop_setup(dev, side=512, shift=0.0):
     ax = (torch.arange(res) + 0.5) / res * 2 - 1
     r = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).norm(dim=-1)
     occ = ((r > 0.45) & (r < 0.8)).to(dev)                      # a shell: ~19 % of the voxels occupied
-    model = DemoField(occ, 2 * 3 ** 0.5 / 512, max_steps=512, seed=1, device=dev)
+    model = DemoField(occ, 2 * 3 ** 0.5 / 512, max_steps=512, seed=1, device=dev, precision=precision)
     o, d, near, far = pinhole_rays(side, dev, shift=shift)
     n = side * side
     rays = dict(num_rays=n, rays_o=o, rays_d=d, near=near, far=far, rays_inds=torch.arange(n, device=dev))
@@ -307,10 +307,10 @@ def _full_loop_setup(dev, side=512, shift=0.0):
     return model, n, fwd_bwd
 
 
-def full_loop_rate(dev, side=512, iters=20, warmup=5):
+def full_loop_rate(dev, side=512, iters=20, warmup=5, precision="float"):
     """BASELINE configs[4] on one GPU: 16-level Hash encode + occ-grid march + pack composite, forward AND backward
     through nerf_ray_query_march_occ (visibility pruning on) with a tiny random MLP head (tools/demo_field.py)."""
-    model, n, fwd_bwd = _full_loop_setup(dev, side)
+    model, n, fwd_bwd = _full_loop_setup(dev, side, precision=precision)
 
     def one():
         model.zero_grad(set_to_none=True)
@@ -329,7 +329,8 @@ def full_loop_rate(dev, side=512, iters=20, warmup=5):
         torch.cuda.synchronize()
         per_iter.append((time.perf_counter() - t0) * 1e3)
     ms = float(np.median(per_iter))
-    return dict(workload=f"march + prune + 16-level Hash LoTD encode + fused MLP decoders (32-wide) + composite, fwd+bwd, {n} rays",
+    return dict(workload=f"march + prune + 16-level Hash LoTD encode + fused MLP decoders (32-wide) + composite, fwd+bwd, {n} rays"
+                         + (" -- half LoTD tables / features + half decoders on the f16 MFMA (the reference's default storage)" if precision == "half" else ", fp32"),
                 samples_marched=marched, samples_rendered=rendered, ms_per_iter=round(ms, 3),
                 ms_per_iter_mean=round(float(np.mean(per_iter)), 3), ms_per_iter_min_max=[round(min(per_iter), 3), round(max(per_iter), 3)],
                 iters=iters, warmup=warmup,
@@ -876,6 +877,7 @@ def main():
                              ("march_composite_262144_rays_shell", lambda: march_composite_rate(dev, iters=20, side=512, occupancy="shell")),
                              ("c1_dense_fwd", lambda: c1_dense_rate(dev)),
                              ("full_loop_1gpu", lambda: full_loop_rate(dev)),
+                             ("full_loop_1gpu_half", lambda: full_loop_rate(dev, precision="half")),
                              ("forest_lotd", lambda: forest_lotd_rate(dev)),
                              ("forest_lotd_by_block", lambda: forest_lotd_rate(dev, by_block=True)),
                              ("lotd_half_params", lambda: lotd_half_rate(dev)),

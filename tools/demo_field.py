@@ -26,26 +26,28 @@ class StaticOccGridAccel:
 class DemoField(nn.Module):
     use_view_dirs = True
 
-    def __init__(self, occ_grid, step_size, max_steps=512, hidden=32, seed=0, device=None):
+    def __init__(self, occ_grid, step_size, max_steps=512, hidden=32, seed=0, device=None, precision="float"):
+        """precision: "float" = fp32 end to end, like the headline benchmark; "half" = the reference's default storage -- half LoTD
+        tables / features (lotd.py: dtype=torch.half) and half decoders (its tcnn FullyFusedMLP; here MLP(dtype=half) on the f16 MFMA)"""
         super().__init__()
         cfg = gen_ngp_cfg()
-        self.encoding = LoTD(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], hashmap_size=cfg["hashmap_size"],
-                             dtype=torch.float)           # fp32 end to end, like the headline benchmark
+        dt = torch.half if precision == "half" else torch.float
+        self.encoding = LoTD(3, cfg["lod_res"], cfg["lod_n_feats"], cfg["lod_types"], hashmap_size=cfg["hashmap_size"], dtype=dt)
         g = torch.Generator().manual_seed(seed)
         n_params = self.encoding.meta.n_params if hasattr(self.encoding, "meta") else self.encoding.n_params
-        self.grid = nn.Parameter(torch.empty(n_params).uniform_(-1e-1, 1e-1, generator=g))
+        self.grid = nn.Parameter(torch.empty(n_params).uniform_(-1e-1, 1e-1, generator=g).to(dt))
         e = self.encoding.out_features
         # the decoder blocks of the package (fused MFMA kernels when they apply; tools/bench: NR3D_DEMO_TORCH_MLP=1 for A/B)
         if os.environ.get("NR3D_DEMO_TORCH_MLP") == "1":
             self.density = nn.Sequential(nn.Linear(e, hidden), nn.ReLU(), nn.Linear(hidden, 1 + 15))
             self.color = nn.Sequential(nn.Linear(15 + 3, hidden), nn.ReLU(), nn.Linear(hidden, 3))
         else:
-            self.density = MLP(e, 1 + 15, D=1, W=hidden, dtype=torch.float)
-            self.color = MLP(15 + 3, 3, D=1, W=hidden, dtype=torch.float)
+            self.density = MLP(e, 1 + 15, D=1, W=hidden, dtype=dt)
+            self.color = MLP(15 + 3, 3, D=1, W=hidden, dtype=dt)
         for p, s in zip(self.parameters(), range(100)):
             if p is not self.grid:
                 with torch.no_grad():
-                    p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() > 1 else 0.1))
+                    p.copy_((torch.randn(p.shape, generator=g) * (0.5 if p.dim() > 1 else 0.1)).to(p.dtype))
         with torch.no_grad():                               # sigma = 20 softplus(h0 + 2): the shift lives in the bias
             last = [m for m in self.density.modules() if getattr(m, "bias", None) is not None][-1]
             last.bias[0] += 2.0
@@ -57,7 +59,7 @@ class DemoField(nn.Module):
     def _h(self, x):
         # [-1, 1]^3 -> [0, 1]^3 in one launch (the encoder clamps to [1e-6, 1 - 1e-6] itself, lotd.py)
         feat = self.encoding(torch.addcmul(self._half, x, self._half), self.grid)
-        h = self.density(feat.float())
+        h = self.density(feat if feat.dtype == self.density.dtype else feat.float()).float()
         return torch.nn.functional.softplus(h[..., 0]) * 20.0, h[..., 1:]
 
     def query_density(self, x, **kw):
@@ -68,7 +70,7 @@ class DemoField(nn.Module):
 
     def forward(self, x, v=None, **kw):
         sigma, geo = self._h(x)
-        rgb = torch.sigmoid(self.color(torch.cat([geo, v if v is not None else torch.zeros_like(x)], -1)))
+        rgb = torch.sigmoid(self.color(torch.cat([geo, v if v is not None else torch.zeros_like(x)], -1)).float())
         return dict(sigma=sigma, rgb=rgb)
 
 
