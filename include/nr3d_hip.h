@@ -67,10 +67,12 @@ enum {
 	NR3D_OPT_CP_DIRECT = 12,         /* 1: CP levels' dL/dparam accumulated in LDS without records */
 	NR3D_OPT_MARCH_GROUP = 13,       /* 0: lanes per ray chosen from the ray count; 1 | 16 | 32 | 64 forces */
 	NR3D_OPT_PACK_SCAN = 14,         /* 1: fused composite on wave prefix products; 0: serial replay */
-	NR3D_OPT_VM_LINES_DIRECT = 15,   /* 1: VM line-table gradients accumulated in LDS, plane updates as records only */
+	NR3D_OPT_VM_LINES_DIRECT = 15,   /* 1: VM line-table gradients accumulated in LDS inside stage A, plane updates as records only (default 0: measured
+	                                  * slower -- the fp64 LDS atomics cost stage A what the smaller records save stage B) */
 	NR3D_OPT_FWD_CELL_MAJOR = 16,    /* 1: forward reads a cell-major replica of the mid Dense levels when the caller supplies one */
 	NR3D_OPT_SORT_WAVE = 17,         /* 1: packed_sort with one wave per pack (bitonic); 0: one lane per pack (heapsort) */
-	NR3D_OPT_COUNT = 18
+	NR3D_OPT_VM_DIRECT = 18,         /* 1: VM levels of <= 4 LDS-sized slices accumulate their dL/dparam in LDS without records (k_vm_direct) */
+	NR3D_OPT_COUNT = 19
 };
 int nr3d_set_option(int id, int64_t value);
 int64_t nr3d_get_option(int id);

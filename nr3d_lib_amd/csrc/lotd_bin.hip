@@ -246,6 +246,8 @@ __device__ __forceinline__ uint32_t emit_vm_component(const Lvl &L, const Cell<3
                                                       TB grid, uint32_t foff, uint32_t (&ent)[NRT], float (&val)[NRT][G]) {
 	static_assert(NRT >= 6, "six records per VM component");
 	constexpr int DA = DC == 0 ? 1 : 0, DB = DC == 2 ? 1 : 2;          // the plane's dims, ascending: bit 0 / bit 1 of m
+	// (round 4, measured: one 8-byte load per feature pair behind a run-time alignment test instead of the two 4-byte loads below is
+	// SLOWER -- k_vm_direct 1.28 -> 1.39 ms, k_bin_vm3 1.03 -> 1.07 -- the pair's second word is an L1 hit either way)
 	float pv[4][G], lv[2][G];
 	uint32_t pe[4], le[2];
 #pragma unroll
@@ -515,29 +517,46 @@ __device__ __forceinline__ uint32_t emit_forest(const ForestDev &fo, const Batch
 // its 72 KB stage allows two 256-thread workgroups per CU: 2 waves per SIMD against ~1 us gathers (profiles/
 // r03k_c4_counters_before_cp16.txt: VALU 30 %, LDS 17 %, L2 requests 55 % of their ceilings).  Threads are component-major
 // (a wave holds 64 consecutive points of ONE component), so the coherent-lane merge sees what it saw.
-template <int D, int G, bool SECOND, int NR, bool DH, bool FO, typename PT, int SPLIT = 1>
+// LINES (round 4, VM levels with SPLIT == 3): the two LINE updates of a component are not records -- a VM level's three line
+// tables are sum_d R_d entries (configs[3]: 288 / 576 / 1152), G fp64 accumulators each fit LDS many times over -- they are added
+// to a per-workgroup LDS table with ds_add_f64, exactly as k_cp_direct does for CP lines; only the component's four PLANE updates
+// are sorted and written out: 12 instead of 18 records per (point, pseudo level).  For the table to be worth flushing the
+// workgroup must see many points, so the grid is (replicas, pseudo levels) and a workgroup walks the point blocks r, r + R, ...
+// (the record slots stay indexed by block: stage B does not change); its line table goes to `lines_out` as fp32 and
+// k_vm_lines_reduce adds the replicas in order.
+constexpr uint32_t kLinesRecPerPoint = 12;
+template <int D, int G, bool SECOND, int NR, bool DH, bool FO, typename PT, int SPLIT = 1, bool LINES = false>
 __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
                                          int32_t max_level, uint32_t smooth, const float *__restrict__ x,
                                          const float *__restrict__ vin_, const float *__restrict__ g,
                                          int64_t g_sn, int64_t g_se, const PT *__restrict__ params,
                                          const Batch &ba, const ForestDev &fo, uint32_t *__restrict__ rec,
-                                         uint32_t *__restrict__ offs_g) {
+                                         uint32_t *__restrict__ offs_g, float *__restrict__ lines_out = nullptr,
+                                         uint32_t line_stride = 0) {
 	constexpr int BP = BinCfg<G, NR>::BP;                 // points per workgroup
 	constexpr int kThr = BP * SPLIT;                      // threads per workgroup
 	constexpr int NRT = NR / SPLIT;                       // record slots per thread
-	constexpr uint32_t cap = BinCfg<G, NR>::cap;
+	constexpr uint32_t cap = LINES ? (uint32_t)BP * kLinesRecPerPoint : BinCfg<G, NR>::cap;
 	constexpr int C = 1 << D;
-	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // stage[(1+G)*cap] | hist[nb + 1]
+	static_assert(!LINES || (SPLIT == 3 && D == 3), "line tables in LDS: the three-threads-per-point VM stage A");
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];   // [LINES: fp64 line table |] stage[(1+G)*cap] | hist[nb + 1]
 	__shared__ uint64_t scan_lds[kThr / 64 > 0 ? kThr / 64 : 1];
-	uint32_t *stage = smem;
-	uint32_t *hist = smem + (size_t)(1 + G) * cap;
-	const uint32_t blk = blockIdx.x, ql = blockIdx.y;
+	const uint32_t ql = blockIdx.y;
 	const uint32_t q = plan.qmap[ql];
 	const uint32_t nb = plan.nb[ql];
 	const uint32_t level = meta_level_of(md, q);
-	const uint32_t comp = SPLIT == 1 ? 0u : threadIdx.x / (uint32_t)BP;      // wave-uniform (BP is a multiple of 64)
-	const uint32_t i = blk * BP + (SPLIT == 1 ? threadIdx.x : threadIdx.x % (uint32_t)BP);
 	const Lvl L = load_level(md, level);
+	const uint32_t n_line = LINES ? (L.res[0] + L.res[1] + L.res[2]) * (uint32_t)G : 0u;     // fp64 accumulators of the line table
+	double *lines = reinterpret_cast<double *>(smem);
+	uint32_t *stage = smem + 2u * (size_t)n_line;
+	uint32_t *hist = stage + (size_t)(1 + G) * cap;
+	const uint32_t comp = SPLIT == 1 ? 0u : threadIdx.x / (uint32_t)BP;      // wave-uniform (BP is a multiple of 64)
+	if (LINES) for (uint32_t t = threadIdx.x; t < n_line; t += kThr) lines[t] = 0.0;
+	// (!LINES: exactly one trip, and in a form the compiler folds -- `blk < blockIdx.x + 1` kept the loop, and its invariants in
+	// 27 more registers: k_bin_vm3 went from 68 to 95 VGPRs and lost its second workgroup per CU)
+#pragma unroll 1
+	for (uint32_t blk = blockIdx.x, once = 1u; LINES ? blk < plan.n_blk : once != 0u; blk += gridDim.x, once = 0u) {
+	const uint32_t i = blk * BP + (SPLIT == 1 ? threadIdx.x : threadIdx.x % (uint32_t)BP);
 
 	for (uint32_t b = threadIdx.x; b <= nb; b += kThr) hist[b] = 0;
 	__syncthreads();
@@ -639,6 +658,16 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			if (same) n_rec = 0;                                         // merged into the head of the run
 		}
 	}
+	if constexpr (LINES) {
+		// records 4 and 5 of a component are its line's two entries: into the LDS table (merged runs: the head lane carries the sum)
+		if (active && n_rec == 6u) {
+#pragma unroll
+			for (uint32_t r = 4; r < 6; ++r)
+#pragma unroll
+				for (int f = 0; f < G; ++f) atomicAdd(&lines[(size_t)ent[r] * G + f], (double)val[r][f]);
+			n_rec = 4u;
+		}
+	}
 	if (nb <= kBallotRankBuckets) {
 		// A coarse level's table is one to four buckets: every record of the block would hit the same few histogram
 		// counters (LDS atomics on one address serialise).  Rank through ballots instead: per distinct bucket in the wave
@@ -725,6 +754,13 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 	}
 	uint32_t *ob = offs_g + plan.offs_base[ql];
 	for (uint32_t b = threadIdx.x; b <= nb; b += kThr) ob[(size_t)b * plan.n_blk + blk] = hist[b];
+	if (LINES) __syncthreads();                          // the next block's histogram reset must not overtake these reads
+	}
+	if constexpr (LINES) {
+		__syncthreads();
+		float *mine = lines_out + ((size_t)ql * gridDim.x + blockIdx.x) * line_stride;
+		for (uint32_t t = threadIdx.x; t < n_line; t += kThr) mine[t] = (float)lines[t];
+	}
 }
 
 // PT: storage type of the tables the product-type levels read their other factors from (DH instantiations read none)
@@ -747,6 +783,33 @@ __global__ __launch_bounds__((BinCfg<G, 24>::BP * 3)) void k_bin_vm3(BinPlan pla
                                                                      Batch ba, uint32_t *__restrict__ rec,
                                                                      uint32_t *__restrict__ offs_g) {
 	bin_body<3, G, SECOND, 24, false, false, PT, 3>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, ForestDev{}, rec, offs_g);
+}
+
+// ... and with the line updates accumulated in LDS (bin_body, LINES): grid = (replicas, pseudo levels), each workgroup walks the
+// point blocks r, r + R, ...; 12 plane records per (point, pseudo level), lines_out [pseudo level][replica][line entries x G] fp32
+template <int G, bool SECOND, typename PT>
+__global__ __launch_bounds__((BinCfg<G, 24>::BP * 3), 6) /* 6 waves per SIMD = two workgroups per CU */ void k_bin_vm3l(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n,
+                                                                      int32_t max_level, uint32_t smooth, const float *__restrict__ x,
+                                                                      const float *__restrict__ vin_, const float *__restrict__ g,
+                                                                      int64_t g_sn, int64_t g_se, const PT *__restrict__ params,
+                                                                      Batch ba, uint32_t *__restrict__ rec,
+                                                                      uint32_t *__restrict__ offs_g, float *__restrict__ lines_out,
+                                                                      uint32_t line_stride) {
+	bin_body<3, G, SECOND, 24, false, false, PT, 3, true>(plan, md, n, max_level, smooth, x, vin_, g, g_sn, g_se, params, ba, ForestDev{}, rec,
+	                                                      offs_g, lines_out, line_stride);
+}
+// dL/dparam of the line tables += the replicas' partial tables, replica 0 first (one thread per (line entry, feature))
+template <int G>
+__global__ __launch_bounds__(256) void k_vm_lines_reduce(BinPlan plan, const nr3d_lotd_meta_t *__restrict__ md, uint32_t R, uint32_t line_stride,
+                                                         const float *__restrict__ lines_part, float *__restrict__ dparam) {
+	const uint32_t ql = blockIdx.y, q = plan.qmap[ql];
+	const Lvl L = load_level(md, meta_level_of(md, q));
+	const uint32_t n_line = (L.res[0] + L.res[1] + L.res[2]) * (uint32_t)G, t = blockIdx.x * 256u + threadIdx.x;
+	if (t >= n_line) return;
+	const float *p0 = lines_part + (size_t)ql * R * line_stride + t;
+	float sum = 0.0f;
+	for (uint32_t r = 0; r < R; ++r) sum += p0[(size_t)r * line_stride];
+	dparam[L.off + (size_t)(t / G) * L.F + meta_cnt_of(md, q) * G + (t % G)] += sum;
 }
 
 // stage A for a forest of blocks (3-D): same sort, corner owners resolved through the octree; NR = 8 Dense / Hash,
@@ -1212,12 +1275,172 @@ static uint64_t cp_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level
 	return mask;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Small VM levels without records (round 4).  A VM level whose table is at most kVmDirectNb LDS-sized slices (8192 entries x 2
+// features x fp64 = 128 KiB) -- configs[3]: level 2, [128, 96, 64] x 8 features = four pseudo levels, 4/7 of all VM records --
+// is accumulated like the pair path's coarse levels: a workgroup owns ONE slice of ONE pseudo level and a share of the points,
+// walks its points, forms a component's six updates (emit_vm_component: the arithmetic of the record path, bit for bit) whenever
+// one of the component's entries can lie in its slice, and adds those that do with ds_add_f64.  No record is written, sorted or
+// read back; every slice's replicas are summed in replica order by k_vm_direct_reduce.  What it costs instead: a point's cell is
+// located once per slice (~50 VALU, four times for configs[3]) and x is re-read from the L2 / Infinity Cache.
+// -------------------------------------------------------------------------------------------------
+constexpr uint32_t kVmDirectNb = 4, kVmDirectLg = 13, kVmDirectMaxItems = 32, kVmDirectThreads = 1024;
+constexpr uint32_t kVmDirectMaxLines = 1024;   // line entries of a level: their fp64 table (16 KiB) sits behind the slice in LDS
+struct VmPlan {
+	uint32_t n_items, R, pts_per_rep, stride;     // stride: floats of one (item, replica) partial table = 2 (8192 + max line entries)
+	uint32_t q[kVmDirectMaxItems];          // pseudo level of item k
+	uint32_t slice[kVmDirectMaxItems];      // ... and which 8192-entry slice of its level
+};
+
+template <bool SECOND, typename PT>
+__global__ __launch_bounds__(kVmDirectThreads) void k_vm_direct(VmPlan vp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n, uint32_t smooth,
+                                                                const float *__restrict__ x, const float *__restrict__ vin_,
+                                                                const float *__restrict__ g, int64_t g_sn, int64_t g_se,
+                                                                const PT *__restrict__ params, float *__restrict__ partial) {
+	extern __shared__ __attribute__((aligned(16))) double vm_acc[];            // [8192 entries][2] | line table [n_lines][2]
+	constexpr uint32_t kEnt = 1u << kVmDirectLg;
+	const uint32_t r = blockIdx.x, item = blockIdx.y;
+	const uint32_t q = vp.q[item], b = vp.slice[item];
+	const Lvl L = load_level(md, meta_level_of(md, q));
+	const uint32_t n_lines = L.res[0] + L.res[1] + L.res[2];
+	double *ln_acc = vm_acc + 2u * kEnt;
+	for (uint32_t t = threadIdx.x; t < 2u * (kEnt + n_lines); t += kVmDirectThreads) vm_acc[t] = 0.0;
+	__syncthreads();
+	const uint32_t foff = meta_cnt_of(md, q) * 2u, col0 = meta_col_of(md, q);
+	const auto grid = make_tab(params + L.off);
+	const uint32_t lo = b << kVmDirectLg, hi = lo + kEnt;
+	// entry range of plane d (the level's layout: [x, y, z lines | yz, xz, xy planes]): a component can only touch this slice when
+	// its plane's range meets [lo, hi)
+	uint32_t p_lo[3], p_hi[3];
+	{
+		uint32_t acc = n_lines;
+		const uint32_t psz[3] = {L.res[1] * L.res[2], L.res[0] * L.res[2], L.res[0] * L.res[1]};
+#pragma unroll
+		for (int d = 0; d < 3; ++d) { p_lo[d] = acc; acc += psz[d]; p_hi[d] = acc; }
+	}
+	const uint32_t i_lo = r * vp.pts_per_rep, i_hi = min(n, i_lo + vp.pts_per_rep);
+	for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += kVmDirectThreads) {
+		float xp[3], a[3], grad[2];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
+		Cell<3> c;
+		locate<3>(xp, L, smooth != 0, c);
+		bool loaded = false;
+		auto component = [&](auto dc_tag) {
+			constexpr int DC = decltype(dc_tag)::value;
+			if (!(p_lo[DC] < hi && p_hi[DC] > lo)) return;                            // block-uniform
+			// the plane's four entries of this point lie between its base corner's and the opposite corner's
+			uint32_t p0[3], p3[3], pl[3], ln[3];
+			corner_pos<3>(c, insert_zero(0u, DC), p0);
+			corner_pos<3>(c, insert_zero(3u, DC), p3);
+			entry_vm(L, p0, pl, ln);
+			const uint32_t e_min = pl[DC];
+			entry_vm(L, p3, pl, ln);
+			const uint32_t e_max = pl[DC];
+			if (!(e_min < hi && e_max >= lo)) return;
+			if (!loaded) {                                                         // most (point, slice) pairs never get here
+#pragma unroll
+				for (int d = 0; d < 3; ++d) a[d] = SECOND ? c.sc[d] * vin_[(size_t)i * 3 + d] * c.dw[d] : 0.0f;
+#pragma unroll
+				for (int f = 0; f < 2; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(col0 + f) * g_se];
+				loaded = true;
+			}
+			uint32_t ent[6];
+			float val[6][2];
+			emit_vm_component<2, DC, 6, SECOND>(L, c, a, grad, grid, foff, ent, val);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				if ((ent[k] >> kVmDirectLg) != b) continue;
+				double *dst = &vm_acc[(size_t)(ent[k] - lo) * 2u];
+				atomicAdd(dst, (double)val[k][0]);
+				atomicAdd(dst + 1, (double)val[k][1]);
+			}
+			// the component's two LINE updates belong to exactly one slice: the one that holds the plane's base entry (a
+			// component whose four plane entries straddle two slices is evaluated in both, its lines counted once)
+			if ((e_min >> kVmDirectLg) == b) {
+#pragma unroll
+				for (int k = 4; k < 6; ++k) {
+					double *dst = &ln_acc[(size_t)ent[k] * 2u];
+					atomicAdd(dst, (double)val[k][0]);
+					atomicAdd(dst + 1, (double)val[k][1]);
+				}
+			}
+		};
+		component(std::integral_constant<int, 0>{});
+		component(std::integral_constant<int, 1>{});
+		component(std::integral_constant<int, 2>{});
+	}
+	__syncthreads();
+	float *mine = partial + ((size_t)item * vp.R + r) * vp.stride;
+	for (uint32_t t = threadIdx.x; t < 2u * (kEnt + n_lines); t += kVmDirectThreads) mine[t] = (float)vm_acc[t];
+}
+
+// dL/dparam of a slice += sum of its replicas' tables (replica 0 first); the workgroups of a level's slice 0 also add the line
+// tables of ALL the level's slices (slice by slice, replica by replica: a fixed order)
+__global__ __launch_bounds__(256) void k_vm_direct_reduce(VmPlan vp, const nr3d_lotd_meta_t *__restrict__ md, const float *__restrict__ partial,
+                                                          float *__restrict__ dparam) {
+	constexpr uint32_t kEnt = 1u << kVmDirectLg;
+	const uint32_t item = blockIdx.y, q = vp.q[item], t = blockIdx.x * 256u + threadIdx.x;
+	const Lvl L = load_level(md, meta_level_of(md, q));
+	const uint32_t n_lines = L.res[0] + L.res[1] + L.res[2];
+	if (t < 2u * kEnt) {
+		const uint32_t entry = (vp.slice[item] << kVmDirectLg) + (t >> 1);
+		if (entry >= L.size || entry < n_lines) return;      // the line entries belong to the other branch (another workgroup: no shared address)
+		const float *p0 = partial + (size_t)item * vp.R * vp.stride + t;
+		float sum = 0.0f;
+		for (uint32_t r = 0; r < vp.R; ++r) sum += p0[(size_t)r * vp.stride];
+		dparam[L.off + (size_t)entry * L.F + meta_cnt_of(md, q) * 2u + (t & 1u)] += sum;
+	} else if (vp.slice[item] == 0u && t - 2u * kEnt < 2u * n_lines) {
+		const uint32_t tl = t - 2u * kEnt;
+		float sum = 0.0f;
+		for (uint32_t it2 = item; it2 < vp.n_items && vp.q[it2] == q; ++it2) {
+			const float *p0 = partial + (size_t)it2 * vp.R * vp.stride + t;
+			for (uint32_t r = 0; r < vp.R; ++r) sum += p0[(size_t)r * vp.stride];
+		}
+		dparam[L.off + (size_t)(tl >> 1) * L.F + meta_cnt_of(md, q) * 2u + (tl & 1u)] += sum;
+	}
+}
+
+// the VM pseudo levels k_vm_direct serves (mask; 0: none): unbatched 3-D metas with 2-feature pseudo levels, levels of at most
+// kVmDirectNb slices inside [min_level, max_level], partial tables inside `part_floats`
+static uint64_t vm_direct_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level, int32_t max_level, uint64_t part_floats, VmPlan &vp) {
+	vp.n_items = 0; vp.R = 1; vp.pts_per_rep = n; vp.stride = 0;
+	uint32_t max_lines = 0;
+	if (!opt::on(NR3D_OPT_VM_DIRECT) || m->n_dims_to_encode != 3 || m->n_feat_per_pseudo_lvl != 2 || m->n_pseudo_levels > 64u || n == 0) return 0;
+	uint64_t mask = 0;
+	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
+		const uint32_t lv = m->map_levels[q];
+		const nr3d_lotd_level_t &L = m->levels[lv];
+		if (L.type != NR3D_LOD_VectorMatrix || (int32_t)lv < min_level || (int32_t)lv > max_level) continue;
+		const uint32_t nb = div_up(L.size, 1u << kVmDirectLg), nl = L.res[0] + L.res[1] + L.res[2];
+		if (nb > kVmDirectNb || vp.n_items + nb > kVmDirectMaxItems || nl > kVmDirectMaxLines) continue;
+		max_lines = nl > max_lines ? nl : max_lines;
+		for (uint32_t b = 0; b < nb; ++b) { vp.q[vp.n_items] = q; vp.slice[vp.n_items] = b; ++vp.n_items; }
+		mask |= 1ull << q;
+	}
+	if (!vp.n_items) return 0;
+	// one workgroup per CU (128 KiB of LDS each): about two rounds of 256, >= 8192 points per replica
+	uint32_t R = (2u * 256u) / vp.n_items;
+	const uint32_t by_points = div_up(n, 8192u);
+	R = R < 1u ? 1u : R;
+	R = R > by_points ? by_points : R;
+	vp.stride = 2u * ((1u << kVmDirectLg) + max_lines);
+	while (R > 1u && (uint64_t)R * vp.n_items * vp.stride > part_floats) --R;
+	if ((uint64_t)R * vp.n_items * vp.stride > part_floats) { vp.n_items = 0; return 0; }
+	vp.R = R;
+	vp.pts_per_rep = div_up(n, R);
+	return mask;
+}
+
 // plan for the pseudo levels of record class `cls` (0 levels => n_pseudo == 0)
+// only != 0: exactly the pseudo levels of that mask, whatever their class, in blocks of `only_bp` points with `only_nr` records per
+// point (the VM levels whose line updates stay in LDS: k_bin_vm3l)
 static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batches, uint32_t cls, BinPlan &plan,
                       uint64_t &offs_words, int32_t min_level = 0, int32_t max_level = 0x7fffffff, bool forest = false,
-                      uint64_t skip = 0) {
+                      uint64_t skip = 0, uint64_t only = 0, uint32_t only_bp = 0, uint32_t only_nr = 0) {
 	const uint32_t D = m->n_dims_to_encode, G = m->n_feat_per_pseudo_lvl;
-	const uint32_t kBinPts = bin_points(G, cls);
+	const uint32_t kBinPts = only ? only_bp : bin_points(G, cls);
+	if (only) cls = only_nr;
 	if (m->n_pseudo_levels > kMaxPlanLevels) return false;
 	uint32_t lg = 0;
 	while ((1u << (lg + 1)) <= (uint32_t)kLdsDoubles / G) ++lg;
@@ -1229,8 +1452,9 @@ static bool make_plan(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_ba
 	uint64_t base = 0;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const nr3d_lotd_level_t &L = m->levels[m->map_levels[q]];
-		if (rec_class(rec_count(L.type, D, forest)) != cls) continue;
-		if (q < 64u && ((skip >> q) & 1ull)) continue;          // served without records (k_cp_direct)
+		if (only) { if (q >= 64u || !((only >> q) & 1ull)) continue; }
+		else if (rec_class(rec_count(L.type, D, forest)) != cls) continue;
+		if (q < 64u && ((skip >> q) & 1ull)) continue;          // served without records (k_cp_direct) or by another plan
 		// levels outside the requested range get no stage-A blocks, offsets or work items (max_level schedules, the
 		// level-bucket calls of the data-parallel path)
 		if ((int32_t)m->map_levels[q] < min_level || (int32_t)m->map_levels[q] > max_level) continue;
@@ -1527,6 +1751,110 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				}
 				hipLaunchKernelGGL(k_cp_reduce, dim3(div_up(max_acc, 256u), cp.n_items), dim3(256), 0, st, cp, md, partial, dparam);
 				NR3D_LAUNCH_CHECK();
+			}
+		}
+		// small VM levels skip the records altogether (k_vm_direct), like the CP levels above
+		if (!forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size) {
+			VmPlan vp;
+			const uint64_t vmask = vm_direct_plan(meta, n, min_level, max_level, lay.part_bytes / 4, vp);
+			if (vmask) {
+				static bool vattr[64] = {};
+				int dev_id = 0;
+				NR3D_HIP_CHECK(hipGetDevice(&dev_id));
+				constexpr int kVmLds = ((2 << kVmDirectLg) + 2 * (int)kVmDirectMaxLines) * 8;
+				if (!vattr[dev_id & 63]) {
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_vm_direct<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kVmLds));
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_vm_direct<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kVmLds));
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_vm_direct<false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kVmLds));
+					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_vm_direct<true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kVmLds));
+					vattr[dev_id & 63] = true;
+				}
+				auto vd_launch = [&](auto kern, auto *tab) {
+					hipLaunchKernelGGL(kern, dim3(vp.R, vp.n_items), dim3(kVmDirectThreads), (size_t)vp.stride * 8, st, vp, md, n, meta->interpolation_type, xc, vc,
+					                   gc, sn, se, tab, partial);
+				};
+				{
+					prof::Scope ps(NR3D_PROF_LOTD_DIRECT, st);
+					if (p_half) {
+						if (second) vd_launch(k_vm_direct<true, __half>, (const __half *)params); else vd_launch(k_vm_direct<false, __half>, (const __half *)params);
+					} else {
+						if (second) vd_launch(k_vm_direct<true, float>, params); else vd_launch(k_vm_direct<false, float>, params);
+					}
+				}
+				hipLaunchKernelGGL(k_vm_direct_reduce, dim3(div_up(vp.stride, 256u), vp.n_items), dim3(256), 0, st, vp, md, partial, dparam);
+				NR3D_LAUNCH_CHECK();
+				cp_mask |= vmask;
+			}
+		}
+		// VM levels: the line tables' gradients accumulate in LDS inside stage A, only the plane updates travel as records
+		// (k_bin_vm3l; 12 instead of 18 records per point and pseudo level), then the usual stage B over those records
+		if (!forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size && D == 3 && G == 2 &&
+		    opt::on(NR3D_OPT_VM_LINES_DIRECT) && vm_split_enabled() && meta->n_pseudo_levels <= 64u) {
+			uint64_t vm_mask = 0;
+			uint32_t line_stride = 0;
+			for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
+				const nr3d_lotd_level_t &Lq = meta->levels[meta->map_levels[q]];
+				if (Lq.type != NR3D_LOD_VectorMatrix || (int32_t)meta->map_levels[q] < min_level || (int32_t)meta->map_levels[q] > max_level) continue;
+				if ((cp_mask >> q) & 1ull) continue;                        // served by k_vm_direct
+				const uint32_t nl = (Lq.res[0] + Lq.res[1] + Lq.res[2]) * G;
+				if ((uint64_t)nl * 8u > 32u * 1024u) continue;              // fp64 line table <= 32 KiB: two workgroups still share a CU
+				vm_mask |= 1ull << q;
+				line_stride = nl > line_stride ? nl : line_stride;
+			}
+			if (vm_mask) {
+				constexpr int BPL = BinCfg<2, 24>::BP;
+				BinPlan pl;
+				uint64_t ow;
+				make_plan(meta, n, n_batches, 0, pl, ow, min_level, max_level, false, cp_mask, vm_mask, (uint32_t)BPL, kLinesRecPerPoint);
+				// replicas: about four workgroups per CU in all (two are resident), never more than there are point blocks
+				uint32_t R = (4u * 256u) / pl.n_pseudo;
+				R = R < 1u ? 1u : (R > pl.n_blk ? pl.n_blk : R);
+				while (R > 1u && (uint64_t)R * pl.n_pseudo * line_stride * 4u > lay.part_bytes) --R;
+				if (pl.n_pseudo && (uint64_t)R * pl.n_pseudo * line_stride * 4u <= lay.part_bytes) {
+					uint32_t nb_max = 0;
+					for (uint32_t q = 0; q < pl.n_pseudo; ++q) nb_max = nb_max > pl.nb[q] ? nb_max : pl.nb[q];
+					const uint32_t NB = pl.bucket_base[pl.n_pseudo];
+					uint32_t *tot = plan_buf, *rep = plan_buf + NB, *item_start = plan_buf + 2 * (size_t)NB;
+					const size_t bin_lds = (size_t)line_stride * 8 + ((size_t)(1 + G) * BPL * kLinesRecPerPoint + nb_max + 1) * sizeof(uint32_t);
+					static bool lattr[64] = {};
+					int dev_id = 0;
+					NR3D_HIP_CHECK(hipGetDevice(&dev_id));
+					if (!lattr[dev_id & 63]) {
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3l<2, true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3l<2, false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3l<2, true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_bin_vm3l<2, false, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kBinLdsDyn));
+						NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_accum<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDoubles * 8));
+						lattr[dev_id & 63] = true;
+					}
+					NR3D_CHECK(bin_lds <= (size_t)kBinLdsDyn, "LoTD::bwd: VM line tables do not fit the stage-A LDS budget");
+					auto vm_launch = [&](auto kern, auto *tab) {
+						hipLaunchKernelGGL(kern, dim3(R, pl.n_pseudo), dim3(BPL * 3), bin_lds, st, pl, md, n, max_level, meta->interpolation_type,
+						                   xc, vc, gc, sn, se, tab, ba, rec, offs, partial, line_stride);
+					};
+					{
+						prof::Scope ps(NR3D_PROF_LOTD_BIN, st);
+						if (p_half) {
+							if (second) vm_launch(k_bin_vm3l<2, true, __half>, (const __half *)params); else vm_launch(k_bin_vm3l<2, false, __half>, (const __half *)params);
+						} else {
+							if (second) vm_launch(k_bin_vm3l<2, true, float>, params); else vm_launch(k_bin_vm3l<2, false, float>, params);
+						}
+					}
+					// the line tables first: stage B's replicas reuse the partial-table region afterwards
+					hipLaunchKernelGGL(k_vm_lines_reduce<2>, dim3(div_up(line_stride, 256u), pl.n_pseudo), dim3(256), 0, st, pl, md, R, line_stride,
+					                   partial, dparam);
+					hipLaunchKernelGGL(k_bucket_totals, dim3(div_up(NB, 4)), dim3(256), 0, st, pl, offs, tot);
+					hipLaunchKernelGGL(k_plan_items, dim3(1), dim3(1024), 0, st, NB, pl.n_blk, work_units(), tot, rep, item_start);
+					{
+						prof::Scope ps(NR3D_PROF_LOTD_ACCUM, st);
+						hipLaunchKernelGGL((k_accum<3, 2>), dim3(work_units() + NB), dim3(kAccThreads), kLdsDoubles * 8, st, pl, md, rec, offs, rep,
+						                   item_start, ba, partial, dparam);
+					}
+					hipLaunchKernelGGL((k_reduce_partials<3, 2>), dim3(NB, kLdsDoubles / kAccThreads), dim3(kAccThreads), 0, st, pl, md, rep, item_start, ba,
+					                   partial, dparam);
+					NR3D_LAUNCH_CHECK();
+					cp_mask |= vm_mask;                          // the record classes below leave these levels out
+				}
 			}
 		}
 		for (uint32_t cls : kClasses) {

@@ -167,16 +167,30 @@ def test_vm_stage_a_three_threads_per_point(oracle, dev, case, coherent, hip_opt
         x = np.clip(base + (np.linspace(0, 3e-3, x.shape[0], dtype=np.float32)[:, None] % 2e-4), 1e-6, 1 - 1e-6).astype(np.float32)
         xt = torch.from_numpy(x).to(dev)
     outs = {}
-    for mode in ("1", "0"):
-        hip_option("vm_split", mode)
+    # "lines": three threads per point, the line tables' gradients accumulated in LDS, 12 plane records (round 4, default);
+    # "1": three threads, 18 records; "0": one thread, 18 records
+    # "direct": VM levels of <= 4 LDS-sized slices (every VM level of these small metas) accumulate in LDS without records
+    for mode, (split, lines, direct) in (("direct", (1, 1, 1)), ("lines", (1, 1, 0)), ("1", (1, 0, 0)), ("0", (0, 0, 0))):
+        hip_option("vm_split", split)
+        hip_option("vm_lines_direct", lines)
+        hip_option("vm_direct", direct)
         dp = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)[1]
         dp2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
                                       need_dLdinput_dinput=False)[1]
-        outs[mode] = (dp, dp2)
+        dpm = _lotd.lod_bwd(m, gt, xt, pt, None, max_level=m.n_levels // 2, need_input_grad=False, need_param_grad=True)[1]
+        outs[mode] = (dp, dp2, dpm)
     assert_close(outs["1"][0], outs["0"][0].cpu().numpy(), rel=1e-6, name="dL/dparam, 3 threads vs 1", levels=m_ref)
     assert_close(outs["1"][1], outs["0"][1].cpu().numpy(), rel=1e-6, name="d(dL/dx)/dparam, 3 threads vs 1", levels=m_ref)
+    for k, nm in enumerate(("dL/dparam", "d(dL/dx)/dparam", "dL/dparam, max_level")):
+        assert_close(outs["lines"][k], outs["1"][k].cpu().numpy(), rel=1e-6, name=f"{nm}, line tables in LDS vs records", levels=m_ref)
     assert_close(outs["1"][0], oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL/dparam", levels=m_ref)
     assert_close(outs["1"][1], oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="d(dL/dx)/dparam", levels=m_ref)
+    for k, nm in enumerate(("dL/dparam", "d(dL/dx)/dparam", "dL/dparam, max_level")):
+        assert_close(outs["direct"][k], outs["1"][k].cpu().numpy(), rel=1e-6, name=f"{nm}, VM levels without records vs records", levels=m_ref)
+    assert_close(outs["direct"][0], oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL/dparam (VM direct)", levels=m_ref)
+    assert_close(outs["direct"][1], oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="d(dL/dx)/dparam (VM direct)", levels=m_ref)
+    assert_close(outs["lines"][0], oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL/dparam (lines in LDS)", levels=m_ref)
+    assert_close(outs["lines"][1], oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True), name="d(dL/dx)/dparam (lines in LDS)", levels=m_ref)
 
 
 @pytest.mark.parametrize("case", ["ngp_small", "ngp_smooth", "ngp_pair", "pair_f4"])
