@@ -428,10 +428,19 @@ __device__ __forceinline__ void pl_item(uint32_t q, uint32_t chunk, const nr3d_l
 #pragma unroll
 				for (int m = 0; m < 4; ++m) off[m] = e[m] * stride;
 			}
+			if ((dbg & 8u) && dense) {
+				// timing experiment (round 4, results wrong): what a CELL-MAJOR replica of the Dense levels would issue -- a
+				// lane's four corner pairs are 32 contiguous bytes of the cell's 64-byte record, two 16-byte loads
+				const uint32_t cb = (off[0] & ~63u) + 32u * side;
+				const float4 lo4 = *reinterpret_cast<const float4 *>(base + cb), hi4 = *reinterpret_cast<const float4 *>(base + cb + 16u);
+				t[u][0] = make_float2(lo4.x, lo4.y); t[u][1] = make_float2(lo4.z, lo4.w);
+				t[u][2] = make_float2(hi4.x, hi4.y); t[u][3] = make_float2(hi4.z, hi4.w);
+			} else {
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
 				if (dbg & 2u) t[u][m] = make_float2(__int_as_float(off[m] | 0x3f000000u), __int_as_float(off[m] ^ 0x3f123456u));
 				else t[u][m] = load_pair<PT>(base + off[m]);
+			}
 			}
 		}
 		// ---- phase 3: pair-dim lerps (the partner gets the feature it interpolates, this lane keeps its own; the true
