@@ -1135,19 +1135,70 @@ template <bool SECOND, typename PT>
 __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n, uint32_t smooth,
                                                           const float *__restrict__ x, const float *__restrict__ vin_,
                                                           const float *__restrict__ g, int64_t g_sn, int64_t g_se,
-                                                          const PT *__restrict__ params, float *__restrict__ partial) {
+                                                          const PT *__restrict__ params, float *__restrict__ partial, uint32_t opt_fix) {
 	extern __shared__ __attribute__((aligned(16))) double cp_acc[];            // [entries][2 np]
+	unsigned long long *cp_fix = reinterpret_cast<unsigned long long *>(cp_acc);
+	__shared__ uint32_t s_bound[3];                                            // max |dL/dy|, max |line entry|, max |dL_ddLdx| as float bits
 	const uint32_t r = blockIdx.x, item = blockIdx.y;
 	const uint32_t q = cp.q[item], np = cp.np[item], row = 2u * np;
 	const Lvl L = load_level(md, meta_level_of(md, q));
 	const uint32_t n_acc = L.size * row;
-	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) cp_acc[t] = 0.0;
+	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) cp_acc[t] = 0.0;        // all-zero bits: 0.0 and fixed-point 0 alike
+	if (threadIdx.x < 3) s_bound[threadIdx.x] = 0u;
 	__syncthreads();
 	const uint32_t foff = meta_cnt_of(md, q) * 2u, col0 = meta_col_of(md, q);
 	const auto grid = make_tab(params + L.off + foff);
 	const bool vec = (tab_addr(grid) % (2u * tab_elt(grid))) == 0u && (L.F & 1u) == 0u;
 	const bool quad = (tab_addr(grid) % (4u * tab_elt(grid))) == 0u && (L.F & 3u) == 0u;       // 4 features (2 pairs) per request
 	const uint32_t p_lo = r * cp.pts_per_rep, p_hi = min(n, p_lo + cp.pts_per_rep);
+	// Fixed-point accumulators (round 4): the kernel was bound by the LDS -- ds_add_f64 costs ~60 cycles per wave instruction,
+	// ds_add_u64 ~35 (tools/ubench_lds; the pair path's k_pair_accum has used them since round 2).  They need a bound on the
+	// updates BEFORE the pass: this workgroup's own maxima -- |dL/dy| over its points and columns, |T| over its line tables
+	// (and |dL_ddLdx| for the second order) -- give |update| <= B = gmax pmax^2 (x 7.5 max_d scale_d vmax, second order: |a_d| <=
+	// 1.5 scale_d |v_d|, the bracket <= 5 pmax^2), hence a scale 2^s with |update| 2^s < 2^44 and the sum of all this
+	// workgroup's updates < 2^62: exact sums, order-independent, resolution B 2^-44 (an fp32 ulp of B is B 2^-24).  Every
+	// workgroup has its own scale (its table leaves as fp32).  Non-finite or zero bounds keep the fp64 accumulators.
+	{
+		uint32_t gb = 0u, pb = 0u, vb = 0u;
+		for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kCpThreads) {
+			for (uint32_t f = 0; f < row; ++f) gb = max(gb, __float_as_uint(g[(int64_t)i * g_sn + (int64_t)(col0 + f) * g_se]) & 0x7FFFFFFFu);
+			if (SECOND)
+#pragma unroll
+				for (int d = 0; d < 3; ++d) vb = max(vb, __float_as_uint(vin_[(size_t)i * 3 + d]) & 0x7FFFFFFFu);
+		}
+		for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads)
+			pb = max(pb, __float_as_uint((float)grid[(t / row) * L.F + (t % row)]) & 0x7FFFFFFFu);
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) {
+			gb = max(gb, (uint32_t)__shfl_xor((int)gb, off, 64)); pb = max(pb, (uint32_t)__shfl_xor((int)pb, off, 64));
+			vb = max(vb, (uint32_t)__shfl_xor((int)vb, off, 64));
+		}
+		if ((threadIdx.x & 63u) == 0u) { atomicMax(&s_bound[0], gb); atomicMax(&s_bound[1], pb); atomicMax(&s_bound[2], vb); }
+	}
+	__syncthreads();
+	double fscale = 0.0, finv = 0.0;
+	bool fix = false;
+	{
+		const float gmax = __uint_as_float(s_bound[0]), pmax = __uint_as_float(s_bound[1]), vmax = __uint_as_float(s_bound[2]);
+		float B = gmax * pmax * pmax;
+		if (SECOND) B *= 7.5f * fmaxf((float)L.res[0], fmaxf((float)L.res[1], (float)L.res[2])) * vmax;
+		const uint32_t bb = __float_as_uint(B);
+		if (opt_fix && bb != 0u && bb < 0x7F000000u && B >= 1e-30f) {
+			const int e = (int)(bb >> 23) - 126;                                       // B < 2^e
+			uint32_t lg = 0;
+			while ((1u << lg) < cp.pts_per_rep) ++lg;                                  // updates per accumulator <= points of the workgroup
+			const int sc = min(62 - (int)lg - 1, 44) - e;
+			if (sc > -1000 && sc < 1000) {
+				fscale = __longlong_as_double((long long)(sc + 1023) << 52);
+				finv = __longlong_as_double((long long)(1023 - sc) << 52);
+				fix = true;
+			}
+		}
+	}
+	auto add = [&](double *dst, float v) {                                             // block-uniform branch
+		if (fix) atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)(__double_as_longlong(__fma_rn((double)v, fscale, 0x1.8p52)) - 0x4338000000000000LL));
+		else atomicAdd(dst, (double)v);
+	};
 #pragma unroll 2
 	for (uint32_t i = p_lo + threadIdx.x; i < p_hi; i += kCpThreads) {
 		float xp[3], a[3], w0[3], w1[3];
@@ -1192,8 +1243,8 @@ __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_
 						v0 = gr[f] * __fmaf_rn(w0[d], cross, -own);
 						v1 = gr[f] * __fmaf_rn(w1[d], cross, own);
 					}
-					atomicAdd(dst0 + f, (double)v0);
-					atomicAdd(dst1 + f, (double)v1);
+					add(dst0 + f, v0);
+					add(dst1 + f, v1);
 				}
 			}
 		};
@@ -1205,7 +1256,7 @@ __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_
 	}
 	__syncthreads();
 	float *mine = partial + cp.part_off[item] + (size_t)r * n_acc;
-	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) mine[t] = (float)cp_acc[t];
+	for (uint32_t t = threadIdx.x; t < n_acc; t += kCpThreads) mine[t] = fix ? (float)((double)(long long)cp_fix[t] * finv) : (float)cp_acc[t];
 }
 
 // dL/dparam of an item's pseudo levels += sum of its replicas' tables (replica 0 first)
@@ -1276,48 +1327,57 @@ static uint64_t cp_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level
 }
 
 // -------------------------------------------------------------------------------------------------
-// Small VM levels without records (round 4).  A VM level whose table is at most kVmDirectNb LDS-sized slices (8192 entries x 2
-// features x fp64 = 128 KiB) -- configs[3]: level 2, [128, 96, 64] x 8 features = four pseudo levels, 4/7 of all VM records --
-// is accumulated like the pair path's coarse levels: a workgroup owns ONE slice of ONE pseudo level and a share of the points,
-// walks its points, forms a component's six updates (emit_vm_component: the arithmetic of the record path, bit for bit) whenever
-// one of the component's entries can lie in its slice, and adds those that do with ds_add_f64.  No record is written, sorted or
-// read back; every slice's replicas are summed in replica order by k_vm_direct_reduce.  What it costs instead: a point's cell is
-// located once per slice (~50 VALU, four times for configs[3]) and x is re-read from the L2 / Infinity Cache.
+// Small VM levels without records (round 4).  A VM level whose three planes each split into at most kVmDirectChunks LDS-sized
+// pieces -- configs[3]: level 2, [128, 96, 64] x 8 features = four pseudo levels, 4/7 of all VM records -- is accumulated like the CP
+// levels: a workgroup owns ONE COMPONENT d of ONE pseudo level (the plane over the two dims != d, or a band of its rows when the plane
+// has more than 8192 entries, plus line d) and a share of the points; it walks its points, forms the component's six updates
+// (emit_vm_component: the arithmetic of the record path, bit for bit) for every point whose cell lies in its band, and adds them
+// to fp64 accumulators in LDS.  No record is written, sorted or read back; the workgroups' tables leave as fp32 and
+// k_vm_direct_reduce adds the replicas in a fixed order.  Plane-major (not table-slice-major, the first version of this round:
+// 2.08 -> 1.28 ms with its lines fixed, still half its lanes idle in every atomic) means every lane of a wave has work: a point
+// is evaluated exactly once per (pseudo level, component), in the band that owns its cell's row -- a band holds one row more than it
+// owns, for the corners one row up; that row is added to its owner's in the reduction.
 // -------------------------------------------------------------------------------------------------
-constexpr uint32_t kVmDirectNb = 4, kVmDirectLg = 13, kVmDirectMaxItems = 32, kVmDirectThreads = 1024;
-constexpr uint32_t kVmDirectMaxLines = 1024;   // line entries of a level: their fp64 table (16 KiB) sits behind the slice in LDS
+constexpr uint32_t kVmDirectChunks = 4, kVmDirectLg = 13, kVmDirectMaxItems = 64, kVmDirectThreads = 1024;
+constexpr uint32_t kVmDirectMaxLines = 1024;   // entries of ONE line: its fp64 table (16 KiB) sits behind the plane band in LDS
 struct VmPlan {
-	uint32_t n_items, R, pts_per_rep, stride;     // stride: floats of one (item, replica) partial table = 2 (8192 + max line entries)
-	uint32_t q[kVmDirectMaxItems];          // pseudo level of item k
-	uint32_t slice[kVmDirectMaxItems];      // ... and which 8192-entry slice of its level
+	uint32_t n_items, R, pts_per_rep, stride;     // stride: floats of one (item, replica) partial table = 2 (8192 + kVmDirectMaxLines)
+	uint16_t q[kVmDirectMaxItems];          // pseudo level of item k
+	uint8_t d[kVmDirectMaxItems];           // ... its component (plane over the dims != d, line d)
+	uint16_t row0[kVmDirectMaxItems];       // ... first CELL row (along the plane's first dim) it owns
+	uint16_t nrows[kVmDirectMaxItems];      // ... and how many (its LDS band holds nrows + 1 rows of entries)
 };
+struct VmGeom { uint32_t Ra, Rb, plane_lo, line_lo, Rd; int a; };
+__host__ __device__ inline VmGeom vm_geom(const uint32_t (&res)[NR3D_LOTD_MAX_DIMS], int d) {
+	VmGeom gm;
+	gm.a = d == 0 ? 1 : 0;
+	const int b = d == 2 ? 1 : 2;
+	gm.Ra = res[gm.a]; gm.Rb = res[b]; gm.Rd = res[d];
+	const uint32_t lines = res[0] + res[1] + res[2];
+	const uint32_t psz[3] = {res[1] * res[2], res[0] * res[2], res[0] * res[1]};
+	gm.plane_lo = lines + (d > 0 ? psz[0] : 0u) + (d > 1 ? psz[1] : 0u);
+	gm.line_lo = (d > 0 ? res[0] : 0u) + (d > 1 ? res[1] : 0u);
+	return gm;
+}
 
 template <bool SECOND, typename PT>
 __global__ __launch_bounds__(kVmDirectThreads) void k_vm_direct(VmPlan vp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n, uint32_t smooth,
                                                                 const float *__restrict__ x, const float *__restrict__ vin_,
                                                                 const float *__restrict__ g, int64_t g_sn, int64_t g_se,
                                                                 const PT *__restrict__ params, float *__restrict__ partial) {
-	extern __shared__ __attribute__((aligned(16))) double vm_acc[];            // [8192 entries][2] | line table [n_lines][2]
+	extern __shared__ __attribute__((aligned(16))) double vm_acc[];            // plane band [<= 8192 entries][2] | line d [Rd][2]
 	constexpr uint32_t kEnt = 1u << kVmDirectLg;
 	const uint32_t r = blockIdx.x, item = blockIdx.y;
-	const uint32_t q = vp.q[item], b = vp.slice[item];
+	const uint32_t q = vp.q[item], dc = vp.d[item], row0 = vp.row0[item], nrows = vp.nrows[item];
 	const Lvl L = load_level(md, meta_level_of(md, q));
-	const uint32_t n_lines = L.res[0] + L.res[1] + L.res[2];
+	const VmGeom gm = vm_geom(L.res, (int)dc);
 	double *ln_acc = vm_acc + 2u * kEnt;
-	for (uint32_t t = threadIdx.x; t < 2u * (kEnt + n_lines); t += kVmDirectThreads) vm_acc[t] = 0.0;
+	const uint32_t n_acc = 2u * kEnt + 2u * gm.Rd;
+	for (uint32_t t = threadIdx.x; t < n_acc; t += kVmDirectThreads) vm_acc[t] = 0.0;
 	__syncthreads();
 	const uint32_t foff = meta_cnt_of(md, q) * 2u, col0 = meta_col_of(md, q);
 	const auto grid = make_tab(params + L.off);
-	const uint32_t lo = b << kVmDirectLg, hi = lo + kEnt;
-	// entry range of plane d (the level's layout: [x, y, z lines | yz, xz, xy planes]): a component can only touch this slice when
-	// its plane's range meets [lo, hi)
-	uint32_t p_lo[3], p_hi[3];
-	{
-		uint32_t acc = n_lines;
-		const uint32_t psz[3] = {L.res[1] * L.res[2], L.res[0] * L.res[2], L.res[0] * L.res[1]};
-#pragma unroll
-		for (int d = 0; d < 3; ++d) { p_lo[d] = acc; acc += psz[d]; p_hi[d] = acc; }
-	}
+	const uint32_t band_lo = gm.plane_lo + row0 * gm.Rb;                       // first entry of this workgroup's band
 	const uint32_t i_lo = r * vp.pts_per_rep, i_hi = min(n, i_lo + vp.pts_per_rep);
 	for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += kVmDirectThreads) {
 		float xp[3], a[3], grad[2];
@@ -1325,106 +1385,106 @@ __global__ __launch_bounds__(kVmDirectThreads) void k_vm_direct(VmPlan vp, const
 		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
 		Cell<3> c;
 		locate<3>(xp, L, smooth != 0, c);
-		bool loaded = false;
-		auto component = [&](auto dc_tag) {
-			constexpr int DC = decltype(dc_tag)::value;
-			if (!(p_lo[DC] < hi && p_hi[DC] > lo)) return;                            // block-uniform
-			// the plane's four entries of this point lie between its base corner's and the opposite corner's
-			uint32_t p0[3], p3[3], pl[3], ln[3];
-			corner_pos<3>(c, insert_zero(0u, DC), p0);
-			corner_pos<3>(c, insert_zero(3u, DC), p3);
-			entry_vm(L, p0, pl, ln);
-			const uint32_t e_min = pl[DC];
-			entry_vm(L, p3, pl, ln);
-			const uint32_t e_max = pl[DC];
-			if (!(e_min < hi && e_max >= lo)) return;
-			if (!loaded) {                                                         // most (point, slice) pairs never get here
+		const uint32_t ca = gm.a == 0 ? c.g[0] : c.g[1];
+		if (ca - row0 >= nrows) continue;                                       // another band of this plane owns the point
 #pragma unroll
-				for (int d = 0; d < 3; ++d) a[d] = SECOND ? c.sc[d] * vin_[(size_t)i * 3 + d] * c.dw[d] : 0.0f;
+		for (int d = 0; d < 3; ++d) a[d] = SECOND ? c.sc[d] * vin_[(size_t)i * 3 + d] * c.dw[d] : 0.0f;
 #pragma unroll
-				for (int f = 0; f < 2; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(col0 + f) * g_se];
-				loaded = true;
-			}
-			uint32_t ent[6];
-			float val[6][2];
-			emit_vm_component<2, DC, 6, SECOND>(L, c, a, grad, grid, foff, ent, val);
+		for (int f = 0; f < 2; ++f) grad[f] = g[(int64_t)i * g_sn + (int64_t)(col0 + f) * g_se];
+		uint32_t ent[6];
+		float val[6][2];
+		if (dc == 0u) emit_vm_component<2, 0, 6, SECOND>(L, c, a, grad, grid, foff, ent, val);            // block-uniform
+		else if (dc == 1u) emit_vm_component<2, 1, 6, SECOND>(L, c, a, grad, grid, foff, ent, val);
+		else emit_vm_component<2, 2, 6, SECOND>(L, c, a, grad, grid, foff, ent, val);
 #pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				if ((ent[k] >> kVmDirectLg) != b) continue;
-				double *dst = &vm_acc[(size_t)(ent[k] - lo) * 2u];
-				atomicAdd(dst, (double)val[k][0]);
-				atomicAdd(dst + 1, (double)val[k][1]);
-			}
-			// the component's two LINE updates belong to exactly one slice: the one that holds the plane's base entry (a
-			// component whose four plane entries straddle two slices is evaluated in both, its lines counted once)
-			if ((e_min >> kVmDirectLg) == b) {
+		for (int k = 0; k < 4; ++k) {
+			double *dst = &vm_acc[(size_t)(ent[k] - band_lo) * 2u];
+			atomicAdd(dst, (double)val[k][0]);
+			atomicAdd(dst + 1, (double)val[k][1]);
+		}
 #pragma unroll
-				for (int k = 4; k < 6; ++k) {
-					double *dst = &ln_acc[(size_t)ent[k] * 2u];
-					atomicAdd(dst, (double)val[k][0]);
-					atomicAdd(dst + 1, (double)val[k][1]);
-				}
-			}
-		};
-		component(std::integral_constant<int, 0>{});
-		component(std::integral_constant<int, 1>{});
-		component(std::integral_constant<int, 2>{});
+		for (int k = 4; k < 6; ++k) {
+			double *dst = &ln_acc[(size_t)(ent[k] - gm.line_lo) * 2u];
+			atomicAdd(dst, (double)val[k][0]);
+			atomicAdd(dst + 1, (double)val[k][1]);
+		}
 	}
 	__syncthreads();
 	float *mine = partial + ((size_t)item * vp.R + r) * vp.stride;
-	for (uint32_t t = threadIdx.x; t < 2u * (kEnt + n_lines); t += kVmDirectThreads) mine[t] = (float)vm_acc[t];
+	for (uint32_t t = threadIdx.x; t < n_acc; t += kVmDirectThreads) mine[t] = (float)vm_acc[t];
 }
 
-// dL/dparam of a slice += sum of its replicas' tables (replica 0 first); the workgroups of a level's slice 0 also add the line
-// tables of ALL the level's slices (slice by slice, replica by replica: a fixed order)
+// dL/dparam += the replicas' tables, replica 0 first.  A band's extra row belongs to the NEXT band of the same plane: that band's
+// workgroups add both (no address is touched by two workgroups); the first band of a component adds line d of all its bands.
 __global__ __launch_bounds__(256) void k_vm_direct_reduce(VmPlan vp, const nr3d_lotd_meta_t *__restrict__ md, const float *__restrict__ partial,
                                                           float *__restrict__ dparam) {
 	constexpr uint32_t kEnt = 1u << kVmDirectLg;
-	const uint32_t item = blockIdx.y, q = vp.q[item], t = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t item = blockIdx.y, q = vp.q[item], dc = vp.d[item], row0 = vp.row0[item], nrows = vp.nrows[item];
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	const Lvl L = load_level(md, meta_level_of(md, q));
-	const uint32_t n_lines = L.res[0] + L.res[1] + L.res[2];
+	const VmGeom gm = vm_geom(L.res, (int)dc);
+	auto sum_item = [&](uint32_t it, uint32_t at) {
+		const float *p0 = partial + (size_t)it * vp.R * vp.stride + at;
+		float s = 0.0f;
+		for (uint32_t r = 0; r < vp.R; ++r) s += p0[(size_t)r * vp.stride];
+		return s;
+	};
 	if (t < 2u * kEnt) {
-		const uint32_t entry = (vp.slice[item] << kVmDirectLg) + (t >> 1);
-		if (entry >= L.size || entry < n_lines) return;      // the line entries belong to the other branch (another workgroup: no shared address)
-		const float *p0 = partial + (size_t)item * vp.R * vp.stride + t;
-		float sum = 0.0f;
-		for (uint32_t r = 0; r < vp.R; ++r) sum += p0[(size_t)r * vp.stride];
-		dparam[L.off + (size_t)entry * L.F + meta_cnt_of(md, q) * 2u + (t & 1u)] += sum;
-	} else if (vp.slice[item] == 0u && t - 2u * kEnt < 2u * n_lines) {
+		const uint32_t le = t >> 1, lr = le / gm.Rb, col = le - lr * gm.Rb, row = row0 + lr;
+		if (lr > nrows || row >= gm.Ra) return;
+		const bool has_next = item + 1u < vp.n_items && vp.q[item + 1u] == q && vp.d[item + 1u] == dc;
+		if (lr == nrows && has_next) return;                                    // the next band's first row: added there
+		float sum = sum_item(item, t);
+		if (lr == 0u && row0 > 0u)                                              // ... the previous band's extra row
+			sum += sum_item(item - 1u, 2u * ((uint32_t)vp.nrows[item - 1u] * gm.Rb + col) + (t & 1u));
+		dparam[L.off + (size_t)(gm.plane_lo + row * gm.Rb + col) * L.F + meta_cnt_of(md, q) * 2u + (t & 1u)] += sum;
+	} else if (row0 == 0u && t - 2u * kEnt < 2u * gm.Rd) {
 		const uint32_t tl = t - 2u * kEnt;
 		float sum = 0.0f;
-		for (uint32_t it2 = item; it2 < vp.n_items && vp.q[it2] == q; ++it2) {
-			const float *p0 = partial + (size_t)it2 * vp.R * vp.stride + t;
-			for (uint32_t r = 0; r < vp.R; ++r) sum += p0[(size_t)r * vp.stride];
-		}
-		dparam[L.off + (size_t)(tl >> 1) * L.F + meta_cnt_of(md, q) * 2u + (tl & 1u)] += sum;
+		for (uint32_t it2 = item; it2 < vp.n_items && vp.q[it2] == q && vp.d[it2] == dc; ++it2) sum += sum_item(it2, t);
+		dparam[L.off + (size_t)(gm.line_lo + (tl >> 1)) * L.F + meta_cnt_of(md, q) * 2u + (tl & 1u)] += sum;
 	}
 }
 
-// the VM pseudo levels k_vm_direct serves (mask; 0: none): unbatched 3-D metas with 2-feature pseudo levels, levels of at most
-// kVmDirectNb slices inside [min_level, max_level], partial tables inside `part_floats`
+// the VM pseudo levels k_vm_direct serves (mask; 0: none): unbatched 3-D metas with 2-feature pseudo levels, levels inside
+// [min_level, max_level] whose planes split into <= kVmDirectChunks bands each, partial tables inside `part_floats`
 static uint64_t vm_direct_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level, int32_t max_level, uint64_t part_floats, VmPlan &vp) {
-	vp.n_items = 0; vp.R = 1; vp.pts_per_rep = n; vp.stride = 0;
-	uint32_t max_lines = 0;
+	vp.n_items = 0; vp.R = 1; vp.pts_per_rep = n; vp.stride = 2u * ((1u << kVmDirectLg) + kVmDirectMaxLines);
 	if (!opt::on(NR3D_OPT_VM_DIRECT) || m->n_dims_to_encode != 3 || m->n_feat_per_pseudo_lvl != 2 || m->n_pseudo_levels > 64u || n == 0) return 0;
 	uint64_t mask = 0;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const uint32_t lv = m->map_levels[q];
 		const nr3d_lotd_level_t &L = m->levels[lv];
 		if (L.type != NR3D_LOD_VectorMatrix || (int32_t)lv < min_level || (int32_t)lv > max_level) continue;
-		const uint32_t nb = div_up(L.size, 1u << kVmDirectLg), nl = L.res[0] + L.res[1] + L.res[2];
-		if (nb > kVmDirectNb || vp.n_items + nb > kVmDirectMaxItems || nl > kVmDirectMaxLines) continue;
-		max_lines = nl > max_lines ? nl : max_lines;
-		for (uint32_t b = 0; b < nb; ++b) { vp.q[vp.n_items] = q; vp.slice[vp.n_items] = b; ++vp.n_items; }
+		uint32_t chunks[3], rows[3], total = 0;
+		bool ok = true;
+		for (int d = 0; d < 3 && ok; ++d) {
+			const VmGeom gm = vm_geom(L.res, d);
+			const uint32_t fit = (1u << kVmDirectLg) / gm.Rb;                  // rows of entries a band can hold
+			if (fit < 2u || gm.Rd > kVmDirectMaxLines || gm.Ra < 2u) { ok = false; break; }
+			const uint32_t cells = gm.Ra - 1u;                                 // cell rows 0 .. Ra - 2
+			chunks[d] = div_up(cells, fit - 1u);
+			rows[d] = div_up(cells, chunks[d]);
+			ok = chunks[d] <= kVmDirectChunks;
+			total += chunks[d];
+		}
+		if (!ok || vp.n_items + total > kVmDirectMaxItems) continue;
+		for (int d = 0; d < 3; ++d) {
+			const uint32_t cells = vm_geom(L.res, d).Ra - 1u;
+			for (uint32_t c = 0; c < chunks[d]; ++c) {
+				const uint32_t r0 = c * rows[d], k = vp.n_items++;
+				vp.q[k] = (uint16_t)q; vp.d[k] = (uint8_t)d; vp.row0[k] = (uint16_t)r0;
+				vp.nrows[k] = (uint16_t)((cells - r0) < rows[d] ? (cells - r0) : rows[d]);
+			}
+		}
 		mask |= 1ull << q;
 	}
 	if (!vp.n_items) return 0;
-	// one workgroup per CU (128 KiB of LDS each): about two rounds of 256, >= 8192 points per replica
+	// one workgroup per CU (144 KiB of LDS each): about two rounds of 256, >= 8192 points per replica
 	uint32_t R = (2u * 256u) / vp.n_items;
 	const uint32_t by_points = div_up(n, 8192u);
 	R = R < 1u ? 1u : R;
 	R = R > by_points ? by_points : R;
-	vp.stride = 2u * ((1u << kVmDirectLg) + max_lines);
 	while (R > 1u && (uint64_t)R * vp.n_items * vp.stride > part_floats) --R;
 	if ((uint64_t)R * vp.n_items * vp.stride > part_floats) { vp.n_items = 0; return 0; }
 	vp.R = R;
@@ -1742,7 +1802,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				const size_t lds = (size_t)max_acc * 8;
 				auto cp_launch = [&](auto kern, auto *tab) {
 					hipLaunchKernelGGL(kern, dim3(cp.R, cp.n_items), dim3(kCpThreads), lds, st, cp, md, n, meta->interpolation_type, xc, vc,
-					                   gc, sn, se, tab, partial);
+					                   gc, sn, se, tab, partial, opt::on(NR3D_OPT_DIRECT_FIXED) ? 1u : 0u);
 				};
 				if (p_half) {
 					if (second) cp_launch(k_cp_direct<true, __half>, (const __half *)params); else cp_launch(k_cp_direct<false, __half>, (const __half *)params);
@@ -1773,6 +1833,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 					hipLaunchKernelGGL(kern, dim3(vp.R, vp.n_items), dim3(kVmDirectThreads), (size_t)vp.stride * 8, st, vp, md, n, meta->interpolation_type, xc, vc,
 					                   gc, sn, se, tab, partial);
 				};
+				// (fixed-point accumulators pay in k_cp_direct, which is LDS bound: 1.29 -> 0.98 ms on configs[3]; in the first,
+				// slice-major k_vm_direct the bound scan and the conversions cost more than they saved, 1.28 -> 1.48 ms: fp64 here)
 				{
 					prof::Scope ps(NR3D_PROF_LOTD_DIRECT, st);
 					if (p_half) {

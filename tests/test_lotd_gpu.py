@@ -877,3 +877,35 @@ def test_points_on_cell_faces(oracle, dev, case):
     g = (rng.standard_normal((n, m.n_encoded_dims)) * 0.1).astype(np.float32)
     dp = _lotd.lod_bwd(m, torch.from_numpy(g).to(dev), xt, pt, None, need_input_grad=False, need_param_grad=True)[1]
     assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL/dparam on faces", levels=m_ref)
+
+
+@pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth", "cp_2d", "cp_only_2d4d"])
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 1e4])
+def test_cp_and_vm_levels_without_records(oracle, dev, case, scale, hip_option):
+    """CP levels (k_cp_direct) and small VM levels (k_vm_direct) accumulate dL/dparam and d(dL/dx)/dparam in LDS without records:
+    64-bit fixed-point accumulators whose scale comes from the workgroup's own bound on its updates (round 4, default) against
+    fp64 accumulators (option direct_fixed = 0), against the record path (options cp_direct = vm_direct = 0) and the oracle;
+    gradients of very different magnitudes (the scale follows them), a point count that gives several replicas"""
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=40013, seed=61)
+    g = (g * scale).astype(np.float32)
+    gt = torch.from_numpy(g).to(dev)
+    outs = {}
+    for mode, (direct, fixed) in (("fixed", (1, 1)), ("fp64", (1, 0)), ("records", (0, 0))):
+        hip_option("cp_direct", direct)
+        hip_option("vm_direct", direct)
+        hip_option("direct_fixed", fixed)
+        dp = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True)[1]
+        dp2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
+                                      need_dLdinput_dinput=False)[1]
+        outs[mode] = (dp, dp2)
+    ref1 = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
+    ref2 = oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True)
+    for mode in outs:
+        assert torch.isfinite(outs[mode][0]).all() and torch.isfinite(outs[mode][1]).all()
+        assert_close(outs[mode][0], ref1, name=f"dL/dparam ({mode})", levels=m_ref)
+        assert_close(outs[mode][1], ref2, name=f"d(dL/dx)/dparam ({mode})", levels=m_ref)
+    assert_close(outs["fixed"][0], outs["fp64"][0].cpu().numpy(), rel=1e-6, name="fixed point vs fp64, first order", levels=m_ref)
+    assert_close(outs["fixed"][1], outs["fp64"][1].cpu().numpy(), rel=1e-6, name="fixed point vs fp64, second order", levels=m_ref)
+    # all-zero gradients: the bound is zero, the kernels keep their fp64 accumulators and must return zeros
+    z = _lotd.lod_bwd(m, torch.zeros_like(gt), xt, pt, None, need_input_grad=False, need_param_grad=True)[1]
+    assert float(z.abs().max()) == 0.0
