@@ -186,7 +186,8 @@ def packed_sum(feats, pack_infos):
     _chk_feats("packed_sum", feats, pack_infos)
     P = pack_infos.shape[0]
     with H.on_device(feats.device):
-        out = torch.zeros((P,) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
+        # every pack's row is written by the kernel (an empty pack gets its zero there): no zero-fill launch in front of it
+        out = H.empty((P,) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
         H.check(H.lib().nr3d_packed_sum(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)), _code(feats),
                                         H.ptr(feats), H.ptr(pack_infos), H.ptr(out), H.stream_of(feats)))
     return out

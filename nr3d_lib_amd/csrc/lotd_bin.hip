@@ -78,7 +78,7 @@ __host__ __device__ inline uint32_t rec_count(uint32_t type, uint32_t D, bool fo
 	default: return 0u;
 	}
 }
-static inline uint32_t rec_class(uint32_t n_rec) {
+__host__ __device__ static inline uint32_t rec_class(uint32_t n_rec) {
 	return n_rec == 0 ? 0u : n_rec <= 8 ? 8u : n_rec <= 16 ? 16u : n_rec <= 24 ? 24u : n_rec <= 32 ? 32u : 48u;
 }
 
@@ -609,7 +609,26 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 			int bk[3];
 #pragma unroll
 			for (int d = 0; d < 3; ++d) bk[d] = fo.block_ks[3 * (size_t)bi + d];
-			n_rec = emit_forest<G, NR>(fo, ba, L, c, w, grad, bk, bi, params, meta_cnt_of(md, q) * G, ent, val);
+			// a cell whose eight corners lie inside the point's own block (all but a ~6/R fraction) is the plain level shifted by one
+			// node: the product types then emit the single-block records -- one per DISTINCT table entry (VM 18, CP 6, NPlaneMul 12)
+			// instead of one per corner and factor (48 / 24 / 24); same per-update arithmetic, fewer records to sort, write and add
+			bool done = false;
+			if constexpr (NR >= 24 && G <= 4) {            // (G = 8: the all-types emitter on top of 48 record slots spills several hundred registers)
+				bool interior = L.type == NR3D_LOD_VectorMatrix || L.type == NR3D_LOD_CP || L.type == NR3D_LOD_NPlaneMul;
+#pragma unroll
+				for (int d = 0; d < 3; ++d) interior = interior && c.g[d] >= 1u && c.g[d] + 1u <= L.res[d];
+				if (interior && rec_class(rec_count(L.type, 3, true)) == (uint32_t)NR) {
+					Cell<D> cs = c;
+#pragma unroll
+					for (int d = 0; d < 3; ++d) cs.g[d] -= 1u;
+					const uint32_t boff = ba.offsets ? (uint32_t)ba.offsets[bi] : bi * ba.n_params;
+					n_rec = emit_updates<D, G, NR, false, SECOND>(L, cs, w, grad, a, vin, make_tab(params + (boff + L.off)), meta_cnt_of(md, q) * G, ent, val);
+#pragma unroll
+					for (uint32_t r = 0; r < (uint32_t)NRT; ++r) if (r < n_rec) ent[r] += bi * L.size;
+					done = true;
+				}
+			}
+			if (!done) n_rec = emit_forest<G, NR>(fo, ba, L, c, w, grad, bk, bi, params, meta_cnt_of(md, q) * G, ent, val);
 		} else if constexpr (SPLIT == 3) {
 			static_assert(D == 3 && NR == 24 && !DH, "three threads per point: 3-D VM levels (record class 24)");
 			if (L.type == NR3D_LOD_VectorMatrix) {

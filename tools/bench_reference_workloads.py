@@ -138,6 +138,40 @@ def lotd_rows(dev):
     return rows
 
 
+def forest_rows(dev):
+    """nr3d_lib/models/grid_encodings/lotd/tests/unit_test_forest.py:16-23 (meta), :36-58 (forest: level 3, six blocks), :112-116 (inputs),
+    :145-181 (timings, 3.6M points).  kaolin builds the reference's octree; here ForestBlockSpace.populate_from_corners."""
+    from nr3d_lib_amd.bindings import _lotd
+    from nr3d_lib_amd.models.spatial import ForestBlockSpace
+    U = "nr3d_lib/models/grid_encodings/lotd/tests/unit_test_forest.py"
+    res = [34, 55, 90, 140, 230, 370, 600, 1000, 1600]
+    meta = _lotd.LoDMeta(3, res, [2] * 9, ["Dense", "Dense"] + ["VM"] * 7)
+    space = ForestBlockSpace(device=dev)
+    space.populate(mode="from_corners", corners=[[1, 1, 0], [1, 1, 1], [1, 1, 2], [2, 2, 2], [3, 2, 2], [4, 2, 2]], level=3)
+    metas = (meta, space.meta)
+    gen = torch.Generator(device="cpu").manual_seed(42)
+    n = 3653653
+    params = (torch.randn(meta.n_params * space.n_trees, generator=gen) / 1.0e2).to(dev).half()
+    x = torch.rand(n, 3, generator=gen).to(dev)
+    blidx = torch.randint(space.n_trees, (n,), generator=gen).to(dev)
+    y, dydx = _lotd.lod_fwd(metas, x, params, blidx, None, None, None, True)
+    grad = (torch.randn(n, meta.n_encoded_dims, generator=gen) / 1.0e4).to(dev).half()
+    label = f"forest ({space.n_trees} blocks, Dense x2 + VM x7), {n} random points (reference: 3.6M real pts)"
+    ops = (("fwd", 9430.0, ":145-150", lambda: _lotd.lod_fwd(metas, x, params, blidx, None, None, None, False)),
+           ("fwd_dydx", 39180.0, ":152-157", lambda: _lotd.lod_fwd(metas, x, params, blidx, None, None, None, True)),
+           ("bwd_dx", 9070.0, ":159-164", lambda: _lotd.lod_bwd(metas, grad, x, params, dydx, blidx, None, None, None, True, False)),
+           ("bwd_dparam", 79050.0, ":166-171", lambda: _lotd.lod_bwd(metas, grad, x, params, dydx, blidx, None, None, None, False, True)),
+           ("bwd_dx_dparam", 86580.0, ":173-178", lambda: _lotd.lod_bwd(metas, grad, x, params, dydx, blidx, None, None, None, True, True)))
+    rows = []
+    for op, refv, lines, fn in ops:
+        r = row(f"lotd {op}, {label}", refv, U + lines, fn, iters=20)
+        r["points"] = n
+        if "ours_us" in r:
+            r["mpoints_per_s"] = round(n / r["ours_us"], 2)
+        rows.append(r)
+    return rows
+
+
 def pack_rows(dev):
     import nr3d_lib_amd.graphics.pack_ops as po
     from nr3d_lib_amd.bindings import _pack_ops as _backend
@@ -227,7 +261,7 @@ def run(dev=None):
     out = dict(protocol="each row: >= 20 timed calls after >= 5 warm-ups; ours_us = wall time per call, back-to-back calls, one "
                         "synchronisation at the end (what Timer.blocked_autorange measures); device_us_* = HIP events around each call",
                ours_hw="1 x MI355X", rows=[])
-    for part in (lotd_rows, pack_rows):
+    for part in (lotd_rows, forest_rows, pack_rows):
         try:
             torch.cuda.empty_cache()
             out["rows"] += part(dev)
