@@ -302,15 +302,21 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
 		} else {
 			load_rows<IN_T>(a.x, a.xs, a.in_dim, row, valid, a.x_vec != 0, lane, xin);
 		}
-		dense<IN_T, W_T, true>(lds, xin, hcur, a.hidden_act, lane);
+		// wide networks (round 4): the LDS base goes through a register the compiler cannot see through, so that it does not hoist
+		// every layer's weight fragments out of the tile loop (hundreds of loop-invariant registers -> 344 scratch instructions
+		// in k_mlp_fwd<4, 4, 4, 2>, round-3 review)
+		uint32_t opaque = 0;
+		if constexpr (IN_T >= 4 || W_T >= 4 || OUT_T >= 4) asm volatile("s_mov_b32 %0, 0" : "=s"(opaque));
+		const float *wl = lds + opaque;
+		dense<IN_T, W_T, true>(wl, xin, hcur, a.hidden_act, lane);
 #pragma unroll 1
 		for (uint32_t l = 1; l + 1 < a.n_layers; ++l) {
 			f16v hn[W_T];
-			dense<W_T, W_T, true>(lds + off_hidden + (l - 1) * sz_hidden, hcur, hn, a.hidden_act, lane);
+			dense<W_T, W_T, true>(wl + off_hidden + (l - 1) * sz_hidden, hcur, hn, a.hidden_act, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
 		}
-		dense<W_T, OUT_T, true>(lds + off_hidden + (a.n_layers - 2) * sz_hidden, hcur, yo, a.out_act, lane);
+		dense<W_T, OUT_T, true>(wl + off_hidden + (a.n_layers - 2) * sz_hidden, hcur, yo, a.out_act, lane);
 		store_rows<OUT_T>(a.y, a.ys, a.out_dim, row, valid, a.y_vec != 0, lane, yo);
 	}
 }
