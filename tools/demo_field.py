@@ -59,8 +59,9 @@ class DemoField(nn.Module):
     def _h(self, x):
         # [-1, 1]^3 -> [0, 1]^3 in one launch (the encoder clamps to [1e-6, 1 - 1e-6] itself, lotd.py)
         feat = self.encoding(torch.addcmul(self._half, x, self._half), self.grid)
-        h = self.density(feat if feat.dtype == self.density.dtype else feat.float()).float()
-        return torch.nn.functional.softplus(h[..., 0]) * 20.0, h[..., 1:]
+        h = self.density(feat if feat.dtype == self.density.dtype else feat.float())
+        # sigma in fp32; the geometry features stay in the decoder's dtype (half decoders: no [n, 16] half -> float pass)
+        return torch.nn.functional.softplus(h[..., 0].float()) * 20.0, h[..., 1:]
 
     def query_density(self, x, **kw):
         return self._h(x)[0]
@@ -70,7 +71,8 @@ class DemoField(nn.Module):
 
     def forward(self, x, v=None, **kw):
         sigma, geo = self._h(x)
-        rgb = torch.sigmoid(self.color(torch.cat([geo, v if v is not None else torch.zeros_like(x)], -1)).float())
+        vv = v if v is not None else torch.zeros_like(x)
+        rgb = torch.sigmoid(self.color(torch.cat([geo, vv.to(geo.dtype)], -1)).float())
         return dict(sigma=sigma, rgb=rgb)
 
 
