@@ -423,8 +423,13 @@ __device__ __forceinline__ void zero_tiles(f16v (&r)[NT]) {
 
 // FAST: 0 = any layout (row-major or, with a.x_fm, feature-major x), 1 = prefetched row-major x and dL/dy, 2 = prefetched
 // feature-major x + row-major dL/dy
+// Networks of 32-wide layers leave room for EIGHT waves per workgroup, two per SIMD: the kernel is a chain of LDS round trips and
+// dependent MFMAs per tile, a second wave per SIMD hides half of it (dW of such a network is <= 64 registers; the cap is then 256 per
+// lane).  64-wide hidden layers keep four waves and the whole register file (at 256 registers 32 -> 64 -> 64 -> 16 spills 300-400 dwords).
+template <int IN_T, int W_T, int OUT_T> struct BwdCfg { static constexpr int kMaxWaves = (IN_T == 1 && W_T == 1 && OUT_T == 1) ? 8 : 4; };
+constexpr int kMaxLdsBwd = 160 * 1024;
 template <int IN_T, int W_T, int OUT_T, int NH, int FAST>
-__global__ __launch_bounds__(kThreads) void k_mlph_bwd(BwdArgs a) {
+__global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T>::kMaxWaves * 64)) void k_mlph_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	stage_weights(a.packed, a.total_bytes, lds);
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -563,9 +568,10 @@ static uint32_t bwd_tile_halfs(const Shape &s) { return (32u * s.in_t + (s.n_lay
 static uint32_t bwd_waves(const Shape &s) {
 	const uint64_t wbytes = packed_bytes(s) + transposed_bytes(s);
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;
-	for (uint32_t nw = 4; nw >= 1; --nw) {
+	const uint32_t max_waves = (s.in_t == 1 && s.w_t == 1 && s.out_t == 1) ? 8u : 4u;      // = BwdCfg<IN_T, W_T, OUT_T>::kMaxWaves
+	for (uint32_t nw = max_waves; nw >= 1; --nw) {
 		const uint64_t t = (uint64_t)nw * bwd_tile_halfs(s) * 2;
-		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)kMaxLds) return nw;
+		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)(nw > 4 ? kMaxLdsBwd : kMaxLds)) return nw;
 	}
 	return 0;
 }
@@ -715,7 +721,7 @@ extern "C" int nr3d_mlp_half_backward(const nr3d_mlp_desc_t *desc, uint64_t n, c
 	const bool gy_fast = a.gy_vec && desc->dims[desc->n_layers] % 4 == 0;
 	const int fast = !gy_fast ? 0 : x_fm ? 2 : (a.x_vec && desc->dims[0] % 4 == 0) ? 1 : 0;
 	auto launch = [&](auto kern) -> int {
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBwd));
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
 		return 0;
 	};

@@ -153,8 +153,15 @@ def test_networks_outside_the_fused_range_take_the_torch_path(dev):
         net = MLP(32, 4, **args)
         assert net.fused_desc() is None
         assert tuple(net(x).shape) == (100, 4)
+    # get_blocks(..., dtype=half, use_tcnn_backend=True) -- the reference's request for its tcnn FullyFusedMLP -- gets the f16-MFMA
+    # kernels since round 4 (rounds 1-3: the torch autocast path); bf16 still takes the torch path
     half = get_blocks(32, 4, D=1, W=64, dtype=torch.half, device=dev, use_tcnn_backend=True, weight_norm=False)
-    assert half.fused_desc() is None and half(x).dtype == torch.float16
+    d = half.fused_desc()
+    assert d is not None and d.half_fusable and d.half_backward_fusable
+    yh = half(x)
+    assert yh.dtype == torch.float16 and "FusedMLPHalfFunction" in type(yh.grad_fn).__name__
+    bf = MLP(32, 4, D=1, W=64, dtype=torch.bfloat16, device=dev)
+    assert bf.fused_desc() is None and bf(x).dtype == torch.bfloat16
     assert _mlp.MLPDesc([32, 64, 16]).fusable and not _mlp.MLPDesc([32, 16]).fusable and not _mlp.MLPDesc([300, 64, 3]).fusable
     with pytest.raises(RuntimeError, match="outside the fused"):
         _mlp.pack(_mlp.MLPDesc([32, 16]), [torch.zeros(16, 32, device=dev)], [None])
