@@ -452,8 +452,12 @@ __device__ __forceinline__ void zero_tiles(f16v (&r)[NT]) {
 // rows requested while this tile is processed (one wave per SIMD: nothing else hides the memory latency)
 // FAST: 0 = any layout (row-major or, with a.x_fm, feature-major x), 1 = prefetched row-major x and dL/dy, 2 = prefetched
 // feature-major x + row-major dL/dy
+// Networks of 32-wide layers with <= 2 hidden layers leave room for EIGHT waves per workgroup, two per SIMD (round 4, as csrc/mlp_half.hip):
+// the kernel is a chain of LDS round trips and dependent MFMAs per tile, a second wave per SIMD hides part of it.
+template <int IN_T, int W_T, int OUT_T, int NH> struct BwdCfg { static constexpr int kMaxWaves = (IN_T == 1 && W_T == 1 && OUT_T == 1 && NH <= 2) ? 8 : 4; };
+constexpr int kMaxLdsBwd = 160 * 1024;
 template <int IN_T, int W_T, int OUT_T, int NH, int FAST>
-__global__ __launch_bounds__(kThreads) void k_mlp_bwd(BwdArgs a) {
+__global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	{
 		const f4v *src = reinterpret_cast<const f4v *>(a.packed);
@@ -613,9 +617,10 @@ static uint32_t bwd_tile_floats(const Shape &s) { return (32u * s.in_t + (s.n_la
 static uint32_t bwd_waves(const Shape &s) {
 	const uint64_t wbytes = (packed_floats(s) + transposed_floats(s)) * 4;
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;     // one layer at a time
-	for (uint32_t nw = 4; nw >= 1; --nw) {
+	const uint32_t max_waves = (s.in_t == 1 && s.w_t == 1 && s.out_t == 1 && s.n_layers - 1 <= 2) ? 8u : 4u;      // = BwdCfg<...>::kMaxWaves
+	for (uint32_t nw = max_waves; nw >= 1; --nw) {
 		const uint64_t t = (uint64_t)nw * bwd_tile_floats(s) * 4;
-		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)kMaxLds) return nw;
+		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)(nw > 4 ? kMaxLdsBwd : kMaxLds)) return nw;
 	}
 	return 0;
 }
@@ -751,7 +756,7 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	const bool gy_fast = a.gy_vec && desc->dims[desc->n_layers] % 4 == 0;
 	const int fast = !gy_fast ? 0 : x_fm ? 2 : (a.x_vec && desc->dims[0] % 4 == 0) ? 1 : 0;
 	auto launch = [&](auto kern) -> int {
-		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBwd));
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
 		return 0;
 	};
