@@ -106,6 +106,75 @@ def fuzz_mlp(rng):
     return "ok"
 
 
+def fuzz_mlp_half(rng):
+    """the half decoder (csrc/mlp_half.hip) against the half contract evaluated in fp64: half x / W / b, every layer's output
+    rounded to half (straight-through for the gradients); random shapes, row-major / strided / feature-major x"""
+    n_hidden = int(rng.integers(1, 4))
+    wide = rng.random() < 0.3
+    if wide:
+        n_hidden = int(rng.integers(1, 7))
+    wmax = 128 if wide else (32 if n_hidden == 3 else 64)
+    dims = [int(rng.integers(1, 129))] + [int(rng.integers(1, wmax + 1)) for _ in range(n_hidden)] + [int(rng.integers(1, 129 if wide else 65))]
+    hid, out = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    desc = _mlp.MLPDesc(dims, hid, out)
+    if not desc.half_fusable:
+        return "skip"
+    n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 257, 1000, 4097, 20011]))
+    bias = [bool(rng.integers(0, 2)) for _ in range(len(dims) - 1)]
+    Ws = [(torch.randn(dims[i + 1], dims[i], device=dev) / max(dims[i], 1) ** 0.5).half() for i in range(len(dims) - 1)]
+    bs = [(torch.randn(dims[i + 1], device=dev) * 0.3).half() if b else None for i, b in enumerate(bias)]
+    pad = int(rng.choice([0, 0, 1, 3, 4]))
+    xb = torch.randn(n, dims[0] + pad, device=dev).half()
+    x = xb[:, pad:] if pad else xb
+    fm = rng.random() < 0.4
+    if fm:
+        x = torch.randn(dims[0], n, device=dev).half().t()
+    gy = torch.randn(n, dims[-1], device=dev).half()
+    rnd = lambda t: t.half().double()
+
+    class _Round(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return rnd(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+    h0 = x.double().detach().requires_grad_(True)
+    h = h0
+    ws = [w.double().requires_grad_(True) for w in Ws]
+    bb = [None if b is None else b.double().requires_grad_(True) for b in bs]
+    for i, (W, b) in enumerate(zip(ws, bb)):
+        h = torch.nn.functional.linear(h, W, b)
+        if (hid if i + 1 < len(ws) else out) == 1:
+            h = torch.relu(h)
+        h = _Round.apply(h)
+    tag = f"half MLP {dims} n={n} hid={hid} out={out} bias={bias} pad={pad} fm={fm}"
+    packed = _mlp.pack_half(desc, Ws, bs, with_backward=desc.half_backward_fusable)
+    y = _mlp.forward_half(desc, x, packed)
+    sc = float(h.detach().abs().max()) or 1.0
+    e = float((y.double() - h.detach()).abs().max()) / sc
+    assert torch.isfinite(y).all() and e <= 2.0 ** -8, f"{tag}: y err {e:.2e}"
+    if not desc.half_backward_fusable:
+        return "fwd"
+    h.backward(gy.double())
+    dx, dWs, dbs = _mlp.backward_half(desc, x, gy, packed, need_dx=True, has_bias=bias)
+    assert not fm or n == 1 or dims[0] == 1 or dx.stride() == (1, n), (dx.stride(), n, dims)
+    # a pre-activation within half rounding of 0 flips a ReLU unit: rows may differ, sums over many rows only slightly
+    bad = ((dx.double() - h0.grad).abs().amax(1) > 2.0 ** -6 * (float(h0.grad.abs().max()) or 1.0))
+    assert float(bad.double().mean()) <= (0.05 if n >= 100 else 1.0), f"{tag}: dx {int(bad.sum())} of {n} rows off"
+    if n >= 100:
+        for l in range(len(Ws)):
+            s_ = float(ws[l].grad.abs().max()) or 1.0
+            e = float((dWs[l].double() - ws[l].grad).abs().max()) / s_
+            assert e <= 2.0 ** -5, f"{tag}: dW{l} err {e:.2e}"
+            if bias[l]:
+                s_ = float(bb[l].grad.abs().max()) or 1.0
+                e = float((dbs[l].double() - bb[l].grad).abs().max()) / s_
+                assert e <= 2.0 ** -5, f"{tag}: db{l} err {e:.2e}"
+    return "ok"
+
+
 TYPES = ["Dense", "VM", "NPlaneMul", "CP", "Hash"]
 
 
@@ -179,10 +248,11 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    counts = {"mlp ok": 0, "mlp kink": 0, "mlp fwd": 0, "mlp skip": 0, "forest ok": 0, "forest skip": 0}
+    counts = {"mlp ok": 0, "mlp kink": 0, "mlp fwd": 0, "mlp skip": 0, "half mlp ok": 0, "half mlp fwd": 0, "half mlp skip": 0, "forest ok": 0, "forest skip": 0}
     t0 = time.time()
     while time.time() - t0 < budget:
         counts["mlp " + fuzz_mlp(rng)] += 1
+        counts["half mlp " + fuzz_mlp_half(rng)] += 1
         counts["forest " + fuzz_forest(rng)] += 1
     print(counts)
 
