@@ -1383,7 +1383,7 @@ template <bool SECOND, typename PT>
 __global__ __launch_bounds__(kVmDirectThreads) void k_vm_direct(VmPlan vp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n, uint32_t smooth,
                                                                 const float *__restrict__ x, const float *__restrict__ vin_,
                                                                 const float *__restrict__ g, int64_t g_sn, int64_t g_se,
-                                                                const PT *__restrict__ params, float *__restrict__ partial) {
+                                                                const PT *__restrict__ params, float *__restrict__ partial, uint32_t opt_fix) {
 	extern __shared__ __attribute__((aligned(16))) double vm_acc[];            // plane band [<= 8192 entries][2] | line d [Rd][2]
 	constexpr uint32_t kEnt = 1u << kVmDirectLg;
 	const uint32_t r = blockIdx.x, item = blockIdx.y;
@@ -1398,6 +1398,50 @@ __global__ __launch_bounds__(kVmDirectThreads) void k_vm_direct(VmPlan vp, const
 	const auto grid = make_tab(params + L.off);
 	const uint32_t band_lo = gm.plane_lo + row0 * gm.Rb;                       // first entry of this workgroup's band
 	const uint32_t i_lo = r * vp.pts_per_rep, i_hi = min(n, i_lo + vp.pts_per_rep);
+	// optional fixed-point accumulators from the workgroup's own bound, as k_cp_direct: |update| <= gmax pmax (first order),
+	// <= gmax pmax 7.5 max R vmax (second order: plane g (wo a_d dl + C_m LI) <= 4 |a| pmax, line g (w PC -+ a PI) <= 5 |a| pmax, |a| <= 1.5 R |v|)
+	double fscale = 0.0, finv = 0.0;
+	bool fix = false;
+	if (opt_fix) {
+		__shared__ uint32_t s_bound[3];
+		if (threadIdx.x < 3) s_bound[threadIdx.x] = 0u;
+		__syncthreads();
+		uint32_t gb = 0u, pb = 0u, vb = 0u;
+		for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += kVmDirectThreads) {
+#pragma unroll
+			for (uint32_t f = 0; f < 2u; ++f) gb = max(gb, __float_as_uint(g[(int64_t)i * g_sn + (int64_t)(col0 + f) * g_se]) & 0x7FFFFFFFu);
+			if (SECOND)
+#pragma unroll
+				for (int d = 0; d < 3; ++d) vb = max(vb, __float_as_uint(vin_[(size_t)i * 3 + d]) & 0x7FFFFFFFu);
+		}
+		for (uint32_t t = threadIdx.x; t < 2u * L.size; t += kVmDirectThreads)
+			pb = max(pb, __float_as_uint((float)grid[(t >> 1) * L.F + foff + (t & 1u)]) & 0x7FFFFFFFu);
+#pragma unroll
+		for (int off = 32; off >= 1; off >>= 1) {
+			gb = max(gb, (uint32_t)__shfl_xor((int)gb, off, 64)); pb = max(pb, (uint32_t)__shfl_xor((int)pb, off, 64));
+			vb = max(vb, (uint32_t)__shfl_xor((int)vb, off, 64));
+		}
+		if ((threadIdx.x & 63u) == 0u) { atomicMax(&s_bound[0], gb); atomicMax(&s_bound[1], pb); atomicMax(&s_bound[2], vb); }
+		__syncthreads();
+		float B = __uint_as_float(s_bound[0]) * __uint_as_float(s_bound[1]);
+		if (SECOND) B *= 8.0f * fmaxf((float)L.res[0], fmaxf((float)L.res[1], (float)L.res[2])) * __uint_as_float(s_bound[2]);
+		const uint32_t bb = __float_as_uint(B);
+		if (bb != 0u && bb < 0x7F000000u && B >= 1e-30f) {
+			const int e = (int)(bb >> 23) - 126;
+			uint32_t lg = 0;
+			while ((1u << lg) < vp.pts_per_rep) ++lg;
+			const int sc = min(62 - (int)lg - 3, 44) - e;
+			if (sc > -1000 && sc < 1000) {
+				fscale = __longlong_as_double((long long)(sc + 1023) << 52);
+				finv = __longlong_as_double((long long)(1023 - sc) << 52);
+				fix = true;
+			}
+		}
+	}
+	auto add = [&](double *dst, float v) {                                             // block-uniform branch
+		if (fix) atomicAdd(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)(__double_as_longlong(__fma_rn((double)v, fscale, 0x1.8p52)) - 0x4338000000000000LL));
+		else atomicAdd(dst, (double)v);
+	};
 	for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += kVmDirectThreads) {
 		float xp[3], a[3], grad[2];
 #pragma unroll
@@ -1418,19 +1462,20 @@ __global__ __launch_bounds__(kVmDirectThreads) void k_vm_direct(VmPlan vp, const
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			double *dst = &vm_acc[(size_t)(ent[k] - band_lo) * 2u];
-			atomicAdd(dst, (double)val[k][0]);
-			atomicAdd(dst + 1, (double)val[k][1]);
+			add(dst, val[k][0]);
+			add(dst + 1, val[k][1]);
 		}
 #pragma unroll
 		for (int k = 4; k < 6; ++k) {
 			double *dst = &ln_acc[(size_t)(ent[k] - gm.line_lo) * 2u];
-			atomicAdd(dst, (double)val[k][0]);
-			atomicAdd(dst + 1, (double)val[k][1]);
+			add(dst, val[k][0]);
+			add(dst + 1, val[k][1]);
 		}
 	}
 	__syncthreads();
 	float *mine = partial + ((size_t)item * vp.R + r) * vp.stride;
-	for (uint32_t t = threadIdx.x; t < n_acc; t += kVmDirectThreads) mine[t] = (float)vm_acc[t];
+	const unsigned long long *vm_fix = reinterpret_cast<const unsigned long long *>(vm_acc);
+	for (uint32_t t = threadIdx.x; t < n_acc; t += kVmDirectThreads) mine[t] = fix ? (float)((double)(long long)vm_fix[t] * finv) : (float)vm_acc[t];
 }
 
 // dL/dparam += the replicas' tables, replica 0 first.  A band's extra row belongs to the NEXT band of the same plane: that band's
@@ -1850,10 +1895,11 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				}
 				auto vd_launch = [&](auto kern, auto *tab) {
 					hipLaunchKernelGGL(kern, dim3(vp.R, vp.n_items), dim3(kVmDirectThreads), (size_t)vp.stride * 8, st, vp, md, n, meta->interpolation_type, xc, vc,
-					                   gc, sn, se, tab, partial);
+					                   gc, sn, se, tab, partial, opt::get(NR3D_OPT_DIRECT_FIXED) == 2 ? 1u : 0u);
 				};
-				// (fixed-point accumulators pay in k_cp_direct, which is LDS bound: 1.29 -> 0.98 ms on configs[3]; in the first,
-				// slice-major k_vm_direct the bound scan and the conversions cost more than they saved, 1.28 -> 1.48 ms: fp64 here)
+				// (fixed-point accumulators pay in k_cp_direct, which is LDS bound: 1.29 -> 0.98 ms on configs[3]; in k_vm_direct the
+				// bound scan and the conversions cost more than they save -- slice-major 1.28 -> 1.48 ms, plane-major 5.13 -> 5.21 ms per
+				// pass: it keeps fp64 unless NR3D_OPT_DIRECT_FIXED is 2)
 				{
 					prof::Scope ps(NR3D_PROF_LOTD_DIRECT, st);
 					if (p_half) {

@@ -890,7 +890,7 @@ def test_cp_and_vm_levels_without_records(oracle, dev, case, scale, hip_option):
     g = (g * scale).astype(np.float32)
     gt = torch.from_numpy(g).to(dev)
     outs = {}
-    for mode, (direct, fixed) in (("fixed", (1, 1)), ("fp64", (1, 0)), ("records", (0, 0))):
+    for mode, (direct, fixed) in (("fixed", (1, 2)), ("fp64", (1, 0)), ("records", (0, 0))):     # 2: k_vm_direct in fixed point too
         hip_option("cp_direct", direct)
         hip_option("vm_direct", direct)
         hip_option("direct_fixed", fixed)
