@@ -179,3 +179,33 @@ def test_reference_call_sites_bind():
     assert not missing, missing
     assert not mismatched, mismatched
     assert bound >= 80
+
+
+def test_option_table_round_trip(hiplib):
+    """the library's selectable code paths (include/nr3d_hip.h NR3D_OPT_*): one table behind nr3d_set_option / nr3d_get_option, no
+    environment variable; Python names cover every id; a negative value restores the default; unknown ids fail"""
+    import ctypes as C
+    import re
+    from nr3d_lib_amd import _hip
+    header = open(os.path.join(ROOT, "include", "nr3d_hip.h")).read()
+    ids = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"NR3D_OPT_([A-Z_0-9]+) = (\d+)", header))
+    count = ids.pop("COUNT")
+    assert sorted(ids.values()) == list(range(count))
+    assert sorted(_hip.OPTION_IDS.values()) == list(range(count)), "nr3d_lib_amd._hip.OPTION_IDS must name every option of the header"
+    for name, i in _hip.OPTION_IDS.items():
+        assert ids[name.upper()] == i, name
+        d = _hip.get_option(name)
+        _hip.set_option(name, 7)
+        assert _hip.get_option(name) == 7
+        _hip.set_option(name, -1)
+        assert _hip.get_option(name) == d
+        with _hip.options(**{name: 3}):
+            assert _hip.get_option(name) == 3
+        assert _hip.get_option(name) == d
+    hiplib.nr3d_get_option.restype = C.c_int64
+    assert hiplib.nr3d_get_option(C.c_int(count)) == -1
+    assert hiplib.nr3d_set_option(C.c_int(count), C.c_int64(1)) != 0
+    # nothing in the shipped library reads the environment
+    blob = open(_hip.LIB_PATH, "rb").read()
+    assert b"getenv" not in blob or b"NR3D_FWD_DBG" not in blob
+    assert blob.count(b"NR3D_LOTD_") == 0 and blob.count(b"NR3D_PAIR_") == 0 and blob.count(b"NR3D_PACK_") == 0
