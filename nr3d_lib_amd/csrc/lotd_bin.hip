@@ -580,6 +580,17 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 		for (int d = 0; d < D; ++d) xp[d] = x[(size_t)i * D + d];
 		Cell<D> c;
 		if constexpr (FO) locate_forest(xp, L, smooth != 0, c); else locate<D>(xp, L, smooth != 0, c);
+		// x outside [0, 1] (the Python layer clamps, the C ABI takes what it gets): a cell outside the level would index the tables,
+		// the bucket histogram and the record stage out of bounds -- such a point emits nothing (unsigned compares)
+		bool inside = true;
+		if constexpr (!FO) {
+#pragma unroll
+			for (int d = 0; d < D; ++d) inside = inside && (c.g[d] + 1u < L.res[d]);
+			if (!inside) {                                                  // the emitters below read the tables: give them a cell that exists
+#pragma unroll
+				for (int d = 0; d < D; ++d) c.g[d] = 0u;
+			}
+		}
 		float grad[G], w[C];
 		const uint32_t col0 = meta_col_of(md, q);
 #pragma unroll
@@ -643,6 +654,7 @@ __device__ __forceinline__ void bin_body(const BinPlan &plan, const nr3d_lotd_me
 		}
 #pragma unroll
 		for (int d = 0; d < D; ++d) cell[d] = c.g[d];
+		if (!inside) n_rec = 0;
 	}
 	// Coherent inputs (samples along a ray: consecutive points sit in the same cell of a coarse level) would emit the
 	// same entries over and over and then collide on the same LDS accumulators in stage B.  Lanes that continue the
@@ -1226,6 +1238,8 @@ __global__ __launch_bounds__(kCpThreads) void k_cp_direct(CpPlan cp, const nr3d_
 		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
 		Cell<3> c;
 		locate<3>(xp, L, smooth != 0, c);
+		// x outside [0, 1]: a cell outside the level would index the line tables and the LDS table out of bounds -- it adds nothing
+		if (!(c.g[0] + 1u < L.res[0] && c.g[1] + 1u < L.res[1] && c.g[2] + 1u < L.res[2])) continue;
 #pragma unroll
 		for (int d = 0; d < 3; ++d) {
 			a[d] = SECOND ? c.sc[d] * vin_[(size_t)i * 3 + d] * c.dw[d] : 0.0f;
@@ -1448,6 +1462,9 @@ __global__ __launch_bounds__(kVmDirectThreads) void k_vm_direct(VmPlan vp, const
 		for (int d = 0; d < 3; ++d) xp[d] = x[(size_t)i * 3 + d];
 		Cell<3> c;
 		locate<3>(xp, L, smooth != 0, c);
+		// x outside [0, 1] (the Python layer clamps, the C ABI takes what it gets): a cell outside the level would index the tables and
+		// the LDS band out of bounds -- such a point adds nothing (unsigned compares: a negative floor is a huge index)
+		if (!(c.g[0] + 1u < L.res[0] && c.g[1] + 1u < L.res[1] && c.g[2] + 1u < L.res[2])) continue;
 		const uint32_t ca = gm.a == 0 ? c.g[0] : c.g[1];
 		if (ca - row0 >= nrows) continue;                                       // another band of this plane owns the point
 #pragma unroll

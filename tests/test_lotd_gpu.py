@@ -787,16 +787,19 @@ def test_dparam_small_coherent_batch_constant_gradient(oracle, dev, n, bin_mode)
         assert abs(tot[off:off + size * F].sum() - n * F) <= 1e-5 * n * F
 
 
-def test_dparam_survives_points_outside_the_unit_cube(oracle, dev, bin_mode):
+@pytest.mark.parametrize("case", ["ngp_small", "mixed", "cp_2d", "hash_4d"])
+def test_dparam_survives_points_outside_the_unit_cube(oracle, dev, bin_mode, case):
     """x outside [0, 1] (the Python layer clamps, lotd.py:68, but the C ABI takes what it is given): a pair whose two
     entries do not share a bucket of the level (or whose bucket lies past the table) is dropped by the record path instead
-    of indexing its LDS histogram / accumulators out of bounds (round-2 advisor finding).  What such points add elsewhere
+    of indexing its LDS histogram / accumulators out of bounds (round-2 advisor finding); since round 4 the generic stage A and
+    the direct kernels (k_cp_direct, k_vm_direct) drop a point whose cell lies outside the level too (cases "mixed", "cp_2d", "hash_4d").  What such points add elsewhere
     is unspecified (the reference wraps / hashes them); the call must complete with finite values and leave the
     device in a state where the next, valid, call is exact."""
-    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, "ngp_small", seed=5)
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, seed=5)
+    D = x.shape[1]
     x_bad = x.copy()
-    x_bad[::7] = np.array([1.5, -0.25, 3.0], np.float32)
-    x_bad[3::11] = np.array([0.5, 40.0, 0.5], np.float32)
+    x_bad[::7] = np.array([1.5, -0.25, 3.0, 0.5], np.float32)[:D]
+    x_bad[3::11] = np.array([0.5, 40.0, 0.5, -7.0], np.float32)[:D]
     _, dp_bad = _lotd.lod_bwd(m, gt, torch.from_numpy(x_bad).to(dev), pt, None, need_input_grad=False, need_param_grad=True)
     torch.cuda.synchronize()
     assert torch.isfinite(dp_bad).all()
