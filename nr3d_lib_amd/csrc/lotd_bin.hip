@@ -116,6 +116,36 @@ __global__ __launch_bounds__(256) void k_transpose(uint32_t n, uint32_t E, const
 	}
 }
 
+// The same copy for a CONTIGUOUS row-major source (what autograd hands over) with E <= 120 (round 4): a workgroup takes 128
+// consecutive points -- one contiguous 128 E-element piece of memory, read with every lane on consecutive addresses (the 32 x 32 tiles
+// above read 128-byte pieces, 72 bytes in the last tile column of configs[3]'s E = 50) -- and writes 512 contiguous bytes per feature.
+// configs[3] (E = 50, 2^22 points): 0.51 -> 0.3x ms per dL/dparam pass that starts from a row-major dL_dy.
+constexpr uint32_t kTrPts = 128;
+template <typename ST>
+__global__ __launch_bounds__(256) void k_transpose_rows(uint32_t n, uint32_t E, const ST *__restrict__ src, float *__restrict__ dst) {
+	extern __shared__ __attribute__((aligned(16))) float tr_tile[];             // [E][kTrPts + 1]
+	const uint32_t i0 = blockIdx.x * kTrPts;
+	const uint32_t np = min(kTrPts, n - i0), total = np * E;
+	const ST *base = src + (size_t)i0 * E;
+	for (uint32_t idx = threadIdx.x; idx < total; idx += 256u) {
+		const uint32_t i = idx / E, e = idx - i * E;
+		tr_tile[e * (kTrPts + 1u) + i] = to_f32<ST>(base[idx]);
+	}
+	__syncthreads();
+	for (uint32_t o = threadIdx.x; o < E * kTrPts; o += 256u) {
+		const uint32_t e = o / kTrPts, i = o % kTrPts;
+		if (i < np) dst[(size_t)e * n + i0 + i] = tr_tile[e * (kTrPts + 1u) + i];
+	}
+}
+// [n, E] -> [E, n]: the row kernel when the source is contiguous and E <= 120, the tile kernel otherwise
+template <typename ST>
+static void launch_transpose(uint32_t n, uint32_t E, const ST *src, int64_t s_sn, int64_t s_se, float *dst, hipStream_t st) {
+	if (s_se == 1 && s_sn == (int64_t)E && E <= 120u && E >= 2u)          // 120 x 129 floats = 62 KB: inside the default dynamic-LDS limit
+		hipLaunchKernelGGL(k_transpose_rows<ST>, dim3(div_up(n, kTrPts)), dim3(256), (size_t)E * (kTrPts + 1u) * 4u, st, n, E, src, dst);
+	else
+		hipLaunchKernelGGL(k_transpose<ST>, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, src, s_sn, s_se, dst);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Stage A: bin the parameter updates of BP points x 1 pseudo level by bucket.
 // BP (points = threads per workgroup) is the largest power of two whose record staging area
@@ -1791,13 +1821,8 @@ extern "C" int nr3d_lotd_dLdy_feature_major(uint32_t n_points, uint32_t n_encode
 	NR3D_CHECK(grad_dtype == NR3D_F32 || grad_dtype == NR3D_F16, "dLdy_feature_major: f32 / f16 dL_dy");
 	if (n_points == 0 || n_encoded_dims == 0) return 0;
 	NR3D_CHECK(dL_dy && out, "dLdy_feature_major: NULL tensor pointer");
-	const dim3 grid(div_up(n_points, 32), div_up(n_encoded_dims, 32));
-	if (grad_dtype == NR3D_F16)
-		hipLaunchKernelGGL(k_transpose<__half>, grid, dim3(256), 0, (hipStream_t)stream, n_points, n_encoded_dims,
-		                   (const __half *)dL_dy, g_sn, g_se, out);
-	else
-		hipLaunchKernelGGL(k_transpose<float>, grid, dim3(256), 0, (hipStream_t)stream, n_points, n_encoded_dims, (const float *)dL_dy,
-		                   g_sn, g_se, out);
+	if (grad_dtype == NR3D_F16) launch_transpose<__half>(n_points, n_encoded_dims, (const __half *)dL_dy, g_sn, g_se, out, (hipStream_t)stream);
+	else launch_transpose<float>(n_points, n_encoded_dims, (const float *)dL_dy, g_sn, g_se, out, (hipStream_t)stream);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
@@ -1848,11 +1873,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		if (ba.inds) ba.inds += p0;
 		ba.first_point = p0;
 		if (row_major) {
-			if (g_half)
-				hipLaunchKernelGGL(k_transpose<__half>, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E,
-				                   reinterpret_cast<const __half *>(gc), g_sn, g_se, gt);
-			else
-				hipLaunchKernelGGL(k_transpose<float>, dim3(div_up(n, 32), div_up(E, 32)), dim3(256), 0, st, n, E, gc, g_sn, g_se, gt);
+			if (g_half) launch_transpose<__half>(n, E, reinterpret_cast<const __half *>(gc), g_sn, g_se, gt, st);
+			else launch_transpose<float>(n, E, gc, g_sn, g_se, gt, st);
 			gc = gt; sn = 1; se = (int64_t)n;
 		}
 		if (use_pair) {
