@@ -493,21 +493,27 @@ int nr3d_sample_step_segments(uint32_t P, const float *nears, const float *fars,
 /* packed_sum (:798-861).  out [P, feat_dim], fully written (empty packs -> 0). */
 int nr3d_packed_sum(uint32_t P, uint64_t S, uint32_t feat_dim, int dtype, const void *feats,
                     const int64_t *pack_infos, void *out, void *stream);
-/* packed_cumsum / packed_cumprod (:864-1095).  out fully written, reference first-element semantics. */
+/* Rows of `out` outside every pack (packed_scan / packed_diff / packed_binary; the reference allocates at::zeros):
+ *   ordered_packs == 0: the kernel writes the rows of the packs only -- pass a zeroed `out`;
+ *   ordered_packs != 0: the caller states pack_infos[p+1].begin >= pack_infos[p].begin + pack_infos[p].len for every p
+ *   (what every producer of pack_infos emits: a marcher, an interleave_* op, get_pack_infos_from_n); the kernel then
+ *   zeroes the rows in front of the first pack, between packs and behind the last pack (up to S) itself, so `out`
+ *   may be uninitialised and no fill launch is needed in front of a launch-bound op. */
+/* packed_cumsum / packed_cumprod (:864-1095).  reference first-element semantics. */
 int nr3d_packed_scan(uint32_t P, uint64_t S, uint32_t feat_dim, int dtype, const void *feats,
-                     const int64_t *pack_infos, int is_prod, int exclusive, int reverse, void *out,
-                     void *stream);
+                     const int64_t *pack_infos, int is_prod, int exclusive, int reverse, int ordered_packs,
+                     void *out, void *stream);
 /* packed_diff / packed_backward_diff (:1098-1333).  edge_a = appends|prepends, edge_fill = last|first fill
- * (at most one non-NULL).  backward != 0 selects packed_backward_diff.  out fully written. */
+ * (at most one non-NULL).  backward != 0 selects packed_backward_diff. */
 int nr3d_packed_diff(uint32_t P, uint64_t S, uint32_t feat_dim, int dtype, const void *feats,
                      const int64_t *pack_infos, const void *edge_a, const void *edge_fill, int backward,
-                     void *out, void *stream);
+                     int ordered_packs, void *out, void *stream);
 /* packed_{add,sub,mul,div,gt,geq,lt,leq,eq,neq} (:1960-2480).  op = PackBinaryOpType value
  * (pack_ops.h:25-37: Add 0, Subtract 1, Multiply 2, Division 3, Matmul 4, Gt 5 ... Neq 10).
  * Comparisons write uint8 (bool).  Matmul: other [P, out_dim, feat_dim], out [S, out_dim]. */
 int nr3d_packed_binary(uint32_t P, uint64_t S, uint32_t feat_dim, uint32_t out_dim, int dtype,
-                       const void *feats, const void *other, const int64_t *pack_infos, int op, void *out,
-                       void *stream);
+                       const void *feats, const void *other, const int64_t *pack_infos, int op,
+                       int ordered_packs, void *out, void *stream);
 /* packed_searchsorted[_packed_vals] (:1336-1503).  val_pack_infos NULL -> vals is [P, num_to_search]. */
 int nr3d_packed_searchsorted(uint32_t P, int dtype, const void *bins, const void *vals,
                              const int64_t *pack_infos, uint32_t num_to_search,

@@ -213,6 +213,48 @@ def read_i64(t):
     return buf.tolist()
 
 
+def host_i64(n, device):
+    """thread-local pinned int64 [n] for a kernel to write its totals INTO (pinned host memory is device-visible at the same
+    address): the count kernel's last store lands in host memory, so the readback is a stream synchronisation and nothing
+    else -- no device->host copy launch behind the kernel (~10 us of a two-phase op that is launch bound at 4096 rays).
+    Pass ``ptr(buf)`` where include/nr3d_hip.h takes `int64_t *total`, then ``wait_i64(buf, device)``."""
+    pinned = getattr(_tls, "host_out", None)
+    if pinned is None:
+        pinned = _tls.host_out = {}
+    key = (device.index, n)
+    buf = pinned.get(key)
+    if buf is None:
+        buf = pinned[key] = torch.empty(n, dtype=torch.int64, pin_memory=True)
+    return buf
+
+
+def wait_i64(buf, device):
+    """the values a kernel wrote into ``host_i64``'s buffer: THE device->host sync of a two-phase op"""
+    torch.cuda.current_stream(device).synchronize()
+    return buf.tolist()
+
+
+def mark_ordered(pack_infos):
+    """tag a pack_infos tensor whose packs are known to be ordered and disjoint (begin[p+1] >= begin[p] + len[p]) BY
+    CONSTRUCTION -- the output of a marcher, an interleave_* producer or get_pack_infos_from_n.  The launch-bound pack ops
+    (packed_cumsum / cumprod / diff / add ...) then let the kernel zero the rows outside the packs (``ordered_packs`` of
+    include/nr3d_hip.h) instead of a zero-fill launch in front of it.  The tag is the tensor's version counter: an
+    in-place edit invalidates it, and a tensor from anywhere else (a slice, a clone, the user's own arithmetic) has no
+    tag, so those take the zero-filled path."""
+    try:
+        pack_infos._nr3d_ordered = pack_infos._version
+    except RuntimeError:                    # inference tensors have no version counter: untagged
+        pass
+    return pack_infos
+
+
+def is_ordered(pack_infos):
+    try:
+        return getattr(pack_infos, "_nr3d_ordered", -1) == pack_infos._version
+    except RuntimeError:
+        return False
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

@@ -86,7 +86,7 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
     with H.on_device(dev):
         st = H.stream_of(rays_o)
         packed_info = H.empty((n, 2), dtype=torch.int32, device=dev)
-        total = None if finish else H.empty(1, dtype=torch.int64, device=dev)
+        total = None if finish else H.host_i64(1, dev)      # pinned host word the scan writes into
         tmp = H.empty((_scan_tmp_bytes(n) + 7) // 8, dtype=torch.int64, device=dev)
         # sample cache: the count pass keeps every sample, the emit pass only compacts (no second march)
         cache_bytes = n * int(max_steps) * 12
@@ -97,20 +97,20 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
             # as well, and the readback fetches the number of samples and of hit rays together -- ONE device->host sync
             ridx_hit = H.empty(n, dtype=torch.int64, device=dev)
             pack_infos = H.empty((n, 2), dtype=torch.int64, device=dev)
-            totals = H.empty(2, dtype=torch.int64, device=dev)
+            totals = H.host_i64(2, dev)
             H.check(H.lib().nr3d_ray_marching_count_finished(
                 H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
                 ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), H.u32(max_steps), C.c_int(int(batched)),
                 H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(ridx_hit), H.ptr(pack_infos), H.ptr(totals), H.ptr(tmp),
                 H.ptr(cache), C.c_uint64(cache_bytes if cache is not None else 0), st))
-            S, n_hit = H.read_i64(totals)
+            S, n_hit = H.wait_i64(totals, dev)
         else:
             H.check(H.lib().nr3d_ray_marching_count(
                 H.u32(n), H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
                 ctype, H.f32(step_size), H.f32(max_step_size), H.f32(dt_gamma), H.u32(max_steps), C.c_int(int(batched)),
                 H.ptr(batch_inds), H.u32(bds), H.ptr(packed_info), H.ptr(total), H.ptr(tmp), H.ptr(cache),
                 C.c_uint64(cache_bytes if cache is not None else 0), st))
-            S = H.read_i64(total)[0]       # the single device->host sync of this op
+            S = H.wait_i64(total, dev)[0]  # the single device->host sync of this op
         t_starts = H.empty((S, 1), dtype=torch.float32, device=dev)
         t_ends = H.empty((S, 1), dtype=torch.float32, device=dev)
         ridx = H.empty(S, dtype=torch.int32, device=dev)
@@ -126,7 +126,7 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
                     H.u32(n), H.ptr(rays_o), H.ptr(rays_d), C.c_int(int(batched)), H.ptr(batch_inds), H.u32(bds),
                     H.ptr(packed_info), H.ptr(cache), H.u32(max_steps), H.ptr(t_starts), H.ptr(t_ends), H.ptr(ridx), H.ptr(bidx),
                     H.ptr(gidx), H.ptr(ridx64), H.ptr(deltas), H.ptr(samples), st))
-            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=pack_infos[:n_hit], t_starts=t_starts.view(-1),
+            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=H.mark_ordered(pack_infos[:n_hit]), t_starts=t_starts.view(-1),
                         t_ends=t_ends.view(-1), ridx=ridx64, deltas=deltas, samples=samples, bidx=bidx, gidx=gidx)
         if S > 0:
             H.check(H.lib().nr3d_ray_marching_emit(
@@ -140,7 +140,7 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
             samples = H.empty((S, 3), dtype=torch.float32, device=dev)
             H.check(H.lib().nr3d_march_finish_samples(C.c_uint64(S), H.ptr(rays_o), H.ptr(rays_d), H.ptr(ridx), H.ptr(t_starts),
                                                       H.ptr(t_ends), H.ptr(ridx64), H.ptr(deltas), H.ptr(samples), st))
-            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=pack_infos[:n_hit], t_starts=t_starts.view(-1),
+            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=H.mark_ordered(pack_infos[:n_hit]), t_starts=t_starts.view(-1),
                         t_ends=t_ends.view(-1), ridx=ridx64, deltas=deltas, samples=samples, bidx=bidx, gidx=gidx)
     if batched:
         return [packed_info, t_starts, t_ends, ridx, bidx, gidx]
@@ -205,7 +205,7 @@ def forest_ray_marching(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, se
         st = H.stream_of(rays_o)
         fc = forest._c()
         packed_info = H.empty((n, 2), dtype=torch.int32, device=dev)
-        total = H.empty(1, dtype=torch.int64, device=dev)
+        total = H.host_i64(1, dev)
         nbytes = int(H.lib().nr3d_scan_tmp_bytes(C.c_uint64(max(n, 1))))
         tmp = H.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
         common = (H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(seg_block_inds), H.ptr(seg_entries),
@@ -213,7 +213,7 @@ def forest_ray_marching(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, se
                   H.f32(max_step_size), H.f32(dt_gamma))
         H.check(H.lib().nr3d_forest_ray_marching_count(C.byref(fc), H.u32(n), *common, H.u32(max_steps),
                                                        H.ptr(packed_info), H.ptr(total), H.ptr(tmp), st))
-        S = H.read_i64(total)[0]       # the single device->host sync of this op
+        S = H.wait_i64(total, dev)[0]  # the single device->host sync of this op
         t_starts = H.empty((S, 1), dtype=torch.float32, device=dev)
         t_ends = H.empty((S, 1), dtype=torch.float32, device=dev)
         ridx = H.empty(S, dtype=torch.int32, device=dev)

@@ -50,6 +50,12 @@ def _chk_feats(fn, feats, pack_infos, dims=(1, 2)):
             raise RuntimeError(f"{fn}: Expected feats to have size {want} at dimension 0, but got size {feats.shape[0]}")
 
 
+def _ordered(pack_infos):
+    """1 when the kernel may zero the rows outside the packs itself (H.mark_ordered: pack_infos from one of this library's
+    producers, unmodified since, at least one pack); 0 -> a zero-filled output, rows outside the packs untouched"""
+    return 1 if (pack_infos.shape[0] > 0 and H.is_ordered(pack_infos)) else 0
+
+
 def _fd(feats):
     return 1 if feats.dim() == 1 else int(feats.shape[1])
 
@@ -68,11 +74,11 @@ def _pack_infos_from_n(n_per_pack):
     P = n_per_pack.shape[0]
     dev = n_per_pack.device
     pi = H.empty((P, 2), dtype=torch.int64, device=dev)
-    total = H.empty(1, dtype=torch.int64, device=dev)
+    total = H.host_i64(1, dev)                  # the scan's last store goes to pinned host memory: no copy launch
     tmp = _scan_tmp(P, dev)
     H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(n_per_pack), H.ptr(pi), H.ptr(total), H.ptr(tmp),
                                            H.stream_of(n_per_pack)))
-    return pi, H.read_i64(total)[0]
+    return H.mark_ordered(pi), H.wait_i64(total, dev)[0]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -195,12 +201,13 @@ def packed_sum(feats, pack_infos):
 
 def _scan(fn, feats, pack_infos, mode, exclusive, reverse):
     _chk_feats(fn, feats, pack_infos)
+    ordered = _ordered(pack_infos)
     with H.on_device(feats.device):
-        out = torch.zeros_like(feats)
+        out = H.empty_like(feats) if ordered else torch.zeros_like(feats)
         H.check(H.lib().nr3d_packed_scan(H.u32(pack_infos.shape[0]), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)),
                                          _code(feats), H.ptr(feats), H.ptr(pack_infos), C.c_int(mode),
-                                         C.c_int(int(bool(exclusive))), C.c_int(int(bool(reverse))), H.ptr(out),
-                                         H.stream_of(feats)))
+                                         C.c_int(int(bool(exclusive))), C.c_int(int(bool(reverse))), C.c_int(ordered),
+                                         H.ptr(out), H.stream_of(feats)))
     return out
 
 
@@ -227,11 +234,12 @@ def _diff(fn, feats, pack_infos, edge_a, edge_fill, backward, names):
         raise RuntimeError("You should only specify AT MOST one of [appends, prepends, last_fill, first_fill]")
     P = pack_infos.shape[0]
     edge_a, edge_fill = _edge(fn, names[0], edge_a, feats, P), _edge(fn, names[1], edge_fill, feats, P)
+    ordered = _ordered(pack_infos)
     with H.on_device(feats.device):
-        out = torch.zeros_like(feats)
+        out = H.empty_like(feats) if ordered else torch.zeros_like(feats)
         H.check(H.lib().nr3d_packed_diff(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(_fd(feats)), _code(feats),
                                          H.ptr(feats), H.ptr(pack_infos), H.ptr(edge_a), H.ptr(edge_fill),
-                                         C.c_int(backward), H.ptr(out), H.stream_of(feats)))
+                                         C.c_int(backward), C.c_int(ordered), H.ptr(out), H.stream_of(feats)))
     return out
 
 
@@ -271,11 +279,12 @@ def _binary(name, feats, other, pack_infos):
             raise RuntimeError(f"{fn}: Expected feats and other to have the same number of dimensions / feature width")
         od = fd
         out_shape, out_dtype = tuple(feats.shape), (torch.bool if op >= 5 else feats.dtype)
+    ordered = _ordered(pack_infos)
     with H.on_device(feats.device):
-        out = torch.zeros(out_shape, dtype=out_dtype, device=feats.device)
+        out = (H.empty if ordered else torch.zeros)(out_shape, dtype=out_dtype, device=feats.device)
         H.check(H.lib().nr3d_packed_binary(H.u32(P), C.c_uint64(feats.shape[0]), H.u32(fd), H.u32(od), _code(feats),
-                                           H.ptr(feats), H.ptr(other), H.ptr(pack_infos), C.c_int(op), H.ptr(out),
-                                           H.stream_of(feats)))
+                                           H.ptr(feats), H.ptr(other), H.ptr(pack_infos), C.c_int(op), C.c_int(ordered),
+                                           H.ptr(out), H.stream_of(feats)))
     return out
 
 
@@ -396,7 +405,7 @@ def packed_alpha_to_vw_forward(alphas, pack_infos, early_stop_eps, alpha_thre, c
             total = H.empty(1, dtype=torch.int64, device=dev)
             H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(num), H.ptr(cpi), H.ptr(total),
                                                    H.ptr(_scan_tmp(P, dev)), st))
-            return None, cpi, sel
+            return None, H.mark_ordered(cpi), sel
         w = H.empty(S, dtype=alphas.dtype, device=dev)
         H.check(H.lib().nr3d_alpha_to_vw_forward(H.u32(P), C.c_uint64(S), H.ptr(alphas), H.ptr(pack_infos),
                                                  H.f32(early_stop_eps), H.f32(alpha_thre), H.ptr(w), None, None, st))
@@ -431,10 +440,10 @@ def packed_compression_compact(alphas, pack_infos, early_stop_eps, alpha_thre, t
         begin_all = H.empty(P, dtype=torch.int64, device=dev)
         idx = H.empty(P, dtype=torch.int64, device=dev)
         cpi = H.empty((P, 2), dtype=torch.int64, device=dev)
-        totals = H.empty(2, dtype=torch.int64, device=dev)
+        totals = H.host_i64(2, dev)
         H.check(H.lib().nr3d_prune_compact_packs(H.u32(P), H.ptr(num), H.ptr(tag), H.ptr(begin_all), H.ptr(idx), H.ptr(cpi),
                                                  H.ptr(totals), H.ptr(_scan_tmp(P, dev)), st))
-        S2, P2 = H.read_i64(totals)                         # the one device->host sync
+        S2, P2 = H.wait_i64(totals, dev)                    # the one device->host sync
         pidx = H.empty(S2, dtype=torch.int64, device=dev) if want_pidx else None
         o1 = H.empty(S2, dtype=torch.float32, device=dev) if f1 is not None else None
         o2 = H.empty(S2, dtype=torch.float32, device=dev) if f2 is not None else None
@@ -444,7 +453,7 @@ def packed_compression_compact(alphas, pack_infos, early_stop_eps, alpha_thre, t
             H.check(H.lib().nr3d_prune_compact_samples(H.u32(P), H.ptr(pack_infos), H.ptr(begin_all), H.ptr(sel), H.ptr(f1),
                                                        H.ptr(f2), H.ptr(f3), H.ptr(l1), H.ptr(pidx), H.ptr(o1), H.ptr(o2),
                                                        H.ptr(o3), H.ptr(ol), st))
-    return idx[:P2], cpi[:P2], pidx, o1, o2, o3, ol
+    return idx[:P2], H.mark_ordered(cpi[:P2]), pidx, o1, o2, o3, ol
 
 
 def tau_to_alpha_forward(sigma, delta):

@@ -35,6 +35,21 @@ __device__ __forceinline__ Pack my_pack(uint32_t P, const int64_t *__restrict__ 
 }
 static inline dim3 grid_for(uint32_t P) { return dim3(div_up(P, kWaves)); }
 
+// ordered packs (begin[p+1] >= begin[p] + len[p], include/nr3d_hip.h): the wave of pack p zeroes the rows between its pack
+// and the next one (the last pack: up to S), the wave of pack 0 the rows in front of it -- `out` needs no fill launch
+template <typename T>
+__device__ __forceinline__ void zero_rows(T *__restrict__ out, uint64_t r0, uint64_t r1, uint32_t w, int lane) {
+	for (uint64_t e = r0 * w + lane; e < r1 * w; e += 64) out[e] = (T)0;
+}
+template <typename T>
+__device__ __forceinline__ void fill_gaps(const Pack &k, uint32_t P, const int64_t *__restrict__ pi, uint64_t S, uint32_t w,
+                                          T *__restrict__ out) {
+	const uint64_t end = (uint64_t)k.begin + k.len;
+	const uint64_t next = (k.p + 1 < P) ? (uint64_t)pi[2 * (size_t)(k.p + 1)] : S;
+	if (next > end) zero_rows<T>(out, end, next, w, k.lane);
+	if (k.p == 0 && k.begin > 0) zero_rows<T>(out, 0, k.begin, w, k.lane);
+}
+
 template <typename T> __device__ __forceinline__ T shfl_up_t(T v, int off) { return __shfl_up(v, off, 64); }
 template <typename T> __device__ __forceinline__ T shfl_t(T v, int src) { return __shfl(v, src, 64); }
 template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int m) { return __shfl_xor(v, m, 64); }
@@ -163,9 +178,11 @@ __global__ __launch_bounds__(kBlock) void k_sum(uint32_t P, uint32_t fd, const T
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_scan(uint32_t P, uint32_t fd, const T *__restrict__ in,
                                                  const int64_t *__restrict__ pi, int mode, int exclusive, int reverse,
-                                                 T *__restrict__ out) {
+                                                 uint64_t S, int ordered, T *__restrict__ out) {
 	const Pack k = my_pack(P, pi);
-	if (!k.valid || k.len == 0) return;
+	if (!k.valid) return;
+	if (ordered) fill_gaps<T>(k, P, pi, S, fd, out);
+	if (k.len == 0) return;
 	const bool prod = mode != 0;
 	const T ident = prod ? (T)1 : (T)0;
 	for (uint32_t j = 0; j < fd; ++j) {
@@ -204,9 +221,12 @@ __global__ __launch_bounds__(kBlock) void k_scan(uint32_t P, uint32_t fd, const 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_diff(uint32_t P, uint32_t fd, const T *__restrict__ in,
                                                  const int64_t *__restrict__ pi, const T *__restrict__ edge_a,
-                                                 const T *__restrict__ edge_fill, int backward, T *__restrict__ out) {
+                                                 const T *__restrict__ edge_fill, int backward, uint64_t S, int ordered,
+                                                 T *__restrict__ out) {
 	const Pack k = my_pack(P, pi);
-	if (!k.valid || k.len == 0) return;
+	if (!k.valid) return;
+	if (ordered) fill_gaps<T>(k, P, pi, S, fd, out);
+	if (k.len == 0) return;
 	const uint32_t total = k.len * fd;
 	for (uint32_t e = k.lane; e < total; e += 64) {
 		const uint32_t i = e / fd, j = e - i * fd;
@@ -229,9 +249,13 @@ __global__ __launch_bounds__(kBlock) void k_diff(uint32_t P, uint32_t fd, const 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_binary(uint32_t P, uint32_t fd, const T *__restrict__ in,
                                                    const T *__restrict__ other, const int64_t *__restrict__ pi, int op,
-                                                   T *__restrict__ out, uint8_t *__restrict__ out_b) {
+                                                   uint64_t S, int ordered, T *__restrict__ out, uint8_t *__restrict__ out_b) {
 	const Pack k = my_pack(P, pi);
 	if (!k.valid) return;
+	if (ordered) {
+		if (op >= 5) fill_gaps<uint8_t>(k, P, pi, S, fd, out_b);
+		else fill_gaps<T>(k, P, pi, S, fd, out);
+	}
 	const uint32_t total = k.len * fd;
 	for (uint32_t e = k.lane; e < total; e += 64) {
 		const uint32_t j = e % fd;
@@ -255,9 +279,10 @@ __global__ __launch_bounds__(kBlock) void k_binary(uint32_t P, uint32_t fd, cons
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_matmul(uint32_t P, uint32_t fd, uint32_t od, const T *__restrict__ in,
                                                    const T *__restrict__ other, const int64_t *__restrict__ pi,
-                                                   T *__restrict__ out) {
+                                                   uint64_t S, int ordered, T *__restrict__ out) {
 	const Pack k = my_pack(P, pi);
 	if (!k.valid) return;
+	if (ordered) fill_gaps<T>(k, P, pi, S, od, out);
 	const T *o = other + (size_t)k.p * od * fd;
 	const uint32_t total = k.len * od;
 	for (uint32_t e = k.lane; e < total; e += 64) {
@@ -1291,38 +1316,42 @@ extern "C" int nr3d_packed_sum(uint32_t P, uint64_t S, uint32_t fd, int dtype, c
 }
 
 extern "C" int nr3d_packed_scan(uint32_t P, uint64_t S, uint32_t fd, int dtype, const void *feats,
-                                const int64_t *pack_infos, int is_prod, int exclusive, int reverse, void *out,
-                                void *stream) {
+                                const int64_t *pack_infos, int is_prod, int exclusive, int reverse, int ordered_packs,
+                                void *out, void *stream) {
+	NR3D_CHECK(P > 0 || !ordered_packs || S == 0, "packed_scan: ordered_packs needs at least one pack (no wave to zero `out`)");
 	if (P == 0) return 0;
 	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_scan<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, fd,
-	                                      (const T *)feats, pack_infos, is_prod, exclusive, reverse, (T *)out));
+	                                      (const T *)feats, pack_infos, is_prod, exclusive, reverse, S, ordered_packs, (T *)out));
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
 
 extern "C" int nr3d_packed_diff(uint32_t P, uint64_t S, uint32_t fd, int dtype, const void *feats,
                                 const int64_t *pack_infos, const void *edge_a, const void *edge_fill, int backward,
-                                void *out, void *stream) {
+                                int ordered_packs, void *out, void *stream) {
 	NR3D_CHECK(!(edge_a && edge_fill), "You should only specify AT MOST one of [appends, prepends, last_fill, first_fill]");
+	NR3D_CHECK(P > 0 || !ordered_packs || S == 0, "packed_diff: ordered_packs needs at least one pack (no wave to zero `out`)");
 	if (P == 0) return 0;
 	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_diff<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, fd,
 	                                      (const T *)feats, pack_infos, (const T *)edge_a, (const T *)edge_fill, backward,
-	                                      (T *)out));
+	                                      S, ordered_packs, (T *)out));
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
 
 extern "C" int nr3d_packed_binary(uint32_t P, uint64_t S, uint32_t fd, uint32_t od, int dtype, const void *feats,
-                                  const void *other, const int64_t *pack_infos, int op, void *out, void *stream) {
+                                  const void *other, const int64_t *pack_infos, int op, int ordered_packs, void *out,
+                                  void *stream) {
 	NR3D_CHECK(op >= 0 && op <= 10, "packed_binary_ops: invalid op %d", op);
+	NR3D_CHECK(P > 0 || !ordered_packs || S == 0, "packed_binary_ops: ordered_packs needs at least one pack (no wave to zero `out`)");
 	if (P == 0) return 0;
 	if (op == 4) {
 		PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_matmul<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
-		                                      fd, od, (const T *)feats, (const T *)other, pack_infos, (T *)out));
+		                                      fd, od, (const T *)feats, (const T *)other, pack_infos, S, ordered_packs, (T *)out));
 	} else {
 		PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_binary<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
-		                                      fd, (const T *)feats, (const T *)other, pack_infos, op, (T *)out,
-		                                      (uint8_t *)out));
+		                                      fd, (const T *)feats, (const T *)other, pack_infos, op, S, ordered_packs,
+		                                      (T *)out, (uint8_t *)out));
 	}
 	NR3D_LAUNCH_CHECK();
 	return 0;

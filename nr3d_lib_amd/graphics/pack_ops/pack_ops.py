@@ -11,6 +11,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 import nr3d_lib_amd.bindings._pack_ops as _backend
+from nr3d_lib_amd._hip import mark_ordered
 
 __all__ = [
     'packed_sort_inplace', 'packed_sort', 'packed_searchsorted', 'packed_searchsorted_packed_vals',
@@ -39,18 +40,19 @@ def get_pack_infos_from_first(first_inds: torch.Tensor, numel: int):
 
 @torch.no_grad()
 def get_pack_infos_from_boundary(boundary: torch.Tensor):
-    return get_pack_infos_from_first(boundary.nonzero().long()[..., 0], boundary.numel())
+    # nonzero() is ascending: ordered, disjoint packs by construction (the tag of _hip.mark_ordered)
+    return mark_ordered(get_pack_infos_from_first(boundary.nonzero().long()[..., 0], boundary.numel()))
 
 
 @torch.no_grad()
 def get_pack_infos_from_n(n_per_pack: torch.Tensor):
-    return torch.stack([n_per_pack.cumsum(0) - n_per_pack, n_per_pack], 1)
+    return mark_ordered(torch.stack([n_per_pack.cumsum(0) - n_per_pack, n_per_pack], 1))
 
 
 @torch.no_grad()
 def get_pack_infos_from_batch(n_batches: int, batch_data_size: int, device=None):
     first = torch.arange(n_batches, device=device, dtype=torch.long) * batch_data_size
-    return torch.stack([first, torch.full_like(first, batch_data_size)], 1)
+    return mark_ordered(torch.stack([first, torch.full_like(first, batch_data_size)], 1))
 
 
 @torch.no_grad()

@@ -51,6 +51,44 @@ def test_sum_scan_diff(oracle, dev, P, shape, fd, dtype):
                      oracle.packed_backward_diff(x, pi, a, f), "backward_diff")
 
 
+@pytest.mark.parametrize("head,tail", [(0, 0), (3, 0), (0, 70), (5, 9)])
+@pytest.mark.parametrize("fd", [None, 3])
+def test_ordered_packs_kernel_zeroes_rows_outside_packs(oracle, dev, P, head, tail, fd):
+    """pack_infos tagged as ordered (_hip.mark_ordered: what the library's own producers emit): no zero-fill launch, the kernel
+    writes the rows in front of / between / behind the packs.  Runs with poisoned empty() buffers (conftest), so a row the
+    kernel misses is a NaN here; packs with gaps and empty packs, outputs equal to the untagged (zero-filled) path's"""
+    from nr3d_lib_amd import _hip as H
+    rng = np.random.default_rng(head * 100 + tail + (fd or 0))
+    lens = rng.integers(0, 90, 41)
+    lens[rng.random(41) < 0.25] = 0
+    gaps = rng.integers(0, 4, 41) * (rng.random(41) < 0.5)
+    begin = head + np.cumsum(lens + gaps) - lens                        # a gap in FRONT of each pack
+    pi = np.stack([begin, lens], 1).astype(np.int64)
+    S = int(begin[-1] + lens[-1] + tail)
+    shp = (S,) if fd is None else (S, fd)
+    x = rng.uniform(0.5, 1.5, shp).astype(np.float32)
+    pit = H.mark_ordered(T(pi, dev))
+    assert H.is_ordered(pit) and P._ordered(pit) == 1
+    for excl in (False, True):
+        for rev in (False, True):
+            assert_close(P.packed_cumsum(T(x, dev), pit, excl, rev), oracle.packed_cumsum(x, pi, excl, rev), rel=1e-5, name="cumsum")
+            assert_close(P.packed_cumprod(T(x, dev), pit, excl, rev), oracle.packed_cumprod(x, pi, excl, rev), rel=1e-4, name="cumprod")
+    e = rng.uniform(0.5, 1.5, (41,) + shp[1:]).astype(np.float32)
+    for a, f in ((None, None), (e, None), (None, e)):
+        assert_equal(P.packed_diff(T(x, dev), pit, T(a, dev), T(f, dev)), oracle.packed_diff(x, pi, a, f), "diff")
+        assert_equal(P.packed_backward_diff(T(x, dev), pit, T(a, dev), T(f, dev)), oracle.packed_backward_diff(x, pi, a, f), "bdiff")
+    o = rng.uniform(0.5, 2.0, (41,) + shp[1:]).astype(np.float32)
+    for op in ("add", "div", "gt", "neq"):
+        assert_equal(getattr(P, f"packed_{op}")(T(x, dev), T(o, dev), pit), oracle.packed_binary(op, x, o, pi), op)
+    if fd:
+        w = rng.standard_normal((41, 2, fd)).astype(np.float32)
+        assert_close(P.packed_matmul(T(x, dev), T(w, dev), pit), oracle.packed_matmul(x, w, pi), name="matmul")
+    # an in-place edit drops the tag (version counter), a slice never had it
+    assert not H.is_ordered(pit[:5])
+    pit[0, 1] += 0
+    assert not H.is_ordered(pit) and P._ordered(pit) == 0
+
+
 def test_reference_known_answers(dev, P):
     """literal tensors of the reference's own test (graphics/pack_ops/unit_test.py:536-563, 4 printed digits)"""
     boundary = np.array([1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0], bool)
