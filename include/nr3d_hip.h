@@ -74,7 +74,10 @@ enum {
 	NR3D_OPT_VM_DIRECT = 18,         /* 1: VM levels whose planes split into <= 4 LDS-sized bands accumulate their dL/dparam in LDS without records (k_vm_direct) */
 	NR3D_OPT_DIRECT_FIXED = 19,      /* 1: k_cp_direct accumulates in 64-bit fixed point (scale from the workgroup's own bound on its updates); 2: k_vm_direct
 	                                  * too (measured slower there, twice: it is not bound by its LDS atomics); 0: fp64 */
-	NR3D_OPT_COUNT = 20
+	NR3D_OPT_VM_SORTED = 20,         /* 1: a dL/dparam pass with a VM level of >= 2^20 entries (over its blocks) and >= 2^19 points sorts the POINTS by
+	                                  * (block, coordinate) and accumulates every VM level band by band in LDS, without records (lotd_sorted.inc;
+	                                  * single tables, batches and forests); 2: whenever the geometry allows (tests); 0: records */
+	NR3D_OPT_COUNT = 21
 };
 int nr3d_set_option(int id, int64_t value);
 int64_t nr3d_get_option(int id);

@@ -36,6 +36,15 @@ struct Scope {
 };
 }  // namespace prof
 
+// device radix sort of (key, value) pairs behind plain functions (sort_glue.hip: rocPRIM through hipCUB, its own translation unit)
+namespace sortglue {
+size_t pairs_tmp_bytes(uint32_t n);
+int pairs_u64(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n, int bits,
+              hipStream_t st);
+int pairs_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n,
+              hipStream_t st);
+}  // namespace sortglue
+
 // ---- dtype <-> float conversions used by kernels templated on storage type ----
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }

@@ -1603,6 +1603,8 @@ static uint64_t vm_direct_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t mi
 	return mask;
 }
 
+#include "lotd_sorted.inc"
+
 // plan for the pseudo levels of record class `cls` (0 levels => n_pseudo == 0)
 // only != 0: exactly the pseudo levels of that mask, whatever their class, in blocks of `only_bp` points with `only_nr` records per
 // point (the VM levels whose line updates stay in LDS: k_bin_vm3l)
@@ -1950,6 +1952,22 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				hipLaunchKernelGGL(k_vm_direct_reduce, dim3(div_up(vp.stride, 256u), vp.n_items), dim3(256), 0, st, vp, md, partial, dparam);
 				NR3D_LAUNCH_CHECK();
 				cp_mask |= vmask;
+			}
+		}
+		// large VM levels (single tables, batches, forests): points sorted by (block, coordinate), bands accumulated in LDS, no records
+		// (lotd_sorted.inc); its scratch is the record / offsets region, which the classes below use afterwards
+		if (!g_half) {
+			VsPlan vsp;
+			const uint64_t smask = vm_sorted_plan(meta, n, n_batches, min_level, max_level, forest != nullptr, cp_mask, vsp);
+			if (smask) {
+				VsScratch vss;
+				vm_sorted_scratch(vsp, n, E, second, forest != nullptr, vss);
+				if (vss.total <= lay.rec_bytes + lay.offs_bytes) {
+					if (int rc = vm_sorted_run(second, vsp, meta, md, n, xc, vc, dL_dy + (int64_t)p0 * g_sn, g_sn, g_se, params, p_half, ba, forest, dparam,
+					                           (char *)workspace, vss, st))
+						return rc;
+					cp_mask |= smask;
+				}
 			}
 		}
 		// VM levels: the line tables' gradients accumulate in LDS inside stage A, only the plane updates travel as records

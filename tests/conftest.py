@@ -31,7 +31,13 @@ def hiplib():
     from nr3d_lib_amd import _hip
     if not os.path.exists(_hip.LIB_PATH):
         _hip.build()
-    return _hip.lib()
+    lib = _hip.lib()
+    # NR3D_TEST_OPTIONS="vm_sorted=2,vm_direct=0": the whole run on a non-default choice of implementations (a second pass of the
+    # suite over a code path the defaults reach only on large inputs); options a test sets itself go back to the DEFAULT afterwards
+    for kv in filter(None, os.environ.get("NR3D_TEST_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        _hip.set_option(k.strip(), int(v))
+    return lib
 
 
 @pytest.fixture(scope="session")

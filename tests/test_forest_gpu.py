@@ -19,6 +19,13 @@ FOREST_METAS = {
 }
 
 
+# VM levels with two-feature pseudo levels (what lotd_sorted.inc serves): cuboid resolutions, several pseudo levels per level
+SORTED_METAS = {
+    "vm_cuboid": ([[5, 7, 6], [9, 8, 11], [4, 4, 4]], [2, 4, 2], ["VM", "VM", "Dense"], None, False),
+    "vm_smooth": ([6, 10], [4, 2], ["VM", "VM"], None, True),
+}
+
+
 def _forest_meta(dev, fo):
     from nr3d_lib_amd.bindings._forest import ForestMeta
     m = ForestMeta()
@@ -57,7 +64,7 @@ def _setup(oracle, dev, forest, case, n=2500, seed=0, continuity=True):
     from nr3d_lib_amd.bindings import _lotd
     level, blocks = FORESTS[forest]
     fo = oracle.forest_from_blocks(blocks, level, continuity_enabled=continuity)
-    res, nf, types, T, smooth = FOREST_METAS[case]
+    res, nf, types, T, smooth = {**FOREST_METAS, **SORTED_METAS}[case]
     m_ref = oracle.lotd_create_meta(3, res, nf, types, T, smooth)
     m = _lotd.LoDMeta(3, res, nf, types, T, smooth)
     arrs = _inputs(m_ref, fo, n, seed)
@@ -311,6 +318,44 @@ def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest, case):
     dpc = _lotd.lod_bwd(metas, torch.from_numpy(gs).to(dev), torch.from_numpy(xs).to(dev), pt, None, torch.from_numpy(bs).to(dev),
                         need_input_grad=False, need_param_grad=True)[1]
     assert_close(dpc, oracle.lotd_forest_bwd_dparam(m_ref, fo, gs, xs, p, block_inds=bs, accum_double=True), name="coherent dparam", levels=m_ref)
+
+
+@pytest.mark.parametrize("forest,continuity", [("plus", True), ("plus", False), ("scatter", True), ("single", True)])
+@pytest.mark.parametrize("case", ["mixed", "vm_cuboid", "vm_smooth"])
+def test_vm_levels_over_sorted_points(oracle, dev, forest, continuity, case, hip_option, monkeypatch):
+    """VM levels of a forest over SORTED points (lotd_sorted.inc, option vm_sorted = 2: whatever the table size): interior cells
+    from the band's own point range, boundary cells corner by corner from the face-distance list, no records -- against the
+    oracle, against the record path, first and second order, twice (the sums have a fixed order)"""
+    from nr3d_lib_amd import _hip
+    _lotd, fo, m_ref, metas, (x, p, g, v, bi), (xt, pt, gt, vt, bit) = _setup(oracle, dev, forest, case, n=20000, seed=31, continuity=continuity)
+    ref1 = oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, accum_double=True)
+    ref2 = oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi, dL_ddLdx=v, accum_double=True)
+    _, j = _lotd.lod_fwd(metas, xt, pt, bit, need_input_grad=True)
+    outs = {}
+    for mode in (2, 0, 2):
+        hip_option("vm_sorted", mode)
+        _hip.prof_enable("lotd_direct")
+        try:
+            dp = _lotd.lod_bwd(metas, gt, xt, pt, None, bit, need_input_grad=False, need_param_grad=True)[1]
+            dp2 = _lotd.lod_bwd_bwd_input(metas, vt, gt, xt, pt, j, bit, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
+                                          need_dLdinput_dinput=False)[1]
+            ran = _hip.prof_read("lotd_direct")[1]
+        finally:
+            _hip.prof_enable()
+        assert (ran > 0) == (mode == 2), f"vm_sorted={mode}: the sorted kernel ran {ran} times"
+        assert_close(dp, ref1, rel=1e-5, name=f"dL_dparam vm_sorted={mode}", levels=m_ref)
+        assert_close(dp2, ref2, rel=1e-5, name=f"d(dLdx)/dparam vm_sorted={mode}", levels=m_ref)
+        if mode in outs:
+            assert torch.equal(dp, outs[mode][0]) and torch.equal(dp2, outs[mode][1]), "two runs over sorted points differ"
+        outs[mode] = (dp, dp2)
+    # half tables read natively: the same bits as the run on their fp32 copy
+    ph, gh = pt.half(), gt.half()
+    hip_option("vm_sorted", 2)
+    halves = []
+    for native in (True, False):
+        monkeypatch.setattr(_lotd, "NATIVE_HALF", native)
+        halves.append(_lotd.lod_bwd(metas, gh, xt, ph, None, bit, need_input_grad=False, need_param_grad=True)[1])
+    assert halves[0].dtype == halves[1].dtype and torch.equal(halves[0], halves[1])
 
 
 def test_forest_accel_end_to_end(oracle, dev):

@@ -882,6 +882,48 @@ def test_points_on_cell_faces(oracle, dev, case):
     assert_close(dp, oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True), name="dL/dparam on faces", levels=m_ref)
 
 
+@pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth"])
+@pytest.mark.parametrize("points", ["uniform", "slab", "batched"])
+def test_vm_levels_over_sorted_points(oracle, dev, case, points, hip_option):
+    """VM levels over SORTED points (lotd_sorted.inc; option vm_sorted = 2 takes it whatever the table size, vm_direct = 0 hands it
+    every VM level): a band's points are one range of the order of x_a; "slab" puts 40 000 points into two cell rows (one band
+    with replicas, added in a fixed order), "batched" three table copies with permuted placement and skipped points.  Against the
+    oracle and the record path, first and second order, twice"""
+    from nr3d_lib_amd import _hip
+    B = 3 if points == "batched" else 1
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=40013, seed=77, n_batch=B)
+    kw_ref, kw = {}, {}
+    if points == "slab":
+        x[:, 0] = (0.43 + 0.02 * x[:, 0]).astype(np.float32)
+        x[:, 1] = (0.61 + 0.02 * x[:, 1]).astype(np.float32)
+        xt = torch.from_numpy(x).to(dev)
+    if points == "batched":
+        rng = np.random.default_rng(5)
+        bi = rng.integers(-1, B, x.shape[0]).astype(np.int64)
+        bo = (np.array([2, 0, 1]) * m.n_params).astype(np.int64)
+        kw_ref, kw = dict(batch_inds=bi, batch_offsets=bo), dict(batch_inds=torch.from_numpy(bi).to(dev), batch_offsets=torch.from_numpy(bo).to(dev))
+    ref1 = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True, **kw_ref)
+    ref2 = oracle.lotd_bwd_bwd_dparam(m_ref, v, g, x, p, accum_double=True, **kw_ref)
+    hip_option("vm_direct", 0)
+    outs = {}
+    for mode in (2, 0, 2):
+        hip_option("vm_sorted", mode)
+        _hip.prof_enable("lotd_direct")
+        try:
+            dp = _lotd.lod_bwd(m, gt, xt, pt, None, need_input_grad=False, need_param_grad=True, **kw)[1]
+            dp2 = _lotd.lod_bwd_bwd_input(m, vt, gt, xt, pt, None, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
+                                          need_dLdinput_dinput=False, **kw)[1]
+            torch.cuda.synchronize()
+        finally:
+            _hip.prof_enable()
+        assert_close(dp, ref1, name=f"dL/dparam vm_sorted={mode}", levels=m_ref)
+        assert_close(dp2, ref2, name=f"d(dL/dx)/dparam vm_sorted={mode}", levels=m_ref)
+        if mode in outs:
+            assert torch.equal(dp, outs[mode][0]) and torch.equal(dp2, outs[mode][1]), "two runs over sorted points differ"
+        outs[mode] = (dp, dp2)
+    assert_close(outs[2][0], outs[0][0].cpu().numpy(), rel=1e-5, name="sorted vs records", levels=m_ref)
+
+
 @pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth", "cp_2d", "cp_only_2d4d"])
 @pytest.mark.parametrize("scale", [1.0, 1e-6, 1e4])
 def test_cp_and_vm_levels_without_records(oracle, dev, case, scale, hip_option):
