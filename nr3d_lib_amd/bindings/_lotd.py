@@ -106,15 +106,9 @@ class LoDMeta:
                                               C.c_uint32(int(hashmap_size or 0)),
                                               C.c_int(int(bool(use_smooth_step))), C.byref(self._c)))
         c = self._c
-        self.level_res_multidim = [[int(c.levels[l].res[d]) for d in range(D)] for l in range(L)]
-        self.level_res = [r[0] if all(v == r[0] for v in r) else 0 for r in self.level_res_multidim]
-        self.level_n_feats = [int(c.levels[l].n_feats) for l in range(L)]
-        self.level_types = [int(c.levels[l].type) for l in range(L)]
-        self.level_sizes = [int(c.levels[l].size) for l in range(L)]
-        self.level_n_params = [s * f for s, f in zip(self.level_sizes, self.level_n_feats)]
-        self.level_offsets = [int(c.levels[l].offset) for l in range(L)] + [int(c.n_params)]
-        self.map_levels = [int(c.map_levels[q]) for q in range(c.n_pseudo_levels)]
-        self.map_cnt = [int(c.map_cnt[q]) for q in range(c.n_pseudo_levels)]
+        # the per-level lists (level_res_multidim, level_res, level_n_feats, level_types, level_sizes, level_n_params, level_offsets,
+        # map_levels, map_cnt) are read out of the C struct on first use (__getattr__ below): building them here was half of the
+        # constructor's host time, and most callers only ever ask for n_params / n_encoded_dims
         self.n_levels = int(c.n_levels)
         self.n_pseudo_levels = int(c.n_pseudo_levels)
         self.n_feat_per_pseudo_lvl = int(c.n_feat_per_pseudo_lvl)
@@ -141,7 +135,7 @@ class LoDMeta:
         # metas keep the single call everywhere (their 2-feature pair kernels are faster than wider lanes).
         # REGROUP = False: always one call.
         self._groups = None
-        if not self._all_dense_hash and any(f % (2 * self.n_feat_per_pseudo_lvl) == 0 for f in self.level_n_feats):
+        if not self._all_dense_hash and any(int(f) % (2 * self.n_feat_per_pseudo_lvl) == 0 for f in lod_n_feats):
             groups = []
             for width in (8, 4, 2):
                 g = _CMeta()
@@ -151,6 +145,26 @@ class LoDMeta:
             if len(groups) > 1 or (groups and groups[0].n_feat_per_pseudo_lvl != self.n_feat_per_pseudo_lvl):
                 self._groups = groups
         self._group_dev_cache = {}
+
+    _LAZY = ("level_res_multidim", "level_res", "level_n_feats", "level_types", "level_sizes", "level_n_params", "level_offsets",
+             "map_levels", "map_cnt")
+
+    def __getattr__(self, name):
+        # only reached for attributes that are not set yet: the lazily built per-level lists
+        if name in LoDMeta._LAZY and "_c" in self.__dict__:
+            c, L, D = self._c, int(self._c.n_levels), int(self._c.n_dims_to_encode)
+            d = self.__dict__
+            d["level_res_multidim"] = [[int(c.levels[l].res[k]) for k in range(D)] for l in range(L)]
+            d["level_res"] = [r[0] if all(v == r[0] for v in r) else 0 for r in d["level_res_multidim"]]
+            d["level_n_feats"] = [int(c.levels[l].n_feats) for l in range(L)]
+            d["level_types"] = [int(c.levels[l].type) for l in range(L)]
+            d["level_sizes"] = [int(c.levels[l].size) for l in range(L)]
+            d["level_n_params"] = [sz * f for sz, f in zip(d["level_sizes"], d["level_n_feats"])]
+            d["level_offsets"] = [int(c.levels[l].offset) for l in range(L)] + [int(c.n_params)]
+            d["map_levels"] = [int(c.map_levels[q]) for q in range(c.n_pseudo_levels)]
+            d["map_cnt"] = [int(c.map_cnt[q]) for q in range(c.n_pseudo_levels)]
+            return d[name]
+        raise AttributeError(name)
 
     # ---- C-ABI views -------------------------------------------------------------------------
     def _cmeta(self):

@@ -3,12 +3,16 @@ root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, root)
 import oracle
 from util import LOTD_CASES, lotd_inputs
 from nr3d_lib_amd.bindings import _lotd
+from nr3d_lib_amd import _hip
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 bad = 0
 cases = [c for c in LOTD_CASES if c not in ("cp_4d",)]
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     case = cases[it % len(cases)]
+    # half of the iterations: VM levels over sorted points whatever their size (lotd_sorted.inc), with / without k_vm_direct in front
+    _hip.set_option("vm_sorted", 2 if (it // len(cases)) % 2 else -1)
+    _hip.set_option("vm_direct", 0 if (it // len(cases)) % 4 >= 2 else -1)
     D, res, nf, types, T, smooth = LOTD_CASES[case]
     n = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 511, 513, 1000, 4097, 9999]))
     m_ref = oracle.lotd_create_meta(D, res, nf, types, T, smooth)
