@@ -339,6 +339,8 @@ int nr3d_lotd_forest_bwd_bwd_dx(const nr3d_lotd_meta_t *meta, const void *meta_d
  * Two-phase: *_count writes num_steps[n_rays] AND the exclusive scan packed_info[n_rays,2]
  * (= [cumsum - num, num], int32) plus the grand total into total_steps[0] (device int32/int64);
  * the caller reads total_steps back (the single host sync), allocates outputs, calls *_emit.
+ * total_steps / total / totals of the count entry points may be DEVICE memory (then copy it back) or pinned, device-visible HOST
+ * memory (hipHostMalloc): the scan's last store lands there and the readback is a stream synchronisation, no copy launch.
  * Optional sample cache (>= nr3d_ray_marching_cache_bytes(n_rays, max_steps) bytes, or NULL): *_count also stores
  * every sample in it and *_emit(sample_cache, cache_max_steps = that max_steps) becomes a parallel compaction
  * instead of a second march (the reference always marches twice, ray_marching.cu:170-240).
