@@ -528,6 +528,16 @@ int nr3d_try_merge_two_packs_sorted_aligned(uint32_t P, int dtype, const void *v
                                             const int64_t *pack_infos_a, const void *vals_b,
                                             const int64_t *pack_infos_b, const int64_t *pack_infos_merged,
                                             int b_sorted, int64_t *pidx_a, int64_t *pidx_b, void *stream);
+/* merge_two_packs_sorted (graphics/pack_ops/pack_ops.py:611-640: the torch.unique / nonzero / index chain in front of the aligned
+ * merge): the UNION of two sorted, unique pack-id lists as ALIGNED descriptors.  Union pack k is (a's pack | an empty one, b's pack |
+ * an empty one): u [<= Pa + Pb] ids, pack_infos_a_u / pack_infos_b_u [<= Pa + Pb, 2], n_u [<= Pa + Pb] merged lengths; the first
+ * total_u[0] = Pa + (packs of b that a does not have) rows are written; total_u may be pinned host memory, like the other totals
+ * (n_only [1] is device scratch).
+ * Then: nr3d_pack_infos_from_n(n_u) and nr3d_try_merge_two_packs_sorted_aligned on the aligned descriptors.
+ * Scratch: only_b [Pb], ob [Pb, 2] (int64), scan_tmp >= nr3d_scan_tmp_bytes(Pb). */
+int nr3d_merge_pack_union(uint32_t Pa, const int64_t *nidx_a, const int64_t *pack_infos_a, uint32_t Pb, const int64_t *nidx_b,
+                          const int64_t *pack_infos_b, int64_t *only_b, int64_t *ob, void *scan_tmp, int64_t *n_only,
+                          int64_t *u, int64_t *pack_infos_a_u, int64_t *pack_infos_b_u, int64_t *n_u, int64_t *total_u, void *stream);
 /* packed_invert_cdf (:1633-1733). */
 int nr3d_packed_invert_cdf(uint32_t P, const float *bins, const float *cdfs, const int64_t *pack_infos,
                            const float *u_vals, uint32_t num_to_sample, float *samples, int64_t *bin_idx,

@@ -352,16 +352,62 @@ def try_merge_two_packs_sorted_aligned(vals_a, pack_infos_a, vals_b, pack_infos_
     _chk_feats(fn, vals_b, pack_infos_b, dims=(1,))
     if vals_a.dtype != vals_b.dtype or pack_infos_a.shape != pack_infos_b.shape:
         raise RuntimeError(f"{fn}: the two packs must be aligned and share a dtype")
-    with H.on_device(vals_a.device):
+    dev, P = vals_a.device, pack_infos_a.shape[0]
+    with H.on_device(dev):
+        # merged lengths -> merged pack_infos through the device scan (its total is len(a) + len(b): not read back)
         n = pack_infos_a[:, 1] + pack_infos_b[:, 1]
-        cs = n.cumsum(0)
-        pim = torch.stack([cs - n, n], 1).contiguous()
-        pa = torch.zeros(vals_a.shape[0], dtype=torch.int64, device=vals_a.device)
-        pb = torch.zeros(vals_b.shape[0], dtype=torch.int64, device=vals_a.device)
+        pim = H.empty((P, 2), dtype=torch.int64, device=dev)
+        if P > 0:
+            tot = H.empty(1, dtype=torch.int64, device=dev)
+            H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(n), H.ptr(pim), H.ptr(tot), H.ptr(_scan_tmp(P, dev)),
+                                                   H.stream_of(vals_a)))
+            H.mark_ordered(pim)
+        pa = torch.zeros(vals_a.shape[0], dtype=torch.int64, device=dev)      # the merge kernel counts into it
+        pb = torch.zeros(vals_b.shape[0], dtype=torch.int64, device=dev)
         H.check(H.lib().nr3d_try_merge_two_packs_sorted_aligned(
             H.u32(pack_infos_a.shape[0]), _code(vals_a), H.ptr(vals_a), H.ptr(pack_infos_a), H.ptr(vals_b),
             H.ptr(pack_infos_b), H.ptr(pim), C.c_int(int(bool(b_sorted))), H.ptr(pa), H.ptr(pb), H.stream_of(vals_a)))
     return pa, pb, pim
+
+
+def merge_two_packs_sorted_general(vals_a, pack_infos_a, nidx_a, vals_b, pack_infos_b, nidx_b):
+    """merge_two_packs_sorted for arbitrary (sorted, unique) pack-id lists -> (pidx_a, pidx_b, pack_infos of the union): the
+    reference's torch.unique / nonzero / index chain (graphics/pack_ops/pack_ops.py:611-640, ~40 launches and six syncs) as the
+    union of the id lists in aligned form (nr3d_merge_pack_union: three launches), ONE readback (the number of union packs), the
+    scan of the merged lengths and the aligned merge kernel over packs that exist in a, in b or in both"""
+    fn = "merge_two_packs_sorted"
+    _chk_feats(fn, vals_a, pack_infos_a, dims=(1,))
+    _chk_feats(fn, vals_b, pack_infos_b, dims=(1,))
+    H.require_gpu(nidx_a, nidx_b)
+    Pa, Pb = pack_infos_a.shape[0], pack_infos_b.shape[0]
+    if vals_a.dtype != vals_b.dtype:
+        raise RuntimeError(f"{fn}: the two packs must share a dtype")
+    for nm, t, P in (("nidx_a", nidx_a, Pa), ("nidx_b", nidx_b, Pb)):
+        if t.dtype != torch.int64 or tuple(t.shape) != (P,) or not t.is_contiguous():
+            raise RuntimeError(f"{fn}: Expected a contiguous int64 {nm} of shape [{P}]")
+    if Pa == 0 or Pb == 0:
+        raise RuntimeError(f"{fn}: both pack lists must be non-empty")
+    dev = vals_a.device
+    with H.on_device(dev):
+        st = H.stream_of(vals_a)
+        scratch = H.empty(3 * Pb + 1, dtype=torch.int64, device=dev)          # only_b [Pb] | ob [Pb, 2] | n_only [1]
+        cap = Pa + Pb
+        out = H.empty(6 * cap, dtype=torch.int64, device=dev)                 # u | pia_u | pib_u | n_u
+        u, pia_u, pib_u, n_u = out[:cap], out[cap:3 * cap].view(cap, 2), out[3 * cap:5 * cap].view(cap, 2), out[5 * cap:]
+        total = H.host_i64(1, dev)
+        H.check(H.lib().nr3d_merge_pack_union(H.u32(Pa), H.ptr(nidx_a), H.ptr(pack_infos_a), H.u32(Pb), H.ptr(nidx_b),
+                                              H.ptr(pack_infos_b), H.ptr(scratch), H.ptr(scratch[Pb:]), H.ptr(_scan_tmp(Pb, dev)),
+                                              H.ptr(scratch[3 * Pb:]), H.ptr(u), H.ptr(pia_u), H.ptr(pib_u), H.ptr(n_u), H.ptr(total), st))
+        Pu = H.wait_i64(total, dev)[0]                                        # the one device->host sync
+        pim = H.empty((Pu, 2), dtype=torch.int64, device=dev)
+        tot = H.empty(1, dtype=torch.int64, device=dev)                       # = len(vals_a) + len(vals_b): not read back
+        H.check(H.lib().nr3d_pack_infos_from_n(H.u32(Pu), H.ptr(n_u), H.ptr(pim), H.ptr(tot), H.ptr(_scan_tmp(Pu, dev)), st))
+        pa = torch.zeros(vals_a.shape[0], dtype=torch.int64, device=dev)      # the merge kernel counts into it
+        pb = torch.full((vals_b.shape[0],), -1, dtype=torch.int64, device=dev)    # (elements outside every pack: no position)
+        H.check(H.lib().nr3d_try_merge_two_packs_sorted_aligned(
+            H.u32(Pu), _code(vals_a), H.ptr(vals_a), H.ptr(pia_u), H.ptr(vals_b), H.ptr(pib_u), H.ptr(pim), C.c_int(1),
+            H.ptr(pa), H.ptr(pb), st))
+    return pa, pb, H.mark_ordered(pim)
 
 
 def packed_invert_cdf(bins, cdfs, u, pack_infos):

@@ -431,6 +431,50 @@ __device__ __forceinline__ void sift_down(T *v, int64_t *ids, int64_t start, int
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// merge_two_packs_sorted (graphics/pack_ops/pack_ops.py:611-640 of the reference: torch.unique + nonzero + index arithmetic): the
+// UNION of two sorted, unique pack-id lists as aligned pack descriptors -- union pack k = (a's pack or an empty one, b's pack or an
+// empty one) -- so that the aligned merge kernel serves packs present in a only, in b only or in both.
+//   only_b[j] = id_b[j] not in a;   ob[j] = #{j' < j : only_b[j']} (scan);   position of a's pack i = i + ob[lower_bound_b(id_a[i])],
+//   of b-only pack j = lower_bound_a(id_b[j]) + ob[j]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_union_flags(uint32_t Pa, const int64_t *__restrict__ ida, uint32_t Pb,
+                                                        const int64_t *__restrict__ idb, int64_t *__restrict__ only_b) {
+	const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+	if (j >= Pb) return;
+	const int64_t id = idb[j];
+	const uint32_t i = lower_bound<int64_t>(id, ida, Pa);
+	only_b[j] = (i < Pa && ida[i] == id) ? 0 : 1;
+}
+__global__ __launch_bounds__(kBlock) void k_union_build(uint32_t Pa, const int64_t *__restrict__ ida, const int64_t *__restrict__ pia,
+                                                        uint32_t Pb, const int64_t *__restrict__ idb, const int64_t *__restrict__ pib,
+                                                        const int64_t *__restrict__ only_b, const int64_t *__restrict__ ob,
+                                                        const int64_t *__restrict__ n_only, int64_t *__restrict__ u,
+                                                        int64_t *__restrict__ pia_u, int64_t *__restrict__ pib_u, int64_t *__restrict__ n_u,
+                                                        int64_t *__restrict__ total_u) {
+	const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+	if (t == 0) total_u[0] = (int64_t)Pa + n_only[0];
+	if (t < Pa) {
+		const int64_t id = ida[t];
+		const uint32_t j = lower_bound<int64_t>(id, idb, Pb);
+		const bool both = j < Pb && idb[j] == id;
+		const size_t pos = (size_t)t + (size_t)(j < Pb ? ob[2 * (size_t)j] : n_only[0]);
+		u[pos] = id;
+		pia_u[2 * pos] = pia[2 * (size_t)t]; pia_u[2 * pos + 1] = pia[2 * (size_t)t + 1];
+		pib_u[2 * pos] = both ? pib[2 * (size_t)j] : 0; pib_u[2 * pos + 1] = both ? pib[2 * (size_t)j + 1] : 0;
+		n_u[pos] = pia[2 * (size_t)t + 1] + (both ? pib[2 * (size_t)j + 1] : 0);
+	} else if (t < Pa + Pb) {
+		const uint32_t j = t - Pa;
+		if (!only_b[j]) return;
+		const int64_t id = idb[j];
+		const size_t pos = (size_t)lower_bound<int64_t>(id, ida, Pa) + (size_t)ob[2 * (size_t)j];
+		u[pos] = id;
+		pia_u[2 * pos] = 0; pia_u[2 * pos + 1] = 0;
+		pib_u[2 * pos] = pib[2 * (size_t)j]; pib_u[2 * pos + 1] = pib[2 * (size_t)j + 1];
+		n_u[pos] = pib[2 * (size_t)j + 1];
+	}
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_sort(uint32_t P, T *__restrict__ vals, int64_t *__restrict__ ids,
                                                  const int64_t *__restrict__ pi) {
@@ -1377,6 +1421,21 @@ extern "C" int nr3d_try_merge_two_packs_sorted_aligned(uint32_t P, int dtype, co
 	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_merge<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
 	                                      (const T *)vals_a, pack_infos_a, (const T *)vals_b, pack_infos_b,
 	                                      pack_infos_merged, pidx_a, pidx_b));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_merge_pack_union(uint32_t Pa, const int64_t *nidx_a, const int64_t *pack_infos_a, uint32_t Pb, const int64_t *nidx_b,
+                                     const int64_t *pack_infos_b, int64_t *only_b, int64_t *ob, void *scan_tmp, int64_t *n_only,
+                                     int64_t *u, int64_t *pack_infos_a_u, int64_t *pack_infos_b_u, int64_t *n_u, int64_t *total_u,
+                                     void *stream) {
+	NR3D_CHECK(Pa > 0 && Pb > 0, "merge_pack_union: both pack lists must be non-empty");
+	NR3D_CHECK(only_b && ob && scan_tmp && n_only && total_u, "merge_pack_union: NULL scratch pointer");
+	hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL(pk::k_union_flags, dim3(div_up(Pb, pk::kBlock)), dim3(pk::kBlock), 0, st, Pa, nidx_a, Pb, nidx_b, only_b);
+	if (int rc = scan::pack_infos_from_counts<int64_t, int64_t>(Pb, only_b, ob, n_only, scan_tmp, st)) return rc;
+	hipLaunchKernelGGL(pk::k_union_build, dim3(div_up((uint64_t)Pa + Pb, pk::kBlock)), dim3(pk::kBlock), 0, st, Pa, nidx_a, pack_infos_a, Pb,
+	                   nidx_b, pack_infos_b, only_b, ob, n_only, u, pack_infos_a_u, pack_infos_b_u, n_u, total_u);
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

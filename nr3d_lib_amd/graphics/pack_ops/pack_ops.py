@@ -613,6 +613,20 @@ def merge_two_packs_sorted(vals_a, pack_infos_a, nidx_a, vals_b, pack_infos_b, n
     if nidx_a.numel() == nidx_b.numel() and torch.equal(nidx_a, nidx_b):
         return merge_two_packs_sorted_aligned(vals_a, pack_infos_a, vals_b, pack_infos_b, b_sorted=True,
                                               return_val=return_val)
+    if (vals_a.is_cuda and vals_a.dim() == 1 and vals_b.dim() == 1 and nidx_a.numel() > 0 and nidx_b.numel() > 0
+            and vals_a.dtype == vals_b.dtype and vals_a.dtype in (torch.float32, torch.float64, torch.int32, torch.int64)):
+        # the union of the pack lists in aligned form + the aligned merge kernel: a handful of launches and one readback
+        pidx_a, pidx_b, pack_infos = _backend.merge_two_packs_sorted_general(
+            vals_a.contiguous(), pack_infos_a.contiguous(), nidx_a.long().contiguous(), vals_b.contiguous(),
+            pack_infos_b.contiguous(), nidx_b.long().contiguous())
+        if return_val:
+            return _scatter_vals(vals_a, pidx_a, vals_b, pidx_b, zeros=True), pack_infos
+        return pidx_a, pidx_b, pack_infos
+    return _merge_two_packs_sorted_torch(vals_a, pack_infos_a, nidx_a, vals_b, pack_infos_b, nidx_b, return_val)
+
+
+def _merge_two_packs_sorted_torch(vals_a, pack_infos_a, nidx_a, vals_b, pack_infos_b, nidx_b, return_val=False):
+    """the same result through set arithmetic in torch (the reference's own formulation; the cross-check of the tests)"""
     with torch.no_grad():
         u, inv_a, inv_b, com_a, com_b, only_a, only_b = torch_intersect1d_unique(nidx_a, nidx_b)
         n_per_pack = pack_infos_a.new_zeros([u.numel()])

@@ -419,6 +419,44 @@ def test_merge_wrappers(oracle, dev):
         assert torch.equal(torch.sort(val)[0], torch.sort(torch.cat([va, vb]))[0])
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.int64])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_merge_two_packs_sorted_native_union(oracle, dev, dtype, seed):
+    """merge_two_packs_sorted on arbitrary pack-id lists: the native route (nr3d_merge_pack_union: union of the id lists in aligned
+    form + scan + the aligned merge kernel, one readback) gives exactly the positions and pack_infos of the reference's
+    torch.unique / nonzero formulation (kept as _merge_two_packs_sorted_torch); disjoint lists, one list inside the other, empty
+    packs, equal values across a and b"""
+    import nr3d_lib_amd.graphics.pack_ops as po
+    from nr3d_lib_amd.graphics.pack_ops import pack_ops as pom
+    rng = np.random.default_rng(100 + seed)
+    ids = np.arange(3000)
+    cases = [(np.sort(rng.choice(ids, 900, replace=False)), np.sort(rng.choice(ids, 700, replace=False))),
+             (np.sort(rng.choice(ids[:1500], 400, replace=False)), np.sort(rng.choice(ids[1500:], 500, replace=False))),   # disjoint
+             (np.array([5]), np.array([2, 5, 9])), (np.array([1, 2, 3]), np.array([0])), (np.array([7]), np.array([8]))]
+
+    def mk(nidx):
+        n = rng.integers(0, 40, len(nidx))
+        if n.sum() == 0:
+            n[0] = 3
+        pi = oracle.get_pack_infos_from_n(n)
+        if dtype == np.float32:
+            v = np.concatenate([np.sort(rng.integers(0, 50, int(k)) / 50.0) for k in n]).astype(np.float32)     # many ties
+        else:
+            v = np.concatenate([np.sort(rng.integers(0, 50, int(k))) for k in n]).astype(np.int64)
+        return T(v, dev), T(pi, dev), T(nidx.astype(np.int64), dev)
+    for ida, idb in cases:
+        va, pia, na = mk(ida)
+        vb, pib, nb = mk(idb)
+        got = po.merge_two_packs_sorted(va, pia, na, vb, pib, nb)
+        want = pom._merge_two_packs_sorted_torch(va, pia, na, vb, pib, nb)
+        for g, w, name in zip(got, want, ("pidx_a", "pidx_b", "pack_infos")):
+            assert g.dtype == w.dtype and torch.equal(g, w), f"{name}: {len(ida)} + {len(idb)} packs"
+        val, pim = po.merge_two_packs_sorted(va, pia, na, vb, pib, nb, return_val=True)
+        assert torch.equal(torch.sort(val)[0], torch.sort(torch.cat([va, vb]))[0])
+        for b, n in pim.tolist():
+            assert (val[b:b + n].diff() >= 0).all()
+
+
 def test_octree_mark_consecutive_segments(oracle, dev):
     """the reference's own example (unit_test.py:760-781: nodes x = 0,1,2 | 5,6 on one ray -> two runs) plus ragged packs"""
     from nr3d_lib_amd.graphics.pack_ops import octree_mark_consecutive_segments
