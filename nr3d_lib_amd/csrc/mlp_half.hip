@@ -340,12 +340,13 @@ struct BwdArgs {
 
 // One layer of the backward sweep.  g = dL/d(pre-activation of this layer's output) in operand form (NO tiles); TG: LDS tile that
 // receives it as [feature][sample]; TB: the layer's INPUT activations as [feature][sample] (NI tiles); wT: packed transposed
-// layer; hin: the same input activations in operand form (registers), for the ReLU mask.  Accumulates dW (NO x NI tiles) and the
+// layer; hmask: which of the lane's input activations are > 0 (bit 16 t + j of tile t, value j of the operand form) -- the ReLU mask
+// as ONE register per layer instead of the activations themselves (16 per 64-wide layer, live across the whole sweep).  Accumulates dW (NO x NI tiles) and the
 // per-lane bias partial sums; when PREV, leaves dL/d(input of the layer) in gp (fp32, C/D map), masked when MASK.
 template <int NO, int NI, bool PREV, bool MASK>
 __device__ __forceinline__ void bwd_layer(const h8 (&g)[NO][2], _Float16 *__restrict__ TG, const _Float16 *__restrict__ TB,
                                           const unsigned char *__restrict__ wT, f16v (&dW)[NO][NI], float (&db)[NO], f16v (&gp)[NI],
-                                          const h8 (&hin)[NI][2], int lane) {
+                                          uint32_t hmask, int lane) {
 	const int r = lane & 31, h = lane >> 5;
 	write_tile<NO>(TG, g, lane);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -372,7 +373,7 @@ __device__ __forceinline__ void bwd_layer(const h8 (&g)[NO][2], _Float16 *__rest
 #pragma unroll
 			for (int t = 0; t < NI; ++t)
 #pragma unroll
-				for (int j = 0; j < 16; ++j) gp[t][j] = (float)hin[t][j >> 3][j & 7] > 0.0f ? gp[t][j] : 0.0f;
+				for (int j = 0; j < 16; ++j) gp[t][j] = ((hmask >> (16 * t + j)) & 1u) ? gp[t][j] : 0.0f;
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -499,7 +500,7 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T>::kMaxWaves * 64)) void k_
 			dense<W_T, W_T, true>(wf + f0 + (l - 1) * fh, hop[l - 1], hacc, a.hidden_act, lane);
 			to_operand<W_T>(hacc, hop[l]);
 			write_tile<W_T>(TH1 + l * 32 * W_T * kTSH, hop[l], lane);
-		}
+			}
 		if (a.out_act == NR3D_MLP_ACT_RELU) {
 			f16v yo[OUT_T];
 			dense<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hop[NH - 1], yo, NR3D_MLP_ACT_NONE, lane);
@@ -510,9 +511,20 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T>::kMaxWaves * 64)) void k_
 		}
 		// ---- backward sweep ----
 		const bool relu = a.hidden_act == NR3D_MLP_ACT_RELU;
+		static_assert(W_T <= 2, "one 32-bit ReLU mask per hidden layer");
+		uint32_t hmask[NH];
+#pragma unroll
+		for (int l = 0; l < NH; ++l) {
+			uint32_t m = 0;
+#pragma unroll
+			for (int t = 0; t < W_T; ++t)
+#pragma unroll
+				for (int j = 0; j < 16; ++j) m |= ((float)hop[l][t][j >> 3][j & 7] > 0.0f ? 1u : 0u) << (16 * t + j);
+			hmask[l] = m;
+		}
 		f16v g[W_T];
-		if (relu) bwd_layer<OUT_T, W_T, true, true>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTSH, wt + t0 + (NH - 1) * th, dWo, dbo, g, hop[NH - 1], lane);
-		else bwd_layer<OUT_T, W_T, true, false>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTSH, wt + t0 + (NH - 1) * th, dWo, dbo, g, hop[NH - 1], lane);
+		if (relu) bwd_layer<OUT_T, W_T, true, true>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTSH, wt + t0 + (NH - 1) * th, dWo, dbo, g, hmask[NH - 1], lane);
+		else bwd_layer<OUT_T, W_T, true, false>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTSH, wt + t0 + (NH - 1) * th, dWo, dbo, g, 0u, lane);
 		h8 gop[W_T][2];
 #pragma unroll
 		for (int l = NH - 1; l >= 1; --l) {                              // hidden layer l: H_l -> H_{l+1}
@@ -520,19 +532,19 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T>::kMaxWaves * 64)) void k_
 			to_operand<W_T>(g, gop);
 			_Float16 *TG = TH1 + l * 32 * W_T * kTSH;                    // H_{l+1}'s tile is dead: the layer above has consumed it
 			const _Float16 *TB = TH1 + (l - 1) * 32 * W_T * kTSH;
-			if (relu) bwd_layer<W_T, W_T, true, true>(gop, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, hop[l - 1], lane);
-			else bwd_layer<W_T, W_T, true, false>(gop, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, hop[l - 1], lane);
+			if (relu) bwd_layer<W_T, W_T, true, true>(gop, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, hmask[l - 1], lane);
+			else bwd_layer<W_T, W_T, true, false>(gop, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, 0u, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) g[t] = gp[t];
-		}
+			}
 		to_operand<W_T>(g, gop);
 		f16v gx[IN_T];
 		if (a.gx) {
-			bwd_layer<W_T, IN_T, true, false>(gop, TH1, TX, wt, dW0, db0, gx, xin, lane);
+			bwd_layer<W_T, IN_T, true, false>(gop, TH1, TX, wt, dW0, db0, gx, 0u, lane);
 			if (a.gx_fm) store_cols<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, lane, gx);
 			else store_rows<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, a.gx_vec != 0, lane, gx);
 		} else {
-			bwd_layer<W_T, IN_T, false, false>(gop, TH1, TX, wt, dW0, db0, gx, xin, lane);
+			bwd_layer<W_T, IN_T, false, false>(gop, TH1, TX, wt, dW0, db0, gx, 0u, lane);
 		}
 	}
 
