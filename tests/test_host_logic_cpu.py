@@ -86,3 +86,39 @@ def test_forest_block_space_bookkeeping():
     assert re.block_ks.tolist() == sparse.block_ks.tolist() and re.meta.level_poffset == sparse.meta.level_poffset
     with pytest.raises(RuntimeError):
         sp.populate(mode="nope")
+
+
+def test_ordered_pack_infos_tag_follows_the_tensor_version():
+    """_hip.mark_ordered / is_ordered (the switch between `empty` + kernel-side zeroing and a zero-filled output in the launch-bound
+    pack ops): the tag holds for the very tensor a producer returned, and only until its next in-place edit"""
+    from nr3d_lib_amd import _hip
+    from nr3d_lib_amd.graphics.pack_ops import get_pack_infos_from_n, get_pack_infos_from_batch, get_pack_infos_from_first
+    pi = get_pack_infos_from_n(torch.tensor([4, 0, 5, 3]))
+    assert pi.tolist() == [[0, 4], [4, 0], [4, 5], [9, 3]] and _hip.is_ordered(pi)
+    assert _hip.is_ordered(get_pack_infos_from_batch(3, 7))
+    assert not _hip.is_ordered(get_pack_infos_from_first(torch.tensor([0, 4, 9]), 12))       # the caller's ids: not ours to vouch for
+    assert not _hip.is_ordered(pi[:2]) and not _hip.is_ordered(pi.clone()) and _hip.is_ordered(pi.contiguous())
+    keep = pi
+    pi[1, 1] += 0                                     # any in-place write, even a no-op, bumps the version
+    assert not _hip.is_ordered(keep)
+    assert _hip.is_ordered(_hip.mark_ordered(keep))   # (re-tagging is the producer's statement)
+    with torch.inference_mode():
+        t = torch.zeros(2, 2, dtype=torch.int64)
+        assert not _hip.is_ordered(_hip.mark_ordered(t))     # no version counter: untagged, zero-filled path
+
+
+def test_lod_meta_lists_are_built_on_first_use(hiplib):
+    """LoDMeta's per-level Python lists come out of the C struct lazily (the constructor is a launch-bound op of the reference's
+    own test script): same values as an eager read, attribute errors stay attribute errors, copies keep working"""
+    import copy
+    from nr3d_lib_amd.bindings import _lotd
+    m = _lotd.LoDMeta(3, [[8, 6, 5], 12, 10], [4, 2, 8], ["Dense", "VM", "CP"], None, True)
+    assert "level_sizes" not in m.__dict__
+    assert m.level_res_multidim == [[8, 6, 5], [12, 12, 12], [10, 10, 10]] and m.level_res == [0, 12, 10]
+    assert m.level_n_feats == [4, 2, 8] and m.level_types == [int(_lotd.string_to_lod_type(t)) for t in ("Dense", "VM", "CP")]
+    assert m.level_sizes[0] == 8 * 6 * 5 and m.level_offsets[-1] == m.n_params == sum(m.level_n_params)
+    assert len(m.map_levels) == len(m.map_cnt) == m.n_pseudo_levels == 7 and m.map_levels == [0, 0, 1, 2, 2, 2, 2]
+    with pytest.raises(AttributeError):
+        m.no_such_attribute
+    m2 = copy.deepcopy(_lotd.LoDMeta(3, [16, 32], [2, 2], ["Dense", "Hash"], 2 ** 10))
+    assert m2.level_offsets == [0, 16 ** 3 * 2, 16 ** 3 * 2 + 2 ** 10 * 2]
