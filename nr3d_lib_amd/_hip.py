@@ -234,15 +234,19 @@ def wait_i64(buf, device):
     return buf.tolist()
 
 
-def mark_ordered(pack_infos):
+def mark_ordered(pack_infos, total=None):
     """tag a pack_infos tensor whose packs are known to be ordered and disjoint (begin[p+1] >= begin[p] + len[p]) BY
     CONSTRUCTION -- the output of a marcher, an interleave_* producer or get_pack_infos_from_n.  The launch-bound pack ops
     (packed_cumsum / cumprod / diff / add ...) then let the kernel zero the rows outside the packs (``ordered_packs`` of
     include/nr3d_hip.h) instead of a zero-fill launch in front of it.  The tag is the tensor's version counter: an
     in-place edit invalidates it, and a tensor from anywhere else (a slice, a clone, the user's own arithmetic) has no
-    tag, so those take the zero-filled path."""
+    tag, so those take the zero-filled path.
+    ``total``: the producer also knows (on the host) that the packs TILE rows [0, total) without a gap -- a marcher's sample
+    count, the scalar a two-phase op read back.  Ops whose kernels write the rows of the packs only (packed_alpha_to_vw)
+    allocate `empty` outputs when the tensor they are called on has exactly that many rows (``tiles``), zeros otherwise."""
     try:
         pack_infos._nr3d_ordered = pack_infos._version
+        pack_infos._nr3d_total = None if total is None else int(total)
     except RuntimeError:                    # inference tensors have no version counter: untagged
         pass
     return pack_infos
@@ -253,6 +257,11 @@ def is_ordered(pack_infos):
         return getattr(pack_infos, "_nr3d_ordered", -1) == pack_infos._version
     except RuntimeError:
         return False
+
+
+def tiles(pack_infos, n_rows):
+    """the packs are known to cover rows [0, n_rows) exactly (see mark_ordered)"""
+    return is_ordered(pack_infos) and getattr(pack_infos, "_nr3d_total", None) == int(n_rows)
 
 
 def require_gpu(*tensors):

@@ -126,7 +126,7 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
                     H.u32(n), H.ptr(rays_o), H.ptr(rays_d), C.c_int(int(batched)), H.ptr(batch_inds), H.u32(bds),
                     H.ptr(packed_info), H.ptr(cache), H.u32(max_steps), H.ptr(t_starts), H.ptr(t_ends), H.ptr(ridx), H.ptr(bidx),
                     H.ptr(gidx), H.ptr(ridx64), H.ptr(deltas), H.ptr(samples), st))
-            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=H.mark_ordered(pack_infos[:n_hit]), t_starts=t_starts.view(-1),
+            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=H.mark_ordered(pack_infos[:n_hit], total=S), t_starts=t_starts.view(-1),
                         t_ends=t_ends.view(-1), ridx=ridx64, deltas=deltas, samples=samples, bidx=bidx, gidx=gidx)
         if S > 0:
             H.check(H.lib().nr3d_ray_marching_emit(
@@ -140,7 +140,7 @@ def _march(rays_o, rays_d, t_min, t_max, batch_inds, batch_data_size, roi, grid_
             samples = H.empty((S, 3), dtype=torch.float32, device=dev)
             H.check(H.lib().nr3d_march_finish_samples(C.c_uint64(S), H.ptr(rays_o), H.ptr(rays_d), H.ptr(ridx), H.ptr(t_starts),
                                                       H.ptr(t_ends), H.ptr(ridx64), H.ptr(deltas), H.ptr(samples), st))
-            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=H.mark_ordered(pack_infos[:n_hit]), t_starts=t_starts.view(-1),
+            return dict(n_hit=n_hit, ridx_hit=ridx_hit[:n_hit], pack_infos=H.mark_ordered(pack_infos[:n_hit], total=S), t_starts=t_starts.view(-1),
                         t_ends=t_ends.view(-1), ridx=ridx64, deltas=deltas, samples=samples, bidx=bidx, gidx=gidx)
     if batched:
         return [packed_info, t_starts, t_ends, ridx, bidx, gidx]

@@ -78,7 +78,8 @@ def _pack_infos_from_n(n_per_pack):
     tmp = _scan_tmp(P, dev)
     H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(n_per_pack), H.ptr(pi), H.ptr(total), H.ptr(tmp),
                                            H.stream_of(n_per_pack)))
-    return H.mark_ordered(pi), H.wait_i64(total, dev)[0]
+    num = H.wait_i64(total, dev)[0]
+    return H.mark_ordered(pi, total=num), num
 
 
 # ------------------------------------------------------------------------------------------------
@@ -407,7 +408,7 @@ def merge_two_packs_sorted_general(vals_a, pack_infos_a, nidx_a, vals_b, pack_in
         H.check(H.lib().nr3d_try_merge_two_packs_sorted_aligned(
             H.u32(Pu), _code(vals_a), H.ptr(vals_a), H.ptr(pia_u), H.ptr(vals_b), H.ptr(pib_u), H.ptr(pim), C.c_int(1),
             H.ptr(pa), H.ptr(pb), st))
-    return pa, pb, H.mark_ordered(pim)
+    return pa, pb, H.mark_ordered(pim, total=vals_a.shape[0] + vals_b.shape[0])
 
 
 def packed_invert_cdf(bins, cdfs, u, pack_infos):
@@ -443,7 +444,9 @@ def packed_alpha_to_vw_forward(alphas, pack_infos, early_stop_eps, alpha_thre, c
         st = H.stream_of(alphas)
         if compression:
             num = torch.zeros(P, dtype=torch.int64, device=dev)
-            sel = H.empty(S, dtype=torch.bool, device=dev)
+            # the kernel writes the rows of the packs; rows outside every pack are zero (at::zeros in the reference): a fill launch
+            # unless the packs are known to tile [0, S) (H.tiles: a marcher's / a two-phase op's pack_infos)
+            sel = (H.empty if H.tiles(pack_infos, S) else torch.zeros)(S, dtype=torch.bool, device=dev)
             H.check(H.lib().nr3d_alpha_to_vw_forward(H.u32(P), C.c_uint64(S), H.ptr(alphas), H.ptr(pack_infos),
                                                      H.f32(early_stop_eps), H.f32(alpha_thre), None, H.ptr(num),
                                                      H.ptr(sel), st))
@@ -452,7 +455,7 @@ def packed_alpha_to_vw_forward(alphas, pack_infos, early_stop_eps, alpha_thre, c
             H.check(H.lib().nr3d_pack_infos_from_n(H.u32(P), H.ptr(num), H.ptr(cpi), H.ptr(total),
                                                    H.ptr(_scan_tmp(P, dev)), st))
             return None, H.mark_ordered(cpi), sel
-        w = H.empty(S, dtype=alphas.dtype, device=dev)
+        w = (H.empty if (H.tiles(pack_infos, S) and P > 0) else torch.zeros)(S, dtype=alphas.dtype, device=dev)
         H.check(H.lib().nr3d_alpha_to_vw_forward(H.u32(P), C.c_uint64(S), H.ptr(alphas), H.ptr(pack_infos),
                                                  H.f32(early_stop_eps), H.f32(alpha_thre), H.ptr(w), None, None, st))
     return w, None, None
@@ -499,7 +502,7 @@ def packed_compression_compact(alphas, pack_infos, early_stop_eps, alpha_thre, t
             H.check(H.lib().nr3d_prune_compact_samples(H.u32(P), H.ptr(pack_infos), H.ptr(begin_all), H.ptr(sel), H.ptr(f1),
                                                        H.ptr(f2), H.ptr(f3), H.ptr(l1), H.ptr(pidx), H.ptr(o1), H.ptr(o2),
                                                        H.ptr(o3), H.ptr(ol), st))
-    return idx[:P2], H.mark_ordered(cpi[:P2]), pidx, o1, o2, o3, ol
+    return idx[:P2], H.mark_ordered(cpi[:P2], total=S2), pidx, o1, o2, o3, ol
 
 
 def tau_to_alpha_forward(sigma, delta):
@@ -540,7 +543,8 @@ def packed_alpha_to_vw_backward(weights, grad_weights, alphas, pack_infos, early
     if weights.dtype != torch.float32:
         raise RuntimeError(f"{fn}: float32 only on this platform")
     with H.on_device(weights.device):
-        g = H.empty_like(alphas)
+        tiled = H.tiles(pack_infos, weights.shape[0]) and pack_infos.shape[0] > 0
+        g = H.empty_like(alphas) if tiled else torch.zeros_like(alphas)
         H.check(H.lib().nr3d_alpha_to_vw_backward(H.u32(pack_infos.shape[0]), C.c_uint64(weights.shape[0]),
                                                   H.ptr(alphas), H.ptr(weights), H.ptr(grad_weights), H.ptr(pack_infos),
                                                   H.f32(early_stop_eps), H.f32(alpha_thre), H.ptr(g),

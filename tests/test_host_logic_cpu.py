@@ -102,6 +102,10 @@ def test_ordered_pack_infos_tag_follows_the_tensor_version():
     pi[1, 1] += 0                                     # any in-place write, even a no-op, bumps the version
     assert not _hip.is_ordered(keep)
     assert _hip.is_ordered(_hip.mark_ordered(keep))   # (re-tagging is the producer's statement)
+    # `total`: only a producer that knows the row count on the host vouches for a gap-free tiling of [0, total)
+    assert not _hip.tiles(keep, 12) and _hip.tiles(_hip.mark_ordered(keep, total=12), 12) and not _hip.tiles(keep, 13)
+    keep[0, 0] += 0
+    assert not _hip.tiles(keep, 12)
     with torch.inference_mode():
         t = torch.zeros(2, 2, dtype=torch.int64)
         assert not _hip.is_ordered(_hip.mark_ordered(t))     # no version counter: untagged, zero-filled path

@@ -7,6 +7,7 @@ import time
 import numpy as np
 import torch
 
+os.environ.setdefault("NR3D_POISON_EMPTY", "1")                   # every empty() output NaN-filled: a row a kernel misses shows up
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle                                                   # noqa: E402  (test infrastructure)
@@ -22,6 +23,11 @@ def packs(rng):
     n = rng.integers(0 if rng.random() < 0.5 else 1, hi + 1, n_packs).astype(np.int64)
     if n.sum() == 0:
         n[0] = 1
+    if rng.random() < 0.4:
+        # ordered packs with rows in front of, between and behind them (the kernels zero those when the tensor is tagged)
+        gap = rng.integers(0, 3, n_packs) * (rng.random(n_packs) < 0.3)
+        begin = int(rng.integers(0, 5)) + np.cumsum(n + gap) - n
+        return np.ascontiguousarray(np.stack([begin, n], 1)), int(begin[-1] + n[-1] + rng.integers(0, 70))
     cs = np.cumsum(n)
     return np.ascontiguousarray(np.stack([cs - n, n], 1)), int(cs[-1])
 
@@ -42,6 +48,8 @@ def one(rng):
     pi, S = packs(rng)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     pit = t(pi)
+    if rng.random() < 0.6:
+        _hip.mark_ordered(pit)                                  # as a producer of this library would hand it over: no zero-fill launch
     fd = int(rng.choice([0, 1, 3, 4]))
     shape = (S,) if fd == 0 else (S, fd)
     f = rng.standard_normal(shape).astype(np.float32)
@@ -105,7 +113,9 @@ def one(rng):
     if pi.shape[0] <= 5000:
         nz = pi[pi[:, 1] > 1]
         if len(nz):
-            bins = np.concatenate([np.sort(rng.random(k).astype(np.float32)) + j for j, k in enumerate(pi[:, 1])]) if S else np.zeros(0, np.float32)
+            bins = np.zeros(S, np.float32)                              # (packs may leave rows out: each pack's bins at its own rows)
+            for j, (b0, k) in enumerate(pi):
+                bins[b0:b0 + k] = np.sort(rng.random(int(k)).astype(np.float32)) + j
             vals = (rng.random((pi.shape[0], 5)).astype(np.float32) * 1.2 - 0.1) + np.arange(pi.shape[0], dtype=np.float32)[:, None]
             close(P.packed_searchsorted(t(bins), t(vals), pit), oracle.packed_searchsorted(bins, vals, pi), "searchsorted " + tag, exact=True)
     b = rng.integers(0, 3, S).cumsum().astype(np.int64)
