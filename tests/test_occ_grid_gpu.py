@@ -481,7 +481,7 @@ def test_marcher_two_threads_two_streams(oracle, dev):
     sets (different sample counts) on their own streams, many times over, each checking every result against the oracle.
     The op's one readback (the sample count that sizes t_starts / ridx / ...) goes through a pinned staging buffer that was
     shared per (device, n) until round 3 -- a thread could then read the other's count and allocate too few samples
-    (round-3 review and advisor finding; thread-local since round 4, nr3d_lib_amd/_hip.py:read_i64)."""
+    (round-3 review and advisor finding; thread-local since round 4, nr3d_lib_amd/_hip.py: host_i64 / wait_i64, the pinned words the count kernels write into)."""
     import threading
     from nr3d_lib_amd.bindings import _occ_grid
     res = (48, 48, 48)
