@@ -216,7 +216,10 @@ __device__ __forceinline__ void store_rows(__half *__restrict__ p, int64_t strid
 			if (f >= dim) continue;
 			_Float16 *dst = reinterpret_cast<_Float16 *>(p) + (int64_t)row * stride + f;
 			const h4 v = {(_Float16)r[t][4 * q], (_Float16)r[t][4 * q + 1], (_Float16)r[t][4 * q + 2], (_Float16)r[t][4 * q + 3]};
-			if (vec && f + 3 < dim) __builtin_nontemporal_store(v, reinterpret_cast<h4 *>(dst));
+			// rows wider than one tile (NT > 1): a lane's 8-byte pieces of a 128-byte row arrive over eight instructions -- as streaming
+			// (non-temporal) stores each piece went to HBM as a partial sector write (32 -> 64 -> 64 -> 64 forward: 1.15 ms for 0.54 GB of
+			// output); as plain stores L2 merges them into whole lines first
+			if (vec && f + 3 < dim) { if (NT > 1) *reinterpret_cast<h4 *>(dst) = v; else __builtin_nontemporal_store(v, reinterpret_cast<h4 *>(dst)); }
 			else {
 #pragma unroll
 				for (int b = 0; b < 4; ++b) if (f + b < dim) dst[b] = v[b];
