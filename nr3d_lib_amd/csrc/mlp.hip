@@ -246,7 +246,8 @@ __device__ __forceinline__ void store_rows(float *__restrict__ p, int64_t stride
 			float *dst = p + (int64_t)row * stride + f;
 			if (vec && f + 3 < dim) {
 				const f4v v = {r[t][4 * q], r[t][4 * q + 1], r[t][4 * q + 2], r[t][4 * q + 3]};
-				__builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst));
+				// (rows wider than one tile: plain stores, L2 merges the row's 16-byte pieces into whole lines -- mlp_half.hip, store_rows)
+				if (NT > 1) *reinterpret_cast<f4v *>(dst) = v; else __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst));
 			} else {
 #pragma unroll
 				for (int b = 0; b < 4; ++b) if (f + b < dim) dst[b] = r[t][4 * q + b];
