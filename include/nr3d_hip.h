@@ -481,6 +481,11 @@ int nr3d_pack_infos_from_n(uint32_t P, const int64_t *n_per_pack, int64_t *pack_
 int nr3d_interleave_linstep(uint32_t P, int dtype, const int64_t *pack_infos, const void *starts,
                             const void *step_sizes, double start_s, double step_s, void *out,
                             int64_t *nidx, void *stream);
+/* the step counts of interleave_arange (graphics/pack_ops/pack_ops.py: stop.subtract(start).div(step_size).ceil().long(), four ATen
+ * launches) in one: num_steps[i] = ceil((stops[i] - starts[i]) / step) as int64, the quotient in float32 for int32 / int64 / float32
+ * tensors (ATen's true division) and in float64 for float64.  step_sizes [P] of the tensors' dtype, or NULL: the scalar step_s. */
+int nr3d_arange_num_steps(uint32_t P, int dtype, const void *starts, const void *stops, const void *step_sizes, double step_s,
+                          int64_t *num_steps, void *stream);
 
 /* interleave_sample_step_wrt_depth_clamped (:480-604), round 1 then round 2. */
 int nr3d_sample_step_count(uint32_t P, const float *nears, const float *fars, uint32_t max_steps,

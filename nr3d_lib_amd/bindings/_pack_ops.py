@@ -126,6 +126,27 @@ def interleave_linstep(start, num_steps, step_size, return_idx):
     return out, nidx
 
 
+def arange_num_steps(start, stop, step_size):
+    """ceil((stop - start) / step_size) as int64 [P] in one launch (the wrapper's stop.subtract(start).div(step).ceil().long())"""
+    fn = "interleave_arange"
+    if start.dim() != 1 or stop.shape != start.shape or stop.dtype != start.dtype or start.dtype not in _SUPPORTED:
+        raise RuntimeError(f"{fn}: Expected 1-D start / stop of the same size and dtype (float32/float64/int32/int64)")
+    H.require_gpu(start, stop)
+    steps_t, step_s = None, 0.0
+    if isinstance(step_size, torch.Tensor):
+        if step_size.shape != start.shape or step_size.dtype != start.dtype:
+            raise RuntimeError(f"{fn}: Expected a step_size tensor with the size and dtype of start")
+        steps_t = step_size.contiguous()
+    else:
+        step_s = float(step_size)
+    start, stop = start.contiguous(), stop.contiguous()
+    with H.on_device(start.device):
+        n = H.empty(start.shape[0], dtype=torch.int64, device=start.device)
+        H.check(H.lib().nr3d_arange_num_steps(H.u32(start.shape[0]), _code(start), H.ptr(start), H.ptr(stop), H.ptr(steps_t),
+                                              C.c_double(step_s), H.ptr(n), H.stream_of(start)))
+    return n
+
+
 def _chk_near_far(fn, near, far):
     if near.dim() != 1 or far.dim() != 1 or near.shape != far.shape:
         raise RuntimeError(f"{fn}: Expected 1-D near / far of the same size")

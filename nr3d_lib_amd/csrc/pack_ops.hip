@@ -12,6 +12,7 @@
 //     values is loaded coalesced, then a wave-uniform loop walks them through lane broadcasts
 //     (v_readlane), every lane tracking the same scalar state and lane j keeping the result of step j.
 //     Loads/stores stay coalesced and the sequence is bit-identical to the one-thread version.
+#include <type_traits>
 #include "common.h"
 #include "scan.h"
 #include <stdlib.h>
@@ -152,6 +153,24 @@ __global__ __launch_bounds__(kBlock) void k_sample_segments(uint32_t P, const fl
 		}
 	}
 	if (!EMIT) n_per_pack[p] = (int64_t)step;
+}
+
+// interleave_arange's step counts, ceil((stop - start) / step) as int64 -- the four ATen launches of the reference wrapper
+// (graphics/pack_ops/pack_ops.py: stop.subtract(start).div(step).ceil().long()) in one, with ATen's arithmetic: the difference in
+// the tensors' own type, the quotient in float32 (integer and float32 tensors; true division) or float64, IEEE division
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_arange_counts(uint32_t P, const T *__restrict__ start, const T *__restrict__ stop,
+                                                          const T *__restrict__ step_t, double step_s, int64_t *__restrict__ n) {
+	const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= P) return;
+	const T d = stop[i] - start[i];
+	if constexpr (sizeof(T) == 8 && !std::is_integral<T>::value) {
+		const double sv = step_t ? (double)step_t[i] : step_s;
+		n[i] = (int64_t)ceil((double)d / sv);
+	} else {
+		const float sv = step_t ? (float)step_t[i] : (float)step_s;
+		n[i] = (int64_t)ceilf((float)d / sv);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1308,6 +1327,16 @@ extern "C" int nr3d_interleave_linstep(uint32_t P, int dtype, const int64_t *pac
 	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_linstep<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
 	                                      pack_infos, (const T *)starts, (const T *)step_sizes, (T)start_s, (T)step_s,
 	                                      (T *)out, nidx));
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+extern "C" int nr3d_arange_num_steps(uint32_t P, int dtype, const void *starts, const void *stops, const void *step_sizes, double step_s,
+                                     int64_t *num_steps, void *stream) {
+	if (P == 0) return 0;
+	NR3D_CHECK(starts && stops && num_steps, "arange_num_steps: NULL pointer");
+	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_arange_counts<T>, dim3(div_up(P, pk::kBlock)), dim3(pk::kBlock), 0, (hipStream_t)stream, P,
+	                                      (const T *)starts, (const T *)stops, (const T *)step_sizes, step_s, num_steps));
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }

@@ -482,7 +482,13 @@ def interleave_linstep(start, num_steps, step_size: Union[torch.Tensor, Number],
 
 @torch.no_grad()
 def interleave_arange(start, stop, step_size: Union[torch.Tensor, Number], return_idx: bool = True):
-    num_steps = stop.subtract(start).div(step_size).ceil().long()
+    same = (start.is_cuda and start.dim() == 1 and stop.shape == start.shape and stop.dtype == start.dtype
+            and start.dtype in (torch.float32, torch.float64, torch.int32, torch.int64)
+            and (not isinstance(step_size, torch.Tensor) or (step_size.shape == start.shape and step_size.dtype == start.dtype)))
+    if same:
+        num_steps = _backend.arange_num_steps(start, stop, step_size)           # one launch, ATen's arithmetic
+    else:
+        num_steps = stop.subtract(start).div(step_size).ceil().long()
     return interleave_linstep(start, num_steps, step_size, return_idx)
 
 

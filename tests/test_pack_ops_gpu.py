@@ -173,6 +173,32 @@ def test_interleave(oracle, dev, P):
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-6)
 
 
+def test_interleave_arange_step_counts(dev):
+    """interleave_arange's step counts in one launch = the wrapper's ATen expression stop.subtract(start).div(step).ceil().long(),
+    bit for bit: int64 / int32 (quotient in float32), float32, float64; tensor and scalar steps"""
+    from nr3d_lib_amd.bindings import _pack_ops as B
+    import nr3d_lib_amd.graphics.pack_ops as po
+    rng = np.random.default_rng(3)
+    n = 5000
+    for dt in (torch.int64, torch.int32, torch.float32, torch.float64):
+        if dt.is_floating_point:
+            a = torch.from_numpy(rng.uniform(-3, 3, n)).to(dt).to(dev)
+            b = a + torch.from_numpy(rng.uniform(0, 40, n)).to(dt).to(dev)
+            st = torch.from_numpy(rng.uniform(0.05, 3, n)).to(dt).to(dev)
+            scalars = (0.37, 1, 2.5)
+        else:
+            a = torch.from_numpy(rng.integers(-5, 5, n)).to(dt).to(dev)
+            b = a + torch.from_numpy(rng.integers(0, 100, n)).to(dt).to(dev)
+            st = torch.from_numpy(rng.integers(1, 7, n)).to(dt).to(dev)
+            scalars = (1, 3, 0.5)
+        for step in (st,) + scalars:
+            want = b.subtract(a).div(step).ceil().long()
+            assert torch.equal(B.arange_num_steps(a, b, step), want), f"{dt} step {type(step).__name__}"
+    z, cnt, one = torch.zeros(64, dtype=torch.int64, device=dev), torch.arange(64, device=dev), torch.ones(64, dtype=torch.int64, device=dev)
+    v, idx = po.interleave_arange(z, cnt, one)
+    assert v.numel() == int(cnt.sum()) and torch.equal(idx, torch.repeat_interleave(torch.arange(64, device=dev), cnt))
+
+
 @pytest.mark.parametrize("gamma,lo,hi", [(0.01, 0.01, 1.0), (0.0, 0.02, 1e10), (0.05, 0.001, 0.04)])
 def test_sample_step(oracle, dev, P, gamma, lo, hi):
     rng = np.random.default_rng(13)
