@@ -358,6 +358,26 @@ def test_vm_levels_over_sorted_points(oracle, dev, forest, continuity, case, hip
     assert halves[0].dtype == halves[1].dtype and torch.equal(halves[0], halves[1])
 
 
+@pytest.mark.parametrize("case", ["mixed", "vm_cuboid"])
+def test_vm_levels_over_sorted_points_all_in_one_block(oracle, dev, case, hip_option):
+    """every point in ONE block of the forest: the other blocks' bands have no points of their own (the empty-band shortcut of
+    k_vm_sorted) but still receive the corners they own of that block's boundary cells"""
+    _lotd, fo, m_ref, metas, (x, p, g, v, bi), (xt, pt, gt, vt, bit) = _setup(oracle, dev, "plus", case, n=12000, seed=47)
+    for blk in (0, fo.n_trees - 1):
+        bi1 = np.full_like(bi, blk)
+        bit1 = torch.from_numpy(bi1).to(dev)
+        ref1 = oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi1, accum_double=True)
+        ref2 = oracle.lotd_forest_bwd_dparam(m_ref, fo, g, x, p, block_inds=bi1, dL_ddLdx=v, accum_double=True)
+        hip_option("vm_sorted", 2)
+        dp = _lotd.lod_bwd(metas, gt, xt, pt, None, bit1, need_input_grad=False, need_param_grad=True)[1]
+        dp2 = _lotd.lod_bwd_bwd_input(metas, vt, gt, xt, pt, None, bit1, need_dLdinput_ddLdoutput=False, need_dLdinput_dparams=True,
+                                      need_dLdinput_dinput=False)[1]
+        assert_close(dp, ref1, rel=1e-5, name=f"dL_dparam, all points in block {blk}", levels=m_ref)
+        assert_close(dp2, ref2, rel=1e-5, name=f"d(dLdx)/dparam, all points in block {blk}", levels=m_ref)
+        per_block = dp.view(fo.n_trees, -1).abs().amax(1)
+        assert int((per_block > 0).sum()) > 1, "a block with neighbours must hand them the corners they own"
+
+
 def test_forest_accel_end_to_end(oracle, dev):
     """ForestBlockSpace + OccGridAccelForest: per-block grids learnt from a world-space field (init, warm-up and steady
     steps, renderer samples), then world rays marched through the blocks they cross -- against the oracle's march on
