@@ -621,7 +621,9 @@ static uint32_t bwd_waves(const Shape &s) {
 	const uint32_t max_waves = (s.in_t == 1 && s.w_t == 1 && s.out_t == 1 && s.n_layers - 1 <= 2) ? 8u : 4u;      // = BwdCfg<...>::kMaxWaves
 	for (uint32_t nw = max_waves; nw >= 1; --nw) {
 		const uint64_t t = (uint64_t)nw * bwd_tile_floats(s) * 4;
-		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)(nw > 4 ? kMaxLdsBwd : kMaxLds)) return nw;
+		// the whole 160 KB (the kernel has no static LDS): 32 -> 64 -> 64 -> 16 needs 149 KB for THREE waves (144 KB gave it two), the
+		// 64-wide input / output shapes 146 KB for two (they ran one wave per CU)
+		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)kMaxLdsBwd) return nw;
 	}
 	return 0;
 }
