@@ -399,7 +399,7 @@ def lotd_large_batch_rate(log2n=24):
     import subprocess
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--log2-points", str(log2n), "--steps", "20", "--warmup", "5",
                         "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=900)
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    line = [l[len("BENCH_FULL "):] for l in r.stdout.splitlines() if l.startswith("BENCH_FULL {")]    # the full tables, not the digest
     if not line:
         return {"error": (r.stderr or r.stdout)[-300:]}
     d = json.loads(line[-1])
@@ -646,6 +646,157 @@ def reference_workloads(dev):
     return brw.run(dev)
 
 
+COMPACT_LIMIT_BYTES = 6000     # the driver parses the LAST stdout line out of an 8 KB tail: it has to stay well under that
+L2_GATHER_CEILING_GREQ_S = 255.0   # 8-byte random gathers alone: 62.3 M requests in 245 us (profiles/r03a_fwd_experiments.txt)
+FWD_REQUESTS_PER_POINT_LEVEL = 4.25    # k_fwd_pairlane: TCP_TCC_READ_REQ per (point, level) (profiles/r04final_counters.txt)
+
+
+def _get(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def _scalars(d, keys):
+    """{short: value} for the (short, path...) entries whose value exists and is not an error"""
+    out = {}
+    for short, *path in keys:
+        v = _get(d, *path)
+        if v is not None:
+            out[short] = v
+    return out
+
+
+def compact_extra(extra):
+    """one scalar group per extra figure (the full tables go to bench_extra.json and to the BENCH_FULL line)"""
+    c = {}
+    for name, item in extra.items():
+        if isinstance(item, dict) and "error" in item:
+            c[name] = {"error": str(item["error"])[:80]}
+    pick = {
+        "lotd_2p24_points": [("ms", "ms_per_step_median"), ("mpts", "mpoints_per_s"), ("whole_step_frac", "whole_step_frac"),
+                             ("fwd_kernel_frac", "per_kernel", PROF_KERNELS["lotd_fwd"], "frac")],
+        "c4_mixed_lotd": [("ms", "ms_total"), ("mpts", "mpoints_per_s"), ("frac", "roofline", "frac"), ("model", "roofline", "model"),
+                          ("dparam_ms", "ms", "bwd_dparam"), ("dparam_frac", "roofline", "per_pass", "bwd_dparam", "frac")],
+        "full_loop_1gpu": [("ms", "ms_per_iter"), ("mrays", "mrays_per_s")],
+        "full_loop_1gpu_half": [("ms", "ms_per_iter"), ("mrays", "mrays_per_s")],
+        "march_composite": [("ms", "ms_per_iter"), ("mrays", "mrays_per_s"), ("kernel_us", "kernel_us_per_iter"),
+                            ("cpu_mrays", "cpu_baseline", "value"), ("cpu_cores", "cpu_baseline", "cores")],
+        "march_composite_shell": [("ms", "ms_per_iter"), ("mrays", "mrays_per_s")],
+        "march_composite_262144_rays": [("ms", "ms_per_iter"), ("mrays", "mrays_per_s")],
+        "march_composite_262144_rays_shell": [("ms", "ms_per_iter"), ("mrays", "mrays_per_s")],
+        "c1_dense_fwd": [("gpu_ms", "gpu_ms"), ("cpu_pytorch_ms", "cpu_pytorch_ms"), ("max_rel_diff", "max_rel_diff")],
+        "forest_lotd": [("ms", "ms_per_iter"), ("mpts", "mpoints_per_s")],
+        "forest_lotd_by_block": [("ms", "ms_per_iter"), ("mpts", "mpoints_per_s")],
+        "lotd_half_params": [("ms", "ms_per_step"), ("mpts", "mpoints_per_s")],
+        "lotd_second_order": [("ms", "ms_total"), ("ms_one_call", "ms_all_three_in_one_call")],
+        "mlp_decoder": [("f32_fwd_ms", "fused", "fwd_ms"), ("f32_fwd_bwd_ms", "fused", "fwd_bwd_ms"),
+                        ("f16_fwd_ms", "half", "fused", "fwd_ms"), ("f16_fwd_bwd_ms", "half", "fused", "fwd_bwd_ms"),
+                        ("f32_mfma_frac_fwd", "roofline", "fwd_frac"), ("f16_hbm_frac_bwd", "half", "roofline", "bwd_frac")],
+        "mlp_decoder_64": [("f32_fwd_bwd_ms", "fused", "fwd_bwd_ms"), ("f16_fwd_bwd_ms", "half", "fused", "fwd_bwd_ms")],
+        "march_composite_262144_rays_per_gpu": [("ms", "ms_per_iter"), ("mrays", "mrays_per_s")],
+        "full_loop_2p21_rays_per_gpu": [("ms", "ms_per_iter"), ("mrays", "mrays_per_s"), ("rays", "rays")],
+    }
+    for name, keys in pick.items():
+        if name in extra and name not in c:
+            c[name] = _scalars(extra[name], keys)
+    rw = extra.get("reference_workloads")
+    if isinstance(rw, dict) and "rows" in rw:
+        rated = [r for r in rw["rows"] if r.get("ref_over_ours") is not None]
+        worst = min(rated, key=lambda r: r["ref_over_ours"]) if rated else None
+        c["reference_workloads"] = dict(rows=_get(rw, "rows_with_reference_figure"), faster=_get(rw, "rows_faster_than_reference_figure"),
+                                        min_ratio=worst and worst["ref_over_ours"], worst_row=worst and str(worst["name"])[:70])
+    return c
+
+
+def compact_line(full):
+    """the ONE line the driver parses: headline + roofline + cpu_baseline + a scalar digest of the extras.
+    tests/test_bench_line_cpu.py holds its size (COMPACT_LIMIT_BYTES) and that it round-trips through json"""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_min_max",
+            "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full[k] for k in keep if k in full}
+    cfg = dict(full.get("config", {}))
+    if isinstance(cfg.get("parallelism"), str):
+        cfg["parallelism"] = cfg["parallelism"][:160]
+    out["config"] = cfg
+    if "kernel_ms" in full:
+        out["kernel_ms"] = full["kernel_ms"]
+    rf = full.get("roofline")
+    if rf:
+        r = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_bytes",
+                                "algorithmic_bytes_per_point", "whole_step_frac", "request_rate") if k in rf}
+        r["timers"] = "in-library HIP events on the launch stream, dominant kernel inside the timed region"
+        if "per_kernel" in rf:        # kernel -> [avg us, frac]
+            r["per_kernel_us_frac"] = {k.split("<")[0]: [v["avg_us"], v["frac"]] for k, v in rf["per_kernel"].items()}
+        out["roofline"] = r
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = full["cpu_baseline"]
+    if "extra" in full:
+        out["extra"] = compact_extra(full["extra"])
+        out["extra"]["full_tables"] = "bench_extra.json; BENCH_FULL line above"
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT_BYTES:                     # never let a digest cost the headline: drop digests, largest first
+        ex = out.get("extra", {})
+        for name in sorted(ex, key=lambda k: -len(json.dumps(ex[k]))):
+            del ex[name]
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= COMPACT_LIMIT_BYTES:
+                break
+    return line
+
+
+def emit(full):
+    """full tables first (one line, prefixed so that no parser takes it for the result, and bench_extra.json), the compact line LAST"""
+    try:
+        with open(os.path.join(ROOT, "bench_extra.json"), "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError:
+        pass
+    print("BENCH_FULL " + json.dumps(full), flush=True)
+    print(compact_line(full), flush=True)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run on this node and
+    become that process (the driver's own `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE and never gets here)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def plumbing_check(args, rank, world):
+    """--plumbing-check: the launch path without a GPU (tests/test_bench_line_cpu.py): gloo group, the barrier / MAX-over-ranks
+    protocol of the timed region around an empty step, rank 0 prints a compact line with value null.  Not a measurement."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        emit({"metric": "plumbing check (no GPU work, not a measurement)", "value": None, "unit": "Mpoints/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "f32", "data": "none",
+              "config": {"workload": "plumbing check", "parallelism": f"dp{world}: gloo, world size {dist.get_world_size()}",
+                         "per_rank_ms_per_step": [round(float(v.item()) / max(1, args.steps) * 1e3, 6) for v in every]}})
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -656,13 +807,24 @@ def main():
     ap.add_argument("--log2-points", type=int, default=N_POINTS_LOG2)
     ap.add_argument("--no-kernel-timers", action="store_true",
                     help="no in-library HIP-event timers inside the timed region (A/B of their cost; roofline from an extra pass)")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="launch path only (gloo, no GPU, no kernels): ranks start, meet, rank 0 prints a line with value null")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): be the launcher
+        if not args.plumbing_check and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
+        launch_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch {args.gpus} ranks, or run bare and let bench.py launch them)")
+    if args.plumbing_check:
+        return plumbing_check(args, rank, world)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -869,6 +1031,16 @@ def main():
                                     for k in names},
                          "whole_step_frac": round(sum(bpp.values()) * N / (sum(kms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
         }
+        if "lotd_fwd" in kernel_us:
+            # the forward gather kernel is not byte bound: its corner gathers are 8 useful bytes per 128-byte L2 line, and what
+            # limits it is the rate at which the L2 channels serve lines.  Its second ceiling, next to the HBM one:
+            # requests of one launch (4.25 per point and level, the counter figure) / launch time against the rate 8-byte
+            # random gathers ALONE reach on this part
+            req = FWD_REQUESTS_PER_POINT_LEVEL * served["lotd_fwd"] * N
+            greq = req / (kernel_us["lotd_fwd"] * 1e-6) / 1e9
+            out["roofline"]["request_rate"] = {"kernel": PROF_KERNELS["lotd_fwd"], "l2_read_requests": int(req),
+                                               "achieved_greq_s": round(greq, 1), "ceiling_greq_s": L2_GATHER_CEILING_GREQ_S,
+                                               "frac": round(greq / L2_GATHER_CEILING_GREQ_S, 4)}
         if world == 1 and not args.no_extra:
             out["extra"] = {}
             for name, fn in (("march_composite", lambda: march_composite_rate(dev, cpu_seconds=0.0 if args.no_cpu_baseline else 4.0)),
@@ -896,7 +1068,7 @@ def main():
             out["extra"]["full_loop_2p21_rays_per_gpu"] = multi_loop
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
