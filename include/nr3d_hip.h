@@ -641,6 +641,17 @@ int nr3d_octree_mark_consecutive_segments(uint32_t P, const int32_t *pidx, const
                                           const int16_t *point_hierarchies, uint8_t *mark_start, uint8_t *mark_end,
                                           void *stream);
 
+/* The library's own point sort (csrc/rsort.hip, ABI 5), exported for its tests -- lotd_sorted.inc orders the points of a large-table
+ * dL/dparam pass with it (the reference's default build has no library sort either: pack_ops_cuda.cu:2621-2629 compiles thrust
+ * out, :2634-2720 is its own kernel).  Stable LSD radix sort of `batch` (1 or 2) independent arrays of (uint32 key, uint32
+ * value) pairs of the same length by key bits [0, bits): kin{0,1} / vin{0,1} -> kout{0,1} / vout{0,1} (the second set ignored
+ * for batch 1).  vin NULL: the values are the element indices.  n_dev (optional): element count in DEVICE memory, <= n_max.
+ * Inputs are left untouched, outputs must not alias them; tmp: nr3d_sort_pairs_u32_tmp_bytes(n_max, batch) bytes. */
+uint64_t nr3d_sort_pairs_u32_tmp_bytes(uint32_t n_max, int batch);
+int nr3d_sort_pairs_u32(void *tmp, int batch, const uint32_t *kin0, const uint32_t *vin0, uint32_t *kout0, uint32_t *vout0,
+                        const uint32_t *kin1, const uint32_t *vin1, uint32_t *kout1, uint32_t *vout1, uint32_t n_max,
+                        const uint32_t *n_dev, int bits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

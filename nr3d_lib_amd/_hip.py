@@ -13,6 +13,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnr3d_hip.so")
+ABI_VERSION = 5          # nr3d_abi_version() of the library these bindings were written against (include/nr3d_hip.h)
 CSRC = os.path.join(_PKG, "csrc")
 
 # dtype codes of include/nr3d_hip.h
@@ -50,6 +51,12 @@ def lib():
                         "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C nr3d_lib_amd/csrc`. "
                         "There is no CPU fallback for the kernel path.")
                 l = C.CDLL(LIB_PATH)
+                # a stale build behind a newer binding would take arguments in the wrong places (an int where a pointer is
+                # expected: wild writes, not an error) -- refuse it here, not in a test
+                have = int(l.nr3d_abi_version())
+                if have != ABI_VERSION:
+                    raise RuntimeError(f"nr3d_lib_amd: {LIB_PATH} has ABI version {have}, these bindings need {ABI_VERSION}: "
+                                       "rebuild it (`make -C nr3d_lib_amd/csrc` or __graft_entry__.build())")
                 l.nr3d_last_error.restype = C.c_char_p
                 l.nr3d_scan_tmp_bytes.restype = C.c_uint64
                 l.nr3d_scan_tmp_bytes.argtypes = [C.c_uint64]
@@ -167,6 +174,32 @@ def stream_of(t):
     if _raw_stream is not None:
         return C.c_void_p(_raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def sort_pairs_u32(keys, values=None, bits=32, n_dev=None):
+    """the library's own stable LSD radix sort (csrc/rsort.hip; nr3d_sort_pairs_u32): keys int32 [n] or a pair of them (two
+    independent sorts in the same launches), read as uint32 and ordered by their low `bits` bits; values int32 [n] (None: the
+    element indices); n_dev int32 [1] on the device: only the first n_dev[0] elements take part (the rest of the outputs is
+    left as allocated).  Returns (sorted keys, values in that order) -- lists when a pair was given.  Internal (the sorted-points
+    dL/dparam path uses it); exported for tests/test_rsort_gpu.py."""
+    pair = isinstance(keys, (list, tuple))
+    ks = list(keys) if pair else [keys]
+    vs = list(values) if isinstance(values, (list, tuple)) else [values] * len(ks)
+    assert len(ks) in (1, 2) and all(k.is_cuda and k.dtype == torch.int32 and k.is_contiguous() and k.shape == ks[0].shape for k in ks)
+    assert all(v is None or (v.is_cuda and v.dtype == torch.int32 and v.is_contiguous() and v.shape == ks[0].shape) for v in vs)
+    n, dev = ks[0].numel(), ks[0].device
+    l = lib()
+    l.nr3d_sort_pairs_u32_tmp_bytes.restype = C.c_uint64
+    tmp = torch.empty(int(l.nr3d_sort_pairs_u32_tmp_bytes(C.c_uint32(n), C.c_int(len(ks)))) or 1, dtype=torch.uint8, device=dev)
+    ko, vo = [empty(n, dtype=torch.int32, device=dev) for _ in ks], [empty(n, dtype=torch.int32, device=dev) for _ in ks]
+    a = []
+    for i in range(2):
+        j = i if i < len(ks) else None
+        a += [ptr(ks[j]) if j is not None else None, ptr(vs[j]) if j is not None else None,
+              ptr(ko[j]) if j is not None else None, ptr(vo[j]) if j is not None else None]
+    with on_device(dev):
+        check(l.nr3d_sort_pairs_u32(ptr(tmp), C.c_int(len(ks)), *a, C.c_uint32(n), ptr(n_dev), C.c_int(int(bits)), stream_of(ks[0])))
+    return (ko, vo) if pair else (ko[0], vo[0])
 
 
 class _NoCtx:

@@ -36,14 +36,14 @@ struct Scope {
 };
 }  // namespace prof
 
-// device radix sort of (key, value) pairs behind plain functions (sort_glue.hip: rocPRIM through hipCUB, its own translation unit)
-namespace sortglue {
-size_t pairs_tmp_bytes(uint32_t n);
-int pairs_u64(void *tmp, size_t tmp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n, int bits,
-              hipStream_t st);
-int pairs_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint32_t n,
-              hipStream_t st);
-}  // namespace sortglue
+// the library's own stable LSD radix sort of (u32 key, u32 value) pairs (rsort.hip): `batch` (1 or 2) independent sorts of the same
+// length per call, by key bits [0, bits); vin[b] == NULL: the values are the element indices; n_dev (optional): the element count
+// in device memory (<= n_max).  Inputs untouched, outputs must not alias them.
+namespace rsort {
+size_t tmp_bytes(uint32_t n_max, int batch);
+int sort_pairs(void *tmp, int batch, const uint32_t *const *kin, const uint32_t *const *vin, uint32_t *const *kout, uint32_t *const *vout,
+               uint32_t n_max, const uint32_t *n_dev, int bits, hipStream_t st);
+}  // namespace rsort
 
 // ---- dtype <-> float conversions used by kernels templated on storage type ----
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }

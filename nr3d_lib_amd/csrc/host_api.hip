@@ -105,7 +105,18 @@ extern "C" int nr3d_set_option(int id, int64_t value) {
 extern "C" int64_t nr3d_get_option(int id) { return (id >= 0 && id < NR3D_OPT_COUNT) ? opt::g_val[id] : -1; }
 
 extern "C" const char *nr3d_last_error(void) { return err_buf(); }
-extern "C" int nr3d_abi_version(void) { return 4; }
+extern "C" int nr3d_abi_version(void) { return 5; }
+
+extern "C" uint64_t nr3d_sort_pairs_u32_tmp_bytes(uint32_t n_max, int batch) { return (uint64_t)rsort::tmp_bytes(n_max, batch == 2 ? 2 : 1); }
+extern "C" int nr3d_sort_pairs_u32(void *tmp, int batch, const uint32_t *kin0, const uint32_t *vin0, uint32_t *kout0, uint32_t *vout0,
+                                   const uint32_t *kin1, const uint32_t *vin1, uint32_t *kout1, uint32_t *vout1, uint32_t n_max,
+                                   const uint32_t *n_dev, int bits, void *stream) {
+	NR3D_CHECK(batch == 1 || batch == 2, "nr3d_sort_pairs_u32: batch must be 1 or 2");
+	NR3D_CHECK(n_max == 0 || (tmp && kin0 && kout0 && vout0 && (batch == 1 || (kin1 && kout1 && vout1))), "nr3d_sort_pairs_u32: NULL argument");
+	const uint32_t *kin[2] = {kin0, kin1}, *vin[2] = {vin0, vin1};
+	uint32_t *kout[2] = {kout0, kout1}, *vout[2] = {vout0, vout1};
+	return rsort::sort_pairs(tmp, batch, kin, vin, kout, vout, n_max, n_dev, bits, (hipStream_t)stream);
+}
 
 extern "C" int nr3d_lotd_meta_create(int32_t n_input_dim, uint32_t n_levels, const int32_t *res_multidim,
                                      const int32_t *n_feats, const int32_t *types, uint32_t hashmap_size,

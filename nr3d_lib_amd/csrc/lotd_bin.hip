@@ -1958,7 +1958,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		// (lotd_sorted.inc); its scratch is the record / offsets region, which the classes below use afterwards
 		if (!g_half) {
 			VsPlan vsp;
-			const uint64_t smask = vm_sorted_plan(meta, n, n_batches, min_level, max_level, cp_mask, vsp);
+			const uint64_t smask = vm_sorted_plan(meta, n, n_batches, forest != nullptr, min_level, max_level, cp_mask, vsp);
 			if (smask) {
 				VsScratch vss;
 				vm_sorted_scratch(vsp, n, E, second, forest != nullptr, vss);

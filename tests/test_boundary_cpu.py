@@ -9,6 +9,8 @@ import subprocess
 import pytest
 import torch
 
+from nr3d_lib_amd import _hip
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -23,7 +25,7 @@ def test_library_exports_every_header_symbol(hiplib):
                         capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r" T (nr3d_[A-Za-z0-9_]+)", nm)))
     assert exported == declared, (set(exported) ^ set(declared))
-    assert hiplib.nr3d_abi_version() == 4          # 2: map_col; 3: forest entry points take param_dtype; 4: option table, bwd_fused removed
+    assert hiplib.nr3d_abi_version() == _hip.ABI_VERSION == 5     # 2: map_col; 3: forest entry points take param_dtype; 4: option table, bwd_fused removed; 5: nr3d_sort_pairs_u32
 
 
 def test_library_is_gfx950_only():
