@@ -641,6 +641,23 @@ int nr3d_octree_mark_consecutive_segments(uint32_t P, const int32_t *pidx, const
                                           const int16_t *point_hierarchies, uint8_t *mark_start, uint8_t *mark_end,
                                           void *stream);
 
+/* Spatial order of a batch of sample positions (ABI 5; csrc/ray_glue.hip): x float [n, 3] -> order int32 [n], order[k] = the sample
+ * at position k of a Morton curve through a 2^bits_per_dim grid over the batch's own bounding box (ties in input order).  The
+ * ray-query driver (graphics/nerf/nerf_ray_query.py) runs the field on the rendered samples in this order: samples of neighbouring
+ * rays that share grid cells become consecutive lanes, which the LoTD backward merges before its scatter and the forward's
+ * gathers coalesce (the reference has no counterpart: nerf_ray_query.py:140-160 queries in ray order).  bits_per_dim 1..10;
+ * tmp: nr3d_spatial_order_tmp_bytes(n) bytes. */
+uint64_t nr3d_spatial_order_tmp_bytes(uint32_t n);
+int nr3d_spatial_order(uint32_t n, const float *x, uint32_t bits_per_dim, int32_t *order, void *tmp, void *stream);
+/* the field's inputs in that order: x_out[k] = x[order[k]], ridx_out[k] = ridx[order[k]] (int64 ray index per sample, optional) and
+ * dirs_out[k] = dirs[ridx[order[k]]] (per-RAY float [n_rays, 3], optional: the view_dirs[ridx] gather of nerf_ray_query.py:78) */
+int nr3d_order_gather_inputs(uint32_t n, const int32_t *order, const float *x, const int64_t *ridx, const float *dirs, float *x_out,
+                             int64_t *ridx_out, float *dirs_out, void *stream);
+/* rows of up to two per-sample float arrays (a [n, wa], b [n, wb]; a width of 0 skips one) between the two orders:
+ * scatter != 0: out[order[k]] = in[k] (the field's outputs back to the samples' own order); else out[k] = in[order[k]] */
+int nr3d_order_move_rows(uint32_t n, const int32_t *order, int scatter, const float *a, uint32_t wa, float *a_out, const float *b,
+                         uint32_t wb, float *b_out, void *stream);
+
 /* The library's own point sort (csrc/rsort.hip, ABI 5), exported for its tests -- lotd_sorted.inc orders the points of a large-table
  * dL/dparam pass with it (the reference's default build has no library sort either: pack_ops_cuda.cu:2621-2629 compiles thrust
  * out, :2634-2720 is its own kernel).  Stable LSD radix sort of `batch` (1 or 2) independent arrays of (uint32 key, uint32

@@ -202,6 +202,54 @@ def sort_pairs_u32(keys, values=None, bits=32, n_dev=None):
     return (ko, vo) if pair else (ko[0], vo[0])
 
 
+def spatial_order(x, bits_per_dim=6):
+    """order int32 [n]: order[k] = the row of x [n, 3] (float32, contiguous, CUDA) at position k of a Morton curve through a
+    2^bits_per_dim grid over the batch's bounding box, ties in input order (nr3d_spatial_order)"""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == 3 and x.is_contiguous()
+    n, dev = x.shape[0], x.device
+    l = lib()
+    l.nr3d_spatial_order_tmp_bytes.restype = C.c_uint64
+    order = empty(n, dtype=torch.int32, device=dev)
+    if n:
+        tmp = torch.empty(int(l.nr3d_spatial_order_tmp_bytes(C.c_uint32(n))), dtype=torch.uint8, device=dev)
+        with on_device(dev):
+            check(l.nr3d_spatial_order(C.c_uint32(n), ptr(x), C.c_uint32(int(bits_per_dim)), ptr(order), ptr(tmp), stream_of(x)))
+    return order
+
+
+def order_gather_inputs(order, x, ridx=None, dirs=None):
+    """(x[order], ridx[order] | None, dirs[ridx[order]] | None) in one launch (nr3d_order_gather_inputs): x float32 [n, 3], ridx int64
+    [n], dirs float32 [n_rays, 3]"""
+    n, dev = x.shape[0], x.device
+    assert x.dtype == torch.float32 and x.is_contiguous() and order.dtype == torch.int32 and order.shape[0] == n
+    assert ridx is None or (ridx.dtype == torch.int64 and ridx.is_contiguous() and ridx.shape[0] == n)
+    assert dirs is None or (ridx is not None and dirs.dtype == torch.float32 and dirs.is_contiguous() and dirs.shape[1] == 3)
+    x_s = empty((n, 3), dtype=torch.float32, device=dev)
+    r_s = empty(n, dtype=torch.int64, device=dev) if ridx is not None else None
+    d_s = empty((n, 3), dtype=torch.float32, device=dev) if dirs is not None else None
+    with on_device(dev):
+        check(lib().nr3d_order_gather_inputs(C.c_uint32(n), ptr(order), ptr(x), ptr(ridx), ptr(dirs), ptr(x_s), ptr(r_s), ptr(d_s), stream_of(x)))
+    return x_s, r_s, d_s
+
+
+def order_move_rows(order, a, b=None, scatter=True):
+    """rows of one or two float32 arrays [n, ...] between the spatial order and the samples' own order (nr3d_order_move_rows):
+    scatter: out[order[k]] = in[k]; else out[k] = in[order[k]]"""
+    n, dev = a.shape[0], a.device
+    a = a.contiguous()
+    wa = a.numel() // max(n, 1)
+    a_out = empty(a.shape, dtype=torch.float32, device=dev)
+    wb, b_out = 0, None
+    if b is not None:
+        b = b.contiguous()
+        wb = b.numel() // max(n, 1)
+        b_out = empty(b.shape, dtype=torch.float32, device=dev)
+    with on_device(dev):
+        check(lib().nr3d_order_move_rows(C.c_uint32(n), ptr(order), C.c_int(1 if scatter else 0), ptr(a), C.c_uint32(wa), ptr(a_out),
+                                         ptr(b), C.c_uint32(wb), ptr(b_out), stream_of(a)))
+    return a_out, b_out
+
+
 class _NoCtx:
     def __enter__(self):
         return None

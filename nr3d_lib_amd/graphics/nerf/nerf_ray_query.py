@@ -19,6 +19,7 @@ from nr3d_lib_amd.graphics.nerf.nerf_utils import (packed_alpha_to_vw, packed_vo
 from nr3d_lib_amd.graphics.pack_ops import (packed_composite, packed_div, packed_sum,
                                             packed_volume_render_compression_gather)
 from nr3d_lib_amd.profile import profile
+from nr3d_lib_amd import _hip as _H
 
 __all__ = ['nerf_ray_query_march_occ', 'composite_packed_volume_buffer']
 
@@ -26,6 +27,59 @@ _PER_RAY_KEYS = (('ts', 'rays_ts'), ('fidx', 'rays_fidx'), ('bidx', 'rays_bidx')
                  ('h_appear', 'rays_h_appear'))
 _PASSTHROUGH = ('flow_fwd', 'flow_fwd_pred_bwd', 'flow_bwd', 'flow_bwd_pred_fwd', 'sigma_static', 'rgb_static',
                 'sigma_dynamic', 'rgb_dynamic')
+
+
+# Round 5: the differentiable query runs on the rendered samples in SPATIAL order (a Morton curve over their bounding box,
+# nr3d_spatial_order) and its outputs are put back into ray order.  Ray-major samples of neighbouring rays share grid cells but sit
+# a ray's length apart; along the curve they are consecutive lanes, which the LoTD backward merges before its scatter and the
+# forward's gathers coalesce.  Results are the same values in the same places (the field is evaluated point by point); parameter
+# gradients differ by summation order only.  0: off (the reference's order); otherwise bits per dimension of the curve's grid.
+# Measured on the full loop (262 144 rays, 1.67 M rendered samples; profiles/r05e_full_loop_*): stage B of dL/dparam 673 -> 450 us, the
+# encoder forward on the rendered samples 309 -> 198 us; the order itself costs 190 us (sort 3 x 31, moving inputs / outputs / gradients
+# 35 + 44 + 29, keys and bounds 20) -- 5.45 -> 5.42 ms per iteration at 8 bits (5.49-5.56 at 5-7 bits): it pays for itself, no more.
+SPATIAL_ORDER_BITS = 8
+SPATIAL_ORDER_MIN_SAMPLES = 1 << 19      # below this the backward is launch bound and the order does not pay
+
+
+class _FromSpatialOrder(torch.autograd.Function):
+    """one or two per-sample float32 outputs of the field from the spatial order back to the samples' own order (one launch);
+    backward: the gradients into the spatial order (one launch).  order is a permutation, so neither direction accumulates."""
+
+    @staticmethod
+    def forward(ctx, order, a, b):
+        ctx.save_for_backward(order)
+        ctx.two = b is not None
+        a_out, b_out = _H.order_move_rows(order, a, b, scatter=True)
+        return (a_out, b_out) if b is not None else a_out
+
+    @staticmethod
+    def backward(ctx, ga, gb=None):
+        order, = ctx.saved_tensors
+        if ga is not None and gb is not None:
+            g1, g2 = _H.order_move_rows(order, ga, gb, scatter=False)
+            return None, g1, g2
+        g1 = _H.order_move_rows(order, ga, None, scatter=False)[0] if ga is not None else None
+        g2 = _H.order_move_rows(order, gb, None, scatter=False)[0] if gb is not None else None
+        return None, g1, g2
+
+
+def _from_spatial_order(order, net_out, n):
+    """every per-sample float32 CUDA tensor of the field's output dict back in the samples' own order, two per launch"""
+    keys = [k for k, v in net_out.items() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n]
+    out = dict(net_out)
+    fast = [k for k in keys if net_out[k].dtype == torch.float32]
+    for k in keys:
+        if k not in fast:                                  # other dtypes (half features, integer tags): plain index ops
+            inv = torch.empty_like(order, dtype=torch.int64)
+            inv[order.long()] = torch.arange(n, device=order.device)
+            out[k] = net_out[k].index_select(0, inv)
+    for i in range(0, len(fast), 2):
+        pair = fast[i:i + 2]
+        if len(pair) == 2:
+            out[pair[0]], out[pair[1]] = _FromSpatialOrder.apply(order, net_out[pair[0]], net_out[pair[1]])
+        else:
+            out[pair[0]] = _FromSpatialOrder.apply(order, net_out[pair[0]], None)
+    return out
 
 
 def _flag(model, name):
@@ -127,8 +181,25 @@ def nerf_ray_query_march_occ(model, ray_tested: Dict[str, torch.Tensor], with_rg
         volume_buffer['rays_bidx_hit'] = ray_tested['rays_bidx'][nidx_useful]     # indexing as in the reference (:148)
 
     with profile("Query"):
-        kw = query_kwargs(samples, ridx_all, full_uses, full_view)
-        net_out = (model.forward if with_rgb else model.forward_density)(**kw, **forward_params)
+        n_render = samples.shape[0]
+        spatial = (SPATIAL_ORDER_BITS and n_render >= SPATIAL_ORDER_MIN_SAMPLES and samples.is_cuda and samples.dtype == torch.float32
+                   and samples.dim() == 2 and samples.shape[1] == 3 and ridx_all.dtype == torch.int64 and torch.is_grad_enabled()
+                   and not samples.requires_grad and (view_dirs is None or (view_dirs.dtype == torch.float32 and not view_dirs.requires_grad)))
+        if not spatial:
+            kw = query_kwargs(samples, ridx_all, full_uses, full_view)
+            net_out = (model.forward if with_rgb else model.forward_density)(**kw, **forward_params)
+        else:
+            order = _H.spatial_order(samples.contiguous(), SPATIAL_ORDER_BITS)
+            # position, ray index and view direction of the sample at every position of the order: one launch
+            x_s, ridx_s, v_s = _H.order_gather_inputs(order, samples.contiguous(), ridx_all.contiguous(),
+                                                      view_dirs.contiguous() if full_view else None)
+            kw = dict(x=x_s)
+            for k, src in _PER_RAY_KEYS:
+                if full_uses[k]:
+                    kw[k] = ray_tested[src][ridx_s]
+            if full_view:
+                kw['v'] = v_s
+            net_out = _from_spatial_order(order, (model.forward if with_rgb else model.forward_density)(**kw, **forward_params), n_render)
     if with_rgb:
         volume_buffer['rgb'] = net_out['rgb'].to(dtype)
     volume_buffer['deltas'] = deltas.to(dtype)

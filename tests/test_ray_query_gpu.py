@@ -151,3 +151,83 @@ def test_accel_and_space_drive_the_same_query(dev):
     assert float(accel.occ._occ_val_grid_pcl.max()) == 99.0
     new_aabb = accel.try_shrink()
     assert tuple(new_aabb.shape) == (2, 3) and bool((new_aabb[0] >= space.aabb[0] - 1e-5).all()) and bool((new_aabb[1] <= space.aabb[1] + 1e-5).all())
+
+
+def _morton_keys_torch(x, bits):
+    """nr3d_spatial_order's key, restated with torch ops on the device (same fp32 operations in the same order)"""
+    lo, hi = x.min(0).values, x.max(0).values
+    ext = hi - lo
+    cells = float(1 << bits)
+    q = torch.where(ext > 0, (x - lo) / ext * cells, torch.zeros_like(x)).clamp(0.0, cells - 1.0).to(torch.int64)
+    key = torch.zeros(x.shape[0], dtype=torch.int64, device=x.device)
+    for d in range(3):
+        for k in range(bits):
+            key |= ((q[:, d] >> k) & 1) << (3 * k + d)
+    return key
+
+
+@pytest.mark.parametrize("n,bits", [(1, 8), (77, 3), (5000, 6), (123_457, 8), (300_000, 10)])
+def test_spatial_order_is_the_stable_morton_order(dev, n, bits):
+    from nr3d_lib_amd import _hip as H
+    g = torch.Generator().manual_seed(n + bits)
+    x = (torch.rand(n, 3, generator=g) * torch.tensor([2.0, 0.5, 7.0]) - torch.tensor([1.0, 0.1, 3.0])).to(dev)
+    if n > 100:
+        x[n // 2:n // 2 + 40] = x[5]                     # a run of identical points: ties keep the input order
+    order = H.spatial_order(x, bits)
+    assert order.dtype == torch.int32
+    assert_equal(torch.sort(order).values, torch.arange(n, device=dev, dtype=torch.int32), "order is a permutation")
+    key = _morton_keys_torch(x, bits)
+    want = torch.sort(key, stable=True).indices
+    assert_equal(order.long(), want, "stable order of the Morton keys")
+    # the movers: inputs along the order, outputs back, gradients along the order again
+    ridx = torch.randint(0, 50, (n,), generator=g).to(dev)
+    dirs = torch.randn(50, 3, generator=g).to(dev)
+    x_s, r_s, d_s = H.order_gather_inputs(order, x, ridx, dirs)
+    assert_equal(x_s, x[want], "x along the order"); assert_equal(r_s, ridx[want], "ridx along the order")
+    assert_equal(d_s, dirs[ridx[want]], "view directions along the order")
+    a, b = torch.randn(n, generator=g).to(dev), torch.randn(n, 3, generator=g).to(dev)
+    a_o, b_o = H.order_move_rows(order, a[want].contiguous(), b[want].contiguous(), scatter=True)
+    assert_equal(a_o, a, "scatter back"); assert_equal(b_o, b, "scatter back [n, 3]")
+    a_s, _ = H.order_move_rows(order, a, None, scatter=False)
+    assert_equal(a_s, a[want], "gather along the order")
+
+
+def test_spatial_order_degenerate_inputs(dev):
+    from nr3d_lib_amd import _hip as H
+    x = torch.zeros(1000, 3, device=dev)                                         # zero extent in every dimension
+    order = H.spatial_order(x, 8)
+    assert_equal(order, torch.arange(1000, device=dev, dtype=torch.int32), "all keys equal: identity")
+    x = torch.rand(4096, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    x[7, 1] = float("nan"); x[9, 0] = float("inf")                              # ignored by the bounds, clamped by the key
+    order = H.spatial_order(x, 8)
+    assert_equal(torch.sort(order).values, torch.arange(4096, device=dev, dtype=torch.int32), "order is a permutation")
+    assert H.spatial_order(torch.empty(0, 3, device=dev), 8).numel() == 0
+
+
+def test_spatial_order_of_the_rendered_samples_changes_nothing_but_the_summation_order(dev, monkeypatch):
+    """the driver with the rendered samples in Morton order (round 5) against the reference's ray order: the volume buffer is the
+    same bit for bit (the field is evaluated point by point), every gradient within the parity tolerance"""
+    from nr3d_lib_amd.graphics.nerf import composite_packed_volume_buffer, nerf_ray_query_march_occ
+    from nr3d_lib_amd.graphics.nerf import nerf_ray_query as drv
+    model, rays, occ, step = _scene(dev, side=96, seed=5)
+    n = rays["num_rays"]
+    rays["rays_o"].requires_grad_(False)
+    res = {}
+    for bits in (0, 8):
+        monkeypatch.setattr(drv, "SPATIAL_ORDER_BITS", bits)
+        monkeypatch.setattr(drv, "SPATIAL_ORDER_MIN_SAMPLES", 1)
+        model.zero_grad(set_to_none=True)
+        vb, det = nerf_ray_query_march_occ(model, rays, with_rgb=True, compression=True)
+        out = composite_packed_volume_buffer(vb, n)
+        (out["rgb_volume"].mean() + out["depth_volume"].mean()).backward()
+        res[bits] = (vb, out, {k: p.grad.clone() for k, p in model.named_parameters()})
+    a, b = res[0], res[8]
+    assert a[0]["sigma"].shape[0] > 20000
+    for k in ("sigma", "rgb", "opacity_alpha", "t", "deltas"):
+        assert_equal(b[0][k], a[0][k], k)
+    for k in ("mask_volume", "depth_volume", "rgb_volume"):
+        assert_equal(b[1][k], a[1][k], k)
+    for k in a[2]:
+        # the table gradient accumulates in fp64 / fixed point (order independent up to the last rounding); the decoders' weight
+        # gradients are fp32 sums over all samples, whose order changes with the samples'
+        assert_close(b[2][k], a[2][k].cpu().numpy(), rel=1e-5 if k == "grid" else 2e-4, name=f"grad {k}")

@@ -50,7 +50,7 @@ def assert_close(got, want, rel=REL_TOL, name="", levels=None):
 
 def assert_equal(got, want, name=""):
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
-    want = np.asarray(want)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
     assert got.shape == want.shape, f"{name}: shape {got.shape} vs {want.shape}"
     assert np.array_equal(got, want), f"{name}: {int((got != want).sum())} of {want.size} entries differ"
 
