@@ -546,16 +546,17 @@ def forest_lotd_rate(dev, log2n=20, iters=20, by_block=False):
                 mpoints_per_s=round(n / ms / 1e3, 2))
 
 
-def mlp_decoder_rate(dev, log2n=22, iters=20):
-    """SURVEY 8f rank 4 (second half) as an extra figure: the fused decoder 32 -> 64 -> 64 -> 16 (ReLU) on 2^22 samples,
+def mlp_decoder_rate(dev, log2n=22, iters=20, dims=(32, 64, 64, 16), with_torch=True):
+    """SURVEY 8f rank 4 (second half) as an extra figure: the fused decoder 32 -> 64 -> 64 -> 16 (ReLU) on 2^22 samples
+    (`dims` = (64, 64, 64, 64): the widest shape the blocks take, every tile count 2),
     forward and backward (dL/dx + all dL/dW, dL/db; forward recomputed inside), against the layer-by-layer PyTorch path.
     Roofline: the f32 MFMA (157.3 TFLOP/s dense; MI355X_MICROARCH.md), FLOPs counted on the UNPADDED layer shapes."""
     from nr3d_lib_amd.models.blocks import MLP
     from nr3d_lib_amd.models.blocks import mlp as mlp_mod
-    dims = [32, 64, 64, 16]
+    dims = list(dims)
     n = 1 << log2n
     torch.manual_seed(0)
-    net = MLP(dims[0], dims[-1], D=2, W=64, dtype=torch.float, device=dev)
+    net = MLP(dims[0], dims[-1], D=len(dims) - 2, W=dims[1], dtype=torch.float, device=dev)
     x = torch.randn(n, dims[0], device=dev)
     gy = torch.randn(n, dims[-1], device=dev)
     mac = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
@@ -579,6 +580,9 @@ def mlp_decoder_rate(dev, log2n=22, iters=20):
         net(xr).backward(gy)
     out = {}
     for name, fused in (("fused", True), ("torch", False)):
+        if not fused and not with_torch:
+            out[name] = None
+            continue
         mlp_mod.USE_FUSED = fused
         try:
             out[name] = dict(fwd_ms=round(timed(fwd), 4), fwd_bwd_ms=round(timed(fwd_bwd), 4))
@@ -589,7 +593,7 @@ def mlp_decoder_rate(dev, log2n=22, iters=20):
     half = {}
     try:
         torch.manual_seed(0)
-        net_h = MLP(dims[0], dims[-1], D=2, W=64, dtype=torch.half, device=dev)
+        net_h = MLP(dims[0], dims[-1], D=len(dims) - 2, W=dims[1], dtype=torch.half, device=dev)
         xh, gyh = x.half(), gy.half()
 
         def fwd_h():
@@ -601,6 +605,8 @@ def mlp_decoder_rate(dev, log2n=22, iters=20):
             net_h.zero_grad(set_to_none=True)
             net_h(xr).backward(gyh)
         for name, fused in (("fused", True), ("torch_autocast", False)):
+            if not fused and not with_torch:
+                continue
             mlp_mod.USE_FUSED = fused
             try:
                 half[name] = dict(fwd_ms=round(timed(fwd_h), 4), fwd_bwd_ms=round(timed(fwd_bwd_h), 4))
@@ -1055,6 +1061,7 @@ def main():
                              ("lotd_half_params", lambda: lotd_half_rate(dev)),
                              ("lotd_second_order", lambda: lotd_second_order_rate(dev)),
                              ("mlp_decoder", lambda: mlp_decoder_rate(dev)),
+                             ("mlp_decoder_64", lambda: mlp_decoder_rate(dev, dims=(64, 64, 64, 64), with_torch=False)),
                              ("c4_mixed_lotd", c4_mixed_rate),
                              ("lotd_2p24_points", lambda: lotd_large_batch_rate(24)),
                              ("reference_workloads", lambda: reference_workloads(dev))):

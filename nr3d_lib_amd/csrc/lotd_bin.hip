@@ -51,7 +51,7 @@ constexpr int kBinLdsDyn = NR3D_BIN_LDS_KB * 1024 + (int)(kMaxBuckets + 1) * 4; 
 		else if (_d == 3 && _g == 8) { constexpr int D = 3, G = 8; __VA_ARGS__; }    \
 		else if (_d == 4 && _g == 2) { constexpr int D = 4, G = 2; __VA_ARGS__; }    \
 		else if (_d == 4 && _g == 4) { constexpr int D = 4, G = 4; __VA_ARGS__; }    \
-		else { constexpr int D = 4, G = 8; __VA_ARGS__; }                            \
+		else return ::nr3d::fail("LoTD::bwd (binned): 4-D pseudo levels of 8 features run as their width-4 regrouping (stage_a_meta)"); \
 	} while (0)
 
 // Record classes: NR = capacity in records per (point, pseudo level).  Updates that hit the same table entry from
@@ -1692,12 +1692,38 @@ static bool layout(const nr3d_lotd_meta_t *m, uint32_t n_chunk, uint32_t n_batch
 	return true;
 }
 
+// A stage-A thread keeps NR record slots of (1 + G) words: with 8-feature pseudo levels the 16-corner classes of 4-D metas (NR = 32)
+// and the per-corner classes of a forest (NR = 48) do not fit the register file -- round 4 shipped k_bin<4, 8, ., 32> with 548-660
+// and k_bin_forest<8, ., 48, __half> with 459-490 spilled dwords.  Such a meta runs as its width-4 regrouping (every pseudo level
+// split into two of four features that write the same columns and table entries: ABI 2's map_col / map_cnt), whose kernels do not
+// spill; the wide instantiations are no longer built.  The narrowed meta needs its own device copy: kStageAMetaBytes at the end of
+// the workspace.
+constexpr uint64_t kStageAMetaBytes = 4096;
+static_assert(sizeof(nr3d_lotd_meta_t) <= kStageAMetaBytes, "room for the narrowed meta's device copy");
+static bool stage_a_meta(const nr3d_lotd_meta_t *m, bool forest, nr3d_lotd_meta_t &out) {
+	if (m->n_feat_per_pseudo_lvl != 8 || !(forest || m->n_dims_to_encode == 4) || 2u * m->n_pseudo_levels > NR3D_LOTD_MAX_PSEUDO) return false;
+	out = *m;
+	out.n_feat_per_pseudo_lvl = 4;
+	out.n_pseudo_levels = 2u * m->n_pseudo_levels;
+	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q)
+		for (uint32_t j = 0; j < 2u; ++j) {
+			out.map_levels[2 * q + j] = m->map_levels[q];
+			out.map_cnt[2 * q + j] = (uint16_t)(2u * m->map_cnt[q] + j);
+			out.map_col[2 * q + j] = (uint16_t)(m->map_col[q] + 4u * j);
+		}
+	return true;
+}
+
 // returns 0 when the binned path does not apply (caller falls back to the atomic kernels)
 uint64_t dparam_workspace_bytes(const nr3d_lotd_meta_t *m, uint32_t n_points, uint32_t n_batches, bool forest) {
-	if (!m || n_points == 0 || !binnable(m, forest)) return 0;
+	if (!m || n_points == 0) return 0;
+	nr3d_lotd_meta_t narrow;
+	const bool narrowed = stage_a_meta(m, forest, narrow);
+	if (narrowed) m = &narrow;
+	if (!binnable(m, forest)) return 0;
 	BinLayout lay;
 	if (!layout(m, chunk_points(n_points), n_batches, lay, forest)) return 0;
-	return lay.total;
+	return lay.total + (narrowed ? kStageAMetaBytes : 0);
 }
 
 // NR3D_OPT_VM_SPLIT = 0: VM levels through the one-thread-per-point stage A (A/B, cross-check)
@@ -1843,9 +1869,17 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	handled = false;
 	BinLayout lay;
 	const uint32_t nc = chunk_points(N);
+	nr3d_lotd_meta_t narrow;
+	const bool narrowed = workspace && stage_a_meta(meta, forest != nullptr, narrow);
+	if (narrowed) meta = &narrow;
 	if (!workspace || !binnable(meta, forest != nullptr) || !layout(meta, nc, n_batches, lay, forest != nullptr)) return 0;
-	if (workspace_bytes < lay.total) return 0;
+	if (workspace_bytes < lay.total + (narrowed ? kStageAMetaBytes : 0)) return 0;
 	handled = true;
+	if (narrowed) {
+		// (pageable source: the runtime stages the 2.6 KB before it returns, `narrow` may go out of scope)
+		NR3D_HIP_CHECK(hipMemcpyAsync((char *)workspace + lay.total, &narrow, sizeof(narrow), hipMemcpyHostToDevice, st));
+		meta_dev = (char *)workspace + lay.total;
+	}
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;
 	const uint32_t D = meta->n_dims_to_encode, G = meta->n_feat_per_pseudo_lvl, E = meta->n_encoded_dims;
 	uint32_t *rec = (uint32_t *)workspace;
@@ -2052,7 +2086,8 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 #define NR3D_FOREST_CLASS(G_, NR_) rc = launch_class<3, G_, NR_, true>(second, pl, meta, md, n, max_level, xc, vc, gc, sn, se, params, p_half, ba, rec, offs, plan_buf, partial, dparam, st, forest)
 #define NR3D_FOREST_G(G_) do { if (cls == 8) NR3D_FOREST_CLASS(G_, 8); else if (cls == 24) NR3D_FOREST_CLASS(G_, 24); \
 	else if (cls == 48) NR3D_FOREST_CLASS(G_, 48); } while (0)
-				if (G == 2) NR3D_FOREST_G(2); else if (G == 4) NR3D_FOREST_G(4); else NR3D_FOREST_G(8);
+				if (G == 2) NR3D_FOREST_G(2); else if (G == 4) NR3D_FOREST_G(4);
+				else return ::nr3d::fail("LoTD forest bwd (binned): pseudo levels of 8 features run as their width-4 regrouping (stage_a_meta)");
 #undef NR3D_FOREST_G
 #undef NR3D_FOREST_CLASS
 				if (rc) return rc;

@@ -23,6 +23,12 @@
 #include "common.h"
 #include <type_traits>
 
+// 1: streaming (non-temporal) row loads / stores as in rounds 3-4; 0: plain (see mlp_half.hip: the 16-byte pieces of a row arrive over
+// four instructions, L1 / L2 serve the re-touches of a line only for plain accesses)
+#ifndef NR3D_MLP_NT
+#define NR3D_MLP_NT 0
+#endif
+
 namespace nr3d {
 namespace mlp {
 
@@ -168,7 +174,7 @@ __device__ __forceinline__ void load_rows(const float *__restrict__ p, int64_t s
 			f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
 			if (valid && f < dim) {
 				const float *src = p + (int64_t)row * stride + f;
-				if (vec && f + 3 < dim) v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(src));
+				if (vec && f + 3 < dim) v = NR3D_MLP_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(src)) : *reinterpret_cast<const f4v *>(src);
 				else {
 #pragma unroll
 					for (int b = 0; b < 4; ++b) if (f + b < dim) v[b] = src[b];
@@ -194,7 +200,7 @@ __device__ __forceinline__ void load_rows_fast(const float *__restrict__ p, int6
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			const uint32_t f = 32u * t + 8u * q + 4u * h;
-			const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + (f < dim ? f : 0u)));
+			const f4v v = NR3D_MLP_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + (f < dim ? f : 0u))) : *reinterpret_cast<const f4v *>(base + (f < dim ? f : 0u));
 #pragma unroll
 			for (int b = 0; b < 4; ++b) r[t][4 * q + b] = v[b];
 		}
@@ -247,7 +253,7 @@ __device__ __forceinline__ void store_rows(float *__restrict__ p, int64_t stride
 			if (vec && f + 3 < dim) {
 				const f4v v = {r[t][4 * q], r[t][4 * q + 1], r[t][4 * q + 2], r[t][4 * q + 3]};
 				// (rows wider than one tile: plain stores, L2 merges the row's 16-byte pieces into whole lines -- mlp_half.hip, store_rows)
-				if (NT > 1) *reinterpret_cast<f4v *>(dst) = v; else __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst));
+				if (NT > 1 || !NR3D_MLP_NT) *reinterpret_cast<f4v *>(dst) = v; else __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst));
 			} else {
 #pragma unroll
 				for (int b = 0; b < 4; ++b) if (f + b < dim) dst[b] = r[t][4 * q + b];

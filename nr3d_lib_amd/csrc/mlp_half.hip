@@ -24,6 +24,17 @@
 #include "common.h"
 #include <type_traits>
 
+// x / dL_dy rows are fetched as 8-byte pieces, four instructions per 64-byte row, and dL/dx / y leave the same way: as streaming
+// (non-temporal) accesses every piece went to L2 / HBM on its own; as plain accesses the L1 serves the three re-touches of a line and L2
+// merges the pieces of a row (round 5, measured at 2^22 samples: 32 -> 64 -> 64 -> 16 fwd + bwd 0.739 -> 0.632 ms, 32 -> 32 -> 32 -> 16
+// 0.489 -> 0.317, 64 -> 64 -> 64 -> 64 1.53 -> 1.22; loads alone 0.645, stores alone 0.685)
+#ifndef NR3D_MLPH_NT_LOAD
+#define NR3D_MLPH_NT_LOAD 0
+#endif
+#ifndef NR3D_MLPH_NT_STORE
+#define NR3D_MLPH_NT_STORE 0
+#endif
+
 namespace nr3d {
 namespace mlph {
 
@@ -31,6 +42,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 256;
 constexpr int kMaxLds = 144 * 1024;
@@ -103,18 +116,21 @@ __device__ __forceinline__ void dense(const unsigned char *__restrict__ wp, cons
 	const int h = lane >> 5;
 	const h8 *wv = reinterpret_cast<const h8 *>(wp) + lane;
 	constexpr bool SPLIT = (NO == 1);                  // one out tile: two accumulators over alternating steps (no dependent MFMA pair)
-	f16v alt;
+	// (round 5) the kernels around this are VALU bound -- ~1800 vector instructions per tile of 32 samples against 48 MFMAs -- so: an
+	// accumulator that starts at zero takes the constant as the first MFMA's C operand instead of 16 moves, and the activation is
+	// ONE wave-uniform branch around 16 v_max per tile instead of a select per element on the runtime code
+	const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+	f16v alt = zero;
+	if (BIAS) {
 #pragma unroll
-	for (int j = 0; j < 16; ++j) alt[j] = 0.0f;
+		for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
-	for (int ot = 0; ot < NO; ++ot)
+			for (int q = 0; q < 4; ++q) {
+				const f4v b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
 #pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			f4v b4 = {0.0f, 0.0f, 0.0f, 0.0f};
-			if (BIAS) b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
-#pragma unroll
-			for (int b = 0; b < 4; ++b) out[ot][4 * q + b] = b4[b];
-		}
+				for (int b = 0; b < 4; ++b) out[ot][4 * q + b] = b4[b];
+			}
+	}
 #pragma unroll
 	for (int it = 0; it < NI; ++it)
 #pragma unroll
@@ -122,18 +138,25 @@ __device__ __forceinline__ void dense(const unsigned char *__restrict__ wp, cons
 			h8 w8[NO];
 #pragma unroll
 			for (int ot = 0; ot < NO; ++ot) w8[ot] = wv[((ot * NI + it) * 2 + s) * 64];
+			const bool first = !BIAS && it == 0 && s == 0;          // compile time after unrolling
 			if constexpr (SPLIT) {
-				if (s & 1) alt = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8[0], in[it][s], alt, 0, 0, 0);
-				else out[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8[0], in[it][s], out[0], 0, 0, 0);
+				if (s & 1) alt = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8[0], in[it][s], (it == 0) ? zero : alt, 0, 0, 0);
+				else out[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8[0], in[it][s], first ? zero : out[0], 0, 0, 0);
 			} else {
 #pragma unroll
-				for (int ot = 0; ot < NO; ++ot) out[ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8[ot], in[it][s], out[ot], 0, 0, 0);
+				for (int ot = 0; ot < NO; ++ot) out[ot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8[ot], in[it][s], first ? zero : out[ot], 0, 0, 0);
 			}
 		}
+	if constexpr (SPLIT) {
 #pragma unroll
-	for (int ot = 0; ot < NO; ++ot)
+		for (int j = 0; j < 16; ++j) out[0][j] += alt[j];
+	}
+	if (act == NR3D_MLP_ACT_RELU) {
 #pragma unroll
-		for (int j = 0; j < 16; ++j) out[ot][j] = activate(SPLIT ? out[ot][j] + alt[j] : out[ot][j], act);
+		for (int ot = 0; ot < NO; ++ot)
+#pragma unroll
+			for (int j = 0; j < 16; ++j) out[ot][j] = fmaxf(out[ot][j], 0.0f);
+	}
 }
 
 // accumulators -> the next layer's B operands: step s = registers 8 s .. 8 s + 7, rounded to half (round to nearest even)
@@ -144,8 +167,33 @@ __device__ __forceinline__ void to_operand(const f16v (&acc)[NT], h8 (&op)[NT][2
 #pragma unroll
 		for (int s = 0; s < 2; ++s)
 #pragma unroll
-			for (int e = 0; e < 8; ++e) op[t][s][e] = (_Float16)acc[t][8 * s + e];
+			for (int e = 0; e < 8; e += 2) {
+				const f2v v = {acc[t][8 * s + e], acc[t][8 * s + e + 1]};
+				const h2 p = __builtin_convertvector(v, h2);              // one v_cvt_pk_f16_f32 (was two conversions and a v_perm)
+				op[t][s][e] = p[0]; op[t][s][e + 1] = p[1];
+			}
 }
+
+// sum of the eight halfs of an operand in fp32: four v_dot2 against (1, 1) (was eight conversions and eight adds)
+__device__ __forceinline__ float sum8(const h8 &v, float acc) {
+	const h2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+	for (int e = 0; e < 8; e += 2) {
+		const h2 p = {v[e], v[e + 1]};
+		acc = __builtin_amdgcn_fdot2(p, ones, acc, false);
+	}
+	return acc;
+}
+
+// ReLU derivative as a bit mask on the operand form: 0xFFFF where the (non-negative) activation is not zero -- two packed integer
+// instructions per pair of values, and an AND per pair to apply it to a gradient that has already been rounded to half (the
+// bit-per-value form costs three instructions to build and three to apply, per value)
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ us8 relu_mask(const h8 &act) {
+	const us8 one = {1, 1, 1, 1, 1, 1, 1, 1}, all = {0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF};
+	return __builtin_elementwise_min(__builtin_bit_cast(us8, act), one) * all;
+}
+__device__ __forceinline__ h8 apply_mask(const h8 &g, const us8 &m) { return __builtin_bit_cast(h8, (us8)(__builtin_bit_cast(us8, g) & m)); }
 
 // rows of a half [n, dim] matrix straight into operand form: lane (sample, h) owns features 32 t + 8 q + 4 h + b = register
 // r = 4 q + b of tile t, i.e. element (q & 1) * 4 + b of step q >> 1
@@ -183,7 +231,7 @@ __device__ __forceinline__ void load_rows_fast(const __half *__restrict__ p, int
 #pragma unroll
 		for (int q = 0; q < 4; ++q) {
 			const uint32_t f = 32u * t + 8u * q + 4u * h;
-			const h4 v = __builtin_nontemporal_load(reinterpret_cast<const h4 *>(base + (f < dim ? f : 0u)));
+			const h4 v = NR3D_MLPH_NT_LOAD ? __builtin_nontemporal_load(reinterpret_cast<const h4 *>(base + (f < dim ? f : 0u))) : *reinterpret_cast<const h4 *>(base + (f < dim ? f : 0u));
 #pragma unroll
 			for (int b = 0; b < 4; ++b) r[t][q >> 1][(q & 1) * 4 + b] = v[b];
 		}
@@ -215,11 +263,13 @@ __device__ __forceinline__ void store_rows(__half *__restrict__ p, int64_t strid
 			const uint32_t f = 32u * t + 8u * q + 4u * h;
 			if (f >= dim) continue;
 			_Float16 *dst = reinterpret_cast<_Float16 *>(p) + (int64_t)row * stride + f;
-			const h4 v = {(_Float16)r[t][4 * q], (_Float16)r[t][4 * q + 1], (_Float16)r[t][4 * q + 2], (_Float16)r[t][4 * q + 3]};
+			const f2v lo2 = {r[t][4 * q], r[t][4 * q + 1]}, hi2 = {r[t][4 * q + 2], r[t][4 * q + 3]};
+			const h2 pl = __builtin_convertvector(lo2, h2), ph = __builtin_convertvector(hi2, h2);
+			const h4 v = {pl[0], pl[1], ph[0], ph[1]};
 			// rows wider than one tile (NT > 1): a lane's 8-byte pieces of a 128-byte row arrive over eight instructions -- as streaming
 			// (non-temporal) stores each piece went to HBM as a partial sector write (32 -> 64 -> 64 -> 64 forward: 1.15 ms for 0.54 GB of
 			// output); as plain stores L2 merges them into whole lines first
-			if (vec && f + 3 < dim) { if (NT > 1) *reinterpret_cast<h4 *>(dst) = v; else __builtin_nontemporal_store(v, reinterpret_cast<h4 *>(dst)); }
+			if (vec && f + 3 < dim) { if (NT > 1 || !NR3D_MLPH_NT_STORE) *reinterpret_cast<h4 *>(dst) = v; else __builtin_nontemporal_store(v, reinterpret_cast<h4 *>(dst)); }
 			else {
 #pragma unroll
 				for (int b = 0; b < 4; ++b) if (f + b < dim) dst[b] = v[b];
@@ -365,10 +415,7 @@ __device__ __forceinline__ void bwd_layer(const h8 (&g)[NO][2], _Float16 *__rest
 #pragma unroll
 		for (int st = 0; st < 2; ++st) {
 			const h8 av = read_op(TG, 32 * ot + r, st, h);
-			float sum = 0.0f;
-#pragma unroll
-			for (int e = 0; e < 8; ++e) sum += (float)av[e];
-			db[ot] += sum;
+			db[ot] = sum8(av, db[ot]);
 #pragma unroll
 			for (int it = 0; it < NI; ++it) dW[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[it][st], dW[ot][it], 0, 0, 0);
 		}
@@ -568,6 +615,213 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T>::kMaxWaves * 64)) void k_
 	reduce_layer<OUT_T, W_T>(dWo, dbo, R, a.dW[NH], a.db[NH], a.dims[NH + 1], a.dims[NH], lane, wave, nw);
 }
 
+
+// =============================================================================================
+// backward, dW SPLIT over the waves of the workgroup (round 5; the 64-wide hidden layers)
+// =============================================================================================
+// k_mlph_bwd keeps every layer's whole dW in each wave's accumulators over all of its tiles: 128 registers for 32 -> 64 -> 64 -> 16,
+// 192 for 64 -> 64 -> 64 -> 64 -- one wave per SIMD with nothing to hide its chain of LDS round trips and dependent MFMAs behind
+// (0.138 of HBM), and 127-189 spilled dwords for every shape with a 64-wide input or output (64 -> 64 -> 64 -> 64 backward: 2.9 ms
+// where its FLOPs say 1.0).  But dW = sum over (tile, K step) of dPre^T . H, and any partition of those terms over the waves is
+// as good as "a wave's own tiles": both operands already pass through LDS as [feature][sample] tiles.  Here the NW waves of a
+// workgroup run their chains (forward, dL/dx) on their own tiles in lockstep rounds, and for the sample contraction wave w takes
+// ONE 32 x 32 block of every layer's dW -- block w % NB of the layer's NB = NO x NI blocks -- over its share of the round's 2 NW
+// (K step, tile) pairs, reading the other waves' tiles: 16 accumulator registers per layer instead of 16 NB, the same number of
+// MFMAs per wave, two workgroup barriers per layer and round (tiles written / tiles free again).  The registers that frees let
+// EIGHT waves share a CU where LDS allows (32 -> 64 -> 64 -> 16: 34 KB of weights + 8 x 15 KB of tiles).
+template <int NO, int NI, int NW>
+struct DwSplit {
+	static constexpr int NB = NO * NI, G = NW / NB;          // blocks of the layer; waves per block
+	static_assert(NB >= 1 && NW % NB == 0, "the blocks of a layer divide the waves of the workgroup");
+};
+
+// this wave's share of one layer's sample contraction for the round: block b = wave % NB (ot = b / NI, it = b % NI), the
+// (step, tile) pairs p = G k + wave / NB.  TG_off / TB_off: offsets of the layer's dPre / input tiles inside a wave's tile area.
+template <int NO, int NI, int NW>
+__device__ __forceinline__ void dw_round(const _Float16 *__restrict__ tiles0, uint32_t tile_halfs, uint32_t TG_off, uint32_t TB_off,
+                                         f16v &dW, float &db, int wave, int lane) {
+	using S = DwSplit<NO, NI, NW>;
+	const int b = wave % S::NB, sub = wave / S::NB, ot = b / NI, it = b % NI;
+	const int r = lane & 31, h = lane >> 5;
+	h8 av[2 * S::NB], bv[2 * S::NB];
+#pragma unroll
+	for (int k = 0; k < 2 * S::NB; ++k) {
+		const int p = S::G * k + sub, st = p / NW, t = p % NW;
+		const _Float16 *T = tiles0 + (size_t)t * tile_halfs;
+		av[k] = read_op(T + TG_off, 32 * ot + r, st, h);
+		bv[k] = read_op(T + TB_off, 32 * it + r, st, h);
+	}
+	float sum = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 2 * S::NB; ++k) {
+		if (it == 0) sum = sum8(av[k], sum);                 // (wave uniform) one wave group per out tile carries the bias gradient
+		dW = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[k], bv[k], dW, 0, 0, 0);
+	}
+	db += sum;
+}
+
+// the workgroup's gradient of one layer: the G waves of a block add their accumulators in LDS one after the other, then one atomic
+// per element (element order of R as in reduce_layer)
+template <int NO, int NI, int NW>
+__device__ __forceinline__ void reduce_split(const f16v &dW, float db, float *__restrict__ R, float *gW, float *gb, uint32_t out_dim,
+                                             uint32_t in_dim, int lane, int wave) {
+	using S = DwSplit<NO, NI, NW>;
+	const int b = wave % S::NB, sub = wave / S::NB, ot = b / NI, it = b % NI;
+	float *Rb = R + S::NB * 1024;
+	for (int g = 0; g < S::G; ++g) {
+		if (sub == g) {
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				const int e = ((b * 16 + j) << 6) + lane;
+				R[e] = (g == 0 ? 0.0f : R[e]) + dW[j];
+			}
+			if (it == 0) Rb[ot * 64 + lane] = (g == 0 ? 0.0f : Rb[ot * 64 + lane]) + db;
+		}
+		__syncthreads();
+	}
+	for (uint32_t e = threadIdx.x; e < (uint32_t)(S::NB * 1024); e += blockDim.x) {
+		const uint32_t ln = e & 63u, j = (e >> 6) & 15u, bi = (e >> 10) % NI, bo = (e >> 10) / NI;
+		const uint32_t k = 32u * bi + (ln & 31u), o = 32u * bo + 8u * (j >> 2) + 4u * (ln >> 5) + (j & 3u);
+		if (o < out_dim && k < in_dim) atomic_add_f32(gW + (size_t)o * in_dim + k, R[e]);
+	}
+	if (gb)
+		for (uint32_t e = threadIdx.x; e < (uint32_t)(NO * 32); e += blockDim.x)
+			if (e < out_dim) atomic_add_f32(gb + e, Rb[(e >> 5) * 64 + (e & 31u)] + Rb[(e >> 5) * 64 + 32 + (e & 31u)]);
+	__syncthreads();
+}
+
+// dL/d(pre-activation of the layer below) in operand form = half(W^T . dPre), masked by the ReLU mask of that layer's output
+template <int NO, int NI>
+__device__ __forceinline__ void dx_layer(const h8 (&g)[NO][2], const unsigned char *__restrict__ wT, h8 (&gop)[NI][2], const us8 (&mask)[NI][2],
+                                         bool relu, int lane) {
+	f16v gp[NI];
+	dense<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);
+	to_operand<NI>(gp, gop);
+	if (relu) {
+#pragma unroll
+		for (int t = 0; t < NI; ++t) { gop[t][0] = apply_mask(gop[t][0], mask[t][0]); gop[t][1] = apply_mask(gop[t][1], mask[t][1]); }
+	}
+}
+
+template <int IN_T, int W_T, int OUT_T, int NH, int FAST, int NW>
+__global__ __launch_bounds__(NW * 64) void k_mlph_bwd_split(BwdArgs a) {
+	static_assert(W_T == 2 && NH >= 1 && NH <= 2, "the shapes whose dW does not fit one wave: 64-wide hidden layers");
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	stage_weights(a.packed, a.total_bytes, lds);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int r = lane & 31;
+	_Float16 *tiles0 = reinterpret_cast<_Float16 *>(lds + a.total_bytes);
+	_Float16 *mine = tiles0 + (size_t)wave * a.tile_halfs;
+	// tile rows of a wave: X | H_1 .. H_NH | G_out (dPre of hidden layer l + 1 overwrites H_{l+1}, whose readers are done by then)
+	constexpr uint32_t oX = 0, oH1 = 32 * IN_T * kTSH, szH = 32 * W_T * kTSH, oGO = oH1 + NH * szH;
+	constexpr uint32_t f0 = layer_bytes(IN_T, W_T), fh = layer_bytes(W_T, W_T), fo = layer_bytes(W_T, OUT_T);
+	constexpr uint32_t t0 = layer_bytes(W_T, IN_T), th = fh, fwd_total = f0 + (NH - 1) * fh + fo;
+
+	f16v dW0, dWh, dWo;                                  // ONE block of every layer (dWh unused for NH == 1)
+	float db0 = 0.0f, dbh = 0.0f, dbo = 0.0f;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) { dW0[j] = 0.0f; dWh[j] = 0.0f; dWo[j] = 0.0f; }
+
+	const uint64_t n_tiles = (a.n + 31) / 32, per_round = (uint64_t)gridDim.x * NW;
+	const uint64_t n_rounds = (n_tiles + per_round - 1) / per_round;                 // the same for every wave: the barriers below
+	auto clamp_row = [&](uint64_t row) { return row < a.n ? row : a.n - 1; };
+	h8 xnext[IN_T][2], gnext[OUT_T][2];
+	if (FAST) {
+		const uint64_t r0 = clamp_row(((uint64_t)blockIdx.x * NW + wave) * 32 + r);
+		prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], r0, lane, xnext);
+		load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], r0, lane, gnext);
+	}
+	const h8 hzero = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+	const bool relu = a.hidden_act == NR3D_MLP_ACT_RELU;
+	for (uint64_t round = 0; round < n_rounds; ++round) {
+		const uint64_t tile = round * per_round + (uint64_t)blockIdx.x * NW + wave;
+		const uint64_t row = tile * 32 + r;
+		const bool valid = row < a.n;                      // a tile past the end runs on clamped rows with dL/dy = 0: it adds zeros
+		uint32_t opaque;                                   // (no hoisting of the weight fragments out of the loop: see k_mlph_bwd)
+		asm volatile("s_mov_b32 %0, 0" : "=s"(opaque));
+		const unsigned char *wf = lds + opaque, *wt = wf + fwd_total;
+		h8 xin[IN_T][2], g_out[OUT_T][2], hop[W_T][2];
+		f16v hacc[W_T];
+		us8 hmask[NH][W_T][2];
+		if (FAST) {
+#pragma unroll
+			for (int t = 0; t < IN_T; ++t) { xin[t][0] = xnext[t][0]; xin[t][1] = xnext[t][1]; }
+#pragma unroll
+			for (int t = 0; t < OUT_T; ++t) { g_out[t][0] = gnext[t][0]; g_out[t][1] = gnext[t][1]; }
+			const uint64_t rn = clamp_row((tile + per_round) * 32 + r);
+			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
+			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
+			if (!valid) {
+#pragma unroll
+				for (int t = 0; t < OUT_T; ++t) { g_out[t][0] = hzero; g_out[t][1] = hzero; }
+			}
+		} else {
+			if (a.x_fm) load_cols_fast<IN_T>(a.x, a.xs, a.dims[0], clamp_row(row), lane, xin);
+			else load_rows<IN_T>(a.x, a.xs, a.dims[0], clamp_row(row), true, a.x_vec != 0, lane, xin);
+			load_rows<OUT_T>(a.gy, a.gys, a.dims[NH + 1], row, valid, a.gy_vec != 0, lane, g_out);
+		}
+		// ---- forward on the wave's own tile: activations to LDS as [feature][sample], their signs as one word per layer ----
+		write_tile<IN_T>(mine + oX, xin, lane);
+		dense<IN_T, W_T, true>(wf, xin, hacc, a.hidden_act, lane);
+		to_operand<W_T>(hacc, hop);
+		write_tile<W_T>(mine + oH1, hop, lane);
+		auto signs = [&](us8 (&m)[W_T][2]) {
+#pragma unroll
+			for (int t = 0; t < W_T; ++t) { m[t][0] = relu_mask(hop[t][0]); m[t][1] = relu_mask(hop[t][1]); }
+		};
+		signs(hmask[0]);
+		if constexpr (NH == 2) {
+			h8 hin[W_T][2];
+#pragma unroll
+			for (int t = 0; t < W_T; ++t) { hin[t][0] = hop[t][0]; hin[t][1] = hop[t][1]; }
+			dense<W_T, W_T, true>(wf + f0, hin, hacc, a.hidden_act, lane);
+			to_operand<W_T>(hacc, hop);
+			write_tile<W_T>(mine + oH1 + szH, hop, lane);
+			signs(hmask[1]);
+		}
+		if (a.out_act == NR3D_MLP_ACT_RELU) {
+			f16v yo[OUT_T];
+			dense<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hop, yo, NR3D_MLP_ACT_NONE, lane);
+#pragma unroll
+			for (int t = 0; t < OUT_T; ++t)
+#pragma unroll
+				for (int j = 0; j < 16; ++j) if (!(yo[t][j] > 0.0f)) g_out[t][j >> 3][j & 7] = (_Float16)0.0f;
+		}
+		// ---- output layer ----
+		write_tile<OUT_T>(mine + oGO, g_out, lane);
+		__syncthreads();                                   // every wave's G_out, H and X tiles are in LDS
+		dw_round<OUT_T, W_T, NW>(tiles0, a.tile_halfs, oGO, oH1 + (NH - 1) * szH, dWo, dbo, wave, lane);
+		h8 gop[W_T][2];
+		dx_layer<OUT_T, W_T>(g_out, wt + t0 + (NH - 1) * th, gop, hmask[NH - 1], relu, lane);
+		__syncthreads();                                   // H_NH has been read by everyone: its rows take dPre of the layer below
+		if constexpr (NH == 2) {
+			write_tile<W_T>(mine + oH1 + szH, gop, lane);
+			__syncthreads();
+			dw_round<W_T, W_T, NW>(tiles0, a.tile_halfs, oH1 + szH, oH1, dWh, dbh, wave, lane);
+			h8 gin[W_T][2];
+#pragma unroll
+			for (int t = 0; t < W_T; ++t) { gin[t][0] = gop[t][0]; gin[t][1] = gop[t][1]; }
+			dx_layer<W_T, W_T>(gin, wt + t0, gop, hmask[0], relu, lane);
+			__syncthreads();
+		}
+		// ---- first layer ----
+		write_tile<W_T>(mine + oH1, gop, lane);
+		__syncthreads();
+		dw_round<W_T, IN_T, NW>(tiles0, a.tile_halfs, oH1, oX, dW0, db0, wave, lane);
+		if (a.gx) {
+			f16v gx[IN_T];
+			dense<W_T, IN_T, false>(wt, gop, gx, NR3D_MLP_ACT_NONE, lane);
+			if (a.gx_fm) store_cols<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, lane, gx);
+			else store_rows<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, a.gx_vec != 0, lane, gx);
+		}
+		__syncthreads();                                   // X and H_1 are free for the next round
+	}
+	float *R = reinterpret_cast<float *>(lds + a.total_bytes);
+	reduce_split<W_T, IN_T, NW>(dW0, db0, R, a.dW[0], a.db[0], a.dims[1], a.dims[0], lane, wave);
+	if constexpr (NH == 2) reduce_split<W_T, W_T, NW>(dWh, dbh, R, a.dW[1], a.db[1], a.dims[2], a.dims[1], lane, wave);
+	reduce_split<OUT_T, W_T, NW>(dWo, dbo, R, a.dW[NH], a.db[NH], a.dims[NH + 1], a.dims[NH], lane, wave);
+}
+
 }  // namespace mlph
 }  // namespace nr3d
 
@@ -599,9 +853,26 @@ static uint32_t bwd_waves(const Shape &s) {
 	return 0;
 }
 
+// k_mlph_bwd_split: eight waves when LDS holds the weights (forward + transposed) and eight waves' tiles, else four
+static uint32_t split_waves(const Shape &s) {
+	const uint64_t wbytes = packed_bytes(s) + transposed_bytes(s);
+	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;
+	// (eight waves = 256 registers per lane: only the narrow-input, narrow-output shapes stay clear of scratch there)
+#ifdef NR3D_MLPH_FORCE_NW4
+	const uint32_t nw_first = 4;
+#else
+	const uint32_t nw_first = (s.in_t == 1 && s.out_t == 1) ? 8 : 4;
+#endif
+	for (uint32_t nw = nw_first; nw >= 4; nw -= 4) {
+		const uint64_t t = (uint64_t)nw * bwd_tile_halfs(s) * 2;
+		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)kMaxLdsBwd) return nw;
+	}
+	return 0;
+}
+
 extern "C" uint64_t nr3d_mlp_half_backward_packed_bytes(const nr3d_mlp_desc_t *desc) {
 	Shape s;
-	if (!shape_of(desc, s) || nr3d_mlp_half_packed_bytes(desc) == 0 || !backward_ok(s) || bwd_waves(s) == 0) return 0;
+	if (!shape_of(desc, s) || nr3d_mlp_half_packed_bytes(desc) == 0 || !backward_ok(s) || (s.w_t == 2 ? split_waves(s) : bwd_waves(s)) == 0) return 0;
 	return transposed_bytes(s);
 }
 
@@ -734,26 +1005,48 @@ extern "C" int nr3d_mlp_half_backward(const nr3d_mlp_desc_t *desc, uint64_t n, c
 	a.gy_vec = ((uintptr_t)dL_dy % 8 == 0 && gy_stride % 4 == 0) ? 1u : 0u;
 	a.gx_vec = (dL_dx && (uintptr_t)dL_dx % 8 == 0 && gx_stride % 4 == 0) ? 1u : 0u;
 	a.tile_halfs = bwd_tile_halfs(s);
-	const uint32_t nw = bwd_waves(s);
-	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;
-	const uint64_t tbytes = (uint64_t)nw * a.tile_halfs * 2;
-	const size_t lds = (size_t)a.total_bytes + (size_t)(tbytes > reduce ? tbytes : reduce);
-	const uint64_t n_tiles = (n + 31) / 32;
-	const uint32_t grid = (uint32_t)(n_tiles / nw + 1 < 256 ? n_tiles / nw + 1 : 256);     // one workgroup per CU: dW lives in registers
 	const uint32_t nh = desc->n_layers - 1;
 	const bool gy_fast = a.gy_vec && desc->dims[desc->n_layers] % 4 == 0;
 	const int fast = !gy_fast ? 0 : x_fm ? 2 : (a.x_vec && desc->dims[0] % 4 == 0) ? 1 : 0;
+	const uint64_t n_tiles = (n + 31) / 32;
+	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;
+	int rc = 0;
+	if (s.w_t == 2) {
+		// 64-wide hidden layers: dW split over the waves of the workgroup (k_mlph_bwd_split), eight waves where LDS holds their tiles
+		const uint32_t nw = split_waves(s);
+		const uint64_t tbytes = (uint64_t)nw * a.tile_halfs * 2;
+		const size_t lds = (size_t)a.total_bytes + (size_t)(tbytes > reduce ? tbytes : reduce);
+		const uint32_t grid = (uint32_t)(n_tiles / nw + 1 < 256 ? n_tiles / nw + 1 : 256);
+		auto launch = [&](auto kern) -> int {
+			NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBwd));
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
+			return 0;
+		};
+#define SPLIT_LAUNCH(I, O, H, NW_) (fast == 2 ? launch(k_mlph_bwd_split<I, 2, O, H, 2, NW_>) : fast == 1 ? launch(k_mlph_bwd_split<I, 2, O, H, 1, NW_>) : launch(k_mlph_bwd_split<I, 2, O, H, 0, NW_>))
+#define SPLIT_CASE(I, O, H) if (s.in_t == I && s.out_t == O && nh == H) rc = SPLIT_LAUNCH(I, O, H, 4); else
+		if (s.in_t == 1 && s.out_t == 1 && nh == 1) rc = nw == 8 ? SPLIT_LAUNCH(1, 1, 1, 8) : SPLIT_LAUNCH(1, 1, 1, 4);
+		else if (s.in_t == 1 && s.out_t == 1 && nh == 2) rc = nw == 8 ? SPLIT_LAUNCH(1, 1, 2, 8) : SPLIT_LAUNCH(1, 1, 2, 4);
+		else
+		SPLIT_CASE(1, 2, 1) SPLIT_CASE(1, 2, 2) SPLIT_CASE(2, 1, 1) SPLIT_CASE(2, 1, 2) SPLIT_CASE(2, 2, 1) SPLIT_CASE(2, 2, 2)
+		rc = ::nr3d::fail("mlp_half_backward: no kernel for this shape");
+#undef SPLIT_LAUNCH
+#undef SPLIT_CASE
+		if (rc) return rc;
+		NR3D_LAUNCH_CHECK();
+		return 0;
+	}
+	const uint32_t nw = bwd_waves(s);
+	const uint64_t tbytes = (uint64_t)nw * a.tile_halfs * 2;
+	const size_t lds = (size_t)a.total_bytes + (size_t)(tbytes > reduce ? tbytes : reduce);
+	const uint32_t grid = (uint32_t)(n_tiles / nw + 1 < 256 ? n_tiles / nw + 1 : 256);     // one workgroup per CU: dW lives in registers
 	auto launch = [&](auto kern) -> int {
 		NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBwd));
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a);
 		return 0;
 	};
-	int rc = 0;
 #define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) \
 		rc = fast == 2 ? launch(k_mlph_bwd<I, W, O, H, 2>) : fast == 1 ? launch(k_mlph_bwd<I, W, O, H, 1>) : launch(k_mlph_bwd<I, W, O, H, 0>); else
 	BWD_CASE(1, 1, 1, 1) BWD_CASE(1, 1, 1, 2) BWD_CASE(1, 1, 1, 3)
-	BWD_CASE(1, 2, 1, 1) BWD_CASE(1, 2, 1, 2) BWD_CASE(1, 2, 2, 1) BWD_CASE(1, 2, 2, 2)
-	BWD_CASE(2, 2, 1, 1) BWD_CASE(2, 2, 1, 2) BWD_CASE(2, 2, 2, 1) BWD_CASE(2, 2, 2, 2)
 	rc = ::nr3d::fail("mlp_half_backward: no kernel for this shape");
 #undef BWD_CASE
 	if (rc) return rc;

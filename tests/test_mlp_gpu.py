@@ -293,7 +293,13 @@ def test_fused_block_reproduces_the_reference_modules_outputs(dev, name):
 # ------------------------------------------------------------------------------------------------------------------------
 # half precision on the f16 MFMA (csrc/mlp_half.hip): MLP(dtype=torch.half)
 # ------------------------------------------------------------------------------------------------------------------------
-HALF_CASES = CASES + [([32, 128, 128, 16], 3001, "relu", None, True), ([128, 64, 128], 515, "relu", None, True)]
+HALF_CASES = CASES + [([32, 128, 128, 16], 3001, "relu", None, True), ([128, 64, 128], 515, "relu", None, True),
+                      # round 5: 64-wide hidden layers run the backward with dW split over the waves of the workgroup (k_mlph_bwd_split):
+                      # every tile-count combination of its two-hidden-layer form, several rounds per workgroup (n > 65 536), an
+                      # input narrower than its tile, an output ReLU, no bias
+                      ([64, 64, 64, 64], 70001, "relu", None, True), ([24, 64, 64, 40], 5000, "relu", None, False),
+                      ([64, 48, 64, 8], 3000, "relu", "relu", True), ([32, 64, 64, 16], 200001, "relu", None, True),
+                      ([33, 64, 50], 66000, None, None, True)]
 
 
 def _half_reference(m, x, gy):

@@ -81,6 +81,9 @@ LOTD_CASES = {
     "cp_only_4d": (4, [5, 6], [2, 2], ["CP", "Dense"], None, False),
     "cp_4d": (4, [5, 6, 4], [2, 2, 2], ["CP", "NPlaneMul", "CPfast"], None, False),
     "nplane_4d": (4, [5, 6, 4], [2, 4, 2], ["NPlaneSum", "NPlaneMul", "Dense"], None, True),
+    # 4-D with 8-feature pseudo levels: the parameter-gradient stage A runs on the width-4 regrouping (16-corner records x 8 features
+    # do not fit the register file: lotd_bin.hip stage_a_meta)
+    "nplane_4d_f8": (4, [5, 6, 4], [8, 16, 8], ["NPlaneMul", "Hash", "Dense"], 2 ** 9, False),
 }
 
 
