@@ -528,7 +528,9 @@ int nr3d_packed_binary(uint32_t P, uint64_t S, uint32_t feat_dim, uint32_t out_d
 int nr3d_packed_searchsorted(uint32_t P, int dtype, const void *bins, const void *vals,
                              const int64_t *pack_infos, uint32_t num_to_search,
                              const int64_t *val_pack_infos, int64_t *pidx, void *stream);
-/* try_merge_two_packs_sorted_aligned (:1505-1631).  pidx_a / pidx_b ZERO-INIT. */
+/* try_merge_two_packs_sorted_aligned (:1505-1631).  The rows of the packs are fully written (ABI 5: the kernel zeroes its own
+ * counting rows); rows of pidx_a / pidx_b outside every pack keep the caller's fill -- 0 as the reference's aligned op, -1 as its
+ * merge_two_packs_sorted. */
 int nr3d_try_merge_two_packs_sorted_aligned(uint32_t P, int dtype, const void *vals_a,
                                             const int64_t *pack_infos_a, const void *vals_b,
                                             const int64_t *pack_infos_b, const int64_t *pack_infos_merged,

@@ -324,12 +324,24 @@ def mark_ordered(pack_infos, total=None):
     tag, so those take the zero-filled path.
     ``total``: the producer also knows (on the host) that the packs TILE rows [0, total) without a gap -- a marcher's sample
     count, the scalar a two-phase op read back.  Ops whose kernels write the rows of the packs only (packed_alpha_to_vw)
-    allocate `empty` outputs when the tensor they are called on has exactly that many rows (``tiles``), zeros otherwise."""
+    allocate `empty` outputs when the tensor they are called on has exactly that many rows (``tiles``), zeros otherwise.
+    LIMIT (round-4 advisor): the version counter sees in-place torch ops only.  A write through ``pack_infos.data`` or by a kernel
+    that got the raw pointer does not bump it, so the tag survives such an edit and the ops would trust a claim that no longer
+    holds (rows of other packs zeroed by the gap fill, unwritten `empty` rows).  Editing a producer's pack_infos that way is NOT
+    supported: clone it first (a clone carries no tag) or call ``clear_ordered``.  tests/test_host_logic_cpu.py pins both halves."""
     try:
         pack_infos._nr3d_ordered = pack_infos._version
         pack_infos._nr3d_total = None if total is None else int(total)
     except RuntimeError:                    # inference tensors have no version counter: untagged
         pass
+    return pack_infos
+
+
+def clear_ordered(pack_infos):
+    """drop the tag (after an edit the version counter cannot see: ``.data`` writes, raw-pointer kernels)"""
+    for a in ("_nr3d_ordered", "_nr3d_total"):
+        if hasattr(pack_infos, a):
+            delattr(pack_infos, a)
     return pack_infos
 
 

@@ -424,8 +424,10 @@ def merge_two_packs_sorted_general(vals_a, pack_infos_a, nidx_a, vals_b, pack_in
         pim = H.empty((Pu, 2), dtype=torch.int64, device=dev)
         tot = H.empty(1, dtype=torch.int64, device=dev)                       # = len(vals_a) + len(vals_b): not read back
         H.check(H.lib().nr3d_pack_infos_from_n(H.u32(Pu), H.ptr(n_u), H.ptr(pim), H.ptr(tot), H.ptr(_scan_tmp(Pu, dev)), st))
-        pa = torch.zeros(vals_a.shape[0], dtype=torch.int64, device=dev)      # the merge kernel counts into it
-        pb = torch.full((vals_b.shape[0],), -1, dtype=torch.int64, device=dev)    # (elements outside every pack: no position)
+        # elements outside every pack have no position: -1, as in the reference (the kernel zeroes the rows of its packs itself
+        # before it counts into them)
+        pa = torch.full((vals_a.shape[0],), -1, dtype=torch.int64, device=dev)
+        pb = torch.full((vals_b.shape[0],), -1, dtype=torch.int64, device=dev)
         H.check(H.lib().nr3d_try_merge_two_packs_sorted_aligned(
             H.u32(Pu), _code(vals_a), H.ptr(vals_a), H.ptr(pia_u), H.ptr(vals_b), H.ptr(pib_u), H.ptr(pim), C.c_int(1),
             H.ptr(pa), H.ptr(pb), st))

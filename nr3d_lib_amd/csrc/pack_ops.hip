@@ -383,7 +383,12 @@ __global__ __launch_bounds__(kBlock) void k_merge(uint32_t P, const T *__restric
 	const int64_t ob = pim[2 * (size_t)k.p];
 	const T *va = va_ + k.begin, *vb = vb_ + bb;
 	int64_t *pa = pa_ + k.begin, *pb = pb_ + bb;
-	// 1. lower bounds + histogram (pa is zero-initialised by the caller)
+	// 0. the histogram below counts into the pack's own rows of pa: zero them here, so that the caller can hand over a buffer
+	//    filled with -1 -- the value the reference leaves in rows that belong to no pack (round-4 advisor: a zero-filled buffer
+	//    gave such rows position 0)
+	for (uint32_t i = k.lane; i < k.len; i += 64) pa[i] = 0;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the zeros have reached L2 before any atomic of this wave
+	// 1. lower bounds + histogram
 	for (uint32_t j = k.lane; j < bl; j += 64) {
 		const uint32_t i = lower_bound<T>(vb[j], va, k.len);
 		pb[j] = (int64_t)i;
@@ -1392,6 +1397,8 @@ extern "C" int nr3d_packed_scan(uint32_t P, uint64_t S, uint32_t fd, int dtype, 
                                 const int64_t *pack_infos, int is_prod, int exclusive, int reverse, int ordered_packs,
                                 void *out, void *stream) {
 	NR3D_CHECK(P > 0 || !ordered_packs || S == 0, "packed_scan: ordered_packs needs at least one pack (no wave to zero `out`)");
+	// the gap fill works on the 32-bit pack bounds the kernels use (my_pack): past 2^32 rows it would zero the wrong ranges
+	NR3D_CHECK(!ordered_packs || (uint64_t)S < (1ull << 32), "packed_scan: ordered_packs is limited to 2^32 - 1 rows per call, got %llu", (unsigned long long)S);
 	if (P == 0) return 0;
 	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_scan<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, fd,
 	                                      (const T *)feats, pack_infos, is_prod, exclusive, reverse, S, ordered_packs, (T *)out));
@@ -1404,6 +1411,8 @@ extern "C" int nr3d_packed_diff(uint32_t P, uint64_t S, uint32_t fd, int dtype, 
                                 int ordered_packs, void *out, void *stream) {
 	NR3D_CHECK(!(edge_a && edge_fill), "You should only specify AT MOST one of [appends, prepends, last_fill, first_fill]");
 	NR3D_CHECK(P > 0 || !ordered_packs || S == 0, "packed_diff: ordered_packs needs at least one pack (no wave to zero `out`)");
+	// the gap fill works on the 32-bit pack bounds the kernels use (my_pack): past 2^32 rows it would zero the wrong ranges
+	NR3D_CHECK(!ordered_packs || (uint64_t)S < (1ull << 32), "packed_diff: ordered_packs is limited to 2^32 - 1 rows per call, got %llu", (unsigned long long)S);
 	if (P == 0) return 0;
 	PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_diff<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P, fd,
 	                                      (const T *)feats, pack_infos, (const T *)edge_a, (const T *)edge_fill, backward,
@@ -1417,6 +1426,8 @@ extern "C" int nr3d_packed_binary(uint32_t P, uint64_t S, uint32_t fd, uint32_t 
                                   void *stream) {
 	NR3D_CHECK(op >= 0 && op <= 10, "packed_binary_ops: invalid op %d", op);
 	NR3D_CHECK(P > 0 || !ordered_packs || S == 0, "packed_binary_ops: ordered_packs needs at least one pack (no wave to zero `out`)");
+	// the gap fill works on the 32-bit pack bounds the kernels use (my_pack): past 2^32 rows it would zero the wrong ranges
+	NR3D_CHECK(!ordered_packs || (uint64_t)S < (1ull << 32), "packed_binary_ops: ordered_packs is limited to 2^32 - 1 rows per call, got %llu", (unsigned long long)S);
 	if (P == 0) return 0;
 	if (op == 4) {
 		PK_DISPATCH(dtype, hipLaunchKernelGGL(pk::k_matmul<T>, pk::grid_for(P), dim3(pk::kBlock), 0, (hipStream_t)stream, P,

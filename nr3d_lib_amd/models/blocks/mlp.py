@@ -118,17 +118,24 @@ class FusedMLPHalfFunction(torch.autograd.Function):
         packed = _mlp.pack_half(desc, ws, bs, with_backward=need)
         xh = x if x.dtype == torch.float16 else x.half()
         if need:
-            ctx.save_for_backward(xh, packed, *[p for p in params if p is not None])
+            # the CALLER's x is saved, not its rounded copy: the create_graph branch of the backward differentiates through it (a
+            # detached x.half() was a fresh leaf: higher-order terms w.r.t. x never reached the caller's tensor -- round-4 advisor)
+            ctx.save_for_backward(x, packed, *[p for p in params if p is not None])
             ctx.desc, ctx.has_bias, ctx.x_dtype = desc, [b is not None for b in bs], x.dtype
         return _mlp.forward_half(desc, xh, packed)
 
     @staticmethod
     def backward(ctx, dL_dy):
         from nr3d_lib_amd.bindings import _mlp
-        xh, packed, *flat = ctx.saved_tensors
+        x, packed, *flat = ctx.saved_tensors
         n_layers = len(ctx.has_bias)
         if torch.is_grad_enabled():
-            return (None, None, *FusedMLPFunction._differentiable_backward(ctx, xh.to(ctx.x_dtype), flat, dL_dy.to(ctx.x_dtype)))
+            # differentiable form: ONE dtype for x, the (fp32) parameters and dL/dy -- F.linear(half, float) raises outside
+            # autocast; the casts are differentiable, so the graph reaches the caller's x whatever its dtype
+            out = FusedMLPFunction._differentiable_backward(ctx, x.float(), flat, dL_dy.float())
+            out[0] = None if out[0] is None else out[0].to(ctx.x_dtype)
+            return (None, None, *out)
+        xh = x if x.dtype == torch.float16 else x.half()
         dx, dWs, dbs = _mlp.backward_half(ctx.desc, xh, dL_dy.half(), packed, need_dx=ctx.needs_input_grad[2], has_bias=ctx.has_bias)
         grads = []
         for i in range(n_layers):

@@ -16,6 +16,8 @@ import json
 import os
 import sys
 
+sys.dont_write_bytecode = True     # (nothing of the reference is imported here; like every generator: no __pycache__ under /root/reference)
+
 REF = "/root/reference"
 MODS = ("_lotd", "_pack_ops", "_occ_grid")
 

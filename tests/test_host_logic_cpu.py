@@ -111,6 +111,20 @@ def test_ordered_pack_infos_tag_follows_the_tensor_version():
         assert not _hip.is_ordered(_hip.mark_ordered(t))     # no version counter: untagged, zero-filled path
 
 
+def test_ordered_tag_does_not_see_dot_data_edits():
+    """the documented LIMIT of the tag (round-4 advisor): a write through `.data` does not bump the version counter, so the tag
+    survives it -- such edits of a producer's pack_infos are unsupported; `clear_ordered` (or a clone) is the way out"""
+    from nr3d_lib_amd import _hip
+    from nr3d_lib_amd.graphics.pack_ops import get_pack_infos_from_n
+    pi = get_pack_infos_from_n(torch.tensor([4, 0, 5, 3]))
+    assert _hip.is_ordered(pi)
+    pi.data[2, 0] = 1                                  # packs overlap now; the counter has not moved
+    assert _hip.is_ordered(pi), "if this starts failing torch bumps versions on .data writes: drop the LIMIT paragraph of mark_ordered"
+    assert not _hip.is_ordered(_hip.clear_ordered(pi)) and not _hip.tiles(pi, 12)
+    assert not _hip.is_ordered(pi.clone())
+    _hip.clear_ordered(pi)                             # idempotent
+
+
 def test_lod_meta_lists_are_built_on_first_use(hiplib):
     """LoDMeta's per-level Python lists come out of the C struct lazily (the constructor is a launch-bound op of the reference's
     own test script): same values as an eager read, attribute errors stay attribute errors, copies keep working"""
