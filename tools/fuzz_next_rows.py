@@ -166,14 +166,18 @@ def fuzz_mlp_half(rng):
     bad = ((dx.double() - h0.grad).abs().amax(1) > 2.0 ** -6 * (float(h0.grad.abs().max()) or 1.0))
     assert float(bad.double().mean()) <= (0.05 if n >= 100 else 1.0), f"{tag}: dx {int(bad.sum())} of {n} rows off"
     if n >= 100:
+        # one flipped unit in one row moves a parameter gradient by that row's share of the sum: a few / n of its scale (round 5:
+        # [22, 28, 15, 24, 31] at n = 100 came in at 3.2e-2 against a flat 2^-5; the packed conversions the kernels use since then
+        # round exactly like the scalar ones -- checked on the GPU -- so it is the kink, not the arithmetic)
+        tol_w = 2.0 ** -5 + 4.0 / n
         for l in range(len(Ws)):
             s_ = float(ws[l].grad.abs().max()) or 1.0
             e = float((dWs[l].double() - ws[l].grad).abs().max()) / s_
-            assert e <= 2.0 ** -5, f"{tag}: dW{l} err {e:.2e}"
+            assert e <= tol_w, f"{tag}: dW{l} err {e:.2e}"
             if bias[l]:
                 s_ = float(bb[l].grad.abs().max()) or 1.0
                 e = float((dbs[l].double() - bb[l].grad).abs().max()) / s_
-                assert e <= 2.0 ** -5, f"{tag}: db{l} err {e:.2e}"
+                assert e <= tol_w, f"{tag}: db{l} err {e:.2e}"
     return "ok"
 
 
