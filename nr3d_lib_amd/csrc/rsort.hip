@@ -7,7 +7,7 @@
 // has no library sort on its default path either (pack_ops_cuda.cu:2621-2629 compiles thrust out; :2634-2720 is its own kernel).
 //
 // One pass = three launches:
-//   k_hist     workgroup = tile of 12 288 elements: digit histogram in LDS -> hist[digit][tile]
+//   k_hist     workgroup = tile of 6 144 elements: digit histogram in LDS -> hist[digit][tile]
 //   k_scan     workgroup = one digit: exclusive scan of its row over the tiles (in place), digit total
 //   k_scatter  workgroup = tile: stable rank of every element among the tile's elements with the same digit -- per wave by matching
 //              digits across lanes with ballots (one LDS counter row per wave, bumped by the leader lane of each match group: no
@@ -20,7 +20,9 @@
 namespace nr3d {
 namespace rsort {
 
-constexpr uint32_t kThreads = 1024, kWaves = kThreads / 64, kItems = 12, kTile = kThreads * kItems;
+// 6 elements per thread: 66-80 KB of LDS per workgroup, two workgroups per CU -- one loads / ranks while the other writes out (12 per thread,
+// one workgroup per CU: 3.65 M pairs x 2, 15 bits: 144 -> 113 us; 2^20 pairs, 32 bits: 113 -> 83 us; tools/bench_rsort.py)
+constexpr uint32_t kThreads = 1024, kWaves = kThreads / 64, kItems = 6, kTile = kThreads * kItems;
 
 struct Job { const uint32_t *kin, *vin; uint32_t *kout, *vout; };
 struct Args {

@@ -8,7 +8,7 @@ from nr3d_lib_amd import _hip as H
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TILE = 12288
+TILE = 6144          # rsort::kTile
 
 
 def _expect(keys, values, bits):
