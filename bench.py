@@ -760,6 +760,7 @@ def emit(full):
             json.dump(full, f, indent=1)
     except OSError:
         pass
+    sys.stdout.flush()
     print("BENCH_FULL " + json.dumps(full), flush=True)
     print(compact_line(full), flush=True)
 
@@ -827,6 +828,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch {args.gpus} ranks, or run bare and let bench.py launch them)")
+    if rank != 0:
+        # only rank 0 reports: whatever the other ranks' libraries write to stdout (RCCL's banner is flushed at process exit, at a time
+        # of its own) must not land behind rank 0's result line
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if args.plumbing_check:
         return plumbing_check(args, rank, world)
     if not torch.cuda.is_available():
@@ -1075,9 +1081,20 @@ def main():
             out["extra"]["full_loop_2p21_rays_per_gpu"] = multi_loop
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        emit(out)
+        result = out
+    else:
+        result = None
     if dist is not None:
         dist.destroy_process_group()
+    # RCCL writes its banner (version, host, library path) through C stdio, which flushes at exit -- AFTER anything Python printed: on a
+    # multi-rank run the last stdout line was "Librccl path : ..." instead of the result.  Tear the group down first, flush C stdio,
+    # then print: the compact JSON line is the last thing this process writes.
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if result is not None:
+        emit(result)
 
 
 if __name__ == "__main__":
