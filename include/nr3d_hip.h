@@ -59,7 +59,8 @@ enum {
 	NR3D_OPT_PAIR_FIXED = 4,         /* 1: 64-bit fixed-point LDS accumulators; 0: fp64 */
 	NR3D_OPT_FWD_PAIRLANE = 5,       /* 1: two-lane forward / Hessian kernels for 3-D Dense/Hash metas; 0: k_fwd (corner sum) */
 	NR3D_OPT_FWD_SPLIT = 6,          /* 1: mixed metas launch per level type */
-	NR3D_OPT_FWD_LDS_STAGE = 7,      /* 1: coarse Dense levels staged in LDS (k_fwd_lds) */
+	NR3D_OPT_FWD_LDS_STAGE = 7,      /* 1: coarse Dense levels whose whole table fits LDS are served from it (k_fwd_lds); 2: also tables that fit in <= 8 slabs of
+	                                  * x-planes, from 2^19 points on (k_fwd_lds_slab: round-5 experiment, bit-identical, slower: off); 0: none */
 	NR3D_OPT_HVP_LEVELS = 8,         /* 1: d(dL/dx)/dx with one lane per (point, level) when a workspace is given */
 	NR3D_OPT_HVP_PAIRLANE = 9,       /* 1: ... through the two-lane gather */
 	NR3D_OPT_HVP_SPLIT = 10,         /* 1: lane-serial d(dL/dx)/dx launches per level type */
@@ -226,6 +227,9 @@ int nr3d_lotd_pair_path_ok(const nr3d_lotd_meta_t *meta);
  * records (levels with <= 4 buckets; 0 when the pair path does not apply or NR3D_OPT_PAIR_DIRECT is 0).  Informational: which
  * kernel serves which level (bench.py's per-kernel byte model). */
 int nr3d_lotd_pair_direct_levels(const nr3d_lotd_meta_t *meta, uint32_t n_points);
+/* which pseudo levels (bit q) nr3d_lotd_fwd serves from LDS for a batch of n_points: whole Dense tables and (*by_slab, ABI 5) Dense
+ * tables staged slab by slab; 0 when the two-lane forward does not apply.  bench.py prices the forward kernels on the levels each serves. */
+uint64_t nr3d_lotd_fwd_lds_levels(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint64_t *by_slab);
 int nr3d_lotd_bwd_dparam_typed(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint32_t n_points, int grad_dtype,
                                const void *dL_dy, int64_t g_sn, int64_t g_se, const void *x, int32_t max_level,
                                int out_dtype, int assign, void *dL_dparam, void *workspace, uint64_t workspace_bytes,

@@ -613,6 +613,209 @@ __global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t 
 }
 
 // =============================================================================================
+// Forward, LDS-staged BY SLAB (round 5; an experiment that LOST, kept behind NR3D_OPT_FWD_LDS_STAGE = 2): Dense levels of 2
+// features whose table does not fit LDS whole but in a few slabs of x-planes (NGP config: level 2 = 30^3, 216 KB, two slabs;
+// level 3 = 42^3, 593 KB, six).  The workgroup owns kLdsPts points as in k_fwd_lds.  It first buckets them by slab in LDS
+// (wave-aggregated counters: one ballot per slab), fetches every point's coordinates once, then walks the slabs: copy the slab's
+// planes (+ one halo plane) into LDS, serve the bucket's points from it -- whole waves, every point once; the results wait in
+// registers and leave through LDS in point order as whole rows.  The arithmetic is k_fwd_lds's: bit-identical outputs
+// (tests/test_lotd_gpu.py::test_forward_lds_slabs_bit_identical).
+// Measured (tools/exp_fwd_slab.py, configs[1], 2^20 points): the two-lane kernel loses levels 2-3 and 48 us (339 -> 291), the
+// two slab launches cost 62 us: +14 us net (first version, results stored through the point index: 73 us -- 8 scattered dword
+// stores per point are 1.5-3.7 partial line writes per point and level; one 8-byte load per staging round trip instead of eight
+// in flight and the coordinates re-fetched inside the slab loop made no difference).  What it is bound by: a workgroup's 2 + 6
+// slab rounds are SERIAL -- stage 108-119 KB, barrier, ~700 points of LDS work, barrier: 4-5 us of latency each with one workgroup
+// per CU (140 KB of LDS) and nothing to overlap with.  A (chunk x slab) grid -- one slab per workgroup, a 6x larger chunk scanned for
+// the slab's points -- would cut the rounds to one (~8 us per level by the same per-phase latencies: ~ -27 us per step, 2.8 %) at
+// the price of scattered outputs and a list that overflows on skewed inputs; not built.
+constexpr uint32_t kSlabBytes = 140 * 1024;        // LDS for the slab's planes (the bucket lists take 8 KB + the counters)
+constexpr uint32_t kSlabMax = 8;                   // slabs per level at most: every workgroup pays one staging round per slab
+struct SlabLevel { uint32_t q, nx, n_slabs; };     // pseudo level, cell planes per slab, slabs
+
+template <bool DYDX, typename PT>
+__global__ __launch_bounds__(kLdsThreads) void k_fwd_lds_slab(const nr3d_lotd_meta_t *__restrict__ md, uint32_t N, SlabLevel sl,
+                                                              uint32_t smooth, const float *__restrict__ x,
+                                                              const PT *__restrict__ params, PT *__restrict__ y, int64_t y_sn,
+                                                              int64_t y_se, float *__restrict__ dydx, int64_t d_sn, int64_t d_se) {
+	extern __shared__ __attribute__((aligned(16))) float2 slab_tab[];
+	__shared__ uint16_t list[kLdsPts];             // local point ids, bucket after bucket
+	__shared__ uint32_t cnt[kSlabMax], base[kSlabMax + 1], cur[kSlabMax];
+	const Lvl L = load_level(md, meta_level_of(md, sl.q));
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t g_first = blockIdx.x * kLdsPts, n_here = (N - g_first) < kLdsPts ? (N - g_first) : kLdsPts;
+	const float sc0 = (float)(L.res[0] - 2u), sc1 = (float)(L.res[1] - 2u), sc2 = (float)(L.res[2] - 2u);
+	const uint32_t sx = L.res[1] * L.res[2], sy = L.res[2];
+	if (threadIdx.x < kSlabMax) { cnt[threadIdx.x] = 0u; cur[threadIdx.x] = 0u; }
+	__syncthreads();
+	// ---- the slab of every point (its x cell, by the exact locator; a cell outside the level is clamped into the last / first slab
+	// and into the staged planes below: x outside [0, 1] reads what k_fwd_lds would not have either, but never outside LDS) ----
+	uint32_t slab_of[kLdsPts / kLdsThreads];
+	const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+	for (uint32_t k4 = 0; k4 < kLdsPts / kLdsThreads; ++k4) {
+		const uint32_t lp = k4 * kLdsThreads + threadIdx.x;
+		uint32_t s = 0xFFFFFFFFu;
+		if (lp < n_here) {
+			const float f0 = floorf(__fmaf_rn(x[(size_t)(g_first + lp) * 3], sc0, 0.5f));
+			const uint32_t c0 = f0 > 0.0f ? (uint32_t)fminf(f0, (float)(L.res[0] - 2u)) : 0u;
+			s = c0 / sl.nx;
+		}
+		slab_of[k4] = s;
+		for (uint32_t t = 0; t < sl.n_slabs; ++t) {
+			const uint64_t m = __ballot(s == t);
+			if (m && lane == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[t], (uint32_t)__popcll(m));
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t run = 0;
+		for (uint32_t t = 0; t < sl.n_slabs; ++t) { base[t] = run; run += cnt[t]; }
+		base[sl.n_slabs] = run;
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t k4 = 0; k4 < kLdsPts / kLdsThreads; ++k4) {
+		const uint32_t lp = k4 * kLdsThreads + threadIdx.x, s = slab_of[k4];
+		for (uint32_t t = 0; t < sl.n_slabs; ++t) {
+			const uint64_t m = __ballot(s == t);
+			if (!m) continue;
+			const uint32_t leader = (uint32_t)(__ffsll((long long)m) - 1);
+			uint32_t at = 0;
+			if (lane == leader) at = atomicAdd(&cur[t], (uint32_t)__popcll(m));
+			at = __shfl(at, (int)leader, 64);
+			if (s == t) list[base[t] + at + (uint32_t)__popcll(m & below)] = (uint16_t)lp;
+		}
+	}
+	__syncthreads();                                                               // the lists are complete
+	// list position p = k4 * 1024 + thread: its point and coordinates, fetched ONCE in front of the slab loop (all loads in flight
+	// together; inside the loop they were a dependent global round trip per slab).  A bucket is a contiguous range of positions, so
+	// the threads that work on a slab are whole waves.
+	constexpr uint32_t kPer = kLdsPts / kLdsThreads;
+	uint32_t pt[kPer];
+	float xp[kPer][3];
+#pragma unroll
+	for (uint32_t k4 = 0; k4 < kPer; ++k4) {
+		const uint32_t p = k4 * kLdsThreads + threadIdx.x;
+		pt[k4] = g_first + (p < n_here ? (uint32_t)list[p] : 0u);
+#pragma unroll
+		for (int d = 0; d < 3; ++d) xp[k4][d] = x[(size_t)pt[k4] * 3 + d];
+	}
+	// results stay in registers until every slab is done, then go through LDS (the slab area is free by then) into point order and
+	// leave as whole rows: written straight through the point index they were 8 scattered dword stores per point -- 1.5-3.7 partial
+	// line writes per (point, level), as dear as the 4.25 reads the staging saves (first version: 73 us for levels 2-3)
+	float res_y[kPer][2], res_j[kPer][2][3];
+	// ---- slab after slab ----
+	for (uint32_t t = 0; t < sl.n_slabs; ++t) {
+		const uint32_t p0 = t * sl.nx;                                              // first plane of the slab
+		const uint32_t planes = (p0 + sl.nx + 1u) <= L.res[0] ? sl.nx + 1u : L.res[0] - p0;
+		if (t) __syncthreads();                                                    // the previous slab's readers are done
+		{
+			// eight loads in flight per thread (a plain copy loop issues one 8-byte load per round trip: 15 round trips per slab)
+			const char *__restrict__ src = reinterpret_cast<const char *>(params + L.off) + (size_t)p0 * sx * (2 * sizeof(PT));
+			const uint32_t total = planes * sx;
+			for (uint32_t e0 = threadIdx.x; e0 < total; e0 += kLdsThreads * 8u) {
+				float2 v[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8u; ++u) {
+					const uint32_t e = e0 + u * kLdsThreads;
+					v[u] = load_pair<PT>(src + (size_t)(e < total ? e : e0) * (2 * sizeof(PT)));
+				}
+#pragma unroll
+				for (uint32_t u = 0; u < 8u; ++u) {
+					const uint32_t e = e0 + u * kLdsThreads;
+					if (e < total) slab_tab[e] = v[u];
+				}
+			}
+		}
+		__syncthreads();
+		const uint32_t b0 = base[t], b1 = base[t + 1];
+#pragma unroll
+		for (uint32_t k4 = 0; k4 < kPer; ++k4) {
+			const uint32_t p = k4 * kLdsThreads + threadIdx.x;
+			if (p < b0 || p >= b1) continue;
+			const uint32_t i = pt[k4];
+			const float x0 = xp[k4][0], x1 = xp[k4][1], x2 = xp[k4][2];
+			// cell locator (explicit fma: decides the integer cell, must match the oracle bit for bit)
+			const float v0 = __fmaf_rn(x0, sc0, 0.5f), v1 = __fmaf_rn(x1, sc1, 0.5f), v2 = __fmaf_rn(x2, sc2, 0.5f);
+			const float f0 = floorf(v0), f1 = floorf(v1), f2 = floorf(v2);
+			float t0 = v0 - f0, t1 = v1 - f1, t2 = v2 - f2;
+			float dw0 = sc0, dw1 = sc1, dw2 = sc2;             // scale * w'
+			if (smooth) {
+				dw0 *= 6.0f * t0 * (1.0f - t0); dw1 *= 6.0f * t1 * (1.0f - t1); dw2 *= 6.0f * t2 * (1.0f - t2);
+				t0 = t0 * t0 * __fmaf_rn(-2.0f, t0, 3.0f); t1 = t1 * t1 * __fmaf_rn(-2.0f, t1, 3.0f); t2 = t2 * t2 * __fmaf_rn(-2.0f, t2, 3.0f);
+			}
+			// local plane of the cell inside the slab (clamped: memory safety for x outside [0, 1])
+			uint32_t c0 = f0 > 0.0f ? (uint32_t)f0 : 0u;
+			c0 = c0 >= p0 ? c0 - p0 : 0u;
+			c0 = c0 + 2u <= planes ? c0 : planes - 2u;
+			uint32_t c1 = f1 > 0.0f ? (uint32_t)f1 : 0u, c2 = f2 > 0.0f ? (uint32_t)f2 : 0u;
+			c1 = c1 + 2u <= L.res[1] ? c1 : L.res[1] - 2u;
+			c2 = c2 + 2u <= L.res[2] ? c2 : L.res[2] - 2u;
+			const uint32_t e00 = (c0 * L.res[1] + c1) * L.res[2] + c2;
+			const uint32_t e[4] = {e00, e00 + sx, e00 + sy, e00 + sx + sy};
+			// the lerp tree of k_fwd_lds / k_fwd_pairlane for a Dense level (pair dim z, then x, then y), both features in one lane
+			const float w1 = 1.0f - t2;
+			float2 b[4], d[4];
+#pragma unroll
+			for (int m = 0; m < 4; ++m) {
+				const float2 lo = slab_tab[e[m]], hi = slab_tab[e[m] + 1u];
+				d[m] = make_float2(hi.x - lo.x, lo.y - hi.y);
+				b[m] = make_float2(__fmaf_rn(t2, d[m].x, lo.x), __fmaf_rn(w1, d[m].y, hi.y));
+			}
+			float yv[2], gx[2], gy[2], gz[2];
+#pragma unroll
+			for (int f = 0; f < 2; ++f) {
+				auto c = [f](const float2 &v) { return f ? v.y : v.x; };
+				const float cA0 = c(b[1]) - c(b[0]), cA1 = c(b[3]) - c(b[2]);
+				const float dA0 = __fmaf_rn(t0, cA0, c(b[0])), dA1 = __fmaf_rn(t0, cA1, c(b[2]));
+				const float eB = dA1 - dA0;
+				yv[f] = __fmaf_rn(t1, eB, dA0);
+				if (DYDX) {
+					const float gA = __fmaf_rn(t1, cA1 - cA0, cA0);
+					const float q0 = __fmaf_rn(t0, c(d[1]) - c(d[0]), c(d[0])), q1 = __fmaf_rn(t0, c(d[3]) - c(d[2]), c(d[2]));
+					const float gP = __fmaf_rn(t1, q1 - q0, q0);
+					gx[f] = gA * dw0; gy[f] = eB * dw1; gz[f] = gP * (f ? -dw2 : dw2);
+				}
+			}
+			res_y[k4][0] = yv[0]; res_y[k4][1] = yv[1];
+			if (DYDX) {
+#pragma unroll
+				for (int f = 0; f < 2; ++f) { res_j[k4][f][0] = gx[f]; res_j[k4][f][1] = gy[f]; res_j[k4][f][2] = gz[f]; }
+			}
+		}
+	}
+	// ---- results: registers -> LDS in point order -> whole rows ----
+	__syncthreads();
+	float *ob = reinterpret_cast<float *>(slab_tab);                               // y [2][kLdsPts] | dy_dx [2][kLdsPts][3]
+#pragma unroll
+	for (uint32_t k4 = 0; k4 < kPer; ++k4) {
+		const uint32_t p = k4 * kLdsThreads + threadIdx.x;
+		if (p >= n_here) continue;
+		const uint32_t lp = (uint32_t)list[p];
+#pragma unroll
+		for (int f = 0; f < 2; ++f) {
+			ob[f * kLdsPts + lp] = res_y[k4][f];
+			if (DYDX) {
+#pragma unroll
+				for (int c = 0; c < 3; ++c) ob[2u * kLdsPts + ((uint32_t)f * kLdsPts + lp) * 3u + c] = res_j[k4][f][c];
+			}
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int f = 0; f < 2; ++f) {
+		PT *yc = y + ((int64_t)g_first * y_sn + (int64_t)(sl.q * 2u + f) * y_se);
+		for (uint32_t k = threadIdx.x; k < n_here; k += kLdsThreads) yc[(int64_t)k * y_sn] = from_f32<PT>(ob[f * kLdsPts + k]);
+		if (DYDX) {
+			float *dc = dydx + ((int64_t)g_first * d_sn + (int64_t)(sl.q * 2u + f) * d_se);
+			const float *oj = ob + 2u * kLdsPts + (uint32_t)f * kLdsPts * 3u;
+			if (d_sn == 3) for (uint32_t k = threadIdx.x; k < 3u * n_here; k += kLdsThreads) dc[k] = oj[k];       // feature-major: one run
+			else for (uint32_t k = threadIdx.x; k < 3u * n_here; k += kLdsThreads) dc[(int64_t)(k / 3u) * d_sn + (k % 3u)] = oj[k];
+		}
+	}
+}
+
+// =============================================================================================
 // dL/dparam (SECOND == false) and d(dL/dx)/dparam (SECOND == true)
 // =============================================================================================
 template <int D, int G, bool SECOND, bool DH, typename PT = float>
@@ -1527,6 +1730,35 @@ static bool pairlane_meta_ok(const nr3d_lotd_meta_t *meta) {
 	return true;
 }
 
+// which Dense levels the forward serves from LDS for a batch of N points: whole tables (k_fwd_lds) and, from 2^19 points on, tables
+// that fit in <= kSlabMax slabs of x-planes (k_fwd_lds_slab); bit q of the result = pseudo level q.  slab[q] = its slab geometry.
+static bool slab_geometry(const nr3d_lotd_level_t &L, uint32_t q, SlabLevel &sl) {
+	const uint64_t plane_bytes = (uint64_t)L.res[1] * L.res[2] * 8u;
+	if (plane_bytes == 0 || L.res[0] < 2) return false;
+	const uint64_t fit = kSlabBytes / plane_bytes;
+	if (fit < 2) return false;
+	sl.q = q; sl.nx = (uint32_t)(fit - 1u);
+	const uint32_t cells = (uint32_t)L.res[0] - 1u;
+	sl.n_slabs = (cells + sl.nx - 1u) / sl.nx;
+	return sl.n_slabs >= 1 && sl.n_slabs <= kSlabMax;
+}
+// (an experiment that lost, kept selectable: option value 2 -- see the kernel's header)
+static bool slab_stage_enabled() { return opt::get(NR3D_OPT_FWD_LDS_STAGE) == 2; }
+static uint64_t fwd_lds_levels(const nr3d_lotd_meta_t *meta, uint32_t N, int32_t max_level, uint64_t *slab_mask) {
+	uint64_t staged = 0, slabs = 0;
+	if (lds_stage_enabled() && N >= lds_stage_min_points() && meta->n_pseudo_levels <= 64)
+		for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
+			const uint32_t lv = meta->map_levels[q];
+			const nr3d_lotd_level_t &L = meta->levels[lv];
+			if ((int32_t)lv > max_level || L.type != NR3D_LOD_Dense || L.n_feats != 2) continue;
+			if ((uint64_t)L.size * 8 <= kLdsMaxBytes) { staged |= 1ull << q; continue; }
+			SlabLevel sl;
+			if (slab_stage_enabled() && N >= (1u << 19) && slab_geometry(L, q, sl)) { staged |= 1ull << q; slabs |= 1ull << q; }
+		}
+	if (slab_mask) *slab_mask = slabs;
+	return staged;
+}
+
 // PT = float | __half (parameter and y storage type).  Returns 1 when it served the call, 0 when the generic kernels
 // have to, < 0 ... never; errors through NR3D_CHECK (positive).  `served` out-param keeps the int status free.
 template <typename PT>
@@ -1566,10 +1798,11 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 #undef NR3D_LDS_LAUNCH
 			n_grp = 0; grp_bytes = 0;
 		};
+		uint64_t slab_mask = 0;
+		const uint64_t lds_mask = fwd_lds_levels(meta, N, max_level, &slab_mask);
 		for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
-			const uint32_t lv = meta->map_levels[q];
-			const nr3d_lotd_level_t &L = meta->levels[lv];
-			if ((int32_t)lv > max_level || L.type != NR3D_LOD_Dense || L.n_feats != 2 || (uint64_t)L.size * 8 > kLdsMaxBytes) continue;
+			if (!((lds_mask >> q) & 1ull) || ((slab_mask >> q) & 1ull)) continue;
+			const nr3d_lotd_level_t &L = meta->levels[meta->map_levels[q]];
 			staged |= 1ull << q;
 			const uint32_t bytes = (L.size * 8u + 15u) & ~15u;     // staged as float pairs whatever the storage type
 			if (n_grp == 2 || (n_grp == 1 && (!pair_levels || grp_bytes + bytes > kLdsGroupBytes))) flush();
@@ -1577,6 +1810,28 @@ static int fwd_fast_path(const nr3d_lotd_meta_t *meta, const nr3d_lotd_meta_t *m
 			++n_grp; grp_bytes += bytes;
 		}
 		flush();
+		if (slab_mask) {
+			static bool sattr_dev[64] = {};
+			if (!sattr_dev[dev_id & 63]) {
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds_slab<true, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSlabBytes));
+				NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_fwd_lds_slab<false, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSlabBytes));
+				sattr_dev[dev_id & 63] = true;
+			}
+			prof::Scope ps(NR3D_PROF_LOTD_FWD_LDS, st);
+			for (uint32_t q = 0; q < meta->n_pseudo_levels; ++q) {
+				if (!((slab_mask >> q) & 1ull)) continue;
+				SlabLevel sl;
+				slab_geometry(meta->levels[meta->map_levels[q]], q, sl);
+				const size_t lds = (size_t)(sl.nx + 1u) * meta->levels[meta->map_levels[q]].res[1] * meta->levels[meta->map_levels[q]].res[2] * 8u;
+				if (dy_dx)
+					hipLaunchKernelGGL((k_fwd_lds_slab<true, PT>), dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, sl, meta->interpolation_type,
+					                   x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
+				else
+					hipLaunchKernelGGL((k_fwd_lds_slab<false, PT>), dim3(div_up(N, kLdsPts)), dim3(kLdsThreads), lds, st, md, N, sl, meta->interpolation_type,
+					                   x, params, y, y_sn, y_se, dy_dx, d_sn, d_se);
+				staged |= 1ull << q;
+			}
+		}
 	}
 	// timing experiments (experiments build only; results wrong by design): FWD_DBG bit 0 no stores, 1 no gathers, 2 no x loads;
 	// FWD_ONLY_LEVEL = one pseudo level
@@ -1784,6 +2039,12 @@ extern "C" int nr3d_lotd_bwd_dparam(const nr3d_lotd_meta_t *meta, const void *me
 }
 
 extern "C" int nr3d_lotd_pair_path_ok(const nr3d_lotd_meta_t *meta) { return (meta && pair_applies(meta)) ? 1 : 0; }
+extern "C" uint64_t nr3d_lotd_fwd_lds_levels(const nr3d_lotd_meta_t *meta, uint32_t n_points, uint64_t *by_slab) {
+	if (by_slab) *by_slab = 0;
+	if (!meta || !pairlane_enabled() || !pairlane_meta_ok(meta)) return 0;
+	return fwd_lds_levels(meta, n_points, 0x7fffffff, by_slab);
+}
+
 extern "C" int nr3d_lotd_pair_direct_levels(const nr3d_lotd_meta_t *meta, uint32_t n_points) {
 	return (meta && pair_applies(meta)) ? (int)pair_direct_levels(meta, n_points) : 0;
 }

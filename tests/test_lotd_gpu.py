@@ -954,3 +954,38 @@ def test_cp_and_vm_levels_without_records(oracle, dev, case, scale, hip_option):
     # all-zero gradients: the bound is zero, the kernels keep their fp64 accumulators and must return zeros
     z = _lotd.lod_bwd(m, torch.zeros_like(gt), xt, pt, None, need_input_grad=False, need_param_grad=True)[1]
     assert float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("smooth,half", [(False, False), (True, False), (False, True)])
+def test_forward_lds_slabs_bit_identical(dev, hip_option, smooth, half):
+    """the three forward routes of a 3-D Dense / Hash meta -- two lanes per (point, level) through L2 (fwd_lds_stage = 0), coarse
+    Dense tables whole in LDS (1, default), and the round-5 experiment that also serves the next Dense levels from LDS slab by slab
+    (2) -- give the same bits: which route a level takes depends on the batch size, so it must never show in the result.
+    N = 2^19 + 77: above both staging thresholds, a ragged last workgroup; levels of 2 and 6 slabs (30^3, 42^3) and a cuboid one."""
+    from nr3d_lib_amd.bindings import _lotd
+    res = [16, 22, 30, 42, [36, 20, 50], 58, 111, 212]
+    meta = _lotd.LoDMeta(3, res, [2] * 8, ["Dense"] * 6 + ["Hash"] * 2, 2 ** 16, smooth)
+    n = (1 << 19) + 77
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(n, 3, generator=g).clamp_(1e-6, 1 - 1e-6).to(dev)
+    x[:64] = torch.tensor([1e-6, 0.5, 1 - 1e-6])[torch.randint(0, 3, (64, 3), generator=g)].to(dev)      # faces and corners of the box
+    params = torch.empty(meta.n_params).uniform_(-1, 1, generator=g).to(dev)
+    if half:
+        params = params.half()
+    out = {}
+    for mode in (0, 1, 2):
+        hip_option("fwd_lds_stage", mode)
+        y, j = _lotd.lod_fwd(meta, x, params, need_input_grad=True)
+        y0, _ = _lotd.lod_fwd(meta, x, params, need_input_grad=False)
+        assert torch.equal(y, y0), "with and without the Jacobian"
+        out[mode] = (y.clone(), j.clone())
+    for mode in (1, 2):
+        assert torch.equal(out[mode][0], out[0][0]), f"y, fwd_lds_stage = {mode}"
+        assert torch.equal(out[mode][1], out[0][1]), f"dy_dx, fwd_lds_stage = {mode}"
+    import ctypes
+    from nr3d_lib_amd import _hip as H
+    H.lib().nr3d_lotd_fwd_lds_levels.restype = ctypes.c_uint64
+    by_slab = ctypes.c_uint64(0)
+    hip_option("fwd_lds_stage", 2)
+    mask = H.lib().nr3d_lotd_fwd_lds_levels(ctypes.byref(meta._cmeta()), ctypes.c_uint32(n), ctypes.byref(by_slab))
+    assert mask == 0b011111 and by_slab.value == 0b011100, (bin(mask), bin(by_slab.value))    # 58^3 needs 15 slabs: left to the two-lane kernel
