@@ -57,11 +57,41 @@ def lib():
                 if have != ABI_VERSION:
                     raise RuntimeError(f"nr3d_lib_amd: {LIB_PATH} has ABI version {have}, these bindings need {ABI_VERSION}: "
                                        "rebuild it (`make -C nr3d_lib_amd/csrc` or __graft_entry__.build())")
-                l.nr3d_last_error.restype = C.c_char_p
-                l.nr3d_scan_tmp_bytes.restype = C.c_uint64
-                l.nr3d_scan_tmp_bytes.argtypes = [C.c_uint64]
+                _declare(l)
                 _lib = l
     return _lib
+
+
+_CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
+          "float": C.c_float, "double": C.c_double, "void": None, "const char *": C.c_char_p}
+
+
+def _declare(l):
+    """argtypes / restype of EVERY entry point, read from include/nr3d_hip.h (round 5).  With them the bindings pass plain Python
+    ints / floats -- ``ptr()`` is ``tensor.data_ptr()``, no ctypes object per argument (a launch-bound op spent ~10 us per iteration
+    wrapping ~50 arguments) -- and a Python int can no longer be taken for a 32-bit C int where a pointer is meant: every pointer
+    parameter is declared c_void_p (which also takes None, ctypes arrays and byref() results).  A declaration this cannot parse, or
+    an exported symbol without one, is an error here, not a truncated pointer later."""
+    import re
+    header = os.path.join(os.path.dirname(_PKG), "include", "nr3d_hip.h")
+    if not os.path.exists(header):
+        raise RuntimeError(f"nr3d_lib_amd: {header} not found (the bindings read the entry points' signatures from it)")
+    txt = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    decls = re.findall(r"\b((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*(?:\s*\*)?)\s*\b(nr3d_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S)
+    if len(decls) < 80:
+        raise RuntimeError(f"nr3d_lib_amd: only {len(decls)} entry points parsed from {header}")
+    for ret, name, args in decls:
+        fn = getattr(l, name)
+        ret = " ".join(ret.split())
+        fn.restype = _CTYPE[ret]
+        at = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if a in ("", "void"):
+                continue
+            at.append(C.c_void_p if ("*" in a or "[" in a) else _CTYPE[" ".join(a.split()[:-1]).replace("const ", "")])
+        fn.argtypes = at
 
 
 # ---- debug hook: poison every uninitialised output -----------------------------------------------------------------
@@ -159,10 +189,10 @@ class options:
 
 
 def ptr(t):
-    """Device (or host) address of a tensor as c_void_p; None -> NULL."""
+    """Device (or host) address of a tensor (a plain int: every pointer parameter is declared c_void_p, _declare); None -> NULL."""
     if t is None:
         return None
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -172,8 +202,8 @@ def stream_of(t):
     """hipStream_t of torch's current stream on the tensor's device (the raw handle: building a torch.cuda.Stream object
     per call costs ~5 us of host time, which the launch-bound ops notice)."""
     if _raw_stream is not None:
-        return C.c_void_p(_raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device()))
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def sort_pairs_u32(keys, values=None, bits=32, n_dev=None):
@@ -364,17 +394,18 @@ def require_gpu(*tensors):
                                "there is no CPU fallback in the product path")
 
 
+# scalar arguments: plain Python values (the entry points' argtypes convert them, _declare)
 def i64(v):
-    return C.c_int64(int(v))
+    return int(v)
 
 
 def u32(v):
-    return C.c_uint32(int(v))
+    return int(v)
 
 
 def i32(v):
-    return C.c_int32(int(v))
+    return int(v)
 
 
 def f32(v):
-    return C.c_float(float(v))
+    return float(v)
