@@ -18,7 +18,13 @@ def main():
     ap.add_argument("--log2-points", type=int, default=22)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--option", action="append", default=[], help="name=value for nr3d_set_option (A/B runs), repeatable")
     a = ap.parse_args()
+    if a.option:
+        from nr3d_lib_amd import _hip as H
+        for kv in a.option:
+            k, val = kv.split("=")
+            H.set_option(k, int(val))
     dev = torch.device("cuda", 0)
     meta = _lotd.LoDMeta(3, RES, FEATS, TYPES, None)
     N = 1 << a.log2_points
