@@ -625,9 +625,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_fwd_lds(const nr3d_lotd_meta_t 
 // stores per point are 1.5-3.7 partial line writes per point and level; one 8-byte load per staging round trip instead of eight
 // in flight and the coordinates re-fetched inside the slab loop made no difference).  What it is bound by: a workgroup's 2 + 6
 // slab rounds are SERIAL -- stage 108-119 KB, barrier, ~700 points of LDS work, barrier: 4-5 us of latency each with one workgroup
-// per CU (140 KB of LDS) and nothing to overlap with.  A (chunk x slab) grid -- one slab per workgroup, a 6x larger chunk scanned for
-// the slab's points -- would cut the rounds to one (~8 us per level by the same per-phase latencies: ~ -27 us per step, 2.8 %) at
-// the price of scattered outputs and a list that overflows on skewed inputs; not built.
+// per CU (140 KB of LDS) and nothing to overlap with.  A (chunk x slab) grid -- one slab per workgroup -- would make it one round, and
+// one round was measured too (a build forcing one slab per level): 39.5 us for the two launches, ~20 us per level against the ~24 us
+// a level costs in the two-lane kernel.  Bucketing + LDS write-out cost what the L2 requests they replace cost: dropped.
 constexpr uint32_t kSlabBytes = 140 * 1024;        // LDS for the slab's planes (the bucket lists take 8 KB + the counters)
 constexpr uint32_t kSlabMax = 8;                   // slabs per level at most: every workgroup pays one staging round per slab
 struct SlabLevel { uint32_t q, nx, n_slabs; };     // pseudo level, cell planes per slab, slabs
@@ -659,6 +659,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_fwd_lds_slab(const nr3d_lotd_me
 			const float f0 = floorf(__fmaf_rn(x[(size_t)(g_first + lp) * 3], sc0, 0.5f));
 			const uint32_t c0 = f0 > 0.0f ? (uint32_t)fminf(f0, (float)(L.res[0] - 2u)) : 0u;
 			s = c0 / sl.nx;
+			s = s < sl.n_slabs ? s : sl.n_slabs - 1u;                // (cannot exceed it for a geometry from slab_geometry; never an unlisted point)
 		}
 		slab_of[k4] = s;
 		for (uint32_t t = 0; t < sl.n_slabs; ++t) {
