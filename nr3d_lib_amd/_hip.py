@@ -152,7 +152,7 @@ def prof_read(name, reset=True):
 # ---- selectable code paths (include/nr3d_hip.h: NR3D_OPT_*) -------------------------------------------------------
 OPTION_IDS = dict(lotd_pair=0, pair_quad=1, pair_second=2, pair_direct=3, pair_fixed=4, fwd_pairlane=5, fwd_split=6,
                   fwd_lds_stage=7, hvp_levels=8, hvp_pairlane=9, hvp_split=10, vm_split=11, cp_direct=12, march_group=13,
-                  pack_scan=14, vm_lines_direct=15, fwd_cell_major=16, sort_wave=17, vm_direct=18, direct_fixed=19, vm_sorted=20)
+                  pack_scan=14, vm_lines_direct=15, fwd_cell_major=16, sort_wave=17, vm_direct=18, direct_fixed=19, vm_sorted=20, mlp_x3=21)
 
 
 def set_option(name, value):

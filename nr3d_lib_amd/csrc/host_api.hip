@@ -53,9 +53,9 @@ static const int64_t kDefault[NR3D_OPT_COUNT] = {
 	/* LOTD_PAIR */ 1, /* PAIR_QUAD */ 1, /* PAIR_SECOND */ 1, /* PAIR_DIRECT */ 1, /* PAIR_FIXED */ 1, /* FWD_PAIRLANE */ 1,
 	/* FWD_SPLIT */ 1, /* FWD_LDS_STAGE */ 1, /* HVP_LEVELS */ 1, /* HVP_PAIRLANE */ 1, /* HVP_SPLIT */ 1, /* VM_SPLIT */ 1,
 	/* CP_DIRECT */ 1, /* MARCH_GROUP */ 0, /* PACK_SCAN */ 1, /* VM_LINES_DIRECT */ 0, /* FWD_CELL_MAJOR */ 1, /* SORT_WAVE */ 1,
-	/* VM_DIRECT */ 1, /* DIRECT_FIXED */ 1, /* VM_SORTED */ 1,
+	/* VM_DIRECT */ 1, /* DIRECT_FIXED */ 1, /* VM_SORTED */ 1, /* MLP_X3 */ 1,
 };
-int64_t g_val[NR3D_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1, 1, 1};
+int64_t g_val[NR3D_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1, 1, 1, 1};
 
 #ifdef NR3D_EXPERIMENTS
 // measurement knobs of the experiments build: NR3D_<NAME> from the environment, looked up once per name

@@ -64,6 +64,28 @@ static uint64_t packed_floats(const Shape &s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp32 forward on the bf16 MFMA (round 5, "x3"): every fp32 value is split into three bf16 pieces, v = v1 + v2 + v3 with
+// v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2) (24 significant bits; the subtractions are exact), and a product is the
+// six piece products whose magnitude is above 2^-25 of it: w1 x1 + (w1 x2 + w2 x1) + (w2 x2 + w1 x3 + w3 x1), each exact in the
+// multiplier and accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- the result is fp32-grade (dropped terms <= 2^-26 of a product,
+// below the rounding of an fp32 multiply), at 6 MFMAs of 8 passes per K = 16 where the f32 MFMA needs 8 of 16 passes: 2.7x the
+// matrix rate of v_mfma_f32_32x32x2_f32, which bounds csrc/mlp.hip's forward (0.55-0.63 of its 157 TFLOP/s).
+// The weights' pieces are made once at pack time, in the operand order of csrc/mlp_half.hip (A of step s, lane (out i, h),
+// element e = W[i][32 it + 8 (2 s + (e >> 2)) + 4 h + (e & 3)]); the activations' pieces per layer from the register map (a step's
+// B operand = eight consecutive accumulator registers).  Region of the packed buffer: behind the f32 forward layers.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+// floats of one x3 layer: three planes of [NO][NI][2 steps][64 lanes][8 bf16] + bias fp32 [NO * 32]
+__host__ __device__ constexpr uint32_t layer_x3_floats(uint32_t ni, uint32_t no) { return no * ni * 1536u + no * 32u; }
+static uint64_t x3_floats(const Shape &s) {
+	const uint64_t n = (uint64_t)layer_x3_floats(s.in_t, s.w_t) + (uint64_t)(s.n_layers - 2) * layer_x3_floats(s.w_t, s.w_t) + layer_x3_floats(s.w_t, s.out_t);
+	return n * 4 <= (uint64_t)kMaxLds ? n : 0;          // a network whose pieces do not fit LDS keeps the f32 MFMA
+}
+static bool x3_enabled() { return opt::on(NR3D_OPT_MLP_X3); }
+
+// ---------------------------------------------------------------------------------------------
 // packing: for layer l, packed[(((ot*NI + it)*4 + a)*64 + lane)*4 + b] = W[32 ot + (lane & 31)][32 it + 8a + 4(lane >> 5) + b]
 // (the transposed layers of the backward pass are packed from the same W with the roles of the two indices swapped)
 // ---------------------------------------------------------------------------------------------
@@ -94,6 +116,31 @@ __global__ __launch_bounds__(256) void k_mlp_pack(PackArgs a, float *__restrict_
 			if (o < a.out_dim[l]) v = a.b[l][o];
 		}
 		packed[a.offset[l] + e] = v;
+	}
+}
+
+// x3 planes of layer l: bf16 index e of plane p at ((((p * NO + ot) * NI + it) * 2 + s) * 64 + lane) * 8 + el; bias fp32 behind them
+__global__ __launch_bounds__(256) void k_mlp_pack_x3(PackArgs a, float *__restrict__ packed) {
+	const uint32_t l = blockIdx.y;
+	const uint32_t nw = a.no[l] * a.ni[l] * 1024u;                        // weights of the (padded) layer
+	__bf16 *wdst = reinterpret_cast<__bf16 *>(packed + a.offset[l]);
+	float *bdst = packed + a.offset[l] + a.no[l] * a.ni[l] * 1536u;
+	for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < nw + a.no[l] * 32u; e += gridDim.x * 256) {
+		if (e < nw) {
+			const uint32_t el = e & 7u, lane = (e >> 3) & 63u, st = (e >> 9) & 1u, tile = e >> 10;
+			const uint32_t it = tile % a.ni[l], ot = tile / a.ni[l];
+			const uint32_t o = 32u * ot + (lane & 31u), f = 32u * it + 8u * (2u * st + (el >> 2)) + 4u * (lane >> 5) + (el & 3u);
+			float v = 0.0f;
+			if (o < a.out_dim[l] && f < a.in_dim[l]) v = a.w[l][(size_t)o * a.in_dim[l] + f];
+			const __bf16 p1 = (__bf16)v;
+			const float r1 = v - (float)p1;
+			const __bf16 p2 = (__bf16)r1;
+			const __bf16 p3 = (__bf16)(r1 - (float)p2);
+			wdst[e] = p1; wdst[nw + e] = p2; wdst[2u * nw + e] = p3;
+		} else {
+			const uint32_t o = e - nw;
+			bdst[o] = (a.b[l] && o < a.out_dim[l]) ? a.b[l][o] : 0.0f;
+		}
 	}
 }
 
@@ -159,6 +206,77 @@ __device__ __forceinline__ void dense(const float *__restrict__ wp, const f16v (
 	for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
 		for (int j = 0; j < 16; ++j) out[ot][j] = activate(SPLIT ? out[ot][j] + alt[j] : out[ot][j], act);
+}
+
+// the three bf16 pieces of registers 8 s .. 8 s + 7 of a register-map tile (a K = 16 step's B operand)
+__device__ __forceinline__ void split3(const f16v &v, int s, bf8 (&p)[3]) {
+#pragma unroll
+	for (int e = 0; e < 8; e += 2) {
+		const f2v a = {v[8 * s + e], v[8 * s + e + 1]};
+		const bf2 p1 = __builtin_convertvector(a, bf2);
+		const f2v r1 = a - __builtin_convertvector(p1, f2v);
+		const bf2 p2 = __builtin_convertvector(r1, bf2);
+		const f2v r2 = r1 - __builtin_convertvector(p2, f2v);
+		const bf2 p3 = __builtin_convertvector(r2, bf2);
+		p[0][e] = p1[0]; p[0][e + 1] = p1[1];
+		p[1][e] = p2[0]; p[1][e + 1] = p2[1];
+		p[2][e] = p3[0]; p[2][e + 1] = p3[1];
+	}
+}
+
+// one dense layer in fp32 on the bf16 MFMA; wp -> LDS copy of the layer's x3 planes (+ bias)
+template <int NI, int NO, bool BIAS>
+__device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
+	const float *bias = wp + NO * NI * 1536;
+	const int h = lane >> 5;
+	constexpr int PLANE = NO * NI * 2 * 64;             // bf8 units per plane
+	const bf8 *wv = reinterpret_cast<const bf8 *>(wp) + lane;
+	constexpr bool SPLIT = (NO == 1);                  // one out tile: the small terms go to a second accumulator (no dependent MFMA chain)
+	const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+	f16v alt = zero;
+#pragma unroll
+	for (int ot = 0; ot < NO; ++ot)
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			f4v b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+			if (BIAS) b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
+#pragma unroll
+			for (int b = 0; b < 4; ++b) out[ot][4 * q + b] = b4[b];
+		}
+	// (weight piece, input piece) of the six kept products, smallest first
+	constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+	for (int it = 0; it < NI; ++it)
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			bf8 xs[3];
+			split3(in[it], s, xs);
+			bf8 w[3][NO];
+#pragma unroll
+			for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+				for (int ot = 0; ot < NO; ++ot) w[pl][ot] = wv[pl * PLANE + ((ot * NI + it) * 2 + s) * 64];
+#pragma unroll
+			for (int t = 0; t < 6; ++t) {
+				if constexpr (SPLIT) {
+					if (t < 5) alt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], xs[PX[t]], alt, 0, 0, 0);
+					else out[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], xs[PX[t]], out[0], 0, 0, 0);
+				} else {
+#pragma unroll
+					for (int ot = 0; ot < NO; ++ot) out[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][ot], xs[PX[t]], out[ot], 0, 0, 0);
+				}
+			}
+		}
+	if constexpr (SPLIT) {
+#pragma unroll
+		for (int j = 0; j < 16; ++j) out[0][j] += alt[j];
+	}
+	if (act == NR3D_MLP_ACT_RELU) {
+#pragma unroll
+		for (int ot = 0; ot < NO; ++ot)
+#pragma unroll
+			for (int j = 0; j < 16; ++j) out[ot][j] = fmaxf(out[ot][j], 0.0f);
+	}
 }
 
 // rows of a [n, dim] matrix on the register map: lane (s = lane & 31, h = lane >> 5) owns features 32t + 8q + 4h + b
@@ -287,13 +405,15 @@ __device__ __forceinline__ void prefetch_x(const float *__restrict__ p, int64_t 
 	else load_rows_fast<NT>(p, stride, dim, row_clamped, lane, r);
 }
 
-template <int IN_T, int W_T, int OUT_T, int XF>
-__global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
+// (X3, one input and one output tile, hidden layers up to 64 wide: two workgroups per CU = two waves per SIMD -- the piece splitting is VALU work, the products MFMA work, and
+// only ANOTHER wave's instructions overlap them; at 260 registers the first version ran one wave per SIMD and the two added up)
+template <int IN_T, int W_T, int OUT_T, int XF, bool X3 = false>
+__global__ __launch_bounds__(kThreads, (X3 && IN_T == 1 && W_T <= 2 && OUT_T == 1) ? 2 : 1) void k_mlp_fwd(FwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
-	stage_weights(a.packed, a.packed_floats, lds);
+	stage_weights(a.packed, a.packed_floats, lds);          // (X3: a.packed points at the x3 region, a.packed_floats is its size)
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint64_t n_tiles = (a.n + 31) / 32, step = (uint64_t)gridDim.x * 4;
-	const uint32_t off_hidden = layer_floats(IN_T, W_T), sz_hidden = layer_floats(W_T, W_T);
+	const uint32_t off_hidden = X3 ? layer_x3_floats(IN_T, W_T) : layer_floats(IN_T, W_T), sz_hidden = X3 ? layer_x3_floats(W_T, W_T) : layer_floats(W_T, W_T);
 	auto clamp_row = [&](uint64_t row) { return row < a.n ? row : a.n - 1; };
 	f16v xnext[IN_T];
 	if (XF) prefetch_x<XF, IN_T>(a.x, a.xs, a.in_dim, clamp_row(((uint64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31)), lane, xnext);
@@ -315,15 +435,18 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(FwdArgs a) {
 		uint32_t opaque = 0;
 		if constexpr (IN_T >= 4 || W_T >= 4 || OUT_T >= 4) asm volatile("s_mov_b32 %0, 0" : "=s"(opaque));
 		const float *wl = lds + opaque;
-		dense<IN_T, W_T, true>(wl, xin, hcur, a.hidden_act, lane);
+		if constexpr (X3) dense_x3<IN_T, W_T, true>(wl, xin, hcur, a.hidden_act, lane);
+		else dense<IN_T, W_T, true>(wl, xin, hcur, a.hidden_act, lane);
 #pragma unroll 1
 		for (uint32_t l = 1; l + 1 < a.n_layers; ++l) {
 			f16v hn[W_T];
-			dense<W_T, W_T, true>(wl + off_hidden + (l - 1) * sz_hidden, hcur, hn, a.hidden_act, lane);
+			if constexpr (X3) dense_x3<W_T, W_T, true>(wl + off_hidden + (l - 1) * sz_hidden, hcur, hn, a.hidden_act, lane);
+			else dense<W_T, W_T, true>(wl + off_hidden + (l - 1) * sz_hidden, hcur, hn, a.hidden_act, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
 		}
-		dense<W_T, OUT_T, true>(wl + off_hidden + (a.n_layers - 2) * sz_hidden, hcur, yo, a.out_act, lane);
+		if constexpr (X3) dense_x3<W_T, OUT_T, true>(wl + off_hidden + (a.n_layers - 2) * sz_hidden, hcur, yo, a.out_act, lane);
+		else dense<W_T, OUT_T, true>(wl + off_hidden + (a.n_layers - 2) * sz_hidden, hcur, yo, a.out_act, lane);
 		store_rows<OUT_T>(a.y, a.ys, a.out_dim, row, valid, a.y_vec != 0, lane, yo);
 	}
 }
@@ -362,7 +485,7 @@ struct BwdArgs {
 	const float *gy; int64_t gys;
 	float *gx; int64_t gxs;                    // NULL: dL/dx not wanted
 	uint32_t x_fm, gx_fm;                      // x is read / dL/dx is stored feature-major (xs / gxs = feature stride)
-	const float *packed;                       // [forward layers | transposed layers]
+	const float *packed, *packed_t;            // forward layers; transposed layers (behind the forward part of the packed buffer)
 	uint32_t fwd_floats, total_floats;
 	float *dW[NR3D_MLP_MAX_LAYERS];            // accumulated into (atomics): zero them for plain gradients
 	float *db[NR3D_MLP_MAX_LAYERS];            // may be NULL
@@ -467,9 +590,10 @@ template <int IN_T, int W_T, int OUT_T, int NH, int FAST>
 __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	{
-		const f4v *src = reinterpret_cast<const f4v *>(a.packed);
+		const f4v *src = reinterpret_cast<const f4v *>(a.packed), *src_t = reinterpret_cast<const f4v *>(a.packed_t);
 		f4v *dst = reinterpret_cast<f4v *>(lds);
-		for (uint32_t i = threadIdx.x; i < a.total_floats / 4; i += blockDim.x) dst[i] = src[i];
+		const uint32_t nf = a.fwd_floats / 4;
+		for (uint32_t i = threadIdx.x; i < a.total_floats / 4; i += blockDim.x) dst[i] = i < nf ? src[i] : src_t[i - nf];
 		__syncthreads();
 	}
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -581,11 +705,14 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 using namespace nr3d;
 using namespace nr3d::mlp;
 
+// the forward part of the packed buffer: [f32 layers | x3 planes of the same layers (0 floats when they do not fit LDS)]
+static uint64_t forward_floats(const Shape &s) { return packed_floats(s) + x3_floats(s); }
+
 extern "C" uint64_t nr3d_mlp_packed_floats(const nr3d_mlp_desc_t *desc) {
 	Shape s;
 	if (!shape_of(desc, s)) return 0;
 	const uint64_t n = packed_floats(s);
-	return n * 4 <= (uint64_t)kMaxLds ? n : 0;      // 0: the fused kernels do not apply to this network
+	return n * 4 <= (uint64_t)kMaxLds ? forward_floats(s) : 0;      // 0: the fused kernels do not apply to this network
 }
 
 static int fill_pack(const nr3d_mlp_desc_t *d, const Shape &s, const float *const *weights, const float *const *biases, PackArgs &p) {
@@ -650,6 +777,13 @@ extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *we
 	PackArgs p;
 	if (int rc = fill_pack(desc, s, weights, biases, p)) return rc;
 	hipLaunchKernelGGL(k_mlp_pack, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, p, packed);
+	if (x3_floats(s)) {
+		PackArgs x = p;
+		uint32_t off = 0;
+		for (uint32_t l = 0; l < desc->n_layers; ++l) { x.offset[l] = off; off += layer_x3_floats(p.ni[l], p.no[l]); }
+		x.offset[desc->n_layers] = off;
+		hipLaunchKernelGGL(k_mlp_pack_x3, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, x, packed + packed_floats(s));
+	}
 	if (with_backward) {
 		// the layers of dH_{l} = W_l^T dPre_{l+1}: packed input tiles = the forward layer's output tiles and vice versa
 		PackArgs t = p;
@@ -661,7 +795,7 @@ extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *we
 			off += layer_floats(t.ni[l], t.no[l]);
 		}
 		t.offset[desc->n_layers] = off;
-		hipLaunchKernelGGL(k_mlp_pack, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, t, packed + packed_floats(s));
+		hipLaunchKernelGGL(k_mlp_pack, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, t, packed + forward_floats(s));
 	}
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -695,6 +829,8 @@ extern "C" int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const f
 	NR3D_CHECK(!x_fm || x_stride == 1, "mlp_forward: x must be row-major (feature stride 1) or feature-major (row stride 1)");
 	a.n = n; a.x = x; a.xs = x_fm ? x_feature_stride : x_stride; a.y = y; a.ys = y_stride; a.packed = packed;
 	a.packed_floats = (uint32_t)packed_floats(s);
+	const bool x3 = x3_enabled() && x3_floats(s) != 0;
+	if (x3) { a.packed = packed + packed_floats(s); a.packed_floats = (uint32_t)x3_floats(s); }
 	a.n_layers = desc->n_layers; a.in_dim = desc->dims[0]; a.out_dim = desc->dims[desc->n_layers];
 	a.hidden_act = (int)desc->hidden_activation; a.out_act = (int)desc->output_activation;
 	a.x_vec = ((uintptr_t)x % 16 == 0 && x_stride % 4 == 0) ? 1u : 0u;
@@ -715,7 +851,23 @@ extern "C" int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const f
 			}
 			attr[dev & 63] = true;
 		}
-		if (x_fm)
+		if (x3) {
+			static bool attr3[64] = {};
+			if (!attr3[dev & 63]) {
+				if (hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess ||
+				    hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess ||
+				    hipFuncSetAttribute((const void *)k_mlp_fwd<IN_T, W_T, OUT_T, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+					rc = ::nr3d::fail("mlp_forward: cannot raise the dynamic LDS limit"); return;
+				}
+				attr3[dev & 63] = true;
+			}
+			if (x_fm)
+				hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, 2, true>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+			else if (a.x_vec && a.in_dim % 4 == 0)
+				hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, 1, true>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+			else
+				hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, 0, true>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
+		} else if (x_fm)
 			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, 2>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
 		else if (a.x_vec && a.in_dim % 4 == 0)
 			hipLaunchKernelGGL((k_mlp_fwd<IN_T, W_T, OUT_T, 1>), dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, a);
@@ -743,6 +895,7 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	a.x_fm = x_fm ? 1u : 0u; a.gx_fm = gx_fm ? 1u : 0u;
 	a.fwd_floats = (uint32_t)packed_floats(s);
 	a.total_floats = a.fwd_floats + (uint32_t)transposed_floats(s);
+	a.packed_t = packed + forward_floats(s);               // (the x3 planes of the forward sit in between)
 	for (uint32_t l = 0; l < desc->n_layers; ++l) {
 		NR3D_CHECK(dL_dW[l] != nullptr, "mlp_backward: dL_dW[%u] is NULL", l);
 		a.dW[l] = dL_dW[l];

@@ -450,3 +450,29 @@ def test_half_fused_agrees_with_the_autocast_layers(dev):
     assert float((outs[True][0] - outs[False][0]).abs().max()) <= 2.0 ** -8 * scale
     for a, b in zip(outs[True][2], outs[False][2]):
         assert float((a - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("dims", [[32, 64, 64, 16], [18, 32, 3], [64, 64, 64, 64], [100, 128, 128, 7], [5, 17, 9]])
+def test_fp32_forward_on_the_bf16_mfma_is_fp32_grade(dev, hip_option, dims):
+    """the fp32 forward's two routes (round 5): the f32 MFMA (mlp_x3 = 0) and the bf16 MFMA on three-piece splits of every value with the
+    six significant piece products (1, default) -- against the same layers in float64: the split route must be as close to it as the
+    f32 route is (both carry fp32 rounding of the accumulations; the split drops terms below 2^-26 of a product)"""
+    m = _net(dims, "relu", None, True, dev, seed=13)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = (torch.randn(4099, dims[0], generator=g) * torch.logspace(-3, 3, dims[0])[None, :].clamp(1e-2, 30)).to(dev)    # columns of very different scale
+    with torch.no_grad():
+        ref = x.double()
+        for i, l in enumerate(m.layers):
+            ref = torch.nn.functional.linear(ref, l.weight.double(), None if l.bias is None else l.bias.double())
+            if i + 1 < len(m.layers):
+                ref = torch.relu(ref)
+    scale = float(ref.abs().max())
+    err = {}
+    for mode in (0, 1):
+        hip_option("mlp_x3", mode)
+        with torch.no_grad():
+            y = m(x)
+        assert torch.isfinite(y).all()
+        err[mode] = float((y.double() - ref).abs().max()) / scale
+    assert err[0] < 5e-6 and err[1] < 5e-6, err
+    assert err[1] <= 3.0 * err[0] + 2e-7, f"three-piece bf16 route {err[1]:.2e} against the f32 MFMA's {err[0]:.2e}"
