@@ -412,7 +412,9 @@ int nr3d_occ_apply_max(uint64_t n_voxels, float ema_decay, const float *vmax, fl
  * Fused fully-connected decoder -- the MLP right after the encoder: nr3d_lib/models/blocks/mlp.py:27-127 (`MLP` /
  * `FCBlock`: D hidden DenseLayers + an output layer, nr3d_lib/models/layers.py:228-300), in the reference a chain of
  * GEMM + elementwise launches (or tiny-cuda-nn's fused fp16 network behind nr3d_lib/models/tcnn_adapter.py:74-237).
- * fp32 in / fp32 accumulate on the f32 MFMA; the whole network in one kernel, activations in registers.
+ * fp32 in / fp32 accumulate; the whole network in one kernel, activations in registers.  Forward: on the bf16 MFMA with every value
+ * split into three bf16 pieces and the six significant piece products (fp32-grade; NR3D_OPT_MLP_X3, ABI 5) or on the f32 MFMA; backward:
+ * f32 MFMA.  The packed buffer holds [f32 layers | the layers' bf16 pieces | transposed f32 layers (with_backward)]: opaque to the caller.
  *   dims[0] = in_features, dims[1..n_layers-1] = hidden widths, dims[n_layers] = out_features; every width 1..128;
  *   weights[l]: f32 [dims[l+1], dims[l]] row-major (torch nn.Linear layout), biases[l]: f32 [dims[l+1]] or NULL.
  * nr3d_mlp_packed_floats: size of the packed-weights buffer, or 0 when the fused kernels do not apply (a single
