@@ -626,11 +626,17 @@ def mlp_decoder_rate(dev, log2n=22, iters=20, dims=(32, 64, 64, 16), with_torch=
     f = out["fused"]
     bwd_ms = f["fwd_bwd_ms"] - f["fwd_ms"]
     peak = 157.3
+    # the forward runs on the bf16 MFMA with three-piece splits (csrc/mlp.hip dense_x3; option mlp_x3): six bf16 products per fp32
+    # product, so its ceiling in fp32 FLOPs is the dense bf16 peak / 6; the backward runs on the f32 MFMA
+    from nr3d_lib_amd import _hip as H
+    x3 = bool(H.get_option("mlp_x3"))
+    peak_fwd = 2500.0 / 6.0 if x3 else peak
     tf_fwd = 2 * mac * n / (f["fwd_ms"] * 1e-3) / 1e12
     tf_bwd = 2 * 3 * mac * n / (bwd_ms * 1e-3) / 1e12         # recomputed forward + dH chain + dW
     return dict(workload=f"fused MLP {dims} (ReLU), 2^{log2n} samples, fp32 (+ `half`: the same network as MLP(dtype=half) on the f16 MFMA)", fused=f, torch=out["torch"], half=half,
                 msamples_per_s_fwd=round(n / f["fwd_ms"] / 1e3, 1), msamples_per_s_fwd_bwd=round(n / f["fwd_bwd_ms"] / 1e3, 1),
-                roofline=dict(bound="mfma", unit="TFLOP/s", peak=peak, fwd_achieved=round(tf_fwd, 1), fwd_frac=round(tf_fwd / peak, 3),
+                roofline=dict(bound="mfma", unit="TFLOP/s", peak=peak, fwd_route="bf16 MFMA, 3-piece splits (6 products)" if x3 else "f32 MFMA",
+                              fwd_peak=round(peak_fwd, 1), fwd_achieved=round(tf_fwd, 1), fwd_frac=round(tf_fwd / peak_fwd, 3),
                               bwd_achieved=round(tf_bwd, 1), bwd_frac=round(tf_bwd / peak, 3)))
 
 
