@@ -189,6 +189,7 @@ int sort_pairs(void *tmp, int batch, const uint32_t *const *kin, const uint32_t 
                uint32_t n_max, const uint32_t *n_dev, int bits, hipStream_t st) {
 	NR3D_CHECK(batch == 1 || batch == 2, "rsort: batch %d", batch);
 	NR3D_CHECK(bits >= 0 && bits <= 32, "rsort: %d key bits", bits);
+	NR3D_CHECK(n_max < (1u << 31), "rsort: %u elements in one call, the limit is 2^31 - 1 (32-bit positions, a tile may overhang)", n_max);
 	if (n_max == 0) return 0;
 	bits = bits < 1 ? 1 : bits;
 	// 8-bit digits when they need no more passes than 9-bit ones (half the counters)
