@@ -22,6 +22,11 @@ extern "C" {
 
 enum { NR3D_F32 = 0, NR3D_F16 = 1, NR3D_F64 = 2, NR3D_I32 = 3, NR3D_I64 = 4, NR3D_U8 = 5, NR3D_I16 = 6, NR3D_I8 = 7 };
 
+/* Bumped whenever an entry point is added, removed or changes its parameters.  nr3d_lib_amd/_abi.py (generated from this header by
+ * tools/gen_abi.py at build time) carries the same number next to every entry point's argument types; the Python loader refuses a
+ * library whose nr3d_abi_version() differs, so a vendored nr3d_lib_amd/ needs this header neither at import nor at run time. */
+#define NR3D_ABI_VERSION 6
+
 const char *nr3d_last_error(void);
 int nr3d_abi_version(void);
 
@@ -48,8 +53,13 @@ int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, int reset);
 /* Selectable code paths (round 4: ONE table instead of environment switches; no launch reads the environment).
  * Every entry chooses between two implementations of the SAME result -- the parity tests run both and compare them with
  * each other and with the oracle -- so a caller never needs them; they exist for A/B measurement and cross-checks.
- * nr3d_set_option(id, value): value < 0 restores the default; returns nonzero for an unknown id.  Process-wide, read at
- * launch time: set them before other threads launch (a plain int, no lock).  nr3d_get_option: current value, -1 if unknown.
+ * nr3d_set_option(id, value): value < 0 restores the default; returns nonzero for an unknown id.  nr3d_get_option: current value,
+ * -1 if unknown.
+ * TEST / MEASUREMENT ONLY -- not part of the drop-in surface.  The table is process-wide on purpose (an option set on the Python main
+ * thread has to reach the launches PyTorch's autograd engine issues from ITS device thread, which a thread-local table would not);
+ * entries are relaxed atomics, so a concurrent set/launch is not a data race, but two host threads that A/B DIFFERENT values at the
+ * same time see each other's choice -- results stay correct (both implementations give the same result), measurements do not.
+ * Production callers never set one: every default is the measured-fastest path.
  * Measurement knobs and timing experiments are NOT options: they exist only in a -DNR3D_EXPERIMENTS build. */
 enum {
 	NR3D_OPT_LOTD_PAIR = 0,          /* 1: pair / quad records for dL/dparam of 3-D Dense/Hash metas (lotd_pair.hip); 0: corner records */
@@ -79,7 +89,11 @@ enum {
 	                                  * (block, coordinate) and accumulates every VM level band by band in LDS, without records (lotd_sorted.inc;
 	                                  * single tables, batches and forests); 2: whenever the geometry allows (tests); 0: records */
 	NR3D_OPT_MLP_X3 = 21,            /* 1: the fp32 fused MLP forward runs on the bf16 MFMA with every value split into three bf16 pieces (six piece products,
-	                                  * fp32 accumulation: fp32-grade results at 2.7x the matrix rate of the f32 MFMA); 0: v_mfma_f32_32x32x2_f32 */
+	                                  * fp32 accumulation: fp32-grade results at 2.7x the matrix rate of the f32 MFMA); 0: v_mfma_f32_32x32x2_f32.
+	                                  * Non-finite inputs: a row holding +-inf (or a magnitude above the bf16 maximum, 3.39e38) comes out as NaN on the
+	                                  * x3 route (inf - bf16(inf) = NaN in the split) where the f32 MFMA gives +-inf or NaN (inf * 0); finite rows of the
+	                                  * same batch are unaffected on both.  A ReLU pre-activation within ~1 ulp of zero may be masked differently by a
+	                                  * forward on one route and a backward recomputation on the other (the gradient of that unit at that sample only). */
 	NR3D_OPT_COUNT = 22
 };
 int nr3d_set_option(int id, int64_t value);

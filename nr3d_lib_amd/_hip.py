@@ -11,9 +11,11 @@ import threading
 
 import torch
 
+from nr3d_lib_amd import _abi
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libnr3d_hip.so")
-ABI_VERSION = 5          # nr3d_abi_version() of the library these bindings were written against (include/nr3d_hip.h)
+ABI_VERSION = _abi.ABI_VERSION      # NR3D_ABI_VERSION of include/nr3d_hip.h when _abi.py was generated; the library must report the same
 CSRC = os.path.join(_PKG, "csrc")
 
 # dtype codes of include/nr3d_hip.h
@@ -36,6 +38,17 @@ def build(verbose=False, jobs=None):
         print(res.stdout)
     if res.returncode != 0:
         raise RuntimeError("nr3d_lib_amd: building libnr3d_hip.so failed (see output above)")
+    # the signature table the loader uses, regenerated from the header the library was just built against (source checkouts only: a
+    # vendored package has no tools/ and keeps the table it came with)
+    gen = os.path.join(os.path.dirname(_PKG), "tools", "gen_abi.py")
+    if os.path.exists(gen):
+        import importlib
+        import sys
+        r = subprocess.run([sys.executable, gen], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("nr3d_lib_amd: tools/gen_abi.py failed:\n" + r.stdout)
+        importlib.reload(_abi)
+        globals()["ABI_VERSION"] = _abi.ABI_VERSION
     return LIB_PATH
 
 
@@ -63,35 +76,28 @@ def lib():
 
 
 _CTYPE = {"int": C.c_int, "int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
-          "float": C.c_float, "double": C.c_double, "void": None, "const char *": C.c_char_p}
+          "float": C.c_float, "double": C.c_double, "void": None, "str": C.c_char_p, "ptr": C.c_void_p}
 
 
 def _declare(l):
-    """argtypes / restype of EVERY entry point, read from include/nr3d_hip.h (round 5).  With them the bindings pass plain Python
+    """argtypes / restype of EVERY entry point, from the table tools/gen_abi.py generated out of include/nr3d_hip.h at build time
+    (nr3d_lib_amd/_abi.py -- inside the package: a vendored copy needs no header).  With them the bindings pass plain Python
     ints / floats -- ``ptr()`` is ``tensor.data_ptr()``, no ctypes object per argument (a launch-bound op spent ~10 us per iteration
     wrapping ~50 arguments) -- and a Python int can no longer be taken for a 32-bit C int where a pointer is meant: every pointer
-    parameter is declared c_void_p (which also takes None, ctypes arrays and byref() results).  A declaration this cannot parse, or
-    an exported symbol without one, is an error here, not a truncated pointer later."""
-    import re
-    header = os.path.join(os.path.dirname(_PKG), "include", "nr3d_hip.h")
-    if not os.path.exists(header):
-        raise RuntimeError(f"nr3d_lib_amd: {header} not found (the bindings read the entry points' signatures from it)")
-    txt = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
-    txt = re.sub(r"//[^\n]*", "", txt)
-    decls = re.findall(r"\b((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*(?:\s*\*)?)\s*\b(nr3d_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S)
-    if len(decls) < 80:
-        raise RuntimeError(f"nr3d_lib_amd: only {len(decls)} entry points parsed from {header}")
-    for ret, name, args in decls:
-        fn = getattr(l, name)
-        ret = " ".join(ret.split())
+    parameter is declared c_void_p (which also takes None, ctypes arrays and byref() results).  An entry point of the table that
+    the library does not export is an error here, not a crash later; that the table matches the header one to one, and the
+    library's exports match both, is tests/test_boundary_cpu.py's job (it regenerates the table and runs nm)."""
+    missing = []
+    for name, (ret, args) in _abi.SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError:
+            missing.append(name)
+            continue
         fn.restype = _CTYPE[ret]
-        at = []
-        for a in args.split(","):
-            a = " ".join(a.split())
-            if a in ("", "void"):
-                continue
-            at.append(C.c_void_p if ("*" in a or "[" in a) else _CTYPE[" ".join(a.split()[:-1]).replace("const ", "")])
-        fn.argtypes = at
+        fn.argtypes = [_CTYPE[a] for a in args]
+    if missing:
+        raise RuntimeError(f"nr3d_lib_amd: {LIB_PATH} does not export {missing} (stale build? `make -C nr3d_lib_amd/csrc`)")
 
 
 # ---- debug hook: poison every uninitialised output -----------------------------------------------------------------
@@ -157,16 +163,14 @@ OPTION_IDS = dict(lotd_pair=0, pair_quad=1, pair_second=2, pair_direct=3, pair_f
 
 def set_option(name, value):
     """choose between two implementations of the same result (A/B measurement, cross-checks in the tests); value < 0 (or None)
-    restores the default.  Process-wide: set it before other threads launch."""
+    restores the default.  TEST / MEASUREMENT ONLY, process-wide (it has to reach the launches of autograd's device thread):
+    include/nr3d_hip.h."""
     l = lib()
-    l.nr3d_set_option.argtypes = [C.c_int, C.c_int64]
     check(l.nr3d_set_option(OPTION_IDS[name], -1 if value is None else int(value)))
 
 
 def get_option(name):
     l = lib()
-    l.nr3d_get_option.restype = C.c_int64
-    l.nr3d_get_option.argtypes = [C.c_int]
     return int(l.nr3d_get_option(OPTION_IDS[name]))
 
 

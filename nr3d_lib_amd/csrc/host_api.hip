@@ -55,7 +55,7 @@ static const int64_t kDefault[NR3D_OPT_COUNT] = {
 	/* CP_DIRECT */ 1, /* MARCH_GROUP */ 0, /* PACK_SCAN */ 1, /* VM_LINES_DIRECT */ 0, /* FWD_CELL_MAJOR */ 1, /* SORT_WAVE */ 1,
 	/* VM_DIRECT */ 1, /* DIRECT_FIXED */ 1, /* VM_SORTED */ 1, /* MLP_X3 */ 1,
 };
-int64_t g_val[NR3D_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1, 1, 1, 1};
+std::atomic<int64_t> g_val[NR3D_OPT_COUNT] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1, 1, 1, 1};
 
 #ifdef NR3D_EXPERIMENTS
 // measurement knobs of the experiments build: NR3D_<NAME> from the environment, looked up once per name
@@ -99,13 +99,13 @@ extern "C" int nr3d_prof_read(int id, double *total_ms, uint32_t *n_intervals, i
 
 extern "C" int nr3d_set_option(int id, int64_t value) {
 	NR3D_CHECK(id >= 0 && id < NR3D_OPT_COUNT, "nr3d_set_option: unknown option %d", id);
-	opt::g_val[id] = value < 0 ? opt::kDefault[id] : value;
+	opt::g_val[id].store(value < 0 ? opt::kDefault[id] : value, std::memory_order_relaxed);
 	return 0;
 }
-extern "C" int64_t nr3d_get_option(int id) { return (id >= 0 && id < NR3D_OPT_COUNT) ? opt::g_val[id] : -1; }
+extern "C" int64_t nr3d_get_option(int id) { return (id >= 0 && id < NR3D_OPT_COUNT) ? opt::get(id) : -1; }
 
 extern "C" const char *nr3d_last_error(void) { return err_buf(); }
-extern "C" int nr3d_abi_version(void) { return 5; }
+extern "C" int nr3d_abi_version(void) { return NR3D_ABI_VERSION; }
 
 extern "C" uint64_t nr3d_sort_pairs_u32_tmp_bytes(uint32_t n_max, int batch) { return (uint64_t)rsort::tmp_bytes(n_max, batch == 2 ? 2 : 1); }
 extern "C" int nr3d_sort_pairs_u32(void *tmp, int batch, const uint32_t *kin0, const uint32_t *vin0, uint32_t *kout0, uint32_t *vout0,

@@ -1855,6 +1855,12 @@ extern "C" int nr3d_lotd_dLdy_feature_major(uint32_t n_points, uint32_t n_encode
 	return 0;
 }
 
+static_assert(sizeof(nr3d_lotd_meta_t) % 4 == 0 && sizeof(nr3d_lotd_meta_t) <= 3584, "the narrowed meta rides in the kernel arguments");
+__global__ void k_store_meta(const nr3d_lotd_meta_t m, uint32_t *__restrict__ dst) {
+	const uint32_t *src = (const uint32_t *)&m;
+	for (uint32_t i = threadIdx.x; i < sizeof(nr3d_lotd_meta_t) / 4; i += blockDim.x) dst[i] = src[i];
+}
+
 namespace nr3d {
 namespace lotd {
 
@@ -1876,8 +1882,12 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 	if (workspace_bytes < lay.total + (narrowed ? kStageAMetaBytes : 0)) return 0;
 	handled = true;
 	if (narrowed) {
-		// (pageable source: the runtime stages the 2.6 KB before it returns, `narrow` may go out of scope)
-		NR3D_HIP_CHECK(hipMemcpyAsync((char *)workspace + lay.total, &narrow, sizeof(narrow), hipMemcpyHostToDevice, st));
+		// the narrowed meta travels BY VALUE in a launch's kernel arguments (2.6 KB of the 4 KB a launch may carry) and one
+		// workgroup writes it to the end of the workspace: no host pointer outlives this call (round-5 advisor: an async copy
+		// from the stack-local `narrow` relied on the runtime staging pageable memory before returning, and a stream capture
+		// would have kept the dangling pointer)
+		k_store_meta<<<1, 256, 0, st>>>(narrow, (uint32_t *)((char *)workspace + lay.total));
+		NR3D_HIP_CHECK(hipGetLastError());
 		meta_dev = (char *)workspace + lay.total;
 	}
 	const auto md = (const nr3d_lotd_meta_t *)meta_dev;

@@ -10,15 +10,18 @@
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include "../../include/nr3d_hip.h"
 
 namespace nr3d {
 namespace opt {
 
-extern int64_t g_val[NR3D_OPT_COUNT];            // host_api.hip (defaults there)
+// process-wide on purpose (autograd launches from its own thread), relaxed atomics: a concurrent set / launch is not a data race
+// (include/nr3d_hip.h: test / measurement only)
+extern std::atomic<int64_t> g_val[NR3D_OPT_COUNT];            // host_api.hip (defaults there)
 
-static inline int64_t get(int id) { return g_val[id]; }
-static inline bool on(int id) { return g_val[id] != 0; }
+static inline int64_t get(int id) { return g_val[id].load(std::memory_order_relaxed); }
+static inline bool on(int id) { return get(id) != 0; }
 
 #ifdef NR3D_EXPERIMENTS
 int64_t experiment_env(const char *name, int64_t dflt);      // host_api.hip: getenv once per name (cached)

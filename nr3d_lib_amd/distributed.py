@@ -43,13 +43,17 @@ def shard(t: torch.Tensor, rank: Optional[int] = None, world: Optional[int] = No
     return t[a:b]
 
 
-def allreduce_grads(grads: Iterable[Optional[torch.Tensor]], average: bool = False, bucket_bytes: int = 64 << 20):
+def allreduce_grads(grads: Iterable[Optional[torch.Tensor]], average: bool = False, bucket_bytes: int = 64 << 20,
+                    single_rank_too: bool = False):
     """In-place all-reduce(SUM) of parameter gradients, coalesced into flat buckets of <= ``bucket_bytes``.
 
     xGMI is point-to-point (7 links per GPU), so a ring all-reduce is per-link bound and its latency term
     is paid per call: the LoTD gradient (46 MiB for the NGP config) goes out as ONE bucket, small tensors
-    (MLP weights, ...) are packed together instead of being reduced one by one."""
-    if not is_dist() or dist.get_world_size() == 1:
+    (MLP weights, ...) are packed together instead of being reduced one by one.
+    ``single_rank_too``: issue the collectives on a one-rank group as well (a SUM over one rank: values unchanged) -- how the
+    one-GPU bench figure and test exercise the flattening and RCCL's launch path at their real sizes; off by default, a
+    one-rank job has nothing to reduce."""
+    if not is_dist() or (dist.get_world_size() == 1 and not single_rank_too):
         return
     world = dist.get_world_size()
     pending, size = [], 0

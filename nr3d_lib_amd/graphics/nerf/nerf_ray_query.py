@@ -29,11 +29,16 @@ _PASSTHROUGH = ('flow_fwd', 'flow_fwd_pred_bwd', 'flow_bwd', 'flow_bwd_pred_fwd'
                 'sigma_dynamic', 'rgb_dynamic')
 
 
-# Round 5: the differentiable query runs on the rendered samples in SPATIAL order (a Morton curve over their bounding box,
-# nr3d_spatial_order) and its outputs are put back into ray order.  Ray-major samples of neighbouring rays share grid cells but sit
+# The differentiable query may run on the rendered samples in SPATIAL order (a Morton curve over their bounding box,
+# nr3d_spatial_order) with its outputs put back into ray order.  Ray-major samples of neighbouring rays share grid cells but sit
 # a ray's length apart; along the curve they are consecutive lanes, which the LoTD backward merges before its scatter and the
-# forward's gathers coalesce.  Results are the same values in the same places (the field is evaluated point by point); parameter
-# gradients differ by summation order only.  0: off (the reference's order); otherwise bits per dimension of the curve's grid.
+# forward's gathers coalesce.  Results are the same values in the same places IF the field is evaluated point by point; parameter
+# gradients differ by summation order only.
+# OPT-IN (round 6, advisor): the reference always queries in ray order (nerf_ray_query.py:150-166), and the reordering is only valid
+# for a model whose forward is strictly point-wise and returns every per-sample output as a TOP-LEVEL tensor of its dict.  A model
+# declares that with the attribute ``pointwise_forward = True`` (tools/demo_field.py does); without it the query runs in ray order.
+# A per-sample tensor nested in a dict / tuple / list of the output cannot be put back and raises instead of coming out permuted.
+# SPATIAL_ORDER_BITS: 0 = off for every model; otherwise bits per dimension of the curve's grid.
 # Measured on the full loop (262 144 rays, 1.67 M rendered samples; profiles/r05e_full_loop_*): stage B of dL/dparam 673 -> 450 us, the
 # encoder forward on the rendered samples 309 -> 198 us; the order itself costs 190 us (sort 3 x 31, moving inputs / outputs / gradients
 # 35 + 44 + 29, keys and bounds 20) -- 5.45 -> 5.42 ms per iteration at 8 bits (5.49-5.56 at 5-7 bits): it pays for itself, no more.
@@ -41,44 +46,60 @@ SPATIAL_ORDER_BITS = 8
 SPATIAL_ORDER_MIN_SAMPLES = 1 << 19      # below this the backward is launch bound and the order does not pay
 
 
-class _FromSpatialOrder(torch.autograd.Function):
-    """one or two per-sample float32 outputs of the field from the spatial order back to the samples' own order (one launch);
-    backward: the gradients into the spatial order (one launch).  order is a permutation, so neither direction accumulates."""
+class _MoveRows(torch.autograd.Function):
+    """one or two per-sample float32 arrays between the spatial order and the samples' own order (one launch; scatter:
+    out[order[k]] = in[k], else out[k] = in[order[k]]).  order is a permutation, so neither direction accumulates and the
+    backward is the same function in the other direction -- applied as a Function, so a create_graph=True backward keeps its graph."""
 
     @staticmethod
-    def forward(ctx, order, a, b):
+    def forward(ctx, order, a, b, scatter):
         ctx.save_for_backward(order)
-        ctx.two = b is not None
-        a_out, b_out = _H.order_move_rows(order, a, b, scatter=True)
+        ctx.scatter = scatter
+        a_out, b_out = _H.order_move_rows(order, a, b, scatter=scatter)
         return (a_out, b_out) if b is not None else a_out
 
     @staticmethod
     def backward(ctx, ga, gb=None):
         order, = ctx.saved_tensors
+        back = not ctx.scatter
         if ga is not None and gb is not None:
-            g1, g2 = _H.order_move_rows(order, ga, gb, scatter=False)
-            return None, g1, g2
-        g1 = _H.order_move_rows(order, ga, None, scatter=False)[0] if ga is not None else None
-        g2 = _H.order_move_rows(order, gb, None, scatter=False)[0] if gb is not None else None
-        return None, g1, g2
+            g1, g2 = _MoveRows.apply(order, ga, gb, back)
+            return None, g1, g2, None
+        g1 = _MoveRows.apply(order, ga, None, back) if ga is not None else None
+        g2 = _MoveRows.apply(order, gb, None, back) if gb is not None else None
+        return None, g1, g2, None
+
+
+def _nested_per_sample(v, n):
+    if isinstance(v, dict):
+        return any(_nested_per_sample(u, n) or (torch.is_tensor(u) and u.dim() >= 1 and u.shape[0] == n) for u in v.values())
+    if isinstance(v, (list, tuple)):
+        return any(_nested_per_sample(u, n) or (torch.is_tensor(u) and u.dim() >= 1 and u.shape[0] == n) for u in v)
+    return False
 
 
 def _from_spatial_order(order, net_out, n):
-    """every per-sample float32 CUDA tensor of the field's output dict back in the samples' own order, two per launch"""
+    """every per-sample tensor of the field's output dict back in the samples' own order (float32: two per launch)"""
+    for k, v in net_out.items():
+        if _nested_per_sample(v, n):
+            raise RuntimeError(f"nerf_ray_query_march_occ: output {k!r} of a pointwise_forward model nests per-sample tensors in a "
+                               "container; the spatial-order query can only put top-level tensors back into ray order "
+                               "(drop `pointwise_forward`, or return them at the top level)")
     keys = [k for k, v in net_out.items() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n]
     out = dict(net_out)
-    fast = [k for k in keys if net_out[k].dtype == torch.float32]
-    for k in keys:
-        if k not in fast:                                  # other dtypes (half features, integer tags): plain index ops
-            inv = torch.empty_like(order, dtype=torch.int64)
-            inv[order.long()] = torch.arange(n, device=order.device)
+    fast = [k for k in keys if net_out[k].dtype == torch.float32 and net_out[k].is_cuda]
+    slow = [k for k in keys if k not in fast]
+    if slow:                                               # other dtypes (half features, integer tags): one inverse, plain index ops
+        inv = torch.empty(n, dtype=torch.int64, device=order.device)
+        inv[order.long()] = torch.arange(n, device=order.device)
+        for k in slow:
             out[k] = net_out[k].index_select(0, inv)
     for i in range(0, len(fast), 2):
         pair = fast[i:i + 2]
         if len(pair) == 2:
-            out[pair[0]], out[pair[1]] = _FromSpatialOrder.apply(order, net_out[pair[0]], net_out[pair[1]])
+            out[pair[0]], out[pair[1]] = _MoveRows.apply(order, net_out[pair[0]], net_out[pair[1]], True)
         else:
-            out[pair[0]] = _FromSpatialOrder.apply(order, net_out[pair[0]], None)
+            out[pair[0]] = _MoveRows.apply(order, net_out[pair[0]], None, True)
     return out
 
 
@@ -182,7 +203,7 @@ def nerf_ray_query_march_occ(model, ray_tested: Dict[str, torch.Tensor], with_rg
 
     with profile("Query"):
         n_render = samples.shape[0]
-        spatial = (SPATIAL_ORDER_BITS and n_render >= SPATIAL_ORDER_MIN_SAMPLES and samples.is_cuda and samples.dtype == torch.float32
+        spatial = (SPATIAL_ORDER_BITS and _flag(model, 'pointwise_forward') and n_render >= SPATIAL_ORDER_MIN_SAMPLES and samples.is_cuda and samples.dtype == torch.float32
                    and samples.dim() == 2 and samples.shape[1] == 3 and ridx_all.dtype == torch.int64 and torch.is_grad_enabled()
                    and not samples.requires_grad and (view_dirs is None or (view_dirs.dtype == torch.float32 and not view_dirs.requires_grad)))
         if not spatial:

@@ -25,7 +25,45 @@ def test_library_exports_every_header_symbol(hiplib):
                         capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r" T (nr3d_[A-Za-z0-9_]+)", nm)))
     assert exported == declared, (set(exported) ^ set(declared))
-    assert hiplib.nr3d_abi_version() == _hip.ABI_VERSION == 5     # 2: map_col; 3: forest entry points take param_dtype; 4: option table, bwd_fused removed; 5: nr3d_sort_pairs_u32
+    # 2: map_col; 3: forest entry points take param_dtype; 4: option table, bwd_fused removed; 5: nr3d_sort_pairs_u32;
+    # 6: NR3D_ABI_VERSION in the header, signature table generated into the package (round 6)
+    m = re.search(r"#define\s+NR3D_ABI_VERSION\s+(\d+)", header)
+    assert hiplib.nr3d_abi_version() == _hip.ABI_VERSION == int(m.group(1)) >= 6
+
+
+def test_signature_table_is_the_header():
+    """nr3d_lib_amd/_abi.py (what the loader declares argtypes from) is exactly what tools/gen_abi.py makes of the header, covers every
+    declared entry point, and the loader has applied it"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_abi", os.path.join(ROOT, "tools", "gen_abi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    version, sigs = gen.parse(open(gen.HEADER).read())
+    assert open(gen.OUT).read() == gen.render(version, sigs), "nr3d_lib_amd/_abi.py is stale: python tools/gen_abi.py"
+    from nr3d_lib_amd import _abi
+    assert _abi.ABI_VERSION == version and _abi.SIGNATURES == sigs
+    header = re.sub(r"/\*.*?\*/", "", open(gen.HEADER).read(), flags=re.S)
+    assert sorted(sigs) == sorted(set(re.findall(r"\b(nr3d_[A-Za-z0-9_]+)\s*\(", header)))
+    l = _hip.lib()
+    for name, (ret, args) in sigs.items():
+        fn = getattr(l, name)
+        assert len(fn.argtypes) == len(args), name
+        assert all((t is ctypes.c_void_p) == (a == "ptr") for t, a in zip(fn.argtypes, args)), name
+
+
+def test_vendored_package_needs_no_header(tmp_path):
+    """a copy of nr3d_lib_amd/ ALONE (no include/, no tools/, no csrc/) imports, loads the library and resolves every entry point"""
+    import shutil
+    import sys
+    dst = tmp_path / "site" / "nr3d_lib_amd"
+    shutil.copytree(os.path.join(ROOT, "nr3d_lib_amd"), dst, ignore=shutil.ignore_patterns("csrc", "__pycache__"))
+    code = ("import nr3d_lib_amd, nr3d_lib_amd._hip as H, os; l = H.lib(); "
+            "assert os.path.dirname(H.LIB_PATH) == os.path.dirname(nr3d_lib_amd.__file__); "
+            "import nr3d_lib_amd.bindings._lotd, nr3d_lib_amd.bindings._pack_ops, nr3d_lib_amd.bindings._occ_grid; "
+            "print('OK', l.nr3d_abi_version(), nr3d_lib_amd.__file__)")
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True,
+                       env=dict(os.environ, PYTHONPATH=str(tmp_path / "site")))
+    assert r.returncode == 0 and "OK" in r.stdout and str(tmp_path) in r.stdout, r.stdout + r.stderr
 
 
 def test_library_is_gfx950_only():

@@ -231,3 +231,44 @@ def test_spatial_order_of_the_rendered_samples_changes_nothing_but_the_summation
         # the table gradient accumulates in fp64 / fixed point (order independent up to the last rounding); the decoders' weight
         # gradients are fp32 sums over all samples, whose order changes with the samples'
         assert_close(b[2][k], a[2][k].cpu().numpy(), rel=1e-5 if k == "grid" else 2e-4, name=f"grad {k}")
+
+
+def test_spatial_order_is_opt_in_and_refuses_nested_outputs(dev, monkeypatch):
+    """round 6 (advisor): without ``pointwise_forward`` the query runs in the reference's ray order (no spatial_order launch at all);
+    with it, a per-sample tensor nested in a container of the output raises instead of coming back permuted; and the put-back is
+    differentiable twice (a mirror Function, not a raw kernel call)"""
+    from nr3d_lib_amd.graphics.nerf import nerf_ray_query_march_occ
+    from nr3d_lib_amd.graphics.nerf import nerf_ray_query as drv
+    model, rays, occ, step = _scene(dev, side=48, seed=6)
+    monkeypatch.setattr(drv, "SPATIAL_ORDER_MIN_SAMPLES", 1)
+    calls = []
+    real = drv._H.spatial_order
+    monkeypatch.setattr(drv._H, "spatial_order", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    vb_s, _ = nerf_ray_query_march_occ(model, rays, with_rgb=True, compression=True)
+    assert calls, "DemoField opts in: the Morton order runs"
+    calls.clear()
+    monkeypatch.setattr(type(model), "pointwise_forward", False)
+    vb_r, _ = nerf_ray_query_march_occ(model, rays, with_rgb=True, compression=True)
+    assert not calls, "a model that does not declare pointwise_forward is queried in ray order"
+    for k in ("sigma", "rgb", "opacity_alpha"):
+        assert_equal(vb_s[k], vb_r[k], k)
+    monkeypatch.setattr(type(model), "pointwise_forward", True)
+    fwd = type(model).forward
+
+    def nested(self, x, v=None, **kw):
+        out = fwd(self, x, v, **kw)
+        out["aux"] = {"per_sample": out["sigma"] * 2}
+        return out
+    monkeypatch.setattr(type(model), "forward", nested)
+    with pytest.raises(RuntimeError, match="nests per-sample tensors"):
+        nerf_ray_query_march_occ(model, rays, with_rgb=True, compression=True)
+    # double backward through the put-back: d/da of (d/da sum(out^2)) = 2 everywhere
+    n = 5000
+    order = torch.randperm(n, device=dev).int()
+    a = torch.randn(n, 3, device=dev, requires_grad=True)
+    out = drv._MoveRows.apply(order, a, None, True)
+    assert_equal(out[order.long()], a.detach(), "scatter")
+    g, = torch.autograd.grad((out ** 2).sum(), a, create_graph=True)
+    assert g.requires_grad
+    gg, = torch.autograd.grad(g.sum(), a)
+    assert_equal(gg, torch.full_like(gg, 2.0), "second derivative through the permutation")

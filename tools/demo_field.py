@@ -25,6 +25,9 @@ class StaticOccGridAccel:
 
 class DemoField(nn.Module):
     use_view_dirs = True
+    # forward() is evaluated point by point and every per-sample output is a top-level tensor of its dict: the driver may query
+    # the rendered samples along a Morton curve (nerf_ray_query.py: opt-in)
+    pointwise_forward = True
 
     def __init__(self, occ_grid, step_size, max_steps=512, hidden=32, seed=0, device=None, precision="float"):
         """precision: "float" = fp32 end to end, like the headline benchmark; "half" = the reference's default storage -- half LoTD
