@@ -270,7 +270,8 @@ def test_c5_per_rank_shard_2p21_rays(dev, nccl_group_fullsize):
         if backward:
             # sums, not means: a chunk's loss must not depend on how many rays the chunk has
             (out["rgb_volume"].sum() * (1.0 / N) + out["depth_volume"].sum() * (1.0 / N)).backward()
-        return {k: v.detach() for k, v in out.items()}, int(det["march.num_per_ray"].sum()), int(det["render.num_per_ray"].sum())
+        cnt = lambda k: int(det[k].sum()) if k in det else 0          # a piece whose rays all miss the shell: empty buffer, no details
+        return {k: v.detach() for k, v in out.items()}, cnt("march.num_per_ray"), cnt("render.num_per_ray")
 
     # --- the shard as bench.py runs it: 8 chunks, gradients accumulate, one all-reduce ---
     model.zero_grad(set_to_none=True)
