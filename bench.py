@@ -216,7 +216,7 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0, occupancy="ran
     gen = torch.Generator(device="cpu").manual_seed(8)
     state = {}
 
-    def one():
+    def two_phase():
         # march (count + emit) and the post-processing every caller applies (hit rays, int64 packs, interval lengths: two
         # launches, the readback shared with the marcher's), then sigma -> alpha in one launch
         m = _occ_grid.ray_marching_finished(o, d, near, far, roi, grid, _occ_grid.ContractionType.AABB, step, 1e10, 0.0, 512, True)
@@ -236,6 +236,20 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0, occupancy="ran
                                                          mask, depth, state["g"][0], state["g"][1], state["g"][2], None,
                                                          packs_tile=True)
         return S, mask, ga
+
+    def one_call():
+        # round 6: the same work as ONE forward call (count -> scan -> emit -> alpha + composite, four launches, no host wait in
+        # between: per-sample buffers sized by the bound n * 512) + the backward launch, THEN the single readback that sizes the views
+        mc = _occ_grid.ray_marching_composite(o, d, near, far, roi, grid, _occ_grid.ContractionType.AABB, step, 1e10, 0.0, 512,
+                                              state["sigma"], state["rgb"], 1e-4, 0.0, True)
+        mc.backward(state["g"][0], state["g"][1], state["g"][2])
+        return mc.totals()[0], mc.view("mask"), mc.grads()[0]          # the readback; views of what the caller looks at
+    S0 = two_phase()[0]                # sizes sigma / rgb (fixed scene) and is the cross-check of the one-call path
+    fused = n * 512 * 72 <= _occ_grid.FUSED_MARCH_COMPOSITE_MAX_BYTES
+    one = one_call if fused else two_phase
+    if fused:
+        a, b = one_call(), two_phase()
+        assert a[0] == b[0] == S0 and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), "one-call march + composite differs from the chain"
     for _ in range(5):               # >= 5 warm-ups; the caching allocator reaches its steady state
         S = one()[0]
     names = ("march", "composite_fwd", "composite_bwd")
@@ -263,9 +277,12 @@ def march_composite_rate(dev, iters=20, side=64, cpu_seconds=0.0, occupancy="ran
                iters=iters, warmup=5,
                samples=int(S), ms_per_iter=round(ms, 4), mrays_per_s=round(n / ms / 1e3, 4),
                kernel_us_per_iter={k: round(v, 2) for k, v in kus.items()},
-               launches_per_iter="march 2 (count; cached emit + per-sample epilogue) + scan 1 (3 above 32768 rays: packed_info "
-                                 "and the hit rays' compaction in the same scan), sigma -> alpha 1, composite 1 + 1 (+ one zero "
-                                 "fill of the per-ray outputs); one device->host readback")
+               route="one call (nr3d_march_composite_fwd) + backward, readback last" if fused else "two-phase chain (count -> readback -> emit -> alpha -> composite)",
+               launches_per_iter=("count, scan (+ hit rays, totals), cached emit (+ per-sample epilogue), sigma -> alpha + composite over all "
+                                  "rays, composite backward: 5 launches enqueued back to back, ONE device->host readback after the last") if fused else
+                                 ("march 2 (count; cached emit + per-sample epilogue) + scan 1 (3 above 32768 rays: packed_info "
+                                  "and the hit rays' compaction in the same scan), sigma -> alpha 1, composite 1 + 1 (+ one zero "
+                                  "fill of the per-ray outputs); one device->host readback"))
     if cpu_seconds > 0:
         # the oracle's marcher counts the grid probes of the byte model, and is the CPU baseline next to the chain
         probes, S_r, base = cpu_baseline(None, c3=((o_c, d_c, near_c, far_c, roi_c, grid_c), n, step, cpu_seconds))

@@ -25,7 +25,7 @@ enum { NR3D_F32 = 0, NR3D_F16 = 1, NR3D_F64 = 2, NR3D_I32 = 3, NR3D_I64 = 4, NR3
 /* Bumped whenever an entry point is added, removed or changes its parameters.  nr3d_lib_amd/_abi.py (generated from this header by
  * tools/gen_abi.py at build time) carries the same number next to every entry point's argument types; the Python loader refuses a
  * library whose nr3d_abi_version() differs, so a vendored nr3d_lib_amd/ needs this header neither at import nor at run time. */
-#define NR3D_ABI_VERSION 6
+#define NR3D_ABI_VERSION 8
 
 const char *nr3d_last_error(void);
 int nr3d_abi_version(void);
@@ -634,6 +634,42 @@ int nr3d_ray_marching_count_finished(uint32_t n_rays, const float *rays_o, const
                                      uint32_t batch_data_size, int32_t *packed_info, int64_t *ridx_hit, int64_t *pack_infos,
                                      int64_t *totals, void *scan_tmp, void *sample_cache, uint64_t sample_cache_bytes,
                                      void *stream);
+
+/* configs[2] in ONE call (round 6): ray_marching (csrc/occ_grid/src/ray_marching.cu:136-244) + the post-processing of
+ * occgrid_raymarch.py:87-112 + alpha = 1 - exp(-sigma * delta) (nerf_utils.py:23-24) + the renderer's composite chain
+ * (nr3d_lib/models/fields/nerf/renderer_mixin.py:298-311), enqueued back to back with NO device->host wait inside:
+ *   count (+ sample cache) -> scan (+ hit rays, totals) -> cached emit (+ ridx64 / deltas / samples) -> composite over ALL rays.
+ * Every per-sample buffer (t_starts, t_ends, ridx, gidx?, ridx64?, deltas, samples?, alphas, vw) has `rows` >= n_rays * max_steps
+ * rows (the bound; checked) and its first S rows are written -- the same values as nr3d_ray_marching_count_finished +
+ * nr3d_ray_marching_emit_finished + nr3d_tau_to_alpha_fwd + nr3d_pack_composite_fwd, vw / mask / depth / rgb_out bit-identical to
+ * them.  sigma [sigma_rows] / rgb [sigma_rows, 3] (rgb optional): the caller's per-sample density / colour; rows beyond sigma_rows
+ * read as density 0 (the caller compares S with sigma_rows after its readback).  mask / depth [n_rays], rgb_out [n_rays, 3] are
+ * FULLY written (rays without samples: zeros -- no fill).  totals (device-visible, normally pinned host memory) = {S, n_hit}: read it
+ * after a stream synchronisation, AFTER this call returned (and after nr3d_march_composite_bwd was enqueued, if wanted).
+ * Needs the sample cache (nr3d_ray_marching_cache_bytes); single grid only (batched / forest marches keep the two-phase calls). */
+int nr3d_march_composite_fwd(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                             const float *roi, const int32_t grid_res[3], const uint8_t *grid_binary, int type, float step_size,
+                             float max_step_size, float dt_gamma, uint32_t max_steps, int32_t *packed_info, int64_t *ridx_hit,
+                             int64_t *pack_infos, int64_t *totals, void *scan_tmp, void *sample_cache, uint64_t sample_cache_bytes,
+                             uint64_t rows, float *t_starts, float *t_ends, int32_t *ridx, int32_t *gidx, int64_t *ridx64,
+                             float *deltas, float *samples, const float *sigma, uint64_t sigma_rows, const float *rgb,
+                             float early_stop_eps, float alpha_thre, int normalize_depth, float *alphas, float *vw, float *mask,
+                             float *depth, float *rgb_out, void *stream);
+/* Host-side wait for words a kernel writes into device-visible HOST memory (pinned; the `totals` of the two-phase and one-call ops):
+ * spins until none of words[0..n) equals `sentinel` (the caller stores the sentinel before the launch; the kernels store the totals
+ * with system scope) or `timeout_us` passed.  Returns 0 when the words arrived, 1 on timeout (NOT an error: the caller falls back to a
+ * stream synchronisation).  Why: a stream synchronisation returns when EVERYTHING enqueued has drained and costs ~20 us of wake-up
+ * latency; the totals are written by the SECOND of the one-call path's launches, and reading them early lets the host build its views
+ * while the composite kernels still run.  Holds no lock, touches no HIP API. */
+int nr3d_wait_host_words(const int64_t *words, int n, int64_t sentinel, uint32_t timeout_us);
+/* its backward (= nr3d_pack_composite_bwd over all rays of packed_info, no ray_index, no g_vw; the same values): g_mask / g_depth
+ * [n_rays], g_rgb [n_rays, 3] (each may be NULL = zero) -> grad_alphas [S rows written], grad_t / grad_rgb optional; grad_sigma
+ * (optional, needs sigma and deltas) = grad_alphas * exp(-sigma * delta) * delta as nr3d_tau_to_alpha_bwd. */
+int nr3d_march_composite_bwd(uint32_t n_rays, const int32_t *packed_info, const float *alphas, const float *vw, const float *t,
+                             const float *rgb, float early_stop_eps, float alpha_thre, int normalize_depth, const float *mask,
+                             const float *depth, const float *g_mask, const float *g_depth, const float *g_rgb, float *grad_alphas,
+                             float *grad_t, float *grad_rgb, const float *sigma, const float *deltas, uint64_t sigma_rows,
+                             float *grad_sigma, void *stream);
 
 /* nr3d_ray_marching_emit from the sample cache of nr3d_ray_marching_count AND nr3d_march_finish_samples in one launch
  * (the cached emit is a per-ray copy: the epilogue rides on it): t_starts / t_ends / ridx (/ bidx / gidx) as

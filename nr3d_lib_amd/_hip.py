@@ -340,12 +340,21 @@ def host_i64(n, device):
     buf = pinned.get(key)
     if buf is None:
         buf = pinned[key] = torch.empty(n, dtype=torch.int64, pin_memory=True)
+    buf.fill_(_SENTINEL)                    # what wait_i64 polls against (totals are counts: never negative)
     return buf
 
 
+_SENTINEL = -1
+POLL_TIMEOUT_US = 5000
+
+
 def wait_i64(buf, device):
-    """the values a kernel wrote into ``host_i64``'s buffer: THE device->host sync of a two-phase op"""
-    torch.cuda.current_stream(device).synchronize()
+    """the values a kernel wrote into ``host_i64``'s buffer: THE device->host sync of a two-phase op.  The kernels store their totals
+    with system scope, so the host polls the pinned words (nr3d_wait_host_words: ~2 us after the store) instead of draining the
+    stream (~20 us of wake-up latency, paid on the critical path of every launch-bound op); if the words do not arrive within
+    POLL_TIMEOUT_US (not observed; e.g. a pinned pool that is not host-coherent), the stream is drained as before."""
+    if lib().nr3d_wait_host_words(buf.data_ptr(), buf.numel(), _SENTINEL, POLL_TIMEOUT_US) != 0:
+        torch.cuda.current_stream(device).synchronize()
     return buf.tolist()
 
 

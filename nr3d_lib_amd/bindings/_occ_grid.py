@@ -8,6 +8,7 @@ sample count (needed to size the outputs -- the reference syncs at the same poin
 """
 import ctypes as C
 import enum
+import threading
 
 import torch
 
@@ -224,3 +225,186 @@ def forest_ray_marching(forest, rays_o, rays_d, t_min, t_max, seg_block_inds, se
                                                           H.ptr(t_starts), H.ptr(t_ends), H.ptr(ridx), H.ptr(blidx),
                                                           H.ptr(gidx), st))
     return [packed_info, t_starts, t_ends, ridx, blidx, gidx]
+
+
+# ---- configs[2] in one call (round 6) -------------------------------------------------------------------------------------------
+# largest bound (n_rays * max_steps rows x ~72 B) the one-call path allocates; above it the two-phase chain (count -> readback ->
+# emit -> alpha -> composite) runs, whose buffers are sized by the actual sample count
+FUSED_MARCH_COMPOSITE_MAX_BYTES = 512 << 20
+
+
+_totals_tls = threading.local()
+_TOTALS_LIMBO = []       # pinned words of handles dropped before their totals were read: kept alive (a late kernel may still write them)
+
+
+def _take_totals():
+    """a pinned int64 [2] of this handle's own (two outstanding handles must not share the word the kernels write into)"""
+    free = getattr(_totals_tls, "free", None)
+    if free is None:
+        free = _totals_tls.free = []
+    return free.pop() if free else torch.empty(2, dtype=torch.int64, pin_memory=True)
+
+
+class MarchComposite:
+    """What ``ray_marching_composite`` returns: the buffers of ONE march + alpha composite whose kernels are (being) enqueued, and the
+    two totals that are read back LAZILY -- ``totals()`` is the op's single device->host sync, and everything that does not need a
+    tensor SHAPE (enqueueing ``backward``) can happen before it.  Tensor views are built on demand (``view(name)``: exactly-sized;
+    the launch-bound caller pays only for what it looks at):
+      per ray   packed_info int32 [n, 2], mask / depth [n], rgb [n, 3] (zeros for rays without samples), ridx_hit int64 [n_hit],
+                pack_infos int64 [n_hit, 2] (tagged ordered, tiling [0, S));
+      per sample [S]: t_starts, t_ends, ridx (int64), ridx32, gidx, deltas, samples [S, 3], alpha, vw.
+    ``result()``: all of them in a dict (+ n_hit)."""
+
+    _SPEC = dict(packed_info=(torch.int32, 2, "n"), ridx_hit=(torch.int64, 0, "hit"), pack_infos=(torch.int64, 2, "hit"),
+                 mask=(torch.float32, 0, "n"), depth=(torch.float32, 0, "n"), rgb_out=(torch.float32, 3, "n"),
+                 t_starts=(torch.float32, 0, "S"), t_ends=(torch.float32, 0, "S"), ridx32=(torch.int32, 0, "S"),
+                 gidx=(torch.int32, 0, "S"), ridx=(torch.int64, 0, "S"), deltas=(torch.float32, 0, "S"),
+                 samples=(torch.float32, 3, "S"), alpha=(torch.float32, 0, "S"), vw=(torch.float32, 0, "S"))
+
+    def __init__(self, dev, n):
+        self.dev, self.n, self._tot, self._host, self.g, self._gpool = dev, n, None, None, None, None
+
+    def totals(self):
+        """(S, n_hit): THE device->host sync of the op (waits on the stream the launches went to)"""
+        if self._tot is None:
+            # the scan (second launch) stores both totals into this pinned word pair with system scope: poll it instead of draining
+            # the stream -- the host goes on to build its views while the composite kernels still run (everything the caller does
+            # with the tensors is stream-ordered behind them anyway).  Timeout (never seen; e.g. a non-coherent pinned pool): drain.
+            if H.lib().nr3d_wait_host_words(self._host.data_ptr(), 2, -1, 5000) != 0:
+                cur = torch.cuda.current_stream(self.dev)
+                if cur.cuda_stream != self._raw_stream:      # the caller changed streams since the launches: wait on THEIR stream
+                    cur = torch.cuda.ExternalStream(self._raw_stream, device=self.dev)
+                cur.synchronize()
+            S, n_hit = self._host.tolist()
+            _totals_tls.free.append(self._host)          # read: the word can serve the next handle of this thread
+            self._host = None
+            self._tot = (int(S), int(n_hit))
+            if S > self.sigma_rows:
+                raise RuntimeError(f"ray_marching_composite: the march produced {S} samples but sigma has {self.sigma_rows} rows")
+        return self._tot
+
+    def __del__(self):
+        if getattr(self, "_host", None) is not None:
+            _TOTALS_LIMBO.append(self._host)
+
+    def view(self, name):
+        if name == "rgb":
+            name = "rgb_out"
+        dtype, inner, kind = self._SPEC[name]
+        o, nb = self._offs[name]
+        if nb == 0:
+            return None
+        rows = self.n if kind == "n" else self.totals()[0 if kind == "S" else 1]
+        esz = 8 if dtype == torch.int64 else 4
+        t = self._pool[o:o + rows * max(inner, 1) * esz].view(dtype)
+        t = t.view(rows, inner) if inner else t
+        if name == "pack_infos":
+            H.mark_ordered(t, total=self.totals()[0])
+        return t
+
+    def result(self):
+        out = {k: self.view(k) for k in self._SPEC}
+        out["rgb"] = out.pop("rgb_out")
+        out["n_hit"] = self.totals()[1]
+        return out
+
+    def backward(self, g_mask, g_depth, g_rgb, need_t=True, need_rgb=True, need_sigma=False):
+        """enqueue the composite's backward (no sync): afterwards ``grads()`` -> (grad_alpha [S], grad_t [S] | None, grad_rgb [S, 3] |
+        None, grad_sigma [S] | None)"""
+        n, dev = self.n, self.dev
+        H.require_gpu(g_mask, g_depth, g_rgb)
+        for name, t, inner in (("g_mask", g_mask, None), ("g_depth", g_depth, None), ("g_rgb", g_rgb, 3)):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != ((n,) if inner is None else (n, inner))):
+                raise RuntimeError(f"ray_marching_composite backward: {name} must be a contiguous float32 tensor over the {n} rays")
+        rows = self.rows
+        base = self._pool.data_ptr()
+        P = lambda name: (base + self._offs[name][0]) if self._offs[name][1] else None
+        with H.on_device(dev):
+            has_rgb = self._rgb is not None
+            widths = [1, 1 if need_t else 0, 3 if (need_rgb and has_rgb) else 0, 1 if need_sigma else 0]
+            self._gpool = pool = H.empty(max(rows, 1) * sum(widths), dtype=torch.float32, device=dev)
+            gb, ptrs, off = pool.data_ptr(), [], 0
+            for w in widths:
+                ptrs.append(gb + 4 * off if w else None)
+                off += rows * w
+            self._gw = widths
+            H.check(H.lib().nr3d_march_composite_bwd(
+                n, P("packed_info"), P("alpha"), P("vw"), P("t_starts"), H.ptr(self._rgb), self.eps, self.thre,
+                1 if self.normalize else 0, P("mask"), P("depth"), H.ptr(g_mask), H.ptr(g_depth), H.ptr(g_rgb), ptrs[0], ptrs[1], ptrs[2],
+                H.ptr(self._sigma), P("deltas"), self.sigma_rows, ptrs[3], self._raw_stream))
+        return self
+
+    def grads(self):
+        S, _ = self.totals()
+        out, off = [], 0
+        for i, w in enumerate(self._gw):
+            if not w:
+                out.append(None)
+                continue
+            t = self._gpool[off:off + S * w]
+            out.append(t.view(S, 3) if w == 3 else t)
+            off += self.rows * w
+        return tuple(out)
+
+
+def ray_marching_composite(rays_o, rays_d, t_min, t_max, roi, grid_binary, contraction_type, step_size, max_step_size, dt_gamma,
+                           max_steps, sigma, rgb=None, early_stop_eps=1e-4, alpha_thre=0.0, normalize_depth=True, return_gidx=True):
+    """ray_marching (ray_marching.cu:136-244) + the post-processing of occgrid_raymarch.py:87-112 + alpha = 1 - exp(-sigma * delta)
+    (nerf_utils.py:23-24) + the renderer's alpha composite (renderer_mixin.py:298-311) as ONE library call that enqueues four launches
+    and never waits for the device (nr3d_march_composite_fwd).  ``sigma`` [>= S] float32 (``rgb`` [same rows, 3], optional): the
+    per-sample density / colour in march order -- e.g. the output of a field evaluated on a previous march of the same scene, or a
+    constant medium.  Returns a ``MarchComposite``; nothing has been read back yet.
+    Above FUSED_MARCH_COMPOSITE_MAX_BYTES of bound-sized buffers, for batched grids, or when there are no rays, use the two-phase
+    chain (``ray_marching_finished`` -> ``tau_to_alpha_forward`` -> ``packed_composite_forward``): raises ValueError then."""
+    _chk("rays_o", rays_o, 2, torch.float32); _chk("rays_d", rays_d, 2, torch.float32)
+    _chk("t_min", t_min, 1, torch.float32); _chk("t_max", t_max, 1, torch.float32)
+    _chk("roi", roi, 1, torch.float32); _chk("grid_binary", grid_binary, 3)
+    _chk("sigma", sigma, 1, torch.float32)
+    if grid_binary.dtype not in (torch.bool, torch.uint8):
+        raise RuntimeError("grid_binary: expected a bool tensor")
+    n = rays_o.shape[0]
+    if tuple(rays_o.shape) != (n, 3) or tuple(rays_d.shape) != (n, 3) or t_min.shape[0] != n or t_max.shape[0] != n or roi.shape[0] != 6:
+        raise RuntimeError("ray_marching_composite: rays_o / rays_d [n, 3], t_min / t_max [n], roi [6] expected")
+    sigma_rows = sigma.shape[0]
+    if rgb is not None:
+        _chk("rgb", rgb, 2, torch.float32)
+        if tuple(rgb.shape) != (sigma_rows, 3):
+            raise RuntimeError("ray_marching_composite: rgb must be [sigma rows, 3]")
+    dev = rays_o.device
+    rows = n * int(max_steps)
+    per_row = 4 * (5 + 3 + 2 + (1 if return_gidx else 0)) + 8 + 12       # t0 t1 ridx deltas + samples + alpha vw (+ gidx) + ridx64 + cache
+    if n == 0 or rows * per_row > FUSED_MARCH_COMPOSITE_MAX_BYTES:
+        raise ValueError("ray_marching_composite: outside the one-call range (no rays, or bound-sized buffers above "
+                         "FUSED_MARCH_COMPOSITE_MAX_BYTES): use the two-phase chain")
+    mc = MarchComposite(dev, n)
+    mc.rows, mc.sigma_rows, mc.eps, mc.thre, mc.normalize = rows, sigma_rows, float(early_stop_eps), float(alpha_thre), bool(normalize_depth)
+    res = (C.c_int32 * 3)(*[int(s) for s in grid_binary.shape])
+    with H.on_device(dev):
+        # ONE allocation, carved into 16-byte aligned pieces (sizes in bytes)
+        scan_b = _scan_tmp_bytes(n)
+        pieces = [("packed_info", n * 8), ("ridx_hit", n * 8), ("pack_infos", n * 16), ("scan_tmp", scan_b + 8), ("cache", rows * 12),
+                  ("t_starts", rows * 4), ("t_ends", rows * 4), ("ridx32", rows * 4), ("gidx", rows * 4 if return_gidx else 0),
+                  ("ridx", rows * 8), ("deltas", rows * 4), ("samples", rows * 12), ("alpha", rows * 4), ("vw", rows * 4),
+                  ("mask", n * 4), ("depth", n * 4), ("rgb_out", n * 12 if rgb is not None else 0)]
+        offs, tot = {}, 0
+        for name, nb in pieces:
+            offs[name] = (tot, nb)
+            tot += (nb + 15) & ~15
+        pool = H.empty(tot, dtype=torch.uint8, device=dev)
+
+        base = pool.data_ptr()
+        P = lambda name: (base + offs[name][0]) if offs[name][1] else None       # raw device addresses: no tensor views before the launch
+        mc._pool, mc._offs = pool, offs
+        mc._sigma, mc._rgb = sigma, rgb
+        mc._host = _take_totals()
+        mc._host.fill_(-1)                                   # the sentinel totals() polls against
+        mc._raw_stream = H.stream_of(rays_o)
+        H.check(H.lib().nr3d_march_composite_fwd(
+            n, H.ptr(rays_o), H.ptr(rays_d), H.ptr(t_min), H.ptr(t_max), H.ptr(roi), res, H.ptr(grid_binary),
+            int(contraction_type), float(step_size), float(max_step_size), float(dt_gamma), int(max_steps),
+            P("packed_info"), P("ridx_hit"), P("pack_infos"), H.ptr(mc._host), P("scan_tmp"), P("cache"),
+            rows * 12, rows, P("t_starts"), P("t_ends"), P("ridx32"), P("gidx"),
+            P("ridx"), P("deltas"), P("samples"), H.ptr(sigma), sigma_rows, H.ptr(rgb),
+            float(early_stop_eps), float(alpha_thre), 1 if normalize_depth else 0, P("alpha"), P("vw"),
+            P("mask"), P("depth"), P("rgb_out"), mc._raw_stream))
+    return mc

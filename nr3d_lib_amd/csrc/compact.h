@@ -51,7 +51,10 @@ static __global__ __launch_bounds__(scan::kThreads) void k_c_scan_tiles(uint32_t
 		if (i < n_tiles) tile_sums[i] = carry + ex;
 		carry += tot;
 	}
-	if (threadIdx.x == 0) { totals[0] = (int64_t)(carry & kLow); totals[1] = (int64_t)(carry >> kShift); }
+	if (threadIdx.x == 0) {
+		__hip_atomic_store(&totals[0], (int64_t)(carry & kLow), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&totals[1], (int64_t)(carry >> kShift), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 // what a pack writes once its exclusive prefix is known
@@ -96,20 +99,42 @@ __global__ __launch_bounds__(scan::kThreads) void k_c_write(uint64_t n, const ui
 	}
 }
 
-// n <= scan::kSmallMax: one workgroup, one launch
-template <typename TCnt, int STRIDE>
-__global__ __launch_bounds__(scan::kThreads) void k_c_small(uint32_t n, uint32_t per, PackWriter<TCnt, STRIDE> w,
-                                                            int64_t *__restrict__ totals) {
-	__shared__ uint64_t lds[4];
-	const uint32_t first = threadIdx.x * per;
-	uint64_t s = 0;
-	for (uint32_t k = 0; k < per; ++k)
-		if (first + k < n) s += cval<TCnt, STRIDE>(w.counts, first + k);
-	uint64_t tot;
-	uint64_t run = scan::block_exclusive(s, tot, lds);
-	for (uint32_t k = 0; k < per; ++k)
-		if (first + k < n) { w(first + k, run); run += cval<TCnt, STRIDE>(w.counts, first + k); }
-	if (threadIdx.x == 0) { totals[0] = (int64_t)(tot & kLow); totals[1] = (int64_t)(tot >> kShift); }
+// n <= scan::kSmallMax: one workgroup, one launch.  Round 6: 1024 threads, every thread's PER consecutive counts loaded ONCE into
+// registers (independent loads, all in flight together) and written from there -- the 256-thread version walked 16 counts per thread
+// through two dependent load loops: 13 us for the 4096 rays of configs[2], on the critical path of a launch-bound op.
+constexpr int kSmallThreads = 1024;
+template <typename TCnt, int STRIDE, int PER>
+__global__ __launch_bounds__(kSmallThreads) void k_c_small(uint32_t n, PackWriter<TCnt, STRIDE> w, int64_t *__restrict__ totals) {
+	__shared__ uint64_t lds[kSmallThreads / 64];
+	const uint32_t first = threadIdx.x * PER;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint64_t v[PER], s = 0;
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		v[k] = (first + k < n) ? cval<TCnt, STRIDE>(w.counts, first + k) : 0;
+		s += v[k];
+	}
+	const uint64_t inc = scan::wave_inclusive(s, lane);
+	if (lane == 63) lds[wave] = inc;
+	__syncthreads();
+	uint64_t wave_off = 0, tot = 0;
+#pragma unroll
+	for (int q = 0; q < kSmallThreads / 64; ++q) {
+		const uint64_t t = lds[q];
+		if (q < wave) wave_off += t;
+		tot += t;
+	}
+	uint64_t run = wave_off + inc - s;
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		if (first + k < n) w(first + k, run);
+		run += v[k];
+	}
+	// system scope: `totals` is normally pinned host memory a host thread may be polling (nr3d_wait_host_words)
+	if (threadIdx.x == 0) {
+		__hip_atomic_store(&totals[0], (int64_t)(tot & kLow), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		__hip_atomic_store(&totals[1], (int64_t)(tot >> kShift), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 template <typename TCnt, int STRIDE>
@@ -120,8 +145,11 @@ static int compact_packs(uint64_t n, const PackWriter<TCnt, STRIDE> &w, int64_t 
 		return 0;
 	}
 	if (n <= scan::kSmallMax) {
-		hipLaunchKernelGGL((k_c_small<TCnt, STRIDE>), dim3(1), dim3(scan::kThreads), 0, st, (uint32_t)n,
-		                   (uint32_t)((n + scan::kThreads - 1) / scan::kThreads), w, totals);
+		const uint32_t per = (uint32_t)((n + kSmallThreads - 1) / kSmallThreads);
+#define NR3D_C_SMALL(PER) hipLaunchKernelGGL((k_c_small<TCnt, STRIDE, PER>), dim3(1), dim3(kSmallThreads), 0, st, (uint32_t)n, w, totals)
+		if (per <= 1) NR3D_C_SMALL(1); else if (per <= 2) NR3D_C_SMALL(2); else if (per <= 4) NR3D_C_SMALL(4);
+		else if (per <= 8) NR3D_C_SMALL(8); else if (per <= 16) NR3D_C_SMALL(16); else NR3D_C_SMALL(32);
+#undef NR3D_C_SMALL
 		NR3D_LAUNCH_CHECK();
 		return 0;
 	}

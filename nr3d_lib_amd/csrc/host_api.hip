@@ -5,6 +5,7 @@
 #include <utility>
 #include <string.h>
 #include <limits>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -103,6 +104,21 @@ extern "C" int nr3d_set_option(int id, int64_t value) {
 	return 0;
 }
 extern "C" int64_t nr3d_get_option(int id) { return (id >= 0 && id < NR3D_OPT_COUNT) ? opt::get(id) : -1; }
+
+extern "C" int nr3d_wait_host_words(const int64_t *words, int n, int64_t sentinel, uint32_t timeout_us) {
+	if (!words || n <= 0) return 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (uint32_t spin = 0;; ++spin) {
+		bool all = true;
+		for (int i = 0; i < n; ++i)
+			if (__atomic_load_n(&words[i], __ATOMIC_ACQUIRE) == sentinel) { all = false; break; }
+		if (all) return 0;
+		__builtin_ia32_pause();
+		if ((spin & 63u) == 63u &&
+		    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > (int64_t)timeout_us)
+			return 1;
+	}
+}
 
 extern "C" const char *nr3d_last_error(void) { return err_buf(); }
 extern "C" int nr3d_abi_version(void) { return NR3D_ABI_VERSION; }

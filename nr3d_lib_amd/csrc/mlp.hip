@@ -21,26 +21,11 @@
 // product contracts over SAMPLES, which the register map has in the lane index, so both operands go through a
 // per-wave LDS transposition tile ([feature][sample] -> one sample pair per MFMA step).
 #include "common.h"
+#include "mlp_device.h"      // register map, dense layers (f32 MFMA / bf16 MFMA x3), loads and stores: shared with lotd_mlp.hip
 #include <type_traits>
-
-// 1: streaming (non-temporal) row loads / stores as in rounds 3-4; 0: plain (see mlp_half.hip: the 16-byte pieces of a row arrive over
-// four instructions, L1 / L2 serve the re-touches of a line only for plain accesses)
-#ifndef NR3D_MLP_NT
-#define NR3D_MLP_NT 0
-#endif
 
 namespace nr3d {
 namespace mlp {
-
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float f4v __attribute__((ext_vector_type(4)));
-
-constexpr int kThreads = 256;                  // 4 waves per workgroup, one 32-sample tile per wave at a time
-constexpr int kMaxLds = 144 * 1024;            // of the CU's 160 KB
-
-__host__ __device__ constexpr uint32_t tiles(uint32_t d) { return (d + 31u) / 32u; }
-// floats of one packed layer: weights [NO][NI][4][64][4] + bias [NO * 32]
-__host__ __device__ constexpr uint32_t layer_floats(uint32_t ni, uint32_t no) { return no * ni * 1024u + no * 32u; }
 
 struct Shape {
 	uint32_t n_layers;                         // linear layers (hidden + output)
@@ -74,11 +59,6 @@ static uint64_t packed_floats(const Shape &s) {
 // element e = W[i][32 it + 8 (2 s + (e >> 2)) + 4 h + (e & 3)]); the activations' pieces per layer from the register map (a step's
 // B operand = eight consecutive accumulator registers).  Region of the packed buffer: behind the f32 forward layers.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-typedef float f2v __attribute__((ext_vector_type(2)));
-// floats of one x3 layer: three planes of [NO][NI][2 steps][64 lanes][8 bf16] + bias fp32 [NO * 32]
-__host__ __device__ constexpr uint32_t layer_x3_floats(uint32_t ni, uint32_t no) { return no * ni * 1536u + no * 32u; }
 static uint64_t x3_floats(const Shape &s) {
 	const uint64_t n = (uint64_t)layer_x3_floats(s.in_t, s.w_t) + (uint64_t)(s.n_layers - 2) * layer_x3_floats(s.w_t, s.w_t) + layer_x3_floats(s.w_t, s.out_t);
 	return n * 4 <= (uint64_t)kMaxLds ? n : 0;          // a network whose pieces do not fit LDS keeps the f32 MFMA
@@ -147,238 +127,6 @@ __global__ __launch_bounds__(256) void k_mlp_pack_x3(PackArgs a, float *__restri
 // ---------------------------------------------------------------------------------------------
 // one dense layer on the register map; wp -> LDS copy of the packed layer
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float activate(float v, int act) { return act == NR3D_MLP_ACT_RELU ? fmaxf(v, 0.0f) : v; }
-
-// Scheduling of the MFMA stream (measured rules, MI355X_MICROARCH.md): an instruction issued between two MFMAs on the
-// SAME accumulator costs ~43 cycles (a cliff), between MFMAs on DIFFERENT accumulators ~6.  So consecutive MFMAs
-// alternate accumulators -- the out tiles of the layer, or, for a single out tile, two partial sums over the even / odd
-// k-steps that are added at the end -- and the weight fragments (one 16-byte LDS read per lane and 4 MFMA steps) are
-// read kWPF groups ahead of their use: with one or two waves per SIMD nothing else would cover the LDS latency.
-constexpr int kWPF = 6;
-
-template <int NI, int NO, bool BIAS>
-__device__ __forceinline__ void dense(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
-	const float *bias = wp + NO * NI * 1024;
-	const int h = lane >> 5;
-	constexpr bool SPLIT = (NO == 1);              // one out tile: two accumulators over alternating k-steps
-	constexpr int G = NO * NI * 4;                 // weight groups, consumed in (it, q, ot) order
-	constexpr int PF = kWPF < G ? kWPF : G;
-	const f4v *wv = reinterpret_cast<const f4v *>(wp) + lane;
-	auto lds_index = [](int g) { const int ot = g % NO, s = g / NO; return ((ot * NI + s / 4) * 4 + (s % 4)) * 64; };   // [ot][it][q] in LDS
-	f4v ring[PF];
-#pragma unroll
-	for (int g = 0; g < PF; ++g) ring[g] = wv[lds_index(g)];
-	f16v alt;                                      // SPLIT: the odd k-steps' partial sum
-#pragma unroll
-	for (int j = 0; j < 16; ++j) alt[j] = 0.0f;
-#pragma unroll
-	for (int ot = 0; ot < NO; ++ot)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			f4v b4 = {0.0f, 0.0f, 0.0f, 0.0f};
-			if (BIAS) b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
-#pragma unroll
-			for (int b = 0; b < 4; ++b) out[ot][4 * q + b] = b4[b];
-		}
-#pragma unroll
-	for (int s = 0; s < NI * 4; ++s) {
-		const int it = s / 4, q = s % 4;
-		f4v w4[NO];
-#pragma unroll
-		for (int ot = 0; ot < NO; ++ot) {
-			const int g = s * NO + ot;
-			w4[ot] = ring[g % PF];
-			if (g + PF < G) ring[g % PF] = wv[lds_index(g + PF)];
-		}
-#pragma unroll
-		for (int b = 0; b < 4; ++b) {
-			if constexpr (SPLIT) {
-				if (b & 1) alt = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0][b], in[it][4 * q + b], alt, 0, 0, 0);
-				else out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0][b], in[it][4 * q + b], out[0], 0, 0, 0);
-			} else {
-#pragma unroll
-				for (int ot = 0; ot < NO; ++ot)
-					out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[ot][b], in[it][4 * q + b], out[ot], 0, 0, 0);
-			}
-		}
-	}
-#pragma unroll
-	for (int ot = 0; ot < NO; ++ot)
-#pragma unroll
-		for (int j = 0; j < 16; ++j) out[ot][j] = activate(SPLIT ? out[ot][j] + alt[j] : out[ot][j], act);
-}
-
-// the three bf16 pieces of registers 8 s .. 8 s + 7 of a register-map tile (a K = 16 step's B operand)
-__device__ __forceinline__ void split3(const f16v &v, int s, bf8 (&p)[3]) {
-#pragma unroll
-	for (int e = 0; e < 8; e += 2) {
-		const f2v a = {v[8 * s + e], v[8 * s + e + 1]};
-		const bf2 p1 = __builtin_convertvector(a, bf2);
-		const f2v r1 = a - __builtin_convertvector(p1, f2v);
-		const bf2 p2 = __builtin_convertvector(r1, bf2);
-		const f2v r2 = r1 - __builtin_convertvector(p2, f2v);
-		const bf2 p3 = __builtin_convertvector(r2, bf2);
-		p[0][e] = p1[0]; p[0][e + 1] = p1[1];
-		p[1][e] = p2[0]; p[1][e + 1] = p2[1];
-		p[2][e] = p3[0]; p[2][e + 1] = p3[1];
-	}
-}
-
-// one dense layer in fp32 on the bf16 MFMA; wp -> LDS copy of the layer's x3 planes (+ bias)
-template <int NI, int NO, bool BIAS>
-__device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
-	const float *bias = wp + NO * NI * 1536;
-	const int h = lane >> 5;
-	constexpr int PLANE = NO * NI * 2 * 64;             // bf8 units per plane
-	const bf8 *wv = reinterpret_cast<const bf8 *>(wp) + lane;
-	constexpr bool SPLIT = (NO == 1);                  // one out tile: the small terms go to a second accumulator (no dependent MFMA chain)
-	const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-	f16v alt = zero;
-#pragma unroll
-	for (int ot = 0; ot < NO; ++ot)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			f4v b4 = {0.0f, 0.0f, 0.0f, 0.0f};
-			if (BIAS) b4 = *reinterpret_cast<const f4v *>(bias + 32 * ot + 8 * q + 4 * h);
-#pragma unroll
-			for (int b = 0; b < 4; ++b) out[ot][4 * q + b] = b4[b];
-		}
-	// (weight piece, input piece) of the six kept products, smallest first
-	constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-	for (int it = 0; it < NI; ++it)
-#pragma unroll
-		for (int s = 0; s < 2; ++s) {
-			bf8 xs[3];
-			split3(in[it], s, xs);
-			bf8 w[3][NO];
-#pragma unroll
-			for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-				for (int ot = 0; ot < NO; ++ot) w[pl][ot] = wv[pl * PLANE + ((ot * NI + it) * 2 + s) * 64];
-#pragma unroll
-			for (int t = 0; t < 6; ++t) {
-				if constexpr (SPLIT) {
-					if (t < 5) alt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], xs[PX[t]], alt, 0, 0, 0);
-					else out[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], xs[PX[t]], out[0], 0, 0, 0);
-				} else {
-#pragma unroll
-					for (int ot = 0; ot < NO; ++ot) out[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][ot], xs[PX[t]], out[ot], 0, 0, 0);
-				}
-			}
-		}
-	if constexpr (SPLIT) {
-#pragma unroll
-		for (int j = 0; j < 16; ++j) out[0][j] += alt[j];
-	}
-	if (act == NR3D_MLP_ACT_RELU) {
-#pragma unroll
-		for (int ot = 0; ot < NO; ++ot)
-#pragma unroll
-			for (int j = 0; j < 16; ++j) out[ot][j] = fmaxf(out[ot][j], 0.0f);
-	}
-}
-
-// rows of a [n, dim] matrix on the register map: lane (s = lane & 31, h = lane >> 5) owns features 32t + 8q + 4h + b
-template <int NT>
-__device__ __forceinline__ void load_rows(const float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row, bool valid,
-                                          bool vec, int lane, f16v (&r)[NT]) {
-	const int h = lane >> 5;
-#pragma unroll
-	for (int t = 0; t < NT; ++t)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			const uint32_t f = 32u * t + 8u * q + 4u * h;
-			f4v v = {0.0f, 0.0f, 0.0f, 0.0f};
-			if (valid && f < dim) {
-				const float *src = p + (int64_t)row * stride + f;
-				if (vec && f + 3 < dim) v = NR3D_MLP_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(src)) : *reinterpret_cast<const f4v *>(src);
-				else {
-#pragma unroll
-					for (int b = 0; b < 4; ++b) if (f + b < dim) v[b] = src[b];
-				}
-			}
-#pragma unroll
-			for (int b = 0; b < 4; ++b) r[t][4 * q + b] = v[b];
-		}
-}
-
-// Branch-free variant for 16-byte aligned rows whose width is a multiple of 4: every lane loads from a valid address
-// (row clamped to the last row, a piece beyond the width re-reads piece 0) and nothing is selected afterwards -- padded
-// features meet zero weights and rows beyond n are never stored -- so no value is consumed before the first MFMA and
-// the loads of the NEXT tile can stay in flight under this tile's arithmetic (a load under a branch makes the compiler
-// drain the memory counter at the join).
-template <int NT>
-__device__ __forceinline__ void load_rows_fast(const float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row_clamped,
-                                               int lane, f16v (&r)[NT]) {
-	const int h = lane >> 5;
-	const float *base = p + (int64_t)row_clamped * stride;
-#pragma unroll
-	for (int t = 0; t < NT; ++t)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			const uint32_t f = 32u * t + 8u * q + 4u * h;
-			const f4v v = NR3D_MLP_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4v *>(base + (f < dim ? f : 0u))) : *reinterpret_cast<const f4v *>(base + (f < dim ? f : 0u));
-#pragma unroll
-			for (int b = 0; b < 4; ++b) r[t][4 * q + b] = v[b];
-		}
-}
-
-// Feature-major input (element (row, f) at p[f * fstride + row], e.g. the [E, N] storage the LoTD kernels write): a
-// half-wave reads 32 consecutive samples of one feature, 128 contiguous bytes per request -- the natural layout of the
-// B operand of H^T = W X^T.  Branch-free like load_rows_fast: the row is clamped, a feature beyond the width re-reads
-// feature 0 (it meets zero weights).  No alignment requirement.
-template <int NT>
-__device__ __forceinline__ void load_cols_fast(const float *__restrict__ p, int64_t fstride, uint32_t dim, uint64_t row_clamped,
-                                               int lane, f16v (&r)[NT]) {
-	const int h = lane >> 5;
-	const float *base = p + row_clamped;
-#pragma unroll
-	for (int t = 0; t < NT; ++t)
-#pragma unroll
-		for (int j = 0; j < 16; ++j) {
-			const uint32_t f = 32u * t + 8u * (j >> 2) + 4u * h + (j & 3);
-			r[t][j] = __builtin_nontemporal_load(base + (int64_t)(f < dim ? f : 0u) * fstride);
-		}
-}
-
-template <int NT>
-__device__ __forceinline__ void store_cols(float *__restrict__ p, int64_t fstride, uint32_t dim, uint64_t row, bool valid, int lane,
-                                           const f16v (&r)[NT]) {
-	const int h = lane >> 5;
-	if (!valid) return;
-#pragma unroll
-	for (int t = 0; t < NT; ++t)
-#pragma unroll
-		for (int j = 0; j < 16; ++j) {
-			const uint32_t f = 32u * t + 8u * (j >> 2) + 4u * h + (j & 3);
-			if (f < dim) __builtin_nontemporal_store(r[t][j], p + (int64_t)f * fstride + row);
-		}
-}
-
-template <int NT>
-__device__ __forceinline__ void store_rows(float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row, bool valid, bool vec,
-                                           int lane, const f16v (&r)[NT]) {
-	const int h = lane >> 5;
-	if (!valid) return;
-#pragma unroll
-	for (int t = 0; t < NT; ++t)
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			const uint32_t f = 32u * t + 8u * q + 4u * h;
-			if (f >= dim) continue;
-			float *dst = p + (int64_t)row * stride + f;
-			if (vec && f + 3 < dim) {
-				const f4v v = {r[t][4 * q], r[t][4 * q + 1], r[t][4 * q + 2], r[t][4 * q + 3]};
-				// (rows wider than one tile: plain stores, L2 merges the row's 16-byte pieces into whole lines -- mlp_half.hip, store_rows)
-				if (NT > 1 || !NR3D_MLP_NT) *reinterpret_cast<f4v *>(dst) = v; else __builtin_nontemporal_store(v, reinterpret_cast<f4v *>(dst));
-			} else {
-#pragma unroll
-				for (int b = 0; b < 4; ++b) if (f + b < dim) dst[b] = r[t][4 * q + b];
-			}
-		}
-}
-
 struct FwdArgs {
 	uint64_t n;
 	const float *x; int64_t xs;
@@ -388,22 +136,6 @@ struct FwdArgs {
 	int hidden_act, out_act;
 	uint32_t x_vec, y_vec;
 };
-
-__device__ __forceinline__ void stage_weights(const float *__restrict__ packed, uint32_t n_floats, float *lds) {
-	const f4v *src = reinterpret_cast<const f4v *>(packed);
-	f4v *dst = reinterpret_cast<f4v *>(lds);
-	for (uint32_t i = threadIdx.x; i < n_floats / 4; i += kThreads) dst[i] = src[i];
-	__syncthreads();
-}
-
-// XF: 0 = row-major input, any alignment / width; 1 = row-major, 16-byte aligned rows of a multiple of 4 floats
-// (prefetched); 2 = feature-major input (a.xs = feature stride, prefetched)
-template <int XF, int NT>
-__device__ __forceinline__ void prefetch_x(const float *__restrict__ p, int64_t stride, uint32_t dim, uint64_t row_clamped, int lane,
-                                           f16v (&r)[NT]) {
-	if constexpr (XF == 2) load_cols_fast<NT>(p, stride, dim, row_clamped, lane, r);
-	else load_rows_fast<NT>(p, stride, dim, row_clamped, lane, r);
-}
 
 // (X3, one input and one output tile, hidden layers up to 64 wide: two workgroups per CU = two waves per SIMD -- the piece splitting is VALU work, the products MFMA work, and
 // only ANOTHER wave's instructions overlap them; at 260 registers the first version ran one wave per SIMD and the two added up)

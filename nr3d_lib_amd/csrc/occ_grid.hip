@@ -14,6 +14,7 @@
 #include "common.h"
 #include "scan.h"
 #include "compact.h"
+#include "pack_launch.h"
 #include <stdlib.h>
 
 namespace nr3d {
@@ -722,6 +723,56 @@ extern "C" int nr3d_ray_marching_emit_finished(uint32_t n_rays, const float *ray
 	                   bidx, gidx, rays_o, rays_d, ridx64, deltas, samples);
 	NR3D_LAUNCH_CHECK();
 	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// configs[2] in one call (round 6): count (+ sample cache) -> scan (+ hit-ray compaction, totals) -> [cached emit (+ per-sample
+// epilogue) + alpha = 1 - exp(-sigma * delta) + alpha composite in ONE launch], enqueued back to back on `stream`.  Nothing here waits for the
+// device: every per-sample buffer has the capacity of the bound n_rays * max_steps, and the composite runs one wave per ray over ALL
+// rays (rays without samples write their own zeros), so neither S nor n_hit is needed on the host before the last launch.  The
+// caller reads `totals` back AFTER this returns (and after enqueueing the backward, if it wants one) and uses it only to slice
+// views.  At 4096 rays the two-phase path spent ~80 us of host time behind the count readback (profiles/r05final_*).
+// ---------------------------------------------------------------------------------------------------
+extern "C" int nr3d_march_composite_fwd(uint32_t n_rays, const float *rays_o, const float *rays_d, const float *t_min,
+                                        const float *t_max, const float *roi, const int32_t grid_res[3],
+                                        const uint8_t *grid_binary, int type, float step_size, float max_step_size,
+                                        float dt_gamma, uint32_t max_steps, int32_t *packed_info, int64_t *ridx_hit,
+                                        int64_t *pack_infos, int64_t *totals, void *scan_tmp, void *sample_cache,
+                                        uint64_t sample_cache_bytes, uint64_t rows, float *t_starts, float *t_ends, int32_t *ridx,
+                                        int32_t *gidx, int64_t *ridx64, float *deltas, float *samples, const float *sigma,
+                                        uint64_t sigma_rows, const float *rgb, float early_stop_eps, float alpha_thre,
+                                        int normalize_depth, float *alphas, float *vw, float *mask, float *depth, float *rgb_out,
+                                        void *stream) {
+	NR3D_CHECK(totals != nullptr, "march_composite_fwd: NULL totals");
+	hipStream_t st = (hipStream_t)stream;
+	if (n_rays == 0) { NR3D_HIP_CHECK(hipMemsetAsync(totals, 0, 2 * sizeof(int64_t), st)); return 0; }
+	NR3D_CHECK(rows >= (uint64_t)n_rays * max_steps, "march_composite_fwd: per-sample buffers hold %llu rows, the bound n_rays * max_steps is %llu",
+	           (unsigned long long)rows, (unsigned long long)n_rays * max_steps);
+	NR3D_CHECK(sample_cache && sample_cache_bytes >= nr3d_ray_marching_cache_bytes(n_rays, max_steps),
+	           "march_composite_fwd: needs the sample cache (nr3d_ray_marching_cache_bytes)");
+	NR3D_CHECK(packed_info && ridx_hit && pack_infos && t_starts && t_ends && ridx && deltas, "march_composite_fwd: NULL march output");
+	NR3D_CHECK(sigma && alphas && vw && mask && depth && (!rgb || rgb_out), "march_composite_fwd: NULL composite tensor");
+	if (int rc = march_count(n_rays, rays_o, rays_d, t_min, t_max, roi, grid_res, grid_binary, type, step_size, max_step_size, dt_gamma,
+	                         max_steps, 0, nullptr, 0u, packed_info, totals, scan_tmp, sample_cache, sample_cache_bytes, ridx_hit,
+	                         pack_infos, stream))
+		return rc;
+	return pk::launch_emit_composite_rays_fwd(n_rays, packed_info, sample_cache, max_steps, rays_o, rays_d, t_starts, t_ends, ridx, gidx, ridx64,
+	                                          deltas, samples, sigma, sigma_rows, rgb, early_stop_eps, alpha_thre, normalize_depth, alphas, vw,
+	                                          mask, depth, rgb_out, st);
+}
+
+extern "C" int nr3d_march_composite_bwd(uint32_t n_rays, const int32_t *packed_info, const float *alphas, const float *vw,
+                                        const float *t, const float *rgb, float early_stop_eps, float alpha_thre,
+                                        int normalize_depth, const float *mask, const float *depth, const float *g_mask,
+                                        const float *g_depth, const float *g_rgb, float *grad_alphas, float *grad_t,
+                                        float *grad_rgb, const float *sigma, const float *deltas, uint64_t sigma_rows,
+                                        float *grad_sigma, void *stream) {
+	if (n_rays == 0) return 0;
+	NR3D_CHECK(packed_info && alphas && vw && t && mask && depth && grad_alphas, "march_composite_bwd: NULL pointer");
+	NR3D_CHECK(!grad_sigma || (sigma && deltas), "march_composite_bwd: grad_sigma needs sigma and deltas");
+	return pk::launch_composite_rays_bwd(n_rays, packed_info, alphas, vw, t, rgb, early_stop_eps, alpha_thre, normalize_depth, mask,
+	                                     depth, g_mask, g_depth, g_rgb, grad_alphas, grad_t, grad_rgb, sigma, deltas, sigma_rows,
+	                                     grad_sigma, (hipStream_t)stream);
 }
 
 static int forest_march_check(const nr3d_forest_meta_t *forest, const void *a, const void *b, const void *c, const void *d,

@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "common.h"
 #include "scan.h"
+#include "pack_launch.h"
 #include <stdlib.h>
 
 namespace nr3d {
@@ -1031,21 +1032,29 @@ __device__ __forceinline__ ChunkT chunk_transmittance(float a, bool mine, bool c
 	return r;
 }
 
-template <bool RGB>
-__global__ __launch_bounds__(kBlock) void k_composite_fwd_scan(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ ts,
-                                                               const float *__restrict__ rgb, const int64_t *__restrict__ pi,
-                                                               const int64_t *__restrict__ ray_index, float eps, float thre,
-                                                               int normalize, float *__restrict__ vw, float *__restrict__ mask,
-                                                               float *__restrict__ depth, float *__restrict__ rgb_out) {
-	const Pack k = my_pack(P, pi);
-	if (!k.valid) return;
+// body of the prefix-product forward for the pack `k`.  FROM_SIGMA: the opacity is alpha = 1 - exp(-(sigma * delta)) (the expression of
+// k_tau_to_alpha_fwd, ray_glue.hip: bit-identical), computed here and stored to `alphas` (an OUTPUT then: not restrict-qualified, the
+// serial replay below reads back what this wave's own lanes stored); rows >= sigma_rows read sigma as 0 (the host raises afterwards).
+template <bool RGB, bool FROM_SIGMA>
+__device__ __forceinline__ void composite_fwd_scan_body(const Pack &k, float *alphas, const float *__restrict__ sigma,
+                                                        const float *__restrict__ delta, uint64_t sigma_rows, const float *__restrict__ ts,
+                                                        const float *__restrict__ rgb, const int64_t *__restrict__ ray_index, float eps,
+                                                        float thre, int normalize, float *__restrict__ vw, float *__restrict__ mask,
+                                                        float *__restrict__ depth, float *__restrict__ rgb_out) {
 	float Tc = 1.0f, s = 0.0f, dt = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
 	bool stopped = false, ambiguous = false;
-	for (uint32_t base = 0; base < k.len && !ambiguous; base += 64) {
+	auto alpha_at = [&](size_t i) -> float {
+		if (!FROM_SIGMA) return alphas[i];
+		const float a = 1.0f - expf(-((i < sigma_rows ? sigma[i] : 0.0f) * delta[i]));
+		alphas[i] = a;
+		return a;
+	};
+	uint32_t base = 0;
+	for (; base < k.len && !ambiguous; base += 64) {
 		const uint32_t n = min(64u, k.len - base);
 		const bool mine = (uint32_t)k.lane < n;
 		const size_t i = (size_t)k.begin + base + k.lane;
-		const float a = mine ? alphas[i] : 0.0f;
+		const float a = mine ? alpha_at(i) : 0.0f;
 		const float t = mine ? ts[i] : 0.0f;
 		float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
 		if (RGB && mine) { r0 = rgb[3 * i]; r1 = rgb[3 * i + 1]; r2 = rgb[3 * i + 2]; }
@@ -1057,6 +1066,8 @@ __global__ __launch_bounds__(kBlock) void k_composite_fwd_scan(uint32_t P, const
 		if (RGB) { c0 += w * r0; c1 += w * r1; c2 += w * r2; }
 	}
 	if (ambiguous) {        // wave-uniform
+		if (FROM_SIGMA)     // the chunks the loop above did not reach: their opacities first
+			for (; base < k.len; base += 64) if ((uint32_t)k.lane < min(64u, k.len - base)) alpha_at((size_t)k.begin + base + k.lane);
 		composite_fwd_serial<RGB>(k, alphas, ts, rgb, ray_index, eps, thre, normalize, vw, mask, depth, rgb_out);
 		return;
 	}
@@ -1074,16 +1085,90 @@ __global__ __launch_bounds__(kBlock) void k_composite_fwd_scan(uint32_t P, const
 }
 
 template <bool RGB>
-__global__ __launch_bounds__(kBlock) void k_composite_bwd_scan(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ vw,
-                                                               const float *__restrict__ ts, const float *__restrict__ rgb,
-                                                               const int64_t *__restrict__ pi, const int64_t *__restrict__ ray_index,
-                                                               float eps, float thre, int normalize, const float *__restrict__ mask,
-                                                               const float *__restrict__ depth, const float *__restrict__ g_mask,
-                                                               const float *__restrict__ g_depth, const float *__restrict__ g_rgb,
-                                                               const float *__restrict__ g_vw, float *__restrict__ grad_alphas,
-                                                               float *__restrict__ grad_t, float *__restrict__ grad_rgb) {
+__global__ __launch_bounds__(kBlock) void k_composite_fwd_scan(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ ts,
+                                                               const float *__restrict__ rgb, const int64_t *__restrict__ pi,
+                                                               const int64_t *__restrict__ ray_index, float eps, float thre,
+                                                               int normalize, float *__restrict__ vw, float *__restrict__ mask,
+                                                               float *__restrict__ depth, float *__restrict__ rgb_out) {
 	const Pack k = my_pack(P, pi);
 	if (!k.valid) return;
+	composite_fwd_scan_body<RGB, false>(k, const_cast<float *>(alphas), nullptr, nullptr, 0, ts, rgb, ray_index, eps, thre, normalize, vw,
+	                                    mask, depth, rgb_out);
+}
+
+// ONE WAVE PER RAY over ALL rays of a marcher's packed_info (int32 [n_rays, 2], nr3d_march_composite_fwd): a ray without samples
+// writes its zeros itself (no fill launch, no compaction of the hit rays needed before the launch), per-ray results at the ray's own index
+__device__ __forceinline__ Pack my_ray(uint32_t n_rays, const int32_t *__restrict__ packed_info) {
+	Pack k;
+	k.lane = threadIdx.x & 63;
+	k.p = blockIdx.x * kWaves + (threadIdx.x >> 6);
+	k.valid = k.p < n_rays;
+	k.begin = k.valid ? (uint32_t)packed_info[2 * (size_t)k.p] : 0u;
+	k.len = k.valid ? (uint32_t)packed_info[2 * (size_t)k.p + 1] : 0u;
+	return k;
+}
+
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_rays_fwd(uint32_t n_rays, const int32_t *__restrict__ packed_info,
+                                                               const float *__restrict__ sigma, const float *__restrict__ delta,
+                                                               uint64_t sigma_rows, const float *__restrict__ ts,
+                                                               const float *__restrict__ rgb, float eps, float thre, int normalize,
+                                                               float *alphas, float *__restrict__ vw, float *__restrict__ mask,
+                                                               float *__restrict__ depth, float *__restrict__ rgb_out) {
+	const Pack k = my_ray(n_rays, packed_info);
+	if (!k.valid) return;
+	composite_fwd_scan_body<RGB, true>(k, alphas, sigma, delta, sigma_rows, ts, rgb, nullptr, eps, thre, normalize, vw, mask, depth, rgb_out);
+}
+
+// the cached emit of the marcher (occ_grid.hip k_emit_cached: the same stores, the same expressions) AND the composite in one launch:
+// the wave of ray i copies the ray's cached samples {t0, t1, cell} to their packed rows -- t_starts / t_ends / ridx (/ gidx / ridx64 /
+// deltas / samples) -- and composites them straight away.  Row begin + j is written and read back by the same lane (j % 64).
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_emit_composite_rays_fwd(uint32_t n_rays, const int32_t *__restrict__ packed_info,
+                                                                    const uint32_t *__restrict__ cache, uint32_t cache_stride,
+                                                                    const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                                    float *t_starts, float *__restrict__ t_ends, int32_t *__restrict__ ridx,
+                                                                    int32_t *__restrict__ gidx, int64_t *__restrict__ ridx64, float *deltas,
+                                                                    float *__restrict__ samples, const float *__restrict__ sigma,
+                                                                    uint64_t sigma_rows, const float *__restrict__ rgb, float eps, float thre,
+                                                                    int normalize, float *alphas, float *__restrict__ vw,
+                                                                    float *__restrict__ mask, float *__restrict__ depth,
+                                                                    float *__restrict__ rgb_out) {
+	const Pack k = my_ray(n_rays, packed_info);
+	if (!k.valid) return;
+	const uint32_t *c = cache + (size_t)k.p * cache_stride * 3;
+	float o[3] = {0.0f, 0.0f, 0.0f}, d[3] = {0.0f, 0.0f, 0.0f};
+	if (samples) {
+#pragma unroll
+		for (int a = 0; a < 3; ++a) { o[a] = rays_o[3 * (size_t)k.p + a]; d[a] = rays_d[3 * (size_t)k.p + a]; }
+	}
+	for (uint32_t j = k.lane; j < k.len; j += 64) {
+		const float a = __uint_as_float(c[3 * j]), e = __uint_as_float(c[3 * j + 1]);
+		const size_t r = (size_t)k.begin + j;
+		t_starts[r] = a;
+		t_ends[r] = e;
+		ridx[r] = (int32_t)k.p;
+		if (gidx) gidx[r] = (int32_t)c[3 * j + 2];
+		if (ridx64) ridx64[r] = (int64_t)k.p;
+		deltas[r] = e - a;
+		if (samples) {
+#pragma unroll
+			for (int q = 0; q < 3; ++q) samples[r * 3 + q] = __fmaf_rn(d[q], a, o[q]);
+		}
+	}
+	composite_fwd_scan_body<RGB, true>(k, alphas, sigma, deltas, sigma_rows, t_starts, rgb, nullptr, eps, thre, normalize, vw, mask, depth,
+	                                   rgb_out);
+}
+
+template <bool RGB>
+__device__ __forceinline__ void composite_bwd_scan_body(const Pack &k, const float *__restrict__ alphas, const float *__restrict__ vw,
+                                                        const float *__restrict__ ts, const float *__restrict__ rgb,
+                                                        const int64_t *__restrict__ ray_index, float eps, float thre, int normalize,
+                                                        const float *__restrict__ mask, const float *__restrict__ depth,
+                                                        const float *__restrict__ g_mask, const float *__restrict__ g_depth,
+                                                        const float *__restrict__ g_rgb, const float *__restrict__ g_vw,
+                                                        float *__restrict__ grad_alphas, float *__restrict__ grad_t,
+                                                        float *__restrict__ grad_rgb) {
 	const size_t o = ray_index ? (size_t)ray_index[k.p] : (size_t)k.p;
 	const CompGrad cg = comp_grad(o, normalize, mask, depth, g_mask, g_depth, g_rgb);
 	// total = sum_j gw_j * w_j; the sample's own "still to come" sum is total minus the prefix before it
@@ -1125,6 +1210,47 @@ __global__ __launch_bounds__(kBlock) void k_composite_bwd_scan(uint32_t P, const
 	if (ambiguous)
 		composite_bwd_serial<RGB>(k, alphas, vw, ts, rgb, ray_index, eps, thre, normalize, mask, depth, g_mask, g_depth, g_rgb, g_vw,
 		                          grad_alphas, grad_t, grad_rgb);
+}
+
+
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_bwd_scan(uint32_t P, const float *__restrict__ alphas, const float *__restrict__ vw,
+                                                               const float *__restrict__ ts, const float *__restrict__ rgb,
+                                                               const int64_t *__restrict__ pi, const int64_t *__restrict__ ray_index,
+                                                               float eps, float thre, int normalize, const float *__restrict__ mask,
+                                                               const float *__restrict__ depth, const float *__restrict__ g_mask,
+                                                               const float *__restrict__ g_depth, const float *__restrict__ g_rgb,
+                                                               const float *__restrict__ g_vw, float *__restrict__ grad_alphas,
+                                                               float *__restrict__ grad_t, float *__restrict__ grad_rgb) {
+	const Pack k = my_pack(P, pi);
+	if (!k.valid) return;
+	composite_bwd_scan_body<RGB>(k, alphas, vw, ts, rgb, ray_index, eps, thre, normalize, mask, depth, g_mask, g_depth, g_rgb, g_vw,
+	                             grad_alphas, grad_t, grad_rgb);
+}
+
+// backward over all rays of a marcher's packed_info (see k_composite_rays_fwd); grad_sigma (optional) = grad_alpha * exp(-(sigma *
+// delta)) * delta, the expression of k_tau_to_alpha_bwd, from the grad_alphas this wave's own lanes have just stored
+template <bool RGB>
+__global__ __launch_bounds__(kBlock) void k_composite_rays_bwd(uint32_t n_rays, const int32_t *__restrict__ packed_info,
+                                                               const float *__restrict__ alphas, const float *__restrict__ vw,
+                                                               const float *__restrict__ ts, const float *__restrict__ rgb, float eps,
+                                                               float thre, int normalize, const float *__restrict__ mask,
+                                                               const float *__restrict__ depth, const float *__restrict__ g_mask,
+                                                               const float *__restrict__ g_depth, const float *__restrict__ g_rgb,
+                                                               float *grad_alphas, float *__restrict__ grad_t,
+                                                               float *__restrict__ grad_rgb, const float *__restrict__ sigma,
+                                                               const float *__restrict__ delta, uint64_t sigma_rows,
+                                                               float *__restrict__ grad_sigma) {
+	const Pack k = my_ray(n_rays, packed_info);
+	if (!k.valid) return;
+	composite_bwd_scan_body<RGB>(k, alphas, vw, ts, rgb, nullptr, eps, thre, normalize, mask, depth, g_mask, g_depth, g_rgb, nullptr,
+	                             grad_alphas, grad_t, grad_rgb);
+	if (grad_sigma)
+		for (uint32_t base = 0; base < k.len; base += 64) {
+			const size_t i = (size_t)k.begin + base + k.lane;
+			if ((uint32_t)k.lane < min(64u, k.len - base))
+				grad_sigma[i] = i < sigma_rows ? grad_alphas[i] * expf(-(sigma[i] * delta[i])) * delta[i] : 0.0f;
+		}
 }
 
 // lane-per-pack forms (many rays): every lane walks its own ray serially, 4 samples per memory request
@@ -1538,6 +1664,63 @@ extern "C" int nr3d_alpha_to_vw_backward(uint32_t P, uint64_t S, const float *al
 	NR3D_LAUNCH_CHECK();
 	return 0;
 }
+
+namespace nr3d {
+namespace pk {
+int launch_composite_rays_fwd(uint32_t n_rays, const int32_t *packed_info, const float *sigma, const float *delta, uint64_t sigma_rows,
+                              const float *ts, const float *rgb, float eps, float thre, int normalize, float *alphas, float *vw,
+                              float *mask, float *depth, float *rgb_out, hipStream_t st) {
+	if (n_rays == 0) return 0;
+	prof::Scope ps(NR3D_PROF_COMPOSITE_FWD, st);
+	if (rgb)
+		hipLaunchKernelGGL(k_composite_rays_fwd<true>, grid_for(n_rays), dim3(kBlock), 0, st, n_rays, packed_info, sigma, delta, sigma_rows,
+		                   ts, rgb, eps, thre, normalize, alphas, vw, mask, depth, rgb_out);
+	else
+		hipLaunchKernelGGL(k_composite_rays_fwd<false>, grid_for(n_rays), dim3(kBlock), 0, st, n_rays, packed_info, sigma, delta, sigma_rows,
+		                   ts, rgb, eps, thre, normalize, alphas, vw, mask, depth, rgb_out);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+int launch_emit_composite_rays_fwd(uint32_t n_rays, const int32_t *packed_info, const void *cache, uint32_t cache_stride,
+                                   const float *rays_o, const float *rays_d, float *t_starts, float *t_ends, int32_t *ridx, int32_t *gidx,
+                                   int64_t *ridx64, float *deltas, float *samples, const float *sigma, uint64_t sigma_rows,
+                                   const float *rgb, float eps, float thre, int normalize, float *alphas, float *vw, float *mask,
+                                   float *depth, float *rgb_out, hipStream_t st) {
+	if (n_rays == 0) return 0;
+	prof::Scope ps(NR3D_PROF_COMPOSITE_FWD, st);
+	if (rgb)
+		hipLaunchKernelGGL(k_emit_composite_rays_fwd<true>, grid_for(n_rays), dim3(kBlock), 0, st, n_rays, packed_info,
+		                   (const uint32_t *)cache, cache_stride, rays_o, rays_d, t_starts, t_ends, ridx, gidx, ridx64, deltas, samples, sigma,
+		                   sigma_rows, rgb, eps, thre, normalize, alphas, vw, mask, depth, rgb_out);
+	else
+		hipLaunchKernelGGL(k_emit_composite_rays_fwd<false>, grid_for(n_rays), dim3(kBlock), 0, st, n_rays, packed_info,
+		                   (const uint32_t *)cache, cache_stride, rays_o, rays_d, t_starts, t_ends, ridx, gidx, ridx64, deltas, samples, sigma,
+		                   sigma_rows, rgb, eps, thre, normalize, alphas, vw, mask, depth, rgb_out);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+
+int launch_composite_rays_bwd(uint32_t n_rays, const int32_t *packed_info, const float *alphas, const float *vw, const float *ts,
+                              const float *rgb, float eps, float thre, int normalize, const float *mask, const float *depth,
+                              const float *g_mask, const float *g_depth, const float *g_rgb, float *grad_alphas, float *grad_t,
+                              float *grad_rgb, const float *sigma, const float *delta, uint64_t sigma_rows, float *grad_sigma,
+                              hipStream_t st) {
+	if (n_rays == 0) return 0;
+	prof::Scope ps(NR3D_PROF_COMPOSITE_BWD, st);
+	if (rgb)
+		hipLaunchKernelGGL(k_composite_rays_bwd<true>, grid_for(n_rays), dim3(kBlock), 0, st, n_rays, packed_info, alphas, vw, ts, rgb, eps,
+		                   thre, normalize, mask, depth, g_mask, g_depth, g_rgb, grad_alphas, grad_t, grad_rgb, sigma, delta, sigma_rows,
+		                   grad_sigma);
+	else
+		hipLaunchKernelGGL(k_composite_rays_bwd<false>, grid_for(n_rays), dim3(kBlock), 0, st, n_rays, packed_info, alphas, vw, ts, rgb, eps,
+		                   thre, normalize, mask, depth, g_mask, g_depth, g_rgb, grad_alphas, grad_t, grad_rgb, sigma, delta, sigma_rows,
+		                   grad_sigma);
+	NR3D_LAUNCH_CHECK();
+	return 0;
+}
+}  // namespace pk
+}  // namespace nr3d
 
 extern "C" int nr3d_pack_composite_fwd(uint32_t P, const float *alphas, const float *t, const float *rgb,
                                        const int64_t *pack_infos, const int64_t *ray_index, float early_stop_eps,

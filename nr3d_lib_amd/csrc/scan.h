@@ -71,7 +71,7 @@ static __global__ __launch_bounds__(kThreads) void k_scan_tile_sums(uint32_t n_t
 		if (i < n_tiles) tile_sums[i] = carry + ex;
 		carry += tot;
 	}
-	if (threadIdx.x == 0) *total_out = (int64_t)carry;
+	if (threadIdx.x == 0) __hip_atomic_store(total_out, (int64_t)carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // a host thread may be polling it
 }
 
 // rescan each tile, add its prefix and write (begin, length) pairs.  Thread t owns kItems CONSECUTIVE counts.
@@ -102,25 +102,40 @@ __global__ __launch_bounds__(kThreads) void k_write_pack_infos(uint64_t n, const
 // n <= kSmallMax: ONE workgroup does the whole job (the three launches above cost ~14 us of launch and drain for 4096
 // counts, this one ~4): thread t owns `per` consecutive counts, sums them, one block scan, then re-reads and writes.
 constexpr uint64_t kSmallMax = 32768;
-template <typename TIn, typename TOut>
-__global__ __launch_bounds__(kThreads) void k_pack_infos_small(uint32_t n, uint32_t per, const TIn *__restrict__ counts,
-                                                               TOut *__restrict__ pack_infos, int64_t *__restrict__ total_out) {
-	__shared__ uint64_t lds[4];
-	const uint32_t first = threadIdx.x * per;
-	uint64_t s = 0;
-	for (uint32_t k = 0; k < per; ++k)
-		if (first + k < n) s += (uint64_t)counts[first + k];
-	uint64_t tot;
-	uint64_t run = block_exclusive(s, tot, lds);
-	for (uint32_t k = 0; k < per; ++k) {
-		if (first + k < n) {
-			const uint64_t c = (uint64_t)counts[first + k];
-			pack_infos[2 * (size_t)(first + k)] = (TOut)run;
-			pack_infos[2 * (size_t)(first + k) + 1] = (TOut)c;
-			run += c;
-		}
+// (round 6: 1024 threads, a thread's PER counts loaded once into registers -- see compact.h k_c_small)
+constexpr int kSmallThreads = 1024;
+template <typename TIn, typename TOut, int PER>
+__global__ __launch_bounds__(kSmallThreads) void k_pack_infos_small(uint32_t n, const TIn *__restrict__ counts,
+                                                                    TOut *__restrict__ pack_infos, int64_t *__restrict__ total_out) {
+	__shared__ uint64_t lds[kSmallThreads / 64];
+	const uint32_t first = threadIdx.x * PER;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint64_t v[PER], s = 0;
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		v[k] = (first + k < n) ? (uint64_t)counts[first + k] : 0;
+		s += v[k];
 	}
-	if (threadIdx.x == 0) *total_out = (int64_t)tot;
+	const uint64_t inc = wave_inclusive(s, lane);
+	if (lane == 63) lds[wave] = inc;
+	__syncthreads();
+	uint64_t wave_off = 0, tot = 0;
+#pragma unroll
+	for (int q = 0; q < kSmallThreads / 64; ++q) {
+		const uint64_t t = lds[q];
+		if (q < wave) wave_off += t;
+		tot += t;
+	}
+	uint64_t run = wave_off + inc - s;
+#pragma unroll
+	for (int k = 0; k < PER; ++k) {
+		if (first + k < n) {
+			pack_infos[2 * (size_t)(first + k)] = (TOut)run;
+			pack_infos[2 * (size_t)(first + k) + 1] = (TOut)v[k];
+		}
+		run += v[k];
+	}
+	if (threadIdx.x == 0) __hip_atomic_store(total_out, (int64_t)tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // a host thread may be polling it
 }
 
 static inline uint64_t tmp_bytes(uint64_t n) { return ((n + kTile - 1) / kTile + 1) * sizeof(uint64_t); }
@@ -134,8 +149,11 @@ static int pack_infos_from_counts(uint64_t n, const TIn *counts, TOut *pack_info
 		return 0;
 	}
 	if (n <= kSmallMax) {
-		hipLaunchKernelGGL((k_pack_infos_small<TIn, TOut>), dim3(1), dim3(kThreads), 0, st, (uint32_t)n,
-		                   (uint32_t)((n + kThreads - 1) / kThreads), counts, pack_infos, total);
+		const uint32_t per = (uint32_t)((n + kSmallThreads - 1) / kSmallThreads);
+#define NR3D_PI_SMALL(PER) hipLaunchKernelGGL((k_pack_infos_small<TIn, TOut, PER>), dim3(1), dim3(kSmallThreads), 0, st, (uint32_t)n, counts, pack_infos, total)
+		if (per <= 1) NR3D_PI_SMALL(1); else if (per <= 2) NR3D_PI_SMALL(2); else if (per <= 4) NR3D_PI_SMALL(4);
+		else if (per <= 8) NR3D_PI_SMALL(8); else if (per <= 16) NR3D_PI_SMALL(16); else NR3D_PI_SMALL(32);
+#undef NR3D_PI_SMALL
 		NR3D_LAUNCH_CHECK();
 		return 0;
 	}

@@ -526,3 +526,86 @@ def test_marcher_two_threads_two_streams(oracle, dev):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("scene", ["c3_random", "shell_rgbless", "sparse_misses"])
+def test_march_composite_in_one_call(oracle, dev, scene):
+    """round 6: ray_marching_composite (count -> scan -> emit -> alpha + composite without the host in between, bound-sized buffers,
+    one lazy readback) against the two-phase chain it replaces -- every march output bit-equal to the oracle's marcher, alpha / vw /
+    mask / depth / rgb and all gradients bit-equal to tau_to_alpha + packed_composite forward / backward on the same samples"""
+    from nr3d_lib_amd.bindings import _occ_grid, _pack_ops
+    rng = np.random.default_rng(11)
+    if scene == "c3_random":                                     # configs[2]: 128^3, 4096 rays, <= 512 samples per ray
+        res, side, step, max_steps, with_rgb = (128, 128, 128), 64, 2 * 3 ** 0.5 / 512, 512, True
+        grid = rng.random(res) > 0.5
+    elif scene == "shell_rgbless":
+        res, side, step, max_steps, with_rgb = (48, 40, 56), 40, 0.01, 300, False
+        grid = grids(res, 3)["shell"]
+    else:                                                        # most rays get no sample at all; a few cells only
+        res, side, step, max_steps, with_rgb = (32, 32, 32), 33, 0.02, 64, True
+        grid = rng.random(res) > 0.995
+    o, d, near, far = pinhole_rays(side, seed=7)
+    n = o.shape[0]
+    ref = oracle.ray_marching(o, d, near, far, ROI, grid, 0, np.float32(step), 1e10, 0.0, max_steps, True)
+    S = ref[1].shape[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ot, dt_, nt, ft, rt, gt = t(o), t(d), t(near), t(far), t(ROI), t(grid)
+    sigma = t((10.0 * rng.random(S + 5) ** 2).astype(np.float32))               # more rows than samples: allowed
+    rgb = t(rng.random((S + 5, 3), dtype=np.float32)) if with_rgb else None
+    thre = 0.02
+    mc = _occ_grid.ray_marching_composite(ot, dt_, nt, ft, rt, gt, _occ_grid.ContractionType.AABB, step, 1e10, 0.0, max_steps, sigma,
+                                          rgb, 1e-4, thre, True)
+    gm, gd, gc = t(rng.standard_normal(n).astype(np.float32)), t(rng.standard_normal(n).astype(np.float32)), \
+        (t(rng.standard_normal((n, 3)).astype(np.float32)) if with_rgb else None)
+    mc.backward(gm, gd, gc, need_sigma=True)                     # enqueued BEFORE anything was read back
+    out = mc.result()
+    ga, gtt, gr, gs = mc.grads()
+    assert (mc.totals()[0], out["n_hit"]) == (S, int((ref[0][:, 1] > 0).sum()))
+    for name, r in zip(["packed_info", "t_starts", "t_ends", "ridx32", "gidx"], ref):
+        assert_equal(out[name].view(r.shape), r, name=name)
+    hit = np.nonzero(ref[0][:, 1])[0]
+    assert_equal(out["ridx_hit"], hit, "ridx_hit")
+    assert_equal(out["pack_infos"], ref[0][hit].astype(np.int64), "pack_infos")
+    assert_equal(out["ridx"], ref[3].astype(np.int64), "ridx (int64)")
+    # the two-phase chain on the same samples
+    m = _occ_grid.ray_marching_finished(ot, dt_, nt, ft, rt, gt, _occ_grid.ContractionType.AABB, step, 1e10, 0.0, max_steps, True)
+    for k in ("deltas", "samples"):
+        assert_equal(out[k], m[k], k)
+    alpha = _pack_ops.tau_to_alpha_forward(sigma[:S].contiguous(), m["deltas"])
+    rgb_s = rgb[:S].contiguous() if with_rgb else None
+    vw, mask, depth, col = _pack_ops.packed_composite_forward(alpha, m["t_starts"], rgb_s, m["pack_infos"], m["ridx_hit"], n, 1e-4, thre,
+                                                              True, packs_tile=True)
+    assert_equal(out["alpha"], alpha, "alpha"); assert_equal(out["vw"], vw, "vw")
+    assert_equal(out["mask"], mask, "mask"); assert_equal(out["depth"], depth, "depth")
+    if with_rgb:
+        assert_equal(out["rgb"], col, "rgb")
+    assert float(mask.abs().sum()) > 0 and int((out["mask"] == 0).sum()) >= n - len(hit)
+    ga2, gt2, gr2 = _pack_ops.packed_composite_backward(alpha, vw, m["t_starts"], rgb_s, m["pack_infos"], m["ridx_hit"], 1e-4, thre, True,
+                                                        mask, depth, gm, gd, gc, None, packs_tile=True)
+    assert_equal(ga, ga2, "grad_alpha"); assert_equal(gtt, gt2, "grad_t")
+    if with_rgb:
+        assert_equal(gr, gr2, "grad_rgb")
+    assert_equal(gs, _pack_ops.tau_to_alpha_backward(sigma[:S].contiguous(), m["deltas"], ga2), "grad_sigma")
+
+
+def test_march_composite_handles_and_limits(dev):
+    """two outstanding handles keep their own totals; sigma with fewer rows than samples raises at the readback; outside the one-call
+    range the binding says so instead of allocating the bound"""
+    from nr3d_lib_amd.bindings import _occ_grid
+    rng = np.random.default_rng(2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    o, d, near, far = pinhole_rays(24, seed=1)
+    args = lambda g: (t(o), t(d), t(near), t(far), t(ROI), t(g), _occ_grid.ContractionType.AABB, 0.02, 1e10, 0.0, 128)
+    g1, g2 = rng.random((32, 32, 32)) > 0.5, rng.random((32, 32, 32)) > 0.9
+    sigma = torch.ones(24 * 24 * 128, device=dev)
+    a = _occ_grid.ray_marching_composite(*args(g1), sigma)
+    b = _occ_grid.ray_marching_composite(*args(g2), sigma)
+    Sa, Sb = a.totals()[0], b.totals()[0]
+    assert Sa > Sb > 0
+    assert _occ_grid.ray_marching(*args(g1), True)[1].shape[0] == Sa and _occ_grid.ray_marching(*args(g2), True)[1].shape[0] == Sb
+    short = _occ_grid.ray_marching_composite(*args(g1), sigma[:Sa - 1].contiguous())
+    with pytest.raises(RuntimeError, match="rows"):
+        short.totals()
+    big = (t(np.repeat(o, 64, 0)), t(np.repeat(d, 64, 0)), t(np.repeat(near, 64)), t(np.repeat(far, 64))) + args(g1)[4:10] + (4096,)
+    with pytest.raises(ValueError, match="two-phase"):
+        _occ_grid.ray_marching_composite(*big, sigma)
