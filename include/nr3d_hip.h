@@ -25,7 +25,7 @@ enum { NR3D_F32 = 0, NR3D_F16 = 1, NR3D_F64 = 2, NR3D_I32 = 3, NR3D_I64 = 4, NR3
 /* Bumped whenever an entry point is added, removed or changes its parameters.  nr3d_lib_amd/_abi.py (generated from this header by
  * tools/gen_abi.py at build time) carries the same number next to every entry point's argument types; the Python loader refuses a
  * library whose nr3d_abi_version() differs, so a vendored nr3d_lib_amd/ needs this header neither at import nor at run time. */
-#define NR3D_ABI_VERSION 8
+#define NR3D_ABI_VERSION 9
 
 const char *nr3d_last_error(void);
 int nr3d_abi_version(void);
@@ -468,6 +468,20 @@ int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, i
                       int64_t gx_feature_stride, float *const *dL_dW, float *const *dL_db, void *stream);
 int nr3d_mlp_forward(const nr3d_mlp_desc_t *desc, uint64_t n, const float *x, int64_t x_stride, int64_t x_feature_stride,
                      const float *packed, float *y, int64_t y_stride, void *stream);
+
+/* LoTD encode + this decoder's FORWARD in one kernel (csrc/lotd_mlp.hip; no reference counterpart -- the reference runs lod_fwd and
+ * the decoder as separate ops): for the no-grad density query of the ray driver (nr3d_lib/graphics/nerf/nerf_ray_query.py:105-127),
+ * which needs ONE number per marched sample.  out[i, c] for c < out_cols = column c of decoder(encode(x[i])) -- the SAME values as
+ * nr3d_lotd_forward followed by nr3d_mlp_forward (bit-identical when both take the two-lane forward, i.e. with the fwd_lds_stage option off; to fp32
+ * rounding of the interpolation otherwise), without the [N, n_encoded_dims] features ever reaching memory.  x [N, 3] float contiguous
+ * (already in the encoder's [0, 1] range), params / param_dtype / max_level / meta_dev as nr3d_lotd_forward, packed = the decoder's
+ * packed buffer (nr3d_mlp_pack), out float with row stride out_stride.  nr3d_lotd_mlp_forward_ok: 1 when the pair is inside the
+ * kernel's range (3-D meta of Dense / Hash levels, 2-feature pseudo levels, <= 32 encoded dims = the decoder's input width; hidden
+ * width <= 64, <= 32 outputs), else 0: the caller keeps the two calls. */
+int nr3d_lotd_mlp_forward_ok(const nr3d_lotd_meta_t *meta, const nr3d_mlp_desc_t *desc);
+int nr3d_lotd_mlp_forward(const nr3d_lotd_meta_t *meta, const void *meta_dev, uint64_t n_points, const float *x, const void *params,
+                          int param_dtype, int32_t max_level, const nr3d_mlp_desc_t *desc, const float *packed, float *out,
+                          int64_t out_stride, uint32_t out_cols, void *stream);
 
 /* The same decoder in HALF precision on the f16 MFMA (csrc/mlp_half.hip) -- the contract of the reference's fast decoder,
  * tiny-cuda-nn's FullyFusedMLP behind nr3d_lib/models/tcnn_adapter.py:37-51,74-146 (`use_tcnn_backend`,

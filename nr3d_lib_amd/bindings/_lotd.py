@@ -410,6 +410,48 @@ def lod_fwd(lod_meta, input, params, batch_inds=None, batch_offsets=None, batch_
 
 
 # ------------------------------------------------------------------------------------------------
+# encode + decoder forward in one kernel (csrc/lotd_mlp.hip; no reference counterpart)
+# ------------------------------------------------------------------------------------------------
+def lod_mlp_fwd_ok(lod_meta, mlp_desc):
+    """can ``lod_mlp_fwd`` serve this (meta, decoder) pair?  (3-D Dense / Hash meta, 2-feature pseudo levels, <= 32 encoded dims = the
+    decoder's input width; fp32 decoder with hidden width <= 64 and <= 32 outputs)"""
+    if isinstance(lod_meta, tuple) or mlp_desc is None or not getattr(mlp_desc, "fusable", False):
+        return False
+    if lod_meta._groups is not None and REGROUP:
+        return False
+    return bool(H.lib().nr3d_lotd_mlp_forward_ok(C.byref(lod_meta._cmeta()), C.byref(mlp_desc._c)))
+
+
+def lod_mlp_fwd(lod_meta, input, params, mlp_desc, mlp_packed, out_cols=None, max_level=None):
+    """out [N, out_cols] float32 = the first ``out_cols`` columns of decoder(lod_fwd(input, params)[0]) (all of them when None), computed
+    by ONE kernel that never writes the [N, n_encoded_dims] features: the no-grad density query of the ray driver
+    (nerf_ray_query.py:105-127).  ``mlp_desc`` / ``mlp_packed``: bindings._mlp.MLPDesc and its packed buffer (``_mlp.pack``).
+    No autograd: callers use it under no_grad."""
+    m = lod_meta
+    if not lod_mlp_fwd_ok(m, mlp_desc):
+        raise RuntimeError("lod_mlp_fwd: this meta / decoder pair is outside the fused kernel's range (lod_mlp_fwd_ok)")
+    N, _ = _check_common("mlp_fwd", m, input, params, None, None, None)
+    H.require_gpu(mlp_packed)
+    n_out = mlp_desc.dims[-1]
+    out_cols = n_out if out_cols is None else int(out_cols)
+    if not 1 <= out_cols <= n_out:
+        raise RuntimeError(f"lod_mlp_fwd: out_cols must be in [1, {n_out}]")
+    max_level = m.n_levels if max_level is None else int(max_level)
+    dev = input.device
+    if max_level <= -1:
+        raise RuntimeError("lod_mlp_fwd: max_level <= -1 (an all-zero encoding) keeps the two calls")
+    native = NATIVE_HALF and params.dtype == torch.float16
+    x32 = _f32c(input.detach())
+    p32 = params.detach() if native else _p32(params)
+    with H.on_device(dev):
+        out = H.empty((N, out_cols), dtype=torch.float32, device=dev)
+        H.check(H.lib().nr3d_lotd_mlp_forward(C.byref(m._cmeta()), H.ptr(m._dev(dev)), N, H.ptr(x32), H.ptr(p32),
+                                              H.F16 if native else H.F32, max_level, C.byref(mlp_desc._c), H.ptr(mlp_packed), H.ptr(out),
+                                              out_cols, out_cols, H.stream_of(input)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # lod_bwd  (lotd.cpp:32-35, lotd_torch_api.cu:397-573)
 # ------------------------------------------------------------------------------------------------
 def lod_bwd(lod_meta, dL_dy, input, params, dy_dx=None, batch_inds=None, batch_offsets=None, batch_data_size=None,

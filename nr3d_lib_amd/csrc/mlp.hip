@@ -440,6 +440,21 @@ using namespace nr3d::mlp;
 // the forward part of the packed buffer: [f32 layers | x3 planes of the same layers (0 floats when they do not fit LDS)]
 static uint64_t forward_floats(const Shape &s) { return packed_floats(s) + x3_floats(s); }
 
+namespace nr3d {
+namespace mlp {
+bool forward_region(const nr3d_mlp_desc_t *desc, const float *packed, bool &x3, const float *&region, uint32_t &region_floats,
+                    uint32_t &in_t, uint32_t &w_t, uint32_t &out_t) {
+	Shape s;
+	if (!shape_of(desc, s) || packed_floats(s) * 4 > (uint64_t)kMaxLds) return false;
+	x3 = x3_enabled() && x3_floats(s) != 0;
+	region = x3 ? packed + packed_floats(s) : packed;
+	region_floats = (uint32_t)(x3 ? x3_floats(s) : packed_floats(s));
+	in_t = s.in_t; w_t = s.w_t; out_t = s.out_t;
+	return true;
+}
+}  // namespace mlp
+}  // namespace nr3d
+
 extern "C" uint64_t nr3d_mlp_packed_floats(const nr3d_mlp_desc_t *desc) {
 	Shape s;
 	if (!shape_of(desc, s)) return 0;

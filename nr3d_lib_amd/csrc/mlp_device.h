@@ -281,5 +281,10 @@ __device__ __forceinline__ void prefetch_x(const float *__restrict__ p, int64_t 
 	else load_rows_fast<NT>(p, stride, dim, row_clamped, lane, r);
 }
 
+// host side (mlp.hip): the region of a packed decoder (nr3d_mlp_pack) the forward kernels stage in LDS -- the x3 planes when the bf16
+// route is on and they exist, else the f32 layers -- and the decoder's tile counts.  false: outside the fused kernels' range.
+bool forward_region(const nr3d_mlp_desc_t *desc, const float *packed, bool &x3, const float *&region, uint32_t &region_floats,
+                    uint32_t &in_t, uint32_t &w_t, uint32_t &out_t);
+
 }  // namespace mlp
 }  // namespace nr3d

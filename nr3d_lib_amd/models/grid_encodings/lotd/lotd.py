@@ -219,6 +219,15 @@ def lotd_get_grid_index(meta, input, bidx=None, batch_offsets=None, input_batche
     return _backend.lod_get_grid_index(meta, input, bidx, batch_offsets, bds, max_level)
 
 
+# True: LoTD.forward_decoded runs the fused encode + decode kernel (csrc/lotd_mlp.hip) where it applies; False (default): the two ops.
+# Round-6 experiment, MEASURED SLOWER and therefore off: on the 6.9 M ray-coherent marched samples of a 262 144-ray pass the fused
+# kernel takes 3.03 ms against 1.95 ms for encoder + decoder (profiles/r06_fused_query_experiment.txt) -- a wave that owns its samples
+# walks the 16 levels one after another, so every CU gathers from all 16 tables at once (46 MiB against 4 MiB of L2 per XCD), where
+# the level-major forward keeps ONE table hot per XCD and 32 waves of gathers in flight per CU; the 883 MB of features it saves
+# are worth less than that.  Values are bit-identical to the two ops; kept for small batches' launch count and as a cross-check.
+FUSE_DECODED = False
+
+
 class LoTD(nn.Module):
     """Parameter-free encoder module (the grid is passed to forward); mirrors the reference's LoTD
     (lotd.py:321-502) including its pickling protocol and read-only meta properties."""
@@ -283,6 +292,32 @@ class LoTD(nn.Module):
                       max_level=None, grad_guard=None):
         return LoTDFunctionBwdDydx.apply(self.meta, dL_dy, input, params.to(self.dtype), dy_dx, bidx, batch_offsets,
                                          self._bds(input, bidx, input_batched), self.loss_scale, max_level, grad_guard)
+
+    def forward_decoded(self, input, params, decoder, out_cols=None, max_level=None):
+        """``decoder(self(input, params))[..., :out_cols]`` WITHOUT gradients -- what a density query under no_grad computes
+        (nerf_ray_query.py:105-127: query_density on every marched sample, to prune).  When the pair is inside the fused kernel's range
+        (``bindings._lotd.lod_mlp_fwd_ok``: 3-D Dense / Hash levels of 2 features, <= 32 encoded dims, an fp32 ``models.blocks.MLP`` of
+        hidden width <= 64 with <= 32 outputs) ONE kernel encodes, decodes and stores only the ``out_cols`` requested columns: the
+        [N, n_encoded_dims] features never reach memory.  Otherwise: the two ops, sliced.  No reference counterpart (the reference runs
+        the encoder and the decoder as separate autograd ops); no autograd here -- a caller that needs gradients uses ``forward``."""
+        n_out = decoder.out_features
+        out_cols = n_out if out_cols is None else int(out_cols)
+        desc = decoder.fused_desc() if (hasattr(decoder, "fused_desc") and getattr(decoder, "dtype", None) in (None, torch.float32)) else None
+        if (FUSE_DECODED and desc is not None and input.is_cuda and input.dtype == torch.float32 and max_level is None
+                and not torch.is_autocast_enabled() and _backend.lod_mlp_fwd_ok(self.meta, desc)):
+            from nr3d_lib_amd.bindings import _mlp
+            with torch.no_grad():
+                prefix, xc, _ = _prep(input, None)
+                ws = [l.weight for l in decoder.layers]
+                bs = [l.bias for l in decoder.layers]
+                packed = _mlp.pack(desc, ws, bs, with_backward=False)
+                out = _backend.lod_mlp_fwd(self.meta, xc.flatten(0, -2), params.to(self.dtype), desc, packed, out_cols)
+            return out.unflatten(0, prefix)
+        with torch.no_grad():
+            feat = self.forward(input, params, max_level=max_level)
+            ddt = getattr(decoder, "dtype", None) or torch.float32
+            h = decoder(feat if feat.dtype == ddt else feat.to(ddt))
+        return h[..., :out_cols]
 
     def __getstate__(self):
         return self.params

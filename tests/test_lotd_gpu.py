@@ -989,3 +989,79 @@ def test_forward_lds_slabs_bit_identical(dev, hip_option, smooth, half):
     hip_option("fwd_lds_stage", 2)
     mask = H.lib().nr3d_lotd_fwd_lds_levels(ctypes.byref(meta._cmeta()), ctypes.c_uint32(n), ctypes.byref(by_slab))
     assert mask == 0b011111 and by_slab.value == 0b011100, (bin(mask), bin(by_slab.value))    # 58^3 needs 15 slabs: left to the two-lane kernel
+
+
+@pytest.mark.parametrize("case,dims", [("ngp_small", (32, 16)), ("ngp_smooth", (64, 64, 1)), ("pair_f4", (32, 32, 16)),
+                                       ("hash_npow2_f2", (48, 5)), ("ngp_pair", (32, 16))])
+@pytest.mark.parametrize("ptype", ["float", "half"])
+def test_encode_and_decode_in_one_kernel(oracle, dev, hip_option, case, dims, ptype):
+    """round 6: nr3d_lotd_mlp_forward (encode -> decoder forward, only the asked columns leave) against the two calls it replaces.
+    With the two-lane forward serving every level (fwd_lds_stage = 0) the features are the same bits and so is the decoder's output,
+    on both decoder routes (f32 MFMA / bf16 x3); against the oracle's features + a float64 decoder to 1e-5 of the column scale."""
+    from nr3d_lib_amd.bindings import _lotd, _mlp
+    # (a hash table whose size is not a power of two, 2-feature levels: the % path of the gather)
+    D, res, nf, types, T, smooth = (3, [9, 17, 33], [2, 2, 2], ["Dense", "Hash", "Hash"], 3001, False) if case == "hash_npow2_f2" else LOTD_CASES[case]
+    m_ref = oracle.lotd_create_meta(D, res, nf, types, T, smooth)
+    m = _lotd.LoDMeta(D, res, nf, types, T, smooth)
+    E = m.n_encoded_dims
+    n = 70001                                               # not a multiple of 64: a ragged last round
+    x, p, _, _ = lotd_inputs(m_ref.as_dict(), n, 5)
+    rng = np.random.default_rng(9)
+    widths = [E, *dims]
+    ws = [torch.from_numpy((rng.standard_normal((b, a)) / np.sqrt(a)).astype(np.float32)).to(dev) for a, b in zip(widths[:-1], widths[1:])]
+    bs = [torch.from_numpy((rng.standard_normal(b) * 0.1).astype(np.float32)).to(dev) for b in widths[1:]]
+    desc = _mlp.MLPDesc(widths, _mlp.ACT_RELU, _mlp.ACT_NONE)
+    assert _lotd.lod_mlp_fwd_ok(m, desc)
+    packed = _mlp.pack(desc, ws, bs)
+    xt = torch.from_numpy(x).to(dev)
+    pt = torch.from_numpy(p).to(dev)
+    pt = pt.half() if ptype == "half" else pt
+    hip_option("fwd_lds_stage", 0)
+    for x3 in (1, 0):
+        hip_option("mlp_x3", x3)
+        y, _ = _lotd.lod_fwd(m, xt, pt)
+        want = _mlp.forward(desc, y.float(), packed)
+        for cols in (None, 1):
+            got = _lotd.lod_mlp_fwd(m, xt, pt, desc, packed, out_cols=cols)
+            assert got.shape == (n, widths[-1] if cols is None else 1)
+            assert_equal(got, want[:, :got.shape[1]], f"x3={x3} cols={cols}: fused vs two calls")
+    # and against the oracle chain in float64
+    feat = oracle.lotd_fwd(m_ref, x, pt.float().cpu().numpy())[0].astype(np.float64)
+    h = feat
+    for l, (w, b) in enumerate(zip(ws, bs)):
+        h = h @ w.double().cpu().numpy().T + b.double().cpu().numpy()
+        if l + 1 < len(ws):
+            h = np.maximum(h, 0)
+    got = _lotd.lod_mlp_fwd(m, xt, pt, desc, packed)
+    assert_close(got, h, rel=2e-5 if ptype == "float" else 2e-3, name="fused encode + decode vs oracle + float64 decoder")
+
+
+def test_encode_and_decode_range_and_module(dev):
+    """outside the kernel's range the check says no and the module takes the two ops; inside, LoTD.forward_decoded == decoder(encoding)"""
+    from nr3d_lib_amd.bindings import _lotd, _mlp
+    from nr3d_lib_amd.models.blocks import MLP
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTD
+    from nr3d_lib_amd.models.grid_encodings.lotd import lotd as lotd_mod
+    D, res, nf, types, T, smooth = LOTD_CASES["mixed"]
+    m = _lotd.LoDMeta(D, res, nf, types, T, smooth)
+    assert not _lotd.lod_mlp_fwd_ok(m, _mlp.MLPDesc([m.n_encoded_dims, 32, 4]))          # VM / CP levels
+    D, res, nf, types, T, smooth = LOTD_CASES["ngp_small"]
+    m = _lotd.LoDMeta(D, res, nf, types, T, smooth)
+    assert not _lotd.lod_mlp_fwd_ok(m, _mlp.MLPDesc([m.n_encoded_dims, 128, 4]))         # hidden width 128
+    assert not _lotd.lod_mlp_fwd_ok(m, _mlp.MLPDesc([m.n_encoded_dims + 1, 32, 4]))      # not the encoder's width
+    enc = LoTD(3, res, nf, types, hashmap_size=T, dtype=torch.float)
+    torch.manual_seed(3)
+    grid = (torch.randn(enc.n_params) * 0.1).to(dev)
+    dec = MLP(enc.out_features, 16, D=1, W=32, dtype=torch.float, device=dev)
+    x = torch.rand(3, 1111, 3, device=dev)
+    with torch.no_grad():
+        want = dec(enc(x, grid))
+    assert lotd_mod.FUSE_DECODED is False              # measured slower on the full loop (round 6): the two ops are the default
+    for fuse in (True, False):
+        lotd_mod.FUSE_DECODED = fuse
+        try:
+            got = enc.forward_decoded(x, grid, dec, out_cols=2)
+        finally:
+            lotd_mod.FUSE_DECODED = False
+        assert got.shape == (3, 1111, 2) and not got.requires_grad
+        assert_close(got.reshape(-1, 2), want[..., :2].reshape(-1, 2).cpu().numpy(), rel=1e-5, name=f"forward_decoded fuse={fuse}")

@@ -67,6 +67,10 @@ class DemoField(nn.Module):
         return torch.nn.functional.softplus(h[..., 0].float()) * 20.0, h[..., 1:]
 
     def query_density(self, x, **kw):
+        if not torch.is_grad_enabled() and isinstance(self.density, MLP) and self.density.dtype in (None, torch.float32):
+            # the pruning query (no grad): encode + density decoder in ONE kernel, only the density column leaves
+            h0 = self.encoding.forward_decoded(torch.addcmul(self._half, x, self._half), self.grid, self.density, out_cols=1)
+            return torch.nn.functional.softplus(h0[..., 0]) * 20.0
         return self._h(x)[0]
 
     def forward_density(self, x, **kw):
