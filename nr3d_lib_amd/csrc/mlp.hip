@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void k_mlp_pack_x3(PackArgs a, float *__restri
 			const uint32_t it = tile % a.ni[l], ot = tile / a.ni[l];
 			const uint32_t o = 32u * ot + (lane & 31u), f = 32u * it + 8u * (2u * st + (el >> 2)) + 4u * (lane >> 5) + (el & 3u);
 			float v = 0.0f;
-			if (o < a.out_dim[l] && f < a.in_dim[l]) v = a.w[l][(size_t)o * a.in_dim[l] + f];
+			if (!a.transposed) { if (o < a.out_dim[l] && f < a.in_dim[l]) v = a.w[l][(size_t)o * a.in_dim[l] + f]; }
+			else { if (o < a.in_dim[l] && f < a.out_dim[l]) v = a.w[l][(size_t)f * a.in_dim[l] + o]; }      // W^T (the dH = W^T dPre layers)
 			const __bf16 p1 = (__bf16)v;
 			const float r1 = v - (float)p1;
 			const __bf16 p2 = (__bf16)r1;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_mlp_pack_x3(PackArgs a, float *__restri
 			wdst[e] = p1; wdst[nw + e] = p2; wdst[2u * nw + e] = p3;
 		} else {
 			const uint32_t o = e - nw;
-			bdst[o] = (a.b[l] && o < a.out_dim[l]) ? a.b[l][o] : 0.0f;
+			bdst[o] = (!a.transposed && a.b[l] && o < a.out_dim[l]) ? a.b[l][o] : 0.0f;
 		}
 	}
 }
@@ -232,31 +233,74 @@ struct BwdArgs {
 // TG: LDS tile that receives g as [feature][sample]; TB: the layer's INPUT activations as [feature][sample] (NI tiles);
 // wT: packed transposed layer.  Accumulates dW (NO x NI tiles) and the per-lane bias partial sums; when PREV, leaves
 // dL/d(input of the layer) in gp, masked with the ReLU derivative of the input activations when MASK.
-template <int NO, int NI, bool PREV, bool MASK>
+// eight consecutive samples of a [feature][sample] tile row as the three bf16 pieces of an MFMA operand (mlp_device.h split3)
+__device__ __forceinline__ void split3_row8(const float *__restrict__ src, bf8 (&p)[3], float &sum) {
+	const f4v lo = *reinterpret_cast<const f4v *>(src), hi = *reinterpret_cast<const f4v *>(src + 4);
+	const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+	for (int e = 0; e < 8; e += 2) {
+		const f2v a = {v[e], v[e + 1]};
+		const bf2 p1 = __builtin_convertvector(a, bf2);
+		const f2v r1 = a - __builtin_convertvector(p1, f2v);
+		const bf2 p2 = __builtin_convertvector(r1, bf2);
+		const f2v r2 = r1 - __builtin_convertvector(p2, f2v);
+		const bf2 p3 = __builtin_convertvector(r2, bf2);
+		p[0][e] = p1[0]; p[0][e + 1] = p1[1];
+		p[1][e] = p2[0]; p[1][e + 1] = p2[1];
+		p[2][e] = p3[0]; p[2][e + 1] = p3[1];
+		sum += v[e] + v[e + 1];
+	}
+}
+
+template <int NO, int NI, bool PREV, bool MASK, bool X3 = false>
 __device__ __forceinline__ void bwd_layer(const f16v (&g)[NO], float *__restrict__ TG, const float *__restrict__ TB,
                                           const float *__restrict__ wT, f16v (&dW)[NO][NI], float (&db)[NO], f16v (&gp)[NI],
                                           int lane) {
 	const int r = lane & 31, h = lane >> 5;
 	write_tile<NO>(TG, NO, g, lane);
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-	float bv[NI][16];
+	if constexpr (X3) {
+		// dW += dPre^T . H on the bf16 MFMA (round 6): the contraction runs over the tile's 32 samples = two K = 16 steps; lane (r, h) holds
+		// samples 16 s + 8 h .. + 7 of row r of both operands, each split into three bf16 pieces, six piece products per step -- the
+		// same fp32-grade sum as dense_x3 (smallest terms first), 12 MFMAs of 8 passes where the f32 MFMA takes 16 of 16 passes
+		constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-	for (int it = 0; it < NI; ++it) read_row16(TB, 32 * it + r, h, bv[it]);
+		for (int st = 0; st < 2; ++st) {
+			bf8 ap[NO][3], bp[NI][3];
+			float dummy = 0.0f;
 #pragma unroll
-	for (int ot = 0; ot < NO; ++ot) {
-		float av[16];
-		read_row16(TG, 32 * ot + r, h, av);
-		float sum = 0.0f;
+			for (int ot = 0; ot < NO; ++ot) split3_row8(TG + (32 * ot + r) * kTS + 16 * st + 8 * h, ap[ot], db[ot]);
 #pragma unroll
-		for (int t = 0; t < 16; ++t) sum += av[t];
-		db[ot] += sum;
+			for (int it = 0; it < NI; ++it) split3_row8(TB + (32 * it + r) * kTS + 16 * st + 8 * h, bp[it], dummy);
 #pragma unroll
-		for (int it = 0; it < NI; ++it)
+			for (int t = 0; t < 6; ++t)
 #pragma unroll
-			for (int t = 0; t < 16; ++t) dW[ot][it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[it][t], dW[ot][it], 0, 0, 0);
+				for (int ot = 0; ot < NO; ++ot)
+#pragma unroll
+					for (int it = 0; it < NI; ++it)
+						dW[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[ot][PW[t]], bp[it][PX[t]], dW[ot][it], 0, 0, 0);
+		}
+	} else {
+		float bv[NI][16];
+#pragma unroll
+		for (int it = 0; it < NI; ++it) read_row16(TB, 32 * it + r, h, bv[it]);
+#pragma unroll
+		for (int ot = 0; ot < NO; ++ot) {
+			float av[16];
+			read_row16(TG, 32 * ot + r, h, av);
+			float sum = 0.0f;
+#pragma unroll
+			for (int t = 0; t < 16; ++t) sum += av[t];
+			db[ot] += sum;
+#pragma unroll
+			for (int it = 0; it < NI; ++it)
+#pragma unroll
+				for (int t = 0; t < 16; ++t) dW[ot][it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[it][t], dW[ot][it], 0, 0, 0);
+		}
 	}
 	if (PREV) {
-		dense<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);
+		if constexpr (X3) dense_x3<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);
+		else dense<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);
 		if (MASK) {
 #pragma unroll
 			for (int t = 0; t < NI; ++t)
@@ -318,7 +362,10 @@ __device__ __forceinline__ void zero_tiles(f16v (&r)[NT]) {
 // the kernel is a chain of LDS round trips and dependent MFMAs per tile, a second wave per SIMD hides part of it.
 template <int IN_T, int W_T, int OUT_T, int NH> struct BwdCfg { static constexpr int kMaxWaves = (IN_T == 1 && W_T == 1 && OUT_T == 1 && NH <= 2) ? 8 : 4; };
 constexpr int kMaxLdsBwd = 160 * 1024;
-template <int IN_T, int W_T, int OUT_T, int NH, int FAST>
+// X3 (round 6): the forward recomputation, the dH = W^T dPre chain and the sample contraction dW = dPre^T H all run on the bf16 MFMA with
+// three-piece splits (dense_x3 / bwd_layer<..., true>); a.packed / a.packed_t then point at the x3 planes of the forward and of the
+// transposed layers.  The ReLU masks come from the SAME forward arithmetic as nr3d_mlp_forward's x3 route.
+template <int IN_T, int W_T, int OUT_T, int NH, int FAST, bool X3 = false>
 __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	{
@@ -336,8 +383,9 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 	float *TH1 = tiles + 32 * IN_T * kTS;                               // H_l at TH1 + (l - 1) * 32 * W_T * kTS
 	float *TGO = TH1 + NH * 32 * W_T * kTS;
 	// packed layers: forward [0 | hidden ... | out], then the transposed ones in the same order
-	constexpr uint32_t f0 = layer_floats(IN_T, W_T), fh = layer_floats(W_T, W_T), fo = layer_floats(W_T, OUT_T);
-	constexpr uint32_t t0 = layer_floats(W_T, IN_T), th = fh, fwd_total = f0 + (NH - 1) * fh + fo;
+	constexpr uint32_t f0 = X3 ? layer_x3_floats(IN_T, W_T) : layer_floats(IN_T, W_T), fh = X3 ? layer_x3_floats(W_T, W_T) : layer_floats(W_T, W_T);
+	constexpr uint32_t fo = X3 ? layer_x3_floats(W_T, OUT_T) : layer_floats(W_T, OUT_T);
+	constexpr uint32_t t0 = X3 ? layer_x3_floats(W_T, IN_T) : layer_floats(W_T, IN_T), th = fh, fwd_total = f0 + (NH - 1) * fh + fo;
 	const float *wf = lds, *wt = lds + fwd_total;
 
 	f16v dW0[W_T][IN_T], dWh[NH > 1 ? NH - 1 : 1][W_T][W_T], dWo[OUT_T][W_T];
@@ -378,12 +426,14 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 		}
 		// ---- forward, activations kept as [feature][sample] tiles ----
 		write_tile<IN_T>(TX, IN_T, xin, lane);
-		dense<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
+		if constexpr (X3) dense_x3<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
+		else dense<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
 		write_tile<W_T>(TH1, W_T, hcur, lane);
 #pragma unroll
 		for (int l = 1; l < NH; ++l) {
 			f16v hn[W_T];
-			dense<W_T, W_T, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
+			if constexpr (X3) dense_x3<W_T, W_T, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
+			else dense<W_T, W_T, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
 			write_tile<W_T>(TH1 + l * 32 * W_T * kTS, W_T, hcur, lane);
@@ -391,7 +441,8 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 		if (FAST && !valid) zero_tiles<OUT_T>(g_out);                    // rows past n were clamped, not zeroed
 		if (a.out_act == NR3D_MLP_ACT_RELU) {
 			f16v yo[OUT_T];
-			dense<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
+			if constexpr (X3) dense_x3<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
+			else dense<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t)
 #pragma unroll
@@ -400,25 +451,25 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 		// ---- backward sweep ----
 		const bool relu = a.hidden_act == NR3D_MLP_ACT_RELU;
 		f16v g[W_T];
-		if (relu) bwd_layer<OUT_T, W_T, true, true>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTS, wt + t0 + (NH - 1) * th, dWo, dbo, g, lane);
-		else bwd_layer<OUT_T, W_T, true, false>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTS, wt + t0 + (NH - 1) * th, dWo, dbo, g, lane);
+		if (relu) bwd_layer<OUT_T, W_T, true, true, X3>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTS, wt + t0 + (NH - 1) * th, dWo, dbo, g, lane);
+		else bwd_layer<OUT_T, W_T, true, false, X3>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTS, wt + t0 + (NH - 1) * th, dWo, dbo, g, lane);
 #pragma unroll
 		for (int l = NH - 1; l >= 1; --l) {                              // hidden layer l: H_l -> H_{l+1}
 			f16v gp[W_T];
 			float *TG = TH1 + l * 32 * W_T * kTS;                       // H_{l+1} is dead once its mask has been applied
 			const float *TB = TH1 + (l - 1) * 32 * W_T * kTS;
-			if (relu) bwd_layer<W_T, W_T, true, true>(g, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, lane);
-			else bwd_layer<W_T, W_T, true, false>(g, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, lane);
+			if (relu) bwd_layer<W_T, W_T, true, true, X3>(g, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, lane);
+			else bwd_layer<W_T, W_T, true, false, X3>(g, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) g[t] = gp[t];
 		}
 		f16v gx[IN_T];
 		if (a.gx) {
-			bwd_layer<W_T, IN_T, true, false>(g, TH1, TX, wt, dW0, db0, gx, lane);
+			bwd_layer<W_T, IN_T, true, false, X3>(g, TH1, TX, wt, dW0, db0, gx, lane);
 			if (a.gx_fm) store_cols<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, lane, gx);
 			else store_rows<IN_T>(a.gx, a.gxs, a.dims[0], row, valid, a.gx_vec != 0, lane, gx);
 		} else {
-			bwd_layer<W_T, IN_T, false, false>(g, TH1, TX, wt, dW0, db0, gx, lane);
+			bwd_layer<W_T, IN_T, false, false, X3>(g, TH1, TX, wt, dW0, db0, gx, lane);
 		}
 	}
 
@@ -492,11 +543,17 @@ static uint64_t transposed_floats(const Shape &s) {
 	return (uint64_t)layer_floats(s.w_t, s.in_t) + (uint64_t)(s.n_layers - 2) * layer_floats(s.w_t, s.w_t) + layer_floats(s.out_t, s.w_t);
 }
 
+// x3 planes of the transposed layers (round 6: the backward on the bf16 MFMA)
+static uint64_t x3t_floats(const Shape &s) {
+	return (uint64_t)layer_x3_floats(s.w_t, s.in_t) + (uint64_t)(s.n_layers - 2) * layer_x3_floats(s.w_t, s.w_t) + layer_x3_floats(s.out_t, s.w_t);
+}
+
 // per-wave [feature][sample] tiles: X, H_1 .. H_NH, G_out
 static uint32_t bwd_tile_floats(const Shape &s) { return (32u * s.in_t + (s.n_layers - 1) * 32u * s.w_t + 32u * s.out_t) * (uint32_t)kTS; }
 
-static uint32_t bwd_waves(const Shape &s) {
-	const uint64_t wbytes = (packed_floats(s) + transposed_floats(s)) * 4;
+static uint32_t bwd_waves(const Shape &s, bool x3 = false) {
+	if (x3 && x3_floats(s) == 0) return 0;
+	const uint64_t wbytes = (x3 ? x3_floats(s) + x3t_floats(s) : packed_floats(s) + transposed_floats(s)) * 4;
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;     // one layer at a time
 	const uint32_t max_waves = (s.in_t == 1 && s.w_t == 1 && s.out_t == 1 && s.n_layers - 1 <= 2) ? 8u : 4u;      // = BwdCfg<...>::kMaxWaves
 	for (uint32_t nw = max_waves; nw >= 1; --nw) {
@@ -508,10 +565,21 @@ static uint32_t bwd_waves(const Shape &s) {
 	return 0;
 }
 
+// the x3 backward is taken for the shapes whose x3 planes (forward + transposed: 1.5 x the f32 bytes) still leave LDS for as many waves'
+// tiles as the f32 kernel runs.  Measured (tools/exp_mlp_x3_bwd.py, 2^22 samples, backward alone, x3 / f32 ms): 18->32->3 0.43 / 0.54,
+// 32->64->16 0.75 / 0.88, 32->32->16 0.44 / 0.43, 32->32->32->16 0.73 / 0.70 (same waves: equal or better) -- but 32->64->64->16
+// 2.63 / 2.36: there the planes cost one of three waves, and the kernel is not bound by its MFMAs (24.6 k of 33 k cycles per tile on
+// the f32 MFMA, 9.2 k of 24 k with the splits' VALU work added and nothing to overlap it with at one wave per SIMD), so it keeps the f32 MFMA.
+static bool backward_x3_fits(const Shape &s) {
+	const uint32_t w3 = bwd_waves(s, true), w1 = bwd_waves(s, false);
+	return w3 != 0 && w3 >= w1;
+}
+
+// [f32 transposed layers | x3 planes of the transposed layers (when the x3 backward fits)]
 extern "C" uint64_t nr3d_mlp_backward_packed_floats(const nr3d_mlp_desc_t *desc) {
 	Shape s;
 	if (!shape_of(desc, s) || nr3d_mlp_packed_floats(desc) == 0 || !backward_ok(s) || bwd_waves(s) == 0) return 0;
-	return transposed_floats(s);
+	return transposed_floats(s) + (backward_x3_fits(s) ? x3t_floats(s) : 0);
 }
 
 extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *weights, const float *const *biases, float *packed,
@@ -543,6 +611,14 @@ extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *we
 		}
 		t.offset[desc->n_layers] = off;
 		hipLaunchKernelGGL(k_mlp_pack, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, t, packed + forward_floats(s));
+		if (backward_x3_fits(s)) {
+			PackArgs x = t;
+			uint32_t o3 = 0;
+			for (uint32_t l = 0; l < desc->n_layers; ++l) { x.offset[l] = o3; o3 += layer_x3_floats(t.ni[l], t.no[l]); }
+			x.offset[desc->n_layers] = o3;
+			hipLaunchKernelGGL(k_mlp_pack_x3, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, x,
+			                   packed + forward_floats(s) + transposed_floats(s));
+		}
 	}
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -640,9 +716,18 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	a.n = n; a.x = x; a.xs = x_fm ? x_feature_stride : x_stride; a.gy = dL_dy; a.gys = gy_stride; a.packed = packed;
 	a.gx = dL_dx; a.gxs = gx_fm ? gx_feature_stride : gx_stride;
 	a.x_fm = x_fm ? 1u : 0u; a.gx_fm = gx_fm ? 1u : 0u;
-	a.fwd_floats = (uint32_t)packed_floats(s);
-	a.total_floats = a.fwd_floats + (uint32_t)transposed_floats(s);
-	a.packed_t = packed + forward_floats(s);               // (the x3 planes of the forward sit in between)
+	// round 6: on the bf16 MFMA with three-piece splits (forward recomputation, dH chain, dW) when the option is on and the planes fit
+	const bool x3 = x3_enabled() && backward_x3_fits(s);
+	if (x3) {
+		a.packed = packed + packed_floats(s);
+		a.fwd_floats = (uint32_t)x3_floats(s);
+		a.total_floats = a.fwd_floats + (uint32_t)x3t_floats(s);
+		a.packed_t = packed + forward_floats(s) + transposed_floats(s);
+	} else {
+		a.fwd_floats = (uint32_t)packed_floats(s);
+		a.total_floats = a.fwd_floats + (uint32_t)transposed_floats(s);
+		a.packed_t = packed + forward_floats(s);               // (the x3 planes of the forward sit in between)
+	}
 	for (uint32_t l = 0; l < desc->n_layers; ++l) {
 		NR3D_CHECK(dL_dW[l] != nullptr, "mlp_backward: dL_dW[%u] is NULL", l);
 		a.dW[l] = dL_dW[l];
@@ -655,7 +740,7 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	a.gy_vec = ((uintptr_t)dL_dy % 16 == 0 && gy_stride % 4 == 0) ? 1u : 0u;
 	a.gx_vec = (dL_dx && (uintptr_t)dL_dx % 16 == 0 && gx_stride % 4 == 0) ? 1u : 0u;
 	a.tile_floats = bwd_tile_floats(s);
-	const uint32_t nw = bwd_waves(s);
+	const uint32_t nw = bwd_waves(s, x3);
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;
 	const uint64_t tbytes = (uint64_t)nw * a.tile_floats * 4;
 	const size_t lds = (size_t)a.total_floats * 4 + (size_t)(tbytes > reduce ? tbytes : reduce);
@@ -670,8 +755,9 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 		return 0;
 	};
 	int rc = 0;
-#define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) \
-		rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1>) : launch(k_mlp_bwd<I, W, O, H, 0>); else
+#define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) { \
+		if (x3) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, true>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, true>) : launch(k_mlp_bwd<I, W, O, H, 0, true>); \
+		else rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1>) : launch(k_mlp_bwd<I, W, O, H, 0>); } else
 	BWD_CASE(1, 1, 1, 1) BWD_CASE(1, 1, 1, 2) BWD_CASE(1, 1, 1, 3)
 	BWD_CASE(1, 2, 1, 1) BWD_CASE(1, 2, 1, 2) BWD_CASE(1, 2, 2, 1) BWD_CASE(1, 2, 2, 2)
 	BWD_CASE(2, 2, 1, 1) BWD_CASE(2, 2, 1, 2) BWD_CASE(2, 2, 2, 1) BWD_CASE(2, 2, 2, 2)

@@ -476,3 +476,41 @@ def test_fp32_forward_on_the_bf16_mfma_is_fp32_grade(dev, hip_option, dims):
         err[mode] = float((y.double() - ref).abs().max()) / scale
     assert err[0] < 5e-6 and err[1] < 5e-6, err
     assert err[1] <= 3.0 * err[0] + 2e-7, f"three-piece bf16 route {err[1]:.2e} against the f32 MFMA's {err[0]:.2e}"
+
+
+@pytest.mark.parametrize("dims", [[32, 64, 64, 16], [32, 32, 16], [18, 32, 3], [27, 32, 32, 32, 1], [32, 64, 48]])
+def test_fp32_backward_on_the_bf16_mfma_is_fp32_grade(dev, hip_option, dims):
+    """round 6: the fp32 backward's two routes -- the f32 MFMA (mlp_x3 = 0) and the bf16 MFMA on three-piece splits (1, default: forward
+    recomputation, dH = W^T dPre chain and the sample contraction dW = dPre^T H) -- against the same network differentiated in float64:
+    the split route must be as close to it as the f32 route is, for dL/dx, every dL/dW and every dL/db"""
+    from nr3d_lib_amd.bindings import _mlp
+    m = _net(dims, "relu", None, True, dev, seed=17)
+    desc = m.fused_desc()
+    assert desc is not None and desc.backward_fusable
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = 8205
+    x = (torch.randn(n, dims[0], generator=g) * torch.logspace(-2, 1, dims[0])[None, :]).to(dev)
+    gy = torch.randn(n, dims[-1], generator=g).to(dev)
+    m64 = [(l.weight.detach().double().requires_grad_(True), l.bias.detach().double().requires_grad_(True)) for l in m.layers]
+    x64 = x.double().requires_grad_(True)
+    h = x64
+    for i, (w, b) in enumerate(m64):
+        h = torch.nn.functional.linear(h, w, b)
+        if i + 1 < len(m64):
+            h = torch.relu(h)
+    h.backward(gy.double())
+    ref = [x64.grad] + [w.grad for w, _ in m64] + [b.grad for _, b in m64]
+    err = {}
+    for mode in (0, 1):
+        hip_option("mlp_x3", mode)
+        xr = x.detach().requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        m(xr).backward(gy)
+        got = [xr.grad] + [l.weight.grad for l in m.layers] + [l.bias.grad for l in m.layers]
+        assert all(torch.isfinite(t).all() for t in got)
+        # a ReLU unit whose pre-activation rounds to the other side of zero flips one sample's contribution on either route: compare
+        # by the norm of the difference relative to the norm of the reference, per tensor
+        err[mode] = [float((a.double() - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(got, ref)]
+    assert max(err[0]) < 2e-5 and max(err[1]) < 2e-5, err
+    for e0, e1 in zip(err[0], err[1]):
+        assert e1 <= 3.0 * e0 + 1e-6, f"three-piece bf16 backward {e1:.2e} against the f32 MFMA's {e0:.2e}"
