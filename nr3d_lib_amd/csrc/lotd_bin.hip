@@ -17,7 +17,8 @@
 //
 // Both stages are pure streaming (12 B per corner update written once and read once); the fp64 accumulation makes
 // the result independent of the update order up to the final f64->f32 rounding.
-#include "lotd_device.h"
+#include "lotd_vm.h"
+#include "lotd_sorted.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -260,74 +261,6 @@ __device__ __forceinline__ uint32_t emit_plane_line(const Lvl &L, const Cell<3> 
 		}
 	}
 	return VM ? 18u : 6u;
-}
-
-// ONE component d of a VM level's updates (records 0..3: the plane's four entries, 4..5: the line's two), for the
-// three-threads-per-point form of stage A (bin_body, SPLIT == 3), in SEPARABLE form: with (A, B) the plane's dims, m its corner,
-// wo_m = w_A w_B, LI = lerp_d(line), PI = sum_m wo_m plane_m:
-//     first order    plane_m += g wo_m LI                              line_s += g w_d(s) PI
-//     second order   plane_m += g (wo_m a_d (line_1 - line_0) + C_m LI) line_s += g (a_d sgn(s) PI + w_d(s) PC)
-//                    C_m = a_A sgn_A w_B + a_B sgn_B w_A,  PC = sum_m C_m plane_m,  a = scale w' v
-// -- what emit_plane_line sums corner by corner from the eight corner weights ((g w_k0) line_0 + (g w_k1) line_1, ...): the
-// same polynomial, other association, a third of the arithmetic and no corner-weight array (stage A of the VM levels was
-// half VALU after the split, profiles/r03m_c4_counters.txt).
-template <int G, int DC, int NRT, bool SECOND, typename TB>
-__device__ __forceinline__ uint32_t emit_vm_component(const Lvl &L, const Cell<3> &c, const float (&a)[3], const float (&grad)[G],
-                                                      TB grid, uint32_t foff, uint32_t (&ent)[NRT], float (&val)[NRT][G]) {
-	static_assert(NRT >= 6, "six records per VM component");
-	constexpr int DA = DC == 0 ? 1 : 0, DB = DC == 2 ? 1 : 2;          // the plane's dims, ascending: bit 0 / bit 1 of m
-	// (round 4, measured: one 8-byte load per feature pair behind a run-time alignment test instead of the two 4-byte loads below is
-	// SLOWER -- k_vm_direct 1.28 -> 1.39 ms, k_bin_vm3 1.03 -> 1.07 -- the pair's second word is an L1 hit either way)
-	float pv[4][G], lv[2][G];
-	uint32_t pe[4], le[2];
-#pragma unroll
-	for (uint32_t m = 0; m < 4; ++m) {
-		uint32_t p[3], pl[3], ln[3];
-		corner_pos<3>(c, insert_zero(m, DC), p);
-		entry_vm(L, p, pl, ln);
-		pe[m] = pl[DC];
-		if (m == 0) le[0] = ln[DC];
-#pragma unroll
-		for (int f = 0; f < G; ++f) pv[m][f] = grid[pe[m] * L.F + foff + f];
-	}
-	le[1] = le[0] + 1u;
-#pragma unroll
-	for (uint32_t sl = 0; sl < 2; ++sl)
-#pragma unroll
-		for (int f = 0; f < G; ++f) lv[sl][f] = grid[le[sl] * L.F + foff + f];
-	const float wd1 = c.w[DC], wd0 = 1.0f - wd1;
-	float wo[4], Cm[4];
-#pragma unroll
-	for (uint32_t m = 0; m < 4; ++m) {
-		const float wa = (m & 1u) ? c.w[DA] : 1.0f - c.w[DA], wb = (m & 2u) ? c.w[DB] : 1.0f - c.w[DB];
-		wo[m] = wa * wb;
-		Cm[m] = SECOND ? __fmaf_rn((m & 1u) ? a[DA] : -a[DA], wb, ((m & 2u) ? a[DB] : -a[DB]) * wa) : 0.0f;
-	}
-#pragma unroll
-	for (int f = 0; f < G; ++f) {
-		const float LI = __fmaf_rn(wd1, lv[1][f], wd0 * lv[0][f]);
-		float PI = 0.0f, PC = 0.0f;
-#pragma unroll
-		for (uint32_t m = 0; m < 4; ++m) { PI = __fmaf_rn(wo[m], pv[m][f], PI); if (SECOND) PC = __fmaf_rn(Cm[m], pv[m][f], PC); }
-		if (!SECOND) {
-			const float gl = grad[f] * LI, gp = grad[f] * PI;
-#pragma unroll
-			for (uint32_t m = 0; m < 4; ++m) val[m][f] = gl * wo[m];
-			val[4][f] = gp * wd0;
-			val[5][f] = gp * wd1;
-		} else {
-			const float dl = a[DC] * (lv[1][f] - lv[0][f]);
-#pragma unroll
-			for (uint32_t m = 0; m < 4; ++m) val[m][f] = grad[f] * __fmaf_rn(wo[m], dl, Cm[m] * LI);
-			const float ap = a[DC] * PI;
-			val[4][f] = grad[f] * __fmaf_rn(wd0, PC, -ap);
-			val[5][f] = grad[f] * __fmaf_rn(wd1, PC, ap);
-		}
-	}
-#pragma unroll
-	for (uint32_t m = 0; m < 4; ++m) ent[m] = pe[m];
-	ent[4] = le[0]; ent[5] = le[1];
-	return 6u;
 }
 
 // The parameter updates of one (point, pseudo level): table entry + G values each.  `w[k]` is the weight of corner k
@@ -1410,18 +1343,6 @@ struct VmPlan {
 	uint16_t row0[kVmDirectMaxItems];       // ... first CELL row (along the plane's first dim) it owns
 	uint16_t nrows[kVmDirectMaxItems];      // ... and how many (its LDS band holds nrows + 1 rows of entries)
 };
-struct VmGeom { uint32_t Ra, Rb, plane_lo, line_lo, Rd; int a; };
-__host__ __device__ inline VmGeom vm_geom(const uint32_t (&res)[NR3D_LOTD_MAX_DIMS], int d) {
-	VmGeom gm;
-	gm.a = d == 0 ? 1 : 0;
-	const int b = d == 2 ? 1 : 2;
-	gm.Ra = res[gm.a]; gm.Rb = res[b]; gm.Rd = res[d];
-	const uint32_t lines = res[0] + res[1] + res[2];
-	const uint32_t psz[3] = {res[1] * res[2], res[0] * res[2], res[0] * res[1]};
-	gm.plane_lo = lines + (d > 0 ? psz[0] : 0u) + (d > 1 ? psz[1] : 0u);
-	gm.line_lo = (d > 0 ? res[0] : 0u) + (d > 1 ? res[1] : 0u);
-	return gm;
-}
 
 template <bool SECOND, typename PT>
 __global__ __launch_bounds__(kVmDirectThreads) void k_vm_direct(VmPlan vp, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n, uint32_t smooth,
@@ -1603,7 +1524,7 @@ static uint64_t vm_direct_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t mi
 	return mask;
 }
 
-#include "lotd_sorted.inc"
+// (the sorted-points path of large VM levels: lotd_sorted.hip, its own translation unit)
 
 // plan for the pseudo levels of record class `cls` (0 levels => n_pseudo == 0)
 // only != 0: exactly the pseudo levels of that mask, whatever their class, in blocks of `only_bp` points with `only_nr` records per

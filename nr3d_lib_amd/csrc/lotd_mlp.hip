@@ -177,7 +177,12 @@ __global__ __launch_bounds__(kThreads, NR3D_FM_MINW) void k_fwd_mlp(Args a) {
 					float yv[kSub];
 					finish_level(ring[d], side, yv);
 #pragma unroll
-					for (int u = 0; u < kSub; ++u) tile[(u * 32 + pl) * kTS + 2u * q + side] = yv[u];
+					for (int u = 0; u < kSub; ++u) {
+						// half tables: the encoder's output is half (lotd_encoding.h:1501-1504) -- the decoder sees the rounded features,
+						// as it does behind the two calls
+						if constexpr (sizeof(PT) == 2) yv[u] = __half2float(__float2half(yv[u]));
+						tile[(u * 32 + pl) * kTS + 2u * q + side] = yv[u];
+					}
 					if (q + kDepth < a.n_pseudo) issue_level<PT>(a, q + kDepth, xp, side, ring[d]);
 				}
 			}

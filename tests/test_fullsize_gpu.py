@@ -266,7 +266,7 @@ def test_c5_per_rank_shard_2p21_rays(dev, nccl_group_fullsize):
         rays = dict(num_rays=hi - lo, rays_o=o[lo:hi], rays_d=d[lo:hi], near=near[lo:hi], far=far[lo:hi],
                     rays_inds=torch.arange(hi - lo, device=dev))
         vb, det = nerf_ray_query_march_occ(model, rays, with_rgb=True, compression=True)
-        out = composite_packed_volume_buffer(vb, hi - lo)
+        out = composite_packed_volume_buffer(vb, hi - lo, device=dev)       # (an empty buffer carries no tensors to take the device from)
         if backward:
             # sums, not means: a chunk's loss must not depend on how many rays the chunk has
             (out["rgb_volume"].sum() * (1.0 / N) + out["depth_volume"].sum() * (1.0 / N)).backward()

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 : > "$OUT/forest_sorted_counters.txt"
 for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
             "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" \
+            "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU" \
             "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
   rm -rf /tmp/prof_fc && rocprofv3 --kernel-trace --pmc $CTRS -d /tmp/prof_fc -o p -- python /tmp/forest_run.py > /tmp/fc.log 2>&1
   DB=$(find /tmp/prof_fc -name '*.db' | head -1)
