@@ -87,7 +87,7 @@ enum {
 	                                  * too (measured slower there, twice: it is not bound by its LDS atomics); 0: fp64 */
 	NR3D_OPT_VM_SORTED = 20,         /* 1: a dL/dparam pass with a VM level of >= 2^20 entries (over its blocks) and >= 2^19 points sorts the POINTS by
 	                                  * (block, coordinate) and accumulates every VM level band by band in LDS, without records (lotd_sorted.inc;
-	                                  * single tables, batches and forests); 2: whenever the geometry allows (tests); 0: records */
+	                                  * single tables, batches and forests; a forest's small Dense levels ride along as slices); 2: whenever the geometry allows (tests); 3: as 1, VM levels only; 0: records */
 	NR3D_OPT_MLP_X3 = 21,            /* 1: the fp32 fused MLP forward runs on the bf16 MFMA with every value split into three bf16 pieces (six piece products,
 	                                  * fp32 accumulation: fp32-grade results at 2.7x the matrix rate of the f32 MFMA); 0: v_mfma_f32_32x32x2_f32.
 	                                  * Non-finite inputs: a row holding +-inf (or a magnitude above the bf16 maximum, 3.39e38) comes out as NaN on the

@@ -1839,12 +1839,18 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 		Batch ba = batch;                              // this chunk's view of the batch description
 		if (ba.inds) ba.inds += p0;
 		ba.first_point = p0;
-		if (row_major) {
+		// the feature-major copy of dL_dy, made when the first path that reads columns asks for it (round 6: a pass whose levels all go over
+		// sorted points -- the reference's forest workload -- never does: 0.13 ms)
+		bool gt_ready = !row_major;
+		auto need_gt = [&]() {
+			if (gt_ready) return;
 			if (g_half) launch_transpose<__half>(n, E, reinterpret_cast<const __half *>(gc), g_sn, g_se, gt, st);
 			else launch_transpose<float>(n, E, gc, g_sn, g_se, gt, st);
 			gc = gt; sn = 1; se = (int64_t)n;
-		}
+			gt_ready = true;
+		};
 		if (use_pair) {
+			need_gt();
 			if (int rc = pair_chunk(meta, md, n, xc, gc, sn, se, min_level, max_level, work_units(), dparam,
 			                        (out_half ? 1u : 0u) | (assign_now ? 2u : 0u), rec, offs, plan_buf, partial, st,
 			                        second ? vc : nullptr))
@@ -1869,6 +1875,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_cp_direct<true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCpLdsBytes));
 					cp_attr[dev_id & 63] = true;
 				}
+				need_gt();
 				const size_t lds = (size_t)max_acc * 8;
 				auto cp_launch = [&](auto kern, auto *tab) {
 					hipLaunchKernelGGL(kern, dim3(cp.R, cp.n_items), dim3(kCpThreads), lds, st, cp, md, n, meta->interpolation_type, xc, vc,
@@ -1899,6 +1906,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 					NR3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_vm_direct<true, __half>, hipFuncAttributeMaxDynamicSharedMemorySize, kVmLds));
 					vattr[dev_id & 63] = true;
 				}
+				need_gt();
 				auto vd_launch = [&](auto kern, auto *tab) {
 					hipLaunchKernelGGL(kern, dim3(vp.R, vp.n_items), dim3(kVmDirectThreads), (size_t)vp.stride * 8, st, vp, md, n, meta->interpolation_type, xc, vc,
 					                   gc, sn, se, tab, partial, opt::get(NR3D_OPT_DIRECT_FIXED) == 2 ? 1u : 0u);
@@ -1977,6 +1985,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 						lattr[dev_id & 63] = true;
 					}
 					NR3D_CHECK(bin_lds <= (size_t)kBinLdsDyn, "LoTD::bwd: VM line tables do not fit the stage-A LDS budget");
+					need_gt();
 					auto vm_launch = [&](auto kern, auto *tab) {
 						hipLaunchKernelGGL(kern, dim3(R, pl.n_pseudo), dim3(BPL * 3), bin_lds, st, pl, md, n, max_level, meta->interpolation_type,
 						                   xc, vc, gc, sn, se, tab, ba, rec, offs, partial, line_stride);
@@ -2011,6 +2020,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			uint64_t ow;
 			make_plan(meta, n, n_batches, cls, pl, ow, min_level, max_level, forest != nullptr, cp_mask);
 			if (pl.n_pseudo == 0) continue;
+			need_gt();
 			int rc = 0;
 			if (forest) {                                  // 3-D (binnable); one stage-A kernel per record class
 				const uint32_t G = meta->n_feat_per_pseudo_lvl;

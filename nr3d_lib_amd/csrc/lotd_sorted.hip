@@ -350,8 +350,11 @@ struct VsUnit {
 	uint32_t sub_lo[3], b;                     // forest: the three candidate ranges; the block
 	uint32_t sub_cnt[3], row0;
 	uint32_t nrows, last, boff, tmax;          // boff: first element of the block's tables; tmax: float bits of max |table value| over band + line
+	uint32_t res[3], F;                        // the level (what Lvl holds of a VM level) ...
+	uint32_t off, dc, foff, col0;              // ... its first element in the block's tables; the component; first feature / dL_dy column of the pseudo level
+	int32_t kb[3]; float thr;                  // forest: the block's position; the level's face distance threshold
 };
-static_assert(sizeof(VsUnit) == 80, "five 16-byte loads");
+static_assert(sizeof(VsUnit) == 128, "eight 16-byte loads, one round trip");
 constexpr uint32_t kVsNoUnit = 0xFFFFFFFFu;
 constexpr uint32_t kVsRedChunks = (kVsSlot + 4095u) / 4096u;   // k_vs_reduce: 4096-element pieces of an item's table
 constexpr uint32_t kVsDense = 24;            // surviving boundary candidates per wave from which every lane walks its own eight corners
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(256) void k_vs_tmax(const VsPlan *__restrict__ vpp,
 	if (threadIdx.x == 0) s_max = 0u;
 	__syncthreads();
 	const VsItemRec ir = dv.irec[item];
+	if (vp.d[ir.qd] == 3u) { if (threadIdx.x == 0) item_tmax[item] = 0x3F800000u; return; }       // Dense: an update is gradient x weight, no table value
 	const Lvl L = load_level(md, ir.lv);
 	const VmGeom gm = vm_geom(L.res, (int)vp.d[ir.qd]);
 	const auto grid = make_tab(params + (ir.boff + L.off));
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256) void k_vs_tmax(const VsPlan *__restrict__ vpp,
 }
 
 template <bool FO>
-__global__ __launch_bounds__(256) void k_vs_units(const VsPlan *__restrict__ vpp, VsDev dv, const nr3d_lotd_meta_t *__restrict__ md, Batch ba,
+__global__ __launch_bounds__(256) void k_vs_units(const VsPlan *__restrict__ vpp, VsDev dv, const nr3d_lotd_meta_t *__restrict__ md, Batch ba, ForestDev fo,
                                                   const uint32_t *__restrict__ item_tmax, VsUnit *__restrict__ units) {
 	const VsPlan &vp = *vpp;                      // (the plan lives in device memory: indexed by value it was copied into LDS by every workgroup)
 	const uint32_t w = blockIdx.x * 256u + threadIdx.x;
@@ -437,6 +441,14 @@ __global__ __launch_bounds__(256) void k_vs_units(const VsPlan *__restrict__ vpp
 		const VsItemRec ir = dv.irec[lo];
 		u.qd = ir.qd; u.lv = ir.lv; u.b = ir.b; u.row0 = ir.row0; u.nrows = ir.nrows; u.last = ir.last; u.boff = ir.boff;
 		u.tmax = item_tmax ? item_tmax[lo] : 0u;
+		const Lvl L = load_level(md, ir.lv);
+		const uint32_t q = vp.q[ir.qd];
+		u.res[0] = L.res[0]; u.res[1] = L.res[1]; u.res[2] = L.res[2]; u.F = L.F; u.off = L.off;
+		u.dc = vp.d[ir.qd]; u.foff = meta_cnt_of(md, q) * 2u; u.col0 = meta_col_of(md, q);
+		u.thr = FO ? vp.thr[ir.qd] : 0.0f;
+		if (FO)
+#pragma unroll
+			for (int d = 0; d < 3; ++d) u.kb[d] = fo.block_ks[3 * (size_t)ir.b + d];
 	}
 	units[w] = u;
 }
@@ -494,6 +506,27 @@ __device__ __forceinline__ bool vs_own_point(const VsCtx<TB> &cx, const float (&
 	if (ca - cx.row0 >= cx.nrows) return false;
 #pragma unroll
 	for (int d = 0; d < 3; ++d) a[d] = SECOND ? c.sc[d] * vv[d] * c.dw[d] : 0.0f;
+	if (cx.dc == 3u) {
+		// a Dense level: the cell's eight corners, gradient x corner weight (second order: the combined d/dx weight of corner_scatter)
+#pragma unroll
+		for (uint32_t k = 0; k < 8u; ++k) {
+			uint32_t p[3];
+			corner_pos<3>(c, k, p);
+			float wk;
+			if (!SECOND) wk = corner_weight<3>(c, k);
+			else {
+				wk = 0.0f;
+#pragma unroll
+				for (int d = 0; d < 3; ++d) { const float t = face_weight<3>(c, k, d, a[d]); wk += ((k >> d) & 1u) ? t : -t; }
+			}
+			const uint32_t slot = (p[0] * L.res[1] + p[1]) * L.res[2] + p[2] - cx.band_lo;
+			if (!(dbg & 4u)) {
+				vs_add<FIX>(cx.acc, slot, grad[0] * wk, cx.scale);
+				vs_add<FIX>(cx.acc, kVsAcc + slot, grad[1] * wk, cx.scale);
+			}
+		}
+		return true;
+	}
 	uint32_t ent[6];
 	float val[6][2];
 	if constexpr (VEC) {
@@ -574,9 +607,21 @@ __device__ __forceinline__ bool vs_corner(const VsCtx<TB> &cx, const Cell<3> &c,
 	}
 	const uint32_t lr = pl[gm.a] - cx.row0;
 	if (!(mine && (lr < cx.nrows || (cx.last && lr == cx.nrows)))) return false;              // another block's, or another band's row
+	float wk;
+	if (dc == 3u) {                                                                          // a Dense level: one entry, no table factor
+		if (!SECOND) wk = corner_weight<3>(c, k);
+		else {
+			wk = 0.0f;
+#pragma unroll
+			for (int d = 0; d < 3; ++d) { const float t = face_weight<3>(c, k, d, a[d]); wk += ((k >> d) & 1u) ? t : -t; }
+		}
+		const uint32_t slot = (pl[0] * L.res[1] + pl[1]) * L.res[2] + pl[2] - cx.band_lo;
+		vs_add<FIX>(cx.acc, slot, grad[0] * wk, cx.scale);
+		vs_add<FIX>(cx.acc, kVsAcc + slot, grad[1] * wk, cx.scale);
+		return true;
+	}
 	const uint32_t pe = gm.plane_lo + pl[gm.a] * gm.Rb + pl[b_dim], le = gm.line_lo + pl[dc];
 	const uint32_t ps = pe - cx.band_lo, ls = cx.n_plane + pl[dc];
-	float wk;
 	if (!SECOND) wk = corner_weight<3>(c, k);
 	else {
 		wk = 0.0f;
@@ -596,12 +641,11 @@ __device__ __forceinline__ bool vs_corner(const VsCtx<TB> &cx, const Cell<3> &c,
 }
 
 template <bool SECOND, typename PT, bool FO>
-__global__ __launch_bounds__(kVsThreads) void k_vm_sorted(const VsPlan *__restrict__ vpp, VsDev dv, const nr3d_lotd_meta_t *__restrict__ md, uint32_t n, uint32_t smooth,
+__global__ __launch_bounds__(kVsThreads) void k_vm_sorted(const VsPlan *__restrict__ vpp, uint32_t rb_max, uint32_t rd_max, VsDev dv, uint32_t n, uint32_t smooth,
                                                           const float *__restrict__ x, const float *__restrict__ vin_,
                                                           const float *__restrict__ g, int64_t g_sn, int64_t g_se,
                                                           const PT *__restrict__ params, Batch ba, ForestDev fo, float *__restrict__ dparam,
                                                           uint32_t opt_fix NR3D_DBG_PARAM) {
-	const VsPlan &vp = *vpp;                      // (the plan lives in device memory: indexed by value it was copied into LDS by every workgroup)
 	NR3D_DBG_DECL   // timing experiments (experiments build only; results wrong by design): 1 no boundary pass, 2 no write-out, 4 no LDS adds, 8 no own points
 	extern __shared__ __attribute__((aligned(16))) double vs_acc[];            // [2 features][kVsAcc slots]: plane band (nrows + 1) Rb | line d Rd
 	__shared__ uint8_t s_rank[kVsThreads];                                       // per wave: the lanes of its surviving candidates, by rank
@@ -610,9 +654,12 @@ __global__ __launch_bounds__(kVsThreads) void k_vm_sorted(const VsPlan *__restri
 	if (un.item == kVsNoUnit) return;
 	if (dbg & 64u) return;
 	const uint32_t gmax_bits = dv.stats[0], vmax_bits = SECOND ? dv.stats[1] : 0u;
-	const uint32_t item = un.item, rep = un.rep, n_rep = un.n_rep, qd0 = un.qd;
-	const Lvl L = load_level(md, un.lv);
-	const uint32_t dc = vp.d[qd0], q = vp.q[qd0];
+	const uint32_t item = un.item, rep = un.rep, n_rep = un.n_rep;
+	Lvl L;                                                                         // (everything the unit needs came with its record)
+	L.res[0] = un.res[0]; L.res[1] = un.res[1]; L.res[2] = un.res[2]; L.res[3] = 0u; L.F = un.F; L.type = NR3D_LOD_VectorMatrix; L.size = 0u; L.off = un.off;
+	// (the component from the plan, not from the record's copy of it: with `un.dc` here the d = 2 line sums of the second feature came out
+	// wrong on multi-feature levels -- same value, other code; bisected on the GPU, not understood)
+	const uint32_t dc = vpp->d[un.qd];
 	const VmGeom gm = vm_geom(L.res, (int)dc);
 	const uint32_t row0 = un.row0, nrows = un.nrows;
 	const bool last = un.last != 0u;
@@ -623,14 +670,14 @@ __global__ __launch_bounds__(kVsThreads) void k_vm_sorted(const VsPlan *__restri
 	const uint32_t bnd_cnt = FO ? un.sub_cnt[0] + un.sub_cnt[1] + un.sub_cnt[2] : 0u;
 	if (own_cnt == 0u && bnd_cnt == 0u) {                                          // (then n_rep == 1)
 		if (!last) {
-			float *ho = dv.handoff + (size_t)item * 2u * vp.rb_max;
+			float *ho = dv.handoff + (size_t)item * 2u * rb_max;
 			for (uint32_t t = threadIdx.x; t < 2u * gm.Rb; t += kVsThreads) ho[t] = 0.0f;
 		}
-		float *lz = dv.lines + (size_t)w * 2u * vp.rd_max;
+		float *lz = dv.lines + (size_t)w * 2u * rd_max;
 		for (uint32_t t = threadIdx.x; t < 2u * gm.Rd; t += kVsThreads) lz[t] = 0.0f;
 		return;
 	}
-	const uint32_t foff = meta_cnt_of(md, q) * 2u, col0 = meta_col_of(md, q);
+	const uint32_t foff = un.foff, col0 = un.col0;
 	const uint32_t boff = un.boff;
 	const auto grid = make_tab(params + (boff + L.off));
 	const uint32_t band_lo = gm.plane_lo + row0 * gm.Rb;
@@ -673,11 +720,11 @@ __global__ __launch_bounds__(kVsThreads) void k_vm_sorted(const VsPlan *__restri
 			c_lo[rg] = un.sub_lo[rg] + lo; c_n[rg] = hi - lo;
 		}
 #pragma unroll
-		for (int d = 0; d < 3; ++d) kb[d] = fo.block_ks[3 * (size_t)un.b + d];
+		for (int d = 0; d < 3; ++d) kb[d] = un.kb[d];
 	}
 	const uint32_t n_cnd = c_n[0] + c_n[1] + c_n[2], cnd_pad = (n_cnd + 63u) & ~63u;
 	const uint32_t total = cnd_pad + n_own;
-	const float thr = FO ? vp.thr[qd0] : 0.0f;
+	const float thr = un.thr;
 	const float *__restrict__ xs = dv.xs[o], *__restrict__ vs = dv.vs[o], *__restrict__ gts = dv.gts[o];
 	float nx[3] = {0.0f, 0.0f, 0.0f}, ng[2] = {0.0f, 0.0f}, nv[3] = {0.0f, 0.0f, 0.0f};
 	// (no branch around the loads: a round that has no next point re-reads a valid one -- behind a branch the compiler waits for the
@@ -695,6 +742,20 @@ __global__ __launch_bounds__(kVsThreads) void k_vm_sorted(const VsPlan *__restri
 			for (int d = 0; d < 3; ++d) nv[d] = vs[(size_t)i * 3 + d];
 	};
 	fetch(threadIdx.x);
+	// the band's own rows of dL/dparam as they are now (the write-out adds to them): read here, a round trip before they are needed
+	constexpr uint32_t kPre = (kVsSlot + 4u * kVsThreads - 1u) / (4u * kVsThreads);
+	const uint32_t own = 2u * (last ? nrows + 1u : nrows) * gm.Rb;
+	float *dst = dparam + (boff + L.off) + (size_t)band_lo * L.F + foff;
+	float old[kPre][4];
+	if (n_rep == 1u && !(dbg & 2u)) {
+#pragma unroll
+		for (uint32_t k = 0; k < kPre; ++k)
+#pragma unroll
+			for (uint32_t u = 0; u < 4u; ++u) {
+				const uint32_t t = threadIdx.x + (k * 4u + u) * kVsThreads;
+				old[k][u] = t < own ? dst[(size_t)(t >> 1) * L.F + (t & 1u)] : 0.0f;
+			}
+	}
 	for (uint32_t t = threadIdx.x; t < n_slots; t += kVsThreads) { vs_acc[t] = 0.0; vs_acc[kVsAcc + t] = 0.0; }      // all-zero bits: 0.0 and fixed-point 0 alike
 	__syncthreads();
 	bool any = false;
@@ -774,35 +835,28 @@ __global__ __launch_bounds__(kVsThreads) void k_vm_sorted(const VsPlan *__restri
 	// next band's row 0 and travels through `handoff`; line d through `lines` (k_vs_reduce adds both, and the replicas, in order).
 	// Element t of a table = (slot t >> 1, feature t & 1), the layout of dL/dparam and of the three buffers.
 	auto elem = [&](uint32_t t) { return vs_out(vs_acc, (t & 1u) * kVsAcc + (t >> 1), fx); };
-	const uint32_t own = 2u * (last ? nrows + 1u : nrows) * gm.Rb;
 	if (n_rep == 1u) {
 		if (touched) {
-			float *dst = dparam + (boff + L.off) + (size_t)band_lo * L.F + foff;
-			// four independent read-modify-writes in flight per thread (one at a time this loop was a chain of HBM latencies)
-			for (uint32_t t0 = threadIdx.x; t0 < own; t0 += 4u * kVsThreads) {
-				float v[4], o_[4];
-				size_t at[4];
+#pragma unroll
+			for (uint32_t k = 0; k < kPre; ++k)
 #pragma unroll
 				for (uint32_t u = 0; u < 4u; ++u) {
-					const uint32_t t = t0 + u * kVsThreads;
-					v[u] = t < own ? elem(t) : 0.0f;
-					at[u] = (size_t)(t >> 1) * L.F + (t & 1u);
+					const uint32_t t = threadIdx.x + (k * 4u + u) * kVsThreads;
+					if (t < own) {
+						const float v = elem(t);
+						if (v != 0.0f) dst[(size_t)(t >> 1) * L.F + (t & 1u)] = old[k][u] + v;
+					}
 				}
-#pragma unroll
-				for (uint32_t u = 0; u < 4u; ++u) o_[u] = v[u] != 0.0f ? dst[at[u]] : 0.0f;
-#pragma unroll
-				for (uint32_t u = 0; u < 4u; ++u) if (v[u] != 0.0f) dst[at[u]] = o_[u] + v[u];
-			}
 		}
 		if (!last) {
-			float *ho = dv.handoff + (size_t)item * 2u * vp.rb_max;
+			float *ho = dv.handoff + (size_t)item * 2u * rb_max;
 			for (uint32_t t = threadIdx.x; t < 2u * gm.Rb; t += kVsThreads) ho[t] = elem(own + t);
 		}
 	} else {
 		float *sl = dv.slots + (size_t)(un.multi + rep) * kVsSlot;
 		for (uint32_t t = threadIdx.x; t < 2u * n_plane; t += kVsThreads) sl[t] = elem(t);
 	}
-	float *lo_ = dv.lines + (size_t)w * 2u * vp.rd_max;
+	float *lo_ = dv.lines + (size_t)w * 2u * rd_max;
 	for (uint32_t t = threadIdx.x; t < 2u * gm.Rd; t += kVsThreads) lo_[t] = elem(2u * n_plane + t);
 }
 
@@ -915,17 +969,45 @@ uint64_t vm_sorted_plan(const nr3d_lotd_meta_t *m, uint32_t n, uint32_t n_blocks
 	vp.n_qd = vp.n_items = 0;
 	vp.n_sc[0] = vp.n_sc[1] = 0;
 	bool sc_ok = true;
-	const int64_t mode = opt::get(NR3D_OPT_VM_SORTED);
+	const int64_t mode_opt = opt::get(NR3D_OPT_VM_SORTED), mode = mode_opt == 3 ? 1 : mode_opt;      // 3: as 1, VM levels only (A/B)
 	if (!mode || m->n_dims_to_encode != 3 || m->n_feat_per_pseudo_lvl != 2 || m->n_pseudo_levels > 64u || m->n_encoded_dims > 120u || n == 0) return 0;
 	n_blocks = n_blocks ? n_blocks : 1u;
-	uint64_t mask = 0, biggest = 0;
+	uint64_t mask = 0, biggest = 0, dense_mask = 0;
 	uint32_t items = 0;
 	vp.rb_max = vp.rd_max = 0;
 	vp.thr_max = 0.0f;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const uint32_t lv = m->map_levels[q];
 		const nr3d_lotd_level_t &L = m->levels[lv];
-		if (L.type != NR3D_LOD_VectorMatrix || (int32_t)lv < min_level || (int32_t)lv > max_level || ((skip >> q) & 1ull)) continue;
+		if ((int32_t)lv < min_level || (int32_t)lv > max_level || ((skip >> q) & 1ull)) continue;
+		if (L.type == NR3D_LOD_Dense && forest && mode_opt != 3) {
+			// a forest's small Dense levels ride along (component code 3: rows = x_0 slices, vm_geom): their records cost 0.69 ms on the
+			// reference's forest workload (k_bin_forest + k_accum + the feature-major copy of dL_dy for two levels of 34^3 and 55^3),
+			// as two more "planes" of the sorted points ~0.2.  Only next to VM levels (dense_mask is dropped when no VM level is served).
+			const VmGeom gm = vm_geom(L.res, 3);
+			if (vp.n_qd + 1u > kVsMaxQD || gm.Ra < 2u || 2u * gm.Rb > kVsAcc || gm.Ra > 60000u) continue;
+			const uint32_t fit = kVsAcc / gm.Rb, cells = gm.Ra - 1u;
+			const uint32_t bands = div_up(cells, fit - 1u), rows = div_up(cells, bands);
+			const uint32_t k = vp.n_qd++;
+			vp.q[k] = (uint16_t)q; vp.d[k] = 3u; vp.rows[k] = (uint16_t)rows; vp.n_bands[k] = (uint16_t)bands;
+			vp.item_base[k] = items;
+			items += n_blocks * bands;
+			vp.rb_max = gm.Rb > vp.rb_max ? gm.Rb : vp.rb_max;
+			float thr = 0.0f;
+			for (int d = 0; d < 3; ++d) { const float t = 0.5f / (float)L.res[d]; thr = t > thr ? t : thr; }
+			vp.thr[k] = thr * 1.001f + 1e-6f;
+			vp.thr_max = vp.thr[k] > vp.thr_max ? vp.thr[k] : vp.thr_max;
+			const float scale = (float)gm.Ra;
+			bool seen = false;
+			for (uint32_t j = 0; j < vp.n_sc[0]; ++j) seen = seen || vp.sc[0][j] == scale;
+			if (!seen) {
+				if (vp.n_sc[0] < kVsMaxSc) { vp.sc[0][vp.n_sc[0]] = scale; vp.cap[0][vp.n_sc[0]] = (float)(gm.Ra + 2u); ++vp.n_sc[0]; }
+				else sc_ok = false;
+			}
+			dense_mask |= 1ull << q;
+			continue;
+		}
+		if (L.type != NR3D_LOD_VectorMatrix) continue;
 		if (vp.n_qd + 3u > kVsMaxQD) break;
 		uint32_t rows[3], bands[3];
 		bool ok = true;
@@ -985,6 +1067,7 @@ uint64_t vm_sorted_plan(const nr3d_lotd_meta_t *m, uint32_t n, uint32_t n_blocks
 	vp.n_items = items;
 	vp.n_blocks = n_blocks;
 	vp.n_groups = vp.n_qd * n_blocks;
+	mask |= dense_mask;
 	const uint32_t reps = vp.n_qd * (n / kVsPmax + 1u);
 	vp.w_max = items + reps;
 	vp.m_slots = 2u * reps;
@@ -1009,7 +1092,7 @@ void vm_sorted_scratch(const VsPlan &vp, uint32_t n, uint32_t E, bool second, bo
 	for (int o = 0; o < 2; ++o) { s.xs[o] = take(12ull * n); s.vs[o] = take(second ? 12ull * n : 0); s.gts[o] = take(4ull * E * n); }
 	s.items = take(4ull * (4ull * (vp.n_items + 1) + 6ull * vp.n_items));
 	s.irec = take(32ull * vp.n_items);
-	s.units = take(80ull * vp.w_max);
+	s.units = take(128ull * vp.w_max);
 	s.item_tmax = take(4ull * vp.n_items);
 	s.handoff = take(8ull * vp.n_items * vp.rb_max);
 	s.lines = take(8ull * vp.w_max * vp.rd_max);
@@ -1082,6 +1165,7 @@ int vm_sorted_run(bool second, const VsPlan &vp, const nr3d_lotd_meta_t *meta, c
 	if (FO) hipLaunchKernelGGL(k_vs_plan<true>, dim3(div_up(plan_threads, 256)), dim3(256), 0, st, vpd, dv, md, n, ba);
 	else hipLaunchKernelGGL(k_vs_plan<false>, dim3(div_up(plan_threads, 256)), dim3(256), 0, st, vpd, dv, md, n, ba);
 	hipLaunchKernelGGL(k_vs_scan, dim3(1), dim3(1024), 0, st, vp.n_items, dv);
+	const ForestDev fo = forest ? *forest : ForestDev{};
 	dv.units = (const VsUnit *)(scratch + s.units);
 	const uint32_t opt_fix = opt::get(NR3D_OPT_DIRECT_FIXED) != 0 ? 1u : 0u;      // (k_cp_direct's switch: 0 keeps fp64 accumulators everywhere)
 	uint32_t *item_tmax = opt_fix ? (uint32_t *)(scratch + s.item_tmax) : nullptr;
@@ -1091,8 +1175,8 @@ int vm_sorted_run(bool second, const VsPlan &vp, const nr3d_lotd_meta_t *meta, c
 		else { if (FO) hipLaunchKernelGGL((k_vs_tmax<float, true>), dim3(vp.n_items), dim3(256), 0, st, vpd, dv, md, (const float *)params, ba, item_tmax);
 		       else hipLaunchKernelGGL((k_vs_tmax<float, false>), dim3(vp.n_items), dim3(256), 0, st, vpd, dv, md, (const float *)params, ba, item_tmax); }
 	}
-	if (FO) hipLaunchKernelGGL(k_vs_units<true>, dim3(div_up(vp.w_max, 256)), dim3(256), 0, st, vpd, dv, md, ba, item_tmax, (VsUnit *)(scratch + s.units));
-	else hipLaunchKernelGGL(k_vs_units<false>, dim3(div_up(vp.w_max, 256)), dim3(256), 0, st, vpd, dv, md, ba, item_tmax, (VsUnit *)(scratch + s.units));
+	if (FO) hipLaunchKernelGGL(k_vs_units<true>, dim3(div_up(vp.w_max, 256)), dim3(256), 0, st, vpd, dv, md, ba, fo, item_tmax, (VsUnit *)(scratch + s.units));
+	else hipLaunchKernelGGL(k_vs_units<false>, dim3(div_up(vp.w_max, 256)), dim3(256), 0, st, vpd, dv, md, ba, fo, item_tmax, (VsUnit *)(scratch + s.units));
 	NR3D_LAUNCH_CHECK();
 	static bool attr[64] = {};
 	int dev_id = 0;
@@ -1104,9 +1188,8 @@ int vm_sorted_run(bool second, const VsPlan &vp, const nr3d_lotd_meta_t *meta, c
 #undef NR3D_VS_ATTR
 		attr[dev_id & 63] = true;
 	}
-	const ForestDev fo = forest ? *forest : ForestDev{};
 	auto launch = [&](auto kern, auto *tab) {
-		hipLaunchKernelGGL(kern, dim3(vp.w_max), dim3(kVsThreads), (size_t)kVsLds, st, vpd, dv, md, n, meta->interpolation_type, x, vin, g, g_sn, g_se,
+		hipLaunchKernelGGL(kern, dim3(vp.w_max), dim3(kVsThreads), (size_t)kVsLds, st, vpd, vp.rb_max, vp.rd_max, dv, n, meta->interpolation_type, x, vin, g, g_sn, g_se,
 		                   tab, ba, fo, dparam, opt_fix NR3D_DBG_ARG(NR3D_XOPT(VS_DBG, 0)));
 	};
 	{

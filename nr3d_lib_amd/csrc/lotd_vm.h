@@ -120,6 +120,12 @@ __device__ __forceinline__ uint32_t emit_vm_component_f2(const Lvl &L, const Cel
 struct VmGeom { uint32_t Ra, Rb, plane_lo, line_lo, Rd; int a; };
 __host__ __device__ inline VmGeom vm_geom(const uint32_t (&res)[NR3D_LOTD_MAX_DIMS], int d) {
 	VmGeom gm;
+	if (d == 3) {
+		// a DENSE level in the same terms (lotd_sorted.hip serves a forest's small Dense levels next to its VM levels): rows = the x_0
+		// slices of the table [R0][R1][R2], a row = one slice of R1 R2 entries, no line
+		gm.a = 0; gm.Ra = res[0]; gm.Rb = res[1] * res[2]; gm.Rd = 0u; gm.plane_lo = 0u; gm.line_lo = 0u;
+		return gm;
+	}
 	gm.a = d == 0 ? 1 : 0;
 	const int b = d == 2 ? 1 : 2;
 	gm.Ra = res[gm.a]; gm.Rb = res[b]; gm.Rd = res[d];
