@@ -22,7 +22,7 @@ struct VsPlan {
 	uint32_t n_sc[2], row_bits[2], row_none[2];
 	float sc[2][kVsMaxSc], cap[2][kVsMaxSc];
 };
-struct VsScratch { uint64_t stats, plan, key_in[2], key_out[2], keyb_in[2], keyb_out[2], idxb, cand_cnt, n_cand, perm[2], permb[2], xm[2], tmp, xs[2], vs[2], gts[2], items, irec, units, item_tmax, cinfo[2], handoff, lines, slots, total; };
+struct VsScratch { uint64_t stats, multi_list, plan, key_in[2], key_out[2], keyb_in[2], keyb_out[2], idxb, cand_cnt, n_cand, perm[2], permb[2], xm[2], tmp, xs[2], vs[2], gts[2], items, irec, units, item_tmax, cinfo[2], handoff, lines, slots, total; };
 
 // which pseudo levels the sorted path serves (mask; 0: none) and its plan; the scratch layout; the run on `st`
 uint64_t vm_sorted_plan(const nr3d_lotd_meta_t *m, uint32_t n, uint32_t n_blocks, bool forest, int32_t min_level, int32_t max_level,

@@ -42,7 +42,8 @@ struct VsDev {
 	const uint32_t *skey[2];               // sorted keys of order o: (block << row_bits[o]) | row sum of x_o
 	const uint32_t *n_cand;                // forest: how many boundary candidates the pass has
 	const struct VsUnit *units;            // [w_max] what every work unit starts from (k_vs_units)
-	const uint32_t *stats;                 // float bits of max |dL_dy| over the served columns, of max |dL_ddLdx| (k_vs_gather)
+	uint32_t *stats;                       // float bits of max |dL_dy| over the served columns, of max |dL_ddLdx| (k_vs_gather); [2]: items with replicas
+	uint32_t *multi_list;                  // those items (k_vs_units)
 	const uint32_t *permb[2];              // forest: the boundary candidates of ALL blocks in the order of x_o (their points)
 	const float *xm[2];                    // ... and those points' coordinates [n, 3]
 	const struct VsCand *cinfo[2];         // ... and their (point index, block, block position) records
@@ -356,7 +357,7 @@ struct VsUnit {
 };
 static_assert(sizeof(VsUnit) == 128, "eight 16-byte loads, one round trip");
 constexpr uint32_t kVsNoUnit = 0xFFFFFFFFu;
-constexpr uint32_t kVsRedChunks = (kVsSlot + 4095u) / 4096u;   // k_vs_reduce: 4096-element pieces of an item's table
+constexpr uint32_t kVsRedPiece = 2048u, kVsRedChunks = (kVsSlot + kVsRedPiece - 1u) / kVsRedPiece;   // k_vs_reduce_items: pieces of an item's table
 constexpr uint32_t kVsDense = 24;            // surviving boundary candidates per wave from which every lane walks its own eight corners
 
 __device__ __forceinline__ uint32_t vs_pair_of(const VsPlan &vp, uint32_t item) {
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(256) void k_vs_units(const VsPlan *__restrict__ vpp
 		while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (dv.rep_base[mid] <= w) lo = mid; else hi = mid; }
 		u.item = lo; u.rep = w - dv.rep_base[lo]; u.n_rep = dv.rep_base[lo + 1] - dv.rep_base[lo]; u.multi = dv.multi_base[lo];
 		u.own_lo = dv.item_lo[lo]; u.own_cnt = dv.item_cnt[lo];
+		if (u.rep == 0u && u.n_rep > 1u) dv.multi_list[atomicAdd(dv.stats + 2, 1u)] = lo;      // (any order: k_vs_reduce_items takes them one by one)
 		if (FO)
 #pragma unroll
 			for (uint32_t rg = 0; rg < 3u; ++rg) { u.sub_lo[rg] = dv.sub_lo[rg * vp.n_items + lo]; u.sub_cnt[rg] = dv.sub_cnt[rg * vp.n_items + lo]; }
@@ -866,11 +868,22 @@ __device__ __forceinline__ uint32_t div_up_dev(uint32_t a, uint32_t b) { return 
 __global__ __launch_bounds__(256) void k_vs_reduce_items(const VsPlan *__restrict__ vpp, VsDev dv, const nr3d_lotd_meta_t *__restrict__ md, Batch ba, float *__restrict__ dparam) {
 	const VsPlan &vp = *vpp;                      // (the plan lives in device memory: indexed by value it was copied into LDS by every workgroup)
 	{
-		// (item, chunk of 4096 table elements): sixteen elements per thread, the replicas' slots added in replica order with sixteen loads in
+		// (item, chunk of 4096 table elements): eight elements per thread, the replicas' slots added in replica order with eight loads in
 		// flight (one 1024-thread workgroup per item and one load at a time, the replica bands of the coarse levels were 400 dependent
 		// loads per thread); 256 threads: most of the 53 000 workgroups have nothing to do and should cost four waves, not sixteen
-		const uint32_t item = blockIdx.x / kVsRedChunks, chunk = blockIdx.x - item * kVsRedChunks;
+		// blocks 0 .. n_items - 1: the items WITHOUT replicas (the row handed over, all of it); behind them (entry j of the list of items with
+		// replicas that k_vs_units wrote, chunk): launched for the most such items a pass can have, all but a few find j beyond the list
+		uint32_t item, chunk = 0u;
+		const bool single = blockIdx.x < vp.n_items;
+		if (single) item = blockIdx.x;
+		else {
+			const uint32_t j = (blockIdx.x - vp.n_items) / kVsRedChunks;
+			chunk = (blockIdx.x - vp.n_items) - j * kVsRedChunks;
+			if (j >= dv.stats[2]) return;
+			item = dv.multi_list[j];
+		}
 		const uint32_t n_rep = dv.rep_base[item + 1] - dv.rep_base[item];
+		if (single && n_rep > 1u) return;
 		const VsItemRec it = dv.irec[item];
 		if (n_rep == 1u && it.band == 0u) return;
 		const uint32_t qd0 = it.qd;
@@ -879,17 +892,17 @@ __global__ __launch_bounds__(256) void k_vs_reduce_items(const VsPlan *__restric
 		const uint32_t own = n_rep > 1u ? 2u * (it.last ? it.nrows + 1u : it.nrows) * gm.Rb : 0u;
 		const uint32_t head = it.band > 0u ? 2u * gm.Rb : 0u;                         // the previous band's last row is this band's row 0
 		const uint32_t t_end = own > head ? own : head;
-		if (chunk * 4096u >= t_end) return;
 		float *dst = dparam + (it.boff + L.off) + (size_t)(gm.plane_lo + it.row0 * gm.Rb) * L.F + meta_cnt_of(md, vp.q[qd0]) * 2u;
 		const float *sl = dv.slots + (size_t)dv.multi_base[item] * kVsSlot;
 		const uint32_t prev = item - (it.band > 0u ? 1u : 0u), p_rep = dv.rep_base[prev + 1] - dv.rep_base[prev], p_rows = vp.rows[qd0];
 		const float *ps = dv.slots + (size_t)dv.multi_base[prev] * kVsSlot + 2u * (size_t)p_rows * gm.Rb;
 		const float *ho = dv.handoff + (size_t)prev * 2u * vp.rb_max;
-		constexpr uint32_t kE = 16u;                                              // elements per thread
+		constexpr uint32_t kE = kVsRedPiece / 256u;                                              // elements per thread
+		for (; chunk * kVsRedPiece < t_end; chunk += single ? 1u : kVsRedChunks) {           // (an item without replicas: <= 2 rounds, the handed-over row)
 		uint32_t t[kE];
 		float s[kE] = {};
 #pragma unroll
-		for (uint32_t u = 0; u < kE; ++u) t[u] = chunk * 4096u + u * 256u + threadIdx.x;
+		for (uint32_t u = 0; u < kE; ++u) t[u] = chunk * kVsRedPiece + u * 256u + threadIdx.x;
 		auto sum_slots = [&](const float *base, uint32_t reps, uint32_t limit, float (&acc)[kE]) {
 			for (uint32_t r = 0; r < reps; ++r) {
 				float v[kE];
@@ -900,7 +913,7 @@ __global__ __launch_bounds__(256) void k_vs_reduce_items(const VsPlan *__restric
 			}
 		};
 		if (own) sum_slots(sl, n_rep, own, s);
-		if (head && chunk * 4096u < head) {
+		if (head && chunk * kVsRedPiece < head) {
 			float h[kE] = {};
 			if (p_rep > 1u) sum_slots(ps, p_rep, head, h);
 			else
@@ -915,7 +928,7 @@ __global__ __launch_bounds__(256) void k_vs_reduce_items(const VsPlan *__restric
 		}
 #pragma unroll
 		for (uint32_t u = 0; u < kE; ++u) if (t[u] < t_end && s[u] != 0.0f) dst[(size_t)(t[u] >> 1) * L.F + (t[u] & 1u)] += s[u];
-		return;
+		}
 	}
 }
 
@@ -1087,7 +1100,8 @@ void vm_sorted_scratch(const VsPlan &vp, uint32_t n, uint32_t E, bool second, bo
 	s.cand_cnt = take(4ull * div_up(n, 1024u));
 	s.n_cand = take(4);
 	s.plan = take(sizeof(VsPlan));
-	s.stats = take(8);
+	s.stats = take(16);
+	s.multi_list = take(4ull * (vp.m_slots / 2u + 1u));
 	s.tmp = take(rsort::tmp_bytes(n, 2));
 	for (int o = 0; o < 2; ++o) { s.xs[o] = take(12ull * n); s.vs[o] = take(second ? 12ull * n : 0); s.gts[o] = take(4ull * E * n); }
 	s.items = take(4ull * (4ull * (vp.n_items + 1) + 6ull * vp.n_items));
@@ -1149,8 +1163,9 @@ int vm_sorted_run(bool second, const VsPlan &vp, const nr3d_lotd_meta_t *meta, c
 		                           (VsCand *)(scratch + s.cinfo[o]));
 	}
 	uint32_t *stats = (uint32_t *)(scratch + s.stats);
-	NR3D_HIP_CHECK(hipMemsetAsync(stats, 0, 8, st));
+	NR3D_HIP_CHECK(hipMemsetAsync(stats, 0, 16, st));
 	dv.stats = stats;
+	dv.multi_list = (uint32_t *)(scratch + s.multi_list);
 	uint64_t cols[2] = {0ull, 0ull};                    // the dL_dy columns of the served pseudo levels (two features each)
 	for (uint32_t k = 0; k < vp.n_qd; ++k)
 		for (uint32_t f = 0; f < 2u; ++f) { const uint32_t c = meta->map_col[vp.q[k]] + f; cols[c >> 6] |= 1ull << (c & 63u); }
@@ -1199,7 +1214,7 @@ int vm_sorted_run(bool second, const VsPlan &vp, const nr3d_lotd_meta_t *meta, c
 		if (FO) NR3D_VS_GO(true); else NR3D_VS_GO(false);
 #undef NR3D_VS_GO
 	}
-	hipLaunchKernelGGL(k_vs_reduce_items, dim3(vp.n_items * kVsRedChunks), dim3(256), 0, st, vpd, dv, md, ba, dparam);
+	hipLaunchKernelGGL(k_vs_reduce_items, dim3(vp.n_items + (vp.m_slots / 2u) * kVsRedChunks), dim3(256), 0, st, vpd, dv, md, ba, dparam);
 	hipLaunchKernelGGL(k_vs_reduce_lines, dim3(vp.n_groups * div_up(2u * vp.rd_max, 64u)), dim3(1024), 0, st, vpd, dv, md, ba, dparam);
 	NR3D_LAUNCH_CHECK();
 	return 0;
