@@ -20,7 +20,7 @@ PASSES=(
 : > "$OUT/counters.txt"
 for CTRS in "${PASSES[@]}"; do
   rm -rf /tmp/prof_c
-  rocprofv3 --kernel-trace --pmc $CTRS -d /tmp/prof_c -o p -- $BENCH > /tmp/pmc.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $CTRS -d /tmp/prof_c -o p -- $BENCH > /tmp/pmc.log 2>&1
   DB=$(find /tmp/prof_c -name '*.db' | head -1)
   if [ -z "$DB" ]; then echo "pass failed: $CTRS" >> "$OUT/counters.txt"; tail -3 /tmp/pmc.log >> "$OUT/counters.txt"; continue; fi
   python $ROOT/tools/prof_summary.py "$DB" pmc | grep -E "counter|$KRE" >> "$OUT/counters.txt"

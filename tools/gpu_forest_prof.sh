@@ -24,6 +24,6 @@ for _ in range(${2:-4}):
     _lotd.lod_bwd(metas, grad, x, params, None, blidx, None, None, None, False, True)
 torch.cuda.synchronize()
 PY
-rm -rf /tmp/prof_f && rocprofv3 --kernel-trace --stats -d /tmp/prof_f -o p -- python /tmp/forest_run.py > $OUT/run.log 2>&1
+rm -rf /tmp/prof_f && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_f -o p -- python /tmp/forest_run.py > $OUT/run.log 2>&1
 python $ROOT/tools/prof_summary.py "$(find /tmp/prof_f -name '*.db' | head -1)" > $OUT/forest_dparam_kernel_stats.txt 2>&1
 head -24 $OUT/forest_dparam_kernel_stats.txt | cut -c1-170
