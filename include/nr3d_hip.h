@@ -86,7 +86,7 @@ enum {
 	NR3D_OPT_DIRECT_FIXED = 19,      /* 1: k_cp_direct accumulates in 64-bit fixed point (scale from the workgroup's own bound on its updates); 2: k_vm_direct
 	                                  * too (measured slower there, twice: it is not bound by its LDS atomics); 0: fp64 */
 	NR3D_OPT_VM_SORTED = 20,         /* 1: a dL/dparam pass with a VM level of >= 2^20 entries (over its blocks) and >= 2^19 points sorts the POINTS by
-	                                  * (block, coordinate) and accumulates every VM level band by band in LDS, without records (lotd_sorted.inc;
+	                                  * (block, coordinate) and accumulates every VM level band by band in LDS, without records (lotd_sorted.hip;
 	                                  * single tables, batches and forests; a forest's small Dense levels ride along as slices); 2: whenever the geometry allows (tests); 3: as 1, VM levels only; 0: records */
 	NR3D_OPT_MLP_X3 = 21,            /* 1: the fp32 fused MLP forward runs on the bf16 MFMA with every value split into three bf16 pieces (six piece products,
 	                                  * fp32 accumulation: fp32-grade results at 2.7x the matrix rate of the f32 MFMA); 0: v_mfma_f32_32x32x2_f32.
@@ -732,7 +732,7 @@ int nr3d_order_gather_inputs(uint32_t n, const int32_t *order, const float *x, c
 int nr3d_order_move_rows(uint32_t n, const int32_t *order, int scatter, const float *a, uint32_t wa, float *a_out, const float *b,
                          uint32_t wb, float *b_out, void *stream);
 
-/* The library's own point sort (csrc/rsort.hip, ABI 5), exported for its tests -- lotd_sorted.inc orders the points of a large-table
+/* The library's own point sort (csrc/rsort.hip, ABI 5), exported for its tests -- lotd_sorted.hip orders the points of a large-table
  * dL/dparam pass with it (the reference's default build has no library sort either: pack_ops_cuda.cu:2621-2629 compiles thrust
  * out, :2634-2720 is its own kernel).  Stable LSD radix sort of `batch` (1 or 2) independent arrays of (uint32 key, uint32
  * value) pairs of the same length by key bits [0, bits): kin{0,1} / vin{0,1} -> kout{0,1} / vout{0,1} (the second set ignored

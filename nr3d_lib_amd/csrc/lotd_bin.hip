@@ -1928,7 +1928,7 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 			}
 		}
 		// large VM levels (single tables, batches, forests): points sorted by (block, coordinate), bands accumulated in LDS, no records
-		// (lotd_sorted.inc); its scratch is the record / offsets region, which the classes below use afterwards
+		// (lotd_sorted.hip); its scratch is the record / offsets region, which the classes below use afterwards
 		if (!g_half) {
 			VsPlan vsp;
 			const uint64_t smask = vm_sorted_plan(meta, n, n_batches, forest != nullptr, min_level, max_level, cp_mask, vsp);

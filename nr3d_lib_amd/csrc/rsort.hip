@@ -2,7 +2,7 @@
 // third-party device code libnr3d_hip.so carried): a stable LSD radix sort of (u32 key, u32 value) pairs for gfx950, up to two
 // independent sorts of the same length per launch (grid.y), element count optionally read from device memory.
 //
-// What it is for: lotd_sorted.inc orders the POINTS of a dL/dparam pass by (table block, cell row) -- keys with few significant
+// What it is for: lotd_sorted.hip orders the POINTS of a dL/dparam pass by (table block, cell row) -- keys with few significant
 // bits (17 for the reference's forest workload), so the sort is two 9-bit passes, not the five a 36-bit key needs.  The reference
 // has no library sort on its default path either (pack_ops_cuda.cu:2621-2629 compiles thrust out; :2634-2720 is its own kernel).
 //

@@ -19,7 +19,7 @@ FOREST_METAS = {
 }
 
 
-# VM levels with two-feature pseudo levels (what lotd_sorted.inc serves): cuboid resolutions, several pseudo levels per level
+# VM levels with two-feature pseudo levels (what lotd_sorted.hip serves): cuboid resolutions, several pseudo levels per level
 SORTED_METAS = {
     "vm_cuboid": ([[5, 7, 6], [9, 8, 11], [4, 4, 4]], [2, 4, 2], ["VM", "VM", "Dense"], None, False),
     "vm_smooth": ([6, 10], [4, 2], ["VM", "VM"], None, True),
@@ -323,7 +323,7 @@ def test_dparam_binned_and_atomic_paths_agree(oracle, dev, forest, case):
 @pytest.mark.parametrize("forest,continuity", [("plus", True), ("plus", False), ("scatter", True), ("single", True)])
 @pytest.mark.parametrize("case", ["mixed", "vm_cuboid", "vm_smooth"])
 def test_vm_levels_over_sorted_points(oracle, dev, forest, continuity, case, hip_option, monkeypatch):
-    """VM levels of a forest over SORTED points (lotd_sorted.inc, option vm_sorted = 2: whatever the table size): interior cells
+    """VM levels of a forest over SORTED points (lotd_sorted.hip, option vm_sorted = 2: whatever the table size): interior cells
     from the band's own point range, boundary cells corner by corner from the face-distance list, no records -- against the
     oracle, against the record path, first and second order, twice (the sums have a fixed order)"""
     from nr3d_lib_amd import _hip

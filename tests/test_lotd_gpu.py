@@ -885,7 +885,7 @@ def test_points_on_cell_faces(oracle, dev, case):
 @pytest.mark.parametrize("case", ["mixed", "mixed_cuboid", "mixed_smooth"])
 @pytest.mark.parametrize("points", ["uniform", "slab", "batched"])
 def test_vm_levels_over_sorted_points(oracle, dev, case, points, hip_option):
-    """VM levels over SORTED points (lotd_sorted.inc; option vm_sorted = 2 takes it whatever the table size, vm_direct = 0 hands it
+    """VM levels over SORTED points (lotd_sorted.hip; option vm_sorted = 2 takes it whatever the table size, vm_direct = 0 hands it
     every VM level): a band's points are one range of the order of x_a; "slab" puts 40 000 points into two cell rows (one band
     with replicas, added in a fixed order), "batched" three table copies with permuted placement and skipped points.  Against the
     oracle and the record path, first and second order, twice"""

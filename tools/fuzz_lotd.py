@@ -10,7 +10,7 @@ bad = 0
 cases = [c for c in LOTD_CASES if c not in ("cp_4d",)]
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     case = cases[it % len(cases)]
-    # half of the iterations: VM levels over sorted points whatever their size (lotd_sorted.inc), with / without k_vm_direct in front
+    # half of the iterations: VM levels over sorted points whatever their size (lotd_sorted.hip), with / without k_vm_direct in front
     _hip.set_option("vm_sorted", 2 if (it // len(cases)) % 2 else -1)
     _hip.set_option("vm_direct", 0 if (it // len(cases)) % 4 >= 2 else -1)
     D, res, nf, types, T, smooth = LOTD_CASES[case]
