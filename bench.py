@@ -316,11 +316,12 @@ def _full_loop_setup(dev, side=512, shift=0.0, precision="float"):
     n = side * side
     rays = dict(num_rays=n, rays_o=o, rays_d=d, near=near, far=far, rays_inds=torch.arange(n, device=dev))
 
-    def fwd_bwd():
+    def fwd_bwd(count=True):
         vb, det = nerf_ray_query_march_occ(model, rays, with_rgb=True, compression=True)
         out = composite_packed_volume_buffer(vb, n)
         (out["rgb_volume"].mean() + out["depth_volume"].mean()).backward()
-        return int(det["march.num_per_ray"].sum()), int(det["render.num_per_ray"].sum())
+        # (the sample counts are the harness's, not the workload's: two reductions + two host syncs -- taken once, outside the timed loop)
+        return (int(det["march.num_per_ray"].sum()), int(det["render.num_per_ray"].sum())) if count else None
     return model, n, fwd_bwd
 
 
@@ -329,10 +330,10 @@ def full_loop_rate(dev, side=512, iters=20, warmup=5, precision="float"):
     through nerf_ray_query_march_occ (visibility pruning on) with a tiny random MLP head (tools/demo_field.py)."""
     model, n, fwd_bwd = _full_loop_setup(dev, side, precision=precision)
 
-    def one():
+    def one(count=False):
         model.zero_grad(set_to_none=True)
-        return fwd_bwd()
-    marched, rendered = one()
+        return fwd_bwd(count)
+    marched, rendered = one(True)
     for _ in range(warmup - 1):
         one()
     # every iteration timed on its own: the driver allocates data-dependent buffers, and an iteration that happens to go

@@ -316,7 +316,10 @@ class LoTD(nn.Module):
         with torch.no_grad():
             feat = self.forward(input, params, max_level=max_level)
             ddt = getattr(decoder, "dtype", None) or torch.float32
-            h = decoder(feat if feat.dtype == ddt else feat.to(ddt))
+            feat = feat if feat.dtype == ddt else feat.to(ddt)
+            if hasattr(decoder, "forward_columns"):
+                return decoder.forward_columns(feat, out_cols)      # only those columns leave the decoder's kernel
+            h = decoder(feat)
         return h[..., :out_cols]
 
     def __getstate__(self):

@@ -137,6 +137,30 @@ def test_fused_handles_strided_rows_leading_dims_and_frozen_inputs(dev):
     torch.testing.assert_close(m.layers[1].weight.grad, 2 * before, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float, torch.half])
+@pytest.mark.parametrize("shape", [(32, 16, 1, 32), (32, 16, 2, 64), (18, 3, 1, 32)])
+def test_forward_columns_is_the_full_forward_sliced(dev, hip_option, dtype, shape):
+    """MLP.forward_columns (round 6; the pruning query keeps one of 16 outputs): the network with its last layer cut to the asked rows on
+    the same kernels -- bit-identical to the slice of the full forward on every route (f32 MFMA, bf16 x3, f16), contiguous; with a
+    gradient in play it IS the slice of the differentiable forward"""
+    from nr3d_lib_amd.models.blocks import MLP
+    fin, fout, D, W = shape
+    torch.manual_seed(5)
+    net = MLP(fin, fout, D=D, W=W, dtype=dtype, device=dev)
+    x = torch.randn(70001, fin, device=dev).to(dtype)
+    for x3 in ((1, 0) if dtype == torch.float else (1,)):
+        hip_option("mlp_x3", x3)
+        with torch.no_grad():
+            full = net(x)
+            for k in (1, min(3, fout)):
+                part = net.forward_columns(x, k)
+                assert (part.is_contiguous() or dtype == torch.half) and tuple(part.shape) == (x.shape[0], k) and part.dtype == full.dtype
+                assert torch.equal(part, full[:, :k]), f"x3={x3} k={k}"
+            assert torch.equal(net.forward_columns(x, fout), full)
+    y = net.forward_columns(x[:100], 1)                                        # grad mode, parameters require grad: the differentiable route
+    assert y.requires_grad and tuple(y.shape) == (100, 1)
+
+
 def test_networks_outside_the_fused_range_take_the_torch_path(dev):
     from nr3d_lib_amd.bindings import _mlp
     from nr3d_lib_amd.models.blocks import MLP, get_blocks

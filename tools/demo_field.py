@@ -64,13 +64,17 @@ class DemoField(nn.Module):
         feat = self.encoding(torch.addcmul(self._half, x, self._half), self.grid)
         h = self.density(feat if feat.dtype == self.density.dtype else feat.float())
         # sigma in fp32; the geometry features stay in the decoder's dtype (half decoders: no [n, 16] half -> float pass)
-        return torch.nn.functional.softplus(h[..., 0].float()) * 20.0, h[..., 1:]
+        # (one split, not two slices: the backward of two slices of h is two zero-filled [n, 16] buffers, two copies and an add; the
+        # backward of a split is one concatenation)
+        h0, geo = h.split([1, h.shape[-1] - 1], dim=-1)
+        return torch.nn.functional.softplus(h0[..., 0].float()) * 20.0, geo
 
     def query_density(self, x, **kw):
-        if not torch.is_grad_enabled() and isinstance(self.density, MLP) and self.density.dtype in (None, torch.float32):
-            # the pruning query (no grad): encode + density decoder in ONE kernel, only the density column leaves
+        if not torch.is_grad_enabled() and isinstance(self.density, MLP):
+            # the pruning query (no grad): only the density column leaves the decoder (LoTD.forward_decoded: in one kernel with the
+            # encoder when lotd.FUSE_DECODED is on, else the two calls with the decoder's last layer cut to that column)
             h0 = self.encoding.forward_decoded(torch.addcmul(self._half, x, self._half), self.grid, self.density, out_cols=1)
-            return torch.nn.functional.softplus(h0[..., 0]) * 20.0
+            return torch.nn.functional.softplus(h0[..., 0].float()) * 20.0
         return self._h(x)[0]
 
     def forward_density(self, x, **kw):
