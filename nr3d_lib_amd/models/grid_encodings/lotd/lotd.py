@@ -4,8 +4,8 @@ LoTDFunctionFwdDydx :121-191, LoTDFunctionBwdDydx :193-268, functional wrappers 
 
 Same public names, call signatures and semantics:
   * inputs are clamped to [1e-6, 1-1e-6] and flattened over their leading dims;
-  * ``loss_scale`` multiplies dL/dy on the way in and divides every gradient on the way out
-    (128 for fp16 params, else 1);
+  * ``loss_scale`` (128 for fp16 params, else 1) multiplies dL/dy on the way in and divides every gradient on the way out -- as two
+    extra passes only with ``APPLY_LOSS_SCALE`` (below: the accumulation here is exact, the scale changes no bit);
   * first-order gradients are once-differentiable; second-order gradients (eikonal / nablas) go through
     LoTDFunctionFwdDydx + LoTDFunctionBwdDydx, which back-propagate to dL/dy and to the params.
 """
@@ -60,13 +60,22 @@ def _unflat(t, prefix):
     return None if t is None else t.unflatten(0, prefix)
 
 
+# The reference multiplies dL/dy by ``loss_scale`` (2^7 for half tables) on the way in and divides every gradient by it on the way out
+# (lotd.py:96-119) to keep its half ``atomicAdd`` scatter out of the underflow range.  The kernels here read half dL/dy as it is,
+# accumulate exactly (64-bit fixed point / fp64) and round each gradient ONCE, so scaling by a power of two and back changes no bit of a
+# normal result (it commutes with the rounding; it would only add an overflow to inf at |dL/dy| > 512) -- and costs two passes over
+# [N, E] and one over the table gradient (78 + 10 us per backward of the full loop).  False: the protocol's arithmetic without those
+# passes; True: the reference's protocol literally.  ``LoTD.loss_scale`` keeps the reference's value either way.
+APPLY_LOSS_SCALE = False
+
+
 def _scaled(t, s):
-    return t if (t is None or s == 1.0) else t / s
+    return t if (t is None or s == 1.0 or not APPLY_LOSS_SCALE) else t / s
 
 
 def _times(t, s):
-    """t * loss_scale without the extra pass over t in the fp32 case (scale 1)"""
-    return t if s == 1.0 else t * s
+    """t * loss_scale without the extra pass over t when the scale is 1 (fp32) or not applied (APPLY_LOSS_SCALE)"""
+    return t if (s == 1.0 or not APPLY_LOSS_SCALE) else t * s
 
 
 class LoTDFunction(torch.autograd.Function):

@@ -991,6 +991,34 @@ def test_forward_lds_slabs_bit_identical(dev, hip_option, smooth, half):
     assert mask == 0b011111 and by_slab.value == 0b011100, (bin(mask), bin(by_slab.value))    # 58^3 needs 15 slabs: left to the two-lane kernel
 
 
+def test_loss_scale_changes_no_bit(dev, monkeypatch):
+    """half tables: the reference's loss scale (x 128 on dL/dy, / 128 on the gradients; lotd.py:96-119) protects its half atomics from
+    underflow; here the accumulation is exact and every gradient is rounded once, so running the protocol literally (two more passes)
+    gives the same bits as skipping it (models/grid_encodings/lotd/lotd.py: APPLY_LOSS_SCALE, off by default)"""
+    from nr3d_lib_amd.models.grid_encodings.lotd import LoTD
+    from nr3d_lib_amd.models.grid_encodings.lotd import lotd as lotd_mod
+    D, res, nf, types, T, smooth = LOTD_CASES["ngp_small"]
+    enc = LoTD(3, res, nf, types, hashmap_size=T, dtype=torch.half)
+    assert enc.loss_scale == 128.0
+    torch.manual_seed(11)
+    x = torch.rand(50001, 3, device=dev)
+    gy = (torch.randn(50001, enc.out_features, device=dev) * 0.05).half()
+    outs = []
+    for apply_scale in (False, True):
+        monkeypatch.setattr(lotd_mod, "APPLY_LOSS_SCALE", apply_scale)
+        grid = (torch.randn(enc.n_params, device=dev) * 0.1).half().requires_grad_(True) if not outs else outs[0][2].detach().clone().requires_grad_(True)
+        xx = x.clone().requires_grad_(True)
+        y = enc(xx, grid)
+        y.backward(gy)
+        outs.append((xx.grad.clone(), grid.grad.clone(), grid))
+    assert outs[0][1].dtype == torch.float16 and float(outs[0][1].float().abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]), "dL/dx"
+    a, b = outs[0][1].float(), outs[1][1].float()
+    normal = (a.abs() >= 2.0 ** -14) & (b.abs() >= 2.0 ** -14) & (b.abs() * 128 < 65504)       # both protocols' half results in the normal range
+    assert int(normal.sum()) > 1000 and torch.equal(a[normal], b[normal]), "dL/dgrid (normal range)"
+    assert float((a - b).abs().max()) <= 2.0 ** -24, "dL/dgrid: subnormal results differ by at most one subnormal step (double rounding of the scaled protocol)"
+
+
 @pytest.mark.parametrize("case,dims", [("ngp_small", (32, 16)), ("ngp_smooth", (64, 64, 1)), ("pair_f4", (32, 32, 16)),
                                        ("hash_npow2_f2", (48, 5)), ("ngp_pair", (32, 16))])
 @pytest.mark.parametrize("ptype", ["float", "half"])
