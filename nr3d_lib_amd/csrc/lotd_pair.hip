@@ -54,6 +54,7 @@ struct DirectPlan {
 	uint32_t qmap[kDirectMaxLv], nb[kDirectMaxLv], epb[kDirectMaxLv], shift[kDirectMaxLv];
 	uint32_t bucket_base[kDirectMaxLv + 1];
 	uint32_t lg, sum_log2, R, pts_per_rep;    // replicas per bucket, points per replica
+	uint32_t merge_min;                       // lanes continuing their neighbour's cell from which a wave rotates its update order (experiments build: knob)
 };
 
 
@@ -609,7 +610,11 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	constexpr uint32_t n_waves = kPAccThreads / 64;
-	const uint32_t blk_lo = (uint32_t)(((uint64_t)plan.n_blk * r) / R), blk_hi = (uint32_t)(((uint64_t)plan.n_blk * (r + 1)) / R);
+	// Replica r takes the point blocks r, r + R, r + 2R, ... (round 6; was: one contiguous range of blocks).  The plan gives a bucket
+	// replicas by its record COUNT; with ordered inputs (samples along rays / a Morton curve) those records sit in a few neighbouring
+	// blocks, so a contiguous range handed one replica all of them and the others none.  Sums are exact (fixed point): the split does
+	// not change the result.  blk_lo / blk_hi below count the replica's blocks, block k of it is r + R k.
+	const uint32_t blk_lo = 0u, blk_hi = (plan.n_blk > r) ? (plan.n_blk - r + R - 1u) / R : 0u;
 	const uint32_t *ob0 = offs_g + plan.offs_base[q] + (size_t)b * plan.n_blk;
 	const uint32_t *ob1 = ob0 + plan.n_blk;
 	const uint32_t kPCap = plan.cap;
@@ -625,10 +630,10 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 	constexpr int kGroup = 8;
 	for (uint32_t blk0 = w_lo; blk0 < w_hi; blk0 += 64) {
 		const uint32_t mb = blk0 + lane;
-		const uint32_t s_l = (mb < w_hi) ? ob0[mb] : 0u;
-		const uint32_t e_l = (mb < w_hi) ? ob1[mb] : 0u;
+		const uint32_t s_l = (mb < w_hi) ? ob0[r + R * mb] : 0u;
+		const uint32_t e_l = (mb < w_hi) ? ob1[r + R * mb] : 0u;
 		const uint32_t n_run = min(64u, w_hi - blk0);
-		const u32x4 *rec_b = rec_q + (size_t)blk0 * kPCap;
+		const u32x4 *rec_b = rec_q + (size_t)(r + R * blk0) * kPCap;
 		for (uint32_t j0 = 0; j0 < n_run; j0 += kGroup) {
 			uint32_t pre[kGroup + 1], rbase[kGroup];
 			pre[0] = 0;
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(kPAccThreads, 8) /* 8 waves per SIMD: two 64 KiB wo
 				const uint32_t j = min(j0 + (uint32_t)u, 63u);
 				const uint32_t s_j = __builtin_amdgcn_readlane(s_l, j), e_j = __builtin_amdgcn_readlane(e_l, j);
 				const uint32_t nrec = (j0 + (uint32_t)u < n_run) ? e_j - s_j : 0u;
-				rbase[u] = s_j + j * kPCap - pre[u];          // record index of stream position p inside run u: rbase[u] + p
+				rbase[u] = s_j + j * R * kPCap - pre[u];      // record index of stream position p inside run u: rbase[u] + p
 				pre[u + 1] = pre[u] + nrec;
 			}
 			const uint32_t total = pre[kGroup];
@@ -768,10 +773,12 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 			for (int m = 0; m < 4; ++m)
 #pragma unroll
 				for (int f = 0; f < 2; ++f) { lo[m][f] = (1.0f - wp[m & kW]) * A[m][f]; hi[m][f] = wp[m & kW] * A[m][f]; }
-			// coherent inputs (samples along a ray sit in one cell of these coarse levels for many consecutive points): lanes
-			// that continue the previous lane's cell are summed into the head of their run, as in stage A -- otherwise all 64
-			// lanes of an LDS atomic hit the same eight addresses and serialise (full loop: 252 us for these two levels)
-			bool head = true;
+			// coherent inputs (samples along a ray or a Morton curve sit in one cell of these coarse levels for many consecutive points):
+			// all 64 lanes of an LDS atomic would hit the same accumulator and serialise (no measures: 206 us for 1.67 M ordered points
+			// against 53 us for random ones).  Rounds 3-5 summed the lanes of a run into its head with 96 ds_bpermute per wave (163 us);
+			// round 6: when >= 8 lanes continue their neighbour's cell, every lane walks its 16 updates in ITS OWN order instead
+			// (below) -- 81 us, random points untouched (tools/exp_pair_direct_order.py)
+			bool rotate = false;
 			{
 				const uint32_t ln = threadIdx.x & 63u;
 				auto prev = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); };
@@ -779,24 +786,36 @@ __global__ __launch_bounds__(kPAccThreads, 8) void k_pair_direct(DirectPlan dp, 
 #pragma unroll
 				for (int d = 0; d < 3; ++d) same = same && (prev(cell[d]) == cell[d]);
 				same = same && (prev(1u) != 0u);
-				const unsigned long long cont = __ballot(same);
-				if (__popcll(cont) >= 16) {
-#pragma unroll
-					for (int off = 1; off < 64; off <<= 1) {
-						const unsigned long long need = (1ull << off) - 1ull;
-						const bool take = (ln + off < 64) && (((cont >> (ln + 1)) & need) == need);
-#pragma unroll
-						for (int m = 0; m < 4; ++m)
-#pragma unroll
-							for (int f = 0; f < 2; ++f) {
-								const float tl = __shfl_down(lo[m][f], off, 64), th = __shfl_down(hi[m][f], off, 64);
-								if (take) { lo[m][f] += tl; hi[m][f] += th; }
-							}
-					}
-					head = !same;
-				}
+				rotate = (uint32_t)__popcll(__ballot(same)) >= dp.merge_min;
 			}
-			if (!head || !valid) return;                     // a run shares its cell, so its head is valid iff its members are
+			if (!valid) return;
+			if (rotate) {
+				// pair (step + lane) mod 4, entry and feature order by lane bits 2 and 3: the lanes of one atomic that share a cell spread
+				// over its 16 accumulators
+				const uint32_t ln = threadIdx.x & 63u;
+				const bool sw = (ln & 4u) != 0u, fs = (ln & 8u) != 0u;
+#pragma unroll
+				for (uint32_t step = 0; step < 4u; ++step) {
+					const uint32_t m = (step + ln) & 3u;
+					auto sel = [&](auto a0, auto a1, auto a2, auto a3) { return m == 0u ? a0 : (m == 1u ? a1 : (m == 2u ? a2 : a3)); };
+					if (sel(bkt[0], bkt[1], bkt[2], bkt[3]) != b) continue;
+					const uint32_t hd = sel(hdr[0], hdr[1], hdr[2], hdr[3]);
+					const float l0 = sel(lo[0][0], lo[1][0], lo[2][0], lo[3][0]), l1 = sel(lo[0][1], lo[1][1], lo[2][1], lo[3][1]);
+					const float h0 = sel(hi[0][0], hi[1][0], hi[2][0], hi[3][0]), h1 = sel(hi[0][1], hi[1][1], hi[2][1], hi[3][1]);
+					const uint32_t i0 = hd & 8191u, i1 = (hd >> 13) & 8191u;
+					const uint32_t ea = sw ? i1 : i0, eb = sw ? i0 : i1;
+					const float a0 = sw ? h0 : l0, a1 = sw ? h1 : l1, b0 = sw ? l0 : h0, b1 = sw ? l1 : h1;
+					const uint32_t fa = fs ? kPEpb : 0u, fb2 = fs ? 0u : kPEpb;
+					if (fix) {
+						atomicAdd(&acc_raw[fa + ea], to_fix(fs ? a1 : a0, fx.scale)); atomicAdd(&acc_raw[fb2 + ea], to_fix(fs ? a0 : a1, fx.scale));
+						atomicAdd(&acc_raw[fa + eb], to_fix(fs ? b1 : b0, fx.scale)); atomicAdd(&acc_raw[fb2 + eb], to_fix(fs ? b0 : b1, fx.scale));
+					} else {
+						atomicAdd(&acc[fa + ea], (double)(fs ? a1 : a0)); atomicAdd(&acc[fb2 + ea], (double)(fs ? a0 : a1));
+						atomicAdd(&acc[fa + eb], (double)(fs ? b1 : b0)); atomicAdd(&acc[fb2 + eb], (double)(fs ? b0 : b1));
+					}
+				}
+				return;
+			}
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
 				if (bkt[m] != b) continue;
@@ -1031,6 +1050,7 @@ static bool pair_direct_enabled() { return opt::on(NR3D_OPT_PAIR_DIRECT); }
 // when nothing would be left for the record path, whose stage A carries the fixed-point scale)
 static uint64_t pair_direct_plan(const PairPlan &full, uint32_t n, DirectPlan &dp) {
 	dp.n = 0; dp.lg = full.lg; dp.sum_log2 = full.sum_log2; dp.R = 1; dp.pts_per_rep = n;
+	dp.merge_min = (uint32_t)NR3D_XOPT(PAIR_DIRECT_ROTATE, 8);
 	dp.bucket_base[0] = 0;
 	if (!pair_direct_enabled()) return 0;
 	uint64_t mask = 0;
