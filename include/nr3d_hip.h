@@ -85,7 +85,7 @@ enum {
 	NR3D_OPT_VM_DIRECT = 18,         /* 1: VM levels whose planes split into <= 4 LDS-sized bands accumulate their dL/dparam in LDS without records (k_vm_direct) */
 	NR3D_OPT_DIRECT_FIXED = 19,      /* 1: k_cp_direct accumulates in 64-bit fixed point (scale from the workgroup's own bound on its updates); 2: k_vm_direct
 	                                  * too (measured slower there, twice: it is not bound by its LDS atomics); 0: fp64 */
-	NR3D_OPT_VM_SORTED = 20,         /* 1: a dL/dparam pass with a VM level of >= 2^20 entries (over its blocks) and >= 2^19 points sorts the POINTS by
+	NR3D_OPT_VM_SORTED = 20,         /* 1: a dL/dparam pass with a VM level of >= 2^20 entries (over its blocks) and >= 2^19 points -- or any VM level and >= 2^21 points -- sorts the POINTS by
 	                                  * (block, coordinate) and accumulates every VM level band by band in LDS, without records (lotd_sorted.hip;
 	                                  * single tables, batches and forests; a forest's small Dense levels ride along as slices); 2: whenever the geometry allows (tests); 3: as 1, VM levels only; 0: records */
 	NR3D_OPT_MLP_X3 = 21,            /* 1: the fp32 fused MLP forward runs on the bf16 MFMA with every value split into three bf16 pieces (six piece products,

@@ -1480,14 +1480,15 @@ __global__ __launch_bounds__(256) void k_vm_direct_reduce(VmPlan vp, const nr3d_
 
 // the VM pseudo levels k_vm_direct serves (mask; 0: none): unbatched 3-D metas with 2-feature pseudo levels, levels inside
 // [min_level, max_level] whose planes split into <= kVmDirectChunks bands each, partial tables inside `part_floats`
-static uint64_t vm_direct_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level, int32_t max_level, uint64_t part_floats, VmPlan &vp) {
+static uint64_t vm_direct_plan(const nr3d_lotd_meta_t *m, uint32_t n, int32_t min_level, int32_t max_level, uint64_t part_floats, VmPlan &vp,
+                               uint64_t skip = 0) {
 	vp.n_items = 0; vp.R = 1; vp.pts_per_rep = n; vp.stride = 2u * ((1u << kVmDirectLg) + kVmDirectMaxLines);
 	if (!opt::on(NR3D_OPT_VM_DIRECT) || m->n_dims_to_encode != 3 || m->n_feat_per_pseudo_lvl != 2 || m->n_pseudo_levels > 64u || n == 0) return 0;
 	uint64_t mask = 0;
 	for (uint32_t q = 0; q < m->n_pseudo_levels; ++q) {
 		const uint32_t lv = m->map_levels[q];
 		const nr3d_lotd_level_t &L = m->levels[lv];
-		if (L.type != NR3D_LOD_VectorMatrix || (int32_t)lv < min_level || (int32_t)lv > max_level) continue;
+		if (L.type != NR3D_LOD_VectorMatrix || (int32_t)lv < min_level || (int32_t)lv > max_level || ((skip >> q) & 1ull)) continue;
 		uint32_t chunks[3], rows[3], total = 0;
 		bool ok = true;
 		for (int d = 0; d < 3 && ok; ++d) {
@@ -1890,10 +1891,28 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				NR3D_LAUNCH_CHECK();
 			}
 		}
+		// VM levels over sorted points (single tables, batches, forests): points sorted by (block, coordinate), bands accumulated in LDS, no
+		// records.  Asked BEFORE k_vm_direct since round 6: with unit records and fixed-point accumulators it beats k_vm_direct + records on
+		// configs[3] too (dL/dparam 4.90 -> 4.46 ms, d(dL/dx)/dparam 5.04 -> 4.71 at 2^22 points), so small tables take it from 2^21 points on
+		// (lotd_sorted.hip); its scratch is the record / offsets region, which the classes below use afterwards
+		if (!g_half) {
+			VsPlan vsp;
+			const uint64_t smask = vm_sorted_plan(meta, n, n_batches, forest != nullptr, min_level, max_level, cp_mask, vsp);
+			if (smask) {
+				VsScratch vss;
+				vm_sorted_scratch(vsp, n, E, second, forest != nullptr, vss);
+				if (vss.total <= lay.rec_bytes + lay.offs_bytes) {
+					if (int rc = vm_sorted_run(second, vsp, meta, md, n, xc, vc, dL_dy + (int64_t)p0 * g_sn, g_sn, g_se, params, p_half, ba, forest, dparam,
+					                           (char *)workspace, vss, st))
+						return rc;
+					cp_mask |= smask;
+				}
+			}
+		}
 		// small VM levels skip the records altogether (k_vm_direct), like the CP levels above
 		if (!forest && n_batches <= 1 && !batch.inds && !batch.offsets && !batch.data_size) {
 			VmPlan vp;
-			const uint64_t vmask = vm_direct_plan(meta, n, min_level, max_level, lay.part_bytes / 4, vp);
+			const uint64_t vmask = vm_direct_plan(meta, n, min_level, max_level, lay.part_bytes / 4, vp, cp_mask);
 			if (vmask) {
 				static bool vattr[64] = {};
 				int dev_id = 0;
@@ -1925,22 +1944,6 @@ int dparam_binned(bool second, const nr3d_lotd_meta_t *meta, const void *meta_de
 				hipLaunchKernelGGL(k_vm_direct_reduce, dim3(div_up(vp.stride, 256u), vp.n_items), dim3(256), 0, st, vp, md, partial, dparam);
 				NR3D_LAUNCH_CHECK();
 				cp_mask |= vmask;
-			}
-		}
-		// large VM levels (single tables, batches, forests): points sorted by (block, coordinate), bands accumulated in LDS, no records
-		// (lotd_sorted.hip); its scratch is the record / offsets region, which the classes below use afterwards
-		if (!g_half) {
-			VsPlan vsp;
-			const uint64_t smask = vm_sorted_plan(meta, n, n_batches, forest != nullptr, min_level, max_level, cp_mask, vsp);
-			if (smask) {
-				VsScratch vss;
-				vm_sorted_scratch(vsp, n, E, second, forest != nullptr, vss);
-				if (vss.total <= lay.rec_bytes + lay.offs_bytes) {
-					if (int rc = vm_sorted_run(second, vsp, meta, md, n, xc, vc, dL_dy + (int64_t)p0 * g_sn, g_sn, g_se, params, p_half, ba, forest, dparam,
-					                           (char *)workspace, vss, st))
-						return rc;
-					cp_mask |= smask;
-				}
 			}
 		}
 		// VM levels: the line tables' gradients accumulate in LDS inside stage A, only the plane updates travel as records

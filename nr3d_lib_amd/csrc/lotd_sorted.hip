@@ -170,23 +170,32 @@ __global__ __launch_bounds__(256) void k_vs_gather(uint32_t n, uint32_t E, const
                                                    const float *__restrict__ vin, const float *__restrict__ g, int64_t g_sn, int64_t g_se,
                                                    uint64_t cols0, uint64_t cols1, float *__restrict__ xs, float *__restrict__ vs,
                                                    float *__restrict__ gts, uint32_t *__restrict__ stats) {
-	extern __shared__ __attribute__((aligned(16))) float vg_tile[];               // [E][kVsGatherPts + 1]
+	extern __shared__ __attribute__((aligned(16))) float vg_tile[];               // [W wanted columns][kVsGatherPts + 1]
 	__shared__ uint32_t src[kVsGatherPts];
+	__shared__ uint8_t wlist[128];                                                 // the wanted columns, ascending
 	const uint32_t i0 = blockIdx.x * kVsGatherPts;
 	const uint32_t np = min(kVsGatherPts, n - i0);
 	if (threadIdx.x < np) src[threadIdx.x] = perm[i0 + threadIdx.x];
-	__syncthreads();
 	auto wanted = [&](uint32_t e) { return (((e < 64u ? cols0 : cols1) >> (e & 63u)) & 1ull) != 0ull; };
+	const uint32_t W = (uint32_t)(__popcll(cols0) + __popcll(cols1));
+	if (threadIdx.x < 128u && threadIdx.x < E && wanted(threadIdx.x)) {
+		const uint32_t e = threadIdx.x;
+		const uint32_t below = e < 64u ? (uint32_t)__popcll(cols0 & ((1ull << e) - 1ull))
+		                               : (uint32_t)(__popcll(cols0) + __popcll(cols1 & ((1ull << (e - 64u)) - 1ull)));
+		wlist[below] = (uint8_t)e;
+	}
+	__syncthreads();
 	uint32_t gb = 0u, vb = 0u;                                                    // float bits of max |dL_dy|, max |dL_ddLdx| (stats != nullptr: order 0 only)
 	{
-		// thread -> (row of the pass, column) by shift and mask over the next power of two >= E (a division by E per load was most of
-		// this kernel's VALU time: 65 M wave instructions, ~100 us of the SIMDs)
+		// thread -> (row of the pass, k-th WANTED column) by shift and mask over the next power of two >= W: no division per load, and
+		// no lanes parked on columns nobody serves (configs[3]: 14 of 50 columns -- with lanes over all E columns a row load ran 14 of
+		// 64 lanes, 527 us per order at 2^22 points)
 		uint32_t lg = 0;
-		while ((1u << lg) < E) ++lg;                                            // E <= 120: lg <= 7
-		const uint32_t e = threadIdx.x & ((1u << lg) - 1u), r0 = threadIdx.x >> lg, step = 256u >> lg;
-		if (e < E && wanted(e)) {
-			const float *ge = g + (int64_t)e * g_se;
-			float *te = vg_tile + e * (kVsGatherPts + 1u);
+		while ((1u << lg) < W) ++lg;                                            // W <= E <= 120: lg <= 7
+		const uint32_t k = threadIdx.x & ((1u << lg) - 1u), r0 = threadIdx.x >> lg, step = 256u >> lg;
+		if (k < W) {
+			const float *ge = g + (int64_t)wlist[k] * g_se;
+			float *te = vg_tile + k * (kVsGatherPts + 1u);
 			for (uint32_t i = r0; i < np; i += step) {
 				const float v = ge[(int64_t)src[i] * g_sn];
 				te[i] = v;
@@ -210,9 +219,9 @@ __global__ __launch_bounds__(256) void k_vs_gather(uint32_t n, uint32_t E, const
 		}
 	}
 	__syncthreads();
-	for (uint32_t o = threadIdx.x; o < E * kVsGatherPts; o += 256u) {
-		const uint32_t e = o / kVsGatherPts, i = o % kVsGatherPts;
-		if (i < np && wanted(e)) gts[(size_t)e * n + i0 + i] = vg_tile[e * (kVsGatherPts + 1u) + i];
+	for (uint32_t o = threadIdx.x; o < W * kVsGatherPts; o += 256u) {
+		const uint32_t k = o / kVsGatherPts, i = o % kVsGatherPts;
+		if (i < np) gts[(size_t)wlist[k] * n + i0 + i] = vg_tile[k * (kVsGatherPts + 1u) + i];
 	}
 }
 
@@ -1061,7 +1070,9 @@ uint64_t vm_sorted_plan(const nr3d_lotd_meta_t *m, uint32_t n, uint32_t n_blocks
 		biggest = sz > biggest ? sz : biggest;
 	}
 	vp.item_base[vp.n_qd] = items;
-	if (!mask || (mode == 1 && (biggest < (1ull << 20) || n < (1u << 19)))) { vp.n_qd = vp.n_items = 0; return 0; }
+	// (mode 1: big tables from 2^19 points on -- the records cost O(point blocks x buckets) there; small tables from 2^21 points on -- the
+	// sorts and gathers are a fixed 0.3 ms, measured against k_vm_direct + records on configs[3])
+	if (!mask || (mode == 1 && (n < (1u << 19) || (biggest < (1ull << 20) && n < (1u << 21))))) { vp.n_qd = vp.n_items = 0; return 0; }
 	// few points per work item (a forest of many blocks, a short pass): the per-band work -- zeroing and writing a 158-KiB table --
 	// would dominate; the records take those
 	if (mode == 1 && (uint64_t)n * vp.n_qd < 256ull * items) { vp.n_qd = vp.n_items = 0; return 0; }
@@ -1169,9 +1180,11 @@ int vm_sorted_run(bool second, const VsPlan &vp, const nr3d_lotd_meta_t *meta, c
 	uint64_t cols[2] = {0ull, 0ull};                    // the dL_dy columns of the served pseudo levels (two features each)
 	for (uint32_t k = 0; k < vp.n_qd; ++k)
 		for (uint32_t f = 0; f < 2u; ++f) { const uint32_t c = meta->map_col[vp.q[k]] + f; cols[c >> 6] |= 1ull << (c & 63u); }
+	uint32_t n_wanted = 0;
+	for (int w = 0; w < 2; ++w) for (uint64_t b = cols[w]; b; b &= b - 1) ++n_wanted;
 	for (int o = 0; o < 2; ++o) {
 		float *xs = (float *)(scratch + s.xs[o]), *vs = (float *)(scratch + s.vs[o]), *gts = (float *)(scratch + s.gts[o]);
-		hipLaunchKernelGGL(k_vs_gather, dim3(div_up(n, kVsGatherPts)), dim3(256), (size_t)E * (kVsGatherPts + 1u) * 4u, st, n, E, perm[o], x,
+		hipLaunchKernelGGL(k_vs_gather, dim3(div_up(n, kVsGatherPts)), dim3(256), (size_t)n_wanted * (kVsGatherPts + 1u) * 4u, st, n, E, perm[o], x,
 		                   second ? vin : nullptr, g, g_sn, g_se, cols[0], cols[1], xs, vs, gts, o == 0 ? stats : nullptr);
 		dv.skey[o] = key_out[o]; dv.xs[o] = xs; dv.vs[o] = vs; dv.gts[o] = gts;
 	}
