@@ -1002,8 +1002,9 @@ uint64_t vm_sorted_plan(const nr3d_lotd_meta_t *m, uint32_t n, uint32_t n_blocks
 		const uint32_t lv = m->map_levels[q];
 		const nr3d_lotd_level_t &L = m->levels[lv];
 		if ((int32_t)lv < min_level || (int32_t)lv > max_level || ((skip >> q) & 1ull)) continue;
-		if (L.type == NR3D_LOD_Dense && forest && mode_opt != 3) {
-			// a forest's small Dense levels ride along (component code 3: rows = x_0 slices, vm_geom): their records cost 0.69 ms on the
+		if (L.type == NR3D_LOD_Dense && mode_opt != 3) {
+			// small Dense levels ride along (component code 3: rows = x_0 slices, vm_geom; forests and, measured on configs[3], plain metas:
+			// two 4-feature Dense levels 1.06 ms of records per pass).  A forest's two: their records cost 0.69 ms on the
 			// reference's forest workload (k_bin_forest + k_accum + the feature-major copy of dL_dy for two levels of 34^3 and 55^3),
 			// as two more "planes" of the sorted points ~0.2.  Only next to VM levels (dense_mask is dropped when no VM level is served).
 			const VmGeom gm = vm_geom(L.res, 3);
@@ -1019,7 +1020,7 @@ uint64_t vm_sorted_plan(const nr3d_lotd_meta_t *m, uint32_t n, uint32_t n_blocks
 			for (int d = 0; d < 3; ++d) { const float t = 0.5f / (float)L.res[d]; thr = t > thr ? t : thr; }
 			vp.thr[k] = thr * 1.001f + 1e-6f;
 			vp.thr_max = vp.thr[k] > vp.thr_max ? vp.thr[k] : vp.thr_max;
-			const float scale = (float)gm.Ra;
+			const float scale = forest ? (float)gm.Ra : (float)(gm.Ra - 2u);
 			bool seen = false;
 			for (uint32_t j = 0; j < vp.n_sc[0]; ++j) seen = seen || vp.sc[0][j] == scale;
 			if (!seen) {
