@@ -105,7 +105,9 @@ def main():
                                    "note": "the 8 MiB of tables are cache resident; HBM carries x, dL_dy, y, the Jacobian and "
                                            "the scatter records.  The forward's fraction prices 1 936 B/point of cache-resident "
                                            "gathers as if they were HBM bytes (SURVEY 8d's no-cache-credit model): a fraction above "
-                                           "the ~0.79 that HBM can deliver does not mean HBM moved those bytes"}}))
+                                           "the ~0.79 that HBM can deliver does not mean HBM moved those bytes.  Likewise the two dL/dparam passes since round 6: "
+                                           "their model charges a read-modify-write of every distinct entry per point (2 G), the kernels accumulate "
+                                           "those in LDS over sorted points and write each table once"}}))
 
 
 if __name__ == "__main__":
