@@ -83,7 +83,7 @@ enum {
 	NR3D_OPT_FWD_CELL_MAJOR = 16,    /* 1: forward reads a cell-major replica of the mid Dense levels when the caller supplies one */
 	NR3D_OPT_SORT_WAVE = 17,         /* 1: packed_sort with one wave per pack (bitonic); 0: one lane per pack (heapsort) */
 	NR3D_OPT_VM_DIRECT = 18,         /* 1: VM levels whose planes split into <= 4 LDS-sized bands accumulate their dL/dparam in LDS without records (k_vm_direct) */
-	NR3D_OPT_DIRECT_FIXED = 19,      /* 1: k_cp_direct accumulates in 64-bit fixed point (scale from the workgroup's own bound on its updates); 2: k_vm_direct
+	NR3D_OPT_DIRECT_FIXED = 19,      /* 1: k_cp_direct and k_vm_sorted accumulate in 64-bit fixed point (scale from the workgroup's own bound on its updates); 2: k_vm_direct
 	                                  * too (measured slower there, twice: it is not bound by its LDS atomics); 0: fp64 */
 	NR3D_OPT_VM_SORTED = 20,         /* 1: a dL/dparam pass with a VM level of >= 2^20 entries (over its blocks) and >= 2^19 points -- or any VM level and >= 2^21 points -- sorts the POINTS by
 	                                  * (block, coordinate) and accumulates every VM level band by band in LDS, without records (lotd_sorted.hip;
