@@ -378,10 +378,14 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 	const int r = lane & 31;
 	float *tiles = lds + a.total_floats + (size_t)wave * a.tile_floats;
-	// tile rows: X | H_1 .. H_NH | G_out
+	// tile rows: X or G_out | H_1 .. H_NH.  G_out (dL/dy as [feature][sample]) lives from the output layer's step of the sweep to its
+	// end, X from the first layer's step on -- the forward reads x from registers --, so they share their rows (round 6: the tile area
+	// of 64 -> 64 -> 64 -> 64 drops from 36.9 to 27.6 KB per wave and TWO waves fit next to 98 KB of weights where one did;
+	// 32 -> 64 -> 64 -> 16: four instead of three)
+	constexpr int XG_T = IN_T > OUT_T ? IN_T : OUT_T;
 	float *TX = tiles;
-	float *TH1 = tiles + 32 * IN_T * kTS;                               // H_l at TH1 + (l - 1) * 32 * W_T * kTS
-	float *TGO = TH1 + NH * 32 * W_T * kTS;
+	float *TGO = tiles;
+	float *TH1 = tiles + 32 * XG_T * kTS;                               // H_l at TH1 + (l - 1) * 32 * W_T * kTS
 	// packed layers: forward [0 | hidden ... | out], then the transposed ones in the same order
 	constexpr uint32_t f0 = X3 ? layer_x3_floats(IN_T, W_T) : layer_floats(IN_T, W_T), fh = X3 ? layer_x3_floats(W_T, W_T) : layer_floats(W_T, W_T);
 	constexpr uint32_t fo = X3 ? layer_x3_floats(W_T, OUT_T) : layer_floats(W_T, OUT_T);
@@ -425,7 +429,6 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 			load_rows<OUT_T>(a.gy, a.gys, a.dims[NH + 1], row, valid, a.gy_vec != 0, lane, g_out);
 		}
 		// ---- forward, activations kept as [feature][sample] tiles ----
-		write_tile<IN_T>(TX, IN_T, xin, lane);
 		if constexpr (X3) dense_x3<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
 		else dense<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
 		write_tile<W_T>(TH1, W_T, hcur, lane);
@@ -453,6 +456,7 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 		f16v g[W_T];
 		if (relu) bwd_layer<OUT_T, W_T, true, true, X3>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTS, wt + t0 + (NH - 1) * th, dWo, dbo, g, lane);
 		else bwd_layer<OUT_T, W_T, true, false, X3>(g_out, TGO, TH1 + (NH - 1) * 32 * W_T * kTS, wt + t0 + (NH - 1) * th, dWo, dbo, g, lane);
+		write_tile<IN_T>(TX, IN_T, xin, lane);                           // into G_out's rows: their reader, the step above, is done; x leaves the registers here
 #pragma unroll
 		for (int l = NH - 1; l >= 1; --l) {                              // hidden layer l: H_l -> H_{l+1}
 			f16v gp[W_T];
@@ -549,7 +553,7 @@ static uint64_t x3t_floats(const Shape &s) {
 }
 
 // per-wave [feature][sample] tiles: X, H_1 .. H_NH, G_out
-static uint32_t bwd_tile_floats(const Shape &s) { return (32u * s.in_t + (s.n_layers - 1) * 32u * s.w_t + 32u * s.out_t) * (uint32_t)kTS; }
+static uint32_t bwd_tile_floats(const Shape &s) { return (32u * (s.in_t > s.out_t ? s.in_t : s.out_t) + (s.n_layers - 1) * 32u * s.w_t) * (uint32_t)kTS; }
 
 static uint32_t bwd_waves(const Shape &s, bool x3 = false) {
 	if (x3 && x3_floats(s) == 0) return 0;
