@@ -991,6 +991,33 @@ def test_forward_lds_slabs_bit_identical(dev, hip_option, smooth, half):
     assert mask == 0b011111 and by_slab.value == 0b011100, (bin(mask), bin(by_slab.value))    # 58^3 needs 15 slabs: left to the two-lane kernel
 
 
+@pytest.mark.parametrize("case", ["ngp_pair", "ngp_small"])
+def test_dparam_does_not_depend_on_the_order_of_the_points(oracle, dev, case):
+    """the pair-record path on ORDERED inputs (round 6: k_pair_direct walks a coherent wave's updates in per-lane rotated order, the
+    replicas of stage B and of the direct levels take interleaved point blocks): the same points along a Morton curve, sorted by x
+    (rays), and with every point repeated 64 times in a row (whole waves in one cell) give the gradient of the random order --
+    sums are exact in fixed point; what may differ is the fp32 rounding of lanes that stage A merges -- and that of the oracle"""
+    from nr3d_lib_amd import _hip
+    _lotd, m_ref, m, (x, p, g, v), (xt, pt, gt, vt) = _setup(oracle, dev, case, n=1 << 18, seed=21)
+    ref = oracle.lotd_bwd_dparam(m_ref, g, x, p, accum_double=True)
+
+    def run(order):
+        xo, go = (xt if order is None else xt[order].contiguous()), (gt if order is None else gt[order].contiguous())
+        return _lotd.lod_bwd(m, go, xo, pt, None, need_input_grad=False, need_param_grad=True)[1]
+    base = run(None)
+    assert_close(base, ref, name="random order vs oracle", levels=m_ref)
+    morton = _hip.spatial_order(xt.contiguous(), 7).long()
+    by_x = torch.argsort(xt[:, 0])
+    for name, order in (("Morton", morton), ("sorted by x", by_x)):
+        got = run(order)
+        assert_close(got, base.cpu().numpy(), rel=2e-6, name=f"{name} vs random order", levels=m_ref)
+    # whole waves in one cell: 4096 distinct points, each 64 times in a row
+    rep = torch.arange(4096, device=dev).repeat_interleave(64)
+    got = _lotd.lod_bwd(m, gt[rep].contiguous(), xt[rep].contiguous(), pt, None, need_input_grad=False, need_param_grad=True)[1]
+    want = 64.0 * _lotd.lod_bwd(m, gt[:4096].contiguous(), xt[:4096].contiguous(), pt, None, need_input_grad=False, need_param_grad=True)[1]
+    assert_close(got, want.cpu().numpy(), rel=2e-6, name="64 copies of every point in a row", levels=m_ref)
+
+
 def test_loss_scale_changes_no_bit(dev, monkeypatch):
     """half tables: the reference's loss scale (x 128 on dL/dy, / 128 on the gradients; lotd.py:96-119) protects its half atomics from
     underflow; here the accumulation is exact and every gradient is rounded once, so running the protocol literally (two more passes)
