@@ -300,7 +300,7 @@ __device__ __forceinline__ void bwd_layer(const f16v (&g)[NO], float *__restrict
 	}
 	if (PREV) {
 		if constexpr (X3) dense_x3<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);
-		else dense<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);
+		else dense_t<NO, NI>(wT, g, gp, lane);                          // wT: the padded copy of the FORWARD layer
 		if (MASK) {
 #pragma unroll
 			for (int t = 0; t < NI; ++t)
@@ -368,11 +368,23 @@ constexpr int kMaxLdsBwd = 160 * 1024;
 template <int IN_T, int W_T, int OUT_T, int NH, int FAST, bool X3 = false>
 __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
-	{
+	if constexpr (X3) {
 		const f4v *src = reinterpret_cast<const f4v *>(a.packed), *src_t = reinterpret_cast<const f4v *>(a.packed_t);
 		f4v *dst = reinterpret_cast<f4v *>(lds);
 		const uint32_t nf = a.fwd_floats / 4;
 		for (uint32_t i = threadIdx.x; i < a.total_floats / 4; i += blockDim.x) dst[i] = i < nf ? src[i] : src_t[i - nf];
+		__syncthreads();
+	} else {
+		// f32 MFMA: ONE padded copy of the forward layers serves the forward recomputation (16-byte reads) and the dH = W^T dPre chain
+		// (dense_t's 4-byte reads) -- the transposed copy's LDS goes to the waves' tiles: 64 -> 64 -> 64 -> 64 runs four waves per CU
+		// where two fitted, 32 -> 64 -> 64 -> 16 keeps its four
+		stage_layer_padded<IN_T, W_T>(a.packed, lds);
+#pragma unroll
+		for (int l = 1; l < NH; ++l)
+			stage_layer_padded<W_T, W_T>(a.packed + layer_floats(IN_T, W_T) + (l - 1) * layer_floats(W_T, W_T),
+			                             lds + layer_floats_pad(IN_T, W_T) + (l - 1) * layer_floats_pad(W_T, W_T));
+		stage_layer_padded<W_T, OUT_T>(a.packed + layer_floats(IN_T, W_T) + (NH - 1) * layer_floats(W_T, W_T),
+		                               lds + layer_floats_pad(IN_T, W_T) + (NH - 1) * layer_floats_pad(W_T, W_T));
 		__syncthreads();
 	}
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -387,10 +399,12 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 	float *TGO = tiles;
 	float *TH1 = tiles + 32 * XG_T * kTS;                               // H_l at TH1 + (l - 1) * 32 * W_T * kTS
 	// packed layers: forward [0 | hidden ... | out], then the transposed ones in the same order
-	constexpr uint32_t f0 = X3 ? layer_x3_floats(IN_T, W_T) : layer_floats(IN_T, W_T), fh = X3 ? layer_x3_floats(W_T, W_T) : layer_floats(W_T, W_T);
-	constexpr uint32_t fo = X3 ? layer_x3_floats(W_T, OUT_T) : layer_floats(W_T, OUT_T);
-	constexpr uint32_t t0 = X3 ? layer_x3_floats(W_T, IN_T) : layer_floats(W_T, IN_T), th = fh, fwd_total = f0 + (NH - 1) * fh + fo;
-	const float *wf = lds, *wt = lds + fwd_total;
+	constexpr uint32_t f0 = X3 ? layer_x3_floats(IN_T, W_T) : layer_floats_pad(IN_T, W_T), fh = X3 ? layer_x3_floats(W_T, W_T) : layer_floats_pad(W_T, W_T);
+	constexpr uint32_t fo = X3 ? layer_x3_floats(W_T, OUT_T) : layer_floats_pad(W_T, OUT_T);
+	constexpr uint32_t fwd_total = f0 + (NH - 1) * fh + fo;
+	// the layers the dH chain reads: the x3 planes of the transposed layers behind the forward ones, or the forward layers themselves
+	constexpr uint32_t t0 = X3 ? layer_x3_floats(W_T, IN_T) : f0, th = fh;
+	const float *wf = lds, *wt = X3 ? lds + fwd_total : lds;
 
 	f16v dW0[W_T][IN_T], dWh[NH > 1 ? NH - 1 : 1][W_T][W_T], dWo[OUT_T][W_T];
 	float db0[W_T], dbh[NH > 1 ? NH - 1 : 1][W_T], dbo[OUT_T];
@@ -430,13 +444,13 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 		}
 		// ---- forward, activations kept as [feature][sample] tiles ----
 		if constexpr (X3) dense_x3<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
-		else dense<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
+		else dense<IN_T, W_T, true, true>(wf, xin, hcur, a.hidden_act, lane);
 		write_tile<W_T>(TH1, W_T, hcur, lane);
 #pragma unroll
 		for (int l = 1; l < NH; ++l) {
 			f16v hn[W_T];
 			if constexpr (X3) dense_x3<W_T, W_T, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
-			else dense<W_T, W_T, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
+			else dense<W_T, W_T, true, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
 			write_tile<W_T>(TH1 + l * 32 * W_T * kTS, W_T, hcur, lane);
@@ -445,7 +459,7 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 		if (a.out_act == NR3D_MLP_ACT_RELU) {
 			f16v yo[OUT_T];
 			if constexpr (X3) dense_x3<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
-			else dense<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
+			else dense<W_T, OUT_T, true, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t)
 #pragma unroll
@@ -552,12 +566,17 @@ static uint64_t x3t_floats(const Shape &s) {
 	return (uint64_t)layer_x3_floats(s.w_t, s.in_t) + (uint64_t)(s.n_layers - 2) * layer_x3_floats(s.w_t, s.w_t) + layer_x3_floats(s.out_t, s.w_t);
 }
 
+// the f32 backward's LDS copy of the forward layers (mlp_device.h kGS / kHS)
+static uint64_t padded_floats(const Shape &s) {
+	return (uint64_t)layer_floats_pad(s.in_t, s.w_t) + (uint64_t)(s.n_layers - 2) * layer_floats_pad(s.w_t, s.w_t) + layer_floats_pad(s.w_t, s.out_t);
+}
+
 // per-wave [feature][sample] tiles: X, H_1 .. H_NH, G_out
 static uint32_t bwd_tile_floats(const Shape &s) { return (32u * (s.in_t > s.out_t ? s.in_t : s.out_t) + (s.n_layers - 1) * 32u * s.w_t) * (uint32_t)kTS; }
 
 static uint32_t bwd_waves(const Shape &s, bool x3 = false) {
 	if (x3 && x3_floats(s) == 0) return 0;
-	const uint64_t wbytes = (x3 ? x3_floats(s) + x3t_floats(s) : packed_floats(s) + transposed_floats(s)) * 4;
+	const uint64_t wbytes = (x3 ? x3_floats(s) + x3t_floats(s) : padded_floats(s)) * 4;
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;     // one layer at a time
 	const uint32_t max_waves = (s.in_t == 1 && s.w_t == 1 && s.out_t == 1 && s.n_layers - 1 <= 2) ? 8u : 4u;      // = BwdCfg<...>::kMaxWaves
 	for (uint32_t nw = max_waves; nw >= 1; --nw) {
@@ -728,9 +747,8 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 		a.total_floats = a.fwd_floats + (uint32_t)x3t_floats(s);
 		a.packed_t = packed + forward_floats(s) + transposed_floats(s);
 	} else {
-		a.fwd_floats = (uint32_t)packed_floats(s);
-		a.total_floats = a.fwd_floats + (uint32_t)transposed_floats(s);
-		a.packed_t = packed + forward_floats(s);               // (the x3 planes of the forward sit in between)
+		a.fwd_floats = a.total_floats = (uint32_t)padded_floats(s);     // of the LDS copy; the kernel pads the packed forward layers itself
+		a.packed_t = nullptr;
 	}
 	for (uint32_t l = 0; l < desc->n_layers; ++l) {
 		NR3D_CHECK(dL_dW[l] != nullptr, "mlp_backward: dL_dW[%u] is NULL", l);

@@ -25,6 +25,12 @@ __host__ __device__ constexpr uint32_t tiles(uint32_t d) { return (d + 31u) / 32
 // floats of one packed layer: weights [NO][NI][4][64][4] + bias [NO * 32]
 __host__ __device__ constexpr uint32_t layer_floats(uint32_t ni, uint32_t no) { return no * ni * 1024u + no * 32u; }
 
+// the backward kernel's padded LDS copy of a packed layer (dense<..., PAD = true> / dense_t): a group of 64 lanes x 4 floats starts
+// every kGS floats and its second half-wave kHS floats in -- 8 and 4 floats of padding that put the transposed 4-byte reads of
+// dense_t on different banks while every quarter wave of the forward's 16-byte reads stays contiguous
+constexpr int kGS = 264, kHS = 132;
+__host__ __device__ constexpr uint32_t layer_floats_pad(uint32_t ni, uint32_t no) { return no * ni * 4u * kGS + no * 32u; }
+
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -42,15 +48,16 @@ __device__ __forceinline__ float activate(float v, int act) { return act == NR3D
 // read kWPF groups ahead of their use: with one or two waves per SIMD nothing else would cover the LDS latency.
 constexpr int kWPF = 6;
 
-template <int NI, int NO, bool BIAS>
+// PAD: wp is the backward kernel's padded copy (kGS / kHS below) instead of the packed layout
+template <int NI, int NO, bool BIAS, bool PAD = false>
 __device__ __forceinline__ void dense(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
-	const float *bias = wp + NO * NI * 1024;
+	const float *bias = wp + NO * NI * (PAD ? 4 * kGS : 1024);
 	const int h = lane >> 5;
 	constexpr bool SPLIT = (NO == 1);              // one out tile: two accumulators over alternating k-steps
 	constexpr int G = NO * NI * 4;                 // weight groups, consumed in (it, q, ot) order
 	constexpr int PF = kWPF < G ? kWPF : G;
-	const f4v *wv = reinterpret_cast<const f4v *>(wp) + lane;
-	auto lds_index = [](int g) { const int ot = g % NO, s = g / NO; return ((ot * NI + s / 4) * 4 + (s % 4)) * 64; };   // [ot][it][q] in LDS
+	const f4v *wv = reinterpret_cast<const f4v *>(wp) + (PAD ? h * (kHS / 4) + (lane & 31) : lane);
+	auto lds_index = [](int g) { const int ot = g % NO, s = g / NO; return ((ot * NI + s / 4) * 4 + (s % 4)) * (PAD ? kGS / 4 : 64); };   // [ot][it][q] in LDS
 	f4v ring[PF];
 #pragma unroll
 	for (int g = 0; g < PF; ++g) ring[g] = wv[lds_index(g)];
@@ -92,6 +99,73 @@ __device__ __forceinline__ void dense(const float *__restrict__ wp, const f16v (
 	for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
 		for (int j = 0; j < 16; ++j) out[ot][j] = activate(SPLIT ? out[ot][j] + alt[j] : out[ot][j], act);
+}
+
+// out = W^T in from the PADDED copy of the forward layer W (NI tiles of W's outputs come in, NO tiles of W's inputs go out; round 6:
+// the backward keeps ONE copy of the weights in LDS).  Lane (r, h) of the A operand of step (it, q, b) holds
+// W[32 it + 8 q + 4 h + b][32 ot + r], which the packed layout keeps at group (it * NO + ot) * 4 + (r >> 3), half-wave (r >> 2) & 1,
+// lane 8 q + 4 h + b, element r & 3: four 4-byte reads 16 bytes apart where dense() takes one 16-byte read.  Unpadded, the lanes'
+// addresses would differ by multiples of 512 bytes (r >> 2) -> 8 lanes per bank; with the padding the 32 lanes of a half-wave fall
+// on 32 different banks ((r >> 3) * 8 + ((r >> 2) & 1) * 4 + (r & 3)).
+template <int NI, int NO>
+__device__ __forceinline__ void dense_t(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int lane) {
+	const int r = lane & 31, h = lane >> 5;
+	constexpr bool SPLIT = (NO == 1);
+	constexpr int G = NO * NI * 4;
+	constexpr int PF = kWPF < G ? kWPF : G;
+	const float *wl = wp + (r >> 3) * kGS + ((r >> 2) & 1) * kHS + (r & 3) + 16 * h;
+	auto fetch = [&](int g) {
+		const int ot = g % NO, s = g / NO;                            // s = it * 4 + q
+		const float *p = wl + ((s / 4) * NO + ot) * 4 * kGS + 32 * (s % 4);
+		const f4v v = {p[0], p[4], p[8], p[12]};
+		return v;
+	};
+	f4v ring[PF];
+#pragma unroll
+	for (int g = 0; g < PF; ++g) ring[g] = fetch(g);
+	f16v alt;
+#pragma unroll
+	for (int j = 0; j < 16; ++j) alt[j] = 0.0f;
+#pragma unroll
+	for (int ot = 0; ot < NO; ++ot)
+#pragma unroll
+		for (int j = 0; j < 16; ++j) out[ot][j] = 0.0f;
+#pragma unroll
+	for (int s = 0; s < NI * 4; ++s) {
+		const int it = s / 4, q = s % 4;
+		f4v w4[NO];
+#pragma unroll
+		for (int ot = 0; ot < NO; ++ot) {
+			const int g = s * NO + ot;
+			w4[ot] = ring[g % PF];
+			if (g + PF < G) ring[g % PF] = fetch(g + PF);
+		}
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			if constexpr (SPLIT) {
+				if (b & 1) alt = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0][b], in[it][4 * q + b], alt, 0, 0, 0);
+				else out[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0][b], in[it][4 * q + b], out[0], 0, 0, 0);
+			} else {
+#pragma unroll
+				for (int ot = 0; ot < NO; ++ot)
+					out[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[ot][b], in[it][4 * q + b], out[ot], 0, 0, 0);
+			}
+		}
+	}
+	if constexpr (SPLIT) {
+#pragma unroll
+		for (int j = 0; j < 16; ++j) out[0][j] += alt[j];
+	}
+}
+
+// one packed layer -> its padded LDS copy (all threads of the workgroup; the caller synchronises)
+template <int NI, int NO>
+__device__ __forceinline__ void stage_layer_padded(const float *__restrict__ src, float *__restrict__ dst) {
+	const f4v *s4 = reinterpret_cast<const f4v *>(src);
+	f4v *d4 = reinterpret_cast<f4v *>(dst);
+	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * NI * 256); i += blockDim.x)
+		d4[(i >> 6) * (kGS / 4) + ((i >> 5) & 1u) * (kHS / 4) + (i & 31u)] = s4[i];
+	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * 32); i += blockDim.x) dst[NO * NI * 4 * kGS + i] = src[NO * NI * 1024 + i];
 }
 
 // the three bf16 pieces of registers 8 s .. 8 s + 7 of a register-map tile (a K = 16 step's B operand)
