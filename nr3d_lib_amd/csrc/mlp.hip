@@ -67,7 +67,7 @@ static bool x3_enabled() { return opt::on(NR3D_OPT_MLP_X3); }
 
 // ---------------------------------------------------------------------------------------------
 // packing: for layer l, packed[(((ot*NI + it)*4 + a)*64 + lane)*4 + b] = W[32 ot + (lane & 31)][32 it + 8a + 4(lane >> 5) + b]
-// (the transposed layers of the backward pass are packed from the same W with the roles of the two indices swapped)
+// (the x3 planes of the transposed layers, backward_mode() 1, are packed from the same W with the roles of the two indices swapped)
 // ---------------------------------------------------------------------------------------------
 struct PackArgs {
 	const float *w[NR3D_MLP_MAX_LAYERS];
@@ -252,7 +252,7 @@ __device__ __forceinline__ void split3_row8(const float *__restrict__ src, bf8 (
 	}
 }
 
-template <int NO, int NI, bool PREV, bool MASK, bool X3 = false>
+template <int NO, int NI, bool PREV, bool MASK, int X3 = 0>
 __device__ __forceinline__ void bwd_layer(const f16v (&g)[NO], float *__restrict__ TG, const float *__restrict__ TB,
                                           const float *__restrict__ wT, f16v (&dW)[NO][NI], float (&db)[NO], f16v (&gp)[NI],
                                           int lane) {
@@ -299,8 +299,9 @@ __device__ __forceinline__ void bwd_layer(const f16v (&g)[NO], float *__restrict
 		}
 	}
 	if (PREV) {
-		if constexpr (X3) dense_x3<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);
-		else dense_t<NO, NI>(wT, g, gp, lane);                          // wT: the padded copy of the FORWARD layer
+		if constexpr (X3 == 1) dense_x3<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);      // wT: the planes of the transposed layer
+		else if constexpr (X3 == 2) dense_x3_t<NO, NI>(wT, g, gp, lane);                         // wT: the padded copy of the FORWARD layer's planes
+		else dense_t<NO, NI>(wT, g, gp, lane);                                                   //     ... of the forward layer
 		if (MASK) {
 #pragma unroll
 			for (int t = 0; t < NI; ++t)
@@ -365,26 +366,29 @@ constexpr int kMaxLdsBwd = 160 * 1024;
 // X3 (round 6): the forward recomputation, the dH = W^T dPre chain and the sample contraction dW = dPre^T H all run on the bf16 MFMA with
 // three-piece splits (dense_x3 / bwd_layer<..., true>); a.packed / a.packed_t then point at the x3 planes of the forward and of the
 // transposed layers.  The ReLU masks come from the SAME forward arithmetic as nr3d_mlp_forward's x3 route.
-template <int IN_T, int W_T, int OUT_T, int NH, int FAST, bool X3 = false>
+template <int IN_T, int W_T, int OUT_T, int NH, int FAST, int X3 = 0>
 __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
-	if constexpr (X3) {
+	constexpr bool PAD = X3 != 1;
+	if constexpr (X3 == 1) {
+		// both orientations of the x3 planes, as packed: every weight read is a 16-byte read
 		const f4v *src = reinterpret_cast<const f4v *>(a.packed), *src_t = reinterpret_cast<const f4v *>(a.packed_t);
 		f4v *dst = reinterpret_cast<f4v *>(lds);
 		const uint32_t nf = a.fwd_floats / 4;
 		for (uint32_t i = threadIdx.x; i < a.total_floats / 4; i += blockDim.x) dst[i] = i < nf ? src[i] : src_t[i - nf];
 		__syncthreads();
 	} else {
-		// f32 MFMA: ONE padded copy of the forward layers serves the forward recomputation (16-byte reads) and the dH = W^T dPre chain
-		// (dense_t's 4-byte reads) -- the transposed copy's LDS goes to the waves' tiles: 64 -> 64 -> 64 -> 64 runs four waves per CU
-		// where two fitted, 32 -> 64 -> 64 -> 16 keeps its four
-		stage_layer_padded<IN_T, W_T>(a.packed, lds);
+		// ONE padded copy of the forward layers (X3 = 0: f32, X3 = 2: their x3 planes) serves the forward recomputation (16-byte
+		// reads) and the dH = W^T dPre chain (dense_t's 4-byte / dense_x3_t's 2-byte transposed reads) -- the transposed copy's LDS goes
+		// to the waves' tiles: on the f32 MFMA 64 -> 64 -> 64 -> 64 runs four waves per CU where two fitted; the x3 planes of
+		// 32 -> 64 -> 64 -> 16 leave room for four waves where both orientations left two
+		constexpr int GPP = X3 ? 6 : 4;
+		constexpr uint32_t s0 = IN_T * W_T * GPP * 256 + W_T * 32, sh = W_T * W_T * GPP * 256 + W_T * 32;      // packed layers
+		constexpr uint32_t d0 = IN_T * W_T * GPP * kGS + W_T * 32, dh = W_T * W_T * GPP * kGS + W_T * 32;      // padded copies
+		stage_layer_padded<IN_T, W_T, GPP>(a.packed, lds);
 #pragma unroll
-		for (int l = 1; l < NH; ++l)
-			stage_layer_padded<W_T, W_T>(a.packed + layer_floats(IN_T, W_T) + (l - 1) * layer_floats(W_T, W_T),
-			                             lds + layer_floats_pad(IN_T, W_T) + (l - 1) * layer_floats_pad(W_T, W_T));
-		stage_layer_padded<W_T, OUT_T>(a.packed + layer_floats(IN_T, W_T) + (NH - 1) * layer_floats(W_T, W_T),
-		                               lds + layer_floats_pad(IN_T, W_T) + (NH - 1) * layer_floats_pad(W_T, W_T));
+		for (int l = 1; l < NH; ++l) stage_layer_padded<W_T, W_T, GPP>(a.packed + s0 + (l - 1) * sh, lds + d0 + (l - 1) * dh);
+		stage_layer_padded<W_T, OUT_T, GPP>(a.packed + s0 + (NH - 1) * sh, lds + d0 + (NH - 1) * dh);
 		__syncthreads();
 	}
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -399,12 +403,12 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 	float *TGO = tiles;
 	float *TH1 = tiles + 32 * XG_T * kTS;                               // H_l at TH1 + (l - 1) * 32 * W_T * kTS
 	// packed layers: forward [0 | hidden ... | out], then the transposed ones in the same order
-	constexpr uint32_t f0 = X3 ? layer_x3_floats(IN_T, W_T) : layer_floats_pad(IN_T, W_T), fh = X3 ? layer_x3_floats(W_T, W_T) : layer_floats_pad(W_T, W_T);
-	constexpr uint32_t fo = X3 ? layer_x3_floats(W_T, OUT_T) : layer_floats_pad(W_T, OUT_T);
-	constexpr uint32_t fwd_total = f0 + (NH - 1) * fh + fo;
-	// the layers the dH chain reads: the x3 planes of the transposed layers behind the forward ones, or the forward layers themselves
-	constexpr uint32_t t0 = X3 ? layer_x3_floats(W_T, IN_T) : f0, th = fh;
-	const float *wf = lds, *wt = X3 ? lds + fwd_total : lds;
+	constexpr uint32_t f0 = X3 == 1 ? layer_x3_floats(IN_T, W_T) : X3 ? layer_x3_floats_pad(IN_T, W_T) : layer_floats_pad(IN_T, W_T);
+	constexpr uint32_t fh = X3 == 1 ? layer_x3_floats(W_T, W_T) : X3 ? layer_x3_floats_pad(W_T, W_T) : layer_floats_pad(W_T, W_T);
+	constexpr uint32_t fo = layer_x3_floats(W_T, OUT_T), fwd_total = f0 + (NH - 1) * fh + fo;      // (X3 == 1 only)
+	// the layers the dH chain reads: X3 == 1 the planes of the transposed layers behind the forward ones, else the forward layers themselves
+	constexpr uint32_t t0 = X3 == 1 ? layer_x3_floats(W_T, IN_T) : f0, th = fh;
+	const float *wf = lds, *wt = X3 == 1 ? lds + fwd_total : lds;
 
 	f16v dW0[W_T][IN_T], dWh[NH > 1 ? NH - 1 : 1][W_T][W_T], dWo[OUT_T][W_T];
 	float db0[W_T], dbh[NH > 1 ? NH - 1 : 1][W_T], dbo[OUT_T];
@@ -443,13 +447,13 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 			load_rows<OUT_T>(a.gy, a.gys, a.dims[NH + 1], row, valid, a.gy_vec != 0, lane, g_out);
 		}
 		// ---- forward, activations kept as [feature][sample] tiles ----
-		if constexpr (X3) dense_x3<IN_T, W_T, true>(wf, xin, hcur, a.hidden_act, lane);
+		if constexpr (X3) dense_x3<IN_T, W_T, true, PAD>(wf, xin, hcur, a.hidden_act, lane);
 		else dense<IN_T, W_T, true, true>(wf, xin, hcur, a.hidden_act, lane);
 		write_tile<W_T>(TH1, W_T, hcur, lane);
 #pragma unroll
 		for (int l = 1; l < NH; ++l) {
 			f16v hn[W_T];
-			if constexpr (X3) dense_x3<W_T, W_T, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
+			if constexpr (X3) dense_x3<W_T, W_T, true, PAD>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
 			else dense<W_T, W_T, true, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
@@ -458,7 +462,7 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 		if (FAST && !valid) zero_tiles<OUT_T>(g_out);                    // rows past n were clamped, not zeroed
 		if (a.out_act == NR3D_MLP_ACT_RELU) {
 			f16v yo[OUT_T];
-			if constexpr (X3) dense_x3<W_T, OUT_T, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
+			if constexpr (X3) dense_x3<W_T, OUT_T, true, PAD>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
 			else dense<W_T, OUT_T, true, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t)
@@ -557,10 +561,6 @@ static bool backward_ok(const Shape &s) {
 	return s.w_t == 1 ? nh <= 3 : nh <= 2;
 }
 
-static uint64_t transposed_floats(const Shape &s) {
-	return (uint64_t)layer_floats(s.w_t, s.in_t) + (uint64_t)(s.n_layers - 2) * layer_floats(s.w_t, s.w_t) + layer_floats(s.out_t, s.w_t);
-}
-
 // x3 planes of the transposed layers (round 6: the backward on the bf16 MFMA)
 static uint64_t x3t_floats(const Shape &s) {
 	return (uint64_t)layer_x3_floats(s.w_t, s.in_t) + (uint64_t)(s.n_layers - 2) * layer_x3_floats(s.w_t, s.w_t) + layer_x3_floats(s.out_t, s.w_t);
@@ -571,38 +571,54 @@ static uint64_t padded_floats(const Shape &s) {
 	return (uint64_t)layer_floats_pad(s.in_t, s.w_t) + (uint64_t)(s.n_layers - 2) * layer_floats_pad(s.w_t, s.w_t) + layer_floats_pad(s.w_t, s.out_t);
 }
 
+static uint64_t padded_x3_floats(const Shape &s) {
+	return (uint64_t)layer_x3_floats_pad(s.in_t, s.w_t) + (uint64_t)(s.n_layers - 2) * layer_x3_floats_pad(s.w_t, s.w_t) + layer_x3_floats_pad(s.w_t, s.out_t);
+}
+
 // per-wave [feature][sample] tiles: X, H_1 .. H_NH, G_out
 static uint32_t bwd_tile_floats(const Shape &s) { return (32u * (s.in_t > s.out_t ? s.in_t : s.out_t) + (s.n_layers - 1) * 32u * s.w_t) * (uint32_t)kTS; }
 
-static uint32_t bwd_waves(const Shape &s, bool x3 = false) {
-	if (x3 && x3_floats(s) == 0) return 0;
-	const uint64_t wbytes = (x3 ? x3_floats(s) + x3t_floats(s) : padded_floats(s)) * 4;
+// weights the backward keeps in LDS.  mode 0: one padded copy of the f32 forward layers; 1: the x3 planes of the forward AND of the
+// transposed layers as packed (every weight read a 16-byte read); 2: one padded copy of the forward layers' x3 planes
+static uint64_t bwd_weight_floats(const Shape &s, int mode) {
+	return mode == 1 ? x3_floats(s) + x3t_floats(s) : mode == 2 ? padded_x3_floats(s) : padded_floats(s);
+}
+
+static uint32_t bwd_waves(const Shape &s, int mode = 0) {
+	if (mode && x3_floats(s) == 0) return 0;
+	const uint64_t wbytes = bwd_weight_floats(s, mode) * 4;
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;     // one layer at a time
 	const uint32_t max_waves = (s.in_t == 1 && s.w_t == 1 && s.out_t == 1 && s.n_layers - 1 <= 2) ? 8u : 4u;      // = BwdCfg<...>::kMaxWaves
 	for (uint32_t nw = max_waves; nw >= 1; --nw) {
 		const uint64_t t = (uint64_t)nw * bwd_tile_floats(s) * 4;
-		// the whole 160 KB (the kernel has no static LDS): 32 -> 64 -> 64 -> 16 needs 149 KB for THREE waves (144 KB gave it two), the
-		// 64-wide input / output shapes 146 KB for two (they ran one wave per CU)
+		// the whole 160 KB (the kernel has no static LDS)
 		if (wbytes + (t > reduce ? t : reduce) <= (uint64_t)kMaxLdsBwd) return nw;
 	}
 	return 0;
 }
 
-// the x3 backward is taken for the shapes whose x3 planes (forward + transposed: 1.5 x the f32 bytes) still leave LDS for as many waves'
-// tiles as the f32 kernel runs.  Measured (tools/exp_mlp_x3_bwd.py, 2^22 samples, backward alone, x3 / f32 ms): 18->32->3 0.43 / 0.54,
-// 32->64->16 0.75 / 0.88, 32->32->16 0.44 / 0.43, 32->32->32->16 0.73 / 0.70 (same waves: equal or better) -- but 32->64->64->16
-// 2.63 / 2.36: there the planes cost one of three waves, and the kernel is not bound by its MFMAs (24.6 k of 33 k cycles per tile on
-// the f32 MFMA, 9.2 k of 24 k with the splits' VALU work added and nothing to overlap it with at one wave per SIMD), so it keeps the f32 MFMA.
-static bool backward_x3_fits(const Shape &s) {
-	const uint32_t w3 = bwd_waves(s, true), w1 = bwd_waves(s, false);
-	return w3 != 0 && w3 >= w1;
+// Which of the three the x3 option selects (without it: mode 0).  The kernel is not bound by its MFMAs -- 24.6 k of 33 k cycles per
+// tile of 32 -> 64 -> 64 -> 16 on the f32 MFMA, 9.2 k of 24 k on the bf16 MFMA, whose piece splitting is VALU work with nothing to overlap
+// it at one wave per SIMD -- so a wave lost to bigger weights costs more than the cheaper products bring, and the rule is "never fewer
+// waves than mode 0".  Measured at 2^22 samples, backward alone (tools/exp_mlp_x3_bwd.py, ms):
+//   mode 1 where it keeps mode 0's waves: 18->32->3 0.43 (mode 0: 0.51), 32->32->16 0.43 (0.43), 32->32->32->16 0.68 (0.69), 32->64->16 0.77 (0.88);
+//   mode 2 there is slower (0.44 / 0.52 / 0.89 / 0.86): its transposed reads are eight 2-byte LDS reads per operand where mode 1 has one;
+//   32->64->64->16: mode 1 has two waves (2.63), mode 2 four like mode 0: 1.63 against 1.77 -> mode 2, the one shape it is built for;
+//   64->64->64->64: mode 1 does not fit, mode 2 three waves 3.96, mode 0 four waves 3.66 -> mode 0 (32->64->64->64: 2.58 / 2.40).
+static int backward_mode(const Shape &s) {
+	const uint32_t w0 = bwd_waves(s, 0);
+	const uint32_t w1 = bwd_waves(s, 1);
+	if (w1 != 0 && w1 >= w0) return 1;
+	if (s.in_t == 1 && s.w_t == 2 && s.out_t == 1 && s.n_layers == 3) { const uint32_t w2 = bwd_waves(s, 2); if (w2 != 0 && w2 >= w0) return 2; }
+	return 0;
 }
 
-// [f32 transposed layers | x3 planes of the transposed layers (when the x3 backward fits)]
+// behind the forward part: [kBwdHeader floats (non-zero size = "the fused backward applies") | x3 planes of the transposed layers (mode 1)]
+constexpr uint32_t kBwdHeader = 4;
 extern "C" uint64_t nr3d_mlp_backward_packed_floats(const nr3d_mlp_desc_t *desc) {
 	Shape s;
 	if (!shape_of(desc, s) || nr3d_mlp_packed_floats(desc) == 0 || !backward_ok(s) || bwd_waves(s) == 0) return 0;
-	return transposed_floats(s) + (backward_x3_fits(s) ? x3t_floats(s) : 0);
+	return kBwdHeader + (backward_mode(s) == 1 ? x3t_floats(s) : 0);
 }
 
 extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *weights, const float *const *biases, float *packed,
@@ -624,23 +640,19 @@ extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *we
 	}
 	if (with_backward) {
 		// the layers of dH_{l} = W_l^T dPre_{l+1}: packed input tiles = the forward layer's output tiles and vice versa
-		PackArgs t = p;
-		t.transposed = 1;
-		uint32_t off = 0;
-		for (uint32_t l = 0; l < desc->n_layers; ++l) {
-			t.ni[l] = p.no[l]; t.no[l] = p.ni[l];
-			t.offset[l] = off;
-			off += layer_floats(t.ni[l], t.no[l]);
-		}
-		t.offset[desc->n_layers] = off;
-		hipLaunchKernelGGL(k_mlp_pack, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, t, packed + forward_floats(s));
-		if (backward_x3_fits(s)) {
-			PackArgs x = t;
+		// (only the bf16 MFMA backward with both orientations, backward_mode() 1, reads them: the other modes read the forward layers)
+		if (backward_mode(s) == 1) {
+			PackArgs x = p;
+			x.transposed = 1;
 			uint32_t o3 = 0;
-			for (uint32_t l = 0; l < desc->n_layers; ++l) { x.offset[l] = o3; o3 += layer_x3_floats(t.ni[l], t.no[l]); }
+			for (uint32_t l = 0; l < desc->n_layers; ++l) {
+				x.ni[l] = p.no[l]; x.no[l] = p.ni[l];
+				x.offset[l] = o3;
+				o3 += layer_x3_floats(x.ni[l], x.no[l]);
+			}
 			x.offset[desc->n_layers] = o3;
 			hipLaunchKernelGGL(k_mlp_pack_x3, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, x,
-			                   packed + forward_floats(s) + transposed_floats(s));
+			                   packed + forward_floats(s) + kBwdHeader);
 		}
 	}
 	NR3D_LAUNCH_CHECK();
@@ -740,16 +752,11 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	a.gx = dL_dx; a.gxs = gx_fm ? gx_feature_stride : gx_stride;
 	a.x_fm = x_fm ? 1u : 0u; a.gx_fm = gx_fm ? 1u : 0u;
 	// round 6: on the bf16 MFMA with three-piece splits (forward recomputation, dH chain, dW) when the option is on and the planes fit
-	const bool x3 = x3_enabled() && backward_x3_fits(s);
-	if (x3) {
-		a.packed = packed + packed_floats(s);
-		a.fwd_floats = (uint32_t)x3_floats(s);
-		a.total_floats = a.fwd_floats + (uint32_t)x3t_floats(s);
-		a.packed_t = packed + forward_floats(s) + transposed_floats(s);
-	} else {
-		a.fwd_floats = a.total_floats = (uint32_t)padded_floats(s);     // of the LDS copy; the kernel pads the packed forward layers itself
-		a.packed_t = nullptr;
-	}
+	const int mode = x3_enabled() ? backward_mode(s) : 0;
+	a.total_floats = (uint32_t)bwd_weight_floats(s, mode);               // of the LDS copy (modes 0 / 2: the kernel pads the packed layers itself)
+	a.fwd_floats = mode == 1 ? (uint32_t)x3_floats(s) : a.total_floats;
+	if (mode) a.packed = packed + packed_floats(s);                      // the x3 planes of the forward layers
+	a.packed_t = mode == 1 ? packed + forward_floats(s) + kBwdHeader : nullptr;
 	for (uint32_t l = 0; l < desc->n_layers; ++l) {
 		NR3D_CHECK(dL_dW[l] != nullptr, "mlp_backward: dL_dW[%u] is NULL", l);
 		a.dW[l] = dL_dW[l];
@@ -762,7 +769,7 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	a.gy_vec = ((uintptr_t)dL_dy % 16 == 0 && gy_stride % 4 == 0) ? 1u : 0u;
 	a.gx_vec = (dL_dx && (uintptr_t)dL_dx % 16 == 0 && gx_stride % 4 == 0) ? 1u : 0u;
 	a.tile_floats = bwd_tile_floats(s);
-	const uint32_t nw = bwd_waves(s, x3);
+	const uint32_t nw = bwd_waves(s, mode);
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;
 	const uint64_t tbytes = (uint64_t)nw * a.tile_floats * 4;
 	const size_t lds = (size_t)a.total_floats * 4 + (size_t)(tbytes > reduce ? tbytes : reduce);
@@ -778,7 +785,9 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	};
 	int rc = 0;
 #define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) { \
-		if (x3) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, true>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, true>) : launch(k_mlp_bwd<I, W, O, H, 0, true>); \
+		if (mode == 1) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, 1>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, 1>) : launch(k_mlp_bwd<I, W, O, H, 0, 1>); \
+		else if (mode == 2) { if constexpr (I == 1 && W == 2 && O == 1 && H == 2) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, 2>) : launch(k_mlp_bwd<I, W, O, H, 0, 2>); \
+		                      else rc = ::nr3d::fail("mlp_backward: no single-copy x3 kernel for this shape"); } \
 		else rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1>) : launch(k_mlp_bwd<I, W, O, H, 0>); } else
 	BWD_CASE(1, 1, 1, 1) BWD_CASE(1, 1, 1, 2) BWD_CASE(1, 1, 1, 3)
 	BWD_CASE(1, 2, 1, 1) BWD_CASE(1, 2, 1, 2) BWD_CASE(1, 2, 2, 1) BWD_CASE(1, 2, 2, 2)

@@ -30,6 +30,8 @@ __host__ __device__ constexpr uint32_t layer_floats(uint32_t ni, uint32_t no) { 
 // dense_t on different banks while every quarter wave of the forward's 16-byte reads stays contiguous
 constexpr int kGS = 264, kHS = 132;
 __host__ __device__ constexpr uint32_t layer_floats_pad(uint32_t ni, uint32_t no) { return no * ni * 4u * kGS + no * 32u; }
+// (the x3 planes have groups of the same size, 64 lanes x 8 bf16: six groups per tile pair)
+__host__ __device__ constexpr uint32_t layer_x3_floats_pad(uint32_t ni, uint32_t no) { return no * ni * 6u * kGS + no * 32u; }
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -159,13 +161,14 @@ __device__ __forceinline__ void dense_t(const float *__restrict__ wp, const f16v
 }
 
 // one packed layer -> its padded LDS copy (all threads of the workgroup; the caller synchronises)
-template <int NI, int NO>
+// (GPP = groups per tile pair: 4 for the f32 layout, 6 for the x3 planes)
+template <int NI, int NO, int GPP = 4>
 __device__ __forceinline__ void stage_layer_padded(const float *__restrict__ src, float *__restrict__ dst) {
 	const f4v *s4 = reinterpret_cast<const f4v *>(src);
 	f4v *d4 = reinterpret_cast<f4v *>(dst);
-	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * NI * 256); i += blockDim.x)
+	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * NI * GPP * 64); i += blockDim.x)
 		d4[(i >> 6) * (kGS / 4) + ((i >> 5) & 1u) * (kHS / 4) + (i & 31u)] = s4[i];
-	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * 32); i += blockDim.x) dst[NO * NI * 4 * kGS + i] = src[NO * NI * 1024 + i];
+	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * 32); i += blockDim.x) dst[NO * NI * GPP * kGS + i] = src[NO * NI * GPP * 256 + i];
 }
 
 // the three bf16 pieces of registers 8 s .. 8 s + 7 of a register-map tile (a K = 16 step's B operand)
@@ -185,12 +188,13 @@ __device__ __forceinline__ void split3(const f16v &v, int s, bf8 (&p)[3]) {
 }
 
 // one dense layer in fp32 on the bf16 MFMA; wp -> LDS copy of the layer's x3 planes (+ bias)
-template <int NI, int NO, bool BIAS>
+template <int NI, int NO, bool BIAS, bool PAD = false>
 __device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
-	const float *bias = wp + NO * NI * 1536;
+	const float *bias = wp + NO * NI * (PAD ? 6 * kGS : 1536);
 	const int h = lane >> 5;
-	constexpr int PLANE = NO * NI * 2 * 64;             // bf8 units per plane
-	const bf8 *wv = reinterpret_cast<const bf8 *>(wp) + lane;
+	constexpr int GU = PAD ? kGS / 4 : 64;              // bf8 units per group
+	constexpr int PLANE = NO * NI * 2 * GU;             // bf8 units per plane
+	const bf8 *wv = reinterpret_cast<const bf8 *>(wp) + (PAD ? h * (kHS / 4) + (lane & 31) : lane);
 	constexpr bool SPLIT = (NO == 1);                  // one out tile: the small terms go to a second accumulator (no dependent MFMA chain)
 	const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 	f16v alt = zero;
@@ -215,7 +219,7 @@ __device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16
 #pragma unroll
 			for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-				for (int ot = 0; ot < NO; ++ot) w[pl][ot] = wv[pl * PLANE + ((ot * NI + it) * 2 + s) * 64];
+				for (int ot = 0; ot < NO; ++ot) w[pl][ot] = wv[pl * PLANE + ((ot * NI + it) * 2 + s) * GU];
 #pragma unroll
 			for (int t = 0; t < 6; ++t) {
 				if constexpr (SPLIT) {
@@ -236,6 +240,56 @@ __device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16
 		for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
 			for (int j = 0; j < 16; ++j) out[ot][j] = fmaxf(out[ot][j], 0.0f);
+	}
+}
+
+// out = W^T in on the bf16 MFMA from the PADDED x3 planes of the forward layer W (dense_t's counterpart: NI tiles of W's outputs come in,
+// NO tiles of W's inputs go out).  Element e = 0 .. 7 of lane (r, h) of the A operand of K = 16 step (it, s) is
+// W_pl[32 it + o][32 ot + r] with o = 16 s + 8 (e >> 2) + 4 h + (e & 3) (the register map's rows), which the planes keep at group
+// (it * NO + ot) * 2 + (r >> 4), half-wave (r >> 2) & 1, lane o, element 4 ((r >> 3) & 1) + (r & 3): eight 2-byte reads
+// (ds_read_u16_d16 / _d16_hi fill the halves of four registers).  The padding puts the half-wave's reads on 16 different banks, two
+// lanes per 4-byte word.  Same piece products in the same order as dense_x3.
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+template <int NI, int NO>
+__device__ __forceinline__ void dense_x3_t(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int lane) {
+	const int r = lane & 31, h = lane >> 5;
+	constexpr int PLANE = NO * NI * 2 * kGS * 2;       // 2-byte units per plane
+	const unsigned short *wl = reinterpret_cast<const unsigned short *>(wp) + (r >> 4) * (kGS * 2) + ((r >> 2) & 1) * (kHS * 2) + 32 * h + 4 * ((r >> 3) & 1) + (r & 3);
+	constexpr bool SPLIT = (NO == 1);
+	const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+	f16v alt = zero;
+#pragma unroll
+	for (int ot = 0; ot < NO; ++ot) out[ot] = zero;
+	constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+	for (int it = 0; it < NI; ++it)
+#pragma unroll
+		for (int s = 0; s < 2; ++s) {
+			bf8 xs[3];
+			split3(in[it], s, xs);
+			bf8 w[3][NO];
+#pragma unroll
+			for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+				for (int ot = 0; ot < NO; ++ot) {
+					const unsigned short *p = wl + pl * PLANE + (it * NO + ot) * 2 * (kGS * 2) + 128 * s;
+					const us8 v = {p[0], p[8], p[16], p[24], p[64], p[72], p[80], p[88]};
+					w[pl][ot] = __builtin_bit_cast(bf8, v);
+				}
+#pragma unroll
+			for (int t = 0; t < 6; ++t) {
+				if constexpr (SPLIT) {
+					if (t < 5) alt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], xs[PX[t]], alt, 0, 0, 0);
+					else out[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][0], xs[PX[t]], out[0], 0, 0, 0);
+				} else {
+#pragma unroll
+					for (int ot = 0; ot < NO; ++ot) out[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PW[t]][ot], xs[PX[t]], out[ot], 0, 0, 0);
+				}
+			}
+		}
+	if constexpr (SPLIT) {
+#pragma unroll
+		for (int j = 0; j < 16; ++j) out[0][j] += alt[j];
 	}
 }
 

@@ -1,4 +1,5 @@
-"""tools/exp_mlp_x3_bwd.py -- fp32 decoder forward / forward+backward with the bf16 x3 route on and off (run on the GPU box)."""
+"""tools/exp_mlp_x3_bwd.py -- fp32 decoder forward / forward+backward with the bf16 x3 route on and off (run on the GPU box).
+mlp_x3 = 1: csrc/mlp.hip backward_mode() picks the backward's weight copy (1 / 2: bf16 MFMA, 0: f32 MFMA); 0: f32 MFMA throughout."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,24 +20,28 @@ def timed(fn, iters=20):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-for dims in ((32, 64, 64, 16), (32, 32, 16), (18, 32, 3), (32, 32, 32, 16), (32, 64, 16), (64, 64, 64, 64)):
-    torch.manual_seed(0)
-    net = MLP(dims[0], dims[-1], D=len(dims) - 2, W=dims[1], dtype=torch.float, device=dev)
+for dims in ((32, 64, 64, 16), (32, 32, 16), (18, 32, 3), (32, 32, 32, 16), (32, 64, 16), (64, 64, 64, 64), (64, 64, 64), (32, 64, 64, 64)):
     x = torch.randn(n, dims[0], device=dev)
     gy = torch.randn(n, dims[-1], device=dev)
-
-    def fwd():
-        with torch.no_grad():
-            return net(x)
-
-    def fwd_bwd():
-        xr = x.detach().requires_grad_(True)
-        net.zero_grad(set_to_none=True)
-        net(xr).backward(gy)
-    row = {}
+    row, grads = {}, {}
     for x3 in (1, 0):
         H.set_option("mlp_x3", x3)
+        torch.manual_seed(0)
+        net = MLP(dims[0], dims[-1], D=len(dims) - 2, W=dims[1], dtype=torch.float, device=dev)
+
+        def fwd():
+            with torch.no_grad():
+                return net(x)
+
+        def fwd_bwd():
+            xr = x.detach().requires_grad_(True)
+            net.zero_grad(set_to_none=True)
+            net(xr).backward(gy)
+            return xr.grad
         f, fb = timed(fwd), timed(fwd_bwd)
         row[x3] = (round(f, 3), round(fb, 3), round(fb - f, 3))
+        gx = fwd_bwd()
+        grads[x3] = [gx] + [p.grad.clone() for p in net.parameters()]
     H.set_option("mlp_x3", -1)
-    print(dims, "x3 (fwd, fwd+bwd, bwd):", row[1], " f32:", row[0])
+    err = max(float((a - b).norm() / b.norm()) for a, b in zip(grads[1], grads[0]))      # (ReLU masks of |pre-activation| < 1 ulp may differ)
+    print(dims, "x3 (fwd, fwd+bwd, bwd):", row[1], " f32:", row[0], " max relative L2 difference of the gradients %.1e" % err, flush=True)
