@@ -370,6 +370,9 @@ template <int IN_T, int W_T, int OUT_T, int NH, int FAST, int X3 = 0>
 __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	constexpr bool PAD = X3 != 1;
+	// the next tile's rows are requested at the top of a tile -- or, with 64-wide inputs or outputs, before its last step: their
+	// 48 - 64 registers then overlap one layer's work instead of five (k_mlp_bwd<2,2,2,2>: 183 -> 139 / 220 -> 187 spilled dwords)
+	constexpr bool LATE = IN_T + OUT_T >= 3;
 	if constexpr (X3 == 1) {
 		// both orientations of the x3 planes, as packed: every weight read is a 16-byte read
 		const f4v *src = reinterpret_cast<const f4v *>(a.packed), *src_t = reinterpret_cast<const f4v *>(a.packed_t);
@@ -438,9 +441,11 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 			for (int t = 0; t < IN_T; ++t) xin[t] = xnext[t];
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t) g_out[t] = gnext[t];
-			const uint64_t rn = clamp_row((tile + step) * 32 + r);
-			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
-			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
+			if constexpr (!LATE) {
+				const uint64_t rn = clamp_row((tile + step) * 32 + r);
+				prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
+				load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
+			}
 		} else {
 			if (a.x_fm) load_cols_fast<IN_T>(a.x, a.xs, a.dims[0], clamp_row(row), lane, xin);   // rows past n: dL/dy is zero there
 			else load_rows<IN_T>(a.x, a.xs, a.dims[0], row, valid, a.x_vec != 0, lane, xin);
@@ -484,6 +489,11 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 			else bwd_layer<W_T, W_T, true, false, X3>(g, TG, TB, wt + t0 + (l - 1) * th, dWh[l - 1], dbh[l - 1], gp, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) g[t] = gp[t];
+		}
+		if constexpr (FAST && LATE) {
+			const uint64_t rn = clamp_row((tile + step) * 32 + r);
+			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
+			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
 		}
 		f16v gx[IN_T];
 		if (a.gx) {
@@ -608,7 +618,7 @@ static uint32_t bwd_waves(const Shape &s, int mode = 0) {
 static int backward_mode(const Shape &s) {
 	const uint32_t w0 = bwd_waves(s, 0);
 	const uint32_t w1 = bwd_waves(s, 1);
-	if (w1 != 0 && w1 >= w0) return 1;
+	if ((s.w_t == 1 || s.n_layers == 2) && w1 != 0 && w1 >= w0) return 1;              // (the shapes k_mlp_bwd<..., 1> is built for: BWD_CASE)
 	if (s.in_t == 1 && s.w_t == 2 && s.out_t == 1 && s.n_layers == 3) { const uint32_t w2 = bwd_waves(s, 2); if (w2 != 0 && w2 >= w0) return 2; }
 	return 0;
 }
@@ -785,7 +795,8 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	};
 	int rc = 0;
 #define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) { \
-		if (mode == 1) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, 1>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, 1>) : launch(k_mlp_bwd<I, W, O, H, 0, 1>); \
+		if (mode == 1) { if constexpr (W == 1 || H == 1) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, 1>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, 1>) : launch(k_mlp_bwd<I, W, O, H, 0, 1>); \
+		                 else rc = ::nr3d::fail("mlp_backward: no two-orientation x3 kernel for this shape"); } \
 		else if (mode == 2) { if constexpr (I == 1 && W == 2 && O == 1 && H == 2) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, 2>) : launch(k_mlp_bwd<I, W, O, H, 0, 2>); \
 		                      else rc = ::nr3d::fail("mlp_backward: no single-copy x3 kernel for this shape"); } \
 		else rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1>) : launch(k_mlp_bwd<I, W, O, H, 0>); } else
