@@ -370,9 +370,9 @@ template <int IN_T, int W_T, int OUT_T, int NH, int FAST, int X3 = 0>
 __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
 	constexpr bool PAD = X3 != 1;
-	// the next tile's rows are requested at the top of a tile -- or, with 64-wide inputs or outputs, before its last step: their
-	// 48 - 64 registers then overlap one layer's work instead of five (k_mlp_bwd<2,2,2,2>: 183 -> 139 / 220 -> 187 spilled dwords)
-	constexpr bool LATE = IN_T + OUT_T >= 3;
+	// FAST: the next tile's rows are requested before a tile's LAST step, not at its top: their 32 - 64 registers then overlap one
+	// layer's work instead of five (k_mlp_bwd<2,2,2,2>: 183 -> 139 / 220 -> 187 spilled dwords, 64 -> 64 -> 64 -> 64 4.38 -> 3.86 ms), and
+	// one step still covers the latency (every measured shape equal or faster, 32 -> 32 -> 32 -> 16 0.66 -> 0.62 ms)
 	if constexpr (X3 == 1) {
 		// both orientations of the x3 planes, as packed: every weight read is a 16-byte read
 		const f4v *src = reinterpret_cast<const f4v *>(a.packed), *src_t = reinterpret_cast<const f4v *>(a.packed_t);
@@ -441,11 +441,6 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 			for (int t = 0; t < IN_T; ++t) xin[t] = xnext[t];
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t) g_out[t] = gnext[t];
-			if constexpr (!LATE) {
-				const uint64_t rn = clamp_row((tile + step) * 32 + r);
-				prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
-				load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
-			}
 		} else {
 			if (a.x_fm) load_cols_fast<IN_T>(a.x, a.xs, a.dims[0], clamp_row(row), lane, xin);   // rows past n: dL/dy is zero there
 			else load_rows<IN_T>(a.x, a.xs, a.dims[0], row, valid, a.x_vec != 0, lane, xin);
@@ -490,7 +485,7 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) g[t] = gp[t];
 		}
-		if constexpr (FAST && LATE) {
+		if constexpr (FAST != 0) {                                       // the next tile's rows (see above)
 			const uint64_t rn = clamp_row((tile + step) * 32 + r);
 			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
 			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
