@@ -30,3 +30,30 @@ def test_mlp_matches_a_hand_written_stack():
     assert nb.layers[0].bias is None and nb.layers[1].bias is not None
     eq = MLP(6, 2, D=1, W=4, equal_lr=True, dtype=torch.float)
     assert abs(eq.layers[0].weight_gain - 1 / 6 ** 0.5) < 1e-12 and tuple(eq(x).shape) == (5, 7, 2)
+
+
+def test_packed_sizes_of_the_fused_decoder():
+    """host logic of csrc/mlp.hip, no kernel runs: the packed buffer is [f32 layers | their bf16 x3 planes when they fit LDS], the
+    backward adds a 4-float header (non-zero = "the fused backward applies") and, only for the small shapes whose backward keeps the
+    planes in BOTH orientations in LDS (backward_mode() 1), the planes of the transposed layers; 0 outside the fused backward's range"""
+    from nr3d_lib_amd.bindings import _mlp
+
+    def layer(ni, no):                    # tiles of 32
+        return no * ni * 1024 + no * 32, no * ni * 1536 + no * 32
+
+    def tiles(d):
+        return (d + 31) // 32
+    for dims, both in (((32, 64, 64, 16), False), ((32, 32, 16), True), ((18, 32, 3), True), ((32, 32, 32, 16), True), ((32, 64, 16), True),
+                       ((64, 64, 64, 64), False), ((64, 64, 64), False), ((32, 64, 64, 64), False), ((32, 64, 64), True), ((64, 64, 16), True)):
+        d = _mlp.MLPDesc(list(dims), 1, 0)
+        t = [tiles(v) for v in dims]
+        f32 = sum(layer(a, b)[0] for a, b in zip(t[:-1], t[1:]))
+        x3 = sum(layer(a, b)[1] for a, b in zip(t[:-1], t[1:]))
+        assert d.packed_floats == f32 + x3, dims
+        x3t = sum(layer(b, a)[1] for a, b in zip(t[:-1], t[1:]))
+        assert d.backward_floats == 4 + (x3t if both else 0), (dims, d.backward_floats)
+        assert d.backward_fusable
+    # hidden width above 64, three hidden layers wider than 32, output wider than the hidden layers: forward only
+    for dims in ((32, 128, 128, 16), (32, 64, 64, 64, 16), (32, 32, 64)):
+        d = _mlp.MLPDesc(list(dims), 1, 0)
+        assert d.packed_floats > 0 and d.backward_floats == 0 and not d.backward_fusable, dims
