@@ -41,7 +41,14 @@ __host__ __device__ constexpr uint32_t layer_x3_floats(uint32_t ni, uint32_t no)
 // ---------------------------------------------------------------------------------------------
 // one dense layer on the register map; wp -> LDS copy of the packed layer
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float activate(float v, int act) { return act == NR3D_MLP_ACT_RELU ? fmaxf(v, 0.0f) : v; }
+// ReLU as ONE instruction, a signed integer maximum on the bits (v_max_i32: negative floats, -0 included, are negative integers).
+// fmaxf(v, 0) costs two -- the compiler canonicalises the MFMA result first (a v_max_f32 v, v, v in front of the v_max_f32 0, v).
+// Same values for every non-NaN input; a NaN with a clear sign bit stays NaN, as torch.relu keeps it (fmaxf returned 0).
+__device__ __forceinline__ float relu(float v) {
+	const int b = __builtin_bit_cast(int, v);
+	return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+__device__ __forceinline__ float activate(float v, int act) { return act == NR3D_MLP_ACT_RELU ? relu(v) : v; }
 
 // Scheduling of the MFMA stream (measured rules, MI355X_MICROARCH.md): an instruction issued between two MFMAs on the
 // SAME accumulator costs ~43 cycles (a cliff), between MFMAs on DIFFERENT accumulators ~6.  So consecutive MFMAs
@@ -239,7 +246,7 @@ __device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16
 #pragma unroll
 		for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
-			for (int j = 0; j < 16; ++j) out[ot][j] = fmaxf(out[ot][j], 0.0f);
+			for (int j = 0; j < 16; ++j) out[ot][j] = relu(out[ot][j]);
 	}
 }
 

@@ -108,7 +108,14 @@ __global__ __launch_bounds__(256) void k_mlph_pack(PackArgs a, unsigned char *__
 // ---------------------------------------------------------------------------------------------
 // one dense layer: in = B operands (two K = 16 steps per 32-feature tile), out = fp32 accumulators on the C/D map
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float activate(float v, int act) { return act == NR3D_MLP_ACT_RELU ? fmaxf(v, 0.0f) : v; }
+// ReLU as ONE instruction, a signed integer maximum on the bits (v_max_i32: negative floats, -0 included, are negative integers).
+// fmaxf(v, 0) costs two -- the compiler canonicalises the MFMA result first (a v_max_f32 v, v, v in front of the v_max_f32 0, v).
+// Same values for every non-NaN input; a NaN with a clear sign bit stays NaN, as torch.relu keeps it (fmaxf returned 0).
+__device__ __forceinline__ float relu(float v) {
+	const int b = __builtin_bit_cast(int, v);
+	return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+__device__ __forceinline__ float activate(float v, int act) { return act == NR3D_MLP_ACT_RELU ? relu(v) : v; }
 
 template <int NI, int NO, bool BIAS>
 __device__ __forceinline__ void dense(const unsigned char *__restrict__ wp, const h8 (&in)[NI][2], f16v (&out)[NO], int act, int lane) {
@@ -155,7 +162,7 @@ __device__ __forceinline__ void dense(const unsigned char *__restrict__ wp, cons
 #pragma unroll
 		for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
-			for (int j = 0; j < 16; ++j) out[ot][j] = fmaxf(out[ot][j], 0.0f);
+			for (int j = 0; j < 16; ++j) out[ot][j] = relu(out[ot][j]);
 	}
 }
 
@@ -358,20 +365,47 @@ __global__ __launch_bounds__(kThreads) void k_mlph_fwd(FwdArgs a) {
 // =============================================================================================
 // backward
 // =============================================================================================
-constexpr int kTSH = 40;                       // row stride (halfs) of the per-wave [feature][sample] tiles: 80 B = 16-byte aligned rows
+constexpr int kTSH = 40;                       // halfs per feature a wave's tile area is sized with (32 samples + slack: bwd_tile_halfs)
 
-// operand form (16 values per lane and 32-feature tile) -> [feature][sample] tile
+// The per-wave tiles that turn "sample in the lane index" into "sample in the K index" (round 6, second form).  They were
+// [feature][sample] arrays written with one 2-byte store per value and read with one 16-byte read per MFMA operand -- and the backward
+// was bound by LDS INSTRUCTIONS (profiles/r06_mlp_half_counters.txt: SQ_ACTIVE_INST_LDS over a CU's eight waves = 82-87 % of the
+// kernel's cycles, two thirds of the instructions those stores).  Now [sample][feature]: a lane owns its sample's row and its operand
+// registers hold runs of four consecutive features, so a 32-feature block goes out as FOUR 8-byte stores instead of sixteen 2-byte
+// ones, and the operand comes back through gfx950's transposing read (ds_read_b64_tr_b16: the 16 lanes of a group hand in the
+// addresses of a 4-sample x 16-feature block, four 8-byte pieces per sample, and lane c gets feature c of the four samples) -- two
+// reads per operand.  Row strides 72 / 152 bytes (one / two 32-feature blocks per row): the four rows of a transposing read fall on
+// disjoint banks and the half-wave's 8-byte stores on 16 different bank pairs.  The area per tile stays inside the old 80 bytes per
+// feature, so the tile offsets and the host's LDS sizing did not change.
+template <int NT> struct TileRow { static_assert(NT == 1 || NT == 2, "tiles of one or two 32-feature blocks"); static constexpr int kHalfs = NT == 1 ? 36 : 76; };
+typedef short s4v __attribute__((ext_vector_type(4)));
+
+// operand form (16 values per lane and 32-feature block) -> [sample][feature] tile
 template <int NT>
 __device__ __forceinline__ void write_tile(_Float16 *__restrict__ T, const h8 (&r)[NT][2], int lane) {
 	const int s = lane & 31, h = lane >> 5;
+	_Float16 *row = T + s * TileRow<NT>::kHalfs + 4 * h;
 #pragma unroll
 	for (int t = 0; t < NT; ++t)
 #pragma unroll
-		for (int j = 0; j < 16; ++j) T[(32 * t + 8 * (j >> 2) + 4 * h + (j & 3)) * kTSH + s] = r[t][j >> 3][j & 7];
+		for (int st = 0; st < 2; ++st) {                   // values 8 st + e <-> features 32 t + 16 st + 8 (e >> 2) + 4 h + (e & 3)
+			const h8 v = r[t][st];
+			const h4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+			*reinterpret_cast<h4 *>(row + 32 * t + 16 * st) = lo;
+			*reinterpret_cast<h4 *>(row + 32 * t + 16 * st + 8) = hi;
+		}
 }
-// samples 16 st + 8 h .. + 7 of feature row `row`: one MFMA operand of the sample contraction
-__device__ __forceinline__ h8 read_op(const _Float16 *__restrict__ T, int row, int st, int h) {
-	return *reinterpret_cast<const h8 *>(T + row * kTSH + 16 * st + 8 * h);
+// one MFMA operand of the sample contraction: lane (r = lane & 31, h = lane >> 5) gets feature 32 t + r of samples 16 st + 8 h .. + 7
+template <int NT>
+__device__ __forceinline__ h8 read_op(const _Float16 *__restrict__ T, int t, int st, int lane) {
+	const int c = lane & 15, fb = lane & 16, h = lane >> 5;
+	const _Float16 *p = T + (16 * st + 8 * h + (c >> 2)) * TileRow<NT>::kHalfs + 32 * t + fb + 4 * (c & 3);
+	typedef s4v __attribute__((address_space(3))) *lds_s4;
+	const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)p);
+	const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p + 4 * TileRow<NT>::kHalfs));
+	const h4 l4 = __builtin_bit_cast(h4, lo), h4_ = __builtin_bit_cast(h4, hi);
+	const h8 v = {l4[0], l4[1], l4[2], l4[3], h4_[0], h4_[1], h4_[2], h4_[3]};
+	return v;
 }
 
 struct BwdArgs {
@@ -409,12 +443,12 @@ __device__ __forceinline__ void bwd_layer(const h8 (&g)[NO][2], _Float16 *__rest
 #pragma unroll
 	for (int it = 0; it < NI; ++it)
 #pragma unroll
-		for (int st = 0; st < 2; ++st) bv[it][st] = read_op(TB, 32 * it + r, st, h);
+		for (int st = 0; st < 2; ++st) bv[it][st] = read_op<NI>(TB, it, st, lane);
 #pragma unroll
 	for (int ot = 0; ot < NO; ++ot)
 #pragma unroll
 		for (int st = 0; st < 2; ++st) {
-			const h8 av = read_op(TG, 32 * ot + r, st, h);
+			const h8 av = read_op<NO>(TG, ot, st, lane);
 			db[ot] = sum8(av, db[ot]);
 #pragma unroll
 			for (int it = 0; it < NI; ++it) dW[ot][it] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv[it][st], dW[ot][it], 0, 0, 0);
@@ -533,9 +567,6 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T>::kMaxWaves * 64)) void k_
 			for (int t = 0; t < IN_T; ++t) { xin[t][0] = xnext[t][0]; xin[t][1] = xnext[t][1]; }
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t) { g_out[t][0] = gnext[t][0]; g_out[t][1] = gnext[t][1]; }
-			const uint64_t rn = clamp_row((tile + step) * 32 + r);
-			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
-			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
 			if (!valid) {                                                   // rows past n were clamped, not zeroed
 #pragma unroll
 				for (int t = 0; t < OUT_T; ++t) { g_out[t][0] = hzero; g_out[t][1] = hzero; }
@@ -596,6 +627,11 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T>::kMaxWaves * 64)) void k_
 			for (int t = 0; t < W_T; ++t) g[t] = gp[t];
 			}
 		to_operand<W_T>(g, gop);
+		if constexpr (FAST != 0) {                                       // the next tile's rows, requested before this tile's last step (as csrc/mlp.hip)
+			const uint64_t rn = clamp_row((tile + step) * 32 + r);
+			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
+			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
+		}
 		f16v gx[IN_T];
 		if (a.gx) {
 			bwd_layer<W_T, IN_T, true, false, BITS>(gop, TH1, TX, wt, dW0, db0, gx, xin, 0u, lane);
@@ -648,8 +684,8 @@ __device__ __forceinline__ void dw_round(const _Float16 *__restrict__ tiles0, ui
 	for (int k = 0; k < 2 * S::NB; ++k) {
 		const int p = S::G * k + sub, st = p / NW, t = p % NW;
 		const _Float16 *T = tiles0 + (size_t)t * tile_halfs;
-		av[k] = read_op(T + TG_off, 32 * ot + r, st, h);
-		bv[k] = read_op(T + TB_off, 32 * it + r, st, h);
+		av[k] = read_op<NO>(T + TG_off, ot, st, lane);
+		bv[k] = read_op<NI>(T + TB_off, it, st, lane);
 	}
 	float sum = 0.0f;
 #pragma unroll
@@ -733,6 +769,9 @@ __global__ __launch_bounds__(NW * 64) void k_mlph_bwd_split(BwdArgs a) {
 	}
 	const h8 hzero = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
 	const bool relu = a.hidden_act == NR3D_MLP_ACT_RELU;
+	// the next round's rows are requested at the top of a round, or before its last layer where that measured faster (same-box A/B at
+	// 2^22 samples, fwd+bwd ms: 32 -> 64 -> 64 -> 16 0.624 -> 0.591; 32 -> 64 -> 16 0.326 -> 0.340 and 64 -> 64 -> 64 -> 64 1.156 -> 1.206 the other way)
+	constexpr bool kLate = NH == 2 && IN_T == 1 && OUT_T == 1;
 	for (uint64_t round = 0; round < n_rounds; ++round) {
 		const uint64_t tile = round * per_round + (uint64_t)blockIdx.x * NW + wave;
 		const uint64_t row = tile * 32 + r;
@@ -748,9 +787,11 @@ __global__ __launch_bounds__(NW * 64) void k_mlph_bwd_split(BwdArgs a) {
 			for (int t = 0; t < IN_T; ++t) { xin[t][0] = xnext[t][0]; xin[t][1] = xnext[t][1]; }
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t) { g_out[t][0] = gnext[t][0]; g_out[t][1] = gnext[t][1]; }
-			const uint64_t rn = clamp_row((tile + per_round) * 32 + r);
-			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
-			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
+			if constexpr (!kLate) {
+				const uint64_t rn = clamp_row((tile + per_round) * 32 + r);
+				prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
+				load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
+			}
 			if (!valid) {
 #pragma unroll
 				for (int t = 0; t < OUT_T; ++t) { g_out[t][0] = hzero; g_out[t][1] = hzero; }
@@ -805,6 +846,11 @@ __global__ __launch_bounds__(NW * 64) void k_mlph_bwd_split(BwdArgs a) {
 			__syncthreads();
 		}
 		// ---- first layer ----
+		if constexpr (FAST != 0 && kLate) {                              // the next round's rows
+			const uint64_t rn = clamp_row((tile + per_round) * 32 + r);
+			prefetch_x<FAST, IN_T>(a.x, a.xs, a.dims[0], rn, lane, xnext);
+			load_rows_fast<OUT_T>(a.gy, a.gys, a.dims[NH + 1], rn, lane, gnext);
+		}
 		write_tile<W_T>(mine + oH1, gop, lane);
 		__syncthreads();
 		dw_round<W_T, IN_T, NW>(tiles0, a.tile_halfs, oH1, oX, dW0, db0, wave, lane);
