@@ -453,8 +453,8 @@ typedef struct nr3d_mlp_desc {
 } nr3d_mlp_desc_t;
 
 uint64_t nr3d_mlp_packed_floats(const nr3d_mlp_desc_t *desc);
-/* extra floats of the packed buffer that nr3d_mlp_backward needs (a 4-float header, plus the bf16 planes of the transposed
- * layers for the small shapes whose backward keeps both orientations in LDS), or 0 when the fused backward does not apply (hidden width > 64, more than 2 hidden layers wider than 32 / 3 narrower ones, input or output wider
+/* extra floats of the packed buffer that nr3d_mlp_backward needs (a 4-float header: the backward reads the forward layers), or 0
+ * when the fused backward does not apply (hidden width > 64, more than 2 hidden layers wider than 32 / 3 narrower ones, input or output wider
  * than the hidden layers): the caller then differentiates its unfused path. */
 uint64_t nr3d_mlp_backward_packed_floats(const nr3d_mlp_desc_t *desc);
 /* packed: nr3d_mlp_packed_floats (+ nr3d_mlp_backward_packed_floats when with_backward != 0) floats */

@@ -67,7 +67,7 @@ static bool x3_enabled() { return opt::on(NR3D_OPT_MLP_X3); }
 
 // ---------------------------------------------------------------------------------------------
 // packing: for layer l, packed[(((ot*NI + it)*4 + a)*64 + lane)*4 + b] = W[32 ot + (lane & 31)][32 it + 8a + 4(lane >> 5) + b]
-// (the x3 planes of the transposed layers, backward_mode() 1, are packed from the same W with the roles of the two indices swapped)
+// (no transposed layers are packed: the backward reads these transposed, mlp_device.h dense_t / dense_x3_t)
 // ---------------------------------------------------------------------------------------------
 struct PackArgs {
 	const float *w[NR3D_MLP_MAX_LAYERS];
@@ -76,7 +76,6 @@ struct PackArgs {
 	uint32_t ni[NR3D_MLP_MAX_LAYERS], no[NR3D_MLP_MAX_LAYERS];            // tiles of the packed layer's input / output
 	uint32_t offset[NR3D_MLP_MAX_LAYERS + 1];                             // first float of every packed layer
 	uint32_t n_layers;
-	uint32_t transposed;                                                  // pack W^T (no bias): the dH = W^T dY layers
 };
 
 __global__ __launch_bounds__(256) void k_mlp_pack(PackArgs a, float *__restrict__ packed) {
@@ -89,9 +88,8 @@ __global__ __launch_bounds__(256) void k_mlp_pack(PackArgs a, float *__restrict_
 			const uint32_t b = e & 3u, lane = (e >> 2) & 63u, q = (e >> 8) & 3u, tile = e >> 10;
 			const uint32_t it = tile % a.ni[l], ot = tile / a.ni[l];
 			const uint32_t o = 32u * ot + (lane & 31u), f = 32u * it + 8u * q + 4u * (lane >> 5) + b;
-			if (!a.transposed) { if (o < a.out_dim[l] && f < a.in_dim[l]) v = a.w[l][(size_t)o * a.in_dim[l] + f]; }
-			else { if (o < a.in_dim[l] && f < a.out_dim[l]) v = a.w[l][(size_t)f * a.in_dim[l] + o]; }
-		} else if (!a.transposed && a.b[l]) {
+			if (o < a.out_dim[l] && f < a.in_dim[l]) v = a.w[l][(size_t)o * a.in_dim[l] + f];
+		} else if (a.b[l]) {
 			const uint32_t o = e - nw;
 			if (o < a.out_dim[l]) v = a.b[l][o];
 		}
@@ -111,8 +109,7 @@ __global__ __launch_bounds__(256) void k_mlp_pack_x3(PackArgs a, float *__restri
 			const uint32_t it = tile % a.ni[l], ot = tile / a.ni[l];
 			const uint32_t o = 32u * ot + (lane & 31u), f = 32u * it + 8u * (2u * st + (el >> 2)) + 4u * (lane >> 5) + (el & 3u);
 			float v = 0.0f;
-			if (!a.transposed) { if (o < a.out_dim[l] && f < a.in_dim[l]) v = a.w[l][(size_t)o * a.in_dim[l] + f]; }
-			else { if (o < a.in_dim[l] && f < a.out_dim[l]) v = a.w[l][(size_t)f * a.in_dim[l] + o]; }      // W^T (the dH = W^T dPre layers)
+			if (o < a.out_dim[l] && f < a.in_dim[l]) v = a.w[l][(size_t)o * a.in_dim[l] + f];
 			const __bf16 p1 = (__bf16)v;
 			const float r1 = v - (float)p1;
 			const __bf16 p2 = (__bf16)r1;
@@ -120,7 +117,7 @@ __global__ __launch_bounds__(256) void k_mlp_pack_x3(PackArgs a, float *__restri
 			wdst[e] = p1; wdst[nw + e] = p2; wdst[2u * nw + e] = p3;
 		} else {
 			const uint32_t o = e - nw;
-			bdst[o] = (!a.transposed && a.b[l] && o < a.out_dim[l]) ? a.b[l][o] : 0.0f;
+			bdst[o] = (a.b[l] && o < a.out_dim[l]) ? a.b[l][o] : 0.0f;
 		}
 	}
 }
@@ -218,8 +215,8 @@ struct BwdArgs {
 	const float *gy; int64_t gys;
 	float *gx; int64_t gxs;                    // NULL: dL/dx not wanted
 	uint32_t x_fm, gx_fm;                      // x is read / dL/dx is stored feature-major (xs / gxs = feature stride)
-	const float *packed, *packed_t;            // forward layers; transposed layers (behind the forward part of the packed buffer)
-	uint32_t fwd_floats, total_floats;
+	const float *packed;                       // the forward layers: f32, or their x3 planes
+	uint32_t total_floats;                     // of their padded LDS copy
 	float *dW[NR3D_MLP_MAX_LAYERS];            // accumulated into (atomics): zero them for plain gradients
 	float *db[NR3D_MLP_MAX_LAYERS];            // may be NULL
 	uint32_t dims[NR3D_MLP_MAX_LAYERS + 1];
@@ -231,7 +228,7 @@ struct BwdArgs {
 
 // One layer of the backward sweep.  g = dL/d(pre-activation of this layer's output) on the register map (NO tiles);
 // TG: LDS tile that receives g as [feature][sample]; TB: the layer's INPUT activations as [feature][sample] (NI tiles);
-// wT: packed transposed layer.  Accumulates dW (NO x NI tiles) and the per-lane bias partial sums; when PREV, leaves
+// wT: the padded LDS copy of THIS layer (read transposed).  Accumulates dW (NO x NI tiles) and the per-lane bias partial sums; when PREV, leaves
 // dL/d(input of the layer) in gp, masked with the ReLU derivative of the input activations when MASK.
 // eight consecutive samples of a [feature][sample] tile row as the three bf16 pieces of an MFMA operand (mlp_device.h split3)
 __device__ __forceinline__ void split3_row8(const float *__restrict__ src, bf8 (&p)[3], float &sum) {
@@ -252,7 +249,7 @@ __device__ __forceinline__ void split3_row8(const float *__restrict__ src, bf8 (
 	}
 }
 
-template <int NO, int NI, bool PREV, bool MASK, int X3 = 0>
+template <int NO, int NI, bool PREV, bool MASK, bool X3 = false>
 __device__ __forceinline__ void bwd_layer(const f16v (&g)[NO], float *__restrict__ TG, const float *__restrict__ TB,
                                           const float *__restrict__ wT, f16v (&dW)[NO][NI], float (&db)[NO], f16v (&gp)[NI],
                                           int lane) {
@@ -299,9 +296,8 @@ __device__ __forceinline__ void bwd_layer(const f16v (&g)[NO], float *__restrict
 		}
 	}
 	if (PREV) {
-		if constexpr (X3 == 1) dense_x3<NO, NI, false>(wT, g, gp, NR3D_MLP_ACT_NONE, lane);      // wT: the planes of the transposed layer
-		else if constexpr (X3 == 2) dense_x3_t<NO, NI>(wT, g, gp, lane);                         // wT: the padded copy of the FORWARD layer's planes
-		else dense_t<NO, NI>(wT, g, gp, lane);                                                   //     ... of the forward layer
+		if constexpr (X3) dense_x3_t<NO, NI>(wT, g, gp, lane);          // wT: the padded copy of the FORWARD layer's x3 planes
+		else dense_t<NO, NI>(wT, g, gp, lane);                          //     ... of the forward layer
 		if (MASK) {
 #pragma unroll
 			for (int t = 0; t < NI; ++t)
@@ -364,30 +360,23 @@ __device__ __forceinline__ void zero_tiles(f16v (&r)[NT]) {
 template <int IN_T, int W_T, int OUT_T, int NH> struct BwdCfg { static constexpr int kMaxWaves = (IN_T == 1 && W_T == 1 && OUT_T == 1 && NH <= 2) ? 8 : 4; };
 constexpr int kMaxLdsBwd = 160 * 1024;
 // X3 (round 6): the forward recomputation, the dH = W^T dPre chain and the sample contraction dW = dPre^T H all run on the bf16 MFMA with
-// three-piece splits (dense_x3 / bwd_layer<..., true>); a.packed / a.packed_t then point at the x3 planes of the forward and of the
-// transposed layers.  The ReLU masks come from the SAME forward arithmetic as nr3d_mlp_forward's x3 route.
-template <int IN_T, int W_T, int OUT_T, int NH, int FAST, int X3 = 0>
+// three-piece splits (dense_x3 / dense_x3_t / bwd_layer<..., true>); a.packed then points at the x3 planes of the forward layers.
+// The ReLU masks come from the SAME forward arithmetic as nr3d_mlp_forward's x3 route.
+template <int IN_T, int W_T, int OUT_T, int NH, int FAST, bool X3 = false>
 __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) void k_mlp_bwd(BwdArgs a) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
-	constexpr bool PAD = X3 != 1;
 	// FAST: the next tile's rows are requested before a tile's LAST step, not at its top: their 32 - 64 registers then overlap one
 	// layer's work instead of five (k_mlp_bwd<2,2,2,2>: 183 -> 139 / 220 -> 187 spilled dwords, 64 -> 64 -> 64 -> 64 4.38 -> 3.86 ms), and
 	// one step still covers the latency (every measured shape equal or faster, 32 -> 32 -> 32 -> 16 0.66 -> 0.62 ms)
-	if constexpr (X3 == 1) {
-		// both orientations of the x3 planes, as packed: every weight read is a 16-byte read
-		const f4v *src = reinterpret_cast<const f4v *>(a.packed), *src_t = reinterpret_cast<const f4v *>(a.packed_t);
-		f4v *dst = reinterpret_cast<f4v *>(lds);
-		const uint32_t nf = a.fwd_floats / 4;
-		for (uint32_t i = threadIdx.x; i < a.total_floats / 4; i += blockDim.x) dst[i] = i < nf ? src[i] : src_t[i - nf];
-		__syncthreads();
-	} else {
-		// ONE padded copy of the forward layers (X3 = 0: f32, X3 = 2: their x3 planes) serves the forward recomputation (16-byte
-		// reads) and the dH = W^T dPre chain (dense_t's 4-byte / dense_x3_t's 2-byte transposed reads) -- the transposed copy's LDS goes
-		// to the waves' tiles: on the f32 MFMA 64 -> 64 -> 64 -> 64 runs four waves per CU where two fitted; the x3 planes of
+	{
+		// ONE padded copy of the forward layers (f32, or their x3 planes) serves the forward recomputation (16-byte reads) and the
+		// dH = W^T dPre chain (dense_t's 4-byte reads / dense_x3_t's transposing reads) -- no second, transposed copy: its LDS goes to
+		// the waves' tiles.  On the f32 MFMA 64 -> 64 -> 64 -> 64 runs four waves per CU where two fitted; the x3 planes of
 		// 32 -> 64 -> 64 -> 16 leave room for four waves where both orientations left two
 		constexpr int GPP = X3 ? 6 : 4;
 		constexpr uint32_t s0 = IN_T * W_T * GPP * 256 + W_T * 32, sh = W_T * W_T * GPP * 256 + W_T * 32;      // packed layers
-		constexpr uint32_t d0 = IN_T * W_T * GPP * kGS + W_T * 32, dh = W_T * W_T * GPP * kGS + W_T * 32;      // padded copies
+		constexpr uint32_t GS = X3 ? kGS3 : kGS;
+		constexpr uint32_t d0 = IN_T * W_T * GPP * GS + W_T * 32, dh = W_T * W_T * GPP * GS + W_T * 32;        // padded copies
 		stage_layer_padded<IN_T, W_T, GPP>(a.packed, lds);
 #pragma unroll
 		for (int l = 1; l < NH; ++l) stage_layer_padded<W_T, W_T, GPP>(a.packed + s0 + (l - 1) * sh, lds + d0 + (l - 1) * dh);
@@ -405,13 +394,11 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 	float *TX = tiles;
 	float *TGO = tiles;
 	float *TH1 = tiles + 32 * XG_T * kTS;                               // H_l at TH1 + (l - 1) * 32 * W_T * kTS
-	// packed layers: forward [0 | hidden ... | out], then the transposed ones in the same order
-	constexpr uint32_t f0 = X3 == 1 ? layer_x3_floats(IN_T, W_T) : X3 ? layer_x3_floats_pad(IN_T, W_T) : layer_floats_pad(IN_T, W_T);
-	constexpr uint32_t fh = X3 == 1 ? layer_x3_floats(W_T, W_T) : X3 ? layer_x3_floats_pad(W_T, W_T) : layer_floats_pad(W_T, W_T);
-	constexpr uint32_t fo = layer_x3_floats(W_T, OUT_T), fwd_total = f0 + (NH - 1) * fh + fo;      // (X3 == 1 only)
-	// the layers the dH chain reads: X3 == 1 the planes of the transposed layers behind the forward ones, else the forward layers themselves
-	constexpr uint32_t t0 = X3 == 1 ? layer_x3_floats(W_T, IN_T) : f0, th = fh;
-	const float *wf = lds, *wt = X3 == 1 ? lds + fwd_total : lds;
+	// the padded layers: [0 | hidden ... | out]; the dH chain reads the same copies (wt + t0 + l th = layer l + 1)
+	constexpr uint32_t f0 = X3 ? layer_x3_floats_pad(IN_T, W_T) : layer_floats_pad(IN_T, W_T);
+	constexpr uint32_t fh = X3 ? layer_x3_floats_pad(W_T, W_T) : layer_floats_pad(W_T, W_T);
+	constexpr uint32_t t0 = f0, th = fh;
+	const float *wf = lds, *wt = lds;
 
 	f16v dW0[W_T][IN_T], dWh[NH > 1 ? NH - 1 : 1][W_T][W_T], dWo[OUT_T][W_T];
 	float db0[W_T], dbh[NH > 1 ? NH - 1 : 1][W_T], dbo[OUT_T];
@@ -447,13 +434,13 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 			load_rows<OUT_T>(a.gy, a.gys, a.dims[NH + 1], row, valid, a.gy_vec != 0, lane, g_out);
 		}
 		// ---- forward, activations kept as [feature][sample] tiles ----
-		if constexpr (X3) dense_x3<IN_T, W_T, true, PAD>(wf, xin, hcur, a.hidden_act, lane);
+		if constexpr (X3) dense_x3<IN_T, W_T, true, true>(wf, xin, hcur, a.hidden_act, lane);
 		else dense<IN_T, W_T, true, true>(wf, xin, hcur, a.hidden_act, lane);
 		write_tile<W_T>(TH1, W_T, hcur, lane);
 #pragma unroll
 		for (int l = 1; l < NH; ++l) {
 			f16v hn[W_T];
-			if constexpr (X3) dense_x3<W_T, W_T, true, PAD>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
+			if constexpr (X3) dense_x3<W_T, W_T, true, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
 			else dense<W_T, W_T, true, true>(wf + f0 + (l - 1) * fh, hcur, hn, a.hidden_act, lane);
 #pragma unroll
 			for (int t = 0; t < W_T; ++t) hcur[t] = hn[t];
@@ -462,7 +449,7 @@ __global__ __launch_bounds__((BwdCfg<IN_T, W_T, OUT_T, NH>::kMaxWaves * 64)) voi
 		if (FAST && !valid) zero_tiles<OUT_T>(g_out);                    // rows past n were clamped, not zeroed
 		if (a.out_act == NR3D_MLP_ACT_RELU) {
 			f16v yo[OUT_T];
-			if constexpr (X3) dense_x3<W_T, OUT_T, true, PAD>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
+			if constexpr (X3) dense_x3<W_T, OUT_T, true, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
 			else dense<W_T, OUT_T, true, true>(wf + f0 + (NH - 1) * fh, hcur, yo, NR3D_MLP_ACT_NONE, lane);
 #pragma unroll
 			for (int t = 0; t < OUT_T; ++t)
@@ -542,7 +529,6 @@ extern "C" uint64_t nr3d_mlp_packed_floats(const nr3d_mlp_desc_t *desc) {
 
 static int fill_pack(const nr3d_mlp_desc_t *d, const Shape &s, const float *const *weights, const float *const *biases, PackArgs &p) {
 	p.n_layers = d->n_layers;
-	p.transposed = 0;
 	uint32_t off = 0;
 	for (uint32_t l = 0; l < d->n_layers; ++l) {
 		NR3D_CHECK(weights[l] != nullptr, "mlp_pack: weights[%u] is NULL", l);
@@ -566,11 +552,6 @@ static bool backward_ok(const Shape &s) {
 	return s.w_t == 1 ? nh <= 3 : nh <= 2;
 }
 
-// x3 planes of the transposed layers (round 6: the backward on the bf16 MFMA)
-static uint64_t x3t_floats(const Shape &s) {
-	return (uint64_t)layer_x3_floats(s.w_t, s.in_t) + (uint64_t)(s.n_layers - 2) * layer_x3_floats(s.w_t, s.w_t) + layer_x3_floats(s.out_t, s.w_t);
-}
-
 // the f32 backward's LDS copy of the forward layers (mlp_device.h kGS / kHS)
 static uint64_t padded_floats(const Shape &s) {
 	return (uint64_t)layer_floats_pad(s.in_t, s.w_t) + (uint64_t)(s.n_layers - 2) * layer_floats_pad(s.w_t, s.w_t) + layer_floats_pad(s.w_t, s.out_t);
@@ -583,15 +564,12 @@ static uint64_t padded_x3_floats(const Shape &s) {
 // per-wave [feature][sample] tiles: X, H_1 .. H_NH, G_out
 static uint32_t bwd_tile_floats(const Shape &s) { return (32u * (s.in_t > s.out_t ? s.in_t : s.out_t) + (s.n_layers - 1) * 32u * s.w_t) * (uint32_t)kTS; }
 
-// weights the backward keeps in LDS.  mode 0: one padded copy of the f32 forward layers; 1: the x3 planes of the forward AND of the
-// transposed layers as packed (every weight read a 16-byte read); 2: one padded copy of the forward layers' x3 planes
-static uint64_t bwd_weight_floats(const Shape &s, int mode) {
-	return mode == 1 ? x3_floats(s) + x3t_floats(s) : mode == 2 ? padded_x3_floats(s) : padded_floats(s);
-}
+// weights the backward keeps in LDS: one padded copy of the forward layers, f32 or (x3) their bf16 planes
+static uint64_t bwd_weight_floats(const Shape &s, bool x3) { return x3 ? padded_x3_floats(s) : padded_floats(s); }
 
-static uint32_t bwd_waves(const Shape &s, int mode = 0) {
-	if (mode && x3_floats(s) == 0) return 0;
-	const uint64_t wbytes = bwd_weight_floats(s, mode) * 4;
+static uint32_t bwd_waves(const Shape &s, bool x3 = false) {
+	if (x3 && x3_floats(s) == 0) return 0;
+	const uint64_t wbytes = bwd_weight_floats(s, x3) * 4;
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;     // one layer at a time
 	const uint32_t max_waves = (s.in_t == 1 && s.w_t == 1 && s.out_t == 1 && s.n_layers - 1 <= 2) ? 8u : 4u;      // = BwdCfg<...>::kMaxWaves
 	for (uint32_t nw = max_waves; nw >= 1; --nw) {
@@ -602,28 +580,24 @@ static uint32_t bwd_waves(const Shape &s, int mode = 0) {
 	return 0;
 }
 
-// Which of the three the x3 option selects (without it: mode 0).  The kernel is not bound by its MFMAs -- 24.6 k of 33 k cycles per
-// tile of 32 -> 64 -> 64 -> 16 on the f32 MFMA, 9.2 k of 24 k on the bf16 MFMA, whose piece splitting is VALU work with nothing to overlap
-// it at one wave per SIMD -- so a wave lost to bigger weights costs more than the cheaper products bring, and the rule is "never fewer
-// waves than mode 0".  Measured at 2^22 samples, backward alone (tools/exp_mlp_x3_bwd.py, ms):
-//   mode 1 where it keeps mode 0's waves: 18->32->3 0.43 (mode 0: 0.51), 32->32->16 0.43 (0.43), 32->32->32->16 0.68 (0.69), 32->64->16 0.77 (0.88);
-//   mode 2 there is slower (0.44 / 0.52 / 0.89 / 0.86): its transposed reads are eight 2-byte LDS reads per operand where mode 1 has one;
-//   32->64->64->16: mode 1 has two waves (2.63), mode 2 four like mode 0: 1.63 against 1.77 -> mode 2, the one shape it is built for;
-//   64->64->64->64: mode 1 does not fit, mode 2 three waves 3.96, mode 0 four waves 3.66 -> mode 0 (32->64->64->64: 2.58 / 2.40).
-static int backward_mode(const Shape &s) {
-	const uint32_t w0 = bwd_waves(s, 0);
-	const uint32_t w1 = bwd_waves(s, 1);
-	if ((s.w_t == 1 || s.n_layers == 2) && w1 != 0 && w1 >= w0) return 1;              // (the shapes k_mlp_bwd<..., 1> is built for: BWD_CASE)
-	if (s.in_t == 1 && s.w_t == 2 && s.out_t == 1 && s.n_layers == 3) { const uint32_t w2 = bwd_waves(s, 2); if (w2 != 0 && w2 >= w0) return 2; }
-	return 0;
+// Does the x3 option put the backward on the bf16 MFMA?  The kernel is not bound by its MFMAs -- counters of 32 -> 64 -> 64 -> 16
+// (profiles/r06_mlp_counters.txt): VALU active 45 % of a wave's cycles (the piece splitting), MFMA pipe 31 %, one wave per SIMD
+// overlaps little of it -- so a wave lost to the bigger planes costs more than the cheaper products bring: x3 where its planes
+// (1.5 x the f32 bytes + padding) leave as many waves as the f32 copy.  Same-box A/B at 2^22 samples, fwd+bwd ms, x3 / f32:
+// 32->64->64->16 1.90 / 2.33, 32->64->16 1.00 / 1.18, 32->32->16 0.60 / 0.63, 18->32->3 0.57 / 0.75; 64->64->64->64 x3 has three waves
+// against four: 5.49 / 3.96 -> f32 (so do 64->64->64 and 32->64->64->64).  Until the transposing read (dense_x3_t) the small shapes
+// kept a second, transposed set of planes in LDS (every weight read 16 bytes): equal within 2 % now, and gone.
+static bool backward_x3(const Shape &s) {
+	const uint32_t w0 = bwd_waves(s, false), w3 = bwd_waves(s, true);
+	return w3 != 0 && w3 >= w0;
 }
 
-// behind the forward part: [kBwdHeader floats (non-zero size = "the fused backward applies") | x3 planes of the transposed layers (mode 1)]
+// behind the forward part: kBwdHeader floats (non-zero size = "the fused backward applies"; the backward reads the forward layers)
 constexpr uint32_t kBwdHeader = 4;
 extern "C" uint64_t nr3d_mlp_backward_packed_floats(const nr3d_mlp_desc_t *desc) {
 	Shape s;
 	if (!shape_of(desc, s) || nr3d_mlp_packed_floats(desc) == 0 || !backward_ok(s) || bwd_waves(s) == 0) return 0;
-	return kBwdHeader + (backward_mode(s) == 1 ? x3t_floats(s) : 0);
+	return kBwdHeader;
 }
 
 extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *weights, const float *const *biases, float *packed,
@@ -642,23 +616,6 @@ extern "C" int nr3d_mlp_pack(const nr3d_mlp_desc_t *desc, const float *const *we
 		for (uint32_t l = 0; l < desc->n_layers; ++l) { x.offset[l] = off; off += layer_x3_floats(p.ni[l], p.no[l]); }
 		x.offset[desc->n_layers] = off;
 		hipLaunchKernelGGL(k_mlp_pack_x3, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, x, packed + packed_floats(s));
-	}
-	if (with_backward) {
-		// the layers of dH_{l} = W_l^T dPre_{l+1}: packed input tiles = the forward layer's output tiles and vice versa
-		// (only the bf16 MFMA backward with both orientations, backward_mode() 1, reads them: the other modes read the forward layers)
-		if (backward_mode(s) == 1) {
-			PackArgs x = p;
-			x.transposed = 1;
-			uint32_t o3 = 0;
-			for (uint32_t l = 0; l < desc->n_layers; ++l) {
-				x.ni[l] = p.no[l]; x.no[l] = p.ni[l];
-				x.offset[l] = o3;
-				o3 += layer_x3_floats(x.ni[l], x.no[l]);
-			}
-			x.offset[desc->n_layers] = o3;
-			hipLaunchKernelGGL(k_mlp_pack_x3, dim3(16, desc->n_layers), dim3(256), 0, (hipStream_t)stream, x,
-			                   packed + forward_floats(s) + kBwdHeader);
-		}
 	}
 	NR3D_LAUNCH_CHECK();
 	return 0;
@@ -757,11 +714,9 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	a.gx = dL_dx; a.gxs = gx_fm ? gx_feature_stride : gx_stride;
 	a.x_fm = x_fm ? 1u : 0u; a.gx_fm = gx_fm ? 1u : 0u;
 	// round 6: on the bf16 MFMA with three-piece splits (forward recomputation, dH chain, dW) when the option is on and the planes fit
-	const int mode = x3_enabled() ? backward_mode(s) : 0;
-	a.total_floats = (uint32_t)bwd_weight_floats(s, mode);               // of the LDS copy (modes 0 / 2: the kernel pads the packed layers itself)
-	a.fwd_floats = mode == 1 ? (uint32_t)x3_floats(s) : a.total_floats;
-	if (mode) a.packed = packed + packed_floats(s);                      // the x3 planes of the forward layers
-	a.packed_t = mode == 1 ? packed + forward_floats(s) + kBwdHeader : nullptr;
+	const bool x3 = x3_enabled() && backward_x3(s);
+	a.total_floats = (uint32_t)bwd_weight_floats(s, x3);                 // of the LDS copy (the kernel pads the packed layers itself)
+	if (x3) a.packed = packed + packed_floats(s);                        // the x3 planes of the forward layers
 	for (uint32_t l = 0; l < desc->n_layers; ++l) {
 		NR3D_CHECK(dL_dW[l] != nullptr, "mlp_backward: dL_dW[%u] is NULL", l);
 		a.dW[l] = dL_dW[l];
@@ -774,7 +729,7 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	a.gy_vec = ((uintptr_t)dL_dy % 16 == 0 && gy_stride % 4 == 0) ? 1u : 0u;
 	a.gx_vec = (dL_dx && (uintptr_t)dL_dx % 16 == 0 && gx_stride % 4 == 0) ? 1u : 0u;
 	a.tile_floats = bwd_tile_floats(s);
-	const uint32_t nw = bwd_waves(s, mode);
+	const uint32_t nw = bwd_waves(s, x3);
 	const uint64_t reduce = ((uint64_t)s.w_t * s.w_t * 1024 + (uint64_t)s.w_t * 64) * 4;
 	const uint64_t tbytes = (uint64_t)nw * a.tile_floats * 4;
 	const size_t lds = (size_t)a.total_floats * 4 + (size_t)(tbytes > reduce ? tbytes : reduce);
@@ -790,10 +745,7 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	};
 	int rc = 0;
 #define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) { \
-		if (mode == 1) { if constexpr (W == 1 || H == 1) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, 1>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, 1>) : launch(k_mlp_bwd<I, W, O, H, 0, 1>); \
-		                 else rc = ::nr3d::fail("mlp_backward: no two-orientation x3 kernel for this shape"); } \
-		else if (mode == 2) { if constexpr (I == 1 && W == 2 && O == 1 && H == 2) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, 2>) : launch(k_mlp_bwd<I, W, O, H, 0, 2>); \
-		                      else rc = ::nr3d::fail("mlp_backward: no single-copy x3 kernel for this shape"); } \
+		if (x3) rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, true>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, true>) : launch(k_mlp_bwd<I, W, O, H, 0, true>); \
 		else rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1>) : launch(k_mlp_bwd<I, W, O, H, 0>); } else
 	BWD_CASE(1, 1, 1, 1) BWD_CASE(1, 1, 1, 2) BWD_CASE(1, 1, 1, 3)
 	BWD_CASE(1, 2, 1, 1) BWD_CASE(1, 2, 1, 2) BWD_CASE(1, 2, 2, 1) BWD_CASE(1, 2, 2, 2)

@@ -30,8 +30,11 @@ __host__ __device__ constexpr uint32_t layer_floats(uint32_t ni, uint32_t no) { 
 // dense_t on different banks while every quarter wave of the forward's 16-byte reads stays contiguous
 constexpr int kGS = 264, kHS = 132;
 __host__ __device__ constexpr uint32_t layer_floats_pad(uint32_t ni, uint32_t no) { return no * ni * 4u * kGS + no * 32u; }
-// (the x3 planes have groups of the same size, 64 lanes x 8 bf16: six groups per tile pair)
-__host__ __device__ constexpr uint32_t layer_x3_floats_pad(uint32_t ni, uint32_t no) { return no * ni * 6u * kGS + no * 32u; }
+// (the x3 planes have groups of the same size, 64 lanes x 8 bf16: six groups per tile pair; their padding is tuned for the
+// transposing read of dense_x3_t instead -- 32 and 16 floats per group and half-wave: the four rows of a 16-lane read, the two
+// halves of a row and the two 16-lane groups of a half-wave all fall on different banks)
+constexpr int kGS3 = 288, kHS3 = 144;
+__host__ __device__ constexpr uint32_t layer_x3_floats_pad(uint32_t ni, uint32_t no) { return no * ni * 6u * kGS3 + no * 32u; }
 
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -171,11 +174,12 @@ __device__ __forceinline__ void dense_t(const float *__restrict__ wp, const f16v
 // (GPP = groups per tile pair: 4 for the f32 layout, 6 for the x3 planes)
 template <int NI, int NO, int GPP = 4>
 __device__ __forceinline__ void stage_layer_padded(const float *__restrict__ src, float *__restrict__ dst) {
+	constexpr int GS = GPP == 4 ? kGS : kGS3, HS = GPP == 4 ? kHS : kHS3;
 	const f4v *s4 = reinterpret_cast<const f4v *>(src);
 	f4v *d4 = reinterpret_cast<f4v *>(dst);
 	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * NI * GPP * 64); i += blockDim.x)
-		d4[(i >> 6) * (kGS / 4) + ((i >> 5) & 1u) * (kHS / 4) + (i & 31u)] = s4[i];
-	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * 32); i += blockDim.x) dst[NO * NI * GPP * kGS + i] = src[NO * NI * GPP * 256 + i];
+		d4[(i >> 6) * (GS / 4) + ((i >> 5) & 1u) * (HS / 4) + (i & 31u)] = s4[i];
+	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * 32); i += blockDim.x) dst[NO * NI * GPP * GS + i] = src[NO * NI * GPP * 256 + i];
 }
 
 // the three bf16 pieces of registers 8 s .. 8 s + 7 of a register-map tile (a K = 16 step's B operand)
@@ -197,11 +201,11 @@ __device__ __forceinline__ void split3(const f16v &v, int s, bf8 (&p)[3]) {
 // one dense layer in fp32 on the bf16 MFMA; wp -> LDS copy of the layer's x3 planes (+ bias)
 template <int NI, int NO, bool BIAS, bool PAD = false>
 __device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int act, int lane) {
-	const float *bias = wp + NO * NI * (PAD ? 6 * kGS : 1536);
+	const float *bias = wp + NO * NI * (PAD ? 6 * kGS3 : 1536);
 	const int h = lane >> 5;
-	constexpr int GU = PAD ? kGS / 4 : 64;              // bf8 units per group
+	constexpr int GU = PAD ? kGS3 / 4 : 64;             // bf8 units per group
 	constexpr int PLANE = NO * NI * 2 * GU;             // bf8 units per plane
-	const bf8 *wv = reinterpret_cast<const bf8 *>(wp) + (PAD ? h * (kHS / 4) + (lane & 31) : lane);
+	const bf8 *wv = reinterpret_cast<const bf8 *>(wp) + (PAD ? h * (kHS3 / 4) + (lane & 31) : lane);
 	constexpr bool SPLIT = (NO == 1);                  // one out tile: the small terms go to a second accumulator (no dependent MFMA chain)
 	const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 	f16v alt = zero;
@@ -252,16 +256,21 @@ __device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16
 
 // out = W^T in on the bf16 MFMA from the PADDED x3 planes of the forward layer W (dense_t's counterpart: NI tiles of W's outputs come in,
 // NO tiles of W's inputs go out).  Element e = 0 .. 7 of lane (r, h) of the A operand of K = 16 step (it, s) is
-// W_pl[32 it + o][32 ot + r] with o = 16 s + 8 (e >> 2) + 4 h + (e & 3) (the register map's rows), which the planes keep at group
-// (it * NO + ot) * 2 + (r >> 4), half-wave (r >> 2) & 1, lane o, element 4 ((r >> 3) & 1) + (r & 3): eight 2-byte reads
-// (ds_read_u16_d16 / _d16_hi fill the halves of four registers).  The padding puts the half-wave's reads on 16 different banks, two
-// lanes per 4-byte word.  Same piece products in the same order as dense_x3.
-typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+// W_pl[32 it + o][32 ot + r] with o = 16 s + 8 (e >> 2) + 4 h + (e & 3) (the register map's rows): for a 16-lane group that is a
+// block of 4 consecutive rows o x 16 consecutive inputs r, which the planes hold as four 8-byte pieces per row (lane o of either
+// half-wave, elements 0 .. 3 or 4 .. 7) -- exactly what gfx950's transposing read takes: ds_read_b64_tr_b16 hands lane c column c of
+// the 4 x 16 block whose pieces the group's lanes point at, so an operand is TWO reads (e >> 2 = 0, 1).  (The first version read
+// eight 2-byte values and packed them: four times the LDS instructions plus the packing, slower than the planes in both
+// orientations wherever those fitted.)  Same piece products in the same order as dense_x3.
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 template <int NI, int NO>
 __device__ __forceinline__ void dense_x3_t(const float *__restrict__ wp, const f16v (&in)[NI], f16v (&out)[NO], int lane) {
-	const int r = lane & 31, h = lane >> 5;
-	constexpr int PLANE = NO * NI * 2 * kGS * 2;       // 2-byte units per plane
-	const unsigned short *wl = reinterpret_cast<const unsigned short *>(wp) + (r >> 4) * (kGS * 2) + ((r >> 2) & 1) * (kHS * 2) + 32 * h + 4 * ((r >> 3) & 1) + (r & 3);
+	const int c = lane & 15, sf = (lane >> 4) & 1, h = lane >> 5;
+	constexpr int PLANE = NO * NI * 2 * kGS3 * 2;      // 2-byte units per plane
+	// this lane's piece of the block: row c >> 2, piece q = c & 3 = inputs 4 q .. 4 q + 3 of the group's 16 -> half-wave q & 1, elements 4 (q >> 1) ..
+	const unsigned short *wl = reinterpret_cast<const unsigned short *>(wp) + sf * (kGS3 * 2) + (c & 1) * (kHS3 * 2) + (4 * h + (c >> 2)) * 8 + 4 * ((c >> 1) & 1);
+	typedef s4v __attribute__((address_space(3))) *lds_s4;
 	constexpr bool SPLIT = (NO == 1);
 	const f16v zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 	f16v alt = zero;
@@ -279,9 +288,11 @@ __device__ __forceinline__ void dense_x3_t(const float *__restrict__ wp, const f
 			for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
 				for (int ot = 0; ot < NO; ++ot) {
-					const unsigned short *p = wl + pl * PLANE + (it * NO + ot) * 2 * (kGS * 2) + 128 * s;
-					const us8 v = {p[0], p[8], p[16], p[24], p[64], p[72], p[80], p[88]};
-					w[pl][ot] = __builtin_bit_cast(bf8, v);
+					const unsigned short *p = wl + pl * PLANE + (it * NO + ot) * 2 * (kGS3 * 2) + 128 * s;
+					const bf4 lo = __builtin_bit_cast(bf4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)p));
+					const bf4 hi = __builtin_bit_cast(bf4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p + 64)));
+					const bf8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+					w[pl][ot] = v;
 				}
 #pragma unroll
 			for (int t = 0; t < 6; ++t) {

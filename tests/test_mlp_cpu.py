@@ -33,9 +33,9 @@ def test_mlp_matches_a_hand_written_stack():
 
 
 def test_packed_sizes_of_the_fused_decoder():
-    """host logic of csrc/mlp.hip, no kernel runs: the packed buffer is [f32 layers | their bf16 x3 planes when they fit LDS], the
-    backward adds a 4-float header (non-zero = "the fused backward applies") and, only for the small shapes whose backward keeps the
-    planes in BOTH orientations in LDS (backward_mode() 1), the planes of the transposed layers; 0 outside the fused backward's range"""
+    """host logic of csrc/mlp.hip, no kernel runs: the packed buffer is [f32 layers | their bf16 x3 planes when they fit LDS]; the
+    backward reads those same layers (transposed, from one padded LDS copy) and adds only a 4-float header (non-zero = "the fused
+    backward applies"); 0 outside the fused backward's range"""
     from nr3d_lib_amd.bindings import _mlp
 
     def layer(ni, no):                    # tiles of 32
@@ -43,16 +43,14 @@ def test_packed_sizes_of_the_fused_decoder():
 
     def tiles(d):
         return (d + 31) // 32
-    for dims, both in (((32, 64, 64, 16), False), ((32, 32, 16), True), ((18, 32, 3), True), ((32, 32, 32, 16), True), ((32, 64, 16), True),
-                       ((64, 64, 64, 64), False), ((64, 64, 64), False), ((32, 64, 64, 64), False), ((32, 64, 64), True), ((64, 64, 16), True)):
+    for dims in ((32, 64, 64, 16), (32, 32, 16), (18, 32, 3), (32, 32, 32, 16), (32, 64, 16), (64, 64, 64, 64), (64, 64, 64), (32, 64, 64, 64),
+                 (32, 64, 64), (64, 64, 16)):
         d = _mlp.MLPDesc(list(dims), 1, 0)
         t = [tiles(v) for v in dims]
         f32 = sum(layer(a, b)[0] for a, b in zip(t[:-1], t[1:]))
         x3 = sum(layer(a, b)[1] for a, b in zip(t[:-1], t[1:]))
         assert d.packed_floats == f32 + x3, dims
-        x3t = sum(layer(b, a)[1] for a, b in zip(t[:-1], t[1:]))
-        assert d.backward_floats == 4 + (x3t if both else 0), (dims, d.backward_floats)
-        assert d.backward_fusable
+        assert d.backward_floats == 4 and d.backward_fusable, (dims, d.backward_floats)
     # hidden width above 64, three hidden layers wider than 32, output wider than the hidden layers: forward only
     for dims in ((32, 128, 128, 16), (32, 64, 64, 64, 16), (32, 32, 64)):
         d = _mlp.MLPDesc(list(dims), 1, 0)
