@@ -236,15 +236,7 @@ __device__ __forceinline__ void split3_row8(const float *__restrict__ src, bf8 (
 	const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
 	for (int e = 0; e < 8; e += 2) {
-		const f2v a = {v[e], v[e + 1]};
-		const bf2 p1 = __builtin_convertvector(a, bf2);
-		const f2v r1 = a - __builtin_convertvector(p1, f2v);
-		const bf2 p2 = __builtin_convertvector(r1, bf2);
-		const f2v r2 = r1 - __builtin_convertvector(p2, f2v);
-		const bf2 p3 = __builtin_convertvector(r2, bf2);
-		p[0][e] = p1[0]; p[0][e + 1] = p1[1];
-		p[1][e] = p2[0]; p[1][e + 1] = p2[1];
-		p[2][e] = p3[0]; p[2][e + 1] = p3[1];
+		split3_pair<false>(v[e], v[e + 1], e, p);
 		sum += v[e] + v[e + 1];
 	}
 }

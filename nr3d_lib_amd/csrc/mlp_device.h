@@ -182,20 +182,46 @@ __device__ __forceinline__ void stage_layer_padded(const float *__restrict__ src
 	for (uint32_t i = threadIdx.x; i < (uint32_t)(NO * 32); i += blockDim.x) dst[NO * NI * GPP * GS + i] = src[NO * NI * GPP * 256 + i];
 }
 
+// two values -> their three bf16 pieces at elements e, e + 1 of the operands.  The conversions are packed (v_cvt_pk_bf16_f32).  The
+// residuals: SCALAR subtractions in the forward kernels (two waves per SIMD: beside MFMAs a v_pk_add_f32 costs about 13 cycles beyond
+// its issue slot, MI355X_MICROARCH.md "price of one filler beside MFMAs", two v_sub_f32 do not -- the empty asm statements keep the
+// SLP vectoriser from packing them again), PACKED in the backward kernels (one wave per SIMD, VALU-bound: the instruction count decides).
+// Same-box A/B at 2^22 samples, scalar against packed: forward 64 -> 64 -> 64 -> 64 0.710 -> 0.656 ms, 32 -> 64 -> 16 0.228 -> 0.220;
+// backward 32 -> 64 -> 64 -> 16 1.45 -> 1.52, 32 -> 32 -> 32 -> 16 0.64 -> 0.68.
+template <bool SCALAR>
+__device__ __forceinline__ void split3_pair(float a0, float a1, int e, bf8 (&p)[3]) {
+	const f2v a = {a0, a1};
+	const bf2 p1 = __builtin_convertvector(a, bf2);
+	f2v r1;
+	if constexpr (SCALAR) {
+		float r0 = a0 - (float)p1[0], rb = a1 - (float)p1[1];
+		asm volatile("" : "+v"(r0));
+		asm volatile("" : "+v"(rb));
+		r1[0] = r0; r1[1] = rb;
+	} else {
+		r1 = a - __builtin_convertvector(p1, f2v);
+	}
+	const bf2 p2 = __builtin_convertvector(r1, bf2);
+	f2v r2;
+	if constexpr (SCALAR) {
+		float q0 = r1[0] - (float)p2[0], q1 = r1[1] - (float)p2[1];
+		asm volatile("" : "+v"(q0));
+		asm volatile("" : "+v"(q1));
+		r2[0] = q0; r2[1] = q1;
+	} else {
+		r2 = r1 - __builtin_convertvector(p2, f2v);
+	}
+	const bf2 p3 = __builtin_convertvector(r2, bf2);
+	p[0][e] = p1[0]; p[0][e + 1] = p1[1];
+	p[1][e] = p2[0]; p[1][e + 1] = p2[1];
+	p[2][e] = p3[0]; p[2][e + 1] = p3[1];
+}
+
 // the three bf16 pieces of registers 8 s .. 8 s + 7 of a register-map tile (a K = 16 step's B operand)
+template <bool SCALAR = false>
 __device__ __forceinline__ void split3(const f16v &v, int s, bf8 (&p)[3]) {
 #pragma unroll
-	for (int e = 0; e < 8; e += 2) {
-		const f2v a = {v[8 * s + e], v[8 * s + e + 1]};
-		const bf2 p1 = __builtin_convertvector(a, bf2);
-		const f2v r1 = a - __builtin_convertvector(p1, f2v);
-		const bf2 p2 = __builtin_convertvector(r1, bf2);
-		const f2v r2 = r1 - __builtin_convertvector(p2, f2v);
-		const bf2 p3 = __builtin_convertvector(r2, bf2);
-		p[0][e] = p1[0]; p[0][e + 1] = p1[1];
-		p[1][e] = p2[0]; p[1][e + 1] = p2[1];
-		p[2][e] = p3[0]; p[2][e + 1] = p3[1];
-	}
+	for (int e = 0; e < 8; e += 2) split3_pair<SCALAR>(v[8 * s + e], v[8 * s + e + 1], e, p);
 }
 
 // one dense layer in fp32 on the bf16 MFMA; wp -> LDS copy of the layer's x3 planes (+ bias)
@@ -225,7 +251,7 @@ __device__ __forceinline__ void dense_x3(const float *__restrict__ wp, const f16
 #pragma unroll
 		for (int s = 0; s < 2; ++s) {
 			bf8 xs[3];
-			split3(in[it], s, xs);
+			split3<!PAD>(in[it], s, xs);            // (PAD = the backward kernels)
 			bf8 w[3][NO];
 #pragma unroll
 			for (int pl = 0; pl < 3; ++pl)
