@@ -506,10 +506,10 @@ def test_fp32_forward_on_the_bf16_mfma_is_fp32_grade(dev, hip_option, dims):
                                   [64, 64, 64], [32, 64, 64, 64], [64, 64, 64, 16], [40, 64, 7]])
 def test_fp32_backward_on_the_bf16_mfma_is_fp32_grade(dev, hip_option, dims):
     """round 6: the fp32 backward's routes -- the f32 MFMA (mlp_x3 = 0: one padded LDS copy of the forward layers, the dH = W^T dPre
-    chain reads it transposed) and the bf16 MFMA on three-piece splits (1, default: forward recomputation, dH chain and the sample
-    contraction dW = dPre^T H; csrc/mlp.hip backward_mode() picks the planes in both orientations for the small shapes, one padded
-    copy with 2-byte transposed reads for 32 -> 64 -> 64 -> 16, the f32 route for the 64-wide inputs / outputs) -- against the same
-    network differentiated in float64: the split route must be as close to it as the f32 route is, for dL/dx, every dL/dW and dL/db"""
+    chain reads it transposed) and the bf16 MFMA on three-piece splits (1, default: forward recomputation, dH chain through the
+    transposing LDS read of the forward layers' planes, sample contraction dW = dPre^T H; csrc/mlp.hip backward_x3() takes it where
+    the planes leave as many waves as the f32 copy, i.e. not for 64-wide inputs AND outputs) -- against the same network
+    differentiated in float64: the split route must be as close to it as the f32 route is, for dL/dx, every dL/dW and dL/db"""
     from nr3d_lib_amd.bindings import _mlp
     m = _net(dims, "relu", None, True, dev, seed=17)
     desc = m.fused_desc()

@@ -1,5 +1,5 @@
 """tools/exp_mlp_x3_bwd.py -- fp32 decoder forward / forward+backward with the bf16 x3 route on and off (run on the GPU box).
-mlp_x3 = 1: csrc/mlp.hip backward_mode() picks the backward's weight copy (1 / 2: bf16 MFMA, 0: f32 MFMA); 0: f32 MFMA throughout."""
+mlp_x3 = 1: csrc/mlp.hip backward_x3() decides whether the backward runs on the bf16 MFMA; 0: f32 MFMA throughout."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
