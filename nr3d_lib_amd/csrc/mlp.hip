@@ -581,7 +581,10 @@ static uint32_t bwd_waves(const Shape &s, bool x3 = false) {
 // kept a second, transposed set of planes in LDS (every weight read 16 bytes): equal within 2 % now, and gone.
 static bool backward_x3(const Shape &s) {
 	const uint32_t w0 = bwd_waves(s, false), w3 = bwd_waves(s, true);
-	if (s.w_t == 2 && s.n_layers == 3 && s.in_t + s.out_t >= 3) return false;     // (w3 < w0 there; no x3 kernel is built: BWD_CASE)
+	// no x3 kernel is built (BWD_CASE) for the 64-wide shapes it loses on: two hidden layers with a 64-wide input or output (w3 < w0),
+	// and 64 -> 64 -> 64 (same waves, but backward 1.72 against 1.52 ms: twelve of its sixteen tile pairs pay the splits for products
+	// the f32 MFMA has time for at four waves)
+	if (s.w_t == 2 && ((s.n_layers == 3 && s.in_t + s.out_t >= 3) || s.in_t + s.out_t >= 4)) return false;
 	return w3 != 0 && w3 >= w0;
 }
 
@@ -738,7 +741,7 @@ extern "C" int nr3d_mlp_backward(const nr3d_mlp_desc_t *desc, uint64_t n, const 
 	};
 	int rc = 0;
 #define BWD_CASE(I, W, O, H) if (s.in_t == I && s.w_t == W && s.out_t == O && nh == H) { \
-		if (x3) { if constexpr (!(W == 2 && H == 2 && I + O >= 3)) /* (backward_x3(): their planes cost a wave) */ \
+		if (x3) { if constexpr (!(W == 2 && ((H == 2 && I + O >= 3) || I + O >= 4))) /* (= backward_x3()) */ \
 		              rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2, true>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1, true>) : launch(k_mlp_bwd<I, W, O, H, 0, true>); \
 		          else rc = ::nr3d::fail("mlp_backward: no bf16 MFMA backward for this shape"); } \
 		else rc = fast == 2 ? launch(k_mlp_bwd<I, W, O, H, 2>) : fast == 1 ? launch(k_mlp_bwd<I, W, O, H, 1>) : launch(k_mlp_bwd<I, W, O, H, 0>); } else

@@ -20,7 +20,7 @@ def timed(fn, iters=20):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-for dims in ((32, 64, 64, 16), (32, 32, 16), (18, 32, 3), (32, 32, 32, 16), (32, 64, 16), (64, 64, 64, 64), (64, 64, 64), (32, 64, 64, 64)):
+for dims in ((32, 64, 64, 16), (32, 32, 16), (18, 32, 3), (32, 32, 32, 16), (32, 64, 16), (64, 64, 64, 64), (64, 64, 64), (32, 64, 64, 64), (32, 64, 64), (64, 64, 16), (64, 64, 64, 16)):
     x = torch.randn(n, dims[0], device=dev)
     gy = torch.randn(n, dims[-1], device=dev)
     row, grads = {}, {}
