@@ -581,9 +581,9 @@ static uint32_t bwd_waves(const Shape &s, bool x3 = false) {
 // kept a second, transposed set of planes in LDS (every weight read 16 bytes): equal within 2 % now, and gone.
 static bool backward_x3(const Shape &s) {
 	const uint32_t w0 = bwd_waves(s, false), w3 = bwd_waves(s, true);
-	// no x3 kernel is built (BWD_CASE) for the 64-wide shapes it loses on: two hidden layers with a 64-wide input or output (w3 < w0),
-	// and 64 -> 64 -> 64 (same waves, but backward 1.72 against 1.52 ms: twelve of its sixteen tile pairs pay the splits for products
-	// the f32 MFMA has time for at four waves)
+	// no x3 kernel is built (BWD_CASE) for the 64-wide shapes it does not win on: two hidden layers with a 64-wide input or output
+	// (w3 < w0), and 64 -> 64 -> 64 (same waves, backward equal within 3 %: the splits of its 64-wide tiles eat what the cheaper
+	// products bring, and the f32 kernel spills less)
 	if (s.w_t == 2 && ((s.n_layers == 3 && s.in_t + s.out_t >= 3) || s.in_t + s.out_t >= 4)) return false;
 	return w3 != 0 && w3 >= w0;
 }
